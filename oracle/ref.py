@@ -1,0 +1,127 @@
+"""TEST INFRASTRUCTURE: ctypes driver for oracle/_ref/libnrsc5_ref*.so -- the UNMODIFIED
+reference compiled by oracle/Makefile, instrumented by ref_shim/ref_harness.c.
+Only tests/, golden-vector generation and bench.py's cpu_baseline leg may import this."""
+from __future__ import annotations
+
+import ctypes
+import os
+import struct
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+TAP_Q15, TAP_FFT, TAP_SOFT, TAP_VIT, TAP_HDC = 1, 2, 4, 8, 16
+REC_BLOCK, REC_STATE, REC_SOFT, REC_PIDS, REC_FRAME, REC_SYNC, REC_LOST_SYNC, REC_MER, REC_BER, REC_HDC, REC_VIT = range(1, 12)
+MODE_FM, MODE_AM = 0, 1
+
+BLOCK_FIELDS = ("state_before", "state_after", "samperr", "cfo", "keep", "bc", "psmi", "cfo_wait",
+                "next_samperr", "prev_angle", "phase_re", "phase_im", "next_angle")
+
+
+def lib_path(sse: bool = False) -> str:
+    return os.path.join(_HERE, "_ref", "libnrsc5_ref_sse.so" if sse else "libnrsc5_ref.so")
+
+
+def available(sse: bool = False) -> bool:
+    return os.path.exists(lib_path(sse))
+
+
+class RefLib:
+    def __init__(self, sse: bool = False):
+        self.lib = ctypes.CDLL(lib_path(sse))
+        L = self.lib
+        L.refh_open.argtypes = [ctypes.c_int, ctypes.c_uint, ctypes.c_uint]
+        L.refh_run_cu8.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint]
+        L.refh_run_cs16.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint]
+        L.refh_buf.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        L.refh_buf.restype = ctypes.c_size_t
+        L.refh_sizeof_session.restype = ctypes.c_size_t
+        for name in ("nrsc5_conv_decode_p1", "nrsc5_conv_decode_pids"):
+            getattr(L, name).argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        L.nrsc5_conv_decode_p3_p4.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.nrsc5_conv_decode_e1.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        L.nrsc5_conv_decode_e2_e3.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+
+    def _buf(self, which: int) -> bytes:
+        p = ctypes.c_void_p()
+        n = self.lib.refh_buf(which, ctypes.byref(p))
+        return ctypes.string_at(p, n) if n else b""
+
+    def run(self, iq: np.ndarray, mode: int = MODE_FM, taps: int = 0, chunk: int = 32768,
+            fft_blocks: int = 4):
+        """Feed a whole capture the way src/main.c:1097-1120 does; returns parsed taps."""
+        iq = np.ascontiguousarray(iq)
+        if self.lib.refh_open(mode, taps, fft_blocks) != 0:
+            raise RuntimeError("refh_open failed")
+        try:
+            if iq.dtype == np.uint8:
+                self.lib.refh_run_cu8(iq.ctypes.data, iq.size, chunk)
+            elif iq.dtype == np.int16:
+                self.lib.refh_run_cs16(iq.ctypes.data, iq.size, chunk)
+            else:
+                raise TypeError(iq.dtype)
+            log, q15, fft = self._buf(0), self._buf(1), self._buf(2)
+        finally:
+            self.lib.refh_close()
+        return parse_log(log), np.frombuffer(q15, dtype=np.int16).reshape(-1, 2), np.frombuffer(fft, dtype=np.complex64)
+
+    def conv_decode(self, soft: np.ndarray, kind: str = "p1") -> np.ndarray:
+        soft = np.ascontiguousarray(soft, dtype=np.int8)
+        n = soft.size // 3
+        out = np.zeros(n, dtype=np.uint8)
+        if kind == "p1":
+            assert n == 146176
+            self.lib.nrsc5_conv_decode_p1(soft.ctypes.data, out.ctypes.data)
+        elif kind == "pids":
+            assert n == 80
+            self.lib.nrsc5_conv_decode_pids(soft.ctypes.data, out.ctypes.data)
+        elif kind == "p3":
+            self.lib.nrsc5_conv_decode_p3_p4(soft.ctypes.data, out.ctypes.data, n)
+        elif kind == "e1":
+            self.lib.nrsc5_conv_decode_e1(soft.ctypes.data, out.ctypes.data, n)
+        elif kind == "e2":
+            self.lib.nrsc5_conv_decode_e2_e3(soft.ctypes.data, out.ctypes.data, n)
+        else:
+            raise ValueError(kind)
+        return out
+
+
+def parse_log(log: bytes):
+    """Ordered list of (kind, payload-dict) records."""
+    out, off = [], 0
+    while off < len(log):
+        kind, n = struct.unpack_from("<II", log, off)
+        off += 8
+        pl = log[off:off + n]
+        off += (n + 3) & ~3
+        if kind == REC_BLOCK:
+            v = struct.unpack("<9i4f", pl)
+            out.append(("block", dict(zip(BLOCK_FIELDS, v))))
+        elif kind == REC_STATE:
+            a, b = struct.unpack("<2i", pl)
+            out.append(("state", {"old": a, "new": b}))
+        elif kind == REC_SOFT:
+            out.append(("soft", {"bc": struct.unpack_from("<I", pl)[0], "bits": np.frombuffer(pl, dtype=np.int8, offset=4)}))
+        elif kind == REC_PIDS:
+            out.append(("pids", {"bits": np.frombuffer(pl, dtype=np.uint8)}))
+        elif kind == REC_FRAME:
+            lc, ln = struct.unpack_from("<II", pl)
+            out.append(("frame", {"lc": lc, "bits": np.frombuffer(pl, dtype=np.uint8, offset=8, count=ln)}))
+        elif kind == REC_SYNC:
+            v = struct.unpack("<f5i", pl)
+            out.append(("sync", dict(zip(("freq_offset", "psmi", "pli", "hppi", "aabi", "rdbi"), v))))
+        elif kind == REC_LOST_SYNC:
+            out.append(("lost_sync", {}))
+        elif kind == REC_MER:
+            lo, up = struct.unpack("<2f", pl)
+            out.append(("mer", {"lower": lo, "upper": up}))
+        elif kind == REC_BER:
+            out.append(("ber", {"cber": struct.unpack("<f", pl)[0]}))
+        elif kind == REC_HDC:
+            prog, cnt, flags = struct.unpack_from("<3I", pl)
+            out.append(("hdc", {"program": prog, "count": cnt, "flags": flags, "data": pl[12:]}))
+        elif kind == REC_VIT:
+            ln = struct.unpack_from("<I", pl)[0]
+            out.append(("vit", {"in": np.frombuffer(pl, dtype=np.int8, offset=4, count=3 * ln),
+                                "out": np.frombuffer(pl, dtype=np.uint8, offset=4 + 3 * ln, count=ln)}))
+    return out

@@ -1,0 +1,28 @@
+/* Minimal librtlsdr prototype stub: librtlsdr is absent in this image and the
+ * IQ-pipe path never touches a device. Only what nrsc5.c / rtltcp.c reference
+ * (nrsc5.c:11-19,64,125,147,173,336-343,423,479-570; rtltcp.c:120-133). */
+#pragma once
+#include <stdint.h>
+typedef struct rtlsdr_dev rtlsdr_dev_t;
+typedef void (*rtlsdr_read_async_cb_t)(unsigned char *buf, uint32_t len, void *ctx);
+enum rtlsdr_tuner {
+    RTLSDR_TUNER_UNKNOWN = 0, RTLSDR_TUNER_E4000, RTLSDR_TUNER_FC0012,
+    RTLSDR_TUNER_FC0013, RTLSDR_TUNER_FC2580, RTLSDR_TUNER_R820T, RTLSDR_TUNER_R828D
+};
+int rtlsdr_open(rtlsdr_dev_t **dev, uint32_t index);
+int rtlsdr_close(rtlsdr_dev_t *dev);
+int rtlsdr_get_tuner_gains(rtlsdr_dev_t *dev, int *gains);
+int rtlsdr_set_tuner_gain(rtlsdr_dev_t *dev, int gain);
+int rtlsdr_get_tuner_gain(rtlsdr_dev_t *dev);
+int rtlsdr_set_tuner_gain_mode(rtlsdr_dev_t *dev, int manual);
+int rtlsdr_read_sync(rtlsdr_dev_t *dev, void *buf, int len, int *n_read);
+int rtlsdr_read_async(rtlsdr_dev_t *dev, rtlsdr_read_async_cb_t cb, void *ctx, uint32_t buf_num, uint32_t buf_len);
+int rtlsdr_cancel_async(rtlsdr_dev_t *dev);
+int rtlsdr_reset_buffer(rtlsdr_dev_t *dev);
+int rtlsdr_set_sample_rate(rtlsdr_dev_t *dev, uint32_t rate);
+int rtlsdr_set_offset_tuning(rtlsdr_dev_t *dev, int on);
+int rtlsdr_set_bias_tee(rtlsdr_dev_t *dev, int on);
+int rtlsdr_set_direct_sampling(rtlsdr_dev_t *dev, int on);
+int rtlsdr_set_freq_correction(rtlsdr_dev_t *dev, int ppm);
+uint32_t rtlsdr_get_center_freq(rtlsdr_dev_t *dev);
+int rtlsdr_set_center_freq(rtlsdr_dev_t *dev, uint32_t freq);
