@@ -1,0 +1,96 @@
+/* TEST INFRASTRUCTURE -- CPU restatement of the reference's IQ -> P1/PIDS hot path.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this
+ * library, and only as the checker.  The product path (nrsc5_amd/csrc, libnrsc5hip.so)
+ * never links, loads or calls anything in oracle/.
+ *
+ * Pinning: the reference ships no unit tests or stage vectors; this
+ * restatement is pinned against the UNMODIFIED reference compiled into oracle/_ref/
+ * (tests/test_oracle_vs_reference.py: exact Q15 stream, soft bits, PIDS/P1 frames,
+ * per-block timing/CFO trace) and against the fixtures under tests/golden/ that the
+ * same reference build produced.  The FFT (third-party fftw3f in the reference,
+ * absent here) is oracle/cpu_fft.c in both builds: parity unpinned at that boundary,
+ * tolerance-checked.
+ *
+ * Each function cites the reference lines it restates.  FM (all hybrid/all-digital
+ * primary-main processing, service mode MP1 end to end) is covered; AM is not yet.
+ */
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { int16_t r, i; } orc_c16;
+
+enum { ORC_SYNC_NONE = 0, ORC_SYNC_COARSE = 1, ORC_SYNC_FINE = 2 };
+
+/* ordered log record kinds: identical numbering/payloads to oracle/ref_shim/ref_harness.c */
+enum {
+    ORC_REC_BLOCK = 1, ORC_REC_STATE, ORC_REC_SOFT, ORC_REC_PIDS, ORC_REC_FRAME, ORC_REC_SYNC,
+    ORC_REC_LOST_SYNC, ORC_REC_MER, ORC_REC_BER
+};
+enum { ORC_TAP_Q15 = 1, ORC_TAP_FFT = 2, ORC_TAP_SOFT = 4 };
+
+/* ---- stage functions: each is the CPU twin of one HIP kernel ------------------------- */
+
+/* K1  input.c:52-69 + firdecim_q15.c:137-165.  cu8 -> Q15 -> 15-tap half-band, 2:1.
+ * hist = last 14 Q15 samples pushed (zeros for a fresh session); nbytes % 4 == 0.
+ * Returns the number of output samples (nbytes / 4). */
+size_t orc_halfband_fm_cu8(orc_c16 hist[14], const uint8_t *iq, size_t nbytes, orc_c16 *out);
+
+/* K2a firdecim_q15.c:95-109,154-158 with acquire.c:28-61 taps.  1-in/1-out 32-tap band-select
+ * FIR; hist = last 31 samples pushed. */
+void orc_fir32_fm(orc_c16 hist[31], const orc_c16 *in, size_t n, orc_c16 *out);
+
+/* K2b acquire.c:122-157.  Cyclic-prefix correlation over a 33-symbol Q15 window already
+ * FIR-filtered; returns samperr and the correlation value at the peak. */
+void orc_cp_correlate_fm(const orc_c16 *filtered /*71280*/, int *samperr, float peak[2]);
+
+/* K6  decode.c:296-342: gather + depuncture of one L1 frame / one block. */
+void orc_deinterleave_p1(const int8_t *pm /*16*23040*/, int8_t *out /*438528*/);
+void orc_deinterleave_pids(const int8_t *pm /*16*23040*/, unsigned bc, int8_t *out /*240*/);
+
+/* K7  conv_dec.c:402-453 + conv_gen.h:32-101: tail-biting soft Viterbi, rate 1/3.
+ * k = 7 (gens 0133,0171,0165) or k = 9 with the three generators given. */
+int orc_viterbi(const int8_t *in /*3*len*/, int len, int k, const unsigned gens[3], uint8_t *out /*len*/);
+int orc_viterbi_k7(const int8_t *in, int len, uint8_t *out);
+
+/* K8  decode.c:279-294 / 234-265 */
+void orc_descramble(uint8_t *bits, unsigned len);
+int orc_bit_errors_k7(const int8_t *coded, const uint8_t *decoded, int len);
+
+/* forward FFT used by the mixer stage (oracle/cpu_fft.c) is declared in cpu_fft.h */
+
+/* ---- whole-path stream object: mirrors input_push_cu8/cs16 (input.c:96-124) ----------- */
+typedef struct orc_stream orc_stream;
+
+/* L2 feedback hook (frame.c:535-540): called with each decoded P1 frame (146176 bits, one per
+ * byte, already descrambled); return nonzero to drop the stream to SYNC_NONE exactly where
+ * the reference's frame_process would. */
+typedef int (*orc_p1_hook)(void *user, const uint8_t *bits, unsigned len);
+
+orc_stream *orc_open(void);
+void orc_close(orc_stream *s);
+void orc_reset(orc_stream *s);                       /* input_reset, fresh-session semantics */
+void orc_set_taps(orc_stream *s, unsigned mask, unsigned fft_limit_blocks);
+void orc_set_p1_hook(orc_stream *s, orc_p1_hook hook, void *user);
+void orc_push_cu8(orc_stream *s, const uint8_t *iq, uint32_t nbytes);   /* nbytes % 4 == 0 */
+void orc_push_cs16(orc_stream *s, const int16_t *iq, uint32_t n);       /* n % 2 == 0 */
+void orc_force_resync(orc_stream *s);                /* input_set_sync_state(NONE) from L2 */
+size_t orc_buf(orc_stream *s, int which, const uint8_t **p);   /* 0 log, 1 q15, 2 fft */
+void orc_clear_bufs(orc_stream *s);
+
+/* per-block internal state, for stage-level parity of the HIP sync kernel */
+typedef struct {
+    int32_t sync_state, bc, psmi, cfo_wait, samperr_next, mer_cnt, acq_cfo, keep_extra;
+    float angle_next, prev_angle, phase_re, phase_im, error_lb, error_ub;
+    float costas_freq[30], costas_phase[30];   /* refs: lower i=0..14 at [2i], upper at [2i+1] */
+} orc_sync_snapshot;
+void orc_snapshot(const orc_stream *s, orc_sync_snapshot *out);
+
+#ifdef __cplusplus
+}
+#endif

@@ -1,0 +1,152 @@
+"""TEST INFRASTRUCTURE: ctypes driver for oracle/liboracle.so (the C restatement,
+oracle/nrsc5_oracle.c).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg may import this; the product path never does."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import numpy as np
+
+from . import ref as _ref
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+
+TAP_Q15, TAP_FFT, TAP_SOFT = 1, 2, 4
+
+
+def build(force: bool = False) -> str:
+    srcs = [os.path.join(_HERE, f) for f in ("nrsc5_oracle.c", "nrsc5_oracle.h", "cpu_fft.c", "cpu_fft.h")]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+class _Snapshot(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ("sync_state", "bc", "psmi", "cfo_wait", "samperr_next", "mer_cnt", "acq_cfo", "keep_extra")] + \
+               [(n, ctypes.c_float) for n in ("angle_next", "prev_angle", "phase_re", "phase_im", "error_lb", "error_ub")] + \
+               [("costas_freq", ctypes.c_float * 30), ("costas_phase", ctypes.c_float * 30)]
+
+
+P1_HOOK = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_uint)
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = L = ctypes.CDLL(build())
+        vp, sz = ctypes.c_void_p, ctypes.c_size_t
+        L.orc_open.restype = vp
+        L.orc_close.argtypes = [vp]
+        L.orc_reset.argtypes = [vp]
+        L.orc_set_taps.argtypes = [vp, ctypes.c_uint, ctypes.c_uint]
+        L.orc_set_p1_hook.argtypes = [vp, P1_HOOK, vp]
+        L.orc_push_cu8.argtypes = [vp, vp, ctypes.c_uint32]
+        L.orc_push_cs16.argtypes = [vp, vp, ctypes.c_uint32]
+        L.orc_force_resync.argtypes = [vp]
+        L.orc_buf.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp)]
+        L.orc_buf.restype = sz
+        L.orc_clear_bufs.argtypes = [vp]
+        L.orc_snapshot.argtypes = [vp, ctypes.POINTER(_Snapshot)]
+        L.orc_halfband_fm_cu8.argtypes = [vp, vp, sz, vp]
+        L.orc_halfband_fm_cu8.restype = sz
+        L.orc_fir32_fm.argtypes = [vp, vp, sz, vp]
+        L.orc_cp_correlate_fm.argtypes = [vp, ctypes.POINTER(ctypes.c_int), vp]
+        L.orc_deinterleave_p1.argtypes = [vp, vp]
+        L.orc_deinterleave_pids.argtypes = [vp, ctypes.c_uint, vp]
+        L.orc_viterbi_k7.argtypes = [vp, ctypes.c_int, vp]
+        L.orc_viterbi.argtypes = [vp, ctypes.c_int, ctypes.c_int, vp, vp]
+        L.orc_descramble.argtypes = [vp, ctypes.c_uint]
+        L.orc_bit_errors_k7.argtypes = [vp, vp, ctypes.c_int]
+        L.oracle_fft_forward.argtypes = [ctypes.c_int, vp, vp]
+
+    # ---- stage functions -------------------------------------------------------------
+    def halfband_fm_cu8(self, iq: np.ndarray, hist: np.ndarray | None = None):
+        iq = np.ascontiguousarray(iq, dtype=np.uint8)
+        h = np.zeros((14, 2), dtype=np.int16) if hist is None else np.ascontiguousarray(hist, dtype=np.int16).copy()
+        out = np.zeros((iq.size // 4, 2), dtype=np.int16)
+        self.lib.orc_halfband_fm_cu8(h.ctypes.data, iq.ctypes.data, iq.size, out.ctypes.data)
+        return out, h
+
+    def fir32_fm(self, x: np.ndarray, hist: np.ndarray | None = None):
+        x = np.ascontiguousarray(x, dtype=np.int16)
+        h = np.zeros((31, 2), dtype=np.int16) if hist is None else np.ascontiguousarray(hist, dtype=np.int16).copy()
+        out = np.zeros_like(x)
+        self.lib.orc_fir32_fm(h.ctypes.data, x.ctypes.data, x.shape[0], out.ctypes.data)
+        return out, h
+
+    def cp_correlate_fm(self, filtered: np.ndarray):
+        f = np.ascontiguousarray(filtered, dtype=np.int16)
+        assert f.shape == (71280, 2)
+        se = ctypes.c_int()
+        pk = np.zeros(2, dtype=np.float32)
+        self.lib.orc_cp_correlate_fm(f.ctypes.data, ctypes.byref(se), pk.ctypes.data)
+        return se.value, complex(pk[0], pk[1])
+
+    def deinterleave_p1(self, pm: np.ndarray) -> np.ndarray:
+        pm = np.ascontiguousarray(pm, dtype=np.int8)
+        out = np.zeros(438528, dtype=np.int8)
+        self.lib.orc_deinterleave_p1(pm.ctypes.data, out.ctypes.data)
+        return out
+
+    def deinterleave_pids(self, pm: np.ndarray, bc: int) -> np.ndarray:
+        pm = np.ascontiguousarray(pm, dtype=np.int8)
+        out = np.zeros(240, dtype=np.int8)
+        self.lib.orc_deinterleave_pids(pm.ctypes.data, bc, out.ctypes.data)
+        return out
+
+    def viterbi_k7(self, soft: np.ndarray) -> np.ndarray:
+        soft = np.ascontiguousarray(soft, dtype=np.int8)
+        out = np.zeros(soft.size // 3, dtype=np.uint8)
+        self.lib.orc_viterbi_k7(soft.ctypes.data, soft.size // 3, out.ctypes.data)
+        return out
+
+    def viterbi(self, soft: np.ndarray, k: int, gens) -> np.ndarray:
+        soft = np.ascontiguousarray(soft, dtype=np.int8)
+        g = (ctypes.c_uint * 3)(*gens)
+        out = np.zeros(soft.size // 3, dtype=np.uint8)
+        self.lib.orc_viterbi(soft.ctypes.data, soft.size // 3, k, g, out.ctypes.data)
+        return out
+
+    def descramble(self, bits: np.ndarray) -> np.ndarray:
+        b = np.ascontiguousarray(bits, dtype=np.uint8).copy()
+        self.lib.orc_descramble(b.ctypes.data, b.size)
+        return b
+
+    def bit_errors_k7(self, coded: np.ndarray, decoded: np.ndarray) -> int:
+        c = np.ascontiguousarray(coded, dtype=np.int8)
+        d = np.ascontiguousarray(decoded, dtype=np.uint8)
+        return self.lib.orc_bit_errors_k7(c.ctypes.data, d.ctypes.data, d.size)
+
+    def fft(self, x: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.complex64)
+        out = np.zeros_like(x)
+        self.lib.oracle_fft_forward(x.size, x.ctypes.data, out.ctypes.data)
+        return out
+
+    # ---- whole path -------------------------------------------------------------------
+    def run(self, iq: np.ndarray, taps: int = 0, chunk: int = 32768, fft_blocks: int = 4, p1_hook=None):
+        iq = np.ascontiguousarray(iq)
+        s = self.lib.orc_open()
+        keep = None
+        try:
+            self.lib.orc_set_taps(s, taps, fft_blocks)
+            if p1_hook is not None:
+                keep = P1_HOOK(lambda user, bits, n: int(p1_hook(np.ctypeslib.as_array(bits, shape=(n,)))))
+                self.lib.orc_set_p1_hook(s, keep, None)
+            step = chunk if iq.dtype == np.uint8 else chunk
+            for off in range(0, iq.size, step):
+                part = iq[off:off + step]
+                if iq.dtype == np.uint8:
+                    self.lib.orc_push_cu8(s, part.ctypes.data, part.size - part.size % 4)
+                else:
+                    self.lib.orc_push_cs16(s, part.ctypes.data, part.size - part.size % 2)
+            bufs = []
+            for which in range(3):
+                p = ctypes.c_void_p()
+                n = self.lib.orc_buf(s, which, ctypes.byref(p))
+                bufs.append(ctypes.string_at(p, n) if n else b"")
+        finally:
+            self.lib.orc_close(s)
+        return (_ref.parse_log(bufs[0]), np.frombuffer(bufs[1], dtype=np.int16).reshape(-1, 2),
+                np.frombuffer(bufs[2], dtype=np.complex64))
