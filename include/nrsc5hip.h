@@ -1,0 +1,151 @@
+/* libnrsc5hip -- C ABI of the MI355X (gfx950) NRSC-5 demodulate/decode engine.
+ *
+ * This is the drop-in boundary for the reference's IQ -> L1-frame hot path.  It replaces the
+ * internal seam of theori-io/nrsc5 between L4 (src/nrsc5.c) and L2 (src/frame.c, src/pids.c):
+ *
+ *   down-calls replaced                      reference interface (file:line)
+ *   ---------------------------------------  ----------------------------------------------
+ *   nrsc5hip_push_cu8                        input_push_cu8      src/input.h:42, input.c:96-117
+ *   nrsc5hip_push_cs16                       input_push_cs16     src/input.h:43, input.c:119-124
+ *   nrsc5hip_stream_reset                    input_reset         src/input.h:39, input.c:126-138
+ *   nrsc5hip_force_resync                    input_set_sync_state(st, SYNC_STATE_NONE) as called
+ *                                            by frame_process    src/frame.c:535-540
+ *   up-calls delivered as ordered records    output_advance (acquire.c:108), nrsc5_report_sync /
+ *   (nrsc5hip_drain)                         _lost_sync (input.c:177-185), nrsc5_report_mer
+ *                                            (sync.c:490-501), nrsc5_report_ber (decode.c:458),
+ *                                            pids_frame_push (decode.c:471, pids.h:98),
+ *                                            frame_push (decode.c:460, frame.h:53)
+ *
+ * plus an additive batch API (device-resident captures, many independent streams per call) that the
+ * reference has no counterpart for.  All functions return 0 on success and a negative NRSC5HIP_E*
+ * code on failure; nothing throws across the boundary; no C++/torch types appear in signatures.
+ * Buffers passed in are borrowed for the duration of the call.  INTEGRATION.md shows the binding a
+ * maintainer of the reference would add (src/input.c replacement + CMake lines).
+ */
+#ifndef NRSC5HIP_H_
+#define NRSC5HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NRSC5HIP_OK            0
+#define NRSC5HIP_EINVAL       (-1)
+#define NRSC5HIP_ENOMEM       (-2)
+#define NRSC5HIP_EHIP         (-3)   /* a HIP runtime call failed; see nrsc5hip_last_error() */
+#define NRSC5HIP_EOVERFLOW    (-4)   /* FIFO / record ring / frame ring capacity exceeded */
+
+#define NRSC5HIP_P1_FRAME_BITS   146176   /* P1_FRAME_LEN_FM, defines.h:42 */
+#define NRSC5HIP_P1_FRAME_WORDS  4568
+#define NRSC5HIP_PIDS_FRAME_BITS 80       /* PIDS_FRAME_LEN, defines.h:47 */
+
+/* sync states, input.h:18 */
+enum { NRSC5HIP_SYNC_NONE = 0, NRSC5HIP_SYNC_COARSE = 1, NRSC5HIP_SYNC_FINE = 2 };
+
+/* nrsc5hip_record.flags */
+enum {
+    NRSC5HIP_REC_PROCESSED = 1u << 0,  /* one acquire block was processed: call output_advance() first */
+    NRSC5HIP_REC_TO_COARSE = 1u << 1,  /* sync state NONE -> COARSE at the top of this block */
+    NRSC5HIP_REC_TO_FINE   = 1u << 2,  /* sync achieved in this block: nrsc5_report_sync(freq_offset, psmi) */
+    NRSC5HIP_REC_MER       = 1u << 3,  /* nrsc5_report_mer(mer_lb, mer_ub) */
+    NRSC5HIP_REC_PIDS      = 1u << 4,  /* pids_frame_push(pids) */
+    NRSC5HIP_REC_P1        = 1u << 5,  /* nrsc5_report_ber(ber); frame_push(P1 frame in slot p1_slot) */
+    NRSC5HIP_REC_LOST_SYNC = 1u << 6   /* reserved */
+};
+
+/* One record per processed 32-symbol block, in stream order.  Events implied by one record fire in
+ * the order of the flag bits above (which is the reference's order inside acquire_process). */
+typedef struct nrsc5hip_record {
+    uint32_t flags;
+    int32_t state_before, state_after;   /* sync state entering / leaving the block */
+    int32_t samperr;                     /* timing pick used for this block, 0..2159 (acquire.c:112,149) */
+    int32_t cfo;                         /* integer carrier offset in bins after this block */
+    int32_t keep;                        /* samples carried to the next window (acquire.c:259) */
+    int32_t bc;                          /* block count after this block */
+    int32_t psmi;
+    int32_t cfo_wait;
+    int32_t next_samperr;                /* tracking feedback for the next block (sync.c:455) */
+    float prev_angle;                    /* CP-lag phase estimate, rad per 2048 samples */
+    float phase_re, phase_im;            /* NCO phase after the block */
+    float next_angle;                    /* residual CFO feedback (sync.c:458) */
+    float freq_offset;                   /* Hz, valid with REC_TO_FINE (input.c:181-184) */
+    float mer_lb, mer_ub;                /* dB, valid with REC_MER */
+    float ber;                           /* valid with REC_P1 */
+    int32_t p1_slot;                     /* valid with REC_P1 */
+    int32_t bc_decoded;                  /* block count the PIDS frame / soft bits belong to, or -1 */
+    uint32_t pids[3];                    /* valid with REC_PIDS: bit i of the frame at pids[i/32] bit i%32 */
+    uint32_t pad;
+} nrsc5hip_record;
+
+typedef struct nrsc5hip_config {
+    int device;                /* HIP device ordinal */
+    int max_streams;           /* independent IQ streams resident in this engine */
+    long long q15_capacity;    /* decimated (744187.5 S/s) samples of FIFO per stream; >= 2 * 71280.
+                                  Batch use: capture length / 2 + 64. */
+    int record_capacity;       /* block records retained per stream between drains (>= 64) */
+    int p1_slots;              /* decoded P1 frames retained per stream between drains (>= 2) */
+    int p1_async;              /* 0: decode each P1 frame before the next block of any stream (exact
+                                  reference event timing; required for nrsc5hip_force_resync feedback);
+                                  1: decode the frames of each 16-block window on a second HIP stream,
+                                  overlapped with the next window (throughput mode) */
+} nrsc5hip_config;
+
+typedef struct nrsc5hip_engine nrsc5hip_engine;
+
+int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engine **out);
+void nrsc5hip_engine_destroy(nrsc5hip_engine *e);
+const char *nrsc5hip_last_error(void);
+/* hipStream_t the engine launches on, as void* (so that callers can order their own work) */
+void *nrsc5hip_engine_hip_stream(nrsc5hip_engine *e);
+
+/* ---- streaming seam (host buffers), one stream at a time --------------------------------------- */
+/* input_push_cu8 (input.c:96-117): nbytes % 4 == 0.  Decimates, appends, and processes every block
+ * whose 33-symbol window is complete; records are then available through nrsc5hip_drain. */
+int nrsc5hip_push_cu8(nrsc5hip_engine *e, int stream, const uint8_t *iq, uint32_t nbytes);
+/* input_push_cs16 (input.c:119-124): n = number of int16 values, n % 2 == 0 */
+int nrsc5hip_push_cs16(nrsc5hip_engine *e, int stream, const int16_t *iq, uint32_t n);
+/* input_reset (input.c:126-138), fresh-session semantics */
+int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream);
+/* L2 feedback (frame.c:535-540): the stream drops to SYNC_NONE before its next block */
+int nrsc5hip_force_resync(nrsc5hip_engine *e, int stream);
+
+/* ---- batch path (device buffers) ------------------------------------------------------------------ */
+/* Decimate + append one cu8 chunk per listed stream.  dev_iq: device pointer, chunk k at
+ * dev_iq + k * stride_bytes (16-byte aligned), nbytes[k] bytes each (host array, % 4 == 0). */
+int nrsc5hip_batch_append_cu8(nrsc5hip_engine *e, int nstreams, const int *stream_ids,
+                              const uint8_t *dev_iq, long long stride_bytes, const uint32_t *nbytes);
+int nrsc5hip_batch_append_cs16(nrsc5hip_engine *e, int nstreams, const int *stream_ids,
+                               const int16_t *dev_iq, long long stride_elems, const uint32_t *nelems);
+/* Run block steps (every listed stream advances by at most one block per step) until no listed stream
+ * has a complete window or max_steps is reached; *steps_done gets the number of steps that did work. */
+int nrsc5hip_batch_process(nrsc5hip_engine *e, int nstreams, const int *stream_ids, int max_steps, int *steps_done);
+
+/* ---- results ----------------------------------------------------------------------------------------- */
+/* Copies up to max records of `stream`, oldest first, that were produced since the previous drain. */
+int nrsc5hip_drain(nrsc5hip_engine *e, int stream, nrsc5hip_record *out, int max, int *n_out);
+/* P1 frame of a REC_P1 record, packed (bit i at words[i/32] bit i%32) ... */
+int nrsc5hip_p1_frame_packed(nrsc5hip_engine *e, int stream, int slot, uint32_t *words /* [4568] */);
+/* ... or one bit per byte, the layout frame_push() takes (frame.h:53) */
+int nrsc5hip_p1_frame_bits(nrsc5hip_engine *e, int stream, int slot, uint8_t *bits /* [146176] */);
+/* Bulk D2H of every record/frame produced by a batch: records[nstreams][max_records],
+ * counts[nstreams]; frames may be NULL, else frames[nstreams][p1_slots][4568] */
+int nrsc5hip_batch_fetch(nrsc5hip_engine *e, int nstreams, const int *stream_ids, nrsc5hip_record *records,
+                         int max_records, int *counts, uint32_t *frames);
+/* unpack helper (host only) */
+void nrsc5hip_unpack_bits(const uint32_t *words, int nbits, uint8_t *bits);
+
+/* ---- stage-level entry points (host buffers): parity tests of single kernels against the oracle ---- */
+int nrsc5hip_stage_halfband_fm_cu8(nrsc5hip_engine *e, const uint8_t *iq, uint32_t nbytes, int16_t *out /* [nbytes/4][2] */);
+int nrsc5hip_stage_fft2048(nrsc5hip_engine *e, const float *in /* [n][2048][2] */, float *out, int n);
+int nrsc5hip_stage_viterbi_k7(nrsc5hip_engine *e, const int8_t *soft /* [nframes][3*len] */, int len, int nframes,
+                              uint8_t *bits /* [nframes][len] */);
+/* debugging aid: soft-bit matrix (16 x 23040 int8) and live FFT bins of a stream's latest block */
+int nrsc5hip_debug_fetch(nrsc5hip_engine *e, int stream, int8_t *pm /* [368640] or NULL */, float *bins /* [32][534][2] or NULL */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NRSC5HIP_H_ */

@@ -1,0 +1,62 @@
+"""Build recipe for libnrsc5hip.so (hipcc, gfx950 only).  `python -m nrsc5_amd.build`.
+
+The CPU-emulated twin used by the `-m "not gpu"` logic tests is built by `build_emu()` into
+tests/simt/ -- test infrastructure, never loaded by the package itself."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "nrsc5_amd", "csrc")
+HIP_SOURCES = ["engine.hip", "k_decimate.hip", "k_acquire.hip", "k_mixfft.hip", "k_sync.hip", "k_decode.hip"]
+LIB = os.path.join(ROOT, "nrsc5_amd", "libnrsc5hip.so")
+EMU_LIB = os.path.join(ROOT, "tests", "simt", "libnrsc5hip_emu.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _deps():
+    d = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    d.append(os.path.join(ROOT, "include", "nrsc5hip.h"))
+    return d
+
+
+def build_hip(force: bool = False, verbose: bool = False) -> str:
+    """Cross-compiles on a GPU-less host too (hipcc --offload-arch=gfx950)."""
+    if force or _stale(LIB, _deps()):
+        srcs = [os.path.join(CSRC, f) for f in HIP_SOURCES if os.path.exists(os.path.join(CSRC, f))]
+        cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+               "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB] + srcs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+def build_emu(force: bool = False) -> str:
+    simt = os.path.join(ROOT, "tests", "simt")
+    deps = _deps() + [os.path.join(simt, "hipemu.h"), os.path.join(simt, "hipemu.cpp")]
+    if force or _stale(EMU_LIB, deps):
+        srcs = [os.path.join(CSRC, f) for f in HIP_SOURCES if os.path.exists(os.path.join(CSRC, f))]
+        cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-w",
+               "-I" + simt, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", EMU_LIB,
+               os.path.join(simt, "hipemu.cpp")]
+        for s in srcs:
+            cmd += ["-x", "c++", s]
+        subprocess.check_call(cmd)
+    return EMU_LIB
+
+
+if __name__ == "__main__":
+    if "--emu" in sys.argv:
+        print(build_emu(force=True))
+    else:
+        print(build_hip(force=True, verbose=True))

@@ -1,0 +1,566 @@
+// Host side of libnrsc5hip: engine object, device-resident per-stream state, the block-step
+// scheduler and the C ABI of include/nrsc5hip.h.  Mirrors the reference's src/input.c seam
+// (input_push_cu8/cs16, input_reset, input_set_sync_state) -- see include/nrsc5hip.h for the map.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+#include <vector>
+#include "nrsc5hip.h"
+#include "kernels.h"
+
+using namespace nrsc5;
+
+static_assert(sizeof(nrsc5hip_record) == sizeof(BlockRecord), "record ABI mismatch");
+static_assert(sizeof(BlockRecord) % 8 == 0, "record alignment");
+
+static thread_local char g_err[512] = "";
+extern "C" const char *nrsc5hip_last_error(void) { return g_err; }
+
+#define HIPCHK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t _e = (expr);                                                                        \
+        if (_e != hipSuccess) {                                                                        \
+            snprintf(g_err, sizeof(g_err), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return NRSC5HIP_EHIP;                                                                      \
+        }                                                                                              \
+    } while (0)
+#define FAIL(code, ...) do { snprintf(g_err, sizeof(g_err), __VA_ARGS__); return (code); } while (0)
+
+struct nrsc5hip_engine {
+    nrsc5hip_config cfg;
+    DevTables tb;
+    DevBuffers db;
+    hipStream_t main, aux;
+    hipEvent_t ev_window[2], ev_decoded[2];
+    bool decoded_pending[2];
+    std::vector<void *> allocs;
+    // host mirrors
+    std::vector<long long> wr_host, base_host;
+    std::vector<int> drained;          // records already handed out per stream
+    bool acq_needed;
+    long long step_count;              // block steps issued so far (P1 window parity in async mode)
+    // staging
+    uint8_t *stage_dev; size_t stage_bytes;
+    int *ids_dev; unsigned *nbytes_dev;
+    int *counters_host;                // pinned
+    int *all_ids_dev;                  // identity list 0..S-1
+};
+
+template <typename T> static int dev_alloc(nrsc5hip_engine *e, T **p, size_t count)
+{
+    void *q = nullptr;
+    hipError_t err = hipMalloc(&q, count * sizeof(T) ? count * sizeof(T) : 1);
+    if (err != hipSuccess) { snprintf(g_err, sizeof(g_err), "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(err)); return NRSC5HIP_ENOMEM; }
+    e->allocs.push_back(q);
+    *p = (T *)q;
+    return 0;
+}
+template <typename T> static int dev_upload(nrsc5hip_engine *e, const T **p, const std::vector<T> &v)
+{
+    T *d; int rc = dev_alloc(e, &d, v.size()); if (rc) return rc;
+    HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *p = d;
+    return 0;
+}
+
+// ---- read-only tables --------------------------------------------------------------------------
+static int build_tables(nrsc5hip_engine *e)
+{
+    static const int8_t PM_V[20] = { 10, 2, 18, 6, 14, 8, 16, 0, 12, 4, 11, 3, 19, 7, 15, 9, 17, 1, 13, 5 };   // decode.c:34-37
+    // interleaver I for P1 (decode.c:296-322 with J=20, B=16, C=36, M=1, N=365440)
+    std::vector<int32_t> p1(P1_CODED);
+    for (unsigned i = 0; i < (unsigned)P1_CODED; i++) {
+        const unsigned part = PM_V[i % 20], block = (i / 20 + 7 * part) % 16, k = i / (20 * 16);
+        const unsigned row = (11 * k) % 32, col = (11 * k + k / (32 * 9)) % 36;
+        p1[i] = (block * 32 + row) * 720 + part * 36 + col;
+    }
+    // interleaver II for PIDS (decode.c:324-342 with b=200, I0=365440): index inside block bc
+    std::vector<uint16_t> pids(16 * PIDS_CODED);
+    for (unsigned bc = 0; bc < 16; bc++)
+        for (unsigned n = 0; n < (unsigned)PIDS_CODED; n++) {
+            const unsigned i = bc * PIDS_CODED + n, part = PM_V[i % 20];
+            const unsigned k = ((i / 20) % (PIDS_CODED / 20)) + P1_CODED / (20 * 16);
+            const unsigned row = (11 * k) % 32, col = (11 * k + k / (32 * 9)) % 36;
+            pids[i] = (uint16_t)(row * 720 + part * 36 + col);
+        }
+    // descrambler stream (decode.c:279-294), packed LSB-first
+    std::vector<uint32_t> scr(P1_WORDS, 0), scr_pids(3, 0);
+    {
+        unsigned val = 0x3ff;
+        for (int i = 0; i < P1_LEN; i++) {
+            const unsigned bit = ((val >> 9) ^ val) & 1;
+            val |= bit << 11; val >>= 1;
+            scr[i >> 5] |= bit << (i & 31);
+            if (i < PIDS_LEN) scr_pids[i >> 5] |= bit << (i & 31);
+        }
+    }
+    std::vector<float2> tw(FFT_N);
+    for (int k = 0; k < FFT_N; k++) {
+        const double a = -2.0 * M_PI * k / FFT_N;
+        tw[k].x = (float)cos(a); tw[k].y = (float)sin(a);
+    }
+    std::vector<float> shape(SYM_N);                           // acquire.c:322-331
+    for (int i = 0; i < SYM_N; i++) {
+        if (i < CP_N) shape[i] = sinf(M_PI / 2 * i / CP_N);
+        else if (i < FFT_N) shape[i] = 1;
+        else shape[i] = cosf(M_PI / 2 * (i - FFT_N) / CP_N);
+    }
+    // Q15 taps: (int16)(tap * 32767.0f) as firdecim_q15_create does (firdecim_q15.c:37-42)
+    static const float hb_taps[4] = { 0.6062333583831787f, -0.13481467962265015f, 0.032919470220804214f, -0.00410953676328063f };   // input.c:35-40
+    static const float acq_taps[32] = {                        // acquire.c:28-61
+        -0.000685643230099231f, 0.005636964458972216f, 0.009015781804919243f, -0.015486305579543114f,
+        -0.035108357667922974f, 0.017446253448724747f, 0.08155813068151474f, 0.007995186373591423f,
+        -0.13311293721199036f, -0.0727422907948494f, 0.15914097428321838f, 0.16498781740665436f,
+        -0.1324498951435089f, -0.2484012246131897f, 0.051773931831121445f, 0.2821577787399292f,
+        0.051773931831121445f, -0.2484012246131897f, -0.1324498951435089f, 0.16498781740665436f,
+        0.15914097428321838f, -0.0727422907948494f, -0.13311293721199036f, 0.007995186373591423f,
+        0.08155813068151474f, 0.017446253448724747f, -0.035108357667922974f, -0.015486305579543114f,
+        0.009015781804919243f, 0.005636964458972216f, -0.000685643230099231f, 0.0f };
+    std::vector<int16_t> hbq(4), acq(17, 0);
+    for (int i = 0; i < 4; i++) hbq[i] = (int16_t)(hb_taps[3 - i] * 32767.0f);
+    for (int i = 1; i <= 16; i++) acq[i] = (int16_t)(acq_taps[31 - i] * 32767.0f);
+
+    int rc;
+    if ((rc = dev_upload(e, &e->tb.p1_gather, p1))) return rc;
+    if ((rc = dev_upload(e, &e->tb.pids_gather, pids))) return rc;
+    if ((rc = dev_upload(e, &e->tb.scr_p1, scr))) return rc;
+    if ((rc = dev_upload(e, &e->tb.scr_pids, scr_pids))) return rc;
+    if ((rc = dev_upload(e, &e->tb.twiddle, tw))) return rc;
+    if ((rc = dev_upload(e, &e->tb.shape, shape))) return rc;
+    if ((rc = dev_upload(e, &e->tb.hb_q15, hbq))) return rc;
+    if ((rc = dev_upload(e, &e->tb.acq_q15, acq))) return rc;
+    return 0;
+}
+
+static void init_state(StreamState &st)
+{
+    memset(&st, 0, sizeof(st));
+    st.psmi = 1;                                               // sync_reset (sync.c:821)
+    st.sync_state = SYNC_NONE;
+}
+
+extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engine **out)
+{
+    if (!cfg || !out) FAIL(NRSC5HIP_EINVAL, "null argument");
+    *out = nullptr;
+    if (cfg->max_streams < 1 || cfg->q15_capacity < 2 * WIN_N || cfg->record_capacity < 64 || cfg->p1_slots < 2)
+        FAIL(NRSC5HIP_EINVAL, "bad config (max_streams>=1, q15_capacity>=%d, record_capacity>=64, p1_slots>=2)", 2 * WIN_N);
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) FAIL(NRSC5HIP_EINVAL, "device %d out of range (%d devices)", cfg->device, ndev);
+    HIPCHK(hipSetDevice(cfg->device));
+    nrsc5hip_engine *e = new (std::nothrow) nrsc5hip_engine();
+    if (!e) FAIL(NRSC5HIP_ENOMEM, "out of host memory");
+    e->cfg = *cfg;
+    const size_t S = cfg->max_streams;
+    int rc = 0;
+    do {
+        if (hipStreamCreate(&e->main) != hipSuccess || hipStreamCreate(&e->aux) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "hipStreamCreate failed"); break; }
+        for (int k = 0; k < 2; k++) { hipEventCreate(&e->ev_window[k]); hipEventCreate(&e->ev_decoded[k]); e->decoded_pending[k] = false; }
+        if ((rc = build_tables(e))) break;
+        DevBuffers &db = e->db;
+        db.q15_cap = cfg->q15_capacity; db.p1_slots = cfg->p1_slots; db.rec_cap = cfg->record_capacity;
+        if ((rc = dev_alloc(e, &db.state, S))) break;
+        if ((rc = dev_alloc(e, &db.q15, S * (size_t)db.q15_cap))) break;
+        if ((rc = dev_alloc(e, &db.acq_filt, S * WIN_N))) break;
+        if ((rc = dev_alloc(e, &db.acq_sums, S * SYM_N))) break;
+        if ((rc = dev_alloc(e, &db.bins, S * NSYM * LIVE_N))) break;
+        if ((rc = dev_alloc(e, &db.pm, S * PM_FRAME))) break;
+        if ((rc = dev_alloc(e, &db.coded, S * 2 * P1_DEPUNCT))) break;
+        if ((rc = dev_alloc(e, &db.dec, S * (size_t)(P1_LEN + 64)))) break;
+        if ((rc = dev_alloc(e, &db.p1_ring, S * db.p1_slots * P1_WORDS))) break;
+        if ((rc = dev_alloc(e, &db.records, S * db.rec_cap))) break;
+        if ((rc = dev_alloc(e, &db.counters, 4))) break;
+        e->stage_bytes = 4u << 20;
+        if ((rc = dev_alloc(e, &e->stage_dev, e->stage_bytes))) break;
+        if ((rc = dev_alloc(e, &e->ids_dev, S))) break;
+        if ((rc = dev_alloc(e, &e->nbytes_dev, S))) break;
+        if ((rc = dev_alloc(e, &e->all_ids_dev, S))) break;
+        if (hipHostMalloc((void **)&e->counters_host, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) { rc = NRSC5HIP_ENOMEM; snprintf(g_err, sizeof(g_err), "hipHostMalloc failed"); break; }
+        std::vector<StreamState> init(S);
+        std::vector<int> ident(S);
+        for (size_t s = 0; s < S; s++) { init_state(init[s]); ident[s] = (int)s; }
+        if (hipMemcpy(db.state, init.data(), S * sizeof(StreamState), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(e->all_ids_dev, ident.data(), S * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemset(db.records, 0, S * db.rec_cap * sizeof(BlockRecord)) != hipSuccess ||
+            hipMemset(db.pm, 0, S * PM_FRAME) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "state init copy failed"); break; }
+        e->wr_host.assign(S, 0); e->base_host.assign(S, 0); e->drained.assign(S, 0);
+        e->acq_needed = true; e->step_count = 0;
+    } while (0);
+    if (rc) { nrsc5hip_engine_destroy(e); return rc; }
+    *out = e;
+    return NRSC5HIP_OK;
+}
+
+extern "C" void nrsc5hip_engine_destroy(nrsc5hip_engine *e)
+{
+    if (!e) return;
+    hipDeviceSynchronize();
+    for (void *p : e->allocs) hipFree(p);
+    if (e->counters_host) hipHostFree(e->counters_host);
+    for (int k = 0; k < 2; k++) { if (e->ev_window[k]) hipEventDestroy(e->ev_window[k]); if (e->ev_decoded[k]) hipEventDestroy(e->ev_decoded[k]); }
+    if (e->main) hipStreamDestroy(e->main);
+    if (e->aux) hipStreamDestroy(e->aux);
+    delete e;
+}
+
+extern "C" void *nrsc5hip_engine_hip_stream(nrsc5hip_engine *e) { return e ? (void *)e->main : nullptr; }
+
+static int check_stream(nrsc5hip_engine *e, int s)
+{
+    if (!e) FAIL(NRSC5HIP_EINVAL, "null engine");
+    if (s < 0 || s >= e->cfg.max_streams) FAIL(NRSC5HIP_EINVAL, "stream %d out of range", s);
+    return 0;
+}
+
+// ---- block-step scheduler --------------------------------------------------------------------------
+// One step = every listed stream whose 33-symbol window is complete advances by one block:
+//   [acquisition kernels if any stream may be un-synchronised] -> prepare -> mix+FFT -> sync (+PIDS)
+//   -> P1 de-interleave -> P1 Viterbi (in order, or deferred to the aux stream once per 16-step window).
+static int issue_step(nrsc5hip_engine *e, int n, const int *ids_dev)
+{
+    const bool async = e->cfg.p1_async != 0;
+    const int parity = async ? (int)((e->step_count / 16) & 1) : 0;
+    if (async && (e->step_count % 16) == 0 && e->decoded_pending[parity]) {
+        // coded[.][parity] is about to be rewritten: the decoder launched two windows ago must be done
+        HIPCHK(hipStreamWaitEvent(e->main, e->ev_decoded[parity], 0));
+        e->decoded_pending[parity] = false;
+    }
+    if (e->acq_needed) launch_acquire(e->tb, e->db, n, ids_dev, e->main);
+    launch_prepare(e->db, n, ids_dev, e->main);
+    launch_mixfft(e->tb, e->db, n, ids_dev, e->main);
+    launch_sync(e->tb, e->db, n, ids_dev, parity, e->main);
+    launch_p1_deint(e->tb, e->db, n, ids_dev, parity, e->main);
+    if (!async) {
+        launch_p1_viterbi(e->tb, e->db, n, ids_dev, parity, e->main);
+    } else if ((e->step_count % 16) == 15) {
+        HIPCHK(hipEventRecord(e->ev_window[parity], e->main));
+        HIPCHK(hipStreamWaitEvent(e->aux, e->ev_window[parity], 0));
+        launch_p1_viterbi(e->tb, e->db, n, ids_dev, parity, e->aux);
+        HIPCHK(hipEventRecord(e->ev_decoded[parity], e->aux));
+        e->decoded_pending[parity] = true;
+    }
+    e->step_count++;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// finish a partially filled decode window (async mode) so that every produced frame gets decoded
+static int flush_p1(nrsc5hip_engine *e, int n, const int *ids_dev)
+{
+    if (!e->cfg.p1_async) return 0;
+    if (e->step_count % 16) {
+        const int parity = (int)((e->step_count / 16) & 1);
+        launch_p1_viterbi(e->tb, e->db, n, ids_dev, parity, e->main);
+        e->step_count += 16 - (e->step_count % 16);           // next batch starts a fresh window
+    }
+    HIPCHK(hipStreamSynchronize(e->aux));
+    e->decoded_pending[0] = e->decoded_pending[1] = false;
+    return 0;
+}
+
+static int run_steps(nrsc5hip_engine *e, int n, const int *ids_dev, int max_steps, int check_every, int *steps_done)
+{
+    int done = 0;
+    while (done < max_steps) {
+        HIPCHK(hipMemsetAsync(e->db.counters, 0, 4 * sizeof(int), e->main));
+        int burst = 0;
+        for (; burst < check_every && done + burst < max_steps; burst++) {
+            int rc = issue_step(e, n, ids_dev);
+            if (rc) return rc;
+        }
+        HIPCHK(hipMemcpyAsync(e->counters_host, e->db.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, e->main));
+        HIPCHK(hipStreamSynchronize(e->main));
+        const int processed = e->counters_host[0];
+        e->acq_needed = e->counters_host[1] > 0;
+        if (processed == 0) break;                             // nothing left to do in this burst
+        done += burst;
+        if (processed < burst && check_every > 1) { /* some steps were empty: the tail is near */ }
+    }
+    int rc = flush_p1(e, n, ids_dev);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(e->main));
+    if (steps_done) *steps_done = done;
+    return 0;
+}
+
+// ---- FIFO space management (streaming) -----------------------------------------------------------------
+__global__ void k_compact(DevBuffers db, int s)
+{
+    // move the unread tail [rd, wr) to the start of the stream's slab; forward copy, dst < src
+    StreamState &st = db.state[s];
+    c16 *buf = db.q15 + (size_t)s * db.q15_cap;
+    const long long off = st.rd - st.base, n = st.wr - st.rd;
+    __shared__ c16 tmp[1024];
+    for (long long c = 0; c < n; c += 1024) {
+        const long long k = c + threadIdx.x;
+        if (k < n) tmp[threadIdx.x] = buf[off + k];
+        __syncthreads();
+        if (k < n) buf[k] = tmp[threadIdx.x];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) st.base = st.rd;
+}
+
+static int ensure_space(nrsc5hip_engine *e, int s, long long incoming)
+{
+    if (e->wr_host[s] - e->base_host[s] + incoming <= e->db.q15_cap) return 0;
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, e->main, e->db, s);
+    long long base = 0;
+    HIPCHK(hipMemcpyAsync(&base, (const char *)(e->db.state + s) + offsetof(StreamState, base), sizeof(long long), hipMemcpyDeviceToHost, e->main));
+    HIPCHK(hipStreamSynchronize(e->main));
+    e->base_host[s] = base;
+    if (e->wr_host[s] - e->base_host[s] + incoming > e->db.q15_cap)
+        FAIL(NRSC5HIP_EOVERFLOW, "stream %d: FIFO capacity %lld too small for %lld more samples", s, e->db.q15_cap, incoming);
+    return 0;
+}
+
+// ---- streaming seam ---------------------------------------------------------------------------------------
+static int push_common(nrsc5hip_engine *e, int s, const void *host, size_t nbytes_total, bool cu8)
+{
+    int rc = check_stream(e, s); if (rc) return rc;
+    const uint8_t *src = (const uint8_t *)host;
+    const size_t unit = 4;                                     // cu8: 2 complex samples; cs16: 1 complex sample
+    if (nbytes_total % unit) FAIL(NRSC5HIP_EINVAL, "length must be a multiple of %zu bytes", unit);
+    while (nbytes_total) {
+        const size_t chunk = nbytes_total > e->stage_bytes ? e->stage_bytes : nbytes_total;
+        const long long nq15 = cu8 ? (long long)chunk / 4 : (long long)chunk / 4;
+        if ((rc = ensure_space(e, s, nq15))) return rc;
+        const unsigned count = cu8 ? (unsigned)chunk : (unsigned)(chunk / 2);
+        HIPCHK(hipMemcpyAsync(e->stage_dev, src, chunk, hipMemcpyHostToDevice, e->main));
+        HIPCHK(hipMemcpyAsync(e->ids_dev, &s, sizeof(int), hipMemcpyHostToDevice, e->main));
+        HIPCHK(hipMemcpyAsync(e->nbytes_dev, &count, sizeof(unsigned), hipMemcpyHostToDevice, e->main));
+        HIPCHK(hipStreamSynchronize(e->main));                 // &s / &count are stack temporaries
+        if (cu8) launch_decimate_fm_cu8(e->tb, e->db, 1, e->ids_dev, e->stage_dev, 0, e->nbytes_dev, count, e->main);
+        else launch_append_cs16(e->db, 1, e->ids_dev, (const int16_t *)e->stage_dev, 0, e->nbytes_dev, count, e->main);
+        e->wr_host[s] += nq15;
+        int steps = 0;
+        if ((rc = run_steps(e, 1, e->ids_dev, 1 << 30, 1, &steps))) return rc;
+        src += chunk; nbytes_total -= chunk;
+    }
+    return 0;
+}
+
+extern "C" int nrsc5hip_push_cu8(nrsc5hip_engine *e, int stream, const uint8_t *iq, uint32_t nbytes)
+{
+    return push_common(e, stream, iq, nbytes, true);
+}
+extern "C" int nrsc5hip_push_cs16(nrsc5hip_engine *e, int stream, const int16_t *iq, uint32_t n)
+{
+    if (n % 2) FAIL(NRSC5HIP_EINVAL, "cs16 length must be even");
+    return push_common(e, stream, iq, (size_t)n * 2, false);
+}
+
+extern "C" int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream)
+{
+    int rc = check_stream(e, stream); if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    StreamState st; init_state(st);
+    HIPCHK(hipMemcpy(e->db.state + stream, &st, sizeof(st), hipMemcpyHostToDevice));
+    e->wr_host[stream] = 0; e->base_host[stream] = 0; e->drained[stream] = 0;
+    e->acq_needed = true;
+    return 0;
+}
+
+__global__ void k_force_none(DevBuffers db, int s) { db.state[s].sync_state = SYNC_NONE; }
+
+extern "C" int nrsc5hip_force_resync(nrsc5hip_engine *e, int stream)
+{
+    int rc = check_stream(e, stream); if (rc) return rc;
+    hipLaunchKernelGGL(k_force_none, dim3(1), dim3(1), 0, e->main, e->db, stream);
+    e->acq_needed = true;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ---- batch path ----------------------------------------------------------------------------------------------
+static int upload_ids(nrsc5hip_engine *e, int n, const int *ids, const uint32_t *counts, const int **ids_dev)
+{
+    if (n < 1 || n > e->cfg.max_streams) FAIL(NRSC5HIP_EINVAL, "nstreams %d out of range", n);
+    if (ids) {
+        for (int k = 0; k < n; k++) if (ids[k] < 0 || ids[k] >= e->cfg.max_streams) FAIL(NRSC5HIP_EINVAL, "stream id %d out of range", ids[k]);
+        HIPCHK(hipMemcpy(e->ids_dev, ids, n * sizeof(int), hipMemcpyHostToDevice));
+        *ids_dev = e->ids_dev;
+    } else {
+        *ids_dev = e->all_ids_dev;
+    }
+    if (counts) HIPCHK(hipMemcpy(e->nbytes_dev, counts, n * sizeof(unsigned), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int nrsc5hip_batch_append_cu8(nrsc5hip_engine *e, int nstreams, const int *stream_ids,
+                                         const uint8_t *dev_iq, long long stride_bytes, const uint32_t *nbytes)
+{
+    if (!e || !dev_iq || !nbytes) FAIL(NRSC5HIP_EINVAL, "null argument");
+    const int *ids_dev; int rc = upload_ids(e, nstreams, stream_ids, nbytes, &ids_dev); if (rc) return rc;
+    unsigned mx = 0;
+    for (int k = 0; k < nstreams; k++) {
+        const int s = stream_ids ? stream_ids[k] : k;
+        if (nbytes[k] % 4) FAIL(NRSC5HIP_EINVAL, "chunk %d: nbytes %% 4 != 0", k);
+        if (e->wr_host[s] - e->base_host[s] + nbytes[k] / 4 > e->db.q15_cap)
+            FAIL(NRSC5HIP_EOVERFLOW, "stream %d: q15_capacity %lld too small for this batch", s, e->db.q15_cap);
+        if (nbytes[k] > mx) mx = nbytes[k];
+    }
+    launch_decimate_fm_cu8(e->tb, e->db, nstreams, ids_dev, dev_iq, stride_bytes, e->nbytes_dev, mx, e->main);
+    for (int k = 0; k < nstreams; k++) e->wr_host[stream_ids ? stream_ids[k] : k] += nbytes[k] / 4;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int nrsc5hip_batch_append_cs16(nrsc5hip_engine *e, int nstreams, const int *stream_ids,
+                                          const int16_t *dev_iq, long long stride_elems, const uint32_t *nelems)
+{
+    if (!e || !dev_iq || !nelems) FAIL(NRSC5HIP_EINVAL, "null argument");
+    const int *ids_dev; int rc = upload_ids(e, nstreams, stream_ids, nelems, &ids_dev); if (rc) return rc;
+    unsigned mx = 0;
+    for (int k = 0; k < nstreams; k++) {
+        const int s = stream_ids ? stream_ids[k] : k;
+        if (nelems[k] % 2) FAIL(NRSC5HIP_EINVAL, "chunk %d: odd cs16 length", k);
+        if (e->wr_host[s] - e->base_host[s] + nelems[k] / 2 > e->db.q15_cap)
+            FAIL(NRSC5HIP_EOVERFLOW, "stream %d: q15_capacity %lld too small for this batch", s, e->db.q15_cap);
+        if (nelems[k] > mx) mx = nelems[k];
+    }
+    launch_append_cs16(e->db, nstreams, ids_dev, dev_iq, stride_elems, e->nbytes_dev, mx, e->main);
+    for (int k = 0; k < nstreams; k++) e->wr_host[stream_ids ? stream_ids[k] : k] += nelems[k] / 2;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int nrsc5hip_batch_process(nrsc5hip_engine *e, int nstreams, const int *stream_ids, int max_steps, int *steps_done)
+{
+    if (!e) FAIL(NRSC5HIP_EINVAL, "null engine");
+    const int *ids_dev; int rc = upload_ids(e, nstreams, stream_ids, nullptr, &ids_dev); if (rc) return rc;
+    return run_steps(e, nstreams, ids_dev, max_steps > 0 ? max_steps : (1 << 30), e->cfg.p1_async ? 16 : 8, steps_done);
+}
+
+// ---- results ------------------------------------------------------------------------------------------------------
+static int fetch_nblocks(nrsc5hip_engine *e, int s, int *nblocks)
+{
+    HIPCHK(hipMemcpy(nblocks, (const char *)(e->db.state + s) + offsetof(StreamState, nblocks), sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int nrsc5hip_drain(nrsc5hip_engine *e, int stream, nrsc5hip_record *out, int max, int *n_out)
+{
+    int rc = check_stream(e, stream); if (rc) return rc;
+    if (!out || !n_out) FAIL(NRSC5HIP_EINVAL, "null argument");
+    HIPCHK(hipStreamSynchronize(e->main));
+    int nb = 0;
+    if ((rc = fetch_nblocks(e, stream, &nb))) return rc;
+    int avail = nb - e->drained[stream];
+    if (avail > e->db.rec_cap) FAIL(NRSC5HIP_EOVERFLOW, "stream %d: %d records overwrote the ring (capacity %d)", stream, avail, e->db.rec_cap);
+    int n = avail < max ? avail : max;
+    {   // at most two contiguous pieces of the ring
+        const int first = e->drained[stream] % e->db.rec_cap;
+        const int n1 = (first + n <= e->db.rec_cap) ? n : e->db.rec_cap - first;
+        const BlockRecord *ring = e->db.records + (size_t)stream * e->db.rec_cap;
+        if (n1 > 0) HIPCHK(hipMemcpy(out, ring + first, (size_t)n1 * sizeof(BlockRecord), hipMemcpyDeviceToHost));
+        if (n - n1 > 0) HIPCHK(hipMemcpy(out + n1, ring, (size_t)(n - n1) * sizeof(BlockRecord), hipMemcpyDeviceToHost));
+    }
+    e->drained[stream] += n;
+    *n_out = n;
+    return 0;
+}
+
+extern "C" int nrsc5hip_p1_frame_packed(nrsc5hip_engine *e, int stream, int slot, uint32_t *words)
+{
+    int rc = check_stream(e, stream); if (rc) return rc;
+    if (slot < 0 || slot >= e->db.p1_slots || !words) FAIL(NRSC5HIP_EINVAL, "bad slot/argument");
+    HIPCHK(hipStreamSynchronize(e->main));
+    HIPCHK(hipMemcpy(words, e->db.p1_ring + ((size_t)stream * e->db.p1_slots + slot) * P1_WORDS, P1_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" void nrsc5hip_unpack_bits(const uint32_t *words, int nbits, uint8_t *bits)
+{
+    for (int i = 0; i < nbits; i++) bits[i] = (words[i >> 5] >> (i & 31)) & 1u;
+}
+
+extern "C" int nrsc5hip_p1_frame_bits(nrsc5hip_engine *e, int stream, int slot, uint8_t *bits)
+{
+    std::vector<uint32_t> w(P1_WORDS);
+    int rc = nrsc5hip_p1_frame_packed(e, stream, slot, w.data()); if (rc) return rc;
+    nrsc5hip_unpack_bits(w.data(), P1_LEN, bits);
+    return 0;
+}
+
+extern "C" int nrsc5hip_batch_fetch(nrsc5hip_engine *e, int nstreams, const int *stream_ids, nrsc5hip_record *records,
+                                    int max_records, int *counts, uint32_t *frames)
+{
+    if (!e || !records || !counts) FAIL(NRSC5HIP_EINVAL, "null argument");
+    HIPCHK(hipStreamSynchronize(e->main));
+    std::vector<StreamState> *dummy = nullptr; (void)dummy;
+    for (int k = 0; k < nstreams; k++) {
+        const int s = stream_ids ? stream_ids[k] : k;
+        int rc = check_stream(e, s); if (rc) return rc;
+        int n = 0;
+        rc = nrsc5hip_drain(e, s, records + (size_t)k * max_records, max_records, &n); if (rc) return rc;
+        counts[k] = n;
+        if (frames)
+            HIPCHK(hipMemcpy(frames + (size_t)k * e->db.p1_slots * P1_WORDS, e->db.p1_ring + (size_t)s * e->db.p1_slots * P1_WORDS,
+                             (size_t)e->db.p1_slots * P1_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
+// ---- stage-level entry points ----------------------------------------------------------------------------------------
+extern "C" int nrsc5hip_stage_halfband_fm_cu8(nrsc5hip_engine *e, const uint8_t *iq, uint32_t nbytes, int16_t *out)
+{
+    // runs the production K1 kernel on stream 0 of a scratch state: requires a freshly reset stream 0
+    int rc = check_stream(e, 0); if (rc) return rc;
+    if (nbytes % 4 || nbytes > e->stage_bytes || nbytes / 4 > e->db.q15_cap) FAIL(NRSC5HIP_EINVAL, "bad length");
+    if ((rc = nrsc5hip_stream_reset(e, 0))) return rc;
+    const int s = 0; const unsigned count = nbytes;
+    HIPCHK(hipMemcpy(e->stage_dev, iq, nbytes, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->ids_dev, &s, sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(e->nbytes_dev, &count, sizeof(unsigned), hipMemcpyHostToDevice));
+    launch_decimate_fm_cu8(e->tb, e->db, 1, e->ids_dev, e->stage_dev, 0, e->nbytes_dev, count, e->main);
+    HIPCHK(hipStreamSynchronize(e->main));
+    HIPCHK(hipMemcpy(out, e->db.q15, (size_t)(nbytes / 4) * sizeof(c16), hipMemcpyDeviceToHost));
+    return nrsc5hip_stream_reset(e, 0);
+}
+
+extern "C" int nrsc5hip_stage_fft2048(nrsc5hip_engine *e, const float *in, float *out, int n)
+{
+    if (!e || !in || !out || n < 1) FAIL(NRSC5HIP_EINVAL, "bad argument");
+    float2 *din = nullptr, *dout = nullptr;
+    const size_t bytes = (size_t)n * FFT_N * sizeof(float2);
+    HIPCHK(hipMalloc((void **)&din, bytes));
+    HIPCHK(hipMalloc((void **)&dout, bytes));
+    HIPCHK(hipMemcpy(din, in, bytes, hipMemcpyHostToDevice));
+    launch_fft2048(e->tb, din, dout, n, e->main);
+    HIPCHK(hipStreamSynchronize(e->main));
+    HIPCHK(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
+    hipFree(din); hipFree(dout);
+    return 0;
+}
+
+extern "C" int nrsc5hip_stage_viterbi_k7(nrsc5hip_engine *e, const int8_t *soft, int len, int nframes, uint8_t *bits)
+{
+    if (!e || !soft || !bits || len < 64 || nframes < 1) FAIL(NRSC5HIP_EINVAL, "bad argument");
+    int8_t *dsoft = nullptr; unsigned long long *ddec = nullptr; uint32_t *dout = nullptr;
+    const int words = (len + 31) / 32;
+    HIPCHK(hipMalloc((void **)&dsoft, (size_t)nframes * 3 * len));
+    HIPCHK(hipMalloc((void **)&ddec, (size_t)nframes * (len + 64) * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&dout, (size_t)nframes * words * sizeof(uint32_t)));
+    HIPCHK(hipMemcpy(dsoft, soft, (size_t)nframes * 3 * len, hipMemcpyHostToDevice));
+    launch_viterbi_frames(dsoft, len, nframes, ddec, dout, e->main);
+    HIPCHK(hipStreamSynchronize(e->main));
+    std::vector<uint32_t> w((size_t)nframes * words);
+    HIPCHK(hipMemcpy(w.data(), dout, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int f = 0; f < nframes; f++) nrsc5hip_unpack_bits(w.data() + (size_t)f * words, len, bits + (size_t)f * len);
+    hipFree(dsoft); hipFree(ddec); hipFree(dout);
+    return 0;
+}
+
+extern "C" int nrsc5hip_debug_fetch(nrsc5hip_engine *e, int stream, int8_t *pm, float *bins)
+{
+    int rc = check_stream(e, stream); if (rc) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    if (pm) HIPCHK(hipMemcpy(pm, e->db.pm + (size_t)stream * PM_FRAME, PM_FRAME, hipMemcpyDeviceToHost));
+    if (bins) HIPCHK(hipMemcpy(bins, e->db.bins + (size_t)stream * NSYM * LIVE_N, (size_t)NSYM * LIVE_N * sizeof(float2), hipMemcpyDeviceToHost));
+    return 0;
+}

@@ -1,0 +1,102 @@
+// L1 FEC stage for gfx950: P1 de-interleave (K6), tail-biting Viterbi (K7), re-encode BER and
+// descrambler (K8).  Replaces decode.c:296-322,451-461 and conv_dec.c for the P1 logical channel.
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+#include "viterbi_wave.h"
+
+namespace nrsc5 {
+
+__device__ inline int stream_of(const int *ids, int idx) { return ids ? ids[idx] : idx; }
+
+// ---- K6: P1 gather + depuncture ---------------------------------------------------------------
+// coded bit i of the frame sits at matrix cell p1_gather[i]; the Viterbi input carries a zero after
+// every 5th coded bit (puncture pattern [1,1,1,1,1,0], decode.c:318-319): position i + i/5.
+// One thread produces one 6-byte group (5 gathers + the erased slot).
+__global__ __launch_bounds__(256) void k_p1_deint(DevTables tb, DevBuffers db, const int *ids, int parity)
+{
+    const int s = stream_of(ids, blockIdx.y);
+    const StreamState &st = db.state[s];
+    if (!st.p1_pending[parity]) return;
+    const int8_t *pm = db.pm + (size_t)s * PM_FRAME;
+    int8_t *out = db.coded + ((size_t)s * 2 + parity) * P1_DEPUNCT;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;       // group index
+    if (g >= P1_CODED / 5) return;
+    const int32_t *idx = tb.p1_gather + 5 * g;
+    int8_t v[6];
+#pragma unroll
+    for (int k = 0; k < 5; k++) v[k] = pm[idx[k]];
+    v[5] = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) out[6 * g + k] = v[k];
+}
+
+// ---- K8 helpers ---------------------------------------------------------------------------------
+// Re-encode the decoded (still scrambled) bits and count sign disagreements with the received soft
+// bits at unpunctured positions (decode.c:234-265).  64 lanes, bit i handled by lane i%64.
+__device__ inline int bit_errors_k7_wave(const int8_t *coded, const uint32_t *bits, int len)
+{
+    const int lane = threadIdx.x & 63;
+    int errors = 0;
+    for (int i = lane; i < len; i += 64) {
+        unsigned r = 0;                                        // r bit 6 = bits[i], bit 6-k = bits[i-k]
+#pragma unroll
+        for (int k = 0; k < 7; k++) {
+            int q = i - k; if (q < 0) q += len;                // tail biting
+            r |= ((bits[q >> 5] >> (q & 31)) & 1u) << (6 - k);
+        }
+        const int j = 3 * i;
+        const int p0 = __popc(r & 0133u) & 1, p1 = __popc(r & 0171u) & 1, p2 = __popc(r & 0165u) & 1;
+        if ((j % 6) != 5 && ((coded[j] > 0) != p0)) errors++;
+        if (((j + 1) % 6) != 5 && ((coded[j + 1] > 0) != p1)) errors++;
+        if (((j + 2) % 6) != 5 && ((coded[j + 2] > 0) != p2)) errors++;
+    }
+    return wave_sum_i32(errors);
+}
+
+// ---- K7: one wave per pending P1 frame ------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_p1_viterbi(DevTables tb, DevBuffers db, const int *ids, int parity)
+{
+    const int s = stream_of(ids, blockIdx.x);
+    StreamState &st = db.state[s];
+    if (!st.p1_pending[parity]) return;                        // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const int8_t *coded = db.coded + ((size_t)s * 2 + parity) * P1_DEPUNCT;
+    unsigned long long *dec = db.dec + (size_t)s * (P1_LEN + 64);
+    uint32_t *out = db.p1_ring + ((size_t)s * db.p1_slots + st.p1_slot[parity]) * P1_WORDS;
+
+    viterbi_k7_wave(coded, P1_LEN, dec, out);
+    __threadfence_block();
+    __syncthreads();                                           // out[] written by lane 0, read by all
+    const int errors = bit_errors_k7_wave(coded, out, P1_LEN);
+    __syncthreads();
+    for (int w = lane; w < P1_WORDS; w += 64) out[w] ^= tb.scr_p1[w];       // descramble
+    if (lane == 0) {
+        db.records[(size_t)s * db.rec_cap + st.p1_record[parity]].ber = (float)errors / P1_CODED;  // decode.c:458
+        st.p1_pending[parity] = 0;
+    }
+}
+
+void launch_p1_deint(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st)
+{
+    dim3 grid((P1_CODED / 5 + 255) / 256, nstreams);
+    hipLaunchKernelGGL(k_p1_deint, grid, dim3(256), 0, st, tb, db, stream_ids, parity);
+}
+
+void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_p1_viterbi, dim3(nstreams), dim3(64), 0, st, tb, db, stream_ids, parity);
+}
+
+// ---- stage-level entry: decode `nframes` independent frames of equal length (parity tests) ----------
+__global__ __launch_bounds__(64) void k_viterbi_frames(const int8_t *coded, int len, unsigned long long *dec, uint32_t *out)
+{
+    const int f = blockIdx.x;
+    viterbi_k7_wave(coded + (size_t)f * 3 * len, len, dec + (size_t)f * (len + 64), out + (size_t)f * ((len + 31) / 32));
+}
+
+void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_viterbi_frames, dim3(nframes), dim3(64), 0, st, coded, len, dec, out);
+}
+
+}  // namespace nrsc5

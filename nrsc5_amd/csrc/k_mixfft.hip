@@ -1,0 +1,197 @@
+// K3 + K4 -- OFDM symbol extraction for gfx950: timing pick, Q15 -> float (conjugated), NCO mix,
+// raised-cosine cyclic-prefix fold (acquire.c:160-168, 237-252) and the 2048-point forward FFT that
+// the reference delegates to fftw3f (acquire.c:254, 315-320) + fftshift (defines.h:123), fused.
+// Only the 2 x 267 bins sync.c:785-789 keeps are written back: 8.6 KB in, 4.3 KB out per symbol.
+//
+// One workgroup (128 lanes = 2 waves) per (stream, symbol).  FFT 2048 = 8 x 16 x 16, each lane
+// carries 16 complex points in registers; two LDS exchanges (17.4 KB, padded pitch 272 / 17 so
+// every ds_read/ds_write of a pass is bank-conflict-free).
+//
+// The reference advances the NCO with a sequential complex recurrence (69120 dependent steps per
+// block, acquire.c:250).  Here the phase of sample j is evaluated in closed form,
+// theta_sym + j * dtheta, in double precision: lanes are independent and the result is within
+// ~1e-5 rad of the recurrence (whose own rounding drift is of that order).
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+
+namespace nrsc5 {
+
+__device__ inline int stream_of(const int *ids, int idx) { return ids ? ids[idx] : idx; }
+
+__device__ inline float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ inline float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ inline float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ inline float2 mul_mj(float2 a) { return make_float2(a.y, -a.x); }      // a * (-j)
+
+// forward 4-point DFT in place, natural order out
+__device__ inline void dft4(float2 &a0, float2 &a1, float2 &a2, float2 &a3)
+{
+    const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mj(csub(a1, a3));
+    a0 = cadd(t0, t2); a1 = cadd(t1, t3); a2 = csub(t0, t2); a3 = csub(t1, t3);
+}
+
+// forward 8-point DFT, natural order in v[0..7] -> natural order out
+__device__ inline void dft8(float2 *v)
+{
+    float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    float2 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    dft4(e0, e1, e2, e3);
+    dft4(o0, o1, o2, o3);
+    const float c = 0.70710678118654752440f;
+    o1 = make_float2(c * (o1.x + o1.y), c * (o1.y - o1.x));          // * W8^1 = c(1 - j)
+    o2 = mul_mj(o2);                                                  // * W8^2 = -j
+    o3 = make_float2(c * (o3.y - o3.x), -c * (o3.x + o3.y));         // * W8^3 = -c(1 + j)
+    v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
+    v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
+    v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
+    v[3] = cadd(e3, o3); v[7] = csub(e3, o3);
+}
+
+// forward 16-point DFT in place; output X[a + 4b] lands in v[4a + b]
+__device__ inline void dft16(float2 *v)
+{
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) dft4(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);   // v[4k1+n2] = Y[k1][n2]
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, c2 = 0.70710678118654752440f;
+    // W16^m, m = n2*k1
+    v[5]  = cmul(v[5],  make_float2(c1, -s1));    // m=1
+    v[6]  = cmul(v[6],  make_float2(c2, -c2));    // m=2
+    v[7]  = cmul(v[7],  make_float2(s1, -c1));    // m=3
+    v[9]  = cmul(v[9],  make_float2(c2, -c2));    // m=2
+    v[10] = mul_mj(v[10]);                        // m=4
+    v[11] = cmul(v[11], make_float2(-c2, -c2));   // m=6
+    v[13] = cmul(v[13], make_float2(s1, -c1));    // m=3
+    v[14] = cmul(v[14], make_float2(-c2, -c2));   // m=6
+    v[15] = cmul(v[15], make_float2(-c1, s1));    // m=9
+#pragma unroll
+    for (int k1 = 0; k1 < 4; k1++) dft4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+}
+
+constexpr int PITCH_A = 272;   // floats2 per k1 row (256 + 16: rows of one half-wave land on disjoint banks)
+constexpr int PITCH_B = 17;    // per r2 row inside a k1 row of the second layout (16 + 1)
+
+// 2048-point forward FFT by a 128-lane workgroup.
+//  in : x[0..7]  = samples r + 256*n1 for r = tid,       n1 = 0..7
+//       x[8..15] = samples r + 256*n1 for r = tid + 128
+//  out: x[4a+b]  = bin  k1 + 8*k2 + 128*(a + 4b)   with k1 = tid >> 4, k2 = tid & 15
+__device__ inline void fft2048_wg(float2 *x, float2 *lds, const float2 *tw)
+{
+    const int tid = threadIdx.x;
+    // stage A: two radix-8 butterflies, twiddle W2048^(k1*r), scatter to [k1][r]
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int r = tid + 128 * h;
+        dft8(x + 8 * h);
+#pragma unroll
+        for (int k1 = 0; k1 < 8; k1++) {
+            float2 v = x[8 * h + k1];
+            if (k1) v = cmul(v, tw[(k1 * r) & 2047]);
+            lds[k1 * PITCH_A + r] = v;
+        }
+    }
+    __syncthreads();
+    // stage B: lane (k1, r2): 16-point DFT over r1 of [k1][r2 + 16 r1], twiddle W256^(r2*k2)
+    {
+        const int k1 = tid >> 4, r2 = tid & 15;
+#pragma unroll
+        for (int r1 = 0; r1 < 16; r1++) x[r1] = lds[k1 * PITCH_A + r2 + 16 * r1];
+        dft16(x);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const int k2 = (i >> 2) + 4 * (i & 3);
+            float2 v = x[i];
+            if (r2) v = cmul(v, tw[(8 * r2 * k2) & 2047]);
+            lds[k1 * PITCH_A + r2 * PITCH_B + k2] = v;
+        }
+    }
+    __syncthreads();
+    // stage C: lane (k1, k2): 16-point DFT over r2
+    {
+        const int k1 = tid >> 4, k2 = tid & 15;
+#pragma unroll
+        for (int r2 = 0; r2 < 16; r2++) x[r2] = lds[k1 * PITCH_A + r2 * PITCH_B + k2];
+        dft16(x);
+    }
+}
+
+__global__ __launch_bounds__(128) void k_mixfft(DevTables tb, DevBuffers db, const int *ids)
+{
+    const int s = stream_of(ids, blockIdx.y);
+    const StreamState &st = db.state[s];
+    if (!st.active) return;                                    // block-uniform
+    __shared__ float2 lds[8 * PITCH_A];
+    const int sym = blockIdx.x, tid = threadIdx.x;
+    const c16 *win = db.q15 + (size_t)s * db.q15_cap + (st.rd - st.base) + sym * SYM_N + st.samperr_cur;
+    const double dth = st.dtheta;
+    const double th0 = st.theta + (double)sym * SYM_N * dth;
+
+    float2 x[16];
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int n1 = 0; n1 < 8; n1++) {
+            const int j = tid + 128 * h + 256 * n1;
+            const c16 q = win[j];
+            double a = th0 + (double)j * dth;
+            a -= 2 * M_PI * rint(a * (1.0 / (2 * M_PI)));
+            float sn, cs; sincosf((float)a, &sn, &cs);
+            const float2 v = make_float2((float)q.r / 32767.0f, (float)q.i / -32767.0f);     // cq15_to_cf_conj
+            float2 m = cmul(make_float2(cs, sn), v);
+            if (j < CP_N) { const float w = tb.shape[j]; m.x *= w; m.y *= w; }
+            x[8 * h + n1] = m;
+        }
+    if (tid < CP_N) {                                          // fold the cyclic extension back (acquire.c:246-247)
+        const int j = FFT_N + tid;
+        const c16 q = win[j];
+        double a = th0 + (double)j * dth;
+        a -= 2 * M_PI * rint(a * (1.0 / (2 * M_PI)));
+        float sn, cs; sincosf((float)a, &sn, &cs);
+        const float2 v = make_float2((float)q.r / 32767.0f, (float)q.i / -32767.0f);
+        float2 m = cmul(make_float2(cs, sn), v);
+        const float w = tb.shape[j];
+        x[0].x += w * m.x; x[0].y += w * m.y;
+    }
+
+    fft2048_wg(x, lds, tb.twiddle);
+
+    float2 *out = db.bins + ((size_t)s * NSYM + sym) * LIVE_N;
+    const int kbase = (tid >> 4) + 8 * (tid & 15);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int k3 = (i >> 2) + 4 * (i & 3);
+        const int b = (kbase + 128 * k3 + FFT_N / 2) & (FFT_N - 1);       // fftshift: bin 1024 = DC
+        if (b >= LB0 && b < LB0 + LIVE_HALF) out[b - LB0] = x[i];
+        else if (b >= UB0 && b <= UB1) out[LIVE_HALF + (b - UB0)] = x[i];
+    }
+}
+
+void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_mixfft, dim3(NSYM, nstreams), dim3(128), 0, st, tb, db, stream_ids);
+}
+
+// ---- stage-level entry: plain 2048-point FFTs, natural order in and out (parity tests) ----------------
+__global__ __launch_bounds__(128) void k_fft2048(DevTables tb, const float2 *in, float2 *out)
+{
+    __shared__ float2 lds[8 * PITCH_A];
+    const int tid = threadIdx.x;
+    const float2 *src = in + (size_t)blockIdx.x * FFT_N;
+    float2 *dst = out + (size_t)blockIdx.x * FFT_N;
+    float2 x[16];
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int n1 = 0; n1 < 8; n1++) x[8 * h + n1] = src[tid + 128 * h + 256 * n1];
+    fft2048_wg(x, lds, tb.twiddle);
+    const int kbase = (tid >> 4) + 8 * (tid & 15);
+#pragma unroll
+    for (int i = 0; i < 16; i++) dst[kbase + 128 * ((i >> 2) + 4 * (i & 3))] = x[i];
+}
+
+void launch_fft2048(const DevTables &tb, const float2 *in, float2 *out, int nffts, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_fft2048, dim3(nffts), dim3(128), 0, st, tb, in, out);
+}
+
+}  // namespace nrsc5

@@ -1,0 +1,419 @@
+// K5 (+ PIDS part of K6/K7/K8) -- per-block synchronisation, equalisation and soft demodulation for
+// gfx950.  One workgroup per stream and block; replaces sync_process_fm (sync.c:339-610), its helpers
+// adjust_ref / decode_ref_fm / find_ref_fm / detect_cfo / adjust_data (sync.c:90-337), sync_adjust
+// (sync.c:769-777), decode_push_pm + decode_process_pids (decode.c:378-391,463-472) and the tail of
+// acquire_process (acquire.c:259-262).
+//
+// Parallel axes inside the workgroup: lanes = reference carriers for the Costas loops (sequential in
+// the 32 symbols by construction), lanes = (partition, symbol, carrier) cells for equalisation / MER /
+// soft bits, lanes = live bins for the brute-force CFO search, one wave for the 144-step PIDS trellis.
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+#include "wave_ops.h"
+#include "viterbi_wave.h"
+
+namespace nrsc5 {
+
+__device__ inline int stream_of(const int *ids, int idx) { return ids ? ids[idx] : idx; }
+
+constexpr int NREF_MAX = 30;          // 15 per sideband (14 partitions + 1)
+constexpr int CFO_LO = -2 * PW, CFO_HI = 2 * PW;   // candidates -38..37 (sync.c:294)
+
+// PSMI -> partitions per sideband (sync.c:29-35, 343-358)
+__device__ inline int partitions_for_psmi(int psmi)
+{
+    const int m6 = psmi & 63, low = m6 & 15;
+    // compatibility_mode[]: 0,1,2,3,1,5,6,5,6,1,2,11,1,5,6,5 then the same 16 entries repeating with [16k] = 6;
+    // one nibble per entry
+    constexpr unsigned long long TAB16 = 0x5651B21656513210ull;
+    int mode = (int)((TAB16 >> (4 * low)) & 15ull);
+    if (low == 0 && m6 != 0) mode = 6;
+    switch (mode) {
+    case 2: return 11;
+    case 3: return 12;
+    case 5: case 6: case 11: return 14;
+    default: return 10;
+    }
+}
+
+__device__ inline int ref_bin(int r) { const int i = r >> 1; return (r & 1) ? UB1 - PW * i : LB0 + PW * i; }
+
+// sync word used to resolve the pi ambiguity (sync.c:96-99): +1 / -1 masks over the 32 symbols
+constexpr uint32_t PAT_POS = (1u << 1) | (1u << 5) | (1u << 6) | (1u << 8) | (1u << 21);
+constexpr uint32_t PAT_NEG = (1u << 0) | (1u << 2) | (1u << 3) | (1u << 4) | (1u << 9) | (1u << 13) | (1u << 14) | (1u << 20) | (1u << 22) | (1u << 31);
+// needle of decode_ref_fm / find_ref_fm (sync.c:171-174): fixed positions and their values (rsid bits added per ref)
+constexpr uint32_t NEEDLE_MASK = 0x7fu | (0xfu << 8) | (3u << 13) | (7u << 20) | (1u << 31);
+constexpr uint32_t NEEDLE_VAL0 = (1u << 1) | (1u << 5) | (1u << 6) | (1u << 8) | (1u << 21);
+__device__ inline uint32_t needle_val(unsigned rsid) { return NEEDLE_VAL0 | ((rsid >> 1) << 10) | ((((rsid >> 1) ^ rsid) & 1u) << 11); }
+
+struct LoopGains { float alpha, beta; };
+__device__ inline LoopGains loop_gains()                      // sync.c:832-841
+{
+    const float loop_bw = 0.05f, damping = 0.70710678f;
+    const float denom = 1 + (2 * damping * loop_bw) + (loop_bw * loop_bw);
+    LoopGains g; g.alpha = (4 * damping * loop_bw) / denom; g.beta = (4 * loop_bw * loop_bw) / denom;
+    return g;
+}
+
+// One reference carrier through its second-order Costas loop for the 32 symbols of a block
+// (sync.c:90-130).  z(n) is fetched through `src` with stride `stride`; optionally the derotated
+// values / loop phases are stored.  Returns the sign bits of the derotated real parts (bit n = re > 0).
+template <bool STORE>
+__device__ inline uint32_t costas_block(const float2 *src, int stride, float &freq, float &phase, int cfo,
+                                        LoopGains g, float2 *zout, float *phout)
+{
+    const float cfo_freq = (float)(2 * M_PI * cfo * CP_N / FFT_N);
+    uint32_t pos = 0, neg = 0;
+    float x = 0.0f;
+    for (int n = 0; n < NSYM; n++) {
+        const float2 z = src[n * stride];
+        float s2, c2; sincosf(2 * phase, &s2, &c2);
+        const float2 w = make_float2(z.x * z.x - z.y * z.y, z.x * z.y + z.y * z.x);
+        const float ur = w.x * c2 + w.y * s2, ui = w.y * c2 - w.x * s2;         // w * e^{-2i phase}
+        const float error = atan2f(ui, ur) * 0.5f;
+        float s1, c1; sincosf(phase, &s1, &c1);
+        const float2 zr = make_float2(z.x * c1 + z.y * s1, z.y * c1 - z.x * s1);   // z * e^{-i phase}
+        if (STORE) { zout[n] = zr; phout[n] = phase; }
+        if (zr.x > 0) pos |= 1u << n;
+        if (zr.x < 0) neg |= 1u << n;
+        const float sgn = ((PAT_POS >> n) & 1u) ? 1.0f : (((PAT_NEG >> n) & 1u) ? -1.0f : 0.0f);
+        x += zr.x * sgn;
+        freq += g.beta * error;
+        if (freq > 0.5f) freq = 0.5f;
+        if (freq < -0.5f) freq = -0.5f;
+        phase += freq + cfo_freq + (g.alpha * error);
+        if ((double)phase > M_PI) phase = (float)((double)phase - 2 * M_PI);
+        if ((double)phase < -M_PI) phase = (float)((double)phase + 2 * M_PI);
+    }
+    if (x < 0) {                                               // off by pi: flip (sync.c:119-129)
+        if (STORE) for (int n = 0; n < NSYM; n++) { phout[n] = (float)((double)phout[n] + M_PI); zout[n] = make_float2(-zout[n].x, -zout[n].y); }
+        phase = (float)((double)phase + M_PI);
+        pos = neg;                                             // a zero real part stays "not positive" after the flip
+    }
+    return pos;
+}
+
+// find_ref_fm (sync.c:188-207): smallest cyclic shift at which the needle matches, trying the sign
+// pattern and then its complement.
+__device__ inline int needle_search(uint32_t d, unsigned rsid)
+{
+    const uint32_t val = needle_val(rsid);
+    for (int n = 0; n < NSYM; n++) { const uint32_t rot = (d >> n) | (n ? (d << (32 - n)) : 0u); if ((rot & NEEDLE_MASK) == val) return n; }
+    d = ~d;
+    for (int n = 0; n < NSYM; n++) { const uint32_t rot = (d >> n) | (n ? (d << (32 - n)) : 0u); if ((rot & NEEDLE_MASK) == val) return n; }
+    return -1;
+}
+
+__device__ inline float half_turn_diff(float a, float b)    // phase_diff, sync.c:284-290
+{
+    float d = a - b;
+    while ((double)d > M_PI / 2) d = (float)((double)d - M_PI);
+    while ((double)d < -M_PI / 2) d = (float)((double)d + M_PI);
+    return d;
+}
+
+__device__ inline float2 cdiv(float2 a, float2 b)
+{
+    const float den = b.x * b.x + b.y * b.y;
+    return make_float2((a.x * b.x + a.y * b.y) / den, (a.y * b.x - a.x * b.y) / den);
+}
+
+__device__ inline int soft_bit(float x, float mult)          // demod, sync.c:69-73
+{
+    const float c = fmaxf(fminf(x, 1.0f), -1.0f);
+    return (int)lroundf(c * mult);
+}
+
+__global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity)
+{
+    const int s = stream_of(ids, blockIdx.x);
+    StreamState &st = db.state[s];
+    if (!st.active) return;                                    // block-uniform
+    const int tid = threadIdx.x;
+
+    __shared__ float2 refz[NREF_MAX][NSYM];                   // derotated reference carriers
+    __shared__ float refph[NREF_MAX][NSYM];                   // loop phase per symbol (phases[][] of the reference)
+    __shared__ float2 refcs[NREF_MAX][NSYM];                  // e^{+i refph}
+    __shared__ float smag[NREF_MAX];
+    __shared__ int ref_ok[NREF_MAX], ref_bc[NREF_MAX], ref_psmi[NREF_MAX];
+    __shared__ int8_t cfo_offs[CFO_HI - CFO_LO][22];
+    __shared__ int sh_i[8];
+    __shared__ float sh_f[8];
+    __shared__ double red[2][4];
+    __shared__ int8_t pids_coded[3 * PIDS_LEN];
+    __shared__ unsigned long long pids_dec[PIDS_LEN + 64];
+    __shared__ uint32_t pids_out[4];
+
+    float2 *bins = db.bins + (size_t)s * NSYM * LIVE_N;       // [sym][live]
+    BlockRecord &rec = db.records[(size_t)s * db.rec_cap + (st.nblocks % db.rec_cap)];
+    const LoopGains g = loop_gains();
+    const int samperr = st.samperr_cur;
+    const int ppb = partitions_for_psmi(st.psmi);
+    const int nref = 2 * (ppb + 1);
+
+    // ---- sync_adjust (sync.c:769-777): timing pick moved by adj samples -> rotate every loop phase
+    {
+        const int adj = SYM_N / 2 - samperr;
+        for (int l = tid; l < LIVE_N; l += 256) {
+            const int b = live_to_bin(l);
+            st.costas_phase[l] = (float)((double)st.costas_phase[l] - (adj * (b - FFT_N / 2)) * 2 * M_PI / FFT_N);
+        }
+    }
+    __syncthreads();
+
+    // ---- Costas loops of the active reference carriers (sync.c:360-364)
+    if (tid < nref) {
+        const int l = bin_to_live(ref_bin(tid));
+        float f = st.costas_freq[l], p = st.costas_phase[l];
+        costas_block<true>(bins + l, LIVE_N, f, p, 0, g, refz[tid], refph[tid]);
+        st.costas_freq[l] = f; st.costas_phase[l] = p;
+    }
+    __syncthreads();
+
+    // ---- COARSE: try to lock (sync.c:366-423)
+    if (st.sync_state == SYNC_COARSE) {
+        if (tid < nref) {
+            // decode_ref_fm (sync.c:169-186)
+            uint32_t d = 0;
+            for (int n = 0; n < NSYM; n++) if (refz[tid][n].x > 0) d |= 1u << n;
+            const unsigned rsid = (30 - (tid >> 1)) & 3;
+            const int ok = ((d & NEEDLE_MASK) == needle_val(rsid));
+            const uint32_t dd = d ^ (d << 1);                  // DBPSK: data[n] = bit[n] ^ bit[n-1]
+            ref_ok[tid] = ok;
+            ref_bc[tid] = (int)((((dd >> 16) & 1) << 3) | (((dd >> 17) & 1) << 2) | (((dd >> 18) & 1) << 1) | ((dd >> 19) & 1));
+            ref_psmi[tid] = (int)((((dd >> 25) & 1) << 5) | (((dd >> 26) & 1) << 4) | (((dd >> 27) & 1) << 3) | (((dd >> 28) & 1) << 2) | (((dd >> 29) & 1) << 1) | ((dd >> 30) & 1));
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int good = 0, seen_bc[16], seen_psmi[64];
+            for (int k = 0; k < 16; k++) seen_bc[k] = 0;
+            for (int k = 0; k < 64; k++) seen_psmi[k] = 0;
+            for (int r = 0; r < nref; r++) if (ref_ok[r]) { good++; seen_bc[ref_bc[r]]++; seen_psmi[ref_psmi[r]]++; }
+            int action = 0;                                    // 0: none, 1: locked, 2: run CFO search
+            if (good >= 4) {
+                int maj_bc = -1, maj_psmi = -1;
+                for (int v = 0; v < 16; v++) if (seen_bc[v] > good / 2) maj_bc = v;
+                for (int v = 0; v < 16; v++) if (seen_psmi[v] > good / 2) maj_psmi = v;     // 0..15 only (sync.c:396)
+                if (maj_bc >= 0 && maj_psmi >= 0) {
+                    st.bc = maj_bc; st.psmi = maj_psmi;
+                    // input_set_sync_state(FINE): EVENT_SYNC payload (input.c:179-185)
+                    rec.freq_offset = (float)(((double)st.prev_angle - 2 * M_PI * st.cfo) * 744187.5 / (2 * M_PI * FFT_N));
+                    rec.flags |= REC_TO_FINE;
+                    st.sync_state = SYNC_FINE;
+                    st.started_pm = 0;                         // decode_reset (decode.c:563-572)
+                    action = 1;
+                }
+            } else if (st.cfo_wait == 0) {
+                action = 2;
+            } else {
+                st.cfo_wait--;
+            }
+            sh_i[0] = action;
+        }
+        __syncthreads();
+        if (sh_i[0] == 2) {
+            // ---- detect_cfo (sync.c:292-337): every candidate offset x every reference position.
+            // Lane = live bin; a bin is visited by at most 11 (cfo, i) pairs, in ascending cfo order,
+            // and each visit advances that bin's loop state exactly as adjust_ref does.
+            for (int k = tid; k < (CFO_HI - CFO_LO) * 22; k += 256) (&cfo_offs[0][0])[k] = -1;
+            __syncthreads();
+            float snap_f[3][11], snap_p[3][11];
+            int snap_cfo[3][11], snap_n[3];
+            for (int pass = 0; pass < 3; pass++) {
+                const int l = tid + 256 * pass;
+                snap_n[pass] = 0;
+                if (l >= LIVE_N) continue;
+                const int b = live_to_bin(l);
+                const bool lower = l < LIVE_HALF;
+                float f = st.costas_freq[l], p = st.costas_phase[l];
+                // is this bin one of the already-derotated active references?
+                int rslot = -1;
+                if (lower) { if ((b - LB0) % PW == 0 && (b - LB0) / PW <= ppb) rslot = 2 * ((b - LB0) / PW); }
+                else { if ((UB1 - b) % PW == 0 && (UB1 - b) / PW <= ppb) rslot = 2 * ((UB1 - b) / PW) + 1; }
+                for (int q = 0; q <= PM_PART; q++) {
+                    const int i = lower ? (PM_PART - q) : q;   // ascending cfo
+                    const int cfo = lower ? (b - LB0 - PW * i) : (b - UB1 + PW * i);
+                    if (cfo < CFO_LO || cfo >= CFO_HI) continue;
+                    uint32_t d;
+                    if (rslot >= 0) d = costas_block<false>(&refz[rslot][0], 1, f, p, cfo, g, nullptr, nullptr);
+                    else d = costas_block<false>(bins + l, LIVE_N, f, p, cfo, g, nullptr, nullptr);
+                    cfo_offs[cfo - CFO_LO][2 * i + (lower ? 0 : 1)] = (int8_t)needle_search(d, (30 - i) & 3);
+                    const int k = snap_n[pass]++;
+                    snap_f[pass][k] = f; snap_p[pass][k] = p; snap_cfo[pass][k] = cfo;
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int found = 0x7fffffff;
+                for (int c = 0; c < CFO_HI - CFO_LO && found == 0x7fffffff; c++) {
+                    int count[NSYM];
+                    for (int k = 0; k < NSYM; k++) count[k] = 0;
+                    for (int r = 0; r < 22; r++) if (cfo_offs[c][r] >= 0) count[cfo_offs[c][r]]++;
+                    int best = -1, best_count = 0;
+                    for (int k = 0; k < NSYM; k++) if (count[k] > best_count) { best = k; best_count = count[k]; }
+                    if (best >= 0 && best_count >= 3) {
+                        st.keep_extra = ((NSYM - best) % NSYM) * SYM_N;      // acquire_keep_extra
+                        st.cfo += c + CFO_LO;                                 // acquire_cfo_adjust
+                        st.cfo_wait = 8;
+                        found = c + CFO_LO;
+                    }
+                }
+                sh_i[1] = found;
+            }
+            __syncthreads();
+            const int last_cfo = sh_i[1];                      // visits with cfo <= last_cfo happened
+            for (int pass = 0; pass < 3; pass++) {
+                const int l = tid + 256 * pass;
+                if (l >= LIVE_N) continue;
+                int k = snap_n[pass] - 1;
+                while (k >= 0 && snap_cfo[pass][k] > last_cfo) k--;
+                if (k >= 0) { st.costas_freq[l] = snap_f[pass][k]; st.costas_phase[l] = snap_p[pass][k]; }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- FINE: equalise, measure, demodulate (sync.c:425-609)
+    if (st.sync_state == SYNC_FINE) {
+        const int bc = st.bc;
+        for (int k = tid; k < nref * NSYM; k += 256) {
+            const int r = k / NSYM, n = k % NSYM;
+            float sn, cs; sincosf(refph[r][n], &sn, &cs);
+            refcs[r][n] = make_float2(cs, sn);
+        }
+        if (tid < nref) {                                      // calc_smag (sync.c:254-261)
+            float sum = 0.0f;
+            for (int n = 0; n < NSYM; n++) sum += fabsf(refz[tid][n].x);
+            smag[tid] = sum / NSYM;
+        }
+        __syncthreads();
+
+        if (tid == 0) {
+            // timing error from the phase slope across each partition, residual CFO from the loop
+            // frequencies (sync.c:426-463); same summation order as the reference
+            float se = 0.0f, angle = 0.0f, sum_xy = 0.0f, sum_x2 = 0.0f;
+            for (int i = 0; i < ppb; i++) {
+                se += half_turn_diff(refph[2 * i][0], refph[2 * (i + 1)][0]);
+                se += half_turn_diff(refph[2 * (i + 1) + 1][0], refph[2 * i + 1][0]);
+            }
+            se = (float)(se / (ppb * 2) * FFT_N / PW / (2 * M_PI));
+            for (int i = 0; i <= ppb; i++) {
+                float x = (float)(LB0 + PW * i - FFT_N / 2), y = st.costas_freq[bin_to_live(LB0 + PW * i)];
+                angle += y; sum_xy += x * y; sum_x2 += x * x;
+                x = (float)(UB1 - PW * i - FFT_N / 2); y = st.costas_freq[bin_to_live(UB1 - PW * i)];
+                angle += y; sum_xy += x * y; sum_x2 += x * x;
+            }
+            se = (float)(se - (sum_xy / sum_x2) * FFT_N / (2 * M_PI) * NSYM);
+            st.samperr = (int)roundf(se);
+            angle /= (ppb + 1) * 2;
+            st.angle = angle;
+            sh_f[0] = angle;
+        }
+        __syncthreads();
+        if (tid < nref) st.costas_freq[bin_to_live(ref_bin(tid))] -= sh_f[0];
+
+        // cell (side, part, n, k): data carrier k = 1..18 of partition `part` (counted from the band edge)
+        const int ncell = 2 * ppb * NSYM * 18;
+        double e_lb = 0.0, e_ub = 0.0;
+        for (int c = tid; c < ncell; c += 256) {
+            const int k = 1 + c % 18, n = (c / 18) % NSYM, part = (c / (18 * NSYM)) % ppb, side = c / (18 * NSYM * ppb);
+            // adjust_data(lower, upper): side 0: refs i=part (low) and part+1 (high); side 1: low = upper-sideband ref part+1
+            const int r_lo = side ? 2 * (part + 1) + 1 : 2 * part, r_hi = side ? 2 * part + 1 : 2 * (part + 1);
+            const int b = ref_bin(r_lo) + k;
+            const float2 lp = refcs[r_lo][n], up = refcs[r_hi][n];
+            const float a = k * smag[r_hi], bq = (PW - k) * smag[r_lo];
+            const float2 den = make_float2(a * up.x + bq * lp.x, a * up.y + bq * lp.y);
+            const float2 C = cdiv(make_float2((float)PW, (float)PW), den);
+            const float2 z = bins[n * LIVE_N + bin_to_live(b)];
+            const float2 v = make_float2(z.x * C.x - z.y * C.y, z.x * C.y + z.y * C.x);
+            bins[n * LIVE_N + bin_to_live(b)] = v;             // keep the equalised cell for the soft-bit pass
+            const float ix = v.x >= 0 ? 1.0f : -1.0f, iy = v.y >= 0 ? 1.0f : -1.0f;
+            const float dx = ix - v.x, dy = iy - v.y;
+            const float e = dx * dx + dy * dy;
+            if (side) e_ub += e; else e_lb += e;
+        }
+        e_lb = wave_sum_f64(e_lb); e_ub = wave_sum_f64(e_ub);
+        if ((tid & 63) == 0) { red[0][tid >> 6] = e_lb; red[1][tid >> 6] = e_ub; }
+        __syncthreads();
+        if (tid == 0) {
+            const float error_lb = (float)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+            const float error_ub = (float)(red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+            st.error_lb += error_lb; st.error_ub += error_ub;
+            if (++st.mer_cnt == 16) {                          // EVENT_MER every 16 blocks (sync.c:490-501)
+                const float signal = (float)(2 * NSYM * (ppb * 18) * st.mer_cnt);
+                rec.mer_lb = 10 * log10f(signal / st.error_lb);
+                rec.mer_ub = 10 * log10f(signal / st.error_ub);
+                rec.flags |= REC_MER;
+                st.mer_cnt = 0; st.error_lb = 0; st.error_ub = 0;
+            }
+            const float mer_lb = 2.0f * NSYM * (float)(ppb * 18) / error_lb;
+            const float mer_ub = 2.0f * NSYM * (float)(ppb * 18) / error_ub;
+            sh_f[1] = fmaxf(fminf(mer_lb * 10, 127.0f), 1.0f);
+            sh_f[2] = fmaxf(fminf(mer_ub * 10, 127.0f), 1.0f);
+        }
+        __syncthreads();
+        const float mult_lb = sh_f[1], mult_ub = sh_f[2];
+
+        // primary-main soft bits -> row `bc` of the stream's 16 x 32 x 720 interleaver matrix (decode.c:380)
+        int8_t *pm_blk = db.pm + (size_t)s * PM_FRAME + (size_t)bc * PM_BLOCK;
+        for (int c = tid; c < NSYM * 360; c += 256) {
+            const int n = c / 360, q = c % 360, part20 = q / 18, j = 1 + q % 18;
+            // partitions 0..9: lower sideband from the edge; 10..19: upper sideband, ascending frequency (sync.c:514-536)
+            const int b = part20 < 10 ? LB0 + PW * part20 + j : UB1 - PW * 10 + PW * (part20 - 10) + j;
+            const float2 v = bins[n * LIVE_N + bin_to_live(b)];
+            const float mult = part20 < 10 ? mult_lb : mult_ub;
+            char2 o; o.x = (signed char)soft_bit(v.x, mult); o.y = (signed char)soft_bit(v.y, mult);
+            *(char2 *)(pm_blk + n * 720 + part20 * 36 + (j - 1) * 2) = o;
+        }
+        __threadfence_block();
+        __syncthreads();
+
+        // ---- PIDS: gather + depuncture (decode.c:324-342), 80-bit tail-biting Viterbi, descramble
+        for (int n = tid; n < PIDS_CODED; n += 256) pids_coded[n + n / 5] = pm_blk[tb.pids_gather[bc * PIDS_CODED + n]];
+        for (int n = tid; n < PIDS_CODED / 5; n += 256) pids_coded[6 * n + 5] = 0;
+        __syncthreads();
+        if (tid < 64) {
+            viterbi_k7_wave(pids_coded, PIDS_LEN, pids_dec, pids_out);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            rec.pids[0] = pids_out[0] ^ tb.scr_pids[0];
+            rec.pids[1] = pids_out[1] ^ tb.scr_pids[1];
+            rec.pids[2] = (pids_out[2] ^ tb.scr_pids[2]) & 0xffffu;
+            rec.flags |= REC_PIDS;
+            rec.bc_decoded = bc;
+            if (bc == 0) st.started_pm = 1;                    // decode.c:383-390
+            if (st.started_pm && bc == 15) {
+                const int slot = st.p1_count % db.p1_slots;
+                st.p1_count++;
+                st.p1_pending[parity] = 1; st.p1_slot[parity] = slot; st.p1_record[parity] = st.nblocks % db.rec_cap;
+                rec.p1_slot = slot; rec.flags |= REC_P1;
+            }
+            st.bc = (bc + 1) % 16;
+        }
+    }
+    __syncthreads();
+
+    // ---- end of acquire_process (acquire.c:259-262) + record
+    if (tid == 0) {
+        const int keep = SYM_N + (SYM_N / 2 - samperr) + st.keep_extra;
+        st.keep_extra = 0;
+        st.rd += WIN_N - keep;
+        double th = st.theta + (double)NSYM * SYM_N * st.dtheta;
+        th -= 2 * M_PI * rint(th / (2 * M_PI));
+        st.theta = th;
+        rec.state_after = st.sync_state; rec.samperr = samperr; rec.cfo = st.cfo; rec.keep = keep;
+        rec.bc = st.bc; rec.psmi = st.psmi; rec.cfo_wait = st.cfo_wait; rec.next_samperr = st.samperr;
+        rec.prev_angle = st.prev_angle; rec.phase_re = (float)cos(th); rec.phase_im = (float)sin(th);
+        rec.next_angle = st.angle;
+        st.nblocks++;
+        st.active = 0;
+    }
+}
+
+void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_sync, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity);
+}
+
+}  // namespace nrsc5

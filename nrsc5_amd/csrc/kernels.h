@@ -1,0 +1,57 @@
+// Host-callable launchers for the gfx950 kernels (one .hip file per pipeline stage).
+#pragma once
+#include "nrsc5_dev.h"
+
+namespace nrsc5 {
+
+// Read-only device tables built once per engine (engine.hip: build_tables()).
+struct DevTables {
+    const int32_t *p1_gather;        // [P1_CODED]  flat index into the 16x32x720 soft-bit matrix (decode.c:296-322)
+    const uint16_t *pids_gather;     // [16][PIDS_CODED] index inside block bc (decode.c:324-342)
+    const uint32_t *scr_p1;          // [P1_WORDS] packed scrambler stream (decode.c:279-294)
+    const uint32_t *scr_pids;        // [3]
+    const float2 *twiddle;           // [2048] e^{-2 pi i k / 2048}
+    const float *shape;              // [2160] pulse shape (acquire.c:322-331)
+    const int16_t *hb_q15;           // [4]  half-band taps, window order
+    const int16_t *acq_q15;          // [17] acquisition FIR taps, [1..16] used
+};
+
+// Engine-wide device buffers (slabs indexed by stream).
+struct DevBuffers {
+    StreamState *state;              // [S]
+    c16 *q15;                        // [S][q15_cap]
+    long long q15_cap;
+    c16 *acq_filt;                   // [S][WIN_N]   acquisition FIR output
+    float2 *acq_sums;                // [S][SYM_N]
+    float2 *bins;                    // [S][NSYM][LIVE_N]
+    int8_t *pm;                      // [S][PM_FRAME]
+    int8_t *coded;                   // [S][2][P1_DEPUNCT]
+    unsigned long long *dec;         // [S][P1_LEN + 64]
+    uint32_t *p1_ring;               // [S][p1_slots][P1_WORDS]
+    int p1_slots;
+    BlockRecord *records;            // [S][rec_cap]
+    int rec_cap;
+    int *counters;                   // [0]: streams that processed a block this step, [1]: not-FINE streams
+};
+
+// ---- K1 -------------------------------------------------------------------------------
+// cu8 -> Q15 half-band 2:1 for one chunk per stream.  iq[s] = base + s*stride, nbytes[s] each.
+void launch_decimate_fm_cu8(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids,
+                            const uint8_t *iq_base, long long iq_stride, const unsigned *nbytes, unsigned max_nbytes,
+                            hipStream_t st);
+void launch_append_cs16(const DevBuffers &db, int nstreams, const int *stream_ids,
+                        const int16_t *iq_base, long long iq_stride, const unsigned *nsamples, unsigned max_n, hipStream_t st);
+
+// ---- one block step for a set of streams ----------------------------------------------------
+void launch_acquire(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
+void launch_prepare(const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
+void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
+void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st);
+void launch_p1_deint(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st);
+void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st);
+
+// ---- stage-level entry points (parity tests) ---------------------------------------------------
+void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st);
+void launch_fft2048(const DevTables &tb, const float2 *in, float2 *out, int nffts, hipStream_t st);
+
+}  // namespace nrsc5

@@ -1,0 +1,227 @@
+"""ctypes binding of libnrsc5hip.so (include/nrsc5hip.h) -- the same stub a Python caller of the
+reference would use next to support/nrsc5.py:676-690.  No fallbacks: if the HIP library is missing
+or a call fails, this raises."""
+from __future__ import annotations
+
+import ctypes
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "libnrsc5hip.so")
+
+SYNC_NONE, SYNC_COARSE, SYNC_FINE = 0, 1, 2
+REC_PROCESSED, REC_TO_COARSE, REC_TO_FINE, REC_MER, REC_PIDS, REC_P1 = 1, 2, 4, 8, 16, 32
+P1_BITS, P1_WORDS, PIDS_BITS = 146176, 4568, 80
+
+RECORD_DTYPE = np.dtype([
+    ("flags", "<u4"), ("state_before", "<i4"), ("state_after", "<i4"), ("samperr", "<i4"), ("cfo", "<i4"),
+    ("keep", "<i4"), ("bc", "<i4"), ("psmi", "<i4"), ("cfo_wait", "<i4"), ("next_samperr", "<i4"),
+    ("prev_angle", "<f4"), ("phase_re", "<f4"), ("phase_im", "<f4"), ("next_angle", "<f4"),
+    ("freq_offset", "<f4"), ("mer_lb", "<f4"), ("mer_ub", "<f4"), ("ber", "<f4"),
+    ("p1_slot", "<i4"), ("bc_decoded", "<i4"), ("pids", "<u4", (3,)), ("pad", "<u4")])
+assert RECORD_DTYPE.itemsize == 96
+
+
+class _Config(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int), ("max_streams", ctypes.c_int), ("q15_capacity", ctypes.c_longlong),
+                ("record_capacity", ctypes.c_int), ("p1_slots", ctypes.c_int), ("p1_async", ctypes.c_int)]
+
+
+class Nrsc5HipError(RuntimeError):
+    pass
+
+
+def load_library(path: str | None = None) -> ctypes.CDLL:
+    path = path or DEFAULT_LIB
+    if not os.path.exists(path):
+        raise Nrsc5HipError(f"{path} not found: build it with `python -m nrsc5_amd.build` (hipcc, gfx950). "
+                            "There is no CPU fallback.")
+    lib = ctypes.CDLL(path)
+    vp, ci = ctypes.c_void_p, ctypes.c_int
+    lib.nrsc5hip_engine_create.argtypes = [ctypes.POINTER(_Config), ctypes.POINTER(vp)]
+    lib.nrsc5hip_engine_destroy.argtypes = [vp]
+    lib.nrsc5hip_engine_destroy.restype = None
+    lib.nrsc5hip_last_error.restype = ctypes.c_char_p
+    lib.nrsc5hip_engine_hip_stream.argtypes = [vp]
+    lib.nrsc5hip_engine_hip_stream.restype = vp
+    lib.nrsc5hip_push_cu8.argtypes = [vp, ci, vp, ctypes.c_uint32]
+    lib.nrsc5hip_push_cs16.argtypes = [vp, ci, vp, ctypes.c_uint32]
+    lib.nrsc5hip_stream_reset.argtypes = [vp, ci]
+    lib.nrsc5hip_force_resync.argtypes = [vp, ci]
+    lib.nrsc5hip_batch_append_cu8.argtypes = [vp, ci, vp, vp, ctypes.c_longlong, vp]
+    lib.nrsc5hip_batch_append_cs16.argtypes = [vp, ci, vp, vp, ctypes.c_longlong, vp]
+    lib.nrsc5hip_batch_process.argtypes = [vp, ci, vp, ci, ctypes.POINTER(ci)]
+    lib.nrsc5hip_drain.argtypes = [vp, ci, vp, ci, ctypes.POINTER(ci)]
+    lib.nrsc5hip_p1_frame_packed.argtypes = [vp, ci, ci, vp]
+    lib.nrsc5hip_p1_frame_bits.argtypes = [vp, ci, ci, vp]
+    lib.nrsc5hip_batch_fetch.argtypes = [vp, ci, vp, vp, ci, vp, vp]
+    lib.nrsc5hip_unpack_bits.argtypes = [vp, ci, vp]
+    lib.nrsc5hip_unpack_bits.restype = None
+    lib.nrsc5hip_stage_halfband_fm_cu8.argtypes = [vp, vp, ctypes.c_uint32, vp]
+    lib.nrsc5hip_stage_fft2048.argtypes = [vp, vp, vp, ci]
+    lib.nrsc5hip_stage_viterbi_k7.argtypes = [vp, vp, ci, ci, vp]
+    lib.nrsc5hip_debug_fetch.argtypes = [vp, ci, vp, vp]
+    return lib
+
+
+EXPORTED_SYMBOLS = [
+    "nrsc5hip_engine_create", "nrsc5hip_engine_destroy", "nrsc5hip_last_error", "nrsc5hip_engine_hip_stream",
+    "nrsc5hip_push_cu8", "nrsc5hip_push_cs16", "nrsc5hip_stream_reset", "nrsc5hip_force_resync",
+    "nrsc5hip_batch_append_cu8", "nrsc5hip_batch_append_cs16", "nrsc5hip_batch_process", "nrsc5hip_drain",
+    "nrsc5hip_p1_frame_packed", "nrsc5hip_p1_frame_bits", "nrsc5hip_batch_fetch", "nrsc5hip_unpack_bits",
+    "nrsc5hip_stage_halfband_fm_cu8", "nrsc5hip_stage_fft2048", "nrsc5hip_stage_viterbi_k7", "nrsc5hip_debug_fetch"]
+
+
+def unpack_bits(words: np.ndarray, nbits: int) -> np.ndarray:
+    w = np.ascontiguousarray(words, dtype="<u4")
+    return np.unpackbits(w.view(np.uint8), bitorder="little")[:nbits]
+
+
+class Engine:
+    """One engine per GPU/process; `max_streams` independent IQ streams resident on the device."""
+
+    def __init__(self, max_streams: int = 1, q15_capacity: int = 1 << 20, record_capacity: int = 256,
+                 p1_slots: int = 4, p1_async: bool = False, device: int = 0, lib_path: str | None = None):
+        self.lib = load_library(lib_path)
+        self.cfg = _Config(device, max_streams, q15_capacity, record_capacity, p1_slots, int(p1_async))
+        self._h = ctypes.c_void_p()
+        self._check(self.lib.nrsc5hip_engine_create(ctypes.byref(self.cfg), ctypes.byref(self._h)))
+        self.max_streams, self.record_capacity, self.p1_slots = max_streams, record_capacity, p1_slots
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise Nrsc5HipError(f"libnrsc5hip error {rc}: {self.lib.nrsc5hip_last_error().decode()}")
+
+    def close(self):
+        if self._h:
+            self.lib.nrsc5hip_engine_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def hip_stream(self) -> int:
+        return self.lib.nrsc5hip_engine_hip_stream(self._h) or 0
+
+    # ---- streaming seam ---------------------------------------------------------------------
+    def push_cu8(self, stream: int, iq: np.ndarray):
+        iq = np.ascontiguousarray(iq, dtype=np.uint8)
+        self._check(self.lib.nrsc5hip_push_cu8(self._h, stream, iq.ctypes.data, iq.size))
+
+    def push_cs16(self, stream: int, iq: np.ndarray):
+        iq = np.ascontiguousarray(iq, dtype=np.int16)
+        self._check(self.lib.nrsc5hip_push_cs16(self._h, stream, iq.ctypes.data, iq.size))
+
+    def reset(self, stream: int):
+        self._check(self.lib.nrsc5hip_stream_reset(self._h, stream))
+
+    def force_resync(self, stream: int):
+        self._check(self.lib.nrsc5hip_force_resync(self._h, stream))
+
+    # ---- batch path (device pointers as ints) ---------------------------------------------------
+    def batch_append_cu8(self, dev_ptr: int, stride_bytes: int, nbytes, stream_ids=None):
+        nb = np.ascontiguousarray(nbytes, dtype=np.uint32)
+        ids = None if stream_ids is None else np.ascontiguousarray(stream_ids, dtype=np.int32)
+        self._check(self.lib.nrsc5hip_batch_append_cu8(self._h, nb.size, None if ids is None else ids.ctypes.data,
+                                                       dev_ptr, stride_bytes, nb.ctypes.data))
+
+    def batch_append_cs16(self, dev_ptr: int, stride_elems: int, nelems, stream_ids=None):
+        ne = np.ascontiguousarray(nelems, dtype=np.uint32)
+        ids = None if stream_ids is None else np.ascontiguousarray(stream_ids, dtype=np.int32)
+        self._check(self.lib.nrsc5hip_batch_append_cs16(self._h, ne.size, None if ids is None else ids.ctypes.data,
+                                                        dev_ptr, stride_elems, ne.ctypes.data))
+
+    def batch_process(self, nstreams: int, stream_ids=None, max_steps: int = 0) -> int:
+        ids = None if stream_ids is None else np.ascontiguousarray(stream_ids, dtype=np.int32)
+        done = ctypes.c_int()
+        self._check(self.lib.nrsc5hip_batch_process(self._h, nstreams, None if ids is None else ids.ctypes.data,
+                                                    max_steps, ctypes.byref(done)))
+        return done.value
+
+    # ---- results ---------------------------------------------------------------------------------
+    def drain(self, stream: int, max_records: int | None = None) -> np.ndarray:
+        mx = max_records or self.record_capacity
+        out = np.zeros(mx, dtype=RECORD_DTYPE)
+        n = ctypes.c_int()
+        self._check(self.lib.nrsc5hip_drain(self._h, stream, out.ctypes.data, mx, ctypes.byref(n)))
+        return out[:n.value]
+
+    def p1_frame_bits(self, stream: int, slot: int) -> np.ndarray:
+        bits = np.zeros(P1_BITS, dtype=np.uint8)
+        self._check(self.lib.nrsc5hip_p1_frame_bits(self._h, stream, slot, bits.ctypes.data))
+        return bits
+
+    def p1_frame_packed(self, stream: int, slot: int) -> np.ndarray:
+        w = np.zeros(P1_WORDS, dtype=np.uint32)
+        self._check(self.lib.nrsc5hip_p1_frame_packed(self._h, stream, slot, w.ctypes.data))
+        return w
+
+    def batch_fetch(self, nstreams: int, stream_ids=None, with_frames: bool = True):
+        ids = None if stream_ids is None else np.ascontiguousarray(stream_ids, dtype=np.int32)
+        recs = np.zeros((nstreams, self.record_capacity), dtype=RECORD_DTYPE)
+        counts = np.zeros(nstreams, dtype=np.int32)
+        frames = np.zeros((nstreams, self.p1_slots, P1_WORDS), dtype=np.uint32) if with_frames else None
+        self._check(self.lib.nrsc5hip_batch_fetch(self._h, nstreams, None if ids is None else ids.ctypes.data,
+                                                  recs.ctypes.data, self.record_capacity, counts.ctypes.data,
+                                                  None if frames is None else frames.ctypes.data))
+        return recs, counts, frames
+
+    # ---- stage-level entry points (parity tests) ----------------------------------------------------
+    def stage_halfband_fm_cu8(self, iq: np.ndarray) -> np.ndarray:
+        iq = np.ascontiguousarray(iq, dtype=np.uint8)
+        out = np.zeros((iq.size // 4, 2), dtype=np.int16)
+        self._check(self.lib.nrsc5hip_stage_halfband_fm_cu8(self._h, iq.ctypes.data, iq.size, out.ctypes.data))
+        return out
+
+    def stage_fft2048(self, x: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.complex64).reshape(-1, 2048)
+        out = np.zeros_like(x)
+        self._check(self.lib.nrsc5hip_stage_fft2048(self._h, x.ctypes.data, out.ctypes.data, x.shape[0]))
+        return out
+
+    def stage_viterbi_k7(self, soft: np.ndarray, length: int) -> np.ndarray:
+        soft = np.ascontiguousarray(soft, dtype=np.int8).reshape(-1, 3 * length)
+        bits = np.zeros((soft.shape[0], length), dtype=np.uint8)
+        self._check(self.lib.nrsc5hip_stage_viterbi_k7(self._h, soft.ctypes.data, length, soft.shape[0], bits.ctypes.data))
+        return bits
+
+    def debug_fetch(self, stream: int):
+        pm = np.zeros(16 * 23040, dtype=np.int8)
+        bins = np.zeros((32, 534), dtype=np.complex64)
+        self._check(self.lib.nrsc5hip_debug_fetch(self._h, stream, pm.ctypes.data, bins.ctypes.data))
+        return pm, bins
+
+
+def records_to_log(engine: Engine, stream: int, recs: np.ndarray, frames: np.ndarray | None = None):
+    """Expand block records into the ordered event list used by the oracle/reference harness logs
+    (oracle/ref.py: parse_log), i.e. the order in which the reference fires them inside one
+    acquire_process call."""
+    out = []
+    for r in recs:
+        fl = int(r["flags"])
+        if fl & REC_TO_COARSE:
+            out.append(("state", {"old": int(r["state_before"]), "new": SYNC_COARSE}))
+        if fl & REC_TO_FINE:
+            out.append(("state", {"old": SYNC_COARSE, "new": SYNC_FINE}))
+            out.append(("sync", {"freq_offset": float(r["freq_offset"]), "psmi": int(r["psmi"]), "pli": -1, "hppi": -1, "aabi": -1, "rdbi": -1}))
+        if fl & REC_MER:
+            out.append(("mer", {"lower": float(r["mer_lb"]), "upper": float(r["mer_ub"])}))
+        if fl & REC_PIDS:
+            out.append(("pids", {"bits": unpack_bits(r["pids"], PIDS_BITS)}))
+        if fl & REC_P1:
+            out.append(("ber", {"cber": float(r["ber"])}))
+            if frames is not None:
+                bits = unpack_bits(frames[int(r["p1_slot"])], P1_BITS)
+            else:
+                bits = engine.p1_frame_bits(stream, int(r["p1_slot"]))
+            out.append(("frame", {"lc": 0, "bits": bits}))
+        blk = {k: (float(r[k]) if RECORD_DTYPE[k].kind == "f" else int(r[k]))
+               for k in ("state_before", "state_after", "samperr", "cfo", "keep", "bc", "psmi", "cfo_wait",
+                         "next_samperr", "prev_angle", "phase_re", "phase_im", "next_angle")}
+        out.append(("block", blk))
+    return out
