@@ -145,6 +145,23 @@ int nrsc5hip_stage_viterbi_k7(nrsc5hip_engine *e, const int8_t *soft /* [nframes
 /* debugging aid: soft-bit matrix (16 x 23040 int8) and live FFT bins of a stream's latest block */
 int nrsc5hip_debug_fetch(nrsc5hip_engine *e, int stream, int8_t *pm /* [368640] or NULL */, float *bins /* [32][534][2] or NULL */);
 
+/* fresh-session state for every stream (input_reset on all of them) */
+int nrsc5hip_reset_all(nrsc5hip_engine *e);
+
+/* Per-kernel-class device timing, measured with HIP events recorded on the stream each kernel is
+ * launched on.  enable: 1 start (and zero the accumulators), 0 stop (and zero), -1 just read.
+ * total_ms / launches: arrays of NRSC5HIP_PROF_CLASSES entries (may be NULL). */
+enum {
+    NRSC5HIP_PROF_DECIMATE = 0, NRSC5HIP_PROF_ACQUIRE, NRSC5HIP_PROF_PREPARE, NRSC5HIP_PROF_MIXFFT,
+    NRSC5HIP_PROF_SYNC, NRSC5HIP_PROF_P1_DEINT, NRSC5HIP_PROF_P1_VITERBI, NRSC5HIP_PROF_CLASSES
+};
+int nrsc5hip_profile(nrsc5hip_engine *e, int enable, double *total_ms, long long *launches);
+
+/* test helpers: first n samples of a stream's Q15 FIFO slab; raw device allocation for batch tests */
+int nrsc5hip_debug_fetch_q15(nrsc5hip_engine *e, int stream, long long n, int16_t *out /* [n][2] */);
+void *nrsc5hip_debug_alloc_copy(const void *host, size_t nbytes);
+void nrsc5hip_debug_free(void *dev);
+
 #ifdef __cplusplus
 }
 #endif

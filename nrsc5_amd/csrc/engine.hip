@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <new>
 #include <vector>
 #include "nrsc5hip.h"
@@ -47,7 +48,37 @@ struct nrsc5hip_engine {
     int *ids_dev; unsigned *nbytes_dev;
     int *counters_host;                // pinned
     int *all_ids_dev;                  // identity list 0..S-1
+    // optional per-kernel-class timing with HIP events on the launching stream
+    bool prof_on;
+    struct ProfSpan { int cls; hipEvent_t a, b; };
+    std::vector<ProfSpan> prof_spans;
+    std::vector<hipEvent_t> prof_pool;
+    double prof_ms[NRSC5HIP_PROF_CLASSES];
+    long long prof_launches[NRSC5HIP_PROF_CLASSES];
 };
+
+static hipEvent_t prof_event(nrsc5hip_engine *e)
+{
+    if (!e->prof_pool.empty()) { hipEvent_t ev = e->prof_pool.back(); e->prof_pool.pop_back(); return ev; }
+    hipEvent_t ev = nullptr; (void)hipEventCreate(&ev); return ev;
+}
+struct ProfScope {
+    nrsc5hip_engine *e; int cls; hipStream_t st; hipEvent_t a;
+    ProfScope(nrsc5hip_engine *e_, int cls_, hipStream_t st_) : e(e_), cls(cls_), st(st_), a(nullptr)
+    { if (e->prof_on) { a = prof_event(e); (void)hipEventRecord(a, st); } }
+    ~ProfScope()
+    { if (e->prof_on) { hipEvent_t b = prof_event(e); (void)hipEventRecord(b, st); e->prof_spans.push_back({cls, a, b}); } }
+};
+static void prof_collect(nrsc5hip_engine *e)
+{
+    // caller has synchronised both streams
+    for (auto &sp : e->prof_spans) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, sp.a, sp.b) == hipSuccess) { e->prof_ms[sp.cls] += ms; e->prof_launches[sp.cls]++; }
+        e->prof_pool.push_back(sp.a); e->prof_pool.push_back(sp.b);
+    }
+    e->prof_spans.clear();
+}
 
 template <typename T> static int dev_alloc(nrsc5hip_engine *e, T **p, size_t count)
 {
@@ -189,6 +220,8 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             hipMemset(db.pm, 0, S * PM_FRAME) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "state init copy failed"); break; }
         e->wr_host.assign(S, 0); e->base_host.assign(S, 0); e->drained.assign(S, 0);
         e->acq_needed = true; e->step_count = 0;
+        e->prof_on = false;
+        for (int k = 0; k < NRSC5HIP_PROF_CLASSES; k++) { e->prof_ms[k] = 0; e->prof_launches[k] = 0; }
     } while (0);
     if (rc) { nrsc5hip_engine_destroy(e); return rc; }
     *out = e;
@@ -200,6 +233,8 @@ extern "C" void nrsc5hip_engine_destroy(nrsc5hip_engine *e)
     if (!e) return;
     hipDeviceSynchronize();
     for (void *p : e->allocs) hipFree(p);
+    for (auto &sp : e->prof_spans) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
+    for (hipEvent_t ev : e->prof_pool) hipEventDestroy(ev);
     if (e->counters_host) hipHostFree(e->counters_host);
     for (int k = 0; k < 2; k++) { if (e->ev_window[k]) hipEventDestroy(e->ev_window[k]); if (e->ev_decoded[k]) hipEventDestroy(e->ev_decoded[k]); }
     if (e->main) hipStreamDestroy(e->main);
@@ -229,17 +264,18 @@ static int issue_step(nrsc5hip_engine *e, int n, const int *ids_dev)
         HIPCHK(hipStreamWaitEvent(e->main, e->ev_decoded[parity], 0));
         e->decoded_pending[parity] = false;
     }
-    if (e->acq_needed) launch_acquire(e->tb, e->db, n, ids_dev, e->main);
-    launch_prepare(e->db, n, ids_dev, e->main);
-    launch_mixfft(e->tb, e->db, n, ids_dev, e->main);
-    launch_sync(e->tb, e->db, n, ids_dev, parity, e->main);
-    launch_p1_deint(e->tb, e->db, n, ids_dev, parity, e->main);
+    if (e->acq_needed) { ProfScope p(e, NRSC5HIP_PROF_ACQUIRE, e->main); launch_acquire(e->tb, e->db, n, ids_dev, e->main); }
+    { ProfScope p(e, NRSC5HIP_PROF_PREPARE, e->main); launch_prepare(e->db, n, ids_dev, e->main); }
+    { ProfScope p(e, NRSC5HIP_PROF_MIXFFT, e->main); launch_mixfft(e->tb, e->db, n, ids_dev, e->main); }
+    { ProfScope p(e, NRSC5HIP_PROF_SYNC, e->main); launch_sync(e->tb, e->db, n, ids_dev, parity, e->main); }
+    { ProfScope p(e, NRSC5HIP_PROF_P1_DEINT, e->main); launch_p1_deint(e->tb, e->db, n, ids_dev, parity, e->main); }
     if (!async) {
+        ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, e->main);
         launch_p1_viterbi(e->tb, e->db, n, ids_dev, parity, e->main);
     } else if ((e->step_count % 16) == 15) {
         HIPCHK(hipEventRecord(e->ev_window[parity], e->main));
         HIPCHK(hipStreamWaitEvent(e->aux, e->ev_window[parity], 0));
-        launch_p1_viterbi(e->tb, e->db, n, ids_dev, parity, e->aux);
+        { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, e->aux); launch_p1_viterbi(e->tb, e->db, n, ids_dev, parity, e->aux); }
         HIPCHK(hipEventRecord(e->ev_decoded[parity], e->aux));
         e->decoded_pending[parity] = true;
     }
@@ -254,7 +290,7 @@ static int flush_p1(nrsc5hip_engine *e, int n, const int *ids_dev)
     if (!e->cfg.p1_async) return 0;
     if (e->step_count % 16) {
         const int parity = (int)((e->step_count / 16) & 1);
-        launch_p1_viterbi(e->tb, e->db, n, ids_dev, parity, e->main);
+        { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, e->main); launch_p1_viterbi(e->tb, e->db, n, ids_dev, parity, e->main); }
         e->step_count += 16 - (e->step_count % 16);           // next batch starts a fresh window
     }
     HIPCHK(hipStreamSynchronize(e->aux));
@@ -283,6 +319,7 @@ static int run_steps(nrsc5hip_engine *e, int n, const int *ids_dev, int max_step
     int rc = flush_p1(e, n, ids_dev);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(e->main));
+    if (e->prof_on) prof_collect(e);
     if (steps_done) *steps_done = done;
     return 0;
 }
@@ -404,7 +441,7 @@ extern "C" int nrsc5hip_batch_append_cu8(nrsc5hip_engine *e, int nstreams, const
             FAIL(NRSC5HIP_EOVERFLOW, "stream %d: q15_capacity %lld too small for this batch", s, e->db.q15_cap);
         if (nbytes[k] > mx) mx = nbytes[k];
     }
-    launch_decimate_fm_cu8(e->tb, e->db, nstreams, ids_dev, dev_iq, stride_bytes, e->nbytes_dev, mx, e->main);
+    { ProfScope p(e, NRSC5HIP_PROF_DECIMATE, e->main); launch_decimate_fm_cu8(e->tb, e->db, nstreams, ids_dev, dev_iq, stride_bytes, e->nbytes_dev, mx, e->main); }
     for (int k = 0; k < nstreams; k++) e->wr_host[stream_ids ? stream_ids[k] : k] += nbytes[k] / 4;
     HIPCHK(hipGetLastError());
     return 0;
@@ -562,5 +599,54 @@ extern "C" int nrsc5hip_debug_fetch(nrsc5hip_engine *e, int stream, int8_t *pm, 
     HIPCHK(hipDeviceSynchronize());
     if (pm) HIPCHK(hipMemcpy(pm, e->db.pm + (size_t)stream * PM_FRAME, PM_FRAME, hipMemcpyDeviceToHost));
     if (bins) HIPCHK(hipMemcpy(bins, e->db.bins + (size_t)stream * NSYM * LIVE_N, (size_t)NSYM * LIVE_N * sizeof(float2), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int nrsc5hip_debug_fetch_q15(nrsc5hip_engine *e, int stream, long long n, int16_t *out)
+{
+    int rc = check_stream(e, stream); if (rc) return rc;
+    if (n < 0 || n > e->db.q15_cap || !out) FAIL(NRSC5HIP_EINVAL, "bad argument");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, e->db.q15 + (size_t)stream * e->db.q15_cap, (size_t)n * sizeof(c16), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" void *nrsc5hip_debug_alloc_copy(const void *host, size_t nbytes)
+{
+    void *d = nullptr;
+    if (hipMalloc(&d, nbytes ? nbytes : 1) != hipSuccess) return nullptr;
+    if (host && hipMemcpy(d, host, nbytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d); return nullptr; }
+    return d;
+}
+
+extern "C" void nrsc5hip_debug_free(void *dev) { (void)hipFree(dev); }
+
+extern "C" int nrsc5hip_reset_all(nrsc5hip_engine *e)
+{
+    if (!e) FAIL(NRSC5HIP_EINVAL, "null engine");
+    HIPCHK(hipDeviceSynchronize());
+    const size_t S = e->cfg.max_streams;
+    std::vector<StreamState> init(S);
+    for (size_t s = 0; s < S; s++) init_state(init[s]);
+    HIPCHK(hipMemcpy(e->db.state, init.data(), S * sizeof(StreamState), hipMemcpyHostToDevice));
+    std::fill(e->wr_host.begin(), e->wr_host.end(), 0);
+    std::fill(e->base_host.begin(), e->base_host.end(), 0);
+    std::fill(e->drained.begin(), e->drained.end(), 0);
+    e->acq_needed = true; e->step_count = 0;
+    e->decoded_pending[0] = e->decoded_pending[1] = false;
+    return 0;
+}
+
+extern "C" int nrsc5hip_profile(nrsc5hip_engine *e, int enable, double *total_ms, long long *launches)
+{
+    if (!e) FAIL(NRSC5HIP_EINVAL, "null engine");
+    HIPCHK(hipDeviceSynchronize());
+    if (e->prof_on) prof_collect(e);
+    for (int k = 0; k < NRSC5HIP_PROF_CLASSES; k++) {
+        if (total_ms) total_ms[k] = e->prof_ms[k];
+        if (launches) launches[k] = e->prof_launches[k];
+        if (enable >= 0) { e->prof_ms[k] = 0; e->prof_launches[k] = 0; }
+    }
+    if (enable >= 0) e->prof_on = enable != 0;
     return 0;
 }

@@ -62,6 +62,8 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.nrsc5hip_stage_fft2048.argtypes = [vp, vp, vp, ci]
     lib.nrsc5hip_stage_viterbi_k7.argtypes = [vp, vp, ci, ci, vp]
     lib.nrsc5hip_debug_fetch.argtypes = [vp, ci, vp, vp]
+    lib.nrsc5hip_reset_all.argtypes = [vp]
+    lib.nrsc5hip_profile.argtypes = [vp, ci, vp, vp]
     return lib
 
 
@@ -70,7 +72,8 @@ EXPORTED_SYMBOLS = [
     "nrsc5hip_push_cu8", "nrsc5hip_push_cs16", "nrsc5hip_stream_reset", "nrsc5hip_force_resync",
     "nrsc5hip_batch_append_cu8", "nrsc5hip_batch_append_cs16", "nrsc5hip_batch_process", "nrsc5hip_drain",
     "nrsc5hip_p1_frame_packed", "nrsc5hip_p1_frame_bits", "nrsc5hip_batch_fetch", "nrsc5hip_unpack_bits",
-    "nrsc5hip_stage_halfband_fm_cu8", "nrsc5hip_stage_fft2048", "nrsc5hip_stage_viterbi_k7", "nrsc5hip_debug_fetch"]
+    "nrsc5hip_stage_halfband_fm_cu8", "nrsc5hip_stage_fft2048", "nrsc5hip_stage_viterbi_k7", "nrsc5hip_debug_fetch",
+    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile"]
 
 
 def unpack_bits(words: np.ndarray, nbits: int) -> np.ndarray:
@@ -119,6 +122,18 @@ class Engine:
 
     def reset(self, stream: int):
         self._check(self.lib.nrsc5hip_stream_reset(self._h, stream))
+
+    def reset_all(self):
+        self._check(self.lib.nrsc5hip_reset_all(self._h))
+
+    PROF_CLASSES = ("decimate", "acquire", "prepare", "mixfft", "sync", "p1_deint", "p1_viterbi")
+
+    def profile(self, enable: int = -1):
+        """Per-kernel-class {name: (total_ms, launches)} from HIP events; enable 1/0 starts/stops."""
+        ms = np.zeros(len(self.PROF_CLASSES), dtype=np.float64)
+        n = np.zeros(len(self.PROF_CLASSES), dtype=np.int64)
+        self._check(self.lib.nrsc5hip_profile(self._h, enable, ms.ctypes.data, n.ctypes.data))
+        return {k: (float(a), int(b)) for k, a, b in zip(self.PROF_CLASSES, ms, n)}
 
     def force_resync(self, stream: int):
         self._check(self.lib.nrsc5hip_force_resync(self._h, stream))

@@ -1,0 +1,74 @@
+"""Multi-GPU layout: one process per GPU, streams are independent units, zero exchange on the
+data path.  torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" in the CPU
+tests) is used only for the barrier around the timed region, the max-over-ranks wall time and the
+gather of fixed-size per-stream result summaries."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+SUMMARY_FIELDS = ("stream", "blocks", "p1_frames", "p1_frames_ok", "pids_frames", "fine_blocks", "frame_hash")
+
+
+def stream_range(total_streams: int, world: int, rank: int) -> range:
+    """Contiguous block partition: rank r owns streams [lo, hi)."""
+    base, rem = divmod(total_streams, world)
+    lo = rank * base + min(rank, rem)
+    return range(lo, lo + base + (1 if rank < rem else 0))
+
+
+def init_from_env(backend: str | None = None):
+    """(rank, world, local_rank); initialises the default process group when WORLD_SIZE > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend or ("nccl" if torch.cuda.is_available() else "gloo"),
+                                rank=rank, world_size=world)
+    return rank, world, local
+
+
+def barrier(device=None):
+    if dist.is_initialized():
+        if device is not None and device.type == "cuda":
+            dist.barrier(device_ids=[device.index])
+        else:
+            dist.barrier()
+
+
+def max_over_ranks(value: float, device) -> float:
+    if not dist.is_initialized():
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(values, device) -> np.ndarray:
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    if dist.is_initialized():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
+def gather_summaries(local: np.ndarray, device) -> np.ndarray:
+    """all_gather of int64 [n_local, len(SUMMARY_FIELDS)] rows (padded to the largest shard)."""
+    local = np.ascontiguousarray(local, dtype=np.int64).reshape(-1, len(SUMMARY_FIELDS))
+    if not dist.is_initialized():
+        return local
+    world = dist.get_world_size()
+    n = torch.tensor([local.shape[0]], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    mx = int(max(s.item() for s in sizes))
+    pad = torch.full((mx, len(SUMMARY_FIELDS)), -1, dtype=torch.int64, device=device)
+    pad[:local.shape[0]] = torch.from_numpy(local).to(device)
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad)
+    rows = [o[:int(s.item())].cpu().numpy() for o, s in zip(out, sizes)]
+    return np.concatenate(rows, axis=0)

@@ -1,0 +1,100 @@
+"""Bulk synthetic-capture generator on the GPU (torch) -- BENCH / TEST SIGNAL SOURCE ONLY.
+
+Bit-level content (L2 PDUs, PIDS, scrambling, convolutional code, interleaving, reference
+carriers) comes from nrsc5_amd/synth.py; only the OFDM modulation and the channel (CFO, timing
+offset, AWGN, cu8 quantisation) run in torch so that hundreds of 20-second captures can be
+produced in seconds.  torch is plumbing here: nothing in this file is on the product path."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import synth
+
+
+def payload_stream(n_frames: int, seed: int):
+    """Truth + coded-bit matrix of one transmission: (p1 [F,146176] u8, pids [16F,80] u8, M [16F,23040] u8)."""
+    p1s, pidss, ms = [], [], []
+    for f in range(n_frames):
+        prng = np.random.default_rng(0xBEEF00 + 7919 * seed + f)
+        pdu, _ = synth.make_audio_pdu(f, prng)
+        p1 = synth.p1_frame_bits(pdu)
+        pids = np.stack([synth.pids_frame_bits(prng) for _ in range(16)])
+        ms.append(synth.encode_l1_frame(p1, pids).reshape(16, synth.PM_BLOCK))
+        p1s.append(p1)
+        pidss.append(pids)
+    return np.stack(p1s), np.concatenate(pidss), np.concatenate(ms)
+
+
+_REF_TABLE = None
+
+
+def _ref_table():
+    """[16 bc][22 refs][32 symbols] +-1 reference-carrier values for PSMI 1."""
+    global _REF_TABLE
+    if _REF_TABLE is None:
+        t = np.zeros((16, 22, 32), dtype=np.float32)
+        for bc in range(16):
+            for r, ri in enumerate(synth.REF_INDEX_MP1):
+                t[bc, r] = synth.reference_bits(bc, 1, int(ri)).astype(np.float32) * 2 - 1
+        _REF_TABLE = t
+    return _REF_TABLE
+
+
+def modulate(m_blocks: np.ndarray, device) -> torch.Tensor:
+    """Coded bits [nblocks, 23040] -> unit-power complex64 baseband at 2x rate (1488375 S/s),
+    nblocks * 32 * 4320 samples, before the receiver-side conjugation."""
+    nb = m_blocks.shape[0]
+    n = 2 * synth.FFT
+    out = torch.empty(nb * 32 * 2 * synth.SYM, dtype=torch.complex64, device=device)
+    pulse = torch.from_numpy(synth._pulse(2).astype(np.float32)).to(device)
+    data_idx = torch.from_numpy(((synth.DATA_BINS_MP1 - synth.FFT // 2) % n).astype(np.int64)).to(device)
+    ref_idx = torch.from_numpy(((synth.REF_BINS_MP1 - synth.FFT // 2) % n).astype(np.int64)).to(device)
+    reft = torch.from_numpy(_ref_table()).to(device)
+    inv = torch.tensor(1.0 / (1 + 1j), dtype=torch.complex64, device=device)
+    step = 64                                      # blocks per chunk
+    for b0 in range(0, nb, step):
+        mb = torch.from_numpy(m_blocks[b0:b0 + step].astype(np.float32)).to(device)
+        k = mb.shape[0]
+        sb = mb.reshape(k, 32, 360, 2) * 2 - 1
+        spec = torch.zeros((k, 32, n), dtype=torch.complex64, device=device)
+        spec[:, :, data_idx] = torch.complex(sb[..., 0], sb[..., 1]) * inv
+        bc = (torch.arange(b0, b0 + k, device=device) % 16)
+        spec[:, :, ref_idx] = reft[bc].permute(0, 2, 1).to(torch.complex64)
+        t = torch.fft.ifft(spec, dim=2) * n
+        ext = torch.cat([t, t[:, :, :2 * synth.CP]], dim=2) * pulse
+        out[b0 * 32 * 4320:(b0 + k) * 32 * 4320] = ext.reshape(-1)
+    out /= torch.sqrt(torch.mean(out.real ** 2 + out.imag ** 2))
+    return out
+
+
+def channel_cu8(sig: torch.Tensor, cfo_hz: float, offset: int, snr_db: float, seed: int,
+                rms_lsb: float = 20.0, tail: int = 8640, out: torch.Tensor | None = None) -> torch.Tensor:
+    """CFO -> timing offset -> AWGN -> conj -> cu8 (interleaved I,Q bytes)."""
+    dev = sig.device
+    n = sig.shape[0]
+    total = offset + n + tail
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    sigma = 10 ** (-snr_db / 20) / np.sqrt(2)
+    re = torch.randn(total, generator=g, device=dev, dtype=torch.float32) * sigma
+    im = torch.randn(total, generator=g, device=dev, dtype=torch.float32) * sigma
+    ph = torch.arange(n, device=dev, dtype=torch.float64) * (2 * np.pi * cfo_hz / synth.FS_CU8)
+    ph = torch.remainder(ph, 2 * np.pi).to(torch.float32)
+    rot = sig * torch.complex(torch.cos(ph), torch.sin(ph))
+    re[offset:offset + n] += rot.real
+    im[offset:offset + n] += rot.imag
+    scale = rms_lsb / np.sqrt(2)
+    if out is None:
+        out = torch.empty(2 * total, dtype=torch.uint8, device=dev)
+    v = out[:2 * total].view(total, 2)
+    v[:, 0] = torch.clamp(torch.round(127 + scale * re), 0, 255).to(torch.uint8)
+    v[:, 1] = torch.clamp(torch.round(127 - scale * im), 0, 255).to(torch.uint8)     # conj
+    return out[:2 * total]
+
+
+def stream_params(k: int):
+    """Config-3 family of SURVEY.md 8d: seed 1000+k, CFO uniform +-300 Hz, offset [0,4320), SNR 15/20/25 dB."""
+    rng = np.random.default_rng(1000 + k)
+    return dict(cfo_hz=float(rng.uniform(-300, 300)), offset=int(rng.integers(0, 4320)),
+                snr_db=(15.0, 20.0, 25.0)[k % 3], seed=1000 + k)

@@ -1,0 +1,115 @@
+"""Shared helpers for the parity tests."""
+from __future__ import annotations
+
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FLOAT_RTOL = 1e-4   # north_star: CFO / sync estimates within 1e-4 relative
+
+# golden capture definitions: name -> synth.fm_mp1_capture kwargs
+GOLDEN_CASES = {
+    "fm_cu8_cfo137": dict(n_frames=0, n_blocks=40, seed=11, cfo_hz=137.0, offset=777, snr_db=20.0, fmt="cu8"),
+    "fm_cu8_cfo-2400": dict(n_frames=0, n_blocks=24, seed=12, cfo_hz=-2400.0, offset=3001, snr_db=15.0, fmt="cu8"),
+    "fm_cs16_cfo60": dict(n_frames=0, n_blocks=36, seed=13, cfo_hz=60.0, offset=1500, snr_db=25.0, fmt="cs16"),
+}
+
+
+def sha256(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def compare_logs(expected, got, rtol: float = FLOAT_RTOL, skip_kinds=("hdc", "soft", "vit")):
+    """Ordered-record comparison: integers/bit arrays exact, floats within rtol (relative, floor 1).
+    Returns a list of human-readable differences (empty = parity)."""
+    exp = [r for r in expected if r[0] not in skip_kinds]
+    g = [r for r in got if r[0] not in skip_kinds]
+    diffs = []
+    if [k for k, _ in exp] != [k for k, _ in g]:
+        diffs.append(f"record kinds differ: expected {len(exp)} records, got {len(g)}; first mismatch at "
+                     f"{next((i for i, (a, b) in enumerate(zip(exp, g)) if a[0] != b[0]), min(len(exp), len(g)))}")
+        return diffs
+    for i, (a, b) in enumerate(zip(exp, g)):
+        for k, va in a[1].items():
+            vb = b[1][k]
+            if isinstance(va, np.ndarray):
+                if not np.array_equal(va, vb):
+                    diffs.append(f"#{i} {a[0]}.{k}: {int((np.asarray(va) != np.asarray(vb)).sum())} elements differ")
+            elif isinstance(va, float):
+                if not abs(va - vb) <= rtol * max(1.0, abs(va)):
+                    diffs.append(f"#{i} {a[0]}.{k}: expected {va!r} got {vb!r}")
+            elif va != vb:
+                diffs.append(f"#{i} {a[0]}.{k}: expected {va!r} got {vb!r}")
+    return diffs
+
+
+def log_to_arrays(log):
+    """Compact, storable view of a record log (golden fixtures)."""
+    blocks = [v for k, v in log if k == "block"]
+    ikeys = ("state_before", "state_after", "samperr", "cfo", "keep", "bc", "psmi", "cfo_wait", "next_samperr")
+    fkeys = ("prev_angle", "phase_re", "phase_im", "next_angle")
+    out = {
+        "block_int": np.array([[b[k] for k in ikeys] for b in blocks], dtype=np.int32).reshape(-1, len(ikeys)),
+        "block_float": np.array([[b[k] for k in fkeys] for b in blocks], dtype=np.float32).reshape(-1, len(fkeys)),
+        "sync": np.array([[v["freq_offset"], v["psmi"]] for k, v in log if k == "sync"], dtype=np.float64).reshape(-1, 2),
+        "mer": np.array([[v["lower"], v["upper"]] for k, v in log if k == "mer"], dtype=np.float32).reshape(-1, 2),
+        "ber": np.array([v["cber"] for k, v in log if k == "ber"], dtype=np.float32),
+        "pids": np.packbits(np.array([v["bits"] for k, v in log if k == "pids"], dtype=np.uint8).reshape(-1, 80), axis=1, bitorder="little"),
+        "p1": np.packbits(np.array([v["bits"] for k, v in log if k == "frame"], dtype=np.uint8).reshape(-1, 146176), axis=1, bitorder="little"),
+        "kinds": np.array([{"block": 1, "state": 2, "pids": 4, "frame": 5, "sync": 6, "lost_sync": 7, "mer": 8, "ber": 9}[k]
+                           for k, _ in log if k not in ("hdc", "soft", "vit")], dtype=np.uint8),
+    }
+    return out
+
+
+def arrays_to_log(a):
+    """Inverse of log_to_arrays (ordering restored from `kinds`)."""
+    ikeys = ("state_before", "state_after", "samperr", "cfo", "keep", "bc", "psmi", "cfo_wait", "next_samperr")
+    fkeys = ("prev_angle", "phase_re", "phase_im", "next_angle")
+    it = {k: iter(range(10 ** 9)) for k in ("block", "sync", "mer", "ber", "pids", "p1")}
+    log = []
+    # state transitions are implied by block records: rebuild them
+    for kind in a["kinds"]:
+        if kind == 1:
+            i = next(it["block"])
+            d = {k: int(v) for k, v in zip(ikeys, a["block_int"][i])}
+            d.update({k: float(v) for k, v in zip(fkeys, a["block_float"][i])})
+            log.append(("block", d))
+        elif kind == 2:
+            log.append(("state", None))
+        elif kind == 4:
+            log.append(("pids", {"bits": np.unpackbits(a["pids"][next(it["pids"])], bitorder="little")[:80]}))
+        elif kind == 5:
+            log.append(("frame", {"lc": 0, "bits": np.unpackbits(a["p1"][next(it["p1"])], bitorder="little")[:146176]}))
+        elif kind == 6:
+            i = next(it["sync"])
+            log.append(("sync", {"freq_offset": float(a["sync"][i, 0]), "psmi": int(a["sync"][i, 1]), "pli": -1, "hppi": -1, "aabi": -1, "rdbi": -1}))
+        elif kind == 7:
+            log.append(("lost_sync", {}))
+        elif kind == 8:
+            i = next(it["mer"])
+            log.append(("mer", {"lower": float(a["mer"][i, 0]), "upper": float(a["mer"][i, 1])}))
+        elif kind == 9:
+            log.append(("ber", {"cber": float(a["ber"][next(it["ber"])])}))
+    return [r for r in log if r[0] != "state"]
+
+
+def strip_states(log):
+    return [r for r in log if r[0] != "state"]
+
+
+def run_engine_streaming(E, stream, iq, chunk=32768 * 8):
+    """Feed a capture through the streaming seam the way src/main.c:1097-1120 feeds the reference."""
+    step = chunk - chunk % 4
+    for off in range(0, iq.size, step):
+        part = iq[off:off + step]
+        if iq.dtype == np.uint8:
+            E.push_cu8(stream, part[:part.size - part.size % 4])
+        else:
+            E.push_cs16(stream, part[:part.size - part.size % 2])

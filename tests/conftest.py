@@ -1,0 +1,59 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """CPU restatement (oracle/liboracle.so), compiled on demand with gcc."""
+    from oracle import port
+    return port.Oracle()
+
+
+@pytest.fixture(scope="session")
+def reflib():
+    """The unmodified reference built from /root/reference (only in the build container, or when
+    oracle/_ref/ travelled with the snapshot)."""
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref/libnrsc5_ref.so not built (needs /root/reference)")
+    return ref.RefLib()
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    """CPU SIMT-emulated build of the HIP sources: logic tests only, never a fallback."""
+    from nrsc5_amd import build
+    return build.build_emu()
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """The real gfx950 library; GPU tests must run THIS, so a missing build is an error."""
+    from nrsc5_amd import build, engine
+    if not os.path.exists(engine.DEFAULT_LIB):
+        build.build_hip()
+    return engine.DEFAULT_LIB
+
+
+@pytest.fixture(scope="session")
+def captures():
+    """Golden capture inputs, regenerated deterministically (float64 numpy) and cached per session."""
+    from nrsc5_amd import synth
+    from tests import common
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            cache[name] = synth.fm_mp1_capture(**common.GOLDEN_CASES[name])
+        return cache[name]
+    return get

@@ -1,0 +1,189 @@
+"""Parity checks of the HIP engine against the oracle / golden fixtures, written once and run twice:
+  * tests/test_emu_logic.py  -- on the CPU SIMT-emulated build (kernel LOGIC only, `-m "not gpu"`),
+  * tests/test_gpu_parity.py -- on the real gfx950 library through the C ABI (`-m gpu`)."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from tests import common
+from nrsc5_amd import engine as eng, synth
+
+GOLDEN_DIR = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def golden(name):
+    return dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+
+
+def check_halfband(lib, oracle, n=20011, seed=0):
+    rng = np.random.default_rng(seed)
+    E = eng.Engine(max_streams=1, q15_capacity=2 * 71280 + n, lib_path=lib)
+    for size in (4, 8, 60, 4 * 1021, 4 * n):               # ragged sizes incl. shorter than the filter
+        iq = rng.integers(0, 256, size=size, dtype=np.uint8)
+        got = E.stage_halfband_fm_cu8(iq)
+        exp, _ = oracle.halfband_fm_cu8(iq)
+        assert np.array_equal(got, exp), f"half-band mismatch at size {size}"
+    # extremes: full-scale input exercises the int16 accumulator range
+    iq = np.tile(np.array([255, 0, 0, 255], dtype=np.uint8), 512)
+    assert np.array_equal(E.stage_halfband_fm_cu8(iq), oracle.halfband_fm_cu8(iq)[0])
+    E.close()
+
+
+def check_halfband_streaming_history(lib, oracle):
+    """Chunked pushes carry the 14-sample history exactly like one big push."""
+    rng = np.random.default_rng(3)
+    iq = rng.integers(0, 256, size=4 * 30000, dtype=np.uint8)
+    exp, _ = oracle.halfband_fm_cu8(iq)
+    E = eng.Engine(max_streams=1, q15_capacity=200000, lib_path=lib)
+    cuts = [0, 4, 12, 4 * 7, 4 * 1000, 4 * 1003, 4 * 20000, iq.size]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        E.push_cu8(0, iq[a:b])
+    import ctypes
+    out = np.zeros((30000, 2), dtype=np.int16)
+    # the FIFO slab of stream 0 starts at q15[0]; nothing was consumed (30000 < 71280)
+    E.lib.nrsc5hip_debug_fetch  # keep symbol referenced
+    from nrsc5_amd.engine import _Config  # noqa: F401
+    got = _fetch_q15(E, 30000)
+    assert np.array_equal(got, exp)
+    E.close()
+
+
+def _fetch_q15(E, n):
+    """Reads the head of stream 0's FIFO through the stage API contract (test helper)."""
+    # re-decimating is not possible without the input; use the debug path: FIFO is exposed via
+    # a dedicated symbol only in the test helper below
+    import ctypes
+    fn = E.lib.nrsc5hip_debug_fetch_q15
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_longlong, ctypes.c_void_p]
+    out = np.zeros((n, 2), dtype=np.int16)
+    rc = fn(E._h, 0, n, out.ctypes.data)
+    assert rc == 0
+    return out
+
+
+def check_fft(lib, oracle, n=4, seed=1):
+    rng = np.random.default_rng(seed)
+    E = eng.Engine(max_streams=1, q15_capacity=2 * 71280, lib_path=lib)
+    x = (rng.standard_normal((n, 2048)) + 1j * rng.standard_normal((n, 2048))).astype(np.complex64)
+    x[0] = 0; x[0, 5] = 1.0                                   # impulse: every twiddle path
+    got = E.stage_fft2048(x)
+    ref = np.fft.fft(x.astype(np.complex128), axis=1)
+    err = np.linalg.norm(got - ref, axis=1) / np.maximum(np.linalg.norm(ref, axis=1), 1e-30)
+    assert err.max() < 1e-5, f"FFT relative L2 error {err.max()}"     # <= 1e-5 vs float64 DFT
+    orc = np.stack([oracle.fft(r) for r in x])
+    assert np.abs(got - orc).max() <= 1e-4 * np.abs(orc).max()
+    E.close()
+
+
+def check_viterbi(lib, oracle, lens=(80, 2304), frames=3, seed=2, structured=True):
+    rng = np.random.default_rng(seed)
+    E = eng.Engine(max_streams=1, q15_capacity=2 * 71280, lib_path=lib)
+    for L in lens:
+        soft = rng.integers(-127, 128, size=(frames, 3 * L), dtype=np.int8)
+        soft[:, 5::6] = 0                                      # punctured positions
+        if structured:
+            soft[0] = 0                                        # all-erasure frame: every ACS is a tie
+            soft[1, :] = 127                                   # saturated
+        got = E.stage_viterbi_k7(soft, L)
+        exp = np.stack([oracle.viterbi_k7(s) for s in soft])
+        assert np.array_equal(got, exp), f"Viterbi mismatch at len {L}"
+    E.close()
+
+
+def check_viterbi_roundtrip(lib, L=4608, frames=4, seed=9, flip=0.04):
+    """encode -> noisy channel -> decode returns the message (domain property, any size)."""
+    rng = np.random.default_rng(seed)
+    E = eng.Engine(max_streams=1, q15_capacity=2 * 71280, lib_path=lib)
+    msg = rng.integers(0, 2, size=(frames, L), dtype=np.uint8)
+    coded = synth.conv_encode_k7(msg).reshape(frames, 3 * L).astype(np.int16) * 2 - 1
+    soft = coded * 40 + rng.normal(0, 14, size=coded.shape)
+    soft[rng.random(coded.shape) < flip] *= -1
+    soft = np.clip(np.rint(soft), -127, 127).astype(np.int8)
+    soft[:, 5::6] = 0
+    got = E.stage_viterbi_k7(soft, L)
+    assert np.array_equal(got, msg)
+    E.close()
+
+
+def run_capture(lib, cap, p1_async=False, chunk=32768 * 8):
+    E = eng.Engine(max_streams=1, q15_capacity=max(2 * 71280 + chunk, 400000), lib_path=lib, p1_async=p1_async)
+    common.run_engine_streaming(E, 0, cap.iq, chunk=chunk)
+    recs = E.drain(0)
+    log = eng.records_to_log(E, 0, recs)
+    return E, recs, log
+
+
+def check_golden_end_to_end(lib, name, captures):
+    """Streaming seam vs the golden trace of the unmodified reference: frames exact, floats 1e-4."""
+    g = golden(name)
+    cap = captures(name)
+    assert common.sha256(cap.iq) == str(g["iq_sha"])
+    E, recs, log = run_capture(lib, cap)
+    diffs = common.compare_logs(common.arrays_to_log(g), common.strip_states(log))
+    assert not diffs, diffs[:10]
+    E.close()
+    return log
+
+
+def check_oracle_end_to_end(lib, oracle, kw, soft_tol=1):
+    from oracle import port
+    cap = synth.fm_mp1_capture(**kw)
+    ol, _, _ = oracle.run(cap.iq, taps=port.TAP_SOFT)
+    E, recs, log = run_capture(lib, cap)
+    diffs = common.compare_logs(common.strip_states(ol), common.strip_states(log))
+    assert not diffs, diffs[:10]
+    # soft bits are diagnostic: at most +-1 LSB on a small fraction of cells
+    softs = [v for k, v in ol if k == "soft"]
+    if softs:
+        pm, _ = E.debug_fetch(0)
+        last = softs[-1]
+        d = pm.reshape(16, 23040)[last["bc"]].astype(int) - last["bits"].astype(int)
+        assert np.abs(d).max() <= soft_tol and (d != 0).mean() < 0.01
+    E.close()
+    return log
+
+
+def check_batch_equals_streaming(lib, caps, p1_async):
+    """Batch path (device-resident captures, many streams per step) == per-stream streaming results."""
+    n = len(caps)
+    singles = []
+    for cap in caps:
+        E, recs, log = run_capture(lib, cap)
+        singles.append(log)
+        E.close()
+    longest = max(c.iq.size for c in caps)
+    stride = (longest + 15) // 16 * 16
+    host = np.zeros((n, stride), dtype=np.uint8)
+    for k, c in enumerate(caps):
+        host[k, :c.iq.size] = c.iq
+    E = eng.Engine(max_streams=n, q15_capacity=stride // 4 + 1024, record_capacity=256, p1_slots=4, p1_async=p1_async, lib_path=lib)
+    dev = _to_device(E, host)
+    E.batch_append_cu8(dev, stride, [c.iq.size - c.iq.size % 4 for c in caps])
+    steps = E.batch_process(n)
+    recs, counts, frames = E.batch_fetch(n)
+    for k in range(n):
+        log = eng.records_to_log(E, k, recs[k, :counts[k]], frames[k])
+        diffs = common.compare_logs(singles[k], log, rtol=0.0)
+        assert not diffs, (k, diffs[:10])
+    _free_device(E, dev)
+    E.close()
+    return steps
+
+
+def _to_device(E, host: np.ndarray) -> int:
+    import ctypes
+    fn = E.lib.nrsc5hip_debug_alloc_copy
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    fn.restype = ctypes.c_void_p
+    p = fn(host.ctypes.data, host.nbytes)
+    assert p
+    return p
+
+
+def _free_device(E, p: int):
+    import ctypes
+    fn = E.lib.nrsc5hip_debug_free
+    fn.argtypes = [ctypes.c_void_p]
+    fn(p)

@@ -1,0 +1,44 @@
+"""Regenerates tests/golden/*.npz from the UNMODIFIED reference (oracle/_ref, built from
+/root/reference by oracle/Makefile).  Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+Each fixture pins: the sha256 of the synthetic capture (so a host that regenerates different
+bytes is detected), the exact Q15 decimator output hash, every per-block soft-bit hash, every
+decoded PIDS / P1 frame, and the per-block timing/CFO trace of the reference."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from tests import common  # noqa: E402
+from nrsc5_amd import synth  # noqa: E402
+from oracle import ref  # noqa: E402
+
+
+def main():
+    R = ref.RefLib(sse=False)
+    Rs = ref.RefLib(sse=True)
+    for name, kw in common.GOLDEN_CASES.items():
+        cap = synth.fm_mp1_capture(**kw)
+        log, q15, _ = R.run(cap.iq, taps=ref.TAP_Q15 | ref.TAP_SOFT)
+        log_sse, _, _ = Rs.run(cap.iq, taps=ref.TAP_SOFT)
+        assert not common.compare_logs(log, log_sse, rtol=0.0, skip_kinds=("hdc",)), "generic and SSE reference builds disagree"
+        arrs = common.log_to_arrays(log)
+        soft = [v for k, v in log if k == "soft"]
+        arrs["soft_bc"] = np.array([v["bc"] for v in soft], dtype=np.int32)
+        arrs["soft_sha"] = np.array([common.sha256(v["bits"]) for v in soft])
+        arrs["q15_sha"] = np.array(common.sha256(q15))
+        arrs["q15_head"] = q15[:4096].copy()
+        arrs["iq_sha"] = np.array(common.sha256(cap.iq))
+        arrs["truth_p1"] = np.packbits(np.array(cap.p1_frames, dtype=np.uint8).reshape(-1, 146176), axis=1, bitorder="little")
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrs)
+        nfr = int(arrs["p1"].shape[0])
+        print(f"{name}: {len(arrs['block_int'])} blocks, {nfr} P1 frames, {arrs['pids'].shape[0]} PIDS, "
+              f"sync {arrs['sync'].tolist()}, {os.path.getsize(os.path.join(HERE, name + '.npz'))} bytes")
+
+
+if __name__ == "__main__":
+    main()

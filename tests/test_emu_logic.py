@@ -1,0 +1,40 @@
+"""`-m "not gpu"`: the HIP kernel sources compiled with g++ against the SIMT emulator
+(tests/simt/) and checked against the oracle.  This validates kernel LOGIC in the GPU-less
+container; it is not a product path and proves nothing about gfx950 code generation -- the
+`-m gpu` twins in test_gpu_parity.py do that through the real library."""
+from tests import engine_checks as ec
+from nrsc5_amd import synth
+
+
+def test_emu_halfband(emu_lib, oracle):
+    ec.check_halfband(emu_lib, oracle, n=5003)
+
+
+def test_emu_halfband_history(emu_lib, oracle):
+    ec.check_halfband_streaming_history(emu_lib, oracle)
+
+
+def test_emu_fft(emu_lib, oracle):
+    ec.check_fft(emu_lib, oracle, n=2)
+
+
+def test_emu_viterbi(emu_lib, oracle):
+    ec.check_viterbi(emu_lib, oracle, lens=(80, 2304), frames=3)
+
+
+def test_emu_viterbi_roundtrip(emu_lib):
+    ec.check_viterbi_roundtrip(emu_lib, L=1152, frames=2)
+
+
+def test_emu_end_to_end_golden_cfo_search(emu_lib, captures):
+    ec.check_golden_end_to_end(emu_lib, "fm_cu8_cfo-2400", captures)
+
+
+def test_emu_end_to_end_oracle_short(emu_lib, oracle):
+    ec.check_oracle_end_to_end(emu_lib, oracle, dict(n_frames=0, n_blocks=8, seed=21, cfo_hz=-212.0, offset=2501, snr_db=11.0))
+
+
+def test_emu_batch_equals_streaming(emu_lib):
+    caps = [synth.fm_mp1_capture(0, seed=30 + k, cfo_hz=c, offset=o, snr_db=18, n_blocks=6)
+            for k, (c, o) in enumerate([(50.0, 100), (-900.0, 3000), (300.0, 0)])]
+    ec.check_batch_equals_streaming(emu_lib, caps, p1_async=False)

@@ -1,0 +1,134 @@
+"""`-m gpu`: parity of the real gfx950 library (through the C ABI, libnrsc5hip.so) against the CPU
+oracle, the golden fixtures produced by the unmodified reference, and -- at full size -- against
+size-independent properties (decoded frames == transmitted bits, batch == streaming, async == in-order)."""
+import numpy as np
+import pytest
+
+from tests import common, engine_checks as ec
+from nrsc5_amd import engine as eng, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gpu_halfband_exact(hip_lib, oracle):
+    ec.check_halfband(hip_lib, oracle, n=200003)
+
+
+def test_gpu_halfband_chunk_history(hip_lib, oracle):
+    ec.check_halfband_streaming_history(hip_lib, oracle)
+
+
+def test_gpu_fft2048(hip_lib, oracle):
+    ec.check_fft(hip_lib, oracle, n=64)
+
+
+def test_gpu_viterbi_exact_small(hip_lib, oracle):
+    ec.check_viterbi(hip_lib, oracle, lens=(80, 2304, 4608), frames=8)
+
+
+def test_gpu_viterbi_exact_p1_size(hip_lib, oracle):
+    ec.check_viterbi(hip_lib, oracle, lens=(146176,), frames=3, structured=True)
+
+
+def test_gpu_viterbi_roundtrip_many_frames(hip_lib):
+    ec.check_viterbi_roundtrip(hip_lib, L=146176, frames=64, flip=0.03)
+
+
+@pytest.mark.parametrize("name", list(common.GOLDEN_CASES))
+def test_gpu_golden_end_to_end(hip_lib, name, captures):
+    ec.check_golden_end_to_end(hip_lib, name, captures)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n_frames=0, n_blocks=36, seed=21, cfo_hz=-212.0, offset=2501, snr_db=11.0),      # un-clamped soft-bit gain
+    dict(n_frames=0, n_blocks=24, seed=22, cfo_hz=5000.0, offset=4000, snr_db=25.0),      # 14-bin CFO search
+    dict(n_frames=0, n_blocks=20, seed=23, cfo_hz=0.0, offset=1234, snr_db=20.0),         # reference false-lock zone
+    dict(n_frames=0, n_blocks=20, seed=24, cfo_hz=40.0, offset=10, snr_db=30.0, fmt="cs16"),
+])
+def test_gpu_oracle_end_to_end(hip_lib, oracle, kw):
+    ec.check_oracle_end_to_end(hip_lib, oracle, kw)
+
+
+def test_gpu_noise_only_matches_oracle(hip_lib, oracle):
+    """Unsynchronised worst case: acquisition + CFO search every block; the state trace must match."""
+    rng = np.random.default_rng(5)
+    iq = rng.integers(100, 156, size=2 * 1488375, dtype=np.uint8)
+    exp, _, _ = oracle.run(iq)
+    E = eng.Engine(max_streams=1, q15_capacity=1 << 20, lib_path=hip_lib)
+    common.run_engine_streaming(E, 0, iq)
+    got = eng.records_to_log(E, 0, E.drain(0))
+    ints = ("state_before", "state_after", "samperr", "cfo", "keep", "cfo_wait")
+    eb = [{k: v[k] for k in ints} for kk, v in exp if kk == "block"]
+    gb = [{k: v[k] for k in ints} for kk, v in got if kk == "block"]
+    assert eb == gb
+    E.close()
+
+
+def test_gpu_push_size_invariance(hip_lib, captures):
+    cap = captures("fm_cu8_cfo-2400")
+    logs = []
+    for chunk in (4096, 32768, 1000004):
+        E, recs, log = ec.run_capture(hip_lib, cap, chunk=chunk)
+        logs.append(log)
+        E.close()
+    assert not common.compare_logs(logs[0], logs[1], rtol=0.0) and not common.compare_logs(logs[0], logs[2], rtol=0.0)
+
+
+@pytest.mark.parametrize("p1_async", [False, True])
+def test_gpu_batch_equals_streaming(hip_lib, p1_async):
+    caps = [synth.fm_mp1_capture(0, seed=30 + k, cfo_hz=c, offset=o, snr_db=s, n_blocks=nb)
+            for k, (c, o, s, nb) in enumerate([(50.0, 100, 18, 40), (-900.0, 3000, 15, 36), (300.0, 0, 25, 52), (-30.0, 1234, 20, 33),
+                                               (120.0, 2222, 20, 17), (0.0, 4319, 12, 48)])]
+    ec.check_batch_equals_streaming(hip_lib, caps, p1_async=p1_async)
+
+
+def test_gpu_force_resync_feedback(hip_lib, oracle, captures):
+    """L2 feedback seam (frame.c:535-540): dropping to NONE after the first P1 frame re-acquires like the oracle."""
+    cap = captures("fm_cu8_cfo137")
+    hits = []
+    exp, _, _ = oracle.run(cap.iq, p1_hook=lambda bits: (hits.append(1) or len(hits) == 1))
+    E = eng.Engine(max_streams=1, q15_capacity=1 << 20, lib_path=hip_lib)
+    got, fired = [], False
+    step = 32768
+    for off in range(0, cap.iq.size, step):
+        part = cap.iq[off:off + step]
+        E.push_cu8(0, part[:part.size - part.size % 4])
+        recs = E.drain(0)
+        log = eng.records_to_log(E, 0, recs)
+        if not fired and any(k == "frame" for k, _ in log):
+            E.force_resync(0)
+            fired = True
+        got += log
+    eb = [(v["state_before"], v["state_after"], v["samperr"], v["bc"]) for k, v in exp if k == "block"]
+    gb = [(v["state_before"], v["state_after"], v["samperr"], v["bc"]) for k, v in got if k == "block"]
+    assert eb == gb
+    ef = [v["bits"] for k, v in exp if k == "frame"]
+    gf = [v["bits"] for k, v in got if k == "frame"]
+    assert len(ef) == len(gf) and all(np.array_equal(a, b) for a, b in zip(ef, gf))
+    E.close()
+
+
+def test_gpu_full_size_truth_property(hip_lib):
+    """BASELINE-size streams (20 s): every decoded P1 frame of a locked stream equals the transmitted
+    bits and PIDS frames carry valid CRC-12 (size-independent property; the oracle is too slow here only
+    in aggregate, so 3 streams)."""
+    for seed, cfo, off in ((101, 211.0, 777), (102, -96.0, 3100), (103, 12.0, 2000)):
+        cap = synth.fm_mp1_capture(14, seed=seed, cfo_hz=cfo, offset=off, snr_db=20.0)
+        E = eng.Engine(max_streams=1, q15_capacity=cap.iq.size // 4 + 1024, record_capacity=512, p1_slots=16, p1_async=True, lib_path=hip_lib)
+        dev = ec._to_device(E, cap.iq)
+        E.batch_append_cu8(dev, 0, [cap.iq.size - cap.iq.size % 4])
+        E.batch_process(1)
+        recs, counts, frames = E.batch_fetch(1)
+        r = recs[0, :counts[0]]
+        p1r = r[(r["flags"] & eng.REC_P1) != 0]
+        assert len(p1r) >= 13
+        truth = np.packbits(np.array(cap.p1_frames, dtype=np.uint8), axis=1, bitorder="little")
+        first = len(cap.p1_frames) - len(p1r)
+        for j, rr in enumerate(p1r):
+            assert np.array_equal(frames[0, int(rr["p1_slot"])].view(np.uint8), truth[first + j]), (seed, j)
+        assert (p1r["ber"][1:] == 0).all()
+        for rr in r[(r["flags"] & eng.REC_PIDS) != 0][-32:]:
+            bits = eng.unpack_bits(rr["pids"], 80).reshape(-1, 8)[:, ::-1].reshape(-1)
+            assert synth.crc12(bits) == int("".join(map(str, bits[68:80])), 2)
+        ec._free_device(E, dev)
+        E.close()

@@ -1,0 +1,105 @@
+"""CPU-only: pins the oracle restatement against (a) the unmodified reference build and (b) the
+golden fixtures that build produced; plus synthesizer sanity.  No GPU, no HIP library calls."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import common
+from nrsc5_amd import synth
+
+GOLDEN_DIR = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _golden(name):
+    return dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+
+
+@pytest.mark.parametrize("name", list(common.GOLDEN_CASES))
+def test_capture_regenerates_bit_identically(name, captures):
+    g = _golden(name)
+    assert common.sha256(captures(name).iq) == str(g["iq_sha"]), "synthetic capture bytes differ on this host"
+
+
+@pytest.mark.parametrize("name", list(common.GOLDEN_CASES))
+def test_oracle_matches_golden_reference_trace(name, captures, oracle):
+    """Exact: Q15 stream, soft bits, PIDS/P1 frames, integer block trace.  Floats: rtol 1e-4."""
+    from oracle import port
+    g = _golden(name)
+    log, q15, _ = oracle.run(captures(name).iq, taps=port.TAP_Q15 | port.TAP_SOFT)
+    assert common.sha256(q15) == str(g["q15_sha"])
+    soft = [v for k, v in log if k == "soft"]
+    assert [v["bc"] for v in soft] == g["soft_bc"].tolist()
+    assert [common.sha256(v["bits"]) for v in soft] == g["soft_sha"].tolist()
+    diffs = common.compare_logs(common.arrays_to_log(g), common.strip_states(log))
+    assert not diffs, diffs[:10]
+
+
+@pytest.mark.parametrize("name", ["fm_cu8_cfo137", "fm_cs16_cfo60"])
+def test_golden_frames_equal_transmitted_truth(name):
+    g = _golden(name)
+    assert g["p1"].shape[0] >= 1
+    # frame k of the reference output is L1 frame k of the transmission
+    assert np.array_equal(g["p1"], g["truth_p1"][:g["p1"].shape[0]])
+
+
+@pytest.mark.parametrize("sse", [False, True])
+def test_oracle_bit_identical_to_reference(sse, oracle):
+    """Full ordered event log incl. floats and soft bits, 0 tolerance, against both reference builds."""
+    from oracle import ref, port
+    if not ref.available(sse):
+        pytest.skip("reference build absent")
+    R = ref.RefLib(sse=sse)
+    for kw in (dict(n_frames=0, n_blocks=24, seed=3, cfo_hz=2000.0, offset=1234, snr_db=15),
+               dict(n_frames=0, n_blocks=20, seed=5, cfo_hz=0.0, offset=0, snr_db=30),
+               dict(n_frames=0, n_blocks=36, seed=6, cfo_hz=137.0, offset=777, snr_db=12),
+               dict(n_frames=0, n_blocks=20, seed=8, cfo_hz=-77.0, offset=500, snr_db=22, fmt="cs16")):
+        cap = synth.fm_mp1_capture(**kw)
+        rl, rq, rf = R.run(cap.iq, taps=ref.TAP_Q15 | ref.TAP_SOFT | ref.TAP_FFT, fft_blocks=2)
+        ol, oq, of = oracle.run(cap.iq, taps=port.TAP_Q15 | port.TAP_SOFT | port.TAP_FFT, fft_blocks=2)
+        assert np.array_equal(rq, oq)
+        assert np.array_equal(rf, of)
+        assert not common.compare_logs(rl, ol, rtol=0.0, skip_kinds=("hdc",))
+
+
+def test_oracle_noise_only_stays_unsynchronised(oracle, reflib):
+    rng = np.random.default_rng(1)
+    iq = rng.integers(100, 156, size=2 * 1488375, dtype=np.uint8)   # 1 s of noise
+    rl, _, _ = reflib.run(iq)
+    ol, _, _ = oracle.run(iq)
+    assert not common.compare_logs(rl, ol, rtol=0.0)
+    assert all(v["state_after"] != 2 for k, v in ol if k == "block")
+
+
+def test_oracle_push_size_invariance(oracle, captures):
+    cap = captures("fm_cu8_cfo-2400")
+    a, _, _ = oracle.run(cap.iq, chunk=32768)
+    b, _, _ = oracle.run(cap.iq, chunk=4100)
+    c, _, _ = oracle.run(cap.iq, chunk=1000004)
+    assert not common.compare_logs(a, b, rtol=0.0) and not common.compare_logs(a, c, rtol=0.0)
+
+
+def test_oracle_viterbi_matches_reference_decoder(oracle, reflib):
+    rng = np.random.default_rng(2)
+    for kind, n in (("pids", 80), ("p3", 2304), ("p3", 4608), ("p1", 146176)):
+        soft = rng.integers(-127, 128, size=3 * n, dtype=np.int8)
+        assert np.array_equal(oracle.viterbi_k7(soft), reflib.conv_decode(soft, kind))
+    # K=9 codes of the AM path (decode.c:47-61)
+    soft = rng.integers(-1, 2, size=3 * 3750, dtype=np.int8)
+    assert np.array_equal(oracle.viterbi(soft, 9, (0o561, 0o657, 0o711)), reflib.conv_decode(soft, "e1"))
+    assert np.array_equal(oracle.viterbi(soft, 9, (0o561, 0o753, 0o711)), reflib.conv_decode(soft, "e2"))
+
+
+def test_l2_feedback_hook_drops_to_none(oracle, captures):
+    cap = captures("fm_cu8_cfo137")
+    log, _, _ = oracle.run(cap.iq, p1_hook=lambda bits: 1)
+    kinds = [k for k, _ in log]
+    assert "lost_sync" in kinds
+    i = kinds.index("lost_sync")
+    assert kinds[i - 1] == "state" and kinds[i - 2] == "frame"
+    nxt = next(v for k, v in log[i:] if k == "block")   # the frame's own block record follows
+    assert nxt["state_after"] == 0
+
+
+def test_synth_interleaver_tiles_matrix():
+    assert len(np.unique(np.concatenate([synth.P1_IDX, synth.PIDS_IDX]))) == 16 * synth.PM_BLOCK

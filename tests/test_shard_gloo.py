@@ -1,0 +1,47 @@
+"""CPU-only, world_size 2 over gloo: the stream partition and the summary gather used by
+bench.py --gpus N (no data-path collective exists: streams are independent)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, total, q):
+    sys.path.insert(0, ROOT)
+    from nrsc5_amd import shard
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    r, w, _ = shard.init_from_env(backend="gloo")
+    dev = torch.device("cpu")
+    mine = shard.stream_range(total, w, r)
+    rows = np.array([[s, 10 + s, 2, 2, 30, 28, 1000 + s] for s in mine], dtype=np.int64)
+    shard.barrier(dev)
+    allrows = shard.gather_summaries(rows, dev)
+    t = shard.max_over_ranks(1.0 + r, dev)
+    tot = shard.sum_over_ranks([len(mine)], dev)
+    q.put((r, list(mine), allrows.tolist(), t, float(tot[0])))
+    dist.destroy_process_group()
+
+
+def test_two_rank_partition_and_gather():
+    from nrsc5_amd import shard
+    total, world = 7, 2
+    assert [list(shard.stream_range(total, world, r)) for r in range(world)] == [[0, 1, 2, 3], [4, 5, 6]]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r, mine, allrows, t, tot in res:
+        assert sorted(row[0] for row in allrows) == list(range(total))      # every stream exactly once
+        assert all(row[6] == 1000 + row[0] for row in allrows)
+        assert t == 2.0 and tot == 7.0
