@@ -265,7 +265,7 @@ static int issue_step(nrsc5hip_engine *e, int n, const int *ids_dev)
         e->decoded_pending[parity] = false;
     }
     if (e->acq_needed) { ProfScope p(e, NRSC5HIP_PROF_ACQUIRE, e->main); launch_acquire(e->tb, e->db, n, ids_dev, e->main); }
-    { ProfScope p(e, NRSC5HIP_PROF_PREPARE, e->main); launch_prepare(e->db, n, ids_dev, e->main); }
+    { ProfScope p(e, NRSC5HIP_PROF_PREPARE, e->main); launch_prepare(e->db, n, ids_dev, parity, e->main); }
     { ProfScope p(e, NRSC5HIP_PROF_MIXFFT, e->main); launch_mixfft(e->tb, e->db, n, ids_dev, e->main); }
     { ProfScope p(e, NRSC5HIP_PROF_SYNC, e->main); launch_sync(e->tb, e->db, n, ids_dev, parity, e->main); }
     { ProfScope p(e, NRSC5HIP_PROF_P1_DEINT, e->main); launch_p1_deint(e->tb, e->db, n, ids_dev, parity, e->main); }

@@ -125,12 +125,15 @@ void launch_acquire(const DevTables &tb, const DevBuffers &db, int nstreams, con
 }
 
 // ---- per-block bookkeeping (acquire.c:98-119,153-168) ----------------------------------------------------
-__global__ void k_prepare(DevBuffers db, const int *ids, int nstreams)
+__global__ void k_prepare(DevBuffers db, const int *ids, int nstreams, int parity)
 {
     const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
     if (sidx >= nstreams) return;
     const int s = stream_of(ids, sidx);
     StreamState &st = db.state[s];
+    // a frame completed in an earlier step of this decode window has been gathered by k_p1_deint of that
+    // step: freeze it (the interleaver matrix is already being refilled with the next frame's blocks)
+    if (st.p1_pending[parity] == 1) st.p1_pending[parity] = 2;
     if (st.sync_state != SYNC_FINE) atomicAdd(&db.counters[1], 1);   // host: keep launching acquisition
     st.active = window_ready(st) ? 1 : 0;
     if (!st.active) return;
@@ -175,9 +178,9 @@ __global__ void k_prepare(DevBuffers db, const int *ids, int nstreams)
     st.theta = th;
 }
 
-void launch_prepare(const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st)
+void launch_prepare(const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_prepare, dim3((nstreams + 63) / 64), dim3(64), 0, st, db, stream_ids, nstreams);
+    hipLaunchKernelGGL(k_prepare, dim3((nstreams + 63) / 64), dim3(64), 0, st, db, stream_ids, nstreams, parity);
 }
 
 }  // namespace nrsc5

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void k_p1_deint(DevTables tb, DevBuffers db, c
 {
     const int s = stream_of(ids, blockIdx.y);
     const StreamState &st = db.state[s];
-    if (!st.p1_pending[parity]) return;
+    if (st.p1_pending[parity] != 1) return;                    // 1 = completed in this step, 2 = already gathered
     const int8_t *pm = db.pm + (size_t)s * PM_FRAME;
     int8_t *out = db.coded + ((size_t)s * 2 + parity) * P1_DEPUNCT;
     const int g = blockIdx.x * blockDim.x + threadIdx.x;       // group index

@@ -44,7 +44,7 @@ void launch_append_cs16(const DevBuffers &db, int nstreams, const int *stream_id
 
 // ---- one block step for a set of streams ----------------------------------------------------
 void launch_acquire(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
-void launch_prepare(const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
+void launch_prepare(const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st);
 void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
 void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st);
 void launch_p1_deint(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st);

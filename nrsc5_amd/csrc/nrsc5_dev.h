@@ -92,7 +92,7 @@ struct StreamState {
     double dtheta;              // effective NCO step (rad/sample) for the current block
     int coarse_samperr; float coarse_re, coarse_im;
     // P1 hand-off, double-buffered by decode-window parity (see engine.hip: P1 pipeline)
-    int p1_pending[2];          // a de-interleaved frame is waiting in coded[s][parity]
+    int p1_pending[2];          // 1: frame completed this step (gather it), 2: gathered into coded[s][parity]
     int p1_slot[2];             // slot of the stream's P1 ring the decoder must fill
     int p1_record[2];           // record index that gets the BER
 };

@@ -38,3 +38,11 @@ def test_emu_batch_equals_streaming(emu_lib):
     caps = [synth.fm_mp1_capture(0, seed=30 + k, cfo_hz=c, offset=o, snr_db=18, n_blocks=6)
             for k, (c, o) in enumerate([(50.0, 100), (-900.0, 3000), (300.0, 0)])]
     ec.check_batch_equals_streaming(emu_lib, caps, p1_async=False)
+
+
+def test_emu_async_p1_window_pipeline(emu_lib):
+    """Frames that complete in the middle of a 16-step decode window (first block spent in COARSE)
+    must be gathered exactly once, before the interleaver matrix is refilled."""
+    caps = [synth.fm_mp1_capture(0, seed=40 + k, cfo_hz=c, offset=o, snr_db=14, n_blocks=nb)
+            for k, (c, o, nb) in enumerate([(0.0, 4319, 20), (350.0, 100, 19)])]
+    ec.check_batch_equals_streaming(emu_lib, caps, p1_async=True)
