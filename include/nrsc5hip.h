@@ -142,6 +142,8 @@ int nrsc5hip_stage_halfband_fm_cu8(nrsc5hip_engine *e, const uint8_t *iq, uint32
 int nrsc5hip_stage_fft2048(nrsc5hip_engine *e, const float *in /* [n][2048][2] */, float *out, int n);
 int nrsc5hip_stage_viterbi_k7(nrsc5hip_engine *e, const int8_t *soft /* [nframes][3*len] */, int len, int nframes,
                               uint8_t *bits /* [nframes][len] */);
+/* device check of the DPP / v_permlane / v_writelane / v_dot4 helpers against generic shuffles: *failures == 0 */
+int nrsc5hip_stage_selftest(nrsc5hip_engine *e, int *failures);
 /* debugging aid: soft-bit matrix (16 x 23040 int8) and live FFT bins of a stream's latest block */
 int nrsc5hip_debug_fetch(nrsc5hip_engine *e, int stream, int8_t *pm /* [368640] or NULL */, float *bins /* [32][534][2] or NULL */);
 

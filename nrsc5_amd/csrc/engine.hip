@@ -650,3 +650,13 @@ extern "C" int nrsc5hip_profile(nrsc5hip_engine *e, int enable, double *total_ms
     if (enable >= 0) e->prof_on = enable != 0;
     return 0;
 }
+
+extern "C" int nrsc5hip_stage_selftest(nrsc5hip_engine *e, int *failures)
+{
+    if (!e || !failures) FAIL(NRSC5HIP_EINVAL, "null argument");
+    HIPCHK(hipMemsetAsync(e->db.counters + 2, 0, sizeof(int), e->main));
+    launch_selftest(e->db.counters + 2, e->main);
+    HIPCHK(hipMemcpyAsync(failures, e->db.counters + 2, sizeof(int), hipMemcpyDeviceToHost, e->main));
+    HIPCHK(hipStreamSynchronize(e->main));
+    return 0;
+}

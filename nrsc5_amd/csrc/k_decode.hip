@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64) void k_p1_viterbi(DevTables tb, DevBuffers db, 
     unsigned long long *dec = db.dec + (size_t)s * (P1_LEN + 64);
     uint32_t *out = db.p1_ring + ((size_t)s * db.p1_slots + st.p1_slot[parity]) * P1_WORDS;
 
-    viterbi_k7_wave(coded, P1_LEN, dec, out);
+    viterbi_k7_decode(coded, P1_LEN, dec, out);
     __threadfence_block();
     __syncthreads();                                           // out[] written by lane 0, read by all
     const int errors = bit_errors_k7_wave(coded, out, P1_LEN);
@@ -91,12 +91,35 @@ void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, 
 __global__ __launch_bounds__(64) void k_viterbi_frames(const int8_t *coded, int len, unsigned long long *dec, uint32_t *out)
 {
     const int f = blockIdx.x;
-    viterbi_k7_wave(coded + (size_t)f * 3 * len, len, dec + (size_t)f * (len + 64), out + (size_t)f * ((len + 31) / 32));
+    viterbi_k7_decode(coded + (size_t)f * 3 * len, len, dec + (size_t)f * (len + 64), out + (size_t)f * ((len + 31) / 32));
 }
 
 void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st)
 {
     hipLaunchKernelGGL(k_viterbi_frames, dim3(nframes), dim3(64), 0, st, coded, len, dec, out);
 }
+
+// ---- device self-test of the register-file lane exchanges against the generic shuffle ----------------
+__global__ __launch_bounds__(64) void k_selftest(int *fail)
+{
+    const int lane = threadIdx.x & 63;
+    int bad = 0;
+    for (int rep = 0; rep < 4; rep++) {
+        const int v = (lane * 2654435 + rep * 977) ^ (lane << 20);
+        bad += lane_xor<1>(v) != __shfl_xor(v, 1);
+        bad += lane_xor<2>(v) != __shfl_xor(v, 2);
+        bad += lane_xor<4>(v) != __shfl_xor(v, 4);
+        bad += lane_xor<8>(v) != __shfl_xor(v, 8);
+        bad += lane_xor<16>(v) != __shfl_xor(v, 16);
+        bad += lane_xor<32>(v) != __shfl_xor(v, 32);
+        int w = wave_writelane_c<37>(v, 12345);
+        bad += w != (lane == 37 ? 12345 : v);
+        const int a = (int)0x00817f05, b = (int)0x00ff0103;   // bytes (5,127,-127,0) . (3,1,-1,0) = 15+127+127
+        bad += dot4_i8(a, b, 7) != 7 + 15 + 127 + 127;
+    }
+    atomicAdd(fail, bad);
+}
+
+void launch_selftest(int *fail, hipStream_t st) { hipLaunchKernelGGL(k_selftest, dim3(4), dim3(64), 0, st, fail); }
 
 }  // namespace nrsc5

@@ -97,4 +97,137 @@ __device__ inline void viterbi_k7_wave(const int8_t *coded, int len, unsigned lo
     }
 }
 
+
+// =====================================================================================================
+// Fast path (len % 64 == 0: P1 146176, P3/P4 4608 / 2304): same trellis, same tie rule, same output bits,
+// restructured for the gfx950 register file:
+//
+//  * ROTATING LAYOUT.  Before step t lane L holds the metric of state rotr6^t(L).  The two predecessors
+//    2b, 2b+1 of a butterfly then always sit in lanes L and L ^ (1 << (t % 6)), so the exchange is a
+//    DPP / v_permlane swap (lane_xor<>) instead of two ds_bpermute round trips through the LDS crossbar,
+//    and the new metric max(own + m, partner - m) belongs in the same lane (state rotr6^(t+1)(L)).
+//  * the branch metric is one v_dot4_i32_i8 of the packed soft triple with per-lane, per-phase signs.
+//  * the stored decision bit is "the survivor came through MY lane" (own-wins), so the traceback runs in
+//    lane space: lane ^= (own ? 0 : 1 << (t % 6)); the decoded bit of step t is bit (t % 6) of the lane.
+//    Tie rule of the reference (`if (sum0 > sum1)`, ties -> predecessor 2b+1): own is the even
+//    predecessor when bit0(state) = 0 (strict >) and the odd one when bit0 = 1 (>=), i.e. X + s0 > Y.
+//  * 64 steps are unrolled at compile time so lane selects are inline constants (v_readlane/v_writelane).
+// =====================================================================================================
+
+__device__ __forceinline__ unsigned rotr6(unsigned v, int k) { k %= 6; return k ? (((v >> k) | (v << (6 - k))) & 63u) : (v & 63u); }
+__device__ __forceinline__ unsigned rotl6(unsigned v, int k) { k %= 6; return k ? (((v << k) | (v >> (6 - k))) & 63u) : (v & 63u); }
+
+struct VitFastConst { int sgw[6]; int s0[6]; };
+
+__device__ inline VitFastConst vit_fast_consts(int lane)
+{
+    VitFastConst k;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        const unsigned S = rotr6((unsigned)lane, r);           // state held by this lane in phase r
+        const unsigned reg = S & 0x3eu;                        // edge 2b -> b (gen_state_info, conv_dec.c:137-153)
+        const int g0 = (__popc(reg & 0133u) & 1) ? 1 : -1, g1 = (__popc(reg & 0171u) & 1) ? 1 : -1, g2 = (__popc(reg & 0165u) & 1) ? 1 : -1;
+        k.sgw[r] = (g0 & 0xff) | ((g1 & 0xff) << 8) | ((g2 & 0xff) << 16);
+        k.s0[r] = (int)(S & 1u);
+    }
+    return k;
+}
+
+template <int R>
+__device__ __forceinline__ unsigned long long vit_fast_step(int &pm, int a, const VitFastConst &k)
+{
+    const int m = dot4_i8(a, k.sgw[R], 0);
+    const int X = pm + m;
+    const int Y = lane_xor<(1 << R)>(pm) - m;
+    const bool own = (X + k.s0[R]) > Y;
+    pm = own ? X : Y;
+    return __ballot(own);
+}
+
+template <int PH0, int S> struct VitFwd {
+    static __device__ __forceinline__ void run(int &pm, int aw, const VitFastConst &k, int &wlo, int &whi)
+    {
+        const int a = wave_readlane(aw, S);
+        const unsigned long long b = vit_fast_step<(PH0 + S) % 6>(pm, a, k);
+        wlo = wave_writelane_c<S>(wlo, (int)(uint32_t)b);
+        whi = wave_writelane_c<S>(whi, (int)(uint32_t)(b >> 32));
+        VitFwd<PH0, S + 1>::run(pm, aw, k, wlo, whi);
+    }
+};
+template <int PH0> struct VitFwd<PH0, 64> {
+    static __device__ __forceinline__ void run(int &, int, const VitFastConst &, int &, int &) {}
+};
+
+template <int PH0, int S> struct VitBack {
+    static __device__ __forceinline__ void run(unsigned &l, int mlo, int mhi, unsigned &ohi, unsigned &olo)
+    {
+        constexpr int R = (PH0 + S) % 6;
+        const unsigned long long w = ((unsigned long long)(uint32_t)wave_readlane(mhi, S) << 32) | (uint32_t)wave_readlane(mlo, S);
+        const unsigned own = (unsigned)(w >> l) & 1u;
+        if (S >= 32) ohi = (ohi << 1) | ((l >> R) & 1u); else olo = (olo << 1) | ((l >> R) & 1u);
+        l ^= own ? 0u : (1u << R);
+        VitBack<PH0, S - 1>::run(l, mlo, mhi, ohi, olo);
+    }
+};
+template <int PH0> struct VitBack<PH0, -1> {
+    static __device__ __forceinline__ void run(unsigned &, int, int, unsigned &, unsigned &) {}
+};
+
+__device__ __forceinline__ int vit_load_soft(const int8_t *coded, int len, int t)
+{
+    const int j = (len - VIT_EXTRA + t) % len;                 // conv_dec.c:407-412
+    return ((int)(uint8_t)coded[3 * j]) | ((int)(uint8_t)coded[3 * j + 1] << 8) | ((int)(uint8_t)coded[3 * j + 2] << 16);
+}
+
+// requires len % 64 == 0; all 64 lanes
+__device__ inline void viterbi_k7_wave_fast(const int8_t *coded, int len, unsigned long long *dec, uint32_t *out)
+{
+    const int lane = threadIdx.x & 63;
+    const VitFastConst k = vit_fast_consts(lane);
+    const int nchunks = len / 64 + 1;                          // steps = len + 2 * VIT_EXTRA
+    int pm = 0;
+    int aw = vit_load_soft(coded, len, lane);
+    for (int c = 0; c < nchunks; c++) {
+        const int aw_next = (c + 1 < nchunks) ? vit_load_soft(coded, len, 64 * (c + 1) + lane) : 0;
+        int wlo = 0, whi = 0;
+        switch (c % 3) {                                       // (64 c) % 6
+        case 0: VitFwd<0, 0>::run(pm, aw, k, wlo, whi); break;
+        case 1: VitFwd<4, 0>::run(pm, aw, k, wlo, whi); break;
+        default: VitFwd<2, 0>::run(pm, aw, k, wlo, whi); break;
+        }
+        dec[64 * c + lane] = ((unsigned long long)(uint32_t)whi << 32) | (uint32_t)wlo;
+        aw = aw_next;
+    }
+
+    // end state: first maximum in STATE order (conv_dec.c:310-318); lane L holds state rotr6^steps(L)
+    const int rend = (64 * nchunks) % 6;
+    const int best = wave_max_i32(pm);
+    const int smin = wave_min_i32(pm == best ? (int)rotr6((unsigned)lane, rend) : 64);
+    unsigned l = (unsigned)wave_uniform((int)rotl6((unsigned)smin, rend));   // lane of the survivor, kept in an SGPR
+
+    for (int c = nchunks - 1; c >= 0; c--) {
+        const unsigned long long mine = dec[64 * c + lane];
+        const int mlo = (int)(uint32_t)mine, mhi = (int)(uint32_t)(mine >> 32);
+        unsigned ohi = 0, olo = 0;
+        l = (unsigned)wave_uniform((int)l);                    // keep the survivor chain on the scalar ALU
+        switch (c % 3) {
+        case 0: VitBack<0, 63>::run(l, mlo, mhi, ohi, olo); break;
+        case 1: VitBack<4, 63>::run(l, mlo, mhi, ohi, olo); break;
+        default: VitBack<2, 63>::run(l, mlo, mhi, ohi, olo); break;
+        }
+        // steps 64c+32..64c+63 -> out word 2c; steps 64c..64c+31 -> out word 2c-1 (bit = step & 31)
+        if (lane == 0) {
+            if (c < nchunks - 1) out[2 * c] = ohi;
+            if (c >= 1) out[2 * c - 1] = olo;
+        }
+    }
+}
+
+// dispatcher used by the kernels
+__device__ inline void viterbi_k7_decode(const int8_t *coded, int len, unsigned long long *dec, uint32_t *out)
+{
+    if ((len & 63) == 0) viterbi_k7_wave_fast(coded, len, dec, out);
+    else viterbi_k7_wave(coded, len, dec, out);
+}
+
 }  // namespace nrsc5

@@ -11,10 +11,72 @@ __device__ inline int wave_readlane(int v, int lane) { return __shfl(v, lane); }
 // v_readlane_b32: lane index must be wave-uniform
 __device__ __forceinline__ int wave_readlane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 #endif
+#ifdef HIPEMU
+__device__ inline int wave_uniform(int v) { return __shfl(v, 0); }
+#else
+// tell the compiler a value is wave-uniform (moves it to an SGPR: scalar ALU from here on)
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+#endif
 // place a wave-uniform value into one lane of a VGPR (v_cmp_eq + v_cndmask; v_writelane_b32 would need
 // the lane select as an inline constant next to an SGPR value -- constant-bus limit on gfx9-class VOP3)
 __device__ __forceinline__ int wave_writelane(int old, int sval, int lane) { return ((int)(threadIdx.x & 63) == lane) ? sval : old; }
 
+// write a wave-uniform value into lane LANE (compile-time) of a VGPR: one v_writelane_b32 (SGPR value +
+// inline-constant lane select fits the constant bus)
+template <int LANE> __device__ __forceinline__ int wave_writelane_c(int old, int sval)
+{
+#ifdef HIPEMU
+    return ((int)(threadIdx.x & 63) == LANE) ? sval : old;
+#else
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(sval), "n"(LANE));
+    return old;
+#endif
+}
+
+// lane_xor<M>(v): value of lane (id ^ M), M a power of two.  On gfx950 these are register-file moves
+// (DPP quad_perm / row_ror, v_permlane16_swap, v_permlane32_swap) -- no LDS crossbar round trip as with
+// ds_bpermute.  Encodings are verified against __shfl_xor on the device by nrsc5hip_stage_selftest.
+template <int M> __device__ __forceinline__ int lane_xor(int v)
+{
+#ifdef HIPEMU
+    return __shfl_xor(v, M);
+#else
+    if constexpr (M == 1) return __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);        // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    else if constexpr (M == 4) {
+        const int t = __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xa, false);                  // row_ror:4 -> lanes 4-7, 12-15
+        return __builtin_amdgcn_update_dpp(t, v, 0x12C, 0xf, 0x5, false);                         // row_ror:12 -> lanes 0-3, 8-11
+    }
+    else if constexpr (M == 8) return __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);  // row_ror:8
+    else if constexpr (M == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);   // {vdst', vsrc'}: odd rows of vdst <-> even rows of vsrc
+        return (threadIdx.x & 16) ? (int)r[0] : (int)r[1];
+    }
+    else {
+        static_assert(M == 32, "lane_xor: M must be 1,2,4,8,16,32");
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);   // upper half of vdst <-> lower half of vsrc
+        return (threadIdx.x & 32) ? (int)r[0] : (int)r[1];
+    }
+#endif
+}
+
+// signed 4 x int8 dot product + accumulator (v_dot4_i32_i8)
+__device__ __forceinline__ int dot4_i8(int a, int b, int acc)
+{
+#ifdef HIPEMU
+    int s = acc;
+    for (int k = 0; k < 4; k++) s += (int)(int8_t)(a >> (8 * k)) * (int)(int8_t)(b >> (8 * k));
+    return s;
+#else
+    return __builtin_amdgcn_sdot4(a, b, acc, false);
+#endif
+}
+
+__device__ inline int wave_min_i32(int v)
+{
+    for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(v, m); v = o < v ? o : v; }
+    return v;
+}
 __device__ inline int wave_max_i32(int v)
 {
     for (int m = 32; m >= 1; m >>= 1) { int o = __shfl_xor(v, m); v = o > v ? o : v; }
