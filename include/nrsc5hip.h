@@ -144,6 +144,8 @@ int nrsc5hip_stage_viterbi_k7(nrsc5hip_engine *e, const int8_t *soft /* [nframes
                               uint8_t *bits /* [nframes][len] */);
 /* device check of the DPP / v_permlane / v_writelane / v_dot4 helpers against generic shuffles: *failures == 0 */
 int nrsc5hip_stage_selftest(nrsc5hip_engine *e, int *failures);
+/* one frame, also returning the len+64 survivor-decision words of the forward pass */
+int nrsc5hip_stage_viterbi_k7_debug(nrsc5hip_engine *e, const int8_t *soft, int len, uint8_t *bits, unsigned long long *dec_out);
 /* debugging aid: soft-bit matrix (16 x 23040 int8) and live FFT bins of a stream's latest block */
 int nrsc5hip_debug_fetch(nrsc5hip_engine *e, int stream, int8_t *pm /* [368640] or NULL */, float *bins /* [32][534][2] or NULL */);
 

@@ -660,3 +660,22 @@ extern "C" int nrsc5hip_stage_selftest(nrsc5hip_engine *e, int *failures)
     HIPCHK(hipStreamSynchronize(e->main));
     return 0;
 }
+
+extern "C" int nrsc5hip_stage_viterbi_k7_debug(nrsc5hip_engine *e, const int8_t *soft, int len, uint8_t *bits, unsigned long long *dec_out)
+{
+    if (!e || !soft || !bits || !dec_out || len < 64) FAIL(NRSC5HIP_EINVAL, "bad argument");
+    int8_t *dsoft = nullptr; unsigned long long *ddec = nullptr; uint32_t *dout = nullptr;
+    const int words = (len + 31) / 32;
+    HIPCHK(hipMalloc((void **)&dsoft, (size_t)3 * len));
+    HIPCHK(hipMalloc((void **)&ddec, (size_t)(len + 64) * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&dout, (size_t)words * sizeof(uint32_t)));
+    HIPCHK(hipMemcpy(dsoft, soft, (size_t)3 * len, hipMemcpyHostToDevice));
+    launch_viterbi_frames(dsoft, len, 1, ddec, dout, e->main);
+    HIPCHK(hipStreamSynchronize(e->main));
+    std::vector<uint32_t> w(words);
+    HIPCHK(hipMemcpy(w.data(), dout, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dec_out, ddec, (size_t)(len + 64) * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    nrsc5hip_unpack_bits(w.data(), len, bits);
+    (void)hipFree(dsoft); (void)hipFree(ddec); (void)hipFree(dout);
+    return 0;
+}

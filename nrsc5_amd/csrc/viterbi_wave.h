@@ -133,29 +133,36 @@ __device__ inline VitFastConst vit_fast_consts(int lane)
     return k;
 }
 
-template <int R>
-__device__ __forceinline__ unsigned long long vit_fast_step(int &pm, int a, const VitFastConst &k)
+// one trellis step in phase R with branch metric m; parks the previous step's ballot in lane PARK
+template <int R, int PARK>
+__device__ __forceinline__ unsigned long long vit_fast_step(int &pm, int m, const VitFastConst &k, unsigned long long prev, int &wlo, int &whi)
 {
-    const int m = dot4_i8(a, k.sgw[R], 0);
     const int X = pm + m;
     const int Y = lane_xor<(1 << R)>(pm) - m;
-    const bool own = (X + k.s0[R]) > Y;
-    pm = own ? X : Y;
-    return __ballot(own);
+    return acs_select_park<PARK>(pm, X, X + k.s0[R], Y, prev, wlo, whi);   // own-wins: X + s0 > Y
+}
+
+template <int R> __device__ __forceinline__ int vit_branch_metric(int aw, int s, const VitFastConst &k)
+{
+    return dot4_i8(wave_readlane(aw, s), k.sgw[R], 0);
 }
 
 template <int PH0, int S> struct VitFwd {
-    static __device__ __forceinline__ void run(int &pm, int aw, const VitFastConst &k, int &wlo, int &whi)
+    static __device__ __forceinline__ void run(int &pm, int aw, const VitFastConst &k, int m, unsigned long long prev, int &wlo, int &whi)
     {
-        const int a = wave_readlane(aw, S);
-        const unsigned long long b = vit_fast_step<(PH0 + S) % 6>(pm, a, k);
-        wlo = wave_writelane_c<S>(wlo, (int)(uint32_t)b);
-        whi = wave_writelane_c<S>(whi, (int)(uint32_t)(b >> 32));
-        VitFwd<PH0, S + 1>::run(pm, aw, k, wlo, whi);
+        // branch metric of the NEXT step first: it does not depend on the path metrics, so it fills the
+        // dependency stalls of this step's exchange/compare chain
+        const int m_next = (S + 1 < 64) ? vit_branch_metric<(PH0 + S + 1) % 6>(aw, (S + 1) & 63, k) : 0;
+        // S == 0 parks a dummy (lane 0 is rewritten by step 1 with the real ballot of step 0)
+        const unsigned long long b = vit_fast_step<(PH0 + S) % 6, (S == 0 ? 0 : S - 1)>(pm, m, k, prev, wlo, whi);
+        VitFwd<PH0, S + 1>::run(pm, aw, k, m_next, b, wlo, whi);
     }
 };
 template <int PH0> struct VitFwd<PH0, 64> {
-    static __device__ __forceinline__ void run(int &, int, const VitFastConst &, int &, int &) {}
+    static __device__ __forceinline__ void run(int &, int, const VitFastConst &, int, unsigned long long prev, int &wlo, int &whi)
+    {
+        park_ballot<63>(prev, wlo, whi);
+    }
 };
 
 template <int PH0, int S> struct VitBack {
@@ -191,9 +198,9 @@ __device__ inline void viterbi_k7_wave_fast(const int8_t *coded, int len, unsign
         const int aw_next = (c + 1 < nchunks) ? vit_load_soft(coded, len, 64 * (c + 1) + lane) : 0;
         int wlo = 0, whi = 0;
         switch (c % 3) {                                       // (64 c) % 6
-        case 0: VitFwd<0, 0>::run(pm, aw, k, wlo, whi); break;
-        case 1: VitFwd<4, 0>::run(pm, aw, k, wlo, whi); break;
-        default: VitFwd<2, 0>::run(pm, aw, k, wlo, whi); break;
+        case 0: VitFwd<0, 0>::run(pm, aw, k, vit_branch_metric<0>(aw, 0, k), 0ull, wlo, whi); break;
+        case 1: VitFwd<4, 0>::run(pm, aw, k, vit_branch_metric<4>(aw, 0, k), 0ull, wlo, whi); break;
+        default: VitFwd<2, 0>::run(pm, aw, k, vit_branch_metric<2>(aw, 0, k), 0ull, wlo, whi); break;
         }
         dec[64 * c + lane] = ((unsigned long long)(uint32_t)whi << 32) | (uint32_t)wlo;
         aw = aw_next;

@@ -33,6 +33,47 @@ template <int LANE> __device__ __forceinline__ int wave_writelane_c(int old, int
 #endif
 }
 
+// Fused ACS select for the rotating-layout Viterbi:
+//   ballot = (xc > y) per lane;  pm = ballot ? x : y;  and, in the shadow of the compare, the PREVIOUS
+//   step's ballot (plo, phi) is parked in lane LANE of (lo, hi).
+// v_writelane_b32 reads its SGPR data operand early in the pipe: it must not follow the VALU write of that
+// SGPR by fewer than ~4 wait states (observed on gfx950: a v_writelane right behind v_cmp stores the OLD
+// mask).  Writing the previous step's mask here guarantees >= 8 instructions of distance without s_nops.
+template <int LANE>
+__device__ __forceinline__ unsigned long long acs_select_park(int &pm, int x, int xc, int y, unsigned long long prev, int &lo, int &hi)
+{
+#ifdef HIPEMU
+    const bool own = xc > y;
+    pm = own ? x : y;
+    if ((int)(threadIdx.x & 63) == LANE) { lo = (int)(uint32_t)prev; hi = (int)(uint32_t)(prev >> 32); }
+    return __ballot(own);
+#else
+    unsigned long long b;
+    int npm;
+    const int plo = (int)(uint32_t)prev, phi = (int)(uint32_t)(prev >> 32);
+    asm("v_cmp_gt_i32_e64 %0, %5, %6\n\t"
+        "v_writelane_b32 %2, %7, %9\n\t"
+        "v_writelane_b32 %3, %8, %9\n\t"
+        "v_cndmask_b32_e64 %1, %6, %4, %0"
+        : "=&s"(b), "=v"(npm), "+v"(lo), "+v"(hi)
+        : "v"(x), "v"(xc), "v"(y), "s"(plo), "s"(phi), "n"(LANE));
+    pm = npm;
+    return b;
+#endif
+}
+
+// plain park with explicit wait states (chunk epilogue only)
+template <int LANE>
+__device__ __forceinline__ void park_ballot(unsigned long long v, int &lo, int &hi)
+{
+#ifdef HIPEMU
+    if ((int)(threadIdx.x & 63) == LANE) { lo = (int)(uint32_t)v; hi = (int)(uint32_t)(v >> 32); }
+#else
+    const int vlo = (int)(uint32_t)v, vhi = (int)(uint32_t)(v >> 32);
+    asm("s_nop 4\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4" : "+v"(lo), "+v"(hi) : "s"(vlo), "s"(vhi), "n"(LANE));
+#endif
+}
+
 // lane_xor<M>(v): value of lane (id ^ M), M a power of two.  On gfx950 these are register-file moves
 // (DPP quad_perm / row_ror, v_permlane16_swap, v_permlane32_swap) -- no LDS crossbar round trip as with
 // ds_bpermute.  Encodings are verified against __shfl_xor on the device by nrsc5hip_stage_selftest.
