@@ -146,6 +146,8 @@ int nrsc5hip_stage_viterbi_k7(nrsc5hip_engine *e, const int8_t *soft /* [nframes
 int nrsc5hip_stage_selftest(nrsc5hip_engine *e, int *failures);
 /* one frame, also returning the len+64 survivor-decision words of the forward pass */
 int nrsc5hip_stage_viterbi_k7_debug(nrsc5hip_engine *e, const int8_t *soft, int len, uint8_t *bits, unsigned long long *dec_out);
+/* micro-benchmark of the Viterbi kernel on random frames: phases bit0 = forward, bit1 = traceback */
+int nrsc5hip_stage_viterbi_bench(nrsc5hip_engine *e, int len, int nframes, int phases, int reps, float *ms_per_launch);
 /* debugging aid: soft-bit matrix (16 x 23040 int8) and live FFT bins of a stream's latest block */
 int nrsc5hip_debug_fetch(nrsc5hip_engine *e, int stream, int8_t *pm /* [368640] or NULL */, float *bins /* [32][534][2] or NULL */);
 

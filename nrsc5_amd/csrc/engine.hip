@@ -679,3 +679,30 @@ extern "C" int nrsc5hip_stage_viterbi_k7_debug(nrsc5hip_engine *e, const int8_t 
     (void)hipFree(dsoft); (void)hipFree(ddec); (void)hipFree(dout);
     return 0;
 }
+
+// micro-benchmark: nframes random frames, `phases` bit0 = forward pass, bit1 = traceback; ms per launch
+extern "C" int nrsc5hip_stage_viterbi_bench(nrsc5hip_engine *e, int len, int nframes, int phases, int reps, float *ms_per_launch)
+{
+    if (!e || !ms_per_launch || len < 64 || nframes < 1 || reps < 1) FAIL(NRSC5HIP_EINVAL, "bad argument");
+    int8_t *dsoft = nullptr; unsigned long long *ddec = nullptr; uint32_t *dout = nullptr;
+    const int words = (len + 31) / 32;
+    std::vector<int8_t> h((size_t)nframes * 3 * len);
+    unsigned x = 12345;
+    for (auto &v : h) { x = x * 1664525u + 1013904223u; v = (int8_t)((int)(x >> 24) - 128); if (v == -128) v = -127; }
+    HIPCHK(hipMalloc((void **)&dsoft, h.size()));
+    HIPCHK(hipMalloc((void **)&ddec, (size_t)nframes * (len + 64) * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&dout, (size_t)nframes * words * sizeof(uint32_t)));
+    HIPCHK(hipMemcpy(dsoft, h.data(), h.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(ddec, 0x55, (size_t)nframes * (len + 64) * sizeof(unsigned long long)));
+    hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    launch_viterbi_frames(dsoft, len, nframes, ddec, dout, e->main, phases);          // warm-up
+    HIPCHK(hipEventRecord(a, e->main));
+    for (int r = 0; r < reps; r++) launch_viterbi_frames(dsoft, len, nframes, ddec, dout, e->main, phases);
+    HIPCHK(hipEventRecord(b, e->main));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b));
+    *ms_per_launch = ms / reps;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    (void)hipFree(dsoft); (void)hipFree(ddec); (void)hipFree(dout);
+    return 0;
+}

@@ -32,12 +32,12 @@ __global__ __launch_bounds__(256) void k_p1_deint(DevTables tb, DevBuffers db, c
 
 // ---- K8 helpers ---------------------------------------------------------------------------------
 // Re-encode the decoded (still scrambled) bits and count sign disagreements with the received soft
-// bits at unpunctured positions (decode.c:234-265).  64 lanes, bit i handled by lane i%64.
-__device__ inline int bit_errors_k7_wave(const int8_t *coded, const uint32_t *bits, int len)
+// bits at unpunctured positions (decode.c:234-265).  Block-stride over the frame; returns this
+// thread's partial count.
+__device__ inline int bit_errors_k7_partial(const int8_t *coded, const uint32_t *bits, int len)
 {
-    const int lane = threadIdx.x & 63;
     int errors = 0;
-    for (int i = lane; i < len; i += 64) {
+    for (int i = threadIdx.x; i < len; i += blockDim.x) {
         unsigned r = 0;                                        // r bit 6 = bits[i], bit 6-k = bits[i-k]
 #pragma unroll
         for (int k = 0; k < 7; k++) {
@@ -50,31 +50,49 @@ __device__ inline int bit_errors_k7_wave(const int8_t *coded, const uint32_t *bi
         if (((j + 1) % 6) != 5 && ((coded[j + 1] > 0) != p1)) errors++;
         if (((j + 2) % 6) != 5 && ((coded[j + 2] > 0) != p2)) errors++;
     }
-    return wave_sum_i32(errors);
+    return errors;
 }
 
-// ---- K7: one wave per pending P1 frame ------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_p1_viterbi(DevTables tb, DevBuffers db, const int *ids, int parity)
+// ---- K7: P1 frame = forward pass by one wave, then traceback/BER/descramble by a 16-wave block -------
+__global__ __launch_bounds__(64) void k_p1_forward(DevBuffers db, const int *ids, int parity)
 {
     const int s = stream_of(ids, blockIdx.x);
     StreamState &st = db.state[s];
     if (!st.p1_pending[parity]) return;                        // wave-uniform
-    const int lane = threadIdx.x & 63;
+    const int8_t *coded = db.coded + ((size_t)s * 2 + parity) * P1_DEPUNCT;
+    unsigned long long *dec = db.dec + (size_t)s * (P1_LEN + 64);
+    const int endlane = viterbi_fast_forward(coded, P1_LEN, dec);
+    if ((threadIdx.x & 63) == 0) st.p1_endlane[parity] = endlane;
+}
+
+constexpr int TB_THREADS = 1024;
+
+__global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBuffers db, const int *ids, int parity)
+{
+    const int s = stream_of(ids, blockIdx.x);
+    StreamState &st = db.state[s];
+    if (!st.p1_pending[parity]) return;                        // block-uniform
+    HIP_DYNAMIC_SHARED(uint8_t, smem)
+    __shared__ int err_total;
+    const int tid = threadIdx.x;
     const int8_t *coded = db.coded + ((size_t)s * 2 + parity) * P1_DEPUNCT;
     unsigned long long *dec = db.dec + (size_t)s * (P1_LEN + 64);
     uint32_t *out = db.p1_ring + ((size_t)s * db.p1_slots + st.p1_slot[parity]) * P1_WORDS;
-
-    viterbi_k7_decode(coded, P1_LEN, dec, out);
+    if (tid == 0) err_total = 0;
+    viterbi_fast_traceback_block(dec, P1_LEN, st.p1_endlane[parity], out, smem);
     __threadfence_block();
-    __syncthreads();                                           // out[] written by lane 0, read by all
-    const int errors = bit_errors_k7_wave(coded, out, P1_LEN);
     __syncthreads();
-    for (int w = lane; w < P1_WORDS; w += 64) out[w] ^= tb.scr_p1[w];       // descramble
-    if (lane == 0) {
-        db.records[(size_t)s * db.rec_cap + st.p1_record[parity]].ber = (float)errors / P1_CODED;  // decode.c:458
+    const int errors = wave_sum_i32(bit_errors_k7_partial(coded, out, P1_LEN));
+    if ((tid & 63) == 0) atomicAdd(&err_total, errors);
+    __syncthreads();
+    for (int w = tid; w < P1_WORDS; w += blockDim.x) out[w] ^= tb.scr_p1[w];       // descramble
+    if (tid == 0) {
+        db.records[(size_t)s * db.rec_cap + st.p1_record[parity]].ber = (float)err_total / P1_CODED;  // decode.c:458
         st.p1_pending[parity] = 0;
     }
 }
+
+static size_t traceback_smem(int len) { return (size_t)(len / 64 + 1) * 65; }
 
 void launch_p1_deint(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st)
 {
@@ -84,19 +102,46 @@ void launch_p1_deint(const DevTables &tb, const DevBuffers &db, int nstreams, co
 
 void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_p1_viterbi, dim3(nstreams), dim3(64), 0, st, tb, db, stream_ids, parity);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)k_p1_traceback, hipFuncAttributeMaxDynamicSharedMemorySize, (int)traceback_smem(P1_LEN));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_p1_forward, dim3(nstreams), dim3(64), 0, st, db, stream_ids, parity);
+    hipLaunchKernelGGL(k_p1_traceback, dim3(nstreams), dim3(TB_THREADS), traceback_smem(P1_LEN), st, tb, db, stream_ids, parity);
 }
 
 // ---- stage-level entry: decode `nframes` independent frames of equal length (parity tests) ----------
-__global__ __launch_bounds__(64) void k_viterbi_frames(const int8_t *coded, int len, unsigned long long *dec, uint32_t *out)
+// phases (micro-benchmark): bit0 forward, bit1 traceback; bit2 selects the single-wave sequential traceback.
+__global__ __launch_bounds__(64) void k_viterbi_frames(const int8_t *coded, int len, unsigned long long *dec, uint32_t *out, int phases)
 {
     const int f = blockIdx.x;
-    viterbi_k7_decode(coded + (size_t)f * 3 * len, len, dec + (size_t)f * (len + 64), out + (size_t)f * ((len + 31) / 32));
+    viterbi_k7_decode(coded + (size_t)f * 3 * len, len, dec + (size_t)f * (len + 64), out + (size_t)f * ((len + 31) / 32), phases);
+}
+__global__ __launch_bounds__(64) void k_viterbi_frames_fwd(const int8_t *coded, int len, unsigned long long *dec, int *endlane)
+{
+    const int f = blockIdx.x;
+    const int e = viterbi_fast_forward(coded + (size_t)f * 3 * len, len, dec + (size_t)f * (len + 64));
+    if ((threadIdx.x & 63) == 0) endlane[f] = e;
+}
+__global__ __launch_bounds__(TB_THREADS) void k_viterbi_frames_tb(unsigned long long *dec, int len, const int *endlane, uint32_t *out)
+{
+    HIP_DYNAMIC_SHARED(uint8_t, smem)
+    const int f = blockIdx.x;
+    viterbi_fast_traceback_block(dec + (size_t)f * (len + 64), len, endlane[f], out + (size_t)f * ((len + 31) / 32), smem);
 }
 
-void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st)
+void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st, int phases)
 {
-    hipLaunchKernelGGL(k_viterbi_frames, dim3(nframes), dim3(64), 0, st, coded, len, dec, out);
+    if ((len & 63) == 0 && !(phases & 4)) {                    // production split: forward wave + parallel traceback
+        static int *endlane = nullptr; static int cap = 0;
+        if (cap < nframes) { if (endlane) (void)hipFree(endlane); (void)hipMalloc((void **)&endlane, sizeof(int) * nframes); cap = nframes; (void)hipMemset(endlane, 0, sizeof(int) * nframes); }
+        (void)hipFuncSetAttribute((const void *)k_viterbi_frames_tb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)traceback_smem(len));
+        if (phases & 1) hipLaunchKernelGGL(k_viterbi_frames_fwd, dim3(nframes), dim3(64), 0, st, coded, len, dec, endlane);
+        if (phases & 2) hipLaunchKernelGGL(k_viterbi_frames_tb, dim3(nframes), dim3(TB_THREADS), traceback_smem(len), st, dec, len, (const int *)endlane, out);
+        return;
+    }
+    hipLaunchKernelGGL(k_viterbi_frames, dim3(nframes), dim3(64), 0, st, coded, len, dec, out, phases & 3);
 }
 
 // ---- device self-test of the register-file lane exchanges against the generic shuffle ----------------

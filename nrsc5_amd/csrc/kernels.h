@@ -51,7 +51,7 @@ void launch_p1_deint(const DevTables &tb, const DevBuffers &db, int nstreams, co
 void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st);
 
 // ---- stage-level entry points (parity tests) ---------------------------------------------------
-void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st);
+void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st, int phases = 3);
 void launch_selftest(int *fail_count, hipStream_t st);
 void launch_fft2048(const DevTables &tb, const float2 *in, float2 *out, int nffts, hipStream_t st);
 

@@ -95,6 +95,7 @@ struct StreamState {
     int p1_pending[2];          // 1: frame completed this step (gather it), 2: gathered into coded[s][parity]
     int p1_slot[2];             // slot of the stream's P1 ring the decoder must fill
     int p1_record[2];           // record index that gets the BER
+    int p1_endlane[2];          // forward pass -> traceback hand-off (lane of the winning end state)
 };
 
 }  // namespace nrsc5

@@ -187,14 +187,14 @@ __device__ __forceinline__ int vit_load_soft(const int8_t *coded, int len, int t
 }
 
 // requires len % 64 == 0; all 64 lanes
-__device__ inline void viterbi_k7_wave_fast(const int8_t *coded, int len, unsigned long long *dec, uint32_t *out)
+__device__ inline void viterbi_k7_wave_fast(const int8_t *coded, int len, unsigned long long *dec, uint32_t *out, int phases = 3)
 {
     const int lane = threadIdx.x & 63;
     const VitFastConst k = vit_fast_consts(lane);
     const int nchunks = len / 64 + 1;                          // steps = len + 2 * VIT_EXTRA
     int pm = 0;
     int aw = vit_load_soft(coded, len, lane);
-    for (int c = 0; c < nchunks; c++) {
+    for (int c = 0; c < ((phases & 1) ? nchunks : 0); c++) {
         const int aw_next = (c + 1 < nchunks) ? vit_load_soft(coded, len, 64 * (c + 1) + lane) : 0;
         int wlo = 0, whi = 0;
         switch (c % 3) {                                       // (64 c) % 6
@@ -212,7 +212,7 @@ __device__ inline void viterbi_k7_wave_fast(const int8_t *coded, int len, unsign
     const int smin = wave_min_i32(pm == best ? (int)rotr6((unsigned)lane, rend) : 64);
     unsigned l = (unsigned)wave_uniform((int)rotl6((unsigned)smin, rend));   // lane of the survivor, kept in an SGPR
 
-    for (int c = nchunks - 1; c >= 0; c--) {
+    for (int c = ((phases & 2) ? nchunks - 1 : -1); c >= 0; c--) {
         const unsigned long long mine = dec[64 * c + lane];
         const int mlo = (int)(uint32_t)mine, mhi = (int)(uint32_t)(mine >> 32);
         unsigned ohi = 0, olo = 0;
@@ -230,10 +230,91 @@ __device__ inline void viterbi_k7_wave_fast(const int8_t *coded, int len, unsign
     }
 }
 
-// dispatcher used by the kernels
-__device__ inline void viterbi_k7_decode(const int8_t *coded, int len, unsigned long long *dec, uint32_t *out)
+// ---- split form used by the P1 decoder: forward pass (one wave) + block-parallel traceback ----------
+// Forward only: fills dec[0 .. len+63] and returns the lane of the winning end state (wave-uniform).
+__device__ inline int viterbi_fast_forward(const int8_t *coded, int len, unsigned long long *dec)
 {
-    if ((len & 63) == 0) viterbi_k7_wave_fast(coded, len, dec, out);
+    const int lane = threadIdx.x & 63;
+    const VitFastConst k = vit_fast_consts(lane);
+    const int nchunks = len / 64 + 1;
+    int pm = 0;
+    int aw = vit_load_soft(coded, len, lane);
+    for (int c = 0; c < nchunks; c++) {
+        const int aw_next = (c + 1 < nchunks) ? vit_load_soft(coded, len, 64 * (c + 1) + lane) : 0;
+        int wlo = 0, whi = 0;
+        switch (c % 3) {
+        case 0: VitFwd<0, 0>::run(pm, aw, k, vit_branch_metric<0>(aw, 0, k), 0ull, wlo, whi); break;
+        case 1: VitFwd<4, 0>::run(pm, aw, k, vit_branch_metric<4>(aw, 0, k), 0ull, wlo, whi); break;
+        default: VitFwd<2, 0>::run(pm, aw, k, vit_branch_metric<2>(aw, 0, k), 0ull, wlo, whi); break;
+        }
+        dec[64 * c + lane] = ((unsigned long long)(uint32_t)whi << 32) | (uint32_t)wlo;
+        aw = aw_next;
+    }
+    const int rend = (64 * nchunks) % 6;
+    const int best = wave_max_i32(pm);
+    const int smin = wave_min_i32(pm == best ? (int)rotr6((unsigned)lane, rend) : 64);
+    return wave_uniform((int)rotl6((unsigned)smin, rend));
+}
+
+// 64 steps of traceback for ALL 64 possible end lanes of a chunk at once (lane = candidate):
+// l <- l ^ (own(l) ? 0 : 1 << R); the bit emitted at a step is bit R of the lane before the move.
+template <int PH0, int S> struct VitMap {
+    static __device__ __forceinline__ void run(unsigned &l, int mlo, int mhi, unsigned &ohi, unsigned &olo)
+    {
+        constexpr int R = (PH0 + S) % 6;
+        const unsigned long long w = ((unsigned long long)(uint32_t)wave_readlane(mhi, S) << 32) | (uint32_t)wave_readlane(mlo, S);
+        const unsigned t = (unsigned)(w >> l) << R;            // bit R = own-wins of the candidate's lane
+        if (S >= 32) ohi = (ohi << 1) | ((l >> R) & 1u); else olo = (olo << 1) | ((l >> R) & 1u);
+        l ^= (1u << R) & ~t;
+        VitMap<PH0, S - 1>::run(l, mlo, mhi, ohi, olo);
+    }
+};
+template <int PH0> struct VitMap<PH0, -1> {
+    static __device__ __forceinline__ void run(unsigned &, int, int, unsigned &, unsigned &) {}
+};
+
+// Block-parallel traceback (blockDim.x a multiple of 64, any number of waves).
+//   pass 1  every wave takes chunks c = wave, wave + nwaves, ...: for each of the 64 candidate end lanes it
+//           walks the chunk back, records the start lane in LDS (map[c][lane]) and overwrites the chunk's 64
+//           decision words IN PLACE with the 64 candidates' decoded 64-bit output.
+//   pass 2  one lane composes the maps from the true end lane backwards (2285 dependent LDS reads for P1).
+//   pass 3  all threads pick the surviving candidate's output words.
+// smem: nchunks * 64 bytes (map) + nchunks bytes (chosen lane per chunk).
+__device__ inline void viterbi_fast_traceback_block(unsigned long long *dec, int len, int endlane, uint32_t *out, uint8_t *smem)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int nchunks = len / 64 + 1;
+    uint8_t *map = smem, *chosen = smem + (size_t)nchunks * 64;
+    for (int c = wave; c < nchunks; c += nwaves) {
+        const unsigned long long mine = dec[64 * c + lane];
+        const int mlo = (int)(uint32_t)mine, mhi = (int)(uint32_t)(mine >> 32);
+        unsigned l = (unsigned)lane, ohi = 0, olo = 0;
+        switch (c % 3) {
+        case 0: VitMap<0, 63>::run(l, mlo, mhi, ohi, olo); break;
+        case 1: VitMap<4, 63>::run(l, mlo, mhi, ohi, olo); break;
+        default: VitMap<2, 63>::run(l, mlo, mhi, ohi, olo); break;
+        }
+        map[64 * c + lane] = (uint8_t)l;
+        dec[64 * c + lane] = ((unsigned long long)ohi << 32) | olo;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (tid == 0) {
+        unsigned e = (unsigned)endlane;
+        for (int c = nchunks - 1; c >= 0; c--) { chosen[c] = (uint8_t)e; e = map[64 * c + e]; }
+    }
+    __syncthreads();
+    for (int c = tid; c < nchunks; c += blockDim.x) {
+        const unsigned long long o = dec[64 * c + chosen[c]];
+        if (c < nchunks - 1) out[2 * c] = (uint32_t)(o >> 32);       // steps 64c+32 .. 64c+63
+        if (c >= 1) out[2 * c - 1] = (uint32_t)o;                    // steps 64c .. 64c+31
+    }
+}
+
+// dispatcher used by the kernels
+__device__ inline void viterbi_k7_decode(const int8_t *coded, int len, unsigned long long *dec, uint32_t *out, int phases = 3)
+{
+    if ((len & 63) == 0) viterbi_k7_wave_fast(coded, len, dec, out, phases);
     else viterbi_k7_wave(coded, len, dec, out);
 }
 

@@ -64,6 +64,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.nrsc5hip_debug_fetch.argtypes = [vp, ci, vp, vp]
     lib.nrsc5hip_stage_selftest.argtypes = [vp, ctypes.POINTER(ci)]
     lib.nrsc5hip_stage_viterbi_k7_debug.argtypes = [vp, vp, ci, vp, vp]
+    lib.nrsc5hip_stage_viterbi_bench.argtypes = [vp, ci, ci, ci, ci, ctypes.POINTER(ctypes.c_float)]
     lib.nrsc5hip_reset_all.argtypes = [vp]
     lib.nrsc5hip_profile.argtypes = [vp, ci, vp, vp]
     return lib
@@ -75,7 +76,7 @@ EXPORTED_SYMBOLS = [
     "nrsc5hip_batch_append_cu8", "nrsc5hip_batch_append_cs16", "nrsc5hip_batch_process", "nrsc5hip_drain",
     "nrsc5hip_p1_frame_packed", "nrsc5hip_p1_frame_bits", "nrsc5hip_batch_fetch", "nrsc5hip_unpack_bits",
     "nrsc5hip_stage_halfband_fm_cu8", "nrsc5hip_stage_fft2048", "nrsc5hip_stage_viterbi_k7", "nrsc5hip_debug_fetch",
-    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug"]
+    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench"]
 
 
 def unpack_bits(words: np.ndarray, nbits: int) -> np.ndarray:
@@ -213,6 +214,11 @@ class Engine:
         dec = np.zeros(length + 64, dtype=np.uint64)
         self._check(self.lib.nrsc5hip_stage_viterbi_k7_debug(self._h, soft.ctypes.data, length, bits.ctypes.data, dec.ctypes.data))
         return bits, dec
+
+    def stage_viterbi_bench(self, length: int, nframes: int, phases: int = 3, reps: int = 3) -> float:
+        ms = ctypes.c_float()
+        self._check(self.lib.nrsc5hip_stage_viterbi_bench(self._h, length, nframes, phases, reps, ctypes.byref(ms)))
+        return ms.value
 
     def stage_selftest(self) -> int:
         n = ctypes.c_int(-1)

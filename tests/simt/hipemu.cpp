@@ -54,6 +54,7 @@ static char *stack_pool;
 static void *sched_sp;
 static int cur = -1, nthreads, nwaves;
 static std::function<void()> *cur_body;
+static std::vector<char> dyn_smem;
 
 static void yield_to_sched() { simt_swap(&fibers[cur].sp, sched_sp); }
 
@@ -66,6 +67,7 @@ static void fiber_main()
 }
 
 int lane_id() { return fibers[cur].lane; }
+void *dynamic_shared() { return dyn_smem.data(); }
 
 void sync_block()
 {
@@ -143,8 +145,9 @@ static void run_block(std::function<void()> &body)
     }
 }
 
-void launch(dim3 grid, dim3 block, size_t, std::function<void()> body)
+void launch(dim3 grid, dim3 block, size_t shmem, std::function<void()> body)
 {
+    if (dyn_smem.size() < shmem + 64) dyn_smem.resize(shmem + 64);
     if (!stack_pool) {
         stack_pool = (char *)mmap(nullptr, STACK_BYTES * MAX_THREADS, PROT_READ | PROT_WRITE,
                                   MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);

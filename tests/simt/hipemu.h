@@ -66,7 +66,9 @@ void sync_block();
 // wave collective: deposits `v` (8 bytes max) for this lane, waits for the wave, returns slots.
 const uint64_t *wave_exchange(uint64_t v, uint64_t *active_mask);
 int lane_id();
+void *dynamic_shared();
 }
+#define HIP_DYNAMIC_SHARED(type, var) type *var = (type *)simt::dynamic_shared();
 
 static inline void __syncthreads() { simt::sync_block(); }
 
@@ -173,6 +175,8 @@ static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = 0) { return hi
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0; return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return hipSuccess; }
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+template <typename F> static inline hipError_t hipFuncSetAttribute(F, int, int) { return hipSuccess; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int) { memset(p, 0, sizeof(*p)); strcpy(p->name, "hipemu"); strcpy(p->gcnArchName, "emu"); p->multiProcessorCount = 1; return hipSuccess; }
 #define hipStreamNonBlocking 1
 #define hipHostMallocDefault 0
