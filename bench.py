@@ -32,7 +32,7 @@ FRAME_SAMPLES = 16 * BLOCK_SAMPLES
 
 # input samples one launch of each kernel class accounts for, per processed stream
 SAMPLES_PER_LAUNCH = {"decimate": None, "acquire": BLOCK_SAMPLES, "prepare": BLOCK_SAMPLES, "mixfft": BLOCK_SAMPLES,
-                      "sync": BLOCK_SAMPLES, "p1_deint": BLOCK_SAMPLES, "p1_viterbi": None}
+                      "sync": BLOCK_SAMPLES, "p1_deint": BLOCK_SAMPLES, "p1_viterbi": None, "pids": BLOCK_SAMPLES}
 
 
 def parse():

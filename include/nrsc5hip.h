@@ -148,6 +148,8 @@ int nrsc5hip_stage_selftest(nrsc5hip_engine *e, int *failures);
 int nrsc5hip_stage_viterbi_k7_debug(nrsc5hip_engine *e, const int8_t *soft, int len, uint8_t *bits, unsigned long long *dec_out);
 /* micro-benchmark of the Viterbi kernel on random frames: phases bit0 = forward, bit1 = traceback */
 int nrsc5hip_stage_viterbi_bench(nrsc5hip_engine *e, int len, int nframes, int phases, int reps, float *ms_per_launch);
+/* accumulated shader cycles per phase of the sync kernel for stream 0 (engine created with NRSC5HIP_SYNC_PHASES=1) */
+int nrsc5hip_debug_sync_phases(nrsc5hip_engine *e, long long *cycles8);
 /* debugging aid: soft-bit matrix (16 x 23040 int8) and live FFT bins of a stream's latest block */
 int nrsc5hip_debug_fetch(nrsc5hip_engine *e, int stream, int8_t *pm /* [368640] or NULL */, float *bins /* [32][534][2] or NULL */);
 
@@ -159,7 +161,7 @@ int nrsc5hip_reset_all(nrsc5hip_engine *e);
  * total_ms / launches: arrays of NRSC5HIP_PROF_CLASSES entries (may be NULL). */
 enum {
     NRSC5HIP_PROF_DECIMATE = 0, NRSC5HIP_PROF_ACQUIRE, NRSC5HIP_PROF_PREPARE, NRSC5HIP_PROF_MIXFFT,
-    NRSC5HIP_PROF_SYNC, NRSC5HIP_PROF_P1_DEINT, NRSC5HIP_PROF_P1_VITERBI, NRSC5HIP_PROF_CLASSES
+    NRSC5HIP_PROF_SYNC, NRSC5HIP_PROF_P1_DEINT, NRSC5HIP_PROF_P1_VITERBI, NRSC5HIP_PROF_PIDS, NRSC5HIP_PROF_CLASSES
 };
 int nrsc5hip_profile(nrsc5hip_engine *e, int enable, double *total_ms, long long *launches);
 

@@ -202,9 +202,17 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if ((rc = dev_alloc(e, &db.pm, S * PM_FRAME))) break;
         if ((rc = dev_alloc(e, &db.coded, S * 2 * P1_DEPUNCT))) break;
         if ((rc = dev_alloc(e, &db.dec, S * (size_t)(P1_LEN + 64)))) break;
+        if ((rc = dev_alloc(e, &db.pids_stage, S * 2 * 16 * 3 * PIDS_LEN))) break;
+        if ((rc = dev_alloc(e, &db.pids_rec, S * 2 * 16))) break;
+        if (hipMemset(db.pids_rec, 0xff, S * 2 * 16 * sizeof(int)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
         if ((rc = dev_alloc(e, &db.p1_ring, S * db.p1_slots * P1_WORDS))) break;
         if ((rc = dev_alloc(e, &db.records, S * db.rec_cap))) break;
         if ((rc = dev_alloc(e, &db.counters, 4))) break;
+        db.sync_phase_cycles = nullptr;
+        if (getenv("NRSC5HIP_SYNC_PHASES")) {
+            if ((rc = dev_alloc(e, &db.sync_phase_cycles, 8))) break;
+            (void)hipMemset(db.sync_phase_cycles, 0, 8 * sizeof(long long));
+        }
         e->stage_bytes = 4u << 20;
         if ((rc = dev_alloc(e, &e->stage_dev, e->stage_bytes))) break;
         if ((rc = dev_alloc(e, &e->ids_dev, S))) break;
@@ -267,14 +275,17 @@ static int issue_step(nrsc5hip_engine *e, int n, const int *ids_dev)
     if (e->acq_needed) { ProfScope p(e, NRSC5HIP_PROF_ACQUIRE, e->main); launch_acquire(e->tb, e->db, n, ids_dev, e->main); }
     { ProfScope p(e, NRSC5HIP_PROF_PREPARE, e->main); launch_prepare(e->db, n, ids_dev, parity, e->main); }
     { ProfScope p(e, NRSC5HIP_PROF_MIXFFT, e->main); launch_mixfft(e->tb, e->db, n, ids_dev, e->main); }
-    { ProfScope p(e, NRSC5HIP_PROF_SYNC, e->main); launch_sync(e->tb, e->db, n, ids_dev, parity, e->main); }
+    const int slot = async ? (int)(e->step_count % 16) : 0;
+    { ProfScope p(e, NRSC5HIP_PROF_SYNC, e->main); launch_sync(e->tb, e->db, n, ids_dev, parity, slot, e->main); }
     { ProfScope p(e, NRSC5HIP_PROF_P1_DEINT, e->main); launch_p1_deint(e->tb, e->db, n, ids_dev, parity, e->main); }
     if (!async) {
+        { ProfScope p(e, NRSC5HIP_PROF_PIDS, e->main); launch_pids_decode(e->tb, e->db, n, ids_dev, parity, 1, e->main); }
         ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, e->main);
         launch_p1_viterbi(e->tb, e->db, n, ids_dev, parity, e->main);
     } else if ((e->step_count % 16) == 15) {
         HIPCHK(hipEventRecord(e->ev_window[parity], e->main));
         HIPCHK(hipStreamWaitEvent(e->aux, e->ev_window[parity], 0));
+        { ProfScope p(e, NRSC5HIP_PROF_PIDS, e->aux); launch_pids_decode(e->tb, e->db, n, ids_dev, parity, 16, e->aux); }
         { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, e->aux); launch_p1_viterbi(e->tb, e->db, n, ids_dev, parity, e->aux); }
         HIPCHK(hipEventRecord(e->ev_decoded[parity], e->aux));
         e->decoded_pending[parity] = true;
@@ -290,6 +301,7 @@ static int flush_p1(nrsc5hip_engine *e, int n, const int *ids_dev)
     if (!e->cfg.p1_async) return 0;
     if (e->step_count % 16) {
         const int parity = (int)((e->step_count / 16) & 1);
+        { ProfScope p(e, NRSC5HIP_PROF_PIDS, e->main); launch_pids_decode(e->tb, e->db, n, ids_dev, parity, 16, e->main); }
         { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, e->main); launch_p1_viterbi(e->tb, e->db, n, ids_dev, parity, e->main); }
         e->step_count += 16 - (e->step_count % 16);           // next batch starts a fresh window
     }
@@ -632,6 +644,7 @@ extern "C" int nrsc5hip_reset_all(nrsc5hip_engine *e)
     std::fill(e->wr_host.begin(), e->wr_host.end(), 0);
     std::fill(e->base_host.begin(), e->base_host.end(), 0);
     std::fill(e->drained.begin(), e->drained.end(), 0);
+    HIPCHK(hipMemset(e->db.pids_rec, 0xff, S * 2 * 16 * sizeof(int)));
     e->acq_needed = true; e->step_count = 0;
     e->decoded_pending[0] = e->decoded_pending[1] = false;
     return 0;
@@ -704,5 +717,14 @@ extern "C" int nrsc5hip_stage_viterbi_bench(nrsc5hip_engine *e, int len, int nfr
     *ms_per_launch = ms / reps;
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     (void)hipFree(dsoft); (void)hipFree(ddec); (void)hipFree(dout);
+    return 0;
+}
+
+extern "C" int nrsc5hip_debug_sync_phases(nrsc5hip_engine *e, long long *cycles8)
+{
+    if (!e || !cycles8) FAIL(NRSC5HIP_EINVAL, "null argument");
+    if (!e->db.sync_phase_cycles) FAIL(NRSC5HIP_EINVAL, "set NRSC5HIP_SYNC_PHASES=1 before creating the engine");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(cycles8, e->db.sync_phase_cycles, 8 * sizeof(long long), hipMemcpyDeviceToHost));
     return 0;
 }

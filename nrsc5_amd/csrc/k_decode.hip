@@ -12,22 +12,24 @@ __device__ inline int stream_of(const int *ids, int idx) { return ids ? ids[idx]
 // coded bit i of the frame sits at matrix cell p1_gather[i]; the Viterbi input carries a zero after
 // every 5th coded bit (puncture pattern [1,1,1,1,1,0], decode.c:318-319): position i + i/5.
 // One thread produces one 6-byte group (5 gathers + the erased slot).
-__global__ __launch_bounds__(256) void k_p1_deint(DevTables tb, DevBuffers db, const int *ids, int parity)
+__global__ __launch_bounds__(1024) void k_p1_deint(DevTables tb, DevBuffers db, const int *ids, int parity)
 {
     const int s = stream_of(ids, blockIdx.y);
     const StreamState &st = db.state[s];
     if (st.p1_pending[parity] != 1) return;                    // 1 = completed in this step, 2 = already gathered
     const int8_t *pm = db.pm + (size_t)s * PM_FRAME;
     int8_t *out = db.coded + ((size_t)s * 2 + parity) * P1_DEPUNCT;
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;       // group index
-    if (g >= P1_CODED / 5) return;
-    const int32_t *idx = tb.p1_gather + 5 * g;
-    int8_t v[6];
+    // 4 groups (24 output bytes, 20 gathers) per thread iteration; the grid has few blocks per stream so that
+    // the 15 of 16 steps in which no frame completes cost one wave-uniform early exit per block
+    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < P1_CODED / 5; g += gridDim.x * blockDim.x) {
+        const int32_t *idx = tb.p1_gather + 5 * g;
+        int8_t v[6];
 #pragma unroll
-    for (int k = 0; k < 5; k++) v[k] = pm[idx[k]];
-    v[5] = 0;
+        for (int k = 0; k < 5; k++) v[k] = pm[idx[k]];
+        v[5] = 0;
 #pragma unroll
-    for (int k = 0; k < 6; k++) out[6 * g + k] = v[k];
+        for (int k = 0; k < 6; k++) out[6 * g + k] = v[k];
+    }
 }
 
 // ---- K8 helpers ---------------------------------------------------------------------------------
@@ -96,8 +98,8 @@ static size_t traceback_smem(int len) { return (size_t)(len / 64 + 1) * 65; }
 
 void launch_p1_deint(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st)
 {
-    dim3 grid((P1_CODED / 5 + 255) / 256, nstreams);
-    hipLaunchKernelGGL(k_p1_deint, grid, dim3(256), 0, st, tb, db, stream_ids, parity);
+    dim3 grid(8, nstreams);
+    hipLaunchKernelGGL(k_p1_deint, grid, dim3(1024), 0, st, tb, db, stream_ids, parity);
 }
 
 void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st)

@@ -126,29 +126,34 @@ __global__ __launch_bounds__(128) void k_mixfft(DevTables tb, DevBuffers db, con
     const double dth = st.dtheta;
     const double th0 = st.theta + (double)sym * SYM_N * dth;
 
+    // NCO phasor of sample j = tid + 128 q (q = 0..16): one accurate evaluation at q = 0 and one of the
+    // 128-sample step, then a 16-step complex recurrence (error ~1e-6, far inside the float pipeline's own)
+    double a0 = th0 + (double)tid * dth;
+    a0 -= 2 * M_PI * rint(a0 * (1.0 / (2 * M_PI)));
+    double a1 = 128.0 * dth;
+    a1 -= 2 * M_PI * rint(a1 * (1.0 / (2 * M_PI)));
+    float2 ph, stp;
+    sincosf((float)a0, &ph.y, &ph.x);
+    sincosf((float)a1, &stp.y, &stp.x);
+    const double inv_q15 = 1.0 / 32767.0;                      // x / 32767.0f (defines.h:111), via an exact-in-practice double product
+
     float2 x[16];
 #pragma unroll
-    for (int h = 0; h < 2; h++)
-#pragma unroll
-        for (int n1 = 0; n1 < 8; n1++) {
-            const int j = tid + 128 * h + 256 * n1;
-            const c16 q = win[j];
-            double a = th0 + (double)j * dth;
-            a -= 2 * M_PI * rint(a * (1.0 / (2 * M_PI)));
-            float sn, cs; sincosf((float)a, &sn, &cs);
-            const float2 v = make_float2((float)q.r / 32767.0f, (float)q.i / -32767.0f);     // cq15_to_cf_conj
-            float2 m = cmul(make_float2(cs, sn), v);
-            if (j < CP_N) { const float w = tb.shape[j]; m.x *= w; m.y *= w; }
-            x[8 * h + n1] = m;
-        }
+    for (int q = 0; q < 16; q++) {
+        const int h = q & 1, n1 = q >> 1;
+        const int j = tid + 128 * q;
+        const c16 s16 = win[j];
+        const float2 v = make_float2((float)((double)s16.r * inv_q15), (float)((double)s16.i * -inv_q15));   // cq15_to_cf_conj
+        float2 m = cmul(ph, v);
+        if (q == 0 && tid < CP_N) { const float w = tb.shape[tid]; m.x *= w; m.y *= w; }
+        x[8 * h + n1] = m;
+        ph = cmul(ph, stp);
+    }
     if (tid < CP_N) {                                          // fold the cyclic extension back (acquire.c:246-247)
         const int j = FFT_N + tid;
-        const c16 q = win[j];
-        double a = th0 + (double)j * dth;
-        a -= 2 * M_PI * rint(a * (1.0 / (2 * M_PI)));
-        float sn, cs; sincosf((float)a, &sn, &cs);
-        const float2 v = make_float2((float)q.r / 32767.0f, (float)q.i / -32767.0f);
-        float2 m = cmul(make_float2(cs, sn), v);
+        const c16 s16 = win[j];
+        const float2 v = make_float2((float)((double)s16.r * inv_q15), (float)((double)s16.i * -inv_q15));
+        const float2 m = cmul(ph, v);                          // ph = phasor of sample tid + 2048
         const float w = tb.shape[j];
         x[0].x += w * m.x; x[0].y += w * m.y;
     }

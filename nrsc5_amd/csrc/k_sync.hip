@@ -65,13 +65,17 @@ __device__ inline uint32_t costas_block(const float2 *src, int stride, float &fr
     const float cfo_freq = (float)(2 * M_PI * cfo * CP_N / FFT_N);
     uint32_t pos = 0, neg = 0;
     float x = 0.0f;
+    float2 zin[NSYM];
+#pragma unroll
+    for (int n = 0; n < NSYM; n++) zin[n] = src[n * stride];   // 32 independent loads in flight
+#pragma unroll 4
     for (int n = 0; n < NSYM; n++) {
-        const float2 z = src[n * stride];
-        float s2, c2; sincosf(2 * phase, &s2, &c2);
+        const float2 z = zin[n];
+        float s1, c1; sincosf(phase, &s1, &c1);
+        const float s2 = 2.0f * s1 * c1, c2 = c1 * c1 - s1 * s1;                // e^{2i phase}
         const float2 w = make_float2(z.x * z.x - z.y * z.y, z.x * z.y + z.y * z.x);
         const float ur = w.x * c2 + w.y * s2, ui = w.y * c2 - w.x * s2;         // w * e^{-2i phase}
         const float error = atan2f(ui, ur) * 0.5f;
-        float s1, c1; sincosf(phase, &s1, &c1);
         const float2 zr = make_float2(z.x * c1 + z.y * s1, z.y * c1 - z.x * s1);   // z * e^{-i phase}
         if (STORE) { zout[n] = zr; phout[n] = phase; }
         if (zr.x > 0) pos |= 1u << n;
@@ -124,12 +128,14 @@ __device__ inline int soft_bit(float x, float mult)          // demod, sync.c:69
     return (int)lroundf(c * mult);
 }
 
-__global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity)
+__global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot)
 {
     const int s = stream_of(ids, blockIdx.x);
     StreamState &st = db.state[s];
     if (!st.active) return;                                    // block-uniform
     const int tid = threadIdx.x;
+    long long tstamp = (db.sync_phase_cycles && s == 0 && tid == 0) ? (long long)clock64() : 0;
+#define SYNC_MARK(i) do { if (db.sync_phase_cycles && s == 0 && tid == 0) { const long long now = (long long)clock64(); db.sync_phase_cycles[i] += now - tstamp; tstamp = now; } } while (0)
 
     __shared__ float2 refz[NREF_MAX][NSYM];                   // derotated reference carriers
     __shared__ float refph[NREF_MAX][NSYM];                   // loop phase per symbol (phases[][] of the reference)
@@ -140,9 +146,7 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
     __shared__ int sh_i[8];
     __shared__ float sh_f[8];
     __shared__ double red[2][4];
-    __shared__ int8_t pids_coded[3 * PIDS_LEN];
-    __shared__ unsigned long long pids_dec[PIDS_LEN + 64];
-    __shared__ uint32_t pids_out[4];
+    __shared__ float ref_freq[NREF_MAX];
 
     float2 *bins = db.bins + (size_t)s * NSYM * LIVE_N;       // [sym][live]
     BlockRecord &rec = db.records[(size_t)s * db.rec_cap + (st.nblocks % db.rec_cap)];
@@ -160,6 +164,7 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         }
     }
     __syncthreads();
+    SYNC_MARK(0);
 
     // ---- Costas loops of the active reference carriers (sync.c:360-364)
     if (tid < nref) {
@@ -167,8 +172,10 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         float f = st.costas_freq[l], p = st.costas_phase[l];
         costas_block<true>(bins + l, LIVE_N, f, p, 0, g, refz[tid], refph[tid]);
         st.costas_freq[l] = f; st.costas_phase[l] = p;
+        ref_freq[tid] = f;
     }
     __syncthreads();
+    SYNC_MARK(1);
 
     // ---- COARSE: try to lock (sync.c:366-423)
     if (st.sync_state == SYNC_COARSE) {
@@ -273,6 +280,7 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         __syncthreads();
     }
 
+    SYNC_MARK(2);
     // ---- FINE: equalise, measure, demodulate (sync.c:425-609)
     if (st.sync_state == SYNC_FINE) {
         const int bc = st.bc;
@@ -298,9 +306,9 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
             }
             se = (float)(se / (ppb * 2) * FFT_N / PW / (2 * M_PI));
             for (int i = 0; i <= ppb; i++) {
-                float x = (float)(LB0 + PW * i - FFT_N / 2), y = st.costas_freq[bin_to_live(LB0 + PW * i)];
+                float x = (float)(LB0 + PW * i - FFT_N / 2), y = ref_freq[2 * i];
                 angle += y; sum_xy += x * y; sum_x2 += x * x;
-                x = (float)(UB1 - PW * i - FFT_N / 2); y = st.costas_freq[bin_to_live(UB1 - PW * i)];
+                x = (float)(UB1 - PW * i - FFT_N / 2); y = ref_freq[2 * i + 1];
                 angle += y; sum_xy += x * y; sum_x2 += x * x;
             }
             se = (float)(se - (sum_xy / sum_x2) * FFT_N / (2 * M_PI) * NSYM);
@@ -310,27 +318,37 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
             sh_f[0] = angle;
         }
         __syncthreads();
-        if (tid < nref) st.costas_freq[bin_to_live(ref_bin(tid))] -= sh_f[0];
+        if (tid < nref) st.costas_freq[bin_to_live(ref_bin(tid))] = ref_freq[tid] - sh_f[0];
+        SYNC_MARK(3);
 
-        // cell (side, part, n, k): data carrier k = 1..18 of partition `part` (counted from the band edge)
+        // cell (side, part, n, k): data carrier k = 1..18 of partition `part` (counted from the band edge).
+        // Each lane owns cells c = tid + 256 i and keeps the equalised values in registers between the MER
+        // pass and the soft-bit pass (one workgroup per CU: the whole VGPR file is ours).
         const int ncell = 2 * ppb * NSYM * 18;
+        constexpr int MAXC = (2 * 14 * NSYM * 18 + 255) / 256;                 // 63
+        float2 cellv[MAXC];
         double e_lb = 0.0, e_ub = 0.0;
-        for (int c = tid; c < ncell; c += 256) {
-            const int k = 1 + c % 18, n = (c / 18) % NSYM, part = (c / (18 * NSYM)) % ppb, side = c / (18 * NSYM * ppb);
-            // adjust_data(lower, upper): side 0: refs i=part (low) and part+1 (high); side 1: low = upper-sideband ref part+1
-            const int r_lo = side ? 2 * (part + 1) + 1 : 2 * part, r_hi = side ? 2 * part + 1 : 2 * (part + 1);
-            const int b = ref_bin(r_lo) + k;
-            const float2 lp = refcs[r_lo][n], up = refcs[r_hi][n];
-            const float a = k * smag[r_hi], bq = (PW - k) * smag[r_lo];
-            const float2 den = make_float2(a * up.x + bq * lp.x, a * up.y + bq * lp.y);
-            const float2 C = cdiv(make_float2((float)PW, (float)PW), den);
-            const float2 z = bins[n * LIVE_N + bin_to_live(b)];
-            const float2 v = make_float2(z.x * C.x - z.y * C.y, z.x * C.y + z.y * C.x);
-            bins[n * LIVE_N + bin_to_live(b)] = v;             // keep the equalised cell for the soft-bit pass
-            const float ix = v.x >= 0 ? 1.0f : -1.0f, iy = v.y >= 0 ? 1.0f : -1.0f;
-            const float dx = ix - v.x, dy = iy - v.y;
-            const float e = dx * dx + dy * dy;
-            if (side) e_ub += e; else e_lb += e;
+#pragma unroll
+        for (int i = 0; i < MAXC; i++) {
+            const int c = tid + 256 * i;
+            cellv[i] = make_float2(0.0f, 0.0f);
+            if (c < ncell) {
+                const int k = 1 + c % 18, n = (c / 18) % NSYM, part = (c / (18 * NSYM)) % ppb, side = c / (18 * NSYM * ppb);
+                // adjust_data(lower, upper): side 0: refs i=part (low) and part+1 (high); side 1: low = upper-sideband ref part+1
+                const int r_lo = side ? 2 * (part + 1) + 1 : 2 * part, r_hi = side ? 2 * part + 1 : 2 * (part + 1);
+                const int b = ref_bin(r_lo) + k;
+                const float2 z = bins[n * LIVE_N + bin_to_live(b)];
+                const float2 lp = refcs[r_lo][n], up = refcs[r_hi][n];
+                const float a = k * smag[r_hi], bq = (PW - k) * smag[r_lo];
+                const float2 den = make_float2(a * up.x + bq * lp.x, a * up.y + bq * lp.y);
+                const float2 C = cdiv(make_float2((float)PW, (float)PW), den);
+                const float2 v = make_float2(z.x * C.x - z.y * C.y, z.x * C.y + z.y * C.x);
+                cellv[i] = v;
+                const float ix = v.x >= 0 ? 1.0f : -1.0f, iy = v.y >= 0 ? 1.0f : -1.0f;
+                const float dx = ix - v.x, dy = iy - v.y;
+                const float e = dx * dx + dy * dy;
+                if (side) e_ub += e; else e_lb += e;
+            }
         }
         e_lb = wave_sum_f64(e_lb); e_ub = wave_sum_f64(e_ub);
         if ((tid & 63) == 0) { red[0][tid >> 6] = e_lb; red[1][tid >> 6] = e_ub; }
@@ -353,33 +371,37 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         }
         __syncthreads();
         const float mult_lb = sh_f[1], mult_ub = sh_f[2];
+        SYNC_MARK(4);
 
-        // primary-main soft bits -> row `bc` of the stream's 16 x 32 x 720 interleaver matrix (decode.c:380)
+        // primary-main soft bits -> row `bc` of the stream's 16 x 32 x 720 interleaver matrix (decode.c:380).
+        // Partitions 0..9 = lower sideband from the edge; 10..19 = upper sideband in ascending frequency
+        // (sync.c:514-536): the upper-sideband cell of partition `part` (from the edge) is matrix partition 19 - part.
         int8_t *pm_blk = db.pm + (size_t)s * PM_FRAME + (size_t)bc * PM_BLOCK;
-        for (int c = tid; c < NSYM * 360; c += 256) {
-            const int n = c / 360, q = c % 360, part20 = q / 18, j = 1 + q % 18;
-            // partitions 0..9: lower sideband from the edge; 10..19: upper sideband, ascending frequency (sync.c:514-536)
-            const int b = part20 < 10 ? LB0 + PW * part20 + j : UB1 - PW * 10 + PW * (part20 - 10) + j;
-            const float2 v = bins[n * LIVE_N + bin_to_live(b)];
-            const float mult = part20 < 10 ? mult_lb : mult_ub;
-            char2 o; o.x = (signed char)soft_bit(v.x, mult); o.y = (signed char)soft_bit(v.y, mult);
-            *(char2 *)(pm_blk + n * 720 + part20 * 36 + (j - 1) * 2) = o;
+#pragma unroll
+        for (int i = 0; i < MAXC; i++) {
+            const int c = tid + 256 * i;
+            if (c < ncell) {
+                const int k = 1 + c % 18, n = (c / 18) % NSYM, part = (c / (18 * NSYM)) % ppb, side = c / (18 * NSYM * ppb);
+                if (part < PM_PART) {
+                    const int part20 = side ? 19 - part : part;
+                    const float mult = side ? mult_ub : mult_lb;
+                    char2 o; o.x = (signed char)soft_bit(cellv[i].x, mult); o.y = (signed char)soft_bit(cellv[i].y, mult);
+                    *(char2 *)(pm_blk + n * 720 + part20 * 36 + (k - 1) * 2) = o;
+                }
+            }
         }
         __threadfence_block();
         __syncthreads();
+        SYNC_MARK(5);
 
-        // ---- PIDS: gather + depuncture (decode.c:324-342), 80-bit tail-biting Viterbi, descramble
-        for (int n = tid; n < PIDS_CODED; n += 256) pids_coded[n + n / 5] = pm_blk[tb.pids_gather[bc * PIDS_CODED + n]];
-        for (int n = tid; n < PIDS_CODED / 5; n += 256) pids_coded[6 * n + 5] = 0;
-        __syncthreads();
-        if (tid < 64) {
-            viterbi_k7_wave(pids_coded, PIDS_LEN, pids_dec, pids_out);
-        }
-        __syncthreads();
+        // ---- PIDS: gather + depuncture now (decode.c:324-342); the 80-bit Viterbi + descramble run in
+        // k_pids_decode, off this kernel's critical path (results only feed the record, not the loops)
+        int8_t *stage = db.pids_stage + (((size_t)s * 2 + parity) * 16 + slot) * (3 * PIDS_LEN);
+        for (int n = tid; n < PIDS_CODED; n += 256) stage[n + n / 5] = pm_blk[tb.pids_gather[bc * PIDS_CODED + n]];
+        for (int n = tid; n < PIDS_CODED / 5; n += 256) stage[6 * n + 5] = 0;
+        SYNC_MARK(6);
         if (tid == 0) {
-            rec.pids[0] = pids_out[0] ^ tb.scr_pids[0];
-            rec.pids[1] = pids_out[1] ^ tb.scr_pids[1];
-            rec.pids[2] = (pids_out[2] ^ tb.scr_pids[2]) & 0xffffu;
+            db.pids_rec[((size_t)s * 2 + parity) * 16 + slot] = st.nblocks % db.rec_cap;
             rec.flags |= REC_PIDS;
             rec.bc_decoded = bc;
             if (bc == 0) st.started_pm = 1;                    // decode.c:383-390
@@ -409,11 +431,42 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         st.nblocks++;
         st.active = 0;
     }
+    SYNC_MARK(7);
 }
 
-void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st)
+void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_sync, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity);
+    hipLaunchKernelGGL(k_sync, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, slot);
+}
+
+// ---- deferred PIDS decode: one wave per (slot, stream) with a staged frame -----------------------------------
+__global__ __launch_bounds__(64) void k_pids_decode(DevTables tb, DevBuffers db, const int *ids, int parity)
+{
+    const int s = stream_of(ids, blockIdx.y), slot = blockIdx.x;
+    int *recp = db.pids_rec + ((size_t)s * 2 + parity) * 16 + slot;
+    const int r = *recp;
+    if (r < 0) return;                                         // wave-uniform
+    __shared__ int8_t coded[3 * PIDS_LEN];
+    __shared__ unsigned long long dec[PIDS_LEN + 64];
+    __shared__ uint32_t out[4];
+    const int8_t *stage = db.pids_stage + (((size_t)s * 2 + parity) * 16 + slot) * (3 * PIDS_LEN);
+    const int lane = threadIdx.x;
+    for (int n = lane; n < 3 * PIDS_LEN; n += 64) coded[n] = stage[n];
+    __syncthreads();
+    viterbi_k7_wave(coded, PIDS_LEN, dec, out);
+    __syncthreads();
+    if (lane == 0) {
+        BlockRecord &rec = db.records[(size_t)s * db.rec_cap + r];
+        rec.pids[0] = out[0] ^ tb.scr_pids[0];                 // descramble (decode.c:470)
+        rec.pids[1] = out[1] ^ tb.scr_pids[1];
+        rec.pids[2] = (out[2] ^ tb.scr_pids[2]) & 0xffffu;
+        *recp = -1;
+    }
+}
+
+void launch_pids_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int nslots, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_pids_decode, dim3(nslots, nstreams), dim3(64), 0, st, tb, db, stream_ids, parity);
 }
 
 }  // namespace nrsc5

@@ -26,12 +26,15 @@ struct DevBuffers {
     float2 *bins;                    // [S][NSYM][LIVE_N]
     int8_t *pm;                      // [S][PM_FRAME]
     int8_t *coded;                   // [S][2][P1_DEPUNCT]
+    int8_t *pids_stage;              // [S][2][16][240]  depunctured PIDS soft bits awaiting k_pids_decode
+    int *pids_rec;                   // [S][2][16]       record index of each staged PIDS frame, -1 = empty
     unsigned long long *dec;         // [S][P1_LEN + 64]
     uint32_t *p1_ring;               // [S][p1_slots][P1_WORDS]
     int p1_slots;
     BlockRecord *records;            // [S][rec_cap]
     int rec_cap;
     int *counters;                   // [0]: streams that processed a block this step, [1]: not-FINE streams
+    long long *sync_phase_cycles;    // [8] optional: accumulated shader cycles per k_sync phase (stream 0 only), or null
 };
 
 // ---- K1 -------------------------------------------------------------------------------
@@ -46,7 +49,8 @@ void launch_append_cs16(const DevBuffers &db, int nstreams, const int *stream_id
 void launch_acquire(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
 void launch_prepare(const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st);
 void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
-void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st);
+void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, hipStream_t st);
+void launch_pids_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int nslots, hipStream_t st);
 void launch_p1_deint(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st);
 void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st);
 

@@ -65,6 +65,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.nrsc5hip_stage_selftest.argtypes = [vp, ctypes.POINTER(ci)]
     lib.nrsc5hip_stage_viterbi_k7_debug.argtypes = [vp, vp, ci, vp, vp]
     lib.nrsc5hip_stage_viterbi_bench.argtypes = [vp, ci, ci, ci, ci, ctypes.POINTER(ctypes.c_float)]
+    lib.nrsc5hip_debug_sync_phases.argtypes = [vp, vp]
     lib.nrsc5hip_reset_all.argtypes = [vp]
     lib.nrsc5hip_profile.argtypes = [vp, ci, vp, vp]
     return lib
@@ -76,7 +77,7 @@ EXPORTED_SYMBOLS = [
     "nrsc5hip_batch_append_cu8", "nrsc5hip_batch_append_cs16", "nrsc5hip_batch_process", "nrsc5hip_drain",
     "nrsc5hip_p1_frame_packed", "nrsc5hip_p1_frame_bits", "nrsc5hip_batch_fetch", "nrsc5hip_unpack_bits",
     "nrsc5hip_stage_halfband_fm_cu8", "nrsc5hip_stage_fft2048", "nrsc5hip_stage_viterbi_k7", "nrsc5hip_debug_fetch",
-    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench"]
+    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases"]
 
 
 def unpack_bits(words: np.ndarray, nbits: int) -> np.ndarray:
@@ -129,7 +130,7 @@ class Engine:
     def reset_all(self):
         self._check(self.lib.nrsc5hip_reset_all(self._h))
 
-    PROF_CLASSES = ("decimate", "acquire", "prepare", "mixfft", "sync", "p1_deint", "p1_viterbi")
+    PROF_CLASSES = ("decimate", "acquire", "prepare", "mixfft", "sync", "p1_deint", "p1_viterbi", "pids")
 
     def profile(self, enable: int = -1):
         """Per-kernel-class {name: (total_ms, launches)} from HIP events; enable 1/0 starts/stops."""
@@ -219,6 +220,11 @@ class Engine:
         ms = ctypes.c_float()
         self._check(self.lib.nrsc5hip_stage_viterbi_bench(self._h, length, nframes, phases, reps, ctypes.byref(ms)))
         return ms.value
+
+    def debug_sync_phases(self) -> np.ndarray:
+        c = np.zeros(8, dtype=np.int64)
+        self._check(self.lib.nrsc5hip_debug_sync_phases(self._h, c.ctypes.data))
+        return c
 
     def stage_selftest(self) -> int:
         n = ctypes.c_int(-1)
