@@ -23,6 +23,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the engine drives 1 main + 3 decode streams next to torch's: give each its own hardware queue
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 FS = 1488375.0
 ALG_BYTES_PER_SAMPLE = 2.008            # 2 B cu8 in + 18432 B decoded bits per 2211840-sample L1 frame

@@ -34,9 +34,9 @@ struct nrsc5hip_engine {
     nrsc5hip_config cfg;
     DevTables tb;
     DevBuffers db;
-    hipStream_t main, aux;
-    hipEvent_t ev_window[2], ev_decoded[2];
-    bool decoded_pending[2];
+    hipStream_t main, aux[NAUX];
+    hipEvent_t ev_window[NWIN], ev_decoded[NWIN];
+    bool decoded_pending[NWIN];
     std::vector<void *> allocs;
     // host mirrors
     std::vector<long long> wr_host, base_host;
@@ -189,8 +189,10 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
     const size_t S = cfg->max_streams;
     int rc = 0;
     do {
-        if (hipStreamCreate(&e->main) != hipSuccess || hipStreamCreate(&e->aux) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "hipStreamCreate failed"); break; }
-        for (int k = 0; k < 2; k++) { hipEventCreate(&e->ev_window[k]); hipEventCreate(&e->ev_decoded[k]); e->decoded_pending[k] = false; }
+        if (hipStreamCreate(&e->main) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "hipStreamCreate failed"); break; }
+        for (int k = 0; k < NAUX; k++) if (hipStreamCreate(&e->aux[k]) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "hipStreamCreate failed"); break; }
+        if (rc) break;
+        for (int k = 0; k < NWIN; k++) { (void)hipEventCreate(&e->ev_window[k]); (void)hipEventCreate(&e->ev_decoded[k]); e->decoded_pending[k] = false; }
         if ((rc = build_tables(e))) break;
         DevBuffers &db = e->db;
         db.q15_cap = cfg->q15_capacity; db.p1_slots = cfg->p1_slots; db.rec_cap = cfg->record_capacity;
@@ -200,11 +202,12 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if ((rc = dev_alloc(e, &db.acq_sums, S * SYM_N))) break;
         if ((rc = dev_alloc(e, &db.bins, S * NSYM * LIVE_N))) break;
         if ((rc = dev_alloc(e, &db.pm, S * PM_FRAME))) break;
-        if ((rc = dev_alloc(e, &db.coded, S * 2 * P1_DEPUNCT))) break;
-        if ((rc = dev_alloc(e, &db.dec, S * (size_t)(P1_LEN + 64)))) break;
-        if ((rc = dev_alloc(e, &db.pids_stage, S * 2 * 16 * 3 * PIDS_LEN))) break;
-        if ((rc = dev_alloc(e, &db.pids_rec, S * 2 * 16))) break;
-        if (hipMemset(db.pids_rec, 0xff, S * 2 * 16 * sizeof(int)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
+        if ((rc = dev_alloc(e, &db.coded, S * NWIN * P1_DEPUNCT))) break;
+        db.nstreams_alloc = (int)S;
+        if ((rc = dev_alloc(e, &db.dec, (size_t)(cfg->p1_async ? NAUX : 1) * S * (size_t)(P1_LEN + 64)))) break;
+        if ((rc = dev_alloc(e, &db.pids_stage, S * NWIN * 16 * 3 * PIDS_LEN))) break;
+        if ((rc = dev_alloc(e, &db.pids_rec, S * NWIN * 16))) break;
+        if (hipMemset(db.pids_rec, 0xff, S * NWIN * 16 * sizeof(int)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
         if ((rc = dev_alloc(e, &db.p1_ring, S * db.p1_slots * P1_WORDS))) break;
         if ((rc = dev_alloc(e, &db.records, S * db.rec_cap))) break;
         if ((rc = dev_alloc(e, &db.counters, 4))) break;
@@ -244,9 +247,9 @@ extern "C" void nrsc5hip_engine_destroy(nrsc5hip_engine *e)
     for (auto &sp : e->prof_spans) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
     for (hipEvent_t ev : e->prof_pool) hipEventDestroy(ev);
     if (e->counters_host) hipHostFree(e->counters_host);
-    for (int k = 0; k < 2; k++) { if (e->ev_window[k]) hipEventDestroy(e->ev_window[k]); if (e->ev_decoded[k]) hipEventDestroy(e->ev_decoded[k]); }
-    if (e->main) hipStreamDestroy(e->main);
-    if (e->aux) hipStreamDestroy(e->aux);
+    for (int k = 0; k < NWIN; k++) { if (e->ev_window[k]) (void)hipEventDestroy(e->ev_window[k]); if (e->ev_decoded[k]) (void)hipEventDestroy(e->ev_decoded[k]); }
+    if (e->main) (void)hipStreamDestroy(e->main);
+    for (int k = 0; k < NAUX; k++) if (e->aux[k]) (void)hipStreamDestroy(e->aux[k]);
     delete e;
 }
 
@@ -266,9 +269,11 @@ static int check_stream(nrsc5hip_engine *e, int s)
 static int issue_step(nrsc5hip_engine *e, int n, const int *ids_dev)
 {
     const bool async = e->cfg.p1_async != 0;
-    const int parity = async ? (int)((e->step_count / 16) & 1) : 0;
+    const long long window = e->step_count / 16;
+    const int parity = async ? (int)(window % NWIN) : 0;       // buffer slot of this decode window
+    const int lane = async ? (int)(window % NAUX) : 0;         // aux stream + decision scratch that will decode it
     if (async && (e->step_count % 16) == 0 && e->decoded_pending[parity]) {
-        // coded[.][parity] is about to be rewritten: the decoder launched two windows ago must be done
+        // the buffers of slot `parity` are about to be rewritten: the decoder launched NWIN windows ago must be done
         HIPCHK(hipStreamWaitEvent(e->main, e->ev_decoded[parity], 0));
         e->decoded_pending[parity] = false;
     }
@@ -281,13 +286,16 @@ static int issue_step(nrsc5hip_engine *e, int n, const int *ids_dev)
     if (!async) {
         { ProfScope p(e, NRSC5HIP_PROF_PIDS, e->main); launch_pids_decode(e->tb, e->db, n, ids_dev, parity, 1, e->main); }
         ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, e->main);
-        launch_p1_viterbi(e->tb, e->db, n, ids_dev, parity, e->main);
+        launch_p1_viterbi(e->tb, e->db, n, ids_dev, parity, 0, e->main);
     } else if ((e->step_count % 16) == 15) {
+        // window complete: decode its PIDS frames and P1 frames on aux stream `lane`, overlapped with the next
+        // windows (NAUX windows decode concurrently, each wave of the forward pass alone on a SIMD)
+        hipStream_t ax = e->aux[lane];
         HIPCHK(hipEventRecord(e->ev_window[parity], e->main));
-        HIPCHK(hipStreamWaitEvent(e->aux, e->ev_window[parity], 0));
-        { ProfScope p(e, NRSC5HIP_PROF_PIDS, e->aux); launch_pids_decode(e->tb, e->db, n, ids_dev, parity, 16, e->aux); }
-        { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, e->aux); launch_p1_viterbi(e->tb, e->db, n, ids_dev, parity, e->aux); }
-        HIPCHK(hipEventRecord(e->ev_decoded[parity], e->aux));
+        HIPCHK(hipStreamWaitEvent(ax, e->ev_window[parity], 0));
+        { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_pids_decode(e->tb, e->db, n, ids_dev, parity, 16, ax); }
+        { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ax); launch_p1_viterbi(e->tb, e->db, n, ids_dev, parity, lane, ax); }
+        HIPCHK(hipEventRecord(e->ev_decoded[parity], ax));
         e->decoded_pending[parity] = true;
     }
     e->step_count++;
@@ -300,13 +308,17 @@ static int flush_p1(nrsc5hip_engine *e, int n, const int *ids_dev)
 {
     if (!e->cfg.p1_async) return 0;
     if (e->step_count % 16) {
-        const int parity = (int)((e->step_count / 16) & 1);
-        { ProfScope p(e, NRSC5HIP_PROF_PIDS, e->main); launch_pids_decode(e->tb, e->db, n, ids_dev, parity, 16, e->main); }
-        { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, e->main); launch_p1_viterbi(e->tb, e->db, n, ids_dev, parity, e->main); }
+        const long long window = e->step_count / 16;
+        const int parity = (int)(window % NWIN), lane = (int)(window % NAUX);
+        hipStream_t ax = e->aux[lane];
+        HIPCHK(hipEventRecord(e->ev_window[parity], e->main));
+        HIPCHK(hipStreamWaitEvent(ax, e->ev_window[parity], 0));
+        { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_pids_decode(e->tb, e->db, n, ids_dev, parity, 16, ax); }
+        { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ax); launch_p1_viterbi(e->tb, e->db, n, ids_dev, parity, lane, ax); }
         e->step_count += 16 - (e->step_count % 16);           // next batch starts a fresh window
     }
-    HIPCHK(hipStreamSynchronize(e->aux));
-    e->decoded_pending[0] = e->decoded_pending[1] = false;
+    for (int k = 0; k < NAUX; k++) HIPCHK(hipStreamSynchronize(e->aux[k]));
+    for (int k = 0; k < NWIN; k++) e->decoded_pending[k] = false;
     return 0;
 }
 
@@ -644,9 +656,9 @@ extern "C" int nrsc5hip_reset_all(nrsc5hip_engine *e)
     std::fill(e->wr_host.begin(), e->wr_host.end(), 0);
     std::fill(e->base_host.begin(), e->base_host.end(), 0);
     std::fill(e->drained.begin(), e->drained.end(), 0);
-    HIPCHK(hipMemset(e->db.pids_rec, 0xff, S * 2 * 16 * sizeof(int)));
+    HIPCHK(hipMemset(e->db.pids_rec, 0xff, S * NWIN * 16 * sizeof(int)));
     e->acq_needed = true; e->step_count = 0;
-    e->decoded_pending[0] = e->decoded_pending[1] = false;
+    for (int k = 0; k < NWIN; k++) e->decoded_pending[k] = false;
     return 0;
 }
 

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(1024) void k_p1_deint(DevTables tb, DevBuffers db, 
     const StreamState &st = db.state[s];
     if (st.p1_pending[parity] != 1) return;                    // 1 = completed in this step, 2 = already gathered
     const int8_t *pm = db.pm + (size_t)s * PM_FRAME;
-    int8_t *out = db.coded + ((size_t)s * 2 + parity) * P1_DEPUNCT;
+    int8_t *out = db.coded + ((size_t)s * NWIN + parity) * P1_DEPUNCT;
     // 4 groups (24 output bytes, 20 gathers) per thread iteration; the grid has few blocks per stream so that
     // the 15 of 16 steps in which no frame completes cost one wave-uniform early exit per block
     for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < P1_CODED / 5; g += gridDim.x * blockDim.x) {
@@ -56,20 +56,20 @@ __device__ inline int bit_errors_k7_partial(const int8_t *coded, const uint32_t 
 }
 
 // ---- K7: P1 frame = forward pass by one wave, then traceback/BER/descramble by a 16-wave block -------
-__global__ __launch_bounds__(64) void k_p1_forward(DevBuffers db, const int *ids, int parity)
+__global__ __launch_bounds__(64) void k_p1_forward(DevBuffers db, const int *ids, int parity, int lane_id)
 {
     const int s = stream_of(ids, blockIdx.x);
     StreamState &st = db.state[s];
     if (!st.p1_pending[parity]) return;                        // wave-uniform
-    const int8_t *coded = db.coded + ((size_t)s * 2 + parity) * P1_DEPUNCT;
-    unsigned long long *dec = db.dec + (size_t)s * (P1_LEN + 64);
+    const int8_t *coded = db.coded + ((size_t)s * NWIN + parity) * P1_DEPUNCT;
+    unsigned long long *dec = db.dec + ((size_t)lane_id * db.nstreams_alloc + s) * (P1_LEN + 64);
     const int endlane = viterbi_fast_forward(coded, P1_LEN, dec);
     if ((threadIdx.x & 63) == 0) st.p1_endlane[parity] = endlane;
 }
 
 constexpr int TB_THREADS = 1024;
 
-__global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBuffers db, const int *ids, int parity)
+__global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id)
 {
     const int s = stream_of(ids, blockIdx.x);
     StreamState &st = db.state[s];
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBu
     HIP_DYNAMIC_SHARED(uint8_t, smem)
     __shared__ int err_total;
     const int tid = threadIdx.x;
-    const int8_t *coded = db.coded + ((size_t)s * 2 + parity) * P1_DEPUNCT;
-    unsigned long long *dec = db.dec + (size_t)s * (P1_LEN + 64);
+    const int8_t *coded = db.coded + ((size_t)s * NWIN + parity) * P1_DEPUNCT;
+    unsigned long long *dec = db.dec + ((size_t)lane_id * db.nstreams_alloc + s) * (P1_LEN + 64);
     uint32_t *out = db.p1_ring + ((size_t)s * db.p1_slots + st.p1_slot[parity]) * P1_WORDS;
     if (tid == 0) err_total = 0;
     viterbi_fast_traceback_block(dec, P1_LEN, st.p1_endlane[parity], out, smem);
@@ -102,15 +102,15 @@ void launch_p1_deint(const DevTables &tb, const DevBuffers &db, int nstreams, co
     hipLaunchKernelGGL(k_p1_deint, grid, dim3(1024), 0, st, tb, db, stream_ids, parity);
 }
 
-void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st)
+void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st)
 {
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)k_p1_traceback, hipFuncAttributeMaxDynamicSharedMemorySize, (int)traceback_smem(P1_LEN));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_p1_forward, dim3(nstreams), dim3(64), 0, st, db, stream_ids, parity);
-    hipLaunchKernelGGL(k_p1_traceback, dim3(nstreams), dim3(TB_THREADS), traceback_smem(P1_LEN), st, tb, db, stream_ids, parity);
+    hipLaunchKernelGGL(k_p1_forward, dim3(nstreams), dim3(64), 0, st, db, stream_ids, parity, lane_id);
+    hipLaunchKernelGGL(k_p1_traceback, dim3(nstreams), dim3(TB_THREADS), traceback_smem(P1_LEN), st, tb, db, stream_ids, parity, lane_id);
 }
 
 // ---- stage-level entry: decode `nframes` independent frames of equal length (parity tests) ----------

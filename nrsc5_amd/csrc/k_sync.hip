@@ -396,12 +396,12 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
 
         // ---- PIDS: gather + depuncture now (decode.c:324-342); the 80-bit Viterbi + descramble run in
         // k_pids_decode, off this kernel's critical path (results only feed the record, not the loops)
-        int8_t *stage = db.pids_stage + (((size_t)s * 2 + parity) * 16 + slot) * (3 * PIDS_LEN);
+        int8_t *stage = db.pids_stage + (((size_t)s * NWIN + parity) * 16 + slot) * (3 * PIDS_LEN);
         for (int n = tid; n < PIDS_CODED; n += 256) stage[n + n / 5] = pm_blk[tb.pids_gather[bc * PIDS_CODED + n]];
         for (int n = tid; n < PIDS_CODED / 5; n += 256) stage[6 * n + 5] = 0;
         SYNC_MARK(6);
         if (tid == 0) {
-            db.pids_rec[((size_t)s * 2 + parity) * 16 + slot] = st.nblocks % db.rec_cap;
+            db.pids_rec[((size_t)s * NWIN + parity) * 16 + slot] = st.nblocks % db.rec_cap;
             rec.flags |= REC_PIDS;
             rec.bc_decoded = bc;
             if (bc == 0) st.started_pm = 1;                    // decode.c:383-390
@@ -443,13 +443,13 @@ void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const 
 __global__ __launch_bounds__(64) void k_pids_decode(DevTables tb, DevBuffers db, const int *ids, int parity)
 {
     const int s = stream_of(ids, blockIdx.y), slot = blockIdx.x;
-    int *recp = db.pids_rec + ((size_t)s * 2 + parity) * 16 + slot;
+    int *recp = db.pids_rec + ((size_t)s * NWIN + parity) * 16 + slot;
     const int r = *recp;
     if (r < 0) return;                                         // wave-uniform
     __shared__ int8_t coded[3 * PIDS_LEN];
     __shared__ unsigned long long dec[PIDS_LEN + 64];
     __shared__ uint32_t out[4];
-    const int8_t *stage = db.pids_stage + (((size_t)s * 2 + parity) * 16 + slot) * (3 * PIDS_LEN);
+    const int8_t *stage = db.pids_stage + (((size_t)s * NWIN + parity) * 16 + slot) * (3 * PIDS_LEN);
     const int lane = threadIdx.x;
     for (int n = lane; n < 3 * PIDS_LEN; n += 64) coded[n] = stage[n];
     __syncthreads();

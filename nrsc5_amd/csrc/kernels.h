@@ -25,10 +25,11 @@ struct DevBuffers {
     float2 *acq_sums;                // [S][SYM_N]
     float2 *bins;                    // [S][NSYM][LIVE_N]
     int8_t *pm;                      // [S][PM_FRAME]
-    int8_t *coded;                   // [S][2][P1_DEPUNCT]
-    int8_t *pids_stage;              // [S][2][16][240]  depunctured PIDS soft bits awaiting k_pids_decode
-    int *pids_rec;                   // [S][2][16]       record index of each staged PIDS frame, -1 = empty
-    unsigned long long *dec;         // [S][P1_LEN + 64]
+    int8_t *coded;                   // [S][NWIN][P1_DEPUNCT]
+    int8_t *pids_stage;              // [S][NWIN][16][240]  depunctured PIDS soft bits awaiting k_pids_decode
+    int *pids_rec;                   // [S][NWIN][16]     record index of each staged PIDS frame, -1 = empty
+    unsigned long long *dec;         // [NAUX][S][P1_LEN + 64]  survivor decisions, one scratch per decode lane
+    int nstreams_alloc;              // S
     uint32_t *p1_ring;               // [S][p1_slots][P1_WORDS]
     int p1_slots;
     BlockRecord *records;            // [S][rec_cap]
@@ -52,7 +53,7 @@ void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, cons
 void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, hipStream_t st);
 void launch_pids_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int nslots, hipStream_t st);
 void launch_p1_deint(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st);
-void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st);
+void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st);
 
 // ---- stage-level entry points (parity tests) ---------------------------------------------------
 void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st, int phases = 3);

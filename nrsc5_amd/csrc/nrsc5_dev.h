@@ -27,6 +27,8 @@ constexpr int PIDS_LEN = 80;
 constexpr int PIDS_CODED = 200;
 constexpr int VIT_EXTRA = 32;          // TAIL_BITING_EXTRA, conv_dec.c:43
 constexpr int P1_WORDS = P1_LEN / 32;  // packed output words per P1 frame (4568)
+constexpr int NWIN = 8;                // decode windows (16 block steps each) that may be in flight: buffers indexed w % NWIN
+constexpr int NAUX = 3;                // HIP streams that decode windows concurrently (each with its own decision scratch)
 
 enum { SYNC_NONE = 0, SYNC_COARSE = 1, SYNC_FINE = 2 };   // input.h:18
 
@@ -91,11 +93,11 @@ struct StreamState {
     int samperr_cur; int pad0;
     double dtheta;              // effective NCO step (rad/sample) for the current block
     int coarse_samperr; float coarse_re, coarse_im;
-    // P1 hand-off, double-buffered by decode-window parity (see engine.hip: P1 pipeline)
-    int p1_pending[2];          // 1: frame completed this step (gather it), 2: gathered into coded[s][parity]
-    int p1_slot[2];             // slot of the stream's P1 ring the decoder must fill
-    int p1_record[2];           // record index that gets the BER
-    int p1_endlane[2];          // forward pass -> traceback hand-off (lane of the winning end state)
+    // P1 hand-off, one slot per in-flight decode window (see engine.hip: P1 pipeline); `parity` = window % NWIN
+    int p1_pending[NWIN];          // 1: frame completed this step (gather it), 2: gathered into coded[s][parity]
+    int p1_slot[NWIN];             // slot of the stream's P1 ring the decoder must fill
+    int p1_record[NWIN];           // record index that gets the BER
+    int p1_endlane[NWIN];          // forward pass -> traceback hand-off (lane of the winning end state)
 };
 
 }  // namespace nrsc5
