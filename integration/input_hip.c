@@ -1,0 +1,165 @@
+/* Drop-in replacement for the reference's src/input.c: same functions, same `input_t` (src/input.h:20-35),
+ * but the whole L3a-L3d hot path (decimate, acquire, sync, decode, Viterbi) runs in libnrsc5hip on an
+ * MI355X.  A maintainer of theori-io/nrsc5 compiles THIS file instead of
+ *     src/input.c src/acquire.c src/sync.c src/decode.c src/conv_dec.c src/firdecim_q15.c
+ * and links libnrsc5hip.so; include/nrsc5.h, src/nrsc5.c, frame.c, pids.c, output.c ... stay untouched.
+ *
+ * Mapping (reference line -> here):
+ *   input_push_cu8  input.c:96-117  -> nrsc5hip_push_cu8 + deliver()
+ *   input_push_cs16 input.c:119-124 -> nrsc5hip_push_cs16 + deliver()
+ *   input_reset     input.c:126-138 -> nrsc5hip_stream_reset + pids_init/frame_reset
+ *   input_set_sync_state input.c:172-188: called by frame_process (frame.c:539) with SYNC_STATE_NONE
+ *                                   -> nrsc5hip_force_resync + nrsc5_report_lost_sync
+ *   up-calls, in the reference's order inside acquire_process: output_advance (acquire.c:108),
+ *   nrsc5_report_sync (input.c:185), decode_reset/frame_reset (sync.c:405-409), nrsc5_report_mer
+ *   (sync.c:497), pids_frame_push (decode.c:471), nrsc5_report_ber (decode.c:458), frame_push (decode.c:460).
+ */
+#include "config.h"
+
+#include <assert.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "defines.h"
+#include "input.h"
+#include "private.h"
+
+#include "nrsc5hip.h"
+
+/* one engine per session; stream 0.  acquire_t's otherwise unused FFTW slots carry the handle so that
+ * input_t keeps the reference's exact layout. */
+#define ENGINE(st) ((nrsc5hip_engine *)(st)->acq.fftin)
+
+static void die(const char *what)
+{
+    fprintf(stderr, "nrsc5hip: %s: %s\n", what, nrsc5hip_last_error());
+    abort();   /* the pipe API cannot report errors (nrsc5.c:624 always returns 0); fail loudly */
+}
+
+static void deliver(input_t *st)
+{
+    static uint8_t bits[NRSC5HIP_P1_FRAME_BITS];
+    nrsc5hip_record rec[64];
+    int n = 0;
+
+    do
+    {
+        if (nrsc5hip_drain(ENGINE(st), 0, rec, 64, &n) != 0) die("drain");
+        for (int k = 0; k < n; k++)
+        {
+            const nrsc5hip_record *r = &rec[k];
+            if (r->flags & NRSC5HIP_REC_PROCESSED)
+                output_advance(st->output);
+            if (r->flags & NRSC5HIP_REC_TO_COARSE)
+                st->sync_state = SYNC_STATE_COARSE;
+            if (r->flags & NRSC5HIP_REC_TO_FINE)
+            {
+                st->sync.psmi = r->psmi;
+                st->sync_state = SYNC_STATE_FINE;
+                nrsc5_report_sync(st->radio, r->freq_offset, r->psmi, -1, -1, -1, -1);
+                pids_init(&st->decode.pids, st);     /* decode_reset (decode.c:563-572) */
+                frame_reset(&st->frame);
+            }
+            if (r->flags & NRSC5HIP_REC_MER)
+                nrsc5_report_mer(st->radio, r->mer_lb, r->mer_ub);
+            if (r->flags & NRSC5HIP_REC_PIDS)
+            {
+                uint8_t pids[PIDS_FRAME_LEN];
+                nrsc5hip_unpack_bits(r->pids, PIDS_FRAME_LEN, pids);
+                pids_frame_push(&st->decode.pids, pids);
+            }
+            if (r->flags & NRSC5HIP_REC_P1)
+            {
+                nrsc5_report_ber(st->radio, r->ber);
+                if (nrsc5hip_p1_frame_bits(ENGINE(st), 0, r->p1_slot, bits) != 0) die("p1_frame_bits");
+                frame_push(&st->frame, bits, P1_FRAME_LEN_FM, P1_LOGICAL_CHANNEL);   /* may call input_set_sync_state(NONE) */
+            }
+        }
+    } while (n == 64);
+}
+
+void input_push_cu8(input_t *st, const uint8_t *buf, const uint32_t len)
+{
+    nrsc5_report_iq(st->radio, buf, len);
+    assert(len % 4 == 0);
+    /* feed block-sized pieces so that the L2 feedback of a frame reaches the engine before the next block,
+       exactly as in the reference (FINE -> NONE only comes from frame_process) */
+    uint32_t consumed = 0;
+    while (consumed < len)
+    {
+        uint32_t piece = len - consumed;
+        if (piece > 4 * 4320) piece = 4 * 4320;
+        if (nrsc5hip_push_cu8(ENGINE(st), 0, buf + consumed, piece) != 0) die("push_cu8");
+        deliver(st);
+        consumed += piece;
+    }
+}
+
+void input_push_cs16(input_t *st, const int16_t *buf, const uint32_t len)
+{
+    assert(len % 2 == 0);
+    uint32_t consumed = 0;
+    while (consumed < len)
+    {
+        uint32_t piece = len - consumed;
+        if (piece > 2 * 4320) piece = 2 * 4320;
+        if (nrsc5hip_push_cs16(ENGINE(st), 0, buf + consumed, piece) != 0) die("push_cs16");
+        deliver(st);
+        consumed += piece;
+    }
+}
+
+void input_set_sync_state(input_t *st, unsigned int new_state)
+{
+    if (st->sync_state == new_state)
+        return;
+    if (st->sync_state == SYNC_STATE_FINE)
+        nrsc5_report_lost_sync(st->radio);
+    if (new_state == SYNC_STATE_NONE && ENGINE(st))
+        if (nrsc5hip_force_resync(ENGINE(st), 0) != 0) die("force_resync");
+    st->sync_state = new_state;
+}
+
+void input_reset(input_t *st)
+{
+    input_set_sync_state(st, SYNC_STATE_NONE);
+    if (nrsc5hip_stream_reset(ENGINE(st), 0) != 0) die("stream_reset");
+    pids_init(&st->decode.pids, st);
+    frame_reset(&st->frame);
+    st->sync.psmi = 1;
+}
+
+void input_init(input_t *st, nrsc5_t *radio, output_t *output)
+{
+    const char *dev = getenv("NRSC5HIP_DEVICE");
+    nrsc5hip_config cfg = { dev ? atoi(dev) : 0, 1, 1 << 20, 256, 4, 0 /* in-order P1: reference event timing */ };
+    nrsc5hip_engine *e = NULL;
+
+    memset(&st->acq, 0, sizeof(st->acq));
+    st->radio = radio;
+    st->output = output;
+    st->sync_state = SYNC_STATE_NONE;
+    if (nrsc5hip_engine_create(&cfg, &e) != 0) die("engine_create");
+    st->acq.fftin = (void *)e;
+    st->decode.input = st;
+    frame_init(&st->frame, st);
+    input_reset(st);
+}
+
+void input_set_mode(input_t *st)
+{
+    if (st->radio->mode != NRSC5_MODE_FM)
+    {
+        fprintf(stderr, "nrsc5hip: AM is not implemented on the HIP path yet\n");
+        abort();
+    }
+    input_reset(st);
+}
+
+void input_free(input_t *st)
+{
+    frame_free(&st->frame);
+    nrsc5hip_engine_destroy(ENGINE(st));
+    st->acq.fftin = NULL;
+}

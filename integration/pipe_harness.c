@@ -1,0 +1,53 @@
+/* TEST INFRASTRUCTURE: drives any libnrsc5 build (the reference's, or the HIP drop-in) through the PUBLIC
+ * pipe API only (nrsc5.h:712-871) and logs the events both must agree on. */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <nrsc5.h>
+
+typedef struct { uint8_t *p; size_t len, cap; } gbuf;
+static gbuf g_log;
+
+static void put(const void *src, size_t n)
+{
+    if (g_log.len + n > g_log.cap) { size_t nc = g_log.cap ? g_log.cap * 2 : 1 << 20; while (nc < g_log.len + n) nc *= 2; g_log.p = realloc(g_log.p, nc); g_log.cap = nc; }
+    memcpy(g_log.p + g_log.len, src, n); g_log.len += n;
+}
+static void rec(uint32_t kind, const void *payload, uint32_t n)
+{
+    uint32_t hdr[2] = { kind, n }, z = 0, pad = (4 - (n & 3)) & 3;
+    put(hdr, 8); if (n) put(payload, n); if (pad) put(&z, pad);
+}
+static void on_event(const nrsc5_event_t *evt, void *opaque)
+{
+    (void)opaque;
+    switch (evt->event) {
+    case NRSC5_EVENT_SYNC: { struct { float f; int32_t a[5]; } r = { evt->sync.freq_offset, { evt->sync.psmi, evt->sync.pli, evt->sync.hppi, evt->sync.aabi, evt->sync.rdbi } }; rec(6, &r, sizeof(r)); break; }
+    case NRSC5_EVENT_LOST_SYNC: rec(7, NULL, 0); break;
+    case NRSC5_EVENT_MER: { float r[2] = { evt->mer.lower, evt->mer.upper }; rec(8, r, sizeof(r)); break; }
+    case NRSC5_EVENT_BER: { float r = evt->ber.cber; rec(9, &r, sizeof(r)); break; }
+    case NRSC5_EVENT_HDC: {
+        uint8_t *tmp = malloc(12 + evt->hdc.count);
+        uint32_t h[3] = { evt->hdc.program, (uint32_t)evt->hdc.count, evt->hdc.flags };
+        memcpy(tmp, h, 12); if (evt->hdc.count) memcpy(tmp + 12, evt->hdc.data, evt->hdc.count);
+        rec(10, tmp, 12 + (uint32_t)evt->hdc.count); free(tmp); break; }
+    default: break;
+    }
+}
+
+size_t pipe_run_cu8(const uint8_t *iq, size_t nbytes, unsigned chunk, const uint8_t **out)
+{
+    nrsc5_t *radio = NULL;
+    g_log.len = 0;
+    if (nrsc5_open_pipe(&radio) != 0) return 0;
+    nrsc5_set_mode(radio, NRSC5_MODE_FM);
+    nrsc5_set_callback(radio, on_event, NULL);
+    for (size_t off = 0; off < nbytes; off += chunk) {
+        unsigned n = (nbytes - off < chunk) ? (unsigned)(nbytes - off) : chunk;
+        nrsc5_pipe_samples_cu8(radio, iq + off, n);
+    }
+    nrsc5_close(radio);
+    *out = g_log.p;
+    return g_log.len;
+}

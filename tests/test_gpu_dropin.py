@@ -1,0 +1,44 @@
+"""`-m gpu`: the DROP-IN seen from the reference's own public API (nrsc5.h): the reference's L4/L2/L1' code,
+unmodified, linked with integration/input_hip.c + libnrsc5hip.so, against the plain reference library.
+Both are driven only through nrsc5_open_pipe / nrsc5_set_mode / nrsc5_set_callback / nrsc5_pipe_samples_cu8.
+The libraries are prebuilt in the build container (integration/Makefile needs /root/reference)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from tests import common
+from oracle import ref
+
+pytestmark = pytest.mark.gpu
+BUILD = os.path.join(common.ROOT, "integration", "_build")
+
+
+def _run(libname, iq, chunk=32768):
+    path = os.path.join(BUILD, libname)
+    if not os.path.exists(path):
+        pytest.skip(f"{libname} not prebuilt (integration/Makefile needs /root/reference)")
+    lib = ctypes.CDLL(path)
+    lib.pipe_run_cu8.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.POINTER(ctypes.c_void_p)]
+    lib.pipe_run_cu8.restype = ctypes.c_size_t
+    p = ctypes.c_void_p()
+    n = lib.pipe_run_cu8(iq.ctypes.data, iq.size, chunk, ctypes.byref(p))
+    return ref.parse_log(ctypes.string_at(p, n))
+
+
+@pytest.mark.parametrize("name", ["fm_cu8_cfo137", "fm_cu8_cfo-2400"])
+def test_dropin_public_api_events_match_reference(name, captures):
+    cap = captures(name)
+    iq = np.ascontiguousarray(cap.iq)
+    exp = _run("libnrsc5_plain.so", iq)
+    got = _run("libnrsc5_hipdropin.so", iq)
+    assert [k for k, _ in exp] == [k for k, _ in got]
+    assert any(k == "hdc" for k, _ in exp) or name != "fm_cu8_cfo137"
+    for (k, a), (_, b) in zip(exp, got):
+        if k == "hdc":
+            assert a["program"] == b["program"] and a["flags"] == b["flags"] and a["data"] == b["data"]
+        elif k in ("sync", "mer", "ber"):
+            for f in a:
+                va, vb = a[f], b[f]
+                assert abs(va - vb) <= common.FLOAT_RTOL * max(1.0, abs(va)), (k, f, va, vb)
