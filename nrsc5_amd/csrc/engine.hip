@@ -14,6 +14,7 @@
 
 using namespace nrsc5;
 
+constexpr int MAX_LANES = 4;
 static_assert(sizeof(nrsc5hip_record) == sizeof(BlockRecord), "record ABI mismatch");
 static_assert(sizeof(BlockRecord) % 8 == 0, "record alignment");
 
@@ -34,19 +35,26 @@ struct nrsc5hip_engine {
     nrsc5hip_config cfg;
     DevTables tb;
     DevBuffers db;
-    hipStream_t main, aux[NAUX];
-    hipEvent_t ev_window[NWIN], ev_decoded[NWIN];
-    bool decoded_pending[NWIN];
+    // Scheduler lanes: each lane advances its own subset of the streams on its own HIP streams, so the
+    // latency-bound per-block kernels of different lanes overlap (lane 0 also serves the streaming seam).
+    struct Lane {
+        hipStream_t main, aux[NAUX];
+        hipEvent_t ev_window[NWIN], ev_decoded[NWIN];
+        bool decoded_pending[NWIN];
+        bool acq_needed;
+        long long step_count;          // block steps issued so far (decode-window bookkeeping in async mode)
+        int *counters_dev, *counters_host;
+        DevBuffers db;                 // engine buffers with this lane's counters
+    } lanes[MAX_LANES];
+    int nlanes;
+    hipStream_t main;                  // = lanes[0].main
     std::vector<void *> allocs;
     // host mirrors
     std::vector<long long> wr_host, base_host;
     std::vector<int> drained;          // records already handed out per stream
-    bool acq_needed;
-    long long step_count;              // block steps issued so far (P1 window parity in async mode)
     // staging
     uint8_t *stage_dev; size_t stage_bytes;
     int *ids_dev; unsigned *nbytes_dev;
-    int *counters_host;                // pinned
     int *all_ids_dev;                  // identity list 0..S-1
     // optional per-kernel-class timing with HIP events on the launching stream
     bool prof_on;
@@ -189,10 +197,25 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
     const size_t S = cfg->max_streams;
     int rc = 0;
     do {
-        if (hipStreamCreate(&e->main) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "hipStreamCreate failed"); break; }
-        for (int k = 0; k < NAUX; k++) if (hipStreamCreate(&e->aux[k]) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "hipStreamCreate failed"); break; }
-        if (rc) break;
-        for (int k = 0; k < NWIN; k++) { (void)hipEventCreate(&e->ev_window[k]); (void)hipEventCreate(&e->ev_decoded[k]); e->decoded_pending[k] = false; }
+        {
+            const char *env = getenv("NRSC5HIP_LANES");
+            e->nlanes = env ? atoi(env) : (cfg->p1_async && cfg->max_streams >= 32 ? 2 : 1);
+            if (e->nlanes < 1) e->nlanes = 1;
+            if (e->nlanes > MAX_LANES) e->nlanes = MAX_LANES;
+        }
+        for (int l = 0; l < e->nlanes && !rc; l++) {
+            nrsc5hip_engine::Lane &ln = e->lanes[l];
+            if (hipStreamCreate(&ln.main) != hipSuccess) rc = NRSC5HIP_EHIP;
+            for (int k = 0; k < NAUX && !rc; k++) if (hipStreamCreate(&ln.aux[k]) != hipSuccess) rc = NRSC5HIP_EHIP;
+            for (int k = 0; k < NWIN && !rc; k++) {
+                if (hipEventCreate(&ln.ev_window[k]) != hipSuccess || hipEventCreate(&ln.ev_decoded[k]) != hipSuccess) rc = NRSC5HIP_EHIP;
+                ln.decoded_pending[k] = false;
+            }
+            ln.acq_needed = true; ln.step_count = 0;
+            if (!rc && hipHostMalloc((void **)&ln.counters_host, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) rc = NRSC5HIP_ENOMEM;
+        }
+        if (rc) { snprintf(g_err, sizeof(g_err), "stream/event creation failed"); break; }
+        e->main = e->lanes[0].main;
         if ((rc = build_tables(e))) break;
         DevBuffers &db = e->db;
         db.q15_cap = cfg->q15_capacity; db.p1_slots = cfg->p1_slots; db.rec_cap = cfg->record_capacity;
@@ -210,7 +233,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if (hipMemset(db.pids_rec, 0xff, S * NWIN * 16 * sizeof(int)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
         if ((rc = dev_alloc(e, &db.p1_ring, S * db.p1_slots * P1_WORDS))) break;
         if ((rc = dev_alloc(e, &db.records, S * db.rec_cap))) break;
-        if ((rc = dev_alloc(e, &db.counters, 4))) break;
+        if ((rc = dev_alloc(e, &db.counters, 4 * MAX_LANES))) break;
         db.sync_phase_cycles = nullptr;
         if (getenv("NRSC5HIP_SYNC_PHASES")) {
             if ((rc = dev_alloc(e, &db.sync_phase_cycles, 8))) break;
@@ -221,7 +244,6 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if ((rc = dev_alloc(e, &e->ids_dev, S))) break;
         if ((rc = dev_alloc(e, &e->nbytes_dev, S))) break;
         if ((rc = dev_alloc(e, &e->all_ids_dev, S))) break;
-        if (hipHostMalloc((void **)&e->counters_host, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) { rc = NRSC5HIP_ENOMEM; snprintf(g_err, sizeof(g_err), "hipHostMalloc failed"); break; }
         std::vector<StreamState> init(S);
         std::vector<int> ident(S);
         for (size_t s = 0; s < S; s++) { init_state(init[s]); ident[s] = (int)s; }
@@ -230,7 +252,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             hipMemset(db.records, 0, S * db.rec_cap * sizeof(BlockRecord)) != hipSuccess ||
             hipMemset(db.pm, 0, S * PM_FRAME) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "state init copy failed"); break; }
         e->wr_host.assign(S, 0); e->base_host.assign(S, 0); e->drained.assign(S, 0);
-        e->acq_needed = true; e->step_count = 0;
+        for (int l = 0; l < e->nlanes; l++) { e->lanes[l].db = db; e->lanes[l].counters_dev = db.counters + 4 * l; e->lanes[l].db.counters = db.counters + 4 * l; }
         e->prof_on = false;
         for (int k = 0; k < NRSC5HIP_PROF_CLASSES; k++) { e->prof_ms[k] = 0; e->prof_launches[k] = 0; }
     } while (0);
@@ -246,10 +268,13 @@ extern "C" void nrsc5hip_engine_destroy(nrsc5hip_engine *e)
     for (void *p : e->allocs) hipFree(p);
     for (auto &sp : e->prof_spans) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
     for (hipEvent_t ev : e->prof_pool) hipEventDestroy(ev);
-    if (e->counters_host) hipHostFree(e->counters_host);
-    for (int k = 0; k < NWIN; k++) { if (e->ev_window[k]) (void)hipEventDestroy(e->ev_window[k]); if (e->ev_decoded[k]) (void)hipEventDestroy(e->ev_decoded[k]); }
-    if (e->main) (void)hipStreamDestroy(e->main);
-    for (int k = 0; k < NAUX; k++) if (e->aux[k]) (void)hipStreamDestroy(e->aux[k]);
+    for (int l = 0; l < e->nlanes; l++) {
+        nrsc5hip_engine::Lane &ln = e->lanes[l];
+        if (ln.counters_host) (void)hipHostFree(ln.counters_host);
+        for (int k = 0; k < NWIN; k++) { if (ln.ev_window[k]) (void)hipEventDestroy(ln.ev_window[k]); if (ln.ev_decoded[k]) (void)hipEventDestroy(ln.ev_decoded[k]); }
+        if (ln.main) (void)hipStreamDestroy(ln.main);
+        for (int k = 0; k < NAUX; k++) if (ln.aux[k]) (void)hipStreamDestroy(ln.aux[k]);
+    }
     delete e;
 }
 
@@ -266,86 +291,99 @@ static int check_stream(nrsc5hip_engine *e, int s)
 // One step = every listed stream whose 33-symbol window is complete advances by one block:
 //   [acquisition kernels if any stream may be un-synchronised] -> prepare -> mix+FFT -> sync (+PIDS)
 //   -> P1 de-interleave -> P1 Viterbi (in order, or deferred to the aux stream once per 16-step window).
-static int issue_step(nrsc5hip_engine *e, int n, const int *ids_dev)
+static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const int *ids_dev)
 {
     const bool async = e->cfg.p1_async != 0;
-    const long long window = e->step_count / 16;
+    const long long window = ln.step_count / 16;
     const int parity = async ? (int)(window % NWIN) : 0;       // buffer slot of this decode window
     const int lane = async ? (int)(window % NAUX) : 0;         // aux stream + decision scratch that will decode it
-    if (async && (e->step_count % 16) == 0 && e->decoded_pending[parity]) {
+    if (async && (ln.step_count % 16) == 0 && ln.decoded_pending[parity]) {
         // the buffers of slot `parity` are about to be rewritten: the decoder launched NWIN windows ago must be done
-        HIPCHK(hipStreamWaitEvent(e->main, e->ev_decoded[parity], 0));
-        e->decoded_pending[parity] = false;
+        HIPCHK(hipStreamWaitEvent(ln.main, ln.ev_decoded[parity], 0));
+        ln.decoded_pending[parity] = false;
     }
-    if (e->acq_needed) { ProfScope p(e, NRSC5HIP_PROF_ACQUIRE, e->main); launch_acquire(e->tb, e->db, n, ids_dev, e->main); }
-    { ProfScope p(e, NRSC5HIP_PROF_PREPARE, e->main); launch_prepare(e->db, n, ids_dev, parity, e->main); }
-    { ProfScope p(e, NRSC5HIP_PROF_MIXFFT, e->main); launch_mixfft(e->tb, e->db, n, ids_dev, e->main); }
-    const int slot = async ? (int)(e->step_count % 16) : 0;
-    { ProfScope p(e, NRSC5HIP_PROF_SYNC, e->main); launch_sync(e->tb, e->db, n, ids_dev, parity, slot, e->main); }
-    { ProfScope p(e, NRSC5HIP_PROF_P1_DEINT, e->main); launch_p1_deint(e->tb, e->db, n, ids_dev, parity, e->main); }
+    if (ln.acq_needed) { ProfScope p(e, NRSC5HIP_PROF_ACQUIRE, ln.main); launch_acquire(e->tb, ln.db, n, ids_dev, ln.main); }
+    { ProfScope p(e, NRSC5HIP_PROF_PREPARE, ln.main); launch_prepare(ln.db, n, ids_dev, parity, ln.main); }
+    { ProfScope p(e, NRSC5HIP_PROF_MIXFFT, ln.main); launch_mixfft(e->tb, ln.db, n, ids_dev, ln.main); }
+    const int slot = async ? (int)(ln.step_count % 16) : 0;
+    { ProfScope p(e, NRSC5HIP_PROF_SYNC, ln.main); launch_sync(e->tb, ln.db, n, ids_dev, parity, slot, ln.main); }
+    { ProfScope p(e, NRSC5HIP_PROF_P1_DEINT, ln.main); launch_p1_deint(e->tb, ln.db, n, ids_dev, parity, ln.main); }
     if (!async) {
-        { ProfScope p(e, NRSC5HIP_PROF_PIDS, e->main); launch_pids_decode(e->tb, e->db, n, ids_dev, parity, 1, e->main); }
-        ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, e->main);
-        launch_p1_viterbi(e->tb, e->db, n, ids_dev, parity, 0, e->main);
-    } else if ((e->step_count % 16) == 15) {
+        { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_pids_decode(e->tb, ln.db, n, ids_dev, parity, 1, ln.main); }
+        ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ln.main);
+        launch_p1_viterbi(e->tb, ln.db, n, ids_dev, parity, 0, ln.main);
+    } else if ((ln.step_count % 16) == 15) {
         // window complete: decode its PIDS frames and P1 frames on aux stream `lane`, overlapped with the next
         // windows (NAUX windows decode concurrently, each wave of the forward pass alone on a SIMD)
-        hipStream_t ax = e->aux[lane];
-        HIPCHK(hipEventRecord(e->ev_window[parity], e->main));
-        HIPCHK(hipStreamWaitEvent(ax, e->ev_window[parity], 0));
-        { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_pids_decode(e->tb, e->db, n, ids_dev, parity, 16, ax); }
-        { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ax); launch_p1_viterbi(e->tb, e->db, n, ids_dev, parity, lane, ax); }
-        HIPCHK(hipEventRecord(e->ev_decoded[parity], ax));
-        e->decoded_pending[parity] = true;
+        hipStream_t ax = ln.aux[lane];
+        HIPCHK(hipEventRecord(ln.ev_window[parity], ln.main));
+        HIPCHK(hipStreamWaitEvent(ax, ln.ev_window[parity], 0));
+        { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_pids_decode(e->tb, ln.db, n, ids_dev, parity, 16, ax); }
+        { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ax); launch_p1_viterbi(e->tb, ln.db, n, ids_dev, parity, lane, ax); }
+        HIPCHK(hipEventRecord(ln.ev_decoded[parity], ax));
+        ln.decoded_pending[parity] = true;
     }
-    e->step_count++;
+    ln.step_count++;
     HIPCHK(hipGetLastError());
     return 0;
 }
 
 // finish a partially filled decode window (async mode) so that every produced frame gets decoded
-static int flush_p1(nrsc5hip_engine *e, int n, const int *ids_dev)
+static int flush_p1(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const int *ids_dev)
 {
     if (!e->cfg.p1_async) return 0;
-    if (e->step_count % 16) {
-        const long long window = e->step_count / 16;
+    if (ln.step_count % 16) {
+        const long long window = ln.step_count / 16;
         const int parity = (int)(window % NWIN), lane = (int)(window % NAUX);
-        hipStream_t ax = e->aux[lane];
-        HIPCHK(hipEventRecord(e->ev_window[parity], e->main));
-        HIPCHK(hipStreamWaitEvent(ax, e->ev_window[parity], 0));
-        { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_pids_decode(e->tb, e->db, n, ids_dev, parity, 16, ax); }
-        { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ax); launch_p1_viterbi(e->tb, e->db, n, ids_dev, parity, lane, ax); }
-        e->step_count += 16 - (e->step_count % 16);           // next batch starts a fresh window
+        hipStream_t ax = ln.aux[lane];
+        HIPCHK(hipEventRecord(ln.ev_window[parity], ln.main));
+        HIPCHK(hipStreamWaitEvent(ax, ln.ev_window[parity], 0));
+        { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_pids_decode(e->tb, ln.db, n, ids_dev, parity, 16, ax); }
+        { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ax); launch_p1_viterbi(e->tb, ln.db, n, ids_dev, parity, lane, ax); }
+        ln.step_count += 16 - (ln.step_count % 16);            // next batch starts a fresh window
     }
-    for (int k = 0; k < NAUX; k++) HIPCHK(hipStreamSynchronize(e->aux[k]));
-    for (int k = 0; k < NWIN; k++) e->decoded_pending[k] = false;
+    for (int k = 0; k < NAUX; k++) HIPCHK(hipStreamSynchronize(ln.aux[k]));
+    for (int k = 0; k < NWIN; k++) ln.decoded_pending[k] = false;
+    return 0;
+}
+
+// Runs block steps for `nl` lanes (lane l: n[l] streams listed at ids_dev[l]) until no lane has work left.
+static int run_steps_lanes(nrsc5hip_engine *e, int nl, const int *n, const int *const *ids_dev, int max_steps, int check_every, int *steps_done)
+{
+    int done = 0;
+    bool live[MAX_LANES];
+    for (int l = 0; l < nl; l++) live[l] = n[l] > 0;
+    while (done < max_steps) {
+        bool any = false;
+        for (int l = 0; l < nl; l++) if (live[l]) { any = true; HIPCHK(hipMemsetAsync(e->lanes[l].counters_dev, 0, 4 * sizeof(int), e->lanes[l].main)); }
+        if (!any) break;
+        int burst = 0;
+        for (; burst < check_every && done + burst < max_steps; burst++)
+            for (int l = 0; l < nl; l++)
+                if (live[l]) { int rc = issue_step(e, e->lanes[l], n[l], ids_dev[l]); if (rc) return rc; }
+        for (int l = 0; l < nl; l++)
+            if (live[l]) HIPCHK(hipMemcpyAsync(e->lanes[l].counters_host, e->lanes[l].counters_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, e->lanes[l].main));
+        bool progressed = false;
+        for (int l = 0; l < nl; l++) {
+            if (!live[l]) continue;
+            HIPCHK(hipStreamSynchronize(e->lanes[l].main));
+            e->lanes[l].acq_needed = e->lanes[l].counters_host[1] > 0;
+            if (e->lanes[l].counters_host[0] == 0) live[l] = false; else progressed = true;
+        }
+        if (!progressed) break;                                // nothing was processed in this burst
+        done += burst;
+    }
+    for (int l = 0; l < nl; l++) { int rc = flush_p1(e, e->lanes[l], n[l], ids_dev[l]); if (rc) return rc; }
+    for (int l = 0; l < nl; l++) HIPCHK(hipStreamSynchronize(e->lanes[l].main));
+    if (e->prof_on) prof_collect(e);
+    if (steps_done) *steps_done = done;
     return 0;
 }
 
 static int run_steps(nrsc5hip_engine *e, int n, const int *ids_dev, int max_steps, int check_every, int *steps_done)
 {
-    int done = 0;
-    while (done < max_steps) {
-        HIPCHK(hipMemsetAsync(e->db.counters, 0, 4 * sizeof(int), e->main));
-        int burst = 0;
-        for (; burst < check_every && done + burst < max_steps; burst++) {
-            int rc = issue_step(e, n, ids_dev);
-            if (rc) return rc;
-        }
-        HIPCHK(hipMemcpyAsync(e->counters_host, e->db.counters, 4 * sizeof(int), hipMemcpyDeviceToHost, e->main));
-        HIPCHK(hipStreamSynchronize(e->main));
-        const int processed = e->counters_host[0];
-        e->acq_needed = e->counters_host[1] > 0;
-        if (processed == 0) break;                             // nothing left to do in this burst
-        done += burst;
-        if (processed < burst && check_every > 1) { /* some steps were empty: the tail is near */ }
-    }
-    int rc = flush_p1(e, n, ids_dev);
-    if (rc) return rc;
-    HIPCHK(hipStreamSynchronize(e->main));
-    if (e->prof_on) prof_collect(e);
-    if (steps_done) *steps_done = done;
-    return 0;
+    const int *ids[1] = { ids_dev };
+    return run_steps_lanes(e, 1, &n, ids, max_steps, check_every, steps_done);
 }
 
 // ---- FIFO space management (streaming) -----------------------------------------------------------------
@@ -422,7 +460,7 @@ extern "C" int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream)
     StreamState st; init_state(st);
     HIPCHK(hipMemcpy(e->db.state + stream, &st, sizeof(st), hipMemcpyHostToDevice));
     e->wr_host[stream] = 0; e->base_host[stream] = 0; e->drained[stream] = 0;
-    e->acq_needed = true;
+    for (int l = 0; l < e->nlanes; l++) e->lanes[l].acq_needed = true;
     return 0;
 }
 
@@ -432,7 +470,7 @@ extern "C" int nrsc5hip_force_resync(nrsc5hip_engine *e, int stream)
 {
     int rc = check_stream(e, stream); if (rc) return rc;
     hipLaunchKernelGGL(k_force_none, dim3(1), dim3(1), 0, e->main, e->db, stream);
-    e->acq_needed = true;
+    for (int l = 0; l < e->nlanes; l++) e->lanes[l].acq_needed = true;
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -494,7 +532,11 @@ extern "C" int nrsc5hip_batch_process(nrsc5hip_engine *e, int nstreams, const in
 {
     if (!e) FAIL(NRSC5HIP_EINVAL, "null engine");
     const int *ids_dev; int rc = upload_ids(e, nstreams, stream_ids, nullptr, &ids_dev); if (rc) return rc;
-    return run_steps(e, nstreams, ids_dev, max_steps > 0 ? max_steps : (1 << 30), e->cfg.p1_async ? 16 : 8, steps_done);
+    // contiguous slices of the id list, one per scheduler lane
+    const int nl = (nstreams >= 2 * e->nlanes) ? e->nlanes : 1;
+    int n[MAX_LANES]; const int *ids[MAX_LANES];
+    for (int l = 0, off = 0; l < nl; l++) { n[l] = nstreams / nl + (l < nstreams % nl ? 1 : 0); ids[l] = ids_dev + off; off += n[l]; }
+    return run_steps_lanes(e, nl, n, ids, max_steps > 0 ? max_steps : (1 << 30), e->cfg.p1_async ? 16 : 8, steps_done);
 }
 
 // ---- results ------------------------------------------------------------------------------------------------------
@@ -657,8 +699,10 @@ extern "C" int nrsc5hip_reset_all(nrsc5hip_engine *e)
     std::fill(e->base_host.begin(), e->base_host.end(), 0);
     std::fill(e->drained.begin(), e->drained.end(), 0);
     HIPCHK(hipMemset(e->db.pids_rec, 0xff, S * NWIN * 16 * sizeof(int)));
-    e->acq_needed = true; e->step_count = 0;
-    for (int k = 0; k < NWIN; k++) e->decoded_pending[k] = false;
+    for (int l = 0; l < e->nlanes; l++) {
+        e->lanes[l].acq_needed = true; e->lanes[l].step_count = 0;
+        for (int k = 0; k < NWIN; k++) e->lanes[l].decoded_pending[k] = false;
+    }
     return 0;
 }
 

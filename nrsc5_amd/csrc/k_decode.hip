@@ -19,16 +19,24 @@ __global__ __launch_bounds__(1024) void k_p1_deint(DevTables tb, DevBuffers db, 
     if (st.p1_pending[parity] != 1) return;                    // 1 = completed in this step, 2 = already gathered
     const int8_t *pm = db.pm + (size_t)s * PM_FRAME;
     int8_t *out = db.coded + ((size_t)s * NWIN + parity) * P1_DEPUNCT;
-    // 4 groups (24 output bytes, 20 gathers) per thread iteration; the grid has few blocks per stream so that
-    // the 15 of 16 steps in which no frame completes cost one wave-uniform early exit per block
-    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < P1_CODED / 5; g += gridDim.x * blockDim.x) {
-        const int32_t *idx = tb.p1_gather + 5 * g;
-        int8_t v[6];
+    // one lane = 4 puncture groups = 20 gathers -> 24 contiguous output bytes, stored as three 8-byte words
+    // (byte stores would turn the 438 KB frame into partial-line writes).  Few blocks per stream, so the 15 of
+    // 16 steps in which no frame completes cost one wave-uniform early exit per block.
+    constexpr int QUADS = P1_CODED / 20;                       // 18272
+    uint2 *out8 = (uint2 *)out;
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < QUADS; q += gridDim.x * blockDim.x) {
+        const int32_t *idx = tb.p1_gather + 20 * q;
+        uint32_t w[6] = { 0, 0, 0, 0, 0, 0 };
 #pragma unroll
-        for (int k = 0; k < 5; k++) v[k] = pm[idx[k]];
-        v[5] = 0;
+        for (int g = 0; g < 4; g++)
 #pragma unroll
-        for (int k = 0; k < 6; k++) out[6 * g + k] = v[k];
+            for (int k = 0; k < 5; k++) {
+                const int pos = 6 * g + k;                     // byte position inside the 24-byte run; slot 6g+5 stays 0
+                w[pos >> 2] |= (uint32_t)(uint8_t)pm[idx[5 * g + k]] << (8 * (pos & 3));
+            }
+        out8[3 * q] = make_uint2(w[0], w[1]);
+        out8[3 * q + 1] = make_uint2(w[2], w[3]);
+        out8[3 * q + 2] = make_uint2(w[4], w[5]);
     }
 }
 
