@@ -42,6 +42,7 @@ struct nrsc5hip_engine {
         hipEvent_t ev_window[NWIN], ev_decoded[NWIN];
         bool decoded_pending[NWIN];
         bool acq_needed;
+        bool prepared_by_sync;         // the previous step's k_sync already ran the next block's bookkeeping
         long long step_count;          // block steps issued so far (decode-window bookkeeping in async mode)
         int *counters_dev, *counters_host;
         DevBuffers db;                 // engine buffers with this lane's counters
@@ -199,7 +200,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
     do {
         {
             const char *env = getenv("NRSC5HIP_LANES");
-            e->nlanes = env ? atoi(env) : (cfg->p1_async && cfg->max_streams >= 32 ? 2 : 1);
+            e->nlanes = env ? atoi(env) : 1;   // more lanes only pay when a step is throughput-bound; it is latency-bound today
             if (e->nlanes < 1) e->nlanes = 1;
             if (e->nlanes > MAX_LANES) e->nlanes = MAX_LANES;
         }
@@ -303,10 +304,13 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
         ln.decoded_pending[parity] = false;
     }
     if (ln.acq_needed) { ProfScope p(e, NRSC5HIP_PROF_ACQUIRE, ln.main); launch_acquire(e->tb, ln.db, n, ids_dev, ln.main); }
-    { ProfScope p(e, NRSC5HIP_PROF_PREPARE, ln.main); launch_prepare(ln.db, n, ids_dev, parity, ln.main); }
+    if (!ln.prepared_by_sync) { ProfScope p(e, NRSC5HIP_PROF_PREPARE, ln.main); launch_prepare(ln.db, n, ids_dev, ln.main); }
     { ProfScope p(e, NRSC5HIP_PROF_MIXFFT, ln.main); launch_mixfft(e->tb, ln.db, n, ids_dev, ln.main); }
     const int slot = async ? (int)(ln.step_count % 16) : 0;
-    { ProfScope p(e, NRSC5HIP_PROF_SYNC, ln.main); launch_sync(e->tb, ln.db, n, ids_dev, parity, slot, ln.main); }
+    // batch pipeline: once every stream of the lane is FINE, the next block's bookkeeping rides in k_sync's tail
+    const int fuse = (async && !ln.acq_needed) ? 1 : 0;
+    { ProfScope p(e, NRSC5HIP_PROF_SYNC, ln.main); launch_sync(e->tb, ln.db, n, ids_dev, parity, slot, fuse, ln.main); }
+    ln.prepared_by_sync = fuse != 0;
     { ProfScope p(e, NRSC5HIP_PROF_P1_DEINT, ln.main); launch_p1_deint(e->tb, ln.db, n, ids_dev, parity, ln.main); }
     if (!async) {
         { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_pids_decode(e->tb, ln.db, n, ids_dev, parity, 1, ln.main); }
@@ -352,7 +356,7 @@ static int run_steps_lanes(nrsc5hip_engine *e, int nl, const int *n, const int *
 {
     int done = 0;
     bool live[MAX_LANES];
-    for (int l = 0; l < nl; l++) live[l] = n[l] > 0;
+    for (int l = 0; l < nl; l++) { live[l] = n[l] > 0; e->lanes[l].prepared_by_sync = false; }
     while (done < max_steps) {
         bool any = false;
         for (int l = 0; l < nl; l++) if (live[l]) { any = true; HIPCHK(hipMemsetAsync(e->lanes[l].counters_dev, 0, 4 * sizeof(int), e->lanes[l].main)); }

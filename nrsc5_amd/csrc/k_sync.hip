@@ -11,6 +11,7 @@
 #include "kernels.h"
 #include "wave_ops.h"
 #include "viterbi_wave.h"
+#include "prepare_block.h"
 
 namespace nrsc5 {
 
@@ -118,8 +119,8 @@ __device__ inline float half_turn_diff(float a, float b)    // phase_diff, sync.
 
 __device__ inline float2 cdiv(float2 a, float2 b)
 {
-    const float den = b.x * b.x + b.y * b.y;
-    return make_float2((a.x * b.x + a.y * b.y) / den, (a.y * b.x - a.x * b.y) / den);
+    const float inv = 1.0f / (b.x * b.x + b.y * b.y);
+    return make_float2((a.x * b.x + a.y * b.y) * inv, (a.y * b.x - a.x * b.y) * inv);
 }
 
 __device__ inline int soft_bit(float x, float mult)          // demod, sync.c:69-73
@@ -128,11 +129,25 @@ __device__ inline int soft_bit(float x, float mult)          // demod, sync.c:69
     return (int)lroundf(c * mult);
 }
 
-__global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot)
+// cell index -> (side, partition from the band edge, symbol, carrier 1..18); PPB > 0 folds the divisions
+template <int PPB> __device__ __forceinline__ void cell_coords(int c, int ppb_rt, int &side, int &part, int &n, int &k)
+{
+    const int ppb = PPB > 0 ? PPB : ppb_rt;
+    k = 1 + c % 18; n = (c / 18) % NSYM; part = (c / (18 * NSYM)) % ppb; side = c / (18 * NSYM * ppb);
+}
+
+__global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare)
 {
     const int s = stream_of(ids, blockIdx.x);
     StreamState &st = db.state[s];
-    if (!st.active) return;                                    // block-uniform
+    // a frame completed in an earlier step of this decode window was gathered by that step's k_p1_deint:
+    // freeze it (the interleaver matrix is about to be refilled with the next frame's blocks)
+    if (threadIdx.x == 0 && st.p1_pending[parity] == 1) st.p1_pending[parity] = 2;
+    if (!st.active) {                                          // block-uniform
+        // no block this step; with the fused pipeline the stream may have become ready since (new samples)
+        if (fuse_prepare && threadIdx.x == 0) prepare_block(db, st, s);
+        return;
+    }
     const int tid = threadIdx.x;
     long long tstamp = (db.sync_phase_cycles && s == 0 && tid == 0) ? (long long)clock64() : 0;
 #define SYNC_MARK(i) do { if (db.sync_phase_cycles && s == 0 && tid == 0) { const long long now = (long long)clock64(); db.sync_phase_cycles[i] += now - tstamp; tstamp = now; } } while (0)
@@ -333,7 +348,8 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
             const int c = tid + 256 * i;
             cellv[i] = make_float2(0.0f, 0.0f);
             if (c < ncell) {
-                const int k = 1 + c % 18, n = (c / 18) % NSYM, part = (c / (18 * NSYM)) % ppb, side = c / (18 * NSYM * ppb);
+                int k, n, part, side;
+                if (ppb == PM_PART) cell_coords<PM_PART>(c, ppb, side, part, n, k); else cell_coords<0>(c, ppb, side, part, n, k);
                 // adjust_data(lower, upper): side 0: refs i=part (low) and part+1 (high); side 1: low = upper-sideband ref part+1
                 const int r_lo = side ? 2 * (part + 1) + 1 : 2 * part, r_hi = side ? 2 * part + 1 : 2 * (part + 1);
                 const int b = ref_bin(r_lo) + k;
@@ -381,7 +397,8 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         for (int i = 0; i < MAXC; i++) {
             const int c = tid + 256 * i;
             if (c < ncell) {
-                const int k = 1 + c % 18, n = (c / 18) % NSYM, part = (c / (18 * NSYM)) % ppb, side = c / (18 * NSYM * ppb);
+                int k, n, part, side;
+                if (ppb == PM_PART) cell_coords<PM_PART>(c, ppb, side, part, n, k); else cell_coords<0>(c, ppb, side, part, n, k);
                 if (part < PM_PART) {
                     const int part20 = side ? 19 - part : part;
                     const float mult = side ? mult_ub : mult_lb;
@@ -430,13 +447,14 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         rec.next_angle = st.angle;
         st.nblocks++;
         st.active = 0;
+        if (fuse_prepare) prepare_block(db, st, s);           // top of the NEXT block's acquire_process
     }
     SYNC_MARK(7);
 }
 
-void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, hipStream_t st)
+void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_sync, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, slot);
+    hipLaunchKernelGGL(k_sync, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare);
 }
 
 // ---- deferred PIDS decode: one wave per (slot, stream) with a staged frame -----------------------------------

@@ -48,9 +48,9 @@ void launch_append_cs16(const DevBuffers &db, int nstreams, const int *stream_id
 
 // ---- one block step for a set of streams ----------------------------------------------------
 void launch_acquire(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
-void launch_prepare(const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st);
+void launch_prepare(const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
 void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
-void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, hipStream_t st);
+void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, hipStream_t st);
 void launch_pids_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int nslots, hipStream_t st);
 void launch_p1_deint(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st);
 void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st);

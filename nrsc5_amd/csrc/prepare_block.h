@@ -1,0 +1,59 @@
+// Per-block bookkeeping that precedes the FFTs (top of acquire_process, acquire.c:98-119,153-168): decides
+// whether the stream has a complete 33-symbol window, picks timing / CFO for the block from the tracking
+// feedback (FINE) or from the coarse acquisition results, opens the block's record.  Runs either as its own
+// tiny kernel (k_prepare) or, in the batch pipeline, in the tail of the previous block's k_sync.
+#pragma once
+#include "kernels.h"
+
+namespace nrsc5 {
+
+__device__ inline bool window_ready(const StreamState &st) { return st.wr - st.rd >= WIN_N; }
+
+__device__ inline void prepare_block(const DevBuffers &db, StreamState &st, int s)
+{
+    if (st.active) return;                                     // already prepared (fused into the previous k_sync)
+    if (st.sync_state != SYNC_FINE) atomicAdd(&db.counters[1], 1);   // host: keep launching acquisition
+    st.active = window_ready(st) ? 1 : 0;
+    if (!st.active) return;
+    atomicAdd(&db.counters[0], 1);
+
+    BlockRecord &rec = db.records[(size_t)s * db.rec_cap + (st.nblocks % db.rec_cap)];
+    BlockRecord r;
+    r.flags = REC_PROCESSED; r.state_before = st.sync_state; r.state_after = 0;
+    r.samperr = 0; r.cfo = 0; r.keep = 0; r.bc = 0; r.psmi = 0; r.cfo_wait = 0; r.next_samperr = 0;
+    r.prev_angle = 0; r.phase_re = 0; r.phase_im = 0; r.next_angle = 0; r.freq_offset = 0; r.mer_lb = 0; r.mer_ub = 0;
+    r.ber = 0; r.p1_slot = -1; r.bc_decoded = -1; r.pids[0] = r.pids[1] = r.pids[2] = 0; r.pad = 0;
+
+    int samperr; float angle;
+    if (st.sync_state == SYNC_FINE) {
+        samperr = SYM_N / 2 + st.samperr; st.samperr = 0;      // acquire.c:112-113
+        const float angle_diff = -st.angle; st.angle = 0;
+        angle = st.prev_angle + angle_diff;
+        st.prev_angle = angle;
+    } else {
+        samperr = st.coarse_samperr;
+        // angle_diff = arg(max_v * e^{-i prev_angle})        (acquire.c:153)
+        float sn, cs; sincosf(-st.prev_angle, &sn, &cs);
+        const float pr = st.coarse_re * cs - st.coarse_im * sn;
+        const float pi = st.coarse_re * sn + st.coarse_im * cs;
+        const float angle_diff = atan2f(pi, pr);
+        const float angle_factor = (st.prev_angle != 0.0f) ? 0.25f : 1.0f;
+        angle = st.prev_angle + (angle_diff * angle_factor);
+        st.prev_angle = angle;
+        if (st.sync_state != SYNC_COARSE) { r.flags |= REC_TO_COARSE; st.sync_state = SYNC_COARSE; }
+    }
+    rec = r;
+    st.samperr_cur = samperr;
+    angle = (float)((double)angle - 2 * M_PI * st.cfo);        // acquire.c:164
+    const float dtheta = angle / FFT_N;
+    // The reference rotates by the float pair (cosf, sinf)(dtheta) once per sample (acquire.c:168,250);
+    // the angle of that rounded unit vector, not dtheta itself, is its effective NCO step.
+    const float inc_c = (float)cos((double)dtheta), inc_s = (float)sin((double)dtheta);
+    st.dtheta = atan2((double)inc_s, (double)inc_c);
+    // phase *= e^{-i (1080 - samperr) angle / 2048}            (acquire.c:166)
+    double th = st.theta + (double)(-(float)(SYM_N / 2 - samperr) * angle / FFT_N);
+    th -= 2 * M_PI * rint(th / (2 * M_PI));
+    st.theta = th;
+}
+
+}  // namespace nrsc5
