@@ -106,7 +106,7 @@ static size_t traceback_smem(int len) { return (size_t)(len / 64 + 1) * 65; }
 
 void launch_p1_deint(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st)
 {
-    dim3 grid(8, nstreams);
+    dim3 grid(18, nstreams);                                   // 18 x 1024 lanes = one 24-byte run per lane
     hipLaunchKernelGGL(k_p1_deint, grid, dim3(1024), 0, st, tb, db, stream_ids, parity);
 }
 

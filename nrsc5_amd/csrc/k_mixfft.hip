@@ -77,38 +77,32 @@ constexpr int PITCH_B = 17;    // per r2 row inside a k1 row of the second layou
 __device__ inline void fft2048_wg(float2 *x, float2 *lds, const float2 *tw)
 {
     const int tid = threadIdx.x;
-    // stage A: two radix-8 butterflies, twiddle W2048^(k1*r) = (W2048^r)^k1: one table read, powers by
-    // products of depth <= 3 (error ~3e-7, the FFT's own rounding is ~1e-6), scatter to [k1][r]
+    // stage A: two radix-8 butterflies, twiddle W2048^(k1*r), scatter to [k1][r]
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         const int r = tid + 128 * h;
         dft8(x + 8 * h);
-        float2 p[8];
-        p[1] = tw[r];
-        p[2] = cmul(p[1], p[1]); p[4] = cmul(p[2], p[2]);
-        p[3] = cmul(p[2], p[1]); p[5] = cmul(p[4], p[1]); p[6] = cmul(p[4], p[2]); p[7] = cmul(p[4], p[3]);
-        lds[r] = x[8 * h];
 #pragma unroll
-        for (int k1 = 1; k1 < 8; k1++) lds[k1 * PITCH_A + r] = cmul(x[8 * h + k1], p[k1]);
+        for (int k1 = 0; k1 < 8; k1++) {
+            float2 v = x[8 * h + k1];
+            if (k1) v = cmul(v, tw[(k1 * r) & 2047]);
+            lds[k1 * PITCH_A + r] = v;
+        }
     }
     __syncthreads();
-    // stage B: lane (k1, r2): 16-point DFT over r1 of [k1][r2 + 16 r1], twiddle W256^(r2*k2) = (W256^r2)^k2
+    // stage B: lane (k1, r2): 16-point DFT over r1 of [k1][r2 + 16 r1], twiddle W256^(r2*k2)
     {
         const int k1 = tid >> 4, r2 = tid & 15;
 #pragma unroll
         for (int r1 = 0; r1 < 16; r1++) x[r1] = lds[k1 * PITCH_A + r2 + 16 * r1];
         dft16(x);
-        float2 p[16];
-        p[1] = tw[8 * r2];
-        p[2] = cmul(p[1], p[1]); p[4] = cmul(p[2], p[2]); p[8] = cmul(p[4], p[4]);
-        p[3] = cmul(p[2], p[1]); p[5] = cmul(p[4], p[1]); p[6] = cmul(p[4], p[2]); p[7] = cmul(p[4], p[3]);
-        p[9] = cmul(p[8], p[1]); p[10] = cmul(p[8], p[2]); p[11] = cmul(p[8], p[3]); p[12] = cmul(p[8], p[4]);
-        p[13] = cmul(p[8], p[5]); p[14] = cmul(p[8], p[6]); p[15] = cmul(p[8], p[7]);
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const int k2 = (i >> 2) + 4 * (i & 3);
-            lds[k1 * PITCH_A + r2 * PITCH_B + k2] = k2 ? cmul(x[i], p[k2]) : x[i];
+            float2 v = x[i];
+            if (r2) v = cmul(v, tw[(8 * r2 * k2) & 2047]);
+            lds[k1 * PITCH_A + r2 * PITCH_B + k2] = v;
         }
     }
     __syncthreads();
@@ -121,85 +115,65 @@ __device__ inline void fft2048_wg(float2 *x, float2 *lds, const float2 *tw)
     }
 }
 
-constexpr int SYMS_PER_WG = 2;
-
-__device__ __forceinline__ void load_symbol(const c16 *win, int tid, uint32_t raw[17])
-{
-#pragma unroll
-    for (int q = 0; q < 16; q++) raw[q] = *(const uint32_t *)(win + tid + 128 * q);
-    raw[16] = (tid < CP_N) ? *(const uint32_t *)(win + FFT_N + tid) : 0u;
-}
-
 __global__ __launch_bounds__(128) void k_mixfft(DevTables tb, DevBuffers db, const int *ids)
 {
     const int s = stream_of(ids, blockIdx.y);
     const StreamState &st = db.state[s];
     if (!st.active) return;                                    // block-uniform
     __shared__ float2 lds[8 * PITCH_A];
-    const int tid = threadIdx.x;
-    const c16 *win0 = db.q15 + (size_t)s * db.q15_cap + (st.rd - st.base) + st.samperr_cur;
+    const int sym = blockIdx.x, tid = threadIdx.x;
+    const c16 *win = db.q15 + (size_t)s * db.q15_cap + (st.rd - st.base) + sym * SYM_N + st.samperr_cur;
     const double dth = st.dtheta;
-    const double inv_q15 = 1.0 / 32767.0;                      // x / 32767.0f (defines.h:111), via an exact-in-practice double product
-    // NCO: 128-sample step phasor (shared by all symbols of the block)
+    const double th0 = st.theta + (double)sym * SYM_N * dth;
+
+    // NCO phasor of sample j = tid + 128 q (q = 0..16): one accurate evaluation at q = 0 and one of the
+    // 128-sample step, then a 16-step complex recurrence (error ~1e-6, far inside the float pipeline's own)
+    double a0 = th0 + (double)tid * dth;
+    a0 -= 2 * M_PI * rint(a0 * (1.0 / (2 * M_PI)));
     double a1 = 128.0 * dth;
     a1 -= 2 * M_PI * rint(a1 * (1.0 / (2 * M_PI)));
-    float2 stp;
+    float2 ph, stp;
+    sincosf((float)a0, &ph.y, &ph.x);
     sincosf((float)a1, &stp.y, &stp.x);
-    const float shape_lo = tid < CP_N ? tb.shape[tid] : 1.0f, shape_hi = tid < CP_N ? tb.shape[FFT_N + tid] : 0.0f;
+    const double inv_q15 = 1.0 / 32767.0;                      // x / 32767.0f (defines.h:111), via an exact-in-practice double product
 
-    uint32_t raw[17], nxt[17];
-    load_symbol(win0 + (blockIdx.x * SYMS_PER_WG) * SYM_N, tid, raw);
+    float2 x[16];
 #pragma unroll
-    for (int it = 0; it < SYMS_PER_WG; it++) {
-        const int sym = blockIdx.x * SYMS_PER_WG + it;
-        if (it + 1 < SYMS_PER_WG) load_symbol(win0 + (sym + 1) * SYM_N, tid, nxt);   // in flight during this symbol's FFT
-        // phasor of sample j = tid + 128 q (q = 0..16): one accurate evaluation at q = 0, then a 16-step
-        // complex recurrence (error ~1e-6, inside the float pipeline's own rounding)
-        double a0 = st.theta + ((double)sym * SYM_N + (double)tid) * dth;
-        a0 -= 2 * M_PI * rint(a0 * (1.0 / (2 * M_PI)));
-        float2 ph;
-        sincosf((float)a0, &ph.y, &ph.x);
+    for (int q = 0; q < 16; q++) {
+        const int h = q & 1, n1 = q >> 1;
+        const int j = tid + 128 * q;
+        const c16 s16 = win[j];
+        const float2 v = make_float2((float)((double)s16.r * inv_q15), (float)((double)s16.i * -inv_q15));   // cq15_to_cf_conj
+        float2 m = cmul(ph, v);
+        if (q == 0 && tid < CP_N) { const float w = tb.shape[tid]; m.x *= w; m.y *= w; }
+        x[8 * h + n1] = m;
+        ph = cmul(ph, stp);
+    }
+    if (tid < CP_N) {                                          // fold the cyclic extension back (acquire.c:246-247)
+        const int j = FFT_N + tid;
+        const c16 s16 = win[j];
+        const float2 v = make_float2((float)((double)s16.r * inv_q15), (float)((double)s16.i * -inv_q15));
+        const float2 m = cmul(ph, v);                          // ph = phasor of sample tid + 2048
+        const float w = tb.shape[j];
+        x[0].x += w * m.x; x[0].y += w * m.y;
+    }
 
-        float2 x[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) {
-            const int h = q & 1, n1 = q >> 1;
-            const int16_t sr = (int16_t)(raw[q] & 0xffffu), si = (int16_t)(raw[q] >> 16);
-            const float2 v = make_float2((float)((double)sr * inv_q15), (float)((double)si * -inv_q15));   // cq15_to_cf_conj
-            float2 m = cmul(ph, v);
-            if (q == 0) { m.x *= shape_lo; m.y *= shape_lo; }  // raised-cosine head (acquire.c:242-243)
-            x[8 * h + n1] = m;
-            ph = cmul(ph, stp);
-        }
-        {                                                      // fold the cyclic extension back (acquire.c:246-247)
-            const int16_t sr = (int16_t)(raw[16] & 0xffffu), si = (int16_t)(raw[16] >> 16);
-            const float2 v = make_float2((float)((double)sr * inv_q15), (float)((double)si * -inv_q15));
-            const float2 m = cmul(ph, v);                      // ph = phasor of sample tid + 2048
-            x[0].x += shape_hi * m.x; x[0].y += shape_hi * m.y;
-        }
+    fft2048_wg(x, lds, tb.twiddle);
 
-        fft2048_wg(x, lds, tb.twiddle);
-
-        float2 *out = db.bins + ((size_t)s * NSYM + sym) * LIVE_N;
-        const int kbase = (tid >> 4) + 8 * (tid & 15);
+    float2 *out = db.bins + ((size_t)s * NSYM + sym) * LIVE_N;
+    const int kbase = (tid >> 4) + 8 * (tid & 15);
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const int k3 = (i >> 2) + 4 * (i & 3);
-            const int b = (kbase + 128 * k3 + FFT_N / 2) & (FFT_N - 1);       // fftshift: bin 1024 = DC
-            if (b >= LB0 && b < LB0 + LIVE_HALF) out[b - LB0] = x[i];
-            else if (b >= UB0 && b <= UB1) out[LIVE_HALF + (b - UB0)] = x[i];
-        }
-        if (it + 1 < SYMS_PER_WG) {
-            __syncthreads();                                   // stage C reads done before the next symbol's stage A writes
-#pragma unroll
-            for (int q = 0; q < 17; q++) raw[q] = nxt[q];
-        }
+    for (int i = 0; i < 16; i++) {
+        const int k3 = (i >> 2) + 4 * (i & 3);
+        const int b = (kbase + 128 * k3 + FFT_N / 2) & (FFT_N - 1);       // fftshift: bin 1024 = DC
+        if (b >= LB0 && b < LB0 + LIVE_HALF) out[b - LB0] = x[i];
+        else if (b >= UB0 && b <= UB1) out[LIVE_HALF + (b - UB0)] = x[i];
     }
 }
 
 void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_mixfft, dim3(NSYM / SYMS_PER_WG, nstreams), dim3(128), 0, st, tb, db, stream_ids);
+    hipLaunchKernelGGL(k_mixfft, dim3(NSYM, nstreams), dim3(128), 0, st, tb, db, stream_ids);
 }
 
 // ---- stage-level entry: plain 2048-point FFTs, natural order in and out (parity tests) ----------------
