@@ -308,7 +308,8 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
     { ProfScope p(e, NRSC5HIP_PROF_MIXFFT, ln.main); launch_mixfft(e->tb, ln.db, n, ids_dev, ln.main); }
     const int slot = async ? (int)(ln.step_count % 16) : 0;
     // batch pipeline: once every stream of the lane is FINE, the next block's bookkeeping rides in k_sync's tail
-    const int fuse = (async && !ln.acq_needed) ? 1 : 0;
+    static const bool no_fuse = getenv("NRSC5HIP_NO_FUSE") != nullptr;
+    const int fuse = (async && !ln.acq_needed && !no_fuse) ? 1 : 0;
     { ProfScope p(e, NRSC5HIP_PROF_SYNC, ln.main); launch_sync(e->tb, ln.db, n, ids_dev, parity, slot, fuse, ln.main); }
     ln.prepared_by_sync = fuse != 0;
     { ProfScope p(e, NRSC5HIP_PROF_P1_DEINT, ln.main); launch_p1_deint(e->tb, ln.db, n, ids_dev, parity, ln.main); }

@@ -136,6 +136,40 @@ template <int PPB> __device__ __forceinline__ void cell_coords(int c, int ppb_rt
     k = 1 + c % 18; n = (c / 18) % NSYM; part = (c / (18 * NSYM)) % ppb; side = c / (18 * NSYM * ppb);
 }
 
+// adjust_data (sync.c:263-282) for one cell: C = (19+19j) / (k m19 e^{j phi19} + (19-k) m0 e^{j phi0})
+template <int PPB>
+__device__ __forceinline__ float2 equalise_cell(int c, int ppb_rt, const float2 *bins, const float2 (*refcs)[NSYM], const float *smag, int &side)
+{
+    int k, n, part;
+    cell_coords<PPB>(c, ppb_rt, side, part, n, k);
+    // side 0: refs i=part (low) and part+1 (high); side 1: low = upper-sideband ref part+1, high = ref part
+    const int r_lo = side ? 2 * (part + 1) + 1 : 2 * part, r_hi = side ? 2 * part + 1 : 2 * (part + 1);
+    const int b = ref_bin(r_lo) + k;
+    const float2 z = bins[n * LIVE_N + bin_to_live(b)];
+    const float2 lp = refcs[r_lo][n], up = refcs[r_hi][n];
+    const float a = k * smag[r_hi], bq = (PW - k) * smag[r_lo];
+    const float2 den = make_float2(a * up.x + bq * lp.x, a * up.y + bq * lp.y);
+    const float2 C = cdiv(make_float2((float)PW, (float)PW), den);
+    return make_float2(z.x * C.x - z.y * C.y, z.x * C.y + z.y * C.x);
+}
+
+__device__ __forceinline__ float cell_error(float2 v)           // |ideal - v|^2 against the nearest QPSK point (sync.c:465-483)
+{
+    const float ix = v.x >= 0 ? 1.0f : -1.0f, iy = v.y >= 0 ? 1.0f : -1.0f;
+    const float dx = ix - v.x, dy = iy - v.y;
+    return dx * dx + dy * dy;
+}
+
+// partitions 0..9 = lower sideband from the edge; 10..19 = upper sideband in ascending frequency (sync.c:514-536):
+// the upper-sideband cell of partition `part` (from the edge) is matrix partition 19 - part
+__device__ __forceinline__ void store_soft(int8_t *pm_blk, float2 v, int side, int part, int n, int k, float mult_lb, float mult_ub)
+{
+    const int part20 = side ? 19 - part : part;
+    const float mult = side ? mult_ub : mult_lb;
+    char2 o; o.x = (signed char)soft_bit(v.x, mult); o.y = (signed char)soft_bit(v.y, mult);
+    *(char2 *)(pm_blk + n * 720 + part20 * 36 + (k - 1) * 2) = o;
+}
+
 __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare)
 {
     const int s = stream_of(ids, blockIdx.x);
@@ -336,33 +370,26 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         if (tid < nref) st.costas_freq[bin_to_live(ref_bin(tid))] = ref_freq[tid] - sh_f[0];
         SYNC_MARK(3);
 
-        // cell (side, part, n, k): data carrier k = 1..18 of partition `part` (counted from the band edge).
-        // Each lane owns cells c = tid + 256 i and keeps the equalised values in registers between the MER
-        // pass and the soft-bit pass (one workgroup per CU: the whole VGPR file is ours).
+        // cell (side, part, n, k): data carrier k = 1..18 of partition `part` (counted from the band edge);
+        // lane tid owns cells c = tid + 256 i.  MP1 (10 partitions, 45 cells per lane) keeps the equalised values
+        // in registers between the MER pass and the soft-bit pass; the wider service modes recompute them.
         const int ncell = 2 * ppb * NSYM * 18;
-        constexpr int MAXC = (2 * 14 * NSYM * 18 + 255) / 256;                 // 63
-        float2 cellv[MAXC];
+        constexpr int MP1C = 2 * PM_PART * NSYM * 18 / 256;                     // 45 exactly
+        float2 cellv[MP1C];
         double e_lb = 0.0, e_ub = 0.0;
+        if (ppb == PM_PART) {
 #pragma unroll
-        for (int i = 0; i < MAXC; i++) {
-            const int c = tid + 256 * i;
-            cellv[i] = make_float2(0.0f, 0.0f);
-            if (c < ncell) {
-                int k, n, part, side;
-                if (ppb == PM_PART) cell_coords<PM_PART>(c, ppb, side, part, n, k); else cell_coords<0>(c, ppb, side, part, n, k);
-                // adjust_data(lower, upper): side 0: refs i=part (low) and part+1 (high); side 1: low = upper-sideband ref part+1
-                const int r_lo = side ? 2 * (part + 1) + 1 : 2 * part, r_hi = side ? 2 * part + 1 : 2 * (part + 1);
-                const int b = ref_bin(r_lo) + k;
-                const float2 z = bins[n * LIVE_N + bin_to_live(b)];
-                const float2 lp = refcs[r_lo][n], up = refcs[r_hi][n];
-                const float a = k * smag[r_hi], bq = (PW - k) * smag[r_lo];
-                const float2 den = make_float2(a * up.x + bq * lp.x, a * up.y + bq * lp.y);
-                const float2 C = cdiv(make_float2((float)PW, (float)PW), den);
-                const float2 v = make_float2(z.x * C.x - z.y * C.y, z.x * C.y + z.y * C.x);
+            for (int i = 0; i < MP1C; i++) {
+                int side;
+                const float2 v = equalise_cell<PM_PART>(tid + 256 * i, ppb, bins, refcs, smag, side);
                 cellv[i] = v;
-                const float ix = v.x >= 0 ? 1.0f : -1.0f, iy = v.y >= 0 ? 1.0f : -1.0f;
-                const float dx = ix - v.x, dy = iy - v.y;
-                const float e = dx * dx + dy * dy;
+                const float e = cell_error(v);
+                if (side) e_ub += e; else e_lb += e;
+            }
+        } else {
+            for (int c = tid; c < ncell; c += 256) {
+                int side;
+                const float e = cell_error(equalise_cell<0>(c, ppb, bins, refcs, smag, side));
                 if (side) e_ub += e; else e_lb += e;
             }
         }
@@ -393,18 +420,18 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         // Partitions 0..9 = lower sideband from the edge; 10..19 = upper sideband in ascending frequency
         // (sync.c:514-536): the upper-sideband cell of partition `part` (from the edge) is matrix partition 19 - part.
         int8_t *pm_blk = db.pm + (size_t)s * PM_FRAME + (size_t)bc * PM_BLOCK;
+        if (ppb == PM_PART) {
 #pragma unroll
-        for (int i = 0; i < MAXC; i++) {
-            const int c = tid + 256 * i;
-            if (c < ncell) {
+            for (int i = 0; i < MP1C; i++) {
                 int k, n, part, side;
-                if (ppb == PM_PART) cell_coords<PM_PART>(c, ppb, side, part, n, k); else cell_coords<0>(c, ppb, side, part, n, k);
-                if (part < PM_PART) {
-                    const int part20 = side ? 19 - part : part;
-                    const float mult = side ? mult_ub : mult_lb;
-                    char2 o; o.x = (signed char)soft_bit(cellv[i].x, mult); o.y = (signed char)soft_bit(cellv[i].y, mult);
-                    *(char2 *)(pm_blk + n * 720 + part20 * 36 + (k - 1) * 2) = o;
-                }
+                cell_coords<PM_PART>(tid + 256 * i, ppb, side, part, n, k);
+                store_soft(pm_blk, cellv[i], side, part, n, k, mult_lb, mult_ub);
+            }
+        } else {
+            for (int c = tid; c < ncell; c += 256) {
+                int k, n, part, side;
+                cell_coords<0>(c, ppb, side, part, n, k);
+                if (part < PM_PART) store_soft(pm_blk, equalise_cell<0>(c, ppb, bins, refcs, smag, side), side, part, n, k, mult_lb, mult_ub);
             }
         }
         __threadfence_block();
