@@ -229,6 +229,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if ((rc = dev_alloc(e, &db.coded, S * NWIN * P1_DEPUNCT))) break;
         db.nstreams_alloc = (int)S;
         if ((rc = dev_alloc(e, &db.dec, (size_t)(cfg->p1_async ? NAUX : 1) * S * (size_t)(P1_LEN + 64)))) break;
+        if ((rc = dev_alloc(e, &db.tbmap, (size_t)(cfg->p1_async ? NAUX : 1) * S * (size_t)(P1_LEN / 64 + 1) * 64))) break;
         if ((rc = dev_alloc(e, &db.pids_stage, S * NWIN * 16 * 3 * PIDS_LEN))) break;
         if ((rc = dev_alloc(e, &db.pids_rec, S * NWIN * 16))) break;
         if (hipMemset(db.pids_rec, 0xff, S * NWIN * 16 * sizeof(int)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }

@@ -89,7 +89,8 @@ __global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBu
     unsigned long long *dec = db.dec + ((size_t)lane_id * db.nstreams_alloc + s) * (P1_LEN + 64);
     uint32_t *out = db.p1_ring + ((size_t)s * db.p1_slots + st.p1_slot[parity]) * P1_WORDS;
     if (tid == 0) err_total = 0;
-    viterbi_fast_traceback_block(dec, P1_LEN, st.p1_endlane[parity], out, smem);
+    uint8_t *gmap = db.tbmap + ((size_t)lane_id * db.nstreams_alloc + s) * ((size_t)(P1_LEN / 64 + 1) * 64);
+    viterbi_fast_traceback_block(dec, P1_LEN, st.p1_endlane[parity], out, gmap, smem);
     __threadfence_block();
     __syncthreads();
     const int errors = wave_sum_i32(bit_errors_k7_partial(coded, out, P1_LEN));
@@ -102,7 +103,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBu
     }
 }
 
-static size_t traceback_smem(int len) { return (size_t)(len / 64 + 1) * 65; }
+static size_t traceback_smem(int len) { const int nchunks = len / 64 + 1; return (size_t)((nchunks + TB_SEG - 1) / TB_SEG) * 64 + nchunks; }
 
 void launch_p1_deint(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st)
 {
@@ -112,11 +113,6 @@ void launch_p1_deint(const DevTables &tb, const DevBuffers &db, int nstreams, co
 
 void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st)
 {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)k_p1_traceback, hipFuncAttributeMaxDynamicSharedMemorySize, (int)traceback_smem(P1_LEN));
-        attr_set = true;
-    }
     hipLaunchKernelGGL(k_p1_forward, dim3(nstreams), dim3(64), 0, st, db, stream_ids, parity, lane_id);
     hipLaunchKernelGGL(k_p1_traceback, dim3(nstreams), dim3(TB_THREADS), traceback_smem(P1_LEN), st, tb, db, stream_ids, parity, lane_id);
 }
@@ -134,21 +130,22 @@ __global__ __launch_bounds__(64) void k_viterbi_frames_fwd(const int8_t *coded, 
     const int e = viterbi_fast_forward(coded + (size_t)f * 3 * len, len, dec + (size_t)f * (len + 64));
     if ((threadIdx.x & 63) == 0) endlane[f] = e;
 }
-__global__ __launch_bounds__(TB_THREADS) void k_viterbi_frames_tb(unsigned long long *dec, int len, const int *endlane, uint32_t *out)
+__global__ __launch_bounds__(TB_THREADS) void k_viterbi_frames_tb(unsigned long long *dec, int len, const int *endlane, uint32_t *out, uint8_t *gmap)
 {
     HIP_DYNAMIC_SHARED(uint8_t, smem)
     const int f = blockIdx.x;
-    viterbi_fast_traceback_block(dec + (size_t)f * (len + 64), len, endlane[f], out + (size_t)f * ((len + 31) / 32), smem);
+    viterbi_fast_traceback_block(dec + (size_t)f * (len + 64), len, endlane[f], out + (size_t)f * ((len + 31) / 32), gmap + (size_t)f * (len / 64 + 1) * 64, smem);
 }
 
 void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st, int phases)
 {
     if ((len & 63) == 0 && !(phases & 4)) {                    // production split: forward wave + parallel traceback
-        static int *endlane = nullptr; static int cap = 0;
+        static int *endlane = nullptr; static int cap = 0; static uint8_t *gmap = nullptr; static size_t gcap = 0;
         if (cap < nframes) { if (endlane) (void)hipFree(endlane); (void)hipMalloc((void **)&endlane, sizeof(int) * nframes); cap = nframes; (void)hipMemset(endlane, 0, sizeof(int) * nframes); }
-        (void)hipFuncSetAttribute((const void *)k_viterbi_frames_tb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)traceback_smem(len));
+        const size_t gneed = (size_t)nframes * (len / 64 + 1) * 64;
+        if (gcap < gneed) { if (gmap) (void)hipFree(gmap); (void)hipMalloc((void **)&gmap, gneed); gcap = gneed; }
         if (phases & 1) hipLaunchKernelGGL(k_viterbi_frames_fwd, dim3(nframes), dim3(64), 0, st, coded, len, dec, endlane);
-        if (phases & 2) hipLaunchKernelGGL(k_viterbi_frames_tb, dim3(nframes), dim3(TB_THREADS), traceback_smem(len), st, dec, len, (const int *)endlane, out);
+        if (phases & 2) hipLaunchKernelGGL(k_viterbi_frames_tb, dim3(nframes), dim3(TB_THREADS), traceback_smem(len), st, dec, len, (const int *)endlane, out, gmap);
         return;
     }
     hipLaunchKernelGGL(k_viterbi_frames, dim3(nframes), dim3(64), 0, st, coded, len, dec, out, phases & 3);

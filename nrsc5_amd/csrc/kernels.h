@@ -30,6 +30,7 @@ struct DevBuffers {
     int *pids_rec;                   // [S][NWIN][16]     record index of each staged PIDS frame, -1 = empty
     unsigned long long *dec;         // [NAUX][S][P1_LEN + 64]  survivor decisions, one scratch per decode lane
     int nstreams_alloc;              // S
+    uint8_t *tbmap;                  // [NAUX][S][2285 * 64]  traceback chunk maps (start lane per end lane)
     uint32_t *p1_ring;               // [S][p1_slots][P1_WORDS]
     int p1_slots;
     BlockRecord *records;            // [S][rec_cap]

@@ -275,16 +275,28 @@ template <int PH0> struct VitMap<PH0, -1> {
 
 // Block-parallel traceback (blockDim.x a multiple of 64, any number of waves).
 //   pass 1  every wave takes chunks c = wave, wave + nwaves, ...: for each of the 64 candidate end lanes it
-//           walks the chunk back, records the start lane in LDS (map[c][lane]) and overwrites the chunk's 64
-//           decision words IN PLACE with the 64 candidates' decoded 64-bit output.
-//   pass 2  one lane composes the maps from the true end lane backwards (2285 dependent LDS reads for P1).
-//   pass 3  all threads pick the surviving candidate's output words.
-// smem: nchunks * 64 bytes (map) + nchunks bytes (chosen lane per chunk).
-__device__ inline void viterbi_fast_traceback_block(unsigned long long *dec, int len, int endlane, uint32_t *out, uint8_t *smem)
+//           walks the chunk back, records the start lane (gmap[c][lane], global scratch) and overwrites the
+//           chunk's 64 decision words IN PLACE with the 64 candidates' decoded 64-bit output.
+//   pass 2  segments of TB_SEG chunks: 64 lanes walk the 64 candidate chains of a segment in parallel
+//           -> segmap[seg][lane] (LDS).   pass 3: one lane composes the segment maps from the true end lane.
+//   pass 4  one lane per segment walks its chunks from the now-known segment end lane -> chosen[c] (LDS).
+//   pass 5  all threads pick the surviving candidate's output words.
+// LDS: nseg * 64 + nchunks bytes (3.5 KB for P1) -- deliberately small so that the front-end kernels of the
+// following blocks stay co-resident on the CU (a 146 KB LDS map stalled them for the whole traceback).
+constexpr int TB_SEG = 128;
+
+__device__ inline size_t viterbi_traceback_lds_bytes(int len)
+{
+    const int nchunks = len / 64 + 1, nseg = (nchunks + TB_SEG - 1) / TB_SEG;
+    return (size_t)nseg * 64 + nchunks;
+}
+
+__device__ inline void viterbi_fast_traceback_block(unsigned long long *dec, int len, int endlane, uint32_t *out, uint8_t *gmap, uint8_t *smem)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    const int nchunks = len / 64 + 1;
-    uint8_t *map = smem, *chosen = smem + (size_t)nchunks * 64;
+    const int nchunks = len / 64 + 1, nseg = (nchunks + TB_SEG - 1) / TB_SEG;
+    uint8_t *segmap = smem, *chosen = smem + (size_t)nseg * 64;
+    __shared__ uint8_t segend[64];                             // end lane of each segment (nseg <= 64: len <= 524224)
     for (int c = wave; c < nchunks; c += nwaves) {
         const unsigned long long mine = dec[64 * c + lane];
         const int mlo = (int)(uint32_t)mine, mhi = (int)(uint32_t)(mine >> 32);
@@ -294,17 +306,30 @@ __device__ inline void viterbi_fast_traceback_block(unsigned long long *dec, int
         case 1: VitMap<4, 63>::run(l, mlo, mhi, ohi, olo); break;
         default: VitMap<2, 63>::run(l, mlo, mhi, ohi, olo); break;
         }
-        map[64 * c + lane] = (uint8_t)l;
+        gmap[64 * c + lane] = (uint8_t)l;
         dec[64 * c + lane] = ((unsigned long long)ohi << 32) | olo;
     }
     __threadfence_block();
     __syncthreads();
-    if (tid == 0) {
-        unsigned e = (unsigned)endlane;
-        for (int c = nchunks - 1; c >= 0; c--) { chosen[c] = (uint8_t)e; e = map[64 * c + e]; }
+    for (int sg = wave; sg < nseg; sg += nwaves) {             // pass 2
+        const int c0 = sg * TB_SEG, c1 = min(nchunks, c0 + TB_SEG);
+        unsigned e = (unsigned)lane;
+        for (int c = c1 - 1; c >= c0; c--) e = gmap[64 * c + e];
+        segmap[64 * sg + lane] = (uint8_t)e;
     }
     __syncthreads();
-    for (int c = tid; c < nchunks; c += blockDim.x) {
+    if (tid == 0) {                                            // pass 3
+        unsigned e = (unsigned)endlane;
+        for (int sg = nseg - 1; sg >= 0; sg--) { segend[sg] = (uint8_t)e; e = segmap[64 * sg + e]; }
+    }
+    __syncthreads();
+    for (int sg = tid; sg < nseg; sg += blockDim.x) {          // pass 4
+        const int c0 = sg * TB_SEG, c1 = min(nchunks, c0 + TB_SEG);
+        unsigned e = segend[sg];
+        for (int c = c1 - 1; c >= c0; c--) { chosen[c] = (uint8_t)e; e = gmap[64 * c + e]; }
+    }
+    __syncthreads();
+    for (int c = tid; c < nchunks; c += blockDim.x) {          // pass 5
         const unsigned long long o = dec[64 * c + chosen[c]];
         if (c < nchunks - 1) out[2 * c] = (uint32_t)(o >> 32);       // steps 64c+32 .. 64c+63
         if (c >= 1) out[2 * c - 1] = (uint32_t)o;                    // steps 64c .. 64c+31
