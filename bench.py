@@ -123,16 +123,23 @@ def main():
     E = eng.Engine(max_streams=S, q15_capacity=int(stride // 4 + 1024), record_capacity=max(256, 16 * n_frames + 32),
                    p1_slots=n_frames + 1, p1_async=not args.sync_p1, device=local)
 
+    host_ms = {"reset": 0.0, "append": 0.0, "process": 0.0, "fetch": 0.0}
+
     def one_pass(fetch=True):
-        E.reset_all()
-        E.batch_append_cu8(iq.data_ptr(), stride, nbytes)
-        steps = E.batch_process(S)
-        out = E.batch_fetch(S) if fetch else None
+        t = [time.perf_counter()]
+        E.reset_all(); t.append(time.perf_counter())
+        E.batch_append_cu8(iq.data_ptr(), stride, nbytes); t.append(time.perf_counter())
+        steps = E.batch_process(S); t.append(time.perf_counter())
+        out = E.batch_fetch_view(S) if fetch else None; t.append(time.perf_counter())
+        for k, name in enumerate(("reset", "append", "process", "fetch")):
+            host_ms[name] += (t[k + 1] - t[k]) * 1e3
         return steps, out
 
     for _ in range(args.warmup):
         one_pass()
     E.profile(1)
+    for k in host_ms:
+        host_ms[k] = 0.0
     shard.barrier(dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -204,7 +211,8 @@ def main():
                 "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": dom_launches,
                 "alg_bytes_per_launch": int(alg_bytes_per_launch),
                 "whole_path_GBps": round(value * ALG_BYTES_PER_SAMPLE / 1e3, 3),
-                "device_ms_per_pass": {k: round(v, 3) for k, v in per_pass_ms.items()}}
+                "device_ms_per_pass": {k: round(v, 3) for k, v in per_pass_ms.items()},
+                "host_ms_per_pass": {k: round(v / args.steps, 3) for k, v in host_ms.items()}}
     cpu = None
     if not args.no_cpu_baseline and world == 1:
         k0 = 0

@@ -134,6 +134,10 @@ int nrsc5hip_p1_frame_bits(nrsc5hip_engine *e, int stream, int slot, uint8_t *bi
  * counts[nstreams]; frames may be NULL, else frames[nstreams][p1_slots][4568] */
 int nrsc5hip_batch_fetch(nrsc5hip_engine *e, int nstreams, const int *stream_ids, nrsc5hip_record *records,
                          int max_records, int *counts, uint32_t *frames);
+/* Zero-copy variant for streams 0..nstreams-1: bulk D2H into engine-owned pinned buffers; *records points at
+ * [nstreams][record_capacity] records, *frames (may be NULL) at [nstreams][p1_slots][4568] words; valid until the
+ * next fetch / reset.  Requires an undrained, unwrapped record ring (batch use after nrsc5hip_reset_all). */
+int nrsc5hip_batch_fetch_view(nrsc5hip_engine *e, int nstreams, const nrsc5hip_record **records, int *counts, const uint32_t **frames);
 /* unpack helper (host only) */
 void nrsc5hip_unpack_bits(const uint32_t *words, int nbits, uint8_t *bits);
 

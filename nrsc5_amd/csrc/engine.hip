@@ -57,6 +57,8 @@ struct nrsc5hip_engine {
     uint8_t *stage_dev; size_t stage_bytes;
     int *ids_dev; unsigned *nbytes_dev;
     int *all_ids_dev;                  // identity list 0..S-1
+    // engine-owned pinned result buffers for nrsc5hip_batch_fetch_view (allocated on first use)
+    BlockRecord *rec_host; uint32_t *frames_host; int *nblocks_host;
     // optional per-kernel-class timing with HIP events on the launching stream
     bool prof_on;
     struct ProfSpan { int cls; hipEvent_t a, b; };
@@ -225,8 +227,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if ((rc = dev_alloc(e, &db.acq_filt, S * WIN_N))) break;
         if ((rc = dev_alloc(e, &db.acq_sums, S * SYM_N))) break;
         if ((rc = dev_alloc(e, &db.bins, S * NSYM * LIVE_N))) break;
-        if ((rc = dev_alloc(e, &db.pm, S * PM_FRAME))) break;
-        if ((rc = dev_alloc(e, &db.coded, S * NWIN * P1_DEPUNCT))) break;
+        if ((rc = dev_alloc(e, &db.pm, S * NPM * PM_FRAME))) break;
         db.nstreams_alloc = (int)S;
         if ((rc = dev_alloc(e, &db.dec, (size_t)(cfg->p1_async ? NAUX : 1) * S * (size_t)(P1_LEN + 64)))) break;
         if ((rc = dev_alloc(e, &db.tbmap, (size_t)(cfg->p1_async ? NAUX : 1) * S * (size_t)(P1_LEN / 64 + 1) * 64))) break;
@@ -252,7 +253,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if (hipMemcpy(db.state, init.data(), S * sizeof(StreamState), hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(e->all_ids_dev, ident.data(), S * sizeof(int), hipMemcpyHostToDevice) != hipSuccess ||
             hipMemset(db.records, 0, S * db.rec_cap * sizeof(BlockRecord)) != hipSuccess ||
-            hipMemset(db.pm, 0, S * PM_FRAME) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "state init copy failed"); break; }
+            hipMemset(db.pm, 0, S * NPM * PM_FRAME) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "state init copy failed"); break; }
         e->wr_host.assign(S, 0); e->base_host.assign(S, 0); e->drained.assign(S, 0);
         for (int l = 0; l < e->nlanes; l++) { e->lanes[l].db = db; e->lanes[l].counters_dev = db.counters + 4 * l; e->lanes[l].db.counters = db.counters + 4 * l; }
         e->prof_on = false;
@@ -268,6 +269,9 @@ extern "C" void nrsc5hip_engine_destroy(nrsc5hip_engine *e)
     if (!e) return;
     hipDeviceSynchronize();
     for (void *p : e->allocs) hipFree(p);
+    if (e->rec_host) (void)hipHostFree(e->rec_host);
+    if (e->frames_host) (void)hipHostFree(e->frames_host);
+    if (e->nblocks_host) (void)hipHostFree(e->nblocks_host);
     for (auto &sp : e->prof_spans) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
     for (hipEvent_t ev : e->prof_pool) hipEventDestroy(ev);
     for (int l = 0; l < e->nlanes; l++) {
@@ -313,7 +317,6 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
     const int fuse = (async && !ln.acq_needed && !no_fuse) ? 1 : 0;
     { ProfScope p(e, NRSC5HIP_PROF_SYNC, ln.main); launch_sync(e->tb, ln.db, n, ids_dev, parity, slot, fuse, ln.main); }
     ln.prepared_by_sync = fuse != 0;
-    { ProfScope p(e, NRSC5HIP_PROF_P1_DEINT, ln.main); launch_p1_deint(e->tb, ln.db, n, ids_dev, parity, ln.main); }
     if (!async) {
         { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_pids_decode(e->tb, ln.db, n, ids_dev, parity, 1, ln.main); }
         ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ln.main);
@@ -669,7 +672,11 @@ extern "C" int nrsc5hip_debug_fetch(nrsc5hip_engine *e, int stream, int8_t *pm, 
 {
     int rc = check_stream(e, stream); if (rc) return rc;
     HIPCHK(hipDeviceSynchronize());
-    if (pm) HIPCHK(hipMemcpy(pm, e->db.pm + (size_t)stream * PM_FRAME, PM_FRAME, hipMemcpyDeviceToHost));
+    if (pm) {
+        int slot = 0;
+        HIPCHK(hipMemcpy(&slot, (const char *)(e->db.state + stream) + offsetof(StreamState, last_pm_slot), sizeof(int), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(pm, e->db.pm + ((size_t)stream * NPM + slot) * PM_FRAME, PM_FRAME, hipMemcpyDeviceToHost));
+    }
     if (bins) HIPCHK(hipMemcpy(bins, e->db.bins + (size_t)stream * NSYM * LIVE_N, (size_t)NSYM * LIVE_N * sizeof(float2), hipMemcpyDeviceToHost));
     return 0;
 }
@@ -788,5 +795,36 @@ extern "C" int nrsc5hip_debug_sync_phases(nrsc5hip_engine *e, long long *cycles8
     if (!e->db.sync_phase_cycles) FAIL(NRSC5HIP_EINVAL, "set NRSC5HIP_SYNC_PHASES=1 before creating the engine");
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(cycles8, e->db.sync_phase_cycles, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// Zero-copy variant of nrsc5hip_batch_fetch for streams 0..nstreams-1: three bulk D2H copies into engine-owned
+// pinned buffers; the returned pointers stay valid until the next fetch/reset.  records: [nstreams][record_capacity],
+// frames: [nstreams][p1_slots][4568].  Requires that nothing was drained since the last reset.
+extern "C" int nrsc5hip_batch_fetch_view(nrsc5hip_engine *e, int nstreams, const nrsc5hip_record **records, int *counts, const uint32_t **frames)
+{
+    if (!e || !records || !counts) FAIL(NRSC5HIP_EINVAL, "null argument");
+    if (nstreams < 1 || nstreams > e->cfg.max_streams) FAIL(NRSC5HIP_EINVAL, "nstreams out of range");
+    const size_t S = e->cfg.max_streams;
+    if (!e->rec_host) {
+        HIPCHK(hipHostMalloc((void **)&e->rec_host, S * e->db.rec_cap * sizeof(BlockRecord), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&e->frames_host, S * e->db.p1_slots * P1_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&e->nblocks_host, S * sizeof(int), hipHostMallocDefault));
+    }
+    HIPCHK(hipStreamSynchronize(e->main));
+    HIPCHK(hipMemcpy2DAsync(e->nblocks_host, sizeof(int), (const char *)e->db.state + offsetof(StreamState, nblocks), sizeof(StreamState),
+                            sizeof(int), nstreams, hipMemcpyDeviceToHost, e->main));
+    HIPCHK(hipMemcpyAsync(e->rec_host, e->db.records, (size_t)nstreams * e->db.rec_cap * sizeof(BlockRecord), hipMemcpyDeviceToHost, e->main));
+    if (frames)
+        HIPCHK(hipMemcpyAsync(e->frames_host, e->db.p1_ring, (size_t)nstreams * e->db.p1_slots * P1_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, e->main));
+    HIPCHK(hipStreamSynchronize(e->main));
+    for (int s = 0; s < nstreams; s++) {
+        if (e->drained[s] != 0 || e->nblocks_host[s] > e->db.rec_cap)
+            FAIL(NRSC5HIP_EOVERFLOW, "stream %d: view needs an undrained, unwrapped record ring (%d records, capacity %d)", s, e->nblocks_host[s], e->db.rec_cap);
+        counts[s] = e->nblocks_host[s];
+        e->drained[s] = e->nblocks_host[s];
+    }
+    *records = (const nrsc5hip_record *)e->rec_host;
+    if (frames) *frames = e->frames_host;
     return 0;
 }

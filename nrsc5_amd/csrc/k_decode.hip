@@ -8,43 +8,12 @@ namespace nrsc5 {
 
 __device__ inline int stream_of(const int *ids, int idx) { return ids ? ids[idx] : idx; }
 
-// ---- K6: P1 gather + depuncture ---------------------------------------------------------------
-// coded bit i of the frame sits at matrix cell p1_gather[i]; the Viterbi input carries a zero after
-// every 5th coded bit (puncture pattern [1,1,1,1,1,0], decode.c:318-319): position i + i/5.
-// One thread produces one 6-byte group (5 gathers + the erased slot).
-__global__ __launch_bounds__(1024) void k_p1_deint(DevTables tb, DevBuffers db, const int *ids, int parity)
-{
-    const int s = stream_of(ids, blockIdx.y);
-    const StreamState &st = db.state[s];
-    if (st.p1_pending[parity] != 1) return;                    // 1 = completed in this step, 2 = already gathered
-    const int8_t *pm = db.pm + (size_t)s * PM_FRAME;
-    int8_t *out = db.coded + ((size_t)s * NWIN + parity) * P1_DEPUNCT;
-    // one lane = 4 puncture groups = 20 gathers -> 24 contiguous output bytes, stored as three 8-byte words
-    // (byte stores would turn the 438 KB frame into partial-line writes).  Few blocks per stream, so the 15 of
-    // 16 steps in which no frame completes cost one wave-uniform early exit per block.
-    constexpr int QUADS = P1_CODED / 20;                       // 18272
-    uint2 *out8 = (uint2 *)out;
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < QUADS; q += gridDim.x * blockDim.x) {
-        const int32_t *idx = tb.p1_gather + 20 * q;
-        uint32_t w[6] = { 0, 0, 0, 0, 0, 0 };
-#pragma unroll
-        for (int g = 0; g < 4; g++)
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                const int pos = 6 * g + k;                     // byte position inside the 24-byte run; slot 6g+5 stays 0
-                w[pos >> 2] |= (uint32_t)(uint8_t)pm[idx[5 * g + k]] << (8 * (pos & 3));
-            }
-        out8[3 * q] = make_uint2(w[0], w[1]);
-        out8[3 * q + 1] = make_uint2(w[2], w[3]);
-        out8[3 * q + 2] = make_uint2(w[4], w[5]);
-    }
-}
-
 // ---- K8 helpers ---------------------------------------------------------------------------------
 // Re-encode the decoded (still scrambled) bits and count sign disagreements with the received soft
 // bits at unpunctured positions (decode.c:234-265).  Block-stride over the frame; returns this
 // thread's partial count.
-__device__ inline int bit_errors_k7_partial(const int8_t *coded, const uint32_t *bits, int len)
+template <typename Src>
+__device__ inline int bit_errors_k7_partial(const Src &src, const uint32_t *bits, int len)
 {
     int errors = 0;
     for (int i = threadIdx.x; i < len; i += blockDim.x) {
@@ -54,24 +23,25 @@ __device__ inline int bit_errors_k7_partial(const int8_t *coded, const uint32_t 
             int q = i - k; if (q < 0) q += len;                // tail biting
             r |= ((bits[q >> 5] >> (q & 31)) & 1u) << (6 - k);
         }
-        const int j = 3 * i;
+        const int w = src.triple(i);
+        const int c0 = (int8_t)w, c1 = (int8_t)(w >> 8), c2 = (int8_t)(w >> 16);
         const int p0 = __popc(r & 0133u) & 1, p1 = __popc(r & 0171u) & 1, p2 = __popc(r & 0165u) & 1;
-        if ((j % 6) != 5 && ((coded[j] > 0) != p0)) errors++;
-        if (((j + 1) % 6) != 5 && ((coded[j + 1] > 0) != p1)) errors++;
-        if (((j + 2) % 6) != 5 && ((coded[j + 2] > 0) != p2)) errors++;
+        if ((c0 > 0) != p0) errors++;
+        if ((c1 > 0) != p1) errors++;
+        if ((i & 1) == 0 && ((c2 > 0) != p2)) errors++;        // odd i: the third bit is punctured [1,1,1,1,1,0]
     }
     return errors;
 }
 
 // ---- K7: P1 frame = forward pass by one wave, then traceback/BER/descramble by a 16-wave block -------
-__global__ __launch_bounds__(64) void k_p1_forward(DevBuffers db, const int *ids, int parity, int lane_id)
+__global__ __launch_bounds__(64) void k_p1_forward(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id)
 {
     const int s = stream_of(ids, blockIdx.x);
     StreamState &st = db.state[s];
     if (!st.p1_pending[parity]) return;                        // wave-uniform
-    const int8_t *coded = db.coded + ((size_t)s * NWIN + parity) * P1_DEPUNCT;
+    const SoftGatherP1 src = { db.pm + ((size_t)s * NPM + st.p1_pmslot[parity]) * PM_FRAME, tb.p1_gather };
     unsigned long long *dec = db.dec + ((size_t)lane_id * db.nstreams_alloc + s) * (P1_LEN + 64);
-    const int endlane = viterbi_fast_forward(coded, P1_LEN, dec);
+    const int endlane = viterbi_fast_forward(src, dec);
     if ((threadIdx.x & 63) == 0) st.p1_endlane[parity] = endlane;
 }
 
@@ -85,7 +55,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBu
     HIP_DYNAMIC_SHARED(uint8_t, smem)
     __shared__ int err_total;
     const int tid = threadIdx.x;
-    const int8_t *coded = db.coded + ((size_t)s * NWIN + parity) * P1_DEPUNCT;
+    const SoftGatherP1 src = { db.pm + ((size_t)s * NPM + st.p1_pmslot[parity]) * PM_FRAME, tb.p1_gather };
     unsigned long long *dec = db.dec + ((size_t)lane_id * db.nstreams_alloc + s) * (P1_LEN + 64);
     uint32_t *out = db.p1_ring + ((size_t)s * db.p1_slots + st.p1_slot[parity]) * P1_WORDS;
     if (tid == 0) err_total = 0;
@@ -93,7 +63,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBu
     viterbi_fast_traceback_block(dec, P1_LEN, st.p1_endlane[parity], out, gmap, smem);
     __threadfence_block();
     __syncthreads();
-    const int errors = wave_sum_i32(bit_errors_k7_partial(coded, out, P1_LEN));
+    const int errors = wave_sum_i32(bit_errors_k7_partial(src, out, P1_LEN));
     if ((tid & 63) == 0) atomicAdd(&err_total, errors);
     __syncthreads();
     for (int w = tid; w < P1_WORDS; w += blockDim.x) out[w] ^= tb.scr_p1[w];       // descramble
@@ -105,15 +75,9 @@ __global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBu
 
 static size_t traceback_smem(int len) { const int nchunks = len / 64 + 1; return (size_t)((nchunks + TB_SEG - 1) / TB_SEG) * 64 + nchunks; }
 
-void launch_p1_deint(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st)
-{
-    dim3 grid(18, nstreams);                                   // 18 x 1024 lanes = one 24-byte run per lane
-    hipLaunchKernelGGL(k_p1_deint, grid, dim3(1024), 0, st, tb, db, stream_ids, parity);
-}
-
 void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_p1_forward, dim3(nstreams), dim3(64), 0, st, db, stream_ids, parity, lane_id);
+    hipLaunchKernelGGL(k_p1_forward, dim3(nstreams), dim3(64), 0, st, tb, db, stream_ids, parity, lane_id);
     hipLaunchKernelGGL(k_p1_traceback, dim3(nstreams), dim3(TB_THREADS), traceback_smem(P1_LEN), st, tb, db, stream_ids, parity, lane_id);
 }
 
@@ -127,7 +91,8 @@ __global__ __launch_bounds__(64) void k_viterbi_frames(const int8_t *coded, int 
 __global__ __launch_bounds__(64) void k_viterbi_frames_fwd(const int8_t *coded, int len, unsigned long long *dec, int *endlane)
 {
     const int f = blockIdx.x;
-    const int e = viterbi_fast_forward(coded + (size_t)f * 3 * len, len, dec + (size_t)f * (len + 64));
+    const SoftContig src = { coded + (size_t)f * 3 * len, len };
+    const int e = viterbi_fast_forward(src, dec + (size_t)f * (len + 64));
     if ((threadIdx.x & 63) == 0) endlane[f] = e;
 }
 __global__ __launch_bounds__(TB_THREADS) void k_viterbi_frames_tb(unsigned long long *dec, int len, const int *endlane, uint32_t *out, uint8_t *gmap)

@@ -174,9 +174,6 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
 {
     const int s = stream_of(ids, blockIdx.x);
     StreamState &st = db.state[s];
-    // a frame completed in an earlier step of this decode window was gathered by that step's k_p1_deint:
-    // freeze it (the interleaver matrix is about to be refilled with the next frame's blocks)
-    if (threadIdx.x == 0 && st.p1_pending[parity] == 1) st.p1_pending[parity] = 2;
     if (!st.active) {                                          // block-uniform
         // no block this step; with the fused pipeline the stream may have become ready since (new samples)
         if (fuse_prepare && threadIdx.x == 0) prepare_block(db, st, s);
@@ -419,7 +416,8 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         // primary-main soft bits -> row `bc` of the stream's 16 x 32 x 720 interleaver matrix (decode.c:380).
         // Partitions 0..9 = lower sideband from the edge; 10..19 = upper sideband in ascending frequency
         // (sync.c:514-536): the upper-sideband cell of partition `part` (from the edge) is matrix partition 19 - part.
-        int8_t *pm_blk = db.pm + (size_t)s * PM_FRAME + (size_t)bc * PM_BLOCK;
+        const int pm_slot = st.pm_slot;
+        int8_t *pm_blk = db.pm + ((size_t)s * NPM + pm_slot) * PM_FRAME + (size_t)bc * PM_BLOCK;
         if (ppb == PM_PART) {
 #pragma unroll
             for (int i = 0; i < MP1C; i++) {
@@ -453,9 +451,12 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
                 const int slot = st.p1_count % db.p1_slots;
                 st.p1_count++;
                 st.p1_pending[parity] = 1; st.p1_slot[parity] = slot; st.p1_record[parity] = st.nblocks % db.rec_cap;
+                st.p1_pmslot[parity] = pm_slot;
                 rec.p1_slot = slot; rec.flags |= REC_P1;
             }
             st.bc = (bc + 1) % 16;
+            st.last_pm_slot = pm_slot;
+            if (bc == 15) st.pm_slot = (pm_slot + 1) % NPM;      // the next frame fills a fresh matrix
         }
     }
     __syncthreads();

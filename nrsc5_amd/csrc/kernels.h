@@ -24,8 +24,7 @@ struct DevBuffers {
     c16 *acq_filt;                   // [S][WIN_N]   acquisition FIR output
     float2 *acq_sums;                // [S][SYM_N]
     float2 *bins;                    // [S][NSYM][LIVE_N]
-    int8_t *pm;                      // [S][PM_FRAME]
-    int8_t *coded;                   // [S][NWIN][P1_DEPUNCT]
+    int8_t *pm;                      // [S][NPM][PM_FRAME]  soft-bit interleaver matrices (one per frame in flight)
     int8_t *pids_stage;              // [S][NWIN][16][240]  depunctured PIDS soft bits awaiting k_pids_decode
     int *pids_rec;                   // [S][NWIN][16]     record index of each staged PIDS frame, -1 = empty
     unsigned long long *dec;         // [NAUX][S][P1_LEN + 64]  survivor decisions, one scratch per decode lane
@@ -53,7 +52,6 @@ void launch_prepare(const DevBuffers &db, int nstreams, const int *stream_ids, h
 void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
 void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, hipStream_t st);
 void launch_pids_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int nslots, hipStream_t st);
-void launch_p1_deint(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st);
 void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st);
 
 // ---- stage-level entry points (parity tests) ---------------------------------------------------

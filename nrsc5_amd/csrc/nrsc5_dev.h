@@ -28,6 +28,7 @@ constexpr int PIDS_CODED = 200;
 constexpr int VIT_EXTRA = 32;          // TAIL_BITING_EXTRA, conv_dec.c:43
 constexpr int P1_WORDS = P1_LEN / 32;  // packed output words per P1 frame (4568)
 constexpr int NWIN = 8;                // decode windows (16 block steps each) that may be in flight: buffers indexed w % NWIN
+constexpr int NPM = NWIN + 3;           // soft-bit matrices per stream: a frame's matrix must outlive its (deferred) decode
 constexpr int NAUX = 3;                // HIP streams that decode windows concurrently (each with its own decision scratch)
 
 enum { SYNC_NONE = 0, SYNC_COARSE = 1, SYNC_FINE = 2 };   // input.h:18
@@ -97,7 +98,10 @@ struct StreamState {
     int p1_pending[NWIN];          // 1: frame completed this step (gather it), 2: gathered into coded[s][parity]
     int p1_slot[NWIN];             // slot of the stream's P1 ring the decoder must fill
     int p1_record[NWIN];           // record index that gets the BER
-    int p1_endlane[NWIN];          // forward pass -> traceback hand-off (lane of the winning end state)
+    int p1_endlane[NWIN];
+    int p1_pmslot[NWIN];        // which of the stream's NPM soft-bit matrices holds the frame
+    int pm_slot;                // matrix being filled; advances after every block 15
+    int last_pm_slot;           // matrix that received the most recent block (debug fetch)          // forward pass -> traceback hand-off (lane of the winning end state)
 };
 
 }  // namespace nrsc5

@@ -186,6 +186,35 @@ __device__ __forceinline__ int vit_load_soft(const int8_t *coded, int len, int t
     return ((int)(uint8_t)coded[3 * j]) | ((int)(uint8_t)coded[3 * j + 1] << 8) | ((int)(uint8_t)coded[3 * j + 2] << 16);
 }
 
+// Where the trellis input comes from: a contiguous depunctured buffer, or -- for P1 -- straight out of the
+// 16 x 32 x 720 soft-bit matrix through interleaver I (decode.c:296-322), so no de-interleaved copy of the frame
+// is ever materialised: info bit j needs coded bits 3j..3j+2 of the depunctured stream; with the puncture pattern
+// [1,1,1,1,1,0] those are interleaver outputs 5(j/2) + {0,1,2} for even j and 5(j/2) + {3,4} + an erasure for odd j.
+struct SoftContig {
+    const int8_t *coded; int len;
+    __device__ __forceinline__ int length() const { return len; }
+    __device__ __forceinline__ int triple(int j) const
+    {
+        return ((int)(uint8_t)coded[3 * j]) | ((int)(uint8_t)coded[3 * j + 1] << 8) | ((int)(uint8_t)coded[3 * j + 2] << 16);
+    }
+};
+struct SoftGatherP1 {
+    const int8_t *pm; const int32_t *gather;
+    __device__ __forceinline__ int length() const { return P1_LEN; }
+    __device__ __forceinline__ int triple(int j) const
+    {
+        const int odd = j & 1, i0 = 5 * (j >> 1) + 3 * odd;
+        const int b0 = (uint8_t)pm[gather[i0]], b1 = (uint8_t)pm[gather[i0 + 1]];
+        const int b2 = odd ? 0 : (int)(uint8_t)pm[gather[i0 + 2]];
+        return b0 | (b1 << 8) | (b2 << 16);
+    }
+};
+template <typename Src> __device__ __forceinline__ int vit_soft_word(const Src &src, int t)
+{
+    const int len = src.length();
+    return src.triple((len - VIT_EXTRA + t) % len);            // conv_dec.c:407-412
+}
+
 // requires len % 64 == 0; all 64 lanes
 __device__ inline void viterbi_k7_wave_fast(const int8_t *coded, int len, unsigned long long *dec, uint32_t *out, int phases = 3)
 {
@@ -232,15 +261,19 @@ __device__ inline void viterbi_k7_wave_fast(const int8_t *coded, int len, unsign
 
 // ---- split form used by the P1 decoder: forward pass (one wave) + block-parallel traceback ----------
 // Forward only: fills dec[0 .. len+63] and returns the lane of the winning end state (wave-uniform).
-__device__ inline int viterbi_fast_forward(const int8_t *coded, int len, unsigned long long *dec)
+// The soft triples of a chunk are fetched two chunks (~4 us) ahead: the P1 gather goes to HBM / Infinity Cache.
+template <typename Src>
+__device__ inline int viterbi_fast_forward(const Src &src, unsigned long long *dec)
 {
     const int lane = threadIdx.x & 63;
+    const int len = src.length();
     const VitFastConst k = vit_fast_consts(lane);
     const int nchunks = len / 64 + 1;
     int pm = 0;
-    int aw = vit_load_soft(coded, len, lane);
+    int aw = vit_soft_word(src, lane);
+    int aw1 = vit_soft_word(src, 64 + lane);                   // nchunks >= 2 always (len >= 64)
     for (int c = 0; c < nchunks; c++) {
-        const int aw_next = (c + 1 < nchunks) ? vit_load_soft(coded, len, 64 * (c + 1) + lane) : 0;
+        const int aw2 = (c + 2 < nchunks) ? vit_soft_word(src, 64 * (c + 2) + lane) : 0;
         int wlo = 0, whi = 0;
         switch (c % 3) {
         case 0: VitFwd<0, 0>::run(pm, aw, k, vit_branch_metric<0>(aw, 0, k), 0ull, wlo, whi); break;
@@ -248,7 +281,7 @@ __device__ inline int viterbi_fast_forward(const int8_t *coded, int len, unsigne
         default: VitFwd<2, 0>::run(pm, aw, k, vit_branch_metric<2>(aw, 0, k), 0ull, wlo, whi); break;
         }
         dec[64 * c + lane] = ((unsigned long long)(uint32_t)whi << 32) | (uint32_t)wlo;
-        aw = aw_next;
+        aw = aw1; aw1 = aw2;
     }
     const int rend = (64 * nchunks) % 6;
     const int best = wave_max_i32(pm);

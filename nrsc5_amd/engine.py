@@ -66,6 +66,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.nrsc5hip_stage_viterbi_k7_debug.argtypes = [vp, vp, ci, vp, vp]
     lib.nrsc5hip_stage_viterbi_bench.argtypes = [vp, ci, ci, ci, ci, ctypes.POINTER(ctypes.c_float)]
     lib.nrsc5hip_debug_sync_phases.argtypes = [vp, vp]
+    lib.nrsc5hip_batch_fetch_view.argtypes = [vp, ci, ctypes.POINTER(vp), vp, ctypes.POINTER(vp)]
     lib.nrsc5hip_reset_all.argtypes = [vp]
     lib.nrsc5hip_profile.argtypes = [vp, ci, vp, vp]
     return lib
@@ -77,7 +78,7 @@ EXPORTED_SYMBOLS = [
     "nrsc5hip_batch_append_cu8", "nrsc5hip_batch_append_cs16", "nrsc5hip_batch_process", "nrsc5hip_drain",
     "nrsc5hip_p1_frame_packed", "nrsc5hip_p1_frame_bits", "nrsc5hip_batch_fetch", "nrsc5hip_unpack_bits",
     "nrsc5hip_stage_halfband_fm_cu8", "nrsc5hip_stage_fft2048", "nrsc5hip_stage_viterbi_k7", "nrsc5hip_debug_fetch",
-    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases"]
+    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_batch_fetch_view"]
 
 
 def unpack_bits(words: np.ndarray, nbits: int) -> np.ndarray:
@@ -188,6 +189,20 @@ class Engine:
         self._check(self.lib.nrsc5hip_batch_fetch(self._h, nstreams, None if ids is None else ids.ctypes.data,
                                                   recs.ctypes.data, self.record_capacity, counts.ctypes.data,
                                                   None if frames is None else frames.ctypes.data))
+        return recs, counts, frames
+
+    def batch_fetch_view(self, nstreams: int, with_frames: bool = True):
+        """Zero-copy views (numpy arrays over engine-owned pinned memory, valid until the next fetch/reset)."""
+        rp, fp = ctypes.c_void_p(), ctypes.c_void_p()
+        counts = np.zeros(nstreams, dtype=np.int32)
+        self._check(self.lib.nrsc5hip_batch_fetch_view(self._h, nstreams, ctypes.byref(rp), counts.ctypes.data,
+                                                       ctypes.byref(fp) if with_frames else None))
+        rec_bytes = nstreams * self.record_capacity * RECORD_DTYPE.itemsize
+        recs = np.frombuffer((ctypes.c_char * rec_bytes).from_address(rp.value), dtype=RECORD_DTYPE).reshape(nstreams, self.record_capacity)
+        frames = None
+        if with_frames:
+            fr_bytes = nstreams * self.p1_slots * P1_WORDS * 4
+            frames = np.frombuffer((ctypes.c_char * fr_bytes).from_address(fp.value), dtype=np.uint32).reshape(nstreams, self.p1_slots, P1_WORDS)
         return recs, counts, frames
 
     # ---- stage-level entry points (parity tests) ----------------------------------------------------

@@ -169,7 +169,10 @@ def check_batch_equals_streaming(lib, caps, p1_async):
     dev = _to_device(E, host)
     E.batch_append_cu8(dev, stride, [c.iq.size - c.iq.size % 4 for c in caps])
     steps = E.batch_process(n)
-    recs, counts, frames = E.batch_fetch(n)
+    if p1_async:                                              # exercise the zero-copy view path too
+        recs, counts, frames = E.batch_fetch_view(n)
+    else:
+        recs, counts, frames = E.batch_fetch(n)
     for k in range(n):
         log = eng.records_to_log(E, k, recs[k, :counts[k]], frames[k])
         diffs = common.compare_logs(singles[k], log, rtol=0.0)

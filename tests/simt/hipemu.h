@@ -157,6 +157,7 @@ template <typename T> static inline hipError_t hipHostMalloc(T **p, size_t n, un
 static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = 0) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t = 0) { for (size_t r = 0; r < h; r++) memmove((char *)d + r * dp, (const char *)s + r * sp, w); return hipSuccess; }
 static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = 0) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = 0; return hipSuccess; }
