@@ -168,6 +168,15 @@ static int build_tables(nrsc5hip_engine *e)
     int rc;
     if ((rc = dev_upload(e, &e->tb.p1_gather, p1))) return rc;
     if ((rc = dev_upload(e, &e->tb.pids_gather, pids))) return rc;
+    {   // byte q of the 384-byte run of one k: q%6==5 is the erasure, else j = q - q/6, part = PM_V[j%20], block = (j/20 + 7 part) % 16
+        std::vector<uint16_t> lut(384);
+        for (int q = 0; q < 384; q++) {
+            if (q % 6 == 5) { lut[q] = 0xffff; continue; }
+            const int j = q - q / 6, part = PM_V[j % 20], block = (j / 20 + 7 * part) % 16;
+            lut[q] = (uint16_t)(block * 720 + part * 36);
+        }
+        if ((rc = dev_upload(e, &e->tb.deint_lut, lut))) return rc;
+    }
     if ((rc = dev_upload(e, &e->tb.scr_p1, scr))) return rc;
     if ((rc = dev_upload(e, &e->tb.scr_pids, scr_pids))) return rc;
     if ((rc = dev_upload(e, &e->tb.twiddle, tw))) return rc;
@@ -229,6 +238,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if ((rc = dev_alloc(e, &db.bins, S * NSYM * LIVE_N))) break;
         if ((rc = dev_alloc(e, &db.pm, S * NPM * PM_FRAME))) break;
         db.nstreams_alloc = (int)S;
+        if ((rc = dev_alloc(e, &db.coded, (size_t)(cfg->p1_async ? NAUX : 1) * S * P1_DEPUNCT))) break;
         if ((rc = dev_alloc(e, &db.dec, (size_t)(cfg->p1_async ? NAUX : 1) * S * (size_t)(P1_LEN + 64)))) break;
         if ((rc = dev_alloc(e, &db.tbmap, (size_t)(cfg->p1_async ? NAUX : 1) * S * (size_t)(P1_LEN / 64 + 1) * 64))) break;
         if ((rc = dev_alloc(e, &db.pids_stage, S * NWIN * 16 * 3 * PIDS_LEN))) break;

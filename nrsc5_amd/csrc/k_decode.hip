@@ -8,6 +8,45 @@ namespace nrsc5 {
 
 __device__ inline int stream_of(const int *ids, int idx) { return ids ? ids[idx] : idx; }
 
+// ---- K6: P1 de-interleave + depuncture (interleaver I, decode.c:296-322) ---------------------------------------
+// Coded bit i = 320 k + j of the frame sits in matrix row (11 k) % 32 of block (j/20 + 7 part) % 16, partition
+// part = PM_V[j % 20], column (11 k + k/288) % 36.  All k that share a matrix row r (k = 3r + 32 m) read the same
+// 16 x 720-byte lines, so one workgroup per (stream, r) stages those 11.5 KB in LDS with coalesced loads and emits
+// its ~36 runs of 384 depunctured bytes (320 soft bits + 64 erasures [1,1,1,1,1,0]) as whole dwords: HBM sees
+// 369 KB in + 438 KB out per frame, instead of one cache line per gathered byte.
+__global__ __launch_bounds__(256) void k_p1_deint(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id)
+{
+    const int s = stream_of(ids, blockIdx.y);
+    const StreamState &st = db.state[s];
+    if (!st.p1_pending[parity]) return;                        // block-uniform
+    __shared__ uint32_t tile[16 * 180];                        // [block][720 bytes]
+    __shared__ uint16_t lut[384];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const int8_t *pm = db.pm + ((size_t)s * NPM + st.p1_pmslot[parity]) * PM_FRAME;
+    uint32_t *out = (uint32_t *)(db.coded + ((size_t)lane_id * db.nstreams_alloc + s) * P1_DEPUNCT);
+    for (int w = tid; w < 16 * 180; w += 256) {
+        const int b = w / 180, x = w % 180;
+        tile[w] = ((const uint32_t *)(pm + ((size_t)b * 32 + r) * 720))[x];
+    }
+    for (int q = tid; q < 384; q += 256) lut[q] = tb.deint_lut[q];
+    __syncthreads();
+    const uint8_t *bytes = (const uint8_t *)tile;
+    const int k0 = (3 * r) & 31;                               // 11 k = r (mod 32)  <=>  k = 3 r (mod 32)
+    const int nk = (P1_CODED / 320 - k0 + 31) / 32;            // k = k0 + 32 m < 1142
+    for (int idx = tid; idx < nk * 96; idx += 256) {
+        const int m = idx / 96, w = idx % 96;
+        const int k = k0 + 32 * m;
+        const int col = (11 * k + k / 288) % 36;
+        uint32_t v = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const unsigned off = lut[4 * w + t];
+            if (off != 0xffffu) v |= (uint32_t)bytes[off + col] << (8 * t);
+        }
+        out[96 * k + w] = v;
+    }
+}
+
 // ---- K8 helpers ---------------------------------------------------------------------------------
 // Re-encode the decoded (still scrambled) bits and count sign disagreements with the received soft
 // bits at unpunctured positions (decode.c:234-265).  Block-stride over the frame; returns this
@@ -39,7 +78,7 @@ __global__ __launch_bounds__(64) void k_p1_forward(DevTables tb, DevBuffers db, 
     const int s = stream_of(ids, blockIdx.x);
     StreamState &st = db.state[s];
     if (!st.p1_pending[parity]) return;                        // wave-uniform
-    const SoftGatherP1 src = { db.pm + ((size_t)s * NPM + st.p1_pmslot[parity]) * PM_FRAME, tb.p1_gather };
+    const SoftContig src = { db.coded + ((size_t)lane_id * db.nstreams_alloc + s) * P1_DEPUNCT, P1_LEN };
     unsigned long long *dec = db.dec + ((size_t)lane_id * db.nstreams_alloc + s) * (P1_LEN + 64);
     const int endlane = viterbi_fast_forward(src, dec);
     if ((threadIdx.x & 63) == 0) st.p1_endlane[parity] = endlane;
@@ -55,7 +94,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBu
     HIP_DYNAMIC_SHARED(uint8_t, smem)
     __shared__ int err_total;
     const int tid = threadIdx.x;
-    const SoftGatherP1 src = { db.pm + ((size_t)s * NPM + st.p1_pmslot[parity]) * PM_FRAME, tb.p1_gather };
+    const SoftContig src = { db.coded + ((size_t)lane_id * db.nstreams_alloc + s) * P1_DEPUNCT, P1_LEN };
     unsigned long long *dec = db.dec + ((size_t)lane_id * db.nstreams_alloc + s) * (P1_LEN + 64);
     uint32_t *out = db.p1_ring + ((size_t)s * db.p1_slots + st.p1_slot[parity]) * P1_WORDS;
     if (tid == 0) err_total = 0;
@@ -77,6 +116,7 @@ static size_t traceback_smem(int len) { const int nchunks = len / 64 + 1; return
 
 void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st)
 {
+    hipLaunchKernelGGL(k_p1_deint, dim3(32, nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, lane_id);
     hipLaunchKernelGGL(k_p1_forward, dim3(nstreams), dim3(64), 0, st, tb, db, stream_ids, parity, lane_id);
     hipLaunchKernelGGL(k_p1_traceback, dim3(nstreams), dim3(TB_THREADS), traceback_smem(P1_LEN), st, tb, db, stream_ids, parity, lane_id);
 }

@@ -7,6 +7,7 @@ namespace nrsc5 {
 // Read-only device tables built once per engine (engine.hip: build_tables()).
 struct DevTables {
     const int32_t *p1_gather;        // [P1_CODED]  flat index into the 16x32x720 soft-bit matrix (decode.c:296-322)
+    const uint16_t *deint_lut;       // [384] byte q of a 384-byte depunctured run -> block*720 + part*36, 0xffff = erasure
     const uint16_t *pids_gather;     // [16][PIDS_CODED] index inside block bc (decode.c:324-342)
     const uint32_t *scr_p1;          // [P1_WORDS] packed scrambler stream (decode.c:279-294)
     const uint32_t *scr_pids;        // [3]
@@ -27,6 +28,7 @@ struct DevBuffers {
     int8_t *pm;                      // [S][NPM][PM_FRAME]  soft-bit interleaver matrices (one per frame in flight)
     int8_t *pids_stage;              // [S][NWIN][16][240]  depunctured PIDS soft bits awaiting k_pids_decode
     int *pids_rec;                   // [S][NWIN][16]     record index of each staged PIDS frame, -1 = empty
+    int8_t *coded;                   // [NAUX][S][P1_DEPUNCT]  depunctured P1 trellis input, one per decode lane
     unsigned long long *dec;         // [NAUX][S][P1_LEN + 64]  survivor decisions, one scratch per decode lane
     int nstreams_alloc;              // S
     uint8_t *tbmap;                  // [NAUX][S][2285 * 64]  traceback chunk maps (start lane per end lane)
