@@ -48,6 +48,7 @@ struct nrsc5hip_engine {
         DevBuffers db;                 // engine buffers with this lane's counters
     } lanes[MAX_LANES];
     int nlanes;
+    int naux;                          // decode streams in use (<= NAUX)
     hipStream_t main;                  // = lanes[0].main
     std::vector<void *> allocs;
     // host mirrors
@@ -214,6 +215,10 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             e->nlanes = env ? atoi(env) : 1;   // more lanes only pay when a step is throughput-bound; it is latency-bound today
             if (e->nlanes < 1) e->nlanes = 1;
             if (e->nlanes > MAX_LANES) e->nlanes = MAX_LANES;
+            const char *ea = getenv("NRSC5HIP_NAUX");
+            e->naux = ea ? atoi(ea) : 3;
+            if (e->naux < 1) e->naux = 1;
+            if (e->naux > NAUX) e->naux = NAUX;
         }
         for (int l = 0; l < e->nlanes && !rc; l++) {
             nrsc5hip_engine::Lane &ln = e->lanes[l];
@@ -312,7 +317,7 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
     const bool async = e->cfg.p1_async != 0;
     const long long window = ln.step_count / 16;
     const int parity = async ? (int)(window % NWIN) : 0;       // buffer slot of this decode window
-    const int lane = async ? (int)(window % NAUX) : 0;         // aux stream + decision scratch that will decode it
+    const int lane = async ? (int)(window % e->naux) : 0;      // aux stream + decision scratch that will decode it
     if (async && (ln.step_count % 16) == 0 && ln.decoded_pending[parity]) {
         // the buffers of slot `parity` are about to be rewritten: the decoder launched NWIN windows ago must be done
         HIPCHK(hipStreamWaitEvent(ln.main, ln.ev_decoded[parity], 0));
@@ -353,7 +358,7 @@ static int flush_p1(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const 
     if (!e->cfg.p1_async) return 0;
     if (ln.step_count % 16) {
         const long long window = ln.step_count / 16;
-        const int parity = (int)(window % NWIN), lane = (int)(window % NAUX);
+        const int parity = (int)(window % NWIN), lane = (int)(window % e->naux);
         hipStream_t ax = ln.aux[lane];
         HIPCHK(hipEventRecord(ln.ev_window[parity], ln.main));
         HIPCHK(hipStreamWaitEvent(ax, ln.ev_window[parity], 0));

@@ -13,6 +13,7 @@
 // ~1e-5 rad of the recurrence (whose own rounding drift is of that order).
 #include <hip/hip_runtime.h>
 #include "kernels.h"
+#include "wave_ops.h"
 
 namespace nrsc5 {
 
@@ -117,6 +118,7 @@ __device__ inline void fft2048_wg(float2 *x, float2 *lds, const float2 *tw)
 
 __global__ __launch_bounds__(128) void k_mixfft(DevTables tb, DevBuffers db, const int *ids)
 {
+    wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
     const int s = stream_of(ids, blockIdx.y);
     const StreamState &st = db.state[s];
     if (!st.active) return;                                    // block-uniform

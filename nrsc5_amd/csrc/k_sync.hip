@@ -172,6 +172,7 @@ __device__ __forceinline__ void store_soft(int8_t *pm_blk, float2 v, int side, i
 
 __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare)
 {
+    wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
     const int s = stream_of(ids, blockIdx.x);
     StreamState &st = db.state[s];
     if (!st.active) {                                          // block-uniform

@@ -29,7 +29,7 @@ constexpr int VIT_EXTRA = 32;          // TAIL_BITING_EXTRA, conv_dec.c:43
 constexpr int P1_WORDS = P1_LEN / 32;  // packed output words per P1 frame (4568)
 constexpr int NWIN = 8;                // decode windows (16 block steps each) that may be in flight: buffers indexed w % NWIN
 constexpr int NPM = NWIN + 3;           // soft-bit matrices per stream: a frame's matrix must outlive its (deferred) decode
-constexpr int NAUX = 3;                // HIP streams that decode windows concurrently (each with its own decision scratch)
+constexpr int NAUX = 5;                // HIP streams that decode windows concurrently (each with its own decision scratch)
 
 enum { SYNC_NONE = 0, SYNC_COARSE = 1, SYNC_FINE = 2 };   // input.h:18
 

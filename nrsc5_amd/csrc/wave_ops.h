@@ -11,6 +11,14 @@ __device__ inline int wave_readlane(int v, int lane) { return __shfl(v, lane); }
 // v_readlane_b32: lane index must be wave-uniform
 __device__ __forceinline__ int wave_readlane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 #endif
+// Raise this wave's issue priority (s_setprio): the per-block kernels are a serial chain of 224 steps per pass, the
+// trellis passes that share their SIMDs are long-running background work.
+#ifdef HIPEMU
+__device__ inline void wave_set_priority_high() {}
+#else
+__device__ __forceinline__ void wave_set_priority_high() { __builtin_amdgcn_s_setprio(3); }
+#endif
+
 #ifdef HIPEMU
 __device__ inline int wave_uniform(int v) { return __shfl(v, 0); }
 #else
