@@ -42,6 +42,7 @@ struct nrsc5hip_engine {
         hipEvent_t ev_window[NWIN], ev_decoded[NWIN];
         bool decoded_pending[NWIN];
         bool acq_needed;
+        int dec_waited;                // chunks of the current chunked append this lane has already waited for
         bool prepared_by_sync;         // the previous step's k_sync already ran the next block's bookkeeping
         long long step_count;          // block steps issued so far (decode-window bookkeeping in async mode)
         int *counters_dev, *counters_host;
@@ -58,6 +59,11 @@ struct nrsc5hip_engine {
     uint8_t *stage_dev; size_t stage_bytes;
     int *ids_dev; unsigned *nbytes_dev;
     int *all_ids_dev;                  // identity list 0..S-1
+    // chunked K1 running ahead of the block steps on its own stream (fresh batches in the async pipeline)
+    hipStream_t dec_stream;
+    std::vector<hipEvent_t> dec_events;    // dec_events[c] fires when output samples [0, (c+1)*dec_chunk) of every stream are committed
+    long long dec_chunk;                   // output samples per chunk, 0 = no chunked append outstanding
+    unsigned *chunk_nbytes_dev; int chunk_cap;
     // engine-owned pinned result buffers for nrsc5hip_batch_fetch_view (allocated on first use)
     BlockRecord *rec_host; uint32_t *frames_host; int *nblocks_host;
     // optional per-kernel-class timing with HIP events on the launching stream
@@ -233,6 +239,8 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         }
         if (rc) { snprintf(g_err, sizeof(g_err), "stream/event creation failed"); break; }
         e->main = e->lanes[0].main;
+        if (hipStreamCreate(&e->dec_stream) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "hipStreamCreate failed"); break; }
+        e->dec_chunk = 0; e->chunk_nbytes_dev = nullptr; e->chunk_cap = 0;
         if ((rc = build_tables(e))) break;
         DevBuffers &db = e->db;
         db.q15_cap = cfg->q15_capacity; db.p1_slots = cfg->p1_slots; db.rec_cap = cfg->record_capacity;
@@ -284,6 +292,8 @@ extern "C" void nrsc5hip_engine_destroy(nrsc5hip_engine *e)
     if (!e) return;
     hipDeviceSynchronize();
     for (void *p : e->allocs) hipFree(p);
+    for (hipEvent_t ev : e->dec_events) (void)hipEventDestroy(ev);
+    if (e->dec_stream) (void)hipStreamDestroy(e->dec_stream);
     if (e->rec_host) (void)hipHostFree(e->rec_host);
     if (e->frames_host) (void)hipHostFree(e->frames_host);
     if (e->nblocks_host) (void)hipHostFree(e->nblocks_host);
@@ -322,6 +332,13 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
         // the buffers of slot `parity` are about to be rewritten: the decoder launched NWIN windows ago must be done
         HIPCHK(hipStreamWaitEvent(ln.main, ln.ev_decoded[parity], 0));
         ln.decoded_pending[parity] = false;
+    }
+    if (e->dec_chunk) {
+        // a stream starting from a fresh reset has read at most 70199 t + 71280 samples when step t begins
+        const long long reach = 70199LL * ln.step_count + WIN_N;
+        int need = (int)(reach / e->dec_chunk) + 1;
+        if (need > (int)e->dec_events.size()) need = (int)e->dec_events.size();
+        for (; ln.dec_waited < need; ln.dec_waited++) HIPCHK(hipStreamWaitEvent(ln.main, e->dec_events[ln.dec_waited], 0));
     }
     if (ln.acq_needed) { ProfScope p(e, NRSC5HIP_PROF_ACQUIRE, ln.main); launch_acquire(e->tb, ln.db, n, ids_dev, ln.main); }
     if (!ln.prepared_by_sync) { ProfScope p(e, NRSC5HIP_PROF_PREPARE, ln.main); launch_prepare(ln.db, n, ids_dev, ln.main); }
@@ -397,6 +414,7 @@ static int run_steps_lanes(nrsc5hip_engine *e, int nl, const int *n, const int *
         if (!progressed) break;                                // nothing was processed in this burst
         done += burst;
     }
+    if (e->dec_chunk) { HIPCHK(hipStreamSynchronize(e->dec_stream)); e->dec_chunk = 0; }
     for (int l = 0; l < nl; l++) { int rc = flush_p1(e, e->lanes[l], n[l], ids_dev[l]); if (rc) return rc; }
     for (int l = 0; l < nl; l++) HIPCHK(hipStreamSynchronize(e->lanes[l].main));
     if (e->prof_on) prof_collect(e);
@@ -527,7 +545,43 @@ extern "C" int nrsc5hip_batch_append_cu8(nrsc5hip_engine *e, int nstreams, const
             FAIL(NRSC5HIP_EOVERFLOW, "stream %d: q15_capacity %lld too small for this batch", s, e->db.q15_cap);
         if (nbytes[k] > mx) mx = nbytes[k];
     }
-    { ProfScope p(e, NRSC5HIP_PROF_DECIMATE, e->main); launch_decimate_fm_cu8(e->tb, e->db, nstreams, ids_dev, dev_iq, stride_bytes, e->nbytes_dev, mx, e->main); }
+    bool fresh = e->cfg.p1_async != 0 && stream_ids == nullptr && nstreams == e->cfg.max_streams;
+    for (int k = 0; k < nstreams && fresh; k++) fresh = e->wr_host[k] == 0;
+    for (int l = 0; l < e->nlanes && fresh; l++) fresh = e->lanes[l].step_count == 0;
+    const long long CH = 16 * 70199LL;                         // one decode window's worth of output samples
+    if (fresh && (long long)mx / 4 > 3 * CH) {
+        // Fresh batch in the pipelined mode: decimate window-sized chunks on a side stream so that K1 (HBM-bound)
+        // overlaps the issue-bound block steps; the scheduler waits for the chunk a step can reach (run_steps_lanes).
+        const int nch = (int)(((long long)mx / 4 + CH - 1) / CH);
+        if (e->chunk_cap < nch * nstreams) {
+            unsigned *p = nullptr;
+            if (dev_alloc(e, &p, (size_t)nch * nstreams)) return NRSC5HIP_ENOMEM;
+            e->chunk_nbytes_dev = p; e->chunk_cap = nch * nstreams;
+        }
+        std::vector<unsigned> cb((size_t)nch * nstreams);
+        for (int c = 0; c < nch; c++)
+            for (int k = 0; k < nstreams; k++) {
+                const long long lo = 4 * CH * c, left = (long long)nbytes[k] - lo;
+                cb[(size_t)c * nstreams + k] = (unsigned)(left <= 0 ? 0 : (left > 4 * CH ? 4 * CH : left));
+            }
+        HIPCHK(hipMemcpy(e->chunk_nbytes_dev, cb.data(), cb.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        while ((int)e->dec_events.size() < nch) { hipEvent_t ev; HIPCHK(hipEventCreate(&ev)); e->dec_events.push_back(ev); }
+        hipEvent_t start; HIPCHK(hipEventCreate(&start));
+        HIPCHK(hipEventRecord(start, e->main));                // after whatever the caller/engine queued before (reset)
+        HIPCHK(hipStreamWaitEvent(e->dec_stream, start, 0));
+        (void)hipEventDestroy(start);
+        for (int c = 0; c < nch; c++) {
+            ProfScope p(e, NRSC5HIP_PROF_DECIMATE, e->dec_stream);
+            launch_decimate_fm_cu8(e->tb, e->db, nstreams, ids_dev, dev_iq + 4 * CH * c, stride_bytes,
+                                   e->chunk_nbytes_dev + (size_t)c * nstreams, (unsigned)(4 * CH), e->dec_stream);
+            HIPCHK(hipEventRecord(e->dec_events[c], e->dec_stream));
+        }
+        e->dec_chunk = CH;
+        for (int l = 0; l < e->nlanes; l++) e->lanes[l].dec_waited = 0;
+    } else {
+        ProfScope p(e, NRSC5HIP_PROF_DECIMATE, e->main);
+        launch_decimate_fm_cu8(e->tb, e->db, nstreams, ids_dev, dev_iq, stride_bytes, e->nbytes_dev, mx, e->main);
+    }
     for (int k = 0; k < nstreams; k++) e->wr_host[stream_ids ? stream_ids[k] : k] += nbytes[k] / 4;
     HIPCHK(hipGetLastError());
     return 0;
@@ -719,6 +773,7 @@ extern "C" int nrsc5hip_reset_all(nrsc5hip_engine *e)
 {
     if (!e) FAIL(NRSC5HIP_EINVAL, "null engine");
     HIPCHK(hipDeviceSynchronize());
+    e->dec_chunk = 0;
     const size_t S = e->cfg.max_streams;
     std::vector<StreamState> init(S);
     for (size_t s = 0; s < S; s++) init_state(init[s]);

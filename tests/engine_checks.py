@@ -197,3 +197,55 @@ def _free_device(E, p: int):
     fn = E.lib.nrsc5hip_debug_free
     fn.argtypes = [ctypes.c_void_p]
     fn(p)
+
+
+def check_small_fifo_compaction(lib, name, captures):
+    """Streaming seam with the minimum FIFO: the unread tail is compacted many times; results unchanged."""
+    g = golden(name)
+    cap = captures(name)
+    chunk = 4 * 9000
+    E = eng.Engine(max_streams=1, q15_capacity=2 * 71280 + chunk // 4, lib_path=lib)
+    common.run_engine_streaming(E, 0, cap.iq, chunk=chunk)
+    log = eng.records_to_log(E, 0, E.drain(0))
+    diffs = common.compare_logs(common.arrays_to_log(g), common.strip_states(log))
+    assert not diffs, diffs[:10]
+    E.close()
+
+
+def check_api_edges(lib):
+    """Error behaviour of the C ABI: bad arguments are rejected with codes, never crashes; empty pushes are no-ops."""
+    import pytest
+    with pytest.raises(eng.Nrsc5HipError):
+        eng.Engine(max_streams=0, lib_path=lib)
+    with pytest.raises(eng.Nrsc5HipError):
+        eng.Engine(max_streams=1, q15_capacity=1000, lib_path=lib)          # below 2 * 71280
+    E = eng.Engine(max_streams=2, q15_capacity=2 * 71280 + 64, lib_path=lib)
+    E.push_cu8(0, np.zeros(0, dtype=np.uint8))                              # empty push
+    assert len(E.drain(0)) == 0
+    with pytest.raises(eng.Nrsc5HipError):
+        E.push_cu8(5, np.zeros(8, dtype=np.uint8))                          # stream out of range
+    with pytest.raises(eng.Nrsc5HipError):
+        E._check(E.lib.nrsc5hip_push_cu8(E._h, 0, np.zeros(8, dtype=np.uint8).ctypes.data, 6))   # length not a multiple of 4
+    with pytest.raises(eng.Nrsc5HipError):
+        E.batch_append_cu8(0, 16, [4 * (2 * 71280 + 1000)])                 # exceeds q15_capacity -> EOVERFLOW before touching memory
+    # a short push below one window produces no records, and a reset brings the stream back to a fresh session
+    E.push_cu8(1, np.full(4 * 1000, 127, dtype=np.uint8))
+    assert len(E.drain(1)) == 0
+    E.reset(1)
+    E.close()
+
+
+def check_cs16_batch(lib, captures):
+    """cs16 captures through the batch path (bypasses K1) == golden."""
+    g = golden("fm_cs16_cfo60")
+    cap = captures("fm_cs16_cfo60")
+    E = eng.Engine(max_streams=1, q15_capacity=cap.iq.size // 2 + 1024, record_capacity=256, p1_slots=4, p1_async=True, lib_path=lib)
+    dev = _to_device(E, cap.iq)
+    E.batch_append_cs16(dev, 0, [cap.iq.size])
+    E.batch_process(1)
+    recs, counts, frames = E.batch_fetch(1)
+    log = eng.records_to_log(E, 0, recs[0, :counts[0]], frames[0])
+    diffs = common.compare_logs(common.arrays_to_log(g), common.strip_states(log))
+    assert not diffs, diffs[:10]
+    _free_device(E, dev)
+    E.close()

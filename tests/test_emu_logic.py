@@ -46,3 +46,11 @@ def test_emu_async_p1_window_pipeline(emu_lib):
     caps = [synth.fm_mp1_capture(0, seed=40 + k, cfo_hz=c, offset=o, snr_db=14, n_blocks=nb)
             for k, (c, o, nb) in enumerate([(0.0, 4319, 20), (350.0, 100, 19)])]
     ec.check_batch_equals_streaming(emu_lib, caps, p1_async=True)
+
+
+def test_emu_small_fifo_compaction(emu_lib, captures):
+    ec.check_small_fifo_compaction(emu_lib, "fm_cu8_cfo-2400", captures)
+
+
+def test_emu_api_edges(emu_lib):
+    ec.check_api_edges(emu_lib)

@@ -91,6 +91,18 @@ def test_gpu_batch_equals_streaming(hip_lib, p1_async):
     ec.check_batch_equals_streaming(hip_lib, caps, p1_async=p1_async)
 
 
+def test_gpu_small_fifo_compaction(hip_lib, captures):
+    ec.check_small_fifo_compaction(hip_lib, "fm_cu8_cfo137", captures)
+
+
+def test_gpu_api_edges(hip_lib):
+    ec.check_api_edges(hip_lib)
+
+
+def test_gpu_cs16_batch(hip_lib, captures):
+    ec.check_cs16_batch(hip_lib, captures)
+
+
 def test_gpu_force_resync_feedback(hip_lib, oracle, captures):
     """L2 feedback seam (frame.c:535-540): dropping to NONE after the first P1 frame re-acquires like the oracle."""
     cap = captures("fm_cu8_cfo137")
