@@ -119,13 +119,6 @@ template <typename T> static int dev_upload(nrsc5hip_engine *e, const T **p, con
 static int build_tables(nrsc5hip_engine *e)
 {
     static const int8_t PM_V[20] = { 10, 2, 18, 6, 14, 8, 16, 0, 12, 4, 11, 3, 19, 7, 15, 9, 17, 1, 13, 5 };   // decode.c:34-37
-    // interleaver I for P1 (decode.c:296-322 with J=20, B=16, C=36, M=1, N=365440)
-    std::vector<int32_t> p1(P1_CODED);
-    for (unsigned i = 0; i < (unsigned)P1_CODED; i++) {
-        const unsigned part = PM_V[i % 20], block = (i / 20 + 7 * part) % 16, k = i / (20 * 16);
-        const unsigned row = (11 * k) % 32, col = (11 * k + k / (32 * 9)) % 36;
-        p1[i] = (block * 32 + row) * 720 + part * 36 + col;
-    }
     // interleaver II for PIDS (decode.c:324-342 with b=200, I0=365440): index inside block bc
     std::vector<uint16_t> pids(16 * PIDS_CODED);
     for (unsigned bc = 0; bc < 16; bc++)
@@ -173,7 +166,6 @@ static int build_tables(nrsc5hip_engine *e)
     for (int i = 1; i <= 16; i++) acq[i] = (int16_t)(acq_taps[31 - i] * 32767.0f);
 
     int rc;
-    if ((rc = dev_upload(e, &e->tb.p1_gather, p1))) return rc;
     if ((rc = dev_upload(e, &e->tb.pids_gather, pids))) return rc;
     {   // byte q of the 384-byte run of one k: q%6==5 is the erasure, else j = q - q/6, part = PM_V[j%20], block = (j/20 + 7 part) % 16
         std::vector<uint16_t> lut(384);

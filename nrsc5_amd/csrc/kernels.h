@@ -6,7 +6,6 @@ namespace nrsc5 {
 
 // Read-only device tables built once per engine (engine.hip: build_tables()).
 struct DevTables {
-    const int32_t *p1_gather;        // [P1_CODED]  flat index into the 16x32x720 soft-bit matrix (decode.c:296-322)
     const uint16_t *deint_lut;       // [384] byte q of a 384-byte depunctured run -> block*720 + part*36, 0xffff = erasure
     const uint16_t *pids_gather;     // [16][PIDS_CODED] index inside block bc (decode.c:324-342)
     const uint32_t *scr_p1;          // [P1_WORDS] packed scrambler stream (decode.c:279-294)

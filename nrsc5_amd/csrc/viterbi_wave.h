@@ -186,27 +186,15 @@ __device__ __forceinline__ int vit_load_soft(const int8_t *coded, int len, int t
     return ((int)(uint8_t)coded[3 * j]) | ((int)(uint8_t)coded[3 * j + 1] << 8) | ((int)(uint8_t)coded[3 * j + 2] << 16);
 }
 
-// Where the trellis input comes from: a contiguous depunctured buffer, or -- for P1 -- straight out of the
-// 16 x 32 x 720 soft-bit matrix through interleaver I (decode.c:296-322), so no de-interleaved copy of the frame
-// is ever materialised: info bit j needs coded bits 3j..3j+2 of the depunctured stream; with the puncture pattern
-// [1,1,1,1,1,0] those are interleaver outputs 5(j/2) + {0,1,2} for even j and 5(j/2) + {3,4} + an erasure for odd j.
+// Trellis input source: a contiguous depunctured buffer (3 soft values per information bit, erasures = 0).
+// (A variant that gathered P1 straight out of the interleaver matrix was measured: the byte gathers through
+// HBM / Infinity Cache made the forward pass 1.6x slower than de-interleaving first with k_p1_deint.)
 struct SoftContig {
     const int8_t *coded; int len;
     __device__ __forceinline__ int length() const { return len; }
     __device__ __forceinline__ int triple(int j) const
     {
         return ((int)(uint8_t)coded[3 * j]) | ((int)(uint8_t)coded[3 * j + 1] << 8) | ((int)(uint8_t)coded[3 * j + 2] << 16);
-    }
-};
-struct SoftGatherP1 {
-    const int8_t *pm; const int32_t *gather;
-    __device__ __forceinline__ int length() const { return P1_LEN; }
-    __device__ __forceinline__ int triple(int j) const
-    {
-        const int odd = j & 1, i0 = 5 * (j >> 1) + 3 * odd;
-        const int b0 = (uint8_t)pm[gather[i0]], b1 = (uint8_t)pm[gather[i0 + 1]];
-        const int b2 = odd ? 0 : (int)(uint8_t)pm[gather[i0 + 2]];
-        return b0 | (b1 << 8) | (b2 << 16);
     }
 };
 template <typename Src> __device__ __forceinline__ int vit_soft_word(const Src &src, int t)
