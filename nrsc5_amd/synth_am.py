@@ -223,17 +223,17 @@ def block_spectrum(pl, pu, s, t, pids1, pids2, bc: int) -> np.ndarray:
 def ofdm_modulate(x: np.ndarray, oversample: int = 1) -> np.ndarray:
     """X[nsym, 256] -> time samples; carrier phases are referenced to the symbol centre (sample 135), because
     the receiver rotates its FFT input by (FFT-CP)/2 = 121 samples (acquire.c:239-247)."""
-    nsym = x.shape[0]
-    k = np.arange(FFT) - FFT // 2
-    t = (np.arange(SYM * oversample) / oversample) - SYM / 2
-    basis = np.exp(2j * np.pi * np.outer(k, t) / FFT)          # [256, 270*os]
+    n = FFT * oversample
+    spec = np.zeros((x.shape[0], n), dtype=np.complex128)
+    spec[:, (np.arange(FFT) - FFT // 2) % n] = x
+    period = np.fft.ifft(spec, axis=1) * n                     # s(t), t = m / oversample, period 256
+    m = (np.arange(SYM * oversample) - (SYM // 2) * oversample) % n
     tt = np.arange(SYM * oversample) / oversample
     pulse = np.ones_like(tt)
     pulse[tt < CP] = np.sin(np.pi / 2 * tt[tt < CP] / CP)
     tail = tt >= FFT
     pulse[tail] = np.cos(np.pi / 2 * (tt[tail] - FFT) / CP)
-    live = np.nonzero(np.abs(x).sum(axis=0))[0]
-    return ((x[:, live] @ basis[live]) * pulse[None, :]).reshape(-1)
+    return (period[:, m] * pulse[None, :]).reshape(-1)
 
 
 @dataclasses.dataclass

@@ -12,8 +12,8 @@
  * absent here) is oracle/cpu_fft.c in both builds: parity unpinned at that boundary,
  * tolerance-checked.
  *
- * Each function cites the reference lines it restates.  FM (all hybrid/all-digital
- * primary-main processing, service mode MP1 end to end) is covered; AM is not yet.
+ * Each function cites the reference lines it restates.  FM: primary-main processing, service mode
+ * MP1 end to end (nrsc5_oracle.c).  AM: MA1 and MA3 (nrsc5_oracle_am.c).
  */
 #pragma once
 #include <stddef.h>
@@ -30,7 +30,8 @@ enum { ORC_SYNC_NONE = 0, ORC_SYNC_COARSE = 1, ORC_SYNC_FINE = 2 };
 /* ordered log record kinds: identical numbering/payloads to oracle/ref_shim/ref_harness.c */
 enum {
     ORC_REC_BLOCK = 1, ORC_REC_STATE, ORC_REC_SOFT, ORC_REC_PIDS, ORC_REC_FRAME, ORC_REC_SYNC,
-    ORC_REC_LOST_SYNC, ORC_REC_MER, ORC_REC_BER
+    ORC_REC_LOST_SYNC, ORC_REC_MER, ORC_REC_BER, ORC_REC_HDC, ORC_REC_VIT,
+    ORC_REC_AMSYM                 /* AM: u32 bc + pl[800] + pu[800] + s[800] + t[800] hard symbols of one block */
 };
 enum { ORC_TAP_Q15 = 1, ORC_TAP_FFT = 2, ORC_TAP_SOFT = 4 };
 
@@ -90,6 +91,39 @@ typedef struct {
     float costas_freq[30], costas_phase[30];   /* refs: lower i=0..14 at [2i], upper at [2i+1] */
 } orc_sync_snapshot;
 void orc_snapshot(const orc_stream *s, orc_sync_snapshot *out);
+
+/* ---- AM (nrsc5_oracle_am.c) ------------------------------------------------------------ */
+
+/* K1-AM  input.c:52-94: cu8 -> (Q15 >> 4) -> five cascaded 15-tap half-bands, 32:1.  Any nbytes % 4 == 0;
+ * stage phases carry over between calls.  Returns the number of output samples. */
+typedef struct orc_am_decim orc_am_decim;
+orc_am_decim *orc_am_decim_new(void);
+void orc_am_decim_free(orc_am_decim *d);
+size_t orc_am_decimate_cu8(orc_am_decim *d, const uint8_t *iq, size_t nbytes, orc_c16 *out);
+
+/* K2a-AM firdecim_q15.c:95-109 with the acquire.c:63-96 taps */
+void orc_am_fir32(orc_c16 hist[31], const orc_c16 *in, size_t n, orc_c16 *out);
+
+/* K6-AM  interleaver_ma1 (decode.c:74-231) incl. the 3-frame diversity delay lines (54000 bits each, updated in
+ * place), and the PIDS bit gather of decode_process_pids_am (decode.c:476-501) */
+void orc_am_deinterleave(int psmi, const uint8_t *pl, const uint8_t *pu, const uint8_t *s, const uint8_t *t,
+                         uint8_t *ml_q, uint8_t *mu_q, uint8_t *eml_q, uint8_t *emu_q, int8_t *vit_p1, int8_t *vit_p3);
+void orc_am_deinterleave_pids(const uint8_t sym[64], int pids1_disabled, int8_t out[240]);
+
+/* K8  decode.c:234-261: re-encode and count sign disagreements at unpunctured positions */
+int orc_bit_errors(const int8_t *coded, const uint8_t *decoded, int k, int len, const unsigned gens[3],
+                   const uint8_t *puncture, int plen);
+
+/* whole-path AM stream: mirrors input_push_cu8/cs16 in NRSC5_MODE_AM; the hook sees every 3750-bit P1 frame */
+typedef struct orc_am_stream orc_am_stream;
+orc_am_stream *orc_am_open(void);
+void orc_am_close(orc_am_stream *s);
+void orc_am_set_taps(orc_am_stream *s, unsigned mask, unsigned fft_limit_blocks);
+void orc_am_set_p1_hook(orc_am_stream *s, orc_p1_hook hook, void *user);
+void orc_am_push_cu8(orc_am_stream *s, const uint8_t *iq, uint32_t nbytes);
+void orc_am_push_cs16(orc_am_stream *s, const int16_t *iq, uint32_t n);
+void orc_am_force_resync(orc_am_stream *s);
+size_t orc_am_buf(orc_am_stream *s, int which, const uint8_t **p);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,7 @@ TAP_Q15, TAP_FFT, TAP_SOFT = 1, 2, 4
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("nrsc5_oracle.c", "nrsc5_oracle.h", "cpu_fft.c", "cpu_fft.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("nrsc5_oracle.c", "nrsc5_oracle_am.c", "nrsc5_oracle.h", "cpu_fft.c", "cpu_fft.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     return _SO
@@ -59,6 +59,23 @@ class Oracle:
         L.orc_descramble.argtypes = [vp, ctypes.c_uint]
         L.orc_bit_errors_k7.argtypes = [vp, vp, ctypes.c_int]
         L.oracle_fft_forward.argtypes = [ctypes.c_int, vp, vp]
+        # AM
+        L.orc_am_open.restype = vp
+        L.orc_am_close.argtypes = [vp]
+        L.orc_am_set_taps.argtypes = [vp, ctypes.c_uint, ctypes.c_uint]
+        L.orc_am_set_p1_hook.argtypes = [vp, P1_HOOK, vp]
+        L.orc_am_push_cu8.argtypes = [vp, vp, ctypes.c_uint32]
+        L.orc_am_push_cs16.argtypes = [vp, vp, ctypes.c_uint32]
+        L.orc_am_force_resync.argtypes = [vp]
+        L.orc_am_buf.argtypes = [vp, ctypes.c_int, ctypes.POINTER(vp)]
+        L.orc_am_buf.restype = sz
+        L.orc_am_decim_new.restype = vp
+        L.orc_am_decim_free.argtypes = [vp]
+        L.orc_am_decimate_cu8.argtypes = [vp, vp, sz, vp]
+        L.orc_am_decimate_cu8.restype = sz
+        L.orc_am_deinterleave.argtypes = [ctypes.c_int] + [vp] * 10
+        L.orc_am_deinterleave_pids.argtypes = [vp, ctypes.c_int, vp]
+        L.orc_bit_errors.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int]
 
     # ---- stage functions -------------------------------------------------------------
     def halfband_fm_cu8(self, iq: np.ndarray, hist: np.ndarray | None = None):
@@ -124,29 +141,71 @@ class Oracle:
         self.lib.oracle_fft_forward(x.size, x.ctypes.data, out.ctypes.data)
         return out
 
+    # ---- AM stage functions -------------------------------------------------------------
+    def am_decimate_cu8(self, chunks) -> np.ndarray:
+        """Feed a list of cu8 chunks through one decimator state; returns the concatenated Q15 output [n, 2]."""
+        d = self.lib.orc_am_decim_new()
+        outs = []
+        try:
+            for c in chunks:
+                c = np.ascontiguousarray(c, dtype=np.uint8)
+                out = np.zeros((c.size // 64 + 2, 2), dtype=np.int16)
+                n = self.lib.orc_am_decimate_cu8(d, c.ctypes.data, c.size, out.ctypes.data)
+                outs.append(out[:n])
+        finally:
+            self.lib.orc_am_decim_free(d)
+        return np.concatenate(outs) if outs else np.zeros((0, 2), dtype=np.int16)
+
+    def am_deinterleave(self, psmi, pl, pu, s, t, queues=None):
+        """interleaver_ma1 for one L1 frame; queues = [ml, mu, eml, emu] delay lines (uint8[54000]), updated in place."""
+        arrs = [np.ascontiguousarray(a, dtype=np.uint8) for a in (pl, pu, s, t)]
+        if queues is None:
+            queues = [np.zeros(54000, dtype=np.uint8) for _ in range(4)]
+        v1 = np.zeros(90000, dtype=np.int8)
+        v3 = np.zeros(90000, dtype=np.int8)
+        self.lib.orc_am_deinterleave(psmi, *[a.ctypes.data for a in arrs], *[q.ctypes.data for q in queues], v1.ctypes.data, v3.ctypes.data)
+        return v1, v3[:72000 if psmi != 2 else 90000], queues
+
+    def am_deinterleave_pids(self, sym64, pids1_disabled=0) -> np.ndarray:
+        s = np.ascontiguousarray(sym64, dtype=np.uint8)
+        out = np.zeros(240, dtype=np.int8)
+        self.lib.orc_am_deinterleave_pids(s.ctypes.data, pids1_disabled, out.ctypes.data)
+        return out
+
+    def bit_errors(self, coded, decoded, k, gens, puncture) -> int:
+        c = np.ascontiguousarray(coded, dtype=np.int8)
+        d = np.ascontiguousarray(decoded, dtype=np.uint8)
+        g = (ctypes.c_uint * 3)(*gens)
+        p = np.ascontiguousarray(puncture, dtype=np.uint8)
+        return self.lib.orc_bit_errors(c.ctypes.data, d.ctypes.data, k, d.size, g, p.ctypes.data, p.size)
+
     # ---- whole path -------------------------------------------------------------------
-    def run(self, iq: np.ndarray, taps: int = 0, chunk: int = 32768, fft_blocks: int = 4, p1_hook=None):
+    def run(self, iq: np.ndarray, taps: int = 0, chunk: int = 32768, fft_blocks: int = 4, p1_hook=None, mode: int = 0):
         iq = np.ascontiguousarray(iq)
-        s = self.lib.orc_open()
+        L = self.lib
+        fn = {0: (L.orc_open, L.orc_close, L.orc_set_taps, L.orc_set_p1_hook, L.orc_push_cu8, L.orc_push_cs16, L.orc_buf),
+              1: (L.orc_am_open, L.orc_am_close, L.orc_am_set_taps, L.orc_am_set_p1_hook, L.orc_am_push_cu8, L.orc_am_push_cs16, L.orc_am_buf)}[mode]
+        f_open, f_close, f_taps, f_hook, f_cu8, f_cs16, f_buf = fn
+        s = f_open()
         keep = None
         try:
-            self.lib.orc_set_taps(s, taps, fft_blocks)
+            f_taps(s, taps, fft_blocks)
             if p1_hook is not None:
                 keep = P1_HOOK(lambda user, bits, n: int(p1_hook(np.ctypeslib.as_array(bits, shape=(n,)))))
-                self.lib.orc_set_p1_hook(s, keep, None)
+                f_hook(s, keep, None)
             step = chunk if iq.dtype == np.uint8 else chunk
             for off in range(0, iq.size, step):
                 part = iq[off:off + step]
                 if iq.dtype == np.uint8:
-                    self.lib.orc_push_cu8(s, part.ctypes.data, part.size - part.size % 4)
+                    f_cu8(s, part.ctypes.data, part.size - part.size % 4)
                 else:
-                    self.lib.orc_push_cs16(s, part.ctypes.data, part.size - part.size % 2)
+                    f_cs16(s, part.ctypes.data, part.size - part.size % 2)
             bufs = []
             for which in range(3):
                 p = ctypes.c_void_p()
-                n = self.lib.orc_buf(s, which, ctypes.byref(p))
+                n = f_buf(s, which, ctypes.byref(p))
                 bufs.append(ctypes.string_at(p, n) if n else b"")
         finally:
-            self.lib.orc_close(s)
+            f_close(s)
         return (_ref.parse_log(bufs[0]), np.frombuffer(bufs[1], dtype=np.int16).reshape(-1, 2),
                 np.frombuffer(bufs[2], dtype=np.complex64))

@@ -20,7 +20,7 @@ enum {
 /* ordered log record kinds */
 enum {
     REC_BLOCK = 1, REC_STATE, REC_SOFT, REC_PIDS, REC_FRAME, REC_SYNC, REC_LOST_SYNC,
-    REC_MER, REC_BER, REC_HDC, REC_VIT
+    REC_MER, REC_BER, REC_HDC, REC_VIT, REC_AMSYM
 };
 
 typedef struct { uint8_t *p; size_t len, cap; } gbuf;
@@ -97,6 +97,19 @@ void __wrap_decode_push_pm(decode_t *st, const int8_t *sbit, unsigned int bc)
         log_rec(REC_SOFT, tmp, sizeof(tmp));
     }
     __real_decode_push_pm(st, sbit, bc);
+}
+
+void __real_decode_push_pl_pu_s_t(decode_t *st, const uint8_t *pl, const uint8_t *pu, const uint8_t *s, const uint8_t *t, unsigned int bc);
+void __wrap_decode_push_pl_pu_s_t(decode_t *st, const uint8_t *pl, const uint8_t *pu, const uint8_t *s, const uint8_t *t, unsigned int bc)
+{
+    if (g_taps & REFH_TAP_SOFT) {
+        const unsigned n = BLKSZ * PARTITION_WIDTH_AM;
+        uint8_t tmp[4 + 4 * BLKSZ * PARTITION_WIDTH_AM];
+        uint32_t b = bc; memcpy(tmp, &b, 4);
+        memcpy(tmp + 4, pl, n); memcpy(tmp + 4 + n, pu, n); memcpy(tmp + 4 + 2 * n, s, n); memcpy(tmp + 4 + 3 * n, t, n);
+        log_rec(REC_AMSYM, tmp, sizeof(tmp));
+    }
+    __real_decode_push_pl_pu_s_t(st, pl, pu, s, t, bc);
 }
 
 void __real_pids_frame_push(pids_t *st, const uint8_t *bits);

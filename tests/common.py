@@ -26,11 +26,19 @@ GOLDEN_CASES = {
 }
 
 
+# AM golden captures: name -> synth_am.am_ma1_capture kwargs
+GOLDEN_AM_CASES = {
+    "am_cs16_cfo3": dict(n_frames=11, seed=21, cfo_hz=3.0, offset=777, fmt="cs16"),
+    "am_cu8_cfo-150": dict(n_frames=10, seed=22, cfo_hz=-150.0, offset=40000, fmt="cu8"),
+}
+AM_FRAME_BITS = {0: 3750, 1: 24000}
+
+
 def sha256(a: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def compare_logs(expected, got, rtol: float = FLOAT_RTOL, skip_kinds=("hdc", "soft", "vit")):
+def compare_logs(expected, got, rtol: float = FLOAT_RTOL, skip_kinds=("hdc", "soft", "vit", "amsym")):
     """Ordered-record comparison: integers/bit arrays exact, floats within rtol (relative, floor 1).
     Returns a list of human-readable differences (empty = parity)."""
     exp = [r for r in expected if r[0] not in skip_kinds]
@@ -106,6 +114,59 @@ def arrays_to_log(a):
         elif kind == 9:
             log.append(("ber", {"cber": float(a["ber"][next(it["ber"])])}))
     return [r for r in log if r[0] != "state"]
+
+
+_KIND_CODE = {"block": 1, "state": 2, "pids": 4, "frame": 5, "sync": 6, "lost_sync": 7, "mer": 8, "ber": 9}
+
+
+def am_log_to_arrays(log):
+    """Storable view of an AM record log (frames of two lengths: P1 3750 bits, P3 24000 bits)."""
+    blocks = [v for k, v in log if k == "block"]
+    ikeys = ("state_before", "state_after", "samperr", "cfo", "keep", "bc", "psmi", "cfo_wait", "next_samperr")
+    fkeys = ("prev_angle", "phase_re", "phase_im", "next_angle")
+    frames = [v for k, v in log if k == "frame"]
+    return {
+        "block_int": np.array([[b[k] for k in ikeys] for b in blocks], dtype=np.int32).reshape(-1, len(ikeys)),
+        "block_float": np.array([[b[k] for k in fkeys] for b in blocks], dtype=np.float32).reshape(-1, len(fkeys)),
+        "sync": np.array([[v["freq_offset"], v["psmi"], v["pli"], v["hppi"], v["aabi"], v["rdbi"]] for k, v in log if k == "sync"], dtype=np.float64).reshape(-1, 6),
+        "ber": np.array([v["cber"] for k, v in log if k == "ber"], dtype=np.float32),
+        "pids": np.packbits(np.array([v["bits"] for k, v in log if k == "pids"], dtype=np.uint8).reshape(-1, 80), axis=1, bitorder="little"),
+        "frame_lc": np.array([v["lc"] for v in frames], dtype=np.uint8),
+        "p1": np.packbits(np.array([v["bits"] for v in frames if v["lc"] == 0], dtype=np.uint8).reshape(-1, 3750), axis=1, bitorder="little"),
+        "p3": np.packbits(np.array([v["bits"] for v in frames if v["lc"] == 1], dtype=np.uint8).reshape(-1, 24000), axis=1, bitorder="little"),
+        "kinds": np.array([_KIND_CODE[k] for k, _ in log if k in _KIND_CODE], dtype=np.uint8),
+    }
+
+
+def am_arrays_to_log(a):
+    ikeys = ("state_before", "state_after", "samperr", "cfo", "keep", "bc", "psmi", "cfo_wait", "next_samperr")
+    fkeys = ("prev_angle", "phase_re", "phase_im", "next_angle")
+    cnt = {k: 0 for k in ("block", "sync", "ber", "pids", "frame", "p1", "p3")}
+
+    def nxt(k):
+        cnt[k] += 1
+        return cnt[k] - 1
+    log = []
+    for kind in a["kinds"]:
+        if kind == 1:
+            i = nxt("block")
+            d = {k: int(v) for k, v in zip(ikeys, a["block_int"][i])}
+            d.update({k: float(v) for k, v in zip(fkeys, a["block_float"][i])})
+            log.append(("block", d))
+        elif kind == 4:
+            log.append(("pids", {"bits": np.unpackbits(a["pids"][nxt("pids")], bitorder="little")[:80]}))
+        elif kind == 5:
+            lc = int(a["frame_lc"][nxt("frame")])
+            key = "p1" if lc == 0 else "p3"
+            log.append(("frame", {"lc": lc, "bits": np.unpackbits(a[key][nxt(key)], bitorder="little")[:AM_FRAME_BITS[lc]]}))
+        elif kind == 6:
+            v = a["sync"][nxt("sync")]
+            log.append(("sync", {"freq_offset": float(v[0]), "psmi": int(v[1]), "pli": int(v[2]), "hppi": int(v[3]), "aabi": int(v[4]), "rdbi": int(v[5])}))
+        elif kind == 7:
+            log.append(("lost_sync", {}))
+        elif kind == 9:
+            log.append(("ber", {"cber": float(a["ber"][nxt("ber")])}))
+    return log
 
 
 def strip_states(log):

@@ -54,6 +54,10 @@ def captures():
 
     def get(name):
         if name not in cache:
-            cache[name] = synth.fm_mp1_capture(**common.GOLDEN_CASES[name])
+            if name in common.GOLDEN_AM_CASES:
+                from nrsc5_amd import synth_am
+                cache[name] = synth_am.am_ma1_capture(**common.GOLDEN_AM_CASES[name])
+            else:
+                cache[name] = synth.fm_mp1_capture(**common.GOLDEN_CASES[name])
         return cache[name]
     return get

@@ -14,7 +14,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 from tests import common  # noqa: E402
-from nrsc5_amd import synth  # noqa: E402
+from nrsc5_amd import synth, synth_am  # noqa: E402
 from oracle import ref  # noqa: E402
 
 
@@ -40,5 +40,31 @@ def main():
               f"sync {arrs['sync'].tolist()}, {os.path.getsize(os.path.join(HERE, name + '.npz'))} bytes")
 
 
+def main_am():
+    R = ref.RefLib(sse=False)
+    Rs = ref.RefLib(sse=True)
+    for name, kw in common.GOLDEN_AM_CASES.items():
+        cap = synth_am.am_ma1_capture(**kw)
+        log, q15, _ = R.run(cap.iq, mode=ref.MODE_AM, taps=ref.TAP_Q15 | ref.TAP_SOFT)
+        log_sse, _, _ = Rs.run(cap.iq, mode=ref.MODE_AM, taps=ref.TAP_SOFT)
+        assert not common.compare_logs(log, log_sse, rtol=0.0, skip_kinds=("hdc",)), "generic and SSE reference builds disagree"
+        arrs = common.am_log_to_arrays(log)
+        sym = [v for k, v in log if k == "amsym"]
+        arrs["sym_bc"] = np.array([v["bc"] for v in sym], dtype=np.int32)
+        arrs["sym_sha"] = np.array([common.sha256(np.concatenate([v["pl"], v["pu"], v["s"], v["t"]])) for v in sym])
+        arrs["q15_sha"] = np.array(common.sha256(q15))
+        arrs["q15_head"] = q15[:4096].copy()
+        arrs["iq_sha"] = np.array(common.sha256(cap.iq))
+        arrs["truth_p1"] = np.packbits(np.array(cap.p1_frames, dtype=np.uint8).reshape(-1, 3750), axis=1, bitorder="little")
+        arrs["truth_p3"] = np.packbits(np.array(cap.p3_frames, dtype=np.uint8).reshape(-1, 24000), axis=1, bitorder="little")
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrs)
+        print(f"{name}: {len(arrs['block_int'])} blocks, {arrs['p1'].shape[0]} P1 + {arrs['p3'].shape[0]} P3 frames, "
+              f"{arrs['pids'].shape[0]} PIDS, ber {arrs['ber'].tolist()}, sync {arrs['sync'].tolist()}, "
+              f"{os.path.getsize(os.path.join(HERE, name + '.npz'))} bytes")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) < 2 or sys.argv[1] == "fm":
+        main()
+    if len(sys.argv) < 2 or sys.argv[1] == "am":
+        main_am()
