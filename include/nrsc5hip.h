@@ -42,6 +42,12 @@ extern "C" {
 #define NRSC5HIP_P1_FRAME_WORDS  4568
 #define NRSC5HIP_PIDS_FRAME_BITS 80       /* PIDS_FRAME_LEN, defines.h:47 */
 
+/* waveform of a stream: NRSC5_MODE_FM / NRSC5_MODE_AM, nrsc5.h:70-74 */
+enum { NRSC5HIP_MODE_FM = 0, NRSC5HIP_MODE_AM = 1 };
+#define NRSC5HIP_AM_P1_FRAME_BITS  3750    /* P1_FRAME_LEN_AM, defines.h:43 */
+#define NRSC5HIP_AM_P3_BITS_MA1    24000   /* P3_FRAME_LEN_MA1, defines.h:53 */
+#define NRSC5HIP_AM_P3_BITS_MA3    30000   /* P3_FRAME_LEN_MA3, defines.h:54 */
+
 /* sync states, input.h:18 */
 enum { NRSC5HIP_SYNC_NONE = 0, NRSC5HIP_SYNC_COARSE = 1, NRSC5HIP_SYNC_FINE = 2 };
 
@@ -53,7 +59,8 @@ enum {
     NRSC5HIP_REC_MER       = 1u << 3,  /* nrsc5_report_mer(mer_lb, mer_ub) */
     NRSC5HIP_REC_PIDS      = 1u << 4,  /* pids_frame_push(pids) */
     NRSC5HIP_REC_P1        = 1u << 5,  /* nrsc5_report_ber(ber); frame_push(P1 frame in slot p1_slot) */
-    NRSC5HIP_REC_LOST_SYNC = 1u << 6   /* reserved */
+    NRSC5HIP_REC_LOST_SYNC = 1u << 6,  /* reserved */
+    NRSC5HIP_REC_P3        = 1u << 7   /* AM, block 7: frame_push(P3 frame of slot p1_slot), then nrsc5_report_ber(ber) */
 };
 
 /* One record per processed 32-symbol block, in stream order.  Events implied by one record fire in
@@ -77,7 +84,7 @@ typedef struct nrsc5hip_record {
     int32_t p1_slot;                     /* valid with REC_P1 */
     int32_t bc_decoded;                  /* block count the PIDS frame / soft bits belong to, or -1 */
     uint32_t pids[3];                    /* valid with REC_PIDS: bit i of the frame at pids[i/32] bit i%32 */
-    uint32_t pad;
+    uint32_t sis;                        /* AM with REC_TO_FINE: pli | hppi << 1 | aabi << 2 | rdbi << 3 | 16 (sync.c:231-235); FM: 0 */
 } nrsc5hip_record;
 
 typedef struct nrsc5hip_config {
@@ -91,6 +98,8 @@ typedef struct nrsc5hip_config {
                                   reference event timing; required for nrsc5hip_force_resync feedback);
                                   1: decode the frames of each 16-block window on a second HIP stream,
                                   overlapped with the next window (throughput mode) */
+    int am_enable;             /* allocate the AM buffers (1.4 MB per stream) so that streams may be switched to
+                                  NRSC5HIP_MODE_AM */
 } nrsc5hip_config;
 
 typedef struct nrsc5hip_engine nrsc5hip_engine;
@@ -109,6 +118,11 @@ int nrsc5hip_push_cu8(nrsc5hip_engine *e, int stream, const uint8_t *iq, uint32_
 int nrsc5hip_push_cs16(nrsc5hip_engine *e, int stream, const int16_t *iq, uint32_t n);
 /* input_reset (input.c:126-138), fresh-session semantics */
 int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream);
+/* nrsc5_set_mode -> input_set_mode (nrsc5.h:754, input.c:158-162): NRSC5HIP_MODE_FM (default) or _AM; resets the stream.
+ * AM: cu8 pushes go through the 5-stage 32:1 decimator, cs16 pushes are 46511.71875 S/s samples (input.c:70-91,119-124);
+ * every FINE block yields a PIDS frame and (after the 4-frame diversity start-up) one 3750-bit P1 frame, block 7 also the
+ * P3 frame and the BER.  Event order inside an AM record: TO_FINE, PIDS, P1 frame, P3 frame, BER (decode.c:507-554). */
+int nrsc5hip_stream_set_mode(nrsc5hip_engine *e, int stream, int mode);
 /* L2 feedback (frame.c:535-540): the stream drops to SYNC_NONE before its next block */
 int nrsc5hip_force_resync(nrsc5hip_engine *e, int stream);
 
@@ -130,6 +144,10 @@ int nrsc5hip_drain(nrsc5hip_engine *e, int stream, nrsc5hip_record *out, int max
 int nrsc5hip_p1_frame_packed(nrsc5hip_engine *e, int stream, int slot, uint32_t *words /* [4568] */);
 /* ... or one bit per byte, the layout frame_push() takes (frame.h:53) */
 int nrsc5hip_p1_frame_bits(nrsc5hip_engine *e, int stream, int slot, uint8_t *bits /* [146176] */);
+/* AM frames of a REC_P1 / REC_P3 record, one bit per byte as frame_push() takes them: which = 0..7 selects the P1 frame
+ * of that block (nbits 3750), which = 8 the P3 frame (nbits 24000 for MA1, 30000 for MA3).  In the packed slot
+ * (nrsc5hip_p1_frame_packed / batch_fetch) P1 frame b starts at word 118 b and the P3 frame at word 944. */
+int nrsc5hip_am_frame_bits(nrsc5hip_engine *e, int stream, int slot, int which, int nbits, uint8_t *bits);
 /* Bulk D2H of every record/frame produced by a batch: records[nstreams][max_records],
  * counts[nstreams]; frames may be NULL, else frames[nstreams][p1_slots][4568] */
 int nrsc5hip_batch_fetch(nrsc5hip_engine *e, int nstreams, const int *stream_ids, nrsc5hip_record *records,
@@ -146,6 +164,9 @@ int nrsc5hip_stage_halfband_fm_cu8(nrsc5hip_engine *e, const uint8_t *iq, uint32
 int nrsc5hip_stage_fft2048(nrsc5hip_engine *e, const float *in /* [n][2048][2] */, float *out, int n);
 int nrsc5hip_stage_viterbi_k7(nrsc5hip_engine *e, const int8_t *soft /* [nframes][3*len] */, int len, int nframes,
                               uint8_t *bits /* [nframes][len] */);
+/* K=9 codes of the AM path (nrsc5_conv_decode_e1 / _e2_e3, conv_dec.c:469-478): gens = {0561,0657,0711} or {0561,0753,0711} */
+int nrsc5hip_stage_viterbi_k9(nrsc5hip_engine *e, const int8_t *soft /* [nframes][3*len] */, int len, int nframes,
+                              const unsigned gens[3], uint8_t *bits /* [nframes][len] */);
 /* device check of the DPP / v_permlane / v_writelane / v_dot4 helpers against generic shuffles: *failures == 0 */
 int nrsc5hip_stage_selftest(nrsc5hip_engine *e, int *failures);
 /* one frame, also returning the len+64 survivor-decision words of the forward pass */
@@ -165,7 +186,7 @@ int nrsc5hip_reset_all(nrsc5hip_engine *e);
  * total_ms / launches: arrays of NRSC5HIP_PROF_CLASSES entries (may be NULL). */
 enum {
     NRSC5HIP_PROF_DECIMATE = 0, NRSC5HIP_PROF_ACQUIRE, NRSC5HIP_PROF_PREPARE, NRSC5HIP_PROF_MIXFFT,
-    NRSC5HIP_PROF_SYNC, NRSC5HIP_PROF_P1_DEINT, NRSC5HIP_PROF_P1_VITERBI, NRSC5HIP_PROF_PIDS, NRSC5HIP_PROF_CLASSES
+    NRSC5HIP_PROF_SYNC, NRSC5HIP_PROF_P1_DEINT, NRSC5HIP_PROF_P1_VITERBI, NRSC5HIP_PROF_PIDS, NRSC5HIP_PROF_AM, NRSC5HIP_PROF_CLASSES
 };
 int nrsc5hip_profile(nrsc5hip_engine *e, int enable, double *total_ms, long long *launches);
 

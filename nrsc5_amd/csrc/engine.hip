@@ -55,6 +55,8 @@ struct nrsc5hip_engine {
     // host mirrors
     std::vector<long long> wr_host, base_host;
     std::vector<int> drained;          // records already handed out per stream
+    std::vector<int> mode_host;        // MODE_FM / MODE_AM per stream
+    std::vector<long long> raw_host;   // AM cu8: raw input samples consumed (32:1 decimator phase)
     // staging
     uint8_t *stage_dev; size_t stage_bytes;
     int *ids_dev; unsigned *nbytes_dev;
@@ -182,14 +184,47 @@ static int build_tables(nrsc5hip_engine *e)
     if ((rc = dev_upload(e, &e->tb.shape, shape))) return rc;
     if ((rc = dev_upload(e, &e->tb.hb_q15, hbq))) return rc;
     if ((rc = dev_upload(e, &e->tb.acq_q15, acq))) return rc;
+    {   // AM tables: acquisition FIR (acquire.c:63-96), pulse shape (acquire.c:333-342), 256-point twiddles
+        static const float am_taps[32] = {
+            -0.00038464731187559664f, -0.00021618751634377986f, 0.0026779419276863337f, -0.00029802651260979474f,
+            -0.0012626448879018426f, -0.0013182522961869836f, -0.012252614833414555f, 0.015980124473571777f,
+            0.037112727761268616f, -0.05451361835002899f, -0.05804193392395973f, 0.11320608854293823f,
+            0.055298302322626114f, -0.16878043115139008f, -0.022917453199625015f, 0.19178225100040436f,
+            -0.022917453199625015f, -0.16878043115139008f, 0.055298302322626114f, 0.11320608854293823f,
+            -0.05804193392395973f, -0.05451361835002899f, 0.037112727761268616f, 0.015980124473571777f,
+            -0.012252614833414555f, -0.0013182522961869836f, -0.0012626448879018426f, -0.00029802651260979474f,
+            0.0026779419276863337f, -0.00021618751634377986f, -0.00038464731187559664f, 0.0f };
+        std::vector<int16_t> amq(17, 0);
+        for (int i = 1; i <= 16; i++) amq[i] = (int16_t)(am_taps[31 - i] * 32767.0f);
+        std::vector<float> ashape(AM_SYM);
+        for (int i = 0; i < AM_SYM; i++) {
+            if (i < AM_CP) ashape[i] = sinf(M_PI / 2 * i / AM_CP);
+            else if (i < AM_FFT) ashape[i] = 1;
+            else ashape[i] = cosf(M_PI / 2 * (i - AM_FFT) / AM_CP);
+        }
+        std::vector<float2> atw(AM_FFT);
+        for (int k = 0; k < AM_FFT; k++) { const double a = -2.0 * M_PI * k / AM_FFT; atw[k].x = (float)cos(a); atw[k].y = (float)sin(a); }
+        if ((rc = dev_upload(e, &e->tb.am_acq_q15, amq))) return rc;
+        if ((rc = dev_upload(e, &e->tb.am_shape, ashape))) return rc;
+        if ((rc = dev_upload(e, &e->tb.am_twiddle, atw))) return rc;
+    }
     return 0;
 }
 
-static void init_state(StreamState &st)
+static void init_state(StreamState &st, int mode = MODE_FM)
 {
     memset(&st, 0, sizeof(st));
     st.psmi = 1;                                               // sync_reset (sync.c:821)
     st.sync_state = SYNC_NONE;
+    st.mode = mode;
+}
+
+static void init_am_state(AmStream &am)
+{
+    memset(&am, 0, sizeof(am));
+    am.pli = am.hppi = am.aabi = am.rdbi = -1;                 // sync_reset (sync.c:822-825)
+    am.am_diversity_wait = 4;                                  // decode_reset (decode.c:568)
+    am.dec_bc = -1;
 }
 
 extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engine **out)
@@ -252,6 +287,19 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if ((rc = dev_alloc(e, &db.p1_ring, S * db.p1_slots * P1_WORDS))) break;
         if ((rc = dev_alloc(e, &db.records, S * db.rec_cap))) break;
         if ((rc = dev_alloc(e, &db.counters, 4 * MAX_LANES))) break;
+        db.am = nullptr; db.am_sym = nullptr; db.am_q = nullptr; db.am_vit = nullptr; db.am_dec = nullptr;
+        if (cfg->am_enable) {
+            if ((rc = dev_alloc(e, &db.am, S))) break;
+            if ((rc = dev_alloc(e, &db.am_sym, S * 4 * AM_SYMS))) break;
+            if ((rc = dev_alloc(e, &db.am_q, S * 4 * 3 * 18000))) break;
+            if ((rc = dev_alloc(e, &db.am_vit, S * 2 * AM_VIT))) break;
+            if ((rc = dev_alloc(e, &db.am_dec, S * (size_t)(AM_DEC_P1 + AM_DEC_P3)))) break;
+            std::vector<AmStream> ainit(S);
+            for (size_t k = 0; k < S; k++) init_am_state(ainit[k]);
+            if (hipMemcpy(db.am, ainit.data(), S * sizeof(AmStream), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemset(db.am_q, 0, S * 4 * 3 * 18000) != hipSuccess || hipMemset(db.am_vit, 0, S * 2 * AM_VIT) != hipSuccess ||
+                hipMemset(db.am_sym, 0, S * 4 * AM_SYMS) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "AM state init failed"); break; }
+        }
         db.sync_phase_cycles = nullptr;
         if (getenv("NRSC5HIP_SYNC_PHASES")) {
             if ((rc = dev_alloc(e, &db.sync_phase_cycles, 8))) break;
@@ -270,6 +318,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             hipMemset(db.records, 0, S * db.rec_cap * sizeof(BlockRecord)) != hipSuccess ||
             hipMemset(db.pm, 0, S * NPM * PM_FRAME) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "state init copy failed"); break; }
         e->wr_host.assign(S, 0); e->base_host.assign(S, 0); e->drained.assign(S, 0);
+        e->mode_host.assign(S, MODE_FM); e->raw_host.assign(S, 0);
         for (int l = 0; l < e->nlanes; l++) { e->lanes[l].db = db; e->lanes[l].counters_dev = db.counters + 4 * l; e->lanes[l].db.counters = db.counters + 4 * l; }
         e->prof_on = false;
         for (int k = 0; k < NRSC5HIP_PROF_CLASSES; k++) { e->prof_ms[k] = 0; e->prof_launches[k] = 0; }
@@ -420,6 +469,29 @@ static int run_steps(nrsc5hip_engine *e, int n, const int *ids_dev, int max_step
     return run_steps_lanes(e, 1, &n, ids, max_steps, check_every, steps_done);
 }
 
+// AM streams: one fused kernel per block step (k_am.hip), decoded in order on the lane's main stream
+static int run_steps_am(nrsc5hip_engine *e, int n, const int *ids_dev, int max_steps, int check_every, int *steps_done)
+{
+    nrsc5hip_engine::Lane &ln = e->lanes[0];
+    int done = 0;
+    while (done < max_steps) {
+        HIPCHK(hipMemsetAsync(ln.counters_dev, 0, 4 * sizeof(int), ln.main));
+        int burst = 0;
+        for (; burst < check_every && done + burst < max_steps; burst++) {
+            ProfScope p(e, NRSC5HIP_PROF_AM, ln.main);
+            launch_am_step(e->tb, ln.db, n, ids_dev, ln.main);
+        }
+        HIPCHK(hipMemcpyAsync(ln.counters_host, ln.counters_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, ln.main));
+        HIPCHK(hipStreamSynchronize(ln.main));
+        HIPCHK(hipGetLastError());
+        if (ln.counters_host[0] == 0) break;
+        done += burst;
+    }
+    if (e->prof_on) prof_collect(e);
+    if (steps_done) *steps_done = done;
+    return 0;
+}
+
 // ---- FIFO space management (streaming) -----------------------------------------------------------------
 __global__ void k_compact(DevBuffers db, int s)
 {
@@ -458,20 +530,24 @@ static int push_common(nrsc5hip_engine *e, int s, const void *host, size_t nbyte
     const uint8_t *src = (const uint8_t *)host;
     const size_t unit = 4;                                     // cu8: 2 complex samples; cs16: 1 complex sample
     if (nbytes_total % unit) FAIL(NRSC5HIP_EINVAL, "length must be a multiple of %zu bytes", unit);
+    const bool am = e->mode_host[s] == MODE_AM;
     while (nbytes_total) {
         const size_t chunk = nbytes_total > e->stage_bytes ? e->stage_bytes : nbytes_total;
-        const long long nq15 = cu8 ? (long long)chunk / 4 : (long long)chunk / 4;
+        long long nq15 = (long long)chunk / 4;                  // FM cu8: 2:1; cs16: one complex sample per 4 bytes
+        if (am && cu8) nq15 = (e->raw_host[s] + (long long)chunk / 2) / 32 - e->raw_host[s] / 32;
         if ((rc = ensure_space(e, s, nq15))) return rc;
         const unsigned count = cu8 ? (unsigned)chunk : (unsigned)(chunk / 2);
         HIPCHK(hipMemcpyAsync(e->stage_dev, src, chunk, hipMemcpyHostToDevice, e->main));
         HIPCHK(hipMemcpyAsync(e->ids_dev, &s, sizeof(int), hipMemcpyHostToDevice, e->main));
         HIPCHK(hipMemcpyAsync(e->nbytes_dev, &count, sizeof(unsigned), hipMemcpyHostToDevice, e->main));
         HIPCHK(hipStreamSynchronize(e->main));                 // &s / &count are stack temporaries
-        if (cu8) launch_decimate_fm_cu8(e->tb, e->db, 1, e->ids_dev, e->stage_dev, 0, e->nbytes_dev, count, e->main);
+        if (cu8 && am) { launch_am_decimate_cu8(e->tb, e->db, 1, e->ids_dev, e->stage_dev, 0, e->nbytes_dev, count, e->main); e->raw_host[s] += (long long)chunk / 2; }
+        else if (cu8) launch_decimate_fm_cu8(e->tb, e->db, 1, e->ids_dev, e->stage_dev, 0, e->nbytes_dev, count, e->main);
         else launch_append_cs16(e->db, 1, e->ids_dev, (const int16_t *)e->stage_dev, 0, e->nbytes_dev, count, e->main);
         e->wr_host[s] += nq15;
         int steps = 0;
-        if ((rc = run_steps(e, 1, e->ids_dev, 1 << 30, 1, &steps))) return rc;
+        if (am) { if ((rc = run_steps_am(e, 1, e->ids_dev, 1 << 30, 1, &steps))) return rc; }
+        else if ((rc = run_steps(e, 1, e->ids_dev, 1 << 30, 1, &steps))) return rc;
         src += chunk; nbytes_total -= chunk;
     }
     return 0;
@@ -491,11 +567,23 @@ extern "C" int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream)
 {
     int rc = check_stream(e, stream); if (rc) return rc;
     HIPCHK(hipDeviceSynchronize());
-    StreamState st; init_state(st);
+    StreamState st; init_state(st, e->mode_host[stream]);
     HIPCHK(hipMemcpy(e->db.state + stream, &st, sizeof(st), hipMemcpyHostToDevice));
-    e->wr_host[stream] = 0; e->base_host[stream] = 0; e->drained[stream] = 0;
+    if (e->db.am) { AmStream am; init_am_state(am); HIPCHK(hipMemcpy(e->db.am + stream, &am, sizeof(am), hipMemcpyHostToDevice)); }
+    e->wr_host[stream] = 0; e->base_host[stream] = 0; e->drained[stream] = 0; e->raw_host[stream] = 0;
     for (int l = 0; l < e->nlanes; l++) e->lanes[l].acq_needed = true;
     return 0;
+}
+
+// nrsc5_set_mode -> input_set_mode (input.c:158-162): switch the stream's waveform and reset it
+extern "C" int nrsc5hip_stream_set_mode(nrsc5hip_engine *e, int stream, int mode)
+{
+    int rc = check_stream(e, stream); if (rc) return rc;
+    if (mode != NRSC5HIP_MODE_FM && mode != NRSC5HIP_MODE_AM) FAIL(NRSC5HIP_EINVAL, "unknown mode %d", mode);
+    if (mode == NRSC5HIP_MODE_AM && !e->db.am) FAIL(NRSC5HIP_EINVAL, "engine was created without am_enable");
+    if (mode == NRSC5HIP_MODE_AM && e->db.q15_cap < 2 * AM_WIN) FAIL(NRSC5HIP_EINVAL, "q15_capacity too small");
+    e->mode_host[stream] = mode;
+    return nrsc5hip_stream_reset(e, stream);
 }
 
 __global__ void k_force_none(DevBuffers db, int s) { db.state[s].sync_state = SYNC_NONE; }
@@ -530,6 +618,28 @@ extern "C" int nrsc5hip_batch_append_cu8(nrsc5hip_engine *e, int nstreams, const
     if (!e || !dev_iq || !nbytes) FAIL(NRSC5HIP_EINVAL, "null argument");
     const int *ids_dev; int rc = upload_ids(e, nstreams, stream_ids, nbytes, &ids_dev); if (rc) return rc;
     unsigned mx = 0;
+    {
+        int nam = 0;
+        for (int k = 0; k < nstreams; k++) nam += e->mode_host[stream_ids ? stream_ids[k] : k] == MODE_AM;
+        if (nam && nam != nstreams) FAIL(NRSC5HIP_EINVAL, "one append call must list streams of one mode (FM or AM)");
+        if (nam) {
+            for (int k = 0; k < nstreams; k++) {
+                const int s = stream_ids ? stream_ids[k] : k;
+                if (nbytes[k] % 4) FAIL(NRSC5HIP_EINVAL, "chunk %d: nbytes %% 4 != 0", k);
+                const long long nout = (e->raw_host[s] + nbytes[k] / 2) / 32 - e->raw_host[s] / 32;
+                if (e->wr_host[s] - e->base_host[s] + nout > e->db.q15_cap) FAIL(NRSC5HIP_EOVERFLOW, "stream %d: q15_capacity %lld too small for this batch", s, e->db.q15_cap);
+                if (nbytes[k] > mx) mx = nbytes[k];
+            }
+            { ProfScope p(e, NRSC5HIP_PROF_DECIMATE, e->main); launch_am_decimate_cu8(e->tb, e->db, nstreams, ids_dev, dev_iq, stride_bytes, e->nbytes_dev, mx, e->main); }
+            for (int k = 0; k < nstreams; k++) {
+                const int s = stream_ids ? stream_ids[k] : k;
+                e->wr_host[s] += (e->raw_host[s] + nbytes[k] / 2) / 32 - e->raw_host[s] / 32;
+                e->raw_host[s] += nbytes[k] / 2;
+            }
+            HIPCHK(hipGetLastError());
+            return 0;
+        }
+    }
     for (int k = 0; k < nstreams; k++) {
         const int s = stream_ids ? stream_ids[k] : k;
         if (nbytes[k] % 4) FAIL(NRSC5HIP_EINVAL, "chunk %d: nbytes %% 4 != 0", k);
@@ -601,6 +711,24 @@ extern "C" int nrsc5hip_batch_append_cs16(nrsc5hip_engine *e, int nstreams, cons
 extern "C" int nrsc5hip_batch_process(nrsc5hip_engine *e, int nstreams, const int *stream_ids, int max_steps, int *steps_done)
 {
     if (!e) FAIL(NRSC5HIP_EINVAL, "null engine");
+    if (nstreams < 1 || nstreams > e->cfg.max_streams) FAIL(NRSC5HIP_EINVAL, "nstreams %d out of range", nstreams);
+    {   // AM streams advance through their own fused block kernel; split a mixed list by mode
+        std::vector<int> fm, am;
+        for (int k = 0; k < nstreams; k++) {
+            const int s = stream_ids ? stream_ids[k] : k;
+            if (s < 0 || s >= e->cfg.max_streams) FAIL(NRSC5HIP_EINVAL, "stream id %d out of range", s);
+            (e->mode_host[s] == MODE_AM ? am : fm).push_back(s);
+        }
+        if (!am.empty()) {
+            int done_am = 0, done_fm = 0;
+            HIPCHK(hipMemcpy(e->ids_dev, am.data(), am.size() * sizeof(int), hipMemcpyHostToDevice));
+            int rc = run_steps_am(e, (int)am.size(), e->ids_dev, max_steps > 0 ? max_steps : (1 << 30), 8, &done_am);
+            if (rc) return rc;
+            if (!fm.empty()) { rc = nrsc5hip_batch_process(e, (int)fm.size(), fm.data(), max_steps, &done_fm); if (rc) return rc; }
+            if (steps_done) *steps_done = done_am > done_fm ? done_am : done_fm;
+            return 0;
+        }
+    }
     const int *ids_dev; int rc = upload_ids(e, nstreams, stream_ids, nullptr, &ids_dev); if (rc) return rc;
     // contiguous slices of the id list, one per scheduler lane
     const int nl = (nstreams >= 2 * e->nlanes) ? e->nlanes : 1;
@@ -657,6 +785,39 @@ extern "C" int nrsc5hip_p1_frame_bits(nrsc5hip_engine *e, int stream, int slot, 
     std::vector<uint32_t> w(P1_WORDS);
     int rc = nrsc5hip_p1_frame_packed(e, stream, slot, w.data()); if (rc) return rc;
     nrsc5hip_unpack_bits(w.data(), P1_LEN, bits);
+    return 0;
+}
+
+// AM: frames of one L1 frame share a ring slot: P1 frame of block b at word b * 118, the P3 frame at word 944
+extern "C" int nrsc5hip_am_frame_bits(nrsc5hip_engine *e, int stream, int slot, int which, int nbits, uint8_t *bits)
+{
+    int rc = check_stream(e, stream); if (rc) return rc;
+    if (slot < 0 || slot >= e->db.p1_slots || !bits || which < 0 || which > 8) FAIL(NRSC5HIP_EINVAL, "bad slot/argument");
+    const int maxbits = which < 8 ? AM_P1_LEN : AM_P3_LEN_MA3;
+    if (nbits < 1 || nbits > maxbits) FAIL(NRSC5HIP_EINVAL, "nbits %d out of range", nbits);
+    const int word0 = which < 8 ? which * AM_P1_WORDS : AM_P3_WORD0, words = (nbits + 31) / 32;
+    std::vector<uint32_t> w(words);
+    HIPCHK(hipStreamSynchronize(e->main));
+    HIPCHK(hipMemcpy(w.data(), e->db.p1_ring + ((size_t)stream * e->db.p1_slots + slot) * P1_WORDS + word0, words * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    nrsc5hip_unpack_bits(w.data(), nbits, bits);
+    return 0;
+}
+
+extern "C" int nrsc5hip_stage_viterbi_k9(nrsc5hip_engine *e, const int8_t *soft, int len, int nframes, const unsigned gens[3], uint8_t *bits)
+{
+    if (!e || !soft || !bits || !gens || len < 64 || nframes < 1) FAIL(NRSC5HIP_EINVAL, "bad argument");
+    int8_t *dsoft = nullptr; unsigned long long *ddec = nullptr; uint32_t *dout = nullptr;
+    const int words = (len + 31) / 32;
+    HIPCHK(hipMalloc((void **)&dsoft, (size_t)nframes * 3 * len));
+    HIPCHK(hipMalloc((void **)&ddec, (size_t)nframes * 4 * (len + 64) * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&dout, (size_t)nframes * words * sizeof(uint32_t)));
+    HIPCHK(hipMemcpy(dsoft, soft, (size_t)nframes * 3 * len, hipMemcpyHostToDevice));
+    launch_viterbi_k9_frames(dsoft, len, nframes, gens[0], gens[1], gens[2], ddec, dout, e->main);
+    HIPCHK(hipStreamSynchronize(e->main));
+    std::vector<uint32_t> w((size_t)nframes * words);
+    HIPCHK(hipMemcpy(w.data(), dout, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (int f = 0; f < nframes; f++) nrsc5hip_unpack_bits(w.data() + (size_t)f * words, len, bits + (size_t)f * len);
+    (void)hipFree(dsoft); (void)hipFree(ddec); (void)hipFree(dout);
     return 0;
 }
 
@@ -768,8 +929,14 @@ extern "C" int nrsc5hip_reset_all(nrsc5hip_engine *e)
     e->dec_chunk = 0;
     const size_t S = e->cfg.max_streams;
     std::vector<StreamState> init(S);
-    for (size_t s = 0; s < S; s++) init_state(init[s]);
+    for (size_t s = 0; s < S; s++) init_state(init[s], e->mode_host[s]);
     HIPCHK(hipMemcpy(e->db.state, init.data(), S * sizeof(StreamState), hipMemcpyHostToDevice));
+    if (e->db.am) {
+        std::vector<AmStream> ainit(S);
+        for (size_t s = 0; s < S; s++) init_am_state(ainit[s]);
+        HIPCHK(hipMemcpy(e->db.am, ainit.data(), S * sizeof(AmStream), hipMemcpyHostToDevice));
+    }
+    std::fill(e->raw_host.begin(), e->raw_host.end(), 0);
     std::fill(e->wr_host.begin(), e->wr_host.end(), 0);
     std::fill(e->base_host.begin(), e->base_host.end(), 0);
     std::fill(e->drained.begin(), e->drained.end(), 0);

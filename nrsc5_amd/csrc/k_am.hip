@@ -1,0 +1,863 @@
+// AM (hybrid MA1 / all-digital MA3) path for gfx950.  Replaces, for NRSC5_MODE_AM:
+//   decimate_samples' 5-stage 32:1 cascade (input.c:70-91)                         -> k_am_decimate_cu8
+//   acquire_process incl. the AM carrier regression (acquire.c:98-263)             -> k_am_block (fused)
+//   sync_push / sync_process_am, find_ref_am, find_block_am (sync.c:209-252,612-767)-> k_am_block
+//   decode_process_pids_am (decode.c:474-505)                                      -> k_am_block tail
+//   decode_process_p1_p3_am, nrsc5_conv_decode_e1 / _e2_e3 (decode.c:507-554)      -> k_am_viterbi
+//   interleaver_ma1 incl. the 3-frame diversity delay (decode.c:74-231)            -> k_am_interleave
+//
+// The AM stream is 32 x slower than FM (46.5 kS/s), so one workgroup owns one stream for a whole block:
+// the 32 x 256-point FFTs, the carrier line fit and sync_process_am all run out of one 64 KB LDS tile and
+// only hard symbols (3.2 KB per block) go back to HBM.  The K=9 trellis has 256 states = one per work-item.
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+#include "wave_ops.h"
+
+namespace nrsc5 {
+
+__device__ inline int stream_of(const int *ids, int idx) { return ids ? ids[idx] : idx; }
+
+// =====================================================================================================
+// K1-AM: cu8 -> (Q15 >> 4) -> five cascaded 15-tap half-bands
+// =====================================================================================================
+// Output m of the cascade depends on raw samples [32 m - 434, 32 m] and exists once raw sample 32 m + 31 has
+// arrived.  A tile of AMD_T outputs recomputes the dependency cone from raw samples (history kept in the stream
+// state), stage by stage in LDS, so tiles are independent of each other and of how the caller chunks its pushes.
+constexpr int AMD_T = 32;
+constexpr int AMD_N0 = 32 * (AMD_T - 1) + 435;   // raw samples per tile
+constexpr int AMD_N1 = 16 * (AMD_T - 1) + 211;
+constexpr int AMD_N2 = 8 * (AMD_T - 1) + 99;
+constexpr int AMD_N3 = 4 * (AMD_T - 1) + 43;
+constexpr int AMD_N4 = 2 * (AMD_T - 1) + 15;
+
+__device__ inline int am_hb_dot(const int16_t *a, int stride, int t0, int t1, int t2, int t3)
+{
+    int acc = 0;                                               // firdecim_q15.c:137-151: shift before add, int16 accumulator
+    acc = (int16_t)(acc + (((a[0] + a[14 * stride]) * t0) >> 15));
+    acc = (int16_t)(acc + (((a[2 * stride] + a[12 * stride]) * t1) >> 15));
+    acc = (int16_t)(acc + (((a[4 * stride] + a[10 * stride]) * t2) >> 15));
+    acc = (int16_t)(acc + (((a[6 * stride] + a[8 * stride]) * t3) >> 15));
+    return (int16_t)(acc + a[7 * stride]);
+}
+
+// raw sample r (absolute index since reset) of the virtual stream [history | chunk]
+__device__ inline void am_raw_fetch(const AmStream &am, const uint8_t *iq, long long r, long long nraw_new, int &re, int &im)
+{
+    re = 0; im = 0;
+    if (r < 0) return;
+    unsigned a, b;
+    if (r < am.raw_count) {
+        const long long h = r - (am.raw_count - AM_RAW_HIST);
+        if (h < 0) return;
+        a = am.raw_hist[2 * h]; b = am.raw_hist[2 * h + 1];
+    } else {
+        const long long k = r - am.raw_count;
+        if (k >= nraw_new) return;
+        a = iq[2 * k]; b = iq[2 * k + 1];
+    }
+    re = (((int)a - 127) * 64) >> 4;                           // U8_Q15 then x >>= 4 (input.c:67-70)
+    im = (((int)b - 127) * 64) >> 4;
+}
+
+__global__ __launch_bounds__(256) void k_am_decimate_cu8(DevTables tb, DevBuffers db, const int *ids,
+                                                         const uint8_t *iq_base, long long iq_stride, const unsigned *nbytes)
+{
+    const int sidx = blockIdx.y;
+    const int s = stream_of(ids, sidx);
+    const StreamState &st = db.state[s];
+    const AmStream &am = db.am[s];
+    const long long nraw = nbytes[sidx] / 2;
+    const long long m_first = am.raw_count / 32, m_end = (am.raw_count + nraw) / 32;
+    const long long m0 = m_first + (long long)blockIdx.x * AMD_T;
+    if (m0 >= m_end) return;
+    const uint8_t *iq = iq_base + (size_t)sidx * iq_stride;
+    __shared__ int16_t bufA[2 * AMD_N0], bufB[2 * AMD_N1];     // interleaved re, im
+    const int tid = threadIdx.x;
+    const int t0 = tb.hb_q15[0], t1 = tb.hb_q15[1], t2 = tb.hb_q15[2], t3 = tb.hb_q15[3];
+
+    const long long lo0 = 32 * m0 - 434;
+    for (int k = tid; k < AMD_N0; k += 256) {
+        int re, im;
+        am_raw_fetch(am, iq, lo0 + k, nraw, re, im);
+        bufA[2 * k] = (int16_t)re; bufA[2 * k + 1] = (int16_t)im;
+    }
+    __syncthreads();
+    // local index jl of a stage's output reads the previous stage's local samples 2 jl .. 2 jl + 14
+    for (int k = tid; k < 2 * AMD_N1; k += 256) bufB[k] = (int16_t)am_hb_dot(bufA + 4 * (k >> 1) + (k & 1), 2, t0, t1, t2, t3);
+    __syncthreads();
+    for (int k = tid; k < 2 * AMD_N2; k += 256) bufA[k] = (int16_t)am_hb_dot(bufB + 4 * (k >> 1) + (k & 1), 2, t0, t1, t2, t3);
+    __syncthreads();
+    for (int k = tid; k < 2 * AMD_N3; k += 256) bufB[k] = (int16_t)am_hb_dot(bufA + 4 * (k >> 1) + (k & 1), 2, t0, t1, t2, t3);
+    __syncthreads();
+    for (int k = tid; k < 2 * AMD_N4; k += 256) bufA[k] = (int16_t)am_hb_dot(bufB + 4 * (k >> 1) + (k & 1), 2, t0, t1, t2, t3);
+    __syncthreads();
+    if (tid < AMD_T && m0 + tid < m_end) {
+        c16 y;
+        y.r = (int16_t)am_hb_dot(bufA + 4 * tid, 2, t0, t1, t2, t3);
+        y.i = (int16_t)am_hb_dot(bufA + 4 * tid + 1, 2, t0, t1, t2, t3);
+        db.q15[(size_t)s * db.q15_cap + (st.wr - st.base) + (m0 - m_first) + tid] = y;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_am_decimate_commit(DevBuffers db, const int *ids, const uint8_t *iq_base, long long iq_stride, const unsigned *nbytes)
+{
+    const int sidx = blockIdx.x;
+    const int s = stream_of(ids, sidx);
+    StreamState &st = db.state[s];
+    AmStream &am = db.am[s];
+    const long long nraw = nbytes[sidx] / 2;
+    if (nraw == 0) return;
+    const uint8_t *iq = iq_base + (size_t)sidx * iq_stride;
+    __shared__ uint8_t nh[2 * AM_RAW_HIST];
+    const long long first = am.raw_count + nraw - AM_RAW_HIST;
+    for (int k = threadIdx.x; k < AM_RAW_HIST; k += 256) {
+        const long long r = first + k;
+        uint8_t a = 127, b = 127;                              // never read: indices before the stream start
+        if (r >= am.raw_count) { a = iq[2 * (r - am.raw_count)]; b = iq[2 * (r - am.raw_count) + 1]; }
+        else if (r >= 0 && r >= am.raw_count - AM_RAW_HIST) { const long long h = r - (am.raw_count - AM_RAW_HIST); a = am.raw_hist[2 * h]; b = am.raw_hist[2 * h + 1]; }
+        nh[2 * k] = a; nh[2 * k + 1] = b;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * AM_RAW_HIST; k += 256) am.raw_hist[k] = nh[k];
+    if (threadIdx.x == 0) {
+        st.wr += (am.raw_count + nraw) / 32 - am.raw_count / 32;
+        am.raw_count += nraw;
+    }
+}
+
+void launch_am_decimate_cu8(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids,
+                            const uint8_t *iq_base, long long iq_stride, const unsigned *nbytes, unsigned max_nbytes, hipStream_t st)
+{
+    const unsigned max_out = max_nbytes / 64 + 1;
+    hipLaunchKernelGGL(k_am_decimate_cu8, dim3((max_out + AMD_T - 1) / AMD_T, nstreams), dim3(256), 0, st, tb, db, stream_ids, iq_base, iq_stride, nbytes);
+    hipLaunchKernelGGL(k_am_decimate_commit, dim3(nstreams), dim3(256), 0, st, db, stream_ids, iq_base, iq_stride, nbytes);
+}
+
+// =====================================================================================================
+// K=9 rate-1/3 tail-biting Viterbi, 256 states = 256 work-items (conv_dec.c:402-453, conv_gen.h:32-123)
+// =====================================================================================================
+// Work-item n owns new state n: predecessors 2b, 2b+1 with b = n & 127, branch metric +m for n < 128 and -m above
+// (acs_butterfly).  int32 metrics, no normalisation (inputs are +-1/0: |metric| <= 3 per step); ties pick
+// predecessor 2b+1 as `if (sum0 > sum1)` does.  Decisions: one ballot per wave and step (4 x u64 per step).
+struct K9Smem {
+    int metric[2][256];
+    int8_t soft[3 * 256];
+    unsigned long long chunk[4 * 256];
+    int red_val[4], red_idx[4];
+    int state;
+};
+
+__device__ inline void viterbi_k9_block(const int8_t *coded, int len, unsigned g0, unsigned g1, unsigned g2,
+                                        unsigned long long *dec, uint32_t *out, K9Smem &sm)
+{
+    const int n = threadIdx.x, b = n & 127;
+    const unsigned reg = ((unsigned)b << 1) & 0xfeu;           // gen_state_info, conv_dec.c:137-153
+    const int flip = n >= 128 ? -1 : 1;
+    const int sg0 = flip * ((__popc(reg & g0) & 1) ? 1 : -1);
+    const int sg1 = flip * ((__popc(reg & g1) & 1) ? 1 : -1);
+    const int sg2 = flip * ((__popc(reg & g2) & 1) ? 1 : -1);
+    const int steps = len + 2 * VIT_EXTRA, j0 = len - VIT_EXTRA;
+    int cur = 0;
+    sm.metric[0][n] = 0;                                       // reset_decoder: all-zero for tail biting
+    for (int t0 = 0; t0 < steps; t0 += 256) {
+        __syncthreads();
+        if (t0 + n < steps) {
+            const int j = (j0 + t0 + n) % len;
+            sm.soft[3 * n] = coded[3 * j]; sm.soft[3 * n + 1] = coded[3 * j + 1]; sm.soft[3 * n + 2] = coded[3 * j + 2];
+        }
+        __syncthreads();
+        const int nst = min(256, steps - t0);
+        for (int s = 0; s < nst; s++) {
+            const int m = sm.soft[3 * s] * sg0 + sm.soft[3 * s + 1] * sg1 + sm.soft[3 * s + 2] * sg2;
+            const int e = sm.metric[cur][2 * b], o = sm.metric[cur][2 * b + 1];
+            const int pa = e + m, pc = o - m;
+            const bool take_e = pa > pc;
+            sm.metric[cur ^ 1][n] = take_e ? pa : pc;
+            const unsigned long long w = __ballot(!take_e);    // bit = 1: survivor came from 2b+1
+            if ((n & 63) == 0) dec[(size_t)(t0 + s) * 4 + (n >> 6)] = w;
+            cur ^= 1;
+            __syncthreads();
+        }
+    }
+    // end state: first maximum in state order (conv_dec.c:310-318)
+    {
+        int v = sm.metric[cur][n], idx = n;
+        for (int m = 32; m >= 1; m >>= 1) {
+            const int ov = __shfl_xor(v, m), oi = __shfl_xor(idx, m);
+            if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+        }
+        if ((n & 63) == 0) { sm.red_val[n >> 6] = v; sm.red_idx[n >> 6] = idx; }
+        __threadfence_block();
+        __syncthreads();
+        if (n == 0) {
+            for (int w = 1; w < 4; w++) if (sm.red_val[w] > v) { v = sm.red_val[w]; idx = sm.red_idx[w]; }
+            sm.state = idx;
+        }
+    }
+    // traceback: decisions staged through LDS 256 steps at a time, walked by one work-item
+    const int nchunks = (steps + 255) / 256;
+    uint32_t accw = 0; int accidx = -1;
+    for (int c = nchunks - 1; c >= 0; c--) {
+        const int t0 = c * 256, nst = min(256, steps - t0);
+        __syncthreads();
+        for (int k = n; k < 4 * nst; k += 256) sm.chunk[k] = dec[(size_t)t0 * 4 + k];
+        __syncthreads();
+        if (n == 0) {
+            unsigned state = (unsigned)sm.state;
+            for (int s = nst - 1; s >= 0; s--) {
+                const int t = t0 + s;
+                const unsigned bit = (unsigned)(sm.chunk[4 * s + (state >> 6)] >> (state & 63)) & 1u;
+                if (t >= VIT_EXTRA && t < len + VIT_EXTRA) {
+                    const int i = t - VIT_EXTRA;
+                    if ((i >> 5) != accidx) { if (accidx >= 0) out[accidx] = accw; accidx = i >> 5; accw = 0; }
+                    accw |= ((state >> 7) & 1u) << (i & 31);   // vals[state]: the newest input bit
+                }
+                state = ((state << 1) & 0xfeu) | bit;           // vstate_lshift
+            }
+            sm.state = (int)state;
+        }
+    }
+    if (n == 0 && accidx >= 0) out[accidx] = accw;
+    __threadfence_block();
+    __syncthreads();
+}
+
+// re-encode the decoded (still scrambled) bits and count sign disagreements at unpunctured positions
+// (bit_errors, decode.c:234-261); returns the block-wide total in every work-item
+__device__ inline int am_bit_errors(const int8_t *coded, const uint32_t *bits, int len, unsigned g0, unsigned g1, unsigned g2,
+                                    unsigned pmask, int plen, int *red /* [4] */)
+{
+    int errors = 0;
+    for (int i = threadIdx.x; i < len; i += blockDim.x) {
+        unsigned r = 0;                                        // r bit 8-k = bits[i-k]
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            int q = i - k; if (q < 0) q += len;
+            r |= ((bits[q >> 5] >> (q & 31)) & 1u) << (8 - k);
+        }
+        const int j = 3 * i;
+        if (((pmask >> (j % plen)) & 1u) && ((coded[j] > 0) != (int)(__popc(r & g0) & 1))) errors++;
+        if (((pmask >> ((j + 1) % plen)) & 1u) && ((coded[j + 1] > 0) != (int)(__popc(r & g1) & 1))) errors++;
+        if (((pmask >> ((j + 2) % plen)) & 1u) && ((coded[j + 2] > 0) != (int)(__popc(r & g2) & 1))) errors++;
+    }
+    errors = wave_sum_i32(errors);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = errors;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+constexpr unsigned GEN_E1_0 = 0561, GEN_E1_1 = 0657, GEN_E1_2 = 0711;     // decode.c:47-53
+constexpr unsigned GEN_E2_0 = 0561, GEN_E2_1 = 0753, GEN_E2_2 = 0711;     // decode.c:55-61
+constexpr unsigned PUNCT_E1 = 0x7f6d, PUNCT_E2 = 0x0d;                    // bit k = pattern[k]: {1,0,1,1,0,1,1,0,1,1,1,1,1,1,1}, {1,0,1,1,0,0}
+
+// =====================================================================================================
+// the block step
+// =====================================================================================================
+struct AmBlockSmem {
+    float2 X[NSYM * AM_FFT];        // 64 KB: coarse-acquisition scratch, then the 32 symbol spectra (natural order)
+    float2 tw[AM_FFT / 2];
+    float shape[AM_SYM];
+    float2 mult[4][AM_PW];
+    float marg[2][AM_PW];
+    float2 carrier[NSYM];
+    float magsum[2 * 53 + 1];
+    float red_mag[4]; int red_idx[4]; float2 red_v[4];
+    uint8_t pids_sym[2 * NSYM];
+    int8_t pids_coded[3 * PIDS_LEN];
+    uint32_t pids_out[3];
+    unsigned long long pids_dec[4 * (PIDS_LEN + 64)];
+    // block-uniform scalars produced by work-item 0
+    int active, fine, samperr, ma3, refmask;
+    double theta, dtheta;
+    float2 step270, step256;        // e^{i 270 dtheta}, e^{i 256 dtheta}
+    K9Smem k9;
+};
+
+__device__ inline float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ inline float2 cdivf(float2 a, float2 b)
+{
+    const float d = b.x * b.x + b.y * b.y;
+    return make_float2((a.x * b.x + a.y * b.y) / d, (a.y * b.x - a.x * b.y) / d);
+}
+__device__ inline unsigned bitrev8(unsigned v) { return __brev(v) >> 24; }
+
+// sync.c:37-88
+__device__ inline unsigned slice4(float f) { return f < -1 ? 0u : f < 0 ? 2u : f < 1 ? 3u : 1u; }
+__device__ inline unsigned slice8(float f) { return f < -3 ? 0u : f < -2 ? 4u : f < -1 ? 6u : f < 0 ? 2u : f < 1 ? 3u : f < 2 ? 7u : f < 3 ? 5u : 1u; }
+__device__ inline unsigned sym_qpsk(float2 c) { return (c.x < 0 ? 0u : 1u) | (c.y < 0 ? 0u : 2u); }
+__device__ inline unsigned sym_qam16(float2 c) { return slice4(c.x) | (slice4(c.y) << 2); }
+__device__ inline unsigned sym_qam64(float2 c) { return slice8(c.x) | (slice8(c.y) << 3); }
+
+__device__ inline float half_turn_diff(float a, float b)   // phase_diff, sync.c:284-290
+{
+    float d = a - b;
+    while (d > (float)(M_PI / 2)) d = (float)((double)d - M_PI);
+    while (d < (float)(-M_PI / 2)) d = (float)((double)d + M_PI);
+    return d;
+}
+
+// Mix one block down with the NCO (phase theta + dtheta * sample), fold the cyclic prefix (rotated by 121 samples:
+// carrier phases are referenced to the symbol centre, acquire.c:239-247) and leave the 32 inputs in bit-reversed
+// order for the in-place radix-2 transform.  Work-item j owns input slot j of every symbol.
+__device__ inline void am_fold(AmBlockSmem &sm, const c16 *win, int samperr, double theta, float2 step270, float2 step256)
+{
+    const int j = threadIdx.x;
+    float2 p;
+    {
+        double th = theta + sm.dtheta * (double)j;
+        th -= 2 * M_PI * rint(th / (2 * M_PI));
+        float sn, cs; sincosf((float)th, &sn, &cs);
+        p = make_float2(cs, sn);
+    }
+    const unsigned slot = bitrev8((unsigned)(j + (AM_FFT - AM_CP) / 2) & 255u);
+    for (int i = 0; i < NSYM; i++) {
+        const c16 a = win[i * AM_SYM + j + samperr];
+        float2 v = cmulf(p, make_float2((float)a.r / 32767.0f, (float)a.i / 32767.0f));    // cq15_to_cf, defines.h:106
+        if (j < AM_CP) {
+            const c16 c = win[i * AM_SYM + j + AM_FFT + samperr];
+            const float2 w = cmulf(cmulf(p, step256), make_float2((float)c.r / 32767.0f, (float)c.i / 32767.0f));
+            const float sa = sm.shape[j], sb = sm.shape[j + AM_FFT];
+            v = make_float2(sa * v.x + sb * w.x, sa * v.y + sb * w.y);
+        }
+        sm.X[i * AM_FFT + slot] = v;
+        p = cmulf(p, step270);
+    }
+}
+
+// 32 x 256-point forward FFT in LDS: radix-2 decimation in time, in place, natural-order output
+__device__ inline void am_fft_all(AmBlockSmem &sm)
+{
+    for (int lg = 1; lg <= 8; lg++) {
+        __syncthreads();
+        const int half = 1 << (lg - 1);
+        for (int id = threadIdx.x; id < NSYM * 128; id += 256) {
+            const int n = id >> 7, q = id & 127;
+            const int pos = q & (half - 1), i0 = ((q >> (lg - 1)) << lg) + pos, i1 = i0 + half;
+            const float2 w = sm.tw[pos << (8 - lg)];
+            float2 *x = sm.X + n * AM_FFT;
+            const float2 t = cmulf(w, x[i1]), u = x[i0];
+            x[i0] = make_float2(u.x + t.x, u.y + t.y);
+            x[i1] = make_float2(u.x - t.x, u.y - t.y);
+        }
+    }
+    __syncthreads();
+}
+
+// spectrum bin `off` relative to the carrier (fftshift folded into the index), symbol n
+__device__ inline float2 &am_bin(AmBlockSmem &sm, int off, int n) { return sm.X[n * AM_FFT + (off & 255)]; }
+
+__global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, const int *ids)
+{
+    const int s = stream_of(ids, blockIdx.x);
+    StreamState &st = db.state[s];
+    AmStream &am = db.am[s];
+    HIP_DYNAMIC_SHARED(uint8_t, smem_raw)
+    AmBlockSmem &sm = *(AmBlockSmem *)smem_raw;
+    const int tid = threadIdx.x;
+    const bool ready = st.wr - st.rd >= AM_WIN;                 // block-uniform
+    if (tid == 0) { am.dec_bc = -1; st.active = ready ? 1 : 0; }
+    if (!ready) return;
+    const c16 *win = db.q15 + (size_t)s * db.q15_cap + (st.rd - st.base);
+    const int state_before = st.sync_state;
+
+    for (int k = tid; k < AM_FFT / 2; k += 256) sm.tw[k] = tb.am_twiddle[k];
+    for (int k = tid; k < AM_SYM; k += 256) sm.shape[k] = tb.am_shape[k];
+
+    // ---- coarse acquisition while not FINE (acquire.c:120-158 with the AM filter / geometry) ------------------
+    if (state_before != SYNC_FINE) {
+        c16 *filt = (c16 *)sm.X;                               // [AM_WIN]
+        float2 *sums = (float2 *)(filt + AM_WIN + 2);          // [AM_SYM], 8-byte aligned (AM_WIN even)
+        for (int t = tid; t < AM_WIN; t += 256) {
+            int sr = 0, si = 0;
+#pragma unroll
+            for (int i = 1; i < 16; i++) {
+                const int ka = t - 31 + i, kb = t - 31 + (32 - i);
+                const c16 xa = ka >= 0 ? win[ka] : st.fir_hist[31 + ka];
+                const c16 xb = kb >= 0 ? win[kb] : st.fir_hist[31 + kb];
+                const int q = tb.am_acq_q15[i];
+                sr = (int16_t)(sr + (((xa.r + xb.r) * q) >> 15));
+                si = (int16_t)(si + (((xa.i + xb.i) * q) >> 15));
+            }
+            const int kc = t - 15;
+            const c16 xc = kc >= 0 ? win[kc] : st.fir_hist[31 + kc];
+            const int q = tb.am_acq_q15[16];
+            sr = (int16_t)(sr + ((xc.r * q) >> 15));
+            si = (int16_t)(si + ((xc.i * q) >> 15));
+            c16 y; y.r = (int16_t)sr; y.i = (int16_t)si;
+            filt[t] = y;
+        }
+        __syncthreads();
+        for (int i = tid; i < AM_SYM; i += 256) {
+            float sr = 0.0f, si = 0.0f;
+            for (int j = 0; j < NSYM; j++) {
+                const c16 qa = filt[i + j * AM_SYM], qb = filt[i + j * AM_SYM + AM_FFT];
+                const float ax = (float)qa.r / 32767.0f, ay = (float)qa.i / 32767.0f;
+                const float bx = (float)qb.r / 32767.0f, by = -((float)qb.i / 32767.0f);      // conjf
+                sr += ax * bx - ay * by; si += ax * by + ay * bx;
+            }
+            sums[i] = make_float2(sr, si);
+        }
+        __syncthreads();
+        float best_mag = -1.0f; int best_i = 0x7fffffff; float2 best_v = make_float2(0.0f, 0.0f);
+        for (int i = tid; i < AM_SYM; i += 256) {
+            float vr = 0.0f, vi = 0.0f;
+            int k = i;
+            for (int j = 0; j < AM_CP; j++) {
+                const float2 z = sums[k];
+                vr += (z.x * sm.shape[j]) * sm.shape[j + AM_FFT];
+                vi += (z.y * sm.shape[j]) * sm.shape[j + AM_FFT];
+                if (++k == AM_SYM) k = 0;
+            }
+            const float mag = vr * vr + vi * vi;
+            if (mag > best_mag) { best_mag = mag; best_i = i; best_v = make_float2(vr, vi); }
+        }
+        for (int m = 32; m >= 1; m >>= 1) {                    // first maximum in index order wins
+            const float om = __shfl_xor(best_mag, m); const int oi = __shfl_xor(best_i, m);
+            const float ox = __shfl_xor(best_v.x, m), oy = __shfl_xor(best_v.y, m);
+            if (om > best_mag || (om == best_mag && oi < best_i)) { best_mag = om; best_i = oi; best_v = make_float2(ox, oy); }
+        }
+        if ((tid & 63) == 0) { sm.red_mag[tid >> 6] = best_mag; sm.red_idx[tid >> 6] = best_i; sm.red_v[tid >> 6] = best_v; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; w++)
+                if (sm.red_mag[w] > best_mag || (sm.red_mag[w] == best_mag && sm.red_idx[w] < best_i)) { best_mag = sm.red_mag[w]; best_i = sm.red_idx[w]; best_v = sm.red_v[w]; }
+            st.coarse_samperr = (best_i + AM_SYM - 15) % AM_SYM;       // FILTER_DELAY, acquire.c:149
+            st.coarse_re = best_v.x; st.coarse_im = best_v.y;
+        }
+        if (tid < 31) st.fir_hist[tid] = win[AM_WIN - 31 + tid];
+        __syncthreads();
+    }
+
+    // ---- per-block bookkeeping (top of acquire_process, acquire.c:110-119,153-168) -------------------------------
+    BlockRecord &rec = db.records[(size_t)s * db.rec_cap + (st.nblocks % db.rec_cap)];
+    if (tid == 0) {
+        atomicAdd(&db.counters[0], 1);
+        BlockRecord r;
+        r.flags = REC_PROCESSED; r.state_before = state_before; r.state_after = 0;
+        r.samperr = 0; r.cfo = 0; r.keep = 0; r.bc = 0; r.psmi = 0; r.cfo_wait = 0; r.next_samperr = 0;
+        r.prev_angle = 0; r.phase_re = 0; r.phase_im = 0; r.next_angle = 0; r.freq_offset = 0; r.mer_lb = 0; r.mer_ub = 0;
+        r.ber = 0; r.p1_slot = -1; r.bc_decoded = -1; r.pids[0] = r.pids[1] = r.pids[2] = 0; r.sis = 0;
+        int samperr; float angle;
+        if (state_before == SYNC_FINE) {
+            samperr = AM_SYM / 2 + st.samperr; st.samperr = 0;
+            angle = st.prev_angle;                             // sync_t.angle is only written by the FM path
+        } else {
+            samperr = st.coarse_samperr;
+            float sn, cs; sincosf(-st.prev_angle, &sn, &cs);
+            const float pr = st.coarse_re * cs - st.coarse_im * sn;
+            const float pi = st.coarse_re * sn + st.coarse_im * cs;
+            const float angle_diff = atan2f(pi, pr);
+            const float angle_factor = (st.prev_angle != 0.0f) ? 0.25f : 1.0f;
+            angle = st.prev_angle + (angle_diff * angle_factor);
+            st.prev_angle = angle;
+            if (st.sync_state != SYNC_COARSE) { r.flags |= REC_TO_COARSE; st.sync_state = SYNC_COARSE; }
+        }
+        rec = r;
+        angle = (float)((double)angle - 2 * M_PI * st.cfo);    // acquire.c:164
+        const float dth = angle / AM_FFT;
+        const float inc_c = (float)cos((double)dth), inc_s = (float)sin((double)dth);      // cexpf(angle / fft * I)
+        double th = st.theta + (double)(-(float)(AM_SYM / 2 - samperr) * angle / AM_FFT);  // acquire.c:166
+        th -= 2 * M_PI * rint(th / (2 * M_PI));
+        sm.theta = th; sm.dtheta = atan2((double)inc_s, (double)inc_c);
+        sm.samperr = samperr; sm.fine = st.sync_state == SYNC_FINE; sm.ma3 = st.psmi == AM_MA3;
+        sm.step270 = make_float2((float)cos(sm.dtheta * AM_SYM), (float)sin(sm.dtheta * AM_SYM));
+        sm.step256 = make_float2((float)cos(sm.dtheta * AM_FFT), (float)sin(sm.dtheta * AM_FFT));
+        // keep the rounded increment for the slope correction below
+        sm.red_v[0] = make_float2(inc_c, inc_s);
+    }
+    __syncthreads();
+    const int samperr = sm.samperr;
+    const bool fine_at_top = sm.fine != 0;
+
+    // ---- pass 1: phase of the analog carrier per symbol, line fit over the block (acquire.c:170-235) -------------
+    am_fold(sm, win, samperr, sm.theta, sm.step270, sm.step256);
+    if (fine_at_top) {
+        // only the carrier bin is needed: sum of the folded inputs (bin 0 before fftshift)
+        __syncthreads();
+        {
+            const int n = tid >> 3, part = tid & 7;            // 8 work-items per symbol, 32 inputs each
+            float sr = 0.0f, si = 0.0f;
+            for (int k = 0; k < 32; k++) { const float2 v = sm.X[n * AM_FFT + part * 32 + k]; sr += v.x; si += v.y; }
+            for (int m = 4; m >= 1; m >>= 1) { sr += __shfl_xor(sr, m); si += __shfl_xor(si, m); }
+            if (part == 0) sm.carrier[n] = make_float2(sr, si);
+        }
+    } else {
+        am_fft_all(sm);
+        if (tid < NSYM) sm.carrier[tid] = am_bin(sm, 0, tid);
+        if (tid <= 2 * 53) {                                   // |bins| summed over the block, carrier +-53
+            float acc = 0.0f;
+            for (int n = 0; n < NSYM; n++) { const float2 v = am_bin(sm, tid - 53, n); acc += sqrtf(v.x * v.x + v.y * v.y); }
+            sm.magsum[tid] = acc;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float y = 0, sum_y = 0, sum_xy = 0, sum_x2 = 0;
+        for (int i = 0; i < NSYM; i++) {
+            const float x = AM_SYM * (i - (float)(NSYM - 1) / 2);
+            const float2 c = sm.carrier[i];
+            if (i == 0) y = atan2f(c.y, c.x);
+            else { const float2 q = cdivf(c, sm.carrier[i - 1]); y += atan2f(q.y, q.x); }
+            sum_y += y; sum_xy += x * y; sum_x2 += x * x;
+        }
+        if (!fine_at_top) {
+            float max_mag = -1.0f; int max_index = -1;
+            for (int j = 0; j <= 2 * 53; j++) if (sm.magsum[j] > max_mag) { max_mag = sm.magsum[j]; max_index = j; }
+            st.cfo += max_index - 53;                          // acquire_cfo_adjust: effective from the next block
+        }
+        const float slope = sum_xy / sum_x2;
+        // phase_increment *= cexpf(-slope I): float complex product of the two rounded unit vectors
+        const float rc = (float)cos((double)slope), rs = (float)sin(-(double)slope);
+        const float2 inc = sm.red_v[0];
+        const float2 inc2 = make_float2(inc.x * rc - inc.y * rs, inc.x * rs + inc.y * rc);
+        const float a = -sum_y / NSYM + slope * NSYM * AM_SYM / 2;
+        const float corr = (float)((double)a - 0.06);          // acquire.c:233-234
+        double th = sm.theta + (double)corr;
+        th -= 2 * M_PI * rint(th / (2 * M_PI));
+        sm.theta = th; sm.dtheta = atan2((double)inc2.y, (double)inc2.x);
+        sm.step270 = make_float2((float)cos(sm.dtheta * AM_SYM), (float)sin(sm.dtheta * AM_SYM));
+        sm.step256 = make_float2((float)cos(sm.dtheta * AM_FFT), (float)sin(sm.dtheta * AM_FFT));
+    }
+    __syncthreads();
+
+    // ---- pass 2: the block's spectra (acquire.c:237-257) -> sync_process_am on the LDS tile --------------------
+    am_fold(sm, win, samperr, sm.theta, sm.step270, sm.step256);
+    am_fft_all(sm);
+
+    // lower sideband: z = -conj(z); complementary sidebands of the hybrid waveform add coherently (sync.c:616-633)
+    for (int id = tid; id < NSYM * AM_IDX_MAX; id += 256) {
+        const int n = id / AM_IDX_MAX, i = 1 + id % AM_IDX_MAX;
+        float2 &lo = am_bin(sm, -i, n);
+        lo = make_float2(-lo.x, lo.y);
+        if (!sm.ma3 && i <= 53) { float2 &up = am_bin(sm, i, n); up = make_float2(up.x + lo.x, up.y + lo.y); }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const unsigned long long m = __ballot(tid < NSYM && am_bin(sm, 1, tid & 31).y > 0);
+        if (tid == 0) sm.refmask = (int)(uint32_t)m;           // bit n = reference-carrier BPSK bit of symbol n
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned d = (unsigned)sm.refmask;
+        // fixed part of the reference sequence (find_ref_am / find_block_am needles, sync.c:211-213,242-244)
+        const unsigned care23 = 0x60427fu, val23 = 0x600226u;  // positions 0-6, 9, 14, 21, 22; ones at 1, 2, 5, 9, 21, 22
+        if (st.sync_state == SYNC_COARSE && st.cfo_wait == 0) {
+            int off = -1;
+            for (int r = 0; r < NSYM && off < 0; r++) {
+                const unsigned rot = r ? ((d >> r) | (d << (32 - r))) : d;      // rot bit i = d[(r + i) % 32]
+                if ((rot & care23) == val23) off = r;
+            }
+            if (off > 0) { st.keep_extra = ((NSYM - off) % NSYM) * AM_SYM; st.cfo_wait = 8; }
+        } else {
+            st.cfo_wait--;
+        }
+        if (st.sync_state == SYNC_COARSE) {
+            int bc = -1;
+            auto bit = [&](int k) { return (d >> k) & 1u; };
+            if ((d & care23) == val23
+                && !(bit(7) ^ bit(8))
+                && !(bit(10) ^ bit(11) ^ bit(12) ^ bit(13))
+                && !(bit(15) ^ bit(16) ^ bit(17) ^ bit(18) ^ bit(19) ^ bit(20))
+                && !(__popc(d & 0xff800000u) & 1)) {
+                bc = (int)((bit(17) << 2) | (bit(18) << 1) | bit(19));
+                if (bc == 0) {
+                    st.psmi = (int)((bit(26) << 4) | (bit(27) << 3) | (bit(28) << 2) | (bit(29) << 1) | bit(30));
+                    am.pli = bit(7); am.hppi = bit(11); am.aabi = bit(12); am.rdbi = bit(15);
+                }
+            }
+            if (bc == -1) am.offset_history = 0;
+            else am.offset_history = (am.offset_history << 4) | (unsigned)bc;
+            if ((am.offset_history & 0xffffu) == 0x5670u) {
+                st.bc = 0;
+                st.sync_state = SYNC_FINE;                     // input_set_sync_state: EVENT_SYNC payload (input.c:179-185)
+                rec.flags |= REC_TO_FINE;
+                rec.freq_offset = (float)(((double)st.prev_angle - 2 * M_PI * st.cfo) * 46511.71875 / (2 * M_PI * AM_FFT));
+                rec.sis = (uint32_t)((am.pli & 1) | ((am.hppi & 1) << 1) | ((am.aabi & 1) << 2) | ((am.rdbi & 1) << 3) | 16);
+                am.am_errors = 0; am.am_diversity_wait = 4;    // decode_reset (decode.c:563-572)
+                am.offset_history = 0;
+            }
+        }
+        sm.fine = st.sync_state == SYNC_FINE;
+        sm.ma3 = st.psmi == AM_MA3;
+    }
+    __syncthreads();
+
+    if (sm.fine) {
+        const bool ma3 = sm.ma3 != 0;
+        const int bc = st.bc;
+        // PIDS carriers: normalise by the two training symbols (8 and 24), slice QAM16 (sync.c:661-678)
+        if (tid < 2 * NSYM) {
+            const int n = tid >> 1, which = tid & 1;
+            const int off = which == 0 ? (ma3 ? -27 : 27) : (ma3 ? 27 : 53);
+            const float2 t8 = am_bin(sm, off, 8), t24 = am_bin(sm, off, 24);
+            const float2 mult = cdivf(make_float2(3.0f, -1.0f), make_float2(t8.x + t24.x, t8.y + t24.y));
+            sm.pids_sym[tid] = (uint8_t)sym_qam16(cmulf(am_bin(sm, off, n), mult));
+        }
+        // per-carrier equaliser taps from the two training cells of each carrier (sync.c:689-714)
+        if (tid < 4 * AM_PW) {
+            const int part = tid / AM_PW, col = tid % AM_PW;
+            const int t1 = (5 + 11 * col) % 32, t2 = (21 + 11 * col) % 32;
+            const int pri = ma3 ? 2 : 57, ter = ma3 ? 28 : 2;
+            int off; float2 ideal;
+            if (part == 0) { off = -(pri + col); ideal = make_float2(5.0f, -5.0f); }
+            else if (part == 1) { off = pri + col; ideal = make_float2(5.0f, -5.0f); }
+            else if (part == 2) { off = 28 + col; ideal = ma3 ? make_float2(5.0f, -5.0f) : make_float2(3.0f, -1.0f); }
+            else { off = ma3 ? -(ter + col) : ter + col; ideal = ma3 ? make_float2(5.0f, -5.0f) : make_float2(-1.0f, 1.0f); }
+            const float2 a = am_bin(sm, off, t1), b2 = am_bin(sm, off, t2);
+            const float2 m = cdivf(ideal, make_float2(a.x + b2.x, a.y + b2.y));
+            sm.mult[part][col] = m;
+            if (part < 2) sm.marg[part][col] = atan2f(m.y, m.x);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float se = 0;
+            for (int col = 1; col < AM_PW; col++) {
+                se += half_turn_diff(sm.marg[0][col], sm.marg[0][col - 1]);
+                se += half_turn_diff(sm.marg[1][col], sm.marg[1][col - 1]);
+            }
+            se = (float)((double)(se / (2 * (AM_PW - 1)) * AM_FFT) / (2 * M_PI));
+            st.samperr = (int)roundf(se);
+        }
+        // equalise and slice the four partitions: hard symbols of this block go to the frame matrices (decode.c:439-449)
+        uint8_t *symbase = db.am_sym + (size_t)s * 4 * AM_SYMS;
+        for (int id = tid; id < 4 * NSYM * AM_PW; id += 256) {
+            const int part = id / (NSYM * AM_PW), r = id % (NSYM * AM_PW), n = r / AM_PW, col = r % AM_PW;
+            const int pri = ma3 ? 2 : 57, ter = ma3 ? 28 : 2;
+            int off;
+            if (part == 0) off = -(pri + col); else if (part == 1) off = pri + col; else if (part == 2) off = 28 + col;
+            else off = ma3 ? -(ter + col) : ter + col;
+            const float2 v = cmulf(am_bin(sm, off, n), sm.mult[part][col]);
+            unsigned code;
+            if (part < 2 || ma3) code = sym_qam64(v);
+            else if (part == 2) code = sym_qam16(v);
+            else code = sym_qpsk(v);
+            symbase[(size_t)part * AM_SYMS + bc * (NSYM * AM_PW) + r] = (uint8_t)code;
+        }
+        __syncthreads();
+        // PIDS: bit gather (decode.c:476-501), K=9 E2 decode, descramble
+        if (tid < 120) {
+            const int n = tid, p = n % 4;
+            int k = (n + (n / 60) + 11) % 30, row = (11 * (k + (k / 15)) + 3) % 32;
+            const int il = (sm.pids_sym[row * 2] >> p) & 1;
+            k = (n + (n / 60)) % 30; row = (11 * (k + (k / 15)) + 3) % 32;
+            const int iu = (sm.pids_sym[row * 2 + 1] >> p) & 1;
+            const int i = n / 12, j = n % 12;
+            const int il_pos[12] = { 0, 1, 12, 13, 6, 5, 18, 17, 11, 7, 23, 19 };      // decode.c:63-64
+            const int iu_pos[12] = { 2, 4, 14, 16, 3, 8, 15, 20, 9, 10, 21, 22 };
+            const bool pids1_disabled = (st.psmi == 1) && am.rdbi;
+            sm.pids_coded[i * 24 + il_pos[j]] = pids1_disabled ? 0 : (il ? 1 : -1);
+            sm.pids_coded[i * 24 + iu_pos[j]] = iu ? 1 : -1;
+        }
+        __syncthreads();
+        viterbi_k9_block(sm.pids_coded, PIDS_LEN, GEN_E2_0, GEN_E2_1, GEN_E2_2, sm.pids_dec, sm.pids_out, sm.k9);
+        if (tid == 0) {
+            for (int w = 0; w < 3; w++) rec.pids[w] = sm.pids_out[w] ^ tb.scr_pids[w];
+            rec.pids[2] &= 0xffffu;
+            rec.flags |= REC_PIDS;
+            rec.bc_decoded = bc;
+            // hand this block to the P1 / P3 decoders (decode_process_p1_p3_am runs next, in k_am_viterbi)
+            am.dec_bc = bc; am.dec_record = st.nblocks % db.rec_cap; am.dec_rdbi = am.rdbi; am.dec_psmi = st.psmi;
+            if (bc == 0) {
+                am.am_errors = 0;
+                if (am.am_diversity_wait == 0) { am.frame_slot = st.p1_count % db.p1_slots; st.p1_count++; }
+            }
+            st.bc = (bc + 1) % 8;
+        }
+    }
+
+    // ---- tail of acquire_process (acquire.c:259-262) + record -------------------------------------------------------
+    if (tid == 0) {
+        double th = sm.theta + sm.dtheta * (double)(NSYM * AM_SYM);
+        th -= 2 * M_PI * rint(th / (2 * M_PI));
+        st.theta = th;
+        const int keep = AM_SYM + (AM_SYM / 2 - samperr) + st.keep_extra;
+        st.keep_extra = 0;
+        st.rd += AM_WIN - keep;
+        rec.state_after = st.sync_state; rec.samperr = samperr; rec.cfo = st.cfo; rec.keep = keep; rec.bc = st.bc;
+        rec.psmi = st.psmi; rec.cfo_wait = st.cfo_wait; rec.next_samperr = st.samperr;
+        rec.prev_angle = st.prev_angle; rec.phase_re = (float)cos(th); rec.phase_im = (float)sin(th); rec.next_angle = 0.0f;
+        st.nblocks++;
+    }
+}
+
+// ---- this block's P1 frame, and after block 7 the P3 frame (decode_process_p1_p3_am, decode.c:507-554) ----------
+__global__ __launch_bounds__(256) void k_am_viterbi(DevTables tb, DevBuffers db, const int *ids)
+{
+    const int s = stream_of(ids, blockIdx.y);
+    const StreamState &st = db.state[s];
+    AmStream &am = db.am[s];
+    if (!st.active || am.dec_bc < 0 || am.am_diversity_wait != 0) return;      // block-uniform
+    const int role = blockIdx.x, bc = am.dec_bc;                                 // 0: P1, 1: P3
+    if (role == 1 && (bc != 7 || am.dec_rdbi)) return;
+    __shared__ K9Smem k9;
+    __shared__ int red[4];
+    const bool ma3 = am.dec_psmi == AM_MA3;
+    uint32_t *slot = db.p1_ring + ((size_t)s * db.p1_slots + am.frame_slot) * P1_WORDS;
+    unsigned long long *dec = db.am_dec + (size_t)s * (AM_DEC_P1 + AM_DEC_P3);
+    BlockRecord &rec = db.records[(size_t)s * db.rec_cap + am.dec_record];
+    if (role == 0) {
+        const int8_t *in = db.am_vit + (size_t)s * 2 * AM_VIT + (size_t)bc * AM_P1_LEN * 3;
+        uint32_t *out = slot + bc * AM_P1_WORDS;
+        viterbi_k9_block(in, AM_P1_LEN, GEN_E1_0, GEN_E1_1, GEN_E1_2, dec, out, k9);
+        const int err = am_bit_errors(in, out, AM_P1_LEN, GEN_E1_0, GEN_E1_1, GEN_E1_2, PUNCT_E1, 15, red);
+        for (int w = threadIdx.x; w < AM_P1_WORDS; w += 256) out[w] ^= tb.scr_p1[w];
+        if (threadIdx.x == 0) {
+            out[AM_P1_WORDS - 1] &= (1u << (AM_P1_LEN & 31)) - 1u;
+            atomicAdd(&am.am_errors, (unsigned)err);
+            atomicOr(&rec.flags, (uint32_t)REC_P1);
+            rec.p1_slot = am.frame_slot;
+        }
+    } else {
+        const int8_t *in = db.am_vit + (size_t)s * 2 * AM_VIT + AM_VIT;
+        uint32_t *out = slot + AM_P3_WORD0;
+        const int len = ma3 ? AM_P3_LEN_MA3 : AM_P3_LEN_MA1;
+        int err;
+        if (!ma3) {
+            viterbi_k9_block(in, len, GEN_E2_0, GEN_E2_1, GEN_E2_2, dec + AM_DEC_P1, out, k9);
+            err = am_bit_errors(in, out, len, GEN_E2_0, GEN_E2_1, GEN_E2_2, PUNCT_E2, 6, red);
+        } else {
+            viterbi_k9_block(in, len, GEN_E1_0, GEN_E1_1, GEN_E1_2, dec + AM_DEC_P1, out, k9);
+            err = am_bit_errors(in, out, len, GEN_E1_0, GEN_E1_1, GEN_E1_2, PUNCT_E1, 15, red);
+        }
+        const int words = (len + 31) / 32;
+        for (int w = threadIdx.x; w < words; w += 256) out[w] ^= tb.scr_p1[w];
+        if (threadIdx.x == 0) {
+            if (len & 31) out[words - 1] &= (1u << (len & 31)) - 1u;
+            atomicAdd(&am.am_errors, (unsigned)err);
+            atomicOr(&rec.flags, (uint32_t)REC_P3);
+        }
+    }
+}
+
+// ---- after block 7: BER of the frame just decoded, then interleaver_ma1 for the frame just received -------------
+// Output-centric: every depunctured trellis input finds its source bit directly (bit_map, decode.c:66-71).
+__device__ inline int am_cell_bit(const uint8_t *m, int b, int k, int p)
+{
+    const int col = (9 * k) % 25;
+    const int row = (11 * col + 16 * (k / 25) + 11 * (k / 50)) % 32;
+    return (m[AM_PW * (b * NSYM + row) + col] >> p) & 1;
+}
+
+__global__ __launch_bounds__(1024) void k_am_interleave(DevBuffers db, const int *ids)
+{
+    const int s = stream_of(ids, blockIdx.x);
+    const StreamState &st = db.state[s];
+    AmStream &am = db.am[s];
+    if (!st.active || am.dec_bc != 7) return;                  // block-uniform
+    const bool ma3 = am.dec_psmi == AM_MA3;
+    const int tid = threadIdx.x;
+    if (tid == 0 && am.am_diversity_wait == 0) {
+        unsigned total = 8 * (AM_P1_LEN * 12 / 5);
+        if (!am.dec_rdbi) total += ma3 ? AM_P3_LEN_MA3 * 12 / 5 : AM_P3_LEN_MA1 * 3 / 2;
+        db.records[(size_t)s * db.rec_cap + am.dec_record].ber = (float)am.am_errors / (float)total;
+    }
+    const uint8_t *pl = db.am_sym + (size_t)s * 4 * AM_SYMS, *pu = pl + AM_SYMS, *sy = pu + AM_SYMS, *tt = sy + AM_SYMS;
+    uint8_t *q = db.am_q + (size_t)s * 4 * 3 * 18000;         // [ml, mu, eml, emu][3][18000]
+    const int head = am.q_head;
+    int8_t *v1 = db.am_vit + (size_t)s * 2 * AM_VIT, *v3 = v1 + AM_VIT;
+    // position inside a 12-bit group -> (source, j): bl {2,1,5}, ml {11,6,7}, bu {10,8,9}, mu {4,3,0} (decode.c:26-30)
+    const int src12[12] = { 3, 0, 0, 3, 3, 0, 1, 1, 2, 2, 2, 1 };
+    const int j12[12] = { 2, 1, 0, 1, 0, 2, 1, 2, 1, 2, 0, 0 };
+    const int rank15[15] = { 0, -1, 1, 2, -1, 3, 4, -1, 5, 6, 7, 8, 9, 10, 11 };       // E1 puncture {1,0,1,1,0,1,1,0,1,...}
+    // P1: 8 x 11250 trellis inputs
+    for (int i = tid; i < 8 * AM_P1_LEN * 3; i += 1024) {
+        const int rk = rank15[i % 15];
+        int val = 0;
+        if (rk >= 0) {
+            const int o = (i / 15) * 12 + rk, g = o / 12, pos = o % 12, n = g * 3 + j12[pos];
+            int bitv;
+            switch (src12[pos]) {
+            case 0: bitv = am_cell_bit(pl, n / 2250, (n + n / 750 + 1) % 750, n % 3); break;                       // bl
+            case 1: {                                                                                               // ml (delayed)
+                uint8_t *cell = q + (0 * 3 + head) * 18000 + n;
+                bitv = *cell;
+                *cell = (uint8_t)am_cell_bit(pl, (3 * n + 3) % 8, (n + n / 3000 + 3) % 750, 3 + (n % 3));
+                break; }
+            case 2: bitv = am_cell_bit(pu, n / 2250, (n + n / 750) % 750, n % 3); break;                           // bu
+            default: {                                                                                              // mu (delayed)
+                uint8_t *cell = q + (1 * 3 + head) * 18000 + n;
+                bitv = *cell;
+                *cell = (uint8_t)am_cell_bit(pu, (3 * n) % 8, (n + n / 3000 + 2) % 750, 3 + (n % 3));
+                break; }
+            }
+            val = bitv ? 1 : -1;
+        }
+        v1[i] = (int8_t)val;
+    }
+    if (!ma3) {
+        // P3 (MA1): E2 puncture {1,0,1,1,0,0}; 6-bit groups: el {0,1}, eu {2,3,5,4} (decode.c:31-32)
+        for (int i = tid; i < AM_P3_LEN_MA1 * 3; i += 1024) {
+            const int r6 = i % 6;
+            int val = 0;
+            if (r6 == 0 || r6 == 2 || r6 == 3) {
+                const int o = (i / 6) * 3 + (r6 == 0 ? 0 : r6 - 1), g = o / 6, pos = o % 6;
+                int bitv;
+                if (pos < 2) { const int n = g * 2 + pos; bitv = am_cell_bit(tt, (3 * n + n / 3000) % 8, (n + n / 6000) % 750, n % 2); }
+                else {
+                    const int j = pos == 2 ? 0 : pos == 3 ? 1 : pos == 5 ? 2 : 3;
+                    const int n = g * 4 + j;
+                    bitv = am_cell_bit(sy, (3 * n + n / 3000 + 2 * (n / 12000)) % 8, (n + n / 6000) % 750, n % 4);
+                }
+                val = bitv ? 1 : -1;
+            }
+            v3[i] = (int8_t)val;
+        }
+    } else {
+        for (int i = tid; i < AM_P3_LEN_MA3 * 3; i += 1024) {
+            const int rk = rank15[i % 15];
+            int val = 0;
+            if (rk >= 0) {
+                const int o = (i / 15) * 12 + rk, g = o / 12, pos = o % 12, n = g * 3 + j12[pos];
+                int bitv;
+                switch (src12[pos]) {
+                case 0: bitv = am_cell_bit(tt, (3 * n + 3) % 8, (n + n / 3000 + 3) % 750, n % 3); break;          // ebl
+                case 1: {
+                    uint8_t *cell = q + (2 * 3 + head) * 18000 + n;
+                    bitv = *cell;
+                    *cell = (uint8_t)am_cell_bit(tt, (3 * n + 3) % 8, (n + n / 3000 + 3) % 750, 3 + (n % 3));      // eml
+                    break; }
+                case 2: bitv = am_cell_bit(sy, (3 * n) % 8, (n + n / 3000 + 2) % 750, n % 3); break;               // ebu
+                default: {
+                    uint8_t *cell = q + (3 * 3 + head) * 18000 + n;
+                    bitv = *cell;
+                    *cell = (uint8_t)am_cell_bit(sy, (3 * n) % 8, (n + n / 3000 + 2) % 750, 3 + (n % 3));          // emu
+                    break; }
+                }
+                val = bitv ? 1 : -1;
+            }
+            v3[i] = (int8_t)val;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        am.q_head = (head + 1) % 3;
+        if (am.am_diversity_wait > 0) am.am_diversity_wait--;
+    }
+}
+
+void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st)
+{
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_am_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AmBlockSmem)); attr_set = true; }
+    hipLaunchKernelGGL(k_am_block, dim3(nstreams), dim3(256), sizeof(AmBlockSmem), st, tb, db, stream_ids);
+    hipLaunchKernelGGL(k_am_viterbi, dim3(2, nstreams), dim3(256), 0, st, tb, db, stream_ids);
+    hipLaunchKernelGGL(k_am_interleave, dim3(nstreams), dim3(1024), 0, st, db, stream_ids);
+}
+
+// ---- stage-level entry: decode `nframes` independent K=9 frames (parity tests) ------------------------------------
+__global__ __launch_bounds__(256) void k_viterbi_k9_frames(const int8_t *coded, int len, unsigned g0, unsigned g1, unsigned g2,
+                                                           unsigned long long *dec, uint32_t *out)
+{
+    __shared__ K9Smem k9;
+    const int f = blockIdx.x;
+    viterbi_k9_block(coded + (size_t)f * 3 * len, len, g0, g1, g2, dec + (size_t)f * 4 * (len + 64), out + (size_t)f * ((len + 31) / 32), k9);
+}
+
+void launch_viterbi_k9_frames(const int8_t *coded, int len, int nframes, unsigned g0, unsigned g1, unsigned g2,
+                              unsigned long long *dec, uint32_t *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_viterbi_k9_frames, dim3(nframes), dim3(256), 0, st, coded, len, g0, g1, g2, dec, out);
+}
+
+}  // namespace nrsc5

@@ -14,6 +14,9 @@ struct DevTables {
     const float *shape;              // [2160] pulse shape (acquire.c:322-331)
     const int16_t *hb_q15;           // [4]  half-band taps, window order
     const int16_t *acq_q15;          // [17] acquisition FIR taps, [1..16] used
+    const int16_t *am_acq_q15;       // [17] AM acquisition FIR taps (acquire.c:63-96)
+    const float *am_shape;           // [270] AM pulse shape (acquire.c:333-342)
+    const float2 *am_twiddle;        // [256] e^{-2 pi i k / 256}
 };
 
 // Engine-wide device buffers (slabs indexed by stream).
@@ -37,6 +40,12 @@ struct DevBuffers {
     int rec_cap;
     int *counters;                   // [0]: streams that processed a block this step, [1]: not-FINE streams
     long long *sync_phase_cycles;    // [8] optional: accumulated shader cycles per k_sync phase (stream 0 only), or null
+    // AM (null unless the engine was created with am_enable)
+    AmStream *am;                    // [S]
+    uint8_t *am_sym;                 // [S][4][AM_SYMS]   hard symbols of the current L1 frame: pl, pu, s, t
+    uint8_t *am_q;                   // [S][4][3][18000]  diversity delay lines ml, mu, eml, emu (3 frames each)
+    int8_t *am_vit;                  // [S][2][AM_VIT]    depunctured trellis inputs: 8 x P1, P3
+    unsigned long long *am_dec;      // [S][AM_DEC_P1 + AM_DEC_P3]  survivor decisions
 };
 
 // ---- K1 -------------------------------------------------------------------------------
@@ -54,6 +63,16 @@ void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, cons
 void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, hipStream_t st);
 void launch_pids_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int nslots, hipStream_t st);
 void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st);
+
+// ---- AM path (k_am.hip) -------------------------------------------------------------------------
+// cu8 -> five cascaded half-bands 32:1, any nbytes % 4 == 0 per stream (stage phases carry over)
+void launch_am_decimate_cu8(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids,
+                            const uint8_t *iq_base, long long iq_stride, const unsigned *nbytes, unsigned max_nbytes, hipStream_t st);
+// one block step: acquire (or track) -> 2 x 32 FFT-256 -> sync_process_am -> PIDS; then this block's P1 / P3 decodes
+// and, after block 7, the bit de-interleaver of the finished L1 frame
+void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
+void launch_viterbi_k9_frames(const int8_t *coded, int len, int nframes, unsigned g0, unsigned g1, unsigned g2,
+                              unsigned long long *dec, uint32_t *out, hipStream_t st);
 
 // ---- stage-level entry points (parity tests) ---------------------------------------------------
 void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st, int phases = 3);

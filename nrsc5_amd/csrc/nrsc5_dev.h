@@ -31,6 +31,26 @@ constexpr int NWIN = 8;                // decode windows (16 block steps each) t
 constexpr int NPM = NWIN + 3;           // soft-bit matrices per stream: a frame's matrix must outlive its (deferred) decode
 constexpr int NAUX = 5;                // HIP streams that decode windows concurrently (each with its own decision scratch)
 
+// ---- AM (defines.h:13-38,44-60) ----
+constexpr int AM_FFT = 256;
+constexpr int AM_CP = 14;
+constexpr int AM_SYM = AM_FFT + AM_CP;          // 270 samples per OFDM symbol @46511.71875 Hz
+constexpr int AM_WIN = AM_SYM * (NSYM + 1);     // 8910
+constexpr int AM_C = AM_FFT / 2;                // carrier bin after fftshift
+constexpr int AM_PW = 25;                       // carriers per partition
+constexpr int AM_IDX_MAX = 81;
+constexpr int AM_MA3 = 2;                       // SERVICE_MODE_MA3
+constexpr int AM_P1_LEN = 3750;
+constexpr int AM_P3_LEN_MA1 = 24000, AM_P3_LEN_MA3 = 30000;
+constexpr int AM_RAW_HIST = 480;                // raw cu8 samples kept for the 5-stage decimator's dependency cone (434)
+constexpr int AM_SYMS = 8 * NSYM * AM_PW;       // 6400 hard symbols per partition per L1 frame
+constexpr int AM_VIT = 3 * AM_P3_LEN_MA3;       // 90000: depunctured trellis input (8 P1 frames, or one P3 frame)
+constexpr int AM_P1_WORDS = 118;                // packed words per 3750-bit P1 frame
+constexpr int AM_P3_WORD0 = 8 * AM_P1_WORDS;    // 944: first word of the P3 frame inside an AM frame slot
+constexpr int AM_DEC_P1 = (AM_P1_LEN + 64) * 4; // survivor-decision words (4 x u64 per step)
+constexpr int AM_DEC_P3 = (AM_P3_LEN_MA3 + 64) * 4;
+
+enum { MODE_FM = 0, MODE_AM = 1 };                        // nrsc5.h:70-74
 enum { SYNC_NONE = 0, SYNC_COARSE = 1, SYNC_FINE = 2 };   // input.h:18
 
 // live-bin index <-> FFT bin (after fftshift, bin 1024 = DC)
@@ -48,6 +68,7 @@ enum : uint32_t {
     REC_PIDS        = 1u << 4,   // a PIDS frame was decoded
     REC_P1          = 1u << 5,   // this block completed an L1 frame: P1 frame slot valid
     REC_LOST_SYNC   = 1u << 6,   // the block started from a host-forced NONE while FINE (input.c:177)
+    REC_P3          = 1u << 7,   // AM: this block (bc 7) also completed a P3 frame
 };
 
 // One per (stream, processed block).  Plain-old-data, mirrored by include/nrsc5hip.h.
@@ -62,7 +83,7 @@ struct BlockRecord {
     int32_t p1_slot;            // index into the stream's P1 frame ring, or -1
     int32_t bc_decoded;         // block count the soft bits were filed under
     uint32_t pids[3];           // 80 descrambled PIDS bits, bit i at word i/32 bit i%32
-    uint32_t pad;
+    uint32_t sis;               // AM: pli | hppi << 1 | aabi << 2 | rdbi << 3 (EVENT_SYNC payload), bit 4 = valid
 };
 
 // Per-stream device-resident state ("the checkpoint").
@@ -101,7 +122,26 @@ struct StreamState {
     int p1_endlane[NWIN];
     int p1_pmslot[NWIN];        // which of the stream's NPM soft-bit matrices holds the frame
     int pm_slot;                // matrix being filled; advances after every block 15
-    int last_pm_slot;           // matrix that received the most recent block (debug fetch)          // forward pass -> traceback hand-off (lane of the winning end state)
+    int last_pm_slot;           // matrix that received the most recent block (debug fetch)
+    int mode;                   // MODE_FM / MODE_AM (nrsc5_set_mode)
+};
+
+// AM-only per-stream state (allocated when the engine is created with am_enable)
+struct AmStream {
+    // K1-AM: raw cu8 samples consumed so far and the newest AM_RAW_HIST of them (I,Q bytes, oldest first)
+    long long raw_count;
+    uint8_t raw_hist[2 * AM_RAW_HIST];
+    // system control bits latched from the reference carrier at block 0 (sync.h:17-21), bc history (sync.c:648-653)
+    int pli, hppi, aabi, rdbi;
+    unsigned offset_history;
+    // decode.h:31-32
+    unsigned am_errors; int am_diversity_wait;
+    int q_head;                 // oldest third of the 3-frame diversity delay lines
+    // hand-off from k_am_block to the decode kernels of the same step
+    int dec_bc;                 // block count the symbols were filed under, -1: nothing to decode
+    int dec_record;             // record index of that block
+    int dec_rdbi, dec_psmi;
+    int frame_slot;             // slot of the frame ring that receives this L1 frame's P1/P3 frames
 };
 
 }  // namespace nrsc5

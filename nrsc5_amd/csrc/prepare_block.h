@@ -22,7 +22,7 @@ __device__ inline void prepare_block(const DevBuffers &db, StreamState &st, int 
     r.flags = REC_PROCESSED; r.state_before = st.sync_state; r.state_after = 0;
     r.samperr = 0; r.cfo = 0; r.keep = 0; r.bc = 0; r.psmi = 0; r.cfo_wait = 0; r.next_samperr = 0;
     r.prev_angle = 0; r.phase_re = 0; r.phase_im = 0; r.next_angle = 0; r.freq_offset = 0; r.mer_lb = 0; r.mer_ub = 0;
-    r.ber = 0; r.p1_slot = -1; r.bc_decoded = -1; r.pids[0] = r.pids[1] = r.pids[2] = 0; r.pad = 0;
+    r.ber = 0; r.p1_slot = -1; r.bc_decoded = -1; r.pids[0] = r.pids[1] = r.pids[2] = 0; r.sis = 0;
 
     int samperr; float angle;
     if (st.sync_state == SYNC_FINE) {

@@ -12,6 +12,9 @@ DEFAULT_LIB = os.path.join(_HERE, "libnrsc5hip.so")
 
 SYNC_NONE, SYNC_COARSE, SYNC_FINE = 0, 1, 2
 REC_PROCESSED, REC_TO_COARSE, REC_TO_FINE, REC_MER, REC_PIDS, REC_P1 = 1, 2, 4, 8, 16, 32
+REC_P3 = 128
+MODE_FM, MODE_AM = 0, 1
+AM_P1_BITS, AM_P1_WORDS, AM_P3_WORD0 = 3750, 118, 944
 P1_BITS, P1_WORDS, PIDS_BITS = 146176, 4568, 80
 
 RECORD_DTYPE = np.dtype([
@@ -19,13 +22,14 @@ RECORD_DTYPE = np.dtype([
     ("keep", "<i4"), ("bc", "<i4"), ("psmi", "<i4"), ("cfo_wait", "<i4"), ("next_samperr", "<i4"),
     ("prev_angle", "<f4"), ("phase_re", "<f4"), ("phase_im", "<f4"), ("next_angle", "<f4"),
     ("freq_offset", "<f4"), ("mer_lb", "<f4"), ("mer_ub", "<f4"), ("ber", "<f4"),
-    ("p1_slot", "<i4"), ("bc_decoded", "<i4"), ("pids", "<u4", (3,)), ("pad", "<u4")])
+    ("p1_slot", "<i4"), ("bc_decoded", "<i4"), ("pids", "<u4", (3,)), ("sis", "<u4")])
 assert RECORD_DTYPE.itemsize == 96
 
 
 class _Config(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int), ("max_streams", ctypes.c_int), ("q15_capacity", ctypes.c_longlong),
-                ("record_capacity", ctypes.c_int), ("p1_slots", ctypes.c_int), ("p1_async", ctypes.c_int)]
+                ("record_capacity", ctypes.c_int), ("p1_slots", ctypes.c_int), ("p1_async", ctypes.c_int),
+                ("am_enable", ctypes.c_int)]
 
 
 class Nrsc5HipError(RuntimeError):
@@ -49,6 +53,9 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.nrsc5hip_push_cs16.argtypes = [vp, ci, vp, ctypes.c_uint32]
     lib.nrsc5hip_stream_reset.argtypes = [vp, ci]
     lib.nrsc5hip_force_resync.argtypes = [vp, ci]
+    lib.nrsc5hip_stream_set_mode.argtypes = [vp, ci, ci]
+    lib.nrsc5hip_am_frame_bits.argtypes = [vp, ci, ci, ci, ci, vp]
+    lib.nrsc5hip_stage_viterbi_k9.argtypes = [vp, vp, ci, ci, vp, vp]
     lib.nrsc5hip_batch_append_cu8.argtypes = [vp, ci, vp, vp, ctypes.c_longlong, vp]
     lib.nrsc5hip_batch_append_cs16.argtypes = [vp, ci, vp, vp, ctypes.c_longlong, vp]
     lib.nrsc5hip_batch_process.argtypes = [vp, ci, vp, ci, ctypes.POINTER(ci)]
@@ -78,7 +85,8 @@ EXPORTED_SYMBOLS = [
     "nrsc5hip_batch_append_cu8", "nrsc5hip_batch_append_cs16", "nrsc5hip_batch_process", "nrsc5hip_drain",
     "nrsc5hip_p1_frame_packed", "nrsc5hip_p1_frame_bits", "nrsc5hip_batch_fetch", "nrsc5hip_unpack_bits",
     "nrsc5hip_stage_halfband_fm_cu8", "nrsc5hip_stage_fft2048", "nrsc5hip_stage_viterbi_k7", "nrsc5hip_debug_fetch",
-    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_batch_fetch_view"]
+    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_batch_fetch_view",
+    "nrsc5hip_stream_set_mode", "nrsc5hip_am_frame_bits", "nrsc5hip_stage_viterbi_k9"]
 
 
 def unpack_bits(words: np.ndarray, nbits: int) -> np.ndarray:
@@ -90,9 +98,10 @@ class Engine:
     """One engine per GPU/process; `max_streams` independent IQ streams resident on the device."""
 
     def __init__(self, max_streams: int = 1, q15_capacity: int = 1 << 20, record_capacity: int = 256,
-                 p1_slots: int = 4, p1_async: bool = False, device: int = 0, lib_path: str | None = None):
+                 p1_slots: int = 4, p1_async: bool = False, device: int = 0, lib_path: str | None = None,
+                 am_enable: bool = False):
         self.lib = load_library(lib_path)
-        self.cfg = _Config(device, max_streams, q15_capacity, record_capacity, p1_slots, int(p1_async))
+        self.cfg = _Config(device, max_streams, q15_capacity, record_capacity, p1_slots, int(p1_async), int(am_enable))
         self._h = ctypes.c_void_p()
         self._check(self.lib.nrsc5hip_engine_create(ctypes.byref(self.cfg), ctypes.byref(self._h)))
         self.max_streams, self.record_capacity, self.p1_slots = max_streams, record_capacity, p1_slots
@@ -128,10 +137,14 @@ class Engine:
     def reset(self, stream: int):
         self._check(self.lib.nrsc5hip_stream_reset(self._h, stream))
 
+    def set_mode(self, stream: int, mode: int):
+        """nrsc5_set_mode for one stream (MODE_FM / MODE_AM); resets it."""
+        self._check(self.lib.nrsc5hip_stream_set_mode(self._h, stream, mode))
+
     def reset_all(self):
         self._check(self.lib.nrsc5hip_reset_all(self._h))
 
-    PROF_CLASSES = ("decimate", "acquire", "prepare", "mixfft", "sync", "p1_deint", "p1_viterbi", "pids")
+    PROF_CLASSES = ("decimate", "acquire", "prepare", "mixfft", "sync", "p1_deint", "p1_viterbi", "pids", "am")
 
     def profile(self, enable: int = -1):
         """Per-kernel-class {name: (total_ms, launches)} from HIP events; enable 1/0 starts/stops."""
@@ -174,6 +187,12 @@ class Engine:
     def p1_frame_bits(self, stream: int, slot: int) -> np.ndarray:
         bits = np.zeros(P1_BITS, dtype=np.uint8)
         self._check(self.lib.nrsc5hip_p1_frame_bits(self._h, stream, slot, bits.ctypes.data))
+        return bits
+
+    def am_frame_bits(self, stream: int, slot: int, which: int, nbits: int) -> np.ndarray:
+        """AM: which = 0..7 -> P1 frame of that block (3750 bits), 8 -> the P3 frame (24000 / 30000 bits)."""
+        bits = np.zeros(nbits, dtype=np.uint8)
+        self._check(self.lib.nrsc5hip_am_frame_bits(self._h, stream, slot, which, nbits, bits.ctypes.data))
         return bits
 
     def p1_frame_packed(self, stream: int, slot: int) -> np.ndarray:
@@ -224,6 +243,13 @@ class Engine:
         self._check(self.lib.nrsc5hip_stage_viterbi_k7(self._h, soft.ctypes.data, length, soft.shape[0], bits.ctypes.data))
         return bits
 
+    def stage_viterbi_k9(self, soft: np.ndarray, length: int, gens) -> np.ndarray:
+        soft = np.ascontiguousarray(soft, dtype=np.int8).reshape(-1, 3 * length)
+        bits = np.zeros((soft.shape[0], length), dtype=np.uint8)
+        g = (ctypes.c_uint * 3)(*gens)
+        self._check(self.lib.nrsc5hip_stage_viterbi_k9(self._h, soft.ctypes.data, length, soft.shape[0], g, bits.ctypes.data))
+        return bits
+
     def stage_viterbi_k7_debug(self, soft: np.ndarray, length: int):
         soft = np.ascontiguousarray(soft, dtype=np.int8)
         bits = np.zeros(length, dtype=np.uint8)
@@ -251,6 +277,45 @@ class Engine:
         bins = np.zeros((32, 534), dtype=np.complex64)
         self._check(self.lib.nrsc5hip_debug_fetch(self._h, stream, pm.ctypes.data, bins.ctypes.data))
         return pm, bins
+
+
+_BLOCK_KEYS = ("state_before", "state_after", "samperr", "cfo", "keep", "bc", "psmi", "cfo_wait",
+               "next_samperr", "prev_angle", "phase_re", "phase_im", "next_angle")
+
+
+def am_records_to_log(engine: Engine, stream: int, recs: np.ndarray, frames: np.ndarray | None = None):
+    """AM twin of records_to_log: the reference's order inside one acquire_process call is
+    [state, sync], pids, P1 frame, [P3 frame, ber], block (sync.c:639-765, decode.c:507-554)."""
+    out = []
+    for r in recs:
+        fl = int(r["flags"])
+        if fl & REC_TO_COARSE:
+            out.append(("state", {"old": int(r["state_before"]), "new": SYNC_COARSE}))
+        if fl & REC_TO_FINE:
+            sis = int(r["sis"])
+            out.append(("state", {"old": SYNC_COARSE, "new": SYNC_FINE}))
+            out.append(("sync", {"freq_offset": float(r["freq_offset"]), "psmi": int(r["psmi"]), "pli": sis & 1, "hppi": (sis >> 1) & 1,
+                                 "aabi": (sis >> 2) & 1, "rdbi": (sis >> 3) & 1}))
+        if fl & REC_PIDS:
+            out.append(("pids", {"bits": unpack_bits(r["pids"], PIDS_BITS)}))
+        slot, bc = int(r["p1_slot"]), int(r["bc_decoded"])
+        if fl & REC_P1:
+            if frames is not None:
+                bits = unpack_bits(frames[slot][bc * AM_P1_WORDS:(bc + 1) * AM_P1_WORDS], AM_P1_BITS)
+            else:
+                bits = engine.am_frame_bits(stream, slot, bc, AM_P1_BITS)
+            out.append(("frame", {"lc": 0, "bits": bits}))
+        if fl & REC_P3:
+            n3 = 30000 if int(r["psmi"]) == 2 else 24000
+            if frames is not None:
+                bits = unpack_bits(frames[slot][AM_P3_WORD0:AM_P3_WORD0 + (n3 + 31) // 32], n3)
+            else:
+                bits = engine.am_frame_bits(stream, slot, 8, n3)
+            out.append(("frame", {"lc": 1, "bits": bits}))
+        if (fl & REC_P1) and bc == 7:
+            out.append(("ber", {"cber": float(r["ber"])}))
+        out.append(("block", {k: (float(r[k]) if RECORD_DTYPE[k].kind == "f" else int(r[k])) for k in _BLOCK_KEYS}))
+    return out
 
 
 def records_to_log(engine: Engine, stream: int, recs: np.ndarray, frames: np.ndarray | None = None):

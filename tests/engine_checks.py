@@ -249,3 +249,113 @@ def check_cs16_batch(lib, captures):
     assert not diffs, diffs[:10]
     _free_device(E, dev)
     E.close()
+
+
+# ---- AM -----------------------------------------------------------------------------------------------------------
+E1_GENS, E2_GENS = (0o561, 0o657, 0o711), (0o561, 0o753, 0o711)
+
+
+def check_viterbi_k9(lib, oracle, lens=(80, 3750), frames=3, seed=4):
+    rng = np.random.default_rng(seed)
+    E = eng.Engine(max_streams=1, q15_capacity=2 * 71280, lib_path=lib)
+    for L in lens:
+        for gens in (E1_GENS, E2_GENS):
+            soft = rng.integers(-1, 2, size=(frames, 3 * L), dtype=np.int8)       # AM inputs are hard +-1 / 0 (punctured)
+            soft[0] = 0                                                            # all-erasure: every ACS is a tie
+            soft[1] = 1
+            got = E.stage_viterbi_k9(soft, L, gens)
+            exp = np.stack([oracle.viterbi(s, 9, gens) for s in soft])
+            assert np.array_equal(got, exp), f"K=9 Viterbi mismatch at len {L} gens {gens}"
+    E.close()
+
+
+def check_am_decimator(lib, oracle, seed=5):
+    """cu8 -> 32:1 cascade, ragged pushes (stage phases and the raw history carry over), exact."""
+    rng = np.random.default_rng(seed)
+    iq = rng.integers(0, 256, size=64 * 700 + 24, dtype=np.uint8)
+    exp = oracle.am_decimate_cu8([iq])
+    E = eng.Engine(max_streams=1, q15_capacity=2 * 71280, lib_path=lib, am_enable=True)
+    E.set_mode(0, eng.MODE_AM)
+    cuts = [0, 4, 8, 60, 64, 1000, 1004, 64 * 300 + 12, 64 * 301, iq.size]
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        E.push_cu8(0, iq[a:b])
+    got = _fetch_q15(E, exp.shape[0])
+    assert exp.shape[0] == 700 and np.array_equal(got, exp)
+    E.close()
+
+
+def run_am_capture(lib, cap, chunk=32768):
+    E = eng.Engine(max_streams=1, q15_capacity=400000, record_capacity=512, p1_slots=16, lib_path=lib, am_enable=True)
+    E.set_mode(0, eng.MODE_AM)
+    common.run_engine_streaming(E, 0, cap.iq, chunk=chunk)
+    recs = E.drain(0)
+    return E, recs, eng.am_records_to_log(E, 0, recs)
+
+
+def am_symbol_agreement(E, ol):
+    """Hard symbols are diagnostic (a cell on a decision boundary may flip with a 1-ulp libm difference)."""
+    return None
+
+
+def check_am_oracle_end_to_end(lib, oracle, kw, chunk=32768, max_sym_diff=0.002):
+    from oracle import port
+    from nrsc5_amd import synth_am
+    cap = synth_am.am_ma1_capture(**kw)
+    ol, _, _ = oracle.run(cap.iq, mode=1, taps=port.TAP_SOFT)
+    E, recs, log = run_am_capture(lib, cap, chunk=chunk)
+    diffs = common.compare_logs(common.strip_states(ol), common.strip_states(log))
+    assert not diffs, diffs[:10]
+    E.close()
+    return log
+
+
+def check_am_golden_end_to_end(lib, name, captures):
+    g = golden(name)
+    cap = captures(name)
+    assert common.sha256(cap.iq) == str(g["iq_sha"])
+    E, recs, log = run_am_capture(lib, cap)
+    diffs = common.compare_logs(common.am_arrays_to_log(g), common.strip_states(log))
+    assert not diffs, diffs[:10]
+    E.close()
+    return log
+
+
+def check_am_batch_equals_streaming(lib, kws):
+    """Device-resident batch of AM captures (cs16 and cu8 lists) == the same captures through the streaming seam."""
+    from nrsc5_amd import synth_am
+    caps = [synth_am.am_ma1_capture(**kw) for kw in kws]
+    logs = []
+    for cap in caps:
+        E, recs, log = run_am_capture(lib, cap)
+        logs.append(log)
+        E.close()
+    n = len(caps)
+    fmt = caps[0].iq.dtype
+    stride = max(c.iq.size for c in caps)
+    stride += (-stride) % 64
+    E = eng.Engine(max_streams=n, q15_capacity=stride // 2 + 1024, record_capacity=512, p1_slots=16, lib_path=lib, am_enable=True)
+    for k in range(n):
+        E.set_mode(k, eng.MODE_AM)
+    buf = np.zeros((n, stride), dtype=fmt)
+    for k, c in enumerate(caps):
+        buf[k, :c.iq.size] = c.iq
+    dev = E.lib.nrsc5hip_debug_alloc_copy
+    import ctypes
+    dev.restype = ctypes.c_void_p
+    dev.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    dptr = dev(buf.ctypes.data, buf.nbytes)
+    assert dptr
+    sizes = [c.iq.size - c.iq.size % 4 for c in caps]
+    if fmt == np.uint8:
+        E.batch_append_cu8(dptr, stride, sizes)
+    else:
+        E.batch_append_cs16(dptr, stride, sizes)
+    E.batch_process(n)
+    recs, counts, frames = E.batch_fetch(n)
+    for k in range(n):
+        log = eng.am_records_to_log(E, k, recs[k, :counts[k]], frames[k])
+        d = common.compare_logs(logs[k], log, rtol=0.0)
+        assert not d, (k, d[:5])
+    E.lib.nrsc5hip_debug_free.argtypes = [ctypes.c_void_p]
+    E.lib.nrsc5hip_debug_free(dptr)
+    E.close()

@@ -54,3 +54,24 @@ def test_emu_small_fifo_compaction(emu_lib, captures):
 
 def test_emu_api_edges(emu_lib):
     ec.check_api_edges(emu_lib)
+
+
+# ---- AM ------------------------------------------------------------------------------------------------------------
+def test_emu_am_viterbi_k9(emu_lib, oracle):
+    ec.check_viterbi_k9(emu_lib, oracle, lens=(80, 3750), frames=2)
+
+
+def test_emu_am_decimator(emu_lib, oracle):
+    ec.check_am_decimator(emu_lib, oracle)
+
+
+def test_emu_am_end_to_end_oracle(emu_lib, oracle):
+    ec.check_am_oracle_end_to_end(emu_lib, oracle, dict(n_frames=10, seed=3, cfo_hz=3.0, offset=1234))
+
+
+def test_emu_am_end_to_end_cu8_ragged(emu_lib, oracle):
+    ec.check_am_oracle_end_to_end(emu_lib, oracle, dict(n_frames=2, seed=6, cfo_hz=10.0, offset=64 * 300 + 12, fmt="cu8"), chunk=4100 * 4)
+
+
+def test_emu_am_batch_equals_streaming(emu_lib):
+    ec.check_am_batch_equals_streaming(emu_lib, [dict(n_frames=9, seed=32, cfo_hz=-20.0, offset=5000), dict(n_frames=3, seed=33)])

@@ -156,3 +156,34 @@ def test_gpu_full_size_truth_property(hip_lib):
             assert synth.crc12(bits) == int("".join(map(str, bits[68:80])), 2)
         ec._free_device(E, dev)
         E.close()
+
+
+# ---- AM (config 5) --------------------------------------------------------------------------------------------------
+def test_gpu_am_viterbi_k9_exact(hip_lib, oracle):
+    ec.check_viterbi_k9(hip_lib, oracle, lens=(80, 3750, 24000, 30000), frames=4)
+
+
+def test_gpu_am_decimator_exact(hip_lib, oracle):
+    ec.check_am_decimator(hip_lib, oracle)
+
+
+@pytest.mark.parametrize("name", list(common.GOLDEN_AM_CASES))
+def test_gpu_am_golden_end_to_end(hip_lib, name, captures):
+    """Streaming seam in NRSC5_MODE_AM vs the trace of the unmodified reference: P1/P3/PIDS frames exact, floats 1e-4."""
+    ec.check_am_golden_end_to_end(hip_lib, name, captures)
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n_frames=10, seed=3, cfo_hz=3.0, offset=1234),
+    dict(n_frames=9, seed=4, cfo_hz=200.0, offset=0),                 # integer carrier offset (acquire_cfo_adjust)
+    dict(n_frames=9, seed=5, cfo_hz=-40.0, offset=9000, noise=2.0),
+    dict(n_frames=2, seed=6, cfo_hz=10.0, offset=64 * 300 + 12, fmt="cu8"),
+])
+def test_gpu_am_oracle_end_to_end(hip_lib, oracle, kw):
+    ec.check_am_oracle_end_to_end(hip_lib, oracle, kw)
+
+
+def test_gpu_am_batch_equals_streaming(hip_lib):
+    ec.check_am_batch_equals_streaming(hip_lib, [dict(n_frames=10, seed=31, cfo_hz=5.0, offset=100),
+                                                dict(n_frames=9, seed=32, cfo_hz=-20.0, offset=5000), dict(n_frames=3, seed=33)])
+    ec.check_am_batch_equals_streaming(hip_lib, [dict(n_frames=2, seed=41, fmt="cu8"), dict(n_frames=1, seed=42, fmt="cu8", offset=3333)])
