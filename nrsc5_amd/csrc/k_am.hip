@@ -701,9 +701,9 @@ __global__ __launch_bounds__(256) void k_am_viterbi(DevTables tb, DevBuffers db,
         uint32_t *out = slot + bc * AM_P1_WORDS;
         viterbi_k9_block(in, AM_P1_LEN, GEN_E1_0, GEN_E1_1, GEN_E1_2, dec, out, k9);
         const int err = am_bit_errors(in, out, AM_P1_LEN, GEN_E1_0, GEN_E1_1, GEN_E1_2, PUNCT_E1, 15, red);
-        for (int w = threadIdx.x; w < AM_P1_WORDS; w += 256) out[w] ^= tb.scr_p1[w];
+        for (int w = threadIdx.x; w < AM_P1_WORDS; w += 256)     // descramble; the last word holds 6 frame bits
+            out[w] = (out[w] ^ tb.scr_p1[w]) & (w == AM_P1_WORDS - 1 ? (1u << (AM_P1_LEN & 31)) - 1u : 0xffffffffu);
         if (threadIdx.x == 0) {
-            out[AM_P1_WORDS - 1] &= (1u << (AM_P1_LEN & 31)) - 1u;
             atomicAdd(&am.am_errors, (unsigned)err);
             atomicOr(&rec.flags, (uint32_t)REC_P1);
             rec.p1_slot = am.frame_slot;
@@ -721,9 +721,9 @@ __global__ __launch_bounds__(256) void k_am_viterbi(DevTables tb, DevBuffers db,
             err = am_bit_errors(in, out, len, GEN_E1_0, GEN_E1_1, GEN_E1_2, PUNCT_E1, 15, red);
         }
         const int words = (len + 31) / 32;
-        for (int w = threadIdx.x; w < words; w += 256) out[w] ^= tb.scr_p1[w];
+        const uint32_t tailmask = (len & 31) ? (1u << (len & 31)) - 1u : 0xffffffffu;
+        for (int w = threadIdx.x; w < words; w += 256) out[w] = (out[w] ^ tb.scr_p1[w]) & (w == words - 1 ? tailmask : 0xffffffffu);
         if (threadIdx.x == 0) {
-            if (len & 31) out[words - 1] &= (1u << (len & 31)) - 1u;
             atomicAdd(&am.am_errors, (unsigned)err);
             atomicOr(&rec.flags, (uint32_t)REC_P3);
         }
