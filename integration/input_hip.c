@@ -13,6 +13,9 @@
  *   up-calls, in the reference's order inside acquire_process: output_advance (acquire.c:108),
  *   nrsc5_report_sync (input.c:185), decode_reset/frame_reset (sync.c:405-409), nrsc5_report_mer
  *   (sync.c:497), pids_frame_push (decode.c:471), nrsc5_report_ber (decode.c:458), frame_push (decode.c:460).
+ *   AM (NRSC5_MODE_AM): input_set_mode -> nrsc5hip_stream_set_mode; per FINE block pids_frame_push (decode.c:504),
+ *   frame_push of the 3750-bit P1 frame (decode.c:519), after block 7 frame_push of the P3 frame and
+ *   nrsc5_report_ber (decode.c:528-543).
  */
 #include "config.h"
 
@@ -42,6 +45,7 @@ static void deliver(input_t *st)
     static uint8_t bits[NRSC5HIP_P1_FRAME_BITS];
     nrsc5hip_record rec[64];
     int n = 0;
+    const int am = st->radio->mode == NRSC5_MODE_AM;
 
     do
     {
@@ -57,7 +61,10 @@ static void deliver(input_t *st)
             {
                 st->sync.psmi = r->psmi;
                 st->sync_state = SYNC_STATE_FINE;
-                nrsc5_report_sync(st->radio, r->freq_offset, r->psmi, -1, -1, -1, -1);
+                if (am)
+                    nrsc5_report_sync(st->radio, r->freq_offset, r->psmi, r->sis & 1, (r->sis >> 1) & 1, (r->sis >> 2) & 1, (r->sis >> 3) & 1);
+                else
+                    nrsc5_report_sync(st->radio, r->freq_offset, r->psmi, -1, -1, -1, -1);
                 pids_init(&st->decode.pids, st);     /* decode_reset (decode.c:563-572) */
                 frame_reset(&st->frame);
             }
@@ -69,7 +76,23 @@ static void deliver(input_t *st)
                 nrsc5hip_unpack_bits(r->pids, PIDS_FRAME_LEN, pids);
                 pids_frame_push(&st->decode.pids, pids);
             }
-            if (r->flags & NRSC5HIP_REC_P1)
+            if (am)
+            {
+                if (r->flags & NRSC5HIP_REC_P1)
+                {
+                    if (nrsc5hip_am_frame_bits(ENGINE(st), 0, r->p1_slot, r->bc_decoded, P1_FRAME_LEN_AM, bits) != 0) die("am_frame_bits");
+                    frame_push(&st->frame, bits, P1_FRAME_LEN_AM, P1_LOGICAL_CHANNEL);   /* may call input_set_sync_state(NONE) */
+                }
+                if (r->flags & NRSC5HIP_REC_P3)
+                {
+                    const int n3 = (r->psmi == SERVICE_MODE_MA3) ? P3_FRAME_LEN_MA3 : P3_FRAME_LEN_MA1;
+                    if (nrsc5hip_am_frame_bits(ENGINE(st), 0, r->p1_slot, 8, n3, bits) != 0) die("am_frame_bits");
+                    frame_push(&st->frame, bits, n3, P3_LOGICAL_CHANNEL);
+                }
+                if ((r->flags & NRSC5HIP_REC_P1) && r->bc_decoded == 7)
+                    nrsc5_report_ber(st->radio, r->ber);
+            }
+            else if (r->flags & NRSC5HIP_REC_P1)
             {
                 nrsc5_report_ber(st->radio, r->ber);
                 if (nrsc5hip_p1_frame_bits(ENGINE(st), 0, r->p1_slot, bits) != 0) die("p1_frame_bits");
@@ -133,7 +156,7 @@ void input_reset(input_t *st)
 void input_init(input_t *st, nrsc5_t *radio, output_t *output)
 {
     const char *dev = getenv("NRSC5HIP_DEVICE");
-    nrsc5hip_config cfg = { dev ? atoi(dev) : 0, 1, 1 << 20, 256, 4, 0 /* in-order P1: reference event timing */ };
+    nrsc5hip_config cfg = { dev ? atoi(dev) : 0, 1, 1 << 20, 256, 4, 0 /* in-order P1: reference event timing */, 1 /* AM too */ };
     nrsc5hip_engine *e = NULL;
 
     memset(&st->acq, 0, sizeof(st->acq));
@@ -149,11 +172,8 @@ void input_init(input_t *st, nrsc5_t *radio, output_t *output)
 
 void input_set_mode(input_t *st)
 {
-    if (st->radio->mode != NRSC5_MODE_FM)
-    {
-        fprintf(stderr, "nrsc5hip: AM is not implemented on the HIP path yet\n");
-        abort();
-    }
+    if (nrsc5hip_stream_set_mode(ENGINE(st), 0, st->radio->mode == NRSC5_MODE_AM ? NRSC5HIP_MODE_AM : NRSC5HIP_MODE_FM) != 0)
+        die("stream_set_mode");
     input_reset(st);
 }
 

@@ -36,18 +36,25 @@ static void on_event(const nrsc5_event_t *evt, void *opaque)
     }
 }
 
-size_t pipe_run_cu8(const uint8_t *iq, size_t nbytes, unsigned chunk, const uint8_t **out)
+/* mode: NRSC5_MODE_FM / NRSC5_MODE_AM; cs16 != 0: iq holds n int16 values, else n bytes of cu8 */
+size_t pipe_run(const void *iq, size_t n, unsigned chunk, int mode, int cs16, const uint8_t **out)
 {
     nrsc5_t *radio = NULL;
     g_log.len = 0;
     if (nrsc5_open_pipe(&radio) != 0) return 0;
-    nrsc5_set_mode(radio, NRSC5_MODE_FM);
+    nrsc5_set_mode(radio, mode);
     nrsc5_set_callback(radio, on_event, NULL);
-    for (size_t off = 0; off < nbytes; off += chunk) {
-        unsigned n = (nbytes - off < chunk) ? (unsigned)(nbytes - off) : chunk;
-        nrsc5_pipe_samples_cu8(radio, iq + off, n);
+    for (size_t off = 0; off < n; off += chunk) {
+        unsigned k = (n - off < chunk) ? (unsigned)(n - off) : chunk;
+        if (cs16) nrsc5_pipe_samples_cs16(radio, (const int16_t *)iq + off, k);
+        else nrsc5_pipe_samples_cu8(radio, (const uint8_t *)iq + off, k);
     }
     nrsc5_close(radio);
     *out = g_log.p;
     return g_log.len;
+}
+
+size_t pipe_run_cu8(const uint8_t *iq, size_t nbytes, unsigned chunk, const uint8_t **out)
+{
+    return pipe_run(iq, nbytes, chunk, NRSC5_MODE_FM, 0, out);
 }

@@ -15,16 +15,38 @@ pytestmark = pytest.mark.gpu
 BUILD = os.path.join(common.ROOT, "integration", "_build")
 
 
-def _run(libname, iq, chunk=32768):
+def _run(libname, iq, chunk=32768, mode=0):
     path = os.path.join(BUILD, libname)
     if not os.path.exists(path):
         pytest.skip(f"{libname} not prebuilt (integration/Makefile needs /root/reference)")
     lib = ctypes.CDLL(path)
-    lib.pipe_run_cu8.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.POINTER(ctypes.c_void_p)]
-    lib.pipe_run_cu8.restype = ctypes.c_size_t
+    lib.pipe_run.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    lib.pipe_run.restype = ctypes.c_size_t
     p = ctypes.c_void_p()
-    n = lib.pipe_run_cu8(iq.ctypes.data, iq.size, chunk, ctypes.byref(p))
+    n = lib.pipe_run(iq.ctypes.data, iq.size, chunk, mode, int(iq.dtype == np.int16), ctypes.byref(p))
     return ref.parse_log(ctypes.string_at(p, n))
+
+
+def _compare_events(exp, got):
+    assert [k for k, _ in exp] == [k for k, _ in got]
+    for (k, a), (_, b) in zip(exp, got):
+        if k == "hdc":
+            assert a["program"] == b["program"] and a["flags"] == b["flags"] and a["data"] == b["data"]
+        elif k in ("sync", "mer", "ber"):
+            for f in a:
+                va, vb = a[f], b[f]
+                assert abs(va - vb) <= common.FLOAT_RTOL * max(1.0, abs(va)), (k, f, va, vb)
+
+
+@pytest.mark.parametrize("name", list(common.GOLDEN_AM_CASES))
+def test_dropin_public_api_am(name, captures):
+    """nrsc5_set_mode(NRSC5_MODE_AM) + nrsc5_pipe_samples_cs16 / _cu8: same HDC packets, SYNC (incl. the system
+    control bits) and BER events as the unmodified reference."""
+    iq = np.ascontiguousarray(captures(name).iq)
+    exp = _run("libnrsc5_plain.so", iq, mode=1)
+    got = _run("libnrsc5_hipdropin.so", iq, mode=1)
+    assert sum(k == "hdc" for k, _ in exp) >= 4 and any(k == "ber" for k, _ in exp)
+    _compare_events(exp, got)
 
 
 @pytest.mark.parametrize("name", ["fm_cu8_cfo137", "fm_cu8_cfo-2400"])
