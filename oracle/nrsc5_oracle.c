@@ -26,6 +26,7 @@
 #define PIDS_LEN   80
 #define PIDS_CODED 200
 #define FS_FM      744187.5
+#define PX_MAX     4608                      /* soft bits per block from 2 extended partitions per sideband = P3 frame bits (MP3/MP11) */
 
 /* ------------------------------------------------------------------------------------ */
 /* constants that are part of the algorithm's contract                                    */
@@ -324,6 +325,7 @@ struct orc_stream {
     /* decode (decode.h:19-62) */
     int8_t pm[16 * PM_BLOCK];
     int started_pm;
+    struct px_chan { int8_t pair[2 * PX_MAX]; int8_t mem[32 * PX_MAX]; unsigned pos, taken[4]; int ready, started; } px[2];
     /* plumbing */
     gbuf log, q15, fft;
     unsigned taps, fft_limit, fft_syms;
@@ -393,6 +395,50 @@ static void decode_block(orc_stream *s, const int8_t *soft, unsigned bc)
         if (s->hook && s->hook(s->hook_user, bits_p1, P1_LEN))
             set_sync_state(s, ORC_SYNC_NONE);           /* frame.c:535-540 */
     }
+}
+
+/* ---- extended sidebands: PX1 -> P3, PX2 -> P4 (decode.c:344-376, 393-437) -------------------- */
+
+/* interleaver_iv: one call consumes the 2 x frame_len soft bits of a block pair and emits one depunctured
+ * (rate 2/3 -> [1,0,1,1,0,1]) trellis input of 3 x frame_len.  Convolutional: a bit read now was written up to
+ * 32 blocks earlier; `mem` persists across calls, `pos` / `taken` restart every 32 blocks. */
+void orc_interleave_px(int8_t *mem, unsigned *pos, unsigned taken[4], int *ready, const int8_t *pair, unsigned frame_len, int8_t *out)
+{
+    const unsigned wide = frame_len == PX_MAX;
+    const unsigned J = wide ? 4 : 2, C = 36, M = wide ? 2 : 4, N = 32 * frame_len;
+    const unsigned bk_bits = 32 * C, bk_adj = 32 * C - 1;
+    if (*pos == N) { *pos = 0; memset(taken, 0, sizeof(unsigned) * 4); *ready = 1; }
+    unsigned o = 0;
+    for (unsigned i = 0; i < frame_len * 2; i++) {
+        const unsigned part = ((*pos + 2 * (M / 4)) / M) % J;
+        const unsigned pti = taken[part]++;
+        const unsigned block = (pti + (part * 7) - (bk_adj * (pti / bk_bits))) % 32;
+        const unsigned row = ((11 * pti) % bk_bits) / C, col = (pti * 11) % C;
+        out[o++] = mem[(block * 32 + row) * (J * C) + part * C + col];
+        if ((o % 6) == 1 || (o % 6) == 4) out[o++] = 0;
+        mem[*pos] = pair[i];
+        (*pos)++;
+    }
+}
+
+static void px_push(orc_stream *s, int ch, const int8_t *soft, unsigned len, unsigned bc)
+{
+    struct px_chan *x = &s->px[ch];
+    if (bc % 2 == 0) x->started = 1;
+    if (!x->started) return;
+    memcpy(x->pair + len * (bc % 2), soft, len);
+    if (bc % 2 == 0) return;
+    int8_t coded[3 * PX_MAX];
+    uint8_t bits[PX_MAX];
+    orc_interleave_px(x->mem, &x->pos, x->taken, &x->ready, x->pair, len, coded);
+    if (!x->ready) return;
+    orc_viterbi_k7(coded, (int)len, bits);
+    orc_descramble(bits, len);
+    uint8_t *tmp = malloc(8 + len);
+    uint32_t h[2] = { 1 + (uint32_t)ch, len };               /* P3_LOGICAL_CHANNEL / P4_LOGICAL_CHANNEL */
+    memcpy(tmp, h, 8); memcpy(tmp + 8, bits, len);
+    log_rec(s, ORC_REC_FRAME, tmp, 8 + len);
+    free(tmp);
 }
 
 /* ---- sync side (sync.c) ---------------------------------------------------------------- */
@@ -575,6 +621,7 @@ static void sync_block(orc_stream *s)
                 s->bc = maj_bc; s->psmi = maj_psmi;
                 set_sync_state(s, ORC_SYNC_FINE);
                 s->started_pm = 0;                       /* decode_reset (decode.c:563-572) */
+                for (int ch = 0; ch < 2; ch++) { s->px[ch].pos = 0; memset(s->px[ch].taken, 0, sizeof(s->px[ch].taken)); s->px[ch].started = 0; s->px[ch].ready = 0; }
             }
         } else if (s->cfo_wait == 0) {
             coarse_cfo_search(s);
@@ -633,8 +680,9 @@ static void sync_block(orc_stream *s)
     const float mult_lb = fmaxf(fminf(mer_lb * 10, 127), 1);
     const float mult_ub = fmaxf(fminf(mer_ub * 10, 127), 1);
 
-    int8_t soft[PM_BLOCK];
-    int o = 0;
+    int8_t soft[PM_BLOCK], px1[PX_MAX], px2[PX_MAX];
+    int o = 0, o1 = 0, o2 = 0;
+    const int compat = COMPAT[s->psmi];
     for (int n = 0; n < NSYM; n++) {
         for (i = LB0; i < LB0 + PM_PART * PW; i += PW)
             for (int j = 1; j < PW; j++) {
@@ -648,6 +696,29 @@ static void sync_block(orc_stream *s)
                 soft[o++] = soft_bit(crealf(c), mult_ub);
                 soft[o++] = soft_bit(cimagf(c), mult_ub);
             }
+        /* extended partitions (sync.c:537-596): 1 per sideband in MP2, 2 in MP3/MP11 -> PX1; 2 more in MP11 -> PX2,
+         * where BOTH sidebands use the lower sideband's gain (the reference's quirk, sync.c:591-592) */
+        const int nx1 = compat == 2 ? 1 : (compat == 3 || compat == 11) ? 2 : 0, nx2 = compat == 11 ? 2 : 0;
+        for (int q = 0; q < nx1; q++)
+            for (int j = 1; j < PW; j++) {
+                float complex c = s->bins[LB0 + (PM_PART + q) * PW + j][n];
+                px1[o1++] = soft_bit(crealf(c), mult_lb); px1[o1++] = soft_bit(cimagf(c), mult_lb);
+            }
+        for (int q = 0; q < nx1; q++)
+            for (int j = 1; j < PW; j++) {
+                float complex c = s->bins[UB1 - (PM_PART + nx1 - q) * PW + j][n];
+                px1[o1++] = soft_bit(crealf(c), mult_ub); px1[o1++] = soft_bit(cimagf(c), mult_ub);
+            }
+        for (int q = 0; q < nx2; q++)
+            for (int j = 1; j < PW; j++) {
+                float complex c = s->bins[LB0 + (PM_PART + 2 + q) * PW + j][n];
+                px2[o2++] = soft_bit(crealf(c), mult_lb); px2[o2++] = soft_bit(cimagf(c), mult_lb);
+            }
+        for (int q = 0; q < nx2; q++)
+            for (int j = 1; j < PW; j++) {
+                float complex c = s->bins[UB1 - (PM_PART + 2 + nx2 - q) * PW + j][n];
+                px2[o2++] = soft_bit(crealf(c), mult_lb); px2[o2++] = soft_bit(cimagf(c), mult_lb);
+            }
     }
     if (s->taps & ORC_TAP_SOFT) {
         uint8_t *tmp = malloc(4 + PM_BLOCK);
@@ -655,7 +726,12 @@ static void sync_block(orc_stream *s)
         log_rec(s, ORC_REC_SOFT, tmp, 4 + PM_BLOCK);
         free(tmp);
     }
-    decode_block(s, soft, s->bc);
+    {
+        const unsigned bc = s->bc;
+        decode_block(s, soft, bc);
+        if (o1 > 0) px_push(s, 0, px1, (unsigned)o1, bc);
+        if (o2 > 0) px_push(s, 1, px2, (unsigned)o2, bc);
+    }
     s->bc = (s->bc + 1) % 16;
 }
 
@@ -778,6 +854,7 @@ void orc_reset(orc_stream *s)
     memset(s->costas_phase, 0, sizeof(s->costas_phase));
     s->sym_idx = 0; s->psmi = 1; s->cfo_wait = 0; s->mer_cnt = 0; s->error_lb = 0; s->error_ub = 0;
     s->started_pm = 0;                                                      /* decode_reset */
+    for (int ch = 0; ch < 2; ch++) { s->px[ch].pos = 0; memset(s->px[ch].taken, 0, sizeof(s->px[ch].taken)); s->px[ch].started = 0; s->px[ch].ready = 0; }
 }
 
 orc_stream *orc_open(void)

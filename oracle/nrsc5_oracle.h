@@ -54,6 +54,10 @@ void orc_cp_correlate_fm(const orc_c16 *filtered /*71280*/, int *samperr, float 
 void orc_deinterleave_p1(const int8_t *pm /*16*23040*/, int8_t *out /*438528*/);
 void orc_deinterleave_pids(const int8_t *pm /*16*23040*/, unsigned bc, int8_t *out /*240*/);
 
+/* K6x decode.c:344-376: interleaver IV of the extended sidebands (PX1 -> P3, PX2 -> P4).  frame_len = 4608 (MP3/MP11)
+ * or 2304 (MP2); pair = the 2 * frame_len soft bits of a block pair; mem[32 * frame_len], pos, taken[4], ready persist. */
+void orc_interleave_px(int8_t *mem, unsigned *pos, unsigned taken[4], int *ready, const int8_t *pair, unsigned frame_len, int8_t *out /*3*frame_len*/);
+
 /* K7  conv_dec.c:402-453 + conv_gen.h:32-101: tail-biting soft Viterbi, rate 1/3.
  * k = 7 (gens 0133,0171,0165) or k = 9 with the three generators given. */
 int orc_viterbi(const int8_t *in /*3*len*/, int len, int k, const unsigned gens[3], uint8_t *out /*len*/);

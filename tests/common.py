@@ -20,6 +20,8 @@ LOOSE_ABS = {"phase_re": 5e-3, "phase_im": 5e-3}
 
 # golden capture definitions: name -> synth.fm_mp1_capture kwargs
 GOLDEN_CASES = {
+    "fm_mp11_cs16": dict(n_frames=0, n_blocks=56, seed=14, cfo_hz=-30.0, offset=900, snr_db=24.0, fmt="cs16", mode="MP11"),
+    "fm_mp2_cu8": dict(n_frames=0, n_blocks=56, seed=15, cfo_hz=80.0, offset=1500, snr_db=22.0, fmt="cu8", mode="MP2"),
     "fm_cu8_cfo137": dict(n_frames=0, n_blocks=40, seed=11, cfo_hz=137.0, offset=777, snr_db=20.0, fmt="cu8"),
     "fm_cu8_cfo-2400": dict(n_frames=0, n_blocks=24, seed=12, cfo_hz=-2400.0, offset=3001, snr_db=15.0, fmt="cu8"),
     "fm_cs16_cfo60": dict(n_frames=0, n_blocks=36, seed=13, cfo_hz=60.0, offset=1500, snr_db=25.0, fmt="cs16"),
@@ -77,7 +79,11 @@ def log_to_arrays(log):
         "mer": np.array([[v["lower"], v["upper"]] for k, v in log if k == "mer"], dtype=np.float32).reshape(-1, 2),
         "ber": np.array([v["cber"] for k, v in log if k == "ber"], dtype=np.float32),
         "pids": np.packbits(np.array([v["bits"] for k, v in log if k == "pids"], dtype=np.uint8).reshape(-1, 80), axis=1, bitorder="little"),
-        "p1": np.packbits(np.array([v["bits"] for k, v in log if k == "frame"], dtype=np.uint8).reshape(-1, 146176), axis=1, bitorder="little"),
+        "p1": np.packbits(np.array([v["bits"] for k, v in log if k == "frame" and v["lc"] == 0], dtype=np.uint8).reshape(-1, 146176), axis=1, bitorder="little"),
+        "frame_lc": np.array([v["lc"] for k, v in log if k == "frame"], dtype=np.uint8),
+        "px_bits": np.array([len(v["bits"]) for k, v in log if k == "frame" and v["lc"] != 0][:1], dtype=np.int32),
+        "px": np.packbits(np.array([v["bits"] for k, v in log if k == "frame" and v["lc"] != 0], dtype=np.uint8).reshape(
+            -1, max([len(v["bits"]) for k, v in log if k == "frame" and v["lc"] != 0] + [8])), axis=1, bitorder="little"),
         "kinds": np.array([{"block": 1, "state": 2, "pids": 4, "frame": 5, "sync": 6, "lost_sync": 7, "mer": 8, "ber": 9}[k]
                            for k, _ in log if k not in ("hdc", "soft", "vit")], dtype=np.uint8),
     }
@@ -88,7 +94,7 @@ def arrays_to_log(a):
     """Inverse of log_to_arrays (ordering restored from `kinds`)."""
     ikeys = ("state_before", "state_after", "samperr", "cfo", "keep", "bc", "psmi", "cfo_wait", "next_samperr")
     fkeys = ("prev_angle", "phase_re", "phase_im", "next_angle")
-    it = {k: iter(range(10 ** 9)) for k in ("block", "sync", "mer", "ber", "pids", "p1")}
+    it = {k: iter(range(10 ** 9)) for k in ("block", "sync", "mer", "ber", "pids", "p1", "frame", "px")}
     log = []
     # state transitions are implied by block records: rebuild them
     for kind in a["kinds"]:
@@ -102,7 +108,11 @@ def arrays_to_log(a):
         elif kind == 4:
             log.append(("pids", {"bits": np.unpackbits(a["pids"][next(it["pids"])], bitorder="little")[:80]}))
         elif kind == 5:
-            log.append(("frame", {"lc": 0, "bits": np.unpackbits(a["p1"][next(it["p1"])], bitorder="little")[:146176]}))
+            lc = int(a["frame_lc"][next(it["frame"])]) if "frame_lc" in a else 0
+            if lc == 0:
+                log.append(("frame", {"lc": 0, "bits": np.unpackbits(a["p1"][next(it["p1"])], bitorder="little")[:146176]}))
+            else:
+                log.append(("frame", {"lc": lc, "bits": np.unpackbits(a["px"][next(it["px"])], bitorder="little")[:int(a["px_bits"][0])]}))
         elif kind == 6:
             i = next(it["sync"])
             log.append(("sync", {"freq_offset": float(a["sync"][i, 0]), "psmi": int(a["sync"][i, 1]), "pli": -1, "hppi": -1, "aabi": -1, "rdbi": -1}))

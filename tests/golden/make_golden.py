@@ -21,7 +21,10 @@ from oracle import ref  # noqa: E402
 def main():
     R = ref.RefLib(sse=False)
     Rs = ref.RefLib(sse=True)
+    only = [a for a in sys.argv[2:]]
     for name, kw in common.GOLDEN_CASES.items():
+        if only and name not in only:
+            continue
         cap = synth.fm_mp1_capture(**kw)
         log, q15, _ = R.run(cap.iq, taps=ref.TAP_Q15 | ref.TAP_SOFT)
         log_sse, _, _ = Rs.run(cap.iq, taps=ref.TAP_SOFT)
@@ -34,6 +37,10 @@ def main():
         arrs["q15_head"] = q15[:4096].copy()
         arrs["iq_sha"] = np.array(common.sha256(cap.iq))
         arrs["truth_p1"] = np.packbits(np.array(cap.p1_frames, dtype=np.uint8).reshape(-1, 146176), axis=1, bitorder="little")
+        if cap.p3_frames:
+            arrs["truth_p3"] = np.packbits(np.array(cap.p3_frames, dtype=np.uint8), axis=1, bitorder="little")
+        if cap.p4_frames:
+            arrs["truth_p4"] = np.packbits(np.array(cap.p4_frames, dtype=np.uint8), axis=1, bitorder="little")
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrs)
         nfr = int(arrs["p1"].shape[0])
         print(f"{name}: {len(arrs['block_int'])} blocks, {nfr} P1 frames, {arrs['pids'].shape[0]} PIDS, "

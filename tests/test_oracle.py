@@ -103,3 +103,44 @@ def test_l2_feedback_hook_drops_to_none(oracle, captures):
 
 def test_synth_interleaver_tiles_matrix():
     assert len(np.unique(np.concatenate([synth.P1_IDX, synth.PIDS_IDX]))) == 16 * synth.PM_BLOCK
+
+
+@pytest.mark.parametrize("mode,kw", [
+    ("MP2", dict(n_blocks=52, seed=31, cfo_hz=20.0, offset=300, snr_db=25)),
+    ("MP3", dict(n_blocks=54, seed=32, cfo_hz=-150.0, offset=500, snr_db=18, fmt="cs16")),
+    ("MP11", dict(n_blocks=52, seed=33, cfo_hz=0.0, offset=64, snr_db=14)),
+])
+def test_oracle_extended_sidebands_bit_identical_to_reference(mode, kw, oracle, reflib):
+    """PX1 / PX2 soft bits -> interleaver IV -> P3 / P4 frames (decode.c:344-437): full log, 0 tolerance."""
+    from oracle import ref, port
+    cap = synth.fm_mp1_capture(0, mode=mode, **kw)
+    rl, _, _ = reflib.run(cap.iq, taps=ref.TAP_SOFT)
+    ol, _, _ = oracle.run(cap.iq, taps=port.TAP_SOFT)
+    assert not common.compare_logs(rl, ol, rtol=0.0, skip_kinds=("hdc",))
+    px = [v for k, v in rl if k == "frame" and v["lc"] != 0]
+    assert len(px) >= (4 if mode == "MP11" else 2)
+
+
+@pytest.mark.parametrize("name", ["fm_mp11_cs16", "fm_mp2_cu8"])
+def test_golden_px_frames_equal_transmitted_truth(name):
+    g = _golden(name)
+    lcs = g["frame_lc"][g["frame_lc"] != 0]
+    assert lcs.size >= 2 and g["sync"].shape[0] == 1
+    i3 = i4 = None
+    for lc, row in zip(lcs, g["px"]):
+        truth = g["truth_p3"] if lc == 1 else g["truth_p4"]
+        hit = [k for k in range(truth.shape[0]) if np.array_equal(truth[k], row)]
+        assert len(hit) == 1
+        if lc == 1:
+            assert i3 is None or hit[0] == i3 + 1
+            i3 = hit[0]
+        else:
+            assert i4 is None or hit[0] == i4 + 1
+            i4 = hit[0]
+
+
+def test_interleaver_iv_is_convolutional():
+    """The synthesizer relies on interleaver_iv being shift-invariant by one block pair (delays 1..N)."""
+    for L in (2304, 4608):
+        d = synth.interleaver_iv_delays(L)
+        assert d.min() >= 1 and d.max() <= 32 * L and len(np.unique((np.arange(2 * L) - d) % (32 * L))) == 2 * L
