@@ -60,7 +60,9 @@ enum {
     NRSC5HIP_REC_PIDS      = 1u << 4,  /* pids_frame_push(pids) */
     NRSC5HIP_REC_P1        = 1u << 5,  /* nrsc5_report_ber(ber); frame_push(P1 frame in slot p1_slot) */
     NRSC5HIP_REC_LOST_SYNC = 1u << 6,  /* reserved */
-    NRSC5HIP_REC_P3        = 1u << 7   /* AM, block 7: frame_push(P3 frame of slot p1_slot), then nrsc5_report_ber(ber) */
+    NRSC5HIP_REC_P3        = 1u << 7,  /* FM (MP2/MP3/MP11, odd blocks): frame_push(P3 frame of PX slot `sis`, 2304 or 4608 bits);
+                                          AM, block 7: frame_push(P3 frame of slot p1_slot), then nrsc5_report_ber(ber) */
+    NRSC5HIP_REC_P4        = 1u << 8   /* FM MP11: frame_push(P4 frame of PX slot `sis`, 4608 bits) */
 };
 
 /* One record per processed 32-symbol block, in stream order.  Events implied by one record fire in
@@ -84,7 +86,8 @@ typedef struct nrsc5hip_record {
     int32_t p1_slot;                     /* valid with REC_P1 */
     int32_t bc_decoded;                  /* block count the PIDS frame / soft bits belong to, or -1 */
     uint32_t pids[3];                    /* valid with REC_PIDS: bit i of the frame at pids[i/32] bit i%32 */
-    uint32_t sis;                        /* AM with REC_TO_FINE: pli | hppi << 1 | aabi << 2 | rdbi << 3 | 16 (sync.c:231-235); FM: 0 */
+    uint32_t sis;                        /* AM with REC_TO_FINE: pli | hppi << 1 | aabi << 2 | rdbi << 3 | 16 (sync.c:231-235);
+                                            FM with REC_P3 / REC_P4: slot of the P3/P4 frame ring (8 * p1_slots slots) */
 } nrsc5hip_record;
 
 typedef struct nrsc5hip_config {
@@ -144,6 +147,11 @@ int nrsc5hip_drain(nrsc5hip_engine *e, int stream, nrsc5hip_record *out, int max
 int nrsc5hip_p1_frame_packed(nrsc5hip_engine *e, int stream, int slot, uint32_t *words /* [4568] */);
 /* ... or one bit per byte, the layout frame_push() takes (frame.h:53) */
 int nrsc5hip_p1_frame_bits(nrsc5hip_engine *e, int stream, int slot, uint8_t *bits /* [146176] */);
+/* FM extended sidebands (decode_push_px1/px2, decode.c:393-437): P3 (channel 0) / P4 (channel 1) frame of a REC_P3 / REC_P4
+ * record, slot = record.sis, nbits = 2304 (MP2) or 4608 (MP3 / MP11), one bit per byte as frame_push() takes it */
+int nrsc5hip_px_frame_bits(nrsc5hip_engine *e, int stream, int slot, int channel, int nbits, uint8_t *bits);
+/* every P3/P4 slot of the listed streams, packed: frames[nstreams][8 * p1_slots][2][144] */
+int nrsc5hip_batch_fetch_px(nrsc5hip_engine *e, int nstreams, const int *stream_ids, uint32_t *frames);
 /* AM frames of a REC_P1 / REC_P3 record, one bit per byte as frame_push() takes them: which = 0..7 selects the P1 frame
  * of that block (nbits 3750), which = 8 the P3 frame (nbits 24000 for MA1, 30000 for MA3).  In the packed slot
  * (nrsc5hip_p1_frame_packed / batch_fetch) P1 frame b starts at word 118 b and the P3 frame at word 944. */
@@ -177,6 +185,9 @@ int nrsc5hip_stage_viterbi_bench(nrsc5hip_engine *e, int len, int nframes, int p
 int nrsc5hip_debug_sync_phases(nrsc5hip_engine *e, long long *cycles8);
 /* debugging aid: soft-bit matrix (16 x 23040 int8) and live FFT bins of a stream's latest block */
 int nrsc5hip_debug_fetch(nrsc5hip_engine *e, int stream, int8_t *pm /* [368640] or NULL */, float *bins /* [32][534][2] or NULL */);
+
+/* debugging aid: PX1 / PX2 soft bits of the stream's current block pair, [2 channels][2 blocks][4608] int8 */
+int nrsc5hip_debug_fetch_px(nrsc5hip_engine *e, int stream, int8_t *pair /* [18432] */);
 
 /* fresh-session state for every stream (input_reset on all of them) */
 int nrsc5hip_reset_all(nrsc5hip_engine *e);

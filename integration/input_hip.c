@@ -13,6 +13,7 @@
  *   up-calls, in the reference's order inside acquire_process: output_advance (acquire.c:108),
  *   nrsc5_report_sync (input.c:185), decode_reset/frame_reset (sync.c:405-409), nrsc5_report_mer
  *   (sync.c:497), pids_frame_push (decode.c:471), nrsc5_report_ber (decode.c:458), frame_push (decode.c:460).
+ *   MP2/MP3/MP11: frame_push of the P3 / P4 frames of the extended sidebands (decode.c:409,432).
  *   AM (NRSC5_MODE_AM): input_set_mode -> nrsc5hip_stream_set_mode; per FINE block pids_frame_push (decode.c:504),
  *   frame_push of the 3750-bit P1 frame (decode.c:519), after block 7 frame_push of the P3 frame and
  *   nrsc5_report_ber (decode.c:528-543).
@@ -97,6 +98,17 @@ static void deliver(input_t *st)
                 nrsc5_report_ber(st->radio, r->ber);
                 if (nrsc5hip_p1_frame_bits(ENGINE(st), 0, r->p1_slot, bits) != 0) die("p1_frame_bits");
                 frame_push(&st->frame, bits, P1_FRAME_LEN_FM, P1_LOGICAL_CHANNEL);   /* may call input_set_sync_state(NONE) */
+            }
+            if (!am && (r->flags & (NRSC5HIP_REC_P3 | NRSC5HIP_REC_P4)))
+            {
+                /* extended sidebands: decode_push_px1 / px2 (decode.c:393-437) */
+                const int nbits = (r->psmi == 2) ? P3_FRAME_LEN_MP2 : P3_FRAME_LEN_MP3_MP11;
+                for (int ch = 0; ch < 2; ch++)
+                {
+                    if (!(r->flags & (ch ? NRSC5HIP_REC_P4 : NRSC5HIP_REC_P3))) continue;
+                    if (nrsc5hip_px_frame_bits(ENGINE(st), 0, (int)r->sis, ch, nbits, bits) != 0) die("px_frame_bits");
+                    frame_push(&st->frame, bits, nbits, ch ? P4_LOGICAL_CHANNEL : P3_LOGICAL_CHANNEL);
+                }
             }
         }
     } while (n == 64);

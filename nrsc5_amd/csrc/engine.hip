@@ -42,6 +42,7 @@ struct nrsc5hip_engine {
         hipEvent_t ev_window[NWIN], ev_decoded[NWIN];
         bool decoded_pending[NWIN];
         bool acq_needed;
+        bool px_needed;                // some stream is not FINE yet or runs a service mode with extended sidebands
         int dec_waited;                // chunks of the current chunked append this lane has already waited for
         bool prepared_by_sync;         // the previous step's k_sync already ran the next block's bookkeeping
         long long step_count;          // block steps issued so far (decode-window bookkeeping in async mode)
@@ -184,6 +185,24 @@ static int build_tables(nrsc5hip_engine *e)
     if ((rc = dev_upload(e, &e->tb.shape, shape))) return rc;
     if ((rc = dev_upload(e, &e->tb.hb_q15, hbq))) return rc;
     if ((rc = dev_upload(e, &e->tb.acq_q15, acq))) return rc;
+    for (int wide = 0; wide < 2; wide++) {
+        // interleaver IV (decode.c:344-376) is convolutional: position i of a block pair reads what was written
+        // delay[i] positions earlier (1..N).  Same arithmetic as the reference's loop, for the first pair of a cycle.
+        const unsigned L = wide ? 4608 : 2304, J = wide ? 4 : 2, C = 36, M = wide ? 2 : 4, N = 32 * L;
+        const unsigned bk_bits = 32 * C, bk_adj = 32 * C - 1;
+        std::vector<uint32_t> delay(2 * L);
+        unsigned taken[4] = { 0, 0, 0, 0 };
+        for (unsigned g = 0; g < 2 * L; g++) {
+            const unsigned part = ((g + 2 * (M / 4)) / M) % J;
+            const unsigned pti = taken[part]++;
+            const unsigned block = (pti + (part * 7) - (bk_adj * (pti / bk_bits))) % 32;
+            const unsigned row = ((11 * pti) % bk_bits) / C, col = (pti * 11) % C;
+            const unsigned rp = (block * 32 + row) * (J * C) + part * C + col;
+            const unsigned d = (g + N - rp) % N;
+            delay[g] = d ? d : N;
+        }
+        if ((rc = dev_upload(e, wide ? &e->tb.px_delay_wide : &e->tb.px_delay_narrow, delay))) return rc;
+    }
     {   // AM tables: acquisition FIR (acquire.c:63-96), pulse shape (acquire.c:333-342), 256-point twiddles
         static const float am_taps[32] = {
             -0.00038464731187559664f, -0.00021618751634377986f, 0.0026779419276863337f, -0.00029802651260979474f,
@@ -261,7 +280,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
                 if (hipEventCreate(&ln.ev_window[k]) != hipSuccess || hipEventCreate(&ln.ev_decoded[k]) != hipSuccess) rc = NRSC5HIP_EHIP;
                 ln.decoded_pending[k] = false;
             }
-            ln.acq_needed = true; ln.step_count = 0;
+            ln.acq_needed = true; ln.px_needed = true; ln.step_count = 0;
             if (!rc && hipHostMalloc((void **)&ln.counters_host, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) rc = NRSC5HIP_ENOMEM;
         }
         if (rc) { snprintf(g_err, sizeof(g_err), "stream/event creation failed"); break; }
@@ -287,6 +306,18 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if ((rc = dev_alloc(e, &db.p1_ring, S * db.p1_slots * P1_WORDS))) break;
         if ((rc = dev_alloc(e, &db.records, S * db.rec_cap))) break;
         if ((rc = dev_alloc(e, &db.counters, 4 * MAX_LANES))) break;
+        {
+            const size_t nax = cfg->p1_async ? NAUX : 1;
+            db.px_slots = 8 * cfg->p1_slots;
+            if ((rc = dev_alloc(e, &db.px_mem, S * 2 * PX_MEM))) break;
+            if ((rc = dev_alloc(e, &db.px_pair, S * 4 * PX_MAX))) break;
+            if ((rc = dev_alloc(e, &db.px_stage, S * NWIN * 16 * (size_t)PX_DEPUNCT))) break;
+            if ((rc = dev_alloc(e, &db.px_job, S * NWIN * 16))) break;
+            if ((rc = dev_alloc(e, &db.px_dec, nax * S * 16 * (size_t)(PX_MAX + 64)))) break;
+            if ((rc = dev_alloc(e, &db.px_ring, S * (size_t)db.px_slots * 2 * PX_WORDS))) break;
+            if (hipMemset(db.px_mem, 0, S * 2 * PX_MEM) != hipSuccess || hipMemset(db.px_pair, 0, S * 4 * PX_MAX) != hipSuccess ||
+                hipMemset(db.px_job, 0xff, S * NWIN * 16 * sizeof(PxJob)) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "PX state init failed"); break; }
+        }
         db.am = nullptr; db.am_sym = nullptr; db.am_q = nullptr; db.am_vit = nullptr; db.am_dec = nullptr;
         if (cfg->am_enable) {
             if ((rc = dev_alloc(e, &db.am, S))) break;
@@ -390,8 +421,10 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
     const int fuse = (async && !ln.acq_needed && !no_fuse) ? 1 : 0;
     { ProfScope p(e, NRSC5HIP_PROF_SYNC, ln.main); launch_sync(e->tb, ln.db, n, ids_dev, parity, slot, fuse, ln.main); }
     ln.prepared_by_sync = fuse != 0;
+    if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_px_deint(e->tb, ln.db, n, ids_dev, parity, slot, ln.main); }
     if (!async) {
         { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_pids_decode(e->tb, ln.db, n, ids_dev, parity, 1, ln.main); }
+        if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_px_decode(e->tb, ln.db, n, ids_dev, parity, 0, ln.main); }
         ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ln.main);
         launch_p1_viterbi(e->tb, ln.db, n, ids_dev, parity, 0, ln.main);
     } else if ((ln.step_count % 16) == 15) {
@@ -401,6 +434,7 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
         HIPCHK(hipEventRecord(ln.ev_window[parity], ln.main));
         HIPCHK(hipStreamWaitEvent(ax, ln.ev_window[parity], 0));
         { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_pids_decode(e->tb, ln.db, n, ids_dev, parity, 16, ax); }
+        if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_px_decode(e->tb, ln.db, n, ids_dev, parity, lane, ax); }
         { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ax); launch_p1_viterbi(e->tb, ln.db, n, ids_dev, parity, lane, ax); }
         HIPCHK(hipEventRecord(ln.ev_decoded[parity], ax));
         ln.decoded_pending[parity] = true;
@@ -421,6 +455,7 @@ static int flush_p1(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const 
         HIPCHK(hipEventRecord(ln.ev_window[parity], ln.main));
         HIPCHK(hipStreamWaitEvent(ax, ln.ev_window[parity], 0));
         { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_pids_decode(e->tb, ln.db, n, ids_dev, parity, 16, ax); }
+        if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_px_decode(e->tb, ln.db, n, ids_dev, parity, lane, ax); }
         { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ax); launch_p1_viterbi(e->tb, ln.db, n, ids_dev, parity, lane, ax); }
         ln.step_count += 16 - (ln.step_count % 16);            // next batch starts a fresh window
     }
@@ -450,6 +485,7 @@ static int run_steps_lanes(nrsc5hip_engine *e, int nl, const int *n, const int *
             if (!live[l]) continue;
             HIPCHK(hipStreamSynchronize(e->lanes[l].main));
             e->lanes[l].acq_needed = e->lanes[l].counters_host[1] > 0;
+            e->lanes[l].px_needed = e->lanes[l].counters_host[2] > 0;
             if (e->lanes[l].counters_host[0] == 0) live[l] = false; else progressed = true;
         }
         if (!progressed) break;                                // nothing was processed in this burst
@@ -571,7 +607,7 @@ extern "C" int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream)
     HIPCHK(hipMemcpy(e->db.state + stream, &st, sizeof(st), hipMemcpyHostToDevice));
     if (e->db.am) { AmStream am; init_am_state(am); HIPCHK(hipMemcpy(e->db.am + stream, &am, sizeof(am), hipMemcpyHostToDevice)); }
     e->wr_host[stream] = 0; e->base_host[stream] = 0; e->drained[stream] = 0; e->raw_host[stream] = 0;
-    for (int l = 0; l < e->nlanes; l++) e->lanes[l].acq_needed = true;
+    for (int l = 0; l < e->nlanes; l++) { e->lanes[l].acq_needed = true; e->lanes[l].px_needed = true; }
     return 0;
 }
 
@@ -592,7 +628,7 @@ extern "C" int nrsc5hip_force_resync(nrsc5hip_engine *e, int stream)
 {
     int rc = check_stream(e, stream); if (rc) return rc;
     hipLaunchKernelGGL(k_force_none, dim3(1), dim3(1), 0, e->main, e->db, stream);
-    for (int l = 0; l < e->nlanes; l++) e->lanes[l].acq_needed = true;
+    for (int l = 0; l < e->nlanes; l++) { e->lanes[l].acq_needed = true; e->lanes[l].px_needed = true; }
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -788,6 +824,32 @@ extern "C" int nrsc5hip_p1_frame_bits(nrsc5hip_engine *e, int stream, int slot, 
     return 0;
 }
 
+// FM extended sidebands: P3 (channel 0) / P4 (channel 1) frame of a REC_P3 / REC_P4 record; slot = record.sis
+extern "C" int nrsc5hip_px_frame_bits(nrsc5hip_engine *e, int stream, int slot, int channel, int nbits, uint8_t *bits)
+{
+    int rc = check_stream(e, stream); if (rc) return rc;
+    if (slot < 0 || slot >= e->db.px_slots || channel < 0 || channel > 1 || !bits || (nbits != 2304 && nbits != 4608)) FAIL(NRSC5HIP_EINVAL, "bad slot/argument");
+    uint32_t w[PX_WORDS];
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(w, e->db.px_ring + (((size_t)stream * e->db.px_slots + slot) * 2 + channel) * PX_WORDS, (nbits / 32) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    nrsc5hip_unpack_bits(w, nbits, bits);
+    return 0;
+}
+
+// bulk variant: all P3/P4 slots of the listed streams, [nstreams][8 * p1_slots][2][144] words
+extern "C" int nrsc5hip_batch_fetch_px(nrsc5hip_engine *e, int nstreams, const int *stream_ids, uint32_t *frames)
+{
+    if (!e || !frames) FAIL(NRSC5HIP_EINVAL, "null argument");
+    HIPCHK(hipDeviceSynchronize());
+    const size_t per = (size_t)e->db.px_slots * 2 * PX_WORDS;
+    for (int k = 0; k < nstreams; k++) {
+        const int s = stream_ids ? stream_ids[k] : k;
+        int rc = check_stream(e, s); if (rc) return rc;
+        HIPCHK(hipMemcpy(frames + (size_t)k * per, e->db.px_ring + (size_t)s * per, per * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+
 // AM: frames of one L1 frame share a ring slot: P1 frame of block b at word b * 118, the P3 frame at word 944
 extern "C" int nrsc5hip_am_frame_bits(nrsc5hip_engine *e, int stream, int slot, int which, int nbits, uint8_t *bits)
 {
@@ -903,6 +965,15 @@ extern "C" int nrsc5hip_debug_fetch(nrsc5hip_engine *e, int stream, int8_t *pm, 
     return 0;
 }
 
+extern "C" int nrsc5hip_debug_fetch_px(nrsc5hip_engine *e, int stream, int8_t *pair)
+{
+    int rc = check_stream(e, stream); if (rc) return rc;
+    if (!pair) FAIL(NRSC5HIP_EINVAL, "null argument");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(pair, e->db.px_pair + (size_t)stream * 4 * PX_MAX, 4 * PX_MAX, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int nrsc5hip_debug_fetch_q15(nrsc5hip_engine *e, int stream, long long n, int16_t *out)
 {
     int rc = check_stream(e, stream); if (rc) return rc;
@@ -941,8 +1012,9 @@ extern "C" int nrsc5hip_reset_all(nrsc5hip_engine *e)
     std::fill(e->base_host.begin(), e->base_host.end(), 0);
     std::fill(e->drained.begin(), e->drained.end(), 0);
     HIPCHK(hipMemset(e->db.pids_rec, 0xff, S * NWIN * 16 * sizeof(int)));
+    HIPCHK(hipMemset(e->db.px_job, 0xff, S * NWIN * 16 * sizeof(PxJob)));
     for (int l = 0; l < e->nlanes; l++) {
-        e->lanes[l].acq_needed = true; e->lanes[l].step_count = 0;
+        e->lanes[l].acq_needed = true; e->lanes[l].px_needed = true; e->lanes[l].step_count = 0;
         for (int k = 0; k < NWIN; k++) e->lanes[l].decoded_pending[k] = false;
     }
     return 0;

@@ -20,23 +20,6 @@ __device__ inline int stream_of(const int *ids, int idx) { return ids ? ids[idx]
 constexpr int NREF_MAX = 30;          // 15 per sideband (14 partitions + 1)
 constexpr int CFO_LO = -2 * PW, CFO_HI = 2 * PW;   // candidates -38..37 (sync.c:294)
 
-// PSMI -> partitions per sideband (sync.c:29-35, 343-358)
-__device__ inline int partitions_for_psmi(int psmi)
-{
-    const int m6 = psmi & 63, low = m6 & 15;
-    // compatibility_mode[]: 0,1,2,3,1,5,6,5,6,1,2,11,1,5,6,5 then the same 16 entries repeating with [16k] = 6;
-    // one nibble per entry
-    constexpr unsigned long long TAB16 = 0x5651B21656513210ull;
-    int mode = (int)((TAB16 >> (4 * low)) & 15ull);
-    if (low == 0 && m6 != 0) mode = 6;
-    switch (mode) {
-    case 2: return 11;
-    case 3: return 12;
-    case 5: case 6: case 11: return 14;
-    default: return 10;
-    }
-}
-
 __device__ inline int ref_bin(int r) { const int i = r >> 1; return (r & 1) ? UB1 - PW * i : LB0 + PW * i; }
 
 // sync word used to resolve the pi ambiguity (sync.c:96-99): +1 / -1 masks over the 32 symbols
@@ -170,6 +153,20 @@ __device__ __forceinline__ void store_soft(int8_t *pm_blk, float2 v, int side, i
     *(char2 *)(pm_blk + n * 720 + part20 * 36 + (k - 1) * 2) = o;
 }
 
+// extended partitions (sync.c:537-596): cell (side, part >= 10, n, k) -> PX1 (1 partition per sideband in MP2, 2 in
+// MP3 / MP11) or PX2 (2 more in MP11, where BOTH sidebands use the lower sideband's gain -- the reference's quirk)
+__device__ __forceinline__ void store_px(int8_t *pair, float2 v, int side, int part, int n, int k, int ppb, int odd, float mult_lb, float mult_ub)
+{
+    const int nx1 = ppb == 11 ? 1 : 2;
+    const int ch = (part - PM_PART) >= nx1 ? 1 : 0;
+    const int count = ch ? 2 : nx1, q = part - PM_PART - (ch ? 2 : 0);
+    const int per_sym = 72 * count, len = NSYM * per_sym;
+    const int idx = side ? 36 * count + (count - 1 - q) * 36 + (k - 1) * 2 : q * 36 + (k - 1) * 2;
+    const float mult = (side && !ch) ? mult_ub : mult_lb;
+    char2 o; o.x = (signed char)soft_bit(v.x, mult); o.y = (signed char)soft_bit(v.y, mult);
+    *(char2 *)(pair + (size_t)ch * 2 * PX_MAX + odd * len + n * per_sym + idx) = o;
+}
+
 __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare)
 {
     wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
@@ -255,6 +252,7 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
                     rec.flags |= REC_TO_FINE;
                     st.sync_state = SYNC_FINE;
                     st.started_pm = 0;                         // decode_reset (decode.c:563-572)
+                    st.px_pos = 0; st.px_ready = 0; st.px_started = 0;   // interleaver_iv_reset
                     action = 1;
                 }
             } else if (st.cfo_wait == 0) {
@@ -331,6 +329,10 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
     // ---- FINE: equalise, measure, demodulate (sync.c:425-609)
     if (st.sync_state == SYNC_FINE) {
         const int bc = st.bc;
+        // The block that achieves lock keeps equalising with the partition count of the PREVIOUS service mode (computed at
+        // the top of sync_process_fm, sync.c:343-358) but already routes PX soft bits by the new one (sync.c:537-596).
+        const int ppb_px = partitions_for_psmi(st.psmi);
+        const bool px_on = ppb_px > PM_PART && (st.px_started || (bc & 1) == 0);   // decode_push_px1/2 (decode.c:393-437)
         for (int k = tid; k < nref * NSYM; k += 256) {
             const int r = k / NSYM, n = k % NSYM;
             float sn, cs; sincosf(refph[r][n], &sn, &cs);
@@ -431,6 +433,16 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
                 int k, n, part, side;
                 cell_coords<0>(c, ppb, side, part, n, k);
                 if (part < PM_PART) store_soft(pm_blk, equalise_cell<0>(c, ppb, bins, refcs, smag, side), side, part, n, k, mult_lb, mult_ub);
+                else if (px_on && part < ppb_px) store_px(db.px_pair + (size_t)s * 4 * PX_MAX, equalise_cell<0>(c, ppb, bins, refcs, smag, side), side, part, n, k, ppb_px, bc & 1, mult_lb, mult_ub);
+            }
+        }
+        if (px_on && ppb_px > ppb) {
+            // lock block only: extended partitions that were not equalised yet -- the reference demodulates the raw bins
+            const int p0 = ppb > PM_PART ? ppb : PM_PART, np = ppb_px - p0;
+            for (int c = tid; c < 2 * np * NSYM * 18; c += 256) {
+                const int k = 1 + c % 18, n = (c / 18) % NSYM, part = p0 + (c / (18 * NSYM)) % np, side = c / (18 * NSYM * np);
+                const int b = (side ? UB1 - PW * (part + 1) : LB0 + PW * part) + k;
+                store_px(db.px_pair + (size_t)s * 4 * PX_MAX, bins[n * LIVE_N + bin_to_live(b)], side, part, n, k, ppb_px, bc & 1, mult_lb, mult_ub);
             }
         }
         __threadfence_block();
@@ -454,6 +466,20 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
                 st.p1_pending[parity] = 1; st.p1_slot[parity] = slot; st.p1_record[parity] = st.nblocks % db.rec_cap;
                 st.p1_pmslot[parity] = pm_slot;
                 rec.p1_slot = slot; rec.flags |= REC_P1;
+            }
+            if (ppb_px > PM_PART) {
+                if ((bc & 1) == 0) st.px_started = 1;
+                if (st.px_started && (bc & 1)) {
+                    // a block pair is complete: k_px_deint runs interleaver IV next; frames appear once it has wrapped
+                    st.px_go = NSYM * 72 * (ppb_px == 11 ? 1 : 2);
+                    st.px_nch = ppb_px == 14 ? 2 : 1;
+                    st.px_record = st.nblocks % db.rec_cap;
+                    if (st.px_ready || st.px_pos == 32 * st.px_go) {
+                        st.px_slot = st.px_count % db.px_slots; st.px_count++;
+                        rec.sis = (uint32_t)st.px_slot;
+                        rec.flags |= REC_P3 | (ppb_px == 14 ? (uint32_t)REC_P4 : 0u);
+                    } else st.px_slot = -1;
+                }
             }
             st.bc = (bc + 1) % 16;
             st.last_pm_slot = pm_slot;
@@ -514,6 +540,91 @@ __global__ __launch_bounds__(64) void k_pids_decode(DevTables tb, DevBuffers db,
 void launch_pids_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int nslots, hipStream_t st)
 {
     hipLaunchKernelGGL(k_pids_decode, dim3(nslots, nstreams), dim3(64), 0, st, tb, db, stream_ids, parity);
+}
+
+// ---- extended sidebands: interleaver IV (decode.c:344-376) for a completed block pair ----------------------------
+// The interleaver is convolutional: the bit read at position i of a pair was written delay[i] positions earlier
+// (1..N, N = 32 blocks), either earlier in this pair (take it from the pair buffer) or in the memory.  All reads of a
+// pair happen before its writes, as in the reference's read-then-write loop, by splitting the pass at a barrier.
+__global__ __launch_bounds__(1024) void k_px_deint(DevTables tb, DevBuffers db, const int *ids, int parity, int slot)
+{
+    const int s = stream_of(ids, blockIdx.y), ch = blockIdx.x;
+    StreamState &st = db.state[s];
+    const int len = st.px_go;                                  // block-uniform
+    if (len == 0 || ch >= st.px_nch) return;
+    const int N = 32 * len, tid = threadIdx.x;
+    int I = st.px_pos, ready = st.px_ready;
+    if (I == N) { I = 0; ready = 1; }
+    const uint32_t *delay = len == PX_MAX ? tb.px_delay_wide : tb.px_delay_narrow;
+    int8_t *mem = db.px_mem + ((size_t)s * 2 + ch) * PX_MEM;
+    const int8_t *pair = db.px_pair + ((size_t)s * 2 + ch) * 2 * PX_MAX;
+    int8_t *stage = db.px_stage + ((((size_t)s * NWIN + parity) * 8 + (slot >> 1)) * 2 + ch) * PX_DEPUNCT;
+    int8_t vals[2 * PX_MAX / 1024];
+#pragma unroll
+    for (int r = 0; r < 2 * PX_MAX / 1024; r++) {
+        const int i = tid + 1024 * r;
+        vals[r] = 0;
+        if (i < 2 * len) {
+            const int d = (int)delay[i];
+            vals[r] = d <= i ? pair[i - d] : mem[(I + i - d + N) % N];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 2 * PX_MAX / 1024; r++) {
+        const int i = tid + 1024 * r;
+        if (i < 2 * len) {
+            mem[I + i] = pair[i];
+            const int o = (i >> 2) * 6 + (i & 3) + ((i & 3) >= 1) + ((i & 3) >= 3);   // kept positions 0, 2, 3, 5 of [1,0,1,1,0,1]
+            stage[o] = vals[r];
+            if ((i & 3) == 0) { stage[o + 1] = 0; stage[o + 4] = 0; }
+        }
+    }
+    if (tid == 0) {
+        PxJob &job = db.px_job[(((size_t)s * NWIN + parity) * 8 + (slot >> 1)) * 2 + ch];
+        job.rec = ready ? st.px_record : -1; job.slot = st.px_slot; job.len = len; job.pad = 0;
+    }
+}
+
+// both channels read px_pos / px_ready above; advance them once both are done
+__global__ void k_px_commit(DevBuffers db, const int *ids, int nstreams)
+{
+    const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= nstreams) return;
+    StreamState &st = db.state[stream_of(ids, sidx)];
+    if (st.px_go == 0) return;
+    const int N = 32 * st.px_go;
+    if (st.px_pos == N) { st.px_pos = 0; st.px_ready = 1; }
+    st.px_pos += 2 * st.px_go;
+    st.px_go = 0;
+}
+
+void launch_px_deint(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_px_deint, dim3(2, nstreams), dim3(1024), 0, st, tb, db, stream_ids, parity, slot);
+    hipLaunchKernelGGL(k_px_commit, dim3((nstreams + 63) / 64), dim3(64), 0, st, db, stream_ids, nstreams);
+}
+
+// ---- staged P3 / P4 frames: K=7 Viterbi (nrsc5_conv_decode_p3_p4), descramble (decode.c:407-409,430-432) --------
+__global__ __launch_bounds__(64) void k_px_decode(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id)
+{
+    const int s = stream_of(ids, blockIdx.y), j = blockIdx.x;   // j = pair slot * 2 + channel
+    PxJob &job = db.px_job[((size_t)s * NWIN + parity) * 16 + j];
+    if (job.rec < 0) return;                                   // wave-uniform
+    const int len = job.len, ch = j & 1;
+    const int8_t *coded = db.px_stage + (((size_t)s * NWIN + parity) * 16 + j) * PX_DEPUNCT;
+    unsigned long long *dec = db.px_dec + (((size_t)lane_id * db.nstreams_alloc + s) * 16 + j) * (PX_MAX + 64);
+    uint32_t *out = db.px_ring + (((size_t)s * db.px_slots + job.slot) * 2 + ch) * PX_WORDS;
+    viterbi_k7_decode(coded, len, dec, out);
+    __threadfence_block();
+    __syncthreads();
+    for (int w = threadIdx.x; w < len / 32; w += 64) out[w] ^= tb.scr_p1[w];
+    if (threadIdx.x == 0) job.rec = -1;
+}
+
+void launch_px_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_px_decode, dim3(16, nstreams), dim3(64), 0, st, tb, db, stream_ids, parity, lane_id);
 }
 
 }  // namespace nrsc5

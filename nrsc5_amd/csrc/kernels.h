@@ -14,6 +14,8 @@ struct DevTables {
     const float *shape;              // [2160] pulse shape (acquire.c:322-331)
     const int16_t *hb_q15;           // [4]  half-band taps, window order
     const int16_t *acq_q15;          // [17] acquisition FIR taps, [1..16] used
+    const uint32_t *px_delay_wide;   // [9216] interleaver IV write-to-read delay per position of a block pair, MP3 / MP11
+    const uint32_t *px_delay_narrow; // [4608] same for MP2
     const int16_t *am_acq_q15;       // [17] AM acquisition FIR taps (acquire.c:63-96)
     const float *am_shape;           // [270] AM pulse shape (acquire.c:333-342)
     const float2 *am_twiddle;        // [256] e^{-2 pi i k / 256}
@@ -40,6 +42,14 @@ struct DevBuffers {
     int rec_cap;
     int *counters;                   // [0]: streams that processed a block this step, [1]: not-FINE streams
     long long *sync_phase_cycles;    // [8] optional: accumulated shader cycles per k_sync phase (stream 0 only), or null
+    // extended sidebands
+    int8_t *px_mem;                  // [S][2][PX_MEM]           interleaver IV memories of PX1, PX2
+    int8_t *px_pair;                 // [S][2][2 * PX_MAX]       soft bits of the current block pair
+    int8_t *px_stage;                // [S][NWIN][8][2][PX_DEPUNCT]  depunctured trellis inputs awaiting k_px_decode
+    PxJob *px_job;                   // [S][NWIN][8][2]
+    unsigned long long *px_dec;      // [NAUX][S][16][PX_MAX + 64] survivor decisions
+    uint32_t *px_ring;               // [S][px_slots][2][PX_WORDS]
+    int px_slots;
     // AM (null unless the engine was created with am_enable)
     AmStream *am;                    // [S]
     uint8_t *am_sym;                 // [S][4][AM_SYMS]   hard symbols of the current L1 frame: pl, pu, s, t
@@ -62,6 +72,9 @@ void launch_prepare(const DevBuffers &db, int nstreams, const int *stream_ids, h
 void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
 void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, hipStream_t st);
 void launch_pids_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int nslots, hipStream_t st);
+// extended sidebands: interleaver IV for streams whose block pair just completed (after k_sync), and the staged P3/P4 decodes
+void launch_px_deint(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, hipStream_t st);
+void launch_px_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st);
 void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st);
 
 // ---- AM path (k_am.hip) -------------------------------------------------------------------------

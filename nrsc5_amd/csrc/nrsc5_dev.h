@@ -31,6 +31,12 @@ constexpr int NWIN = 8;                // decode windows (16 block steps each) t
 constexpr int NPM = NWIN + 3;           // soft-bit matrices per stream: a frame's matrix must outlive its (deferred) decode
 constexpr int NAUX = 5;                // HIP streams that decode windows concurrently (each with its own decision scratch)
 
+// ---- extended sidebands PX1 / PX2 -> P3 / P4 (defines.h:50-52, decode.h:9-17) ----
+constexpr int PX_MAX = 4608;                    // soft bits per block from 2 extended partitions per sideband = P3 frame bits (MP3 / MP11)
+constexpr int PX_MEM = 32 * PX_MAX;             // interleaver IV memory (147456)
+constexpr int PX_WORDS = PX_MAX / 32;           // 144 packed words per P3 / P4 frame
+constexpr int PX_DEPUNCT = 3 * PX_MAX;          // 13824
+
 // ---- AM (defines.h:13-38,44-60) ----
 constexpr int AM_FFT = 256;
 constexpr int AM_CP = 14;
@@ -68,7 +74,8 @@ enum : uint32_t {
     REC_PIDS        = 1u << 4,   // a PIDS frame was decoded
     REC_P1          = 1u << 5,   // this block completed an L1 frame: P1 frame slot valid
     REC_LOST_SYNC   = 1u << 6,   // the block started from a host-forced NONE while FINE (input.c:177)
-    REC_P3          = 1u << 7,   // AM: this block (bc 7) also completed a P3 frame
+    REC_P3          = 1u << 7,   // a P3 frame completed (FM: odd blocks once the PX1 interleaver is primed, slot in `sis`; AM: block 7)
+    REC_P4          = 1u << 8,   // FM MP11: a P4 frame completed (same slot)
 };
 
 // One per (stream, processed block).  Plain-old-data, mirrored by include/nrsc5hip.h.
@@ -83,8 +90,11 @@ struct BlockRecord {
     int32_t p1_slot;            // index into the stream's P1 frame ring, or -1
     int32_t bc_decoded;         // block count the soft bits were filed under
     uint32_t pids[3];           // 80 descrambled PIDS bits, bit i at word i/32 bit i%32
-    uint32_t sis;               // AM: pli | hppi << 1 | aabi << 2 | rdbi << 3 (EVENT_SYNC payload), bit 4 = valid
+    uint32_t sis;               // AM: pli | hppi << 1 | aabi << 2 | rdbi << 3 (EVENT_SYNC payload), bit 4 = valid; FM: P3/P4 frame slot
 };
+
+// one staged P3 / P4 decode (filled by k_px_deint, consumed by k_px_decode)
+struct PxJob { int rec, slot, len, pad; };                      // rec < 0: empty
 
 // Per-stream device-resident state ("the checkpoint").
 struct StreamState {
@@ -124,6 +134,11 @@ struct StreamState {
     int pm_slot;                // matrix being filled; advances after every block 15
     int last_pm_slot;           // matrix that received the most recent block (debug fetch)
     int mode;                   // MODE_FM / MODE_AM (nrsc5_set_mode)
+    // extended-sideband interleavers (interleaver_iv_t, decode.h:9-17): both channels advance in lock step
+    int px_pos, px_ready, px_started;
+    int px_count;               // block pairs that produced frames so far (ring slot)
+    int px_go;                  // this step: soft bits per block of a completed pair (0: nothing to de-interleave)
+    int px_nch, px_slot, px_record;
 };
 
 // AM-only per-stream state (allocated when the engine is created with am_enable)

@@ -7,12 +7,30 @@
 
 namespace nrsc5 {
 
+// PSMI -> partitions per sideband (sync.c:29-35, 343-358)
+__device__ inline int partitions_for_psmi(int psmi)
+{
+    const int m6 = psmi & 63, low = m6 & 15;
+    // compatibility_mode[]: 0,1,2,3,1,5,6,5,6,1,2,11,1,5,6,5 then the same 16 entries repeating with [16k] = 6;
+    // one nibble per entry
+    constexpr unsigned long long TAB16 = 0x5651B21656513210ull;
+    int mode = (int)((TAB16 >> (4 * low)) & 15ull);
+    if (low == 0 && m6 != 0) mode = 6;
+    switch (mode) {
+    case 2: return 11;
+    case 3: return 12;
+    case 5: case 6: case 11: return 14;
+    default: return 10;
+    }
+}
+
 __device__ inline bool window_ready(const StreamState &st) { return st.wr - st.rd >= WIN_N; }
 
 __device__ inline void prepare_block(const DevBuffers &db, StreamState &st, int s)
 {
     if (st.active) return;                                     // already prepared (fused into the previous k_sync)
     if (st.sync_state != SYNC_FINE) atomicAdd(&db.counters[1], 1);   // host: keep launching acquisition
+    if (st.sync_state != SYNC_FINE || partitions_for_psmi(st.psmi) > PM_PART) atomicAdd(&db.counters[2], 1);   // ... and the PX kernels
     st.active = window_ready(st) ? 1 : 0;
     if (!st.active) return;
     atomicAdd(&db.counters[0], 1);

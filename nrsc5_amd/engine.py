@@ -12,7 +12,8 @@ DEFAULT_LIB = os.path.join(_HERE, "libnrsc5hip.so")
 
 SYNC_NONE, SYNC_COARSE, SYNC_FINE = 0, 1, 2
 REC_PROCESSED, REC_TO_COARSE, REC_TO_FINE, REC_MER, REC_PIDS, REC_P1 = 1, 2, 4, 8, 16, 32
-REC_P3 = 128
+REC_P3, REC_P4 = 128, 256
+PX_WORDS = 144
 MODE_FM, MODE_AM = 0, 1
 AM_P1_BITS, AM_P1_WORDS, AM_P3_WORD0 = 3750, 118, 944
 P1_BITS, P1_WORDS, PIDS_BITS = 146176, 4568, 80
@@ -53,6 +54,8 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.nrsc5hip_push_cs16.argtypes = [vp, ci, vp, ctypes.c_uint32]
     lib.nrsc5hip_stream_reset.argtypes = [vp, ci]
     lib.nrsc5hip_force_resync.argtypes = [vp, ci]
+    lib.nrsc5hip_px_frame_bits.argtypes = [vp, ci, ci, ci, ci, vp]
+    lib.nrsc5hip_batch_fetch_px.argtypes = [vp, ci, vp, vp]
     lib.nrsc5hip_stream_set_mode.argtypes = [vp, ci, ci]
     lib.nrsc5hip_am_frame_bits.argtypes = [vp, ci, ci, ci, ci, vp]
     lib.nrsc5hip_stage_viterbi_k9.argtypes = [vp, vp, ci, ci, vp, vp]
@@ -86,7 +89,8 @@ EXPORTED_SYMBOLS = [
     "nrsc5hip_p1_frame_packed", "nrsc5hip_p1_frame_bits", "nrsc5hip_batch_fetch", "nrsc5hip_unpack_bits",
     "nrsc5hip_stage_halfband_fm_cu8", "nrsc5hip_stage_fft2048", "nrsc5hip_stage_viterbi_k7", "nrsc5hip_debug_fetch",
     "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_batch_fetch_view",
-    "nrsc5hip_stream_set_mode", "nrsc5hip_am_frame_bits", "nrsc5hip_stage_viterbi_k9"]
+    "nrsc5hip_stream_set_mode", "nrsc5hip_am_frame_bits", "nrsc5hip_stage_viterbi_k9", "nrsc5hip_px_frame_bits",
+    "nrsc5hip_batch_fetch_px", "nrsc5hip_debug_fetch_px"]
 
 
 def unpack_bits(words: np.ndarray, nbits: int) -> np.ndarray:
@@ -189,6 +193,18 @@ class Engine:
         self._check(self.lib.nrsc5hip_p1_frame_bits(self._h, stream, slot, bits.ctypes.data))
         return bits
 
+    def px_frame_bits(self, stream: int, slot: int, channel: int, nbits: int) -> np.ndarray:
+        """FM extended sidebands: channel 0 = P3, 1 = P4; nbits 2304 (MP2) or 4608 (MP3 / MP11)."""
+        bits = np.zeros(nbits, dtype=np.uint8)
+        self._check(self.lib.nrsc5hip_px_frame_bits(self._h, stream, slot, channel, nbits, bits.ctypes.data))
+        return bits
+
+    def batch_fetch_px(self, nstreams: int, stream_ids=None) -> np.ndarray:
+        ids = None if stream_ids is None else np.ascontiguousarray(stream_ids, dtype=np.int32)
+        out = np.zeros((nstreams, 8 * self.p1_slots, 2, PX_WORDS), dtype=np.uint32)
+        self._check(self.lib.nrsc5hip_batch_fetch_px(self._h, nstreams, None if ids is None else ids.ctypes.data, out.ctypes.data))
+        return out
+
     def am_frame_bits(self, stream: int, slot: int, which: int, nbits: int) -> np.ndarray:
         """AM: which = 0..7 -> P1 frame of that block (3750 bits), 8 -> the P3 frame (24000 / 30000 bits)."""
         bits = np.zeros(nbits, dtype=np.uint8)
@@ -272,6 +288,12 @@ class Engine:
         self._check(self.lib.nrsc5hip_stage_selftest(self._h, ctypes.byref(n)))
         return n.value
 
+    def debug_fetch_px(self, stream: int) -> np.ndarray:
+        out = np.zeros((2, 2, 4608), dtype=np.int8)
+        self.lib.nrsc5hip_debug_fetch_px.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        self._check(self.lib.nrsc5hip_debug_fetch_px(self._h, stream, out.ctypes.data))
+        return out
+
     def debug_fetch(self, stream: int):
         pm = np.zeros(16 * 23040, dtype=np.int8)
         bins = np.zeros((32, 534), dtype=np.complex64)
@@ -318,7 +340,7 @@ def am_records_to_log(engine: Engine, stream: int, recs: np.ndarray, frames: np.
     return out
 
 
-def records_to_log(engine: Engine, stream: int, recs: np.ndarray, frames: np.ndarray | None = None):
+def records_to_log(engine: Engine, stream: int, recs: np.ndarray, frames: np.ndarray | None = None, px_frames: np.ndarray | None = None):
     """Expand block records into the ordered event list used by the oracle/reference harness logs
     (oracle/ref.py: parse_log), i.e. the order in which the reference fires them inside one
     acquire_process call."""
@@ -341,6 +363,14 @@ def records_to_log(engine: Engine, stream: int, recs: np.ndarray, frames: np.nda
             else:
                 bits = engine.p1_frame_bits(stream, int(r["p1_slot"]))
             out.append(("frame", {"lc": 0, "bits": bits}))
+        for flag, ch in ((REC_P3, 0), (REC_P4, 1)):           # decode_push_px1 / px2 (decode.c:393-437)
+            if fl & flag:
+                nbits = 2304 if int(r["psmi"]) == 2 else 4608
+                if px_frames is not None:
+                    bits = unpack_bits(px_frames[int(r["sis"]), ch], nbits)
+                else:
+                    bits = engine.px_frame_bits(stream, int(r["sis"]), ch, nbits)
+                out.append(("frame", {"lc": 1 + ch, "bits": bits}))
         blk = {k: (float(r[k]) if RECORD_DTYPE[k].kind == "f" else int(r[k]))
                for k in ("state_before", "state_after", "samperr", "cfo", "keep", "bc", "psmi", "cfo_wait",
                          "next_samperr", "prev_angle", "phase_re", "phase_im", "next_angle")}

@@ -424,6 +424,13 @@ void orc_interleave_px(int8_t *mem, unsigned *pos, unsigned taken[4], int *ready
 static void px_push(orc_stream *s, int ch, const int8_t *soft, unsigned len, unsigned bc)
 {
     struct px_chan *x = &s->px[ch];
+    if (s->taps & ORC_TAP_SOFT) {
+        uint8_t *tmp = malloc(12 + len);
+        uint32_t h[3] = { (uint32_t)ch, bc, len };
+        memcpy(tmp, h, 12); memcpy(tmp + 12, soft, len);
+        log_rec(s, ORC_REC_PXSOFT, tmp, 12 + len);
+        free(tmp);
+    }
     if (bc % 2 == 0) x->started = 1;
     if (!x->started) return;
     memcpy(x->pair + len * (bc % 2), soft, len);

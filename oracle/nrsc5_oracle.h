@@ -31,7 +31,8 @@ enum { ORC_SYNC_NONE = 0, ORC_SYNC_COARSE = 1, ORC_SYNC_FINE = 2 };
 enum {
     ORC_REC_BLOCK = 1, ORC_REC_STATE, ORC_REC_SOFT, ORC_REC_PIDS, ORC_REC_FRAME, ORC_REC_SYNC,
     ORC_REC_LOST_SYNC, ORC_REC_MER, ORC_REC_BER, ORC_REC_HDC, ORC_REC_VIT,
-    ORC_REC_AMSYM                 /* AM: u32 bc + pl[800] + pu[800] + s[800] + t[800] hard symbols of one block */
+    ORC_REC_AMSYM,                /* AM: u32 bc + pl[800] + pu[800] + s[800] + t[800] hard symbols of one block */
+    ORC_REC_PXSOFT                /* FM: u32 channel (0 PX1, 1 PX2), u32 bc, u32 len + soft bits handed to decode_push_px1/px2 */
 };
 enum { ORC_TAP_Q15 = 1, ORC_TAP_FFT = 2, ORC_TAP_SOFT = 4 };
 

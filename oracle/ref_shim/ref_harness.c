@@ -20,7 +20,7 @@ enum {
 /* ordered log record kinds */
 enum {
     REC_BLOCK = 1, REC_STATE, REC_SOFT, REC_PIDS, REC_FRAME, REC_SYNC, REC_LOST_SYNC,
-    REC_MER, REC_BER, REC_HDC, REC_VIT, REC_AMSYM
+    REC_MER, REC_BER, REC_HDC, REC_VIT, REC_AMSYM, REC_PXSOFT
 };
 
 typedef struct { uint8_t *p; size_t len, cap; } gbuf;
@@ -111,6 +111,20 @@ void __wrap_decode_push_pl_pu_s_t(decode_t *st, const uint8_t *pl, const uint8_t
     }
     __real_decode_push_pl_pu_s_t(st, pl, pu, s, t, bc);
 }
+
+static void log_px(uint32_t ch, const int8_t *sbit, unsigned int len, unsigned int bc)
+{
+    if (!(g_taps & REFH_TAP_SOFT)) return;
+    uint8_t *tmp = malloc(12 + len);
+    uint32_t h[3] = { ch, bc, len };
+    memcpy(tmp, h, 12); memcpy(tmp + 12, sbit, len);
+    log_rec(REC_PXSOFT, tmp, 12 + len);
+    free(tmp);
+}
+void __real_decode_push_px1(decode_t *st, const int8_t *sbit, unsigned int len, unsigned int bc);
+void __wrap_decode_push_px1(decode_t *st, const int8_t *sbit, unsigned int len, unsigned int bc) { log_px(0, sbit, len, bc); __real_decode_push_px1(st, sbit, len, bc); }
+void __real_decode_push_px2(decode_t *st, const int8_t *sbit, unsigned int len, unsigned int bc);
+void __wrap_decode_push_px2(decode_t *st, const int8_t *sbit, unsigned int len, unsigned int bc) { log_px(1, sbit, len, bc); __real_decode_push_px2(st, sbit, len, bc); }
 
 void __real_pids_frame_push(pids_t *st, const uint8_t *bits);
 void __wrap_pids_frame_push(pids_t *st, const uint8_t *bits)

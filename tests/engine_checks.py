@@ -127,11 +127,11 @@ def check_golden_end_to_end(lib, name, captures):
     return log
 
 
-def check_oracle_end_to_end(lib, oracle, kw, soft_tol=1, garbage_frames_ok=False):
+def check_oracle_end_to_end(lib, oracle, kw, soft_tol=1, garbage_frames_ok=False, p1_async=False):
     from oracle import port
     cap = synth.fm_mp1_capture(**kw)
     ol, _, _ = oracle.run(cap.iq, taps=port.TAP_SOFT)
-    E, recs, log = run_capture(lib, cap)
+    E, recs, log = run_capture(lib, cap, p1_async=p1_async)
     diffs = common.compare_logs(common.strip_states(ol), common.strip_states(log))
     if garbage_frames_ok:
         bad_ber = [v["cber"] for k, v in ol if k == "ber"]
@@ -148,6 +148,15 @@ def check_oracle_end_to_end(lib, oracle, kw, soft_tol=1, garbage_frames_ok=False
         last = softs[-1]
         d = pm.reshape(16, 23040)[last["bc"]].astype(int) - last["bits"].astype(int)
         assert np.abs(d).max() <= soft_tol and (d != 0).mean() < 0.01
+    pxs = [v for k, v in ol if k == "pxsoft"]
+    if pxs and pxs[-1]["bc"] % 2 == 1:                        # extended sidebands: soft bits of the last block pair
+        px = E.debug_fetch_px(0)
+        nch = 1 + max(x["ch"] for x in pxs[-4:])
+        for v in pxs[-2 * nch:]:                              # the two blocks of the last pair, each channel
+            n = len(v["bits"])
+            got = px[v["ch"]].reshape(-1)[(v["bc"] % 2) * n:(v["bc"] % 2 + 1) * n]
+            d = got.astype(int) - v["bits"].astype(int)
+            assert np.abs(d).max() <= soft_tol and (d != 0).mean() < 0.01
     E.close()
     return log
 

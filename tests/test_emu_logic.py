@@ -56,6 +56,17 @@ def test_emu_api_edges(emu_lib):
     ec.check_api_edges(emu_lib)
 
 
+def test_emu_extended_sidebands_mp11(emu_lib, oracle):
+    """PX1 / PX2 -> interleaver IV -> P3 / P4 (MP11), in-order and through the deferred decode windows."""
+    kw = dict(n_frames=0, n_blocks=44, seed=5, mode="MP11", cfo_hz=50.0, offset=500, snr_db=25, fmt="cs16")
+    ec.check_oracle_end_to_end(emu_lib, oracle, kw)
+    ec.check_oracle_end_to_end(emu_lib, oracle, kw, p1_async=True)
+
+
+def test_emu_extended_sidebands_mp2(emu_lib, oracle):
+    ec.check_oracle_end_to_end(emu_lib, oracle, dict(n_frames=0, n_blocks=40, seed=6, mode="MP2", cfo_hz=-20.0, offset=777, snr_db=20))
+
+
 # ---- AM ------------------------------------------------------------------------------------------------------------
 def test_emu_am_viterbi_k9(emu_lib, oracle):
     ec.check_viterbi_k9(emu_lib, oracle, lens=(80, 3750), frames=2)

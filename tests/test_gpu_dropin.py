@@ -49,7 +49,7 @@ def test_dropin_public_api_am(name, captures):
     _compare_events(exp, got)
 
 
-@pytest.mark.parametrize("name", ["fm_cu8_cfo137", "fm_cu8_cfo-2400"])
+@pytest.mark.parametrize("name", ["fm_cu8_cfo137", "fm_cu8_cfo-2400", "fm_mp2_cu8"])
 def test_dropin_public_api_events_match_reference(name, captures):
     cap = captures(name)
     iq = np.ascontiguousarray(cap.iq)

@@ -91,6 +91,12 @@ def test_gpu_batch_equals_streaming(hip_lib, p1_async):
     ec.check_batch_equals_streaming(hip_lib, caps, p1_async=p1_async)
 
 
+def test_gpu_batch_equals_streaming_extended_modes(hip_lib):
+    caps = [synth.fm_mp1_capture(0, seed=50 + k, cfo_hz=c, offset=o, snr_db=20, n_blocks=nb, mode=m)
+            for k, (c, o, nb, m) in enumerate([(10.0, 100, 44, "MP11"), (-60.0, 3000, 41, "MP3"), (300.0, 0, 20, "MP1"), (0.0, 64, 40, "MP2")])]
+    ec.check_batch_equals_streaming(hip_lib, caps, p1_async=True)
+
+
 def test_gpu_small_fifo_compaction(hip_lib, captures):
     ec.check_small_fifo_compaction(hip_lib, "fm_cu8_cfo137", captures)
 
@@ -156,6 +162,19 @@ def test_gpu_full_size_truth_property(hip_lib):
             assert synth.crc12(bits) == int("".join(map(str, bits[68:80])), 2)
         ec._free_device(E, dev)
         E.close()
+
+
+# ---- extended sidebands: MP2 / MP3 / MP11 (PX1 / PX2 -> interleaver IV -> P3 / P4) -------------------------------------
+@pytest.mark.parametrize("mode,kw", [
+    ("MP2", dict(n_blocks=52, seed=31, cfo_hz=20.0, offset=300, snr_db=25)),
+    ("MP3", dict(n_blocks=54, seed=32, cfo_hz=-150.0, offset=500, snr_db=18, fmt="cs16")),
+    ("MP11", dict(n_blocks=52, seed=33, cfo_hz=0.0, offset=64, snr_db=14)),
+])
+@pytest.mark.parametrize("p1_async", [False, True])
+def test_gpu_extended_sidebands_oracle(hip_lib, oracle, mode, kw, p1_async):
+    log = ec.check_oracle_end_to_end(hip_lib, oracle, dict(n_frames=0, mode=mode, **kw), p1_async=p1_async)
+    assert sum(1 for k, v in log if k == "frame" and v["lc"] == 1) >= 2
+    assert (mode != "MP11") or sum(1 for k, v in log if k == "frame" and v["lc"] == 2) >= 2
 
 
 # ---- AM (config 5) --------------------------------------------------------------------------------------------------
