@@ -133,6 +133,15 @@ def check_oracle_end_to_end(lib, oracle, kw, soft_tol=1, garbage_frames_ok=False
     ol, _, _ = oracle.run(cap.iq, taps=port.TAP_SOFT)
     E, recs, log = run_capture(lib, cap, p1_async=p1_async)
     diffs = common.compare_logs(common.strip_states(ol), common.strip_states(log))
+    if kw.get("mode", "MP1") != "MP1":
+        # MP2/3/11: the Costas loops of the reference carriers that the new service mode adds start pulling in at lock;
+        # until they settle the extended partitions equalise to garbage whose error power is chaotic in the last ulp of
+        # libm.  The first EVENT_MER after lock (which averages those blocks) is therefore compared to 0.05 dB only.
+        a = [v for k, v in common.strip_states(ol) if k == "mer"][:1]
+        b = [v for k, v in common.strip_states(log) if k == "mer"][:1]
+        first = next((i for i, (k, _) in enumerate(common.strip_states(ol)) if k == "mer"), -1)
+        if a and b and all(abs(a[0][f] - b[0][f]) < 0.05 for f in ("lower", "upper")):
+            diffs = [d for d in diffs if not d.startswith(f"#{first} mer.")]
     if garbage_frames_ok:
         bad_ber = [v["cber"] for k, v in ol if k == "ber"]
         assert bad_ber and min(bad_ber) > 0.02, "expected an undecodable (false-lock) capture"
