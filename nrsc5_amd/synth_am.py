@@ -118,11 +118,19 @@ def _idx_tables():
     t["el"] = (_cell_index((3 * n + n // 3000) % 8, (n + n // 6000) % 750), n % 2)
     n = np.arange(24000)
     t["eu"] = (_cell_index((3 * n + n // 3000 + 2 * (n // 12000)) % 8, (n + n // 6000) % 750), n % 4)
+    # MA3 (decode.c:114-133): the tertiary / secondary partitions carry a second E1 code word like the primary pair
+    n = np.arange(18000)
+    t["ebl"] = (_cell_index((3 * n + 3) % 8, (n + n // 3000 + 3) % 750), n % 3)
+    t["eml"] = (_cell_index((3 * n + 3) % 8, (n + n // 3000 + 3) % 750), 3 + n % 3)
+    t["ebu"] = (_cell_index((3 * n) % 8, (n + n // 3000 + 2) % 750), n % 3)
+    t["emu"] = (_cell_index((3 * n) % 8, (n + n // 3000 + 2) % 750), 3 + n % 3)
     return t
 
 
 _IDX = _idx_tables()
-_SCR = synth.scrambler_sequence(P3_BITS)
+P3_BITS_MA3 = 30000
+P3_PDU_LEN_MA3 = (P3_BITS_MA3 - 24) // 8     # 3747
+_SCR = synth.scrambler_sequence(P3_BITS_MA3)
 
 
 def _set_bits(matrix: np.ndarray, key: str, bits: np.ndarray):
@@ -165,6 +173,31 @@ def _qam16(code):
 
 def _qpsk(code):
     return ((code & 1) - 0.5) + 1j * ((code >> 1) - 0.5)
+
+
+def block_spectrum_ma3(pl, pu, s, t, pids1, pids2, bc: int) -> np.ndarray:
+    """All-digital MA3 layout (sync.c:612-767 with psmi == 2): nothing is complementary; primary = +-(2..26), secondary =
+    +(28..52), tertiary = -(28..52), PIDS at -27 / +27, everything QAM64 except PIDS (QAM16)."""
+    x = np.zeros((BLKSZ, FFT), dtype=np.complex128)
+    c = FFT // 2
+    col = np.arange(25)
+    x[:, c - 2 - col] = -np.conj(LEVEL_PRIMARY * _qam64(pl))
+    x[:, c + 2 + col] = LEVEL_PRIMARY * _qam64(pu)
+    x[:, c + 28 + col] = LEVEL_PRIMARY * _qam64(s)
+    x[:, c - 28 - col] = -np.conj(LEVEL_PRIMARY * _qam64(t))
+    x[:, c - 27] = -np.conj(LEVEL_PIDS * _qam16(pids1))
+    x[:, c + 27] = LEVEL_PIDS * _qam16(pids2)
+    # The reference's acquisition filter (acquire.c:63-96) only passes carriers 53..81, which MA3 does not occupy: its
+    # cyclic-prefix correlation would never find symbol timing.  Test-vector aid: fixed QPSK filler in +-(57..81), which
+    # the MA3 demodulator ignores, gives the correlator something to lock to.
+    filler = ((((col * 7 + 3) % 4) & 1) - 0.5) + 1j * ((((col * 7 + 3) % 4) >> 1) - 0.5)
+    x[:, c + 57 + col] = 2.0 * filler
+    x[:, c - 57 - col] = 2.0 * np.conj(filler)
+    ref = 1j * LEVEL_REF * (reference_bits(bc, psmi=2).astype(np.float64) * 2 - 1)
+    x[:, c + 1] = ref
+    x[:, c - 1] = -np.conj(ref)
+    x[:, c] = LEVEL_CARRIER
+    return x
 
 
 def reference_bits(bc: int, psmi: int = 1) -> np.ndarray:
@@ -248,13 +281,14 @@ class AmCapture:
 
 
 def am_ma1_capture(n_frames: int, seed: int = 1, cfo_hz: float = 3.0, offset: int = 1000, noise: float = 0.5,
-                   fmt: str = "cs16", tail_samples: int = 1080, unit_lsb: float | None = None) -> AmCapture:
+                   fmt: str = "cs16", tail_samples: int = 1080, unit_lsb: float | None = None, mode: str = "MA1") -> AmCapture:
     """Hybrid-AM MA1 capture of n_frames L1 frames (8 blocks x 32 symbols each).  `noise` = per-sample complex
     noise sigma in primary QAM64 grid units; `unit_lsb` = LSBs per grid unit (default 100 for cs16, 0.8 for cu8)."""
     rng = np.random.default_rng(seed)
     oversample = 1 if fmt == "cs16" else 32
     fs = FS_CS16 if fmt == "cs16" else FS_CU8
-    coded_p1, p1_list, p3_list, pids_list, chunks = [], [], [], [], []
+    coded_p1, coded_p3, p1_list, p3_list, pids_list, chunks = [], [], [], [], [], []
+    ma3 = mode == "MA3"
     for f in range(n_frames):
         prng = np.random.default_rng(0xA11CE + 1000003 * seed + f)
         p1 = []
@@ -264,9 +298,14 @@ def am_ma1_capture(n_frames: int, seed: int = 1, cfo_hz: float = 3.0, offset: in
         p1 = np.stack(p1)
         c1 = _puncture(conv_encode_k9(p1 ^ _SCR[None, :P1_BITS], GENS_E1), PUNCT_E1).reshape(-1)      # 72000
         coded_p1.append(_split_p1(c1))
-        pdu3, _ = synth.make_audio_pdu(f, prng, nop=16, pdu_len=P3_PDU_LEN, stream_id=1)
-        p3 = frame_bits(pdu3, P3_BITS, 120, 992, 24)
-        el, eu = _split_p3(_puncture(conv_encode_k9(p3 ^ _SCR, GENS_E2), PUNCT_E2))
+        if not ma3:
+            pdu3, _ = synth.make_audio_pdu(f, prng, nop=16, pdu_len=P3_PDU_LEN, stream_id=1)
+            p3 = frame_bits(pdu3, P3_BITS, 120, 992, 24)
+            el, eu = _split_p3(_puncture(conv_encode_k9(p3 ^ _SCR[:P3_BITS], GENS_E2), PUNCT_E2))
+        else:
+            pdu3, _ = synth.make_audio_pdu(f, prng, nop=16, pdu_len=P3_PDU_LEN_MA3, stream_id=1)
+            p3 = frame_bits(pdu3, P3_BITS_MA3, 120, 1240, 24)
+            coded_p3.append(_split_p1(_puncture(conv_encode_k9(p3 ^ _SCR, GENS_E1), PUNCT_E1)))
         pids = np.stack([synth.pids_frame_bits(prng) for _ in range(BLOCKS_PER_FRAME)])
 
         pl = np.zeros(8 * 32 * 25, dtype=np.uint8); pu = np.zeros_like(pl)
@@ -275,12 +314,19 @@ def am_ma1_capture(n_frames: int, seed: int = 1, cfo_hz: float = 3.0, offset: in
         _set_bits(pl, "ml", ml); _set_bits(pu, "mu", mu)                    # main: this frame
         if f >= 3:                                                          # backup: content of 3 frames ago
             _set_bits(pl, "bl", coded_p1[f - 3][0]); _set_bits(pu, "bu", coded_p1[f - 3][2])
-        _set_bits(t, "el", el); _set_bits(s, "eu", eu)
+        if not ma3:
+            _set_bits(t, "el", el); _set_bits(s, "eu", eu)
+        else:
+            _, eml, _, emu = coded_p3[f]
+            _set_bits(t, "eml", eml); _set_bits(s, "emu", emu)
+            if f >= 3:
+                _set_bits(t, "ebl", coded_p3[f - 3][0]); _set_bits(s, "ebu", coded_p3[f - 3][2])
         pl = _with_training(pl, TRAIN_QAM64); pu = _with_training(pu, TRAIN_QAM64)
-        s = _with_training(s, TRAIN_QAM16); t = _with_training(t, TRAIN_QPSK)
+        s = _with_training(s, TRAIN_QAM64 if ma3 else TRAIN_QAM16); t = _with_training(t, TRAIN_QAM64 if ma3 else TRAIN_QPSK)
         for bc in range(BLOCKS_PER_FRAME):
             s1, s2 = pids_symbols(pids[bc])
-            chunks.append(ofdm_modulate(block_spectrum(pl[bc], pu[bc], s[bc], t[bc], s1, s2, bc), oversample))
+            spec = block_spectrum_ma3 if ma3 else block_spectrum
+            chunks.append(ofdm_modulate(spec(pl[bc], pu[bc], s[bc], t[bc], s1, s2, bc), oversample))
             pids_list.append(pids[bc])
         p1_list.append(p1); p3_list.append(p3)
     sig = np.concatenate(chunks)

@@ -37,6 +37,7 @@ GOLDEN_CASES = {
 GOLDEN_AM_CASES = {
     "am_cs16_cfo3": dict(n_frames=11, seed=21, cfo_hz=3.0, offset=777, fmt="cs16"),
     "am_cu8_cfo-150": dict(n_frames=10, seed=22, cfo_hz=-150.0, offset=40000, fmt="cu8"),
+    "am_ma3_cs16": dict(n_frames=8, seed=23, cfo_hz=-6.0, offset=2000, fmt="cs16", mode="MA3"),
 }
 AM_FRAME_BITS = {0: 3750, 1: 24000}
 
@@ -149,7 +150,9 @@ def am_log_to_arrays(log):
         "pids": np.packbits(np.array([v["bits"] for k, v in log if k == "pids"], dtype=np.uint8).reshape(-1, 80), axis=1, bitorder="little"),
         "frame_lc": np.array([v["lc"] for v in frames], dtype=np.uint8),
         "p1": np.packbits(np.array([v["bits"] for v in frames if v["lc"] == 0], dtype=np.uint8).reshape(-1, 3750), axis=1, bitorder="little"),
-        "p3": np.packbits(np.array([v["bits"] for v in frames if v["lc"] == 1], dtype=np.uint8).reshape(-1, 24000), axis=1, bitorder="little"),
+        "p3_bits": np.array([len(v["bits"]) for v in frames if v["lc"] == 1][:1], dtype=np.int32),
+        "p3": np.packbits(np.array([v["bits"] for v in frames if v["lc"] == 1], dtype=np.uint8).reshape(
+            -1, max([len(v["bits"]) for v in frames if v["lc"] == 1] + [8])), axis=1, bitorder="little"),
         "kinds": np.array([_KIND_CODE[k] for k, _ in log if k in _KIND_CODE], dtype=np.uint8),
     }
 
@@ -174,7 +177,8 @@ def am_arrays_to_log(a):
         elif kind == 5:
             lc = int(a["frame_lc"][nxt("frame")])
             key = "p1" if lc == 0 else "p3"
-            log.append(("frame", {"lc": lc, "bits": np.unpackbits(a[key][nxt(key)], bitorder="little")[:AM_FRAME_BITS[lc]]}))
+            nbits = AM_FRAME_BITS[lc] if lc == 0 or "p3_bits" not in a or not len(a["p3_bits"]) else int(a["p3_bits"][0])
+            log.append(("frame", {"lc": lc, "bits": np.unpackbits(a[key][nxt(key)], bitorder="little")[:nbits]}))
         elif kind == 6:
             v = a["sync"][nxt("sync")]
             log.append(("sync", {"freq_offset": float(v[0]), "psmi": int(v[1]), "pli": int(v[2]), "hppi": int(v[3]), "aabi": int(v[4]), "rdbi": int(v[5])}))

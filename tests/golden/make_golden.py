@@ -50,7 +50,10 @@ def main():
 def main_am():
     R = ref.RefLib(sse=False)
     Rs = ref.RefLib(sse=True)
+    only = [a for a in sys.argv[2:]]
     for name, kw in common.GOLDEN_AM_CASES.items():
+        if only and name not in only:
+            continue
         cap = synth_am.am_ma1_capture(**kw)
         log, q15, _ = R.run(cap.iq, mode=ref.MODE_AM, taps=ref.TAP_Q15 | ref.TAP_SOFT)
         log_sse, _, _ = Rs.run(cap.iq, mode=ref.MODE_AM, taps=ref.TAP_SOFT)
@@ -63,7 +66,7 @@ def main_am():
         arrs["q15_head"] = q15[:4096].copy()
         arrs["iq_sha"] = np.array(common.sha256(cap.iq))
         arrs["truth_p1"] = np.packbits(np.array(cap.p1_frames, dtype=np.uint8).reshape(-1, 3750), axis=1, bitorder="little")
-        arrs["truth_p3"] = np.packbits(np.array(cap.p3_frames, dtype=np.uint8).reshape(-1, 24000), axis=1, bitorder="little")
+        arrs["truth_p3"] = np.packbits(np.array(cap.p3_frames, dtype=np.uint8), axis=1, bitorder="little")
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrs)
         print(f"{name}: {len(arrs['block_int'])} blocks, {arrs['p1'].shape[0]} P1 + {arrs['p3'].shape[0]} P3 frames, "
               f"{arrs['pids'].shape[0]} PIDS, ber {arrs['ber'].tolist()}, sync {arrs['sync'].tolist()}, "

@@ -197,6 +197,7 @@ def test_gpu_am_golden_end_to_end(hip_lib, name, captures):
     dict(n_frames=9, seed=4, cfo_hz=200.0, offset=0),                 # integer carrier offset (acquire_cfo_adjust)
     dict(n_frames=9, seed=5, cfo_hz=-40.0, offset=9000, noise=2.0),
     dict(n_frames=2, seed=6, cfo_hz=10.0, offset=64 * 300 + 12, fmt="cu8"),
+    dict(n_frames=9, seed=8, cfo_hz=-6.0, offset=2000, mode="MA3"),    # all-digital layout, 30000-bit P3 frames
 ])
 def test_gpu_am_oracle_end_to_end(hip_lib, oracle, kw):
     ec.check_am_oracle_end_to_end(hip_lib, oracle, kw)

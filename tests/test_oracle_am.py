@@ -44,7 +44,8 @@ def test_am_golden_frames_equal_transmitted_truth(name):
     assert n1 >= 16 and n3 >= 2 and np.all(g["ber"] == 0)
     first = next(i for i in range(g["truth_p1"].shape[0]) if np.array_equal(g["truth_p1"][i], g["p1"][0]))
     assert first % 8 == 0 and np.array_equal(g["p1"], g["truth_p1"][first:first + n1])
-    f3 = first // 8 + 3
+    # MA1: the P3 code word is not diversity-delayed (decoded frame = the one just received); MA3: it is, like P1
+    f3 = first // 8 + (0 if name == "am_ma3_cs16" else 3)
     assert np.array_equal(g["p3"], g["truth_p3"][f3:f3 + n3])
 
 
@@ -58,7 +59,8 @@ def test_am_oracle_bit_identical_to_reference(sse, oracle):
     for kw in (dict(n_frames=10, seed=3, cfo_hz=3.0, offset=1234),
                dict(n_frames=7, seed=4, cfo_hz=200.0, offset=0),
                dict(n_frames=7, seed=5, cfo_hz=-40.0, offset=9000, noise=2.0),
-               dict(n_frames=2, seed=6, cfo_hz=10.0, offset=64 * 300 + 12, fmt="cu8")):
+               dict(n_frames=2, seed=6, cfo_hz=10.0, offset=64 * 300 + 12, fmt="cu8"),
+               dict(n_frames=9, seed=8, cfo_hz=-6.0, offset=2000, mode="MA3")):
         cap = synth_am.am_ma1_capture(**kw)
         rl, rq, rf = R.run(cap.iq, mode=ref.MODE_AM, taps=ref.TAP_Q15 | ref.TAP_SOFT | ref.TAP_FFT, fft_blocks=2)
         ol, oq, of = oracle.run(cap.iq, mode=1, taps=port.TAP_Q15 | port.TAP_SOFT | port.TAP_FFT, fft_blocks=2)
