@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--seconds", type=float, default=20.0, help="capture length per stream (SURVEY 8d: 20 s)")
     ap.add_argument("--payloads", type=int, default=8, help="distinct transmissions shared by the streams (each stream has its own CFO/offset/noise)")
     ap.add_argument("--sync-p1", action="store_true", help="decode P1 frames in order on the main stream (exact reference event timing) instead of the overlapped window pipeline")
+    ap.add_argument("--l2-feedback", type=int, default=1, help="1: the engine applies the reference's L2 -> L1 sync-loss feedback itself (RS check of the first L2 header on the device), as the CPU baseline's frame.c does; 0: off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
@@ -121,7 +122,7 @@ def main():
     total_samples_rank = float(nbytes.astype(np.float64).sum() / 2)
 
     E = eng.Engine(max_streams=S, q15_capacity=int(stride // 4 + 1024), record_capacity=max(256, 16 * n_frames + 32),
-                   p1_slots=n_frames + 1, p1_async=not args.sync_p1, device=local)
+                   p1_slots=n_frames + 1, p1_async=not args.sync_p1, device=local, l2_feedback=bool(args.l2_feedback))
 
     host_ms = {"reset": 0.0, "append": 0.0, "process": 0.0, "fetch": 0.0}
 
@@ -227,13 +228,13 @@ def main():
         "config": {"workload": f"configs[2]: batch={S} independent hybrid-FM MP1 cu8 streams @1.488375 MS/s per GPU, "
                                f"{nbytes[0] / 2 / FS:.2f} s each ({n_frames} L1 frames), CFO +-300 Hz, offset [0,4320), SNR 15/20/25 dB",
                    "streams_per_gpu": S, "seconds_per_stream": round(float(nbytes[0]) / 2 / FS, 3),
-                   "p1_decode": "in-order" if args.sync_p1 else "windowed-overlap", "block_steps_per_pass": int(block_steps),
+                   "p1_decode": "in-order" if args.sync_p1 else "windowed-overlap", "l2_feedback": "on-device" if args.l2_feedback else "off", "block_steps_per_pass": int(block_steps),
                    "distinct_payloads": args.payloads, "hbm_resident_input_GB": round(float(nbytes.sum()) / 1e9, 2)},
         "roofline": roofline, "cpu_baseline": cpu,
         "parity": {"streams": n_total, "streams_locked_and_all_p1_frames_equal_transmitted_bits": good,
                    "p1_frames_decoded": int(allrows[:, 2].sum()), "p1_frames_bit_exact_vs_truth": int(allrows[:, 3].sum()),
                    "pids_frames_decoded": int(allrows[:, 4].sum()),
-                   "note": "streams whose timing offset falls in the reference algorithm's false-lock zone (sync.c phase-slope ambiguity, ~10 % of uniform offsets) decode garbage in the reference too; they are parity-checked against the oracle in tests, not against truth"},
+                   "note": "streams whose timing offset falls in the reference algorithm's false-lock zone (sync.c phase-slope ambiguity, ~6 % of uniform offsets) decode one garbage frame in the reference too, whose L2 then forces a re-acquisition; with l2_feedback the engine does the same on the device (deferred decode: a few blocks later than the reference), without it such streams stay falsely locked"},
         "gen_seconds": round(t_gen, 1),
     }
     print(json.dumps(line))

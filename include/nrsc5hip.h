@@ -59,7 +59,7 @@ enum {
     NRSC5HIP_REC_MER       = 1u << 3,  /* nrsc5_report_mer(mer_lb, mer_ub) */
     NRSC5HIP_REC_PIDS      = 1u << 4,  /* pids_frame_push(pids) */
     NRSC5HIP_REC_P1        = 1u << 5,  /* nrsc5_report_ber(ber); frame_push(P1 frame in slot p1_slot) */
-    NRSC5HIP_REC_LOST_SYNC = 1u << 6,  /* reserved */
+    NRSC5HIP_REC_LOST_SYNC = 1u << 6,  /* l2_feedback only: after this block's frames the engine dropped the stream to NONE (nrsc5_report_lost_sync) */
     NRSC5HIP_REC_P3        = 1u << 7,  /* FM (MP2/MP3/MP11, odd blocks): frame_push(P3 frame of PX slot `sis`, 2304 or 4608 bits);
                                           AM, block 7: frame_push(P3 frame of slot p1_slot), then nrsc5_report_ber(ber) */
     NRSC5HIP_REC_P4        = 1u << 8   /* FM MP11: frame_push(P4 frame of PX slot `sis`, 4608 bits) */
@@ -101,6 +101,10 @@ typedef struct nrsc5hip_config {
                                   reference event timing; required for nrsc5hip_force_resync feedback);
                                   1: decode the frames of each 16-block window on a second HIP stream,
                                   overlapped with the next window (throughput mode) */
+    int l2_feedback;           /* 1: the engine itself applies the L2 -> L1 feedback of frame_process (frame.c:516-540): a P1 frame
+                                  whose first L2 header fails the RS(255,247) check drops the stream to SYNC_NONE (REC_LOST_SYNC).
+                                  Exact reference timing with p1_async = 0; with p1_async = 1 it takes effect when the deferred
+                                  decode completes.  0: the host does it through nrsc5hip_force_resync (the drop-in shim). */
     int am_enable;             /* allocate the AM buffers (1.4 MB per stream) so that streams may be switched to
                                   NRSC5HIP_MODE_AM */
 } nrsc5hip_config;

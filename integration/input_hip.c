@@ -168,7 +168,7 @@ void input_reset(input_t *st)
 void input_init(input_t *st, nrsc5_t *radio, output_t *output)
 {
     const char *dev = getenv("NRSC5HIP_DEVICE");
-    nrsc5hip_config cfg = { dev ? atoi(dev) : 0, 1, 1 << 20, 256, 4, 0 /* in-order P1: reference event timing */, 1 /* AM too */ };
+    nrsc5hip_config cfg = { dev ? atoi(dev) : 0, 1, 1 << 20, 256, 4, 0 /* in-order P1: reference event timing */, 0 /* L2 feedback comes from frame.c through input_set_sync_state */, 1 /* AM too */ };
     nrsc5hip_engine *e = NULL;
 
     memset(&st->acq, 0, sizeof(st->acq));

@@ -412,6 +412,7 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
         if (need > (int)e->dec_events.size()) need = (int)e->dec_events.size();
         for (; ln.dec_waited < need; ln.dec_waited++) HIPCHK(hipStreamWaitEvent(ln.main, e->dec_events[ln.dec_waited], 0));
     }
+    if (e->cfg.l2_feedback && !async) ln.acq_needed = true;   // an in-order P1 decode may send any stream back to NONE for the next block
     if (ln.acq_needed) { ProfScope p(e, NRSC5HIP_PROF_ACQUIRE, ln.main); launch_acquire(e->tb, ln.db, n, ids_dev, ln.main); }
     if (!ln.prepared_by_sync) { ProfScope p(e, NRSC5HIP_PROF_PREPARE, ln.main); launch_prepare(ln.db, n, ids_dev, ln.main); }
     { ProfScope p(e, NRSC5HIP_PROF_MIXFFT, ln.main); launch_mixfft(e->tb, ln.db, n, ids_dev, ln.main); }
@@ -419,14 +420,14 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
     // batch pipeline: once every stream of the lane is FINE, the next block's bookkeeping rides in k_sync's tail
     static const bool no_fuse = getenv("NRSC5HIP_NO_FUSE") != nullptr;
     const int fuse = (async && !ln.acq_needed && !no_fuse) ? 1 : 0;
-    { ProfScope p(e, NRSC5HIP_PROF_SYNC, ln.main); launch_sync(e->tb, ln.db, n, ids_dev, parity, slot, fuse, ln.main); }
+    { ProfScope p(e, NRSC5HIP_PROF_SYNC, ln.main); launch_sync(e->tb, ln.db, n, ids_dev, parity, slot, fuse, ln.main, ln.acq_needed ? 1 : 0); }
     ln.prepared_by_sync = fuse != 0;
     if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_px_deint(e->tb, ln.db, n, ids_dev, parity, slot, ln.main); }
     if (!async) {
         { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_pids_decode(e->tb, ln.db, n, ids_dev, parity, 1, ln.main); }
         if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_px_decode(e->tb, ln.db, n, ids_dev, parity, 0, ln.main); }
         ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ln.main);
-        launch_p1_viterbi(e->tb, ln.db, n, ids_dev, parity, 0, ln.main);
+        launch_p1_viterbi(e->tb, ln.db, n, ids_dev, parity, 0, ln.main, e->cfg.l2_feedback ? 1 : 0);
     } else if ((ln.step_count % 16) == 15) {
         // window complete: decode its PIDS frames and P1 frames on aux stream `lane`, overlapped with the next
         // windows (NAUX windows decode concurrently, each wave of the forward pass alone on a SIMD)
@@ -435,7 +436,7 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
         HIPCHK(hipStreamWaitEvent(ax, ln.ev_window[parity], 0));
         { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_pids_decode(e->tb, ln.db, n, ids_dev, parity, 16, ax); }
         if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_px_decode(e->tb, ln.db, n, ids_dev, parity, lane, ax); }
-        { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ax); launch_p1_viterbi(e->tb, ln.db, n, ids_dev, parity, lane, ax); }
+        { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ax); launch_p1_viterbi(e->tb, ln.db, n, ids_dev, parity, lane, ax, e->cfg.l2_feedback ? 2 : 0); }
         HIPCHK(hipEventRecord(ln.ev_decoded[parity], ax));
         ln.decoded_pending[parity] = true;
     }
@@ -456,7 +457,7 @@ static int flush_p1(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const 
         HIPCHK(hipStreamWaitEvent(ax, ln.ev_window[parity], 0));
         { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_pids_decode(e->tb, ln.db, n, ids_dev, parity, 16, ax); }
         if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_px_decode(e->tb, ln.db, n, ids_dev, parity, lane, ax); }
-        { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ax); launch_p1_viterbi(e->tb, ln.db, n, ids_dev, parity, lane, ax); }
+        { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ax); launch_p1_viterbi(e->tb, ln.db, n, ids_dev, parity, lane, ax, e->cfg.l2_feedback ? 2 : 0); }
         ln.step_count += 16 - (ln.step_count % 16);            // next batch starts a fresh window
     }
     for (int k = 0; k < NAUX; k++) HIPCHK(hipStreamSynchronize(ln.aux[k]));
@@ -515,7 +516,7 @@ static int run_steps_am(nrsc5hip_engine *e, int n, const int *ids_dev, int max_s
         int burst = 0;
         for (; burst < check_every && done + burst < max_steps; burst++) {
             ProfScope p(e, NRSC5HIP_PROF_AM, ln.main);
-            launch_am_step(e->tb, ln.db, n, ids_dev, ln.main);
+            launch_am_step(e->tb, ln.db, n, ids_dev, ln.main, e->cfg.l2_feedback);
         }
         HIPCHK(hipMemcpyAsync(ln.counters_host, ln.counters_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, ln.main));
         HIPCHK(hipStreamSynchronize(ln.main));

@@ -12,6 +12,7 @@
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 #include "wave_ops.h"
+#include "l2_header.h"
 
 namespace nrsc5 {
 
@@ -682,7 +683,7 @@ __global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, c
 }
 
 // ---- this block's P1 frame, and after block 7 the P3 frame (decode_process_p1_p3_am, decode.c:507-554) ----------
-__global__ __launch_bounds__(256) void k_am_viterbi(DevTables tb, DevBuffers db, const int *ids)
+__global__ __launch_bounds__(256) void k_am_viterbi(DevTables tb, DevBuffers db, const int *ids, int l2_feedback)
 {
     const int s = stream_of(ids, blockIdx.y);
     const StreamState &st = db.state[s];
@@ -703,10 +704,18 @@ __global__ __launch_bounds__(256) void k_am_viterbi(DevTables tb, DevBuffers db,
         const int err = am_bit_errors(in, out, AM_P1_LEN, GEN_E1_0, GEN_E1_1, GEN_E1_2, PUNCT_E1, 15, red);
         for (int w = threadIdx.x; w < AM_P1_WORDS; w += 256)     // descramble; the last word holds 6 frame bits
             out[w] = (out[w] ^ tb.scr_p1[w]) & (w == AM_P1_WORDS - 1 ? (1u << (AM_P1_LEN & 31)) - 1u : 0xffffffffu);
+        __threadfence_block();
+        __syncthreads();
         if (threadIdx.x == 0) {
             atomicAdd(&am.am_errors, (unsigned)err);
             atomicOr(&rec.flags, (uint32_t)REC_P1);
             rec.p1_slot = am.frame_slot;
+            if (l2_feedback) {                                 // frame.c:535-540 for the 466-byte AM PDU
+                __shared__ L2Smem l2;
+                l2_gf_init(l2);
+                StreamState &stw = db.state[s];
+                if (!l2_first_header_ok_am(out, l2) && stw.sync_state == SYNC_FINE) { stw.sync_state = SYNC_NONE; rec.state_after = SYNC_NONE; atomicOr(&rec.flags, (uint32_t)REC_LOST_SYNC); }
+            }
         }
     } else {
         const int8_t *in = db.am_vit + (size_t)s * 2 * AM_VIT + AM_VIT;
@@ -836,12 +845,12 @@ __global__ __launch_bounds__(1024) void k_am_interleave(DevBuffers db, const int
     }
 }
 
-void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st)
+void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int l2_feedback)
 {
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_am_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AmBlockSmem)); attr_set = true; }
     hipLaunchKernelGGL(k_am_block, dim3(nstreams), dim3(256), sizeof(AmBlockSmem), st, tb, db, stream_ids);
-    hipLaunchKernelGGL(k_am_viterbi, dim3(2, nstreams), dim3(256), 0, st, tb, db, stream_ids);
+    hipLaunchKernelGGL(k_am_viterbi, dim3(2, nstreams), dim3(256), 0, st, tb, db, stream_ids, l2_feedback);
     hipLaunchKernelGGL(k_am_interleave, dim3(nstreams), dim3(1024), 0, st, db, stream_ids);
 }
 

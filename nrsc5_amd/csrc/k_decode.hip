@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 #include "viterbi_wave.h"
+#include "l2_header.h"
 
 namespace nrsc5 {
 
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(64) void k_p1_forward(DevTables tb, DevBuffers db, 
 
 constexpr int TB_THREADS = 1024;
 
-__global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id)
+__global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id, int l2_mode)
 {
     const int s = stream_of(ids, blockIdx.x);
     StreamState &st = db.state[s];
@@ -106,19 +107,33 @@ __global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBu
     if ((tid & 63) == 0) atomicAdd(&err_total, errors);
     __syncthreads();
     for (int w = tid; w < P1_WORDS; w += blockDim.x) out[w] ^= tb.scr_p1[w];       // descramble
+    __threadfence_block();
+    __syncthreads();
     if (tid == 0) {
-        db.records[(size_t)s * db.rec_cap + st.p1_record[parity]].ber = (float)err_total / P1_CODED;  // decode.c:458
+        BlockRecord &rec = db.records[(size_t)s * db.rec_cap + st.p1_record[parity]];
+        rec.ber = (float)err_total / P1_CODED;                 // decode.c:458
+        if (l2_mode) {
+            // frame_process -> input_set_sync_state(NONE) when the first L2 header does not decode (frame.c:535-540).
+            // l2_mode 1: in-order decode on the main stream -> the very next block starts from NONE, as in the reference;
+            // l2_mode 2: deferred decode -> request it, k_sync applies it at the next block whose step runs the acquisition
+            __shared__ L2Smem l2;
+            l2_gf_init(l2);
+            if (!l2_first_header_ok_fm(out, l2)) {
+                if (l2_mode == 1) { if (st.sync_state == SYNC_FINE) { st.sync_state = SYNC_NONE; rec.state_after = SYNC_NONE; rec.flags |= REC_LOST_SYNC; } }
+                else st.force_none = 1;
+            }
+        }
         st.p1_pending[parity] = 0;
     }
 }
 
 static size_t traceback_smem(int len) { const int nchunks = len / 64 + 1; return (size_t)((nchunks + TB_SEG - 1) / TB_SEG) * 64 + nchunks; }
 
-void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st)
+void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st, int l2_mode)
 {
     hipLaunchKernelGGL(k_p1_deint, dim3(32, nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, lane_id);
     hipLaunchKernelGGL(k_p1_forward, dim3(nstreams), dim3(64), 0, st, tb, db, stream_ids, parity, lane_id);
-    hipLaunchKernelGGL(k_p1_traceback, dim3(nstreams), dim3(TB_THREADS), traceback_smem(P1_LEN), st, tb, db, stream_ids, parity, lane_id);
+    hipLaunchKernelGGL(k_p1_traceback, dim3(nstreams), dim3(TB_THREADS), traceback_smem(P1_LEN), st, tb, db, stream_ids, parity, lane_id, l2_mode);
 }
 
 // ---- stage-level entry: decode `nframes` independent frames of equal length (parity tests) ----------

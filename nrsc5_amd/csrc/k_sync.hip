@@ -167,7 +167,7 @@ __device__ __forceinline__ void store_px(int8_t *pair, float2 v, int side, int p
     *(char2 *)(pair + (size_t)ch * 2 * PX_MAX + odd * len + n * per_sym + idx) = o;
 }
 
-__global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare)
+__global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare, int acq_on)
 {
     wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
     const int s = stream_of(ids, blockIdx.x);
@@ -500,6 +500,11 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         rec.bc = st.bc; rec.psmi = st.psmi; rec.cfo_wait = st.cfo_wait; rec.next_samperr = st.samperr;
         rec.prev_angle = st.prev_angle; rec.phase_re = (float)cos(th); rec.phase_im = (float)sin(th);
         rec.next_angle = st.angle;
+        if (st.force_none && acq_on && st.sync_state == SYNC_FINE) {
+            // L2 feedback raised by a deferred P1 decode (l2_header.h): this step's successor runs the acquisition kernels
+            st.sync_state = SYNC_NONE; st.force_none = 0;
+            rec.flags |= REC_LOST_SYNC;
+        }
         st.nblocks++;
         st.active = 0;
         if (fuse_prepare) prepare_block(db, st, s);           // top of the NEXT block's acquire_process
@@ -507,9 +512,9 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
     SYNC_MARK(7);
 }
 
-void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, hipStream_t st)
+void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, hipStream_t st, int acq_on)
 {
-    hipLaunchKernelGGL(k_sync, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare);
+    hipLaunchKernelGGL(k_sync, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, acq_on);
 }
 
 // ---- deferred PIDS decode: one wave per (slot, stream) with a staged frame -----------------------------------

@@ -70,12 +70,12 @@ void launch_append_cs16(const DevBuffers &db, int nstreams, const int *stream_id
 void launch_acquire(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
 void launch_prepare(const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
 void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
-void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, hipStream_t st);
+void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, hipStream_t st, int acq_on = 0);
 void launch_pids_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int nslots, hipStream_t st);
 // extended sidebands: interleaver IV for streams whose block pair just completed (after k_sync), and the staged P3/P4 decodes
 void launch_px_deint(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, hipStream_t st);
 void launch_px_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st);
-void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st);
+void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st, int l2_mode = 0);
 
 // ---- AM path (k_am.hip) -------------------------------------------------------------------------
 // cu8 -> five cascaded half-bands 32:1, any nbytes % 4 == 0 per stream (stage phases carry over)
@@ -83,7 +83,7 @@ void launch_am_decimate_cu8(const DevTables &tb, const DevBuffers &db, int nstre
                             const uint8_t *iq_base, long long iq_stride, const unsigned *nbytes, unsigned max_nbytes, hipStream_t st);
 // one block step: acquire (or track) -> 2 x 32 FFT-256 -> sync_process_am -> PIDS; then this block's P1 / P3 decodes
 // and, after block 7, the bit de-interleaver of the finished L1 frame
-void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
+void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int l2_feedback = 0);
 void launch_viterbi_k9_frames(const int8_t *coded, int len, int nframes, unsigned g0, unsigned g1, unsigned g2,
                               unsigned long long *dec, uint32_t *out, hipStream_t st);
 

@@ -1,0 +1,132 @@
+// The one piece of L2 that feeds back into the hot path: frame_process drops the receiver to
+// SYNC_STATE_NONE when the first L2 header of a P1 frame fails its RS(255,247) check (frame.c:516-540).  With it on
+// the device the batch pipeline follows the reference through false locks without a host round trip.
+//   frame_push bit unpacking        frame.c:645-714      -> l2_extract_*
+//   has_audio / has_fixed           frame.c:138-151      -> l2_pci_wants_check
+//   fix_header                      frame.c:153-179      -> l2_header_codeword_ok
+//   decode_rs_char (libfec, vendored as src/rs_decode.c; init_rs_char(8, 0x11d, 1, 1, 8), frame.c:747)
+//                                                        -> rs255_247_decode: syndromes, Berlekamp-Massey, Chien,
+//                                                           Forney with the same accept / reject decisions
+// Single work-item code: ~6 k GF operations per frame, once per 2.2 M input samples.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nrsc5 {
+
+struct L2Smem { uint8_t gexp[512], glog[256], r[255], pdu[96]; };
+
+__device__ inline void l2_gf_init(L2Smem &g)                 // GF(256), x^8 + x^4 + x^3 + x^2 + 1
+{
+    unsigned x = 1;
+    for (int i = 0; i < 255; i++) { g.gexp[i] = (uint8_t)x; g.glog[x] = (uint8_t)i; x <<= 1; if (x & 0x100u) x ^= 0x11du; }
+    for (int i = 255; i < 512; i++) g.gexp[i] = g.gexp[i - 255];
+    g.glog[0] = 0;
+}
+__device__ inline unsigned l2_mul(const L2Smem &g, unsigned a, unsigned b) { return (a && b) ? g.gexp[g.glog[a] + g.glog[b]] : 0u; }
+__device__ inline unsigned l2_div(const L2Smem &g, unsigned a, unsigned b) { return a ? g.gexp[g.glog[a] + 255 - g.glog[b]] : 0u; }
+__device__ inline unsigned l2_alpha(const L2Smem &g, unsigned e) { return g.gexp[e % 255u]; }
+
+// g.r[0] = coefficient of x^254.  Returns the number of corrected symbols or -1 (g.r is corrected in place).
+__device__ inline int rs255_247_decode(L2Smem &g)
+{
+    unsigned S[8], any = 0;
+    for (int i = 0; i < 8; i++) {
+        const unsigned a = l2_alpha(g, (unsigned)(i + 1));
+        unsigned acc = g.r[0];
+        for (int j = 1; j < 255; j++) acc = l2_mul(g, acc, a) ^ g.r[j];
+        S[i] = acc; any |= acc;
+    }
+    if (!any) return 0;
+    unsigned lam[9], B[9], T[9];
+    for (int i = 0; i < 9; i++) { lam[i] = 0; B[i] = 0; }
+    lam[0] = 1; B[0] = 1;
+    int L = 0;
+    for (int step = 1; step <= 8; step++) {
+        unsigned delta = 0;
+        for (int i = 0; i < step; i++) delta ^= l2_mul(g, lam[i], S[step - 1 - i]);
+        if (!delta) { for (int i = 8; i > 0; i--) B[i] = B[i - 1]; B[0] = 0; continue; }
+        T[0] = lam[0];
+        for (int i = 0; i < 8; i++) T[i + 1] = lam[i + 1] ^ l2_mul(g, delta, B[i]);
+        if (2 * L <= step - 1) {
+            L = step - L;
+            for (int i = 0; i <= 8; i++) B[i] = l2_div(g, lam[i], delta);
+        } else { for (int i = 8; i > 0; i--) B[i] = B[i - 1]; B[0] = 0; }
+        for (int i = 0; i <= 8; i++) lam[i] = T[i];
+    }
+    int deg = 0;
+    for (int i = 0; i <= 8; i++) if (lam[i]) deg = i;
+    int root[8], count = 0;
+    for (int i = 1; i <= 255 && count < 8; i++) {
+        unsigned q = 1;
+        for (int j = 1; j <= deg; j++) q ^= l2_mul(g, lam[j], l2_alpha(g, (unsigned)(i * j)));
+        if (q) continue;
+        root[count] = i;
+        if (++count == deg) break;
+    }
+    if (count != deg) return -1;
+    unsigned om[8]; int deg_om = 0;
+    for (int i = 0; i < 8; i++) {
+        unsigned t = 0;
+        for (int j = (deg < i ? deg : i); j >= 0; j--) t ^= l2_mul(g, S[i - j], lam[j]);
+        om[i] = t; if (t) deg_om = i;
+    }
+    for (int k = count - 1; k >= 0; k--) {
+        unsigned num = 0, den = 0;
+        for (int i = deg_om; i >= 0; i--) num ^= l2_mul(g, om[i], l2_alpha(g, (unsigned)(i * root[k])));
+        for (int i = (deg < 7 ? deg : 7) & ~1; i >= 0; i -= 2) den ^= l2_mul(g, lam[i + 1], l2_alpha(g, (unsigned)(i * root[k])));
+        if (!den) return -1;
+        if (num) g.r[root[k] - 1] ^= (uint8_t)l2_div(g, num, den);
+    }
+    return count;
+}
+
+__device__ inline bool l2_pci_wants_check(unsigned pci)
+{
+    const unsigned p = pci & 0xFFFFFCu;
+    if (p == (0x3634CEu & 0xFFFFFCu)) return false;                                          // !has_audio
+    if (p == (0xE3634Cu & 0xFFFFFCu) || p == (0x8D8D33u & 0xFFFFFCu)) return false;         // has_fixed: audio_end not modelled
+    return true;
+}
+
+__device__ inline bool l2_header_codeword_ok(L2Smem &g)       // fix_header on g.pdu[0..95]
+{
+    for (int i = 0; i < 159; i++) g.r[i] = 0;
+    for (int i = 0; i < 96; i++) g.r[254 - i] = g.pdu[i];
+    if (rs255_247_decode(g) < 0) return false;
+    for (int i = 0; i < 159; i++) if (g.r[i]) return false;
+    return true;
+}
+
+__device__ inline unsigned l2_bit(const uint32_t *w, unsigned i) { return (w[i >> 5] >> (i & 31)) & 1u; }
+
+// FM P1 frame (146176 descrambled bits, packed LSB-first): the 24 PCI bits sit at 116176 + 1248 h, far behind the
+// first 96 PDU bytes, and frame_push's per-byte bit reversal turns PDU byte q into byte q of the packed frame.
+__device__ inline bool l2_first_header_ok_fm(const uint32_t *w, L2Smem &g)
+{
+    unsigned pci = 0;
+    for (unsigned h = 0; h < 24; h++) { const unsigned i = 116176u + 1248u * h; pci |= l2_bit(w, (i & ~7u) + 7u - (i & 7u)) << (23 - h); }
+    if (!l2_pci_wants_check(pci)) return true;
+    for (int q = 0; q < 96; q++) g.pdu[q] = (uint8_t)(w[q >> 2] >> (8 * (q & 3)));
+    return l2_header_codeword_ok(g);
+}
+
+// AM P1 frame (3750 bits): 22 PCI bits at 120 + 160 h are interleaved with the first PDU bytes -> generic unpacking
+__device__ inline bool l2_first_header_ok_am(const uint32_t *w, L2Smem &g)
+{
+    const unsigned len = 3750;
+    unsigned nbytes = 0, j = 0, h = 0, val = 0, pci = 0;
+    for (unsigned i = 0; i < len; i++) {
+        const unsigned b0 = (i >> 3) << 3, blen = (len - b0 < 8) ? len - b0 : 8;
+        const unsigned bit = l2_bit(w, b0 + blen - 1 - (i & 7));
+        if (i >= 120 && ((i - 120) % 160) == 0 && h < 22) { pci |= bit << (23 - h); ++h; }
+        else {
+            val |= bit << (7 - j);
+            if (++j == 8) { if (nbytes < 96) g.pdu[nbytes] = (uint8_t)val; nbytes++; val = 0; j = 0; }
+        }
+    }
+    if (!l2_pci_wants_check(pci)) return true;
+    return l2_header_codeword_ok(g);
+}
+
+}  // namespace nrsc5

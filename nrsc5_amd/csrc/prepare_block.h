@@ -29,7 +29,7 @@ __device__ inline bool window_ready(const StreamState &st) { return st.wr - st.r
 __device__ inline void prepare_block(const DevBuffers &db, StreamState &st, int s)
 {
     if (st.active) return;                                     // already prepared (fused into the previous k_sync)
-    if (st.sync_state != SYNC_FINE) atomicAdd(&db.counters[1], 1);   // host: keep launching acquisition
+    if (st.sync_state != SYNC_FINE || st.force_none) atomicAdd(&db.counters[1], 1);   // host: keep launching acquisition
     if (st.sync_state != SYNC_FINE || partitions_for_psmi(st.psmi) > PM_PART) atomicAdd(&db.counters[2], 1);   // ... and the PX kernels
     st.active = window_ready(st) ? 1 : 0;
     if (!st.active) return;

@@ -13,6 +13,7 @@ DEFAULT_LIB = os.path.join(_HERE, "libnrsc5hip.so")
 SYNC_NONE, SYNC_COARSE, SYNC_FINE = 0, 1, 2
 REC_PROCESSED, REC_TO_COARSE, REC_TO_FINE, REC_MER, REC_PIDS, REC_P1 = 1, 2, 4, 8, 16, 32
 REC_P3, REC_P4 = 128, 256
+REC_LOST_SYNC = 64
 PX_WORDS = 144
 MODE_FM, MODE_AM = 0, 1
 AM_P1_BITS, AM_P1_WORDS, AM_P3_WORD0 = 3750, 118, 944
@@ -30,7 +31,7 @@ assert RECORD_DTYPE.itemsize == 96
 class _Config(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int), ("max_streams", ctypes.c_int), ("q15_capacity", ctypes.c_longlong),
                 ("record_capacity", ctypes.c_int), ("p1_slots", ctypes.c_int), ("p1_async", ctypes.c_int),
-                ("am_enable", ctypes.c_int)]
+                ("l2_feedback", ctypes.c_int), ("am_enable", ctypes.c_int)]
 
 
 class Nrsc5HipError(RuntimeError):
@@ -103,9 +104,9 @@ class Engine:
 
     def __init__(self, max_streams: int = 1, q15_capacity: int = 1 << 20, record_capacity: int = 256,
                  p1_slots: int = 4, p1_async: bool = False, device: int = 0, lib_path: str | None = None,
-                 am_enable: bool = False):
+                 am_enable: bool = False, l2_feedback: bool = False):
         self.lib = load_library(lib_path)
-        self.cfg = _Config(device, max_streams, q15_capacity, record_capacity, p1_slots, int(p1_async), int(am_enable))
+        self.cfg = _Config(device, max_streams, q15_capacity, record_capacity, p1_slots, int(p1_async), int(l2_feedback), int(am_enable))
         self._h = ctypes.c_void_p()
         self._check(self.lib.nrsc5hip_engine_create(ctypes.byref(self.cfg), ctypes.byref(self._h)))
         self.max_streams, self.record_capacity, self.p1_slots = max_streams, record_capacity, p1_slots
@@ -327,6 +328,9 @@ def am_records_to_log(engine: Engine, stream: int, recs: np.ndarray, frames: np.
             else:
                 bits = engine.am_frame_bits(stream, slot, bc, AM_P1_BITS)
             out.append(("frame", {"lc": 0, "bits": bits}))
+            if fl & REC_LOST_SYNC:                              # frame_push(P1) -> frame_process -> input_set_sync_state(NONE)
+                out.append(("state", {"old": SYNC_FINE, "new": SYNC_NONE}))
+                out.append(("lost_sync", {}))
         if fl & REC_P3:
             n3 = 30000 if int(r["psmi"]) == 2 else 24000
             if frames is not None:
@@ -371,6 +375,9 @@ def records_to_log(engine: Engine, stream: int, recs: np.ndarray, frames: np.nda
                 else:
                     bits = engine.px_frame_bits(stream, int(r["sis"]), ch, nbits)
                 out.append(("frame", {"lc": 1 + ch, "bits": bits}))
+        if fl & REC_LOST_SYNC:
+            out.append(("state", {"old": SYNC_FINE, "new": SYNC_NONE}))
+            out.append(("lost_sync", {}))
         blk = {k: (float(r[k]) if RECORD_DTYPE[k].kind == "f" else int(r[k]))
                for k in ("state_before", "state_after", "samperr", "cfo", "keep", "bc", "psmi", "cfo_wait",
                          "next_samperr", "prev_angle", "phase_re", "phase_im", "next_angle")}

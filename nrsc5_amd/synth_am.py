@@ -281,7 +281,8 @@ class AmCapture:
 
 
 def am_ma1_capture(n_frames: int, seed: int = 1, cfo_hz: float = 3.0, offset: int = 1000, noise: float = 0.5,
-                   fmt: str = "cs16", tail_samples: int = 1080, unit_lsb: float | None = None, mode: str = "MA1") -> AmCapture:
+                   fmt: str = "cs16", tail_samples: int = 1080, unit_lsb: float | None = None, mode: str = "MA1",
+                   burst: tuple | None = None) -> AmCapture:
     """Hybrid-AM MA1 capture of n_frames L1 frames (8 blocks x 32 symbols each).  `noise` = per-sample complex
     noise sigma in primary QAM64 grid units; `unit_lsb` = LSBs per grid unit (default 100 for cs16, 0.8 for cu8)."""
     rng = np.random.default_rng(seed)
@@ -337,6 +338,12 @@ def am_ma1_capture(n_frames: int, seed: int = 1, cfo_hz: float = 3.0, offset: in
     full[offset:offset + n] = sig
     sigma = noise * np.sqrt(oversample)      # keep the in-band noise density independent of the sample rate
     full += sigma * (rng.standard_normal(full.shape[0]) + 1j * rng.standard_normal(full.shape[0])) / np.sqrt(2)
+    if burst is not None:                                      # (first L1 frame, number of frames, sigma): an interference burst
+        f0, nf, bs = burst
+        a = offset + int(f0 * 8 * BLKSZ * SYM * oversample)
+        b = min(full.shape[0], a + int(nf * 8 * BLKSZ * SYM * oversample))
+        brng = np.random.default_rng(seed + 4242)
+        full[a:b] += bs * np.sqrt(oversample) * (brng.standard_normal(b - a) + 1j * brng.standard_normal(b - a)) / np.sqrt(2)
     if fmt == "cs16":
         unit = 100.0 if unit_lsb is None else unit_lsb
         q = np.rint(unit * np.stack([full.real, full.imag], axis=1))

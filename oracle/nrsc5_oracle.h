@@ -97,6 +97,11 @@ typedef struct {
 } orc_sync_snapshot;
 void orc_snapshot(const orc_stream *s, orc_sync_snapshot *out);
 
+/* ---- the L2 -> L1 feedback (nrsc5_oracle_l2.c) ------------------------------------------------ */
+/* frame.c:516-540 + fix_header + RS(255,247): 1 = frame_process keeps sync after this P1 frame, 0 = it drops to NONE */
+int orc_rs255_247_decode(uint8_t r[255]);
+int orc_l2_first_header_ok(const uint8_t *bits, unsigned len);
+
 /* ---- AM (nrsc5_oracle_am.c) ------------------------------------------------------------ */
 
 /* K1-AM  input.c:52-94: cu8 -> (Q15 >> 4) -> five cascaded 15-tap half-bands, 32:1.  Any nbytes % 4 == 0;

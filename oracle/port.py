@@ -17,7 +17,7 @@ TAP_Q15, TAP_FFT, TAP_SOFT = 1, 2, 4
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("nrsc5_oracle.c", "nrsc5_oracle_am.c", "nrsc5_oracle.h", "cpu_fft.c", "cpu_fft.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("nrsc5_oracle.c", "nrsc5_oracle_am.c", "nrsc5_oracle_l2.c", "nrsc5_oracle.h", "cpu_fft.c", "cpu_fft.h")]
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     return _SO
@@ -59,6 +59,8 @@ class Oracle:
         L.orc_descramble.argtypes = [vp, ctypes.c_uint]
         L.orc_bit_errors_k7.argtypes = [vp, vp, ctypes.c_int]
         L.oracle_fft_forward.argtypes = [ctypes.c_int, vp, vp]
+        L.orc_l2_first_header_ok.argtypes = [vp, ctypes.c_uint]
+        L.orc_rs255_247_decode.argtypes = [vp]
         # AM
         L.orc_am_open.restype = vp
         L.orc_am_close.argtypes = [vp]
@@ -140,6 +142,19 @@ class Oracle:
         out = np.zeros_like(x)
         self.lib.oracle_fft_forward(x.size, x.ctypes.data, out.ctypes.data)
         return out
+
+    def l2_first_header_ok(self, bits: np.ndarray) -> bool:
+        """The L2 -> L1 feedback decision of frame_process for one P1 frame (bits as handed to frame_push)."""
+        b = np.ascontiguousarray(bits, dtype=np.uint8)
+        return bool(self.lib.orc_l2_first_header_ok(b.ctypes.data, b.size))
+
+    def l2_hook(self):
+        """p1_hook for run(): drop to SYNC_NONE exactly when the reference's frame_process would."""
+        return lambda bits: 0 if self.l2_first_header_ok(bits) else 1
+
+    def rs_decode(self, word255: np.ndarray):
+        w = np.ascontiguousarray(word255, dtype=np.uint8).copy()
+        return self.lib.orc_rs255_247_decode(w.ctypes.data), w
 
     # ---- AM stage functions -------------------------------------------------------------
     def am_decimate_cu8(self, chunks) -> np.ndarray:

@@ -21,7 +21,9 @@ LOOSE_ABS = {"phase_re": 5e-3, "phase_im": 5e-3}
 # 16 x 16128 cells (sync.c:465-483).  When a few huge terms dominate (the blocks right after lock in MP2/3/11, whose
 # new reference carriers are still pulling in) that sum itself is only good to ~1e-4, so MER values may also agree
 # to 2e-3 dB absolute instead of 1e-4 relative.
-EITHER_ABS = {"lower": 2e-3, "upper": 2e-3}
+# EVENT_SYNC.freq_offset is in Hz (prev_angle x 57.8): near 0 Hz the relative bound degenerates, 0.01 Hz = 1e-4 of the
+# +-100 Hz range the tracking loop works in.
+EITHER_ABS = {"lower": 2e-3, "upper": 2e-3, "freq_offset": 1e-2}
 
 # golden capture definitions: name -> synth.fm_mp1_capture kwargs
 GOLDEN_CASES = {

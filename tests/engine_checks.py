@@ -107,8 +107,8 @@ def check_viterbi_roundtrip(lib, L=4608, frames=4, seed=9, flip=0.004):
     E.close()
 
 
-def run_capture(lib, cap, p1_async=False, chunk=32768 * 8):
-    E = eng.Engine(max_streams=1, q15_capacity=max(2 * 71280 + chunk, 400000), lib_path=lib, p1_async=p1_async)
+def run_capture(lib, cap, p1_async=False, chunk=32768 * 8, l2_feedback=False):
+    E = eng.Engine(max_streams=1, q15_capacity=max(2 * 71280 + chunk, 400000), lib_path=lib, p1_async=p1_async, l2_feedback=l2_feedback)
     common.run_engine_streaming(E, 0, cap.iq, chunk=chunk)
     recs = E.drain(0)
     log = eng.records_to_log(E, 0, recs)
@@ -378,3 +378,29 @@ def check_am_batch_equals_streaming(lib, kws):
     E.lib.nrsc5hip_debug_free.argtypes = [ctypes.c_void_p]
     E.lib.nrsc5hip_debug_free(dptr)
     E.close()
+
+
+def check_l2_feedback(lib, oracle, kw, am=False):
+    """Engine-side L2 -> L1 feedback (RS(255,247) first-header check on the device, in-order decode) == the oracle driven
+    by the restated frame_process decision, which itself is pinned against the unmodified reference incl. its L2."""
+    from nrsc5_amd import synth_am
+    if am:
+        cap = synth_am.am_ma1_capture(**kw)
+        ol, _, _ = oracle.run(cap.iq, mode=1, p1_hook=oracle.l2_hook())
+        E = eng.Engine(max_streams=1, q15_capacity=400000, record_capacity=512, p1_slots=16, lib_path=lib, am_enable=True, l2_feedback=True)
+        E.set_mode(0, eng.MODE_AM)
+        common.run_engine_streaming(E, 0, cap.iq, chunk=32768)
+        log = eng.am_records_to_log(E, 0, E.drain(0))
+    else:
+        cap = synth.fm_mp1_capture(**kw)
+        ol, _, _ = oracle.run(cap.iq, p1_hook=oracle.l2_hook())
+        E, recs, log = run_capture(lib, cap, l2_feedback=True)
+    assert any(k == "lost_sync" for k, _ in ol), "capture does not exercise the feedback"
+    diffs = common.compare_logs(common.strip_states(ol), common.strip_states(log))
+    # frames decoded while falsely locked are Viterbi output on noise (see check_oracle_end_to_end)
+    bad = {i for i, (k, v) in enumerate([r for r in common.strip_states(ol) if r[0] not in ("hdc", "soft", "vit", "amsym", "pxsoft")])
+           if k == "ber" and v["cber"] > 0.02}
+    diffs = [d for d in diffs if not any(d.startswith(f"#{i} ") or d.startswith(f"#{i + 1} frame") or d.startswith(f"#{i - 1} frame") for i in bad)]
+    assert not diffs, diffs[:10]
+    E.close()
+    return log

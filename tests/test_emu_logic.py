@@ -91,3 +91,11 @@ def test_emu_am_batch_equals_streaming(emu_lib):
 def test_emu_am_ma3_end_to_end(emu_lib, oracle):
     """All-digital layout (psmi 2): no sideband combining, QAM64 everywhere, 30000-bit P3 frames through the E1 code."""
     ec.check_am_oracle_end_to_end(emu_lib, oracle, dict(n_frames=8, seed=8, cfo_hz=-6.0, offset=2000, mode="MA3"))
+
+
+def test_emu_l2_feedback_on_device_fm(emu_lib, oracle):
+    ec.check_l2_feedback(emu_lib, oracle, dict(n_frames=0, n_blocks=40, seed=23, cfo_hz=0.0, offset=1234, snr_db=20.0))
+
+
+def test_emu_l2_feedback_on_device_am(emu_lib, oracle):
+    ec.check_l2_feedback(emu_lib, oracle, dict(n_frames=16, seed=9, cfo_hz=2.0, offset=500, burst=(8.3, 0.5, 40.0)), am=True)

@@ -207,3 +207,44 @@ def test_gpu_am_batch_equals_streaming(hip_lib):
     ec.check_am_batch_equals_streaming(hip_lib, [dict(n_frames=10, seed=31, cfo_hz=5.0, offset=100),
                                                 dict(n_frames=9, seed=32, cfo_hz=-20.0, offset=5000), dict(n_frames=3, seed=33)])
     ec.check_am_batch_equals_streaming(hip_lib, [dict(n_frames=2, seed=41, fmt="cu8"), dict(n_frames=1, seed=42, fmt="cu8", offset=3333)])
+
+
+# ---- the L2 -> L1 feedback on the device ------------------------------------------------------------------
+@pytest.mark.parametrize("kw", [
+    dict(n_frames=0, n_blocks=40, seed=23, cfo_hz=0.0, offset=1234, snr_db=20.0),
+    dict(n_frames=0, n_blocks=52, seed=15, cfo_hz=80.0, offset=2100, snr_db=22.0, mode="MP2"),
+])
+def test_gpu_l2_feedback_on_device_fm(hip_lib, oracle, kw):
+    """RS(255,247) first-header check + drop to NONE inside the engine (in-order decode) == reference incl. its L2."""
+    ec.check_l2_feedback(hip_lib, oracle, kw)
+
+
+def test_gpu_l2_feedback_on_device_am(hip_lib, oracle):
+    ec.check_l2_feedback(hip_lib, oracle, dict(n_frames=16, seed=9, cfo_hz=2.0, offset=500, burst=(8.3, 0.5, 40.0)), am=True)
+
+
+def test_gpu_l2_feedback_deferred_recovers_false_locks(hip_lib):
+    """Throughput mode: the feedback arrives when the deferred decode completes; falsely locked streams still re-acquire
+    and then deliver the transmitted frames."""
+    caps = [synth.fm_mp1_capture(0, seed=60 + k, cfo_hz=20.0 * k, offset=o, snr_db=20, n_blocks=120) for k, o in enumerate([1234, 2208, 777])]
+    n = len(caps)
+    stride = max(c.iq.size for c in caps); stride += (-stride) % 256
+    buf = np.zeros((n, stride), dtype=np.uint8)
+    for k, c in enumerate(caps):
+        buf[k, :c.iq.size] = c.iq
+    good = []
+    for fb in (False, True):
+        E = eng.Engine(max_streams=n, q15_capacity=stride // 4 + 1024, record_capacity=256, p1_slots=16, p1_async=True, l2_feedback=fb, lib_path=hip_lib)
+        dev = ec._to_device(E, buf)
+        E.batch_append_cu8(dev, stride, [c.iq.size - c.iq.size % 4 for c in caps])
+        E.batch_process(n)
+        recs, counts, frames = E.batch_fetch(n)
+        ok = []
+        for k, c in enumerate(caps):
+            truth = {np.packbits(f, bitorder="little").tobytes() for f in c.p1_frames}
+            ok.append(sum(1 for r in recs[k, :counts[k]] if (int(r["flags"]) & eng.REC_P1) and frames[k, int(r["p1_slot"])].tobytes() in truth))
+        good.append(ok)
+        ec._free_device(E, dev)
+        E.close()
+    assert good[0][0] == 0 and good[0][1] == 0 and good[0][2] >= 6        # without feedback the two false locks never recover
+    assert good[1][0] >= 3 and good[1][1] >= 3 and good[1][2] == good[0][2]

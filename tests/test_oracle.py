@@ -144,3 +144,46 @@ def test_interleaver_iv_is_convolutional():
     for L in (2304, 4608):
         d = synth.interleaver_iv_delays(L)
         assert d.min() >= 1 and d.max() <= 32 * L and len(np.unique((np.arange(2 * L) - d) % (32 * L))) == 2 * L
+
+
+def test_rs_decoder_matches_reference_decoder(oracle):
+    """Restated RS(255,247) (oracle/nrsc5_oracle_l2.c) == the decoder the reference links (rs_decode.c via oracle/_ref):
+    same return value and same corrected word for 0..7 symbol errors, incl. its mis-corrections beyond 4 errors."""
+    import ctypes
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("reference build absent")
+    lib = ctypes.CDLL(ref.lib_path())
+    lib.init_rs_char.restype = ctypes.c_void_p
+    lib.init_rs_char.argtypes = [ctypes.c_uint] * 5
+    lib.decode_rs_char.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    rs = lib.init_rs_char(8, 0x11d, 1, 1, 8)
+    rng = np.random.default_rng(0)
+    seen = set()
+    for _ in range(3000):
+        data = [int(x) for x in rng.integers(0, 256, size=247)]
+        w = np.array(data + synth._GF.rs_parity(data), dtype=np.uint8)
+        ne = int(rng.integers(0, 8))
+        pos = rng.choice(255, size=ne, replace=False)
+        w[pos] ^= rng.integers(1, 256, size=ne).astype(np.uint8)
+        a = w.copy()
+        rc_ref = lib.decode_rs_char(rs, a.ctypes.data, None, 0)
+        rc, b = oracle.rs_decode(w)
+        assert rc == rc_ref and (rc < 0 or np.array_equal(a, b))
+        seen.add((ne > 4, rc_ref < 0))
+    assert len(seen) >= 3
+
+
+@pytest.mark.parametrize("kw", [
+    dict(n_frames=0, n_blocks=40, seed=23, cfo_hz=0.0, offset=1234, snr_db=20.0),          # false lock -> header fails -> resync
+    dict(n_frames=0, n_blocks=52, seed=15, cfo_hz=80.0, offset=2100, snr_db=22.0, mode="MP2"),
+    dict(n_frames=0, n_blocks=36, seed=25, cfo_hz=10.0, offset=777, snr_db=20.0),          # good lock: no feedback
+])
+def test_l2_feedback_restatement_matches_reference_l2(kw, oracle, reflib):
+    """The unmodified reference (with its real L2) vs the oracle driven by orc_l2_first_header_ok: identical logs,
+    incl. LOST_SYNC and the re-acquisition after it."""
+    cap = synth.fm_mp1_capture(**kw)
+    rl, _, _ = reflib.run(cap.iq)
+    ol, _, _ = oracle.run(cap.iq, p1_hook=oracle.l2_hook())
+    assert not common.compare_logs(rl, ol, rtol=0.0)
+    assert (kw["offset"] == 777) != any(k == "lost_sync" for k, _ in rl)

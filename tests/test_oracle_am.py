@@ -112,3 +112,13 @@ def test_am_synth_cells_tile_matrices():
         assert used[:, nbits:].sum() == 0 and used.max() == 1
         per_cell = used[:, :nbits].sum(axis=1)
         assert set(np.unique(per_cell)) == {0, nbits} and (per_cell == 0).sum() == 8 * 50     # 2 training cells / carrier / block
+
+
+def test_am_l2_feedback_restatement_matches_reference_l2(oracle, reflib):
+    """An interference burst wipes out a P1 frame: the reference's frame_process drops sync on the 466-byte PDU's header."""
+    from oracle import ref
+    cap = synth_am.am_ma1_capture(n_frames=16, seed=9, cfo_hz=2.0, offset=500, burst=(8.3, 0.5, 40.0))
+    rl, _, _ = reflib.run(cap.iq, mode=ref.MODE_AM)
+    ol, _, _ = oracle.run(cap.iq, mode=1, p1_hook=oracle.l2_hook())
+    assert any(k == "lost_sync" for k, _ in rl)
+    assert not common.compare_logs(rl, ol, rtol=0.0)
