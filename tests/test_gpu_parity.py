@@ -226,7 +226,7 @@ def test_gpu_l2_feedback_on_device_am(hip_lib, oracle):
 def test_gpu_l2_feedback_deferred_recovers_false_locks(hip_lib):
     """Throughput mode: the feedback arrives when the deferred decode completes; falsely locked streams still re-acquire
     and then deliver the transmitted frames."""
-    caps = [synth.fm_mp1_capture(0, seed=60 + k, cfo_hz=20.0 * k, offset=o, snr_db=20, n_blocks=120) for k, o in enumerate([1234, 2208, 777])]
+    caps = [synth.fm_mp1_capture(0, seed=sd, cfo_hz=c, offset=o, snr_db=20, n_blocks=120) for sd, c, o in ((23, 0.0, 1234), (24, 10.0, 2208), (25, 10.0, 777))]
     n = len(caps)
     stride = max(c.iq.size for c in caps); stride += (-stride) % 256
     buf = np.zeros((n, stride), dtype=np.uint8)
