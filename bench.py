@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--payloads", type=int, default=8, help="distinct transmissions shared by the streams (each stream has its own CFO/offset/noise)")
     ap.add_argument("--sync-p1", action="store_true", help="decode P1 frames in order on the main stream (exact reference event timing) instead of the overlapped window pipeline")
     ap.add_argument("--l2-feedback", type=int, default=1, help="1: the engine applies the reference's L2 -> L1 sync-loss feedback itself (RS check of the first L2 header on the device), as the CPU baseline's frame.c does; 0: off")
+    ap.add_argument("--no-profile", action="store_true", help="diagnostic: no HIP-event kernel timing inside the timed region (roofline fields become 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
@@ -138,7 +139,7 @@ def main():
 
     for _ in range(args.warmup):
         one_pass()
-    E.profile(1)
+    E.profile(0 if args.no_profile else 1)
     for k in host_ms:
         host_ms[k] = 0.0
     shard.barrier(dev)
