@@ -1,6 +1,7 @@
 // L1 FEC stage for gfx950: P1 de-interleave (K6), tail-biting Viterbi (K7), re-encode BER and
 // descrambler (K8).  Replaces decode.c:296-322,451-461 and conv_dec.c for the P1 logical channel.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "kernels.h"
 #include "viterbi_wave.h"
 #include "l2_header.h"
@@ -74,8 +75,9 @@ __device__ inline int bit_errors_k7_partial(const Src &src, const uint32_t *bits
 }
 
 // ---- K7: P1 frame = forward pass by one wave, then traceback/BER/descramble by a 16-wave block -------
-__global__ __launch_bounds__(64) void k_p1_forward(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id)
+__global__ __launch_bounds__(64) void k_p1_forward(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id, int prio)
 {
+    wave_set_priority(prio);
     const int s = stream_of(ids, blockIdx.x);
     StreamState &st = db.state[s];
     if (!st.p1_pending[parity]) return;                        // wave-uniform
@@ -87,8 +89,9 @@ __global__ __launch_bounds__(64) void k_p1_forward(DevTables tb, DevBuffers db, 
 
 constexpr int TB_THREADS = 1024;
 
-__global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id, int l2_mode)
+__global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id, int l2_mode, int prio)
 {
+    wave_set_priority(prio);
     const int s = stream_of(ids, blockIdx.x);
     StreamState &st = db.state[s];
     if (!st.p1_pending[parity]) return;                        // block-uniform
@@ -132,8 +135,10 @@ static size_t traceback_smem(int len) { const int nchunks = len / 64 + 1; return
 void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st, int l2_mode)
 {
     hipLaunchKernelGGL(k_p1_deint, dim3(32, nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, lane_id);
-    hipLaunchKernelGGL(k_p1_forward, dim3(nstreams), dim3(64), 0, st, tb, db, stream_ids, parity, lane_id);
-    hipLaunchKernelGGL(k_p1_traceback, dim3(nstreams), dim3(TB_THREADS), traceback_smem(P1_LEN), st, tb, db, stream_ids, parity, lane_id, l2_mode);
+    static const int prio_fwd = getenv("NRSC5HIP_PRIO_FWD") ? atoi(getenv("NRSC5HIP_PRIO_FWD")) : 0;
+    static const int prio_tb = getenv("NRSC5HIP_PRIO_TB") ? atoi(getenv("NRSC5HIP_PRIO_TB")) : 0;
+    hipLaunchKernelGGL(k_p1_forward, dim3(nstreams), dim3(64), 0, st, tb, db, stream_ids, parity, lane_id, prio_fwd);
+    hipLaunchKernelGGL(k_p1_traceback, dim3(nstreams), dim3(TB_THREADS), traceback_smem(P1_LEN), st, tb, db, stream_ids, parity, lane_id, l2_mode, prio_tb);
 }
 
 // ---- stage-level entry: decode `nframes` independent frames of equal length (parity tests) ----------

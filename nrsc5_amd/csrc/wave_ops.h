@@ -14,6 +14,17 @@ __device__ __forceinline__ int wave_readlane(int v, int lane) { return __builtin
 // Raise this wave's issue priority (s_setprio): the per-block kernels are a serial chain of 224 steps per pass, the
 // trellis passes that share their SIMDs are long-running background work.
 #ifdef HIPEMU
+__device__ inline void wave_set_priority(int) {}
+#else
+// s_setprio takes an immediate: 0 (default) .. 3
+__device__ __forceinline__ void wave_set_priority(int p)
+{
+    if (p == 1) __builtin_amdgcn_s_setprio(1);
+    else if (p == 2) __builtin_amdgcn_s_setprio(2);
+    else if (p == 3) __builtin_amdgcn_s_setprio(3);
+}
+#endif
+#ifdef HIPEMU
 __device__ inline void wave_set_priority_high() {}
 #else
 __device__ __forceinline__ void wave_set_priority_high() { __builtin_amdgcn_s_setprio(3); }
