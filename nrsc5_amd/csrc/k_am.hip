@@ -223,6 +223,97 @@ __device__ inline void viterbi_k9_block(const int8_t *coded, int len, unsigned g
     __syncthreads();
 }
 
+// ---- the same trellis on ONE wave64: lane L owns butterflies 2L and 2L+1, i.e. old states 4L..4L+3 (one 16-byte LDS
+// read) and new states {2L, 2L+1} and {2L+128, 2L+129} (two 8-byte LDS writes into the other half of a ping-pong
+// buffer).  No workgroup barrier per step: a single-wave workgroup orders its own LDS traffic (s_barrier is a no-op
+// for it, the wait on lgkmcnt is what __syncthreads() leaves).  Decisions: 4 ballots per step -- word w = 2 (n >= 128)
+// + (n & 1), bit (n & 127) >> 1 for new state n.  The P1 / P3 frames of an AM stream decode 4-5 x faster than with
+// the 256-work-item form (which stays in use for the 80-bit PIDS frame inside k_am_block).
+struct K9WSmem { int metric[2][256]; };
+
+__device__ inline int k9_sign_word(unsigned b, unsigned g0, unsigned g1, unsigned g2)
+{
+    const unsigned reg = (b << 1) & 0xfeu;
+    const int s0 = (__popc(reg & g0) & 1) ? 1 : -1, s1 = (__popc(reg & g1) & 1) ? 1 : -1, s2 = (__popc(reg & g2) & 1) ? 1 : -1;
+    return (s0 & 0xff) | ((s1 & 0xff) << 8) | ((s2 & 0xff) << 16);
+}
+
+__device__ inline void viterbi_k9_wave(const int8_t *coded, int len, unsigned g0, unsigned g1, unsigned g2,
+                                       unsigned long long *dec, uint32_t *out, K9WSmem &sm)
+{
+    const int lane = threadIdx.x & 63;
+    const int sgw0 = k9_sign_word(2u * lane, g0, g1, g2), sgw1 = k9_sign_word(2u * lane + 1u, g0, g1, g2);
+    const int steps = len + 2 * VIT_EXTRA, j0 = len - VIT_EXTRA, nchunks = (steps + 63) >> 6;
+    int cur = 0;
+    for (int k = 0; k < 4; k++) sm.metric[0][4 * lane + k] = 0;
+    __syncthreads();
+    for (int c = 0; c < nchunks; c++) {
+        const int t0 = c << 6;
+        int aw = 0;                                            // this lane's step of the chunk: soft triple packed as 3 x int8
+        if (t0 + lane < steps) {
+            const int j = (j0 + t0 + lane) % len;
+            aw = (coded[3 * j] & 0xff) | ((coded[3 * j + 1] & 0xff) << 8) | ((coded[3 * j + 2] & 0xff) << 16);
+        }
+        const int nst = min(64, steps - t0);
+        for (int s = 0; s < nst; s++) {
+            const int a = wave_readlane(aw, s);
+            const int m0 = dot4_i8(a, sgw0, 0), m1 = dot4_i8(a, sgw1, 0);
+            const int4 old = *(const int4 *)&sm.metric[cur][4 * lane];
+            const int pa = old.x + m0, pb = old.y - m0;        // -> state 2L
+            const int pc = old.x - m0, pd = old.y + m0;        // -> state 2L + 128
+            const int qa = old.z + m1, qb = old.w - m1;        // -> state 2L + 1
+            const int qc = old.z - m1, qd = old.w + m1;        // -> state 2L + 129
+            const bool tA = pa > pb, tB = qa > qb, tC = pc > pd, tD = qc > qd;     // true: survivor from the even predecessor
+            *(int2 *)&sm.metric[cur ^ 1][2 * lane] = make_int2(tA ? pa : pb, tB ? qa : qb);
+            *(int2 *)&sm.metric[cur ^ 1][2 * lane + 128] = make_int2(tC ? pc : pd, tD ? qc : qd);
+            const unsigned long long wA = __ballot(!tA), wB = __ballot(!tB), wC = __ballot(!tC), wD = __ballot(!tD);
+            if (lane < 4) dec[(size_t)(t0 + s) * 4 + lane] = lane == 0 ? wA : lane == 1 ? wB : lane == 2 ? wC : wD;
+            cur ^= 1;
+            __syncthreads();
+        }
+    }
+    // end state: first maximum in state order (conv_dec.c:310-318)
+    unsigned state;
+    {
+        const int4 m = *(const int4 *)&sm.metric[cur][4 * lane];
+        int v = m.x, idx = 4 * lane;
+        if (m.y > v) { v = m.y; idx = 4 * lane + 1; }
+        if (m.z > v) { v = m.z; idx = 4 * lane + 2; }
+        if (m.w > v) { v = m.w; idx = 4 * lane + 3; }
+        for (int k = 32; k >= 1; k >>= 1) {
+            const int ov = __shfl_xor(v, k), oi = __shfl_xor(idx, k);
+            if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
+        }
+        state = (unsigned)wave_uniform(idx);
+    }
+    __threadfence_block();
+    __syncthreads();
+    // traceback: lane l holds the 4 decision words of step t0 + l; the walk itself is scalar (uniform state)
+    for (int c = nchunks - 1; c >= 0; c--) {
+        const int t0 = c << 6, nst = min(64, steps - t0);
+        unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+        if (lane < nst) { const unsigned long long *d = dec + (size_t)(t0 + lane) * 4; w0 = d[0]; w1 = d[1]; w2 = d[2]; w3 = d[3]; }
+        unsigned long long obits = 0;
+        for (int s = nst - 1; s >= 0; s--) {
+            const unsigned w = ((state >> 7) << 1) | (state & 1u), bitpos = (state & 127u) >> 1;
+            const unsigned long long mine = w == 0 ? w0 : w == 1 ? w1 : w == 2 ? w2 : w3;
+            const int half = bitpos < 32 ? (int)(uint32_t)mine : (int)(uint32_t)(mine >> 32);
+            const unsigned bit = ((unsigned)wave_readlane(half, s) >> (bitpos & 31u)) & 1u;
+            obits |= (unsigned long long)((state >> 7) & 1u) << s;          // vals[state]: the newest input bit
+            state = ((state << 1) & 0xfeu) | bit;                           // vstate_lshift
+        }
+        // steps t0 .. t0+63 -> frame bits t0-32 .. t0+31: low half of obits = second half of word (t0-32)/32 ... i.e.
+        // bits [t0-32, t0) -> word c*2-1, bits [t0, t0+32) -> word c*2
+        if (lane == 0) {
+            const int wl = 2 * c - 1, wh = 2 * c;
+            if (wl >= 0 && wl * 32 < len) out[wl] = (uint32_t)obits;
+            if (wh * 32 < len) out[wh] = (uint32_t)(obits >> 32);
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+
 // re-encode the decoded (still scrambled) bits and count sign disagreements at unpunctured positions
 // (bit_errors, decode.c:234-261); returns the block-wide total in every work-item
 __device__ inline int am_bit_errors(const int8_t *coded, const uint32_t *bits, int len, unsigned g0, unsigned g1, unsigned g2,
@@ -245,7 +336,9 @@ __device__ inline int am_bit_errors(const int8_t *coded, const uint32_t *bits, i
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = errors;
     __syncthreads();
-    return red[0] + red[1] + red[2] + red[3];
+    int total = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) total += red[w];
+    return total;
 }
 
 constexpr unsigned GEN_E1_0 = 0561, GEN_E1_1 = 0657, GEN_E1_2 = 0711;     // decode.c:47-53
@@ -683,7 +776,7 @@ __global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, c
 }
 
 // ---- this block's P1 frame, and after block 7 the P3 frame (decode_process_p1_p3_am, decode.c:507-554) ----------
-__global__ __launch_bounds__(256) void k_am_viterbi(DevTables tb, DevBuffers db, const int *ids, int l2_feedback)
+__global__ __launch_bounds__(64) void k_am_viterbi(DevTables tb, DevBuffers db, const int *ids, int l2_feedback)
 {
     const int s = stream_of(ids, blockIdx.y);
     const StreamState &st = db.state[s];
@@ -691,7 +784,7 @@ __global__ __launch_bounds__(256) void k_am_viterbi(DevTables tb, DevBuffers db,
     if (!st.active || am.dec_bc < 0 || am.am_diversity_wait != 0) return;      // block-uniform
     const int role = blockIdx.x, bc = am.dec_bc;                                 // 0: P1, 1: P3
     if (role == 1 && (bc != 7 || am.dec_rdbi)) return;
-    __shared__ K9Smem k9;
+    __shared__ K9WSmem k9;
     __shared__ int red[4];
     const bool ma3 = am.dec_psmi == AM_MA3;
     uint32_t *slot = db.p1_ring + ((size_t)s * db.p1_slots + am.frame_slot) * P1_WORDS;
@@ -700,9 +793,9 @@ __global__ __launch_bounds__(256) void k_am_viterbi(DevTables tb, DevBuffers db,
     if (role == 0) {
         const int8_t *in = db.am_vit + (size_t)s * 2 * AM_VIT + (size_t)bc * AM_P1_LEN * 3;
         uint32_t *out = slot + bc * AM_P1_WORDS;
-        viterbi_k9_block(in, AM_P1_LEN, GEN_E1_0, GEN_E1_1, GEN_E1_2, dec, out, k9);
+        viterbi_k9_wave(in, AM_P1_LEN, GEN_E1_0, GEN_E1_1, GEN_E1_2, dec, out, k9);
         const int err = am_bit_errors(in, out, AM_P1_LEN, GEN_E1_0, GEN_E1_1, GEN_E1_2, PUNCT_E1, 15, red);
-        for (int w = threadIdx.x; w < AM_P1_WORDS; w += 256)     // descramble; the last word holds 6 frame bits
+        for (int w = threadIdx.x; w < AM_P1_WORDS; w += 64)      // descramble; the last word holds 6 frame bits
             out[w] = (out[w] ^ tb.scr_p1[w]) & (w == AM_P1_WORDS - 1 ? (1u << (AM_P1_LEN & 31)) - 1u : 0xffffffffu);
         __threadfence_block();
         __syncthreads();
@@ -723,15 +816,15 @@ __global__ __launch_bounds__(256) void k_am_viterbi(DevTables tb, DevBuffers db,
         const int len = ma3 ? AM_P3_LEN_MA3 : AM_P3_LEN_MA1;
         int err;
         if (!ma3) {
-            viterbi_k9_block(in, len, GEN_E2_0, GEN_E2_1, GEN_E2_2, dec + AM_DEC_P1, out, k9);
+            viterbi_k9_wave(in, len, GEN_E2_0, GEN_E2_1, GEN_E2_2, dec + AM_DEC_P1, out, k9);
             err = am_bit_errors(in, out, len, GEN_E2_0, GEN_E2_1, GEN_E2_2, PUNCT_E2, 6, red);
         } else {
-            viterbi_k9_block(in, len, GEN_E1_0, GEN_E1_1, GEN_E1_2, dec + AM_DEC_P1, out, k9);
+            viterbi_k9_wave(in, len, GEN_E1_0, GEN_E1_1, GEN_E1_2, dec + AM_DEC_P1, out, k9);
             err = am_bit_errors(in, out, len, GEN_E1_0, GEN_E1_1, GEN_E1_2, PUNCT_E1, 15, red);
         }
         const int words = (len + 31) / 32;
         const uint32_t tailmask = (len & 31) ? (1u << (len & 31)) - 1u : 0xffffffffu;
-        for (int w = threadIdx.x; w < words; w += 256) out[w] = (out[w] ^ tb.scr_p1[w]) & (w == words - 1 ? tailmask : 0xffffffffu);
+        for (int w = threadIdx.x; w < words; w += 64) out[w] = (out[w] ^ tb.scr_p1[w]) & (w == words - 1 ? tailmask : 0xffffffffu);
         if (threadIdx.x == 0) {
             atomicAdd(&am.am_errors, (unsigned)err);
             atomicOr(&rec.flags, (uint32_t)REC_P3);
@@ -850,7 +943,7 @@ void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, con
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_am_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AmBlockSmem)); attr_set = true; }
     hipLaunchKernelGGL(k_am_block, dim3(nstreams), dim3(256), sizeof(AmBlockSmem), st, tb, db, stream_ids);
-    hipLaunchKernelGGL(k_am_viterbi, dim3(2, nstreams), dim3(256), 0, st, tb, db, stream_ids, l2_feedback);
+    hipLaunchKernelGGL(k_am_viterbi, dim3(2, nstreams), dim3(64), 0, st, tb, db, stream_ids, l2_feedback);
     hipLaunchKernelGGL(k_am_interleave, dim3(nstreams), dim3(1024), 0, st, db, stream_ids);
 }
 
@@ -862,11 +955,20 @@ __global__ __launch_bounds__(256) void k_viterbi_k9_frames(const int8_t *coded, 
     const int f = blockIdx.x;
     viterbi_k9_block(coded + (size_t)f * 3 * len, len, g0, g1, g2, dec + (size_t)f * 4 * (len + 64), out + (size_t)f * ((len + 31) / 32), k9);
 }
+__global__ __launch_bounds__(64) void k_viterbi_k9_frames_wave(const int8_t *coded, int len, unsigned g0, unsigned g1, unsigned g2,
+                                                               unsigned long long *dec, uint32_t *out)
+{
+    __shared__ K9WSmem k9;
+    const int f = blockIdx.x;
+    viterbi_k9_wave(coded + (size_t)f * 3 * len, len, g0, g1, g2, dec + (size_t)f * 4 * (len + 64), out + (size_t)f * ((len + 31) / 32), k9);
+}
 
 void launch_viterbi_k9_frames(const int8_t *coded, int len, int nframes, unsigned g0, unsigned g1, unsigned g2,
                               unsigned long long *dec, uint32_t *out, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_viterbi_k9_frames, dim3(nframes), dim3(256), 0, st, coded, len, g0, g1, g2, dec, out);
+    // frames longer than a PIDS frame take the production single-wave form; 80-bit frames the 256-work-item form
+    if (len > 80) hipLaunchKernelGGL(k_viterbi_k9_frames_wave, dim3(nframes), dim3(64), 0, st, coded, len, g0, g1, g2, dec, out);
+    else hipLaunchKernelGGL(k_viterbi_k9_frames, dim3(nframes), dim3(256), 0, st, coded, len, g0, g1, g2, dec, out);
 }
 
 }  // namespace nrsc5
