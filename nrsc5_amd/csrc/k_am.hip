@@ -229,7 +229,7 @@ __device__ inline void viterbi_k9_block(const int8_t *coded, int len, unsigned g
 // for it, the wait on lgkmcnt is what __syncthreads() leaves).  Decisions: 4 ballots per step -- word w = 2 (n >= 128)
 // + (n & 1), bit (n & 127) >> 1 for new state n.  The P1 / P3 frames of an AM stream decode 4-5 x faster than with
 // the 256-work-item form (which stays in use for the 80-bit PIDS frame inside k_am_block).
-struct K9WSmem { int metric[2][256]; };
+struct K9WSmem { int metric[2][256]; unsigned long long decbuf[64 * 4]; };
 
 __device__ inline int k9_sign_word(unsigned b, unsigned g0, unsigned g1, unsigned g2)
 {
@@ -246,7 +246,7 @@ __device__ inline void viterbi_k9_wave(const int8_t *coded, int len, unsigned g0
     const int steps = len + 2 * VIT_EXTRA, j0 = len - VIT_EXTRA, nchunks = (steps + 63) >> 6;
     int cur = 0;
     for (int k = 0; k < 4; k++) sm.metric[0][4 * lane + k] = 0;
-    __syncthreads();
+    WAVE_LDS_SYNC();
     for (int c = 0; c < nchunks; c++) {
         const int t0 = c << 6;
         int aw = 0;                                            // this lane's step of the chunk: soft triple packed as 3 x int8
@@ -267,10 +267,13 @@ __device__ inline void viterbi_k9_wave(const int8_t *coded, int len, unsigned g0
             *(int2 *)&sm.metric[cur ^ 1][2 * lane] = make_int2(tA ? pa : pb, tB ? qa : qb);
             *(int2 *)&sm.metric[cur ^ 1][2 * lane + 128] = make_int2(tC ? pc : pd, tD ? qc : qd);
             const unsigned long long wA = __ballot(!tA), wB = __ballot(!tB), wC = __ballot(!tC), wD = __ballot(!tD);
-            if (lane < 4) dec[(size_t)(t0 + s) * 4 + lane] = lane == 0 ? wA : lane == 1 ? wB : lane == 2 ? wC : wD;
+            if (lane < 4) sm.decbuf[4 * s + lane] = lane == 0 ? wA : lane == 1 ? wB : lane == 2 ? wC : wD;
             cur ^= 1;
-            __syncthreads();
+            WAVE_LDS_SYNC();
         }
+        // the chunk's 64 x 4 decision words go out as four coalesced 512-byte rows
+        for (int k = lane; k < 4 * nst; k += 64) dec[(size_t)t0 * 4 + k] = sm.decbuf[k];
+        WAVE_LDS_SYNC();
     }
     // end state: first maximum in state order (conv_dec.c:310-318)
     unsigned state;

@@ -11,6 +11,15 @@ __device__ inline int wave_readlane(int v, int lane) { return __shfl(v, lane); }
 // v_readlane_b32: lane index must be wave-uniform
 __device__ __forceinline__ int wave_readlane(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 #endif
+// Order this wave's own LDS traffic without a workgroup barrier: the LDS unit serves one wave's requests in issue order,
+// so a ds_read issued after a ds_write of the same wave sees it; all that is needed is that the compiler keeps the
+// order.  (__syncthreads() would also wait for outstanding GLOBAL stores -- hundreds of cycles per trellis step.)
+// Only valid in single-wave workgroups.
+#ifdef HIPEMU
+#define WAVE_LDS_SYNC() __syncthreads()
+#else
+#define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
 // Raise this wave's issue priority (s_setprio): the per-block kernels are a serial chain of 224 steps per pass, the
 // trellis passes that share their SIMDs are long-running background work.
 #ifdef HIPEMU
