@@ -46,6 +46,8 @@ struct nrsc5hip_engine {
         int dec_waited;                // chunks of the current chunked append this lane has already waited for
         bool prepared_by_sync;         // the previous step's k_sync already ran the next block's bookkeeping
         long long step_count;          // block steps issued so far (decode-window bookkeeping in async mode)
+        long long am_step_count;       // same for the AM window pipeline (8 steps per window)
+        bool am_decoded_pending[NWIN];
         int *counters_dev, *counters_host;
         DevBuffers db;                 // engine buffers with this lane's counters
     } lanes[MAX_LANES];
@@ -280,7 +282,8 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
                 if (hipEventCreate(&ln.ev_window[k]) != hipSuccess || hipEventCreate(&ln.ev_decoded[k]) != hipSuccess) rc = NRSC5HIP_EHIP;
                 ln.decoded_pending[k] = false;
             }
-            ln.acq_needed = true; ln.px_needed = true; ln.step_count = 0;
+            ln.acq_needed = true; ln.px_needed = true; ln.step_count = 0; ln.am_step_count = 0;
+            for (int k = 0; k < NWIN; k++) ln.am_decoded_pending[k] = false;
             if (!rc && hipHostMalloc((void **)&ln.counters_host, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) rc = NRSC5HIP_ENOMEM;
         }
         if (rc) { snprintf(g_err, sizeof(g_err), "stream/event creation failed"); break; }
@@ -318,17 +321,22 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             if (hipMemset(db.px_mem, 0, S * 2 * PX_MEM) != hipSuccess || hipMemset(db.px_pair, 0, S * 4 * PX_MAX) != hipSuccess ||
                 hipMemset(db.px_job, 0xff, S * NWIN * 16 * sizeof(PxJob)) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "PX state init failed"); break; }
         }
-        db.am = nullptr; db.am_sym = nullptr; db.am_q = nullptr; db.am_vit = nullptr; db.am_dec = nullptr;
+        db.am = nullptr; db.am_sym = nullptr; db.am_q = nullptr; db.am_vit = nullptr; db.am_dec = nullptr; db.am_job = nullptr; db.am_ber = nullptr; db.am_nvit = 1;
         if (cfg->am_enable) {
             if ((rc = dev_alloc(e, &db.am, S))) break;
             if ((rc = dev_alloc(e, &db.am_sym, S * 4 * AM_SYMS))) break;
             if ((rc = dev_alloc(e, &db.am_q, S * 4 * 3 * 18000))) break;
-            if ((rc = dev_alloc(e, &db.am_vit, S * 2 * AM_VIT))) break;
-            if ((rc = dev_alloc(e, &db.am_dec, S * (size_t)(AM_DEC_P1 + AM_DEC_P3)))) break;
+            db.am_nvit = cfg->p1_async ? NWIN : 1;
+            const size_t ndec = cfg->p1_async ? NAUX : 1;
+            if ((rc = dev_alloc(e, &db.am_vit, S * db.am_nvit * 2 * AM_VIT))) break;
+            if ((rc = dev_alloc(e, &db.am_dec, ndec * S * (size_t)(8 * AM_DEC_P1 + AM_DEC_P3)))) break;
+            if ((rc = dev_alloc(e, &db.am_job, S * NWIN))) break;
+            if ((rc = dev_alloc(e, &db.am_ber, S * (size_t)cfg->p1_slots))) break;
+            if (hipMemset(db.am_job, 0, S * NWIN * sizeof(AmJob)) != hipSuccess || hipMemset(db.am_ber, 0, S * (size_t)cfg->p1_slots * sizeof(float)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
             std::vector<AmStream> ainit(S);
             for (size_t k = 0; k < S; k++) init_am_state(ainit[k]);
             if (hipMemcpy(db.am, ainit.data(), S * sizeof(AmStream), hipMemcpyHostToDevice) != hipSuccess ||
-                hipMemset(db.am_q, 0, S * 4 * 3 * 18000) != hipSuccess || hipMemset(db.am_vit, 0, S * 2 * AM_VIT) != hipSuccess ||
+                hipMemset(db.am_q, 0, S * 4 * 3 * 18000) != hipSuccess || hipMemset(db.am_vit, 0, S * db.am_nvit * 2 * AM_VIT) != hipSuccess ||
                 hipMemset(db.am_sym, 0, S * 4 * AM_SYMS) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "AM state init failed"); break; }
         }
         db.sync_phase_cycles = nullptr;
@@ -506,17 +514,51 @@ static int run_steps(nrsc5hip_engine *e, int n, const int *ids_dev, int max_step
     return run_steps_lanes(e, 1, &n, ids, max_steps, check_every, steps_done);
 }
 
-// AM streams: one fused kernel per block step (k_am.hip), decoded in order on the lane's main stream
+// AM streams: one fused kernel per block step (k_am.hip).  p1_async = 0: every frame decodes in order on the main stream
+// (reference event timing).  p1_async = 1: window pipeline as for FM -- each 8-step window hands the L1 frames whose
+// de-interleave fell into it to one of the decode streams, where their 8 P1 frames and P3 frame decode concurrently.
+static int am_flush(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const int *ids_dev)
+{
+    if (!e->cfg.p1_async) return 0;
+    if (ln.am_step_count % 8) {
+        const long long window = ln.am_step_count / 8;
+        const int parity = (int)(window % NWIN), lane = (int)(window % e->naux);
+        hipStream_t ax = ln.aux[lane];
+        HIPCHK(hipEventRecord(ln.ev_window[parity], ln.main));
+        HIPCHK(hipStreamWaitEvent(ax, ln.ev_window[parity], 0));
+        { ProfScope p(e, NRSC5HIP_PROF_AM, ax); launch_am_decode(e->tb, ln.db, n, ids_dev, parity, lane, e->cfg.l2_feedback, ax); }
+        ln.am_step_count += 8 - (ln.am_step_count % 8);
+    }
+    for (int k = 0; k < NAUX; k++) HIPCHK(hipStreamSynchronize(ln.aux[k]));
+    for (int k = 0; k < NWIN; k++) ln.am_decoded_pending[k] = false;
+    return 0;
+}
+
 static int run_steps_am(nrsc5hip_engine *e, int n, const int *ids_dev, int max_steps, int check_every, int *steps_done)
 {
     nrsc5hip_engine::Lane &ln = e->lanes[0];
+    const bool pipe = e->cfg.p1_async != 0;
     int done = 0;
     while (done < max_steps) {
         HIPCHK(hipMemsetAsync(ln.counters_dev, 0, 4 * sizeof(int), ln.main));
         int burst = 0;
         for (; burst < check_every && done + burst < max_steps; burst++) {
-            ProfScope p(e, NRSC5HIP_PROF_AM, ln.main);
-            launch_am_step(e->tb, ln.db, n, ids_dev, ln.main, e->cfg.l2_feedback);
+            const long long window = ln.am_step_count / 8;
+            const int parity = pipe ? (int)(window % NWIN) : -1, lane = (int)(window % e->naux);
+            if (pipe && (ln.am_step_count % 8) == 0 && ln.am_decoded_pending[parity]) {
+                HIPCHK(hipStreamWaitEvent(ln.main, ln.ev_decoded[parity], 0));   // the window that used these buffers NWIN windows ago
+                ln.am_decoded_pending[parity] = false;
+            }
+            { ProfScope p(e, NRSC5HIP_PROF_AM, ln.main); launch_am_step(e->tb, ln.db, n, ids_dev, ln.main, e->cfg.l2_feedback, parity); }
+            if (pipe && (ln.am_step_count % 8) == 7) {
+                hipStream_t ax = ln.aux[lane];
+                HIPCHK(hipEventRecord(ln.ev_window[parity], ln.main));
+                HIPCHK(hipStreamWaitEvent(ax, ln.ev_window[parity], 0));
+                { ProfScope p(e, NRSC5HIP_PROF_AM, ax); launch_am_decode(e->tb, ln.db, n, ids_dev, parity, lane, e->cfg.l2_feedback, ax); }
+                HIPCHK(hipEventRecord(ln.ev_decoded[parity], ax));
+                ln.am_decoded_pending[parity] = true;
+            }
+            ln.am_step_count++;
         }
         HIPCHK(hipMemcpyAsync(ln.counters_host, ln.counters_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, ln.main));
         HIPCHK(hipStreamSynchronize(ln.main));
@@ -524,6 +566,8 @@ static int run_steps_am(nrsc5hip_engine *e, int n, const int *ids_dev, int max_s
         if (ln.counters_host[0] == 0) break;
         done += burst;
     }
+    { int rc = am_flush(e, ln, n, ids_dev); if (rc) return rc; }
+    HIPCHK(hipStreamSynchronize(ln.main));
     if (e->prof_on) prof_collect(e);
     if (steps_done) *steps_done = done;
     return 0;
@@ -606,7 +650,11 @@ extern "C" int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream)
     HIPCHK(hipDeviceSynchronize());
     StreamState st; init_state(st, e->mode_host[stream]);
     HIPCHK(hipMemcpy(e->db.state + stream, &st, sizeof(st), hipMemcpyHostToDevice));
-    if (e->db.am) { AmStream am; init_am_state(am); HIPCHK(hipMemcpy(e->db.am + stream, &am, sizeof(am), hipMemcpyHostToDevice)); }
+    if (e->db.am) {
+        AmStream am; init_am_state(am);
+        HIPCHK(hipMemcpy(e->db.am + stream, &am, sizeof(am), hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(e->db.am_job + (size_t)stream * NWIN, 0, NWIN * sizeof(AmJob)));
+    }
     e->wr_host[stream] = 0; e->base_host[stream] = 0; e->drained[stream] = 0; e->raw_host[stream] = 0;
     for (int l = 0; l < e->nlanes; l++) { e->lanes[l].acq_needed = true; e->lanes[l].px_needed = true; }
     return 0;
@@ -781,6 +829,22 @@ static int fetch_nblocks(nrsc5hip_engine *e, int s, int *nblocks)
     return 0;
 }
 
+// Window pipeline, AM: the BER of an L1 frame is known when the last of its nine deferred decodes finishes, after the
+// record of its block 7 was written -- it is kept per ring slot and merged into the records handed to the caller.
+static int patch_am_ber(nrsc5hip_engine *e, int stream, nrsc5hip_record *recs, int n, const float *ber_row)
+{
+    std::vector<float> tmp;
+    if (!ber_row) {
+        tmp.resize(e->db.p1_slots);
+        HIPCHK(hipMemcpy(tmp.data(), e->db.am_ber + (size_t)stream * e->db.p1_slots, tmp.size() * sizeof(float), hipMemcpyDeviceToHost));
+        ber_row = tmp.data();
+    }
+    for (int k = 0; k < n; k++)
+        if ((recs[k].flags & NRSC5HIP_REC_P1) && recs[k].bc_decoded == 7 && recs[k].p1_slot >= 0 && recs[k].p1_slot < e->db.p1_slots)
+            recs[k].ber = ber_row[recs[k].p1_slot];
+    return 0;
+}
+
 extern "C" int nrsc5hip_drain(nrsc5hip_engine *e, int stream, nrsc5hip_record *out, int max, int *n_out)
 {
     int rc = check_stream(e, stream); if (rc) return rc;
@@ -800,6 +864,7 @@ extern "C" int nrsc5hip_drain(nrsc5hip_engine *e, int stream, nrsc5hip_record *o
     }
     e->drained[stream] += n;
     *n_out = n;
+    if (e->cfg.p1_async && e->db.am && e->mode_host[stream] == MODE_AM && n > 0) return patch_am_ber(e, stream, out, n, nullptr);
     return 0;
 }
 
@@ -1007,6 +1072,7 @@ extern "C" int nrsc5hip_reset_all(nrsc5hip_engine *e)
         std::vector<AmStream> ainit(S);
         for (size_t s = 0; s < S; s++) init_am_state(ainit[s]);
         HIPCHK(hipMemcpy(e->db.am, ainit.data(), S * sizeof(AmStream), hipMemcpyHostToDevice));
+        HIPCHK(hipMemset(e->db.am_job, 0, S * NWIN * sizeof(AmJob)));
     }
     std::fill(e->raw_host.begin(), e->raw_host.end(), 0);
     std::fill(e->wr_host.begin(), e->wr_host.end(), 0);
@@ -1015,7 +1081,8 @@ extern "C" int nrsc5hip_reset_all(nrsc5hip_engine *e)
     HIPCHK(hipMemset(e->db.pids_rec, 0xff, S * NWIN * 16 * sizeof(int)));
     HIPCHK(hipMemset(e->db.px_job, 0xff, S * NWIN * 16 * sizeof(PxJob)));
     for (int l = 0; l < e->nlanes; l++) {
-        e->lanes[l].acq_needed = true; e->lanes[l].px_needed = true; e->lanes[l].step_count = 0;
+        e->lanes[l].acq_needed = true; e->lanes[l].px_needed = true; e->lanes[l].step_count = 0; e->lanes[l].am_step_count = 0;
+        for (int k = 0; k < NWIN; k++) e->lanes[l].am_decoded_pending[k] = false;
         for (int k = 0; k < NWIN; k++) e->lanes[l].decoded_pending[k] = false;
     }
     return 0;
@@ -1120,6 +1187,19 @@ extern "C" int nrsc5hip_batch_fetch_view(nrsc5hip_engine *e, int nstreams, const
     if (frames)
         HIPCHK(hipMemcpyAsync(e->frames_host, e->db.p1_ring, (size_t)nstreams * e->db.p1_slots * P1_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, e->main));
     HIPCHK(hipStreamSynchronize(e->main));
+    if (e->cfg.p1_async && e->db.am) {
+        std::vector<float> ber((size_t)nstreams * e->db.p1_slots);
+        bool any = false;
+        for (int s = 0; s < nstreams; s++) any |= e->mode_host[s] == MODE_AM;
+        if (any) {
+            HIPCHK(hipMemcpy(ber.data(), e->db.am_ber, ber.size() * sizeof(float), hipMemcpyDeviceToHost));
+            for (int s = 0; s < nstreams; s++)
+                if (e->mode_host[s] == MODE_AM) {
+                    const int nrec = e->nblocks_host[s] < e->db.rec_cap ? e->nblocks_host[s] : e->db.rec_cap;
+                    patch_am_ber(e, s, (nrsc5hip_record *)e->rec_host + (size_t)s * e->db.rec_cap, nrec, ber.data() + (size_t)s * e->db.p1_slots);
+                }
+        }
+    }
     for (int s = 0; s < nstreams; s++) {
         if (e->drained[s] != 0 || e->nblocks_host[s] > e->db.rec_cap)
             FAIL(NRSC5HIP_EOVERFLOW, "stream %d: view needs an undrained, unwrapped record ring (%d records, capacity %d)", s, e->nblocks_host[s], e->db.rec_cap);

@@ -444,7 +444,7 @@ __device__ inline void am_fft_all(AmBlockSmem &sm)
 // spectrum bin `off` relative to the carrier (fftshift folded into the index), symbol n
 __device__ inline float2 &am_bin(AmBlockSmem &sm, int off, int n) { return sm.X[n * AM_FFT + (off & 255)]; }
 
-__global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, const int *ids)
+__global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, const int *ids, int pipeline)
 {
     const int s = stream_of(ids, blockIdx.x);
     StreamState &st = db.state[s];
@@ -453,7 +453,12 @@ __global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, c
     AmBlockSmem &sm = *(AmBlockSmem *)smem_raw;
     const int tid = threadIdx.x;
     const bool ready = st.wr - st.rd >= AM_WIN;                 // block-uniform
-    if (tid == 0) { am.dec_bc = -1; st.active = ready ? 1 : 0; }
+    if (tid == 0) {
+        am.dec_bc = -1; st.active = ready ? 1 : 0;
+        // late L2 feedback raised by a deferred decode (window pipeline): take it before this block, as input.c:172-188
+        if (ready && st.force_none) { if (st.sync_state == SYNC_FINE) st.sync_state = SYNC_NONE; st.force_none = 0; }
+    }
+    __syncthreads();
     if (!ready) return;
     const c16 *win = db.q15 + (size_t)s * db.q15_cap + (st.rd - st.base);
     const int state_before = st.sync_state;
@@ -757,7 +762,13 @@ __global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, c
             am.dec_bc = bc; am.dec_record = st.nblocks % db.rec_cap; am.dec_rdbi = am.rdbi; am.dec_psmi = st.psmi;
             if (bc == 0) {
                 am.am_errors = 0;
-                if (am.am_diversity_wait == 0) { am.frame_slot = st.p1_count % db.p1_slots; st.p1_count++; }
+                if (am.am_diversity_wait == 0) am.frame_slot = am.next_slot;
+            }
+            if (pipeline && am.am_diversity_wait == 0) {
+                // the frame's decodes run (or ran) on a decode stream from the trellis inputs of the previous L1 frame:
+                // this block only announces what decode_process_p1_p3_am delivers here (decode.c:507-554)
+                rec.flags |= REC_P1 | ((bc == 7 && !am.rdbi) ? (uint32_t)REC_P3 : 0u);
+                rec.p1_slot = am.frame_slot;
             }
             st.bc = (bc + 1) % 8;
         }
@@ -785,16 +796,16 @@ __global__ __launch_bounds__(64) void k_am_viterbi(DevTables tb, DevBuffers db, 
     const StreamState &st = db.state[s];
     AmStream &am = db.am[s];
     if (!st.active || am.dec_bc < 0 || am.am_diversity_wait != 0) return;      // block-uniform
-    const int role = blockIdx.x, bc = am.dec_bc;                                 // 0: P1, 1: P3
+    const int role = blockIdx.x, bc = am.dec_bc;                                 // 0: P1, 1: P3 (in-order mode)
     if (role == 1 && (bc != 7 || am.dec_rdbi)) return;
     __shared__ K9WSmem k9;
     __shared__ int red[4];
     const bool ma3 = am.dec_psmi == AM_MA3;
     uint32_t *slot = db.p1_ring + ((size_t)s * db.p1_slots + am.frame_slot) * P1_WORDS;
-    unsigned long long *dec = db.am_dec + (size_t)s * (AM_DEC_P1 + AM_DEC_P3);
+    unsigned long long *dec = db.am_dec + (size_t)s * (size_t)(8 * AM_DEC_P1 + AM_DEC_P3);
     BlockRecord &rec = db.records[(size_t)s * db.rec_cap + am.dec_record];
     if (role == 0) {
-        const int8_t *in = db.am_vit + (size_t)s * 2 * AM_VIT + (size_t)bc * AM_P1_LEN * 3;
+        const int8_t *in = db.am_vit + (size_t)s * db.am_nvit * 2 * AM_VIT + (size_t)bc * AM_P1_LEN * 3;
         uint32_t *out = slot + bc * AM_P1_WORDS;
         viterbi_k9_wave(in, AM_P1_LEN, GEN_E1_0, GEN_E1_1, GEN_E1_2, dec, out, k9);
         const int err = am_bit_errors(in, out, AM_P1_LEN, GEN_E1_0, GEN_E1_1, GEN_E1_2, PUNCT_E1, 15, red);
@@ -814,15 +825,15 @@ __global__ __launch_bounds__(64) void k_am_viterbi(DevTables tb, DevBuffers db, 
             }
         }
     } else {
-        const int8_t *in = db.am_vit + (size_t)s * 2 * AM_VIT + AM_VIT;
+        const int8_t *in = db.am_vit + (size_t)s * db.am_nvit * 2 * AM_VIT + AM_VIT;
         uint32_t *out = slot + AM_P3_WORD0;
         const int len = ma3 ? AM_P3_LEN_MA3 : AM_P3_LEN_MA1;
         int err;
         if (!ma3) {
-            viterbi_k9_wave(in, len, GEN_E2_0, GEN_E2_1, GEN_E2_2, dec + AM_DEC_P1, out, k9);
+            viterbi_k9_wave(in, len, GEN_E2_0, GEN_E2_1, GEN_E2_2, dec + (size_t)8 * AM_DEC_P1, out, k9);
             err = am_bit_errors(in, out, len, GEN_E2_0, GEN_E2_1, GEN_E2_2, PUNCT_E2, 6, red);
         } else {
-            viterbi_k9_wave(in, len, GEN_E1_0, GEN_E1_1, GEN_E1_2, dec + AM_DEC_P1, out, k9);
+            viterbi_k9_wave(in, len, GEN_E1_0, GEN_E1_1, GEN_E1_2, dec + (size_t)8 * AM_DEC_P1, out, k9);
             err = am_bit_errors(in, out, len, GEN_E1_0, GEN_E1_1, GEN_E1_2, PUNCT_E1, 15, red);
         }
         const int words = (len + 31) / 32;
@@ -844,7 +855,7 @@ __device__ inline int am_cell_bit(const uint8_t *m, int b, int k, int p)
     return (m[AM_PW * (b * NSYM + row) + col] >> p) & 1;
 }
 
-__global__ __launch_bounds__(1024) void k_am_interleave(DevBuffers db, const int *ids)
+__global__ __launch_bounds__(1024) void k_am_interleave(DevBuffers db, const int *ids, int parity)
 {
     const int s = stream_of(ids, blockIdx.x);
     const StreamState &st = db.state[s];
@@ -852,7 +863,8 @@ __global__ __launch_bounds__(1024) void k_am_interleave(DevBuffers db, const int
     if (!st.active || am.dec_bc != 7) return;                  // block-uniform
     const bool ma3 = am.dec_psmi == AM_MA3;
     const int tid = threadIdx.x;
-    if (tid == 0 && am.am_diversity_wait == 0) {
+    const int vslot = parity < 0 ? 0 : parity;                 // window pipeline: one set of trellis inputs per window in flight
+    if (tid == 0 && parity < 0 && am.am_diversity_wait == 0) {
         unsigned total = 8 * (AM_P1_LEN * 12 / 5);
         if (!am.dec_rdbi) total += ma3 ? AM_P3_LEN_MA3 * 12 / 5 : AM_P3_LEN_MA1 * 3 / 2;
         db.records[(size_t)s * db.rec_cap + am.dec_record].ber = (float)am.am_errors / (float)total;
@@ -860,7 +872,7 @@ __global__ __launch_bounds__(1024) void k_am_interleave(DevBuffers db, const int
     const uint8_t *pl = db.am_sym + (size_t)s * 4 * AM_SYMS, *pu = pl + AM_SYMS, *sy = pu + AM_SYMS, *tt = sy + AM_SYMS;
     uint8_t *q = db.am_q + (size_t)s * 4 * 3 * 18000;         // [ml, mu, eml, emu][3][18000]
     const int head = am.q_head;
-    int8_t *v1 = db.am_vit + (size_t)s * 2 * AM_VIT, *v3 = v1 + AM_VIT;
+    int8_t *v1 = db.am_vit + ((size_t)s * db.am_nvit + vslot) * 2 * AM_VIT, *v3 = v1 + AM_VIT;
     // position inside a 12-bit group -> (source, j): bl {2,1,5}, ml {11,6,7}, bu {10,8,9}, mu {4,3,0} (decode.c:26-30)
     const int src12[12] = { 3, 0, 0, 3, 3, 0, 1, 1, 2, 2, 2, 1 };
     const int j12[12] = { 2, 1, 0, 1, 0, 2, 1, 2, 1, 2, 0, 0 };
@@ -938,16 +950,86 @@ __global__ __launch_bounds__(1024) void k_am_interleave(DevBuffers db, const int
     if (tid == 0) {
         am.q_head = (head + 1) % 3;
         if (am.am_diversity_wait > 0) am.am_diversity_wait--;
+        if (am.am_diversity_wait == 0) {
+            // the next L1 frame delivers what these trellis inputs decode to: reserve its ring slot now
+            StreamState &stw = db.state[s];
+            am.next_slot = stw.p1_count % db.p1_slots; stw.p1_count++;
+            if (parity >= 0) {
+                AmJob &job = db.am_job[(size_t)s * NWIN + parity];
+                job.slot = am.next_slot; job.psmi = am.dec_psmi; job.rdbi = am.dec_rdbi; job.errors = 0; job.done = 0; job.valid = 1;
+            }
+        }
     }
 }
 
-void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int l2_feedback)
+// ---- window pipeline: all nine frames of an L1 frame decode concurrently on a decode stream ---------------------------
+__global__ __launch_bounds__(64) void k_am_decode(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id, int l2_feedback)
+{
+    const int s = stream_of(ids, blockIdx.y), role = blockIdx.x;           // 0..7: P1 frame of that block, 8: P3
+    AmJob &job = db.am_job[(size_t)s * NWIN + parity];
+    if (!job.valid) return;                                                // wave-uniform
+    if (role == 8 && job.rdbi) return;
+    __shared__ K9WSmem k9;
+    __shared__ int red[4];
+    const bool ma3 = job.psmi == AM_MA3;
+    const int8_t *vit = db.am_vit + ((size_t)s * db.am_nvit + parity) * 2 * AM_VIT;
+    uint32_t *slot = db.p1_ring + ((size_t)s * db.p1_slots + job.slot) * P1_WORDS;
+    unsigned long long *dec = db.am_dec + ((size_t)lane_id * db.nstreams_alloc + s) * (size_t)(8 * AM_DEC_P1 + AM_DEC_P3);
+    int err;
+    if (role < 8) {
+        const int8_t *in = vit + (size_t)role * AM_P1_LEN * 3;
+        uint32_t *out = slot + role * AM_P1_WORDS;
+        viterbi_k9_wave(in, AM_P1_LEN, GEN_E1_0, GEN_E1_1, GEN_E1_2, dec + (size_t)role * AM_DEC_P1, out, k9);
+        err = am_bit_errors(in, out, AM_P1_LEN, GEN_E1_0, GEN_E1_1, GEN_E1_2, PUNCT_E1, 15, red);
+        for (int w = threadIdx.x; w < AM_P1_WORDS; w += 64)
+            out[w] = (out[w] ^ tb.scr_p1[w]) & (w == AM_P1_WORDS - 1 ? (1u << (AM_P1_LEN & 31)) - 1u : 0xffffffffu);
+        __threadfence_block();
+        __syncthreads();
+        if (l2_feedback && threadIdx.x == 0) {                 // frame.c:535-540, applied by the next k_am_block of the stream
+            __shared__ L2Smem l2;
+            l2_gf_init(l2);
+            if (!l2_first_header_ok_am(out, l2)) db.state[s].force_none = 1;
+        }
+    } else {
+        const int8_t *in = vit + AM_VIT;
+        uint32_t *out = slot + AM_P3_WORD0;
+        const int len = ma3 ? AM_P3_LEN_MA3 : AM_P3_LEN_MA1;
+        if (!ma3) {
+            viterbi_k9_wave(in, len, GEN_E2_0, GEN_E2_1, GEN_E2_2, dec + (size_t)8 * AM_DEC_P1, out, k9);
+            err = am_bit_errors(in, out, len, GEN_E2_0, GEN_E2_1, GEN_E2_2, PUNCT_E2, 6, red);
+        } else {
+            viterbi_k9_wave(in, len, GEN_E1_0, GEN_E1_1, GEN_E1_2, dec + (size_t)8 * AM_DEC_P1, out, k9);
+            err = am_bit_errors(in, out, len, GEN_E1_0, GEN_E1_1, GEN_E1_2, PUNCT_E1, 15, red);
+        }
+        const int words = (len + 31) / 32;
+        const uint32_t tailmask = (len & 31) ? (1u << (len & 31)) - 1u : 0xffffffffu;
+        for (int w = threadIdx.x; w < words; w += 64) out[w] = (out[w] ^ tb.scr_p1[w]) & (w == words - 1 ? tailmask : 0xffffffffu);
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(&job.errors, (unsigned)err);
+        __threadfence();
+        const int expected = job.rdbi ? 8 : 9;
+        if (atomicAdd(&job.done, 1) == expected - 1) {         // last of the frame's decodes: nrsc5_report_ber's value (decode.c:545)
+            unsigned total = 8 * (AM_P1_LEN * 12 / 5);
+            if (!job.rdbi) total += ma3 ? AM_P3_LEN_MA3 * 12 / 5 : AM_P3_LEN_MA1 * 3 / 2;
+            db.am_ber[(size_t)s * db.p1_slots + job.slot] = (float)atomicAdd(&job.errors, 0u) / (float)total;
+            job.valid = 0;
+        }
+    }
+}
+
+void launch_am_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, int l2_feedback, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_am_decode, dim3(9, nstreams), dim3(64), 0, st, tb, db, stream_ids, parity, lane_id, l2_feedback);
+}
+
+void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int l2_feedback, int pipeline_parity)
 {
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_am_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AmBlockSmem)); attr_set = true; }
-    hipLaunchKernelGGL(k_am_block, dim3(nstreams), dim3(256), sizeof(AmBlockSmem), st, tb, db, stream_ids);
-    hipLaunchKernelGGL(k_am_viterbi, dim3(2, nstreams), dim3(64), 0, st, tb, db, stream_ids, l2_feedback);
-    hipLaunchKernelGGL(k_am_interleave, dim3(nstreams), dim3(1024), 0, st, db, stream_ids);
+    hipLaunchKernelGGL(k_am_block, dim3(nstreams), dim3(256), sizeof(AmBlockSmem), st, tb, db, stream_ids, pipeline_parity >= 0 ? 1 : 0);
+    if (pipeline_parity < 0) hipLaunchKernelGGL(k_am_viterbi, dim3(2, nstreams), dim3(64), 0, st, tb, db, stream_ids, l2_feedback);
+    hipLaunchKernelGGL(k_am_interleave, dim3(nstreams), dim3(1024), 0, st, db, stream_ids, pipeline_parity);
 }
 
 // ---- stage-level entry: decode `nframes` independent K=9 frames (parity tests) ------------------------------------

@@ -54,8 +54,11 @@ struct DevBuffers {
     AmStream *am;                    // [S]
     uint8_t *am_sym;                 // [S][4][AM_SYMS]   hard symbols of the current L1 frame: pl, pu, s, t
     uint8_t *am_q;                   // [S][4][3][18000]  diversity delay lines ml, mu, eml, emu (3 frames each)
-    int8_t *am_vit;                  // [S][2][AM_VIT]    depunctured trellis inputs: 8 x P1, P3
-    unsigned long long *am_dec;      // [S][AM_DEC_P1 + AM_DEC_P3]  survivor decisions
+    int8_t *am_vit;                  // [S][am_nvit][2][AM_VIT]  depunctured trellis inputs: 8 x P1, P3 (am_nvit = NWIN in the window pipeline, else 1)
+    int am_nvit;
+    unsigned long long *am_dec;      // [am_ndec][S][8 * AM_DEC_P1 + AM_DEC_P3]  survivor decisions (one set per decode stream)
+    AmJob *am_job;                   // [S][NWIN]
+    float *am_ber;                   // [S][p1_slots]  window pipeline: BER of the L1 frame in each ring slot
 };
 
 // ---- K1 -------------------------------------------------------------------------------
@@ -83,7 +86,9 @@ void launch_am_decimate_cu8(const DevTables &tb, const DevBuffers &db, int nstre
                             const uint8_t *iq_base, long long iq_stride, const unsigned *nbytes, unsigned max_nbytes, hipStream_t st);
 // one block step: acquire (or track) -> 2 x 32 FFT-256 -> sync_process_am -> PIDS; then this block's P1 / P3 decodes
 // and, after block 7, the bit de-interleaver of the finished L1 frame
-void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int l2_feedback = 0);
+void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int l2_feedback = 0, int pipeline_parity = -1);
+// window pipeline: the 8 P1 frames and the P3 frame of every L1 frame whose de-interleave happened in window `parity`
+void launch_am_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, int l2_feedback, hipStream_t st);
 void launch_viterbi_k9_frames(const int8_t *coded, int len, int nframes, unsigned g0, unsigned g1, unsigned g2,
                               unsigned long long *dec, uint32_t *out, hipStream_t st);
 

@@ -157,6 +157,11 @@ struct AmStream {
     int dec_record;             // record index of that block
     int dec_rdbi, dec_psmi;
     int frame_slot;             // slot of the frame ring that receives this L1 frame's P1/P3 frames
+    int next_slot;              // slot assigned (by the de-interleaver) to the frame whose trellis inputs it just produced
+    int vit_parity;             // in-order mode: always 0; window pipeline: vit buffer of the frame being delivered
 };
+
+// window pipeline: one L1 frame's worth of decodes (8 x P1 + P3) handed to k_am_decode
+struct AmJob { int valid, slot, psmi, rdbi; unsigned errors; int done; int pad[2]; };
 
 }  // namespace nrsc5

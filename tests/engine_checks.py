@@ -339,7 +339,7 @@ def check_am_golden_end_to_end(lib, name, captures):
     return log
 
 
-def check_am_batch_equals_streaming(lib, kws):
+def check_am_batch_equals_streaming(lib, kws, p1_async=False):
     """Device-resident batch of AM captures (cs16 and cu8 lists) == the same captures through the streaming seam."""
     from nrsc5_amd import synth_am
     caps = [synth_am.am_ma1_capture(**kw) for kw in kws]
@@ -352,7 +352,7 @@ def check_am_batch_equals_streaming(lib, kws):
     fmt = caps[0].iq.dtype
     stride = max(c.iq.size for c in caps)
     stride += (-stride) % 64
-    E = eng.Engine(max_streams=n, q15_capacity=stride // 2 + 1024, record_capacity=512, p1_slots=16, lib_path=lib, am_enable=True)
+    E = eng.Engine(max_streams=n, q15_capacity=stride // 2 + 1024, record_capacity=512, p1_slots=16, lib_path=lib, am_enable=True, p1_async=p1_async)
     for k in range(n):
         E.set_mode(k, eng.MODE_AM)
     buf = np.zeros((n, stride), dtype=fmt)
@@ -370,7 +370,7 @@ def check_am_batch_equals_streaming(lib, kws):
     else:
         E.batch_append_cs16(dptr, stride, sizes)
     E.batch_process(n)
-    recs, counts, frames = E.batch_fetch(n)
+    recs, counts, frames = E.batch_fetch_view(n) if p1_async else E.batch_fetch(n)
     for k in range(n):
         log = eng.am_records_to_log(E, k, recs[k, :counts[k]], frames[k])
         d = common.compare_logs(logs[k], log, rtol=0.0)

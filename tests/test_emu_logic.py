@@ -88,6 +88,12 @@ def test_emu_am_batch_equals_streaming(emu_lib):
     ec.check_am_batch_equals_streaming(emu_lib, [dict(n_frames=9, seed=32, cfo_hz=-20.0, offset=5000), dict(n_frames=3, seed=33)])
 
 
+def test_emu_am_window_pipeline_equals_in_order(emu_lib):
+    """p1_async: the nine frames of an L1 frame decode concurrently on a decode stream, BER merged at fetch time."""
+    ec.check_am_batch_equals_streaming(emu_lib, [dict(n_frames=11, seed=34, cfo_hz=7.0, offset=300), dict(n_frames=9, seed=35, offset=4000),
+                                                 dict(n_frames=9, seed=8, cfo_hz=-6.0, offset=2000, mode="MA3")], p1_async=True)
+
+
 def test_emu_am_ma3_end_to_end(emu_lib, oracle):
     """All-digital layout (psmi 2): no sideband combining, QAM64 everywhere, 30000-bit P3 frames through the E1 code."""
     ec.check_am_oracle_end_to_end(emu_lib, oracle, dict(n_frames=8, seed=8, cfo_hz=-6.0, offset=2000, mode="MA3"))

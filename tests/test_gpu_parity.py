@@ -209,6 +209,12 @@ def test_gpu_am_batch_equals_streaming(hip_lib):
     ec.check_am_batch_equals_streaming(hip_lib, [dict(n_frames=2, seed=41, fmt="cu8"), dict(n_frames=1, seed=42, fmt="cu8", offset=3333)])
 
 
+def test_gpu_am_window_pipeline_equals_in_order(hip_lib):
+    ec.check_am_batch_equals_streaming(hip_lib, [dict(n_frames=14, seed=34, cfo_hz=7.0, offset=300), dict(n_frames=9, seed=35, offset=4000),
+                                                dict(n_frames=12, seed=8, cfo_hz=-6.0, offset=2000, mode="MA3"),
+                                                dict(n_frames=10, seed=36, cfo_hz=-3.0, offset=0)], p1_async=True)
+
+
 # ---- the L2 -> L1 feedback on the device ------------------------------------------------------------------
 @pytest.mark.parametrize("kw", [
     dict(n_frames=0, n_blocks=40, seed=23, cfo_hz=0.0, offset=1234, snr_db=20.0),

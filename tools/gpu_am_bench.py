@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--streams", type=int, default=256)
     ap.add_argument("--frames", type=int, default=41, help="L1 frames per stream (41 = 61 s)")
     ap.add_argument("--fmt", default="cs16", choices=["cs16", "cu8"])
+    ap.add_argument("--in-order", action="store_true", help="decode every frame in order on the main stream (reference event timing)")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     args = ap.parse_args()
@@ -37,7 +38,7 @@ def main():
     torch.cuda.synchronize()
     nsamp = n / 2
     E = eng.Engine(max_streams=S, q15_capacity=int(nsamp / (1 if args.fmt == "cs16" else 32)) + 4096, record_capacity=8 * args.frames + 16,
-                   p1_slots=args.frames, am_enable=True)
+                   p1_slots=args.frames, am_enable=True, p1_async=not args.in_order)
     for k in range(S):
         E.set_mode(k, eng.MODE_AM)
     sizes = np.full(S, n, dtype=np.uint32)
@@ -49,7 +50,7 @@ def main():
         else:
             E.batch_append_cu8(iq.data_ptr(), n, sizes)
         steps = E.batch_process(S)
-        return steps, E.batch_fetch(S)
+        return steps, (E.batch_fetch(S) if args.in_order else E.batch_fetch_view(S))
 
     for _ in range(args.warmup):
         one_pass()
@@ -78,7 +79,7 @@ def main():
                 ok3 += np.packbits(eng.unpack_bits(w, 24000), bitorder="little").tobytes() in truth3
     out = {"metric": "AM IQ MS/s demodulated and decoded", "fmt": args.fmt, "streams": S, "seconds_per_stream": round(nsamp / fs, 2),
            "value": round(S * nsamp / dt / 1e6, 3), "x_realtime": round(S * nsamp / fs / dt, 1), "ms_per_pass": round(dt * 1e3, 2),
-           "block_steps": steps, "device_ms_per_pass": {k: round(v[0] / args.steps, 3) for k, v in prof.items() if v[1]},
+           "decode": "in-order" if args.in_order else "window pipeline", "block_steps": steps, "device_ms_per_pass": {k: round(v[0] / args.steps, 3) for k, v in prof.items() if v[1]},
            "launches_per_pass": {k: v[1] // args.steps for k, v in prof.items() if v[1]},
            "truth": {"p1_checked": n1, "p1_exact": int(ok1), "p3_checked": n3, "p3_exact": int(ok3)}}
     print(json.dumps(out))
