@@ -5,5 +5,7 @@ mkdir -p gpurun_out
 ( time timeout 600 python -m pytest tests -m gpu -q -x -k "am" ) > gpurun_out/pytest_am.log 2>&1; echo "pytest am rc=$?"
 tail -5 gpurun_out/pytest_am.log
 ( timeout 300 python tools/gpu_am_bench.py --streams 256 --frames 41 --fmt cs16 ) > gpurun_out/am_bench_cs16.log 2>&1; echo "rc=$?"; grep "^{" gpurun_out/am_bench_cs16.log
+( timeout 300 python tools/gpu_am_bench.py --streams 256 --frames 41 --fmt cs16 --in-order ) > gpurun_out/am_bench_cs16_inorder.log 2>&1; echo "rc=$?"; grep "^{" gpurun_out/am_bench_cs16_inorder.log
+( timeout 300 python tools/gpu_am_bench.py --streams 128 --frames 41 --fmt cu8 --steps 2 ) > gpurun_out/am_bench_cu8.log 2>&1; echo "rc=$?"; grep "^{" gpurun_out/am_bench_cu8.log
 cd /tmp && ( timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_am -o am -- python $GRAFT_REPO_ROOT/tools/gpu_am_bench.py --streams 256 --frames 20 --fmt cs16 --steps 2 ) > $GRAFT_REPO_ROOT/gpurun_out/am_rocprof.log 2>&1
 cd $GRAFT_REPO_ROOT; head -6 $(find gpurun_out/prof_am -name "*kernel_stats*" | head -1)
