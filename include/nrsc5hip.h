@@ -185,6 +185,7 @@ int nrsc5hip_stage_selftest(nrsc5hip_engine *e, int *failures);
 int nrsc5hip_stage_viterbi_k7_debug(nrsc5hip_engine *e, const int8_t *soft, int len, uint8_t *bits, unsigned long long *dec_out);
 /* micro-benchmark of the Viterbi kernel on random frames: phases bit0 = forward, bit1 = traceback */
 int nrsc5hip_stage_viterbi_bench(nrsc5hip_engine *e, int len, int nframes, int phases, int reps, float *ms_per_launch);
+int nrsc5hip_stage_viterbi_k9_bench(nrsc5hip_engine *e, int len, int nframes, int phases, int reps, float *ms_per_launch);
 /* accumulated shader cycles per phase of the sync kernel for stream 0 (engine created with NRSC5HIP_SYNC_PHASES=1) */
 int nrsc5hip_debug_sync_phases(nrsc5hip_engine *e, long long *cycles8);
 /* debugging aid: soft-bit matrix (16 x 23040 int8) and live FFT bins of a stream's latest block */

@@ -1158,6 +1158,33 @@ extern "C" int nrsc5hip_stage_viterbi_bench(nrsc5hip_engine *e, int len, int nfr
     return 0;
 }
 
+// micro-benchmark of the K=9 trellis kernel (E2 code) on random hard-decision frames: phases bit0 = forward, bit1 = traceback
+extern "C" int nrsc5hip_stage_viterbi_k9_bench(nrsc5hip_engine *e, int len, int nframes, int phases, int reps, float *ms_per_launch)
+{
+    if (!e || !ms_per_launch || len < 128 || nframes < 1 || reps < 1) FAIL(NRSC5HIP_EINVAL, "bad argument");
+    int8_t *dsoft = nullptr; unsigned long long *ddec = nullptr; uint32_t *dout = nullptr;
+    const int words = (len + 31) / 32;
+    std::vector<int8_t> h((size_t)nframes * 3 * len);
+    unsigned x = 4321;
+    for (auto &v : h) { x = x * 1664525u + 1013904223u; v = (int8_t)((int)((x >> 24) % 3) - 1); }
+    HIPCHK(hipMalloc((void **)&dsoft, h.size()));
+    HIPCHK(hipMalloc((void **)&ddec, (size_t)nframes * 4 * (len + 64) * sizeof(unsigned long long)));
+    HIPCHK(hipMalloc((void **)&dout, (size_t)nframes * words * sizeof(uint32_t)));
+    HIPCHK(hipMemcpy(dsoft, h.data(), h.size(), hipMemcpyHostToDevice));
+    HIPCHK(hipMemset(ddec, 0x55, (size_t)nframes * 4 * (len + 64) * sizeof(unsigned long long)));
+    hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    launch_viterbi_k9_frames(dsoft, len, nframes, 0561, 0753, 0711, ddec, dout, e->main, phases);
+    HIPCHK(hipEventRecord(a, e->main));
+    for (int r = 0; r < reps; r++) launch_viterbi_k9_frames(dsoft, len, nframes, 0561, 0753, 0711, ddec, dout, e->main, phases);
+    HIPCHK(hipEventRecord(b, e->main));
+    HIPCHK(hipEventSynchronize(b));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b));
+    *ms_per_launch = ms / reps;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    (void)hipFree(dsoft); (void)hipFree(ddec); (void)hipFree(dout);
+    return 0;
+}
+
 extern "C" int nrsc5hip_debug_sync_phases(nrsc5hip_engine *e, long long *cycles8)
 {
     if (!e || !cycles8) FAIL(NRSC5HIP_EINVAL, "null argument");

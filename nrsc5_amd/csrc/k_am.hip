@@ -239,7 +239,7 @@ __device__ inline int k9_sign_word(unsigned b, unsigned g0, unsigned g1, unsigne
 }
 
 __device__ inline void viterbi_k9_wave(const int8_t *coded, int len, unsigned g0, unsigned g1, unsigned g2,
-                                       unsigned long long *dec, uint32_t *out, K9WSmem &sm)
+                                       unsigned long long *dec, uint32_t *out, K9WSmem &sm, int phases = 3)
 {
     const int lane = threadIdx.x & 63;
     const int sgw0 = k9_sign_word(2u * lane, g0, g1, g2), sgw1 = k9_sign_word(2u * lane + 1u, g0, g1, g2);
@@ -247,7 +247,7 @@ __device__ inline void viterbi_k9_wave(const int8_t *coded, int len, unsigned g0
     int cur = 0;
     for (int k = 0; k < 4; k++) sm.metric[0][4 * lane + k] = 0;
     WAVE_LDS_SYNC();
-    for (int c = 0; c < nchunks; c++) {
+    for (int c = 0; c < ((phases & 1) ? nchunks : 0); c++) {
         const int t0 = c << 6;
         int aw = 0;                                            // this lane's step of the chunk: soft triple packed as 3 x int8
         if (t0 + lane < steps) {
@@ -292,7 +292,7 @@ __device__ inline void viterbi_k9_wave(const int8_t *coded, int len, unsigned g0
     __threadfence_block();
     __syncthreads();
     // traceback: lane l holds the 4 decision words of step t0 + l; the walk itself is scalar (uniform state)
-    for (int c = nchunks - 1; c >= 0; c--) {
+    for (int c = ((phases & 2) ? nchunks - 1 : -1); c >= 0; c--) {
         const int t0 = c << 6, nst = min(64, steps - t0);
         unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0;
         if (lane < nst) { const unsigned long long *d = dec + (size_t)(t0 + lane) * 4; w0 = d[0]; w1 = d[1]; w2 = d[2]; w3 = d[3]; }
@@ -1041,18 +1041,18 @@ __global__ __launch_bounds__(256) void k_viterbi_k9_frames(const int8_t *coded, 
     viterbi_k9_block(coded + (size_t)f * 3 * len, len, g0, g1, g2, dec + (size_t)f * 4 * (len + 64), out + (size_t)f * ((len + 31) / 32), k9);
 }
 __global__ __launch_bounds__(64) void k_viterbi_k9_frames_wave(const int8_t *coded, int len, unsigned g0, unsigned g1, unsigned g2,
-                                                               unsigned long long *dec, uint32_t *out)
+                                                               unsigned long long *dec, uint32_t *out, int phases)
 {
     __shared__ K9WSmem k9;
     const int f = blockIdx.x;
-    viterbi_k9_wave(coded + (size_t)f * 3 * len, len, g0, g1, g2, dec + (size_t)f * 4 * (len + 64), out + (size_t)f * ((len + 31) / 32), k9);
+    viterbi_k9_wave(coded + (size_t)f * 3 * len, len, g0, g1, g2, dec + (size_t)f * 4 * (len + 64), out + (size_t)f * ((len + 31) / 32), k9, phases);
 }
 
 void launch_viterbi_k9_frames(const int8_t *coded, int len, int nframes, unsigned g0, unsigned g1, unsigned g2,
-                              unsigned long long *dec, uint32_t *out, hipStream_t st)
+                              unsigned long long *dec, uint32_t *out, hipStream_t st, int phases)
 {
     // frames longer than a PIDS frame take the production single-wave form; 80-bit frames the 256-work-item form
-    if (len > 80) hipLaunchKernelGGL(k_viterbi_k9_frames_wave, dim3(nframes), dim3(64), 0, st, coded, len, g0, g1, g2, dec, out);
+    if (len > 80) hipLaunchKernelGGL(k_viterbi_k9_frames_wave, dim3(nframes), dim3(64), 0, st, coded, len, g0, g1, g2, dec, out, phases);
     else hipLaunchKernelGGL(k_viterbi_k9_frames, dim3(nframes), dim3(256), 0, st, coded, len, g0, g1, g2, dec, out);
 }
 

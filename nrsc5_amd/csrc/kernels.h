@@ -90,7 +90,7 @@ void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, con
 // window pipeline: the 8 P1 frames and the P3 frame of every L1 frame whose de-interleave happened in window `parity`
 void launch_am_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, int l2_feedback, hipStream_t st);
 void launch_viterbi_k9_frames(const int8_t *coded, int len, int nframes, unsigned g0, unsigned g1, unsigned g2,
-                              unsigned long long *dec, uint32_t *out, hipStream_t st);
+                              unsigned long long *dec, uint32_t *out, hipStream_t st, int phases = 3);
 
 // ---- stage-level entry points (parity tests) ---------------------------------------------------
 void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st, int phases = 3);

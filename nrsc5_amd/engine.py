@@ -91,7 +91,7 @@ EXPORTED_SYMBOLS = [
     "nrsc5hip_stage_halfband_fm_cu8", "nrsc5hip_stage_fft2048", "nrsc5hip_stage_viterbi_k7", "nrsc5hip_debug_fetch",
     "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_batch_fetch_view",
     "nrsc5hip_stream_set_mode", "nrsc5hip_am_frame_bits", "nrsc5hip_stage_viterbi_k9", "nrsc5hip_px_frame_bits",
-    "nrsc5hip_batch_fetch_px", "nrsc5hip_debug_fetch_px"]
+    "nrsc5hip_batch_fetch_px", "nrsc5hip_debug_fetch_px", "nrsc5hip_stage_viterbi_k9_bench"]
 
 
 def unpack_bits(words: np.ndarray, nbits: int) -> np.ndarray:
@@ -277,6 +277,12 @@ class Engine:
     def stage_viterbi_bench(self, length: int, nframes: int, phases: int = 3, reps: int = 3) -> float:
         ms = ctypes.c_float()
         self._check(self.lib.nrsc5hip_stage_viterbi_bench(self._h, length, nframes, phases, reps, ctypes.byref(ms)))
+        return ms.value
+
+    def stage_viterbi_k9_bench(self, length: int, nframes: int, phases: int = 3, reps: int = 3) -> float:
+        ms = ctypes.c_float()
+        self.lib.nrsc5hip_stage_viterbi_k9_bench.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float)]
+        self._check(self.lib.nrsc5hip_stage_viterbi_k9_bench(self._h, length, nframes, phases, reps, ctypes.byref(ms)))
         return ms.value
 
     def debug_sync_phases(self) -> np.ndarray:
