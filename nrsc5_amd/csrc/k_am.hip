@@ -223,13 +223,17 @@ __device__ inline void viterbi_k9_block(const int8_t *coded, int len, unsigned g
     __syncthreads();
 }
 
-// ---- the same trellis on ONE wave64: lane L owns butterflies 2L and 2L+1, i.e. old states 4L..4L+3 (one 16-byte LDS
-// read) and new states {2L, 2L+1} and {2L+128, 2L+129} (two 8-byte LDS writes into the other half of a ping-pong
-// buffer).  No workgroup barrier per step: a single-wave workgroup orders its own LDS traffic (s_barrier is a no-op
-// for it, the wait on lgkmcnt is what __syncthreads() leaves).  Decisions: 4 ballots per step -- word w = 2 (n >= 128)
-// + (n & 1), bit (n & 127) >> 1 for new state n.  The P1 / P3 frames of an AM stream decode 4-5 x faster than with
-// the 256-work-item form (which stays in use for the 80-bit PIDS frame inside k_am_block).
-struct K9WSmem { int metric[2][256]; unsigned long long decbuf[64 * 4]; };
+// ---- the same trellis on ONE wave64, two steps per LDS round trip ------------------------------------------------------
+// Lane L reads old states 4L..4L+3 (one 16-byte LDS read).  Step t: butterflies 2L and 2L+1 give the four intermediate
+// states (i0 << 7) | (2L + xh); step t+1: butterflies L and L + 64 combine them into the four new states
+// (i1 << 7) | (i0 << 6) | L, written at stride 64 (conflict-free) into the other half of a ping-pong buffer, where they are
+// again states 4L'..4L'+3 of some lane L'.  Same eight compares per lane as two single steps, same tie rule, same int32
+// metrics -> bit-identical decisions; half the LDS latency and loop overhead per trellis step.
+// No workgroup barrier: a single-wave workgroup orders its own LDS traffic (WAVE_LDS_SYNC, wave_ops.h).
+// Decisions per step pair: 8 ballots -- [i0 * 2 + xh] for step t (1 = survivor from old state 4L + 2 xh + 1),
+// [4 + i1 * 2 + i0] for step t+1 (1 = survivor from xh = 1); bit L of each.  Traceback: prev = ((n & 63) << 2) | xh << 1 | xl,
+// walked from a decision chunk staged in LDS (uniform address: one broadcast read per lookup).
+struct K9WSmem { int metric[2][256]; unsigned long long decbuf[64 * 8]; };
 
 __device__ inline int k9_sign_word(unsigned b, unsigned g0, unsigned g1, unsigned g2)
 {
@@ -238,41 +242,58 @@ __device__ inline int k9_sign_word(unsigned b, unsigned g0, unsigned g1, unsigne
     return (s0 & 0xff) | ((s1 & 0xff) << 8) | ((s2 & 0xff) << 16);
 }
 
+__device__ inline int k9_soft_word(const int8_t *coded, int j)
+{
+    return (coded[3 * j] & 0xff) | ((coded[3 * j + 1] & 0xff) << 8) | ((coded[3 * j + 2] & 0xff) << 16);
+}
+
 __device__ inline void viterbi_k9_wave(const int8_t *coded, int len, unsigned g0, unsigned g1, unsigned g2,
                                        unsigned long long *dec, uint32_t *out, K9WSmem &sm, int phases = 3)
 {
     const int lane = threadIdx.x & 63;
-    const int sgw0 = k9_sign_word(2u * lane, g0, g1, g2), sgw1 = k9_sign_word(2u * lane + 1u, g0, g1, g2);
-    const int steps = len + 2 * VIT_EXTRA, j0 = len - VIT_EXTRA, nchunks = (steps + 63) >> 6;
+    const int sgA = k9_sign_word(2u * lane, g0, g1, g2), sgB = k9_sign_word(2u * lane + 1u, g0, g1, g2);   // step t: b = 2L + xh
+    const int sgC = k9_sign_word((unsigned)lane, g0, g1, g2), sgD = k9_sign_word((unsigned)lane + 64u, g0, g1, g2);   // step t+1: b = (i0 << 6) | L
+    const int steps = len + 2 * VIT_EXTRA, j0 = len - VIT_EXTRA;       // even: every frame length of the AM path is even
+    const int npairs = steps >> 1, nchunks = (npairs + 63) >> 6;
     int cur = 0;
     for (int k = 0; k < 4; k++) sm.metric[0][4 * lane + k] = 0;
     WAVE_LDS_SYNC();
     for (int c = 0; c < ((phases & 1) ? nchunks : 0); c++) {
-        const int t0 = c << 6;
-        int aw = 0;                                            // this lane's step of the chunk: soft triple packed as 3 x int8
-        if (t0 + lane < steps) {
-            const int j = (j0 + t0 + lane) % len;
-            aw = (coded[3 * j] & 0xff) | ((coded[3 * j + 1] & 0xff) << 8) | ((coded[3 * j + 2] & 0xff) << 16);
+        const int p0 = c << 6, np = min(64, npairs - p0);
+        int aw0 = 0, aw1 = 0;                                   // this lane's step pair of the chunk
+        if (lane < np) {
+            const int t = 2 * (p0 + lane);
+            aw0 = k9_soft_word(coded, (j0 + t) % len);
+            aw1 = k9_soft_word(coded, (j0 + t + 1) % len);
         }
-        const int nst = min(64, steps - t0);
-        for (int s = 0; s < nst; s++) {
-            const int a = wave_readlane(aw, s);
-            const int m0 = dot4_i8(a, sgw0, 0), m1 = dot4_i8(a, sgw1, 0);
+        for (int s = 0; s < np; s++) {
+            const int a0 = wave_readlane(aw0, s), a1 = wave_readlane(aw1, s);
+            const int mA = dot4_i8(a0, sgA, 0), mB = dot4_i8(a0, sgB, 0), nC = dot4_i8(a1, sgC, 0), nD = dot4_i8(a1, sgD, 0);
             const int4 old = *(const int4 *)&sm.metric[cur][4 * lane];
-            const int pa = old.x + m0, pb = old.y - m0;        // -> state 2L
-            const int pc = old.x - m0, pd = old.y + m0;        // -> state 2L + 128
-            const int qa = old.z + m1, qb = old.w - m1;        // -> state 2L + 1
-            const int qc = old.z - m1, qd = old.w + m1;        // -> state 2L + 129
-            const bool tA = pa > pb, tB = qa > qb, tC = pc > pd, tD = qc > qd;     // true: survivor from the even predecessor
-            *(int2 *)&sm.metric[cur ^ 1][2 * lane] = make_int2(tA ? pa : pb, tB ? qa : qb);
-            *(int2 *)&sm.metric[cur ^ 1][2 * lane + 128] = make_int2(tC ? pc : pd, tD ? qc : qd);
-            const unsigned long long wA = __ballot(!tA), wB = __ballot(!tB), wC = __ballot(!tC), wD = __ballot(!tD);
-            if (lane < 4) sm.decbuf[4 * s + lane] = lane == 0 ? wA : lane == 1 ? wB : lane == 2 ? wC : wD;
+            // step t
+            const int e00 = old.x + mA, o00 = old.y - mA, e10 = old.x - mA, o10 = old.y + mA;   // xh = 0: i0 = 0, i0 = 1
+            const int e01 = old.z + mB, o01 = old.w - mB, e11 = old.z - mB, o11 = old.w + mB;   // xh = 1
+            const bool t00 = e00 > o00, t01 = e01 > o01, t10 = e10 > o10, t11 = e11 > o11;       // t[i0][xh]: survivor from the even predecessor
+            const int u00 = t00 ? e00 : o00, u01 = t01 ? e01 : o01, u10 = t10 ? e10 : o10, u11 = t11 ? e11 : o11;
+            // step t+1: new state (i1, i0, L) from u[i0][0] (even) and u[i0][1] (odd)
+            const int f00 = u00 + nC, p00 = u01 - nC, f10 = u00 - nC, p10 = u01 + nC;           // i0 = 0: i1 = 0, i1 = 1
+            const int f01 = u10 + nD, p01 = u11 - nD, f11 = u10 - nD, p11 = u11 + nD;           // i0 = 1
+            const bool r00 = f00 > p00, r01 = f01 > p01, r10 = f10 > p10, r11 = f11 > p11;       // r[i1][i0]
+            int *nxt = sm.metric[cur ^ 1];
+            nxt[lane] = r00 ? f00 : p00;                        // state (0, 0, L)
+            nxt[64 + lane] = r01 ? f01 : p01;                   // state (0, 1, L)
+            nxt[128 + lane] = r10 ? f10 : p10;                  // state (1, 0, L)
+            nxt[192 + lane] = r11 ? f11 : p11;                  // state (1, 1, L)
+            const unsigned long long d0 = __ballot(!t00), d1 = __ballot(!t01), d2 = __ballot(!t10), d3 = __ballot(!t11);
+            const unsigned long long d4 = __ballot(!r00), d5 = __ballot(!r01), d6 = __ballot(!r10), d7 = __ballot(!r11);
+            if (lane == 0) {
+                unsigned long long *q = sm.decbuf + 8 * s;
+                q[0] = d0; q[1] = d1; q[2] = d2; q[3] = d3; q[4] = d4; q[5] = d5; q[6] = d6; q[7] = d7;
+            }
             cur ^= 1;
             WAVE_LDS_SYNC();
         }
-        // the chunk's 64 x 4 decision words go out as four coalesced 512-byte rows
-        for (int k = lane; k < 4 * nst; k += 64) dec[(size_t)t0 * 4 + k] = sm.decbuf[k];
+        for (int k = lane; k < 8 * np; k += 64) dec[(size_t)p0 * 8 + k] = sm.decbuf[k];     // coalesced rows of 512 bytes
         WAVE_LDS_SYNC();
     }
     // end state: first maximum in state order (conv_dec.c:310-318)
@@ -291,26 +312,29 @@ __device__ inline void viterbi_k9_wave(const int8_t *coded, int len, unsigned g0
     }
     __threadfence_block();
     __syncthreads();
-    // traceback: lane l holds the 4 decision words of step t0 + l; the walk itself is scalar (uniform state)
+    // traceback, two steps per iteration; the chunk's decisions are staged in LDS and looked up at a wave-uniform address
+    const uint32_t *dw = (const uint32_t *)sm.decbuf;
     for (int c = ((phases & 2) ? nchunks - 1 : -1); c >= 0; c--) {
-        const int t0 = c << 6, nst = min(64, steps - t0);
-        unsigned long long w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-        if (lane < nst) { const unsigned long long *d = dec + (size_t)(t0 + lane) * 4; w0 = d[0]; w1 = d[1]; w2 = d[2]; w3 = d[3]; }
-        unsigned long long obits = 0;
-        for (int s = nst - 1; s >= 0; s--) {
-            const unsigned w = ((state >> 7) << 1) | (state & 1u), bitpos = (state & 127u) >> 1;
-            const unsigned long long mine = w == 0 ? w0 : w == 1 ? w1 : w == 2 ? w2 : w3;
-            const int half = bitpos < 32 ? (int)(uint32_t)mine : (int)(uint32_t)(mine >> 32);
-            const unsigned bit = ((unsigned)wave_readlane(half, s) >> (bitpos & 31u)) & 1u;
-            obits |= (unsigned long long)((state >> 7) & 1u) << s;          // vals[state]: the newest input bit
-            state = ((state << 1) & 0xfeu) | bit;                           // vstate_lshift
+        const int p0 = c << 6, np = min(64, npairs - p0);
+        for (int k = lane; k < 8 * np; k += 64) sm.decbuf[k] = dec[(size_t)p0 * 8 + k];
+        WAVE_LDS_SYNC();
+        unsigned long long olo = 0, ohi = 0;                    // output bits of steps 2 p0 .. 2 p0 + 63 / + 64 .. + 127
+        for (int s = np - 1; s >= 0; s--) {
+            const unsigned i1 = state >> 7, i0 = (state >> 6) & 1u, L = state & 63u;
+            const unsigned xh = (dw[(8 * s + 4 + 2 * i1 + i0) * 2 + (L >> 5)] >> (L & 31u)) & 1u;
+            const unsigned xl = (dw[(8 * s + 2 * i0 + xh) * 2 + (L >> 5)] >> (L & 31u)) & 1u;
+            const unsigned long long pair = (unsigned long long)(i0 | (i1 << 1));    // step t -> bit 2s, step t+1 -> bit 2s+1
+            if (s < 32) olo |= pair << (2 * s); else ohi |= pair << (2 * s - 64);
+            state = (unsigned)wave_uniform((int)((L << 2) | (xh << 1) | xl));
         }
-        // steps t0 .. t0+63 -> frame bits t0-32 .. t0+31: low half of obits = second half of word (t0-32)/32 ... i.e.
-        // bits [t0-32, t0) -> word c*2-1, bits [t0, t0+32) -> word c*2
+        WAVE_LDS_SYNC();
+        // steps T .. T+127 (T = 128 c) are frame bits T-32 .. T+95: words 4c-1 (low half of olo) .. 4c+2 (low half of ohi's top)
         if (lane == 0) {
-            const int wl = 2 * c - 1, wh = 2 * c;
-            if (wl >= 0 && wl * 32 < len) out[wl] = (uint32_t)obits;
-            if (wh * 32 < len) out[wh] = (uint32_t)(obits >> 32);
+            const uint32_t w[4] = { (uint32_t)olo, (uint32_t)(olo >> 32), (uint32_t)ohi, (uint32_t)(ohi >> 32) };
+            for (int k = 0; k < 4; k++) {
+                const int wi = 4 * c - 1 + k;                   // frame bits 32 wi .. 32 wi + 31 = steps 32 wi + 32 ..
+                if (wi >= 0 && wi * 32 < len && 2 * p0 + 32 * k < steps) out[wi] = w[k];
+            }
         }
     }
     __threadfence_block();
