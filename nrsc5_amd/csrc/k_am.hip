@@ -320,9 +320,12 @@ __device__ inline void viterbi_k9_wave(const int8_t *coded, int len, unsigned g0
         WAVE_LDS_SYNC();
         unsigned long long olo = 0, ohi = 0;                    // output bits of steps 2 p0 .. 2 p0 + 63 / + 64 .. + 127
         for (int s = np - 1; s >= 0; s--) {
-            const unsigned i1 = state >> 7, i0 = (state >> 6) & 1u, L = state & 63u;
-            const unsigned xh = (dw[(8 * s + 4 + 2 * i1 + i0) * 2 + (L >> 5)] >> (L & 31u)) & 1u;
-            const unsigned xl = (dw[(8 * s + 2 * i0 + xh) * 2 + (L >> 5)] >> (L & 31u)) & 1u;
+            const unsigned i1 = state >> 7, i0 = (state >> 6) & 1u, L = state & 63u, half = L >> 5, sh = L & 31u;
+            // three independent broadcast reads (step t+1's word, both candidates of step t): one LDS latency per step pair
+            const uint32_t q2 = dw[16 * s + (4 + 2 * i1 + i0) * 2 + half];
+            const uint32_t q0 = dw[16 * s + (2 * i0) * 2 + half], q1 = dw[16 * s + (2 * i0 + 1) * 2 + half];
+            const unsigned xh = (q2 >> sh) & 1u;
+            const unsigned xl = ((xh ? q1 : q0) >> sh) & 1u;
             const unsigned long long pair = (unsigned long long)(i0 | (i1 << 1));    // step t -> bit 2s, step t+1 -> bit 2s+1
             if (s < 32) olo |= pair << (2 * s); else ohi |= pair << (2 * s - 64);
             state = (unsigned)wave_uniform((int)((L << 2) | (xh << 1) | xl));
