@@ -230,9 +230,9 @@ __device__ inline void viterbi_k9_block(const int8_t *coded, int len, unsigned g
 // again states 4L'..4L'+3 of some lane L'.  Same eight compares per lane as two single steps, same tie rule, same int32
 // metrics -> bit-identical decisions; half the LDS latency and loop overhead per trellis step.
 // No workgroup barrier: a single-wave workgroup orders its own LDS traffic (WAVE_LDS_SYNC, wave_ops.h).
-// Decisions per step pair: 8 ballots -- [i0 * 2 + xh] for step t (1 = survivor from old state 4L + 2 xh + 1),
-// [4 + i1 * 2 + i0] for step t+1 (1 = survivor from xh = 1); bit L of each.  Traceback: prev = ((n & 63) << 2) | xh << 1 | xl,
-// walked from a decision chunk staged in LDS (uniform address: one broadcast read per lookup).
+// Decisions per step pair: one byte per lane -- bit i0 * 2 + xh for step t (1 = survivor from old state 4L + 2 xh + 1),
+// bit 4 + i1 * 2 + i0 for step t+1 (1 = survivor from xh = 1) -- so a step pair of the traceback needs ONE byte, the one
+// of lane n & 63: prev = ((n & 63) << 2) | xh << 1 | xl, read at a wave-uniform address from a chunk staged in LDS.
 struct K9WSmem { int metric[2][256]; unsigned long long decbuf[64 * 8]; };
 
 __device__ inline int k9_sign_word(unsigned b, unsigned g0, unsigned g1, unsigned g2)
@@ -284,12 +284,10 @@ __device__ inline void viterbi_k9_wave(const int8_t *coded, int len, unsigned g0
             nxt[64 + lane] = r01 ? f01 : p01;                   // state (0, 1, L)
             nxt[128 + lane] = r10 ? f10 : p10;                  // state (1, 0, L)
             nxt[192 + lane] = r11 ? f11 : p11;                  // state (1, 1, L)
-            const unsigned long long d0 = __ballot(!t00), d1 = __ballot(!t01), d2 = __ballot(!t10), d3 = __ballot(!t11);
-            const unsigned long long d4 = __ballot(!r00), d5 = __ballot(!r01), d6 = __ballot(!r10), d7 = __ballot(!r11);
-            if (lane == 0) {
-                unsigned long long *q = sm.decbuf + 8 * s;
-                q[0] = d0; q[1] = d1; q[2] = d2; q[3] = d3; q[4] = d4; q[5] = d5; q[6] = d6; q[7] = d7;
-            }
+            // this lane's eight decisions of the step pair in one byte: bit i0*2+xh for step t, bit 4+i1*2+i0 for step t+1
+            const unsigned dbyte = (t00 ? 0u : 1u) | (t01 ? 0u : 2u) | (t10 ? 0u : 4u) | (t11 ? 0u : 8u)
+                                 | (r00 ? 0u : 16u) | (r01 ? 0u : 32u) | (r10 ? 0u : 64u) | (r11 ? 0u : 128u);
+            ((uint8_t *)sm.decbuf)[64 * s + lane] = (uint8_t)dbyte;
             cur ^= 1;
             WAVE_LDS_SYNC();
         }
@@ -313,21 +311,20 @@ __device__ inline void viterbi_k9_wave(const int8_t *coded, int len, unsigned g0
     __threadfence_block();
     __syncthreads();
     // traceback, two steps per iteration; the chunk's decisions are staged in LDS and looked up at a wave-uniform address
-    const uint32_t *dw = (const uint32_t *)sm.decbuf;
+    const uint8_t *db8 = (const uint8_t *)sm.decbuf;
     for (int c = ((phases & 2) ? nchunks - 1 : -1); c >= 0; c--) {
         const int p0 = c << 6, np = min(64, npairs - p0);
         for (int k = lane; k < 8 * np; k += 64) sm.decbuf[k] = dec[(size_t)p0 * 8 + k];
         WAVE_LDS_SYNC();
         unsigned long long olo = 0, ohi = 0;                    // output bits of steps 2 p0 .. 2 p0 + 63 / + 64 .. + 127
         for (int s = np - 1; s >= 0; s--) {
-            const unsigned i1 = state >> 7, i0 = (state >> 6) & 1u, L = state & 63u, half = L >> 5, sh = L & 31u;
-            // three independent broadcast reads (step t+1's word, both candidates of step t): one LDS latency per step pair
-            const uint32_t q2 = dw[16 * s + (4 + 2 * i1 + i0) * 2 + half];
-            const uint32_t q0 = dw[16 * s + (2 * i0) * 2 + half], q1 = dw[16 * s + (2 * i0 + 1) * 2 + half];
-            const unsigned xh = (q2 >> sh) & 1u;
-            const unsigned xl = ((xh ? q1 : q0) >> sh) & 1u;
-            const unsigned long long pair = (unsigned long long)(i0 | (i1 << 1));    // step t -> bit 2s, step t+1 -> bit 2s+1
-            if (s < 32) olo |= pair << (2 * s); else ohi |= pair << (2 * s - 64);
+            const unsigned i1 = state >> 7, i0 = (state >> 6) & 1u, L = state & 63u;
+            const unsigned q = db8[64 * s + L];                  // lane L's decision byte of this step pair: one broadcast read
+            const unsigned xh = (q >> (4 + 2 * i1 + i0)) & 1u;
+            const unsigned xl = (q >> (2 * i0 + xh)) & 1u;
+            // 128-bit shift register: the pair walked last (s = 0) ends up in bits 0..1 (step t -> even bit, t+1 -> odd bit)
+            ohi = (ohi << 2) | (olo >> 62);
+            olo = (olo << 2) | (unsigned long long)(i0 | (i1 << 1));
             state = (unsigned)wave_uniform((int)((L << 2) | (xh << 1) | xl));
         }
         WAVE_LDS_SYNC();
