@@ -11,7 +11,7 @@ import json
 import os
 import sys
 
-CLASS_KERNELS = {"p1_viterbi": ("k_p1_forward", "k_p1_traceback"), "sync": ("k_sync",), "mixfft": ("k_mixfft",),
+CLASS_KERNELS = {"p1_viterbi": ("k_p1_forward", "k_p1_traceback", "k_p1_deint"), "sync": ("k_sync",), "mixfft": ("k_mixfft",),
                  "decimate": ("k_decimate_fm_cu8",), "p1_deint": ("k_p1_deint",)}
 
 
