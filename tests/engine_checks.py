@@ -404,3 +404,30 @@ def check_l2_feedback(lib, oracle, kw, am=False):
     assert not diffs, diffs[:10]
     E.close()
     return log
+
+
+def check_mode_switch(lib, oracle):
+    """nrsc5_set_mode on a live session: FM capture, then AM, then FM again on the same stream -- each run equals a fresh
+    oracle session of that mode (input_set_mode resets the stream, input.c:158-162)."""
+    import pytest
+    from nrsc5_amd import synth_am
+    fm = synth.fm_mp1_capture(0, seed=71, cfo_hz=33.0, offset=640, snr_db=20, n_blocks=20)
+    am = synth_am.am_ma1_capture(9, seed=72, cfo_hz=1.0, offset=900)
+    exp_fm, _, _ = oracle.run(fm.iq)
+    exp_am, _, _ = oracle.run(am.iq, mode=1)
+    plain = eng.Engine(max_streams=1, q15_capacity=400000, lib_path=lib)
+    with pytest.raises(eng.Nrsc5HipError):
+        plain.set_mode(0, eng.MODE_AM)                        # engine created without am_enable
+    with pytest.raises(eng.Nrsc5HipError):
+        plain.set_mode(0, 7)
+    plain.close()
+    E = eng.Engine(max_streams=2, q15_capacity=400000, record_capacity=512, p1_slots=16, lib_path=lib, am_enable=True)
+    for mode in (eng.MODE_FM, eng.MODE_AM, eng.MODE_FM):
+        E.set_mode(1, mode)
+        cap, exp = (fm, exp_fm) if mode == eng.MODE_FM else (am, exp_am)
+        common.run_engine_streaming(E, 1, cap.iq, chunk=32768)
+        recs = E.drain(1)
+        log = eng.records_to_log(E, 1, recs) if mode == eng.MODE_FM else eng.am_records_to_log(E, 1, recs)
+        diffs = common.compare_logs(common.strip_states(exp), common.strip_states(log))
+        assert not diffs, (mode, diffs[:5])
+    E.close()

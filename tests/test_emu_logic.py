@@ -105,3 +105,7 @@ def test_emu_l2_feedback_on_device_fm(emu_lib, oracle):
 
 def test_emu_l2_feedback_on_device_am(emu_lib, oracle):
     ec.check_l2_feedback(emu_lib, oracle, dict(n_frames=16, seed=9, cfo_hz=2.0, offset=500, burst=(8.3, 0.5, 40.0)), am=True)
+
+
+def test_emu_mode_switch_on_live_stream(emu_lib, oracle):
+    ec.check_mode_switch(emu_lib, oracle)

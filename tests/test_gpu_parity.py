@@ -254,3 +254,7 @@ def test_gpu_l2_feedback_deferred_recovers_false_locks(hip_lib):
         E.close()
     assert good[0][0] == 0 and good[0][1] == 0 and good[0][2] >= 6        # without feedback the two false locks never recover
     assert good[1][0] >= 1 and good[1][1] >= 1 and good[1][2] == good[0][2]   # late (deferred decode), but they come back
+
+
+def test_gpu_mode_switch_on_live_stream(hip_lib, oracle):
+    ec.check_mode_switch(hip_lib, oracle)
