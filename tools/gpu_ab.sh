@@ -1,7 +1,13 @@
 #!/bin/bash
-cd "${GRAFT_REPO_ROOT:-.}"; R=$PWD; export TMPDIR=/tmp; mkdir -p gpurun_out
-for A in 3 4 5; do
-  ( NRSC5HIP_NAUX=$A timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline ) > gpurun_out/bench_a$A.log 2>&1
-  echo "naux=$A $(grep -o '"value": [0-9.]*' gpurun_out/bench_a$A.log | head -1) $(grep -o '"ms_per_step": [0-9.]*' gpurun_out/bench_a$A.log) $(grep -o '"p1_frames_bit_exact_vs_truth": [0-9]*' gpurun_out/bench_a$A.log)"
-  grep -o '"device_ms_per_pass": {[^}]*}' gpurun_out/bench_a$A.log
+cd "${GRAFT_REPO_ROOT:-.}"
+export TMPDIR=/tmp
+mkdir -p gpurun_out
+for i in 1 2; do
+( timeout 300 python bench.py --no-cpu-baseline --steps 4 ) > gpurun_out/b.log 2>&1
+python - <<PY
+import json
+l=[x for x in open("gpurun_out/b.log") if x.startswith("{")]
+j=json.loads(l[-1]); d=j["roofline"]["device_ms_per_pass"]; print(j["value"], j["ms_per_step"], "vit", d["p1_viterbi"], "pids", d["pids"], "sync", d["sync"], "mix", d["mixfft"], j["parity"]["p1_frames_bit_exact_vs_truth"])
+PY
 done
+( time timeout 600 python -m pytest tests -m gpu -q -k "batch or async or extended or golden" ) > gpurun_out/pytest_ab.log 2>&1; grep -E "passed|failed" gpurun_out/pytest_ab.log
