@@ -38,8 +38,8 @@ struct nrsc5hip_engine {
     // Scheduler lanes: each lane advances its own subset of the streams on its own HIP streams, so the
     // latency-bound per-block kernels of different lanes overlap (lane 0 also serves the streaming seam).
     struct Lane {
-        hipStream_t main, aux[NAUX], side;   // side: the short per-window decodes (PIDS, P3/P4) that nothing waits for until the fetch
-        hipEvent_t ev_window[NWIN], ev_decoded[NWIN], ev_side[NWIN];
+        hipStream_t main, aux[NAUX];
+        hipEvent_t ev_window[NWIN], ev_decoded[NWIN];
         bool decoded_pending[NWIN];
         bool acq_needed;
         bool px_needed;                // some stream is not FINE yet or runs a service mode with extended sidebands
@@ -278,9 +278,8 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             nrsc5hip_engine::Lane &ln = e->lanes[l];
             if (hipStreamCreate(&ln.main) != hipSuccess) rc = NRSC5HIP_EHIP;
             for (int k = 0; k < NAUX && !rc; k++) if (hipStreamCreate(&ln.aux[k]) != hipSuccess) rc = NRSC5HIP_EHIP;
-            if (!rc && hipStreamCreate(&ln.side) != hipSuccess) rc = NRSC5HIP_EHIP;
             for (int k = 0; k < NWIN && !rc; k++) {
-                if (hipEventCreate(&ln.ev_window[k]) != hipSuccess || hipEventCreate(&ln.ev_decoded[k]) != hipSuccess || hipEventCreate(&ln.ev_side[k]) != hipSuccess) rc = NRSC5HIP_EHIP;
+                if (hipEventCreate(&ln.ev_window[k]) != hipSuccess || hipEventCreate(&ln.ev_decoded[k]) != hipSuccess) rc = NRSC5HIP_EHIP;
                 ln.decoded_pending[k] = false;
             }
             ln.acq_needed = true; ln.px_needed = true; ln.step_count = 0; ln.am_step_count = 0;
@@ -383,8 +382,7 @@ extern "C" void nrsc5hip_engine_destroy(nrsc5hip_engine *e)
     for (int l = 0; l < e->nlanes; l++) {
         nrsc5hip_engine::Lane &ln = e->lanes[l];
         if (ln.counters_host) (void)hipHostFree(ln.counters_host);
-        for (int k = 0; k < NWIN; k++) { if (ln.ev_window[k]) (void)hipEventDestroy(ln.ev_window[k]); if (ln.ev_decoded[k]) (void)hipEventDestroy(ln.ev_decoded[k]); if (ln.ev_side[k]) (void)hipEventDestroy(ln.ev_side[k]); }
-        if (ln.side) (void)hipStreamDestroy(ln.side);
+        for (int k = 0; k < NWIN; k++) { if (ln.ev_window[k]) (void)hipEventDestroy(ln.ev_window[k]); if (ln.ev_decoded[k]) (void)hipEventDestroy(ln.ev_decoded[k]); }
         if (ln.main) (void)hipStreamDestroy(ln.main);
         for (int k = 0; k < NAUX; k++) if (ln.aux[k]) (void)hipStreamDestroy(ln.aux[k]);
     }
@@ -413,7 +411,6 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
     if (async && (ln.step_count % 16) == 0 && ln.decoded_pending[parity]) {
         // the buffers of slot `parity` are about to be rewritten: the decoder launched NWIN windows ago must be done
         HIPCHK(hipStreamWaitEvent(ln.main, ln.ev_decoded[parity], 0));
-        HIPCHK(hipStreamWaitEvent(ln.main, ln.ev_side[parity], 0));
         ln.decoded_pending[parity] = false;
     }
     if (e->dec_chunk) {
@@ -445,10 +442,8 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
         hipStream_t ax = ln.aux[lane];
         HIPCHK(hipEventRecord(ln.ev_window[parity], ln.main));
         HIPCHK(hipStreamWaitEvent(ax, ln.ev_window[parity], 0));
-        HIPCHK(hipStreamWaitEvent(ln.side, ln.ev_window[parity], 0));
-        { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.side); launch_pids_decode(e->tb, ln.db, n, ids_dev, parity, 16, ln.side); }
-        if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.side); launch_px_decode(e->tb, ln.db, n, ids_dev, parity, lane, ln.side); }
-        HIPCHK(hipEventRecord(ln.ev_side[parity], ln.side));
+        { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_pids_decode(e->tb, ln.db, n, ids_dev, parity, 16, ax); }
+        if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_px_decode(e->tb, ln.db, n, ids_dev, parity, lane, ax); }
         { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ax); launch_p1_viterbi(e->tb, ln.db, n, ids_dev, parity, lane, ax, e->cfg.l2_feedback ? 2 : 0); }
         HIPCHK(hipEventRecord(ln.ev_decoded[parity], ax));
         ln.decoded_pending[parity] = true;
@@ -468,13 +463,11 @@ static int flush_p1(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const 
         hipStream_t ax = ln.aux[lane];
         HIPCHK(hipEventRecord(ln.ev_window[parity], ln.main));
         HIPCHK(hipStreamWaitEvent(ax, ln.ev_window[parity], 0));
-        HIPCHK(hipStreamWaitEvent(ln.side, ln.ev_window[parity], 0));
-        { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.side); launch_pids_decode(e->tb, ln.db, n, ids_dev, parity, 16, ln.side); }
-        if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.side); launch_px_decode(e->tb, ln.db, n, ids_dev, parity, lane, ln.side); }
+        { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_pids_decode(e->tb, ln.db, n, ids_dev, parity, 16, ax); }
+        if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_px_decode(e->tb, ln.db, n, ids_dev, parity, lane, ax); }
         { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ax); launch_p1_viterbi(e->tb, ln.db, n, ids_dev, parity, lane, ax, e->cfg.l2_feedback ? 2 : 0); }
         ln.step_count += 16 - (ln.step_count % 16);            // next batch starts a fresh window
     }
-    HIPCHK(hipStreamSynchronize(ln.side));
     for (int k = 0; k < NAUX; k++) HIPCHK(hipStreamSynchronize(ln.aux[k]));
     for (int k = 0; k < NWIN; k++) ln.decoded_pending[k] = false;
     return 0;
