@@ -8,7 +8,6 @@
 // the 32 symbols by construction), lanes = (partition, symbol, carrier) cells for equalisation / MER /
 // soft bits, lanes = live bins for the brute-force CFO search, one wave for the 144-step PIDS trellis.
 #include <hip/hip_runtime.h>
-#include <stdlib.h>
 #include "kernels.h"
 #include "wave_ops.h"
 #include "viterbi_wave.h"
@@ -168,7 +167,7 @@ __device__ __forceinline__ void store_px(int8_t *pair, float2 v, int side, int p
     *(char2 *)(pair + (size_t)ch * 2 * PX_MAX + odd * len + n * per_sym + idx) = o;
 }
 
-__global__ __launch_bounds__(768) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare, int acq_on)
+__global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare, int acq_on)
 {
     wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
     const int s = stream_of(ids, blockIdx.x);
@@ -178,13 +177,7 @@ __global__ __launch_bounds__(768) void k_sync(DevTables tb, DevBuffers db, const
         if (fuse_prepare && threadIdx.x == 0) prepare_block(db, st, s);
         return;
     }
-    // 256 work-items do the block; while any stream may be acquiring the kernel is launched with 768 so that the
-    // brute-force CFO search (one lane per live bin, 534 of them) runs in one pass instead of three.  For the helpers
-    // `tid` is a value that makes every `for (k = tid; k < N; ...)` loop empty and every `tid < x`, `tid == 0`,
-    // `(tid & 63) == 0` test false; they only take part in the barriers and in the search.
-    const int tid_all = threadIdx.x, nthreads = blockDim.x;
-    const bool core = tid_all < 256;
-    const int tid = core ? tid_all : 0x40000001;
+    const int tid = threadIdx.x;
     long long tstamp = (db.sync_phase_cycles && s == 0 && tid == 0) ? (long long)clock64() : 0;
 #define SYNC_MARK(i) do { if (db.sync_phase_cycles && s == 0 && tid == 0) { const long long now = (long long)clock64(); db.sync_phase_cycles[i] += now - tstamp; tstamp = now; } } while (0)
 
@@ -279,7 +272,7 @@ __global__ __launch_bounds__(768) void k_sync(DevTables tb, DevBuffers db, const
             float snap_f[3][11], snap_p[3][11];
             int snap_cfo[3][11], snap_n[3];
             for (int pass = 0; pass < 3; pass++) {
-                const int l = tid_all + nthreads * pass;
+                const int l = tid + 256 * pass;
                 snap_n[pass] = 0;
                 if (l >= LIVE_N) continue;
                 const int b = live_to_bin(l);
@@ -322,7 +315,7 @@ __global__ __launch_bounds__(768) void k_sync(DevTables tb, DevBuffers db, const
             __syncthreads();
             const int last_cfo = sh_i[1];                      // visits with cfo <= last_cfo happened
             for (int pass = 0; pass < 3; pass++) {
-                const int l = tid_all + nthreads * pass;
+                const int l = tid + 256 * pass;
                 if (l >= LIVE_N) continue;
                 int k = snap_n[pass] - 1;
                 while (k >= 0 && snap_cfo[pass][k] > last_cfo) k--;
@@ -384,8 +377,7 @@ __global__ __launch_bounds__(768) void k_sync(DevTables tb, DevBuffers db, const
         constexpr int MP1C = 2 * PM_PART * NSYM * 18 / 256;                     // 45 exactly
         float2 cellv[MP1C];
         double e_lb = 0.0, e_ub = 0.0;
-        if (!core) {
-        } else if (ppb == PM_PART) {
+        if (ppb == PM_PART) {
 #pragma unroll
             for (int i = 0; i < MP1C; i++) {
                 int side;
@@ -429,8 +421,7 @@ __global__ __launch_bounds__(768) void k_sync(DevTables tb, DevBuffers db, const
         // (sync.c:514-536): the upper-sideband cell of partition `part` (from the edge) is matrix partition 19 - part.
         const int pm_slot = st.pm_slot;
         int8_t *pm_blk = db.pm + ((size_t)s * NPM + pm_slot) * PM_FRAME + (size_t)bc * PM_BLOCK;
-        if (!core) {
-        } else if (ppb == PM_PART) {
+        if (ppb == PM_PART) {
 #pragma unroll
             for (int i = 0; i < MP1C; i++) {
                 int k, n, part, side;
@@ -523,8 +514,7 @@ __global__ __launch_bounds__(768) void k_sync(DevTables tb, DevBuffers db, const
 
 void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, hipStream_t st, int acq_on)
 {
-    static const bool wide = getenv("NRSC5HIP_SYNC_NARROW") == nullptr;
-    hipLaunchKernelGGL(k_sync, dim3(nstreams), dim3(acq_on && wide ? 768 : 256), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, acq_on);
+    hipLaunchKernelGGL(k_sync, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, acq_on);
 }
 
 // ---- deferred PIDS decode: one wave per (slot, stream) with a staged frame -----------------------------------
