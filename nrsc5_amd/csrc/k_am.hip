@@ -470,6 +470,7 @@ __device__ inline float2 &am_bin(AmBlockSmem &sm, int off, int n) { return sm.X[
 
 __global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, const int *ids, int pipeline)
 {
+    wave_set_priority_high();                                  // block-step chain = critical path; the decode waves run at priority 0
     const int s = stream_of(ids, blockIdx.x);
     StreamState &st = db.state[s];
     AmStream &am = db.am[s];
@@ -881,6 +882,7 @@ __device__ inline int am_cell_bit(const uint8_t *m, int b, int k, int p)
 
 __global__ __launch_bounds__(1024) void k_am_interleave(DevBuffers db, const int *ids, int parity)
 {
+    wave_set_priority_high();
     const int s = stream_of(ids, blockIdx.x);
     const StreamState &st = db.state[s];
     AmStream &am = db.am[s];
