@@ -233,7 +233,7 @@ __device__ inline void viterbi_k9_block(const int8_t *coded, int len, unsigned g
 // Decisions per step pair: one byte per lane -- bit i0 * 2 + xh for step t (1 = survivor from old state 4L + 2 xh + 1),
 // bit 4 + i1 * 2 + i0 for step t+1 (1 = survivor from xh = 1) -- so a step pair of the traceback needs ONE byte, the one
 // of lane n & 63: prev = ((n & 63) << 2) | xh << 1 | xl, read at a wave-uniform address from a chunk staged in LDS.
-struct K9WSmem { int metric[2][256]; unsigned long long decbuf[64 * 8]; };
+struct K9WSmem { int metric[2][256]; unsigned long long decbuf[32 * 8]; };   // 4 KB per frame in flight: up to 27 decode workgroups share a CU with k_am_block's 70 KB tile
 
 __device__ inline int k9_sign_word(unsigned b, unsigned g0, unsigned g1, unsigned g2)
 {
@@ -287,12 +287,15 @@ __device__ inline void viterbi_k9_wave(const int8_t *coded, int len, unsigned g0
             // this lane's eight decisions of the step pair in one byte: bit i0*2+xh for step t, bit 4+i1*2+i0 for step t+1
             const unsigned dbyte = (t00 ? 0u : 1u) | (t01 ? 0u : 2u) | (t10 ? 0u : 4u) | (t11 ? 0u : 8u)
                                  | (r00 ? 0u : 16u) | (r01 ? 0u : 32u) | (r10 ? 0u : 64u) | (r11 ? 0u : 128u);
-            ((uint8_t *)sm.decbuf)[64 * s + lane] = (uint8_t)dbyte;
+            ((uint8_t *)sm.decbuf)[64 * (s & 31) + lane] = (uint8_t)dbyte;
             cur ^= 1;
             WAVE_LDS_SYNC();
+            if ((s & 31) == 31 || s == np - 1) {               // 32 step pairs of decisions go out as coalesced 512-byte rows
+                const int first = s & ~31, cnt = s - first + 1;
+                for (int k = lane; k < 8 * cnt; k += 64) dec[(size_t)(p0 + first) * 8 + k] = sm.decbuf[k];
+                WAVE_LDS_SYNC();
+            }
         }
-        for (int k = lane; k < 8 * np; k += 64) dec[(size_t)p0 * 8 + k] = sm.decbuf[k];     // coalesced rows of 512 bytes
-        WAVE_LDS_SYNC();
     }
     // end state: first maximum in state order (conv_dec.c:310-318)
     unsigned state;
@@ -310,31 +313,29 @@ __device__ inline void viterbi_k9_wave(const int8_t *coded, int len, unsigned g0
     }
     __threadfence_block();
     __syncthreads();
-    // traceback, two steps per iteration; the chunk's decisions are staged in LDS and looked up at a wave-uniform address
+    // traceback, two steps per iteration; 32 step pairs of decisions at a time are staged in LDS and looked up at a
+    // wave-uniform address
     const uint8_t *db8 = (const uint8_t *)sm.decbuf;
-    for (int c = ((phases & 2) ? nchunks - 1 : -1); c >= 0; c--) {
-        const int p0 = c << 6, np = min(64, npairs - p0);
+    const int ntb = (npairs + 31) >> 5;
+    for (int c = ((phases & 2) ? ntb - 1 : -1); c >= 0; c--) {
+        const int p0 = c << 5, np = min(32, npairs - p0);
         for (int k = lane; k < 8 * np; k += 64) sm.decbuf[k] = dec[(size_t)p0 * 8 + k];
         WAVE_LDS_SYNC();
-        unsigned long long olo = 0, ohi = 0;                    // output bits of steps 2 p0 .. 2 p0 + 63 / + 64 .. + 127
+        unsigned long long obits = 0;                           // output bits of steps 2 p0 .. 2 p0 + 63
         for (int s = np - 1; s >= 0; s--) {
             const unsigned i1 = state >> 7, i0 = (state >> 6) & 1u, L = state & 63u;
             const unsigned q = db8[64 * s + L];                  // lane L's decision byte of this step pair: one broadcast read
             const unsigned xh = (q >> (4 + 2 * i1 + i0)) & 1u;
             const unsigned xl = (q >> (2 * i0 + xh)) & 1u;
-            // 128-bit shift register: the pair walked last (s = 0) ends up in bits 0..1 (step t -> even bit, t+1 -> odd bit)
-            ohi = (ohi << 2) | (olo >> 62);
-            olo = (olo << 2) | (unsigned long long)(i0 | (i1 << 1));
+            obits = (obits << 2) | (unsigned long long)(i0 | (i1 << 1));    // the pair walked last (s = 0) ends in bits 0..1
             state = (unsigned)wave_uniform((int)((L << 2) | (xh << 1) | xl));
         }
         WAVE_LDS_SYNC();
-        // steps T .. T+127 (T = 128 c) are frame bits T-32 .. T+95: words 4c-1 (low half of olo) .. 4c+2 (low half of ohi's top)
+        // steps 64 c .. 64 c + 63 are frame bits 64 c - 32 .. 64 c + 31: words 2c - 1 (low half) and 2c (high half)
         if (lane == 0) {
-            const uint32_t w[4] = { (uint32_t)olo, (uint32_t)(olo >> 32), (uint32_t)ohi, (uint32_t)(ohi >> 32) };
-            for (int k = 0; k < 4; k++) {
-                const int wi = 4 * c - 1 + k;                   // frame bits 32 wi .. 32 wi + 31 = steps 32 wi + 32 ..
-                if (wi >= 0 && wi * 32 < len && 2 * p0 + 32 * k < steps) out[wi] = w[k];
-            }
+            const int wl = 2 * c - 1, wh = 2 * c;
+            if (wl >= 0 && wl * 32 < len) out[wl] = (uint32_t)obits;
+            if (wh * 32 < len && 2 * p0 + 32 < steps) out[wh] = (uint32_t)(obits >> 32);
         }
     }
     __threadfence_block();
@@ -387,13 +388,13 @@ struct AmBlockSmem {
     uint8_t pids_sym[2 * NSYM];
     int8_t pids_coded[3 * PIDS_LEN];
     uint32_t pids_out[3];
-    unsigned long long pids_dec[4 * (PIDS_LEN + 64)];
     // block-uniform scalars produced by work-item 0
     int active, fine, samperr, ma3, refmask;
     double theta, dtheta;
     float2 step270, step256;        // e^{i 270 dtheta}, e^{i 256 dtheta}
-    K9Smem k9;
 };
+// the PIDS trellis runs after the spectra are consumed: its scratch aliases the head of X
+static_assert(sizeof(K9Smem) + 4 * (PIDS_LEN + 64) * sizeof(unsigned long long) <= sizeof(float2) * NSYM * AM_FFT, "PIDS scratch must fit in X");
 
 __device__ inline float2 cmulf(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 __device__ inline float2 cdivf(float2 a, float2 b)
@@ -777,7 +778,9 @@ __global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, c
             sm.pids_coded[i * 24 + iu_pos[j]] = iu ? 1 : -1;
         }
         __syncthreads();
-        viterbi_k9_block(sm.pids_coded, PIDS_LEN, GEN_E2_0, GEN_E2_1, GEN_E2_2, sm.pids_dec, sm.pids_out, sm.k9);
+        K9Smem &k9 = *(K9Smem *)sm.X;
+        unsigned long long *pids_dec = (unsigned long long *)((uint8_t *)sm.X + sizeof(K9Smem));
+        viterbi_k9_block(sm.pids_coded, PIDS_LEN, GEN_E2_0, GEN_E2_1, GEN_E2_2, pids_dec, sm.pids_out, k9);
         if (tid == 0) {
             for (int w = 0; w < 3; w++) rec.pids[w] = sm.pids_out[w] ^ tb.scr_pids[w];
             rec.pids[2] &= 0xffffu;
@@ -843,7 +846,8 @@ __global__ __launch_bounds__(64) void k_am_viterbi(DevTables tb, DevBuffers db, 
             atomicOr(&rec.flags, (uint32_t)REC_P1);
             rec.p1_slot = am.frame_slot;
             if (l2_feedback) {                                 // frame.c:535-540 for the 466-byte AM PDU
-                __shared__ L2Smem l2;
+                static_assert(sizeof(L2Smem) <= sizeof(K9WSmem), "L2 scratch aliases the trellis scratch");
+                L2Smem &l2 = *(L2Smem *)&k9;                   // the trellis scratch is dead by now
                 l2_gf_init(l2);
                 StreamState &stw = db.state[s];
                 if (!l2_first_header_ok_am(out, l2) && stw.sync_state == SYNC_FINE) { stw.sync_state = SYNC_NONE; rec.state_after = SYNC_NONE; atomicOr(&rec.flags, (uint32_t)REC_LOST_SYNC); }
@@ -1012,7 +1016,7 @@ __global__ __launch_bounds__(64) void k_am_decode(DevTables tb, DevBuffers db, c
         __threadfence_block();
         __syncthreads();
         if (l2_feedback && threadIdx.x == 0) {                 // frame.c:535-540, applied by the next k_am_block of the stream
-            __shared__ L2Smem l2;
+            L2Smem &l2 = *(L2Smem *)&k9;                       // the trellis scratch is dead by now
             l2_gf_init(l2);
             if (!l2_first_header_ok_am(out, l2)) db.state[s].force_none = 1;
         }
