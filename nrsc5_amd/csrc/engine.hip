@@ -205,6 +205,45 @@ static int build_tables(nrsc5hip_engine *e)
         }
         if ((rc = dev_upload(e, wide ? &e->tb.px_delay_wide : &e->tb.px_delay_narrow, delay))) return rc;
     }
+    {   // interleaver_ma1 (decode.c:66-231) folded into one table per code word: for every depunctured trellis input, which
+        // bit of which hard-symbol matrix it is (bit_map), whether it passes the 3-frame diversity delay line, or a
+        // punctured zero.  Same arithmetic as the reference's loops, evaluated once.
+        static const int src12[12] = { 3, 0, 0, 3, 3, 0, 1, 1, 2, 2, 2, 1 };      // position in a 12-bit group -> bl / ml / bu / mu (decode.c:26-30)
+        static const int j12[12] = { 2, 1, 0, 1, 0, 2, 1, 2, 1, 2, 0, 0 };
+        static const int rank15[15] = { 0, -1, 1, 2, -1, 3, 4, -1, 5, 6, 7, 8, 9, 10, 11 };   // E1 puncture {1,0,1,1,0,1,1,0,1,1,1,1,1,1,1}
+        auto cell_of = [](int b, int k) { const int col = (9 * k) % 25, row = (11 * col + 16 * (k / 25) + 11 * (k / 50)) % 32; return 25 * (b * 32 + row) + col; };
+        auto entry = [](int cell, int bit, int matrix, int delayed, int queue, int n) {
+            uint2 v; v.x = (unsigned)cell | ((unsigned)bit << 13) | ((unsigned)matrix << 16) | (delayed ? AMT_DELAYED : 0u) | ((unsigned)queue << 20); v.y = (unsigned)n; return v; };
+        std::vector<uint2> t1(AM_VIT), t3b(AM_VIT), t3a(3 * AM_P3_LEN_MA1);
+        for (int i = 0; i < AM_VIT; i++) {
+            const int rk = rank15[i % 15];
+            if (rk < 0) { t1[i].x = AMT_PUNCT; t1[i].y = 0; t3b[i] = t1[i]; continue; }
+            const int o = (i / 15) * 12 + rk, g = o / 12, pos = o % 12, n = g * 3 + j12[pos];
+            switch (src12[pos]) {       // matrices: 0 pl, 1 pu, 2 s, 3 t
+            case 0: t1[i] = entry(cell_of(n / 2250, (n + n / 750 + 1) % 750), n % 3, 0, 0, 0, 0);                 // bl
+                    t3b[i] = entry(cell_of((3 * n + 3) % 8, (n + n / 3000 + 3) % 750), n % 3, 3, 0, 0, 0); break;   // ebl
+            case 1: t1[i] = entry(cell_of((3 * n + 3) % 8, (n + n / 3000 + 3) % 750), 3 + n % 3, 0, 1, 0, n);      // ml
+                    t3b[i] = entry(cell_of((3 * n + 3) % 8, (n + n / 3000 + 3) % 750), 3 + n % 3, 3, 1, 2, n); break;   // eml
+            case 2: t1[i] = entry(cell_of(n / 2250, (n + n / 750) % 750), n % 3, 1, 0, 0, 0);                     // bu
+                    t3b[i] = entry(cell_of((3 * n) % 8, (n + n / 3000 + 2) % 750), n % 3, 2, 0, 0, 0); break;     // ebu
+            default: t1[i] = entry(cell_of((3 * n) % 8, (n + n / 3000 + 2) % 750), 3 + n % 3, 1, 1, 1, n);         // mu
+                    t3b[i] = entry(cell_of((3 * n) % 8, (n + n / 3000 + 2) % 750), 3 + n % 3, 2, 1, 3, n); break;  // emu
+            }
+        }
+        for (int i = 0; i < 3 * AM_P3_LEN_MA1; i++) {             // E2 puncture {1,0,1,1,0,0}; 6-bit groups: el {0,1}, eu {2,3,5,4}
+            const int r6 = i % 6;
+            if (!(r6 == 0 || r6 == 2 || r6 == 3)) { t3a[i].x = AMT_PUNCT; t3a[i].y = 0; continue; }
+            const int o = (i / 6) * 3 + (r6 == 0 ? 0 : r6 - 1), g = o / 6, pos = o % 6;
+            if (pos < 2) { const int n = g * 2 + pos; t3a[i] = entry(cell_of((3 * n + n / 3000) % 8, (n + n / 6000) % 750), n % 2, 3, 0, 0, 0); }
+            else {
+                const int j = pos == 2 ? 0 : pos == 3 ? 1 : pos == 5 ? 2 : 3, n = g * 4 + j;
+                t3a[i] = entry(cell_of((3 * n + n / 3000 + 2 * (n / 12000)) % 8, (n + n / 6000) % 750), n % 4, 2, 0, 0, 0);
+            }
+        }
+        if ((rc = dev_upload(e, &e->tb.am_deint_p1, t1))) return rc;
+        if ((rc = dev_upload(e, &e->tb.am_deint_p3_ma3, t3b))) return rc;
+        if ((rc = dev_upload(e, &e->tb.am_deint_p3_ma1, t3a))) return rc;
+    }
     {   // AM tables: acquisition FIR (acquire.c:63-96), pulse shape (acquire.c:333-342), 256-point twiddles
         static const float am_taps[32] = {
             -0.00038464731187559664f, -0.00021618751634377986f, 0.0026779419276863337f, -0.00029802651260979474f,

@@ -876,15 +876,24 @@ __global__ __launch_bounds__(64) void k_am_viterbi(DevTables tb, DevBuffers db, 
 }
 
 // ---- after block 7: BER of the frame just decoded, then interleaver_ma1 for the frame just received -------------
-// Output-centric: every depunctured trellis input finds its source bit directly (bit_map, decode.c:66-71).
-__device__ inline int am_cell_bit(const uint8_t *m, int b, int k, int p)
+// Output-centric and table-driven: every depunctured trellis input looks up which bit of which hard-symbol matrix it is
+// (DevTables::am_deint_*, built from decode.c:66-231 by engine.hip), the main (m*) bits pass through the 3-frame
+// diversity delay lines -- a 3-slot ring whose oldest slot is read and refilled in place by the same work-item.
+__device__ inline int8_t am_deint_one(uint2 e, const uint8_t *sym, uint8_t *q, int head)
 {
-    const int col = (9 * k) % 25;
-    const int row = (11 * col + 16 * (k / 25) + 11 * (k / 50)) % 32;
-    return (m[AM_PW * (b * NSYM + row) + col] >> p) & 1;
+    if (e.x & AMT_PUNCT) return 0;
+    const uint8_t *m = sym + (size_t)((e.x >> 16) & 3u) * AM_SYMS;
+    int bit = (m[e.x & 0x1fffu] >> ((e.x >> 13) & 7u)) & 1;
+    if (e.x & AMT_DELAYED) {
+        uint8_t *cell = q + (((e.x >> 20) & 3u) * 3 + head) * 18000 + e.y;
+        const int old = *cell;
+        *cell = (uint8_t)bit;
+        bit = old;
+    }
+    return bit ? 1 : -1;
 }
 
-__global__ __launch_bounds__(1024) void k_am_interleave(DevBuffers db, const int *ids, int parity)
+__global__ __launch_bounds__(1024) void k_am_interleave(DevTables tb, DevBuffers db, const int *ids, int parity)
 {
     wave_set_priority_high();
     const int s = stream_of(ids, blockIdx.x);
@@ -899,83 +908,13 @@ __global__ __launch_bounds__(1024) void k_am_interleave(DevBuffers db, const int
         if (!am.dec_rdbi) total += ma3 ? AM_P3_LEN_MA3 * 12 / 5 : AM_P3_LEN_MA1 * 3 / 2;
         db.records[(size_t)s * db.rec_cap + am.dec_record].ber = (float)am.am_errors / (float)total;
     }
-    const uint8_t *pl = db.am_sym + (size_t)s * 4 * AM_SYMS, *pu = pl + AM_SYMS, *sy = pu + AM_SYMS, *tt = sy + AM_SYMS;
+    const uint8_t *sym = db.am_sym + (size_t)s * 4 * AM_SYMS;  // [pl, pu, s, t][8 blocks][32][25]
     uint8_t *q = db.am_q + (size_t)s * 4 * 3 * 18000;         // [ml, mu, eml, emu][3][18000]
     const int head = am.q_head;
     int8_t *v1 = db.am_vit + ((size_t)s * db.am_nvit + vslot) * 2 * AM_VIT, *v3 = v1 + AM_VIT;
-    // position inside a 12-bit group -> (source, j): bl {2,1,5}, ml {11,6,7}, bu {10,8,9}, mu {4,3,0} (decode.c:26-30)
-    const int src12[12] = { 3, 0, 0, 3, 3, 0, 1, 1, 2, 2, 2, 1 };
-    const int j12[12] = { 2, 1, 0, 1, 0, 2, 1, 2, 1, 2, 0, 0 };
-    const int rank15[15] = { 0, -1, 1, 2, -1, 3, 4, -1, 5, 6, 7, 8, 9, 10, 11 };       // E1 puncture {1,0,1,1,0,1,1,0,1,...}
-    // P1: 8 x 11250 trellis inputs
-    for (int i = tid; i < 8 * AM_P1_LEN * 3; i += 1024) {
-        const int rk = rank15[i % 15];
-        int val = 0;
-        if (rk >= 0) {
-            const int o = (i / 15) * 12 + rk, g = o / 12, pos = o % 12, n = g * 3 + j12[pos];
-            int bitv;
-            switch (src12[pos]) {
-            case 0: bitv = am_cell_bit(pl, n / 2250, (n + n / 750 + 1) % 750, n % 3); break;                       // bl
-            case 1: {                                                                                               // ml (delayed)
-                uint8_t *cell = q + (0 * 3 + head) * 18000 + n;
-                bitv = *cell;
-                *cell = (uint8_t)am_cell_bit(pl, (3 * n + 3) % 8, (n + n / 3000 + 3) % 750, 3 + (n % 3));
-                break; }
-            case 2: bitv = am_cell_bit(pu, n / 2250, (n + n / 750) % 750, n % 3); break;                           // bu
-            default: {                                                                                              // mu (delayed)
-                uint8_t *cell = q + (1 * 3 + head) * 18000 + n;
-                bitv = *cell;
-                *cell = (uint8_t)am_cell_bit(pu, (3 * n) % 8, (n + n / 3000 + 2) % 750, 3 + (n % 3));
-                break; }
-            }
-            val = bitv ? 1 : -1;
-        }
-        v1[i] = (int8_t)val;
-    }
-    if (!ma3) {
-        // P3 (MA1): E2 puncture {1,0,1,1,0,0}; 6-bit groups: el {0,1}, eu {2,3,5,4} (decode.c:31-32)
-        for (int i = tid; i < AM_P3_LEN_MA1 * 3; i += 1024) {
-            const int r6 = i % 6;
-            int val = 0;
-            if (r6 == 0 || r6 == 2 || r6 == 3) {
-                const int o = (i / 6) * 3 + (r6 == 0 ? 0 : r6 - 1), g = o / 6, pos = o % 6;
-                int bitv;
-                if (pos < 2) { const int n = g * 2 + pos; bitv = am_cell_bit(tt, (3 * n + n / 3000) % 8, (n + n / 6000) % 750, n % 2); }
-                else {
-                    const int j = pos == 2 ? 0 : pos == 3 ? 1 : pos == 5 ? 2 : 3;
-                    const int n = g * 4 + j;
-                    bitv = am_cell_bit(sy, (3 * n + n / 3000 + 2 * (n / 12000)) % 8, (n + n / 6000) % 750, n % 4);
-                }
-                val = bitv ? 1 : -1;
-            }
-            v3[i] = (int8_t)val;
-        }
-    } else {
-        for (int i = tid; i < AM_P3_LEN_MA3 * 3; i += 1024) {
-            const int rk = rank15[i % 15];
-            int val = 0;
-            if (rk >= 0) {
-                const int o = (i / 15) * 12 + rk, g = o / 12, pos = o % 12, n = g * 3 + j12[pos];
-                int bitv;
-                switch (src12[pos]) {
-                case 0: bitv = am_cell_bit(tt, (3 * n + 3) % 8, (n + n / 3000 + 3) % 750, n % 3); break;          // ebl
-                case 1: {
-                    uint8_t *cell = q + (2 * 3 + head) * 18000 + n;
-                    bitv = *cell;
-                    *cell = (uint8_t)am_cell_bit(tt, (3 * n + 3) % 8, (n + n / 3000 + 3) % 750, 3 + (n % 3));      // eml
-                    break; }
-                case 2: bitv = am_cell_bit(sy, (3 * n) % 8, (n + n / 3000 + 2) % 750, n % 3); break;               // ebu
-                default: {
-                    uint8_t *cell = q + (3 * 3 + head) * 18000 + n;
-                    bitv = *cell;
-                    *cell = (uint8_t)am_cell_bit(sy, (3 * n) % 8, (n + n / 3000 + 2) % 750, 3 + (n % 3));          // emu
-                    break; }
-                }
-                val = bitv ? 1 : -1;
-            }
-            v3[i] = (int8_t)val;
-        }
-    }
+    for (int i = tid; i < AM_VIT; i += 1024) v1[i] = am_deint_one(tb.am_deint_p1[i], sym, q, head);
+    if (!ma3) for (int i = tid; i < 3 * AM_P3_LEN_MA1; i += 1024) v3[i] = am_deint_one(tb.am_deint_p3_ma1[i], sym, q, head);
+    else for (int i = tid; i < AM_VIT; i += 1024) v3[i] = am_deint_one(tb.am_deint_p3_ma3[i], sym, q, head);
     __syncthreads();
     if (tid == 0) {
         am.q_head = (head + 1) % 3;
@@ -1059,7 +998,7 @@ void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, con
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_am_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AmBlockSmem)); attr_set = true; }
     hipLaunchKernelGGL(k_am_block, dim3(nstreams), dim3(256), sizeof(AmBlockSmem), st, tb, db, stream_ids, pipeline_parity >= 0 ? 1 : 0);
     if (pipeline_parity < 0) hipLaunchKernelGGL(k_am_viterbi, dim3(2, nstreams), dim3(64), 0, st, tb, db, stream_ids, l2_feedback);
-    hipLaunchKernelGGL(k_am_interleave, dim3(nstreams), dim3(1024), 0, st, db, stream_ids, pipeline_parity);
+    hipLaunchKernelGGL(k_am_interleave, dim3(nstreams), dim3(1024), 0, st, tb, db, stream_ids, pipeline_parity);
 }
 
 // ---- stage-level entry: decode `nframes` independent K=9 frames (parity tests) ------------------------------------

@@ -2,7 +2,8 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-for na in 3 4 5; do
+( timeout 600 python -m pytest tests -m gpu -q -x -k "am" ) > gpurun_out/pytest_am.log 2>&1; grep -E "passed|failed" gpurun_out/pytest_am.log
+for na in 3 4; do
 NRSC5HIP_NAUX=$na timeout 300 python tools/gpu_am_bench.py --streams 256 --frames 41 --fmt cs16 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
