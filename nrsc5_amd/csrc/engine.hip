@@ -53,6 +53,7 @@ struct nrsc5hip_engine {
     } lanes[MAX_LANES];
     int nlanes;
     int naux;                          // decode streams in use (<= NAUX)
+    int naux_am;                       // ... by the AM window pipeline (its decodes are longer and thinner: 4 measured best)
     hipStream_t main;                  // = lanes[0].main
     std::vector<void *> allocs;
     // host mirrors
@@ -312,6 +313,10 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             e->naux = ea ? atoi(ea) : 3;
             if (e->naux < 1) e->naux = 1;
             if (e->naux > NAUX) e->naux = NAUX;
+            const char *eam = getenv("NRSC5HIP_NAUX_AM");
+            e->naux_am = eam ? atoi(eam) : 4;
+            if (e->naux_am < 1) e->naux_am = 1;
+            if (e->naux_am > NAUX) e->naux_am = NAUX;
         }
         for (int l = 0; l < e->nlanes && !rc; l++) {
             nrsc5hip_engine::Lane &ln = e->lanes[l];
@@ -561,7 +566,7 @@ static int am_flush(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const 
     if (!e->cfg.p1_async) return 0;
     if (ln.am_step_count % 8) {
         const long long window = ln.am_step_count / 8;
-        const int parity = (int)(window % NWIN), lane = (int)(window % e->naux);
+        const int parity = (int)(window % NWIN), lane = (int)(window % e->naux_am);
         hipStream_t ax = ln.aux[lane];
         HIPCHK(hipEventRecord(ln.ev_window[parity], ln.main));
         HIPCHK(hipStreamWaitEvent(ax, ln.ev_window[parity], 0));
@@ -583,7 +588,7 @@ static int run_steps_am(nrsc5hip_engine *e, int n, const int *ids_dev, int max_s
         int burst = 0;
         for (; burst < check_every && done + burst < max_steps; burst++) {
             const long long window = ln.am_step_count / 8;
-            const int parity = pipe ? (int)(window % NWIN) : -1, lane = (int)(window % e->naux);
+            const int parity = pipe ? (int)(window % NWIN) : -1, lane = (int)(window % e->naux_am);
             if (pipe && (ln.am_step_count % 8) == 0 && ln.am_decoded_pending[parity]) {
                 HIPCHK(hipStreamWaitEvent(ln.main, ln.ev_decoded[parity], 0));   // the window that used these buffers NWIN windows ago
                 ln.am_decoded_pending[parity] = false;
