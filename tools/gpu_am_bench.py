@@ -77,11 +77,29 @@ def main():
                 n3 += 1
                 w = frames[k, slot, 944:944 + 750]
                 ok3 += np.packbits(eng.unpack_bits(w, 24000), bitorder="little").tobytes() in truth3
+    # CPU baseline beside it: the unmodified reference (oracle/_ref, SSE build) or the restatement, one stream on one host core
+    cpu = None
+    try:
+        from oracle import ref, port
+        one = np.ascontiguousarray(cap.iq[:n])
+        if ref.available(sse=True):
+            R = ref.RefLib(sse=True); run = lambda: R.run(one, mode=ref.MODE_AM); kind = "reference"
+        else:
+            O = port.Oracle(); run = lambda: O.run(one, mode=1); kind = "port"
+        run()
+        reps, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < 8.0:
+            run(); reps += 1
+        dtc = (time.perf_counter() - t1) / reps
+        cpu = {"value": round(nsamp / dtc / 1e6, 3), "unit": "IQ MS/s", "x_realtime": round(nsamp / fs / dtc, 1), "cores": 1, "kind": kind,
+               "sample": f"{reps}x one {nsamp / fs:.0f}-s stream of this workload, 32768-byte pushes"}
+    except Exception as ex:                                     # the checker is optional here
+        cpu = {"error": str(ex)}
     out = {"metric": "AM IQ MS/s demodulated and decoded", "fmt": args.fmt, "streams": S, "seconds_per_stream": round(nsamp / fs, 2),
            "value": round(S * nsamp / dt / 1e6, 3), "x_realtime": round(S * nsamp / fs / dt, 1), "ms_per_pass": round(dt * 1e3, 2),
            "decode": "in-order" if args.in_order else "window pipeline", "block_steps": steps, "device_ms_per_pass": {k: round(v[0] / args.steps, 3) for k, v in prof.items() if v[1]},
            "launches_per_pass": {k: v[1] // args.steps for k, v in prof.items() if v[1]},
-           "truth": {"p1_checked": n1, "p1_exact": int(ok1), "p3_checked": n3, "p3_exact": int(ok3)}}
+           "truth": {"p1_checked": n1, "p1_exact": int(ok1), "p3_checked": n3, "p3_exact": int(ok3)}, "cpu_baseline": cpu}
     print(json.dumps(out))
 
 
