@@ -62,7 +62,8 @@ enum {
     NRSC5HIP_REC_LOST_SYNC = 1u << 6,  /* l2_feedback only: after this block's frames the engine dropped the stream to NONE (nrsc5_report_lost_sync) */
     NRSC5HIP_REC_P3        = 1u << 7,  /* FM (MP2/MP3/MP11, odd blocks): frame_push(P3 frame of PX slot `sis`, 2304 or 4608 bits);
                                           AM, block 7: frame_push(P3 frame of slot p1_slot), then nrsc5_report_ber(ber) */
-    NRSC5HIP_REC_P4        = 1u << 8   /* FM MP11: frame_push(P4 frame of PX slot `sis`, 4608 bits) */
+    NRSC5HIP_REC_P4        = 1u << 8,  /* FM MP11: frame_push(P4 frame of PX slot `sis`, 4608 bits) */
+    NRSC5HIP_REC_PIDS_CRC  = 1u << 9   /* with REC_PIDS: the frame passes pids_frame_push's CRC-12 (pids.c:52-86), i.e. sis_decode will see it */
 };
 
 /* One record per processed 32-symbol block, in stream order.  Events implied by one record fire in

@@ -71,7 +71,7 @@ static void deliver(input_t *st)
             }
             if (r->flags & NRSC5HIP_REC_MER)
                 nrsc5_report_mer(st->radio, r->mer_lb, r->mer_ub);
-            if (r->flags & NRSC5HIP_REC_PIDS)
+            if (r->flags & NRSC5HIP_REC_PIDS)      /* (NRSC5HIP_REC_PIDS_CRC tells whether its CRC-12 passes; pids_frame_push re-checks) */
             {
                 uint8_t pids[PIDS_FRAME_LEN];
                 nrsc5hip_unpack_bits(r->pids, PIDS_FRAME_LEN, pids);

@@ -784,7 +784,7 @@ __global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, c
         if (tid == 0) {
             for (int w = 0; w < 3; w++) rec.pids[w] = sm.pids_out[w] ^ tb.scr_pids[w];
             rec.pids[2] &= 0xffffu;
-            rec.flags |= REC_PIDS;
+            rec.flags |= REC_PIDS | (pids_crc_ok(rec.pids) ? (uint32_t)REC_PIDS_CRC : 0u);
             rec.bc_decoded = bc;
             // hand this block to the P1 / P3 decoders (decode_process_p1_p3_am runs next, in k_am_viterbi)
             am.dec_bc = bc; am.dec_record = st.nblocks % db.rec_cap; am.dec_rdbi = am.rdbi; am.dec_psmi = st.psmi;

@@ -12,6 +12,7 @@
 #include "wave_ops.h"
 #include "viterbi_wave.h"
 #include "prepare_block.h"
+#include "l2_header.h"
 
 namespace nrsc5 {
 
@@ -538,6 +539,7 @@ __global__ __launch_bounds__(64) void k_pids_decode(DevTables tb, DevBuffers db,
         rec.pids[0] = out[0] ^ tb.scr_pids[0];                 // descramble (decode.c:470)
         rec.pids[1] = out[1] ^ tb.scr_pids[1];
         rec.pids[2] = (out[2] ^ tb.scr_pids[2]) & 0xffffu;
+        if (pids_crc_ok(rec.pids)) atomicOr(&rec.flags, (uint32_t)REC_PIDS_CRC);
         *recp = -1;
     }
 }

@@ -129,4 +129,23 @@ __device__ inline bool l2_first_header_ok_am(const uint32_t *w, L2Smem &g)
     return l2_header_codeword_ok(g);
 }
 
+// pids_frame_push's acceptance test (pids.c:52-86, 1032-1050) on the 80 descrambled bits packed LSB-first in w[0..2]:
+// undo the per-byte bit reversal, CRC-12 over logical bits 0..67 (from bit 67 down), compare with bits 68..79
+__device__ inline bool pids_crc_ok(const uint32_t *w)
+{
+    auto logical = [&](int i) -> unsigned { const int k = ((i >> 3) << 3) + 7 - (i & 7); return (w[k >> 5] >> (k & 31)) & 1u; };
+    unsigned reg = 0;
+    for (int i = 67; i >= 0; i--) {
+        const unsigned low = reg & 1u;
+        reg >>= 1;
+        reg ^= logical(i) << 15;
+        if (low) reg ^= 0xD010u;
+    }
+    for (int i = 0; i < 16; i++) { const unsigned low = reg & 1u; reg >>= 1; if (low) reg ^= 0xD010u; }
+    reg ^= 0x955u;
+    unsigned expected = 0;
+    for (int i = 68; i < 80; i++) expected = (expected << 1) | logical(i);
+    return expected == (reg & 0xfffu);
+}
+
 }  // namespace nrsc5

@@ -76,6 +76,7 @@ enum : uint32_t {
     REC_LOST_SYNC   = 1u << 6,   // the block started from a host-forced NONE while FINE (input.c:177)
     REC_P3          = 1u << 7,   // a P3 frame completed (FM: odd blocks once the PX1 interleaver is primed, slot in `sis`; AM: block 7)
     REC_P4          = 1u << 8,   // FM MP11: a P4 frame completed (same slot)
+    REC_PIDS_CRC    = 1u << 9,   // the PIDS frame passes pids_frame_push's CRC-12 (pids.c:52-86)
 };
 
 // One per (stream, processed block).  Plain-old-data, mirrored by include/nrsc5hip.h.

@@ -14,6 +14,7 @@ SYNC_NONE, SYNC_COARSE, SYNC_FINE = 0, 1, 2
 REC_PROCESSED, REC_TO_COARSE, REC_TO_FINE, REC_MER, REC_PIDS, REC_P1 = 1, 2, 4, 8, 16, 32
 REC_P3, REC_P4 = 128, 256
 REC_LOST_SYNC = 64
+REC_PIDS_CRC = 512
 PX_WORDS = 144
 MODE_FM, MODE_AM = 0, 1
 AM_P1_BITS, AM_P1_WORDS, AM_P3_WORD0 = 3750, 118, 944

@@ -101,6 +101,8 @@ void orc_snapshot(const orc_stream *s, orc_sync_snapshot *out);
 /* frame.c:516-540 + fix_header + RS(255,247): 1 = frame_process keeps sync after this P1 frame, 0 = it drops to NONE */
 int orc_rs255_247_decode(uint8_t r[255]);
 int orc_l2_first_header_ok(const uint8_t *bits, unsigned len);
+/* pids.c:52-86,1032-1050: does pids_frame_push accept this PIDS frame (CRC-12)? */
+int orc_pids_crc_ok(const uint8_t bits[80]);
 
 /* ---- AM (nrsc5_oracle_am.c) ------------------------------------------------------------ */
 

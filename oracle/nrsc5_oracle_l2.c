@@ -107,3 +107,23 @@ int orc_l2_first_header_ok(const uint8_t *bits, unsigned len)
     for (int i = 0; i < 159; i++) if (r[i]) return 0;
     return 1;
 }
+
+/* pids_frame_push's acceptance test (pids.c:52-86, 1032-1050): undo the per-byte bit reversal, CRC-12 over logical bits
+ * 0..67 (processed from bit 67 down), compare with bits 68..79.  1 = the frame goes on to sis_decode. */
+int orc_pids_crc_ok(const uint8_t bits[80])
+{
+    uint8_t p[80];
+    for (int i = 0; i < 80; i++) p[i] = bits[((i >> 3) << 3) + 7 - (i & 7)];
+    uint16_t reg = 0;
+    for (int i = 67; i >= 0; i--) {
+        const int low = reg & 1;
+        reg >>= 1;
+        reg ^= (uint16_t)(p[i] << 15);
+        if (low) reg ^= 0xD010;
+    }
+    for (int i = 0; i < 16; i++) { const int low = reg & 1; reg >>= 1; if (low) reg ^= 0xD010; }
+    reg ^= 0x955;
+    unsigned expected = 0;
+    for (int i = 68; i < 80; i++) expected = (expected << 1) | p[i];
+    return expected == (reg & 0xfffu);
+}

@@ -61,6 +61,7 @@ class Oracle:
         L.oracle_fft_forward.argtypes = [ctypes.c_int, vp, vp]
         L.orc_l2_first_header_ok.argtypes = [vp, ctypes.c_uint]
         L.orc_rs255_247_decode.argtypes = [vp]
+        L.orc_pids_crc_ok.argtypes = [vp]
         # AM
         L.orc_am_open.restype = vp
         L.orc_am_close.argtypes = [vp]
@@ -147,6 +148,10 @@ class Oracle:
         """The L2 -> L1 feedback decision of frame_process for one P1 frame (bits as handed to frame_push)."""
         b = np.ascontiguousarray(bits, dtype=np.uint8)
         return bool(self.lib.orc_l2_first_header_ok(b.ctypes.data, b.size))
+
+    def pids_crc_ok(self, bits80: np.ndarray) -> bool:
+        b = np.ascontiguousarray(bits80, dtype=np.uint8)
+        return bool(self.lib.orc_pids_crc_ok(b.ctypes.data))
 
     def l2_hook(self):
         """p1_hook for run(): drop to SYNC_NONE exactly when the reference's frame_process would."""

@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 TAP_Q15, TAP_FFT, TAP_SOFT, TAP_VIT, TAP_HDC = 1, 2, 4, 8, 16
-REC_BLOCK, REC_STATE, REC_SOFT, REC_PIDS, REC_FRAME, REC_SYNC, REC_LOST_SYNC, REC_MER, REC_BER, REC_HDC, REC_VIT, REC_AMSYM, REC_PXSOFT = range(1, 14)
+REC_BLOCK, REC_STATE, REC_SOFT, REC_PIDS, REC_FRAME, REC_SYNC, REC_LOST_SYNC, REC_MER, REC_BER, REC_HDC, REC_VIT, REC_AMSYM, REC_PXSOFT, REC_STATION = range(1, 15)
 MODE_FM, MODE_AM = 0, 1
 
 BLOCK_FIELDS = ("state_before", "state_after", "samperr", "cfo", "keep", "bc", "psmi", "cfo_wait",
@@ -126,6 +126,9 @@ def parse_log(log: bytes):
         elif kind == REC_PXSOFT:
             ch, bc, ln = struct.unpack_from("<3I", pl)
             out.append(("pxsoft", {"ch": ch, "bc": bc, "bits": np.frombuffer(pl, dtype=np.int8, offset=12, count=ln)}))
+        elif kind == REC_STATION:
+            fcc, cc = struct.unpack("<i4s", pl)
+            out.append(("station", {"fcc": fcc, "country": cc.rstrip(b"\0").decode()}))
         elif kind == REC_VIT:
             ln = struct.unpack_from("<I", pl)[0]
             out.append(("vit", {"in": np.frombuffer(pl, dtype=np.int8, offset=4, count=3 * ln),

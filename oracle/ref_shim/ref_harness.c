@@ -20,7 +20,7 @@ enum {
 /* ordered log record kinds */
 enum {
     REC_BLOCK = 1, REC_STATE, REC_SOFT, REC_PIDS, REC_FRAME, REC_SYNC, REC_LOST_SYNC,
-    REC_MER, REC_BER, REC_HDC, REC_VIT, REC_AMSYM, REC_PXSOFT
+    REC_MER, REC_BER, REC_HDC, REC_VIT, REC_AMSYM, REC_PXSOFT, REC_STATION
 };
 
 typedef struct { uint8_t *p; size_t len, cap; } gbuf;
@@ -180,6 +180,10 @@ static void on_event(const nrsc5_event_t *evt, void *opaque)
     case NRSC5_EVENT_LOST_SYNC: log_rec(REC_LOST_SYNC, NULL, 0); break;
     case NRSC5_EVENT_MER: { float r[2] = { evt->mer.lower, evt->mer.upper }; log_rec(REC_MER, r, sizeof(r)); break; }
     case NRSC5_EVENT_BER: { float r = evt->ber.cber; log_rec(REC_BER, &r, sizeof(r)); break; }
+    case NRSC5_EVENT_STATION_ID: {
+        struct { int32_t fcc; char cc[4]; } r = { evt->station_id.fcc_facility_id, { 0, 0, 0, 0 } };
+        strncpy(r.cc, evt->station_id.country_code, 3);
+        log_rec(REC_STATION, &r, sizeof(r)); break; }
     case NRSC5_EVENT_HDC: {
         size_t n = (g_taps & REFH_TAP_HDC) ? evt->hdc.count : 0;
         uint8_t *tmp = malloc(12 + n);

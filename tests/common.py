@@ -48,7 +48,7 @@ def sha256(a: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def compare_logs(expected, got, rtol: float = FLOAT_RTOL, skip_kinds=("hdc", "soft", "vit", "amsym", "pxsoft")):
+def compare_logs(expected, got, rtol: float = FLOAT_RTOL, skip_kinds=("hdc", "soft", "vit", "amsym", "pxsoft", "station")):
     """Ordered-record comparison: integers/bit arrays exact, floats within rtol (relative, floor 1).
     Returns a list of human-readable differences (empty = parity)."""
     exp = [r for r in expected if r[0] not in skip_kinds]

@@ -431,3 +431,27 @@ def check_mode_switch(lib, oracle):
         diffs = common.compare_logs(common.strip_states(exp), common.strip_states(log))
         assert not diffs, (mode, diffs[:5])
     E.close()
+
+
+def check_pids_crc_flag(lib, oracle, am=False):
+    """REC_PIDS_CRC == pids_frame_push's CRC-12 decision (restated in the oracle, pinned against the reference's
+    STATION_ID events): frames with a fresh station id in every block, every fifth one with a broken CRC."""
+    from nrsc5_amd import synth_am
+    if am:
+        cap = synth_am.am_ma1_capture(8, seed=12, cfo_hz=1.0, offset=700)
+        E = eng.Engine(max_streams=1, q15_capacity=400000, record_capacity=512, p1_slots=16, lib_path=lib, am_enable=True)
+        E.set_mode(0, eng.MODE_AM)
+        common.run_engine_streaming(E, 0, cap.iq, chunk=32768)
+    else:
+        cap = synth.fm_mp1_capture(0, n_blocks=40, seed=77, cfo_hz=30.0, offset=777, snr_db=25, station_ids=True)
+        E = eng.Engine(max_streams=1, q15_capacity=400000, lib_path=lib)
+        common.run_engine_streaming(E, 0, cap.iq)
+    recs = E.drain(0)
+    n = good = 0
+    for r in recs:
+        if int(r["flags"]) & eng.REC_PIDS:
+            ok = oracle.pids_crc_ok(eng.unpack_bits(r["pids"], eng.PIDS_BITS))
+            assert bool(int(r["flags"]) & eng.REC_PIDS_CRC) == ok
+            n += 1; good += ok
+    assert n >= 20 and good >= 16 and (am or good < n)
+    E.close()

@@ -109,3 +109,8 @@ def test_emu_l2_feedback_on_device_am(emu_lib, oracle):
 
 def test_emu_mode_switch_on_live_stream(emu_lib, oracle):
     ec.check_mode_switch(emu_lib, oracle)
+
+
+def test_emu_pids_crc_flag(emu_lib, oracle):
+    ec.check_pids_crc_flag(emu_lib, oracle)
+    ec.check_pids_crc_flag(emu_lib, oracle, am=True)

@@ -258,3 +258,8 @@ def test_gpu_l2_feedback_deferred_recovers_false_locks(hip_lib):
 
 def test_gpu_mode_switch_on_live_stream(hip_lib, oracle):
     ec.check_mode_switch(hip_lib, oracle)
+
+
+def test_gpu_pids_crc_flag(hip_lib, oracle):
+    ec.check_pids_crc_flag(hip_lib, oracle)
+    ec.check_pids_crc_flag(hip_lib, oracle, am=True)

@@ -187,3 +187,18 @@ def test_l2_feedback_restatement_matches_reference_l2(kw, oracle, reflib):
     ol, _, _ = oracle.run(cap.iq, p1_hook=oracle.l2_hook())
     assert not common.compare_logs(rl, ol, rtol=0.0)
     assert (kw["offset"] == 777) != any(k == "lost_sync" for k, _ in rl)
+
+
+def test_pids_crc_restatement_matches_reference_sis_events(oracle, reflib):
+    """Every block carries a new station id, every fifth PIDS frame a broken CRC: the unmodified reference fires
+    NRSC5_EVENT_STATION_ID exactly for the frames the restated CRC-12 accepts, with their ids in order."""
+    cap = synth.fm_mp1_capture(0, n_blocks=40, seed=77, cfo_hz=30.0, offset=777, snr_db=25, station_ids=True)
+    log, _, _ = reflib.run(cap.iq)
+    pids = [v["bits"] for k, v in log if k == "pids"]
+    ok = [oracle.pids_crc_ok(b) for b in pids]
+
+    def station_id(b):
+        p = np.array([b[((i >> 3) << 3) + 7 - (i & 7)] for i in range(80)])
+        return int("".join(str(int(x)) for x in p[19:38]), 2)
+    assert 0 < sum(ok) < len(ok)
+    assert [station_id(b) for b, o in zip(pids, ok) if o] == [v["fcc"] for k, v in log if k == "station"]
