@@ -320,24 +320,8 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         }
         for (int l = 0; l < e->nlanes && !rc; l++) {
             nrsc5hip_engine::Lane &ln = e->lanes[l];
-            // Optional CU partition (experiment, NRSC5HIP_CU_DEC = n): the decode streams only get the first n bits of the CU
-            // mask (on gfx94x/95x consecutive bits alternate between XCDs), the block-step stream the rest
-            // (NRSC5HIP_CU_MAIN_ALL=1: everything).
-            const char *ecd = getenv("NRSC5HIP_CU_DEC");
-            const int ncu_dec = ecd ? atoi(ecd) : 0;
-            int ncu_total = 0;
-            (void)hipDeviceGetAttribute(&ncu_total, hipDeviceAttributeMultiprocessorCount, cfg->device);
-            if (ncu_dec > 0 && ncu_dec < ncu_total) {
-                const int words = (ncu_total + 31) / 32;
-                std::vector<uint32_t> mdec(words, 0), mmain(words, 0);
-                for (int c = 0; c < ncu_total; c++) (c < ncu_dec ? mdec : mmain)[c >> 5] |= 1u << (c & 31);
-                if (getenv("NRSC5HIP_CU_MAIN_ALL")) for (int c = 0; c < ncu_total; c++) mmain[c >> 5] |= 1u << (c & 31);
-                if (hipExtStreamCreateWithCUMask(&ln.main, (uint32_t)words, mmain.data()) != hipSuccess) rc = NRSC5HIP_EHIP;
-                for (int k = 0; k < NAUX && !rc; k++) if (hipExtStreamCreateWithCUMask(&ln.aux[k], (uint32_t)words, mdec.data()) != hipSuccess) rc = NRSC5HIP_EHIP;
-            } else {
             if (hipStreamCreate(&ln.main) != hipSuccess) rc = NRSC5HIP_EHIP;
             for (int k = 0; k < NAUX && !rc; k++) if (hipStreamCreate(&ln.aux[k]) != hipSuccess) rc = NRSC5HIP_EHIP;
-            }
             for (int k = 0; k < NWIN && !rc; k++) {
                 if (hipEventCreate(&ln.ev_window[k]) != hipSuccess || hipEventCreate(&ln.ev_decoded[k]) != hipSuccess) rc = NRSC5HIP_EHIP;
                 ln.decoded_pending[k] = false;
