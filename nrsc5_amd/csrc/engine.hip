@@ -50,7 +50,7 @@ struct nrsc5hip_engine {
         bool am_decoded_pending[NWIN];
         int *counters_dev, *counters_host;
         DevBuffers db;                 // engine buffers with this lane's counters
-    } lanes[MAX_LANES + 1];            // lanes[nlanes] serves the AM streams: a mixed batch advances both waveforms concurrently
+    } lanes[MAX_LANES];
     int nlanes;
     int naux;                          // decode streams in use (<= NAUX)
     int naux_am;                       // ... by the AM window pipeline (its decodes are longer and thinner: 4 measured best)
@@ -318,7 +318,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             if (e->naux_am < 1) e->naux_am = 1;
             if (e->naux_am > NAUX) e->naux_am = NAUX;
         }
-        for (int l = 0; l <= e->nlanes && !rc; l++) {
+        for (int l = 0; l < e->nlanes && !rc; l++) {
             nrsc5hip_engine::Lane &ln = e->lanes[l];
             if (hipStreamCreate(&ln.main) != hipSuccess) rc = NRSC5HIP_EHIP;
             for (int k = 0; k < NAUX && !rc; k++) if (hipStreamCreate(&ln.aux[k]) != hipSuccess) rc = NRSC5HIP_EHIP;
@@ -352,7 +352,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if (hipMemset(db.pids_rec, 0xff, S * NWIN * 16 * sizeof(int)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
         if ((rc = dev_alloc(e, &db.p1_ring, S * db.p1_slots * P1_WORDS))) break;
         if ((rc = dev_alloc(e, &db.records, S * db.rec_cap))) break;
-        if ((rc = dev_alloc(e, &db.counters, 4 * (MAX_LANES + 1)))) break;
+        if ((rc = dev_alloc(e, &db.counters, 4 * MAX_LANES))) break;
         {
             const size_t nax = cfg->p1_async ? NAUX : 1;
             db.px_slots = 8 * cfg->p1_slots;
@@ -402,7 +402,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             hipMemset(db.pm, 0, S * NPM * PM_FRAME) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "state init copy failed"); break; }
         e->wr_host.assign(S, 0); e->base_host.assign(S, 0); e->drained.assign(S, 0);
         e->mode_host.assign(S, MODE_FM); e->raw_host.assign(S, 0);
-        for (int l = 0; l <= e->nlanes; l++) { e->lanes[l].db = db; e->lanes[l].counters_dev = db.counters + 4 * l; e->lanes[l].db.counters = db.counters + 4 * l; }
+        for (int l = 0; l < e->nlanes; l++) { e->lanes[l].db = db; e->lanes[l].counters_dev = db.counters + 4 * l; e->lanes[l].db.counters = db.counters + 4 * l; }
         e->prof_on = false;
         for (int k = 0; k < NRSC5HIP_PROF_CLASSES; k++) { e->prof_ms[k] = 0; e->prof_launches[k] = 0; }
     } while (0);
@@ -423,7 +423,7 @@ extern "C" void nrsc5hip_engine_destroy(nrsc5hip_engine *e)
     if (e->nblocks_host) (void)hipHostFree(e->nblocks_host);
     for (auto &sp : e->prof_spans) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
     for (hipEvent_t ev : e->prof_pool) hipEventDestroy(ev);
-    for (int l = 0; l <= e->nlanes; l++) {
+    for (int l = 0; l < e->nlanes; l++) {
         nrsc5hip_engine::Lane &ln = e->lanes[l];
         if (ln.counters_host) (void)hipHostFree(ln.counters_host);
         for (int k = 0; k < NWIN; k++) { if (ln.ev_window[k]) (void)hipEventDestroy(ln.ev_window[k]); if (ln.ev_decoded[k]) (void)hipEventDestroy(ln.ev_decoded[k]); }
@@ -578,77 +578,43 @@ static int am_flush(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const 
     return 0;
 }
 
-static int am_issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const int *ids_dev)
-{
-    const bool pipe = e->cfg.p1_async != 0;
-    const long long window = ln.am_step_count / 8;
-    const int parity = pipe ? (int)(window % NWIN) : -1, lane = (int)(window % e->naux_am);
-    if (pipe && (ln.am_step_count % 8) == 0 && ln.am_decoded_pending[parity]) {
-        HIPCHK(hipStreamWaitEvent(ln.main, ln.ev_decoded[parity], 0));   // the window that used these buffers NWIN windows ago
-        ln.am_decoded_pending[parity] = false;
-    }
-    { ProfScope p(e, NRSC5HIP_PROF_AM, ln.main); launch_am_step(e->tb, ln.db, n, ids_dev, ln.main, e->cfg.l2_feedback, parity); }
-    if (pipe && (ln.am_step_count % 8) == 7) {
-        hipStream_t ax = ln.aux[lane];
-        HIPCHK(hipEventRecord(ln.ev_window[parity], ln.main));
-        HIPCHK(hipStreamWaitEvent(ax, ln.ev_window[parity], 0));
-        { ProfScope p(e, NRSC5HIP_PROF_AM, ax); launch_am_decode(e->tb, ln.db, n, ids_dev, parity, lane, e->cfg.l2_feedback, ax); }
-        HIPCHK(hipEventRecord(ln.ev_decoded[parity], ax));
-        ln.am_decoded_pending[parity] = true;
-    }
-    ln.am_step_count++;
-    return 0;
-}
-
-// Advances FM streams (scheduler lane 0, bursts of fm_every steps) and AM streams (the AM lane, bursts of am_every steps)
-// side by side until neither has a complete window left; either list may be empty.
-static int run_steps_mixed(nrsc5hip_engine *e, int nfm, const int *ids_fm, int fm_every, int nam, const int *ids_am, int am_every,
-                           int max_steps, int *steps_done)
-{
-    nrsc5hip_engine::Lane &lf = e->lanes[0], &la = e->lanes[e->nlanes];
-    bool fm_live = nfm > 0, am_live = nam > 0;
-    int done_fm = 0, done_am = 0;
-    lf.prepared_by_sync = false;
-    while ((fm_live && done_fm < max_steps) || (am_live && done_am < max_steps)) {
-        int bf = 0, ba = 0;
-        if (fm_live) {
-            HIPCHK(hipMemsetAsync(lf.counters_dev, 0, 4 * sizeof(int), lf.main));
-            for (; bf < fm_every && done_fm + bf < max_steps; bf++) { int rc = issue_step(e, lf, nfm, ids_fm); if (rc) return rc; }
-            HIPCHK(hipMemcpyAsync(lf.counters_host, lf.counters_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, lf.main));
-        }
-        if (am_live) {
-            HIPCHK(hipMemsetAsync(la.counters_dev, 0, 4 * sizeof(int), la.main));
-            for (; ba < am_every && done_am + ba < max_steps; ba++) { int rc = am_issue_step(e, la, nam, ids_am); if (rc) return rc; }
-            HIPCHK(hipMemcpyAsync(la.counters_host, la.counters_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, la.main));
-        }
-        if (fm_live) {
-            HIPCHK(hipStreamSynchronize(lf.main));
-            lf.acq_needed = lf.counters_host[1] > 0; lf.px_needed = lf.counters_host[2] > 0;
-            if (lf.counters_host[0] == 0) fm_live = false; else done_fm += bf;
-        }
-        if (am_live) {
-            HIPCHK(hipStreamSynchronize(la.main));
-            if (la.counters_host[0] == 0) am_live = false; else done_am += ba;
-        }
-        HIPCHK(hipGetLastError());
-    }
-    if (nfm > 0) {
-        if (e->dec_chunk) { HIPCHK(hipStreamSynchronize(e->dec_stream)); e->dec_chunk = 0; }
-        int rc = flush_p1(e, lf, nfm, ids_fm); if (rc) return rc;
-        HIPCHK(hipStreamSynchronize(lf.main));
-    }
-    if (nam > 0) {
-        int rc = am_flush(e, la, nam, ids_am); if (rc) return rc;
-        HIPCHK(hipStreamSynchronize(la.main));
-    }
-    if (e->prof_on) prof_collect(e);
-    if (steps_done) *steps_done = done_fm > done_am ? done_fm : done_am;
-    return 0;
-}
-
 static int run_steps_am(nrsc5hip_engine *e, int n, const int *ids_dev, int max_steps, int check_every, int *steps_done)
 {
-    return run_steps_mixed(e, 0, nullptr, 1, n, ids_dev, check_every, max_steps, steps_done);
+    nrsc5hip_engine::Lane &ln = e->lanes[0];
+    const bool pipe = e->cfg.p1_async != 0;
+    int done = 0;
+    while (done < max_steps) {
+        HIPCHK(hipMemsetAsync(ln.counters_dev, 0, 4 * sizeof(int), ln.main));
+        int burst = 0;
+        for (; burst < check_every && done + burst < max_steps; burst++) {
+            const long long window = ln.am_step_count / 8;
+            const int parity = pipe ? (int)(window % NWIN) : -1, lane = (int)(window % e->naux_am);
+            if (pipe && (ln.am_step_count % 8) == 0 && ln.am_decoded_pending[parity]) {
+                HIPCHK(hipStreamWaitEvent(ln.main, ln.ev_decoded[parity], 0));   // the window that used these buffers NWIN windows ago
+                ln.am_decoded_pending[parity] = false;
+            }
+            { ProfScope p(e, NRSC5HIP_PROF_AM, ln.main); launch_am_step(e->tb, ln.db, n, ids_dev, ln.main, e->cfg.l2_feedback, parity); }
+            if (pipe && (ln.am_step_count % 8) == 7) {
+                hipStream_t ax = ln.aux[lane];
+                HIPCHK(hipEventRecord(ln.ev_window[parity], ln.main));
+                HIPCHK(hipStreamWaitEvent(ax, ln.ev_window[parity], 0));
+                { ProfScope p(e, NRSC5HIP_PROF_AM, ax); launch_am_decode(e->tb, ln.db, n, ids_dev, parity, lane, e->cfg.l2_feedback, ax); }
+                HIPCHK(hipEventRecord(ln.ev_decoded[parity], ax));
+                ln.am_decoded_pending[parity] = true;
+            }
+            ln.am_step_count++;
+        }
+        HIPCHK(hipMemcpyAsync(ln.counters_host, ln.counters_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, ln.main));
+        HIPCHK(hipStreamSynchronize(ln.main));
+        HIPCHK(hipGetLastError());
+        if (ln.counters_host[0] == 0) break;
+        done += burst;
+    }
+    { int rc = am_flush(e, ln, n, ids_dev); if (rc) return rc; }
+    HIPCHK(hipStreamSynchronize(ln.main));
+    if (e->prof_on) prof_collect(e);
+    if (steps_done) *steps_done = done;
+    return 0;
 }
 
 // ---- FIFO space management (streaming) -----------------------------------------------------------------
@@ -672,7 +638,6 @@ __global__ void k_compact(DevBuffers db, int s)
 static int ensure_space(nrsc5hip_engine *e, int s, long long incoming)
 {
     if (e->wr_host[s] - e->base_host[s] + incoming <= e->db.q15_cap) return 0;
-    if (e->mode_host[s] == MODE_AM) HIPCHK(hipStreamSynchronize(e->lanes[e->nlanes].main));   // the compaction below runs on e->main
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, e->main, e->db, s);
     long long base = 0;
     HIPCHK(hipMemcpyAsync(&base, (const char *)(e->db.state + s) + offsetof(StreamState, base), sizeof(long long), hipMemcpyDeviceToHost, e->main));
@@ -691,20 +656,19 @@ static int push_common(nrsc5hip_engine *e, int s, const void *host, size_t nbyte
     const size_t unit = 4;                                     // cu8: 2 complex samples; cs16: 1 complex sample
     if (nbytes_total % unit) FAIL(NRSC5HIP_EINVAL, "length must be a multiple of %zu bytes", unit);
     const bool am = e->mode_host[s] == MODE_AM;
-    hipStream_t q = am ? e->lanes[e->nlanes].main : e->main;   // AM streams live on the AM lane's stream
     while (nbytes_total) {
         const size_t chunk = nbytes_total > e->stage_bytes ? e->stage_bytes : nbytes_total;
         long long nq15 = (long long)chunk / 4;                  // FM cu8: 2:1; cs16: one complex sample per 4 bytes
         if (am && cu8) nq15 = (e->raw_host[s] + (long long)chunk / 2) / 32 - e->raw_host[s] / 32;
         if ((rc = ensure_space(e, s, nq15))) return rc;
         const unsigned count = cu8 ? (unsigned)chunk : (unsigned)(chunk / 2);
-        HIPCHK(hipMemcpyAsync(e->stage_dev, src, chunk, hipMemcpyHostToDevice, q));
-        HIPCHK(hipMemcpyAsync(e->ids_dev, &s, sizeof(int), hipMemcpyHostToDevice, q));
-        HIPCHK(hipMemcpyAsync(e->nbytes_dev, &count, sizeof(unsigned), hipMemcpyHostToDevice, q));
-        HIPCHK(hipStreamSynchronize(q));                 // &s / &count are stack temporaries
-        if (cu8 && am) { launch_am_decimate_cu8(e->tb, e->db, 1, e->ids_dev, e->stage_dev, 0, e->nbytes_dev, count, q); e->raw_host[s] += (long long)chunk / 2; }
+        HIPCHK(hipMemcpyAsync(e->stage_dev, src, chunk, hipMemcpyHostToDevice, e->main));
+        HIPCHK(hipMemcpyAsync(e->ids_dev, &s, sizeof(int), hipMemcpyHostToDevice, e->main));
+        HIPCHK(hipMemcpyAsync(e->nbytes_dev, &count, sizeof(unsigned), hipMemcpyHostToDevice, e->main));
+        HIPCHK(hipStreamSynchronize(e->main));                 // &s / &count are stack temporaries
+        if (cu8 && am) { launch_am_decimate_cu8(e->tb, e->db, 1, e->ids_dev, e->stage_dev, 0, e->nbytes_dev, count, e->main); e->raw_host[s] += (long long)chunk / 2; }
         else if (cu8) launch_decimate_fm_cu8(e->tb, e->db, 1, e->ids_dev, e->stage_dev, 0, e->nbytes_dev, count, e->main);
-        else launch_append_cs16(e->db, 1, e->ids_dev, (const int16_t *)e->stage_dev, 0, e->nbytes_dev, count, q);
+        else launch_append_cs16(e->db, 1, e->ids_dev, (const int16_t *)e->stage_dev, 0, e->nbytes_dev, count, e->main);
         e->wr_host[s] += nq15;
         int steps = 0;
         if (am) { if ((rc = run_steps_am(e, 1, e->ids_dev, 1 << 30, 1, &steps))) return rc; }
@@ -756,7 +720,7 @@ __global__ void k_force_none(DevBuffers db, int s) { db.state[s].sync_state = SY
 extern "C" int nrsc5hip_force_resync(nrsc5hip_engine *e, int stream)
 {
     int rc = check_stream(e, stream); if (rc) return rc;
-    hipLaunchKernelGGL(k_force_none, dim3(1), dim3(1), 0, e->mode_host[stream] == MODE_AM ? e->lanes[e->nlanes].main : e->main, e->db, stream);
+    hipLaunchKernelGGL(k_force_none, dim3(1), dim3(1), 0, e->main, e->db, stream);
     for (int l = 0; l < e->nlanes; l++) { e->lanes[l].acq_needed = true; e->lanes[l].px_needed = true; }
     HIPCHK(hipGetLastError());
     return 0;
@@ -795,7 +759,7 @@ extern "C" int nrsc5hip_batch_append_cu8(nrsc5hip_engine *e, int nstreams, const
                 if (e->wr_host[s] - e->base_host[s] + nout > e->db.q15_cap) FAIL(NRSC5HIP_EOVERFLOW, "stream %d: q15_capacity %lld too small for this batch", s, e->db.q15_cap);
                 if (nbytes[k] > mx) mx = nbytes[k];
             }
-            { hipStream_t q = e->lanes[e->nlanes].main; ProfScope p(e, NRSC5HIP_PROF_DECIMATE, q); launch_am_decimate_cu8(e->tb, e->db, nstreams, ids_dev, dev_iq, stride_bytes, e->nbytes_dev, mx, q); HIPCHK(hipStreamSynchronize(q)); }
+            { ProfScope p(e, NRSC5HIP_PROF_DECIMATE, e->main); launch_am_decimate_cu8(e->tb, e->db, nstreams, ids_dev, dev_iq, stride_bytes, e->nbytes_dev, mx, e->main); }
             for (int k = 0; k < nstreams; k++) {
                 const int s = stream_ids ? stream_ids[k] : k;
                 e->wr_host[s] += (e->raw_host[s] + nbytes[k] / 2) / 32 - e->raw_host[s] / 32;
@@ -867,12 +831,7 @@ extern "C" int nrsc5hip_batch_append_cs16(nrsc5hip_engine *e, int nstreams, cons
             FAIL(NRSC5HIP_EOVERFLOW, "stream %d: q15_capacity %lld too small for this batch", s, e->db.q15_cap);
         if (nelems[k] > mx) mx = nelems[k];
     }
-    {
-        const bool am = e->mode_host[stream_ids ? stream_ids[0] : 0] == MODE_AM;
-        hipStream_t q = am ? e->lanes[e->nlanes].main : e->main;
-        launch_append_cs16(e->db, nstreams, ids_dev, dev_iq, stride_elems, e->nbytes_dev, mx, q);
-        if (am) HIPCHK(hipStreamSynchronize(q));                // e->ids_dev / e->nbytes_dev are shared scratch
-    }
+    launch_append_cs16(e->db, nstreams, ids_dev, dev_iq, stride_elems, e->nbytes_dev, mx, e->main);
     for (int k = 0; k < nstreams; k++) e->wr_host[stream_ids ? stream_ids[k] : k] += nelems[k] / 2;
     HIPCHK(hipGetLastError());
     return 0;
@@ -882,7 +841,7 @@ extern "C" int nrsc5hip_batch_process(nrsc5hip_engine *e, int nstreams, const in
 {
     if (!e) FAIL(NRSC5HIP_EINVAL, "null engine");
     if (nstreams < 1 || nstreams > e->cfg.max_streams) FAIL(NRSC5HIP_EINVAL, "nstreams %d out of range", nstreams);
-    {   // AM streams advance through their own fused block kernel on the AM lane; a mixed list runs both side by side
+    {   // AM streams advance through their own fused block kernel; split a mixed list by mode
         std::vector<int> fm, am;
         for (int k = 0; k < nstreams; k++) {
             const int s = stream_ids ? stream_ids[k] : k;
@@ -890,11 +849,13 @@ extern "C" int nrsc5hip_batch_process(nrsc5hip_engine *e, int nstreams, const in
             (e->mode_host[s] == MODE_AM ? am : fm).push_back(s);
         }
         if (!am.empty()) {
-            HIPCHK(hipStreamSynchronize(e->main));
-            if (!fm.empty()) HIPCHK(hipMemcpy(e->ids_dev, fm.data(), fm.size() * sizeof(int), hipMemcpyHostToDevice));
-            HIPCHK(hipMemcpy(e->ids_dev + fm.size(), am.data(), am.size() * sizeof(int), hipMemcpyHostToDevice));
-            return run_steps_mixed(e, (int)fm.size(), e->ids_dev, e->cfg.p1_async ? 16 : 8, (int)am.size(), e->ids_dev + fm.size(), 8,
-                                   max_steps > 0 ? max_steps : (1 << 30), steps_done);
+            int done_am = 0, done_fm = 0;
+            HIPCHK(hipMemcpy(e->ids_dev, am.data(), am.size() * sizeof(int), hipMemcpyHostToDevice));
+            int rc = run_steps_am(e, (int)am.size(), e->ids_dev, max_steps > 0 ? max_steps : (1 << 30), 8, &done_am);
+            if (rc) return rc;
+            if (!fm.empty()) { rc = nrsc5hip_batch_process(e, (int)fm.size(), fm.data(), max_steps, &done_fm); if (rc) return rc; }
+            if (steps_done) *steps_done = done_am > done_fm ? done_am : done_fm;
+            return 0;
         }
     }
     const int *ids_dev; int rc = upload_ids(e, nstreams, stream_ids, nullptr, &ids_dev); if (rc) return rc;
@@ -933,7 +894,6 @@ extern "C" int nrsc5hip_drain(nrsc5hip_engine *e, int stream, nrsc5hip_record *o
     int rc = check_stream(e, stream); if (rc) return rc;
     if (!out || !n_out) FAIL(NRSC5HIP_EINVAL, "null argument");
     HIPCHK(hipStreamSynchronize(e->main));
-    HIPCHK(hipStreamSynchronize(e->lanes[e->nlanes].main));
     int nb = 0;
     if ((rc = fetch_nblocks(e, stream, &nb))) return rc;
     int avail = nb - e->drained[stream];
@@ -1164,7 +1124,7 @@ extern "C" int nrsc5hip_reset_all(nrsc5hip_engine *e)
     std::fill(e->drained.begin(), e->drained.end(), 0);
     HIPCHK(hipMemset(e->db.pids_rec, 0xff, S * NWIN * 16 * sizeof(int)));
     HIPCHK(hipMemset(e->db.px_job, 0xff, S * NWIN * 16 * sizeof(PxJob)));
-    for (int l = 0; l <= e->nlanes; l++) {
+    for (int l = 0; l < e->nlanes; l++) {
         e->lanes[l].acq_needed = true; e->lanes[l].px_needed = true; e->lanes[l].step_count = 0; e->lanes[l].am_step_count = 0;
         for (int k = 0; k < NWIN; k++) e->lanes[l].am_decoded_pending[k] = false;
         for (int k = 0; k < NWIN; k++) e->lanes[l].decoded_pending[k] = false;
@@ -1292,7 +1252,6 @@ extern "C" int nrsc5hip_batch_fetch_view(nrsc5hip_engine *e, int nstreams, const
         HIPCHK(hipHostMalloc((void **)&e->nblocks_host, S * sizeof(int), hipHostMallocDefault));
     }
     HIPCHK(hipStreamSynchronize(e->main));
-    HIPCHK(hipStreamSynchronize(e->lanes[e->nlanes].main));
     HIPCHK(hipMemcpy2DAsync(e->nblocks_host, sizeof(int), (const char *)e->db.state + offsetof(StreamState, nblocks), sizeof(StreamState),
                             sizeof(int), nstreams, hipMemcpyDeviceToHost, e->main));
     HIPCHK(hipMemcpyAsync(e->rec_host, e->db.records, (size_t)nstreams * e->db.rec_cap * sizeof(BlockRecord), hipMemcpyDeviceToHost, e->main));
