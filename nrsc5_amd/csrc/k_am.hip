@@ -233,7 +233,8 @@ __device__ inline void viterbi_k9_block(const int8_t *coded, int len, unsigned g
 // Decisions per step pair: one byte per lane -- bit i0 * 2 + xh for step t (1 = survivor from old state 4L + 2 xh + 1),
 // bit 4 + i1 * 2 + i0 for step t+1 (1 = survivor from xh = 1) -- so a step pair of the traceback needs ONE byte, the one
 // of lane n & 63: prev = ((n & 63) << 2) | xh << 1 | xl, read at a wave-uniform address from a chunk staged in LDS.
-struct K9WSmem { int metric[2][256]; unsigned long long decbuf[32 * 8]; };   // 4 KB per frame in flight: up to 27 decode workgroups share a CU with k_am_block's 70 KB tile
+struct K9WSmem { int metric[2][256]; };   // 2 KB per frame in flight (the traceback stages decisions in the same 2 KB): 32 decode
+                                         // workgroups per CU still leave room for k_am_block's 70 KB tile
 
 __device__ inline int k9_sign_word(unsigned b, unsigned g0, unsigned g1, unsigned g2)
 {
@@ -287,14 +288,9 @@ __device__ inline void viterbi_k9_wave(const int8_t *coded, int len, unsigned g0
             // this lane's eight decisions of the step pair in one byte: bit i0*2+xh for step t, bit 4+i1*2+i0 for step t+1
             const unsigned dbyte = (t00 ? 0u : 1u) | (t01 ? 0u : 2u) | (t10 ? 0u : 4u) | (t11 ? 0u : 8u)
                                  | (r00 ? 0u : 16u) | (r01 ? 0u : 32u) | (r10 ? 0u : 64u) | (r11 ? 0u : 128u);
-            ((uint8_t *)sm.decbuf)[64 * (s & 31) + lane] = (uint8_t)dbyte;
+            ((uint8_t *)dec)[(size_t)(p0 + s) * 64 + lane] = (uint8_t)dbyte;     // one 64-byte row per step pair, fire and forget
             cur ^= 1;
             WAVE_LDS_SYNC();
-            if ((s & 31) == 31 || s == np - 1) {               // 32 step pairs of decisions go out as coalesced 512-byte rows
-                const int first = s & ~31, cnt = s - first + 1;
-                for (int k = lane; k < 8 * cnt; k += 64) dec[(size_t)(p0 + first) * 8 + k] = sm.decbuf[k];
-                WAVE_LDS_SYNC();
-            }
         }
     }
     // end state: first maximum in state order (conv_dec.c:310-318)
@@ -315,11 +311,12 @@ __device__ inline void viterbi_k9_wave(const int8_t *coded, int len, unsigned g0
     __syncthreads();
     // traceback, two steps per iteration; 32 step pairs of decisions at a time are staged in LDS and looked up at a
     // wave-uniform address
-    const uint8_t *db8 = (const uint8_t *)sm.decbuf;
+    unsigned long long *stage = (unsigned long long *)&sm.metric[0][0];      // the metrics are dead: 2 KB = 32 step pairs of decisions
+    const uint8_t *db8 = (const uint8_t *)stage;
     const int ntb = (npairs + 31) >> 5;
     for (int c = ((phases & 2) ? ntb - 1 : -1); c >= 0; c--) {
         const int p0 = c << 5, np = min(32, npairs - p0);
-        for (int k = lane; k < 8 * np; k += 64) sm.decbuf[k] = dec[(size_t)p0 * 8 + k];
+        for (int k = lane; k < 8 * np; k += 64) stage[k] = dec[(size_t)p0 * 8 + k];
         WAVE_LDS_SYNC();
         unsigned long long obits = 0;                           // output bits of steps 2 p0 .. 2 p0 + 63
         for (int s = np - 1; s >= 0; s--) {
