@@ -12,6 +12,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the engine drives 1 main + up to 5 decode streams next to torch's: give each its own hardware queue (read at HIP init)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 FS = 1488375.0
 
 
