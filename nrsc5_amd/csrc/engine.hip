@@ -365,7 +365,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             if (hipMemset(db.px_mem, 0, S * 2 * PX_MEM) != hipSuccess || hipMemset(db.px_pair, 0, S * 4 * PX_MAX) != hipSuccess ||
                 hipMemset(db.px_job, 0xff, S * NWIN * 16 * sizeof(PxJob)) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "PX state init failed"); break; }
         }
-        db.am = nullptr; db.am_sym = nullptr; db.am_q = nullptr; db.am_vit = nullptr; db.am_dec = nullptr; db.am_job = nullptr; db.am_ber = nullptr; db.am_nvit = 1;
+        db.am = nullptr; db.am_sym = nullptr; db.am_q = nullptr; db.am_vit = nullptr; db.am_dec = nullptr; db.am_job = nullptr; db.am_ber = nullptr; db.am_pids_stage = nullptr; db.am_pids_rec = nullptr; db.am_nvit = 1;
         if (cfg->am_enable) {
             if ((rc = dev_alloc(e, &db.am, S))) break;
             if ((rc = dev_alloc(e, &db.am_sym, S * 4 * AM_SYMS))) break;
@@ -376,6 +376,9 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             if ((rc = dev_alloc(e, &db.am_dec, ndec * S * (size_t)(8 * AM_DEC_P1 + AM_DEC_P3)))) break;
             if ((rc = dev_alloc(e, &db.am_job, S * NWIN))) break;
             if ((rc = dev_alloc(e, &db.am_ber, S * (size_t)cfg->p1_slots))) break;
+            if ((rc = dev_alloc(e, &db.am_pids_stage, S * NWIN * 8 * (size_t)(3 * PIDS_LEN)))) break;
+            if ((rc = dev_alloc(e, &db.am_pids_rec, S * NWIN * 8))) break;
+            if (hipMemset(db.am_pids_rec, 0xff, S * NWIN * 8 * sizeof(int)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
             if (hipMemset(db.am_job, 0, S * NWIN * sizeof(AmJob)) != hipSuccess || hipMemset(db.am_ber, 0, S * (size_t)cfg->p1_slots * sizeof(float)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
             std::vector<AmStream> ainit(S);
             for (size_t k = 0; k < S; k++) init_am_state(ainit[k]);
@@ -593,7 +596,7 @@ static int run_steps_am(nrsc5hip_engine *e, int n, const int *ids_dev, int max_s
                 HIPCHK(hipStreamWaitEvent(ln.main, ln.ev_decoded[parity], 0));   // the window that used these buffers NWIN windows ago
                 ln.am_decoded_pending[parity] = false;
             }
-            { ProfScope p(e, NRSC5HIP_PROF_AM, ln.main); launch_am_step(e->tb, ln.db, n, ids_dev, ln.main, e->cfg.l2_feedback, parity); }
+            { ProfScope p(e, NRSC5HIP_PROF_AM, ln.main); launch_am_step(e->tb, ln.db, n, ids_dev, ln.main, e->cfg.l2_feedback, parity, (int)(ln.am_step_count % 8)); }
             if (pipe && (ln.am_step_count % 8) == 7) {
                 hipStream_t ax = ln.aux[lane];
                 HIPCHK(hipEventRecord(ln.ev_window[parity], ln.main));
@@ -698,6 +701,7 @@ extern "C" int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream)
         AmStream am; init_am_state(am);
         HIPCHK(hipMemcpy(e->db.am + stream, &am, sizeof(am), hipMemcpyHostToDevice));
         HIPCHK(hipMemset(e->db.am_job + (size_t)stream * NWIN, 0, NWIN * sizeof(AmJob)));
+        HIPCHK(hipMemset(e->db.am_pids_rec + (size_t)stream * NWIN * 8, 0xff, NWIN * 8 * sizeof(int)));
     }
     e->wr_host[stream] = 0; e->base_host[stream] = 0; e->drained[stream] = 0; e->raw_host[stream] = 0;
     for (int l = 0; l < e->nlanes; l++) { e->lanes[l].acq_needed = true; e->lanes[l].px_needed = true; }
@@ -1117,6 +1121,7 @@ extern "C" int nrsc5hip_reset_all(nrsc5hip_engine *e)
         for (size_t s = 0; s < S; s++) init_am_state(ainit[s]);
         HIPCHK(hipMemcpy(e->db.am, ainit.data(), S * sizeof(AmStream), hipMemcpyHostToDevice));
         HIPCHK(hipMemset(e->db.am_job, 0, S * NWIN * sizeof(AmJob)));
+        HIPCHK(hipMemset(e->db.am_pids_rec, 0xff, S * NWIN * 8 * sizeof(int)));
     }
     std::fill(e->raw_host.begin(), e->raw_host.end(), 0);
     std::fill(e->wr_host.begin(), e->wr_host.end(), 0);

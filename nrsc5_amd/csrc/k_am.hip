@@ -466,7 +466,7 @@ __device__ inline void am_fft_all(AmBlockSmem &sm)
 // spectrum bin `off` relative to the carrier (fftshift folded into the index), symbol n
 __device__ inline float2 &am_bin(AmBlockSmem &sm, int off, int n) { return sm.X[n * AM_FFT + (off & 255)]; }
 
-__global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, const int *ids, int pipeline)
+__global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, const int *ids, int pipeline, int parity, int slot)
 {
     wave_set_priority_high();                                  // block-step chain = critical path; the decode waves run at priority 0
     const int s = stream_of(ids, blockIdx.x);
@@ -775,13 +775,23 @@ __global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, c
             sm.pids_coded[i * 24 + iu_pos[j]] = iu ? 1 : -1;
         }
         __syncthreads();
-        K9Smem &k9 = *(K9Smem *)sm.X;
-        unsigned long long *pids_dec = (unsigned long long *)((uint8_t *)sm.X + sizeof(K9Smem));
-        viterbi_k9_block(sm.pids_coded, PIDS_LEN, GEN_E2_0, GEN_E2_1, GEN_E2_2, pids_dec, sm.pids_out, k9);
+        if (pipeline) {
+            // window pipeline: the 144-step PIDS trellis leaves the step chain -- stage its input for k_am_decode
+            int8_t *stage = db.am_pids_stage + (((size_t)s * NWIN + parity) * 8 + slot) * (3 * PIDS_LEN);
+            if (tid < 3 * PIDS_LEN) stage[tid] = sm.pids_coded[tid];
+            if (tid == 0) db.am_pids_rec[((size_t)s * NWIN + parity) * 8 + slot] = st.nblocks % db.rec_cap;
+        } else {
+            K9Smem &k9 = *(K9Smem *)sm.X;
+            unsigned long long *pids_dec = (unsigned long long *)((uint8_t *)sm.X + sizeof(K9Smem));
+            viterbi_k9_block(sm.pids_coded, PIDS_LEN, GEN_E2_0, GEN_E2_1, GEN_E2_2, pids_dec, sm.pids_out, k9);
+        }
         if (tid == 0) {
-            for (int w = 0; w < 3; w++) rec.pids[w] = sm.pids_out[w] ^ tb.scr_pids[w];
-            rec.pids[2] &= 0xffffu;
-            rec.flags |= REC_PIDS | (pids_crc_ok(rec.pids) ? (uint32_t)REC_PIDS_CRC : 0u);
+            if (!pipeline) {
+                for (int w = 0; w < 3; w++) rec.pids[w] = sm.pids_out[w] ^ tb.scr_pids[w];
+                rec.pids[2] &= 0xffffu;
+                rec.flags |= pids_crc_ok(rec.pids) ? (uint32_t)REC_PIDS_CRC : 0u;
+            }
+            rec.flags |= REC_PIDS;
             rec.bc_decoded = bc;
             // hand this block to the P1 / P3 decoders (decode_process_p1_p3_am runs next, in k_am_viterbi)
             am.dec_bc = bc; am.dec_record = st.nblocks % db.rec_cap; am.dec_rdbi = am.rdbi; am.dec_psmi = st.psmi;
@@ -931,11 +941,29 @@ __global__ __launch_bounds__(1024) void k_am_interleave(DevTables tb, DevBuffers
 // ---- window pipeline: all nine frames of an L1 frame decode concurrently on a decode stream ---------------------------
 __global__ __launch_bounds__(64) void k_am_decode(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id, int l2_feedback)
 {
-    const int s = stream_of(ids, blockIdx.y), role = blockIdx.x;           // 0..7: P1 frame of that block, 8: P3
+    const int s = stream_of(ids, blockIdx.y), role = blockIdx.x;           // 0..7: P1 frame of that block, 8: P3, 9..16: PIDS frames
+    __shared__ K9WSmem k9;
+    if (role >= 9) {
+        // decode_process_pids_am's trellis (decode.c:502-504) for the block processed in step `role - 9` of this window
+        int *recp = db.am_pids_rec + ((size_t)s * NWIN + parity) * 8 + (role - 9);
+        const int r = *recp;
+        if (r < 0) return;                                                 // wave-uniform
+        __shared__ uint32_t pout[4];
+        const int8_t *stage = db.am_pids_stage + (((size_t)s * NWIN + parity) * 8 + (role - 9)) * (3 * PIDS_LEN);
+        unsigned long long *pdec = db.am_dec + ((size_t)lane_id * db.nstreams_alloc + s) * (size_t)(8 * AM_DEC_P1 + AM_DEC_P3)
+                                 + (size_t)8 * AM_DEC_P1 + AM_DEC_P3 - (size_t)(9 - (role - 9)) * 4 * (PIDS_LEN + 64);   // tail of the P3 scratch: its frame is shorter than AM_P3_LEN_MA3 + 64 only by the slack reserved here
+        viterbi_k9_wave(stage, PIDS_LEN, GEN_E2_0, GEN_E2_1, GEN_E2_2, pdec, pout, k9);
+        if (threadIdx.x == 0) {
+            BlockRecord &rec = db.records[(size_t)s * db.rec_cap + r];
+            rec.pids[0] = pout[0] ^ tb.scr_pids[0]; rec.pids[1] = pout[1] ^ tb.scr_pids[1]; rec.pids[2] = (pout[2] ^ tb.scr_pids[2]) & 0xffffu;
+            if (pids_crc_ok(rec.pids)) atomicOr(&rec.flags, (uint32_t)REC_PIDS_CRC);
+            *recp = -1;
+        }
+        return;
+    }
     AmJob &job = db.am_job[(size_t)s * NWIN + parity];
     if (!job.valid) return;                                                // wave-uniform
     if (role == 8 && job.rdbi) return;
-    __shared__ K9WSmem k9;
     __shared__ int red[4];
     const bool ma3 = job.psmi == AM_MA3;
     const int8_t *vit = db.am_vit + ((size_t)s * db.am_nvit + parity) * 2 * AM_VIT;
@@ -986,14 +1014,14 @@ __global__ __launch_bounds__(64) void k_am_decode(DevTables tb, DevBuffers db, c
 
 void launch_am_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, int l2_feedback, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_am_decode, dim3(9, nstreams), dim3(64), 0, st, tb, db, stream_ids, parity, lane_id, l2_feedback);
+    hipLaunchKernelGGL(k_am_decode, dim3(17, nstreams), dim3(64), 0, st, tb, db, stream_ids, parity, lane_id, l2_feedback);
 }
 
-void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int l2_feedback, int pipeline_parity)
+void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int l2_feedback, int pipeline_parity, int slot)
 {
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_am_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AmBlockSmem)); attr_set = true; }
-    hipLaunchKernelGGL(k_am_block, dim3(nstreams), dim3(256), sizeof(AmBlockSmem), st, tb, db, stream_ids, pipeline_parity >= 0 ? 1 : 0);
+    hipLaunchKernelGGL(k_am_block, dim3(nstreams), dim3(256), sizeof(AmBlockSmem), st, tb, db, stream_ids, pipeline_parity >= 0 ? 1 : 0, pipeline_parity, slot);
     if (pipeline_parity < 0) hipLaunchKernelGGL(k_am_viterbi, dim3(2, nstreams), dim3(64), 0, st, tb, db, stream_ids, l2_feedback);
     hipLaunchKernelGGL(k_am_interleave, dim3(nstreams), dim3(1024), 0, st, tb, db, stream_ids, pipeline_parity);
 }

@@ -62,6 +62,8 @@ struct DevBuffers {
     unsigned long long *am_dec;      // [am_ndec][S][8 * AM_DEC_P1 + AM_DEC_P3]  survivor decisions (one set per decode stream)
     AmJob *am_job;                   // [S][NWIN]
     float *am_ber;                   // [S][p1_slots]  window pipeline: BER of the L1 frame in each ring slot
+    int8_t *am_pids_stage;           // [S][NWIN][8][240]  window pipeline: PIDS trellis inputs awaiting k_am_decode
+    int *am_pids_rec;                // [S][NWIN][8]       record index of each staged PIDS frame, -1 = empty
 };
 
 // ---- K1 -------------------------------------------------------------------------------
@@ -89,7 +91,7 @@ void launch_am_decimate_cu8(const DevTables &tb, const DevBuffers &db, int nstre
                             const uint8_t *iq_base, long long iq_stride, const unsigned *nbytes, unsigned max_nbytes, hipStream_t st);
 // one block step: acquire (or track) -> 2 x 32 FFT-256 -> sync_process_am -> PIDS; then this block's P1 / P3 decodes
 // and, after block 7, the bit de-interleaver of the finished L1 frame
-void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int l2_feedback = 0, int pipeline_parity = -1);
+void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int l2_feedback = 0, int pipeline_parity = -1, int slot = 0);
 // entry of the AM de-interleave tables: x = cell | bit << 13 | matrix << 16 | delayed << 18 | punctured << 19 | queue << 20, y = index in the delay line
 constexpr unsigned AMT_DELAYED = 1u << 18, AMT_PUNCT = 1u << 19;
 // window pipeline: the 8 P1 frames and the P3 frame of every L1 frame whose de-interleave happened in window `parity`

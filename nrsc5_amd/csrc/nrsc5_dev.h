@@ -54,7 +54,7 @@ constexpr int AM_VIT = 3 * AM_P3_LEN_MA3;       // 90000: depunctured trellis in
 constexpr int AM_P1_WORDS = 118;                // packed words per 3750-bit P1 frame
 constexpr int AM_P3_WORD0 = 8 * AM_P1_WORDS;    // 944: first word of the P3 frame inside an AM frame slot
 constexpr int AM_DEC_P1 = (AM_P1_LEN + 64) * 4; // survivor-decision words (4 x u64 per step)
-constexpr int AM_DEC_P3 = (AM_P3_LEN_MA3 + 64) * 4;
+constexpr int AM_DEC_P3 = (AM_P3_LEN_MA3 + 64) * 4 + 9 * 4 * (PIDS_LEN + 64);   // + scratch for the window's 8 deferred PIDS decodes
 
 enum { MODE_FM = 0, MODE_AM = 1 };                        // nrsc5.h:70-74
 enum { SYNC_NONE = 0, SYNC_COARSE = 1, SYNC_FINE = 2 };   // input.h:18
