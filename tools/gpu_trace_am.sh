@@ -2,7 +2,7 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 mkdir -p gpurun_out
-cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/trace -o tr -- python $GRAFT_REPO_ROOT/tools/gpu_am_bench.py --streams 256 --frames 41 --fmt cs16 --steps 1 --warmup 1 > $GRAFT_REPO_ROOT/gpurun_out/trace.log 2>&1
+cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/trace -o tr -- env GPU_MAX_HW_QUEUES=8 python $GRAFT_REPO_ROOT/tools/gpu_am_bench.py --streams 256 --frames 41 --fmt cs16 --steps 1 --warmup 1 > $GRAFT_REPO_ROOT/gpurun_out/trace.log 2>&1
 cd $GRAFT_REPO_ROOT; python - <<'PY'
 import csv, glob, gzip
 f = glob.glob("gpurun_out/trace/*kernel_trace.csv")[0]
