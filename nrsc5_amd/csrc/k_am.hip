@@ -900,50 +900,40 @@ __device__ inline int8_t am_deint_one(uint2 e, const uint8_t *sym, uint8_t *q, i
     return bit ? 1 : -1;
 }
 
-constexpr int AMI_BLOCKS = 16;          // workgroups per stream: 162 000 table look-ups are latency-bound, spread them
-
 __global__ __launch_bounds__(1024) void k_am_interleave(DevTables tb, DevBuffers db, const int *ids, int parity)
 {
     wave_set_priority_high();
-    const int s = stream_of(ids, blockIdx.y);
+    const int s = stream_of(ids, blockIdx.x);
     const StreamState &st = db.state[s];
-    const AmStream &am = db.am[s];
+    AmStream &am = db.am[s];
     if (!st.active || am.dec_bc != 7) return;                  // block-uniform
     const bool ma3 = am.dec_psmi == AM_MA3;
-    const int gtid = blockIdx.x * 1024 + threadIdx.x, gstride = AMI_BLOCKS * 1024;
+    const int tid = threadIdx.x;
     const int vslot = parity < 0 ? 0 : parity;                 // window pipeline: one set of trellis inputs per window in flight
-    const uint8_t *sym = db.am_sym + (size_t)s * 4 * AM_SYMS;  // [pl, pu, s, t][8 blocks][32][25]
-    uint8_t *q = db.am_q + (size_t)s * 4 * 3 * 18000;         // [ml, mu, eml, emu][3][18000]
-    const int head = am.q_head;
-    int8_t *v1 = db.am_vit + ((size_t)s * db.am_nvit + vslot) * 2 * AM_VIT, *v3 = v1 + AM_VIT;
-    for (int i = gtid; i < AM_VIT; i += gstride) v1[i] = am_deint_one(tb.am_deint_p1[i], sym, q, head);
-    if (!ma3) for (int i = gtid; i < 3 * AM_P3_LEN_MA1; i += gstride) v3[i] = am_deint_one(tb.am_deint_p3_ma1[i], sym, q, head);
-    else for (int i = gtid; i < AM_VIT; i += gstride) v3[i] = am_deint_one(tb.am_deint_p3_ma3[i], sym, q, head);
-}
-
-// bookkeeping of interleaver_ma1 / decode_process_p1_p3_am once all of a stream's workgroups above are done (next kernel)
-__global__ void k_am_interleave_commit(DevBuffers db, const int *ids, int nstreams, int parity)
-{
-    const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sidx >= nstreams) return;
-    const int s = stream_of(ids, sidx);
-    StreamState &st = db.state[s];
-    AmStream &am = db.am[s];
-    if (!st.active || am.dec_bc != 7) return;
-    const bool ma3 = am.dec_psmi == AM_MA3;
-    if (parity < 0 && am.am_diversity_wait == 0) {             // in-order mode: nrsc5_report_ber's value (decode.c:545)
+    if (tid == 0 && parity < 0 && am.am_diversity_wait == 0) {
         unsigned total = 8 * (AM_P1_LEN * 12 / 5);
         if (!am.dec_rdbi) total += ma3 ? AM_P3_LEN_MA3 * 12 / 5 : AM_P3_LEN_MA1 * 3 / 2;
         db.records[(size_t)s * db.rec_cap + am.dec_record].ber = (float)am.am_errors / (float)total;
     }
-    am.q_head = (am.q_head + 1) % 3;
-    if (am.am_diversity_wait > 0) am.am_diversity_wait--;
-    if (am.am_diversity_wait == 0) {
-        // the next L1 frame delivers what these trellis inputs decode to: reserve its ring slot now
-        am.next_slot = st.p1_count % db.p1_slots; st.p1_count++;
-        if (parity >= 0) {
-            AmJob &job = db.am_job[(size_t)s * NWIN + parity];
-            job.slot = am.next_slot; job.psmi = am.dec_psmi; job.rdbi = am.dec_rdbi; job.errors = 0; job.done = 0; job.valid = 1;
+    const uint8_t *sym = db.am_sym + (size_t)s * 4 * AM_SYMS;  // [pl, pu, s, t][8 blocks][32][25]
+    uint8_t *q = db.am_q + (size_t)s * 4 * 3 * 18000;         // [ml, mu, eml, emu][3][18000]
+    const int head = am.q_head;
+    int8_t *v1 = db.am_vit + ((size_t)s * db.am_nvit + vslot) * 2 * AM_VIT, *v3 = v1 + AM_VIT;
+    for (int i = tid; i < AM_VIT; i += 1024) v1[i] = am_deint_one(tb.am_deint_p1[i], sym, q, head);
+    if (!ma3) for (int i = tid; i < 3 * AM_P3_LEN_MA1; i += 1024) v3[i] = am_deint_one(tb.am_deint_p3_ma1[i], sym, q, head);
+    else for (int i = tid; i < AM_VIT; i += 1024) v3[i] = am_deint_one(tb.am_deint_p3_ma3[i], sym, q, head);
+    __syncthreads();
+    if (tid == 0) {
+        am.q_head = (head + 1) % 3;
+        if (am.am_diversity_wait > 0) am.am_diversity_wait--;
+        if (am.am_diversity_wait == 0) {
+            // the next L1 frame delivers what these trellis inputs decode to: reserve its ring slot now
+            StreamState &stw = db.state[s];
+            am.next_slot = stw.p1_count % db.p1_slots; stw.p1_count++;
+            if (parity >= 0) {
+                AmJob &job = db.am_job[(size_t)s * NWIN + parity];
+                job.slot = am.next_slot; job.psmi = am.dec_psmi; job.rdbi = am.dec_rdbi; job.errors = 0; job.done = 0; job.valid = 1;
+            }
         }
     }
 }
@@ -1033,8 +1023,7 @@ void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, con
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_am_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AmBlockSmem)); attr_set = true; }
     hipLaunchKernelGGL(k_am_block, dim3(nstreams), dim3(256), sizeof(AmBlockSmem), st, tb, db, stream_ids, pipeline_parity >= 0 ? 1 : 0, pipeline_parity, slot);
     if (pipeline_parity < 0) hipLaunchKernelGGL(k_am_viterbi, dim3(2, nstreams), dim3(64), 0, st, tb, db, stream_ids, l2_feedback);
-    hipLaunchKernelGGL(k_am_interleave, dim3(AMI_BLOCKS, nstreams), dim3(1024), 0, st, tb, db, stream_ids, pipeline_parity);
-    hipLaunchKernelGGL(k_am_interleave_commit, dim3((nstreams + 63) / 64), dim3(64), 0, st, db, stream_ids, nstreams, pipeline_parity);
+    hipLaunchKernelGGL(k_am_interleave, dim3(nstreams), dim3(1024), 0, st, tb, db, stream_ids, pipeline_parity);
 }
 
 // ---- stage-level entry: decode `nframes` independent K=9 frames (parity tests) ------------------------------------
