@@ -919,22 +919,9 @@ __global__ __launch_bounds__(1024) void k_am_interleave(DevTables tb, DevBuffers
     uint8_t *q = db.am_q + (size_t)s * 4 * 3 * 18000;         // [ml, mu, eml, emu][3][18000]
     const int head = am.q_head;
     int8_t *v1 = db.am_vit + ((size_t)s * db.am_nvit + vslot) * 2 * AM_VIT, *v3 = v1 + AM_VIT;
-    // 162 000 dependent look-ups (table -> symbol byte -> delay line) per frame: keep four of them in flight per work-item
-    auto run = [&](const uint2 *tab, int8_t *out, int n) {
-        for (int i0 = tid; i0 < n; i0 += 4096) {
-            uint2 e[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) { const int i = i0 + 1024 * k; e[k] = i < n ? tab[i] : make_uint2(AMT_PUNCT, 0u); }
-            int8_t v[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) v[k] = am_deint_one(e[k], sym, q, head);
-#pragma unroll
-            for (int k = 0; k < 4; k++) { const int i = i0 + 1024 * k; if (i < n) out[i] = v[k]; }
-        }
-    };
-    run(tb.am_deint_p1, v1, AM_VIT);
-    if (!ma3) run(tb.am_deint_p3_ma1, v3, 3 * AM_P3_LEN_MA1);
-    else run(tb.am_deint_p3_ma3, v3, AM_VIT);
+    for (int i = tid; i < AM_VIT; i += 1024) v1[i] = am_deint_one(tb.am_deint_p1[i], sym, q, head);
+    if (!ma3) for (int i = tid; i < 3 * AM_P3_LEN_MA1; i += 1024) v3[i] = am_deint_one(tb.am_deint_p3_ma1[i], sym, q, head);
+    else for (int i = tid; i < AM_VIT; i += 1024) v3[i] = am_deint_one(tb.am_deint_p3_ma3[i], sym, q, head);
     __syncthreads();
     if (tid == 0) {
         am.q_head = (head + 1) % 3;
