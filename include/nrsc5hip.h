@@ -172,6 +172,63 @@ int nrsc5hip_batch_fetch_view(nrsc5hip_engine *e, int nstreams, const nrsc5hip_r
 /* unpack helper (host only) */
 void nrsc5hip_unpack_bits(const uint32_t *words, int nbits, uint8_t *bits);
 
+/* ---- L2 audio transport index (frame.c:516-714), an additive post-pass over decoded frames that are still in HBM ----
+ * frame_push (PCI extraction, bit order) and the audio walk of frame_process run on the device: every audio PDU's
+ * RS(255,247)-corrected header, its locators, header expansion fields, PSD span and the CRC-8 verdict of each packet,
+ * i.e. what frame_process hands to output_align / parse_hdlc / output_push, as offsets into the frame's PDU bytes.
+ * A host that takes the index need not touch the 146 176 bits of a P1 frame one by one (frame.c:688-709). */
+#define NRSC5HIP_L2_MAX_PDUS     16
+#define NRSC5HIP_L2_MAX_PACKETS  64      /* MAX_AUDIO_PACKETS, frame.c:30 */
+#define NRSC5HIP_L2_MAX_BYTES    18269   /* MAX_PDU_LEN, defines.h:63 */
+enum {                                   /* nrsc5hip_l2_frame.status: why the walk ended */
+    NRSC5HIP_L2_END = 0,                 /* ran to the end of the frame (frame.c:525) */
+    NRSC5HIP_L2_NO_AUDIO,                /* !has_audio (frame.c:522) */
+    NRSC5HIP_L2_FIXED_DATA,              /* has_fixed: audio_end depends on process_fixed_data's state (frame.c:433-514); not indexed, the host walks it */
+    NRSC5HIP_L2_HEADER_RS,               /* fix_header failed (frame.c:534-541); lost_sync tells whether this drops the receiver to SYNC_STATE_NONE */
+    NRSC5HIP_L2_BAD_LOCATORS,            /* one of the returns of frame.c:547-556 (typical: zero padding after the last PDU) */
+    NRSC5HIP_L2_TOO_MANY_PDUS,           /* more than NRSC5HIP_L2_MAX_PDUS audio PDUs */
+    NRSC5HIP_L2_HEF_OVERRUN,             /* header expansion runs past la_location: the reference's parse_hdlc length wraps (undefined) */
+    NRSC5HIP_L2_BAD_STREAM,              /* stream_id >= MAX_STREAMS with nop == 0: the reference reads locations[-1] */
+    NRSC5HIP_L2_BAD_LENGTH               /* not one of frame_push's six frame lengths (frame.c:683) */
+};
+typedef struct nrsc5hip_l2_pdu {
+    uint32_t start;                      /* offset of the PDU (its RS parity bytes) in the frame's PDU bytes */
+    uint32_t psd_off; int32_t psd_len;   /* the span frame_process gives parse_hdlc (frame.c:611) */
+    uint32_t audio_off;                  /* first byte of packet 0 = start + la_location + 1 */
+    uint32_t crc_bad_lo, crc_bad_hi;     /* bit j: packet j fails its CRC-8 (PACKET_FLAG_CRC_ERROR, frame.c:616-627) */
+    uint32_t pdu_marker;                 /* HEF class 4 */
+    uint16_t hef_pdu_len;                /* HEF class 1 */
+    uint16_t loc[NRSC5HIP_L2_MAX_PACKETS]; /* offset of packet j's CRC byte; packet j = [loc[j-1] + 1 (audio_off for j = 0), loc[j]) */
+    uint8_t codec_mode, stream_id, pdu_seq, blend_control, per_stream_delay, common_delay, latency, pfirst, plast, seq, nop,
+            hef, la_location;            /* parse_header, frame.c:181-196 */
+    uint8_t rs_corrections;              /* symbols fix_header corrected in this header */
+    uint8_t class_ind, prog_num, access, prog_type, applied_services;   /* parse_hef, frame.c:198-265 */
+    uint8_t elastic_seq;                 /* `seq` of packet 0 in the elastic buffer, frame.c:593 */
+    uint8_t align_offset;                /* output_align's offset, frame.c:595-600 */
+    uint8_t skipped;                     /* stream_id >= MAX_STREAMS: packets skipped as frame.c:559-564 does */
+} nrsc5hip_l2_pdu;
+typedef struct nrsc5hip_l2_frame {
+    uint32_t pci;                        /* protocol control information bits, frame.c:695-699 */
+    uint32_t nbytes;                     /* PDU bytes of the frame */
+    uint32_t n_pdu, status;
+    uint32_t end_offset;                 /* where the walk stopped */
+    uint32_t lost_sync;                  /* 1: frame_process calls input_set_sync_state(SYNC_STATE_NONE) on this frame (frame.c:537-538) */
+    nrsc5hip_l2_pdu pdu[NRSC5HIP_L2_MAX_PDUS];
+} nrsc5hip_l2_frame;
+enum { NRSC5HIP_L2_FM_P1 = 0, NRSC5HIP_L2_FM_PX = 1, NRSC5HIP_L2_AM = 2 };
+typedef struct nrsc5hip_l2_job {
+    int32_t stream, slot;                /* as for nrsc5hip_p1_frame_bits / _px_frame_bits / _am_frame_bits */
+    int32_t kind;                        /* NRSC5HIP_L2_FM_P1 | _FM_PX (which = channel) | _AM (which = 0..7 P1 of that block, 8 = P3) */
+    int32_t which, nbits;                /* nbits: 146176 | 2304 / 4608 | 3750 / 24000 / 30000 */
+} nrsc5hip_l2_job;
+/* Index njobs decoded frames in one launch.  out[njobs]; pdu_bytes may be NULL, else job k's PDU bytes (RS-corrected
+ * headers) go to pdu_bytes + k * stride (stride >= (nbits - pci bits) / 8).  Host buffers. */
+int nrsc5hip_l2_index(nrsc5hip_engine *e, int njobs, const nrsc5hip_l2_job *jobs, nrsc5hip_l2_frame *out,
+                      uint8_t *pdu_bytes, long long stride);
+/* stage-level twin: nframes logical frames given as frame_push takes them (one bit per byte, nbits each) */
+int nrsc5hip_stage_l2_index(nrsc5hip_engine *e, const uint8_t *bits, int nbits, int nframes, nrsc5hip_l2_frame *out,
+                            uint8_t *pdu_bytes, long long stride);
+
 /* ---- stage-level entry points (host buffers): parity tests of single kernels against the oracle ---- */
 int nrsc5hip_stage_halfband_fm_cu8(nrsc5hip_engine *e, const uint8_t *iq, uint32_t nbytes, int16_t *out /* [nbytes/4][2] */);
 int nrsc5hip_stage_fft2048(nrsc5hip_engine *e, const float *in /* [n][2048][2] */, float *out, int n);

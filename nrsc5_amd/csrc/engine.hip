@@ -979,6 +979,70 @@ extern "C" int nrsc5hip_am_frame_bits(nrsc5hip_engine *e, int stream, int slot, 
     return 0;
 }
 
+// ---- L2 audio transport index ---------------------------------------------------------------------------------------
+static int l2_run(nrsc5hip_engine *e, const std::vector<L2Job> &jobs, nrsc5hip_l2_frame *out, uint8_t *pdu_bytes, long long stride)
+{
+    const int n = (int)jobs.size();
+    if (pdu_bytes && stride < L2_MAX_BYTES) {
+        for (const L2Job &j : jobs) if ((j.nbits - 22) / 8 > stride) FAIL(NRSC5HIP_EINVAL, "stride %lld too small for a %d-bit frame", stride, j.nbits);
+    }
+    L2Job *djobs = nullptr; nrsc5hip_l2_frame *dout = nullptr; uint8_t *dbytes = nullptr;
+    HIPCHK(hipMalloc((void **)&djobs, sizeof(L2Job) * n));
+    HIPCHK(hipMalloc((void **)&dout, sizeof(nrsc5hip_l2_frame) * n));
+    if (pdu_bytes) HIPCHK(hipMalloc((void **)&dbytes, (size_t)stride * n));
+    HIPCHK(hipMemcpy(djobs, jobs.data(), sizeof(L2Job) * n, hipMemcpyHostToDevice));
+    launch_l2_index(djobs, n, dout, dbytes, stride, e->main);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(e->main));
+    HIPCHK(hipMemcpy(out, dout, sizeof(nrsc5hip_l2_frame) * n, hipMemcpyDeviceToHost));
+    if (pdu_bytes) HIPCHK(hipMemcpy(pdu_bytes, dbytes, (size_t)stride * n, hipMemcpyDeviceToHost));
+    (void)hipFree(djobs); (void)hipFree(dout); if (dbytes) (void)hipFree(dbytes);
+    return 0;
+}
+
+extern "C" int nrsc5hip_l2_index(nrsc5hip_engine *e, int njobs, const nrsc5hip_l2_job *jobs, nrsc5hip_l2_frame *out, uint8_t *pdu_bytes, long long stride)
+{
+    if (!e || !jobs || !out || njobs < 1) FAIL(NRSC5HIP_EINVAL, "bad argument");
+    std::vector<L2Job> dj((size_t)njobs);
+    for (int k = 0; k < njobs; k++) {
+        const nrsc5hip_l2_job &j = jobs[k];
+        int rc = check_stream(e, j.stream); if (rc) return rc;
+        const uint32_t *words = nullptr;
+        if (j.kind == NRSC5HIP_L2_FM_P1) {
+            if (j.slot < 0 || j.slot >= e->db.p1_slots || j.nbits != P1_LEN) FAIL(NRSC5HIP_EINVAL, "job %d: bad P1 slot / length", k);
+            words = e->db.p1_ring + ((size_t)j.stream * e->db.p1_slots + j.slot) * P1_WORDS;
+        } else if (j.kind == NRSC5HIP_L2_FM_PX) {
+            if (j.slot < 0 || j.slot >= e->db.px_slots || j.which < 0 || j.which > 1 || (j.nbits != 2304 && j.nbits != 4608)) FAIL(NRSC5HIP_EINVAL, "job %d: bad P3/P4 slot / channel / length", k);
+            words = e->db.px_ring + (((size_t)j.stream * e->db.px_slots + j.slot) * 2 + j.which) * PX_WORDS;
+        } else if (j.kind == NRSC5HIP_L2_AM) {
+            const bool p1 = j.which >= 0 && j.which < 8 && j.nbits == AM_P1_LEN;
+            const bool p3 = j.which == 8 && (j.nbits == AM_P3_LEN_MA1 || j.nbits == AM_P3_LEN_MA3);
+            if (j.slot < 0 || j.slot >= e->db.p1_slots || !(p1 || p3)) FAIL(NRSC5HIP_EINVAL, "job %d: bad AM slot / frame / length", k);
+            words = e->db.p1_ring + ((size_t)j.stream * e->db.p1_slots + j.slot) * P1_WORDS + (p1 ? j.which * AM_P1_WORDS : AM_P3_WORD0);
+        } else FAIL(NRSC5HIP_EINVAL, "job %d: unknown kind %d", k, j.kind);
+        dj[k] = L2Job{words, j.nbits, 0};
+    }
+    HIPCHK(hipDeviceSynchronize());                 // the frames may still be in flight on a decode stream
+    return l2_run(e, dj, out, pdu_bytes, stride);
+}
+
+extern "C" int nrsc5hip_stage_l2_index(nrsc5hip_engine *e, const uint8_t *bits, int nbits, int nframes, nrsc5hip_l2_frame *out, uint8_t *pdu_bytes, long long stride)
+{
+    if (!e || !bits || !out || nbits < 1 || nframes < 1) FAIL(NRSC5HIP_EINVAL, "bad argument");
+    const int words = (nbits + 31) / 32;
+    std::vector<uint32_t> w((size_t)words * nframes, 0u);
+    for (int f = 0; f < nframes; f++)
+        for (int i = 0; i < nbits; i++) w[(size_t)f * words + (i >> 5)] |= (uint32_t)(bits[(size_t)f * nbits + i] & 1u) << (i & 31);
+    uint32_t *dw = nullptr;
+    HIPCHK(hipMalloc((void **)&dw, w.size() * sizeof(uint32_t)));
+    HIPCHK(hipMemcpy(dw, w.data(), w.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    std::vector<L2Job> dj((size_t)nframes);
+    for (int f = 0; f < nframes; f++) dj[f] = L2Job{dw + (size_t)f * words, nbits, 0};
+    const int rc = l2_run(e, dj, out, pdu_bytes, stride);
+    (void)hipFree(dw);
+    return rc;
+}
+
 extern "C" int nrsc5hip_stage_viterbi_k9(nrsc5hip_engine *e, const int8_t *soft, int len, int nframes, const unsigned gens[3], uint8_t *bits)
 {
     if (!e || !soft || !bits || !gens || len < 64 || nframes < 1) FAIL(NRSC5HIP_EINVAL, "bad argument");

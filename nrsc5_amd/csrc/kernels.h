@@ -1,5 +1,6 @@
 // Host-callable launchers for the gfx950 kernels (one .hip file per pipeline stage).
 #pragma once
+#include "nrsc5hip.h"
 #include "nrsc5_dev.h"
 
 namespace nrsc5 {
@@ -98,6 +99,11 @@ constexpr unsigned AMT_DELAYED = 1u << 18, AMT_PUNCT = 1u << 19;
 void launch_am_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, int l2_feedback, hipStream_t st);
 void launch_viterbi_k9_frames(const int8_t *coded, int len, int nframes, unsigned g0, unsigned g1, unsigned g2,
                               unsigned long long *dec, uint32_t *out, hipStream_t st, int phases = 3);
+
+// ---- L2 audio transport index (k_l2.hip): one workgroup per decoded frame --------------------------------------
+constexpr int L2_MAX_BYTES = 18269;
+struct L2Job { const uint32_t *words; int nbits; int pad; };        // packed frame (bit i at words[i / 32] bit i % 32)
+void launch_l2_index(const L2Job *jobs, int njobs, nrsc5hip_l2_frame *frames, uint8_t *bytes_out, long long stride, hipStream_t st);
 
 // ---- stage-level entry points (parity tests) ---------------------------------------------------
 void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st, int phases = 3);

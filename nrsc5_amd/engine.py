@@ -35,6 +35,44 @@ class _Config(ctypes.Structure):
                 ("l2_feedback", ctypes.c_int), ("am_enable", ctypes.c_int)]
 
 
+class L2Pdu(ctypes.Structure):
+    """nrsc5hip_l2_pdu (include/nrsc5hip.h)"""
+    _fields_ = ([("start", ctypes.c_uint32), ("psd_off", ctypes.c_uint32), ("psd_len", ctypes.c_int32), ("audio_off", ctypes.c_uint32),
+                 ("crc_bad_lo", ctypes.c_uint32), ("crc_bad_hi", ctypes.c_uint32), ("pdu_marker", ctypes.c_uint32),
+                 ("hef_pdu_len", ctypes.c_uint16), ("loc", ctypes.c_uint16 * 64)] +
+                [(n, ctypes.c_uint8) for n in ("codec_mode", "stream_id", "pdu_seq", "blend_control", "per_stream_delay", "common_delay",
+                                               "latency", "pfirst", "plast", "seq", "nop", "hef", "la_location", "rs_corrections",
+                                               "class_ind", "prog_num", "access", "prog_type", "applied_services", "elastic_seq",
+                                               "align_offset", "skipped")])
+
+
+class L2Frame(ctypes.Structure):
+    """nrsc5hip_l2_frame"""
+    _fields_ = [("pci", ctypes.c_uint32), ("nbytes", ctypes.c_uint32), ("n_pdu", ctypes.c_uint32), ("status", ctypes.c_uint32),
+                ("end_offset", ctypes.c_uint32), ("lost_sync", ctypes.c_uint32), ("pdu", L2Pdu * 16)]
+
+
+class L2Job(ctypes.Structure):
+    """nrsc5hip_l2_job"""
+    _fields_ = [("stream", ctypes.c_int32), ("slot", ctypes.c_int32), ("kind", ctypes.c_int32), ("which", ctypes.c_int32),
+                ("nbits", ctypes.c_int32)]
+
+
+L2_FM_P1, L2_FM_PX, L2_AM = 0, 1, 2
+L2_STATUS = ("end", "no_audio", "fixed_data", "header_rs", "bad_locators", "too_many_pdus", "hef_overrun", "bad_stream", "bad_length")
+
+
+def l2_frame_to_dict(fr: L2Frame) -> dict:
+    out = {k: int(getattr(fr, k)) for k in ("pci", "nbytes", "n_pdu", "status", "end_offset", "lost_sync")}
+    out["pdus"] = []
+    for i in range(min(fr.n_pdu, 16)):
+        p = fr.pdu[i]
+        d = {name: int(getattr(p, name)) for name, _ in p._fields_ if name != "loc"}
+        d["loc"] = [int(x) for x in p.loc[:p.nop]]
+        out["pdus"].append(d)
+    return out
+
+
 class Nrsc5HipError(RuntimeError):
     pass
 
@@ -81,6 +119,8 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.nrsc5hip_batch_fetch_view.argtypes = [vp, ci, ctypes.POINTER(vp), vp, ctypes.POINTER(vp)]
     lib.nrsc5hip_reset_all.argtypes = [vp]
     lib.nrsc5hip_profile.argtypes = [vp, ci, vp, vp]
+    lib.nrsc5hip_l2_index.argtypes = [vp, ci, vp, vp, vp, ctypes.c_longlong]
+    lib.nrsc5hip_stage_l2_index.argtypes = [vp, vp, ci, ci, vp, vp, ctypes.c_longlong]
     return lib
 
 
@@ -92,7 +132,8 @@ EXPORTED_SYMBOLS = [
     "nrsc5hip_stage_halfband_fm_cu8", "nrsc5hip_stage_fft2048", "nrsc5hip_stage_viterbi_k7", "nrsc5hip_debug_fetch",
     "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_batch_fetch_view",
     "nrsc5hip_stream_set_mode", "nrsc5hip_am_frame_bits", "nrsc5hip_stage_viterbi_k9", "nrsc5hip_px_frame_bits",
-    "nrsc5hip_batch_fetch_px", "nrsc5hip_debug_fetch_px", "nrsc5hip_stage_viterbi_k9_bench"]
+    "nrsc5hip_batch_fetch_px", "nrsc5hip_debug_fetch_px", "nrsc5hip_stage_viterbi_k9_bench",
+    "nrsc5hip_l2_index", "nrsc5hip_stage_l2_index"]
 
 
 def unpack_bits(words: np.ndarray, nbits: int) -> np.ndarray:
@@ -268,6 +309,29 @@ class Engine:
         self._check(self.lib.nrsc5hip_stage_viterbi_k9(self._h, soft.ctypes.data, length, soft.shape[0], g, bits.ctypes.data))
         return bits
 
+    def l2_index(self, jobs, want_bytes: bool = True):
+        """L2 audio transport index of decoded frames still on the device.  jobs: (stream, slot, kind, which, nbits)
+        tuples; returns [(dict, PDU bytes or None)] in job order."""
+        n = len(jobs)
+        arr = (L2Job * n)(*[L2Job(*j) for j in jobs])
+        out = (L2Frame * n)()
+        stride = 18272
+        by = np.zeros((n, stride), dtype=np.uint8) if want_bytes else None
+        self._check(self.lib.nrsc5hip_l2_index(self._h, n, arr, out, by.ctypes.data if want_bytes else None, stride))
+        return [(l2_frame_to_dict(out[k]), by[k, :out[k].nbytes].copy() if want_bytes else None) for k in range(n)]
+
+    def stage_l2_index(self, frames_bits: np.ndarray, want_bytes: bool = True):
+        """Same kernel on logical frames given as frame_push takes them: frames_bits [nframes][nbits] of 0/1."""
+        b = np.ascontiguousarray(frames_bits, dtype=np.uint8)
+        if b.ndim == 1:
+            b = b[None, :]
+        n, nbits = b.shape
+        out = (L2Frame * n)()
+        stride = 18272
+        by = np.zeros((n, stride), dtype=np.uint8) if want_bytes else None
+        self._check(self.lib.nrsc5hip_stage_l2_index(self._h, b.ctypes.data, nbits, n, out, by.ctypes.data if want_bytes else None, stride))
+        return [(l2_frame_to_dict(out[k]), by[k, :out[k].nbytes].copy() if want_bytes else None) for k in range(n)]
+
     def stage_viterbi_k7_debug(self, soft: np.ndarray, length: int):
         soft = np.ascontiguousarray(soft, dtype=np.int8)
         bits = np.zeros(length, dtype=np.uint8)
@@ -307,6 +371,25 @@ class Engine:
         bins = np.zeros((32, 534), dtype=np.complex64)
         self._check(self.lib.nrsc5hip_debug_fetch(self._h, stream, pm.ctypes.data, bins.ctypes.data))
         return pm, bins
+
+
+def l2_jobs_from_records(stream: int, recs: np.ndarray, mode: int = 0):
+    """nrsc5hip_l2_job tuples for every logical frame the records announce, in the order frame_push would see them."""
+    jobs = []
+    for r in recs:
+        fl = int(r["flags"])
+        if mode == MODE_AM:
+            if fl & REC_P1:
+                jobs.append((stream, int(r["p1_slot"]), L2_AM, int(r["bc_decoded"]), AM_P1_BITS))
+            if fl & REC_P3:
+                jobs.append((stream, int(r["p1_slot"]), L2_AM, 8, 30000 if int(r["psmi"]) == 2 else 24000))
+        else:
+            if fl & REC_P1:
+                jobs.append((stream, int(r["p1_slot"]), L2_FM_P1, 0, P1_BITS))
+            for flag, ch in ((REC_P3, 0), (REC_P4, 1)):
+                if fl & flag:
+                    jobs.append((stream, int(r["sis"]), L2_FM_PX, ch, 2304 if int(r["psmi"]) == 2 else 4608))
+    return jobs
 
 
 _BLOCK_KEYS = ("state_before", "state_after", "samperr", "cfo", "keep", "bc", "psmi", "cfo_wait",

@@ -104,6 +104,28 @@ int orc_l2_first_header_ok(const uint8_t *bits, unsigned len);
 /* pids.c:52-86,1032-1050: does pids_frame_push accept this PIDS frame (CRC-12)? */
 int orc_pids_crc_ok(const uint8_t bits[80]);
 
+/* The audio-transport walk of frame_push / frame_process (frame.c:516-714) restated as an index: PDU bytes (PCI removed,
+ * bit order restored, RS-corrected headers) plus, per audio PDU, the header fields, the PSD span and every packet with
+ * its CRC-8 verdict -- i.e. exactly what frame_process hands to output_align / parse_hdlc / output_push. */
+#define ORC_L2_MAX_PDUS 16
+enum { ORC_L2_END = 0, ORC_L2_NO_AUDIO, ORC_L2_FIXED_DATA, ORC_L2_HEADER_RS, ORC_L2_BAD_LOCATORS, ORC_L2_TOO_MANY_PDUS,
+       ORC_L2_HEF_OVERRUN, ORC_L2_BAD_STREAM };
+typedef struct orc_l2_pdu {
+    uint32_t start, psd_off; int32_t psd_len; uint32_t audio_off, crc_bad_lo, crc_bad_hi, pdu_marker;
+    uint16_t hef_pdu_len, loc[64];
+    uint8_t codec_mode, stream_id, pdu_seq, blend_control, per_stream_delay, common_delay, latency, pfirst, plast, seq, nop,
+            hef, la_location, rs_corrections, class_ind, prog_num, access, prog_type, applied_services, elastic_seq,
+            align_offset, skipped;
+} orc_l2_pdu;
+typedef struct orc_l2_frame {
+    uint32_t pci, nbytes, n_pdu, status, end_offset, lost_sync;
+    orc_l2_pdu pdu[ORC_L2_MAX_PDUS];
+} orc_l2_frame;
+/* bits = the frame as handed to frame_push (one bit per byte); len one of 146176, 4608, 2304, 3750, 24000, 30000.
+ * bytes (may be NULL): room for (len - pci_len) / 8 PDU bytes.  Returns 0, or -1 for an unknown length. */
+int orc_l2_index(const uint8_t *bits, unsigned len, orc_l2_frame *out, uint8_t *bytes);
+uint8_t orc_crc8(const uint8_t *p, unsigned n);
+
 /* ---- AM (nrsc5_oracle_am.c) ------------------------------------------------------------ */
 
 /* K1-AM  input.c:52-94: cu8 -> (Q15 >> 4) -> five cascaded 15-tap half-bands, 32:1.  Any nbytes % 4 == 0;

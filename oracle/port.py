@@ -23,6 +23,36 @@ def build(force: bool = False) -> str:
     return _SO
 
 
+class L2Pdu(ctypes.Structure):
+    _fields_ = ([("start", ctypes.c_uint32), ("psd_off", ctypes.c_uint32), ("psd_len", ctypes.c_int32), ("audio_off", ctypes.c_uint32),
+                 ("crc_bad_lo", ctypes.c_uint32), ("crc_bad_hi", ctypes.c_uint32), ("pdu_marker", ctypes.c_uint32),
+                 ("hef_pdu_len", ctypes.c_uint16), ("loc", ctypes.c_uint16 * 64)] +
+                [(n, ctypes.c_uint8) for n in ("codec_mode", "stream_id", "pdu_seq", "blend_control", "per_stream_delay", "common_delay",
+                                               "latency", "pfirst", "plast", "seq", "nop", "hef", "la_location", "rs_corrections",
+                                               "class_ind", "prog_num", "access", "prog_type", "applied_services", "elastic_seq",
+                                               "align_offset", "skipped")])
+
+
+class L2Frame(ctypes.Structure):
+    _fields_ = [("pci", ctypes.c_uint32), ("nbytes", ctypes.c_uint32), ("n_pdu", ctypes.c_uint32), ("status", ctypes.c_uint32),
+                ("end_offset", ctypes.c_uint32), ("lost_sync", ctypes.c_uint32), ("pdu", L2Pdu * 16)]
+
+
+L2_STATUS = ("end", "no_audio", "fixed_data", "header_rs", "bad_locators", "too_many_pdus", "hef_overrun", "bad_stream")
+
+
+def l2_frame_to_dict(fr) -> dict:
+    """Works for any ctypes struct with the field names above (the oracle's and the product's)."""
+    out = {k: int(getattr(fr, k)) for k in ("pci", "nbytes", "n_pdu", "status", "end_offset", "lost_sync")}
+    out["pdus"] = []
+    for i in range(min(fr.n_pdu, 16)):
+        p = fr.pdu[i]
+        d = {name: int(getattr(p, name)) for name, _ in p._fields_ if name != "loc"}
+        d["loc"] = [int(x) for x in p.loc[:p.nop]]
+        out["pdus"].append(d)
+    return out
+
+
 class _Snapshot(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in ("sync_state", "bc", "psmi", "cfo_wait", "samperr_next", "mer_cnt", "acq_cfo", "keep_extra")] + \
                [(n, ctypes.c_float) for n in ("angle_next", "prev_angle", "phase_re", "phase_im", "error_lb", "error_ub")] + \
@@ -62,6 +92,9 @@ class Oracle:
         L.orc_l2_first_header_ok.argtypes = [vp, ctypes.c_uint]
         L.orc_rs255_247_decode.argtypes = [vp]
         L.orc_pids_crc_ok.argtypes = [vp]
+        L.orc_l2_index.argtypes = [vp, ctypes.c_uint, vp, vp]
+        L.orc_crc8.argtypes = [vp, ctypes.c_uint]
+        L.orc_crc8.restype = ctypes.c_uint8
         # AM
         L.orc_am_open.restype = vp
         L.orc_am_close.argtypes = [vp]
@@ -152,6 +185,15 @@ class Oracle:
     def pids_crc_ok(self, bits80: np.ndarray) -> bool:
         b = np.ascontiguousarray(bits80, dtype=np.uint8)
         return bool(self.lib.orc_pids_crc_ok(b.ctypes.data))
+
+    def l2_index(self, bits: np.ndarray):
+        """frame_push + frame_process restated as an index: (dict, PDU bytes with RS-corrected headers)."""
+        b = np.ascontiguousarray(bits, dtype=np.uint8)
+        fr = L2Frame()
+        by = np.zeros(b.size // 8 + 8, dtype=np.uint8)
+        if self.lib.orc_l2_index(b.ctypes.data, b.size, ctypes.addressof(fr), by.ctypes.data) != 0:
+            raise ValueError("unknown frame length %d" % b.size)
+        return l2_frame_to_dict(fr), by[:fr.nbytes].copy()
 
     def l2_hook(self):
         """p1_hook for run(): drop to SYNC_NONE exactly when the reference's frame_process would."""

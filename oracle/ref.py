@@ -10,8 +10,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
-TAP_Q15, TAP_FFT, TAP_SOFT, TAP_VIT, TAP_HDC = 1, 2, 4, 8, 16
-REC_BLOCK, REC_STATE, REC_SOFT, REC_PIDS, REC_FRAME, REC_SYNC, REC_LOST_SYNC, REC_MER, REC_BER, REC_HDC, REC_VIT, REC_AMSYM, REC_PXSOFT, REC_STATION = range(1, 15)
+TAP_Q15, TAP_FFT, TAP_SOFT, TAP_VIT, TAP_HDC, TAP_L2 = 1, 2, 4, 8, 16, 32
+REC_BLOCK, REC_STATE, REC_SOFT, REC_PIDS, REC_FRAME, REC_SYNC, REC_LOST_SYNC, REC_MER, REC_BER, REC_HDC, REC_VIT, REC_AMSYM, REC_PXSOFT, REC_STATION, REC_L2PKT, REC_L2ALIGN = range(1, 17)
 MODE_FM, MODE_AM = 0, 1
 
 BLOCK_FIELDS = ("state_before", "state_after", "samperr", "cfo", "keep", "bc", "psmi", "cfo_wait",
@@ -36,6 +36,7 @@ class RefLib:
         L.refh_buf.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         L.refh_buf.restype = ctypes.c_size_t
         L.refh_sizeof_session.restype = ctypes.c_size_t
+        L.refh_frame_push.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
         for name in ("nrsc5_conv_decode_p1", "nrsc5_conv_decode_pids"):
             getattr(L, name).argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.nrsc5_conv_decode_p3_p4.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
@@ -64,6 +65,23 @@ class RefLib:
         finally:
             self.lib.refh_close()
         return parse_log(log), np.frombuffer(q15, dtype=np.int16).reshape(-1, 2), np.frombuffer(fft, dtype=np.complex64)
+
+    def l2_frames(self, frames, mode: int = MODE_FM, lc: int = 0):
+        """Hand logical frames (bit arrays as frame_push takes them) straight to the reference's L2 in one session;
+        returns, per frame, the ordered taps: output_align / output_push calls, state changes, HDC events."""
+        if self.lib.refh_open(mode, TAP_L2 | TAP_HDC, 0) != 0:
+            raise RuntimeError("refh_open failed")
+        out, seen = [], 0
+        try:
+            for bits in frames:
+                b = np.ascontiguousarray(bits, dtype=np.uint8)
+                self.lib.refh_frame_push(b.ctypes.data, b.size, lc)
+                log = self._buf(0)
+                out.append(parse_log(log[seen:]))
+                seen = len(log)
+        finally:
+            self.lib.refh_close()
+        return out
 
     def conv_decode(self, soft: np.ndarray, kind: str = "p1") -> np.ndarray:
         soft = np.ascontiguousarray(soft, dtype=np.int8)
@@ -126,6 +144,13 @@ def parse_log(log: bytes):
         elif kind == REC_PXSOFT:
             ch, bc, ln = struct.unpack_from("<3I", pl)
             out.append(("pxsoft", {"ch": ch, "bc": bc, "bits": np.frombuffer(pl, dtype=np.int8, offset=12, count=ln)}))
+        elif kind == REC_L2PKT:
+            prog, sid, seq, size, flags, shape = struct.unpack_from("<6I", pl)
+            out.append(("l2pkt", {"program": prog, "stream_id": sid, "seq": seq, "size": size, "flags": flags, "shape": shape,
+                                  "data": pl[24:24 + size + 1]}))
+        elif kind == REC_L2ALIGN:
+            prog, sid, align = struct.unpack("<3I", pl)
+            out.append(("l2align", {"program": prog, "stream_id": sid, "offset": align}))
         elif kind == REC_STATION:
             fcc, cc = struct.unpack("<i4s", pl)
             out.append(("station", {"fcc": fcc, "country": cc.rstrip(b"\0").decode()}))

@@ -15,12 +15,13 @@ enum {
     REFH_TAP_SOFT  = 1 << 2,   /* decode_push_pm soft bits */
     REFH_TAP_VIT   = 1 << 3,   /* conv decoder in/out */
     REFH_TAP_HDC   = 1 << 4,   /* HDC packet payloads in the log */
+    REFH_TAP_L2    = 1 << 5,   /* output_align / output_push calls of frame_process (frame.c:600,631) */
 };
 
 /* ordered log record kinds */
 enum {
     REC_BLOCK = 1, REC_STATE, REC_SOFT, REC_PIDS, REC_FRAME, REC_SYNC, REC_LOST_SYNC,
-    REC_MER, REC_BER, REC_HDC, REC_VIT, REC_AMSYM, REC_PXSOFT, REC_STATION
+    REC_MER, REC_BER, REC_HDC, REC_VIT, REC_AMSYM, REC_PXSOFT, REC_STATION, REC_L2PKT, REC_L2ALIGN
 };
 
 typedef struct { uint8_t *p; size_t len, cap; } gbuf;
@@ -168,6 +169,26 @@ int __wrap_nrsc5_conv_decode_p1(const int8_t *in, uint8_t *out)
     return rc;
 }
 
+/* L2 audio transport taps: what frame_process hands to the elastic buffer */
+void __real_output_push(output_t *st, const packet_ref_t *ref);
+void __wrap_output_push(output_t *st, const packet_ref_t *ref)
+{
+    if (g_taps & REFH_TAP_L2) {
+        uint8_t *tmp = malloc(24 + ref->size + 1);
+        uint32_t h[6] = { ref->program, ref->stream_id, ref->seq, ref->size, ref->flags, ref->shape };
+        memcpy(tmp, h, 24); memcpy(tmp + 24, ref->data, ref->size + 1);      /* payload + its CRC byte */
+        log_rec(REC_L2PKT, tmp, 24 + ref->size + 1);
+        free(tmp);
+    }
+    __real_output_push(st, ref);
+}
+void __real_output_align(output_t *st, unsigned int program, unsigned int stream_id, unsigned int offset);
+void __wrap_output_align(output_t *st, unsigned int program, unsigned int stream_id, unsigned int offset)
+{
+    if (g_taps & REFH_TAP_L2) { uint32_t h[3] = { program, stream_id, offset }; log_rec(REC_L2ALIGN, h, sizeof(h)); }
+    __real_output_align(st, program, stream_id, offset);
+}
+
 /* ---- public-API event callback ------------------------------------------------ */
 static void on_event(const nrsc5_event_t *evt, void *opaque)
 {
@@ -223,6 +244,16 @@ int refh_run_cs16(const int16_t *iq, size_t n, unsigned chunk)
         nrsc5_pipe_samples_cs16(g_radio, iq + off, k);
     }
     return 0;
+}
+/* hand one logical frame straight to the reference's L2 (frame.c:645): pins oracle/nrsc5_oracle_l2.c without a demod run.
+ * The session is put in FINE first so that the sync-loss feedback of frame_process shows up as a REC_STATE record. */
+void refh_frame_push(const uint8_t *bits, size_t length, int lc)
+{
+    uint8_t *tmp = malloc(length);
+    memcpy(tmp, bits, length);
+    g_radio->input.sync_state = SYNC_STATE_FINE;
+    __real_frame_push(&g_radio->input.frame, tmp, length, (logical_channel_t)lc);
+    free(tmp);
 }
 void refh_force_resync(void) { input_set_sync_state(&g_radio->input, SYNC_STATE_NONE); }
 void refh_close(void) { if (g_radio) { nrsc5_close(g_radio); g_radio = NULL; } }

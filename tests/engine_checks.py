@@ -455,3 +455,71 @@ def check_pids_crc_flag(lib, oracle, am=False):
             n += 1; good += ok
     assert n >= 20 and good >= 16 and (am or good < n)
     E.close()
+
+
+def check_l2_index_stage(lib, oracle, lengths=None):
+    """k_l2_index == orc_l2_index (itself pinned against the reference's frame_push / frame_process in
+    tests/test_oracle_l2.py) on frames that walk every branch: index fields and RS-corrected PDU bytes, bit-exact."""
+    from nrsc5_amd import synth_l2
+    from oracle import port
+    E = eng.Engine(max_streams=1, lib_path=lib)
+    seen = set()
+    for nbits in (lengths or sorted(synth_l2.LAYOUT)):
+        cases = synth_l2.test_frames(nbits)
+        frames = np.stack([b for _, b, _ in cases])
+        got = E.stage_l2_index(frames)
+        for (name, bits, _), (gi, gb) in zip(cases, got):
+            oi, ob = oracle.l2_index(bits)
+            assert gi == oi, (nbits, name, {k: (gi[k], oi[k]) for k in gi if gi[k] != oi[k]})
+            assert np.array_equal(gb, ob), (nbits, name)
+            seen.add(port.L2_STATUS[oi["status"]])
+    if lengths is None:
+        assert seen == set(port.L2_STATUS), seen
+    # unknown frame length: reported, not guessed
+    gi, _ = E.stage_l2_index(np.zeros((1, 1000), dtype=np.uint8))[0]
+    assert eng.L2_STATUS[gi["status"]] == "bad_length" and gi["n_pdu"] == 0
+    E.close()
+
+
+def _l2_job_bits(E, job):
+    stream, slot, kind, which, nbits = job
+    if kind == eng.L2_FM_P1:
+        return E.p1_frame_bits(stream, slot)
+    if kind == eng.L2_FM_PX:
+        return E.px_frame_bits(stream, slot, which, nbits)
+    return E.am_frame_bits(stream, slot, which, nbits)
+
+
+def check_l2_index_end_to_end(lib, oracle, am=False, mode="MP3", p1_async=False):
+    """IQ -> decoded frames -> nrsc5hip_l2_index on the frames still in HBM == the oracle's index of the same frames;
+    for the FM signal source every audio packet the transmitter built comes back with a good CRC-8."""
+    from nrsc5_amd import synth_am
+    if am:
+        cap = synth_am.am_ma1_capture(9, seed=31, cfo_hz=2.0, offset=300)
+        E = eng.Engine(max_streams=1, q15_capacity=400000, record_capacity=512, p1_slots=16, lib_path=lib, am_enable=True, p1_async=p1_async)
+        E.set_mode(0, eng.MODE_AM)
+    else:
+        cap = synth.fm_mp1_capture(3, seed=52, cfo_hz=-40.0, offset=500, snr_db=25, mode=mode)
+        E = eng.Engine(max_streams=1, q15_capacity=cap.iq.size // 4 + 200000, record_capacity=512, p1_slots=8, lib_path=lib, p1_async=p1_async)
+    common.run_engine_streaming(E, 0, cap.iq, chunk=32768 * 8)
+    recs = E.drain(0)
+    jobs = eng.l2_jobs_from_records(0, recs, eng.MODE_AM if am else eng.MODE_FM)
+    assert len(jobs) >= (9 if am else 2), len(jobs)
+    got = E.l2_index(jobs)
+    kinds = set()
+    for job, (gi, gb) in zip(jobs, got):
+        oi, ob = oracle.l2_index(_l2_job_bits(E, job))
+        assert gi == oi, (job, {k: (gi[k], oi[k]) for k in gi if gi[k] != oi[k]})
+        assert np.array_equal(gb, ob), job
+        kinds.add((job[2], job[4]))
+        if not am and job[2] == eng.L2_FM_P1:
+            assert gi["n_pdu"] == 1 and gi["pdus"][0]["nop"] == 32 and gi["pdus"][0]["crc_bad_lo"] == 0 and gi["lost_sync"] == 0
+    assert len(kinds) >= 2, kinds
+    # argument errors are reported, not executed
+    for bad in ((0, 99, eng.L2_FM_P1, 0, 146176), (0, 0, 7, 0, 146176), (0, 0, eng.L2_FM_PX, 2, 4608), (0, 0, eng.L2_AM, 8, 3750)):
+        try:
+            E.l2_index([bad])
+            raise AssertionError(f"job {bad} accepted")
+        except eng.Nrsc5HipError:
+            pass
+    E.close()

@@ -114,3 +114,14 @@ def test_emu_mode_switch_on_live_stream(emu_lib, oracle):
 def test_emu_pids_crc_flag(emu_lib, oracle):
     ec.check_pids_crc_flag(emu_lib, oracle)
     ec.check_pids_crc_flag(emu_lib, oracle, am=True)
+
+
+def test_emu_l2_index_every_branch(emu_lib, oracle):
+    """frame_push + the audio walk of frame_process on the device == the oracle's index (pinned against the reference's
+    own frame_push in test_oracle_l2.py), all six frame lengths."""
+    ec.check_l2_index_stage(emu_lib, oracle)
+
+
+def test_emu_l2_index_end_to_end(emu_lib, oracle):
+    ec.check_l2_index_end_to_end(emu_lib, oracle, am=True)
+    ec.check_l2_index_end_to_end(emu_lib, oracle, am=False, mode="MP3")

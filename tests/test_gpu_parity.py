@@ -263,3 +263,15 @@ def test_gpu_mode_switch_on_live_stream(hip_lib, oracle):
 def test_gpu_pids_crc_flag(hip_lib, oracle):
     ec.check_pids_crc_flag(hip_lib, oracle)
     ec.check_pids_crc_flag(hip_lib, oracle, am=True)
+
+
+def test_gpu_l2_index_every_branch(hip_lib, oracle):
+    """k_l2_index (frame_push + frame_process's audio walk + CRC-8 of every packet) == the oracle's index, itself pinned
+    against the unmodified reference's frame_push: all six frame lengths, every exit of the walk, bit-exact bytes."""
+    ec.check_l2_index_stage(hip_lib, oracle)
+
+
+@pytest.mark.parametrize("kw", [dict(am=False, mode="MP3"), dict(am=False, mode="MP11", p1_async=True), dict(am=True), dict(am=True, p1_async=True)])
+def test_gpu_l2_index_end_to_end(hip_lib, oracle, kw):
+    """IQ -> frames in HBM -> index, in-order and through the decode windows (FM P1 / P3 / P4, AM P1 / P3)."""
+    ec.check_l2_index_end_to_end(hip_lib, oracle, **kw)

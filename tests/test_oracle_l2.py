@@ -1,0 +1,88 @@
+"""`-m "not gpu"`: pins the oracle's restatement of frame_push / frame_process (oracle/nrsc5_oracle_l2.c, orc_l2_index)
+against the UNMODIFIED reference: every logical frame is handed to the reference's own frame_push and the calls it
+makes to output_align / output_push (tapped with --wrap in oracle/ref_shim/ref_harness.c) must be exactly the ones the
+index describes -- program, stream, elastic-buffer sequence, size, CRC flag, half-packet shape and the bytes."""
+import numpy as np
+import pytest
+
+from oracle import port
+from nrsc5_amd import synth_l2
+
+
+def expected_taps(idx, by):
+    """What frame_process does with a frame, derived from the index alone (frame.c:600-640, 535-540)."""
+    out = []
+    for d in idx["pdus"]:
+        if d["skipped"]:
+            continue
+        out.append(("l2align", d["prog_num"], d["stream_id"], d["align_offset"]))
+        off = d["audio_off"]
+        bad = d["crc_bad_lo"] | (d["crc_bad_hi"] << 32)
+        for j, loc in enumerate(d["loc"]):
+            shape = 3 if (j == 0 and d["pfirst"]) else 2 if (j == d["nop"] - 1 and d["plast"]) else 1   # HALF_BACK / HALF_FRONT / FULL
+            out.append(("l2pkt", d["prog_num"], d["stream_id"], (d["elastic_seq"] + j) % 64, loc - off, (bad >> j) & 1, shape, bytes(by[off:loc + 1])))
+            off = loc + 1
+    if idx["lost_sync"]:
+        out.append(("state", 2, 0))
+    return out
+
+
+def reference_taps(log):
+    out = []
+    for k, v in log:
+        if k == "l2align":
+            out.append((k, v["program"], v["stream_id"], v["offset"]))
+        elif k == "l2pkt":
+            out.append((k, v["program"], v["stream_id"], v["seq"], v["size"], v["flags"], v["shape"], bytes(v["data"])))
+        elif k == "state":
+            out.append((k, v["old"], v["new"]))
+    return out
+
+
+@pytest.mark.parametrize("nbits", sorted(synth_l2.LAYOUT))
+def test_l2_index_matches_reference_frame_process(oracle, reflib, nbits):
+    cases = synth_l2.test_frames(nbits)
+    statuses = set()
+    for name, bits, safe in cases:
+        idx, by = oracle.l2_index(bits)
+        statuses.add(port.L2_STATUS[idx["status"]])
+        if not safe or port.L2_STATUS[idx["status"]] == "fixed_data":
+            continue                      # reference undefined / fixed-data walk not indexed (status says so)
+        log = reflib.l2_frames([bits])[0]
+        assert expected_taps(idx, by) == reference_taps(log), (nbits, name)
+        if idx["n_pdu"]:
+            assert any(k == "l2pkt" for k, _ in log) or all(d["nop"] == 0 or d["skipped"] for d in idx["pdus"])
+    assert {"end", "no_audio", "fixed_data", "header_rs", "bad_locators", "hef_overrun", "bad_stream"} <= statuses
+
+
+def test_l2_index_sequence_through_one_session(oracle, reflib):
+    """Frames pushed back to back through ONE reference session (services / elastic buffer state evolving) still yield,
+    frame by frame, exactly the calls the stateless index describes."""
+    frames = [b for _, b, safe in synth_l2.test_frames(146176, seed=3) if safe]
+    frames = [b for b in frames if port.L2_STATUS[oracle.l2_index(b)[0]["status"]] != "fixed_data"]
+    logs = reflib.l2_frames(frames)
+    for bits, log in zip(frames, logs):
+        idx, by = oracle.l2_index(bits)
+        assert expected_taps(idx, by) == reference_taps(log)
+
+
+def test_l2_index_agrees_with_first_header_check(oracle):
+    """lost_sync of the index == the L2 -> L1 feedback decision used by the engine (orc_l2_first_header_ok)."""
+    for nbits in (146176, 3750):
+        for name, bits, _ in synth_l2.test_frames(nbits, seed=5):
+            idx, _ = oracle.l2_index(bits)
+            assert bool(idx["lost_sync"]) == (not oracle.l2_first_header_ok(bits)), (nbits, name)
+
+
+def test_l2_index_on_synth_capture_frames(oracle):
+    """The PDUs of the end-to-end signal source: 32 packets, all CRCs good, header fields as generated."""
+    from nrsc5_amd import synth
+    rng = np.random.default_rng(4)
+    pdu, packets = synth.make_audio_pdu(3, rng)
+    idx, by = oracle.l2_index(synth.p1_frame_bits(pdu))
+    assert idx["n_pdu"] == 1 and idx["pdus"][0]["nop"] == 32 and idx["pdus"][0]["crc_bad_lo"] == 0
+    d = idx["pdus"][0]
+    off = d["audio_off"]
+    for j, loc in enumerate(d["loc"]):
+        assert bytes(by[off:loc]) == packets[j]
+        off = loc + 1
