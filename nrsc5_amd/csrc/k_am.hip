@@ -479,7 +479,10 @@ __global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, c
     if (tid == 0) {
         am.dec_bc = -1; st.active = ready ? 1 : 0;
         // late L2 feedback raised by a deferred decode (window pipeline): take it before this block, as input.c:172-188
-        if (ready && st.force_none) { if (st.sync_state == SYNC_FINE) st.sync_state = SYNC_NONE; st.force_none = 0; }
+        if (const int req = ready ? st.force_none : 0) {       // requests of an earlier lock are stale (see k_sync)
+            if (st.sync_state == SYNC_FINE && req == st.fine_epoch + 1) st.sync_state = SYNC_NONE;
+            atomicCAS(&st.force_none, req, 0);
+        }
     }
     __syncthreads();
     if (!ready) return;
@@ -695,7 +698,7 @@ __global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, c
             else am.offset_history = (am.offset_history << 4) | (unsigned)bc;
             if ((am.offset_history & 0xffffu) == 0x5670u) {
                 st.bc = 0;
-                st.sync_state = SYNC_FINE;                     // input_set_sync_state: EVENT_SYNC payload (input.c:179-185)
+                st.sync_state = SYNC_FINE; st.fine_epoch++;    // input_set_sync_state: EVENT_SYNC payload (input.c:179-185)
                 rec.flags |= REC_TO_FINE;
                 rec.freq_offset = (float)(((double)st.prev_angle - 2 * M_PI * st.cfo) * 46511.71875 / (2 * M_PI * AM_FFT));
                 rec.sis = (uint32_t)((am.pli & 1) | ((am.hppi & 1) << 1) | ((am.aabi & 1) << 2) | ((am.rdbi & 1) << 3) | 16);
@@ -932,7 +935,7 @@ __global__ __launch_bounds__(1024) void k_am_interleave(DevTables tb, DevBuffers
             am.next_slot = stw.p1_count % db.p1_slots; stw.p1_count++;
             if (parity >= 0) {
                 AmJob &job = db.am_job[(size_t)s * NWIN + parity];
-                job.slot = am.next_slot; job.psmi = am.dec_psmi; job.rdbi = am.dec_rdbi; job.errors = 0; job.done = 0; job.valid = 1;
+                job.slot = am.next_slot; job.psmi = am.dec_psmi; job.rdbi = am.dec_rdbi; job.errors = 0; job.done = 0; job.epoch = stw.fine_epoch; job.valid = 1;
             }
         }
     }
@@ -982,7 +985,7 @@ __global__ __launch_bounds__(64) void k_am_decode(DevTables tb, DevBuffers db, c
         if (l2_feedback && threadIdx.x == 0) {                 // frame.c:535-540, applied by the next k_am_block of the stream
             L2Smem &l2 = *(L2Smem *)&k9;                       // the trellis scratch is dead by now
             l2_gf_init(l2);
-            if (!l2_first_header_ok_am(out, l2)) db.state[s].force_none = 1;
+            if (!l2_first_header_ok_am(out, l2)) atomicMax(&db.state[s].force_none, job.epoch + 1);
         }
     } else {
         const int8_t *in = vit + AM_VIT;

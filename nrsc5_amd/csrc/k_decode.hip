@@ -123,7 +123,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBu
             l2_gf_init(l2);
             if (!l2_first_header_ok_fm(out, l2)) {
                 if (l2_mode == 1) { if (st.sync_state == SYNC_FINE) { st.sync_state = SYNC_NONE; rec.state_after = SYNC_NONE; rec.flags |= REC_LOST_SYNC; } }
-                else st.force_none = 1;
+                else atomicMax(&st.force_none, st.p1_epoch[parity] + 1);
             }
         }
         st.p1_pending[parity] = 0;

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
                     // input_set_sync_state(FINE): EVENT_SYNC payload (input.c:179-185)
                     rec.freq_offset = (float)(((double)st.prev_angle - 2 * M_PI * st.cfo) * 744187.5 / (2 * M_PI * FFT_N));
                     rec.flags |= REC_TO_FINE;
-                    st.sync_state = SYNC_FINE;
+                    st.sync_state = SYNC_FINE; st.fine_epoch++;
                     st.started_pm = 0;                         // decode_reset (decode.c:563-572)
                     st.px_pos = 0; st.px_ready = 0; st.px_started = 0;   // interleaver_iv_reset
                     action = 1;
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
             if (st.started_pm && bc == 15) {
                 const int slot = st.p1_count % db.p1_slots;
                 st.p1_count++;
-                st.p1_pending[parity] = 1; st.p1_slot[parity] = slot; st.p1_record[parity] = st.nblocks % db.rec_cap;
+                st.p1_pending[parity] = 1; st.p1_slot[parity] = slot; st.p1_record[parity] = st.nblocks % db.rec_cap; st.p1_epoch[parity] = st.fine_epoch;
                 st.p1_pmslot[parity] = pm_slot;
                 rec.p1_slot = slot; rec.flags |= REC_P1;
             }
@@ -501,10 +501,15 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         rec.bc = st.bc; rec.psmi = st.psmi; rec.cfo_wait = st.cfo_wait; rec.next_samperr = st.samperr;
         rec.prev_angle = st.prev_angle; rec.phase_re = (float)cos(th); rec.phase_im = (float)sin(th);
         rec.next_angle = st.angle;
-        if (st.force_none && acq_on && st.sync_state == SYNC_FINE) {
-            // L2 feedback raised by a deferred P1 decode (l2_header.h): this step's successor runs the acquisition kernels
-            st.sync_state = SYNC_NONE; st.force_none = 0;
-            rec.flags |= REC_LOST_SYNC;
+        if (const int req = st.force_none) {
+            // L2 feedback raised by a deferred P1 decode (l2_header.h).  A request that belongs to an earlier lock is stale
+            // (the decode of a frame received before the last re-acquisition finished late): drop it, keep the lock.
+            const bool current = st.sync_state == SYNC_FINE && req == st.fine_epoch + 1;
+            if (!current) atomicCAS(&st.force_none, req, 0);
+            else if (acq_on) {                                 // this step's successor runs the acquisition kernels
+                st.sync_state = SYNC_NONE; atomicCAS(&st.force_none, req, 0);
+                rec.flags |= REC_LOST_SYNC;
+            }
         }
         st.nblocks++;
         st.active = 0;

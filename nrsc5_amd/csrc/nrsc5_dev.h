@@ -120,7 +120,8 @@ struct StreamState {
     // bookkeeping
     int nblocks;                // processed blocks so far (record index)
     int p1_count;               // P1 frames produced so far
-    int force_none;             // host request: drop to SYNC_NONE before the next block
+    int force_none;             // deferred L2 feedback: fine_epoch + 1 of the P1 frame whose first header failed (0 = none)
+    int fine_epoch;             // number of transitions into SYNC_FINE so far: a request from an earlier lock is stale
     // per-step scratch written by k_prepare / acquisition
     int active;                 // this step processes a block for this stream
     int samperr_cur; int pad0;
@@ -130,6 +131,7 @@ struct StreamState {
     int p1_pending[NWIN];          // 1: frame completed this step (gather it), 2: gathered into coded[s][parity]
     int p1_slot[NWIN];             // slot of the stream's P1 ring the decoder must fill
     int p1_record[NWIN];           // record index that gets the BER
+    int p1_epoch[NWIN];            // fine_epoch the frame was received in
     int p1_endlane[NWIN];
     int p1_pmslot[NWIN];        // which of the stream's NPM soft-bit matrices holds the frame
     int pm_slot;                // matrix being filled; advances after every block 15
@@ -163,6 +165,6 @@ struct AmStream {
 };
 
 // window pipeline: one L1 frame's worth of decodes (8 x P1 + P3) handed to k_am_decode
-struct AmJob { int valid, slot, psmi, rdbi; unsigned errors; int done; int pad[2]; };
+struct AmJob { int valid, slot, psmi, rdbi; unsigned errors; int done; int epoch; int pad; };
 
 }  // namespace nrsc5

@@ -523,3 +523,33 @@ def check_l2_index_end_to_end(lib, oracle, am=False, mode="MP3", p1_async=False)
         except eng.Nrsc5HipError:
             pass
     E.close()
+
+
+def check_deferred_feedback_recovers(lib, n_blocks=256):
+    """Window pipeline + on-device L2 feedback on captures the reference algorithm falsely locks on (seeds 23 / 24) and one
+    it does not.  The verdict of a deferred decode may arrive up to NWIN = 8 windows late; 256 blocks leave room for the
+    worst case (128 blocks of latency + re-acquisition + one aligned L1 frame)."""
+    caps = [synth.fm_mp1_capture(0, seed=sd, cfo_hz=c, offset=o, snr_db=20, n_blocks=n_blocks) for sd, c, o in ((23, 0.0, 1234), (24, 10.0, 2208), (25, 10.0, 777))]
+    n = len(caps)
+    stride = max(c.iq.size for c in caps); stride += (-stride) % 256
+    buf = np.zeros((n, stride), dtype=np.uint8)
+    for k, c in enumerate(caps):
+        buf[k, :c.iq.size] = c.iq
+    good = []
+    for fb in (False, True):
+        E = eng.Engine(max_streams=n, q15_capacity=stride // 4 + 1024, record_capacity=512, p1_slots=32, p1_async=True, l2_feedback=fb, lib_path=lib)
+        dev = _to_device(E, buf)
+        E.batch_append_cu8(dev, stride, [c.iq.size - c.iq.size % 4 for c in caps])
+        E.batch_process(n)
+        recs, counts, frames = E.batch_fetch(n)
+        ok = []
+        for k, c in enumerate(caps):
+            truth = {np.packbits(f, bitorder="little").tobytes() for f in c.p1_frames}
+            ok.append(sum(1 for r in recs[k, :counts[k]] if (int(r["flags"]) & eng.REC_P1) and frames[k, int(r["p1_slot"])].tobytes() in truth))
+        good.append(ok)
+        _free_device(E, dev)
+        E.close()
+    total = n_blocks // 16
+    assert good[0][0] == 0 and good[0][1] == 0 and good[0][2] >= total - 2, good     # without feedback the two false locks never recover
+    assert good[1][0] >= 1 and good[1][1] >= 1 and good[1][2] == good[0][2], good    # late (deferred decode), but they come back
+    return good

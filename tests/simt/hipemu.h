@@ -129,6 +129,7 @@ static inline unsigned __brev(unsigned v) { unsigned r = 0; for (int i = 0; i < 
 
 template <typename T> static inline T atomicAdd(T *p, T v) { T o = *p; *p = o + v; return o; }
 template <typename T> static inline T atomicMax(T *p, T v) { T o = *p; *p = std::max(o, v); return o; }
+template <typename T> static inline T atomicCAS(T *p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
 template <typename T> static inline T atomicMin(T *p, T v) { T o = *p; *p = std::min(o, v); return o; }
 template <typename T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
 template <typename T> static inline T atomicExch(T *p, T v) { T o = *p; *p = v; return o; }

@@ -1,7 +1,8 @@
 """L2 index kernel timing: 1024 FM P1 frames (5 audio PDUs, 87 packets each) + 2048 AM P1 frames in one launch each.
 Run under rocprofv3 --kernel-trace --stats (tools/gpu_l2.sh); prints host wall times as a cross-check."""
 import sys, time
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from nrsc5_amd import engine as eng, synth_l2
 
