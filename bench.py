@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--l2-feedback", type=int, default=1, help="1: the engine applies the reference's L2 -> L1 sync-loss feedback itself (RS check of the first L2 header on the device), as the CPU baseline's frame.c does; 0: off")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no HIP-event kernel timing inside the timed region (roofline fields become 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-l2-index", action="store_true", help="skip the (untimed) L2 audio-index property check of the decoded frames")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="optional PMC-derived HBM bytes per launch for the dominant kernel (written by profiles/collect_pmc.py)")
@@ -157,6 +158,7 @@ def main():
     # ---- verification of the last pass against the transmitted truth ----------------------------------
     rows = []
     n_locked = 0
+    l2_jobs, l2_exact = [], []
     for k, gs in enumerate(my_streams):
         r = recs[k, :counts[k]]
         truth = pool[gs % args.payloads][0]
@@ -168,19 +170,37 @@ def main():
             w = frames[k, int(rr["p1_slot"])]
             h = zlib.crc32(w.tobytes(), h)
             b = w.view(np.uint8)
+            exact = 0
             if first is None:
                 match = np.nonzero((truth == b[None, :]).all(axis=1))[0]
                 if match.size:
                     first = int(match[0]) - j
-                    ok += 1
+                    exact = 1
             else:
                 idx = first + j
-                ok += int(0 <= idx < truth.shape[0] and np.array_equal(truth[idx], b))
+                exact = int(0 <= idx < truth.shape[0] and np.array_equal(truth[idx], b))
+            ok += exact
+            l2_jobs.append((k, int(rr["p1_slot"]), eng.L2_FM_P1, 0, eng.P1_BITS)); l2_exact.append(exact)
         fine = int((r["state_after"] == eng.SYNC_FINE).sum())
         locked = len(p1r) > 0 and ok >= len(p1r) - 1
         n_locked += int(locked)
         rows.append([gs, len(r), len(p1r), ok, int(((r["flags"] & eng.REC_PIDS) != 0).sum()), fine, h])
     allrows = shard.gather_summaries(np.array(rows, dtype=np.int64), dev)
+    # ---- full-size property check on the device: the L2 audio index of every decoded P1 frame (frame_push + RS header +
+    # CRC-8 of all 32 audio packets, k_l2_index) must be clean exactly for the frames that equal the transmitted bits
+    l2 = None
+    if l2_jobs and not args.no_l2_index:
+        try:
+            t_l2 = time.perf_counter()
+            idx = E.l2_index(l2_jobs, want_bytes=False)
+            t_l2 = time.perf_counter() - t_l2
+            clean = [int(d["n_pdu"] == 1 and d["pdus"][0]["nop"] == 32 and d["pdus"][0]["crc_bad_lo"] == 0 and d["lost_sync"] == 0) for d, _ in idx]
+            l2 = {"frames_indexed": len(idx), "host_ms_incl_copies": round(t_l2 * 1e3, 2),
+                  "audio_packets_crc_ok": int(sum(sum(p["nop"] - bin(p["crc_bad_lo"] | (p["crc_bad_hi"] << 32)).count("1") for p in d["pdus"]) for d, _ in idx)),
+                  "frames_clean": int(sum(clean)), "clean_and_bit_exact": int(sum(c & e for c, e in zip(clean, l2_exact))),
+                  "bit_exact": int(sum(l2_exact)), "frames_flagged_lost_sync": int(sum(d["lost_sync"] for d, _ in idx))}
+        except Exception as ex:                       # informational, never allowed to take the bench line down
+            l2 = {"error": repr(ex)}
 
     if rank != 0:
         return
@@ -234,7 +254,7 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu,
         "parity": {"streams": n_total, "streams_locked_and_all_p1_frames_equal_transmitted_bits": good,
                    "p1_frames_decoded": int(allrows[:, 2].sum()), "p1_frames_bit_exact_vs_truth": int(allrows[:, 3].sum()),
-                   "pids_frames_decoded": int(allrows[:, 4].sum()),
+                   "pids_frames_decoded": int(allrows[:, 4].sum()), "l2_index_rank0": l2,
                    "note": "streams whose timing offset falls in the reference algorithm's false-lock zone (sync.c phase-slope ambiguity, ~6 % of uniform offsets) decode one garbage frame in the reference too, whose L2 then forces a re-acquisition; with l2_feedback the engine does the same on the device (deferred decode: a few blocks later than the reference), without it such streams stay falsely locked"},
         "gen_seconds": round(t_gen, 1),
     }

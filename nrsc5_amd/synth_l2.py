@@ -190,3 +190,42 @@ def test_frames(nbits: int, seed: int = 0):
     f = bytearray(make_pdu(rng, min(n, 3000), nop=2, hef=b"\x80\x80\x80\x00", psd=b"")); f[13] -= 2; add("hef_overrun", reparity(bytes(f)), safe=False)
     f = bytearray(make_pdu(rng, min(n, 3000), nop=2, hef=b"\x91\x80", psd=b"")); add("hef_truncated_field", reparity(bytes(f)), safe=False)
     return cases
+
+
+def random_frame(rng: np.random.Generator):
+    """(nbits, frame bits): 1..6 PDUs with random codec modes (12- / 16-bit locators, unknown modes), packet counts,
+    enhanced streams, HEF combinations, half packets, CRC failures, then maybe 1..6 corrupted bytes in one header."""
+    nbits = int(rng.choice([146176, 146176, 24000, 30000, 4608, 3750, 2304]))
+    n = pdu_bytes_of(nbits)
+    pdus, used = [], 0
+    for _ in range(int(rng.integers(1, 7))):
+        room = n - used
+        if room < 260:
+            break
+        codec = int(rng.choice([0, 0, 1, 2, 3, 10, 13, 5]))
+        sid = int(rng.integers(0, 2))
+        twelve = lc_bits(codec, sid) == 12
+        room = int(min(room, rng.integers(260, 5000), 4000 if twelve else 1 << 30))
+        hef = b"" if rng.random() < 0.4 else hef_bytes(
+            prog_num=int(rng.integers(0, 8)), class_ind=int(rng.integers(0, 16)) if rng.random() < 0.5 else None,
+            access=int(rng.integers(0, 2)) if rng.random() < 0.5 else None, prog_type=int(rng.integers(0, 256)),
+            pdu_len=int(rng.integers(0, 1 << 14)) if rng.random() < 0.3 else None,
+            marker=int(rng.integers(0, 1 << 21)) if rng.random() < 0.3 else None)
+        psd = bytes(rng.integers(0, 256, size=int(rng.integers(0, 12)), dtype=np.uint8))
+        max_nop = max(1, min(63, (room - 60 - len(hef) - len(psd)) // 4, (200 - len(hef) - len(psd)) // 2))
+        nop = int(rng.integers(1, max_nop + 1))
+        p = make_pdu(rng, room, nop=nop, codec_mode=codec, stream_id=sid, pdu_seq=int(rng.integers(0, 8)),
+                     seq=int(rng.integers(0, 64)), pfirst=int(rng.integers(0, 2)), plast=int(rng.integers(0, 2)),
+                     latency=int(rng.integers(0, 8)), blend=int(rng.integers(0, 4)), psd_delay=int(rng.integers(0, 32)),
+                     common_delay=int(rng.integers(0, 64)), hef=hef, psd=psd,
+                     bad_crc=tuple(int(x) for x in rng.choice(nop, size=int(rng.integers(0, 3)), replace=False)) if nop > 2 else (),
+                     fill=bool(rng.integers(0, 2)))
+        pdus.append(p)
+        used += len(p)
+    body = b"".join(pdus)
+    if rng.random() < 0.5:
+        which = int(rng.integers(0, len(pdus)))
+        base = sum(len(p) for p in pdus[:which])
+        body = corrupt(body, base + rng.choice(96, size=int(rng.integers(1, 7)), replace=False), rng)
+    bits = frame_from_bytes(body, nbits, pci=int(rng.choice([PCI_AUDIO, PCI_AUDIO_OPP])), tail=None if rng.random() < 0.7 else b"\xa5")
+    return nbits, bits

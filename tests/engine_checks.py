@@ -475,6 +475,15 @@ def check_l2_index_stage(lib, oracle, lengths=None):
             seen.add(port.L2_STATUS[oi["status"]])
     if lengths is None:
         assert seen == set(port.L2_STATUS), seen
+        rng = np.random.default_rng(7)                         # randomised structures, batched per frame length
+        by_len = {}
+        for _ in range(120):
+            nbits, bits = synth_l2.random_frame(rng)
+            by_len.setdefault(nbits, []).append(bits)
+        for nbits, frames in by_len.items():
+            for bits, (gi, gb) in zip(frames, E.stage_l2_index(np.stack(frames))):
+                oi, ob = oracle.l2_index(bits)
+                assert gi == oi and np.array_equal(gb, ob), (nbits, {k: (gi[k], oi[k]) for k in gi if gi[k] != oi[k]})
     # unknown frame length: reported, not guessed
     gi, _ = E.stage_l2_index(np.zeros((1, 1000), dtype=np.uint8))[0]
     assert eng.L2_STATUS[gi["status"]] == "bad_length" and gi["n_pdu"] == 0

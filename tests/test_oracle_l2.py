@@ -86,3 +86,20 @@ def test_l2_index_on_synth_capture_frames(oracle):
     for j, loc in enumerate(d["loc"]):
         assert bytes(by[off:loc]) == packets[j]
         off = loc + 1
+
+
+def test_l2_index_random_structures_match_reference(oracle, reflib):
+    """Randomised frames: 1..6 PDUs with random codec modes (12- / 16-bit locators, unknown modes), packet counts 0..63,
+    enhanced streams, HEF combinations, half packets, CRC failures, then 0..6 corrupted bytes in a random header."""
+    rng = np.random.default_rng(99)
+    statuses = {}
+    for trial in range(150):
+        nbits, bits = synth_l2.random_frame(rng)
+        idx, by = oracle.l2_index(bits)
+        st = port.L2_STATUS[idx["status"]]
+        statuses[st] = statuses.get(st, 0) + 1
+        if st in ("hef_overrun", "bad_stream", "too_many_pdus"):
+            continue
+        log = reflib.l2_frames([bits])[0]
+        assert expected_taps(idx, by) == reference_taps(log), (trial, nbits, st)
+    assert statuses.get("end", 0) + statuses.get("bad_locators", 0) >= 40 and statuses.get("header_rs", 0) >= 10, statuses
