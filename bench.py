@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--l2-feedback", type=int, default=1, help="1: the engine applies the reference's L2 -> L1 sync-loss feedback itself (RS check of the first L2 header on the device), as the CPU baseline's frame.c does; 0: off")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no HIP-event kernel timing inside the timed region (roofline fields become 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--l2-index-inline", action="store_true", help="engine option l2_index: index every P1 frame on the decode streams inside the timed region (default: untimed post-pass)")
     ap.add_argument("--no-l2-index", action="store_true", help="skip the (untimed) L2 audio-index property check of the decoded frames")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
@@ -124,7 +125,7 @@ def main():
     total_samples_rank = float(nbytes.astype(np.float64).sum() / 2)
 
     E = eng.Engine(max_streams=S, q15_capacity=int(stride // 4 + 1024), record_capacity=max(256, 16 * n_frames + 32),
-                   p1_slots=n_frames + 1, p1_async=not args.sync_p1, device=local, l2_feedback=bool(args.l2_feedback))
+                   p1_slots=n_frames + 1, p1_async=not args.sync_p1, device=local, l2_feedback=bool(args.l2_feedback), l2_index=bool(args.l2_index_inline))
 
     host_ms = {"reset": 0.0, "append": 0.0, "process": 0.0, "fetch": 0.0}
 
@@ -192,10 +193,15 @@ def main():
     if l2_jobs and not args.no_l2_index:
         try:
             t_l2 = time.perf_counter()
-            idx = E.l2_index(l2_jobs, want_bytes=False)
+            if args.l2_index_inline:
+                ring = E.batch_fetch_l2(S)
+                idx = [(eng.l2_frame_to_dict(ring[j[0]][j[1]]), None) for j in l2_jobs]
+            else:
+                idx = E.l2_index(l2_jobs, want_bytes=False)
             t_l2 = time.perf_counter() - t_l2
             clean = [int(d["n_pdu"] == 1 and d["pdus"][0]["nop"] == 32 and d["pdus"][0]["crc_bad_lo"] == 0 and d["lost_sync"] == 0) for d, _ in idx]
-            l2 = {"frames_indexed": len(idx), "host_ms_incl_copies": round(t_l2 * 1e3, 2),
+            l2 = {"where": "decode streams, inside the timed region" if args.l2_index_inline else "post-pass, untimed",
+                  "frames_indexed": len(idx), "host_ms_incl_copies": round(t_l2 * 1e3, 2),
                   "audio_packets_crc_ok": int(sum(sum(p["nop"] - bin(p["crc_bad_lo"] | (p["crc_bad_hi"] << 32)).count("1") for p in d["pdus"]) for d, _ in idx)),
                   "frames_clean": int(sum(clean)), "clean_and_bit_exact": int(sum(c & e for c, e in zip(clean, l2_exact))),
                   "bit_exact": int(sum(l2_exact)), "frames_flagged_lost_sync": int(sum(d["lost_sync"] for d, _ in idx))}

@@ -108,6 +108,9 @@ typedef struct nrsc5hip_config {
                                   decode completes.  0: the host does it through nrsc5hip_force_resync (the drop-in shim). */
     int am_enable;             /* allocate the AM buffers (1.4 MB per stream) so that streams may be switched to
                                   NRSC5HIP_MODE_AM */
+    int l2_index;              /* 1: every FM P1 frame is also indexed on the decode stream right after its traceback
+                                  (nrsc5hip_l2_frame per ring slot, read with nrsc5hip_l2_frame_get / nrsc5hip_batch_fetch_l2);
+                                  0: indexes only on request (nrsc5hip_l2_index) */
 } nrsc5hip_config;
 
 typedef struct nrsc5hip_engine nrsc5hip_engine;
@@ -225,6 +228,10 @@ typedef struct nrsc5hip_l2_job {
  * headers) go to pdu_bytes + k * stride (stride >= (nbits - pci bits) / 8).  Host buffers. */
 int nrsc5hip_l2_index(nrsc5hip_engine *e, int njobs, const nrsc5hip_l2_job *jobs, nrsc5hip_l2_frame *out,
                       uint8_t *pdu_bytes, long long stride);
+/* engine option l2_index: the index computed in the pipeline for the FM P1 frame in `slot` (the slot a REC_P1 record names) */
+int nrsc5hip_l2_frame_get(nrsc5hip_engine *e, int stream, int slot, nrsc5hip_l2_frame *out);
+/* ... and of every P1 slot of the listed streams: out[nstreams][p1_slots] */
+int nrsc5hip_batch_fetch_l2(nrsc5hip_engine *e, int nstreams, const int *stream_ids, nrsc5hip_l2_frame *out);
 /* stage-level twin: nframes logical frames given as frame_push takes them (one bit per byte, nbits each) */
 int nrsc5hip_stage_l2_index(nrsc5hip_engine *e, const uint8_t *bits, int nbits, int nframes, nrsc5hip_l2_frame *out,
                             uint8_t *pdu_bytes, long long stride);

@@ -365,6 +365,11 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             if (hipMemset(db.px_mem, 0, S * 2 * PX_MEM) != hipSuccess || hipMemset(db.px_pair, 0, S * 4 * PX_MAX) != hipSuccess ||
                 hipMemset(db.px_job, 0xff, S * NWIN * 16 * sizeof(PxJob)) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "PX state init failed"); break; }
         }
+        db.l2_ring = nullptr;
+        if (cfg->l2_index) {
+            if ((rc = dev_alloc(e, &db.l2_ring, S * (size_t)cfg->p1_slots))) break;
+            if (hipMemset(db.l2_ring, 0, S * (size_t)cfg->p1_slots * sizeof(nrsc5hip_l2_frame)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
+        }
         db.am = nullptr; db.am_sym = nullptr; db.am_q = nullptr; db.am_vit = nullptr; db.am_dec = nullptr; db.am_job = nullptr; db.am_ber = nullptr; db.am_pids_stage = nullptr; db.am_pids_rec = nullptr; db.am_nvit = 1;
         if (cfg->am_enable) {
             if ((rc = dev_alloc(e, &db.am, S))) break;
@@ -1024,6 +1029,37 @@ extern "C" int nrsc5hip_l2_index(nrsc5hip_engine *e, int njobs, const nrsc5hip_l
     }
     HIPCHK(hipDeviceSynchronize());                 // the frames may still be in flight on a decode stream
     return l2_run(e, dj, out, pdu_bytes, stride);
+}
+
+extern "C" int nrsc5hip_l2_frame_get(nrsc5hip_engine *e, int stream, int slot, nrsc5hip_l2_frame *out)
+{
+    int rc = check_stream(e, stream); if (rc) return rc;
+    if (!e->db.l2_ring) FAIL(NRSC5HIP_EINVAL, "engine was created without l2_index");
+    if (slot < 0 || slot >= e->db.p1_slots || !out) FAIL(NRSC5HIP_EINVAL, "bad slot/argument");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(out, e->db.l2_ring + (size_t)stream * e->db.p1_slots + slot, sizeof(*out), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int nrsc5hip_batch_fetch_l2(nrsc5hip_engine *e, int nstreams, const int *stream_ids, nrsc5hip_l2_frame *out)
+{
+    if (!e || !out || nstreams < 1) FAIL(NRSC5HIP_EINVAL, "bad argument");
+    if (!e->db.l2_ring) FAIL(NRSC5HIP_EINVAL, "engine was created without l2_index");
+    HIPCHK(hipDeviceSynchronize());
+    const size_t per = (size_t)e->db.p1_slots;
+    bool contiguous = true;
+    for (int k = 0; k < nstreams; k++) {
+        const int s = stream_ids ? stream_ids[k] : k;
+        int rc = check_stream(e, s); if (rc) return rc;
+        if (s != (stream_ids ? stream_ids[0] : 0) + k) contiguous = false;
+    }
+    if (contiguous) {
+        HIPCHK(hipMemcpy(out, e->db.l2_ring + (size_t)(stream_ids ? stream_ids[0] : 0) * per, (size_t)nstreams * per * sizeof(*out), hipMemcpyDeviceToHost));
+    } else {
+        for (int k = 0; k < nstreams; k++)
+            HIPCHK(hipMemcpy(out + (size_t)k * per, e->db.l2_ring + (size_t)stream_ids[k] * per, per * sizeof(*out), hipMemcpyDeviceToHost));
+    }
+    return 0;
 }
 
 extern "C" int nrsc5hip_stage_l2_index(nrsc5hip_engine *e, const uint8_t *bits, int nbits, int nframes, nrsc5hip_l2_frame *out, uint8_t *pdu_bytes, long long stride)

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBu
                 else atomicMax(&st.force_none, st.p1_epoch[parity] + 1);
             }
         }
+        if (db.l2_ring) st.p1_l2slot[parity] = st.p1_slot[parity] + 1;
         st.p1_pending[parity] = 0;
     }
 }
@@ -139,6 +140,7 @@ void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, 
     static const int prio_tb = getenv("NRSC5HIP_PRIO_TB") ? atoi(getenv("NRSC5HIP_PRIO_TB")) : 3;   // short kernel at the end of each decode chain: let it through (measured +1.5 %)
     hipLaunchKernelGGL(k_p1_forward, dim3(nstreams), dim3(64), 0, st, tb, db, stream_ids, parity, lane_id, prio_fwd);
     hipLaunchKernelGGL(k_p1_traceback, dim3(nstreams), dim3(TB_THREADS), traceback_smem(P1_LEN), st, tb, db, stream_ids, parity, lane_id, l2_mode, prio_tb);
+    if (db.l2_ring) launch_l2_index_window(db, nstreams, stream_ids, parity, st);
 }
 
 // ---- stage-level entry: decode `nframes` independent frames of equal length (parity tests) ----------

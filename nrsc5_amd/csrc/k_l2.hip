@@ -18,6 +18,8 @@
 
 namespace nrsc5 {
 
+__device__ inline int stream_of(const int *ids, int idx) { return ids ? ids[idx] : idx; }
+
 struct L2IndexSmem {
     L2Smem rs;
     uint8_t crc_tab[256];
@@ -90,14 +92,10 @@ __device__ inline unsigned l2_parse_hef(const uint8_t *buf, unsigned length, nrs
     return at;
 }
 
-__global__ __launch_bounds__(256) void k_l2_index(const L2Job *jobs, nrsc5hip_l2_frame *frames, uint8_t *bytes_out, long long stride)
+// One workgroup of 256 work-items indexes one frame: w = packed frame bits, dst (may be null) receives the PDU bytes.
+__device__ inline void l2_index_frame(L2IndexSmem &sm, const uint32_t *w, unsigned len, nrsc5hip_l2_frame &out, uint8_t *dst)
 {
-    __shared__ L2IndexSmem sm;
     const int tid = (int)threadIdx.x;
-    const L2Job job = jobs[blockIdx.x];
-    nrsc5hip_l2_frame &out = frames[blockIdx.x];
-    const uint32_t *w = job.words;
-    const unsigned len = (unsigned)job.nbits;
 
     for (unsigned k = (unsigned)tid; k < sizeof(nrsc5hip_l2_frame) / 4u; k += 256u) ((uint32_t *)&out)[k] = 0u;
     {   // CRC-8 table: MSB-first, polynomial 0x31 (the table of frame.c:60-90)
@@ -225,10 +223,32 @@ __global__ __launch_bounds__(256) void k_l2_index(const L2Job *jobs, nrsc5hip_l2
         out.n_pdu = n_pdu; out.status = known ? status : (unsigned)NRSC5HIP_L2_BAD_LENGTH;
         out.end_offset = offset; out.lost_sync = lost;
     }
-    if (bytes_out) {
-        uint8_t *dst = bytes_out + (long long)blockIdx.x * stride;
-        for (unsigned q = (unsigned)tid; q < nbytes; q += 256u) dst[q] = sm.bytes[q];
-    }
+    if (dst) for (unsigned q = (unsigned)tid; q < nbytes; q += 256u) dst[q] = sm.bytes[q];
+}
+
+__global__ __launch_bounds__(256) void k_l2_index(const L2Job *jobs, nrsc5hip_l2_frame *frames, uint8_t *bytes_out, long long stride)
+{
+    __shared__ L2IndexSmem sm;
+    const L2Job job = jobs[blockIdx.x];
+    l2_index_frame(sm, job.words, (unsigned)job.nbits, frames[blockIdx.x], bytes_out ? bytes_out + (long long)blockIdx.x * stride : nullptr);
+}
+
+// Fused variant (engine option l2_index): runs on the decode stream right behind k_p1_traceback and indexes the P1 frame
+// that kernel just finished for this stream, if any, into the slot's entry of the index ring.
+__global__ __launch_bounds__(256) void k_l2_index_window(DevBuffers db, const int *ids, int parity)
+{
+    __shared__ L2IndexSmem sm;
+    const int s = stream_of(ids, blockIdx.x);
+    StreamState &st = db.state[s];
+    const int slot = st.p1_l2slot[parity] - 1;                 // block-uniform; written by k_p1_traceback
+    if (slot < 0) return;
+    l2_index_frame(sm, db.p1_ring + ((size_t)s * db.p1_slots + slot) * P1_WORDS, (unsigned)P1_LEN, db.l2_ring[(size_t)s * db.p1_slots + slot], nullptr);
+    if (threadIdx.x == 0) st.p1_l2slot[parity] = 0;
+}
+
+void launch_l2_index_window(const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_l2_index_window, dim3(nstreams), dim3(256), 0, st, db, stream_ids, parity);
 }
 
 void launch_l2_index(const L2Job *jobs, int njobs, nrsc5hip_l2_frame *frames, uint8_t *bytes_out, long long stride, hipStream_t st)

@@ -65,6 +65,7 @@ struct DevBuffers {
     float *am_ber;                   // [S][p1_slots]  window pipeline: BER of the L1 frame in each ring slot
     int8_t *am_pids_stage;           // [S][NWIN][8][240]  window pipeline: PIDS trellis inputs awaiting k_am_decode
     int *am_pids_rec;                // [S][NWIN][8]       record index of each staged PIDS frame, -1 = empty
+    nrsc5hip_l2_frame *l2_ring;      // [S][p1_slots]  engine option l2_index: audio-transport index of each P1 frame slot (else null)
 };
 
 // ---- K1 -------------------------------------------------------------------------------
@@ -104,6 +105,8 @@ void launch_viterbi_k9_frames(const int8_t *coded, int len, int nframes, unsigne
 constexpr int L2_MAX_BYTES = 18269;
 struct L2Job { const uint32_t *words; int nbits; int pad; };        // packed frame (bit i at words[i / 32] bit i % 32)
 void launch_l2_index(const L2Job *jobs, int njobs, nrsc5hip_l2_frame *frames, uint8_t *bytes_out, long long stride, hipStream_t st);
+// engine option l2_index: index the P1 frames k_p1_traceback finished in decode window `parity` (called by launch_p1_viterbi)
+void launch_l2_index_window(const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st);
 
 // ---- stage-level entry points (parity tests) ---------------------------------------------------
 void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st, int phases = 3);

@@ -132,6 +132,7 @@ struct StreamState {
     int p1_slot[NWIN];             // slot of the stream's P1 ring the decoder must fill
     int p1_record[NWIN];           // record index that gets the BER
     int p1_epoch[NWIN];            // fine_epoch the frame was received in
+    int p1_l2slot[NWIN];           // slot + 1 of a freshly decoded frame awaiting k_l2_index_window, 0 = none
     int p1_endlane[NWIN];
     int p1_pmslot[NWIN];        // which of the stream's NPM soft-bit matrices holds the frame
     int pm_slot;                // matrix being filled; advances after every block 15

@@ -32,7 +32,7 @@ assert RECORD_DTYPE.itemsize == 96
 class _Config(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int), ("max_streams", ctypes.c_int), ("q15_capacity", ctypes.c_longlong),
                 ("record_capacity", ctypes.c_int), ("p1_slots", ctypes.c_int), ("p1_async", ctypes.c_int),
-                ("l2_feedback", ctypes.c_int), ("am_enable", ctypes.c_int)]
+                ("l2_feedback", ctypes.c_int), ("am_enable", ctypes.c_int), ("l2_index", ctypes.c_int)]
 
 
 class L2Pdu(ctypes.Structure):
@@ -121,6 +121,8 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.nrsc5hip_profile.argtypes = [vp, ci, vp, vp]
     lib.nrsc5hip_l2_index.argtypes = [vp, ci, vp, vp, vp, ctypes.c_longlong]
     lib.nrsc5hip_stage_l2_index.argtypes = [vp, vp, ci, ci, vp, vp, ctypes.c_longlong]
+    lib.nrsc5hip_l2_frame_get.argtypes = [vp, ci, ci, vp]
+    lib.nrsc5hip_batch_fetch_l2.argtypes = [vp, ci, vp, vp]
     return lib
 
 
@@ -133,7 +135,7 @@ EXPORTED_SYMBOLS = [
     "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_batch_fetch_view",
     "nrsc5hip_stream_set_mode", "nrsc5hip_am_frame_bits", "nrsc5hip_stage_viterbi_k9", "nrsc5hip_px_frame_bits",
     "nrsc5hip_batch_fetch_px", "nrsc5hip_debug_fetch_px", "nrsc5hip_stage_viterbi_k9_bench",
-    "nrsc5hip_l2_index", "nrsc5hip_stage_l2_index"]
+    "nrsc5hip_l2_index", "nrsc5hip_stage_l2_index", "nrsc5hip_l2_frame_get", "nrsc5hip_batch_fetch_l2"]
 
 
 def unpack_bits(words: np.ndarray, nbits: int) -> np.ndarray:
@@ -146,9 +148,9 @@ class Engine:
 
     def __init__(self, max_streams: int = 1, q15_capacity: int = 1 << 20, record_capacity: int = 256,
                  p1_slots: int = 4, p1_async: bool = False, device: int = 0, lib_path: str | None = None,
-                 am_enable: bool = False, l2_feedback: bool = False):
+                 am_enable: bool = False, l2_feedback: bool = False, l2_index: bool = False):
         self.lib = load_library(lib_path)
-        self.cfg = _Config(device, max_streams, q15_capacity, record_capacity, p1_slots, int(p1_async), int(l2_feedback), int(am_enable))
+        self.cfg = _Config(device, max_streams, q15_capacity, record_capacity, p1_slots, int(p1_async), int(l2_feedback), int(am_enable), int(l2_index))
         self._h = ctypes.c_void_p()
         self._check(self.lib.nrsc5hip_engine_create(ctypes.byref(self.cfg), ctypes.byref(self._h)))
         self.max_streams, self.record_capacity, self.p1_slots = max_streams, record_capacity, p1_slots
@@ -319,6 +321,18 @@ class Engine:
         by = np.zeros((n, stride), dtype=np.uint8) if want_bytes else None
         self._check(self.lib.nrsc5hip_l2_index(self._h, n, arr, out, by.ctypes.data if want_bytes else None, stride))
         return [(l2_frame_to_dict(out[k]), by[k, :out[k].nbytes].copy() if want_bytes else None) for k in range(n)]
+
+    def l2_frame(self, stream: int, slot: int) -> dict:
+        """Engine option l2_index: the index computed in the pipeline for the P1 frame in `slot`."""
+        fr = L2Frame()
+        self._check(self.lib.nrsc5hip_l2_frame_get(self._h, stream, slot, ctypes.byref(fr)))
+        return l2_frame_to_dict(fr)
+
+    def batch_fetch_l2(self, nstreams: int):
+        """[nstreams][p1_slots] L2Frame ctypes array for streams 0..nstreams-1."""
+        out = ((L2Frame * self.p1_slots) * nstreams)()
+        self._check(self.lib.nrsc5hip_batch_fetch_l2(self._h, nstreams, None, out))
+        return out
 
     def stage_l2_index(self, frames_bits: np.ndarray, want_bytes: bool = True):
         """Same kernel on logical frames given as frame_push takes them: frames_bits [nframes][nbits] of 0/1."""

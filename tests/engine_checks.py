@@ -562,3 +562,39 @@ def check_deferred_feedback_recovers(lib, n_blocks=256):
     assert good[0][0] == 0 and good[0][1] == 0 and good[0][2] >= total - 2, good     # without feedback the two false locks never recover
     assert good[1][0] >= 1 and good[1][1] >= 1 and good[1][2] == good[0][2], good    # late (deferred decode), but they come back
     return good
+
+
+def check_l2_index_fused(lib, oracle, p1_async=False):
+    """Engine option l2_index: the index written on the decode stream behind each P1 traceback == the post-pass index
+    == the oracle's, for every P1 slot the records name (streaming getter and bulk fetch)."""
+    caps = [synth.fm_mp1_capture(2, seed=61 + k, cfo_hz=c, offset=o, snr_db=22) for k, (c, o) in enumerate([(25.0, 400), (-310.0, 3100)])]
+    n = len(caps)
+    E = eng.Engine(max_streams=n, q15_capacity=max(c.iq.size for c in caps) // 4 + 200000, record_capacity=256, p1_slots=4,
+                   lib_path=lib, p1_async=p1_async, l2_index=True, l2_feedback=True)
+    for k, c in enumerate(caps):
+        common.run_engine_streaming(E, k, c.iq, chunk=32768 * 8)
+    bulk = E.batch_fetch_l2(n)
+    seen = 0
+    for k in range(n):
+        recs = E.drain(k)
+        jobs = eng.l2_jobs_from_records(k, recs)
+        assert jobs, "no P1 frame decoded"
+        post = E.l2_index(jobs, want_bytes=False)
+        for job, (pi, _) in zip(jobs, post):
+            fused = E.l2_frame(k, job[1])
+            oi, _ = oracle.l2_index(E.p1_frame_bits(k, job[1]))
+            assert fused == pi == oi, (job, {key: (fused[key], oi[key]) for key in oi if fused[key] != oi[key]})
+            assert eng.l2_frame_to_dict(bulk[k][job[1]]) == oi
+            assert fused["n_pdu"] == 1 and fused["pdus"][0]["nop"] == 32 and fused["pdus"][0]["crc_bad_lo"] == 0
+            seen += 1
+    assert seen >= 2 * n - 1
+    E.close()
+    # without the option the getters refuse, loudly
+    E = eng.Engine(max_streams=1, lib_path=lib)
+    for call in (lambda: E.l2_frame(0, 0), lambda: E.batch_fetch_l2(1)):
+        try:
+            call()
+            raise AssertionError("l2 getter worked without l2_index")
+        except eng.Nrsc5HipError:
+            pass
+    E.close()

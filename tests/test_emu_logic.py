@@ -125,3 +125,7 @@ def test_emu_l2_index_every_branch(emu_lib, oracle):
 def test_emu_l2_index_end_to_end(emu_lib, oracle):
     ec.check_l2_index_end_to_end(emu_lib, oracle, am=True)
     ec.check_l2_index_end_to_end(emu_lib, oracle, am=False, mode="MP3")
+
+
+def test_emu_l2_index_fused_into_decode(emu_lib, oracle):
+    ec.check_l2_index_fused(emu_lib, oracle, p1_async=True)

@@ -266,3 +266,9 @@ def test_gpu_l2_index_every_branch(hip_lib, oracle):
 def test_gpu_l2_index_end_to_end(hip_lib, oracle, kw):
     """IQ -> frames in HBM -> index, in-order and through the decode windows (FM P1 / P3 / P4, AM P1 / P3)."""
     ec.check_l2_index_end_to_end(hip_lib, oracle, **kw)
+
+
+@pytest.mark.parametrize("p1_async", [False, True])
+def test_gpu_l2_index_fused_into_decode(hip_lib, oracle, p1_async):
+    """Engine option l2_index: index kernel on the decode stream behind each P1 traceback == post-pass == oracle."""
+    ec.check_l2_index_fused(hip_lib, oracle, p1_async=p1_async)
