@@ -985,23 +985,25 @@ extern "C" int nrsc5hip_am_frame_bits(nrsc5hip_engine *e, int stream, int slot, 
 }
 
 // ---- L2 audio transport index ---------------------------------------------------------------------------------------
+struct DevTmp { void *p = nullptr; ~DevTmp() { if (p) (void)hipFree(p); } };
+
 static int l2_run(nrsc5hip_engine *e, const std::vector<L2Job> &jobs, nrsc5hip_l2_frame *out, uint8_t *pdu_bytes, long long stride)
 {
     const int n = (int)jobs.size();
     if (pdu_bytes && stride < L2_MAX_BYTES) {
         for (const L2Job &j : jobs) if ((j.nbits - 22) / 8 > stride) FAIL(NRSC5HIP_EINVAL, "stride %lld too small for a %d-bit frame", stride, j.nbits);
     }
-    L2Job *djobs = nullptr; nrsc5hip_l2_frame *dout = nullptr; uint8_t *dbytes = nullptr;
-    HIPCHK(hipMalloc((void **)&djobs, sizeof(L2Job) * n));
-    HIPCHK(hipMalloc((void **)&dout, sizeof(nrsc5hip_l2_frame) * n));
-    if (pdu_bytes) HIPCHK(hipMalloc((void **)&dbytes, (size_t)stride * n));
+    DevTmp tj, to, tb;                                  // freed on every return path
+    HIPCHK(hipMalloc(&tj.p, sizeof(L2Job) * n));
+    HIPCHK(hipMalloc(&to.p, sizeof(nrsc5hip_l2_frame) * n));
+    if (pdu_bytes) HIPCHK(hipMalloc(&tb.p, (size_t)stride * n));
+    L2Job *djobs = (L2Job *)tj.p; nrsc5hip_l2_frame *dout = (nrsc5hip_l2_frame *)to.p; uint8_t *dbytes = (uint8_t *)tb.p;
     HIPCHK(hipMemcpy(djobs, jobs.data(), sizeof(L2Job) * n, hipMemcpyHostToDevice));
     launch_l2_index(djobs, n, dout, dbytes, stride, e->main);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(e->main));
     HIPCHK(hipMemcpy(out, dout, sizeof(nrsc5hip_l2_frame) * n, hipMemcpyDeviceToHost));
     if (pdu_bytes) HIPCHK(hipMemcpy(pdu_bytes, dbytes, (size_t)stride * n, hipMemcpyDeviceToHost));
-    (void)hipFree(djobs); (void)hipFree(dout); if (dbytes) (void)hipFree(dbytes);
     return 0;
 }
 
@@ -1069,14 +1071,13 @@ extern "C" int nrsc5hip_stage_l2_index(nrsc5hip_engine *e, const uint8_t *bits, 
     std::vector<uint32_t> w((size_t)words * nframes, 0u);
     for (int f = 0; f < nframes; f++)
         for (int i = 0; i < nbits; i++) w[(size_t)f * words + (i >> 5)] |= (uint32_t)(bits[(size_t)f * nbits + i] & 1u) << (i & 31);
-    uint32_t *dw = nullptr;
-    HIPCHK(hipMalloc((void **)&dw, w.size() * sizeof(uint32_t)));
+    DevTmp tw;
+    HIPCHK(hipMalloc(&tw.p, w.size() * sizeof(uint32_t)));
+    uint32_t *dw = (uint32_t *)tw.p;
     HIPCHK(hipMemcpy(dw, w.data(), w.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     std::vector<L2Job> dj((size_t)nframes);
     for (int f = 0; f < nframes; f++) dj[f] = L2Job{dw + (size_t)f * words, nbits, 0};
-    const int rc = l2_run(e, dj, out, pdu_bytes, stride);
-    (void)hipFree(dw);
-    return rc;
+    return l2_run(e, dj, out, pdu_bytes, stride);
 }
 
 extern "C" int nrsc5hip_stage_viterbi_k9(nrsc5hip_engine *e, const int8_t *soft, int len, int nframes, const unsigned gens[3], uint8_t *bits)
