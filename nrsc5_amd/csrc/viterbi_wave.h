@@ -196,7 +196,20 @@ struct SoftContig {
     {
         return ((int)(uint8_t)coded[3 * j]) | ((int)(uint8_t)coded[3 * j + 1] << 8) | ((int)(uint8_t)coded[3 * j + 2] << 16);
     }
+    // the same three bytes as two raw loads whose assembly the caller postpones (see viterbi_fast_forward)
+    __device__ __forceinline__ void raw(int j, int &b01, int &b2) const
+    {
+        b01 = ((int)(uint8_t)coded[3 * j]) | ((int)(uint8_t)coded[3 * j + 1] << 8);
+        b2 = (int)(uint8_t)coded[3 * j + 2];
+    }
 };
+// Pin two just-loaded values at this point of the instruction stream: the compiler must have them in registers here (so
+// its s_waitcnt lands here and not right behind the loads) and may not assemble them any earlier.
+#ifdef HIPEMU
+__device__ inline void vit_pin_loaded(int &, int &) {}
+#else
+__device__ __forceinline__ void vit_pin_loaded(int &a, int &b) { asm volatile("" : "+v"(a), "+v"(b)); }
+#endif
 template <typename Src> __device__ __forceinline__ int vit_soft_word(const Src &src, int t)
 {
     const int len = src.length();
@@ -261,7 +274,12 @@ __device__ inline int viterbi_fast_forward(const Src &src, unsigned long long *d
     int aw = vit_soft_word(src, lane);
     int aw1 = vit_soft_word(src, 64 + lane);                   // nchunks >= 2 always (len >= 64)
     for (int c = 0; c < nchunks; c++) {
-        const int aw2 = (c + 2 < nchunks) ? vit_soft_word(src, 64 * (c + 2) + lane) : 0;
+        // Soft triple of chunk c + 2: the loads are issued here, but nothing touches their result until the 64 steps of
+        // this chunk are done -- the SQ counters showed the wave parked a quarter of its life on the s_waitcnt that sat
+        // right behind these loads when the three bytes were assembled at once.  Index clamped instead of branched on.
+        const int cn = (c + 2 < nchunks) ? c + 2 : nchunks - 1;
+        int b01, b2;
+        src.raw((len - VIT_EXTRA + 64 * cn + lane) % len, b01, b2);
         int wlo = 0, whi = 0;
         switch (c % 3) {
         case 0: VitFwd<0, 0>::run(pm, aw, k, vit_branch_metric<0>(aw, 0, k), 0ull, wlo, whi); break;
@@ -269,7 +287,8 @@ __device__ inline int viterbi_fast_forward(const Src &src, unsigned long long *d
         default: VitFwd<2, 0>::run(pm, aw, k, vit_branch_metric<2>(aw, 0, k), 0ull, wlo, whi); break;
         }
         dec[64 * c + lane] = ((unsigned long long)(uint32_t)whi << 32) | (uint32_t)wlo;
-        aw = aw1; aw1 = aw2;
+        vit_pin_loaded(b01, b2);
+        aw = aw1; aw1 = b01 | (b2 << 16);
     }
     const int rend = (64 * nchunks) % 6;
     const int best = wave_max_i32(pm);
