@@ -204,3 +204,40 @@ def run_engine_streaming(E, stream, iq, chunk=32768 * 8):
             E.push_cu8(stream, part[:part.size - part.size % 4])
         else:
             E.push_cs16(stream, part[:part.size - part.size % 2])
+
+
+# ---- L2 audio-transport index: what frame_process does with a frame, from the index alone / from the reference's taps ----
+def l2_expected_taps(idx, by):
+    """What frame_process does with a frame, derived from the index alone (frame.c:600-640, 535-540)."""
+    out = []
+    for d in idx["pdus"]:
+        if d["skipped"]:
+            continue
+        out.append(("l2align", d["prog_num"], d["stream_id"], d["align_offset"]))
+        off = d["audio_off"]
+        bad = d["crc_bad_lo"] | (d["crc_bad_hi"] << 32)
+        for j, loc in enumerate(d["loc"]):
+            shape = 3 if (j == 0 and d["pfirst"]) else 2 if (j == d["nop"] - 1 and d["plast"]) else 1   # HALF_BACK / HALF_FRONT / FULL
+            out.append(("l2pkt", d["prog_num"], d["stream_id"], (d["elastic_seq"] + j) % 64, loc - off, (bad >> j) & 1, shape, bytes(by[off:loc + 1])))
+            off = loc + 1
+    if idx["lost_sync"]:
+        out.append(("state", 2, 0))
+    return out
+
+
+def l2_reference_taps(log):
+    out = []
+    for k, v in log:
+        if k == "l2align":
+            out.append((k, v["program"], v["stream_id"], v["offset"]))
+        elif k == "l2pkt":
+            out.append((k, v["program"], v["stream_id"], v["seq"], v["size"], v["flags"], v["shape"], bytes(v["data"])))
+        elif k == "state":
+            out.append((k, v["old"], v["new"]))
+    return out
+
+
+def l2_taps_digest(taps):
+    """JSON-able form of a tap list: packet payloads replaced by their CRC-32."""
+    import zlib
+    return [list(t[:-1]) + [zlib.crc32(t[-1])] if t[0] == "l2pkt" else list(t) for t in taps]

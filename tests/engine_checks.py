@@ -598,3 +598,25 @@ def check_l2_index_fused(lib, oracle, p1_async=False):
         except eng.Nrsc5HipError:
             pass
     E.close()
+
+
+def check_l2_index_vs_reference_golden(lib):
+    """Device index -> the output_align / output_push calls it implies == the calls the UNMODIFIED reference made for the
+    same frames (tests/golden/l2_reference_taps.json, recorded by tests/golden/make_golden_l2.py).  No oracle involved."""
+    import hashlib
+    import json
+    from nrsc5_amd import synth_l2
+    gold = json.load(open(os.path.join(GOLDEN_DIR, "l2_reference_taps.json")))
+    E = eng.Engine(max_streams=1, lib_path=lib)
+    checked = 0
+    for nbits in sorted(synth_l2.LAYOUT):
+        frames = {name: bits for name, bits, _ in synth_l2.test_frames(nbits)}
+        cases = gold[str(nbits)]
+        stack = np.stack([frames[c["name"]] for c in cases])
+        for c, (gi, gb) in zip(cases, E.stage_l2_index(stack)):
+            assert hashlib.sha1(frames[c["name"]].tobytes()).hexdigest() == c["bits_sha1"], "test-frame generator drifted: regenerate the golden"
+            got = json.loads(json.dumps(common.l2_taps_digest(common.l2_expected_taps(gi, gb))))
+            assert got == c["taps"], (nbits, c["name"])
+            checked += len(got)
+    assert checked > 1500
+    E.close()

@@ -129,3 +129,7 @@ def test_emu_l2_index_end_to_end(emu_lib, oracle):
 
 def test_emu_l2_index_fused_into_decode(emu_lib, oracle):
     ec.check_l2_index_fused(emu_lib, oracle, p1_async=True)
+
+
+def test_emu_l2_index_vs_reference_golden(emu_lib):
+    ec.check_l2_index_vs_reference_golden(emu_lib)

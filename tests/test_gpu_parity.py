@@ -272,3 +272,8 @@ def test_gpu_l2_index_end_to_end(hip_lib, oracle, kw):
 def test_gpu_l2_index_fused_into_decode(hip_lib, oracle, p1_async):
     """Engine option l2_index: index kernel on the decode stream behind each P1 traceback == post-pass == oracle."""
     ec.check_l2_index_fused(hip_lib, oracle, p1_async=p1_async)
+
+
+def test_gpu_l2_index_vs_reference_golden(hip_lib):
+    """Device index vs the calls the unmodified reference's frame_push made for the same frames (committed golden)."""
+    ec.check_l2_index_vs_reference_golden(hip_lib)

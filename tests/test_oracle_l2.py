@@ -9,34 +9,7 @@ from oracle import port
 from nrsc5_amd import synth_l2
 
 
-def expected_taps(idx, by):
-    """What frame_process does with a frame, derived from the index alone (frame.c:600-640, 535-540)."""
-    out = []
-    for d in idx["pdus"]:
-        if d["skipped"]:
-            continue
-        out.append(("l2align", d["prog_num"], d["stream_id"], d["align_offset"]))
-        off = d["audio_off"]
-        bad = d["crc_bad_lo"] | (d["crc_bad_hi"] << 32)
-        for j, loc in enumerate(d["loc"]):
-            shape = 3 if (j == 0 and d["pfirst"]) else 2 if (j == d["nop"] - 1 and d["plast"]) else 1   # HALF_BACK / HALF_FRONT / FULL
-            out.append(("l2pkt", d["prog_num"], d["stream_id"], (d["elastic_seq"] + j) % 64, loc - off, (bad >> j) & 1, shape, bytes(by[off:loc + 1])))
-            off = loc + 1
-    if idx["lost_sync"]:
-        out.append(("state", 2, 0))
-    return out
-
-
-def reference_taps(log):
-    out = []
-    for k, v in log:
-        if k == "l2align":
-            out.append((k, v["program"], v["stream_id"], v["offset"]))
-        elif k == "l2pkt":
-            out.append((k, v["program"], v["stream_id"], v["seq"], v["size"], v["flags"], v["shape"], bytes(v["data"])))
-        elif k == "state":
-            out.append((k, v["old"], v["new"]))
-    return out
+from tests.common import l2_expected_taps as expected_taps, l2_reference_taps as reference_taps  # noqa: E402
 
 
 @pytest.mark.parametrize("nbits", sorted(synth_l2.LAYOUT))
@@ -103,3 +76,21 @@ def test_l2_index_random_structures_match_reference(oracle, reflib):
         log = reflib.l2_frames([bits])[0]
         assert expected_taps(idx, by) == reference_taps(log), (trial, nbits, st)
     assert statuses.get("end", 0) + statuses.get("bad_locators", 0) >= 40 and statuses.get("header_rs", 0) >= 10, statuses
+
+
+def test_l2_golden_is_current(oracle, reflib):
+    """The committed golden equals what the reference produces now, and the oracle's index implies the same calls."""
+    import hashlib
+    import json
+    import os
+    from tests import common
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "l2_reference_taps.json")))
+    for nbits in sorted(synth_l2.LAYOUT):
+        frames = {name: bits for name, bits, _ in synth_l2.test_frames(nbits)}
+        for c in gold[str(nbits)]:
+            bits = frames[c["name"]]
+            assert hashlib.sha1(bits.tobytes()).hexdigest() == c["bits_sha1"]
+            now = json.loads(json.dumps(common.l2_taps_digest(reference_taps(reflib.l2_frames([bits])[0]))))
+            idx, by = oracle.l2_index(bits)
+            mine = json.loads(json.dumps(common.l2_taps_digest(expected_taps(idx, by))))
+            assert now == c["taps"] == mine, (nbits, c["name"])
