@@ -40,6 +40,9 @@ SAMPLES_PER_LAUNCH = {"decimate": None, "acquire": BLOCK_SAMPLES, "prepare": BLO
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--workload", default="fm", choices=["fm", "am-cs16", "am-cu8", "mixed"],
+                    help="fm (default): the headline metric, configs[2]; the others run the side measurements of BASELINE "
+                         "configs[4] (tools/gpu_am_bench.py, tools/gpu_mixed_bench.py; single GPU, their own JSON line)")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
@@ -86,8 +89,21 @@ def cpu_baseline(stream_iq: np.ndarray, budget_s: float):
             "kind": kind, "sample": f"{reps}x one {nsamp / FS:.1f}-s stream of this workload on 1 host core, 32768-byte pushes"}
 
 
+def side_workload(args):
+    """BASELINE configs[4] side measurements live in tools/ (same engine, same C ABI); dispatch to them."""
+    import runpy
+    if args.workload == "mixed":
+        sys.argv = [os.path.join(ROOT, "tools", "gpu_mixed_bench.py"), "--steps", str(args.steps)]
+    else:
+        sys.argv = [os.path.join(ROOT, "tools", "gpu_am_bench.py"), "--fmt", args.workload.split("-")[1],
+                    "--streams", str(256 if args.workload == "am-cs16" else 128), "--steps", str(args.steps), "--warmup", str(args.warmup)]
+    runpy.run_path(sys.argv[0], run_name="__main__")
+
+
 def main():
     args = parse()
+    if args.workload != "fm":
+        return side_workload(args)
     import torch
     from nrsc5_amd import engine as eng, shard, synth_torch as stt
 
