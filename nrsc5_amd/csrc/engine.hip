@@ -422,15 +422,15 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
 extern "C" void nrsc5hip_engine_destroy(nrsc5hip_engine *e)
 {
     if (!e) return;
-    hipDeviceSynchronize();
-    for (void *p : e->allocs) hipFree(p);
+    (void)hipDeviceSynchronize();
+    for (void *p : e->allocs) (void)hipFree(p);
     for (hipEvent_t ev : e->dec_events) (void)hipEventDestroy(ev);
     if (e->dec_stream) (void)hipStreamDestroy(e->dec_stream);
     if (e->rec_host) (void)hipHostFree(e->rec_host);
     if (e->frames_host) (void)hipHostFree(e->frames_host);
     if (e->nblocks_host) (void)hipHostFree(e->nblocks_host);
-    for (auto &sp : e->prof_spans) { hipEventDestroy(sp.a); hipEventDestroy(sp.b); }
-    for (hipEvent_t ev : e->prof_pool) hipEventDestroy(ev);
+    for (auto &sp : e->prof_spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
+    for (hipEvent_t ev : e->prof_pool) (void)hipEventDestroy(ev);
     for (int l = 0; l < e->nlanes; l++) {
         nrsc5hip_engine::Lane &ln = e->lanes[l];
         if (ln.counters_host) (void)hipHostFree(ln.counters_host);
@@ -1145,7 +1145,7 @@ extern "C" int nrsc5hip_stage_fft2048(nrsc5hip_engine *e, const float *in, float
     launch_fft2048(e->tb, din, dout, n, e->main);
     HIPCHK(hipStreamSynchronize(e->main));
     HIPCHK(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
-    hipFree(din); hipFree(dout);
+    (void)hipFree(din); (void)hipFree(dout);
     return 0;
 }
 
@@ -1163,7 +1163,7 @@ extern "C" int nrsc5hip_stage_viterbi_k7(nrsc5hip_engine *e, const int8_t *soft,
     std::vector<uint32_t> w((size_t)nframes * words);
     HIPCHK(hipMemcpy(w.data(), dout, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (int f = 0; f < nframes; f++) nrsc5hip_unpack_bits(w.data() + (size_t)f * words, len, bits + (size_t)f * len);
-    hipFree(dsoft); hipFree(ddec); hipFree(dout);
+    (void)hipFree(dsoft); (void)hipFree(ddec); (void)hipFree(dout);
     return 0;
 }
 
