@@ -346,6 +346,17 @@ class Engine:
         self._check(self.lib.nrsc5hip_stage_l2_index(self._h, b.ctypes.data, nbits, n, out, by.ctypes.data if want_bytes else None, stride))
         return [(l2_frame_to_dict(out[k]), by[k, :out[k].nbytes].copy() if want_bytes else None) for k in range(n)]
 
+    def stage_l2_index_raw(self, frames_bits: np.ndarray):
+        """As stage_l2_index, but returns the C structs themselves: (L2Frame ctypes array, PDU bytes [n, 18272])."""
+        b = np.ascontiguousarray(frames_bits, dtype=np.uint8)
+        if b.ndim == 1:
+            b = b[None, :]
+        n, nbits = b.shape
+        out = (L2Frame * n)()
+        by = np.zeros((n, 18272), dtype=np.uint8)
+        self._check(self.lib.nrsc5hip_stage_l2_index(self._h, b.ctypes.data, nbits, n, out, by.ctypes.data, 18272))
+        return out, by
+
     def stage_viterbi_k7_debug(self, soft: np.ndarray, length: int):
         soft = np.ascontiguousarray(soft, dtype=np.int8)
         bits = np.zeros(length, dtype=np.uint8)

@@ -229,3 +229,56 @@ def random_frame(rng: np.random.Generator):
         body = corrupt(body, base + rng.choice(96, size=int(rng.integers(1, 7)), replace=False), rng)
     bits = frame_from_bytes(body, nbits, pci=int(rng.choice([PCI_AUDIO, PCI_AUDIO_OPP])), tail=None if rng.random() < 0.7 else b"\xa5")
     return nbits, bits
+
+
+def fcs16(data: bytes) -> int:
+    """PPP FCS-16 (RFC 1662; the table of frame.c:92-125): reflected 0x8408, initial value 0xFFFF."""
+    crc = 0xFFFF
+    for b in data:
+        crc ^= b
+        for _ in range(8):
+            crc = (crc >> 1) ^ 0x8408 if crc & 1 else crc >> 1
+    return crc
+
+
+def hdlc_frame(payload: bytes) -> bytes:
+    """One HDLC frame as parse_hdlc / aas_push expect it (frame.c:330-391): 0x7E, escaped payload + FCS, 0x7E."""
+    body = payload + (fcs16(payload) ^ 0xFFFF).to_bytes(2, "little")
+    out = bytearray([0x7E])
+    for b in body:
+        if b in (0x7E, 0x7D):
+            out += bytes([0x7D, b ^ 0x20])
+        else:
+            out.append(b)
+    out.append(0x7E)
+    return bytes(out)
+
+
+def psd_sequence(seed: int = 0, nbits: int = 146176, n_frames: int = 6):
+    """Frames whose PDUs carry a PSD byte stream for two programs: AAS packets (protocol 0x21, good and bad FCS, escaped
+    bytes) cut at arbitrary places so that HDLC frames span PDUs and logical frames, plus changing service parameters."""
+    rng = np.random.default_rng(seed)
+    streams = {}
+    for prog in (0, 3):
+        s = bytearray()
+        for k in range(12):
+            pay = bytes([0x21]) + rng.integers(0, 256, size=int(rng.integers(5, 60)), dtype=np.uint8).tobytes() + (b"\x7e\x7d" if k % 3 == 0 else b"")
+            f = bytearray(hdlc_frame(pay))
+            if k % 5 == 4:
+                f[3] ^= 0x10                                   # broken FCS: dropped by aas_push
+            s += f + b"\x7e" * int(rng.integers(0, 3))
+        streams[prog] = bytes(s)
+    pos = {0: 0, 3: 0}
+    frames = []
+    n = pdu_bytes_of(nbits)
+    for fi in range(n_frames):
+        pdus = []
+        for prog in (0, 3):
+            take = int(rng.integers(10, 70))
+            psd = streams[prog][pos[prog]:pos[prog] + take]
+            pos[prog] += take
+            pdus.append(make_pdu(rng, min(n // 3, 3500), nop=4 + fi % 3, codec_mode=0 if prog == 0 else 13, seq=(7 * fi) % 64, pdu_seq=fi % 8,
+                                 hef=hef_bytes(prog_num=prog, access=fi // 4 % 2, prog_type=10 + fi // 3) if prog else b"",
+                                 psd=psd, latency=fi // 2 % 8, blend=fi // 3 % 4, common_delay=fi // 2 % 64))
+        frames.append(frame_from_bytes(b"".join(pdus), nbits))
+    return frames

@@ -195,6 +195,15 @@ class Oracle:
             raise ValueError("unknown frame length %d" % b.size)
         return l2_frame_to_dict(fr), by[:fr.nbytes].copy()
 
+    def l2_index_struct(self, bits: np.ndarray):
+        """(ctypes struct with the nrsc5hip_l2_frame layout, PDU bytes) -- what a consumer of the C ABI receives."""
+        b = np.ascontiguousarray(bits, dtype=np.uint8)
+        fr = L2Frame()
+        by = np.zeros(b.size // 8 + 8, dtype=np.uint8)
+        if self.lib.orc_l2_index(b.ctypes.data, b.size, ctypes.addressof(fr), by.ctypes.data) != 0:
+            raise ValueError("unknown frame length %d" % b.size)
+        return fr, by[:fr.nbytes].copy()
+
     def l2_hook(self):
         """p1_hook for run(): drop to SYNC_NONE exactly when the reference's frame_process would."""
         return lambda bits: 0 if self.l2_first_header_ok(bits) else 1

@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 TAP_Q15, TAP_FFT, TAP_SOFT, TAP_VIT, TAP_HDC, TAP_L2 = 1, 2, 4, 8, 16, 32
-REC_BLOCK, REC_STATE, REC_SOFT, REC_PIDS, REC_FRAME, REC_SYNC, REC_LOST_SYNC, REC_MER, REC_BER, REC_HDC, REC_VIT, REC_AMSYM, REC_PXSOFT, REC_STATION, REC_L2PKT, REC_L2ALIGN = range(1, 17)
+REC_BLOCK, REC_STATE, REC_SOFT, REC_PIDS, REC_FRAME, REC_SYNC, REC_LOST_SYNC, REC_MER, REC_BER, REC_HDC, REC_VIT, REC_AMSYM, REC_PXSOFT, REC_STATION, REC_L2PKT, REC_L2ALIGN, REC_L2AAS, REC_L2SVC = range(1, 19)
 MODE_FM, MODE_AM = 0, 1
 
 BLOCK_FIELDS = ("state_before", "state_after", "samperr", "cfo", "keep", "bc", "psmi", "cfo_wait",
@@ -37,6 +37,7 @@ class RefLib:
         L.refh_buf.restype = ctypes.c_size_t
         L.refh_sizeof_session.restype = ctypes.c_size_t
         L.refh_frame_push.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        L.refh_frame_push_indexed.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         for name in ("nrsc5_conv_decode_p1", "nrsc5_conv_decode_pids"):
             getattr(L, name).argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         L.nrsc5_conv_decode_p3_p4.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
@@ -76,6 +77,23 @@ class RefLib:
             for bits in frames:
                 b = np.ascontiguousarray(bits, dtype=np.uint8)
                 self.lib.refh_frame_push(b.ctypes.data, b.size, lc)
+                log = self._buf(0)
+                out.append(parse_log(log[seen:]))
+                seen = len(log)
+        finally:
+            self.lib.refh_close()
+        return out
+
+    def l2_frames_indexed(self, items, mode: int = MODE_FM, lc: int = 0):
+        """Same taps as l2_frames, but every frame enters through frame_push_indexed (oracle/ref_shim/frame_indexed.c):
+        items = (ctypes index struct with the nrsc5hip_l2_frame layout, PDU bytes) per frame, one session."""
+        if self.lib.refh_open(mode, TAP_L2 | TAP_HDC, 0) != 0:
+            raise RuntimeError("refh_open failed")
+        out, seen = [], 0
+        try:
+            for ix, by in items:
+                b = np.ascontiguousarray(by, dtype=np.uint8)
+                self.lib.refh_frame_push_indexed(ctypes.addressof(ix), b.ctypes.data, lc)
                 log = self._buf(0)
                 out.append(parse_log(log[seen:]))
                 seen = len(log)
@@ -151,6 +169,10 @@ def parse_log(log: bytes):
         elif kind == REC_L2ALIGN:
             prog, sid, align = struct.unpack("<3I", pl)
             out.append(("l2align", {"program": prog, "stream_id": sid, "offset": align}))
+        elif kind == REC_L2AAS:
+            out.append(("l2aas", {"data": bytes(pl)}))
+        elif kind == REC_L2SVC:
+            out.append(("l2svc", dict(zip(("program", "access", "type", "codec_mode", "blend_control", "digital_audio_gain", "common_delay", "latency"), struct.unpack("<8i", pl)))))
         elif kind == REC_STATION:
             fcc, cc = struct.unpack("<i4s", pl)
             out.append(("station", {"fcc": fcc, "country": cc.rstrip(b"\0").decode()}))

@@ -21,7 +21,7 @@ enum {
 /* ordered log record kinds */
 enum {
     REC_BLOCK = 1, REC_STATE, REC_SOFT, REC_PIDS, REC_FRAME, REC_SYNC, REC_LOST_SYNC,
-    REC_MER, REC_BER, REC_HDC, REC_VIT, REC_AMSYM, REC_PXSOFT, REC_STATION, REC_L2PKT, REC_L2ALIGN
+    REC_MER, REC_BER, REC_HDC, REC_VIT, REC_AMSYM, REC_PXSOFT, REC_STATION, REC_L2PKT, REC_L2ALIGN, REC_L2AAS, REC_L2SVC
 };
 
 typedef struct { uint8_t *p; size_t len, cap; } gbuf;
@@ -189,6 +189,13 @@ void __wrap_output_align(output_t *st, unsigned int program, unsigned int stream
     __real_output_align(st, program, stream_id, offset);
 }
 
+void __real_output_aas_push(output_t *st, uint8_t *psd, unsigned int len);
+void __wrap_output_aas_push(output_t *st, uint8_t *psd, unsigned int len)
+{
+    if (g_taps & REFH_TAP_L2) log_rec(REC_L2AAS, psd, len);
+    __real_output_aas_push(st, psd, len);
+}
+
 /* ---- public-API event callback ------------------------------------------------ */
 static void on_event(const nrsc5_event_t *evt, void *opaque)
 {
@@ -205,6 +212,15 @@ static void on_event(const nrsc5_event_t *evt, void *opaque)
         struct { int32_t fcc; char cc[4]; } r = { evt->station_id.fcc_facility_id, { 0, 0, 0, 0 } };
         strncpy(r.cc, evt->station_id.country_code, 3);
         log_rec(REC_STATION, &r, sizeof(r)); break; }
+    case NRSC5_EVENT_AUDIO_SERVICE: {
+        if (g_taps & REFH_TAP_L2) {
+            int32_t r[8] = { (int32_t)evt->audio_service.program, (int32_t)evt->audio_service.access, (int32_t)evt->audio_service.type,
+                             (int32_t)evt->audio_service.codec_mode, (int32_t)evt->audio_service.blend_control,
+                             (int32_t)evt->audio_service.digital_audio_gain, (int32_t)evt->audio_service.common_delay,
+                             (int32_t)evt->audio_service.latency };
+            log_rec(REC_L2SVC, r, sizeof(r));
+        }
+        break; }
     case NRSC5_EVENT_HDC: {
         size_t n = (g_taps & REFH_TAP_HDC) ? evt->hdc.count : 0;
         uint8_t *tmp = malloc(12 + n);
@@ -254,6 +270,14 @@ void refh_frame_push(const uint8_t *bits, size_t length, int lc)
     g_radio->input.sync_state = SYNC_STATE_FINE;
     __real_frame_push(&g_radio->input.frame, tmp, length, (logical_channel_t)lc);
     free(tmp);
+}
+/* the same frame through the entry point a maintainer would add for the device's L2 index (ref_shim/frame_indexed.c) */
+struct nrsc5hip_l2_frame;
+void frame_push_indexed(frame_t *st, const struct nrsc5hip_l2_frame *ix, const uint8_t *pdu_bytes, logical_channel_t lc);
+void refh_frame_push_indexed(const void *ix, const uint8_t *pdu_bytes, int lc)
+{
+    g_radio->input.sync_state = SYNC_STATE_FINE;
+    frame_push_indexed(&g_radio->input.frame, (const struct nrsc5hip_l2_frame *)ix, pdu_bytes, (logical_channel_t)lc);
 }
 void refh_force_resync(void) { input_set_sync_state(&g_radio->input, SYNC_STATE_NONE); }
 void refh_close(void) { if (g_radio) { nrsc5_close(g_radio); g_radio = NULL; } }

@@ -620,3 +620,27 @@ def check_l2_index_vs_reference_golden(lib):
             checked += len(got)
     assert checked > 1500
     E.close()
+
+
+def check_frame_push_indexed_with_device_index(lib, reflib):
+    """The device's index (C-ABI structs exactly as nrsc5hip_stage_l2_index returns them) fed to frame_push_indexed inside
+    the unmodified reference (oracle/ref_shim/frame_indexed.c) makes it do what its own frame_push does with the bits:
+    output_align / output_push / AAS packets / audio-service reports / HDC events / sync loss, over whole sessions."""
+    from nrsc5_amd import synth_l2
+    from tests.test_oracle_l2 import _all_l2_taps
+    E = eng.Engine(max_streams=1, lib_path=lib)
+    sessions = [synth_l2.psd_sequence(seed=1), synth_l2.psd_sequence(seed=2, nbits=24000, n_frames=4),
+                [b for _, b, safe in synth_l2.test_frames(146176, seed=7) if safe]]
+    skip = {eng.L2_STATUS.index(s) for s in ("fixed_data", "hef_overrun", "bad_stream", "too_many_pdus")}
+    n_pkt = n_aas = 0
+    for frames in sessions:
+        structs, by = E.stage_l2_index_raw(np.stack(frames))
+        keep = [k for k in range(len(frames)) if structs[k].status not in skip]
+        direct = reflib.l2_frames([frames[k] for k in keep])
+        indexed = reflib.l2_frames_indexed([(structs[k], by[k, :structs[k].nbytes]) for k in keep])
+        for a, b in zip(direct, indexed):
+            ta, tb = _all_l2_taps(a), _all_l2_taps(b)
+            assert ta == tb
+            n_pkt += sum(1 for t in ta if t[0] == "l2pkt"); n_aas += sum(1 for t in ta if t[0] == "l2aas")
+    assert n_pkt >= 400 and n_aas >= 8, (n_pkt, n_aas)
+    E.close()

@@ -133,3 +133,7 @@ def test_emu_l2_index_fused_into_decode(emu_lib, oracle):
 
 def test_emu_l2_index_vs_reference_golden(emu_lib):
     ec.check_l2_index_vs_reference_golden(emu_lib)
+
+
+def test_emu_frame_push_indexed_with_device_index(emu_lib, reflib):
+    ec.check_frame_push_indexed_with_device_index(emu_lib, reflib)

@@ -277,3 +277,8 @@ def test_gpu_l2_index_fused_into_decode(hip_lib, oracle, p1_async):
 def test_gpu_l2_index_vs_reference_golden(hip_lib):
     """Device index vs the calls the unmodified reference's frame_push made for the same frames (committed golden)."""
     ec.check_l2_index_vs_reference_golden(hip_lib)
+
+
+def test_gpu_frame_push_indexed_with_device_index(hip_lib, reflib):
+    """INTEGRATION.md's binding executed with the device's index inside the unmodified reference (needs oracle/_ref)."""
+    ec.check_frame_push_indexed_with_device_index(hip_lib, reflib)

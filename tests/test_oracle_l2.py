@@ -94,3 +94,46 @@ def test_l2_golden_is_current(oracle, reflib):
             idx, by = oracle.l2_index(bits)
             mine = json.loads(json.dumps(common.l2_taps_digest(expected_taps(idx, by))))
             assert now == c["taps"] == mine, (nbits, c["name"])
+
+
+def _all_l2_taps(log):
+    out = []
+    for k, v in log:
+        if k in ("l2align", "l2pkt", "state"):
+            out += reference_taps([(k, v)])
+        elif k == "l2aas":
+            out.append((k, v["data"]))
+        elif k == "l2svc":
+            out.append((k,) + tuple(v.values()))
+        elif k == "hdc":
+            out.append((k, v["program"], v["count"], v["flags"], bytes(v["data"])))
+    return out
+
+
+def test_frame_push_indexed_equals_frame_push_inside_the_reference(oracle, reflib):
+    """The binding INTEGRATION.md proposes, executed: oracle/ref_shim/frame_indexed.c includes the reference's frame.c
+    verbatim and adds frame_push_indexed(); fed with the index (C-ABI struct layout) + PDU bytes it must make the reference
+    do exactly what its own frame_push does with the raw bits -- output_align, output_push, PSD / AAS packets through
+    parse_hdlc, audio-service reports, HDC events out of the elastic buffer, sync loss -- over whole sessions."""
+    sessions = {
+        "psd": synth_l2.psd_sequence(seed=1),
+        "psd_am": synth_l2.psd_sequence(seed=2, nbits=24000, n_frames=4),
+        "branches": [b for _, b, safe in synth_l2.test_frames(146176, seed=7) if safe],
+        "random": [synth_l2.random_frame(np.random.default_rng(500 + k))[1] for k in range(40)],
+    }
+    n_aas = n_svc = n_pkt = 0
+    for name, frames in sessions.items():
+        keep, items = [], []
+        for bits in frames:
+            fr, by = oracle.l2_index_struct(bits)
+            if port.L2_STATUS[fr.status] in ("fixed_data", "hef_overrun", "bad_stream", "too_many_pdus"):
+                continue                  # the host keeps walking those itself (INTEGRATION.md)
+            keep.append(bits)
+            items.append((fr, by))
+        direct = reflib.l2_frames(keep)
+        indexed = reflib.l2_frames_indexed(items)
+        for k, (a, b) in enumerate(zip(direct, indexed)):
+            ta, tb = _all_l2_taps(a), _all_l2_taps(b)
+            assert ta == tb, (name, k, [x[:6] for x in ta[:4]], [x[:6] for x in tb[:4]])
+            n_aas += sum(1 for t in ta if t[0] == "l2aas"); n_svc += sum(1 for t in ta if t[0] == "l2svc"); n_pkt += sum(1 for t in ta if t[0] == "l2pkt")
+    assert n_aas >= 8 and n_svc >= 6 and n_pkt >= 500, (n_aas, n_svc, n_pkt)
