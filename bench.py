@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--l2-index-inline", action="store_true", help="engine option l2_index: index every P1 frame on the decode streams inside the timed region (default: untimed post-pass)")
     ap.add_argument("--no-l2-index", action="store_true", help="skip the (untimed) L2 audio-index property check of the decoded frames")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
+    ap.add_argument("--oracle-streams", type=int, default=4, help="parity block: how many falsely-locking streams of the last pass are compared with the oracle (plus half as many others)")
+    ap.add_argument("--launch-check", action="store_true", help="only start the ranks, form the process group (RCCL; gloo without a GPU) and print what it sees -- no workload")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="optional PMC-derived HBM bytes per launch for the dominant kernel (written by profiles/collect_pmc.py)")
     return ap.parse_args()
@@ -100,18 +102,40 @@ def side_workload(args):
     runpy.run_path(sys.argv[0], run_name="__main__")
 
 
+def launch_check(args):
+    """--launch-check: the multi-rank start-up of --gpus N without the workload (runs on CPU with gloo too)."""
+    import torch
+    from nrsc5_amd import shard
+    rank, world, local = shard.init_from_env(expect_world=args.gpus)
+    cuda = torch.cuda.is_available()
+    dev = torch.device("cuda", local) if cuda else torch.device("cpu")
+    if cuda:
+        torch.cuda.set_device(dev)
+    shard.barrier(dev)
+    ranks = shard.sum_over_ranks([1.0, float(rank)], dev)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_in_process_group": int(ranks[0]), "rank_sum": int(ranks[1]),
+                          "backend": "nccl(RCCL)" if cuda else "gloo", "launched_by": os.environ.get("NRSC5_BENCH_LAUNCHER", "external torchrun" if world > 1 else "single process")}))
+
+
 def main():
     args = parse()
+    from nrsc5_amd import shard
+    if args.gpus > 1 and not shard.launched_by_torchrun():
+        # `python bench.py --gpus N` on its own: start the N ranks here, the way the driver's torchrun line does
+        sys.exit(shard.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, {"NRSC5_BENCH_LAUNCHER": "bench.py"}))
+    if args.launch_check:
+        return launch_check(args)
     if args.workload != "fm":
         return side_workload(args)
     import torch
-    from nrsc5_amd import engine as eng, shard, synth_torch as stt
+    from nrsc5_amd import engine as eng, synth_torch as stt
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); there is no CPU fallback")
-    rank, world, local = shard.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if torch.cuda.device_count() < max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))):
+        raise SystemExit(f"--gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
+    rank, world, local = shard.init_from_env(expect_world=args.gpus)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
@@ -140,8 +164,10 @@ def main():
     t_gen = time.perf_counter() - t_gen
     total_samples_rank = float(nbytes.astype(np.float64).sum() / 2)
 
-    E = eng.Engine(max_streams=S, q15_capacity=int(stride // 4 + 1024), record_capacity=max(256, 16 * n_frames + 32),
-                   p1_slots=n_frames + 1, p1_async=not args.sync_p1, device=local, l2_feedback=bool(args.l2_feedback), l2_index=bool(args.l2_index_inline))
+    # replay (window pipeline + L2 feedback): blocks that ran behind a failed P1 frame keep their records / ring slots
+    # (marked void, never delivered), so both rings carry head-room for the speculated stretch
+    E = eng.Engine(max_streams=S, q15_capacity=int(stride // 4 + 1024), record_capacity=max(512, 2 * 16 * n_frames + 64),
+                   p1_slots=n_frames + 12, p1_async=not args.sync_p1, device=local, l2_feedback=bool(args.l2_feedback), l2_index=bool(args.l2_index_inline))
 
     host_ms = {"reset": 0.0, "append": 0.0, "process": 0.0, "fetch": 0.0}
 
@@ -170,7 +196,8 @@ def main():
     dt = time.perf_counter() - t0
     prof = E.profile(0)
     dt = shard.max_over_ranks(dt, dev)
-    total_samples = float(shard.sum_over_ranks([total_samples_rank], dev)[0])
+    tot = shard.sum_over_ranks([total_samples_rank, 1.0], dev)
+    total_samples, ranks_seen = float(tot[0]), int(tot[1])     # ranks_seen: counted through the collective itself
 
     # ---- verification of the last pass against the transmitted truth ----------------------------------
     rows = []
@@ -226,6 +253,35 @@ def main():
 
     if rank != 0:
         return
+    # ---- reference-equality of the benchmarked mode on a sample of this pass's streams (untimed checker leg) ----------
+    # streams the reference algorithm first locks falsely on (their log has LOST_SYNC) + the first streams that did not:
+    # the complete ordered log -- sync / lost-sync blocks, every PIDS and P1 frame, MER / BER / CFO -- against the oracle
+    # driven by the restated frame_process decision
+    ref_eq = None
+    if not args.no_cpu_baseline and world == 1:
+        try:
+            from oracle import port
+            from tests import common
+            O = port.Oracle()
+            lost = [k for k in range(len(my_streams)) if ((recs[k, :counts[k]]["flags"] & eng.REC_LOST_SYNC) != 0).any()]
+            sample = lost[:args.oracle_streams] + [k for k in range(len(my_streams)) if k not in lost][:max(1, args.oracle_streams // 2)]
+            t_or = time.perf_counter()
+            equal, first_diffs = 0, []
+            for k in sample:
+                ol, _, _ = O.run(iq[k, :int(nbytes[k])].cpu().numpy(), p1_hook=O.l2_hook())
+                log = eng.records_to_log(E, k, recs[k, :counts[k]], frames[k])
+                diffs = common.compare_logs(common.strip_states(ol), common.strip_states(log))
+                kept = [x for x in common.strip_states(ol) if x[0] not in ("hdc", "soft", "vit", "amsym", "pxsoft")]
+                bad = {i for i, (kk, v) in enumerate(kept) if kk == "ber" and v["cber"] > 0.02}     # frames decoded while falsely locked: noise in, noise out
+                diffs = [d for d in diffs if not any(d.startswith(f"#{i} ber") or d.startswith(f"#{i + 1} frame") for i in bad)]
+                equal += not diffs
+                if diffs and len(first_diffs) < 3:
+                    first_diffs.append({"stream": int(my_streams[k]), "diff": diffs[0]})
+            ref_eq = {"streams_with_lost_sync_this_pass": len(lost), "streams_checked": len(sample), "of_which_with_lost_sync": len([k for k in sample if k in lost]),
+                      "logs_equal_to_oracle_with_l2_hook": int(equal), "first_diffs": first_diffs, "seconds": round(time.perf_counter() - t_or, 1),
+                      "compared": "ordered log: state/sync/lost_sync blocks, PIDS + P1 frames bit-exact (frames with cber > 0.02 = decoded while falsely locked excepted), floats 1e-4"}
+        except Exception as ex:
+            ref_eq = {"error": repr(ex)}
     value = total_samples * args.steps / dt / 1e6
     # ---- roofline of the dominant kernel (by device time, HIP events on its launch stream) -----------
     blocks_rank = int(counts.sum())
@@ -265,7 +321,7 @@ def main():
     good = int(((allrows[:, 2] > 0) & (allrows[:, 3] >= allrows[:, 2] - 1)).sum())
     line = {
         "metric": "IQ MS/s demod+decoded", "value": round(value, 2), "unit": "IQ MS/s",
-        "x_realtime": round(value * 1e6 / FS, 1), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "x_realtime": round(value * 1e6 / FS, 1), "n_gpus": world, "ranks_in_process_group": ranks_seen, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int16 Q15 front end / f32 OFDM+sync / int32 Viterbi metrics", "data": "synthetic",
         "config": {"workload": f"configs[2]: batch={S} independent hybrid-FM MP1 cu8 streams @1.488375 MS/s per GPU, "
@@ -276,8 +332,8 @@ def main():
         "roofline": roofline, "cpu_baseline": cpu,
         "parity": {"streams": n_total, "streams_locked_and_all_p1_frames_equal_transmitted_bits": good,
                    "p1_frames_decoded": int(allrows[:, 2].sum()), "p1_frames_bit_exact_vs_truth": int(allrows[:, 3].sum()),
-                   "pids_frames_decoded": int(allrows[:, 4].sum()), "l2_index_rank0": l2,
-                   "note": "streams whose timing offset falls in the reference algorithm's false-lock zone (sync.c phase-slope ambiguity, ~6 % of uniform offsets) decode one garbage frame in the reference too, whose L2 then forces a re-acquisition; with l2_feedback the engine does the same on the device (deferred decode: a few blocks later than the reference), without it such streams stay falsely locked"},
+                   "pids_frames_decoded": int(allrows[:, 4].sum()), "reference_equality_rank0": ref_eq, "l2_index_rank0": l2,
+                   "note": "streams whose timing offset falls in the reference algorithm's false-lock zone (sync.c phase-slope ambiguity, ~6 % of uniform offsets) decode one garbage frame in the reference too, whose L2 then forces a re-acquisition; with l2_feedback the engine does the same on the device: the verdict of the deferred decode rewinds the stream to the end of that frame's block (k_replay.hip), so LOST_SYNC and the re-acquisition land on the reference's blocks"},
         "gen_seconds": round(t_gen, 1),
     }
     print(json.dumps(line))

@@ -63,7 +63,9 @@ enum {
     NRSC5HIP_REC_P3        = 1u << 7,  /* FM (MP2/MP3/MP11, odd blocks): frame_push(P3 frame of PX slot `sis`, 2304 or 4608 bits);
                                           AM, block 7: frame_push(P3 frame of slot p1_slot), then nrsc5_report_ber(ber) */
     NRSC5HIP_REC_P4        = 1u << 8,  /* FM MP11: frame_push(P4 frame of PX slot `sis`, 4608 bits) */
-    NRSC5HIP_REC_PIDS_CRC  = 1u << 9   /* with REC_PIDS: the frame passes pids_frame_push's CRC-12 (pids.c:52-86), i.e. sis_decode will see it */
+    NRSC5HIP_REC_PIDS_CRC  = 1u << 9,  /* with REC_PIDS: the frame passes pids_frame_push's CRC-12 (pids.c:52-86), i.e. sis_decode will see it */
+    NRSC5HIP_REC_DISCARDED = 1u << 10  /* internal (p1_async + l2_feedback): a block that ran speculatively behind a P1 frame whose first L2 header
+                                          failed; the stream was rewound to that frame.  nrsc5hip_drain / _batch_fetch* never deliver such records */
 };
 
 /* One record per processed 32-symbol block, in stream order.  Events implied by one record fire in
@@ -103,9 +105,13 @@ typedef struct nrsc5hip_config {
                                   1: decode the frames of each 16-block window on a second HIP stream,
                                   overlapped with the next window (throughput mode) */
     int l2_feedback;           /* 1: the engine itself applies the L2 -> L1 feedback of frame_process (frame.c:516-540): a P1 frame
-                                  whose first L2 header fails the RS(255,247) check drops the stream to SYNC_NONE (REC_LOST_SYNC).
-                                  Exact reference timing with p1_async = 0; with p1_async = 1 it takes effect when the deferred
-                                  decode completes.  0: the host does it through nrsc5hip_force_resync (the drop-in shim). */
+                                  whose first L2 header fails the RS(255,247) check drops the stream to SYNC_NONE (REC_LOST_SYNC)
+                                  before its next block, as in the reference.  With p1_async = 1 (FM) the verdict of a deferred decode
+                                  arrives windows later: the stream is then rewound to the end of the frame's block and re-run from
+                                  there, so the delivered records and frames are the reference's all the same (needs the samples since
+                                  that block still in the FIFO: batch use, or pushes whose records are drained after each call; and
+                                  record_capacity >= 256).  AM with p1_async = 1: applied when the deferred decode completes.
+                                  0: the host does it through nrsc5hip_force_resync (the drop-in shim). */
     int am_enable;             /* allocate the AM buffers (1.4 MB per stream) so that streams may be switched to
                                   NRSC5HIP_MODE_AM */
     int l2_index;              /* 1: every FM P1 frame is also indexed on the decode stream right after its traceback

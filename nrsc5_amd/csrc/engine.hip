@@ -14,7 +14,7 @@
 
 using namespace nrsc5;
 
-constexpr int MAX_LANES = 4;
+constexpr int MAX_LANES = 1;   // one scheduler lane: a block step is latency-bound, stream groups on separate HIP streams gained nothing
 static_assert(sizeof(nrsc5hip_record) == sizeof(BlockRecord), "record ABI mismatch");
 static_assert(sizeof(BlockRecord) % 8 == 0, "record alignment");
 
@@ -41,8 +41,9 @@ struct nrsc5hip_engine {
         hipStream_t main, aux[NAUX];
         hipEvent_t ev_window[NWIN], ev_decoded[NWIN];
         bool decoded_pending[NWIN];
-        bool acq_needed;
+        bool acq_needed;               // some stream of the CURRENT stream set may be un-synchronised: launch the acquisition kernels
         bool px_needed;                // some stream is not FINE yet or runs a service mode with extended sidebands
+        unsigned long long set_sig;    // identity of the stream set the two flags above were measured on (0 = none)
         int dec_waited;                // chunks of the current chunked append this lane has already waited for
         bool prepared_by_sync;         // the previous step's k_sync already ran the next block's bookkeeping
         long long step_count;          // block steps issued so far (decode-window bookkeeping in async mode)
@@ -54,6 +55,7 @@ struct nrsc5hip_engine {
     int nlanes;
     int naux;                          // decode streams in use (<= NAUX)
     int naux_am;                       // ... by the AM window pipeline (its decodes are longer and thinner: 4 measured best)
+    int verdict_lag;                   // test hook (NRSC5HIP_TEST_VERDICT_LAG at create): replay takes verdicts this many windows late
     hipStream_t main;                  // = lanes[0].main
     std::vector<void *> allocs;
     // host mirrors
@@ -305,14 +307,15 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
     int rc = 0;
     do {
         {
-            const char *env = getenv("NRSC5HIP_LANES");
-            e->nlanes = env ? atoi(env) : 1;   // more lanes only pay when a step is throughput-bound; it is latency-bound today
-            if (e->nlanes < 1) e->nlanes = 1;
-            if (e->nlanes > MAX_LANES) e->nlanes = MAX_LANES;
+            e->nlanes = 1;
             const char *ea = getenv("NRSC5HIP_NAUX");
             e->naux = ea ? atoi(ea) : 3;
             if (e->naux < 1) e->naux = 1;
             if (e->naux > NAUX) e->naux = NAUX;
+            const char *elag = getenv("NRSC5HIP_TEST_VERDICT_LAG");
+            e->verdict_lag = elag ? atoi(elag) : 0;
+            if (e->verdict_lag < 0) e->verdict_lag = 0;
+            if (e->verdict_lag > NWIN) e->verdict_lag = NWIN;
             const char *eam = getenv("NRSC5HIP_NAUX_AM");
             e->naux_am = eam ? atoi(eam) : 4;
             if (e->naux_am < 1) e->naux_am = 1;
@@ -326,7 +329,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
                 if (hipEventCreate(&ln.ev_window[k]) != hipSuccess || hipEventCreate(&ln.ev_decoded[k]) != hipSuccess) rc = NRSC5HIP_EHIP;
                 ln.decoded_pending[k] = false;
             }
-            ln.acq_needed = true; ln.px_needed = true; ln.step_count = 0; ln.am_step_count = 0;
+            ln.acq_needed = true; ln.px_needed = true; ln.set_sig = 0; ln.step_count = 0; ln.am_step_count = 0;
             for (int k = 0; k < NWIN; k++) ln.am_decoded_pending[k] = false;
             if (!rc && hipHostMalloc((void **)&ln.counters_host, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) rc = NRSC5HIP_ENOMEM;
         }
@@ -338,6 +341,11 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         DevBuffers &db = e->db;
         db.q15_cap = cfg->q15_capacity; db.p1_slots = cfg->p1_slots; db.rec_cap = cfg->record_capacity;
         if ((rc = dev_alloc(e, &db.state, S))) break;
+        db.ckpt = nullptr;
+        if (cfg->p1_async && cfg->l2_feedback) {
+            if (cfg->record_capacity < 2 * NWIN * 16) { rc = NRSC5HIP_EINVAL; snprintf(g_err, sizeof(g_err), "p1_async with l2_feedback needs record_capacity >= %d (speculated blocks keep their records)", 2 * NWIN * 16); break; }
+            if ((rc = dev_alloc(e, &db.ckpt, S * NWIN))) break;
+        }
         if ((rc = dev_alloc(e, &db.q15, S * (size_t)db.q15_cap))) break;
         if ((rc = dev_alloc(e, &db.acq_filt, S * WIN_N))) break;
         if ((rc = dev_alloc(e, &db.acq_sums, S * SYM_N))) break;
@@ -454,6 +462,21 @@ static int check_stream(nrsc5hip_engine *e, int s)
 // One step = every listed stream whose 33-symbol window is complete advances by one block:
 //   [acquisition kernels if any stream may be un-synchronised] -> prepare -> mix+FFT -> sync (+PIDS)
 //   -> P1 de-interleave -> P1 Viterbi (in order, or deferred to the aux stream once per 16-step window).
+static int launch_window_decode(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const int *ids_dev, int parity, int lane)
+{
+    // decode the window's PIDS frames and P1 frames on aux stream `lane`, overlapped with the next windows
+    // (NAUX windows decode concurrently, each wave of the forward pass alone on a SIMD)
+    hipStream_t ax = ln.aux[lane];
+    HIPCHK(hipEventRecord(ln.ev_window[parity], ln.main));
+    HIPCHK(hipStreamWaitEvent(ax, ln.ev_window[parity], 0));
+    { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_pids_decode(e->tb, ln.db, n, ids_dev, parity, 16, ax); }
+    if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_px_decode(e->tb, ln.db, n, ids_dev, parity, lane, ax); }
+    { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ax); launch_p1_viterbi(e->tb, ln.db, n, ids_dev, parity, lane, ax, e->cfg.l2_feedback ? 2 : 0); }
+    HIPCHK(hipEventRecord(ln.ev_decoded[parity], ax));
+    ln.decoded_pending[parity] = true;
+    return 0;
+}
+
 static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const int *ids_dev)
 {
     const bool async = e->cfg.p1_async != 0;
@@ -474,13 +497,14 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
     }
     if (e->cfg.l2_feedback && !async) ln.acq_needed = true;   // an in-order P1 decode may send any stream back to NONE for the next block
     if (ln.acq_needed) { ProfScope p(e, NRSC5HIP_PROF_ACQUIRE, ln.main); launch_acquire(e->tb, ln.db, n, ids_dev, ln.main); }
-    if (!ln.prepared_by_sync) { ProfScope p(e, NRSC5HIP_PROF_PREPARE, ln.main); launch_prepare(ln.db, n, ids_dev, ln.main); }
+    // prepare_block is idempotent for a stream the previous k_sync already prepared; a stream that is not FINE is only
+    // prepared here, on a step that ran the acquisition kernels for its current window
+    if (!ln.prepared_by_sync || ln.acq_needed) { ProfScope p(e, NRSC5HIP_PROF_PREPARE, ln.main); launch_prepare(ln.db, n, ids_dev, ln.acq_needed ? 1 : 0, ln.main); }
     { ProfScope p(e, NRSC5HIP_PROF_MIXFFT, ln.main); launch_mixfft(e->tb, ln.db, n, ids_dev, ln.main); }
     const int slot = async ? (int)(ln.step_count % 16) : 0;
-    // batch pipeline: once every stream of the lane is FINE, the next block's bookkeeping rides in k_sync's tail
-    static const bool no_fuse = getenv("NRSC5HIP_NO_FUSE") != nullptr;
-    const int fuse = (async && !ln.acq_needed && !no_fuse) ? 1 : 0;
-    { ProfScope p(e, NRSC5HIP_PROF_SYNC, ln.main); launch_sync(e->tb, ln.db, n, ids_dev, parity, slot, fuse, ln.main, ln.acq_needed ? 1 : 0); }
+    // batch pipeline: once every stream of the set is FINE, the next block's bookkeeping rides in k_sync's tail
+    const int fuse = (async && !ln.acq_needed) ? 1 : 0;
+    { ProfScope p(e, NRSC5HIP_PROF_SYNC, ln.main); launch_sync(e->tb, ln.db, n, ids_dev, parity, slot, fuse, (int)window, ln.main); }
     ln.prepared_by_sync = fuse != 0;
     if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_px_deint(e->tb, ln.db, n, ids_dev, parity, slot, ln.main); }
     if (!async) {
@@ -489,81 +513,80 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
         ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ln.main);
         launch_p1_viterbi(e->tb, ln.db, n, ids_dev, parity, 0, ln.main, e->cfg.l2_feedback ? 1 : 0);
     } else if ((ln.step_count % 16) == 15) {
-        // window complete: decode its PIDS frames and P1 frames on aux stream `lane`, overlapped with the next
-        // windows (NAUX windows decode concurrently, each wave of the forward pass alone on a SIMD)
-        hipStream_t ax = ln.aux[lane];
-        HIPCHK(hipEventRecord(ln.ev_window[parity], ln.main));
-        HIPCHK(hipStreamWaitEvent(ax, ln.ev_window[parity], 0));
-        { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_pids_decode(e->tb, ln.db, n, ids_dev, parity, 16, ax); }
-        if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_px_decode(e->tb, ln.db, n, ids_dev, parity, lane, ax); }
-        { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ax); launch_p1_viterbi(e->tb, ln.db, n, ids_dev, parity, lane, ax, e->cfg.l2_feedback ? 2 : 0); }
-        HIPCHK(hipEventRecord(ln.ev_decoded[parity], ax));
-        ln.decoded_pending[parity] = true;
+        int rc = launch_window_decode(e, ln, n, ids_dev, parity, lane); if (rc) return rc;
     }
     ln.step_count++;
     HIPCHK(hipGetLastError());
     return 0;
 }
 
-// finish a partially filled decode window (async mode) so that every produced frame gets decoded
+// finish a partially filled decode window (async mode) so that every produced frame gets decoded, and wait for all decodes
 static int flush_p1(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const int *ids_dev)
 {
     if (!e->cfg.p1_async) return 0;
     if (ln.step_count % 16) {
         const long long window = ln.step_count / 16;
-        const int parity = (int)(window % NWIN), lane = (int)(window % e->naux);
-        hipStream_t ax = ln.aux[lane];
-        HIPCHK(hipEventRecord(ln.ev_window[parity], ln.main));
-        HIPCHK(hipStreamWaitEvent(ax, ln.ev_window[parity], 0));
-        { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_pids_decode(e->tb, ln.db, n, ids_dev, parity, 16, ax); }
-        if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_px_decode(e->tb, ln.db, n, ids_dev, parity, lane, ax); }
-        { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ax); launch_p1_viterbi(e->tb, ln.db, n, ids_dev, parity, lane, ax, e->cfg.l2_feedback ? 2 : 0); }
-        ln.step_count += 16 - (ln.step_count % 16);            // next batch starts a fresh window
+        int rc = launch_window_decode(e, ln, n, ids_dev, (int)(window % NWIN), (int)(window % e->naux)); if (rc) return rc;
+        ln.step_count += 16 - (ln.step_count % 16);            // the next steps start a fresh window
     }
     for (int k = 0; k < NAUX; k++) HIPCHK(hipStreamSynchronize(ln.aux[k]));
     for (int k = 0; k < NWIN; k++) ln.decoded_pending[k] = false;
     return 0;
 }
 
-// Runs block steps for `nl` lanes (lane l: n[l] streams listed at ids_dev[l]) until no lane has work left.
-static int run_steps_lanes(nrsc5hip_engine *e, int nl, const int *n, const int *const *ids_dev, int max_steps, int check_every, int *steps_done)
+// Runs block steps for the n streams listed at ids_dev until none of them has a complete window left (or max_steps).
+// `set_sig` identifies the stream set: the acquisition / PX launch flags measured on one set say nothing about another.
+static int run_steps(nrsc5hip_engine *e, int n, const int *ids_dev, unsigned long long set_sig, int max_steps, int check_every, int *steps_done)
 {
+    nrsc5hip_engine::Lane &ln = e->lanes[0];
+    if (set_sig != ln.set_sig) { ln.acq_needed = true; ln.px_needed = true; ln.set_sig = set_sig; }
+    ln.prepared_by_sync = false;
+    const bool replay = e->db.ckpt != nullptr;
     int done = 0;
-    bool live[MAX_LANES];
-    for (int l = 0; l < nl; l++) { live[l] = n[l] > 0; e->lanes[l].prepared_by_sync = false; }
-    while (done < max_steps) {
-        bool any = false;
-        for (int l = 0; l < nl; l++) if (live[l]) { any = true; HIPCHK(hipMemsetAsync(e->lanes[l].counters_dev, 0, 4 * sizeof(int), e->lanes[l].main)); }
-        if (!any) break;
-        int burst = 0;
-        for (; burst < check_every && done + burst < max_steps; burst++)
-            for (int l = 0; l < nl; l++)
-                if (live[l]) { int rc = issue_step(e, e->lanes[l], n[l], ids_dev[l]); if (rc) return rc; }
-        for (int l = 0; l < nl; l++)
-            if (live[l]) HIPCHK(hipMemcpyAsync(e->lanes[l].counters_host, e->lanes[l].counters_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, e->lanes[l].main));
-        bool progressed = false;
-        for (int l = 0; l < nl; l++) {
-            if (!live[l]) continue;
-            HIPCHK(hipStreamSynchronize(e->lanes[l].main));
-            e->lanes[l].acq_needed = e->lanes[l].counters_host[1] > 0;
-            e->lanes[l].px_needed = e->lanes[l].counters_host[2] > 0;
-            if (e->lanes[l].counters_host[0] == 0) live[l] = false; else progressed = true;
+    for (;;) {
+        bool live = n > 0;
+        while (live && done < max_steps) {
+            HIPCHK(hipMemsetAsync(ln.counters_dev, 0, 4 * sizeof(int), ln.main));
+            int burst = 0;
+            for (; burst < check_every && done + burst < max_steps; burst++) { int rc = issue_step(e, ln, n, ids_dev); if (rc) return rc; }
+            if (replay && (ln.step_count % 16) == 0) {
+                // Window boundary: take the first-header verdicts of the deferred decodes that have finished.  The decode whose
+                // job slot the next window reuses (launched NWIN windows before it) must be among them.
+                const long long window = ln.step_count / 16;
+                const int parity = (int)(window % NWIN);
+                if (ln.decoded_pending[parity]) { HIPCHK(hipStreamWaitEvent(ln.main, ln.ev_decoded[parity], 0)); ln.decoded_pending[parity] = false; }
+                ProfScope p(e, NRSC5HIP_PROF_PREPARE, ln.main);
+                launch_rollback(ln.db, n, ids_dev, (int)window, e->verdict_lag, ln.main);
+            }
+            HIPCHK(hipMemcpyAsync(ln.counters_host, ln.counters_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, ln.main));
+            HIPCHK(hipStreamSynchronize(ln.main));
+            ln.acq_needed = ln.counters_host[1] > 0;
+            ln.px_needed = ln.counters_host[2] > 0;
+            if (ln.counters_host[0] == 0) live = false;        // nothing was processed (or is pending) in this burst
+            else done += burst;
         }
-        if (!progressed) break;                                // nothing was processed in this burst
-        done += burst;
+        if (e->dec_chunk) { HIPCHK(hipStreamSynchronize(e->dec_stream)); e->dec_chunk = 0; }
+        { int rc = flush_p1(e, ln, n, ids_dev); if (rc) return rc; }
+        if (!replay || done >= max_steps) break;
+        // every decode has finished: apply what is left of their verdicts; a rewound stream has work again
+        HIPCHK(hipMemsetAsync(ln.counters_dev, 0, 4 * sizeof(int), ln.main));
+        launch_rollback(ln.db, n, ids_dev, (int)(ln.step_count / 16), 0, ln.main);
+        HIPCHK(hipMemcpyAsync(ln.counters_host, ln.counters_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, ln.main));
+        HIPCHK(hipStreamSynchronize(ln.main));
+        if (ln.counters_host[3] == 0) break;
+        ln.acq_needed = true; ln.prepared_by_sync = false;
     }
-    if (e->dec_chunk) { HIPCHK(hipStreamSynchronize(e->dec_stream)); e->dec_chunk = 0; }
-    for (int l = 0; l < nl; l++) { int rc = flush_p1(e, e->lanes[l], n[l], ids_dev[l]); if (rc) return rc; }
-    for (int l = 0; l < nl; l++) HIPCHK(hipStreamSynchronize(e->lanes[l].main));
+    HIPCHK(hipStreamSynchronize(ln.main));
     if (e->prof_on) prof_collect(e);
     if (steps_done) *steps_done = done;
     return 0;
 }
 
-static int run_steps(nrsc5hip_engine *e, int n, const int *ids_dev, int max_steps, int check_every, int *steps_done)
+static unsigned long long set_signature(int n, const int *ids)
 {
-    const int *ids[1] = { ids_dev };
-    return run_steps_lanes(e, 1, &n, ids, max_steps, check_every, steps_done);
+    unsigned long long h = 0xcbf29ce484222325ull ^ (unsigned long long)n;
+    if (ids) for (int k = 0; k < n; k++) h = (h ^ (unsigned long long)(unsigned)ids[k]) * 0x100000001b3ull;
+    return h | 1ull;                                           // never 0 (= "no set measured yet")
 }
 
 // AM streams: one fused kernel per block step (k_am.hip).  p1_async = 0: every frame decodes in order on the main stream
@@ -680,7 +703,7 @@ static int push_common(nrsc5hip_engine *e, int s, const void *host, size_t nbyte
         e->wr_host[s] += nq15;
         int steps = 0;
         if (am) { if ((rc = run_steps_am(e, 1, e->ids_dev, 1 << 30, 1, &steps))) return rc; }
-        else if ((rc = run_steps(e, 1, e->ids_dev, 1 << 30, 1, &steps))) return rc;
+        else if ((rc = run_steps(e, 1, e->ids_dev, set_signature(1, &s), 1 << 30, 1, &steps))) return rc;
         src += chunk; nbytes_total -= chunk;
     }
     return 0;
@@ -709,7 +732,7 @@ extern "C" int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream)
         HIPCHK(hipMemset(e->db.am_pids_rec + (size_t)stream * NWIN * 8, 0xff, NWIN * 8 * sizeof(int)));
     }
     e->wr_host[stream] = 0; e->base_host[stream] = 0; e->drained[stream] = 0; e->raw_host[stream] = 0;
-    for (int l = 0; l < e->nlanes; l++) { e->lanes[l].acq_needed = true; e->lanes[l].px_needed = true; }
+    for (int l = 0; l < e->nlanes; l++) { e->lanes[l].acq_needed = true; e->lanes[l].px_needed = true; e->lanes[l].set_sig = 0; }
     return 0;
 }
 
@@ -730,7 +753,7 @@ extern "C" int nrsc5hip_force_resync(nrsc5hip_engine *e, int stream)
 {
     int rc = check_stream(e, stream); if (rc) return rc;
     hipLaunchKernelGGL(k_force_none, dim3(1), dim3(1), 0, e->main, e->db, stream);
-    for (int l = 0; l < e->nlanes; l++) { e->lanes[l].acq_needed = true; e->lanes[l].px_needed = true; }
+    for (int l = 0; l < e->nlanes; l++) { e->lanes[l].acq_needed = true; e->lanes[l].px_needed = true; e->lanes[l].set_sig = 0; }
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -868,11 +891,7 @@ extern "C" int nrsc5hip_batch_process(nrsc5hip_engine *e, int nstreams, const in
         }
     }
     const int *ids_dev; int rc = upload_ids(e, nstreams, stream_ids, nullptr, &ids_dev); if (rc) return rc;
-    // contiguous slices of the id list, one per scheduler lane
-    const int nl = (nstreams >= 2 * e->nlanes) ? e->nlanes : 1;
-    int n[MAX_LANES]; const int *ids[MAX_LANES];
-    for (int l = 0, off = 0; l < nl; l++) { n[l] = nstreams / nl + (l < nstreams % nl ? 1 : 0); ids[l] = ids_dev + off; off += n[l]; }
-    return run_steps_lanes(e, nl, n, ids, max_steps > 0 ? max_steps : (1 << 30), e->cfg.p1_async ? 16 : 8, steps_done);
+    return run_steps(e, nstreams, ids_dev, set_signature(nstreams, stream_ids), max_steps > 0 ? max_steps : (1 << 30), e->cfg.p1_async ? 16 : 8, steps_done);
 }
 
 // ---- results ------------------------------------------------------------------------------------------------------
@@ -916,6 +935,11 @@ extern "C" int nrsc5hip_drain(nrsc5hip_engine *e, int stream, nrsc5hip_record *o
         if (n - n1 > 0) HIPCHK(hipMemcpy(out + n1, ring, (size_t)(n - n1) * sizeof(BlockRecord), hipMemcpyDeviceToHost));
     }
     e->drained[stream] += n;
+    if (e->db.ckpt) {                                          // replay: blocks that ran behind a failed P1 frame are void (k_replay.hip)
+        int m = 0;
+        for (int k = 0; k < n; k++) if (!(out[k].flags & NRSC5HIP_REC_DISCARDED)) { if (m != k) out[m] = out[k]; m++; }
+        n = m;
+    }
     *n_out = n;
     if (e->cfg.p1_async && e->db.am && e->mode_host[stream] == MODE_AM && n > 0) return patch_am_ber(e, stream, out, n, nullptr);
     return 0;
@@ -1231,7 +1255,7 @@ extern "C" int nrsc5hip_reset_all(nrsc5hip_engine *e)
     HIPCHK(hipMemset(e->db.pids_rec, 0xff, S * NWIN * 16 * sizeof(int)));
     HIPCHK(hipMemset(e->db.px_job, 0xff, S * NWIN * 16 * sizeof(PxJob)));
     for (int l = 0; l < e->nlanes; l++) {
-        e->lanes[l].acq_needed = true; e->lanes[l].px_needed = true; e->lanes[l].step_count = 0; e->lanes[l].am_step_count = 0;
+        e->lanes[l].acq_needed = true; e->lanes[l].px_needed = true; e->lanes[l].set_sig = 0; e->lanes[l].step_count = 0; e->lanes[l].am_step_count = 0;
         for (int k = 0; k < NWIN; k++) e->lanes[l].am_decoded_pending[k] = false;
         for (int k = 0; k < NWIN; k++) e->lanes[l].decoded_pending[k] = false;
     }
@@ -1380,8 +1404,15 @@ extern "C" int nrsc5hip_batch_fetch_view(nrsc5hip_engine *e, int nstreams, const
     for (int s = 0; s < nstreams; s++) {
         if (e->drained[s] != 0 || e->nblocks_host[s] > e->db.rec_cap)
             FAIL(NRSC5HIP_EOVERFLOW, "stream %d: view needs an undrained, unwrapped record ring (%d records, capacity %d)", s, e->nblocks_host[s], e->db.rec_cap);
-        counts[s] = e->nblocks_host[s];
-        e->drained[s] = e->nblocks_host[s];
+        int n = e->nblocks_host[s];
+        e->drained[s] = n;
+        if (e->db.ckpt) {                                      // replay: squeeze the void records out, in place in the pinned buffer
+            BlockRecord *r = e->rec_host + (size_t)s * e->db.rec_cap;
+            int m = 0;
+            for (int k = 0; k < n; k++) if (!(r[k].flags & REC_DISCARDED)) { if (m != k) r[m] = r[k]; m++; }
+            n = m;
+        }
+        counts[s] = n;
     }
     *records = (const nrsc5hip_record *)e->rec_host;
     if (frames) *frames = e->frames_host;

@@ -125,17 +125,17 @@ void launch_acquire(const DevTables &tb, const DevBuffers &db, int nstreams, con
 }
 
 // ---- per-block bookkeeping: see prepare_block.h ---------------------------------------------------------
-__global__ void k_prepare(DevBuffers db, const int *ids, int nstreams)
+__global__ void k_prepare(DevBuffers db, const int *ids, int nstreams, int acq_on)
 {
     const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
     if (sidx >= nstreams) return;
     const int s = stream_of(ids, sidx);
-    prepare_block(db, db.state[s], s);
+    prepare_block(db, db.state[s], s, acq_on != 0);
 }
 
-void launch_prepare(const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st)
+void launch_prepare(const DevBuffers &db, int nstreams, const int *stream_ids, int acq_on, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_prepare, dim3((nstreams + 63) / 64), dim3(64), 0, st, db, stream_ids, nstreams);
+    hipLaunchKernelGGL(k_prepare, dim3((nstreams + 63) / 64), dim3(64), 0, st, db, stream_ids, nstreams, acq_on);
 }
 
 }  // namespace nrsc5

@@ -168,14 +168,15 @@ __device__ __forceinline__ void store_px(int8_t *pair, float2 v, int side, int p
     *(char2 *)(pair + (size_t)ch * 2 * PX_MAX + odd * len + n * per_sym + idx) = o;
 }
 
-__global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare, int acq_on)
+__global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare, int window)
 {
     wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
     const int s = stream_of(ids, blockIdx.x);
     StreamState &st = db.state[s];
     if (!st.active) {                                          // block-uniform
-        // no block this step; with the fused pipeline the stream may have become ready since (new samples)
-        if (fuse_prepare && threadIdx.x == 0) prepare_block(db, st, s);
+        // no block this step; with the fused pipeline the stream may have become ready since (new samples).  Fused steps
+        // run without the acquisition kernels, so only FINE streams can be prepared here (prepare_block.h).
+        if (fuse_prepare && threadIdx.x == 0) prepare_block(db, st, s, false);
         return;
     }
     const int tid = threadIdx.x;
@@ -192,6 +193,7 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
     __shared__ float sh_f[8];
     __shared__ double red[2][4];
     __shared__ float ref_freq[NREF_MAX];
+    if (tid == 0) sh_i[2] = 0;                                 // set when this block completes a P1 frame (replay checkpoint below)
 
     float2 *bins = db.bins + (size_t)s * NSYM * LIVE_N;       // [sym][live]
     BlockRecord &rec = db.records[(size_t)s * db.rec_cap + (st.nblocks % db.rec_cap)];
@@ -466,6 +468,8 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
                 st.p1_count++;
                 st.p1_pending[parity] = 1; st.p1_slot[parity] = slot; st.p1_record[parity] = st.nblocks % db.rec_cap; st.p1_epoch[parity] = st.fine_epoch;
                 st.p1_pmslot[parity] = pm_slot;
+                st.p1_verdict[parity] = 0; st.p1_recabs[parity] = st.nblocks; st.p1_window[parity] = window;
+                sh_i[2] = 1;
                 rec.p1_slot = slot; rec.flags |= REC_P1;
             }
             if (ppb_px > PM_PART) {
@@ -501,26 +505,29 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         rec.bc = st.bc; rec.psmi = st.psmi; rec.cfo_wait = st.cfo_wait; rec.next_samperr = st.samperr;
         rec.prev_angle = st.prev_angle; rec.phase_re = (float)cos(th); rec.phase_im = (float)sin(th);
         rec.next_angle = st.angle;
-        if (const int req = st.force_none) {
-            // L2 feedback raised by a deferred P1 decode (l2_header.h).  A request that belongs to an earlier lock is stale
-            // (the decode of a frame received before the last re-acquisition finished late): drop it, keep the lock.
-            const bool current = st.sync_state == SYNC_FINE && req == st.fine_epoch + 1;
-            if (!current) atomicCAS(&st.force_none, req, 0);
-            else if (acq_on) {                                 // this step's successor runs the acquisition kernels
-                st.sync_state = SYNC_NONE; atomicCAS(&st.force_none, req, 0);
-                rec.flags |= REC_LOST_SYNC;
-            }
-        }
         st.nblocks++;
         st.active = 0;
-        if (fuse_prepare) prepare_block(db, st, s);           // top of the NEXT block's acquire_process
     }
+    if (db.ckpt) {                                             // block-uniform: window pipeline with the on-device L2 feedback
+        // Replay checkpoint.  The reference judges a P1 frame's first L2 header inside this block (frame.c:535-540) and starts
+        // the next one from SYNC_STATE_NONE when it fails; here the verdict comes from the deferred decode, windows later.
+        // The state as of now -- after this block, before the next block's bookkeeping -- is what k_rollback rewinds to.
+        __threadfence_block();
+        __syncthreads();
+        if (sh_i[2]) {
+            const uint32_t *src = (const uint32_t *)&st;
+            uint32_t *dst = (uint32_t *)(db.ckpt + (size_t)s * NWIN + parity);
+            for (int k = tid; k < (int)(sizeof(StreamState) / 4); k += 256) dst[k] = src[k];
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && fuse_prepare) prepare_block(db, st, s, false);   // top of the NEXT block's acquire_process (FINE streams only)
     SYNC_MARK(7);
 }
 
-void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, hipStream_t st, int acq_on)
+void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, int window, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_sync, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, acq_on);
+    hipLaunchKernelGGL(k_sync, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window);
 }
 
 // ---- deferred PIDS decode: one wave per (slot, stream) with a staged frame -----------------------------------

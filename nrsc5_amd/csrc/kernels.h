@@ -28,6 +28,8 @@ struct DevTables {
 // Engine-wide device buffers (slabs indexed by stream).
 struct DevBuffers {
     StreamState *state;              // [S]
+    StreamState *ckpt;               // [S][NWIN] replay: the stream's state right after the block that completed the P1 frame of decode
+                                     // window w (slot w % NWIN), before the next block's bookkeeping; null unless p1_async && l2_feedback
     c16 *q15;                        // [S][q15_cap]
     long long q15_cap;
     c16 *acq_filt;                   // [S][WIN_N]   acquisition FIR output
@@ -44,7 +46,8 @@ struct DevBuffers {
     int p1_slots;
     BlockRecord *records;            // [S][rec_cap]
     int rec_cap;
-    int *counters;                   // [0]: streams that processed a block this step, [1]: not-FINE streams
+    int *counters;                   // per burst: [0] blocks prepared, [1] not-FINE streams seen (host: keep launching the acquisition kernels),
+                                     // [2] streams that need the PX kernels, [3] streams rewound by k_rollback
     long long *sync_phase_cycles;    // [8] optional: accumulated shader cycles per k_sync phase (stream 0 only), or null
     // extended sidebands
     int8_t *px_mem;                  // [S][2][PX_MEM]           interleaver IV memories of PX1, PX2
@@ -78,9 +81,11 @@ void launch_append_cs16(const DevBuffers &db, int nstreams, const int *stream_id
 
 // ---- one block step for a set of streams ----------------------------------------------------
 void launch_acquire(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
-void launch_prepare(const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
+void launch_prepare(const DevBuffers &db, int nstreams, const int *stream_ids, int acq_on, hipStream_t st);
 void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
-void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, hipStream_t st, int acq_on = 0);
+void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, int window, hipStream_t st);
+// replay (k_replay.hip): apply the first-header verdicts of finished deferred P1 decodes -- rewind the stream to the failed frame
+void launch_rollback(const DevBuffers &db, int nstreams, const int *stream_ids, int cur_window, int min_age, hipStream_t st);
 void launch_pids_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int nslots, hipStream_t st);
 // extended sidebands: interleaver IV for streams whose block pair just completed (after k_sync), and the staged P3/P4 decodes
 void launch_px_deint(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, hipStream_t st);

@@ -84,8 +84,10 @@ __device__ inline int rs255_247_decode(L2Smem &g)
 __device__ inline bool l2_pci_wants_check(unsigned pci)
 {
     const unsigned p = pci & 0xFFFFFCu;
-    if (p == (0x3634CEu & 0xFFFFFCu)) return false;                                          // !has_audio
-    if (p == (0xE3634Cu & 0xFFFFFCu) || p == (0x8D8D33u & 0xFFFFFCu)) return false;         // has_fixed: audio_end not modelled
+    if (p == (0x3634CEu & 0xFFFFFCu)) return false;                                          // !has_audio (PCI_FIXED)
+    // PCI_AUDIO_FIXED / _OPP: frame_process still runs fix_header at offset 0 -- the loop condition 0 < audio_end - 96
+    // (frame.c:525) holds unless the fixed-data sub-channels fill all but 96 bytes of the 18 269-byte PDU, which no
+    // service mode allows -- so the check applies to them as to plain audio frames.
     return true;
 }
 

@@ -77,6 +77,8 @@ enum : uint32_t {
     REC_P3          = 1u << 7,   // a P3 frame completed (FM: odd blocks once the PX1 interleaver is primed, slot in `sis`; AM: block 7)
     REC_P4          = 1u << 8,   // FM MP11: a P4 frame completed (same slot)
     REC_PIDS_CRC    = 1u << 9,   // the PIDS frame passes pids_frame_push's CRC-12 (pids.c:52-86)
+    REC_DISCARDED   = 1u << 10,  // window pipeline + l2_feedback: the block ran speculatively behind a P1 frame whose first L2 header
+                                 // failed (frame.c:535-540); the stream was rewound to that frame and this record is void (k_replay.hip)
 };
 
 // One per (stream, processed block).  Plain-old-data, mirrored by include/nrsc5hip.h.
@@ -120,7 +122,7 @@ struct StreamState {
     // bookkeeping
     int nblocks;                // processed blocks so far (record index)
     int p1_count;               // P1 frames produced so far
-    int force_none;             // deferred L2 feedback: fine_epoch + 1 of the P1 frame whose first header failed (0 = none)
+    int force_none;             // AM window pipeline: deferred L2 feedback, fine_epoch + 1 of the P1 frame whose first header failed (0 = none)
     int fine_epoch;             // number of transitions into SYNC_FINE so far: a request from an earlier lock is stale
     // per-step scratch written by k_prepare / acquisition
     int active;                 // this step processes a block for this stream
@@ -135,6 +137,10 @@ struct StreamState {
     int p1_l2slot[NWIN];           // slot + 1 of a freshly decoded frame awaiting k_l2_index_window, 0 = none
     int p1_endlane[NWIN];
     int p1_pmslot[NWIN];        // which of the stream's NPM soft-bit matrices holds the frame
+    // replay (k_replay.hip): verdict of the frame's first L2 header once its deferred decode is done (0: none yet / consumed,
+    // 1: ok, 2: failed), absolute index of the record that announced the frame, absolute decode window it belongs to
+    int p1_verdict[NWIN], p1_recabs[NWIN], p1_window[NWIN];
+    int ndiscard;               // records marked REC_DISCARDED so far
     int pm_slot;                // matrix being filled; advances after every block 15
     int last_pm_slot;           // matrix that received the most recent block (debug fetch)
     int mode;                   // MODE_FM / MODE_AM (nrsc5_set_mode)

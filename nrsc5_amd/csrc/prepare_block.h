@@ -26,13 +26,19 @@ __device__ inline int partitions_for_psmi(int psmi)
 
 __device__ inline bool window_ready(const StreamState &st) { return st.wr - st.rd >= WIN_N; }
 
-__device__ inline void prepare_block(const DevBuffers &db, StreamState &st, int s)
+// acq_ran: the acquisition kernels ran in this step, i.e. coarse_samperr / coarse_re / coarse_im belong to the window at
+// st.rd.  A stream that is not FINE only advances on such steps (the host launches them whenever counters[1] > 0 at the
+// last burst boundary); anywhere else it waits -- never a block on stale coarse results.
+__device__ inline void prepare_block(const DevBuffers &db, StreamState &st, int s, bool acq_ran)
 {
     if (st.active) return;                                     // already prepared (fused into the previous k_sync)
-    if (st.sync_state != SYNC_FINE || st.force_none) atomicAdd(&db.counters[1], 1);   // host: keep launching acquisition
+    if (st.sync_state != SYNC_FINE) atomicAdd(&db.counters[1], 1);   // host: keep launching acquisition
     if (st.sync_state != SYNC_FINE || partitions_for_psmi(st.psmi) > PM_PART) atomicAdd(&db.counters[2], 1);   // ... and the PX kernels
-    st.active = window_ready(st) ? 1 : 0;
-    if (!st.active) return;
+    st.active = (window_ready(st) && (st.sync_state == SYNC_FINE || acq_ran)) ? 1 : 0;
+    if (!st.active) {
+        if (window_ready(st)) atomicAdd(&db.counters[0], 1);   // work is pending: the host must keep stepping
+        return;
+    }
     atomicAdd(&db.counters[0], 1);
 
     BlockRecord &rec = db.records[(size_t)s * db.rec_cap + (st.nblocks % db.rec_cap)];

@@ -15,6 +15,7 @@ REC_PROCESSED, REC_TO_COARSE, REC_TO_FINE, REC_MER, REC_PIDS, REC_P1 = 1, 2, 4, 
 REC_P3, REC_P4 = 128, 256
 REC_LOST_SYNC = 64
 REC_PIDS_CRC = 512
+REC_DISCARDED = 1024      # never delivered by drain / batch_fetch* (replay, k_replay.hip)
 PX_WORDS = 144
 MODE_FM, MODE_AM = 0, 1
 AM_P1_BITS, AM_P1_WORDS, AM_P3_WORD0 = 3750, 118, 944

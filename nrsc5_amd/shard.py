@@ -20,8 +20,10 @@ def stream_range(total_streams: int, world: int, rank: int) -> range:
     return range(lo, lo + base + (1 if rank < rem else 0))
 
 
-def init_from_env(backend: str | None = None):
-    """(rank, world, local_rank); initialises the default process group when WORLD_SIZE > 1."""
+def init_from_env(backend: str | None = None, expect_world: int | None = None):
+    """(rank, world, local_rank); initialises the default process group when WORLD_SIZE > 1.  expect_world: the rank count
+    the caller was asked for (--gpus N) -- a mismatch with what the process group reports is an error, never a silent
+    single-rank run."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -30,7 +32,35 @@ def init_from_env(backend: str | None = None):
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend or ("nccl" if torch.cuda.is_available() else "gloo"),
                                 rank=rank, world_size=world)
+    seen = dist.get_world_size() if dist.is_initialized() else 1
+    if seen != world or (expect_world is not None and seen != expect_world):
+        raise RuntimeError(f"asked for {expect_world} ranks, WORLD_SIZE={world}, process group reports {seen}")
     return rank, world, local
+
+
+def launched_by_torchrun() -> bool:
+    return "WORLD_SIZE" in os.environ and "RANK" in os.environ
+
+
+def free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(script: str, argv, nproc: int, extra_env: dict | None = None) -> int:
+    """Start `nproc` ranks of `script argv` on this node -- one process per GPU -- exactly as the driver does:
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P script argv.
+    Returns the launcher's exit code; the ranks inherit stdout / stderr (rank 0 prints the result line)."""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
+    return subprocess.call(cmd, env=env)
 
 
 def barrier(device=None):

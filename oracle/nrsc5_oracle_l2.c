@@ -77,8 +77,9 @@ int orc_rs255_247_decode(uint8_t r[255])
 
 /* Would frame_process keep the receiver synchronised after this P1 frame?  bits = the frame as handed to frame_push
  * (one bit per byte), len = 146176 (FM) or 3750 (AM).  1 = yes / no check applies, 0 = it calls
- * input_set_sync_state(SYNC_STATE_NONE).  Frames that announce fixed-data sub-channels (has_fixed) move audio_end by
- * state this restatement does not model: they are reported as 1. */
+ * input_set_sync_state(SYNC_STATE_NONE).  Frames that announce fixed-data sub-channels next to audio (PCI_AUDIO_FIXED /
+ * _OPP) move audio_end (process_fixed_data, frame.c:458-514), but the header at offset 0 is still checked as long as
+ * 0 < audio_end - 96 (frame.c:525), i.e. always for a P1 PDU: same decision as for plain audio frames. */
 int orc_l2_first_header_ok(const uint8_t *bits, unsigned len)
 {
     unsigned start, step, pci_len;
@@ -98,7 +99,6 @@ int orc_l2_first_header_ok(const uint8_t *bits, unsigned len)
     }
     const unsigned p = pci & 0xFFFFFC;
     if (p == (0x3634CE & 0xFFFFFC)) return 1;                  /* !has_audio */
-    if (p == (0xE3634C & 0xFFFFFC) || p == (0x8D8D33 & 0xFFFFFC)) return 1;   /* has_fixed: not modelled */
     if (nbytes <= 96) return 1;                                /* while (offset < audio_end - RS_CODEWORD_LEN) not entered */
     uint8_t r[255];
     memset(r, 0, 159);

@@ -40,8 +40,7 @@ def emu_lib():
 def hip_lib():
     """The real gfx950 library; GPU tests must run THIS, so a missing build is an error."""
     from nrsc5_amd import build, engine
-    if not os.path.exists(engine.DEFAULT_LIB):
-        build.build_hip()
+    build.build_hip()                                          # rebuilds only when a source is newer than the library
     return engine.DEFAULT_LIB
 
 

@@ -218,6 +218,57 @@ def _free_device(E, p: int):
     fn(p)
 
 
+def check_interleaved_streams(lib, p1_async=False):
+    """Streams of one engine advanced through alternating calls: the scheduler's launch flags (acquisition / PX kernels)
+    measured on one stream set must not leak into a call that lists another set.  (a) two streams fed by block-sized
+    interleaved pushes, the second starting late while the first is FINE; (b) batch_process over alternating subsets.
+    Each stream's log must equal its single-stream run."""
+    caps = [synth.fm_mp1_capture(0, seed=90 + k, cfo_hz=c, offset=o, snr_db=20, n_blocks=nb, mode=m)
+            for k, (c, o, nb, m) in enumerate([(20.0, 500, 12, "MP1"), (-700.0, 2900, 10, "MP1"), (5.0, 64, 44, "MP3")])]
+    singles = []
+    for cap in caps:
+        E, recs, log = run_capture(lib, cap, p1_async=p1_async)
+        singles.append(log)
+        E.close()
+    # (a) interleaved pushes of one block's worth of input; stream 1 starts after stream 0 locked
+    E = eng.Engine(max_streams=3, q15_capacity=400000, record_capacity=256, p1_slots=4, p1_async=p1_async, lib_path=lib)
+    chunk = 4 * 70200
+    pos = [0, -3 * chunk, 0]
+    while any(p < c.iq.size for p, c in zip(pos, caps)):
+        for k, c in enumerate(caps):
+            if 0 <= pos[k] < c.iq.size:
+                part = c.iq[pos[k]:pos[k] + chunk]
+                E.push_cu8(k, part[:part.size - part.size % 4])
+            pos[k] += chunk
+    for k in range(3):
+        log = eng.records_to_log(E, k, E.drain(k))
+        diffs = common.compare_logs(singles[k], log, rtol=0.0)
+        assert not diffs, ("interleaved pushes", k, diffs[:6])
+    E.close()
+    # (b) batch over alternating subsets, a few steps at a time
+    n = len(caps)
+    stride = max(c.iq.size for c in caps); stride += (-stride) % 16
+    host = np.zeros((n, stride), dtype=np.uint8)
+    for k, c in enumerate(caps):
+        host[k, :c.iq.size] = c.iq
+    E = eng.Engine(max_streams=n, q15_capacity=stride // 4 + 1024, record_capacity=256, p1_slots=4, p1_async=p1_async, lib_path=lib)
+    dev = _to_device(E, host)
+    E.batch_append_cu8(dev, stride, [c.iq.size - c.iq.size % 4 for c in caps])
+    for rnd in range(40):
+        did = 0
+        for subset in ([0], [1, 2], [0, 2], [1]):
+            did += E.batch_process(len(subset), stream_ids=subset, max_steps=3)
+        if did == 0:
+            break
+    recs, counts, frames = E.batch_fetch(n)
+    for k in range(n):
+        log = eng.records_to_log(E, k, recs[k, :counts[k]], frames[k])
+        diffs = common.compare_logs(singles[k], log, rtol=0.0)
+        assert not diffs, ("subset batches", k, diffs[:6])
+    _free_device(E, dev)
+    E.close()
+
+
 def check_small_fifo_compaction(lib, name, captures):
     """Streaming seam with the minimum FIFO: the unread tail is compacted many times; results unchanged."""
     g = golden(name)
@@ -562,6 +613,56 @@ def check_deferred_feedback_recovers(lib, n_blocks=256):
     assert good[0][0] == 0 and good[0][1] == 0 and good[0][2] >= total - 2, good     # without feedback the two false locks never recover
     assert good[1][0] >= 1 and good[1][1] >= 1 and good[1][2] == good[0][2], good    # late (deferred decode), but they come back
     return good
+
+
+FALSE_LOCK_CASES = ((23, 0.0, 1234), (24, 10.0, 2208), (25, 10.0, 777))     # seeds 23 / 24: the reference algorithm locks falsely first
+
+
+def check_deferred_feedback_equals_reference(lib, oracle, n_blocks=96, verdict_lag=0, extra=()):
+    """THE benchmarked mode (batch, window pipeline, on-device L2 feedback) against the oracle driven by the restated
+    frame_process decision (itself pinned against the unmodified reference incl. its L2): the complete ordered log --
+    LOST_SYNC on the reference's block, re-acquisition, every PIDS / P1 frame, SYNC / MER / BER -- must be equal, no matter
+    how late the verdict of the deferred decode arrives (verdict_lag forces it `lag` windows late: deep speculation)."""
+    caps = [synth.fm_mp1_capture(0, seed=sd, cfo_hz=c, offset=o, snr_db=20, n_blocks=n_blocks) for sd, c, o in FALSE_LOCK_CASES + tuple(extra)]
+    n = len(caps)
+    stride = max(c.iq.size for c in caps); stride += (-stride) % 256
+    buf = np.zeros((n, stride), dtype=np.uint8)
+    for k, c in enumerate(caps):
+        buf[k, :c.iq.size] = c.iq
+    old = os.environ.get("NRSC5HIP_TEST_VERDICT_LAG")
+    os.environ["NRSC5HIP_TEST_VERDICT_LAG"] = str(verdict_lag)
+    try:
+        E = eng.Engine(max_streams=n, q15_capacity=stride // 4 + 1024, record_capacity=1024, p1_slots=48, p1_async=True, l2_feedback=True, lib_path=lib)
+    finally:
+        if old is None:
+            del os.environ["NRSC5HIP_TEST_VERDICT_LAG"]
+        else:
+            os.environ["NRSC5HIP_TEST_VERDICT_LAG"] = old
+    dev = _to_device(E, buf)
+    E.batch_append_cu8(dev, stride, [c.iq.size - c.iq.size % 4 for c in caps])
+    E.batch_process(n)
+    recs, counts, frames = E.batch_fetch_view(n)
+    lost = 0
+    for k, c in enumerate(caps):
+        ol, _, _ = oracle.run(c.iq, p1_hook=oracle.l2_hook())
+        r = recs[k, :counts[k]]
+        assert not (r["flags"] & eng.REC_DISCARDED).any()
+        log = eng.records_to_log(E, k, r, frames[k])
+        diffs = common.compare_logs(common.strip_states(ol), common.strip_states(log))
+        # frames decoded while falsely locked are Viterbi output on noise (see check_oracle_end_to_end): their bits / BER are
+        # compared loosely, everything else -- including that the frame exists and fails its header check -- exactly
+        kept = [x for x in common.strip_states(ol) if x[0] not in ("hdc", "soft", "vit", "amsym", "pxsoft")]
+        bad = {i for i, (kk, v) in enumerate(kept) if kk == "ber" and v["cber"] > 0.02}
+        diffs = [d for d in diffs if not any(d.startswith(f"#{i} ber") or d.startswith(f"#{i + 1} frame") for i in bad)]
+        assert not diffs, (k, diffs[:10])
+        lost += sum(1 for kk, _ in ol if kk == "lost_sync")
+        # every decodable frame equals the transmitted bits
+        truth = {np.packbits(f, bitorder="little").tobytes() for f in c.p1_frames}
+        good = sum(1 for x in r if (int(x["flags"]) & eng.REC_P1) and frames[k, int(x["p1_slot"])].tobytes() in truth)
+        assert good >= n_blocks // 16 - 2, (k, good)
+    assert lost >= 2, "captures do not exercise the feedback"
+    _free_device(E, dev)
+    E.close()
 
 
 def check_l2_index_fused(lib, oracle, p1_async=False):

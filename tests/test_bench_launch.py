@@ -1,0 +1,40 @@
+"""CPU-only: `python bench.py --gpus 2` with no torchrun around it must start 2 ranks itself (one per GPU on the GPU box),
+give each its RANK / LOCAL_RANK / WORLD_SIZE, form the process group and report the rank count the collective saw.
+Here the ranks have no GPU, so --launch-check stops after the process group (gloo); the workload path is the -m gpu tests'."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, [json.loads(ln) for ln in lines]
+
+
+def test_bench_spawns_its_own_ranks():
+    r, lines = _run(["--gpus", "2", "--launch-check"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1, r.stdout                    # rank 0 only
+    assert lines[0]["n_gpus"] == 2 and lines[0]["ranks_in_process_group"] == 2 and lines[0]["rank_sum"] == 1
+    assert lines[0]["launched_by"] == "bench.py"
+
+
+def test_bench_single_rank_is_one_process():
+    r, lines = _run(["--gpus", "1", "--launch-check"])
+    assert r.returncode == 0 and lines == [{"launch_check": True, "n_gpus": 1, "ranks_in_process_group": 1, "rank_sum": 0,
+                                            "backend": "gloo", "launched_by": "single process"}], r.stdout + r.stderr[-1000:]
+
+
+def test_world_size_mismatch_is_an_error():
+    """--gpus 4 inside a 2-rank torchrun (the driver's own launch line, wrong N) must fail loudly, not run 2 ranks."""
+    from nrsc5_amd import shard
+    rc = shard.launch_ranks(os.path.join(ROOT, "bench.py"), ["--gpus", "4", "--launch-check"], 2)
+    assert rc != 0

@@ -48,6 +48,10 @@ def test_emu_async_p1_window_pipeline(emu_lib):
     ec.check_batch_equals_streaming(emu_lib, caps, p1_async=True)
 
 
+def test_emu_interleaved_streams_and_subset_batches(emu_lib):
+    ec.check_interleaved_streams(emu_lib)
+
+
 def test_emu_small_fifo_compaction(emu_lib, captures):
     ec.check_small_fifo_compaction(emu_lib, "fm_cu8_cfo-2400", captures)
 
@@ -105,6 +109,12 @@ def test_emu_l2_feedback_on_device_fm(emu_lib, oracle):
 
 def test_emu_l2_feedback_on_device_am(emu_lib, oracle):
     ec.check_l2_feedback(emu_lib, oracle, dict(n_frames=16, seed=9, cfo_hz=2.0, offset=500, burst=(8.3, 0.5, 40.0)), am=True)
+
+
+def test_emu_deferred_feedback_equals_reference(emu_lib, oracle):
+    """Window pipeline + on-device L2 feedback (the benchmarked mode): replay makes it reference-identical, here with the
+    verdicts taking effect 3 decode windows after their frame (48 speculated blocks are rewound)."""
+    ec.check_deferred_feedback_equals_reference(emu_lib, oracle, n_blocks=80, verdict_lag=3)
 
 
 def test_emu_mode_switch_on_live_stream(emu_lib, oracle):

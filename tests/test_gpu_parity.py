@@ -97,6 +97,12 @@ def test_gpu_batch_equals_streaming_extended_modes(hip_lib):
     ec.check_batch_equals_streaming(hip_lib, caps, p1_async=True)
 
 
+@pytest.mark.parametrize("p1_async", [False, True])
+def test_gpu_interleaved_streams_and_subset_batches(hip_lib, p1_async):
+    """Launch flags measured on one stream set must not leak into calls that list another (round-1 advisor finding)."""
+    ec.check_interleaved_streams(hip_lib, p1_async=p1_async)
+
+
 def test_gpu_small_fifo_compaction(hip_lib, captures):
     ec.check_small_fifo_compaction(hip_lib, "fm_cu8_cfo137", captures)
 
@@ -227,6 +233,14 @@ def test_gpu_l2_feedback_on_device_fm(hip_lib, oracle, kw):
 
 def test_gpu_l2_feedback_on_device_am(hip_lib, oracle):
     ec.check_l2_feedback(hip_lib, oracle, dict(n_frames=16, seed=9, cfo_hz=2.0, offset=500, burst=(8.3, 0.5, 40.0)), am=True)
+
+
+@pytest.mark.parametrize("lag", [0, 2, 5])
+def test_gpu_deferred_feedback_equals_reference(hip_lib, oracle, lag):
+    """The benchmarked mode -- batch, window pipeline, on-device L2 feedback -- delivers the reference's log on false-lock
+    captures: LOST_SYNC on the reference's block, re-acquisition, every frame (replay, k_replay.hip)."""
+    ec.check_deferred_feedback_equals_reference(hip_lib, oracle, n_blocks=160, verdict_lag=lag,
+                                                extra=((26, -120.0, 3333), (27, 250.0, 1234), (28, 0.0, 4000)))
 
 
 def test_gpu_l2_feedback_deferred_recovers_false_locks(hip_lib):
