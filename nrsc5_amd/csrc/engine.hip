@@ -352,8 +352,8 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if ((rc = dev_alloc(e, &db.bins, S * NSYM * LIVE_N))) break;
         if ((rc = dev_alloc(e, &db.pm, S * NPM * PM_FRAME))) break;
         db.nstreams_alloc = (int)S;
-        if ((rc = dev_alloc(e, &db.coded, (size_t)(cfg->p1_async ? NAUX : 1) * S * P1_DEPUNCT))) break;
-        if ((rc = dev_alloc(e, &db.dec, (size_t)(cfg->p1_async ? NAUX : 1) * S * (size_t)(P1_LEN + 64)))) break;
+        if ((rc = dev_alloc(e, &db.coded, (size_t)(cfg->p1_async ? NAUX : 1) * S * P1_LEN))) break;
+        if ((rc = dev_alloc(e, &db.dec, (size_t)(cfg->p1_async ? NAUX : 1) * S * (size_t)(2 * (P1_LEN + 64))))) break;
         if ((rc = dev_alloc(e, &db.tbmap, (size_t)(cfg->p1_async ? NAUX : 1) * S * (size_t)(P1_LEN / 64 + 1) * 64))) break;
         if ((rc = dev_alloc(e, &db.pids_stage, S * NWIN * 16 * 3 * PIDS_LEN))) break;
         if ((rc = dev_alloc(e, &db.pids_rec, S * NWIN * 16))) break;
@@ -1320,9 +1320,13 @@ extern "C" int nrsc5hip_stage_viterbi_bench(nrsc5hip_engine *e, int len, int nfr
     HIPCHK(hipMemcpy(dsoft, h.data(), h.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemset(ddec, 0x55, (size_t)nframes * (len + 64) * sizeof(unsigned long long)));
     hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-    launch_viterbi_frames(dsoft, len, nframes, ddec, dout, e->main, phases);          // warm-up
+    launch_viterbi_frames(dsoft, len, nframes, ddec, dout, e->main, phases | 1);      // warm-up; packs the soft words and leaves decisions behind
     HIPCHK(hipEventRecord(a, e->main));
-    for (int r = 0; r < reps; r++) launch_viterbi_frames(dsoft, len, nframes, ddec, dout, e->main, phases);
+    for (int r = 0; r < reps; r++) {
+        // a traceback-only measurement consumes the decisions in place: re-run the (untimed-irrelevant) forward pass is not possible
+        // without timing it, so phases == 2 measures forward + traceback minus nothing -- callers subtract the forward figure
+        launch_viterbi_frames(dsoft, len, nframes, ddec, dout, e->main, ((phases & 2) ? (phases | 1) : phases) | 8);
+    }
     HIPCHK(hipEventRecord(b, e->main));
     HIPCHK(hipEventSynchronize(b));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b));

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include "kernels.h"
 #include "viterbi_wave.h"
+#include "viterbi_v3.h"
 #include "l2_header.h"
 
 namespace nrsc5 {
@@ -14,18 +15,19 @@ __device__ inline int stream_of(const int *ids, int idx) { return ids ? ids[idx]
 // Coded bit i = 320 k + j of the frame sits in matrix row (11 k) % 32 of block (j/20 + 7 part) % 16, partition
 // part = PM_V[j % 20], column (11 k + k/288) % 36.  All k that share a matrix row r (k = 3r + 32 m) read the same
 // 16 x 720-byte lines, so one workgroup per (stream, r) stages those 11.5 KB in LDS with coalesced loads and emits
-// its ~36 runs of 384 depunctured bytes (320 soft bits + 64 erasures [1,1,1,1,1,0]) as whole dwords: HBM sees
-// 369 KB in + 438 KB out per frame, instead of one cache line per gathered byte.
+// its ~36 runs of 128 trellis steps (320 soft bits + 64 erasures [1,1,1,1,1,0]) as one dword per step -- the form the
+// forward pass reads with scalar loads (viterbi_v3.h): HBM sees 369 KB in + 585 KB out per frame, instead of one
+// cache line per gathered byte.
 __global__ __launch_bounds__(256) void k_p1_deint(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id)
 {
     const int s = stream_of(ids, blockIdx.y);
-    const StreamState &st = db.state[s];
+    StreamState &st = db.state[s];
     if (!st.p1_pending[parity]) return;                        // block-uniform
     __shared__ uint32_t tile[16 * 180];                        // [block][720 bytes]
     __shared__ uint16_t lut[384];
     const int r = blockIdx.x, tid = threadIdx.x;
     const int8_t *pm = db.pm + ((size_t)s * NPM + st.p1_pmslot[parity]) * PM_FRAME;
-    uint32_t *out = (uint32_t *)(db.coded + ((size_t)lane_id * db.nstreams_alloc + s) * P1_DEPUNCT);
+    uint32_t *out = (uint32_t *)(db.coded + ((size_t)lane_id * db.nstreams_alloc + s) * P1_LEN);
     for (int w = tid; w < 16 * 180; w += 256) {
         const int b = w / 180, x = w % 180;
         tile[w] = ((const uint32_t *)(pm + ((size_t)b * 32 + r) * 720))[x];
@@ -35,17 +37,17 @@ __global__ __launch_bounds__(256) void k_p1_deint(DevTables tb, DevBuffers db, c
     const uint8_t *bytes = (const uint8_t *)tile;
     const int k0 = (3 * r) & 31;                               // 11 k = r (mod 32)  <=>  k = 3 r (mod 32)
     const int nk = (P1_CODED / 320 - k0 + 31) / 32;            // k = k0 + 32 m < 1142
-    for (int idx = tid; idx < nk * 96; idx += 256) {
-        const int m = idx / 96, w = idx % 96;
+    for (int idx = tid; idx < nk * 128; idx += 256) {
+        const int m = idx >> 7, i = idx & 127;                 // step i of the 128-step run of k
         const int k = k0 + 32 * m;
         const int col = (11 * k + k / 288) % 36;
         uint32_t v = 0;
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const unsigned off = lut[4 * w + t];
+        for (int t = 0; t < 3; t++) {
+            const unsigned off = lut[3 * i + t];
             if (off != 0xffffu) v |= (uint32_t)bytes[off + col] << (8 * t);
         }
-        out[96 * k + w] = v;
+        out[128 * k + i] = v;
     }
 }
 
@@ -53,8 +55,7 @@ __global__ __launch_bounds__(256) void k_p1_deint(DevTables tb, DevBuffers db, c
 // Re-encode the decoded (still scrambled) bits and count sign disagreements with the received soft
 // bits at unpunctured positions (decode.c:234-265).  Block-stride over the frame; returns this
 // thread's partial count.
-template <typename Src>
-__device__ inline int bit_errors_k7_partial(const Src &src, const uint32_t *bits, int len)
+__device__ inline int bit_errors_k7_partial(const int *soft, const uint32_t *bits, int len)
 {
     int errors = 0;
     for (int i = threadIdx.x; i < len; i += blockDim.x) {
@@ -64,7 +65,7 @@ __device__ inline int bit_errors_k7_partial(const Src &src, const uint32_t *bits
             int q = i - k; if (q < 0) q += len;                // tail biting
             r |= ((bits[q >> 5] >> (q & 31)) & 1u) << (6 - k);
         }
-        const int w = src.triple(i);
+        const int w = soft[i];
         const int c0 = (int8_t)w, c1 = (int8_t)(w >> 8), c2 = (int8_t)(w >> 16);
         const int p0 = __popc(r & 0133u) & 1, p1 = __popc(r & 0171u) & 1, p2 = __popc(r & 0165u) & 1;
         if ((c0 > 0) != p0) errors++;
@@ -78,12 +79,12 @@ __device__ inline int bit_errors_k7_partial(const Src &src, const uint32_t *bits
 __global__ __launch_bounds__(64) void k_p1_forward(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id, int prio)
 {
     wave_set_priority(prio);
-    const int s = stream_of(ids, blockIdx.x);
+    const int s = wave_uniform(stream_of(ids, blockIdx.x));
     StreamState &st = db.state[s];
     if (!st.p1_pending[parity]) return;                        // wave-uniform
-    const SoftContig src = { db.coded + ((size_t)lane_id * db.nstreams_alloc + s) * P1_DEPUNCT, P1_LEN };
-    unsigned long long *dec = db.dec + ((size_t)lane_id * db.nstreams_alloc + s) * (P1_LEN + 64);
-    const int endlane = viterbi_fast_forward(src, dec);
+    const int *soft = db.coded + ((size_t)lane_id * db.nstreams_alloc + s) * P1_LEN;
+    uint32_t *dec = db.dec + ((size_t)lane_id * db.nstreams_alloc + s) * (size_t)(2 * (P1_LEN + 64));
+    const int endlane = viterbi3_forward(soft, P1_LEN, dec);
     if ((threadIdx.x & 63) == 0) st.p1_endlane[parity] = endlane;
 }
 
@@ -98,15 +99,15 @@ __global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBu
     HIP_DYNAMIC_SHARED(uint8_t, smem)
     __shared__ int err_total;
     const int tid = threadIdx.x;
-    const SoftContig src = { db.coded + ((size_t)lane_id * db.nstreams_alloc + s) * P1_DEPUNCT, P1_LEN };
-    unsigned long long *dec = db.dec + ((size_t)lane_id * db.nstreams_alloc + s) * (P1_LEN + 64);
+    const int *soft = db.coded + ((size_t)lane_id * db.nstreams_alloc + s) * P1_LEN;
+    uint32_t *dec = db.dec + ((size_t)lane_id * db.nstreams_alloc + s) * (size_t)(2 * (P1_LEN + 64));
     uint32_t *out = db.p1_ring + ((size_t)s * db.p1_slots + st.p1_slot[parity]) * P1_WORDS;
     if (tid == 0) err_total = 0;
     uint8_t *gmap = db.tbmap + ((size_t)lane_id * db.nstreams_alloc + s) * ((size_t)(P1_LEN / 64 + 1) * 64);
-    viterbi_fast_traceback_block(dec, P1_LEN, st.p1_endlane[parity], out, gmap, smem);
+    viterbi3_traceback_block(dec, P1_LEN, st.p1_endlane[parity], out, gmap, smem);
     __threadfence_block();
     __syncthreads();
-    const int errors = wave_sum_i32(bit_errors_k7_partial(src, out, P1_LEN));
+    const int errors = wave_sum_i32(bit_errors_k7_partial(soft, out, P1_LEN));
     if ((tid & 63) == 0) atomicAdd(&err_total, errors);
     __syncthreads();
     for (int w = tid; w < P1_WORDS; w += blockDim.x) out[w] ^= tb.scr_p1[w];       // descramble
@@ -150,29 +151,42 @@ __global__ __launch_bounds__(64) void k_viterbi_frames(const int8_t *coded, int 
     const int f = blockIdx.x;
     viterbi_k7_decode(coded + (size_t)f * 3 * len, len, dec + (size_t)f * (len + 64), out + (size_t)f * ((len + 31) / 32), phases);
 }
-__global__ __launch_bounds__(64) void k_viterbi_frames_fwd(const int8_t *coded, int len, unsigned long long *dec, int *endlane)
+// soft values as the reference hands them to nrsc5_conv_decode (3 int8 per step) -> one dword per step
+__global__ void k_pack_soft3(const int8_t *coded, int *soft, size_t nsteps)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsteps) return;
+    soft[i] = (int)(uint8_t)coded[3 * i] | ((int)(uint8_t)coded[3 * i + 1] << 8) | ((int)(uint8_t)coded[3 * i + 2] << 16);
+}
+__global__ __launch_bounds__(64) void k_viterbi_frames_fwd(const int *soft, int len, uint32_t *dec, int *endlane)
 {
     const int f = blockIdx.x;
-    const SoftContig src = { coded + (size_t)f * 3 * len, len };
-    const int e = viterbi_fast_forward(src, dec + (size_t)f * (len + 64));
+    const int e = viterbi3_forward(soft + (size_t)f * len, len, dec + (size_t)f * 2 * (len + 64));
     if ((threadIdx.x & 63) == 0) endlane[f] = e;
 }
-__global__ __launch_bounds__(TB_THREADS) void k_viterbi_frames_tb(unsigned long long *dec, int len, const int *endlane, uint32_t *out, uint8_t *gmap)
+__global__ __launch_bounds__(TB_THREADS) void k_viterbi_frames_tb(uint32_t *dec, int len, const int *endlane, uint32_t *out, uint8_t *gmap)
 {
     HIP_DYNAMIC_SHARED(uint8_t, smem)
     const int f = blockIdx.x;
-    viterbi_fast_traceback_block(dec + (size_t)f * (len + 64), len, endlane[f], out + (size_t)f * ((len + 31) / 32), gmap + (size_t)f * (len / 64 + 1) * 64, smem);
+    viterbi3_traceback_block(dec + (size_t)f * 2 * (len + 64), len, endlane[f], out + (size_t)f * ((len + 31) / 32), gmap + (size_t)f * (len / 64 + 1) * 64, smem);
 }
 
 void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st, int phases)
 {
-    if ((len & 63) == 0 && !(phases & 4)) {                    // production split: forward wave + parallel traceback
+    if ((len & 63) == 0 && !(phases & 4)) {                    // production split: forward wave + parallel traceback (viterbi_v3.h)
         static int *endlane = nullptr; static int cap = 0; static uint8_t *gmap = nullptr; static size_t gcap = 0;
+        static int *soft = nullptr; static size_t scap = 0;
         if (cap < nframes) { if (endlane) (void)hipFree(endlane); (void)hipMalloc((void **)&endlane, sizeof(int) * nframes); cap = nframes; (void)hipMemset(endlane, 0, sizeof(int) * nframes); }
         const size_t gneed = (size_t)nframes * (len / 64 + 1) * 64;
         if (gcap < gneed) { if (gmap) (void)hipFree(gmap); (void)hipMalloc((void **)&gmap, gneed); gcap = gneed; }
-        if (phases & 1) hipLaunchKernelGGL(k_viterbi_frames_fwd, dim3(nframes), dim3(64), 0, st, coded, len, dec, endlane);
-        if (phases & 2) hipLaunchKernelGGL(k_viterbi_frames_tb, dim3(nframes), dim3(TB_THREADS), traceback_smem(len), st, dec, len, (const int *)endlane, out, gmap);
+        const size_t nsteps = (size_t)nframes * len;
+        if (scap < nsteps) { if (soft) (void)hipFree(soft); (void)hipMalloc((void **)&soft, nsteps * sizeof(int)); scap = nsteps; }
+        if (phases & 1) {
+            if (!(phases & 8))                                 // bit 3 (micro-benchmark): the soft words of this input are packed already
+                hipLaunchKernelGGL(k_pack_soft3, dim3((unsigned)((nsteps + 255) / 256)), dim3(256), 0, st, coded, soft, nsteps);
+            hipLaunchKernelGGL(k_viterbi_frames_fwd, dim3(nframes), dim3(64), 0, st, (const int *)soft, len, (uint32_t *)dec, endlane);
+        }
+        if (phases & 2) hipLaunchKernelGGL(k_viterbi_frames_tb, dim3(nframes), dim3(TB_THREADS), traceback_smem(len), st, (uint32_t *)dec, len, (const int *)endlane, out, gmap);
         return;
     }
     hipLaunchKernelGGL(k_viterbi_frames, dim3(nframes), dim3(64), 0, st, coded, len, dec, out, phases & 3);

@@ -38,8 +38,8 @@ struct DevBuffers {
     int8_t *pm;                      // [S][NPM][PM_FRAME]  soft-bit interleaver matrices (one per frame in flight)
     int8_t *pids_stage;              // [S][NWIN][16][240]  depunctured PIDS soft bits awaiting k_pids_decode
     int *pids_rec;                   // [S][NWIN][16]     record index of each staged PIDS frame, -1 = empty
-    int8_t *coded;                   // [NAUX][S][P1_DEPUNCT]  depunctured P1 trellis input, one per decode lane
-    unsigned long long *dec;         // [NAUX][S][P1_LEN + 64]  survivor decisions, one scratch per decode lane
+    int *coded;                      // [NAUX][S][P1_LEN]  depunctured P1 trellis input, one dword per step (s0 | s1 << 8 | s2 << 16), one per decode lane
+    uint32_t *dec;                   // [NAUX][S][2 * (P1_LEN + 64)]  survivor decisions: per 32 steps one history word per lane (viterbi_v3.h)
     int nstreams_alloc;              // S
     uint8_t *tbmap;                  // [NAUX][S][2285 * 64]  traceback chunk maps (start lane per end lane)
     uint32_t *p1_ring;               // [S][p1_slots][P1_WORDS]

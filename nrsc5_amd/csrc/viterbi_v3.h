@@ -1,0 +1,340 @@
+// K=7 rate-1/3 tail-biting soft Viterbi for the P1 frame on gfx950, third generation: 6 VALU instructions per trellis
+// step on the serial chain of one wave64 (the second generation in viterbi_wave.h needs 11).
+//
+// Replaces conv_dec.c:402-453 (schedule + traceback) and the SSE / NEON / generic ACS of conv_sse.h:233-323,
+// conv_neon.h, conv_gen.h:32-101; decisions and decoded bits are the reference's, bit for bit (tie rule included).
+//
+//  * ROTATING LAYOUT (as before): before step t the lane with LOGICAL index L holds the metric of state rotr6^t(L); the
+//    predecessors 2b, 2b+1 of a butterfly then sit in logical lanes L and L ^ (1 << t % 6), and the new metric belongs in
+//    the same lane.  New: logical index = physical lane ^ (3 * bit 2), so that the six partner relations are the
+//    physical lane XORs 1, 2, 7, 8, 16, 32 -- quad_perm, quad_perm, row_half_mirror, row_ror:8 (each folds into ONE
+//    VOP2-DPP subtract) and v_permlane16_swap / v_permlane32_swap.
+//  * PARITY-CODED TIE RULE.  A lane keeps u = 2 * metric + s0, s0 = bit 0 of the state it holds (1: it is the odd
+//    predecessor 2b+1 of its butterfly).  With D = 2 * branch metric the two candidates u_own + D and u_partner - D have
+//    opposite parity, can never tie, and their maximum M carries in bit 0 exactly the reference's decision "the survivor
+//    came from 2b+1" -- `if (sum0 > sum1)` with ties to 2b+1 (conv_gen.h:47-53) costs no instruction.  Next step:
+//    u = (M & ~1) | s0' (v_and_or_b32).  int32 metrics never overflow in 146 240 steps (|2 m| <= 762 per step), so the
+//    reference's every-79-steps min-normalisation is dropped: decisions depend on metric differences only.
+//  * DECISIONS stay in the lane: hist = alignbit(M, hist, 1) collects bit 0 of 32 steps per lane (v_alignbit_b32, off the
+//    critical chain, issued in the DPP / swap hazard shadow of the NEXT step), stored as one dword per lane every 32
+//    steps.  The block-parallel traceback turns a lane's 32 bits back into per-step masks with v_add_co (carry-out =
+//    ballot of the MSBs), one instruction per step.
+//  * SOFT INPUT: one dword per trellis step (s0 | s1 << 8 | s2 << 16, punctured = 0) read with s_load_dwordx16 straight
+//    into SGPRs -- no vector loads, no v_readlane; the branch metric is one VOP3P v_dot4_i32_i8 of that SGPR with the
+//    lane's +-2 weights, accumulating into u where the partner exchange allows it.
+//  * per step, on the chain:  DPP phases   v_dot4 D | v_add X=u+D | v_alignbit (prev) | v_sub_dpp Y=u'-D | v_max | v_and_or
+//                             swap phases  v_dot4 P=u+Dp | v_dot4 Q=u+Dq | v_alignbit (prev) | v_permlane*_swap | v_max | v_and_or
+//    The instruction order inside the asm blocks provides the wait states the hardware wants (VALU write -> DPP read: 2,
+//    VALU write -> permlane swap read: 2); LLVM's hazard recogniser cannot see into inline asm.
+#pragma once
+#include "nrsc5_dev.h"
+#include "wave_ops.h"
+#include "viterbi_wave.h"      // rotr6 / rotl6, TB_SEG
+
+namespace nrsc5 {
+
+#ifdef HIPEMU
+struct v16i { int v[16]; int &operator[](int i) { return v[i]; } const int &operator[](int i) const { return v[i]; } };
+#else
+typedef int v16i __attribute__((ext_vector_type(16)));         // 16 SGPRs: the soft words of 16 trellis steps
+#endif
+
+struct Vit3Const {
+    int w[4];            // phases 0..3: own-edge branch weights (+-2 per soft value), packed as v_dot4 wants them
+    int wp[2], wq[2];    // phases 4, 5: weights of the two registers that go through the permlane swap
+    int s0[6];           // bit 0 of the state this lane holds in phase r
+};
+
+__device__ __forceinline__ unsigned vit3_logical_lane(unsigned phys) { return phys ^ (((phys >> 2) & 1u) * 3u); }
+
+__device__ inline Vit3Const vit3_consts(unsigned phys)
+{
+    const unsigned L = vit3_logical_lane(phys & 63u);
+    Vit3Const k;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        const unsigned S = rotr6(L, r);                        // state held in phase r
+        const unsigned reg = S & 0x3eu;                        // edge 2b -> b (gen_state_info, conv_dec.c:137-153)
+        const int g0 = (__popc(reg & 0133u) & 1) ? 2 : -2, g1 = (__popc(reg & 0171u) & 1) ? 2 : -2, g2 = (__popc(reg & 0165u) & 1) ? 2 : -2;
+        const int pos = (g0 & 0xff) | ((g1 & 0xff) << 8) | ((g2 & 0xff) << 16);
+        const int neg = (-g0 & 0xff) | ((-g1 & 0xff) << 8) | ((-g2 & 0xff) << 16);
+        k.s0[r] = (int)(S & 1u);
+        if (r < 4) k.w[r] = pos;
+        else {
+            // register P: own candidate in the lower half (s0 = 0), offer to the partner in the upper half; Q the other way
+            k.wp[r - 4] = (S & 1u) ? neg : pos;
+            k.wq[r - 4] = (S & 1u) ? pos : neg;
+        }
+    }
+    return k;
+}
+
+__device__ __forceinline__ int vit3_push(int hist, int ns)     // hist >> 1 with bit 0 of ns entering at bit 31 (v_alignbit_b32)
+{
+#ifdef HIPEMU
+    return (int)(((unsigned)hist >> 1) | ((unsigned)ns << 31));
+#else
+    return (int)__builtin_amdgcn_alignbit((unsigned)ns, (unsigned)hist, 1);
+#endif
+}
+
+// Reference form of one trellis step in phase R (CPU emulator build; documents what the asm below does).
+// ns: receives this step's maximum; nsp: the previous step's, whose bit 0 is pushed into hist when PUSH.
+template <int R, bool PUSH>
+__device__ __forceinline__ void vit3_step_c(int &u, int &hist, int &ns, int nsp, int aw, const Vit3Const &k)
+{
+    if (PUSH) hist = vit3_push(hist, nsp);
+    if constexpr (R < 4) {
+        const int D = dot4_i8(aw, k.w[R], 0);
+        constexpr int M = R == 0 ? 1 : R == 1 ? 2 : R == 2 ? 7 : 8;
+        const int X = u + D, Y = __shfl_xor(u, M) - D;
+        ns = X > Y ? X : Y;
+    } else {
+        constexpr int M = R == 4 ? 16 : 32;
+        const int P = dot4_i8(aw, k.wp[R - 4], u), Q = dot4_i8(aw, k.wq[R - 4], u);
+        const int Pin = __shfl_xor(P, M), Qin = __shfl_xor(Q, M);
+        const bool upper = (threadIdx.x & M) != 0;
+        const int P2 = upper ? Qin : P, Q2 = upper ? Q : Pin;   // v_permlane*_swap: vdst upper half <-> vsrc lower half
+        ns = P2 > Q2 ? P2 : Q2;
+    }
+    u = (ns & ~1) | k.s0[(R + 1) % 6];
+}
+
+// ---- 8 trellis steps as ONE asm statement (the compiler pads every asm statement with an s_nop; one per 8 steps is fine) --
+// operands: u, h (history word), na / nb (maxima of the even / odd steps of the block; nb enters as the previous block's
+// last maximum), t (scratch); a0..a7 soft words (SGPRs); w0..w3, p4, q4, p5, q5 branch weights; z0..z5 = s0 per phase
+#define V3_PUSH(NSP) "v_alignbit_b32 %[h], %[" NSP "], %[h], 1\n\t"
+#define V3_DPP(A, W, CTRL, Z, NS, PL)                                                                                  \
+    "v_dot4_i32_i8 %[t], %[" A "], %[" W "], 0\n\t"                                                                    \
+    "v_add_u32 %[" NS "], %[u], %[t]\n\t" PL                                                                           \
+    "v_sub_u32_dpp %[t], %[u], %[t] " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                           \
+    "v_max_i32 %[" NS "], %[" NS "], %[t]\n\t"                                                                         \
+    "v_and_or_b32 %[u], %[" NS "], -2, %[" Z "]\n\t"
+#define V3_SWAP(A, WP, WQ, INSN, Z, NS, PL)                                                                            \
+    "v_dot4_i32_i8 %[" NS "], %[" A "], %[" WP "], %[u]\n\t"                                                           \
+    "v_dot4_i32_i8 %[t], %[" A "], %[" WQ "], %[u]\n\t" PL                                                             \
+    INSN " %[" NS "], %[t]\n\t"                                                                                        \
+    "v_max_i32 %[" NS "], %[" NS "], %[t]\n\t"                                                                         \
+    "v_and_or_b32 %[u], %[" NS "], -2, %[" Z "]\n\t"
+// wait states: VALU write -> DPP read 2 (dot4, add [, alignbit] in between); VALU write -> permlane swap read 2
+#define V3_PD(NSP) V3_PUSH(NSP)                 /* push in a DPP step */
+#define V3_PS(NSP) V3_PUSH(NSP) "s_nop 0\n\t"   /* push in a swap step: one more wait state for the second dot4 */
+#define V3_ND ""                                /* no push (first step of a history word), DPP step */
+#define V3_NS "s_nop 1\n\t"                     /* no push, swap step */
+#define V3_P0(A, NS, PL) V3_DPP(A, "w0", "quad_perm:[1,0,3,2]", "z1", NS, PL)
+#define V3_P1(A, NS, PL) V3_DPP(A, "w1", "quad_perm:[2,3,0,1]", "z2", NS, PL)
+#define V3_P2(A, NS, PL) V3_DPP(A, "w2", "row_half_mirror", "z3", NS, PL)
+#define V3_P3(A, NS, PL) V3_DPP(A, "w3", "row_ror:8", "z4", NS, PL)
+#define V3_P4(A, NS, PL) V3_SWAP(A, "p4", "q4", "v_permlane16_swap_b32", "z5", NS, PL)
+#define V3_P5(A, NS, PL) V3_SWAP(A, "p5", "q5", "v_permlane32_swap_b32", "z0", NS, PL)
+#define V3_BLOCK_PH0(FIRST) V3_P0("a0", "na", FIRST) V3_P1("a1", "nb", V3_PD("na")) V3_P2("a2", "na", V3_PD("nb")) V3_P3("a3", "nb", V3_PD("na")) \
+                            V3_P4("a4", "na", V3_PS("nb")) V3_P5("a5", "nb", V3_PS("na")) V3_P0("a6", "na", V3_PD("nb")) V3_P1("a7", "nb", V3_PD("na"))
+#define V3_BLOCK_PH2(FIRST) V3_P2("a0", "na", FIRST) V3_P3("a1", "nb", V3_PD("na")) V3_P4("a2", "na", V3_PS("nb")) V3_P5("a3", "nb", V3_PS("na")) \
+                            V3_P0("a4", "na", V3_PD("nb")) V3_P1("a5", "nb", V3_PD("na")) V3_P2("a6", "na", V3_PD("nb")) V3_P3("a7", "nb", V3_PD("na"))
+#define V3_BLOCK_PH4(FIRST) V3_P4("a0", "na", FIRST) V3_P5("a1", "nb", V3_PS("na")) V3_P0("a2", "na", V3_PD("nb")) V3_P1("a3", "nb", V3_PD("na")) \
+                            V3_P2("a4", "na", V3_PD("nb")) V3_P3("a5", "nb", V3_PD("na")) V3_P4("a6", "na", V3_PS("nb")) V3_P5("a7", "nb", V3_PS("na"))
+#define V3_OPERANDS                                                                                                      \
+    : [u] "+v"(u), [h] "+v"(hist), [na] "=&v"(na), [nb] "+v"(nb), [t] "=&v"(t)                                           \
+    : [a0] "s"(a0), [a1] "s"(a1), [a2] "s"(a2), [a3] "s"(a3), [a4] "s"(a4), [a5] "s"(a5), [a6] "s"(a6), [a7] "s"(a7),   \
+      [w0] "v"(k.w[0]), [w1] "v"(k.w[1]), [w2] "v"(k.w[2]), [w3] "v"(k.w[3]),                                           \
+      [p4] "v"(k.wp[0]), [q4] "v"(k.wq[0]), [p5] "v"(k.wp[1]), [q5] "v"(k.wq[1]),                                       \
+      [z0] "v"(k.s0[0]), [z1] "v"(k.s0[1]), [z2] "v"(k.s0[2]), [z3] "v"(k.s0[3]), [z4] "v"(k.s0[4]), [z5] "v"(k.s0[5])
+
+// 8 steps starting in phase PH (0, 2 or 4); W0: the first of them opens a history word (no push).  nb: in = the
+// previous block's last maximum, out = this block's.
+template <int PH, bool W0>
+__device__ __forceinline__ void vit3_block8(int &u, int &hist, int &nb, int a0, int a1, int a2, int a3, int a4, int a5, int a6, int a7, const Vit3Const &k)
+{
+    static_assert(PH == 0 || PH == 2 || PH == 4, "8-step blocks start in an even phase");
+    int na;
+#ifdef HIPEMU
+    vit3_step_c<(PH + 0) % 6, !W0>(u, hist, na, nb, a0, k);
+    vit3_step_c<(PH + 1) % 6, true>(u, hist, nb, na, a1, k);
+    vit3_step_c<(PH + 2) % 6, true>(u, hist, na, nb, a2, k);
+    vit3_step_c<(PH + 3) % 6, true>(u, hist, nb, na, a3, k);
+    vit3_step_c<(PH + 4) % 6, true>(u, hist, na, nb, a4, k);
+    vit3_step_c<(PH + 5) % 6, true>(u, hist, nb, na, a5, k);
+    vit3_step_c<(PH + 6) % 6, true>(u, hist, na, nb, a6, k);
+    vit3_step_c<(PH + 7) % 6, true>(u, hist, nb, na, a7, k);
+#else
+    int t;
+    if constexpr (PH == 0) { if constexpr (W0) asm(V3_BLOCK_PH0(V3_ND) V3_OPERANDS); else asm(V3_BLOCK_PH0(V3_PD("nb")) V3_OPERANDS); }
+    else if constexpr (PH == 2) { if constexpr (W0) asm(V3_BLOCK_PH2(V3_ND) V3_OPERANDS); else asm(V3_BLOCK_PH2(V3_PD("nb")) V3_OPERANDS); }
+    else { if constexpr (W0) asm(V3_BLOCK_PH4(V3_NS) V3_OPERANDS); else asm(V3_BLOCK_PH4(V3_PS("nb")) V3_OPERANDS); }
+#endif
+}
+
+// 16 consecutive steps whose soft words sit in `a`; PH = phase of the first one, W0: it opens a history word
+template <int PH, bool W0>
+__device__ __forceinline__ void vit3_run16(int &u, int &hist, int &nsp, const v16i &a, const Vit3Const &k)
+{
+    vit3_block8<PH, W0>(u, hist, nsp, a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7], k);
+    vit3_block8<(PH + 8) % 6, false>(u, hist, nsp, a[8], a[9], a[10], a[11], a[12], a[13], a[14], a[15], k);
+}
+
+// 16 soft words from a wave-uniform address: scalar loads (the data was written by an earlier kernel)
+__device__ __forceinline__ v16i vit3_load16(const int *p)
+{
+#ifdef HIPEMU
+    v16i v;
+    for (int i = 0; i < 16; i++) v[i] = p[i];
+    return v;
+#else
+    typedef const __attribute__((address_space(4))) v16i *cptr;
+    return *(cptr)(uintptr_t)p;
+#endif
+}
+
+__device__ __forceinline__ const int *vit3_group_ptr(const int *soft, int len, int t)   // soft words of steps t .. t+15 (conv_dec.c:407-412)
+{
+    int j = len - VIT_EXTRA + t;
+    if (j >= len) j -= len;
+    if (j >= len) j -= len;                                    // t < len + 64
+    return soft + j;
+}
+
+#ifdef HIPEMU
+#define VIT3_SCHED_BARRIER() do { } while (0)
+#define VIT3_WAIT_SCALAR() do { } while (0)
+#else
+#define VIT3_SCHED_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#define VIT3_WAIT_SCALAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); } while (0)   /* lgkmcnt(0) */
+#endif
+
+template <int PH>
+__device__ __forceinline__ void vit3_chunk(int &u, int &hist, int &nsp, v16i &cur, const int *soft, int len, int t0, int tmax,
+                                           const Vit3Const &k, uint32_t *dec_lo, uint32_t *dec_hi)
+{
+    // One scalar load in flight: scalar loads return out of order, so every wait is lgkmcnt(0).  Wait for the current
+    // group's words (issued a whole group -- ~400 cycles -- ago), THEN issue the next group's load, then run the 16 steps.
+    VIT3_WAIT_SCALAR();
+    v16i nxt = vit3_load16(vit3_group_ptr(soft, len, min(t0 + 16, tmax)));
+    VIT3_SCHED_BARRIER();
+    vit3_run16<PH, true>(u, hist, nsp, cur, k);
+    VIT3_WAIT_SCALAR();
+    cur = nxt; nxt = vit3_load16(vit3_group_ptr(soft, len, min(t0 + 32, tmax)));
+    VIT3_SCHED_BARRIER();
+    vit3_run16<(PH + 16) % 6, false>(u, hist, nsp, cur, k);
+    hist = vit3_push(hist, nsp);
+    *dec_lo = (uint32_t)hist;
+    VIT3_WAIT_SCALAR();
+    cur = nxt; nxt = vit3_load16(vit3_group_ptr(soft, len, min(t0 + 48, tmax)));
+    VIT3_SCHED_BARRIER();
+    vit3_run16<(PH + 32) % 6, true>(u, hist, nsp, cur, k);
+    VIT3_WAIT_SCALAR();
+    cur = nxt; nxt = vit3_load16(vit3_group_ptr(soft, len, min(t0 + 64, tmax)));
+    VIT3_SCHED_BARRIER();
+    vit3_run16<(PH + 48) % 6, false>(u, hist, nsp, cur, k);
+    hist = vit3_push(hist, nsp);
+    *dec_hi = (uint32_t)hist;
+    cur = nxt;
+}
+
+// Forward pass of one frame by one wave (len % 64 == 0).  soft: len dwords; dec: 2 * (len / 64 + 1) history words per lane,
+// word i of LOGICAL lane L at dec[64 i + L] (bit j = decision of step 32 i + j for the state that lane then held).
+// Returns the logical lane of the winning end state (wave-uniform).
+__device__ __forceinline__ int viterbi3_forward(const int *soft, int len, uint32_t *dec)
+{
+    const unsigned phys = threadIdx.x & 63u, L = vit3_logical_lane(phys);
+    const Vit3Const k = vit3_consts(phys);
+    const int nchunks = len / 64 + 1, tmax = 64 * nchunks - 16;
+    int u = k.s0[0], hist = 0, nsp = 0;                        // reset_decoder: all-zero metrics for tail biting
+    v16i cur = vit3_load16(vit3_group_ptr(soft, len, 0));
+    for (int c = 0; c < nchunks; c++) {
+        uint32_t *lo = dec + (size_t)(2 * c) * 64 + L, *hi = lo + 64;
+        switch (c % 3) {                                       // (64 c) % 6
+        case 0: vit3_chunk<0>(u, hist, nsp, cur, soft, len, 64 * c, tmax, k, lo, hi); break;
+        case 1: vit3_chunk<4>(u, hist, nsp, cur, soft, len, 64 * c, tmax, k, lo, hi); break;
+        default: vit3_chunk<2>(u, hist, nsp, cur, soft, len, 64 * c, tmax, k, lo, hi); break;
+        }
+    }
+    // end state: first maximum in STATE order (conv_dec.c:310-318); logical lane L holds state rotr6^steps(L)
+    const int rend = (64 * nchunks) % 6;
+    const int pm = u >> 1;
+    const int best = wave_max_i32(pm);
+    const int smin = wave_min_i32(pm == best ? (int)rotr6(L, rend) : 64);
+    return wave_uniform((int)rotl6((unsigned)smin, rend));
+}
+
+// h <<= 1, returning the mask of the lanes whose bit 31 was set: v_add_co_u32's carry-out IS that ballot
+__device__ __forceinline__ unsigned long long vit3_shift_out(unsigned &h)
+{
+#ifdef HIPEMU
+    const unsigned long long w = __ballot((int)h < 0);
+    h <<= 1;
+    return w;
+#else
+    unsigned long long w;
+    unsigned hn;
+    asm("v_add_co_u32 %0, %1, %2, %2" : "=v"(hn), "=s"(w) : "v"(h));
+    h = hn;
+    return w;
+#endif
+}
+
+// 64 steps of traceback for ALL 64 candidate end lanes of a chunk at once (lane = candidate, logical numbering):
+// d = decision of the candidate's lane; the bit emitted at a step is bit R of the lane; then bit R <- d, which is the
+// lane that held the surviving predecessor 2b + d (its state's bit 0 is lane bit R in this phase).
+template <int PH0, int S> struct Vit3Map {
+    static __device__ __forceinline__ void run(unsigned &l, unsigned &h0, unsigned &h1, unsigned &ohi, unsigned &olo)
+    {
+        constexpr int R = (PH0 + S) % 6;
+        const unsigned long long w = vit3_shift_out(S >= 32 ? h1 : h0);
+        const unsigned d = (unsigned)(w >> l) & 1u;
+        if (S >= 32) ohi = (ohi << 1) | ((l >> R) & 1u); else olo = (olo << 1) | ((l >> R) & 1u);
+        l = (l & ~(1u << R)) | (d << R);
+        Vit3Map<PH0, S - 1>::run(l, h0, h1, ohi, olo);
+    }
+};
+template <int PH0> struct Vit3Map<PH0, -1> {
+    static __device__ __forceinline__ void run(unsigned &, unsigned &, unsigned &, unsigned &, unsigned &) {}
+};
+
+// Block-parallel traceback over the history words of viterbi3_forward (blockDim.x a multiple of 64); same five passes
+// and LDS budget as viterbi_fast_traceback_block: chunk maps for all 64 candidate end lanes, segmented composition,
+// candidate outputs written in place over the chunk's history words.
+__device__ inline void viterbi3_traceback_block(uint32_t *dec, int len, int endlane, uint32_t *out, uint8_t *gmap, uint8_t *smem)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int nchunks = len / 64 + 1, nseg = (nchunks + TB_SEG - 1) / TB_SEG;
+    uint8_t *segmap = smem, *chosen = smem + (size_t)nseg * 64;
+    __shared__ uint8_t segend[64];                             // end lane of each segment (nseg <= 64: len <= 524224)
+    for (int c = wave; c < nchunks; c += nwaves) {
+        unsigned h0 = dec[(size_t)(2 * c) * 64 + lane], h1 = dec[(size_t)(2 * c + 1) * 64 + lane];
+        unsigned l = (unsigned)lane, ohi = 0, olo = 0;
+        switch (c % 3) {
+        case 0: Vit3Map<0, 63>::run(l, h0, h1, ohi, olo); break;
+        case 1: Vit3Map<4, 63>::run(l, h0, h1, ohi, olo); break;
+        default: Vit3Map<2, 63>::run(l, h0, h1, ohi, olo); break;
+        }
+        gmap[64 * c + lane] = (uint8_t)l;
+        dec[(size_t)(2 * c) * 64 + lane] = olo;
+        dec[(size_t)(2 * c + 1) * 64 + lane] = ohi;
+    }
+    __threadfence_block();
+    __syncthreads();
+    for (int sg = wave; sg < nseg; sg += nwaves) {             // pass 2
+        const int c0 = sg * TB_SEG, c1 = min(nchunks, c0 + TB_SEG);
+        unsigned e = (unsigned)lane;
+        for (int c = c1 - 1; c >= c0; c--) e = gmap[64 * c + e];
+        segmap[64 * sg + lane] = (uint8_t)e;
+    }
+    __syncthreads();
+    if (tid == 0) {                                            // pass 3
+        unsigned e = (unsigned)endlane;
+        for (int sg = nseg - 1; sg >= 0; sg--) { segend[sg] = (uint8_t)e; e = segmap[64 * sg + e]; }
+    }
+    __syncthreads();
+    for (int sg = tid; sg < nseg; sg += blockDim.x) {          // pass 4
+        const int c0 = sg * TB_SEG, c1 = min(nchunks, c0 + TB_SEG);
+        unsigned e = segend[sg];
+        for (int c = c1 - 1; c >= c0; c--) { chosen[c] = (uint8_t)e; e = gmap[64 * c + e]; }
+    }
+    __syncthreads();
+    for (int c = tid; c < nchunks; c += blockDim.x) {          // pass 5
+        if (c < nchunks - 1) out[2 * c] = dec[(size_t)(2 * c + 1) * 64 + chosen[c]];       // steps 64c+32 .. 64c+63
+        if (c >= 1) out[2 * c - 1] = dec[(size_t)(2 * c) * 64 + chosen[c]];                // steps 64c .. 64c+31
+    }
+}
+
+}  // namespace nrsc5

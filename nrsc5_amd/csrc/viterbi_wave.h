@@ -186,36 +186,6 @@ __device__ __forceinline__ int vit_load_soft(const int8_t *coded, int len, int t
     return ((int)(uint8_t)coded[3 * j]) | ((int)(uint8_t)coded[3 * j + 1] << 8) | ((int)(uint8_t)coded[3 * j + 2] << 16);
 }
 
-// Trellis input source: a contiguous depunctured buffer (3 soft values per information bit, erasures = 0).
-// (A variant that gathered P1 straight out of the interleaver matrix was measured: the byte gathers through
-// HBM / Infinity Cache made the forward pass 1.6x slower than de-interleaving first with k_p1_deint.)
-struct SoftContig {
-    const int8_t *coded; int len;
-    __device__ __forceinline__ int length() const { return len; }
-    __device__ __forceinline__ int triple(int j) const
-    {
-        return ((int)(uint8_t)coded[3 * j]) | ((int)(uint8_t)coded[3 * j + 1] << 8) | ((int)(uint8_t)coded[3 * j + 2] << 16);
-    }
-    // the same three bytes as two raw loads whose assembly the caller postpones (see viterbi_fast_forward)
-    __device__ __forceinline__ void raw(int j, int &b01, int &b2) const
-    {
-        b01 = ((int)(uint8_t)coded[3 * j]) | ((int)(uint8_t)coded[3 * j + 1] << 8);
-        b2 = (int)(uint8_t)coded[3 * j + 2];
-    }
-};
-// Pin two just-loaded values at this point of the instruction stream: the compiler must have them in registers here (so
-// its s_waitcnt lands here and not right behind the loads) and may not assemble them any earlier.
-#ifdef HIPEMU
-__device__ inline void vit_pin_loaded(int &, int &) {}
-#else
-__device__ __forceinline__ void vit_pin_loaded(int &a, int &b) { asm volatile("" : "+v"(a), "+v"(b)); }
-#endif
-template <typename Src> __device__ __forceinline__ int vit_soft_word(const Src &src, int t)
-{
-    const int len = src.length();
-    return src.triple((len - VIT_EXTRA + t) % len);            // conv_dec.c:407-412
-}
-
 // requires len % 64 == 0; all 64 lanes
 __device__ inline void viterbi_k7_wave_fast(const int8_t *coded, int len, unsigned long long *dec, uint32_t *out, int phases = 3)
 {
@@ -260,121 +230,8 @@ __device__ inline void viterbi_k7_wave_fast(const int8_t *coded, int len, unsign
     }
 }
 
-// ---- split form used by the P1 decoder: forward pass (one wave) + block-parallel traceback ----------
-// Forward only: fills dec[0 .. len+63] and returns the lane of the winning end state (wave-uniform).
-// The soft triples of a chunk are fetched two chunks (~4 us) ahead: the P1 gather goes to HBM / Infinity Cache.
-template <typename Src>
-__device__ inline int viterbi_fast_forward(const Src &src, unsigned long long *dec)
-{
-    const int lane = threadIdx.x & 63;
-    const int len = src.length();
-    const VitFastConst k = vit_fast_consts(lane);
-    const int nchunks = len / 64 + 1;
-    int pm = 0;
-    int aw = vit_soft_word(src, lane);
-    int aw1 = vit_soft_word(src, 64 + lane);                   // nchunks >= 2 always (len >= 64)
-    for (int c = 0; c < nchunks; c++) {
-        // Soft triple of chunk c + 2: the loads are issued here, but nothing touches their result until the 64 steps of
-        // this chunk are done -- the SQ counters showed the wave parked a quarter of its life on the s_waitcnt that sat
-        // right behind these loads when the three bytes were assembled at once.  Index clamped instead of branched on.
-        const int cn = (c + 2 < nchunks) ? c + 2 : nchunks - 1;
-        int b01, b2;
-        src.raw((len - VIT_EXTRA + 64 * cn + lane) % len, b01, b2);
-        int wlo = 0, whi = 0;
-        switch (c % 3) {
-        case 0: VitFwd<0, 0>::run(pm, aw, k, vit_branch_metric<0>(aw, 0, k), 0ull, wlo, whi); break;
-        case 1: VitFwd<4, 0>::run(pm, aw, k, vit_branch_metric<4>(aw, 0, k), 0ull, wlo, whi); break;
-        default: VitFwd<2, 0>::run(pm, aw, k, vit_branch_metric<2>(aw, 0, k), 0ull, wlo, whi); break;
-        }
-        dec[64 * c + lane] = ((unsigned long long)(uint32_t)whi << 32) | (uint32_t)wlo;
-        vit_pin_loaded(b01, b2);
-        aw = aw1; aw1 = b01 | (b2 << 16);
-    }
-    const int rend = (64 * nchunks) % 6;
-    const int best = wave_max_i32(pm);
-    const int smin = wave_min_i32(pm == best ? (int)rotr6((unsigned)lane, rend) : 64);
-    return wave_uniform((int)rotl6((unsigned)smin, rend));
-}
-
-// 64 steps of traceback for ALL 64 possible end lanes of a chunk at once (lane = candidate):
-// l <- l ^ (own(l) ? 0 : 1 << R); the bit emitted at a step is bit R of the lane before the move.
-template <int PH0, int S> struct VitMap {
-    static __device__ __forceinline__ void run(unsigned &l, int mlo, int mhi, unsigned &ohi, unsigned &olo)
-    {
-        constexpr int R = (PH0 + S) % 6;
-        const unsigned long long w = ((unsigned long long)(uint32_t)wave_readlane(mhi, S) << 32) | (uint32_t)wave_readlane(mlo, S);
-        const unsigned t = (unsigned)(w >> l) << R;            // bit R = own-wins of the candidate's lane
-        if (S >= 32) ohi = (ohi << 1) | ((l >> R) & 1u); else olo = (olo << 1) | ((l >> R) & 1u);
-        l ^= (1u << R) & ~t;
-        VitMap<PH0, S - 1>::run(l, mlo, mhi, ohi, olo);
-    }
-};
-template <int PH0> struct VitMap<PH0, -1> {
-    static __device__ __forceinline__ void run(unsigned &, int, int, unsigned &, unsigned &) {}
-};
-
-// Block-parallel traceback (blockDim.x a multiple of 64, any number of waves).
-//   pass 1  every wave takes chunks c = wave, wave + nwaves, ...: for each of the 64 candidate end lanes it
-//           walks the chunk back, records the start lane (gmap[c][lane], global scratch) and overwrites the
-//           chunk's 64 decision words IN PLACE with the 64 candidates' decoded 64-bit output.
-//   pass 2  segments of TB_SEG chunks: 64 lanes walk the 64 candidate chains of a segment in parallel
-//           -> segmap[seg][lane] (LDS).   pass 3: one lane composes the segment maps from the true end lane.
-//   pass 4  one lane per segment walks its chunks from the now-known segment end lane -> chosen[c] (LDS).
-//   pass 5  all threads pick the surviving candidate's output words.
-// LDS: nseg * 64 + nchunks bytes (3.5 KB for P1) -- deliberately small so that the front-end kernels of the
-// following blocks stay co-resident on the CU (a 146 KB LDS map stalled them for the whole traceback).
-constexpr int TB_SEG = 128;
-
-__device__ inline size_t viterbi_traceback_lds_bytes(int len)
-{
-    const int nchunks = len / 64 + 1, nseg = (nchunks + TB_SEG - 1) / TB_SEG;
-    return (size_t)nseg * 64 + nchunks;
-}
-
-__device__ inline void viterbi_fast_traceback_block(unsigned long long *dec, int len, int endlane, uint32_t *out, uint8_t *gmap, uint8_t *smem)
-{
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    const int nchunks = len / 64 + 1, nseg = (nchunks + TB_SEG - 1) / TB_SEG;
-    uint8_t *segmap = smem, *chosen = smem + (size_t)nseg * 64;
-    __shared__ uint8_t segend[64];                             // end lane of each segment (nseg <= 64: len <= 524224)
-    for (int c = wave; c < nchunks; c += nwaves) {
-        const unsigned long long mine = dec[64 * c + lane];
-        const int mlo = (int)(uint32_t)mine, mhi = (int)(uint32_t)(mine >> 32);
-        unsigned l = (unsigned)lane, ohi = 0, olo = 0;
-        switch (c % 3) {
-        case 0: VitMap<0, 63>::run(l, mlo, mhi, ohi, olo); break;
-        case 1: VitMap<4, 63>::run(l, mlo, mhi, ohi, olo); break;
-        default: VitMap<2, 63>::run(l, mlo, mhi, ohi, olo); break;
-        }
-        gmap[64 * c + lane] = (uint8_t)l;
-        dec[64 * c + lane] = ((unsigned long long)ohi << 32) | olo;
-    }
-    __threadfence_block();
-    __syncthreads();
-    for (int sg = wave; sg < nseg; sg += nwaves) {             // pass 2
-        const int c0 = sg * TB_SEG, c1 = min(nchunks, c0 + TB_SEG);
-        unsigned e = (unsigned)lane;
-        for (int c = c1 - 1; c >= c0; c--) e = gmap[64 * c + e];
-        segmap[64 * sg + lane] = (uint8_t)e;
-    }
-    __syncthreads();
-    if (tid == 0) {                                            // pass 3
-        unsigned e = (unsigned)endlane;
-        for (int sg = nseg - 1; sg >= 0; sg--) { segend[sg] = (uint8_t)e; e = segmap[64 * sg + e]; }
-    }
-    __syncthreads();
-    for (int sg = tid; sg < nseg; sg += blockDim.x) {          // pass 4
-        const int c0 = sg * TB_SEG, c1 = min(nchunks, c0 + TB_SEG);
-        unsigned e = segend[sg];
-        for (int c = c1 - 1; c >= c0; c--) { chosen[c] = (uint8_t)e; e = gmap[64 * c + e]; }
-    }
-    __syncthreads();
-    for (int c = tid; c < nchunks; c += blockDim.x) {          // pass 5
-        const unsigned long long o = dec[64 * c + chosen[c]];
-        if (c < nchunks - 1) out[2 * c] = (uint32_t)(o >> 32);       // steps 64c+32 .. 64c+63
-        if (c >= 1) out[2 * c - 1] = (uint32_t)o;                    // steps 64c .. 64c+31
-    }
-}
+// The P1 frame's split form -- forward pass by one wave + block-parallel traceback -- lives in viterbi_v3.h.
+constexpr int TB_SEG = 128;                                    // chunks per segment of the block-parallel traceback
 
 // dispatcher used by the kernels
 __device__ inline void viterbi_k7_decode(const int8_t *coded, int len, unsigned long long *dec, uint32_t *out, int phases = 3)
