@@ -30,6 +30,9 @@
 #include "nrsc5_dev.h"
 #include "wave_ops.h"
 #include "viterbi_wave.h"      // rotr6 / rotl6, TB_SEG
+#ifndef HIPEMU
+#include "viterbi_v3_asm.h"
+#endif
 
 namespace nrsc5 {
 
@@ -100,67 +103,38 @@ __device__ __forceinline__ void vit3_step_c(int &u, int &hist, int &ns, int nsp,
     u = (ns & ~1) | k.s0[(R + 1) % 6];
 }
 
-// ---- 8 trellis steps as ONE asm statement (the compiler pads every asm statement with an s_nop; one per 8 steps is fine) --
-// operands: u, h (history word), na / nb (maxima of the even / odd steps of the block; nb enters as the previous block's
-// last maximum), t (scratch); a0..a7 soft words (SGPRs); w0..w3, p4, q4, p5, q5 branch weights; z0..z5 = s0 per phase
-#define V3_PUSH(NSP) "v_alignbit_b32 %[h], %[" NSP "], %[h], 1\n\t"
-#define V3_DPP(A, W, CTRL, Z, NS, PL)                                                                                  \
-    "v_dot4_i32_i8 %[t], %[" A "], %[" W "], 0\n\t"                                                                    \
-    "v_add_u32 %[" NS "], %[u], %[t]\n\t" PL                                                                           \
-    "v_sub_u32_dpp %[t], %[u], %[t] " CTRL " row_mask:0xf bank_mask:0xf\n\t"                                           \
-    "v_max_i32 %[" NS "], %[" NS "], %[t]\n\t"                                                                         \
-    "v_and_or_b32 %[u], %[" NS "], -2, %[" Z "]\n\t"
-#define V3_SWAP(A, WP, WQ, INSN, Z, NS, PL)                                                                            \
-    "v_dot4_i32_i8 %[" NS "], %[" A "], %[" WP "], %[u]\n\t"                                                           \
-    "v_dot4_i32_i8 %[t], %[" A "], %[" WQ "], %[u]\n\t" PL                                                             \
-    INSN " %[" NS "], %[t]\n\t"                                                                                        \
-    "v_max_i32 %[" NS "], %[" NS "], %[t]\n\t"                                                                         \
-    "v_and_or_b32 %[u], %[" NS "], -2, %[" Z "]\n\t"
-// wait states: VALU write -> DPP read 2 (dot4, add [, alignbit] in between); VALU write -> permlane swap read 2
-#define V3_PD(NSP) V3_PUSH(NSP)                 /* push in a DPP step */
-#define V3_PS(NSP) V3_PUSH(NSP) "s_nop 0\n\t"   /* push in a swap step: one more wait state for the second dot4 */
-#define V3_ND ""                                /* no push (first step of a history word), DPP step */
-#define V3_NS "s_nop 1\n\t"                     /* no push, swap step */
-#define V3_P0(A, NS, PL) V3_DPP(A, "w0", "quad_perm:[1,0,3,2]", "z1", NS, PL)
-#define V3_P1(A, NS, PL) V3_DPP(A, "w1", "quad_perm:[2,3,0,1]", "z2", NS, PL)
-#define V3_P2(A, NS, PL) V3_DPP(A, "w2", "row_half_mirror", "z3", NS, PL)
-#define V3_P3(A, NS, PL) V3_DPP(A, "w3", "row_ror:8", "z4", NS, PL)
-#define V3_P4(A, NS, PL) V3_SWAP(A, "p4", "q4", "v_permlane16_swap_b32", "z5", NS, PL)
-#define V3_P5(A, NS, PL) V3_SWAP(A, "p5", "q5", "v_permlane32_swap_b32", "z0", NS, PL)
-#define V3_BLOCK_PH0(FIRST) V3_P0("a0", "na", FIRST) V3_P1("a1", "nb", V3_PD("na")) V3_P2("a2", "na", V3_PD("nb")) V3_P3("a3", "nb", V3_PD("na")) \
-                            V3_P4("a4", "na", V3_PS("nb")) V3_P5("a5", "nb", V3_PS("na")) V3_P0("a6", "na", V3_PD("nb")) V3_P1("a7", "nb", V3_PD("na"))
-#define V3_BLOCK_PH2(FIRST) V3_P2("a0", "na", FIRST) V3_P3("a1", "nb", V3_PD("na")) V3_P4("a2", "na", V3_PS("nb")) V3_P5("a3", "nb", V3_PS("na")) \
-                            V3_P0("a4", "na", V3_PD("nb")) V3_P1("a5", "nb", V3_PD("na")) V3_P2("a6", "na", V3_PD("nb")) V3_P3("a7", "nb", V3_PD("na"))
-#define V3_BLOCK_PH4(FIRST) V3_P4("a0", "na", FIRST) V3_P5("a1", "nb", V3_PS("na")) V3_P0("a2", "na", V3_PD("nb")) V3_P1("a3", "nb", V3_PD("na")) \
-                            V3_P2("a4", "na", V3_PD("nb")) V3_P3("a5", "nb", V3_PD("na")) V3_P4("a6", "na", V3_PS("nb")) V3_P5("a7", "nb", V3_PS("na"))
+// ---- 8 trellis steps as ONE asm statement: viterbi_v3_asm.h, generated by tools/gen_vit3_asm.py, which schedules the
+// steps (branch metrics one step ahead, history push as filler) and enforces gfx950's wait-state rules on the result.
+// operands: u, h (history word), ns (in: the previous block's last maximum, still to be pushed unless the block opens a
+// history word; out: this block's), x, d0..d3 (scratch); a0..a7 soft words (SGPRs); w0..w3, p4, q4, p5, q5 branch
+// weights; z0..z5 = s0 per phase
 #define V3_OPERANDS                                                                                                      \
-    : [u] "+v"(u), [h] "+v"(hist), [na] "=&v"(na), [nb] "+v"(nb), [t] "=&v"(t)                                           \
+    : [u] "+v"(u), [h] "+v"(hist), [ns] "+v"(ns), [x] "=&v"(x), [d0] "=&v"(d0), [d1] "=&v"(d1), [d2] "=&v"(d2), [d3] "=&v"(d3)   \
     : [a0] "s"(a0), [a1] "s"(a1), [a2] "s"(a2), [a3] "s"(a3), [a4] "s"(a4), [a5] "s"(a5), [a6] "s"(a6), [a7] "s"(a7),   \
       [w0] "v"(k.w[0]), [w1] "v"(k.w[1]), [w2] "v"(k.w[2]), [w3] "v"(k.w[3]),                                           \
       [p4] "v"(k.wp[0]), [q4] "v"(k.wq[0]), [p5] "v"(k.wp[1]), [q5] "v"(k.wq[1]),                                       \
       [z0] "v"(k.s0[0]), [z1] "v"(k.s0[1]), [z2] "v"(k.s0[2]), [z3] "v"(k.s0[3]), [z4] "v"(k.s0[4]), [z5] "v"(k.s0[5])
 
-// 8 steps starting in phase PH (0, 2 or 4); W0: the first of them opens a history word (no push).  nb: in = the
-// previous block's last maximum, out = this block's.
+// 8 steps starting in phase PH (0, 2 or 4); W0: the first of them opens a history word (nothing to push).
 template <int PH, bool W0>
-__device__ __forceinline__ void vit3_block8(int &u, int &hist, int &nb, int a0, int a1, int a2, int a3, int a4, int a5, int a6, int a7, const Vit3Const &k)
+__device__ __forceinline__ void vit3_block8(int &u, int &hist, int &ns, int a0, int a1, int a2, int a3, int a4, int a5, int a6, int a7, const Vit3Const &k)
 {
     static_assert(PH == 0 || PH == 2 || PH == 4, "8-step blocks start in an even phase");
-    int na;
 #ifdef HIPEMU
-    vit3_step_c<(PH + 0) % 6, !W0>(u, hist, na, nb, a0, k);
-    vit3_step_c<(PH + 1) % 6, true>(u, hist, nb, na, a1, k);
-    vit3_step_c<(PH + 2) % 6, true>(u, hist, na, nb, a2, k);
-    vit3_step_c<(PH + 3) % 6, true>(u, hist, nb, na, a3, k);
-    vit3_step_c<(PH + 4) % 6, true>(u, hist, na, nb, a4, k);
-    vit3_step_c<(PH + 5) % 6, true>(u, hist, nb, na, a5, k);
-    vit3_step_c<(PH + 6) % 6, true>(u, hist, na, nb, a6, k);
-    vit3_step_c<(PH + 7) % 6, true>(u, hist, nb, na, a7, k);
+    int na;
+    vit3_step_c<(PH + 0) % 6, !W0>(u, hist, na, ns, a0, k);
+    vit3_step_c<(PH + 1) % 6, true>(u, hist, ns, na, a1, k);
+    vit3_step_c<(PH + 2) % 6, true>(u, hist, na, ns, a2, k);
+    vit3_step_c<(PH + 3) % 6, true>(u, hist, ns, na, a3, k);
+    vit3_step_c<(PH + 4) % 6, true>(u, hist, na, ns, a4, k);
+    vit3_step_c<(PH + 5) % 6, true>(u, hist, ns, na, a5, k);
+    vit3_step_c<(PH + 6) % 6, true>(u, hist, na, ns, a6, k);
+    vit3_step_c<(PH + 7) % 6, true>(u, hist, ns, na, a7, k);
 #else
-    int t;
-    if constexpr (PH == 0) { if constexpr (W0) asm(V3_BLOCK_PH0(V3_ND) V3_OPERANDS); else asm(V3_BLOCK_PH0(V3_PD("nb")) V3_OPERANDS); }
-    else if constexpr (PH == 2) { if constexpr (W0) asm(V3_BLOCK_PH2(V3_ND) V3_OPERANDS); else asm(V3_BLOCK_PH2(V3_PD("nb")) V3_OPERANDS); }
-    else { if constexpr (W0) asm(V3_BLOCK_PH4(V3_NS) V3_OPERANDS); else asm(V3_BLOCK_PH4(V3_PS("nb")) V3_OPERANDS); }
+    int x, d0, d1, d2, d3;
+    if constexpr (PH == 0) { if constexpr (W0) asm(VIT3_ASM_PH0_OPEN V3_OPERANDS); else asm(VIT3_ASM_PH0_CONT V3_OPERANDS); }
+    else if constexpr (PH == 2) { if constexpr (W0) asm(VIT3_ASM_PH2_OPEN V3_OPERANDS); else asm(VIT3_ASM_PH2_CONT V3_OPERANDS); }
+    else { if constexpr (W0) asm(VIT3_ASM_PH4_OPEN V3_OPERANDS); else asm(VIT3_ASM_PH4_CONT V3_OPERANDS); }
 #endif
 }
 
@@ -185,14 +159,12 @@ __device__ __forceinline__ v16i vit3_load16(const int *p)
 #endif
 }
 
-__device__ __forceinline__ const int *vit3_group_ptr(const int *soft, int len, int t)   // soft words of steps t .. t+15 (conv_dec.c:407-412)
-{
-    int j = len - VIT_EXTRA + t;
-    if (j >= len) j -= len;
-    if (j >= len) j -= len;                                    // t < len + 64
-    return soft + j;
-}
-
+constexpr int VIT3_WARM = 6;                                   // chunks (64 steps each) of look-ahead of the L2 warm-up load
+#ifdef HIPEMU
+__device__ inline void vit3_keep(int) {}
+#else
+__device__ __forceinline__ void vit3_keep(int v) { asm volatile("" :: "v"(v)); }
+#endif
 #ifdef HIPEMU
 #define VIT3_SCHED_BARRIER() do { } while (0)
 #define VIT3_WAIT_SCALAR() do { } while (0)
@@ -201,33 +173,23 @@ __device__ __forceinline__ const int *vit3_group_ptr(const int *soft, int len, i
 #define VIT3_WAIT_SCALAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); } while (0)   /* lgkmcnt(0) */
 #endif
 
+// One history word = 32 steps starting in phase PH: wait for its soft words (issued a whole word -- ~900 cycles -- ago),
+// issue the next word's two scalar loads, run the steps, flush the last decision and store the word.  Scalar loads return
+// out of order, so the only wait there is is lgkmcnt(0); that is why exactly one word's loads are in flight.
+// jn: index (mod len) of the soft words of the NEXT word; words never straddle the tail-biting wrap (len % 32 == 0).
 template <int PH>
-__device__ __forceinline__ void vit3_chunk(int &u, int &hist, int &nsp, v16i &cur, const int *soft, int len, int t0, int tmax,
-                                           const Vit3Const &k, uint32_t *dec_lo, uint32_t *dec_hi)
+__device__ __forceinline__ void vit3_word(int &u, int &hist, int &nsp, v16i &c0, v16i &c1, const int *soft, int len, int &jn,
+                                          const Vit3Const &k, uint32_t *dec_word)
 {
-    // One scalar load in flight: scalar loads return out of order, so every wait is lgkmcnt(0).  Wait for the current
-    // group's words (issued a whole group -- ~400 cycles -- ago), THEN issue the next group's load, then run the 16 steps.
     VIT3_WAIT_SCALAR();
-    v16i nxt = vit3_load16(vit3_group_ptr(soft, len, min(t0 + 16, tmax)));
+    const v16i n0 = vit3_load16(soft + jn), n1 = vit3_load16(soft + jn + 16);
+    jn += 32; if (jn >= len) jn -= len;
     VIT3_SCHED_BARRIER();
-    vit3_run16<PH, true>(u, hist, nsp, cur, k);
-    VIT3_WAIT_SCALAR();
-    cur = nxt; nxt = vit3_load16(vit3_group_ptr(soft, len, min(t0 + 32, tmax)));
-    VIT3_SCHED_BARRIER();
-    vit3_run16<(PH + 16) % 6, false>(u, hist, nsp, cur, k);
+    vit3_run16<PH, true>(u, hist, nsp, c0, k);
+    vit3_run16<(PH + 16) % 6, false>(u, hist, nsp, c1, k);
     hist = vit3_push(hist, nsp);
-    *dec_lo = (uint32_t)hist;
-    VIT3_WAIT_SCALAR();
-    cur = nxt; nxt = vit3_load16(vit3_group_ptr(soft, len, min(t0 + 48, tmax)));
-    VIT3_SCHED_BARRIER();
-    vit3_run16<(PH + 32) % 6, true>(u, hist, nsp, cur, k);
-    VIT3_WAIT_SCALAR();
-    cur = nxt; nxt = vit3_load16(vit3_group_ptr(soft, len, min(t0 + 64, tmax)));
-    VIT3_SCHED_BARRIER();
-    vit3_run16<(PH + 48) % 6, false>(u, hist, nsp, cur, k);
-    hist = vit3_push(hist, nsp);
-    *dec_hi = (uint32_t)hist;
-    cur = nxt;
+    *dec_word = (uint32_t)hist;
+    c0 = n0; c1 = n1;
 }
 
 // Forward pass of one frame by one wave (len % 64 == 0).  soft: len dwords; dec: 2 * (len / 64 + 1) history words per lane,
@@ -237,17 +199,27 @@ __device__ __forceinline__ int viterbi3_forward(const int *soft, int len, uint32
 {
     const unsigned phys = threadIdx.x & 63u, L = vit3_logical_lane(phys);
     const Vit3Const k = vit3_consts(phys);
-    const int nchunks = len / 64 + 1, tmax = 64 * nchunks - 16;
+    const int nchunks = len / 64 + 1;
     int u = k.s0[0], hist = 0, nsp = 0;                        // reset_decoder: all-zero metrics for tail biting
-    v16i cur = vit3_load16(vit3_group_ptr(soft, len, 0));
-    for (int c = 0; c < nchunks; c++) {
-        uint32_t *lo = dec + (size_t)(2 * c) * 64 + L, *hi = lo + 64;
+    int jn = len - VIT_EXTRA;                                  // step t reads soft[(len - 32 + t) % len] (conv_dec.c:407-412)
+    v16i c0 = vit3_load16(soft + jn), c1 = vit3_load16(soft + jn + 16);
+    jn = 0;
+    // L2 warm-up: the scalar loads have one word (~900 cycles) of cover, enough for an L2 / Infinity Cache hit but not for
+    // HBM; one vector load per chunk touches the 256 bytes that will be needed VIT3_WARM chunks from now
+    int jw = (64 * VIT3_WARM - VIT_EXTRA) % len, warm = 0;
+    uint32_t *w0 = dec + L;
+    for (int c = 0; c < nchunks; c++, w0 += 128) {
+        int jl = jw + (int)phys; if (jl >= len) jl -= len;
+        const int warm_next = soft[jl];
+        jw += 64; if (jw >= len) jw -= len;
         switch (c % 3) {                                       // (64 c) % 6
-        case 0: vit3_chunk<0>(u, hist, nsp, cur, soft, len, 64 * c, tmax, k, lo, hi); break;
-        case 1: vit3_chunk<4>(u, hist, nsp, cur, soft, len, 64 * c, tmax, k, lo, hi); break;
-        default: vit3_chunk<2>(u, hist, nsp, cur, soft, len, 64 * c, tmax, k, lo, hi); break;
+        case 0: vit3_word<0>(u, hist, nsp, c0, c1, soft, len, jn, k, w0); vit3_word<2>(u, hist, nsp, c0, c1, soft, len, jn, k, w0 + 64); break;
+        case 1: vit3_word<4>(u, hist, nsp, c0, c1, soft, len, jn, k, w0); vit3_word<0>(u, hist, nsp, c0, c1, soft, len, jn, k, w0 + 64); break;
+        default: vit3_word<2>(u, hist, nsp, c0, c1, soft, len, jn, k, w0); vit3_word<4>(u, hist, nsp, c0, c1, soft, len, jn, k, w0 + 64); break;
         }
+        warm ^= warm_next;                                     // consumed at the end of the chunk: its vmcnt wait is free by then
     }
+    vit3_keep(warm);
     // end state: first maximum in STATE order (conv_dec.c:310-318); logical lane L holds state rotr6^steps(L)
     const int rend = (64 * nchunks) % 6;
     const int pm = u >> 1;
@@ -266,7 +238,9 @@ __device__ __forceinline__ unsigned long long vit3_shift_out(unsigned &h)
 #else
     unsigned long long w;
     unsigned hn;
-    asm("v_add_co_u32 %0, %1, %2, %2" : "=v"(hn), "=s"(w) : "v"(h));
+    // gfx940-class hazard: VALU writes an SGPR -> VALU reads it as a constant needs 2 wait states, and the compiler
+    // cannot see that this asm is such a writer
+    asm("v_add_co_u32 %0, %1, %2, %2\n\ts_nop 1" : "=v"(hn), "=s"(w) : "v"(h));
     h = hn;
     return w;
 #endif
