@@ -1,0 +1,60 @@
+// Short transcendental forms for the serial chains of the sync kernels (Costas loops: 32 dependent sincos + atan2 per
+// reference carrier and block, sync.c:90-130).  The device's libm (ocml) spends ~100 instructions per call on argument
+// reduction and ulp-exact polynomials; here the argument is reduced exactly in double (3 instructions), sine / cosine come
+// from the transcendental unit (v_sin_f32 / v_cos_f32, input in revolutions) and the arc tangent from a 4-term polynomial
+// after the tan(pi/8) reduction.  Measured on the MI355X against double precision (tools/probe/math_probe.hip):
+// |error| <= 5e-7 in sin / cos for |x| <= 2000 rad, <= 3e-7 rad in atan2 -- the reference's own float32 chain (glibc)
+// is not reproduced to the last ulp by ANY other libm either; SURVEY 8c pins these quantities at 1e-4.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace nrsc5 {
+
+__device__ __forceinline__ void fast_sincos(float x, float &s, float &c)
+{
+#ifdef HIPEMU
+    s = sinf(x); c = cosf(x);
+#else
+    const double t = (double)x * 0.15915494309189533577;       // revolutions
+    const float f = (float)(t - rint(t));                      // [-0.5, 0.5], exact to float precision for any float x
+    s = __builtin_amdgcn_sinf(f);
+    c = __builtin_amdgcn_cosf(f);
+#endif
+}
+
+// x already inside [-pi, pi] (or a few turns): no double needed
+__device__ __forceinline__ void fast_sincos_reduced(float x, float &s, float &c)
+{
+#ifdef HIPEMU
+    s = sinf(x); c = cosf(x);
+#else
+    const float f = x * 0.15915494309189533577f;
+    s = __builtin_amdgcn_sinf(f);
+    c = __builtin_amdgcn_cosf(f);
+#endif
+}
+
+__device__ __forceinline__ float fast_atan2(float y, float x)
+{
+#ifdef HIPEMU
+    return atan2f(y, x);
+#else
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float a = mn * __builtin_amdgcn_rcpf(mx);                  // [0, 1]; 0 / 0 -> NaN, handled below
+    if (mx == 0.0f) a = 0.0f;
+    float y0 = 0.0f, z = a;
+    if (a > 0.41421356237309503f) { y0 = 0.78539816339744831f; z = (a - 1.0f) * __builtin_amdgcn_rcpf(a + 1.0f); }
+    const float w = z * z;
+    float p = __builtin_fmaf(8.05374449538e-2f, w, -1.38776856032e-1f);
+    p = __builtin_fmaf(p, w, 1.99777106478e-1f);
+    p = __builtin_fmaf(p, w, -3.33329491539e-1f);
+    float r = y0 + __builtin_fmaf(p * w, z, z);
+    if (ay > ax) r = 1.57079632679489662f - r;
+    if (x < 0.0f) r = 3.14159265358979324f - r;
+    return copysignf(r, y);
+#endif
+}
+
+}  // namespace nrsc5

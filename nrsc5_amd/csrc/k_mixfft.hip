@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 #include "wave_ops.h"
+#include "fastmath.h"
 
 namespace nrsc5 {
 
@@ -135,8 +136,8 @@ __global__ __launch_bounds__(128) void k_mixfft(DevTables tb, DevBuffers db, con
     double a1 = 128.0 * dth;
     a1 -= 2 * M_PI * rint(a1 * (1.0 / (2 * M_PI)));
     float2 ph, stp;
-    sincosf((float)a0, &ph.y, &ph.x);
-    sincosf((float)a1, &stp.y, &stp.x);
+    fast_sincos_reduced((float)a0, ph.y, ph.x);                // both angles were reduced to [-pi, pi] in double above
+    fast_sincos_reduced((float)a1, stp.y, stp.x);
     const double inv_q15 = 1.0 / 32767.0;                      // x / 32767.0f (defines.h:111), via an exact-in-practice double product
 
     float2 x[16];

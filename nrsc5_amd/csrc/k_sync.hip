@@ -13,6 +13,7 @@
 #include "viterbi_wave.h"
 #include "prepare_block.h"
 #include "l2_header.h"
+#include "fastmath.h"
 
 namespace nrsc5 {
 
@@ -56,11 +57,11 @@ __device__ inline uint32_t costas_block(const float2 *src, int stride, float &fr
 #pragma unroll 4
     for (int n = 0; n < NSYM; n++) {
         const float2 z = zin[n];
-        float s1, c1; sincosf(phase, &s1, &c1);
+        float s1, c1; fast_sincos(phase, s1, c1);              // cexpf(-I phase): see fastmath.h
         const float s2 = 2.0f * s1 * c1, c2 = c1 * c1 - s1 * s1;                // e^{2i phase}
         const float2 w = make_float2(z.x * z.x - z.y * z.y, z.x * z.y + z.y * z.x);
         const float ur = w.x * c2 + w.y * s2, ui = w.y * c2 - w.x * s2;         // w * e^{-2i phase}
-        const float error = atan2f(ui, ur) * 0.5f;
+        const float error = fast_atan2(ui, ur) * 0.5f;
         const float2 zr = make_float2(z.x * c1 + z.y * s1, z.y * c1 - z.x * s1);   // z * e^{-i phase}
         if (STORE) { zout[n] = zr; phout[n] = phase; }
         if (zr.x > 0) pos |= 1u << n;
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         const bool px_on = ppb_px > PM_PART && (st.px_started || (bc & 1) == 0);   // decode_push_px1/2 (decode.c:393-437)
         for (int k = tid; k < nref * NSYM; k += 256) {
             const int r = k / NSYM, n = k % NSYM;
-            float sn, cs; sincosf(refph[r][n], &sn, &cs);
+            float sn, cs; fast_sincos(refph[r][n], sn, cs);
             refcs[r][n] = make_float2(cs, sn);
         }
         if (tid < nref) {                                      // calc_smag (sync.c:254-261)
