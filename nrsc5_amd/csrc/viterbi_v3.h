@@ -173,23 +173,24 @@ __device__ __forceinline__ void vit3_keep(int v) { asm volatile("" :: "v"(v)); }
 #define VIT3_WAIT_SCALAR() do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_waitcnt(0xc07f); __builtin_amdgcn_sched_barrier(0); } while (0)   /* lgkmcnt(0) */
 #endif
 
-// One history word = 32 steps starting in phase PH: wait for its soft words (issued a whole word -- ~900 cycles -- ago),
-// issue the next word's two scalar loads, run the steps, flush the last decision and store the word.  Scalar loads return
-// out of order, so the only wait there is is lgkmcnt(0); that is why exactly one word's loads are in flight.
-// jn: index (mod len) of the soft words of the NEXT word; words never straddle the tail-biting wrap (len % 32 == 0).
+// One history word = 32 steps starting in phase PH, soft words in (c0, c1): wait for them (their loads were issued a whole
+// word -- ~900 cycles -- ago), issue the next word's two scalar loads into (n0, n1), run the steps, flush the last decision
+// and store the word.  Scalar loads return out of order, so the only wait there is is lgkmcnt(0); that is why exactly one
+// word's loads are in flight.  jn: index (mod len) of the NEXT word's soft words; words never straddle the tail-biting
+// wrap (len % 32 == 0).  Callers alternate two register sets so that no 16-SGPR tuple is ever copied.
 template <int PH>
-__device__ __forceinline__ void vit3_word(int &u, int &hist, int &nsp, v16i &c0, v16i &c1, const int *soft, int len, int &jn,
-                                          const Vit3Const &k, uint32_t *dec_word)
+__device__ __forceinline__ void vit3_word(int &u, int &hist, int &nsp, const v16i &c0, const v16i &c1, v16i &n0, v16i &n1,
+                                          const int *soft, int len, int &jn, const Vit3Const &k, uint32_t *&dec_word)
 {
     VIT3_WAIT_SCALAR();
-    const v16i n0 = vit3_load16(soft + jn), n1 = vit3_load16(soft + jn + 16);
+    n0 = vit3_load16(soft + jn); n1 = vit3_load16(soft + jn + 16);
     jn += 32; if (jn >= len) jn -= len;
     VIT3_SCHED_BARRIER();
     vit3_run16<PH, true>(u, hist, nsp, c0, k);
     vit3_run16<(PH + 16) % 6, false>(u, hist, nsp, c1, k);
     hist = vit3_push(hist, nsp);
     *dec_word = (uint32_t)hist;
-    c0 = n0; c1 = n1;
+    dec_word += 64;
 }
 
 // Forward pass of one frame by one wave (len % 64 == 0).  soft: len dwords; dec: 2 * (len / 64 + 1) history words per lane,
@@ -202,22 +203,34 @@ __device__ __forceinline__ int viterbi3_forward(const int *soft, int len, uint32
     const int nchunks = len / 64 + 1;
     int u = k.s0[0], hist = 0, nsp = 0;                        // reset_decoder: all-zero metrics for tail biting
     int jn = len - VIT_EXTRA;                                  // step t reads soft[(len - 32 + t) % len] (conv_dec.c:407-412)
-    v16i c0 = vit3_load16(soft + jn), c1 = vit3_load16(soft + jn + 16);
+    v16i a0 = vit3_load16(soft + jn), a1 = vit3_load16(soft + jn + 16), b0, b1;
     jn = 0;
     // L2 warm-up: the scalar loads have one word (~900 cycles) of cover, enough for an L2 / Infinity Cache hit but not for
-    // HBM; one vector load per chunk touches the 256 bytes that will be needed VIT3_WARM chunks from now
+    // HBM; one vector load per 3 chunks touches the 768 bytes that will be needed VIT3_WARM chunks from now
     int jw = (64 * VIT3_WARM - VIT_EXTRA) % len, warm = 0;
-    uint32_t *w0 = dec + L;
-    for (int c = 0; c < nchunks; c++, w0 += 128) {
+    uint32_t *w = dec + L;
+    // 3 chunks = 192 steps = 6 history words per trip: the phase pattern (0, 2, 4, 0, 2, 4) and the roles of the two
+    // soft-word register sets repeat exactly, so the loop carries no register shuffles
+    for (int it = nchunks / 3; it > 0; it--) {
         int jl = jw + (int)phys; if (jl >= len) jl -= len;
-        const int warm_next = soft[jl];
-        jw += 64; if (jw >= len) jw -= len;
-        switch (c % 3) {                                       // (64 c) % 6
-        case 0: vit3_word<0>(u, hist, nsp, c0, c1, soft, len, jn, k, w0); vit3_word<2>(u, hist, nsp, c0, c1, soft, len, jn, k, w0 + 64); break;
-        case 1: vit3_word<4>(u, hist, nsp, c0, c1, soft, len, jn, k, w0); vit3_word<0>(u, hist, nsp, c0, c1, soft, len, jn, k, w0 + 64); break;
-        default: vit3_word<2>(u, hist, nsp, c0, c1, soft, len, jn, k, w0); vit3_word<4>(u, hist, nsp, c0, c1, soft, len, jn, k, w0 + 64); break;
-        }
-        warm ^= warm_next;                                     // consumed at the end of the chunk: its vmcnt wait is free by then
+        const int w0 = soft[jl], w1 = soft[jl + 64 < len ? jl + 64 : jl + 64 - len], w2 = soft[jl + 128 < len ? jl + 128 : jl + 128 - len];
+        jw += 192; if (jw >= len) jw -= len;
+        vit3_word<0>(u, hist, nsp, a0, a1, b0, b1, soft, len, jn, k, w);
+        vit3_word<2>(u, hist, nsp, b0, b1, a0, a1, soft, len, jn, k, w);
+        vit3_word<4>(u, hist, nsp, a0, a1, b0, b1, soft, len, jn, k, w);
+        vit3_word<0>(u, hist, nsp, b0, b1, a0, a1, soft, len, jn, k, w);
+        vit3_word<2>(u, hist, nsp, a0, a1, b0, b1, soft, len, jn, k, w);
+        vit3_word<4>(u, hist, nsp, b0, b1, a0, a1, soft, len, jn, k, w);
+        warm ^= w0 ^ w1 ^ w2;                                  // consumed at the end of the trip: their vmcnt wait is free by then
+    }
+    const int rest = nchunks % 3;                              // 1 or 2 chunks more (phases 0, then 4)
+    if (rest >= 1) {
+        vit3_word<0>(u, hist, nsp, a0, a1, b0, b1, soft, len, jn, k, w);
+        vit3_word<2>(u, hist, nsp, b0, b1, a0, a1, soft, len, jn, k, w);
+    }
+    if (rest == 2) {
+        vit3_word<4>(u, hist, nsp, a0, a1, b0, b1, soft, len, jn, k, w);
+        vit3_word<0>(u, hist, nsp, b0, b1, a0, a1, soft, len, jn, k, w);
     }
     vit3_keep(warm);
     // end state: first maximum in STATE order (conv_dec.c:310-318); logical lane L holds state rotr6^steps(L)

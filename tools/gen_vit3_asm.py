@@ -104,17 +104,17 @@ def gen_block(ph0, opens_word):
     for i, r in enumerate(phases):
         nd = dots_for(i + 1, phases[i + 1], regs[i + 1], S) if i < 7 else []
         z = f"z{(r + 1) % 6}"
+        # the first of the next step's branch metrics goes FIRST: it separates the and_or that produced u from the add that
+        # reads it (a dependent instruction issued back to back costs an extra cycle on this in-order pipe)
+        if nd and r < 4:               # (swap steps need their fillers between the adds and the swap instead)
+            nd.pop(0)()
         if r < 4:
             d = regs[i][0]
             S.emit(f"v_add_u32 %[x], %[u], %[{d}]", "valu", reads=("u", d), writes=("x",))
             if nd:
                 nd.pop(0)()
-            elif push_pending:
-                push(); push_pending = False
             S.emit(f"v_sub_u32_dpp %[{d}], %[u], %[{d}] {DPP_CTRL[r]} row_mask:0xf bank_mask:0xf", "valu",
                    reads=(d,), dpp_reads=("u",), writes=(d,))
-            if nd:
-                nd.pop(0)()
             if push_pending:
                 push(); push_pending = False
             S.emit(f"v_max_i32 %[ns], %[x], %[{d}]", "valu", reads=("x", d), writes=("ns",))
