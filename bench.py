@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--payloads", type=int, default=8, help="distinct transmissions shared by the streams (each stream has its own CFO/offset/noise)")
     ap.add_argument("--sync-p1", action="store_true", help="decode P1 frames in order on the main stream (exact reference event timing) instead of the overlapped window pipeline")
     ap.add_argument("--l2-feedback", type=int, default=1, help="1: the engine applies the reference's L2 -> L1 sync-loss feedback itself (RS check of the first L2 header on the device), as the CPU baseline's frame.c does; 0: off")
+    ap.add_argument("--copy-input", action="store_true", help="decimate the captures into the engine's Q15 FIFO first (K1 as its own kernel) instead of reading them in place")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no HIP-event kernel timing inside the timed region (roofline fields become 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--l2-index-inline", action="store_true", help="engine option l2_index: index every P1 frame on the decode streams inside the timed region (default: untimed post-pass)")
@@ -166,8 +167,12 @@ def main():
 
     # replay (window pipeline + L2 feedback): blocks that ran behind a failed P1 frame keep their records / ring slots
     # (marked void, never delivered), so both rings carry head-room for the speculated stretch
-    E = eng.Engine(max_streams=S, q15_capacity=int(stride // 4 + 1024), record_capacity=max(512, 2 * 16 * n_frames + 64),
-                   p1_slots=n_frames + 12, p1_async=not args.sync_p1, device=local, l2_feedback=bool(args.l2_feedback), l2_index=bool(args.l2_index_inline))
+    # zero-copy batch: the captures are read where they are (half-band fused into the symbol kernel): no decimated copy,
+    # so the FIFO stays at its minimum size
+    zero_copy = not args.copy_input
+    E = eng.Engine(max_streams=S, q15_capacity=2 * 71280 if zero_copy else int(stride // 4 + 1024), record_capacity=max(512, 2 * 16 * n_frames + 64),
+                   p1_slots=n_frames + 12, p1_async=not args.sync_p1, device=local, l2_feedback=bool(args.l2_feedback), l2_index=bool(args.l2_index_inline),
+                   batch_zero_copy=zero_copy)
 
     host_ms = {"reset": 0.0, "append": 0.0, "process": 0.0, "fetch": 0.0}
 
@@ -327,7 +332,7 @@ def main():
         "config": {"workload": f"configs[2]: batch={S} independent hybrid-FM MP1 cu8 streams @1.488375 MS/s per GPU, "
                                f"{nbytes[0] / 2 / FS:.2f} s each ({n_frames} L1 frames), CFO +-300 Hz, offset [0,4320), SNR 15/20/25 dB",
                    "streams_per_gpu": S, "seconds_per_stream": round(float(nbytes[0]) / 2 / FS, 3),
-                   "p1_decode": "in-order" if args.sync_p1 else "windowed-overlap", "l2_feedback": "on-device" if args.l2_feedback else "off", "block_steps_per_pass": int(block_steps),
+                   "p1_decode": "in-order" if args.sync_p1 else "windowed-overlap", "l2_feedback": "on-device" if args.l2_feedback else "off", "input": "read in place (half-band fused into the symbol kernel)" if zero_copy else "decimated copy in the Q15 FIFO", "block_steps_per_pass": int(block_steps),
                    "distinct_payloads": args.payloads, "hbm_resident_input_GB": round(float(nbytes.sum()) / 1e9, 2)},
         "roofline": roofline, "cpu_baseline": cpu,
         "parity": {"streams": n_total, "streams_locked_and_all_p1_frames_equal_transmitted_bits": good,

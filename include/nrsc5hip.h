@@ -114,6 +114,12 @@ typedef struct nrsc5hip_config {
                                   0: the host does it through nrsc5hip_force_resync (the drop-in shim). */
     int am_enable;             /* allocate the AM buffers (1.4 MB per stream) so that streams may be switched to
                                   NRSC5HIP_MODE_AM */
+    int batch_zero_copy;       /* 1: nrsc5hip_batch_append_cu8 on freshly reset FM streams does NOT decimate into the FIFO: the engine keeps a
+                                  reference to the caller's device buffer and the block steps read the cu8 samples directly (half-band
+                                  fused into the symbol kernel: the capture is read from HBM once, no 4-byte-per-sample Q15 copy).
+                                  The buffer must stay valid and unchanged until those streams are reset; one append per stream and
+                                  reset; q15_capacity may then be the minimum (2 * 71280).  0: samples are copied (decimated) into the
+                                  engine's FIFO during the call, as the streaming seam does. */
     int l2_index;              /* 1: every FM P1 frame is also indexed on the decode stream right after its traceback
                                   (nrsc5hip_l2_frame per ring slot, read with nrsc5hip_l2_frame_get / nrsc5hip_batch_fetch_l2);
                                   0: indexes only on request (nrsc5hip_l2_index) */

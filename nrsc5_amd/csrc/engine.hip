@@ -63,6 +63,7 @@ struct nrsc5hip_engine {
     std::vector<int> drained;          // records already handed out per stream
     std::vector<int> mode_host;        // MODE_FM / MODE_AM per stream
     std::vector<long long> raw_host;   // AM cu8: raw input samples consumed (32:1 decimator phase)
+    std::vector<char> attached;        // zero-copy batch: the stream reads the caller's capture (one append per reset)
     // staging
     uint8_t *stage_dev; size_t stage_bytes;
     int *ids_dev; unsigned *nbytes_dev;
@@ -335,6 +336,9 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         }
         if (rc) { snprintf(g_err, sizeof(g_err), "stream/event creation failed"); break; }
         e->main = e->lanes[0].main;
+        // K1 of the copying batch path runs ahead of the block steps on this stream (confining it to a slice of the CUs
+        // with hipExtStreamCreateWithCUMask was measured: no gain, profiles/r02_k1cus.txt -- it is the HBM traffic itself that
+        // slows the latency-bound step kernels; the zero-copy batch path has no K1 at all)
         if (hipStreamCreate(&e->dec_stream) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "hipStreamCreate failed"); break; }
         e->dec_chunk = 0; e->chunk_nbytes_dev = nullptr; e->chunk_cap = 0;
         if ((rc = build_tables(e))) break;
@@ -347,6 +351,8 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             if ((rc = dev_alloc(e, &db.ckpt, S * NWIN))) break;
         }
         if ((rc = dev_alloc(e, &db.q15, S * (size_t)db.q15_cap))) break;
+        db.acq_win = nullptr;
+        if (cfg->batch_zero_copy && (rc = dev_alloc(e, &db.acq_win, S * WIN_N))) break;
         if ((rc = dev_alloc(e, &db.acq_filt, S * WIN_N))) break;
         if ((rc = dev_alloc(e, &db.acq_sums, S * SYM_N))) break;
         if ((rc = dev_alloc(e, &db.bins, S * NSYM * LIVE_N))) break;
@@ -417,7 +423,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             hipMemset(db.records, 0, S * db.rec_cap * sizeof(BlockRecord)) != hipSuccess ||
             hipMemset(db.pm, 0, S * NPM * PM_FRAME) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "state init copy failed"); break; }
         e->wr_host.assign(S, 0); e->base_host.assign(S, 0); e->drained.assign(S, 0);
-        e->mode_host.assign(S, MODE_FM); e->raw_host.assign(S, 0);
+        e->mode_host.assign(S, MODE_FM); e->raw_host.assign(S, 0); e->attached.assign(S, 0);
         for (int l = 0; l < e->nlanes; l++) { e->lanes[l].db = db; e->lanes[l].counters_dev = db.counters + 4 * l; e->lanes[l].db.counters = db.counters + 4 * l; }
         e->prof_on = false;
         for (int k = 0; k < NRSC5HIP_PROF_CLASSES; k++) { e->prof_ms[k] = 0; e->prof_launches[k] = 0; }
@@ -687,6 +693,7 @@ static int push_common(nrsc5hip_engine *e, int s, const void *host, size_t nbyte
     const size_t unit = 4;                                     // cu8: 2 complex samples; cs16: 1 complex sample
     if (nbytes_total % unit) FAIL(NRSC5HIP_EINVAL, "length must be a multiple of %zu bytes", unit);
     const bool am = e->mode_host[s] == MODE_AM;
+    if (e->attached[s]) FAIL(NRSC5HIP_EINVAL, "stream %d reads a zero-copy capture: reset it before pushing samples", s);
     while (nbytes_total) {
         const size_t chunk = nbytes_total > e->stage_bytes ? e->stage_bytes : nbytes_total;
         long long nq15 = (long long)chunk / 4;                  // FM cu8: 2:1; cs16: one complex sample per 4 bytes
@@ -731,7 +738,7 @@ extern "C" int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream)
         HIPCHK(hipMemset(e->db.am_job + (size_t)stream * NWIN, 0, NWIN * sizeof(AmJob)));
         HIPCHK(hipMemset(e->db.am_pids_rec + (size_t)stream * NWIN * 8, 0xff, NWIN * 8 * sizeof(int)));
     }
-    e->wr_host[stream] = 0; e->base_host[stream] = 0; e->drained[stream] = 0; e->raw_host[stream] = 0;
+    e->wr_host[stream] = 0; e->base_host[stream] = 0; e->drained[stream] = 0; e->raw_host[stream] = 0; e->attached[stream] = 0;
     for (int l = 0; l < e->nlanes; l++) { e->lanes[l].acq_needed = true; e->lanes[l].px_needed = true; e->lanes[l].set_sig = 0; }
     return 0;
 }
@@ -797,6 +804,23 @@ extern "C" int nrsc5hip_batch_append_cu8(nrsc5hip_engine *e, int nstreams, const
                 e->wr_host[s] += (e->raw_host[s] + nbytes[k] / 2) / 32 - e->raw_host[s] / 32;
                 e->raw_host[s] += nbytes[k] / 2;
             }
+            HIPCHK(hipGetLastError());
+            return 0;
+        }
+    }
+    for (int k = 0; k < nstreams; k++) {
+        const int s = stream_ids ? stream_ids[k] : k;
+        if (e->attached[s]) FAIL(NRSC5HIP_EINVAL, "stream %d already reads a zero-copy capture (one append per reset)", s);
+    }
+    if (e->cfg.batch_zero_copy) {
+        bool all_fresh = true;
+        for (int k = 0; k < nstreams; k++) all_fresh = all_fresh && e->wr_host[stream_ids ? stream_ids[k] : k] == 0;
+        if (all_fresh) {
+            // zero-copy: the capture stays where it is; the block steps decimate what they read (k_mixfft, k_acq_decimate)
+            if (((uintptr_t)dev_iq | (uintptr_t)stride_bytes) & 3) FAIL(NRSC5HIP_EINVAL, "zero-copy captures must be 4-byte aligned");
+            for (int k = 0; k < nstreams; k++) if (nbytes[k] % 4) FAIL(NRSC5HIP_EINVAL, "chunk %d: nbytes %% 4 != 0", k);
+            launch_attach_raw(e->db, nstreams, ids_dev, dev_iq, stride_bytes, e->nbytes_dev, e->main);
+            for (int k = 0; k < nstreams; k++) { const int s = stream_ids ? stream_ids[k] : k; e->wr_host[s] += nbytes[k] / 4; e->attached[s] = 1; }
             HIPCHK(hipGetLastError());
             return 0;
         }
@@ -1249,6 +1273,7 @@ extern "C" int nrsc5hip_reset_all(nrsc5hip_engine *e)
         HIPCHK(hipMemset(e->db.am_pids_rec, 0xff, S * NWIN * 8 * sizeof(int)));
     }
     std::fill(e->raw_host.begin(), e->raw_host.end(), 0);
+    std::fill(e->attached.begin(), e->attached.end(), 0);
     std::fill(e->wr_host.begin(), e->wr_host.end(), 0);
     std::fill(e->base_host.begin(), e->base_host.end(), 0);
     std::fill(e->drained.begin(), e->drained.end(), 0);

@@ -11,12 +11,30 @@
 #include "kernels.h"
 #include "wave_ops.h"
 #include "prepare_block.h"
+#include "halfband_raw.h"
 
 namespace nrsc5 {
 
 __device__ inline int stream_of(const int *ids, int idx) { return ids ? ids[idx] : idx; }
 
 __device__ inline bool needs_coarse(const StreamState &st) { return window_ready(st) && st.sync_state != SYNC_FINE; }
+
+// acquisition window of a stream: the FIFO at rd, or -- zero-copy batch -- the window decimated by k_acq_decimate
+__device__ inline const c16 *acq_window(const DevBuffers &db, const StreamState &st, int s)
+{
+    return st.raw ? db.acq_win + (size_t)s * WIN_N : db.q15 + (size_t)s * db.q15_cap + (st.rd - st.base);
+}
+
+// ---- zero-copy batch: decimate the 33-symbol window of an un-synchronised stream out of its cu8 capture ----------
+__global__ __launch_bounds__(256) void k_acq_decimate(DevTables tb, DevBuffers db, const int *ids)
+{
+    const int s = stream_of(ids, blockIdx.y);
+    const StreamState &st = db.state[s];
+    if (!st.raw || !needs_coarse(st)) return;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= WIN_N) return;
+    db.acq_win[(size_t)s * WIN_N + t] = hb_sample_q15(st.raw, st.rd + t, hb_taps(tb.hb_q15));
+}
 
 // ---- a) FIR ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_acq_fir(DevTables tb, DevBuffers db, const int *ids)
@@ -26,7 +44,7 @@ __global__ __launch_bounds__(256) void k_acq_fir(DevTables tb, DevBuffers db, co
     if (!needs_coarse(st)) return;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= WIN_N) return;
-    const c16 *win = db.q15 + (size_t)s * db.q15_cap + (st.rd - st.base);
+    const c16 *win = acq_window(db, st, s);
     // a[k] = sample t-31+k; indices < 0 come from the filter's carried history
     int sr = 0, si = 0;
 #pragma unroll
@@ -114,11 +132,12 @@ __global__ __launch_bounds__(256) void k_acq_peak(DevTables tb, DevBuffers db, c
         st.coarse_re = best_v.x; st.coarse_im = best_v.y;
     }
     // the FIR's sliding window now ends at the last sample of this acquire window
-    if (tid < 31) st.fir_hist[tid] = db.q15[(size_t)s * db.q15_cap + (st.rd - st.base) + WIN_N - 31 + tid];
+    if (tid < 31) st.fir_hist[tid] = acq_window(db, st, s)[WIN_N - 31 + tid];
 }
 
 void launch_acquire(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st)
 {
+    if (db.acq_win) hipLaunchKernelGGL(k_acq_decimate, dim3((WIN_N + 255) / 256, nstreams), dim3(256), 0, st, tb, db, stream_ids);
     hipLaunchKernelGGL(k_acq_fir, dim3((WIN_N + 255) / 256, nstreams), dim3(256), 0, st, tb, db, stream_ids);
     hipLaunchKernelGGL(k_acq_corr, dim3((SYM_N + 255) / 256, nstreams), dim3(256), 0, st, db, stream_ids);
     hipLaunchKernelGGL(k_acq_peak, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids);

@@ -110,6 +110,24 @@ void launch_decimate_fm_cu8(const DevTables &tb, const DevBuffers &db, int nstre
     hipLaunchKernelGGL(k_decimate_commit, dim3((nstreams + 63) / 64), dim3(64), 0, st, db, stream_ids, iq_base, iq_stride, nbytes, nstreams);
 }
 
+// engine option batch_zero_copy: a freshly reset stream takes the caller's capture as is -- nothing is copied; the symbol
+// kernel (k_mixfft) and the acquisition (k_acq_decimate) run the half-band on the fly (halfband_raw.h)
+__global__ void k_attach_raw(DevBuffers db, const int *ids, const uint8_t *iq_base, long long iq_stride, const unsigned *nbytes, int nstreams)
+{
+    const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= nstreams) return;
+    StreamState &st = db.state[stream_of(ids, sidx)];
+    st.raw = iq_base + (size_t)sidx * iq_stride;
+    st.wr = nbytes[sidx] / 4;                                  // decimated samples the capture holds
+    st.base = 0;
+}
+
+void launch_attach_raw(const DevBuffers &db, int nstreams, const int *stream_ids, const uint8_t *iq_base, long long iq_stride,
+                       const unsigned *nbytes, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_attach_raw, dim3((nstreams + 63) / 64), dim3(64), 0, st, db, stream_ids, iq_base, iq_stride, nbytes, nstreams);
+}
+
 // cs16 input is already at 744187.5 S/s: it bypasses the decimator (input.c:119-124)
 __global__ __launch_bounds__(256) void k_append_cs16(DevBuffers db, const int *ids, const int16_t *iq_base, long long iq_stride, const unsigned *nsamples)
 {

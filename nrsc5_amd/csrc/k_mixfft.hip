@@ -15,6 +15,7 @@
 #include "kernels.h"
 #include "wave_ops.h"
 #include "fastmath.h"
+#include "halfband_raw.h"
 
 namespace nrsc5 {
 
@@ -117,6 +118,31 @@ __device__ inline void fft2048_wg(float2 *x, float2 *lds, const float2 *tw)
     }
 }
 
+// Zero-copy batch: the symbol's 2160 decimated samples straight from the cu8 capture.  Work-item t produces the
+// contiguous outputs 17 t .. 17 t + 16 from 24 consecutive dwords (each raw sample is unpacked once and feeds up to eight
+// outputs), converts them as cq15_to_cf_conj does and parks them in the FFT's LDS tile; the callers then pick their
+// strided 17 samples from there.
+__device__ inline void decimate_symbol_raw(const uint8_t *raw, long long a0, float2 *tile, const HbTaps &taps)
+{
+    const int m0 = 17 * (int)threadIdx.x;
+    const int nout = min(17, SYM_N - m0);                      // 17 for work-items 0..126, 1 for the last
+    const uint32_t *rw = (const uint32_t *)raw;
+    float2 E[24], O[17];
+#pragma unroll
+    for (int k = 0; k < 24; k++) {
+        const uint32_t w = (k < nout + 7) ? hb_raw_dword(rw, a0 + m0 - 7 + k) : 0x7f7f7f7fu;
+        E[k] = hb_even(w);
+        if (k >= 3 && k < 20) O[k - 3] = hb_odd(w);
+    }
+#pragma unroll
+    for (int i = 0; i < 17; i++) {
+        if (i < nout) {
+            const float2 y = hb_output(E + i, O[i], taps);
+            tile[m0 + i] = make_float2(q15_to_float(y.x), -q15_to_float(y.y));      // conj: the FM receiver's spectrum flip
+        }
+    }
+}
+
 __global__ __launch_bounds__(128) void k_mixfft(DevTables tb, DevBuffers db, const int *ids)
 {
     wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
@@ -124,42 +150,50 @@ __global__ __launch_bounds__(128) void k_mixfft(DevTables tb, DevBuffers db, con
     const StreamState &st = db.state[s];
     if (!st.active) return;                                    // block-uniform
     __shared__ float2 lds[8 * PITCH_A];
+    static_assert(8 * PITCH_A >= SYM_N, "a symbol's decimated samples fit in the FFT tile");
     const int sym = blockIdx.x, tid = threadIdx.x;
-    const c16 *win = db.q15 + (size_t)s * db.q15_cap + (st.rd - st.base) + sym * SYM_N + st.samperr_cur;
+    const long long a0 = (st.rd - st.base) + sym * SYM_N + st.samperr_cur;     // first sample of the symbol in the decimated stream
     const double dth = st.dtheta;
     const double th0 = st.theta + (double)sym * SYM_N * dth;
+    const uint8_t *raw = st.raw;                               // block-uniform
+    if (raw) {
+        decimate_symbol_raw(raw, a0, lds, hb_taps(tb.hb_q15));
+        __syncthreads();
+    }
 
     // NCO phasor of sample j = tid + 128 q (q = 0..16): one accurate evaluation at q = 0 and one of the
     // 128-sample step, then a 16-step complex recurrence (error ~1e-6, far inside the float pipeline's own)
-    double a0 = th0 + (double)tid * dth;
-    a0 -= 2 * M_PI * rint(a0 * (1.0 / (2 * M_PI)));
+    double a0p = th0 + (double)tid * dth;
+    a0p -= 2 * M_PI * rint(a0p * (1.0 / (2 * M_PI)));
     double a1 = 128.0 * dth;
     a1 -= 2 * M_PI * rint(a1 * (1.0 / (2 * M_PI)));
     float2 ph, stp;
-    fast_sincos_reduced((float)a0, ph.y, ph.x);                // both angles were reduced to [-pi, pi] in double above
+    fast_sincos_reduced((float)a0p, ph.y, ph.x);               // both angles were reduced to [-pi, pi] in double above
     fast_sincos_reduced((float)a1, stp.y, stp.x);
-    const double inv_q15 = 1.0 / 32767.0;                      // x / 32767.0f (defines.h:111), via an exact-in-practice double product
+    const c16 *win = db.q15 + (size_t)s * db.q15_cap + a0;     // FIFO path (streaming seam, cs16 input)
 
+    auto sample = [&](int j) -> float2 {
+        if (raw) return lds[j];
+        const c16 s16 = win[j];
+        return make_float2(q15_to_float((float)s16.r), -q15_to_float((float)s16.i));   // cq15_to_cf_conj, defines.h:111
+    };
     float2 x[16];
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         const int h = q & 1, n1 = q >> 1;
         const int j = tid + 128 * q;
-        const c16 s16 = win[j];
-        const float2 v = make_float2((float)((double)s16.r * inv_q15), (float)((double)s16.i * -inv_q15));   // cq15_to_cf_conj
-        float2 m = cmul(ph, v);
+        float2 m = cmul(ph, sample(j));
         if (q == 0 && tid < CP_N) { const float w = tb.shape[tid]; m.x *= w; m.y *= w; }
         x[8 * h + n1] = m;
         ph = cmul(ph, stp);
     }
     if (tid < CP_N) {                                          // fold the cyclic extension back (acquire.c:246-247)
         const int j = FFT_N + tid;
-        const c16 s16 = win[j];
-        const float2 v = make_float2((float)((double)s16.r * inv_q15), (float)((double)s16.i * -inv_q15));
-        const float2 m = cmul(ph, v);                          // ph = phasor of sample tid + 2048
+        const float2 m = cmul(ph, sample(j));                  // ph = phasor of sample tid + 2048
         const float w = tb.shape[j];
         x[0].x += w * m.x; x[0].y += w * m.y;
     }
+    if (raw) __syncthreads();                                  // every work-item has its samples: the tile becomes the FFT's
 
     fft2048_wg(x, lds, tb.twiddle);
 

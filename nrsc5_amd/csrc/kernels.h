@@ -32,6 +32,7 @@ struct DevBuffers {
                                      // window w (slot w % NWIN), before the next block's bookkeeping; null unless p1_async && l2_feedback
     c16 *q15;                        // [S][q15_cap]
     long long q15_cap;
+    c16 *acq_win;                    // [S][WIN_N]   zero-copy batch only: decimated acquisition window of streams that are not FINE
     c16 *acq_filt;                   // [S][WIN_N]   acquisition FIR output
     float2 *acq_sums;                // [S][SYM_N]
     float2 *bins;                    // [S][NSYM][LIVE_N]
@@ -76,6 +77,9 @@ struct DevBuffers {
 void launch_decimate_fm_cu8(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids,
                             const uint8_t *iq_base, long long iq_stride, const unsigned *nbytes, unsigned max_nbytes,
                             hipStream_t st);
+// engine option batch_zero_copy: attach the caller's cu8 captures to freshly reset streams (no copy, no decimation)
+void launch_attach_raw(const DevBuffers &db, int nstreams, const int *stream_ids, const uint8_t *iq_base, long long iq_stride,
+                       const unsigned *nbytes, hipStream_t st);
 void launch_append_cs16(const DevBuffers &db, int nstreams, const int *stream_ids,
                         const int16_t *iq_base, long long iq_stride, const unsigned *nsamples, unsigned max_n, hipStream_t st);
 

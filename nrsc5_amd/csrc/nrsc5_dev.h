@@ -103,6 +103,9 @@ struct PxJob { int rec, slot, len, pad; };                      // rec < 0: empt
 struct StreamState {
     // decimated Q15 FIFO: absolute sample counters; q15[(abs - base)] addresses the slab
     long long wr, rd, base;
+    // zero-copy batch (engine option batch_zero_copy): the stream's whole cu8 capture in the caller's device buffer; decimated
+    // sample a is the half-band output over raw complex samples 2a-14 .. 2a (zeros before the start).  null: use the FIFO
+    const uint8_t *raw;
     // K1 state
     c16 hb_hist[14];
     // acquisition state (acquire.h:25-29)

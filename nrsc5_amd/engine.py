@@ -33,7 +33,7 @@ assert RECORD_DTYPE.itemsize == 96
 class _Config(ctypes.Structure):
     _fields_ = [("device", ctypes.c_int), ("max_streams", ctypes.c_int), ("q15_capacity", ctypes.c_longlong),
                 ("record_capacity", ctypes.c_int), ("p1_slots", ctypes.c_int), ("p1_async", ctypes.c_int),
-                ("l2_feedback", ctypes.c_int), ("am_enable", ctypes.c_int), ("l2_index", ctypes.c_int)]
+                ("l2_feedback", ctypes.c_int), ("am_enable", ctypes.c_int), ("batch_zero_copy", ctypes.c_int), ("l2_index", ctypes.c_int)]
 
 
 class L2Pdu(ctypes.Structure):
@@ -149,9 +149,9 @@ class Engine:
 
     def __init__(self, max_streams: int = 1, q15_capacity: int = 1 << 20, record_capacity: int = 256,
                  p1_slots: int = 4, p1_async: bool = False, device: int = 0, lib_path: str | None = None,
-                 am_enable: bool = False, l2_feedback: bool = False, l2_index: bool = False):
+                 am_enable: bool = False, l2_feedback: bool = False, l2_index: bool = False, batch_zero_copy: bool = False):
         self.lib = load_library(lib_path)
-        self.cfg = _Config(device, max_streams, q15_capacity, record_capacity, p1_slots, int(p1_async), int(l2_feedback), int(am_enable), int(l2_index))
+        self.cfg = _Config(device, max_streams, q15_capacity, record_capacity, p1_slots, int(p1_async), int(l2_feedback), int(am_enable), int(batch_zero_copy), int(l2_index))
         self._h = ctypes.c_void_p()
         self._check(self.lib.nrsc5hip_engine_create(ctypes.byref(self.cfg), ctypes.byref(self._h)))
         self.max_streams, self.record_capacity, self.p1_slots = max_streams, record_capacity, p1_slots

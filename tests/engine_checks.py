@@ -201,6 +201,44 @@ def check_batch_equals_streaming(lib, caps, p1_async):
     return steps
 
 
+def check_zero_copy_batch(lib, caps, p1_async=True, l2_feedback=False):
+    """Engine option batch_zero_copy (K1 fused into the symbol kernel, captures read in place) == the copying batch path
+    == the streaming seam, record for record; plus the error behaviour of the attached state."""
+    import pytest
+    n = len(caps)
+    singles = []
+    for cap in caps:
+        E, recs, log = run_capture(lib, cap, l2_feedback=l2_feedback)
+        singles.append(log)
+        E.close()
+    stride = max(c.iq.size for c in caps); stride += (-stride) % 16
+    host = np.zeros((n, stride), dtype=np.uint8)
+    for k, c in enumerate(caps):
+        host[k, :c.iq.size] = c.iq
+    E = eng.Engine(max_streams=n, q15_capacity=2 * 71280, record_capacity=512, p1_slots=8, p1_async=p1_async, l2_feedback=l2_feedback,
+                   batch_zero_copy=True, lib_path=lib)                           # FIFO at its minimum: nothing is copied into it
+    dev = _to_device(E, host)
+    sizes = [c.iq.size - c.iq.size % 4 for c in caps]
+    E.batch_append_cu8(dev, stride, sizes)
+    with pytest.raises(eng.Nrsc5HipError):
+        E.batch_append_cu8(dev, stride, sizes)                                   # one append per reset
+    with pytest.raises(eng.Nrsc5HipError):
+        E.push_cu8(0, np.zeros(64, dtype=np.uint8))                              # attached streams take no pushes
+    E.batch_process(n)
+    recs, counts, frames = E.batch_fetch_view(n) if p1_async else E.batch_fetch(n)
+    for k in range(n):
+        log = eng.records_to_log(E, k, recs[k, :counts[k]], frames[k])
+        diffs = common.compare_logs(singles[k], log, rtol=0.0)
+        assert not diffs, (k, diffs[:10])
+    # reset detaches: the same engine then takes the streaming seam again
+    E.reset_all()
+    E2log = []
+    common.run_engine_streaming(E, 0, caps[0].iq[:4 * 70000], chunk=4 * 35000)
+    assert len(E.drain(0)) == 0                                                  # (less than one window; the point is that the push is accepted)
+    _free_device(E, dev)
+    E.close()
+
+
 def _to_device(E, host: np.ndarray) -> int:
     import ctypes
     fn = E.lib.nrsc5hip_debug_alloc_copy

@@ -52,6 +52,14 @@ def test_emu_interleaved_streams_and_subset_batches(emu_lib):
     ec.check_interleaved_streams(emu_lib)
 
 
+def test_emu_zero_copy_batch_equals_streaming(emu_lib):
+    """batch_zero_copy: captures read in place, half-band fused into the symbol kernel (incl. a stream that needs the CFO
+    search, i.e. the on-the-fly acquisition window)."""
+    caps = [synth.fm_mp1_capture(0, seed=70 + k, cfo_hz=c, offset=o, snr_db=18, n_blocks=nb)
+            for k, (c, o, nb) in enumerate([(40.0, 123, 20), (-2300.0, 3001, 8)])]
+    ec.check_zero_copy_batch(emu_lib, caps)
+
+
 def test_emu_small_fifo_compaction(emu_lib, captures):
     ec.check_small_fifo_compaction(emu_lib, "fm_cu8_cfo-2400", captures)
 

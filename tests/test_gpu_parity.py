@@ -103,6 +103,15 @@ def test_gpu_interleaved_streams_and_subset_batches(hip_lib, p1_async):
     ec.check_interleaved_streams(hip_lib, p1_async=p1_async)
 
 
+@pytest.mark.parametrize("p1_async,l2_feedback", [(True, False), (True, True), (False, False)])
+def test_gpu_zero_copy_batch_equals_streaming(hip_lib, p1_async, l2_feedback):
+    """Engine option batch_zero_copy: captures read in place (half-band fused into k_mixfft, acquisition window decimated on
+    the fly) == the streaming seam, incl. CFO search, a falsely locking capture with replay, ragged lengths."""
+    caps = [synth.fm_mp1_capture(0, seed=70 + k, cfo_hz=c, offset=o, snr_db=sn, n_blocks=nb)
+            for k, (c, o, sn, nb) in enumerate([(40.0, 123, 18, 40), (-2300.0, 3001, 15, 24), (0.0, 1234, 20, 52), (280.0, 4319, 25, 36), (5000.0, 4000, 25, 24)])]
+    ec.check_zero_copy_batch(hip_lib, caps, p1_async=p1_async, l2_feedback=l2_feedback)
+
+
 def test_gpu_small_fifo_compaction(hip_lib, captures):
     ec.check_small_fifo_compaction(hip_lib, "fm_cu8_cfo137", captures)
 

@@ -1,0 +1,40 @@
+"""CPU-only: the float32 formulation of the half-band decimator used by the zero-copy batch path
+(nrsc5_amd/csrc/halfband_raw.h) is EXACTLY the reference's integer code (firdecim_q15.c:137-165 via the oracle), and
+the divider-free x / 32767.0f equals the IEEE quotient for every int16 x.  numpy float32 mirrors the device arithmetic
+operation by operation (every intermediate is an exactly representable small integer or a 24-bit product)."""
+import numpy as np
+
+
+def _fma32(a, b, c):
+    """float32 fma: a*b+c with ONE rounding (products of a 24-bit and a 15-bit number are exact in float64)"""
+    return (a.astype(np.float64) * np.float64(b) + c.astype(np.float64)).astype(np.float32)
+
+
+def test_q15_to_float_equals_ieee_division_for_every_int16():
+    y = np.arange(-32768, 32768, dtype=np.int64).astype(np.float32)
+    r = np.float32(1.0) / np.float32(32767.0)
+    q0 = (y * r).astype(np.float32)
+    e = _fma32(-q0, 32767.0, y)
+    q = (q0.astype(np.float64) + e.astype(np.float64) * np.float64(r)).astype(np.float32)
+    assert np.array_equal(q, y / np.float32(32767.0))
+    assert (q0 != y / np.float32(32767.0)).sum() > 1000          # the correction step is not decoration
+
+
+def test_float_halfband_equals_oracle(oracle):
+    rng = np.random.default_rng(11)
+    n = 60000
+    iq = rng.integers(0, 256, size=4 * n, dtype=np.uint8)
+    iq[:4000] = rng.choice(np.array([0, 255], dtype=np.uint8), size=4000)      # full-scale: the accumulator's extremes
+    exp, _ = oracle.halfband_fm_cu8(iq)                                          # [n, 2] int16, zero history
+    x = iq.astype(np.float32).reshape(-1, 2) - np.float32(127.0)                # raw complex samples as x' = byte - 127
+    x = np.concatenate([np.zeros((14, 2), dtype=np.float32), x])               # history before the stream: Q15 zero
+    taps = [np.float32(v) for v in (0.6062333583831787, -0.13481467962265015, 0.032919470220804214, -0.00410953676328063)]
+    hbq = [np.float32(np.int16(t * np.float32(32767.0))) for t in taps][::-1]   # window order, as DevTables::hb_q15
+    tf = [h * np.float32(1.0 / 512.0) for h in hbq]
+    m = np.arange(n)
+    acc = np.float32(64.0) * x[2 * m + 7]                                        # raw sample 2a - 7 (index shifted by the 14 zeros)
+    for i in range(4):
+        s = x[2 * m + 2 * i] + x[2 * m + 14 - 2 * i]
+        acc = acc + np.floor((s * tf[i]).astype(np.float32))
+    assert np.array_equal(acc.astype(np.int16), exp)
+    assert np.abs(exp.astype(int)).max() < 32768 - 8192                          # the int16 accumulator has room: it never wraps

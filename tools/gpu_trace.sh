@@ -41,6 +41,14 @@ gaps = [(b["s"] - a["e"]) / 1e3 for a, b in zip(rs[:-1], rs[1:])]
 for (a, b), g in zip(zip(rs[:-1], rs[1:]), gaps):
     if g > 100: print(f"   gap {g:8.1f} us after {a['n']} (ends {(a['e'] - t0) / 1e6:.2f} ms) before {b['n']}; chain kernel index {rs.index(a)} of {len(rs)}")
 print(f"chain queue gaps: median {st.median(gaps):.1f} us, mean {st.mean(gaps):.1f} us, total {sum(g for g in gaps if g > 0) / 1e3:.2f} ms; gaps > 100 us: {[round(g) for g in gaps if g > 100][:20]}")
+# the first 20 steps in detail: everything on the chain queue up to the 20th k_sync
+n_sync = 0
+print("first steps on the chain queue (start ms, duration us):")
+for r in rs:
+    print(f"   {(r['s'] - t0) / 1e6:8.3f}  {(r['e'] - r['s']) / 1e3:9.1f}  {r['n']}")
+    if r["n"] == "k_sync":
+        n_sync += 1
+        if n_sync == 20: break
 # step-by-step: time per 16-step window along the chain
 for w in range(0, len(sync), 16):
     seg = sync[w:w + 16]
