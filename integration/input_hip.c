@@ -43,7 +43,9 @@ static void die(const char *what)
 
 static void deliver(input_t *st)
 {
-    static uint8_t bits[NRSC5HIP_P1_FRAME_BITS];
+    /* frame bits as frame_push takes them: the session's own descrambler buffer (decode.h, P1_FRAME_LEN_FM bytes, unused
+     * here because descrambling happens on the device) -- per session, so concurrent sessions of one process do not share it */
+    uint8_t *bits = st->decode.scrambler_p1;
     nrsc5hip_record rec[64];
     int n = 0;
     const int am = st->radio->mode == NRSC5_MODE_AM;

@@ -1,7 +1,6 @@
 // L1 FEC stage for gfx950: P1 de-interleave (K6), tail-biting Viterbi (K7), re-encode BER and
 // descrambler (K8).  Replaces decode.c:296-322,451-461 and conv_dec.c for the P1 logical channel.
 #include <hip/hip_runtime.h>
-#include <stdlib.h>
 #include "kernels.h"
 #include "viterbi_wave.h"
 #include "viterbi_v3.h"
@@ -137,8 +136,10 @@ static size_t traceback_smem(int len) { const int nchunks = len / 64 + 1; return
 void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st, int l2_mode)
 {
     hipLaunchKernelGGL(k_p1_deint, dim3(32, nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, lane_id);
-    static const int prio_fwd = getenv("NRSC5HIP_PRIO_FWD") ? atoi(getenv("NRSC5HIP_PRIO_FWD")) : 0;
-    static const int prio_tb = getenv("NRSC5HIP_PRIO_TB") ? atoi(getenv("NRSC5HIP_PRIO_TB")) : 3;   // short kernel at the end of each decode chain: let it through (measured +1.5 %)
+    // wave priorities (s_setprio): the forward pass is long-running background work next to the step chain (priority 3);
+    // raising it to 1 or 2 was measured again with the 6-instruction trellis: no gain (profiles/r02_naux.txt).  The traceback is
+    // the short kernel at the end of each decode chain: let it through (+1.5 %).
+    constexpr int prio_fwd = 0, prio_tb = 3;
     hipLaunchKernelGGL(k_p1_forward, dim3(nstreams), dim3(64), 0, st, tb, db, stream_ids, parity, lane_id, prio_fwd);
     hipLaunchKernelGGL(k_p1_traceback, dim3(nstreams), dim3(TB_THREADS), traceback_smem(P1_LEN), st, tb, db, stream_ids, parity, lane_id, l2_mode, prio_tb);
     if (db.l2_ring) launch_l2_index_window(db, nstreams, stream_ids, parity, st);

@@ -242,6 +242,10 @@ int refh_open(int mode, unsigned taps, unsigned fft_limit_blocks)
     nrsc5_set_callback(g_radio, on_event, NULL);
     return 0;
 }
+/* nrsc5_set_mode on the live session (-> input_set_mode -> input_reset, input.c:126-162); the taps keep accumulating.
+ * Returns the length of the log so far so that the caller can split it at the switch. */
+size_t refh_set_mode(int mode) { nrsc5_set_mode(g_radio, mode); return g_log.len; }
+size_t refh_q15_len(void) { return g_q15.len; }
 int refh_push_cu8(const uint8_t *iq, unsigned nbytes) { return nrsc5_pipe_samples_cu8(g_radio, iq, nbytes); }
 int refh_push_cs16(const int16_t *iq, unsigned n) { return nrsc5_pipe_samples_cs16(g_radio, iq, n); }
 /* feed a whole capture in `chunk`-byte calls, as src/main.c:1097-1120 does with 32768 */

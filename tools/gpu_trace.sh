@@ -14,7 +14,7 @@ for r in rows:
     r["n"] = r["Kernel_Name"].split("(")[0].replace("nrsc5::", ""); r["s"] = int(r["Start_Timestamp"]); r["e"] = int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
 # the last pass starts at the last k_decimate_fm_cu8 burst: find the last big gap before a decimate kernel
-dec = [r for r in rows if r["n"] == "k_decimate_fm_cu8"]
+dec = [r for r in rows if r["n"] in ("k_decimate_fm_cu8", "k_attach_raw")]
 starts = [dec[0]["s"]]
 for a, b in zip(dec[:-1], dec[1:]):
     if b["s"] - a["e"] > 5_000_000: starts.append(b["s"])
@@ -32,7 +32,7 @@ sync = [r for r in P if r["n"] == "k_sync"]
 mix = [r for r in P if r["n"] == "k_mixfft"]
 print(f"step chain: {len(sync)} steps, first k_mixfft at {(mix[0]['s'] - t0) / 1e6:.2f} ms, last k_sync ends at {(sync[-1]['e'] - t0) / 1e6:.2f} ms")
 import statistics as st
-for nm in ("k_mixfft", "k_sync", "k_p1_forward", "k_p1_traceback", "k_p1_deint", "k_pids_decode", "k_rollback", "k_prepare", "k_acq_fir", "k_decimate_fm_cu8"):
+for nm in ("k_attach_raw", "k_acq_decimate", "k_mixfft", "k_sync", "k_p1_forward", "k_p1_traceback", "k_p1_deint", "k_pids_decode", "k_rollback", "k_prepare", "k_acq_fir", "k_decimate_fm_cu8"):
     d = [(r["e"] - r["s"]) / 1e3 for r in P if r["n"] == nm]
     if d: print(f"  {nm:20s} n={len(d):4d} median {st.median(d):9.1f} us  mean {st.mean(d):9.1f} us  max {max(d):9.1f} us  total {sum(d) / 1e3:8.2f} ms")
 # gaps on the chain queue between consecutive kernels
