@@ -1,14 +1,21 @@
 #!/usr/bin/env python
 """Headline benchmark: IQ MS/s demodulated AND decoded (x real-time) on MI355X.
 
-A "step" = one complete pass of the hot path over one batch of synthetic captures that are already
-resident in HBM: reset stream state -> K1 decimate -> per 32-symbol block {acquire | mix+FFT | sync /
-equalise / soft-demod / PIDS Viterbi} -> per L1 frame {de-interleave, P1 Viterbi, BER, descramble} ->
-D2H of every block record and decoded P1 frame.  Workload = BASELINE.json configs[2]:
-`--streams` (default 256) independent hybrid-FM MP1 cu8 streams @1.488375 MS/s per GPU (weak scaling
-for --gpus N: 256 per GPU, the configs[3] family).  configs[1] (one stream) is a parity-test case.
+A "step" = one complete pass of the hot path over one batch of synthetic captures that are already resident in HBM:
+reset stream state -> per 32-symbol block {acquire | half-band + mix + FFT | sync / equalise / soft-demod} -> per L1 frame
+{de-interleave, Viterbi, BER, descramble, first-header RS check} -> D2H of every block record and decoded frame.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+Workloads (`--workload`), all with the same JSON schema:
+  fm        BASELINE.json configs[2] (default, the headline metric): `--streams` (256) independent hybrid-FM MP1 cu8 streams
+            @1.488375 MS/s per GPU; with --gpus N the configs[3] family (256 per GPU, weak scaling)
+  am-cs16   configs[4], AM half: 256 hybrid-AM MA1 cs16 streams @46511.71875 S/s, 61 s each
+  am-cu8    configs[4], AM half through the 5-stage 32:1 decimator: 128 MA1 cu8 streams @1.488375 MS/s
+  mixed     configs[4]: 128 FM cu8 + 64 AM cs16 + 64 AM cu8 streams in one engine
+configs[1] (one FM stream) is reported inside the fm line (`single_stream`), next to the in-order (reference event timing)
+figure of the same batch (`in_order`).
+
+`python bench.py --gpus N` starts its N ranks itself (one process per GPU, torch.distributed over RCCL) unless it already
+runs under torchrun.  Prints ONE JSON line on rank 0 with `roofline` and `cpu_baseline`.
 """
 from __future__ import annotations
 
@@ -23,84 +30,110 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# the engine drives 1 main + 3 decode streams next to torch's: give each its own hardware queue
+# the engine drives 1 main + 3-4 decode streams next to torch's: give each its own hardware queue
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 FS = 1488375.0
-ALG_BYTES_PER_SAMPLE = 2.008            # 2 B cu8 in + 18432 B decoded bits per 2211840-sample L1 frame
+FS_AM = 46511.71875
 HBM_PEAK_GBPS = 8000.0                  # MI355X_MICROARCH.md: 8 TB/s spec
-BLOCK_SAMPLES = 138240                  # cu8 complex samples per 32-symbol block
+BLOCK_SAMPLES = 138240                  # cu8 complex samples per 32-symbol FM block
 FRAME_SAMPLES = 16 * BLOCK_SAMPLES
-
-# input samples one launch of each kernel class accounts for, per processed stream
-SAMPLES_PER_LAUNCH = {"decimate": None, "acquire": BLOCK_SAMPLES, "prepare": BLOCK_SAMPLES, "mixfft": BLOCK_SAMPLES,
-                      "sync": BLOCK_SAMPLES, "p1_deint": BLOCK_SAMPLES, "p1_viterbi": None, "pids": BLOCK_SAMPLES}
+# algorithmic bytes per input complex sample: input bytes + packed decoded bits
+ALG_FM_CU8 = 2.0 + 18432.0 / FRAME_SAMPLES                      # 2.008
+ALG_AM_CS16 = 4.0 + 6830.0 / 69120.0                            # 4.10
+ALG_AM_CU8 = 2.0 + 6830.0 / (69120.0 * 32)                      # 2.003
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--workload", default="fm", choices=["fm", "am-cs16", "am-cu8", "mixed"],
-                    help="fm (default): the headline metric, configs[2]; the others run the side measurements of BASELINE "
-                         "configs[4] (tools/gpu_am_bench.py, tools/gpu_mixed_bench.py; single GPU, their own JSON line)")
+    ap.add_argument("--workload", default="fm", choices=["fm", "am-cs16", "am-cu8", "mixed"])
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--streams", type=int, default=256, help="streams per GPU")
-    ap.add_argument("--seconds", type=float, default=20.0, help="capture length per stream (SURVEY 8d: 20 s)")
-    ap.add_argument("--payloads", type=int, default=8, help="distinct transmissions shared by the streams (each stream has its own CFO/offset/noise)")
-    ap.add_argument("--sync-p1", action="store_true", help="decode P1 frames in order on the main stream (exact reference event timing) instead of the overlapped window pipeline")
+    ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: 256; am-cu8: 128)")
+    ap.add_argument("--seconds", type=float, default=20.0, help="FM capture length per stream (SURVEY 8d: 20 s)")
+    ap.add_argument("--am-frames", type=int, default=41, help="AM L1 frames per stream (41 = 61 s)")
+    ap.add_argument("--payloads", type=int, default=8, help="distinct FM transmissions shared by the streams (each stream has its own CFO/offset/noise)")
+    ap.add_argument("--sync-p1", action="store_true", help="decode frames in order on the main stream (reference event timing) instead of the overlapped window pipeline")
     ap.add_argument("--l2-feedback", type=int, default=1, help="1: the engine applies the reference's L2 -> L1 sync-loss feedback itself (RS check of the first L2 header on the device), as the CPU baseline's frame.c does; 0: off")
-    ap.add_argument("--copy-input", action="store_true", help="decimate the captures into the engine's Q15 FIFO first (K1 as its own kernel) instead of reading them in place")
+    ap.add_argument("--copy-input", action="store_true", help="fm: decimate the captures into the engine's Q15 FIFO first (K1 as its own kernel) instead of reading them in place")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no HIP-event kernel timing inside the timed region (roofline fields become 0)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--l2-index-inline", action="store_true", help="engine option l2_index: index every P1 frame on the decode streams inside the timed region (default: untimed post-pass)")
-    ap.add_argument("--no-l2-index", action="store_true", help="skip the (untimed) L2 audio-index property check of the decoded frames")
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=15.0)
-    ap.add_argument("--oracle-streams", type=int, default=4, help="parity block: how many falsely-locking streams of the last pass are compared with the oracle (plus half as many others)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every checker leg that runs on the host cores (CPU baseline, oracle equality)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="fm: skip the single-stream (configs[1]) and in-order measurements")
+    ap.add_argument("--l2-index-inline", action="store_true", help="fm: engine option l2_index: index every P1 frame on the decode streams inside the timed region (default: untimed post-pass)")
+    ap.add_argument("--no-l2-index", action="store_true", help="fm: skip the (untimed) L2 audio-index property check of the decoded frames")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-processes", type=int, default=0, help="processes of the N-core CPU aggregate (default: all host cores, at most 64)")
+    ap.add_argument("--oracle-streams", type=int, default=4, help="fm parity block: how many falsely-locking streams of the last pass are compared with the oracle (plus half as many others)")
     ap.add_argument("--launch-check", action="store_true", help="only start the ranks, form the process group (RCCL; gloo without a GPU) and print what it sees -- no workload")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
-                    help="optional PMC-derived HBM bytes per launch for the dominant kernel (written by profiles/collect_pmc.py)")
+                    help="PMC-derived HBM bytes (profiles/collect_pmc.py); used only if it was collected from THIS source tree")
     return ap.parse_args()
 
 
-def cpu_baseline(stream_iq: np.ndarray, budget_s: float):
-    """Reference (oracle/_ref, the unmodified C sources, SSE build) or, if that build did not travel,
-    the C restatement ('port'), single thread, fed in 32768-byte calls like src/main.c:1097-1120."""
+# ---- CPU baseline (checker leg): the unmodified reference (oracle/_ref, SSE build) or the restatement ----------------
+def _cpu_runner(mode: int):
     from oracle import ref, port
-    kind = "port"
-    runner = None
     if ref.available(sse=True):
         try:
             R = ref.RefLib(sse=True)
-            runner = lambda iq: R.run(iq)
-            kind = "reference"
+            return (lambda iq: R.run(iq, mode=mode)), "reference"
         except OSError:
-            runner = None
-    if runner is None:
-        O = port.Oracle()
-        runner = lambda iq: O.run(iq)
-    t0 = time.perf_counter()
-    runner(stream_iq)
-    dt1 = time.perf_counter() - t0
-    reps = max(1, min(64, int(budget_s / max(dt1, 1e-3)) - 1))
+            pass
+    O = port.Oracle()
+    return (lambda iq: O.run(iq, mode=mode)), "port"
+
+
+def _cpu_worker(path: str, mode: int, reps: int, q):
+    sys.path.insert(0, ROOT)
+    iq = np.load(path, mmap_mode="r")
+    run, _ = _cpu_runner(mode)
+    iq = np.ascontiguousarray(iq)
     t0 = time.perf_counter()
     for _ in range(reps):
-        runner(stream_iq)
+        run(iq)
+    q.put(time.perf_counter() - t0)
+
+
+def cpu_baseline(stream_iq: np.ndarray, fs: float, mode: int, budget_s: float, nproc: int):
+    """One stream of the workload through the CPU path, fed in 32768-byte pushes like src/main.c:1097-1120:
+    (a) one host core, (b) one process per host core, each with its own session and the same stream (aggregate)."""
+    import multiprocessing as mp
+    import tempfile
+    run, kind = _cpu_runner(mode)
+    t0 = time.perf_counter(); run(stream_iq); dt1 = time.perf_counter() - t0
+    reps = max(1, min(64, int(0.5 * budget_s / max(dt1, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        run(stream_iq)
     dt = (time.perf_counter() - t0) / reps
     nsamp = stream_iq.size / 2
-    return {"value": round(nsamp / dt / 1e6, 3), "unit": "IQ MS/s", "x_realtime": round(nsamp / dt / FS, 2), "cores": 1,
-            "kind": kind, "sample": f"{reps}x one {nsamp / FS:.1f}-s stream of this workload on 1 host core, 32768-byte pushes"}
-
-
-def side_workload(args):
-    """BASELINE configs[4] side measurements live in tools/ (same engine, same C ABI); dispatch to them."""
-    import runpy
-    if args.workload == "mixed":
-        sys.argv = [os.path.join(ROOT, "tools", "gpu_mixed_bench.py"), "--steps", str(args.steps)]
-    else:
-        sys.argv = [os.path.join(ROOT, "tools", "gpu_am_bench.py"), "--fmt", args.workload.split("-")[1],
-                    "--streams", str(256 if args.workload == "am-cs16" else 128), "--steps", str(args.steps), "--warmup", str(args.warmup)]
-    runpy.run_path(sys.argv[0], run_name="__main__")
+    out = {"value": round(nsamp / dt / 1e6, 3), "unit": "IQ MS/s", "x_realtime": round(nsamp / dt / fs, 2), "cores": 1, "kind": kind,
+           "fft": "oracle/cpu_fft.c (radix-4 Stockham shim; fftw3f is not installed on this box)",
+           "sample": f"{reps}x one {nsamp / fs:.1f}-s stream of this workload on 1 host core, 32768-byte pushes"}
+    ncpu = os.cpu_count() or 1
+    n = nproc if nproc > 0 else min(ncpu, 64)
+    if n > 1:
+        try:
+            fd, path = tempfile.mkstemp(suffix=".npy", dir="/tmp"); os.close(fd)
+            np.save(path, stream_iq)
+            per = max(1, int(0.5 * budget_s / max(dt, 1e-3)))
+            ctx = mp.get_context("spawn")
+            q = ctx.Queue()
+            procs = [ctx.Process(target=_cpu_worker, args=(path, mode, per, q)) for _ in range(n)]
+            t0 = time.perf_counter()
+            for p in procs:
+                p.start()
+            times = [q.get(timeout=600) for _ in procs]
+            for p in procs:
+                p.join(timeout=60)
+            wall = time.perf_counter() - t0               # includes process start-up: a lower bound on the aggregate
+            os.unlink(path)
+            out["all_cores"] = {"value": round(n * per * nsamp / max(times) / 1e6, 2), "unit": "IQ MS/s", "x_realtime": round(n * per * nsamp / max(times) / fs, 1),
+                                "cores": n, "host_cores": ncpu, "sample": f"{n} processes x {per} passes of that stream, one session each; slowest process {max(times):.1f} s (wall incl. start-up {wall:.1f} s)"}
+        except Exception as ex:                           # a baseline, never allowed to take the bench line down
+            out["all_cores"] = {"error": repr(ex)}
+    return out
 
 
 def launch_check(args):
@@ -119,6 +152,364 @@ def launch_check(args):
                           "backend": "nccl(RCCL)" if cuda else "gloo", "launched_by": os.environ.get("NRSC5_BENCH_LAUNCHER", "external torchrun" if world > 1 else "single process")}))
 
 
+# ---- workloads ----------------------------------------------------------------------------------------------------------
+class Fm:
+    """configs[2] / configs[3]: hybrid-FM MP1 cu8 streams (seed 1000+k, CFO +-300 Hz, offset [0, 4320), SNR 15/20/25 dB)"""
+    fs, mode, alg = FS, 0, ALG_FM_CU8
+    dtype = "exact float32 half-band (== int16 Q15) / f32 OFDM + sync / int32 Viterbi metrics"
+
+    def __init__(self, args, dev, local, my_streams):
+        import torch
+        from nrsc5_amd import engine as eng, synth_torch as stt
+        self.args, self.dev, self.eng, self.my_streams = args, dev, eng, my_streams
+        S = self.S = len(my_streams)
+        self.n_frames = n_frames = max(2, int(np.ceil(args.seconds * FS / FRAME_SAMPLES)))
+        self.pool = []
+        for p in range(args.payloads):
+            p1, pids, m = stt.payload_stream(n_frames, seed=p)
+            self.pool.append((np.packbits(p1, axis=1, bitorder="little"), stt.modulate(m, dev)))
+        nsig = self.pool[0][1].shape[0]
+        tail = 8640
+        self.stride = (2 * (4320 + nsig + tail) + 255) // 256 * 256
+        self.iq = torch.zeros((S, self.stride), dtype=torch.uint8, device=dev)
+        self.nbytes = np.zeros(S, dtype=np.uint32)
+        for k, gs in enumerate(my_streams):
+            prm = stt.stream_params(gs)
+            out = stt.channel_cu8(self.pool[gs % args.payloads][1], prm["cfo_hz"], prm["offset"], prm["snr_db"], prm["seed"], tail=tail, out=self.iq[k])
+            self.nbytes[k] = out.shape[0] - out.shape[0] % 4
+        torch.cuda.synchronize()
+        self.samples = float(self.nbytes.astype(np.float64).sum() / 2)
+        self.signal_seconds = self.samples / FS
+        self.zero_copy = not args.copy_input
+        self.E = self.make_engine(S, local, in_order=args.sync_p1)
+
+    def make_engine(self, S, local, in_order):
+        a = self.args
+        # replay (window pipeline + L2 feedback): blocks that ran behind a failed P1 frame keep their records / ring slots
+        # (marked void, never delivered), so both rings carry head-room for the speculated stretch.  Zero-copy: the captures
+        # are read where they are, so the FIFO stays at its minimum size.
+        return self.eng.Engine(max_streams=S, q15_capacity=2 * 71280 if self.zero_copy else int(self.stride // 4 + 1024),
+                               record_capacity=max(512, 2 * 16 * self.n_frames + 64), p1_slots=self.n_frames + 12, p1_async=not in_order, device=local,
+                               l2_feedback=bool(a.l2_feedback), l2_index=bool(a.l2_index_inline), batch_zero_copy=self.zero_copy)
+
+    def one_pass(self, E=None, S=None, host_ms=None):
+        E = E or self.E; S = S or self.S
+        t = [time.perf_counter()]
+        E.reset_all(); t.append(time.perf_counter())
+        E.batch_append_cu8(self.iq.data_ptr(), self.stride, self.nbytes[:S]); t.append(time.perf_counter())
+        steps = E.batch_process(S); t.append(time.perf_counter())
+        out = E.batch_fetch_view(S) if E.cfg.p1_async else E.batch_fetch(S); t.append(time.perf_counter())
+        if host_ms is not None:
+            for k, name in enumerate(("reset", "append", "process", "fetch")):
+                host_ms[name] += (t[k + 1] - t[k]) * 1e3
+        return steps, out
+
+    def describe(self, steps):
+        a = self.args
+        return {"workload": f"configs[2]: batch={self.S} independent hybrid-FM MP1 cu8 streams @1.488375 MS/s per GPU, "
+                            f"{self.nbytes[0] / 2 / FS:.2f} s each ({self.n_frames} L1 frames), CFO +-300 Hz, offset [0,4320), SNR 15/20/25 dB",
+                "streams_per_gpu": self.S, "seconds_per_stream": round(float(self.nbytes[0]) / 2 / FS, 3),
+                "p1_decode": "in-order" if a.sync_p1 else "windowed-overlap", "l2_feedback": "on-device" if a.l2_feedback else "off",
+                "input": "read in place (half-band fused into the symbol kernel)" if self.zero_copy else "decimated copy in the Q15 FIFO",
+                "block_steps_per_pass": int(steps), "distinct_payloads": a.payloads, "hbm_resident_input_GB": round(float(self.nbytes.sum()) / 1e9, 2)}
+
+    def verify(self, recs, counts, frames):
+        """last pass vs the transmitted truth: per stream [id, blocks, P1 frames, exact frames, PIDS frames, FINE blocks, CRC of frames]"""
+        eng = self.eng
+        rows, self.l2_jobs, self.l2_exact = [], [], []
+        for k, gs in enumerate(self.my_streams):
+            r = recs[k, :counts[k]]
+            truth = self.pool[gs % self.args.payloads][0]
+            p1r = r[(r["flags"] & eng.REC_P1) != 0]
+            ok, h, first = 0, 0, None
+            for j, rr in enumerate(p1r):
+                w = frames[k, int(rr["p1_slot"])]
+                h = zlib.crc32(w.tobytes(), h)
+                b = w.view(np.uint8)
+                exact = 0
+                if first is None:
+                    match = np.nonzero((truth == b[None, :]).all(axis=1))[0]
+                    if match.size:
+                        first = int(match[0]) - j
+                        exact = 1
+                else:
+                    idx = first + j
+                    exact = int(0 <= idx < truth.shape[0] and np.array_equal(truth[idx], b))
+                ok += exact
+                self.l2_jobs.append((k, int(rr["p1_slot"]), eng.L2_FM_P1, 0, eng.P1_BITS)); self.l2_exact.append(exact)
+            rows.append([gs, len(r), len(p1r), ok, int(((r["flags"] & eng.REC_PIDS) != 0).sum()), int((r["state_after"] == eng.SYNC_FINE).sum()), h])
+        return rows
+
+    def parity(self, allrows):
+        good = int(((allrows[:, 2] > 0) & (allrows[:, 3] >= allrows[:, 2] - 1)).sum())
+        return {"streams": int(allrows.shape[0]), "streams_locked_and_all_p1_frames_equal_transmitted_bits": good,
+                "p1_frames_decoded": int(allrows[:, 2].sum()), "p1_frames_bit_exact_vs_truth": int(allrows[:, 3].sum()),
+                "pids_frames_decoded": int(allrows[:, 4].sum()),
+                "note": "streams whose timing offset falls in the reference algorithm's false-lock zone (sync.c phase-slope ambiguity, ~6 % of uniform offsets) "
+                        "decode one garbage frame in the reference too, whose L2 then forces a re-acquisition; with l2_feedback the engine does the same on the "
+                        "device: the verdict of the deferred decode rewinds the stream to the end of that frame's block (k_replay.hip), so LOST_SYNC and the "
+                        "re-acquisition land on the reference's blocks"}
+
+    def cpu_sample(self):
+        return self.iq[0, :int(self.nbytes[0])].cpu().numpy()
+
+    # ---- fm-only checker / side legs (rank 0, N = 1) ----------------------------------------------------------------------
+    def reference_equality(self, recs, counts, frames):
+        """Streams the reference algorithm first locks falsely on (their log has LOST_SYNC) + the first streams that did not:
+        the complete ordered log -- sync / lost-sync blocks, every PIDS and P1 frame, MER / BER / CFO -- against the oracle
+        driven by the restated frame_process decision."""
+        from oracle import port
+        from tests import common
+        eng, O = self.eng, port.Oracle()
+        lost = [k for k in range(self.S) if ((recs[k, :counts[k]]["flags"] & eng.REC_LOST_SYNC) != 0).any()]
+        n = self.args.oracle_streams
+        sample = lost[:n] + [k for k in range(self.S) if k not in lost][:max(1, n // 2)]
+        t0 = time.perf_counter()
+        equal, first_diffs = 0, []
+        for k in sample:
+            ol, _, _ = O.run(self.iq[k, :int(self.nbytes[k])].cpu().numpy(), p1_hook=O.l2_hook())
+            log = eng.records_to_log(self.E, k, recs[k, :counts[k]], frames[k])
+            diffs = common.compare_logs(common.strip_states(ol), common.strip_states(log))
+            kept = [x for x in common.strip_states(ol) if x[0] not in ("hdc", "soft", "vit", "amsym", "pxsoft")]
+            bad = {i for i, (kk, v) in enumerate(kept) if kk == "ber" and v["cber"] > 0.02}     # frames decoded while falsely locked: noise in, noise out
+            diffs = [d for d in diffs if not any(d.startswith(f"#{i} ber") or d.startswith(f"#{i + 1} frame") for i in bad)]
+            equal += not diffs
+            if diffs and len(first_diffs) < 3:
+                first_diffs.append({"stream": int(self.my_streams[k]), "diff": diffs[0]})
+        return {"streams_with_lost_sync_this_pass": len(lost), "streams_checked": len(sample), "of_which_with_lost_sync": len([k for k in sample if k in lost]),
+                "logs_equal_to_oracle_with_l2_hook": int(equal), "first_diffs": first_diffs, "seconds": round(time.perf_counter() - t0, 1),
+                "compared": "ordered log: state/sync/lost_sync blocks, PIDS + P1 frames bit-exact (frames with cber > 0.02 = decoded while falsely locked excepted), floats 1e-4"}
+
+    def l2_property(self):
+        """full-size property check on the device: the L2 audio index of every decoded P1 frame (frame_push + RS header + CRC-8 of
+        all 32 audio packets, k_l2_index) must be clean exactly for the frames that equal the transmitted bits"""
+        eng, a = self.eng, self.args
+        t0 = time.perf_counter()
+        if a.l2_index_inline:
+            ring = self.E.batch_fetch_l2(self.S)
+            idx = [(eng.l2_frame_to_dict(ring[j[0]][j[1]]), None) for j in self.l2_jobs]
+        else:
+            idx = self.E.l2_index(self.l2_jobs, want_bytes=False)
+        dt = time.perf_counter() - t0
+        clean = [int(d["n_pdu"] == 1 and d["pdus"][0]["nop"] == 32 and d["pdus"][0]["crc_bad_lo"] == 0 and d["lost_sync"] == 0) for d, _ in idx]
+        return {"where": "decode streams, inside the timed region" if a.l2_index_inline else "post-pass, untimed",
+                "frames_indexed": len(idx), "host_ms_incl_copies": round(dt * 1e3, 2),
+                "audio_packets_crc_ok": int(sum(sum(p["nop"] - bin(p["crc_bad_lo"] | (p["crc_bad_hi"] << 32)).count("1") for p in d["pdus"]) for d, _ in idx)),
+                "frames_clean": int(sum(clean)), "clean_and_bit_exact": int(sum(c & e for c, e in zip(clean, self.l2_exact))),
+                "bit_exact": int(sum(self.l2_exact)), "frames_flagged_lost_sync": int(sum(d["lost_sync"] for d, _ in idx))}
+
+    def extra_legs(self, local):
+        """configs[1] (one stream through the same engine build) and the in-order mode (reference event timing) of the whole batch"""
+        import torch
+        out = {}
+        self.E.close(); self.E = None
+        E1 = self.make_engine(1, local, in_order=False)
+        self.one_pass(E1, 1)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5):
+            steps, (recs, counts, frames) = self.one_pass(E1, 1)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
+        n1 = float(self.nbytes[0]) / 2
+        p1 = int(((recs[0, :counts[0]]["flags"] & self.eng.REC_P1) != 0).sum())
+        out["single_stream"] = {"workload": "configs[1]: stream 0 of the batch alone on the GPU (window pipeline, L2 feedback, zero-copy)",
+                                "ms_per_pass": round(dt * 1e3, 3), "x_realtime": round(n1 / FS / dt, 1), "value_MSps": round(n1 / dt / 1e6, 2),
+                                "us_per_block": round(dt * 1e6 / max(int(counts[0]), 1), 1), "blocks": int(counts[0]), "p1_frames": p1}
+        E1.close()
+        if not self.args.sync_p1:
+            E2 = self.make_engine(self.S, local, in_order=True)
+            self.one_pass(E2)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            steps, (recs, counts, frames) = self.one_pass(E2)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            out["in_order"] = {"what": "same batch with p1_async = 0: every frame decoded before the next block of any stream (the reference's event timing "
+                                       "without replay), 1 pass", "ms_per_step": round(dt * 1e3, 2), "value_MSps": round(self.samples / dt / 1e6, 1),
+                               "x_realtime": round(self.signal_seconds / dt, 1), "block_steps": int(steps),
+                               "p1_frames": int(sum(((recs[k, :counts[k]]["flags"] & self.eng.REC_P1) != 0).sum() for k in range(self.S)))}
+            E2.close()
+        return out
+
+
+class Am:
+    """configs[4], AM half: hybrid-AM MA1 streams, cs16 @46511.71875 S/s or cu8 @1.488375 MS/s (32:1 cascade), one transmission,
+    streams staggered in time"""
+    mode = 1
+    dtype = "int16 Q15 decimator (cu8) / f32 OFDM + sync / int32 K=9 Viterbi metrics"
+
+    def __init__(self, args, dev, local, my_streams, fmt):
+        import torch
+        from nrsc5_amd import engine as eng, synth_am
+        self.args, self.dev, self.eng, self.my_streams, self.fmt = args, dev, eng, my_streams, fmt
+        S = self.S = len(my_streams)
+        self.fs = synth_am.FS_CS16 if fmt == "cs16" else synth_am.FS_CU8
+        self.alg = ALG_AM_CS16 if fmt == "cs16" else ALG_AM_CU8
+        self.cap = cap = synth_am.am_ma1_capture(args.am_frames, seed=77, cfo_hz=4.0, offset=3000 * (32 if fmt == "cu8" else 1), fmt=fmt)
+        base = torch.from_numpy(cap.iq).to(dev)
+        per = 4 if fmt == "cs16" else 64
+        self.n = n = (cap.iq.size - 2 * per * 97) // 4 * 4
+        self.iq = torch.empty((S, n), dtype=base.dtype, device=dev)
+        for k, gs in enumerate(my_streams):
+            self.iq[k] = base[2 * per * (gs % 97): 2 * per * (gs % 97) + n]
+        torch.cuda.synchronize()
+        self.samples = S * n / 2.0
+        self.signal_seconds = self.samples / self.fs
+        self.sizes = np.full(S, n, dtype=np.uint32)
+        self.E = eng.Engine(max_streams=S, q15_capacity=int(n / 2 / (1 if fmt == "cs16" else 32)) + 4096, record_capacity=8 * args.am_frames + 16,
+                            p1_slots=args.am_frames, am_enable=True, p1_async=not args.sync_p1, l2_feedback=bool(args.l2_feedback), device=local)
+        for k in range(S):
+            self.E.set_mode(k, eng.MODE_AM)
+
+    def one_pass(self, host_ms=None):
+        E = self.E
+        t = [time.perf_counter()]
+        E.reset_all(); t.append(time.perf_counter())
+        if self.fmt == "cs16":
+            E.batch_append_cs16(self.iq.data_ptr(), self.n, self.sizes)
+        else:
+            E.batch_append_cu8(self.iq.data_ptr(), self.n, self.sizes)
+        t.append(time.perf_counter())
+        steps = E.batch_process(self.S); t.append(time.perf_counter())
+        out = E.batch_fetch(self.S) if self.args.sync_p1 else E.batch_fetch_view(self.S); t.append(time.perf_counter())
+        if host_ms is not None:
+            for k, name in enumerate(("reset", "append", "process", "fetch")):
+                host_ms[name] += (t[k + 1] - t[k]) * 1e3
+        return steps, out
+
+    def describe(self, steps):
+        return {"workload": f"configs[4], AM half: batch={self.S} hybrid-AM MA1 {self.fmt} streams @{self.fs:.5f} S/s per GPU, {self.n / 2 / self.fs:.1f} s each "
+                            f"({self.args.am_frames} L1 frames), one transmission staggered in time" + (", through the 5-stage 32:1 decimator" if self.fmt == "cu8" else ""),
+                "streams_per_gpu": self.S, "seconds_per_stream": round(self.n / 2 / self.fs, 2), "p1_decode": "in-order" if self.args.sync_p1 else "windowed-overlap",
+                "l2_feedback": "on-device" if self.args.l2_feedback else "off", "block_steps_per_pass": int(steps), "hbm_resident_input_GB": round(self.iq.numel() * self.iq.element_size() / 1e9, 2)}
+
+    def verify(self, recs, counts, frames):
+        eng, cap = self.eng, self.cap
+        if not hasattr(self, "_t1"):
+            self._t1 = {np.packbits(b, bitorder="little").tobytes() for fr in cap.p1_frames for b in fr}
+            self._t3 = {np.packbits(b, bitorder="little").tobytes() for b in cap.p3_frames}
+        rows = []
+        for k, gs in enumerate(self.my_streams):
+            r = recs[k, :counts[k]]
+            n1 = ok1 = n3 = ok3 = 0
+            check = (k % max(1, self.S // 16)) == 0             # frame-by-frame truth check on every 16th stream; counts on all
+            for rr in r:
+                fl, slot, bc = int(rr["flags"]), int(rr["p1_slot"]), int(rr["bc_decoded"])
+                if fl & eng.REC_P1:
+                    n1 += 1
+                    if check:
+                        ok1 += np.packbits(eng.unpack_bits(frames[k, slot, bc * 118:(bc + 1) * 118], 3750), bitorder="little").tobytes() in self._t1
+                if fl & eng.REC_P3:
+                    n3 += 1
+                    if check:
+                        ok3 += np.packbits(eng.unpack_bits(frames[k, slot, 944:944 + 750], 24000), bitorder="little").tobytes() in self._t3
+            rows.append([gs, len(r), n1 + n3, (ok1 + ok3) if check else -1, int(((r["flags"] & eng.REC_PIDS) != 0).sum()), int((r["state_after"] == eng.SYNC_FINE).sum()), n3])
+        return rows
+
+    def parity(self, allrows):
+        chk = allrows[allrows[:, 3] >= 0]
+        return {"streams": int(allrows.shape[0]), "frames_decoded_p1_plus_p3": int(allrows[:, 2].sum()), "p3_frames_decoded": int(allrows[:, 6].sum()),
+                "pids_frames_decoded": int(allrows[:, 4].sum()), "streams_checked_frame_by_frame": int(chk.shape[0]),
+                "frames_checked": int(chk[:, 2].sum()), "frames_equal_transmitted_bits": int(chk[:, 3].sum())}
+
+    def cpu_sample(self):
+        return np.ascontiguousarray(self.cap.iq[:self.n])
+
+
+class Mixed:
+    """configs[4]: 128 FM cu8 + 64 AM cs16 + 64 AM cu8 streams in ONE engine (the FM and AM halves run back to back)"""
+    dtype = "as the fm and am workloads"
+
+    def __init__(self, args, dev, local, my_streams):
+        import torch
+        from nrsc5_amd import engine as eng, synth_am, synth_torch as stt
+        self.args, self.dev, self.eng, self.my_streams = args, dev, eng, my_streams
+        S = self.S = len(my_streams)
+        self.nfm = nfm = S // 2
+        nam = S - nfm
+        self.n16, self.n8 = nam // 2, nam - nam // 2
+        n_frames = self.n_frames = max(2, int(np.ceil(args.seconds * FS / FRAME_SAMPLES)))
+        self.pool = []
+        for p in range(4):
+            p1, pids, m = stt.payload_stream(n_frames, seed=p)
+            self.pool.append((np.packbits(p1, axis=1, bitorder="little"), stt.modulate(m, dev)))
+        tail = 8640
+        self.stride_fm = (2 * (4320 + self.pool[0][1].shape[0] + tail) + 255) // 256 * 256
+        self.fm = torch.zeros((nfm, self.stride_fm), dtype=torch.uint8, device=dev)
+        self.fm_bytes = np.zeros(nfm, dtype=np.uint32)
+        for k in range(nfm):
+            prm = stt.stream_params(my_streams[k])
+            out = stt.channel_cu8(self.pool[k % 4][1], prm["cfo_hz"], prm["offset"], prm["snr_db"], prm["seed"], tail=tail, out=self.fm[k])
+            self.fm_bytes[k] = out.shape[0] - out.shape[0] % 4
+        c16 = synth_am.am_ma1_capture(args.am_frames, seed=77, cfo_hz=4.0, offset=3000, fmt="cs16")
+        c8 = synth_am.am_ma1_capture(args.am_frames, seed=78, cfo_hz=-3.0, offset=3000 * 32, fmt="cu8")
+        b16, b8 = torch.from_numpy(c16.iq).to(dev), torch.from_numpy(c8.iq).to(dev)
+        self.len16 = (c16.iq.size - 8 * 97) // 4 * 4
+        self.len8 = (c8.iq.size - 128 * 97) // 4 * 4
+        self.am16 = torch.stack([b16[8 * (k % 97): 8 * (k % 97) + self.len16] for k in range(self.n16)])
+        self.am8 = torch.stack([b8[128 * (k % 97): 128 * (k % 97) + self.len8] for k in range(self.n8)])
+        self.cap8 = c8
+        torch.cuda.synchronize()
+        self.samples = float(self.fm_bytes.sum()) / 2 + self.n16 * self.len16 / 2 + self.n8 * self.len8 / 2
+        self.signal_seconds = float(self.fm_bytes.sum()) / 2 / FS + self.n16 * (self.len16 / 2) / synth_am.FS_CS16 + self.n8 * (self.len8 / 2) / synth_am.FS_CU8
+        self.alg_bytes = float(self.fm_bytes.sum()) / 2 * ALG_FM_CU8 + self.n16 * self.len16 / 2 * ALG_AM_CS16 + self.n8 * self.len8 / 2 * ALG_AM_CU8
+        self.alg = self.alg_bytes / self.samples
+        self.fs = self.samples / self.signal_seconds            # for the x real-time of the line
+        cap = max(self.len16 // 2, self.len8 // 64, 2 * 71280) + 4096
+        self.E = eng.Engine(max_streams=S, q15_capacity=int(cap), record_capacity=max(2 * 16 * n_frames + 64, 8 * args.am_frames + 32, 512),
+                            p1_slots=max(n_frames + 12, args.am_frames), p1_async=True, am_enable=True, l2_feedback=bool(args.l2_feedback),
+                            batch_zero_copy=True, device=local)
+        self.ids_fm = np.arange(nfm, dtype=np.int32)
+        self.ids16 = np.arange(nfm, nfm + self.n16, dtype=np.int32)
+        self.ids8 = np.arange(nfm + self.n16, S, dtype=np.int32)
+        for s in list(self.ids16) + list(self.ids8):
+            self.E.set_mode(int(s), eng.MODE_AM)
+
+    def one_pass(self, host_ms=None):
+        E = self.E
+        t = [time.perf_counter()]
+        E.reset_all(); t.append(time.perf_counter())
+        E.batch_append_cu8(self.fm.data_ptr(), self.stride_fm, self.fm_bytes, stream_ids=self.ids_fm)
+        E.batch_append_cs16(self.am16.data_ptr(), self.len16, np.full(self.n16, self.len16, dtype=np.uint32), stream_ids=self.ids16)
+        E.batch_append_cu8(self.am8.data_ptr(), self.len8, np.full(self.n8, self.len8, dtype=np.uint32), stream_ids=self.ids8)
+        t.append(time.perf_counter())
+        steps = E.batch_process(self.S); t.append(time.perf_counter())
+        out = E.batch_fetch_view(self.S); t.append(time.perf_counter())
+        if host_ms is not None:
+            for k, name in enumerate(("reset", "append", "process", "fetch")):
+                host_ms[name] += (t[k + 1] - t[k]) * 1e3
+        return steps, out
+
+    def describe(self, steps):
+        return {"workload": f"configs[4]: mixed batch of {self.nfm} hybrid-FM MP1 cu8 streams ({self.n_frames} L1 frames each, read in place) + {self.n16} AM MA1 cs16 + "
+                            f"{self.n8} AM MA1 cu8 streams ({self.args.am_frames} L1 frames each) in one engine",
+                "streams_per_gpu": self.S, "signal_seconds_per_pass": round(self.signal_seconds, 1), "p1_decode": "windowed-overlap",
+                "l2_feedback": "on-device" if self.args.l2_feedback else "off", "block_steps_per_pass": int(steps)}
+
+    def verify(self, recs, counts, frames):
+        eng = self.eng
+        rows = []
+        for k, gs in enumerate(self.my_streams):
+            r = recs[k, :counts[k]]
+            nfr = int(((r["flags"] & eng.REC_P1) != 0).sum())
+            ok = -1
+            if k < self.nfm:
+                truth = {t.tobytes() for t in self.pool[k % 4][0]}
+                ok = sum(1 for rr in r if (int(rr["flags"]) & eng.REC_P1) and frames[k, int(rr["p1_slot"])].view(np.uint8).tobytes() in truth)
+            rows.append([gs, len(r), nfr, ok, int(((r["flags"] & eng.REC_PIDS) != 0).sum()), int((r["state_after"] == eng.SYNC_FINE).sum()), int(k < self.nfm)])
+        return rows
+
+    def parity(self, allrows):
+        fm = allrows[allrows[:, 6] == 1]; am = allrows[allrows[:, 6] == 0]
+        return {"streams": int(allrows.shape[0]), "fm_p1_frames_decoded": int(fm[:, 2].sum()), "fm_p1_frames_bit_exact_vs_truth": int(fm[:, 3].sum()),
+                "am_p1_frames_decoded": int(am[:, 2].sum()), "pids_frames_decoded": int(allrows[:, 4].sum())}
+
+    def cpu_sample(self):
+        return None
+
+
+def source_fingerprint():
+    from nrsc5_amd import build
+    return build.source_sha()
+
+
 def main():
     args = parse()
     from nrsc5_amd import shard
@@ -127,11 +518,7 @@ def main():
         sys.exit(shard.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, {"NRSC5_BENCH_LAUNCHER": "bench.py"}))
     if args.launch_check:
         return launch_check(args)
-    if args.workload != "fm":
-        return side_workload(args)
     import torch
-    from nrsc5_amd import engine as eng, synth_torch as stt
-
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); there is no CPU fallback")
     if torch.cuda.device_count() < max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))):
@@ -140,207 +527,104 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    S = args.streams
-    n_frames = max(2, int(np.ceil(args.seconds * FS / FRAME_SAMPLES)))
-    my_streams = list(shard.stream_range(S * world, world, rank))
-
-    # ---- synthetic captures, resident in HBM before timing starts -----------------------------------
+    S = args.streams or (128 if args.workload == "am-cu8" else 256)
+    my_streams = list(shard.stream_range(S * world, world, rank))      # contiguous stream ranges per rank: no data-path collective
     t_gen = time.perf_counter()
-    pool = []
-    for p in range(args.payloads):
-        p1, pids, m = stt.payload_stream(n_frames, seed=p)
-        pool.append((np.packbits(p1, axis=1, bitorder="little"), stt.modulate(m, dev)))
-    nsig = pool[0][1].shape[0]
-    tail = 8640
-    stride = (2 * (4320 + nsig + tail) + 255) // 256 * 256
-    iq = torch.zeros((S, stride), dtype=torch.uint8, device=dev)
-    nbytes = np.zeros(S, dtype=np.uint32)
-    params = []
-    for k, gs in enumerate(my_streams):
-        prm = stt.stream_params(gs)
-        out = stt.channel_cu8(pool[gs % args.payloads][1], prm["cfo_hz"], prm["offset"], prm["snr_db"], prm["seed"], tail=tail, out=iq[k])
-        nbytes[k] = out.shape[0] - out.shape[0] % 4
-        params.append(prm)
-    torch.cuda.synchronize()
+    if args.workload == "fm":
+        W = Fm(args, dev, local, my_streams)
+    elif args.workload == "mixed":
+        W = Mixed(args, dev, local, my_streams)
+    else:
+        W = Am(args, dev, local, my_streams, args.workload.split("-")[1])
     t_gen = time.perf_counter() - t_gen
-    total_samples_rank = float(nbytes.astype(np.float64).sum() / 2)
-
-    # replay (window pipeline + L2 feedback): blocks that ran behind a failed P1 frame keep their records / ring slots
-    # (marked void, never delivered), so both rings carry head-room for the speculated stretch
-    # zero-copy batch: the captures are read where they are (half-band fused into the symbol kernel): no decimated copy,
-    # so the FIFO stays at its minimum size
-    zero_copy = not args.copy_input
-    E = eng.Engine(max_streams=S, q15_capacity=2 * 71280 if zero_copy else int(stride // 4 + 1024), record_capacity=max(512, 2 * 16 * n_frames + 64),
-                   p1_slots=n_frames + 12, p1_async=not args.sync_p1, device=local, l2_feedback=bool(args.l2_feedback), l2_index=bool(args.l2_index_inline),
-                   batch_zero_copy=zero_copy)
+    E = W.E
 
     host_ms = {"reset": 0.0, "append": 0.0, "process": 0.0, "fetch": 0.0}
-
-    def one_pass(fetch=True):
-        t = [time.perf_counter()]
-        E.reset_all(); t.append(time.perf_counter())
-        E.batch_append_cu8(iq.data_ptr(), stride, nbytes); t.append(time.perf_counter())
-        steps = E.batch_process(S); t.append(time.perf_counter())
-        out = E.batch_fetch_view(S) if fetch else None; t.append(time.perf_counter())
-        for k, name in enumerate(("reset", "append", "process", "fetch")):
-            host_ms[name] += (t[k + 1] - t[k]) * 1e3
-        return steps, out
-
     for _ in range(args.warmup):
-        one_pass()
+        W.one_pass()
     E.profile(0 if args.no_profile else 1)
-    for k in host_ms:
-        host_ms[k] = 0.0
     shard.barrier(dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        block_steps, (recs, counts, frames) = one_pass()
+        block_steps, (recs, counts, frames) = W.one_pass(host_ms=host_ms)
     torch.cuda.synchronize()
     shard.barrier(dev)
     dt = time.perf_counter() - t0
     prof = E.profile(0)
     dt = shard.max_over_ranks(dt, dev)
-    tot = shard.sum_over_ranks([total_samples_rank, 1.0], dev)
-    total_samples, ranks_seen = float(tot[0]), int(tot[1])     # ranks_seen: counted through the collective itself
+    tot = shard.sum_over_ranks([W.samples, W.signal_seconds, 1.0], dev)
+    total_samples, total_seconds, ranks_seen = float(tot[0]), float(tot[1]), int(tot[2])     # ranks_seen: counted through the collective itself
 
-    # ---- verification of the last pass against the transmitted truth ----------------------------------
-    rows = []
-    n_locked = 0
-    l2_jobs, l2_exact = [], []
-    for k, gs in enumerate(my_streams):
-        r = recs[k, :counts[k]]
-        truth = pool[gs % args.payloads][0]
-        p1r = r[(r["flags"] & eng.REC_P1) != 0]
-        ok = 0
-        h = 0
-        first = None
-        for j, rr in enumerate(p1r):
-            w = frames[k, int(rr["p1_slot"])]
-            h = zlib.crc32(w.tobytes(), h)
-            b = w.view(np.uint8)
-            exact = 0
-            if first is None:
-                match = np.nonzero((truth == b[None, :]).all(axis=1))[0]
-                if match.size:
-                    first = int(match[0]) - j
-                    exact = 1
-            else:
-                idx = first + j
-                exact = int(0 <= idx < truth.shape[0] and np.array_equal(truth[idx], b))
-            ok += exact
-            l2_jobs.append((k, int(rr["p1_slot"]), eng.L2_FM_P1, 0, eng.P1_BITS)); l2_exact.append(exact)
-        fine = int((r["state_after"] == eng.SYNC_FINE).sum())
-        locked = len(p1r) > 0 and ok >= len(p1r) - 1
-        n_locked += int(locked)
-        rows.append([gs, len(r), len(p1r), ok, int(((r["flags"] & eng.REC_PIDS) != 0).sum()), fine, h])
+    rows = W.verify(recs, counts, frames)
     allrows = shard.gather_summaries(np.array(rows, dtype=np.int64), dev)
-    # ---- full-size property check on the device: the L2 audio index of every decoded P1 frame (frame_push + RS header +
-    # CRC-8 of all 32 audio packets, k_l2_index) must be clean exactly for the frames that equal the transmitted bits
-    l2 = None
-    if l2_jobs and not args.no_l2_index:
-        try:
-            t_l2 = time.perf_counter()
-            if args.l2_index_inline:
-                ring = E.batch_fetch_l2(S)
-                idx = [(eng.l2_frame_to_dict(ring[j[0]][j[1]]), None) for j in l2_jobs]
-            else:
-                idx = E.l2_index(l2_jobs, want_bytes=False)
-            t_l2 = time.perf_counter() - t_l2
-            clean = [int(d["n_pdu"] == 1 and d["pdus"][0]["nop"] == 32 and d["pdus"][0]["crc_bad_lo"] == 0 and d["lost_sync"] == 0) for d, _ in idx]
-            l2 = {"where": "decode streams, inside the timed region" if args.l2_index_inline else "post-pass, untimed",
-                  "frames_indexed": len(idx), "host_ms_incl_copies": round(t_l2 * 1e3, 2),
-                  "audio_packets_crc_ok": int(sum(sum(p["nop"] - bin(p["crc_bad_lo"] | (p["crc_bad_hi"] << 32)).count("1") for p in d["pdus"]) for d, _ in idx)),
-                  "frames_clean": int(sum(clean)), "clean_and_bit_exact": int(sum(c & e for c, e in zip(clean, l2_exact))),
-                  "bit_exact": int(sum(l2_exact)), "frames_flagged_lost_sync": int(sum(d["lost_sync"] for d, _ in idx))}
-        except Exception as ex:                       # informational, never allowed to take the bench line down
-            l2 = {"error": repr(ex)}
-
     if rank != 0:
         return
-    # ---- reference-equality of the benchmarked mode on a sample of this pass's streams (untimed checker leg) ----------
-    # streams the reference algorithm first locks falsely on (their log has LOST_SYNC) + the first streams that did not:
-    # the complete ordered log -- sync / lost-sync blocks, every PIDS and P1 frame, MER / BER / CFO -- against the oracle
-    # driven by the restated frame_process decision
-    ref_eq = None
-    if not args.no_cpu_baseline and world == 1:
-        try:
-            from oracle import port
-            from tests import common
-            O = port.Oracle()
-            lost = [k for k in range(len(my_streams)) if ((recs[k, :counts[k]]["flags"] & eng.REC_LOST_SYNC) != 0).any()]
-            sample = lost[:args.oracle_streams] + [k for k in range(len(my_streams)) if k not in lost][:max(1, args.oracle_streams // 2)]
-            t_or = time.perf_counter()
-            equal, first_diffs = 0, []
-            for k in sample:
-                ol, _, _ = O.run(iq[k, :int(nbytes[k])].cpu().numpy(), p1_hook=O.l2_hook())
-                log = eng.records_to_log(E, k, recs[k, :counts[k]], frames[k])
-                diffs = common.compare_logs(common.strip_states(ol), common.strip_states(log))
-                kept = [x for x in common.strip_states(ol) if x[0] not in ("hdc", "soft", "vit", "amsym", "pxsoft")]
-                bad = {i for i, (kk, v) in enumerate(kept) if kk == "ber" and v["cber"] > 0.02}     # frames decoded while falsely locked: noise in, noise out
-                diffs = [d for d in diffs if not any(d.startswith(f"#{i} ber") or d.startswith(f"#{i + 1} frame") for i in bad)]
-                equal += not diffs
-                if diffs and len(first_diffs) < 3:
-                    first_diffs.append({"stream": int(my_streams[k]), "diff": diffs[0]})
-            ref_eq = {"streams_with_lost_sync_this_pass": len(lost), "streams_checked": len(sample), "of_which_with_lost_sync": len([k for k in sample if k in lost]),
-                      "logs_equal_to_oracle_with_l2_hook": int(equal), "first_diffs": first_diffs, "seconds": round(time.perf_counter() - t_or, 1),
-                      "compared": "ordered log: state/sync/lost_sync blocks, PIDS + P1 frames bit-exact (frames with cber > 0.02 = decoded while falsely locked excepted), floats 1e-4"}
-        except Exception as ex:
-            ref_eq = {"error": repr(ex)}
+    parity = W.parity(allrows)
+    checker = not args.no_cpu_baseline and world == 1
+    if args.workload == "fm":
+        if checker:
+            try:
+                parity["reference_equality_rank0"] = W.reference_equality(recs, counts, frames)
+            except Exception as ex:
+                parity["reference_equality_rank0"] = {"error": repr(ex)}
+        if not args.no_l2_index:
+            try:
+                parity["l2_index_rank0"] = W.l2_property()
+            except Exception as ex:                       # informational, never allowed to take the bench line down
+                parity["l2_index_rank0"] = {"error": repr(ex)}
+
     value = total_samples * args.steps / dt / 1e6
-    # ---- roofline of the dominant kernel (by device time, HIP events on its launch stream) -----------
-    blocks_rank = int(counts.sum())
-    frames_rank = int(sum(row[2] for row in rows))
-    dom = max(prof, key=lambda k: prof[k][0])
-    dom_ms, dom_launches = prof[dom]
-    per_pass_ms = {k: v[0] / args.steps for k, v in prof.items()}
-    if dom == "decimate":
-        dom_samples = total_samples_rank * args.steps
-    elif dom == "p1_viterbi":
-        dom_samples = frames_rank * FRAME_SAMPLES * args.steps
-    else:
-        dom_samples = blocks_rank * BLOCK_SAMPLES * args.steps
-    alg_bytes_per_launch = dom_samples * ALG_BYTES_PER_SAMPLE / max(dom_launches, 1)
-    avg_launch_s = dom_ms / 1e3 / max(dom_launches, 1)
-    achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-    traffic = None
-    if os.path.exists(args.traffic_json):
-        try:
-            tj = json.load(open(args.traffic_json))
-            if tj.get("kernel_class") == dom:
-                traffic = tj.get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic,
-                "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": dom_launches,
-                "alg_bytes_per_launch": int(alg_bytes_per_launch),
-                "whole_path_GBps": round(value * ALG_BYTES_PER_SAMPLE / 1e3, 3),
-                "device_ms_per_pass": {k: round(v, 3) for k, v in per_pass_ms.items()},
-                "host_ms_per_pass": {k: round(v / args.steps, 3) for k, v in host_ms.items()}}
+    # ---- roofline of the dominant kernel class (by device time, HIP events on its launch stream) --------------------------
+    used = {k: v for k, v in prof.items() if v[1]}
+    roofline = None
+    if used:
+        dom = max(used, key=lambda k: used[k][0])
+        dom_ms, dom_launches = used[dom]
+        # every kernel class sees each input sample of the pass once: algorithmic bytes per launch = bytes of the pass / launches per pass
+        alg_bytes_per_launch = W.samples * W.alg * args.steps / max(dom_launches, 1)
+        avg_launch_s = dom_ms / 1e3 / max(dom_launches, 1)
+        achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        traffic, whole = None, None
+        if os.path.exists(args.traffic_json):
+            try:
+                tj = json.load(open(args.traffic_json))
+                if tj.get("source_sha") == source_fingerprint() and tj.get("workload") == args.workload:
+                    traffic = tj.get("per_class_hbm_bytes_per_launch", {}).get(dom)
+                    whole = {"hbm_bytes_per_pass": tj.get("whole_path_hbm_bytes_per_pass"), "over_algorithmic": tj.get("whole_path_over_algorithmic"), "file": os.path.relpath(args.traffic_json, ROOT)}
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "whole_path_traffic": whole,
+                    "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": dom_launches,
+                    "avg_launch_ms_note": "HIP events on the kernel's own launch stream; up to three decode streams and the block-step chain run concurrently, so this is a per-launch latency under contention, not an exclusive-occupancy figure",
+                    "alg_bytes_per_launch": int(alg_bytes_per_launch), "alg_bytes_per_sample": round(W.alg, 4),
+                    "whole_path_GBps": round(value * W.alg / 1e3, 3),
+                    "device_ms_per_pass": {k: round(v[0] / args.steps, 3) for k, v in used.items()},
+                    "host_ms_per_pass": {k: round(v / args.steps, 3) for k, v in host_ms.items()}}
     cpu = None
-    if not args.no_cpu_baseline and world == 1:
-        k0 = 0
-        cpu = cpu_baseline(iq[k0, :int(nbytes[k0])].cpu().numpy(), args.cpu_baseline_seconds)
-    n_total = allrows.shape[0]
-    good = int(((allrows[:, 2] > 0) & (allrows[:, 3] >= allrows[:, 2] - 1)).sum())
+    if checker:
+        sample = W.cpu_sample()
+        if sample is not None:
+            try:
+                cpu = cpu_baseline(sample, W.fs, W.mode, args.cpu_baseline_seconds, args.cpu_processes)
+            except Exception as ex:
+                cpu = {"error": repr(ex)}
+    extra = {}
+    if args.workload == "fm" and world == 1 and not args.no_extra_legs:
+        try:
+            extra = W.extra_legs(local)
+        except Exception as ex:
+            extra = {"extra_legs_error": repr(ex)}
     line = {
         "metric": "IQ MS/s demod+decoded", "value": round(value, 2), "unit": "IQ MS/s",
-        "x_realtime": round(value * 1e6 / FS, 1), "n_gpus": world, "ranks_in_process_group": ranks_seen, "steps": args.steps, "warmup": args.warmup,
+        "x_realtime": round(total_seconds * args.steps / dt, 1), "n_gpus": world, "ranks_in_process_group": ranks_seen, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "int16 Q15 front end / f32 OFDM+sync / int32 Viterbi metrics", "data": "synthetic",
-        "config": {"workload": f"configs[2]: batch={S} independent hybrid-FM MP1 cu8 streams @1.488375 MS/s per GPU, "
-                               f"{nbytes[0] / 2 / FS:.2f} s each ({n_frames} L1 frames), CFO +-300 Hz, offset [0,4320), SNR 15/20/25 dB",
-                   "streams_per_gpu": S, "seconds_per_stream": round(float(nbytes[0]) / 2 / FS, 3),
-                   "p1_decode": "in-order" if args.sync_p1 else "windowed-overlap", "l2_feedback": "on-device" if args.l2_feedback else "off", "input": "read in place (half-band fused into the symbol kernel)" if zero_copy else "decimated copy in the Q15 FIFO", "block_steps_per_pass": int(block_steps),
-                   "distinct_payloads": args.payloads, "hbm_resident_input_GB": round(float(nbytes.sum()) / 1e9, 2)},
-        "roofline": roofline, "cpu_baseline": cpu,
-        "parity": {"streams": n_total, "streams_locked_and_all_p1_frames_equal_transmitted_bits": good,
-                   "p1_frames_decoded": int(allrows[:, 2].sum()), "p1_frames_bit_exact_vs_truth": int(allrows[:, 3].sum()),
-                   "pids_frames_decoded": int(allrows[:, 4].sum()), "reference_equality_rank0": ref_eq, "l2_index_rank0": l2,
-                   "note": "streams whose timing offset falls in the reference algorithm's false-lock zone (sync.c phase-slope ambiguity, ~6 % of uniform offsets) decode one garbage frame in the reference too, whose L2 then forces a re-acquisition; with l2_feedback the engine does the same on the device: the verdict of the deferred decode rewinds the stream to the end of that frame's block (k_replay.hip), so LOST_SYNC and the re-acquisition land on the reference's blocks"},
+        "vs_baseline": None, "dtype": W.dtype, "data": "synthetic",
+        "config": W.describe(block_steps), "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         "gen_seconds": round(t_gen, 1),
     }
+    line.update(extra)
     print(json.dumps(line))
 
 

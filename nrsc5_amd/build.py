@@ -29,6 +29,17 @@ def _deps():
     return d
 
 
+def source_sha() -> str:
+    """Fingerprint of the device sources: measurements stored under profiles/ carry it, so that bench.py can tell whether a PMC
+    figure was collected from THIS tree."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(_deps()):
+        if f.endswith((".hip", ".h")):
+            h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build_hip(force: bool = False, verbose: bool = False) -> str:
     """Cross-compiles on a GPU-less host too (hipcc --offload-arch=gfx950)."""
     if force or _stale(LIB, _deps()):

@@ -1,48 +1,65 @@
-"""Turns two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md prescribes)
-of `python bench.py` into HBM bytes per launch of the dominant kernel class -> profiles/traffic_latest.json.
+"""Turns two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md prescribes) of
+`python bench.py --steps 1 --warmup 0` into HBM bytes per launch of every kernel class and of the whole path
+-> profiles/traffic_latest.json, stamped with the fingerprint of the device sources it was collected from
+(bench.py ignores the file when that differs from the tree it runs in).
 
 gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB-units of 1024 B
 (hbm_bytes = counter * 1024) and FETCH_SIZE under-reports wide coalesced streaming reads by 2x (128-B requests
-tallied at 64 B).  The trellis kernels read bytes / 8-byte words, not 16-B lanes, so both the raw and the
-2x-corrected read figures are recorded; `hbm_bytes_per_launch` uses the raw read count + writes (lower bound)."""
+tallied at 64 B).  Both the raw and the 2x-corrected read figures are recorded; the per-launch / whole-path figures use the
+raw read count + writes (a lower bound on traffic)."""
 import csv
 import glob
 import json
 import os
 import sys
 
-CLASS_KERNELS = {"p1_viterbi": ("k_p1_forward", "k_p1_traceback", "k_p1_deint"), "sync": ("k_sync",), "mixfft": ("k_mixfft",),
-                 "decimate": ("k_decimate_fm_cu8",), "p1_deint": ("k_p1_deint",)}
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+# kernel-name fragments -> the classes of nrsc5hip_profile (include/nrsc5hip.h)
+CLASSES = {"decimate": ("k_decimate_fm_cu8", "k_decimate_commit", "k_append_cs16", "k_attach_raw", "k_am_decimate"),
+           "acquire": ("k_acq_",), "prepare": ("k_prepare", "k_rollback"), "mixfft": ("k_mixfft",), "sync": ("k_sync", "k_px_deint", "k_px_commit"),
+           "p1_viterbi": ("k_p1_forward", "k_p1_traceback", "k_p1_deint", "k_l2_index_window"), "pids": ("k_pids_decode", "k_px_decode"),
+           "am": ("k_am_",)}
+LEAD = {"decimate": "k_decimate_fm_cu8", "acquire": "k_acq_fir", "prepare": "k_prepare", "mixfft": "k_mixfft", "sync": "k_sync",
+        "p1_viterbi": "k_p1_forward", "pids": "k_pids_decode", "am": "k_am_block"}
 
 
 def load(dirname, counter):
     tot, calls = {}, {}
     for f in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            if row.get("Counter_Name") != counter:
+            if row.get("Counter_Name") != counter or "nrsc5::" not in row["Kernel_Name"]:
                 continue
-            name = row["Kernel_Name"]
+            name = row["Kernel_Name"].split("(")[0].replace("nrsc5::", "")
             tot[name] = tot.get(name, 0.0) + float(row["Counter_Value"])
             calls[name] = calls.get(name, 0) + 1
     return tot, calls
 
 
-def main(fetch_dir, write_dir, kernel_class, out):
+def main(fetch_dir, write_dir, workload, alg_bytes_per_pass, out):
+    from nrsc5_amd import build
     ft, fc = load(fetch_dir, "FETCH_SIZE")
     wt, wc = load(write_dir, "WRITE_SIZE")
-    keys = CLASS_KERNELS[kernel_class]
-    rd = sum(v for k, v in ft.items() if any(x in k for x in keys)) * 1024
-    wr = sum(v for k, v in wt.items() if any(x in k for x in keys)) * 1024
-    launches = sum(c for k, c in fc.items() if keys[0] in k)
-    res = {"kernel_class": kernel_class, "launches": launches,
-           "fetch_bytes_per_launch_raw": rd / max(launches, 1), "fetch_bytes_per_launch_x2": 2 * rd / max(launches, 1),
-           "write_bytes_per_launch": wr / max(launches, 1),
-           "hbm_bytes_per_launch": (rd + wr) / max(launches, 1),
-           "per_kernel_fetch_KiB": {k[:60]: v for k, v in sorted(ft.items(), key=lambda kv: -kv[1])[:8]},
-           "per_kernel_write_KiB": {k[:60]: v for k, v in sorted(wt.items(), key=lambda kv: -kv[1])[:8]}}
+    per_class, per_class_detail = {}, {}
+    for cls, frags in CLASSES.items():
+        rd = sum(v for k, v in ft.items() if any(k.startswith(x) for x in frags)) * 1024
+        wr = sum(v for k, v in wt.items() if any(k.startswith(x) for x in frags)) * 1024
+        launches = sum(c for k, c in fc.items() if k.startswith(LEAD[cls]))
+        if launches:
+            per_class[cls] = (rd + wr) / launches
+            per_class_detail[cls] = {"launches": launches, "fetch_bytes_raw": rd, "fetch_bytes_x2": 2 * rd, "write_bytes": wr}
+    rd_all, wr_all = sum(ft.values()) * 1024, sum(wt.values()) * 1024
+    res = {"source_sha": build.source_sha(), "workload": workload, "passes": 1,
+           "per_class_hbm_bytes_per_launch": per_class, "per_class": per_class_detail,
+           "whole_path_fetch_bytes_raw": rd_all, "whole_path_fetch_bytes_x2": 2 * rd_all, "whole_path_write_bytes": wr_all,
+           "whole_path_hbm_bytes_per_pass": rd_all + wr_all, "algorithmic_bytes_per_pass": float(alg_bytes_per_pass),
+           "whole_path_over_algorithmic": (rd_all + wr_all) / float(alg_bytes_per_pass),
+           "per_kernel_fetch_MB": {k: round(v * 1024 / 1e6, 1) for k, v in sorted(ft.items(), key=lambda kv: -kv[1])[:12]},
+           "per_kernel_write_MB": {k: round(v * 1024 / 1e6, 1) for k, v in sorted(wt.items(), key=lambda kv: -kv[1])[:12]}}
     json.dump(res, open(out, "w"), indent=1)
-    print(json.dumps(res)[:600])
+    print(json.dumps({k: res[k] for k in ("source_sha", "whole_path_hbm_bytes_per_pass", "whole_path_over_algorithmic", "per_class_hbm_bytes_per_launch")}))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4])
+    main(sys.argv[1], sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5])

@@ -1,0 +1,20 @@
+#!/bin/bash
+# every bench workload once (same JSON schema), then the PMC traffic of the headline workload
+cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
+TAG=${1:-r02}
+for wl in fm am-cs16 am-cu8 mixed; do
+  ( time timeout 400 python bench.py --workload $wl ) > gpurun_out/${TAG}_bench_${wl}.log 2>&1; echo "$wl rc=$?"
+  grep "^{" gpurun_out/${TAG}_bench_${wl}.log | tail -1 > gpurun_out/${TAG}_bench_${wl}.json
+  python - "$TAG" "$wl" <<'PY'
+import json, sys
+try:
+    d = json.load(open(f"gpurun_out/{sys.argv[1]}_bench_{sys.argv[2]}.json"))
+    print({k: d.get(k) for k in ("value", "x_realtime", "ms_per_step")}, (d.get("roofline") or {}).get("kernel"), (d.get("roofline") or {}).get("frac"), "cpu", (d.get("cpu_baseline") or {}).get("x_realtime"), ((d.get("cpu_baseline") or {}).get("all_cores") or {}).get("x_realtime"))
+    for k in ("single_stream", "in_order"):
+        if k in d: print("  ", k, d[k])
+    print("  parity", {k: v for k, v in d["parity"].items() if not isinstance(v, (dict, str))})
+except Exception as ex:
+    print("no json", ex); print(open(f"gpurun_out/{sys.argv[1]}_bench_{sys.argv[2]}.log").read()[-1500:])
+PY
+done
+bash tools/gpu_pmc.sh fm; cat gpurun_out/traffic_fm.json | head -40
