@@ -117,7 +117,7 @@ def cpu_baseline(stream_iq: np.ndarray, fs: float, mode: int, budget_s: float, n
         try:
             fd, path = tempfile.mkstemp(suffix=".npy", dir="/tmp"); os.close(fd)
             np.save(path, stream_iq)
-            per = max(1, int(0.5 * budget_s / max(dt, 1e-3)))
+            per = max(1, min(4, int(0.5 * budget_s / max(dt, 1e-3))))      # contention (shared caches, SMT) stretches these passes 3-4x
             ctx = mp.get_context("spawn")
             q = ctx.Queue()
             procs = [ctx.Process(target=_cpu_worker, args=(path, mode, per, q)) for _ in range(n)]

@@ -248,6 +248,26 @@ int nrsc5hip_batch_fetch_l2(nrsc5hip_engine *e, int nstreams, const int *stream_
 int nrsc5hip_stage_l2_index(nrsc5hip_engine *e, const uint8_t *bits, int nbits, int nframes, nrsc5hip_l2_frame *out,
                             uint8_t *pdu_bytes, long long stride);
 
+/* ---- batch HDC hand-off (host side) --------------------------------------------------------------------
+ * The reference keeps a 22.9 MB nrsc5_t per session, 18.7 MB of it the elastic buffers of output_t (output.h:104-122).  A
+ * batch of 2048 streams cannot; this consumer keeps ~40 KB per stream and program and reproduces, from the L2 index
+ * (nrsc5hip_l2_frame + the PDU bytes nrsc5hip_l2_index returns), exactly the NRSC5_EVENT_HDC sequence of the reference:
+ *   nrsc5hip_hdc_push_frame = frame_process's output_align / output_push calls for one frame   (frame.c:590-640, output.c:31-92)
+ *   nrsc5hip_hdc_advance    = output_advance: call it once per block record (NRSC5HIP_REC_PROCESSED), BEFORE handing over
+ *                             the frames that record announces, as acquire.c:108 does; every complete packet goes to `cb`
+ *                             with the event's fields (program, data, count, flags; nrsc5.c:709-728).  Returns the count.
+ *   nrsc5hip_hdc_adts       = dump_hdc's framing (main.c:182-212): 7-byte ADTS header + payload into out[count + 7]
+ * No device work: plain host functions, usable from any thread (one consumer object per thread). */
+typedef struct nrsc5hip_hdc nrsc5hip_hdc;
+typedef void (*nrsc5hip_hdc_cb)(void *opaque, int stream, unsigned program, const uint8_t *data, unsigned count, unsigned flags);
+int nrsc5hip_hdc_create(int nstreams, nrsc5hip_hdc **out);
+void nrsc5hip_hdc_destroy(nrsc5hip_hdc *h);
+int nrsc5hip_hdc_reset(nrsc5hip_hdc *h, int stream);                 /* output_reset (output.c:204-218) */
+int nrsc5hip_hdc_push_frame(nrsc5hip_hdc *h, int stream, const nrsc5hip_l2_frame *ix, const uint8_t *pdu_bytes);
+int nrsc5hip_hdc_advance(nrsc5hip_hdc *h, int stream, int mode /* NRSC5HIP_MODE_FM | _AM */, nrsc5hip_hdc_cb cb, void *opaque);
+size_t nrsc5hip_hdc_adts(const uint8_t *data, unsigned count, uint8_t *out);
+size_t nrsc5hip_hdc_host_bytes(const nrsc5hip_hdc *h);                /* host memory held by the consumer */
+
 /* ---- stage-level entry points (host buffers): parity tests of single kernels against the oracle ---- */
 int nrsc5hip_stage_halfband_fm_cu8(nrsc5hip_engine *e, const uint8_t *iq, uint32_t nbytes, int16_t *out /* [nbytes/4][2] */);
 int nrsc5hip_stage_fft2048(nrsc5hip_engine *e, const float *in /* [n][2048][2] */, float *out, int n);

@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "nrsc5_amd", "csrc")
-HIP_SOURCES = ["engine.hip", "k_decimate.hip", "k_acquire.hip", "k_mixfft.hip", "k_sync.hip", "k_decode.hip", "k_replay.hip", "k_am.hip", "k_l2.hip"]
+HIP_SOURCES = ["engine.hip", "k_decimate.hip", "k_acquire.hip", "k_mixfft.hip", "k_sync.hip", "k_decode.hip", "k_replay.hip", "k_am.hip", "k_l2.hip", "hdc_consumer.hip"]
 LIB = os.path.join(ROOT, "nrsc5_amd", "libnrsc5hip.so")
 EMU_LIB = os.path.join(ROOT, "tests", "simt", "libnrsc5hip_emu.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

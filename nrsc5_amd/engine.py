@@ -74,6 +74,9 @@ def l2_frame_to_dict(fr: L2Frame) -> dict:
     return out
 
 
+HDC_CB = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.POINTER(ctypes.c_uint8), ctypes.c_uint, ctypes.c_uint)
+
+
 class Nrsc5HipError(RuntimeError):
     pass
 
@@ -124,6 +127,16 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.nrsc5hip_stage_l2_index.argtypes = [vp, vp, ci, ci, vp, vp, ctypes.c_longlong]
     lib.nrsc5hip_l2_frame_get.argtypes = [vp, ci, ci, vp]
     lib.nrsc5hip_batch_fetch_l2.argtypes = [vp, ci, vp, vp]
+    lib.nrsc5hip_hdc_create.argtypes = [ci, ctypes.POINTER(vp)]
+    lib.nrsc5hip_hdc_destroy.argtypes = [vp]
+    lib.nrsc5hip_hdc_destroy.restype = None
+    lib.nrsc5hip_hdc_reset.argtypes = [vp, ci]
+    lib.nrsc5hip_hdc_push_frame.argtypes = [vp, ci, vp, vp]
+    lib.nrsc5hip_hdc_advance.argtypes = [vp, ci, ci, HDC_CB, vp]
+    lib.nrsc5hip_hdc_adts.argtypes = [vp, ctypes.c_uint, vp]
+    lib.nrsc5hip_hdc_adts.restype = ctypes.c_size_t
+    lib.nrsc5hip_hdc_host_bytes.argtypes = [vp]
+    lib.nrsc5hip_hdc_host_bytes.restype = ctypes.c_size_t
     return lib
 
 
@@ -136,7 +149,9 @@ EXPORTED_SYMBOLS = [
     "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_batch_fetch_view",
     "nrsc5hip_stream_set_mode", "nrsc5hip_am_frame_bits", "nrsc5hip_stage_viterbi_k9", "nrsc5hip_px_frame_bits",
     "nrsc5hip_batch_fetch_px", "nrsc5hip_debug_fetch_px", "nrsc5hip_stage_viterbi_k9_bench",
-    "nrsc5hip_l2_index", "nrsc5hip_stage_l2_index", "nrsc5hip_l2_frame_get", "nrsc5hip_batch_fetch_l2"]
+    "nrsc5hip_l2_index", "nrsc5hip_stage_l2_index", "nrsc5hip_l2_frame_get", "nrsc5hip_batch_fetch_l2",
+    "nrsc5hip_hdc_create", "nrsc5hip_hdc_destroy", "nrsc5hip_hdc_reset", "nrsc5hip_hdc_push_frame", "nrsc5hip_hdc_advance",
+    "nrsc5hip_hdc_adts", "nrsc5hip_hdc_host_bytes"]
 
 
 def unpack_bits(words: np.ndarray, nbits: int) -> np.ndarray:
@@ -323,6 +338,16 @@ class Engine:
         self._check(self.lib.nrsc5hip_l2_index(self._h, n, arr, out, by.ctypes.data if want_bytes else None, stride))
         return [(l2_frame_to_dict(out[k]), by[k, :out[k].nbytes].copy() if want_bytes else None) for k in range(n)]
 
+    def l2_index_raw(self, jobs):
+        """As l2_index, but returns the C structs themselves: (L2Frame ctypes array, PDU bytes [n, 18272]) -- what
+        nrsc5hip_hdc_push_frame takes."""
+        n = len(jobs)
+        arr = (L2Job * n)(*[L2Job(*j) for j in jobs])
+        out = (L2Frame * n)()
+        by = np.zeros((n, 18272), dtype=np.uint8)
+        self._check(self.lib.nrsc5hip_l2_index(self._h, n, arr, out, by.ctypes.data, 18272))
+        return out, by
+
     def l2_frame(self, stream: int, slot: int) -> dict:
         """Engine option l2_index: the index computed in the pipeline for the P1 frame in `slot`."""
         fr = L2Frame()
@@ -397,6 +422,71 @@ class Engine:
         bins = np.zeros((32, 534), dtype=np.complex64)
         self._check(self.lib.nrsc5hip_debug_fetch(self._h, stream, pm.ctypes.data, bins.ctypes.data))
         return pm, bins
+
+
+class HdcConsumer:
+    """Slim batch consumer of the L2 index (nrsc5hip_hdc_*): elastic buffers of `nstreams` streams in ~40 KB each instead of
+    one nrsc5_t per stream; delivers the reference's NRSC5_EVENT_HDC sequence."""
+
+    def __init__(self, nstreams: int, lib: ctypes.CDLL | None = None, lib_path: str | None = None):
+        self.lib = lib or load_library(lib_path)
+        self._h = ctypes.c_void_p()
+        if self.lib.nrsc5hip_hdc_create(nstreams, ctypes.byref(self._h)) != 0:
+            raise Nrsc5HipError("nrsc5hip_hdc_create failed")
+        self.events = []
+        self._cb = HDC_CB(self._on_packet)
+
+    def _on_packet(self, opaque, stream, program, data, count, flags):
+        self.events.append((int(stream), int(program), int(count), int(flags), bytes(ctypes.string_at(data, count)) if count else b""))
+
+    def push_frame(self, stream: int, frame: L2Frame, pdu_bytes: np.ndarray):
+        b = np.ascontiguousarray(pdu_bytes, dtype=np.uint8)
+        if self.lib.nrsc5hip_hdc_push_frame(self._h, stream, ctypes.byref(frame), b.ctypes.data) != 0:
+            raise Nrsc5HipError("nrsc5hip_hdc_push_frame failed")
+
+    def advance(self, stream: int, mode: int = MODE_FM) -> int:
+        return self.lib.nrsc5hip_hdc_advance(self._h, stream, mode, self._cb, None)
+
+    def reset(self, stream: int):
+        self.lib.nrsc5hip_hdc_reset(self._h, stream)
+
+    def host_bytes(self) -> int:
+        return int(self.lib.nrsc5hip_hdc_host_bytes(self._h))
+
+    def adts(self, data: bytes) -> bytes:
+        out = (ctypes.c_uint8 * (len(data) + 7))()
+        src = (ctypes.c_uint8 * max(len(data), 1)).from_buffer_copy(data or b"\0")
+        n = self.lib.nrsc5hip_hdc_adts(src, len(data), out)
+        return bytes(out[:n])
+
+    def close(self):
+        if self._h:
+            self.lib.nrsc5hip_hdc_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def feed_hdc(engine: Engine, consumer: HdcConsumer, stream: int, recs: np.ndarray, mode: int = MODE_FM, target_stream: int | None = None):
+    """Replays one stream's block records into the consumer in the reference's order: output_advance at the top of every
+    processed block (acquire.c:108), then the frames that block delivers (frame_push -> frame_process)."""
+    t = stream if target_stream is None else target_stream
+    jobs_all = []
+    per_rec = []
+    for r in recs:
+        jobs = l2_jobs_from_records(stream, np.array([r], dtype=RECORD_DTYPE), mode)
+        per_rec.append((len(jobs_all), len(jobs)))
+        jobs_all += jobs
+    frames, by = engine.l2_index_raw(jobs_all) if jobs_all else (None, None)
+    for r, (first, n) in zip(recs, per_rec):
+        if int(r["flags"]) & REC_PROCESSED:
+            consumer.advance(t, mode)
+        for k in range(first, first + n):
+            consumer.push_frame(t, frames[k], by[k, :frames[k].nbytes])
 
 
 def l2_jobs_from_records(stream: int, recs: np.ndarray, mode: int = 0):

@@ -703,6 +703,31 @@ def check_deferred_feedback_equals_reference(lib, oracle, n_blocks=96, verdict_l
     E.close()
 
 
+def check_hdc_consumer(lib, reflib, caps, p1_async=False):
+    """IQ -> engine -> L2 index (device) -> nrsc5hip_hdc_* == the NRSC5_EVENT_HDC sequence of the unmodified reference."""
+    from oracle import ref
+    n = len(caps)
+    E = eng.Engine(max_streams=n, q15_capacity=max(c.iq.size for c in caps) // 4 + 200000, record_capacity=1024, p1_slots=16, lib_path=lib,
+                   p1_async=p1_async, l2_feedback=True)
+    H = eng.HdcConsumer(n, lib=E.lib)
+    total = 0
+    for k, cap in enumerate(caps):
+        common.run_engine_streaming(E, k, cap.iq, chunk=32768 * 8)
+        recs = E.drain(k)
+        eng.feed_hdc(E, H, k, recs)
+        got = [(p, c, f, d) for (s, p, c, f, d) in H.events if s == k]
+        log, _, _ = reflib.run(cap.iq, taps=ref.TAP_HDC)
+        exp = [(v["program"], v["count"], v["flags"], bytes(v["data"])) for kk, v in log if kk == "hdc"]
+        assert len(exp) >= 32, "capture yields too few HDC packets to mean anything"
+        assert [(p, c, f) for p, c, f, _ in got] == [(p, c, f) for p, c, f, _ in exp], (k, len(got), len(exp))
+        assert all(a[3] == b[3] for a, b in zip(got, exp)), k
+        total += len(exp)
+    assert H.host_bytes() < n * 256 * 1024
+    H.close()
+    E.close()
+    return total
+
+
 def check_l2_index_fused(lib, oracle, p1_async=False):
     """Engine option l2_index: the index written on the decode stream behind each P1 traceback == the post-pass index
     == the oracle's, for every P1 slot the records name (streaming getter and bulk fetch)."""

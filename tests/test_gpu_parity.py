@@ -305,3 +305,13 @@ def test_gpu_l2_index_vs_reference_golden(hip_lib):
 def test_gpu_frame_push_indexed_with_device_index(hip_lib, reflib):
     """INTEGRATION.md's binding executed with the device's index inside the unmodified reference (needs oracle/_ref)."""
     ec.check_frame_push_indexed_with_device_index(hip_lib, reflib)
+
+
+@pytest.mark.parametrize("p1_async", [False, True])
+def test_gpu_hdc_consumer_equals_reference_events(hip_lib, reflib, p1_async):
+    """device L2 index -> nrsc5hip_hdc_* (slim host state) == the unmodified reference's NRSC5_EVENT_HDC packets
+    (program, count, flags, payload, order), incl. a capture with a false lock, LOST_SYNC and re-acquisition."""
+    caps = [synth.fm_mp1_capture(4, seed=91, cfo_hz=35.0, offset=700, snr_db=22),
+            synth.fm_mp1_capture(0, n_blocks=70, seed=23, cfo_hz=0.0, offset=1234, snr_db=20),
+            synth.fm_mp1_capture(3, seed=52, cfo_hz=-40.0, offset=500, snr_db=25, mode="MP3")]
+    assert ec.check_hdc_consumer(hip_lib, reflib, caps, p1_async=p1_async) >= 200
