@@ -198,14 +198,19 @@ void nrsc5hip_unpack_bits(const uint32_t *words, int nbits, uint8_t *bits);
 enum {                                   /* nrsc5hip_l2_frame.status: why the walk ended */
     NRSC5HIP_L2_END = 0,                 /* ran to the end of the frame (frame.c:525) */
     NRSC5HIP_L2_NO_AUDIO,                /* !has_audio (frame.c:522) */
-    NRSC5HIP_L2_FIXED_DATA,              /* has_fixed: audio_end depends on process_fixed_data's state (frame.c:433-514); not indexed, the host walks it */
+    NRSC5HIP_L2_FIXED_DATA,              /* (unused since round 2: frames with fixed-data sub-channels ARE indexed, with audio_end = nbytes - 1, the
+                                            largest value process_fixed_data can return; the consumer cuts the index back with the true value:
+                                            nrsc5hip_l2_apply_audio_end, done inside nrsc5hip_hdc_push_frame) */
     NRSC5HIP_L2_HEADER_RS,               /* fix_header failed (frame.c:534-541); lost_sync tells whether this drops the receiver to SYNC_STATE_NONE */
     NRSC5HIP_L2_BAD_LOCATORS,            /* one of the returns of frame.c:547-556 (typical: zero padding after the last PDU) */
     NRSC5HIP_L2_TOO_MANY_PDUS,           /* more than NRSC5HIP_L2_MAX_PDUS audio PDUs */
     NRSC5HIP_L2_HEF_OVERRUN,             /* header expansion runs past la_location: the reference's parse_hdlc length wraps (undefined) */
     NRSC5HIP_L2_BAD_STREAM,              /* stream_id >= MAX_STREAMS with nop == 0: the reference reads locations[-1] */
-    NRSC5HIP_L2_BAD_LENGTH               /* not one of frame_push's six frame lengths (frame.c:683) */
+    NRSC5HIP_L2_BAD_LENGTH,              /* not one of frame_push's six frame lengths (frame.c:683) */
+    NRSC5HIP_L2_AUDIO_END                /* set by nrsc5hip_l2_apply_audio_end: the walk ended where the fixed-data region begins (frame.c:525,547-556) */
 };
+/* PCI values that announce fixed-data sub-channels next to audio (has_fixed && has_audio, frame.c:138-151) */
+#define NRSC5HIP_L2_PCI_HAS_FIXED(pci) ((((pci) & 0xFFFFFCu) == (0xE3634Cu & 0xFFFFFCu)) || (((pci) & 0xFFFFFCu) == (0x8D8D33u & 0xFFFFFCu)))
 typedef struct nrsc5hip_l2_pdu {
     uint32_t start;                      /* offset of the PDU (its RS parity bytes) in the frame's PDU bytes */
     uint32_t psd_off; int32_t psd_len;   /* the span frame_process gives parse_hdlc (frame.c:611) */
@@ -263,7 +268,17 @@ typedef void (*nrsc5hip_hdc_cb)(void *opaque, int stream, unsigned program, cons
 int nrsc5hip_hdc_create(int nstreams, nrsc5hip_hdc **out);
 void nrsc5hip_hdc_destroy(nrsc5hip_hdc *h);
 int nrsc5hip_hdc_reset(nrsc5hip_hdc *h, int stream);                 /* output_reset (output.c:204-218) */
-int nrsc5hip_hdc_push_frame(nrsc5hip_hdc *h, int stream, const nrsc5hip_l2_frame *ix, const uint8_t *pdu_bytes);
+/* lc: logical channel of the frame (0 = P1, 1 = P3, 2 = P4), which selects the fixed-data (CCC) state it advances */
+int nrsc5hip_hdc_push_frame(nrsc5hip_hdc *h, int stream, int lc, const nrsc5hip_l2_frame *ix, const uint8_t *pdu_bytes);
+/* frames with fixed-data sub-channels: process_fixed_data's audio_end for this frame (frame.c:458-514: sync-byte tracking,
+ * CCC HDLC frames, sub-channel lengths) -- advances the stream's CCC state; and the cut of an index that was built with
+ * audio_end = nbytes - 1 back to it (the loop / locator conditions of frame.c:525,547-556).  nrsc5hip_hdc_push_frame calls both
+ * for such frames; they are exported for consumers that keep their own elastic buffers.  apply returns the PDUs kept, or -1
+ * when a header expansion ran into the fixed-data region (the reference's parse is cut there: walk that frame on the host). */
+unsigned nrsc5hip_hdc_fixed_audio_end(nrsc5hip_hdc *h, int stream, int lc, const uint8_t *pdu_bytes, unsigned nbytes);
+int nrsc5hip_l2_apply_audio_end(nrsc5hip_l2_frame *ix, unsigned audio_end);
+/* sync.c:405-409: frame_reset when a stream enters FINE (NRSC5HIP_REC_TO_FINE) clears the CCC state; the elastic buffers stay */
+int nrsc5hip_hdc_frame_reset(nrsc5hip_hdc *h, int stream);
 int nrsc5hip_hdc_advance(nrsc5hip_hdc *h, int stream, int mode /* NRSC5HIP_MODE_FM | _AM */, nrsc5hip_hdc_cb cb, void *opaque);
 size_t nrsc5hip_hdc_adts(const uint8_t *data, unsigned count, uint8_t *out);
 size_t nrsc5hip_hdc_host_bytes(const nrsc5hip_hdc *h);                /* host memory held by the consumer */

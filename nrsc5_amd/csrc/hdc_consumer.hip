@@ -23,16 +23,27 @@ constexpr int MAX_PROGRAMS = 8, MAX_STREAMS = 2;               // defines.h:67-6
 enum { SHAPE_NONE = 0, SHAPE_FULL = 1, SHAPE_HALF_FRONT = 2, SHAPE_HALF_BACK = 3 };   // packet shapes, output.h
 constexpr unsigned FLAG_CRC_ERROR = 1;                         // PACKET_FLAG_CRC_ERROR
 
+// process_fixed_data's state (ccc_data_t, frame.h:30-38) as far as audio_end depends on it
+struct Ccc {
+    unsigned sync_width = 0, sync_count = 0;
+    uint8_t buf[32];
+    int idx = -1, fixed_ready = 0;
+    unsigned length[4] = {0, 0, 0, 0};
+    void reset() { sync_width = 0; sync_count = 0; idx = -1; fixed_ready = 0; for (unsigned &l : length) l = 0; }
+};
+
 struct Packet { std::vector<uint8_t> data; unsigned size = 0, flags = 0, shape = SHAPE_NONE; };
 struct Elastic { Packet packets[ELASTIC_LEN]; };
 struct Stream {
     int audio_offset[MAX_PROGRAMS][MAX_STREAMS];
     std::unique_ptr<Elastic> elastic[MAX_PROGRAMS];            // stream_id 0 only: output_push ignores the enhanced stream (output.c:52-53)
+    Ccc ccc[3];                                                // per logical channel P1 / P3 / P4
     Stream() { reset(); }
     void reset()
     {
         for (auto &a : audio_offset) for (int &v : a) v = -1;  // output_reset, output.c:204-218
         for (auto &e : elastic) if (e) for (Packet &p : e->packets) { p.size = 0; p.flags = 0; p.shape = SHAPE_NONE; }
+        for (Ccc &c : ccc) c.reset();
     }
 };
 
@@ -59,10 +70,91 @@ extern "C" int nrsc5hip_hdc_reset(nrsc5hip_hdc *h, int stream)
     return NRSC5HIP_OK;
 }
 
-extern "C" int nrsc5hip_hdc_push_frame(nrsc5hip_hdc *h, int stream, const nrsc5hip_l2_frame *ix, const uint8_t *pdu_bytes)
+// fcs16 (frame.c:138-144): PPP FCS-16, reflected polynomial 0x8408, good residue 0xf0b8
+static unsigned fcs16(const uint8_t *p, unsigned n)
 {
-    if (!h || !ix || !pdu_bytes || stream < 0 || stream >= (int)h->streams.size()) return NRSC5HIP_EINVAL;
+    unsigned crc = 0xffff;
+    for (unsigned i = 0; i < n; i++) {
+        crc ^= p[i];
+        for (int k = 0; k < 8; k++) crc = (crc & 1u) ? (crc >> 1) ^ 0x8408u : crc >> 1;
+    }
+    return crc & 0xffffu;
+}
+
+static void ccc_message(Ccc &c, uint8_t *buf, unsigned len)     // process_fixed_ccc, frame.c:393-431
+{
+    unsigned n = 0;                                            // unescape_hdlc, frame.c:328-340
+    for (unsigned i = 0; i < len; i++) { if (buf[i] == 0x7D) { ++i; buf[n++] = (uint8_t)(buf[i] | 0x20); } else buf[n++] = buf[i]; }
+    if (n == 0 || c.fixed_ready) return;
+    if (fcs16(buf, n) != 0xf0b8u) return;
+    for (unsigned i = 0; i < 4; i++) {
+        c.length[i] = 0;
+        if (5 + i * 4 <= n) {
+            const unsigned mode = buf[1 + i * 4] | (buf[2 + i * 4] << 8), length = buf[3 + i * 4] | (buf[4 + i * 4] << 8);
+            if (mode == 0) c.length[i] = length;
+        }
+    }
+    c.fixed_ready = 1;
+}
+
+extern "C" unsigned nrsc5hip_hdc_fixed_audio_end(nrsc5hip_hdc *h, int stream, int lc, const uint8_t *b, unsigned nbytes)
+{
+    if (!h || !b || nbytes == 0 || stream < 0 || stream >= (int)h->streams.size() || lc < 0 || lc > 2) return nbytes;
+    Ccc &c = h->streams[stream].ccc[lc];
+    unsigned p = nbytes - 1;                                   // process_fixed_data, frame.c:458-514
+    if (c.sync_count < 2) {
+        const uint8_t byte = b[p];
+        const unsigned width = byte == 0 ? 1u : ((byte >> 4) == (byte & 0xf)) ? (byte & 0xfu) * 2u : 0u;      // sync_width, frame.c:448-456
+        if (width > 0 && c.sync_width == width) c.sync_count++; else c.sync_count = 0;
+        c.sync_width = width;
+        if (c.sync_count < 2) return p;
+    }
+    p -= c.sync_width;
+    for (unsigned i = 0; i < c.sync_width; i++) {              // parse_hdlc into ccc_buf, frame.c:369-391
+        const uint8_t byte = b[p + i];
+        if (byte == 0x7E) { if (c.idx >= 0) ccc_message(c, c.buf, (unsigned)c.idx); c.idx = 0; }
+        else if (c.idx >= 0) { if (c.idx == (int)sizeof(c.buf)) { c.idx = -1; continue; } c.buf[c.idx++] = byte; }
+    }
+    if (!c.fixed_ready) return p;
+    for (int i = 3; i >= 0; i--) p -= c.length[i];
+    return p;
+}
+
+extern "C" int nrsc5hip_l2_apply_audio_end(nrsc5hip_l2_frame *ix, unsigned audio_end)
+{
+    if (!ix) return NRSC5HIP_EINVAL;
+    for (unsigned k = 0; k < ix->n_pdu && k < NRSC5HIP_L2_MAX_PDUS; k++) {
+        const nrsc5hip_l2_pdu &p = ix->pdu[k];
+        bool cut = !(p.start < audio_end - 96u);                                  // while (offset < audio_end - RS_CODEWORD_LEN), unsigned
+        if (!cut && p.start + p.la_location >= audio_end) cut = true;             // frame.c:548
+        for (unsigned j = 0; !cut && j < p.nop && j < NRSC5HIP_L2_MAX_PACKETS; j++) if (p.loc[j] >= audio_end) cut = true;   // frame.c:554
+        if (cut) { ix->n_pdu = k; ix->status = NRSC5HIP_L2_AUDIO_END; ix->end_offset = p.start; if (k == 0 && p.start == 0) ix->lost_sync = 0; return (int)k; }
+        if (p.hef && !p.skipped && p.psd_off > audio_end) return -1;              // parse_hef(.., audio_end - offset) would have been cut short
+    }
+    // a header failure recorded beyond the audio region never happened for the reference
+    if (ix->status == NRSC5HIP_L2_HEADER_RS && !(ix->end_offset < audio_end - 96u)) { ix->status = NRSC5HIP_L2_AUDIO_END; ix->lost_sync = 0; }
+    return (int)ix->n_pdu;
+}
+
+extern "C" int nrsc5hip_hdc_frame_reset(nrsc5hip_hdc *h, int stream)
+{
+    if (!h || stream < 0 || stream >= (int)h->streams.size()) return NRSC5HIP_EINVAL;
+    for (Ccc &c : h->streams[stream].ccc) c.reset();
+    return NRSC5HIP_OK;
+}
+
+extern "C" int nrsc5hip_hdc_push_frame(nrsc5hip_hdc *h, int stream, int lc, const nrsc5hip_l2_frame *ix_in, const uint8_t *pdu_bytes)
+{
+    if (!h || !ix_in || !pdu_bytes || stream < 0 || stream >= (int)h->streams.size() || lc < 0 || lc > 2) return NRSC5HIP_EINVAL;
     Stream &st = h->streams[stream];
+    const nrsc5hip_l2_frame *ix = ix_in;
+    std::unique_ptr<nrsc5hip_l2_frame> cut;
+    if (NRSC5HIP_L2_PCI_HAS_FIXED(ix_in->pci)) {
+        const unsigned audio_end = nrsc5hip_hdc_fixed_audio_end(h, stream, lc, pdu_bytes, ix_in->nbytes);
+        cut.reset(new nrsc5hip_l2_frame(*ix_in));
+        if (nrsc5hip_l2_apply_audio_end(cut.get(), audio_end) < 0) return NRSC5HIP_EINVAL;
+        ix = cut.get();
+    }
     for (unsigned k = 0; k < ix->n_pdu && k < NRSC5HIP_L2_MAX_PDUS; k++) {
         const nrsc5hip_l2_pdu &p = ix->pdu[k];
         if (p.skipped || p.prog_num >= MAX_PROGRAMS || p.stream_id >= MAX_STREAMS) continue;     // frame.c:559-564

@@ -9,8 +9,11 @@
 //   crc8 of every packet                                        frame.c:130-136,613-640 -> one work-item per packet
 // Output: nrsc5hip_l2_frame (what frame_process hands to output_align / parse_hdlc / output_push, as offsets) and,
 // optionally, the PDU bytes with the RS-corrected headers those offsets refer to.
-// Not modelled (reported, not guessed): frames whose PCI announces fixed data (audio_end then depends on the CCC state
-// machine of process_fixed_data, frame.c:433-514) -> NRSC5HIP_L2_FIXED_DATA, the host walks those.
+// Frames whose PCI announces fixed-data sub-channels next to audio (PCI_AUDIO_FIXED / _OPP): audio_end then depends on the
+// CCC state machine of process_fixed_data (frame.c:458-514), which is host state.  Every condition of the walk that
+// involves audio_end only gets stricter as audio_end shrinks, and process_fixed_data never returns more than length - 1, so
+// the device walks with audio_end = nbytes - 1 (a superset of what the reference will accept) and the host cuts the index
+// back with the true value (nrsc5hip_l2_apply_audio_end; nrsc5hip_hdc_push_frame does both).
 #include <hip/hip_runtime.h>
 #include "nrsc5hip.h"
 #include "kernels.h"
@@ -123,7 +126,7 @@ __device__ inline void l2_index_frame(L2IndexSmem &sm, const uint32_t *w, unsign
     __syncthreads();                                        // also orders the zero fill of `out` before thread 0's stores
     __threadfence_block();
 
-    unsigned offset = 0, status = NRSC5HIP_L2_END, n_pdu = 0, lost = 0;
+    unsigned offset = 0, status = NRSC5HIP_L2_END, n_pdu = 0, lost = 0, audio_end = nbytes;   // audio_end: work-item 0's
     bool walking = known;
     if (tid == 0 && known) {
         unsigned pci = 0;
@@ -131,9 +134,8 @@ __device__ inline void l2_index_frame(L2IndexSmem &sm, const uint32_t *w, unsign
         out.pci = pci; out.nbytes = nbytes;
         const unsigned p = pci & 0xFFFFFCu;
         if (p == (0x3634CEu & 0xFFFFFCu)) { status = NRSC5HIP_L2_NO_AUDIO; walking = false; }
-        else if (p == (0xE3634Cu & 0xFFFFFCu) || p == (0x8D8D33u & 0xFFFFFCu)) { status = NRSC5HIP_L2_FIXED_DATA; walking = false; }
+        else if (p == (0xE3634Cu & 0xFFFFFCu) || p == (0x8D8D33u & 0xFFFFFCu)) audio_end = nbytes - 1u;   // has_fixed: see the header
     }
-    const unsigned audio_end = nbytes;
     const bool is_p1 = (len == 146176u || len == 3750u);   // length == MAX_PDU_LEN || P1_PDU_LEN_AM, frame.c:537
 
     for (;;) {

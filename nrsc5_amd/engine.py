@@ -60,7 +60,7 @@ class L2Job(ctypes.Structure):
 
 
 L2_FM_P1, L2_FM_PX, L2_AM = 0, 1, 2
-L2_STATUS = ("end", "no_audio", "fixed_data", "header_rs", "bad_locators", "too_many_pdus", "hef_overrun", "bad_stream", "bad_length")
+L2_STATUS = ("end", "no_audio", "fixed_data", "header_rs", "bad_locators", "too_many_pdus", "hef_overrun", "bad_stream", "bad_length", "audio_end")
 
 
 def l2_frame_to_dict(fr: L2Frame) -> dict:
@@ -131,7 +131,11 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.nrsc5hip_hdc_destroy.argtypes = [vp]
     lib.nrsc5hip_hdc_destroy.restype = None
     lib.nrsc5hip_hdc_reset.argtypes = [vp, ci]
-    lib.nrsc5hip_hdc_push_frame.argtypes = [vp, ci, vp, vp]
+    lib.nrsc5hip_hdc_push_frame.argtypes = [vp, ci, ci, vp, vp]
+    lib.nrsc5hip_hdc_fixed_audio_end.argtypes = [vp, ci, ci, vp, ctypes.c_uint]
+    lib.nrsc5hip_hdc_fixed_audio_end.restype = ctypes.c_uint
+    lib.nrsc5hip_l2_apply_audio_end.argtypes = [vp, ctypes.c_uint]
+    lib.nrsc5hip_hdc_frame_reset.argtypes = [vp, ci]
     lib.nrsc5hip_hdc_advance.argtypes = [vp, ci, ci, HDC_CB, vp]
     lib.nrsc5hip_hdc_adts.argtypes = [vp, ctypes.c_uint, vp]
     lib.nrsc5hip_hdc_adts.restype = ctypes.c_size_t
@@ -151,7 +155,7 @@ EXPORTED_SYMBOLS = [
     "nrsc5hip_batch_fetch_px", "nrsc5hip_debug_fetch_px", "nrsc5hip_stage_viterbi_k9_bench",
     "nrsc5hip_l2_index", "nrsc5hip_stage_l2_index", "nrsc5hip_l2_frame_get", "nrsc5hip_batch_fetch_l2",
     "nrsc5hip_hdc_create", "nrsc5hip_hdc_destroy", "nrsc5hip_hdc_reset", "nrsc5hip_hdc_push_frame", "nrsc5hip_hdc_advance",
-    "nrsc5hip_hdc_adts", "nrsc5hip_hdc_host_bytes"]
+    "nrsc5hip_hdc_adts", "nrsc5hip_hdc_host_bytes", "nrsc5hip_hdc_fixed_audio_end", "nrsc5hip_l2_apply_audio_end", "nrsc5hip_hdc_frame_reset"]
 
 
 def unpack_bits(words: np.ndarray, nbits: int) -> np.ndarray:
@@ -439,10 +443,17 @@ class HdcConsumer:
     def _on_packet(self, opaque, stream, program, data, count, flags):
         self.events.append((int(stream), int(program), int(count), int(flags), bytes(ctypes.string_at(data, count)) if count else b""))
 
-    def push_frame(self, stream: int, frame: L2Frame, pdu_bytes: np.ndarray):
+    def push_frame(self, stream: int, frame: L2Frame, pdu_bytes: np.ndarray, lc: int = 0):
         b = np.ascontiguousarray(pdu_bytes, dtype=np.uint8)
-        if self.lib.nrsc5hip_hdc_push_frame(self._h, stream, ctypes.byref(frame), b.ctypes.data) != 0:
+        if self.lib.nrsc5hip_hdc_push_frame(self._h, stream, lc, ctypes.byref(frame), b.ctypes.data) != 0:
             raise Nrsc5HipError("nrsc5hip_hdc_push_frame failed")
+
+    def fixed_audio_end(self, stream: int, lc: int, pdu_bytes: np.ndarray) -> int:
+        b = np.ascontiguousarray(pdu_bytes, dtype=np.uint8)
+        return int(self.lib.nrsc5hip_hdc_fixed_audio_end(self._h, stream, lc, b.ctypes.data, b.size))
+
+    def frame_reset(self, stream: int):
+        self.lib.nrsc5hip_hdc_frame_reset(self._h, stream)
 
     def advance(self, stream: int, mode: int = MODE_FM) -> int:
         return self.lib.nrsc5hip_hdc_advance(self._h, stream, mode, self._cb, None)
@@ -485,8 +496,12 @@ def feed_hdc(engine: Engine, consumer: HdcConsumer, stream: int, recs: np.ndarra
     for r, (first, n) in zip(recs, per_rec):
         if int(r["flags"]) & REC_PROCESSED:
             consumer.advance(t, mode)
+        if int(r["flags"]) & REC_TO_FINE:
+            consumer.frame_reset(t)                              # sync.c:405-409
         for k in range(first, first + n):
-            consumer.push_frame(t, frames[k], by[k, :frames[k].nbytes])
+            kind, which = jobs_all[k][2], jobs_all[k][3]
+            lc = 0 if kind == L2_FM_P1 or (kind == L2_AM and which < 8) else (1 + which if kind == L2_FM_PX else 1)
+            consumer.push_frame(t, frames[k], by[k, :frames[k].nbytes], lc)
 
 
 def l2_jobs_from_records(stream: int, recs: np.ndarray, mode: int = 0):

@@ -282,3 +282,30 @@ def psd_sequence(seed: int = 0, nbits: int = 146176, n_frames: int = 6):
                                  psd=psd, latency=fi // 2 % 8, blend=fi // 3 % 4, common_delay=fi // 2 % 64))
         frames.append(frame_from_bytes(b"".join(pdus), nbits))
     return frames
+
+
+def fixed_data_session(seed: int = 0, nbits: int = 146176, n_frames: int = 7, sub_len: int = 4000, sync_byte: int = 0x88):
+    """Frames that carry fixed-data sub-channels next to audio (PCI_AUDIO_FIXED / _OPP, frame.c:138-151,458-514): the last
+    byte is the sync byte (0x88: 16 CCC bytes per frame in front of it), the CCC bytes carry an HDLC message announcing one
+    sub-channel of `sub_len` bytes, and five audio PDUs fill the frame -- so that audio_end is length - 1 for the first two
+    frames (sync not yet confirmed), length - 17 while the CCC message is incomplete, and length - 17 - sub_len after it:
+    the last PDUs then lie in the fixed-data region and the reference's walk stops in front of them."""
+    rng = np.random.default_rng(7000 + seed)
+    n = pdu_bytes_of(nbits)
+    width = (sync_byte & 0xF) * 2 if sync_byte else 1
+    msg = hdlc_frame(bytes([0x00]) + (0).to_bytes(2, "little") + sub_len.to_bytes(2, "little"))
+    # the CCC byte stream, `width` bytes of it per frame; the first two frames only establish the sync byte (their CCC bytes are
+    # not parsed), the message then straddles frames 3 and 4
+    ccc = (b"\x7e" * (3 * width - 4) + msg + b"\x7e" * 128)
+    frames, pos = [], 0
+    for fi in range(n_frames):
+        room = n // 5
+        pdus = [make_pdu(rng, room, nop=6 + (fi + k) % 4, seq=(5 * fi + 11 * k) % 64, pdu_seq=(fi + k) % 8, codec_mode=0 if k % 2 == 0 else 13,
+                         hef=hef_bytes(prog_num=k % 3) if k else b"") for k in range(5)]
+        body = bytearray(b"".join(pdus))
+        body += bytes(n - len(body))
+        body[n - 1] = sync_byte
+        body[n - 1 - width:n - 1] = ccc[pos:pos + width]
+        pos += width
+        frames.append(frame_from_bytes(bytes(body), nbits, pci=PCI_AUDIO_FIXED if fi % 2 == 0 else PCI_AUDIO_FIXED_OPP))
+    return frames

@@ -210,10 +210,13 @@ int orc_l2_index(const uint8_t *bits, unsigned len, orc_l2_frame *out, uint8_t *
         else { val |= bit << (7 - j); if (++j == 8) { buf[nbytes++] = (uint8_t)val; val = 0; j = 0; } }
     }
     out->pci = pci; out->nbytes = nbytes;
-    const unsigned p = pci & 0xFFFFFC, audio_end = nbytes;
+    const unsigned p = pci & 0xFFFFFC;
+    /* has_fixed next to audio: process_fixed_data (frame.c:458-514) moves audio_end by host state, never beyond length - 1;
+     * the index is built with that largest value (every audio_end test below only gets stricter below it) and the consumer
+     * cuts it back (orc_l2_apply_audio_end) */
+    const unsigned audio_end = (p == (0xE3634C & 0xFFFFFC) || p == (0x8D8D33 & 0xFFFFFC)) ? nbytes - 1 : nbytes;
     const int is_p1 = (len == 146176 || len == 3750);          /* length == MAX_PDU_LEN || P1_PDU_LEN_AM, frame.c:537 */
     if (p == (0x3634CE & 0xFFFFFC)) { out->status = ORC_L2_NO_AUDIO; return 0; }
-    if (p == (0xE3634C & 0xFFFFFC) || p == (0x8D8D33 & 0xFFFFFC)) { out->status = ORC_L2_FIXED_DATA; return 0; }
     unsigned offset = 0;
     out->status = ORC_L2_END;
     while (offset < audio_end - 96) {                          /* unsigned, as frame.c:525 */

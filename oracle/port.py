@@ -38,7 +38,7 @@ class L2Frame(ctypes.Structure):
                 ("end_offset", ctypes.c_uint32), ("lost_sync", ctypes.c_uint32), ("pdu", L2Pdu * 16)]
 
 
-L2_STATUS = ("end", "no_audio", "fixed_data", "header_rs", "bad_locators", "too_many_pdus", "hef_overrun", "bad_stream")
+L2_STATUS = ("end", "no_audio", "fixed_data", "header_rs", "bad_locators", "too_many_pdus", "hef_overrun", "bad_stream", "bad_length", "audio_end")
 
 
 def l2_frame_to_dict(fr) -> dict:

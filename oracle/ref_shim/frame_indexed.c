@@ -6,11 +6,38 @@
 #include "frame.c"                        /* -I$(REF)/src */
 #include "../../include/nrsc5hip.h"
 
-/* same effects as frame_push + frame_process (frame.c:516-714) for a frame whose walk the device already did */
-void frame_push_indexed(frame_t *st, const nrsc5hip_l2_frame *ix, const uint8_t *pdu_bytes, logical_channel_t lc)
+/* the cut libnrsc5hip exports as nrsc5hip_l2_apply_audio_end (nrsc5_amd/csrc/hdc_consumer.hip), restated here because this
+ * translation unit is linked into the reference-only checker: an index built with audio_end = nbytes - 1 taken back to the
+ * audio_end process_fixed_data returned (the loop / locator conditions of frame.c:525,547-556) */
+static int apply_audio_end(nrsc5hip_l2_frame *ix, unsigned int audio_end)
 {
+    for (unsigned int k = 0; k < ix->n_pdu; k++)
+    {
+        const nrsc5hip_l2_pdu *p = &ix->pdu[k];
+        int cut = !(p->start < audio_end - RS_CODEWORD_LEN) || p->start + p->la_location >= audio_end;
+        for (unsigned int j = 0; !cut && j < p->nop; j++) if (p->loc[j] >= audio_end) cut = 1;
+        if (cut) { ix->n_pdu = k; if (k == 0 && p->start == 0) ix->lost_sync = 0; return (int)k; }
+        if (p->hef && !p->skipped && p->psd_off > audio_end) return -1;
+    }
+    if (ix->status == NRSC5HIP_L2_HEADER_RS && !(ix->end_offset < audio_end - RS_CODEWORD_LEN)) ix->lost_sync = 0;
+    return (int)ix->n_pdu;
+}
+
+/* same effects as frame_push + frame_process (frame.c:516-714) for a frame whose walk the device already did */
+void frame_push_indexed(frame_t *st, const nrsc5hip_l2_frame *ix_in, const uint8_t *pdu_bytes, logical_channel_t lc)
+{
+    nrsc5hip_l2_frame cut;
+    const nrsc5hip_l2_frame *ix = ix_in;
     memcpy(st->buffer, pdu_bytes, ix->nbytes);                 /* PCI removed, bit order restored, headers RS-corrected */
     st->pci = ix->pci;
+    if (has_fixed(st))                                         /* frame.c:521-522: the fixed-data state machine stays host code */
+    {
+        const unsigned int audio_end = (unsigned int)process_fixed_data(st, ix->nbytes, lc);
+        if (!has_audio(st)) return;
+        cut = *ix_in;
+        if (apply_audio_end(&cut, audio_end) < 0) { frame_process(st, ix->nbytes, lc); return; }   /* (never seen: HEF into the fixed region) */
+        ix = &cut;
+    }
     if (ix->lost_sync) input_set_sync_state(st->input, SYNC_STATE_NONE);          /* frame.c:537-538 */
     for (unsigned int k = 0; k < ix->n_pdu; k++)
     {

@@ -563,7 +563,7 @@ def check_l2_index_stage(lib, oracle, lengths=None):
             assert np.array_equal(gb, ob), (nbits, name)
             seen.add(port.L2_STATUS[oi["status"]])
     if lengths is None:
-        assert seen == set(port.L2_STATUS), seen
+        assert seen == {"end", "no_audio", "header_rs", "bad_locators", "too_many_pdus", "hef_overrun", "bad_stream"}, seen
         rng = np.random.default_rng(7)                         # randomised structures, batched per frame length
         by_len = {}
         for _ in range(120):
@@ -794,8 +794,8 @@ def check_frame_push_indexed_with_device_index(lib, reflib):
     from tests.test_oracle_l2 import _all_l2_taps
     E = eng.Engine(max_streams=1, lib_path=lib)
     sessions = [synth_l2.psd_sequence(seed=1), synth_l2.psd_sequence(seed=2, nbits=24000, n_frames=4),
-                [b for _, b, safe in synth_l2.test_frames(146176, seed=7) if safe]]
-    skip = {eng.L2_STATUS.index(s) for s in ("fixed_data", "hef_overrun", "bad_stream", "too_many_pdus")}
+                [b for _, b, safe in synth_l2.test_frames(146176, seed=7) if safe], synth_l2.fixed_data_session(seed=2)]
+    skip = {eng.L2_STATUS.index(s) for s in ("hef_overrun", "bad_stream", "too_many_pdus")}
     n_pkt = n_aas = 0
     for frames in sessions:
         structs, by = E.stage_l2_index_raw(np.stack(frames))

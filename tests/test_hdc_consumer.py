@@ -58,7 +58,7 @@ def test_2048_streams_bounded_host_state(emu_lib, oracle):
         for s in range(2048):
             for _ in range(16):
                 delivered += H.lib.nrsc5hip_hdc_advance(H._h, s, eng.MODE_FM, eng.HDC_CB(0), None)   # null callback: count only
-            H.push_frame(s, fr, np.frombuffer(by, dtype=np.uint8))
+            H.push_frame(s, fr, np.frombuffer(by, dtype=np.uint8), 0)
     per_stream = H.host_bytes() / 2048
     rss_growth_mb = (resource.getrusage(resource.RUSAGE_SELF).ru_maxrss - rss0) / 1024
     assert delivered >= 2048 * 32                                    # packets flowed

@@ -19,20 +19,20 @@ def test_l2_index_matches_reference_frame_process(oracle, reflib, nbits):
     for name, bits, safe in cases:
         idx, by = oracle.l2_index(bits)
         statuses.add(port.L2_STATUS[idx["status"]])
-        if not safe or port.L2_STATUS[idx["status"]] == "fixed_data":
-            continue                      # reference undefined / fixed-data walk not indexed (status says so)
+        if not safe:
+            continue                      # reference undefined (its parse_hdlc length wraps)
         log = reflib.l2_frames([bits])[0]
         assert expected_taps(idx, by) == reference_taps(log), (nbits, name)
         if idx["n_pdu"]:
             assert any(k == "l2pkt" for k, _ in log) or all(d["nop"] == 0 or d["skipped"] for d in idx["pdus"])
-    assert {"end", "no_audio", "fixed_data", "header_rs", "bad_locators", "hef_overrun", "bad_stream"} <= statuses
+    assert {"end", "no_audio", "header_rs", "bad_locators", "hef_overrun", "bad_stream"} <= statuses
+    assert "fixed_data" not in statuses   # frames with fixed-data sub-channels are indexed like the others since round 2
 
 
 def test_l2_index_sequence_through_one_session(oracle, reflib):
     """Frames pushed back to back through ONE reference session (services / elastic buffer state evolving) still yield,
     frame by frame, exactly the calls the stateless index describes."""
     frames = [b for _, b, safe in synth_l2.test_frames(146176, seed=3) if safe]
-    frames = [b for b in frames if port.L2_STATUS[oracle.l2_index(b)[0]["status"]] != "fixed_data"]
     logs = reflib.l2_frames(frames)
     for bits, log in zip(frames, logs):
         idx, by = oracle.l2_index(bits)
@@ -126,7 +126,7 @@ def test_frame_push_indexed_equals_frame_push_inside_the_reference(oracle, refli
         keep, items = [], []
         for bits in frames:
             fr, by = oracle.l2_index_struct(bits)
-            if port.L2_STATUS[fr.status] in ("fixed_data", "hef_overrun", "bad_stream", "too_many_pdus"):
+            if port.L2_STATUS[fr.status] in ("hef_overrun", "bad_stream", "too_many_pdus"):
                 continue                  # the host keeps walking those itself
             keep.append(bits)
             items.append((fr, by))
@@ -137,3 +137,35 @@ def test_frame_push_indexed_equals_frame_push_inside_the_reference(oracle, refli
             assert ta == tb, (name, k, [x[:6] for x in ta[:4]], [x[:6] for x in tb[:4]])
             n_aas += sum(1 for t in ta if t[0] == "l2aas"); n_svc += sum(1 for t in ta if t[0] == "l2svc"); n_pkt += sum(1 for t in ta if t[0] == "l2pkt")
     assert n_aas >= 8 and n_svc >= 6 and n_pkt >= 500, (n_aas, n_svc, n_pkt)
+
+
+def test_fixed_data_frames_index_cut_back_equals_reference(oracle, reflib, emu_lib):
+    """Frames with fixed-data sub-channels (has_fixed, frame.c:458-514): the index is built with audio_end = nbytes - 1 and the
+    consumer cuts it back with process_fixed_data's value.  One reference session over frames whose audio_end moves from
+    length - 1 to length - 17 to length - 4017: (1) the host restatement of the CCC state machine (nrsc5hip_hdc_fixed_audio_end)
+    + nrsc5hip_l2_apply_audio_end imply exactly the reference's output_align / output_push calls, frame by frame;
+    (2) frame_push_indexed inside the reference (which runs the reference's own process_fixed_data) does what frame_push does."""
+    import ctypes
+    from nrsc5_amd import engine as eng
+    frames = synth_l2.fixed_data_session(seed=1)
+    direct = reflib.l2_frames(frames)
+    lib = eng.load_library(emu_lib)                              # host-only functions of the product library (no device needed)
+    H = eng.HdcConsumer(1, lib=lib)
+    ends, kept = [], []
+    for bits, log in zip(frames, direct):
+        fr, by = oracle.l2_index_struct(bits)
+        assert fr.status != port.L2_STATUS.index("fixed_data") and fr.n_pdu == 5          # walked with the largest audio_end
+        audio_end = H.fixed_audio_end(0, 0, np.frombuffer(by, dtype=np.uint8)[:fr.nbytes])
+        cut = eng.L2Frame.from_buffer_copy(fr)
+        n = lib.nrsc5hip_l2_apply_audio_end(ctypes.byref(cut), audio_end)
+        assert n >= 0
+        ends.append(audio_end); kept.append(n)
+        assert expected_taps(eng.l2_frame_to_dict(cut), np.frombuffer(by, dtype=np.uint8)) == reference_taps(log)
+    nb = (146176 - 24) // 8
+    assert ends[0] == ends[1] == nb - 1 and nb - 17 in ends and ends[-1] == nb - 17 - 4000, ends
+    assert kept[0] == 5 and kept[-1] < 5, kept                                              # the cut really removes PDUs
+    H.close()
+    items = [oracle.l2_index_struct(b) for b in frames]
+    indexed = reflib.l2_frames_indexed(items)
+    for a, b in zip(direct, indexed):
+        assert _all_l2_taps(a) == _all_l2_taps(b)
