@@ -324,8 +324,12 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         }
         for (int l = 0; l < e->nlanes && !rc; l++) {
             nrsc5hip_engine::Lane &ln = e->lanes[l];
-            if (hipStreamCreate(&ln.main) != hipSuccess) rc = NRSC5HIP_EHIP;
-            for (int k = 0; k < NAUX && !rc; k++) if (hipStreamCreate(&ln.aux[k]) != hipSuccess) rc = NRSC5HIP_EHIP;
+            // the block-step chain is the critical path: its queue is served first when workgroup slots free up; the decode
+            // streams (long one-wave-per-frame trellis passes) take what is left (-0.5 ms per pass, profiles/r02_ab_prio_demod.txt)
+            int prio_lo = 0, prio_hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // numerically lower = more urgent
+            if (hipStreamCreateWithPriority(&ln.main, hipStreamDefault, prio_hi) != hipSuccess) rc = NRSC5HIP_EHIP;
+            for (int k = 0; k < NAUX && !rc; k++) if (hipStreamCreateWithPriority(&ln.aux[k], hipStreamDefault, prio_lo) != hipSuccess) rc = NRSC5HIP_EHIP;
             for (int k = 0; k < NWIN && !rc; k++) {
                 if (hipEventCreate(&ln.ev_window[k]) != hipSuccess || hipEventCreate(&ln.ev_decoded[k]) != hipSuccess) rc = NRSC5HIP_EHIP;
                 ln.decoded_pending[k] = false;

@@ -58,6 +58,88 @@ __device__ inline c16 hb_sample_q15(const uint8_t *raw, long long a, const HbTap
     return r;
 }
 
+// ---- the symbol kernel's form: one fused multiply-add per product ---------------------------------------------------
+// With the float32 rounding mode set to round-toward-minus-infinity, acc' = fma(s, t_i / 512, acc) IS acc + floor(s t_i / 512)
+// as long as acc is an integer in [2^23, 2^24) (ulp 1): the product is exact inside the fma and the single rounding drops its
+// fraction downwards.  The accumulator therefore starts at HB_BIAS = 1.5 * 2^23 (+ the centre sample) and HB_BIAS is taken
+// off at the end; |y| < 2^15 keeps it in range.  Both components of a complex sample ride one v_pk_fma_f32.
+// Everything else the decimator does between hb_round_down() and hb_round_nearest() is exact in any rounding mode (byte ->
+// float conversions, sums of small integers, the bias subtraction), and the Q15 -> float division that is NOT is left to the
+// reader of the tile (k_mixfft's sample()), so the compiler has nothing rounding-sensitive to move into the region.
+constexpr float HB_BIAS = 12582912.0f;
+
+#ifdef HIPEMU
+struct hb_v2 { float x, y; };
+__device__ __forceinline__ hb_v2 hb_make(float x, float y) { hb_v2 r; r.x = x; r.y = y; return r; }
+__device__ __forceinline__ hb_v2 hb_add(hb_v2 a, hb_v2 b) { return hb_make(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ void hb_round_down() {}
+__device__ __forceinline__ void hb_round_nearest() {}
+__device__ __forceinline__ float hb_byte(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }
+// two outputs' four products each (interleaved on the device so that no fma waits for its predecessor)
+__device__ __forceinline__ void hb_fma4x2(hb_v2 &a, hb_v2 &b, const hb_v2 *pa, const hb_v2 *pb, const hb_v2 *t)
+{
+    for (int i = 0; i < 4; i++) {
+        a.x += floorf(pa[i].x * t[i].x); a.y += floorf(pa[i].y * t[i].y);
+        b.x += floorf(pb[i].x * t[i].x); b.y += floorf(pb[i].y * t[i].y);
+    }
+}
+__device__ __forceinline__ void hb_fma4(hb_v2 &a, const hb_v2 *pa, const hb_v2 *t)
+{
+    for (int i = 0; i < 4; i++) { a.x += floorf(pa[i].x * t[i].x); a.y += floorf(pa[i].y * t[i].y); }
+}
+#else
+typedef float hb_v2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ hb_v2 hb_make(float x, float y) { hb_v2 r; r.x = x; r.y = y; return r; }
+__device__ __forceinline__ hb_v2 hb_add(hb_v2 a, hb_v2 b) { return a + b; }
+// MODE[1:0] = single-precision rounding: 0 nearest-even, 2 toward -inf.  The asm statements are volatile (ordered among
+// themselves) and the sched_barrier keeps the machine scheduler from moving anything else across the switch.
+__device__ __forceinline__ void hb_round_down()
+{
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 2\n\ts_nop 1" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void hb_round_nearest()
+{
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 0\n\ts_nop 1" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ float hb_byte(uint32_t w, int k)
+{
+    float f;
+    switch (k) {
+    case 0: asm("v_cvt_f32_ubyte0_e32 %0, %1" : "=v"(f) : "v"(w)); break;
+    case 1: asm("v_cvt_f32_ubyte1_e32 %0, %1" : "=v"(f) : "v"(w)); break;
+    case 2: asm("v_cvt_f32_ubyte2_e32 %0, %1" : "=v"(f) : "v"(w)); break;
+    default: asm("v_cvt_f32_ubyte3_e32 %0, %1" : "=v"(f) : "v"(w)); break;
+    }
+    return f;
+}
+__device__ __forceinline__ void hb_fma4x2(hb_v2 &a, hb_v2 &b, const hb_v2 *pa, const hb_v2 *pb, const hb_v2 *t)
+{
+    asm volatile("v_pk_fma_f32 %0, %2, %10, %0\n\t"
+                 "v_pk_fma_f32 %1, %6, %10, %1\n\t"
+                 "v_pk_fma_f32 %0, %3, %11, %0\n\t"
+                 "v_pk_fma_f32 %1, %7, %11, %1\n\t"
+                 "v_pk_fma_f32 %0, %4, %12, %0\n\t"
+                 "v_pk_fma_f32 %1, %8, %12, %1\n\t"
+                 "v_pk_fma_f32 %0, %5, %13, %0\n\t"
+                 "v_pk_fma_f32 %1, %9, %13, %1"
+                 : "+v"(a), "+v"(b)
+                 : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pb[0]), "v"(pb[1]), "v"(pb[2]), "v"(pb[3]),
+                   "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]));
+}
+__device__ __forceinline__ void hb_fma4(hb_v2 &a, const hb_v2 *pa, const hb_v2 *t)
+{
+    asm volatile("v_pk_fma_f32 %0, %1, %5, %0\n\t"
+                 "v_pk_fma_f32 %0, %2, %6, %0\n\t"
+                 "v_pk_fma_f32 %0, %3, %7, %0\n\t"
+                 "v_pk_fma_f32 %0, %4, %8, %0"
+                 : "+v"(a)
+                 : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]));
+}
+#endif
+
 // x / 32767.0f, correctly rounded, without the divider: q0 = x r, one Newton correction through the exact residual
 // (equal to the IEEE quotient for every int16 x: tests/test_halfband_float.py).  cq15_to_cf / _conj, defines.h:106-111.
 __device__ __forceinline__ float q15_to_float(float x)

@@ -122,25 +122,74 @@ __device__ inline void fft2048_wg(float2 *x, float2 *lds, const float2 *tw)
 // contiguous outputs 17 t .. 17 t + 16 from 24 consecutive dwords (each raw sample is unpacked once and feeds up to eight
 // outputs), converts them as cq15_to_cf_conj does and parks them in the FFT's LDS tile; the callers then pick their
 // strided 17 samples from there.
+//
+// Even raw samples E[k] (dword a0 + 17 t - 7 + k, low half) pair up as (E[i + j], E[i + 7 - j]) for output i: one index of
+// every pair is even and one odd, so the -127 offsets of both (x' = byte - 127) are applied as -254 to the even-indexed E
+// only; the centre sample's -127 * 64 goes into the accumulator's start value.  The tile receives the Q15 INTEGERS
+// (imaginary part negated: the FM receiver's spectrum flip); sample() below divides by 32767 on the way out.
 __device__ inline void decimate_symbol_raw(const uint8_t *raw, long long a0, float2 *tile, const HbTaps &taps)
 {
     const int m0 = 17 * (int)threadIdx.x;
     const int nout = min(17, SYM_N - m0);                      // 17 for work-items 0..126, 1 for the last
     const uint32_t *rw = (const uint32_t *)raw;
-    float2 E[24], O[17];
+    const long long d0 = a0 + m0 - 7;
+    uint32_t W[24];
+    if (a0 >= 7) {                                             // block-uniform: all but a stream's very first symbol
+#ifdef HIPEMU
+        struct u32x4 { uint32_t x, y, z, w; };
+        typedef u32x4 u32x4_dw;
+        const uint32_t *gw = rw;
+#else
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef u32x4 u32x4_dw __attribute__((aligned(4)));
+        const __attribute__((address_space(1))) uint32_t *gw = (const __attribute__((address_space(1))) uint32_t *)rw;   // captures live in HBM: global_load, not flat
+#endif
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            u32x4 v = {0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu};
+            if (4 * k < nout + 7) v = *(const u32x4_dw *)(gw + d0 + 4 * k);       // the last work-item stops at the symbol's end
+            W[4 * k] = v.x; W[4 * k + 1] = v.y; W[4 * k + 2] = v.z; W[4 * k + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 24; k++) W[k] = (k < nout + 7) ? hb_raw_dword(rw, d0 + k) : 0x7f7f7f7fu;
+    }
+    const hb_v2 T[4] = {hb_make(taps.t0, taps.t0), hb_make(taps.t1, taps.t1), hb_make(taps.t2, taps.t2), hb_make(taps.t3, taps.t3)};
+    const hb_v2 off = hb_make(-254.0f, -254.0f);
+    hb_v2 E[24];
 #pragma unroll
     for (int k = 0; k < 24; k++) {
-        const uint32_t w = (k < nout + 7) ? hb_raw_dword(rw, a0 + m0 - 7 + k) : 0x7f7f7f7fu;
-        E[k] = hb_even(w);
-        if (k >= 3 && k < 20) O[k - 3] = hb_odd(w);
+        E[k] = hb_make(hb_byte(W[k], 0), hb_byte(W[k], 1));
+        if (!(k & 1)) E[k] = hb_add(E[k], off);
     }
+    auto start = [&](int i) -> hb_v2 {                          // HB_BIAS + 64 (o - 127), o = raw sample 2(m0 + i) - 7: exact
+        const float c = HB_BIAS - 127.0f * 64.0f;
+        return hb_make(__builtin_fmaf(hb_byte(W[i + 3], 2), 64.0f, c), __builtin_fmaf(hb_byte(W[i + 3], 3), 64.0f, c));
+    };
+    auto pairs = [&](int i, hb_v2 *p) {
 #pragma unroll
-    for (int i = 0; i < 17; i++) {
-        if (i < nout) {
-            const float2 y = hb_output(E + i, O[i], taps);
-            tile[m0 + i] = make_float2(q15_to_float(y.x), -q15_to_float(y.y));      // conj: the FM receiver's spectrum flip
-        }
+        for (int j = 0; j < 4; j++) p[j] = hb_add(E[i + j], E[i + 7 - j]);
+    };
+    auto park = [&](int i, hb_v2 acc) {
+        tile[m0 + i] = make_float2(acc.x - HB_BIAS, HB_BIAS - acc.y);      // the last work-item's spare outputs land in the tile's unused tail
+    };
+    hb_round_down();
+#pragma unroll
+    for (int i = 0; i < 16; i += 2) {
+        hb_v2 pa[4], pb[4];
+        pairs(i, pa); pairs(i + 1, pb);
+        hb_v2 a = start(i), b = start(i + 1);
+        hb_fma4x2(a, b, pa, pb, T);
+        park(i, a); park(i + 1, b);
     }
+    {
+        hb_v2 pa[4];
+        pairs(16, pa);
+        hb_v2 a = start(16);
+        hb_fma4(a, pa, T);
+        park(16, a);
+    }
+    hb_round_nearest();
 }
 
 __global__ __launch_bounds__(128) void k_mixfft(DevTables tb, DevBuffers db, const int *ids)
@@ -150,7 +199,7 @@ __global__ __launch_bounds__(128) void k_mixfft(DevTables tb, DevBuffers db, con
     const StreamState &st = db.state[s];
     if (!st.active) return;                                    // block-uniform
     __shared__ float2 lds[8 * PITCH_A];
-    static_assert(8 * PITCH_A >= SYM_N, "a symbol's decimated samples fit in the FFT tile");
+    static_assert(8 * PITCH_A >= 17 * 128 && 17 * 127 < SYM_N, "17 decimated samples per work-item fit in the FFT tile");
     const int sym = blockIdx.x, tid = threadIdx.x;
     const long long a0 = (st.rd - st.base) + sym * SYM_N + st.samperr_cur;     // first sample of the symbol in the decimated stream
     const double dth = st.dtheta;
@@ -173,7 +222,7 @@ __global__ __launch_bounds__(128) void k_mixfft(DevTables tb, DevBuffers db, con
     const c16 *win = db.q15 + (size_t)s * db.q15_cap + a0;     // FIFO path (streaming seam, cs16 input)
 
     auto sample = [&](int j) -> float2 {
-        if (raw) return lds[j];
+        if (raw) { const float2 y = lds[j]; return make_float2(q15_to_float(y.x), q15_to_float(y.y)); }
         const c16 s16 = win[j];
         return make_float2(q15_to_float((float)s16.r), -q15_to_float((float)s16.i));   // cq15_to_cf_conj, defines.h:111
     };

@@ -38,3 +38,31 @@ def test_float_halfband_equals_oracle(oracle):
         acc = acc + np.floor((s * tf[i]).astype(np.float32))
     assert np.array_equal(acc.astype(np.int16), exp)
     assert np.abs(exp.astype(int)).max() < 32768 - 8192                          # the int16 accumulator has room: it never wraps
+
+
+def test_round_down_fma_chain_equals_oracle(oracle):
+    """k_mixfft's form (halfband_raw.h: hb_fma4 under round-toward-minus-infinity): acc <- RD(acc + s * t_i / 512), started at
+    HB_BIAS + 64 (o - 127).  Modelled exactly: the fma's unrounded value is acc + s * T_i / 512 (rational), RD to the float32
+    grid; while acc is an integer in [2^23, 2^24) the grid step is 1, so RD is floor.  Checks the identity on random and
+    full-scale input and that the accumulator never leaves the binade (which is what makes the single rounding a floor)."""
+    rng = np.random.default_rng(12)
+    n = 40000
+    iq = rng.integers(0, 256, size=4 * n, dtype=np.uint8)
+    iq[:8000] = rng.choice(np.array([0, 255], dtype=np.uint8), size=8000)
+    exp, _ = oracle.halfband_fm_cu8(iq)
+    raw = np.concatenate([np.full((14, 2), 127, dtype=np.int64), iq.astype(np.int64).reshape(-1, 2)])   # bytes; history = 127
+    taps = [np.float32(v) for v in (0.6062333583831787, -0.13481467962265015, 0.032919470220804214, -0.00410953676328063)]
+    T = [int(np.int16(t * np.float32(32767.0))) for t in taps][::-1]             # integer Q15 taps, window order
+    BIAS = 12582912                                                               # 1.5 * 2^23
+    m = np.arange(n)
+    acc = BIAS - 127 * 64 + 64 * raw[2 * m + 7]                                   # fma(o, 64, HB_BIAS - 127 * 64): exact
+    lo, hi = acc.min(), acc.max()
+    for i in range(4):
+        # the kernel biases the even-indexed sample of each pair by -254 (= both samples' -127) before the pair sum
+        s = (raw[2 * m + 2 * i] - 254) + raw[2 * m + 14 - 2 * i]
+        acc = acc + np.floor_divide(s * T[i], 512)                                # RD(acc + s T_i / 512) on a grid of step 1
+        lo, hi = min(lo, acc.min()), max(hi, acc.max())
+    assert 2 ** 23 <= lo and hi < 2 ** 24                                         # one binade: ulp 1 throughout
+    assert np.array_equal((acc - BIAS).astype(np.int16), exp)
+    # and the products are exact inside the fma: |s| < 2^9, |T| < 2^15 -> 24 significant bits
+    assert max(abs(t) for t in T) < 2 ** 15

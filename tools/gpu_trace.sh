@@ -3,7 +3,7 @@
 # gpurun --timeout 600 -- 'bash tools/gpu_trace.sh TAG [extra bench args]'
 cd "${GRAFT_REPO_ROOT:-.}"; R=$PWD; export TMPDIR=/tmp; mkdir -p gpurun_out
 TAG=${1:-trace}; shift
-( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_raw -o tr -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-l2-index "$@" ) > gpurun_out/${TAG}.log 2>&1
+( cd /tmp && timeout 400 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_raw -o tr -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-profile --no-l2-index --no-extra-legs "$@" ) > gpurun_out/${TAG}.log 2>&1
 grep "^{" gpurun_out/${TAG}.log | tail -1 | cut -c1-200
 python - "$TAG" <<'PY' | tee gpurun_out/${TAG}_summary.txt
 import csv, glob, sys, collections
