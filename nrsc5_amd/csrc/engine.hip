@@ -324,12 +324,10 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         }
         for (int l = 0; l < e->nlanes && !rc; l++) {
             nrsc5hip_engine::Lane &ln = e->lanes[l];
-            // the block-step chain is the critical path: its queue is served first when workgroup slots free up; the decode
-            // streams (long one-wave-per-frame trellis passes) take what is left (-0.5 ms per pass, profiles/r02_ab_prio_demod.txt)
-            int prio_lo = 0, prio_hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // numerically lower = more urgent
-            if (hipStreamCreateWithPriority(&ln.main, hipStreamDefault, prio_hi) != hipSuccess) rc = NRSC5HIP_EHIP;
-            for (int k = 0; k < NAUX && !rc; k++) if (hipStreamCreateWithPriority(&ln.aux[k], hipStreamDefault, prio_lo) != hipSuccess) rc = NRSC5HIP_EHIP;
+            // (queue priorities -- chain stream high, decode streams low -- were measured: nothing for the batch, +15 % per block for
+            // a lone stream, profiles/r02_ab_prio_demod.txt)
+            if (hipStreamCreate(&ln.main) != hipSuccess) rc = NRSC5HIP_EHIP;
+            for (int k = 0; k < NAUX && !rc; k++) if (hipStreamCreate(&ln.aux[k]) != hipSuccess) rc = NRSC5HIP_EHIP;
             for (int k = 0; k < NWIN && !rc; k++) {
                 if (hipEventCreate(&ln.ev_window[k]) != hipSuccess || hipEventCreate(&ln.ev_decoded[k]) != hipSuccess) rc = NRSC5HIP_EHIP;
                 ln.decoded_pending[k] = false;
@@ -358,6 +356,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         db.acq_win = nullptr;
         if (cfg->batch_zero_copy && (rc = dev_alloc(e, &db.acq_win, S * WIN_N))) break;
         if ((rc = dev_alloc(e, &db.acq_filt, S * WIN_N))) break;
+        if ((rc = dev_alloc(e, &db.acq_list, S + 1))) break;
         if ((rc = dev_alloc(e, &db.acq_sums, S * SYM_N))) break;
         if ((rc = dev_alloc(e, &db.bins, S * NSYM * LIVE_N))) break;
         if ((rc = dev_alloc(e, &db.pm, S * NPM * PM_FRAME))) break;
@@ -369,6 +368,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if ((rc = dev_alloc(e, &db.pids_rec, S * NWIN * 16))) break;
         if (hipMemset(db.pids_rec, 0xff, S * NWIN * 16 * sizeof(int)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
         if ((rc = dev_alloc(e, &db.p1_ring, S * db.p1_slots * P1_WORDS))) break;
+        db.p1_mirror = nullptr;
         if ((rc = dev_alloc(e, &db.records, S * db.rec_cap))) break;
         if ((rc = dev_alloc(e, &db.counters, 4 * MAX_LANES))) break;
         {
@@ -1411,15 +1411,36 @@ extern "C" int nrsc5hip_batch_fetch_view(nrsc5hip_engine *e, int nstreams, const
     const size_t S = e->cfg.max_streams;
     if (!e->rec_host) {
         HIPCHK(hipHostMalloc((void **)&e->rec_host, S * e->db.rec_cap * sizeof(BlockRecord), hipHostMallocDefault));
-        HIPCHK(hipHostMalloc((void **)&e->frames_host, S * e->db.p1_slots * P1_WORDS * sizeof(uint32_t), hipHostMallocDefault));
         HIPCHK(hipHostMalloc((void **)&e->nblocks_host, S * sizeof(int), hipHostMallocDefault));
     }
     HIPCHK(hipStreamSynchronize(e->main));
     HIPCHK(hipMemcpy2DAsync(e->nblocks_host, sizeof(int), (const char *)e->db.state + offsetof(StreamState, nblocks), sizeof(StreamState),
                             sizeof(int), nstreams, hipMemcpyDeviceToHost, e->main));
-    HIPCHK(hipMemcpyAsync(e->rec_host, e->db.records, (size_t)nstreams * e->db.rec_cap * sizeof(BlockRecord), hipMemcpyDeviceToHost, e->main));
-    if (frames)
-        HIPCHK(hipMemcpyAsync(e->frames_host, e->db.p1_ring, (size_t)nstreams * e->db.p1_slots * P1_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, e->main));
+    HIPCHK(hipStreamSynchronize(e->main));
+    int maxn = 0;
+    bool any_am = false;
+    for (int s = 0; s < nstreams; s++) { if (e->nblocks_host[s] > maxn) maxn = e->nblocks_host[s]; any_am |= e->mode_host[s] == MODE_AM; }
+    if (maxn > e->db.rec_cap) maxn = e->db.rec_cap;
+    // records: only the used head of every stream's ring (the view needs unwrapped rings anyway, checked below)
+    if (maxn > 0)
+        HIPCHK(hipMemcpy2DAsync(e->rec_host, (size_t)e->db.rec_cap * sizeof(BlockRecord), e->db.records, (size_t)e->db.rec_cap * sizeof(BlockRecord),
+                                (size_t)maxn * sizeof(BlockRecord), nstreams, hipMemcpyDeviceToHost, e->main));
+    if (frames) {
+        // P1 frames: the first view copies the ring and hands the pinned buffer to the FM traceback as a mirror (DevBuffers::
+        // p1_mirror); from then on every frame reaches the host while the pass is still running and nothing is left to copy here.
+        // AM frames are written by other kernels: a batch with AM streams keeps copying.
+        const size_t nwords = (size_t)e->db.p1_slots * P1_WORDS;
+        if (!e->frames_host) {
+            HIPCHK(hipHostMalloc((void **)&e->frames_host, S * nwords * sizeof(uint32_t), hipHostMallocMapped));
+            HIPCHK(hipMemcpyAsync(e->frames_host, e->db.p1_ring, S * nwords * sizeof(uint32_t), hipMemcpyDeviceToHost, e->main));
+            void *dp = nullptr;
+            HIPCHK(hipHostGetDevicePointer(&dp, e->frames_host, 0));
+            e->db.p1_mirror = (uint32_t *)dp;
+            for (int l = 0; l < e->nlanes; l++) e->lanes[l].db.p1_mirror = (uint32_t *)dp;
+        } else if (any_am) {
+            HIPCHK(hipMemcpyAsync(e->frames_host, e->db.p1_ring, (size_t)nstreams * nwords * sizeof(uint32_t), hipMemcpyDeviceToHost, e->main));
+        }
+    }
     HIPCHK(hipStreamSynchronize(e->main));
     if (e->cfg.p1_async && e->db.am) {
         std::vector<float> ber((size_t)nstreams * e->db.p1_slots);

@@ -26,45 +26,70 @@ __device__ inline const c16 *acq_window(const DevBuffers &db, const StreamState 
 }
 
 // ---- zero-copy batch: decimate the 33-symbol window of an un-synchronised stream out of its cu8 capture ----------
-__global__ __launch_bounds__(256) void k_acq_decimate(DevTables tb, DevBuffers db, const int *ids)
+// ---- which streams of the set need the acquisition kernels this step ----------------------------------------------------
+// Most steps that run them at all do so for a handful of streams (the ones replaying after a lost lock), so the wide kernels
+// walk a compacted list with a fixed small grid instead of dispatching 279 empty workgroups per listed stream.
+constexpr int ACQ_ROWS = 32;                                    // grid.y of the two window-wide kernels; row r serves list entries r, r + 32, ...
+
+__global__ __launch_bounds__(256) void k_acq_list(DevBuffers db, const int *ids, int nstreams)
 {
-    const int s = stream_of(ids, blockIdx.y);
-    const StreamState &st = db.state[s];
-    if (!st.raw || !needs_coarse(st)) return;
+    __shared__ int count;
+    if (threadIdx.x == 0) count = 0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < nstreams; k += 256) {
+        const int s = stream_of(ids, k);
+        if (needs_coarse(db.state[s])) db.acq_list[atomicAdd(&count, 1)] = s;      // order is irrelevant: streams are independent
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) db.acq_list[db.nstreams_alloc] = count;
+}
+
+// ---- zero-copy batch: decimate the 33-symbol window of an un-synchronised stream out of its cu8 capture ----------
+__global__ __launch_bounds__(256) void k_acq_decimate(DevTables tb, DevBuffers db)
+{
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= WIN_N) return;
-    db.acq_win[(size_t)s * WIN_N + t] = hb_sample_q15(st.raw, st.rd + t, hb_taps(tb.hb_q15));
+    const int n = db.acq_list[db.nstreams_alloc];
+    const HbTaps taps = hb_taps(tb.hb_q15);
+    for (int k = blockIdx.y; k < n; k += ACQ_ROWS) {
+        const int s = db.acq_list[k];
+        const StreamState &st = db.state[s];
+        if (!st.raw) continue;
+        db.acq_win[(size_t)s * WIN_N + t] = hb_sample_q15(st.raw, st.rd + t, taps);
+    }
 }
 
 // ---- a) FIR ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_acq_fir(DevTables tb, DevBuffers db, const int *ids)
+__global__ __launch_bounds__(256) void k_acq_fir(DevTables tb, DevBuffers db)
 {
-    const int s = stream_of(ids, blockIdx.y);
-    const StreamState &st = db.state[s];
-    if (!needs_coarse(st)) return;
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= WIN_N) return;
-    const c16 *win = acq_window(db, st, s);
-    // a[k] = sample t-31+k; indices < 0 come from the filter's carried history
-    int sr = 0, si = 0;
+    const int n = db.acq_list[db.nstreams_alloc];
+    for (int k = blockIdx.y; k < n; k += ACQ_ROWS) {
+        const int s = db.acq_list[k];
+        const StreamState &st = db.state[s];
+        const c16 *win = acq_window(db, st, s);
+        // a[k] = sample t-31+k; indices < 0 come from the filter's carried history
+        int sr = 0, si = 0;
 #pragma unroll
-    for (int i = 1; i < 16; i++) {
-        const int ka = t - 31 + i, kb = t - 31 + (32 - i);
-        const c16 xa = ka >= 0 ? win[ka] : st.fir_hist[31 + ka];
-        const c16 xb = kb >= 0 ? win[kb] : st.fir_hist[31 + kb];
-        const int q = tb.acq_q15[i];
-        sr = (int16_t)(sr + (((xa.r + xb.r) * q) >> 15));
-        si = (int16_t)(si + (((xa.i + xb.i) * q) >> 15));
+        for (int i = 1; i < 16; i++) {
+            const int ka = t - 31 + i, kb = t - 31 + (32 - i);
+            const c16 xa = ka >= 0 ? win[ka] : st.fir_hist[31 + ka];
+            const c16 xb = kb >= 0 ? win[kb] : st.fir_hist[31 + kb];
+            const int q = tb.acq_q15[i];
+            sr = (int16_t)(sr + (((xa.r + xb.r) * q) >> 15));
+            si = (int16_t)(si + (((xa.i + xb.i) * q) >> 15));
+        }
+        {
+            const int kc = t - 15;
+            const c16 xc = kc >= 0 ? win[kc] : st.fir_hist[31 + kc];
+            const int q = tb.acq_q15[16];
+            sr = (int16_t)(sr + ((xc.r * q) >> 15));
+            si = (int16_t)(si + ((xc.i * q) >> 15));
+        }
+        c16 y; y.r = (int16_t)sr; y.i = (int16_t)si;
+        db.acq_filt[(size_t)s * WIN_N + t] = y;
     }
-    {
-        const int kc = t - 15;
-        const c16 xc = kc >= 0 ? win[kc] : st.fir_hist[31 + kc];
-        const int q = tb.acq_q15[16];
-        sr = (int16_t)(sr + ((xc.r * q) >> 15));
-        si = (int16_t)(si + ((xc.i * q) >> 15));
-    }
-    c16 y; y.r = (int16_t)sr; y.i = (int16_t)si;
-    db.acq_filt[(size_t)s * WIN_N + t] = y;
 }
 
 __device__ inline float2 q15_conj_f(c16 v) { return make_float2((float)v.r / 32767.0f, (float)v.i / -32767.0f); }   // defines.h:111
@@ -137,8 +162,10 @@ __global__ __launch_bounds__(256) void k_acq_peak(DevTables tb, DevBuffers db, c
 
 void launch_acquire(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st)
 {
-    if (db.acq_win) hipLaunchKernelGGL(k_acq_decimate, dim3((WIN_N + 255) / 256, nstreams), dim3(256), 0, st, tb, db, stream_ids);
-    hipLaunchKernelGGL(k_acq_fir, dim3((WIN_N + 255) / 256, nstreams), dim3(256), 0, st, tb, db, stream_ids);
+    const int rows = nstreams < ACQ_ROWS ? nstreams : ACQ_ROWS;
+    hipLaunchKernelGGL(k_acq_list, dim3(1), dim3(256), 0, st, db, stream_ids, nstreams);
+    if (db.acq_win) hipLaunchKernelGGL(k_acq_decimate, dim3((WIN_N + 255) / 256, rows), dim3(256), 0, st, tb, db);
+    hipLaunchKernelGGL(k_acq_fir, dim3((WIN_N + 255) / 256, rows), dim3(256), 0, st, tb, db);
     hipLaunchKernelGGL(k_acq_corr, dim3((SYM_N + 255) / 256, nstreams), dim3(256), 0, st, db, stream_ids);
     hipLaunchKernelGGL(k_acq_peak, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids);
 }

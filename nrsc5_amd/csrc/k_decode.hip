@@ -109,7 +109,12 @@ __global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBu
     const int errors = wave_sum_i32(bit_errors_k7_partial(soft, out, P1_LEN));
     if ((tid & 63) == 0) atomicAdd(&err_total, errors);
     __syncthreads();
-    for (int w = tid; w < P1_WORDS; w += blockDim.x) out[w] ^= tb.scr_p1[w];       // descramble
+    uint32_t *mirror = db.p1_mirror ? db.p1_mirror + ((size_t)s * db.p1_slots + st.p1_slot[parity]) * P1_WORDS : nullptr;
+    for (int w = tid; w < P1_WORDS; w += blockDim.x) {
+        const uint32_t v = out[w] ^ tb.scr_p1[w];              // descramble
+        out[w] = v;
+        if (mirror) mirror[w] = v;                             // the host's copy, posted over PCIe while the pass is still running
+    }
     __threadfence_block();
     __syncthreads();
     if (tid == 0) {

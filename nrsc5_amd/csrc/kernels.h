@@ -34,6 +34,7 @@ struct DevBuffers {
     long long q15_cap;
     c16 *acq_win;                    // [S][WIN_N]   zero-copy batch only: decimated acquisition window of streams that are not FINE
     c16 *acq_filt;                   // [S][WIN_N]   acquisition FIR output
+    int *acq_list;                   // [S + 1]      streams that need the acquisition kernels this step (k_acq_list); [S] = how many
     float2 *acq_sums;                // [S][SYM_N]
     float2 *bins;                    // [S][NSYM][LIVE_N]
     int8_t *pm;                      // [S][NPM][PM_FRAME]  soft-bit interleaver matrices (one per frame in flight)
@@ -44,6 +45,8 @@ struct DevBuffers {
     int nstreams_alloc;              // S
     uint8_t *tbmap;                  // [NAUX][S][2285 * 64]  traceback chunk maps (start lane per end lane)
     uint32_t *p1_ring;               // [S][p1_slots][P1_WORDS]
+    uint32_t *p1_mirror;             // same layout in pinned host memory (device-visible), written beside p1_ring by the FM traceback once
+                                     // nrsc5hip_batch_fetch_view has set it up; null before
     int p1_slots;
     BlockRecord *records;            // [S][rec_cap]
     int rec_cap;

@@ -196,6 +196,21 @@ def check_batch_equals_streaming(lib, caps, p1_async):
         log = eng.records_to_log(E, k, recs[k, :counts[k]], frames[k])
         diffs = common.compare_logs(singles[k], log, rtol=0.0)
         assert not diffs, (k, diffs[:10])
+    if p1_async and n > 1:
+        # second pass on the same engine with the captures rotated by one stream: the view's frames now come from the pinned
+        # mirror the traceback kernel writes (set up by the first view), not from a copy of the ring
+        E.reset_all()
+        rot = [(k + 1) % n for k in range(n)]
+        host2 = host[rot]
+        dev2 = _to_device(E, host2)
+        E.batch_append_cu8(dev2, stride, [caps[r].iq.size - caps[r].iq.size % 4 for r in rot])
+        E.batch_process(n)
+        recs, counts, frames = E.batch_fetch_view(n)
+        for k in range(n):
+            log = eng.records_to_log(E, k, recs[k, :counts[k]], frames[k])
+            diffs = common.compare_logs(singles[rot[k]], log, rtol=0.0)
+            assert not diffs, ("mirror pass", k, diffs[:10])
+        _free_device(E, dev2)
     _free_device(E, dev)
     E.close()
     return steps

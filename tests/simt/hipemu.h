@@ -161,6 +161,8 @@ static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMem
 static inline hipError_t hipMemcpy2DAsync(void *d, size_t dp, const void *s, size_t sp, size_t w, size_t h, hipMemcpyKind, hipStream_t = 0) { for (size_t r = 0; r < h; r++) memmove((char *)d + r * dp, (const char *)s + r * sp, w); return hipSuccess; }
 static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = 0) { memset(d, v, n); return hipSuccess; }
+#define hipHostMallocMapped 0u
+static inline hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { *d = h; return hipSuccess; }
 static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = 0; return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = 0; return hipSuccess; }
 #define hipStreamDefault 0u
