@@ -310,11 +310,13 @@ int nrsc5hip_debug_fetch_px(nrsc5hip_engine *e, int stream, int8_t *pair /* [184
 int nrsc5hip_reset_all(nrsc5hip_engine *e);
 
 /* Per-kernel-class device timing, measured with HIP events recorded on the stream each kernel is
- * launched on.  enable: 1 start (and zero the accumulators), 0 stop (and zero), -1 just read.
+ * launched on.  enable: 1 start (and zero the accumulators), 0x100 | class start but time that class only (the events around
+ * every launch of the block-step chain cost ~9 % of a batch pass), 0 stop (and zero), -1 just read.
  * total_ms / launches: arrays of NRSC5HIP_PROF_CLASSES entries (may be NULL). */
 enum {
     NRSC5HIP_PROF_DECIMATE = 0, NRSC5HIP_PROF_ACQUIRE, NRSC5HIP_PROF_PREPARE, NRSC5HIP_PROF_MIXFFT,
-    NRSC5HIP_PROF_SYNC, NRSC5HIP_PROF_P1_DEINT, NRSC5HIP_PROF_P1_VITERBI, NRSC5HIP_PROF_PIDS, NRSC5HIP_PROF_AM, NRSC5HIP_PROF_CLASSES
+    NRSC5HIP_PROF_SYNC, NRSC5HIP_PROF_P1_DEINT, NRSC5HIP_PROF_P1_VITERBI, NRSC5HIP_PROF_PIDS, NRSC5HIP_PROF_AM /* block steps */, NRSC5HIP_PROF_AM_DECODE /* window pipeline: the deferred decodes */,
+    NRSC5HIP_PROF_CLASSES
 };
 int nrsc5hip_profile(nrsc5hip_engine *e, int enable, double *total_ms, long long *launches);
 

@@ -77,6 +77,7 @@ struct nrsc5hip_engine {
     BlockRecord *rec_host; uint32_t *frames_host; int *nblocks_host;
     // optional per-kernel-class timing with HIP events on the launching stream
     bool prof_on;
+    int prof_only;                     // -1: every class is timed; else only this one (events cost ~5 us of the chain's time per kernel)
     struct ProfSpan { int cls; hipEvent_t a, b; };
     std::vector<ProfSpan> prof_spans;
     std::vector<hipEvent_t> prof_pool;
@@ -92,9 +93,9 @@ static hipEvent_t prof_event(nrsc5hip_engine *e)
 struct ProfScope {
     nrsc5hip_engine *e; int cls; hipStream_t st; hipEvent_t a;
     ProfScope(nrsc5hip_engine *e_, int cls_, hipStream_t st_) : e(e_), cls(cls_), st(st_), a(nullptr)
-    { if (e->prof_on) { a = prof_event(e); (void)hipEventRecord(a, st); } }
+    { if (e->prof_on && (e->prof_only < 0 || e->prof_only == cls)) { a = prof_event(e); (void)hipEventRecord(a, st); } }
     ~ProfScope()
-    { if (e->prof_on) { hipEvent_t b = prof_event(e); (void)hipEventRecord(b, st); e->prof_spans.push_back({cls, a, b}); } }
+    { if (a) { hipEvent_t b = prof_event(e); (void)hipEventRecord(b, st); e->prof_spans.push_back({cls, a, b}); } }
 };
 static void prof_collect(nrsc5hip_engine *e)
 {
@@ -176,6 +177,22 @@ static int build_tables(nrsc5hip_engine *e)
 
     int rc;
     if ((rc = dev_upload(e, &e->tb.pids_gather, pids))) return rc;
+    {
+        // MP1 equaliser: every data cell's operands, so that k_sync neither divides nor takes remainders per cell
+        const int ncell = 2 * PM_PART * NSYM * 18;
+        std::vector<uint32_t> cell(ncell);
+        std::vector<uint16_t> outp(ncell);
+        for (int c = 0; c < ncell; c++) {
+            const int k = 1 + c % 18, n = (c / 18) % NSYM, part = (c / (18 * NSYM)) % PM_PART, side = c / (18 * NSYM * PM_PART);
+            const int r_lo = side ? 2 * (part + 1) + 1 : 2 * part, r_hi = side ? 2 * part + 1 : 2 * (part + 1);
+            const int ref_lo_bin = (r_lo & 1) ? UB1 - PW * (r_lo >> 1) : LB0 + PW * (r_lo >> 1);
+            const int live = bin_to_live(ref_lo_bin + k);
+            cell[c] = (uint32_t)live | (uint32_t)n << 10 | (uint32_t)r_lo << 15 | (uint32_t)r_hi << 20 | (uint32_t)k << 25 | (uint32_t)side << 30;
+            outp[c] = (uint16_t)(n * 720 + (side ? 19 - part : part) * 36 + (k - 1) * 2);
+        }
+        if ((rc = dev_upload(e, &e->tb.eq_cell, cell))) return rc;
+        if ((rc = dev_upload(e, &e->tb.eq_out, outp))) return rc;
+    }
     {   // byte q of the 384-byte run of one k: q%6==5 is the erasure, else j = q - q/6, part = PM_V[j%20], block = (j/20 + 7 part) % 16
         std::vector<uint16_t> lut(384);
         for (int q = 0; q < 384; q++) {
@@ -429,7 +446,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         e->wr_host.assign(S, 0); e->base_host.assign(S, 0); e->drained.assign(S, 0);
         e->mode_host.assign(S, MODE_FM); e->raw_host.assign(S, 0); e->attached.assign(S, 0);
         for (int l = 0; l < e->nlanes; l++) { e->lanes[l].db = db; e->lanes[l].counters_dev = db.counters + 4 * l; e->lanes[l].db.counters = db.counters + 4 * l; }
-        e->prof_on = false;
+        e->prof_on = false; e->prof_only = -1;
         for (int k = 0; k < NRSC5HIP_PROF_CLASSES; k++) { e->prof_ms[k] = 0; e->prof_launches[k] = 0; }
     } while (0);
     if (rc) { nrsc5hip_engine_destroy(e); return rc; }
@@ -611,7 +628,7 @@ static int am_flush(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const 
         hipStream_t ax = ln.aux[lane];
         HIPCHK(hipEventRecord(ln.ev_window[parity], ln.main));
         HIPCHK(hipStreamWaitEvent(ax, ln.ev_window[parity], 0));
-        { ProfScope p(e, NRSC5HIP_PROF_AM, ax); launch_am_decode(e->tb, ln.db, n, ids_dev, parity, lane, e->cfg.l2_feedback, ax); }
+        { ProfScope p(e, NRSC5HIP_PROF_AM_DECODE, ax); launch_am_decode(e->tb, ln.db, n, ids_dev, parity, lane, e->cfg.l2_feedback, ax); }
         ln.am_step_count += 8 - (ln.am_step_count % 8);
     }
     for (int k = 0; k < NAUX; k++) HIPCHK(hipStreamSynchronize(ln.aux[k]));
@@ -639,7 +656,7 @@ static int run_steps_am(nrsc5hip_engine *e, int n, const int *ids_dev, int max_s
                 hipStream_t ax = ln.aux[lane];
                 HIPCHK(hipEventRecord(ln.ev_window[parity], ln.main));
                 HIPCHK(hipStreamWaitEvent(ax, ln.ev_window[parity], 0));
-                { ProfScope p(e, NRSC5HIP_PROF_AM, ax); launch_am_decode(e->tb, ln.db, n, ids_dev, parity, lane, e->cfg.l2_feedback, ax); }
+                { ProfScope p(e, NRSC5HIP_PROF_AM_DECODE, ax); launch_am_decode(e->tb, ln.db, n, ids_dev, parity, lane, e->cfg.l2_feedback, ax); }
                 HIPCHK(hipEventRecord(ln.ev_decoded[parity], ax));
                 ln.am_decoded_pending[parity] = true;
             }
@@ -1301,7 +1318,7 @@ extern "C" int nrsc5hip_profile(nrsc5hip_engine *e, int enable, double *total_ms
         if (launches) launches[k] = e->prof_launches[k];
         if (enable >= 0) { e->prof_ms[k] = 0; e->prof_launches[k] = 0; }
     }
-    if (enable >= 0) e->prof_on = enable != 0;
+    if (enable >= 0) { e->prof_on = enable != 0; e->prof_only = (enable & 0x100) ? (enable & 0xff) : -1; }
     return 0;
 }
 

@@ -54,10 +54,10 @@ __device__ inline uint32_t costas_block(const float2 *src, int stride, float &fr
     float2 zin[NSYM];
 #pragma unroll
     for (int n = 0; n < NSYM; n++) zin[n] = src[n * stride];   // 32 independent loads in flight
+    float s1, c1; fast_sincos(phase, s1, c1);                  // cexpf(-I phase), see fastmath.h; the next symbol's at the end of each step
 #pragma unroll 4
     for (int n = 0; n < NSYM; n++) {
         const float2 z = zin[n];
-        float s1, c1; fast_sincos(phase, s1, c1);              // cexpf(-I phase): see fastmath.h
         const float s2 = 2.0f * s1 * c1, c2 = c1 * c1 - s1 * s1;                // e^{2i phase}
         const float2 w = make_float2(z.x * z.x - z.y * z.y, z.x * z.y + z.y * z.x);
         const float ur = w.x * c2 + w.y * s2, ui = w.y * c2 - w.x * s2;         // w * e^{-2i phase}
@@ -72,8 +72,22 @@ __device__ inline uint32_t costas_block(const float2 *src, int stride, float &fr
         if (freq > 0.5f) freq = 0.5f;
         if (freq < -0.5f) freq = -0.5f;
         phase += freq + cfo_freq + (g.alpha * error);
-        if ((double)phase > M_PI) phase = (float)((double)phase - 2 * M_PI);
-        if ((double)phase < -M_PI) phase = (float)((double)phase + 2 * M_PI);
+        if (STORE && fabsf(phase) < 12.0f) {
+            // Steady tracking: the phase is within two turns.  The reference's `if (phase > M_PI) phase -= 2 * M_PI` (double
+            // comparison, double difference rounded to float) without leaving float32: (double)phase > M_PI <=> phase > the
+            // largest float below pi; phase - 2 pi as an exact difference with float(2 pi) (Sterbenz: pi < phase < 4 pi) plus
+            // the rest of the constant, one rounding (equal on 2e6 random phases, tests/test_halfband_float.py).  A phase this
+            // small needs no double-precision argument reduction for the next symbol's rotation either.
+            constexpr float PI_BELOW = 3.14159250259399414f, TWO_PI_HI = 6.28318548202514648f, TWO_PI_LO = -1.74845553e-7f;
+            if (phase > PI_BELOW) phase = (phase - TWO_PI_HI) - TWO_PI_LO;
+            if (phase < -PI_BELOW) phase = (phase + TWO_PI_HI) + TWO_PI_LO;
+            fast_sincos_reduced(phase, s1, c1);
+        } else {
+            // after a large timing correction (sync_adjust rotates every loop by up to ~1800 rad) and in the CFO search
+            if ((double)phase > M_PI) phase = (float)((double)phase - 2 * M_PI);
+            if ((double)phase < -M_PI) phase = (float)((double)phase + 2 * M_PI);
+            fast_sincos(phase, s1, c1);
+        }
     }
     if (x < 0) {                                               // off by pi: flip (sync.c:119-129)
         if (STORE) for (int n = 0; n < NSYM; n++) { phout[n] = (float)((double)phout[n] + M_PI); zout[n] = make_float2(-zout[n].x, -zout[n].y); }
@@ -382,13 +396,25 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         float2 cellv[MP1C];
         double e_lb = 0.0, e_ub = 0.0;
         if (ppb == PM_PART) {
+            // operands from the cell table (DevTables::eq_cell), all 45 bins of the lane requested before the first is used
+            uint32_t cw[MP1C];
+#pragma unroll
+            for (int i = 0; i < MP1C; i++) cw[i] = tb.eq_cell[tid + 256 * i];
+#pragma unroll
+            for (int i = 0; i < MP1C; i++) cellv[i] = bins[((cw[i] >> 10) & 31u) * LIVE_N + (cw[i] & 1023u)];
 #pragma unroll
             for (int i = 0; i < MP1C; i++) {
-                int side;
-                const float2 v = equalise_cell<PM_PART>(tid + 256 * i, ppb, bins, refcs, smag, side);
+                const uint32_t w = cw[i];
+                const int n = (w >> 10) & 31u, r_lo = (w >> 15) & 31u, r_hi = (w >> 20) & 31u, k = (w >> 25) & 31u;
+                const float2 z = cellv[i];
+                const float2 lp = refcs[r_lo][n], up = refcs[r_hi][n];
+                const float a = k * smag[r_hi], bq = (PW - k) * smag[r_lo];
+                const float2 den = make_float2(a * up.x + bq * lp.x, a * up.y + bq * lp.y);
+                const float2 C = cdiv(make_float2((float)PW, (float)PW), den);
+                const float2 v = make_float2(z.x * C.x - z.y * C.y, z.x * C.y + z.y * C.x);
                 cellv[i] = v;
                 const float e = cell_error(v);
-                if (side) e_ub += e; else e_lb += e;
+                if (w >> 30) e_ub += e; else e_lb += e;
             }
         } else {
             for (int c = tid; c < ncell; c += 256) {
@@ -428,9 +454,10 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         if (ppb == PM_PART) {
 #pragma unroll
             for (int i = 0; i < MP1C; i++) {
-                int k, n, part, side;
-                cell_coords<PM_PART>(tid + 256 * i, ppb, side, part, n, k);
-                store_soft(pm_blk, cellv[i], side, part, n, k, mult_lb, mult_ub);
+                const int c = tid + 256 * i;
+                const float mult = c >= ncell / 2 ? mult_ub : mult_lb;              // cells of the upper sideband come second
+                char2 o; o.x = (signed char)soft_bit(cellv[i].x, mult); o.y = (signed char)soft_bit(cellv[i].y, mult);
+                *(char2 *)(pm_blk + tb.eq_out[c]) = o;
             }
         } else {
             for (int c = tid; c < ncell; c += 256) {

@@ -9,6 +9,9 @@ namespace nrsc5 {
 struct DevTables {
     const uint16_t *deint_lut;       // [384] byte q of a 384-byte depunctured run -> block*720 + part*36, 0xffff = erasure
     const uint16_t *pids_gather;     // [16][PIDS_CODED] index inside block bc (decode.c:324-342)
+    const uint32_t *eq_cell;         // [11520] MP1 data cell c = ((side * 10 + part) * 32 + n) * 18 + k - 1, packed: live bin | n << 10 | low ref << 15 |
+                                     //         high ref << 20 | k << 25 | side << 30 (adjust_data's operands, sync.c:263-282)
+    const uint16_t *eq_out;          // [11520] where the cell's soft-bit pair goes inside the block's interleaver rows (sync.c:514-536)
     const uint32_t *scr_p1;          // [P1_WORDS] packed scrambler stream (decode.c:279-294)
     const uint32_t *scr_pids;        // [3]
     const float2 *twiddle;           // [2048] e^{-2 pi i k / 2048}

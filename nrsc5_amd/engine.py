@@ -213,10 +213,13 @@ class Engine:
     def reset_all(self):
         self._check(self.lib.nrsc5hip_reset_all(self._h))
 
-    PROF_CLASSES = ("decimate", "acquire", "prepare", "mixfft", "sync", "p1_deint", "p1_viterbi", "pids", "am")
+    PROF_CLASSES = ("decimate", "acquire", "prepare", "mixfft", "sync", "p1_deint", "p1_viterbi", "pids", "am", "am_decode")
 
     def profile(self, enable: int = -1):
-        """Per-kernel-class {name: (total_ms, launches)} from HIP events; enable 1/0 starts/stops."""
+        """Per-kernel-class {name: (total_ms, launches)} from HIP events; enable 1/0 starts/stops, a class name starts timing
+        that class only."""
+        if isinstance(enable, str):
+            enable = 0x100 | self.PROF_CLASSES.index(enable)
         ms = np.zeros(len(self.PROF_CLASSES), dtype=np.float64)
         n = np.zeros(len(self.PROF_CLASSES), dtype=np.int64)
         self._check(self.lib.nrsc5hip_profile(self._h, enable, ms.ctypes.data, n.ctypes.data))

@@ -66,3 +66,19 @@ def test_round_down_fma_chain_equals_oracle(oracle):
     assert np.array_equal((acc - BIAS).astype(np.int16), exp)
     # and the products are exact inside the fma: |s| < 2^9, |T| < 2^15 -> 24 significant bits
     assert max(abs(t) for t in T) < 2 ** 15
+
+
+def test_float_phase_wrap_equals_double_formulation():
+    """k_sync's Costas loop wraps the phase as the reference does (sync.c: `if (phase > M_PI) phase -= 2 * M_PI`, evaluated in
+    double and rounded to float) but in float32 arithmetic while |phase| < 12: same decision, same result, bit for bit."""
+    rng = np.random.default_rng(5)
+    edge = np.nextafter(np.float32(np.pi), np.float32(0))       # largest float below pi
+    ph = np.concatenate([rng.uniform(-12.0, 12.0, 2_000_000), edge + np.arange(-50, 50) * 2.4e-7, -edge + np.arange(-50, 50) * 2.4e-7]).astype(np.float32)
+    d = ph.astype(np.float64)
+    ref = np.where(d > np.pi, d - 2 * np.pi, d)
+    ref = np.where(ref < -np.pi, ref + 2 * np.pi, ref).astype(np.float32)   # the reference applies both tests in sequence
+    hi, lo, below = np.float32(6.28318548202514648), np.float32(-1.74845553e-7), np.float32(3.14159250259399414)
+    assert below == edge
+    mine = np.where(ph > below, ((ph - hi).astype(np.float32) - lo).astype(np.float32), ph)
+    mine = np.where(mine < -below, ((mine + hi).astype(np.float32) + lo).astype(np.float32), mine)
+    assert np.array_equal(ref, mine)
