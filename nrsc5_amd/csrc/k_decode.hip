@@ -75,10 +75,16 @@ __device__ inline int bit_errors_k7_partial(const int *soft, const uint32_t *bit
 }
 
 // ---- K7: P1 frame = forward pass by one wave, then traceback/BER/descramble by a 16-wave block -------
-__global__ __launch_bounds__(64) void k_p1_forward(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id, int prio)
+// Four frames per workgroup, one per wave: the waves of a workgroup land on the four SIMDs of one CU, so no two trellis
+// passes of a launch share a SIMD (with one-wave workgroups the dispatcher sometimes stacks them, and the launch lasts as long
+// as its slowest wave).
+constexpr int FWD_WAVES = 4;
+__global__ __launch_bounds__(64 * FWD_WAVES) void k_p1_forward(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id, int prio, int nstreams)
 {
     wave_set_priority(prio);
-    const int s = wave_uniform(stream_of(ids, blockIdx.x));
+    const int sidx = wave_uniform((int)(blockIdx.x * FWD_WAVES + (threadIdx.x >> 6)));
+    if (sidx >= nstreams) return;                              // wave-uniform
+    const int s = wave_uniform(stream_of(ids, sidx));
     StreamState &st = db.state[s];
     if (!st.p1_pending[parity]) return;                        // wave-uniform
     const int *soft = db.coded + ((size_t)lane_id * db.nstreams_alloc + s) * P1_LEN;
@@ -145,7 +151,7 @@ void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, 
     // raising it to 1 or 2 was measured again with the 6-instruction trellis: no gain (profiles/r02_naux.txt).  The traceback is
     // the short kernel at the end of each decode chain: let it through (+1.5 %).
     constexpr int prio_fwd = 0, prio_tb = 3;
-    hipLaunchKernelGGL(k_p1_forward, dim3(nstreams), dim3(64), 0, st, tb, db, stream_ids, parity, lane_id, prio_fwd);
+    hipLaunchKernelGGL(k_p1_forward, dim3((nstreams + FWD_WAVES - 1) / FWD_WAVES), dim3(64 * FWD_WAVES), 0, st, tb, db, stream_ids, parity, lane_id, prio_fwd, nstreams);
     hipLaunchKernelGGL(k_p1_traceback, dim3(nstreams), dim3(TB_THREADS), traceback_smem(P1_LEN), st, tb, db, stream_ids, parity, lane_id, l2_mode, prio_tb);
     if (db.l2_ring) launch_l2_index_window(db, nstreams, stream_ids, parity, st);
 }

@@ -70,6 +70,39 @@ __device__ inline void dft16(float2 *v)
     for (int k1 = 0; k1 < 4; k1++) dft4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
 }
 
+// dft16 reduced to the six outputs a work-item of the symbol kernel can ever store: bins k1 + 8 k2 + 128 m with
+// m = 2, 3, 4 (upper sideband) and 11, 12, 13 (lower sideband) -- the other ten lie outside sync.c:785-789's 2 x 267 live bins
+// for every (k1, k2).  Same first stage and twiddles as dft16; of the second stage's 4-point transforms only the wanted
+// outputs: v[8] = X[2], v[12] = X[3], v[1] = X[4], v[14] = X[11], v[3] = X[12], v[7] = X[13].
+__device__ inline void dft16_live(float2 *v)
+{
+#pragma unroll
+    for (int n2 = 0; n2 < 4; n2++) dft4(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, c2 = 0.70710678118654752440f;
+    v[5]  = cmul(v[5],  make_float2(c1, -s1));
+    v[6]  = cmul(v[6],  make_float2(c2, -c2));
+    v[7]  = cmul(v[7],  make_float2(s1, -c1));
+    v[9]  = cmul(v[9],  make_float2(c2, -c2));
+    v[10] = mul_mj(v[10]);
+    v[11] = cmul(v[11], make_float2(-c2, -c2));
+    v[13] = cmul(v[13], make_float2(s1, -c1));
+    v[14] = cmul(v[14], make_float2(-c2, -c2));
+    v[15] = cmul(v[15], make_float2(-c1, s1));
+    {   // a = 0: outputs b = 1 (X[4]) and b = 3 (X[12])
+        const float2 t1 = csub(v[0], v[2]), t3 = mul_mj(csub(v[1], v[3]));
+        v[1] = cadd(t1, t3); v[3] = csub(t1, t3);
+    }
+    {   // a = 1: b = 3 (X[13])
+        const float2 t1 = csub(v[4], v[6]), t3 = mul_mj(csub(v[5], v[7]));
+        v[7] = csub(t1, t3);
+    }
+    v[8] = cadd(cadd(v[8], v[10]), cadd(v[9], v[11]));         // a = 2: b = 0 (X[2])
+    {   // a = 3: b = 0 (X[3]) and b = 2 (X[11])
+        const float2 t0 = cadd(v[12], v[14]), t2 = cadd(v[13], v[15]);
+        v[12] = cadd(t0, t2); v[14] = csub(t0, t2);
+    }
+}
+
 constexpr int PITCH_A = 272;   // floats2 per k1 row (256 + 16: rows of one half-wave land on disjoint banks)
 constexpr int PITCH_B = 17;    // per r2 row inside a k1 row of the second layout (16 + 1)
 
@@ -77,6 +110,8 @@ constexpr int PITCH_B = 17;    // per r2 row inside a k1 row of the second layou
 //  in : x[0..7]  = samples r + 256*n1 for r = tid,       n1 = 0..7
 //       x[8..15] = samples r + 256*n1 for r = tid + 128
 //  out: x[4a+b]  = bin  k1 + 8*k2 + 128*(a + 4b)   with k1 = tid >> 4, k2 = tid & 15
+//  LIVE: only x[1], x[3], x[7], x[8], x[12], x[14] are produced (dft16_live)
+template <bool LIVE>
 __device__ inline void fft2048_wg(float2 *x, float2 *lds, const float2 *tw)
 {
     const int tid = threadIdx.x;
@@ -114,7 +149,7 @@ __device__ inline void fft2048_wg(float2 *x, float2 *lds, const float2 *tw)
         const int k1 = tid >> 4, k2 = tid & 15;
 #pragma unroll
         for (int r2 = 0; r2 < 16; r2++) x[r2] = lds[k1 * PITCH_A + r2 * PITCH_B + k2];
-        dft16(x);
+        if (LIVE) dft16_live(x); else dft16(x);
     }
 }
 
@@ -192,21 +227,17 @@ __device__ inline void decimate_symbol_raw(const uint8_t *raw, long long a0, flo
     hb_round_nearest();
 }
 
-__global__ __launch_bounds__(128) void k_mixfft(DevTables tb, DevBuffers db, const int *ids)
+// RAW: the stream reads its cu8 capture in place (zero-copy batch) -- else its samples come from the Q15 FIFO.  Block-uniform, so
+// the two forms are separate instantiations rather than a test per sample.
+template <bool RAW>
+__device__ __forceinline__ void mixfft_symbol(const DevTables &tb, const DevBuffers &db, const StreamState &st, int s, float2 *lds)
 {
-    wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
-    const int s = stream_of(ids, blockIdx.y);
-    const StreamState &st = db.state[s];
-    if (!st.active) return;                                    // block-uniform
-    __shared__ float2 lds[8 * PITCH_A];
-    static_assert(8 * PITCH_A >= 17 * 128 && 17 * 127 < SYM_N, "17 decimated samples per work-item fit in the FFT tile");
     const int sym = blockIdx.x, tid = threadIdx.x;
     const long long a0 = (st.rd - st.base) + sym * SYM_N + st.samperr_cur;     // first sample of the symbol in the decimated stream
     const double dth = st.dtheta;
     const double th0 = st.theta + (double)sym * SYM_N * dth;
-    const uint8_t *raw = st.raw;                               // block-uniform
-    if (raw) {
-        decimate_symbol_raw(raw, a0, lds, hb_taps(tb.hb_q15));
+    if (RAW) {
+        decimate_symbol_raw(st.raw, a0, lds, hb_taps(tb.hb_q15));
         __syncthreads();
     }
 
@@ -222,7 +253,7 @@ __global__ __launch_bounds__(128) void k_mixfft(DevTables tb, DevBuffers db, con
     const c16 *win = db.q15 + (size_t)s * db.q15_cap + a0;     // FIFO path (streaming seam, cs16 input)
 
     auto sample = [&](int j) -> float2 {
-        if (raw) { const float2 y = lds[j]; return make_float2(q15_to_float(y.x), q15_to_float(y.y)); }
+        if (RAW) { const float2 y = lds[j]; return make_float2(q15_to_float(y.x), q15_to_float(y.y)); }   // the tile holds Q15 integers, conjugated
         const c16 s16 = win[j];
         return make_float2(q15_to_float((float)s16.r), -q15_to_float((float)s16.i));   // cq15_to_cf_conj, defines.h:111
     };
@@ -242,19 +273,33 @@ __global__ __launch_bounds__(128) void k_mixfft(DevTables tb, DevBuffers db, con
         const float w = tb.shape[j];
         x[0].x += w * m.x; x[0].y += w * m.y;
     }
-    if (raw) __syncthreads();                                  // every work-item has its samples: the tile becomes the FFT's
+    if (RAW) __syncthreads();                                  // every work-item has its samples: the tile becomes the FFT's
 
-    fft2048_wg(x, lds, tb.twiddle);
+    fft2048_wg<true>(x, lds, tb.twiddle);
 
+    // fftshift (bin 1024 = DC) and the live-bin cut: x[4a + b] = bin kbase + 128 (a + 4 b); after the shift the work-item's
+    // six candidates sit at kbase + 128 m', m' = 10, 11, 12 (upper sideband, bins 1304 .. 1570) and 3, 4, 5 (lower, 478 .. 744)
     float2 *out = db.bins + ((size_t)s * NSYM + sym) * LIVE_N;
     const int kbase = (tid >> 4) + 8 * (tid & 15);
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        const int k3 = (i >> 2) + 4 * (i & 3);
-        const int b = (kbase + 128 * k3 + FFT_N / 2) & (FFT_N - 1);       // fftshift: bin 1024 = DC
-        if (b >= LB0 && b < LB0 + LIVE_HALF) out[b - LB0] = x[i];
-        else if (b >= UB0 && b <= UB1) out[LIVE_HALF + (b - UB0)] = x[i];
-    }
+    static_assert(LB0 == 478 && UB0 == 1304 && UB1 == 1570 && LIVE_HALF == 267, "the six-output cut below is laid out for these edges");
+    if (kbase >= LB0 - 384) out[kbase + 384 - LB0] = x[14];                    // m' = 3  (X[11])
+    out[kbase + 512 - LB0] = x[3];                                             // m' = 4  (X[12])
+    if (kbase + 640 < LB0 + LIVE_HALF) out[kbase + 640 - LB0] = x[7];          // m' = 5  (X[13])
+    if (kbase + 1280 >= UB0) out[LIVE_HALF + kbase + 1280 - UB0] = x[8];       // m' = 10 (X[2])
+    out[LIVE_HALF + kbase + 1408 - UB0] = x[12];                               // m' = 11 (X[3])
+    if (kbase + 1536 <= UB1) out[LIVE_HALF + kbase + 1536 - UB0] = x[1];       // m' = 12 (X[4])
+}
+
+__global__ __launch_bounds__(128) void k_mixfft(DevTables tb, DevBuffers db, const int *ids)
+{
+    wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
+    const int s = stream_of(ids, blockIdx.y);
+    const StreamState &st = db.state[s];
+    if (!st.active) return;                                    // block-uniform
+    __shared__ float2 lds[8 * PITCH_A];
+    static_assert(8 * PITCH_A >= 17 * 128 && 17 * 127 < SYM_N, "17 decimated samples per work-item fit in the FFT tile");
+    if (st.raw) mixfft_symbol<true>(tb, db, st, s, lds);
+    else mixfft_symbol<false>(tb, db, st, s, lds);
 }
 
 void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st)
@@ -274,7 +319,7 @@ __global__ __launch_bounds__(128) void k_fft2048(DevTables tb, const float2 *in,
     for (int h = 0; h < 2; h++)
 #pragma unroll
         for (int n1 = 0; n1 < 8; n1++) x[8 * h + n1] = src[tid + 128 * h + 256 * n1];
-    fft2048_wg(x, lds, tb.twiddle);
+    fft2048_wg<false>(x, lds, tb.twiddle);
     const int kbase = (tid >> 4) + 8 * (tid & 15);
 #pragma unroll
     for (int i = 0; i < 16; i++) dst[kbase + 128 * ((i >> 2) + 4 * (i & 3))] = x[i];

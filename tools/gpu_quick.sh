@@ -19,4 +19,4 @@ try:
 except Exception as ex:
     print("no json", ex); print(open(f"gpurun_out/{sys.argv[1]}_bench.log").read()[-3000:])
 PY
-bash tools/gpu_trace.sh ${TAG}_trace > /dev/null 2>&1; head -24 gpurun_out/${TAG}_trace_summary.txt
+bash tools/gpu_trace.sh ${TAG}_trace > /dev/null 2>&1; head -24 gpurun_out/${TAG}_trace_summary.txt; grep -A40 "decode kernels" gpurun_out/${TAG}_trace_summary.txt

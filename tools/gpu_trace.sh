@@ -55,5 +55,9 @@ for w in range(0, len(sync), 16):
     print(f"   window {w // 16:2d}: steps {w:3d}..{w + len(seg) - 1:3d}  {(seg[-1]['e'] - (mix[w]['s'] if w < len(mix) else seg[0]['s'])) / 1e6:6.2f} ms", end="")
     if (w // 16) % 4 == 3: print()
 print()
+print("decode kernels (queue, start ms, duration us):")
+for r in P:
+    if r["n"] in ("k_p1_forward", "k_p1_traceback"):
+        print(f"   q{r['Queue_Id']} {(r['s'] - t0) / 1e6:9.3f} {(r['e'] - r['s']) / 1e3:9.1f}  {r['n']}")
 PY
 rm -rf gpurun_out/${TAG}_raw
