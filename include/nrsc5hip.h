@@ -121,7 +121,8 @@ typedef struct nrsc5hip_config {
                                   reset; q15_capacity may then be the minimum (2 * 71280).  0: samples are copied (decimated) into the
                                   engine's FIFO during the call, as the streaming seam does. */
     int l2_index;              /* 1: every FM P1 frame is also indexed on the decode stream right after its traceback
-                                  (nrsc5hip_l2_frame per ring slot, read with nrsc5hip_l2_frame_get / nrsc5hip_batch_fetch_l2);
+                                  (nrsc5hip_l2_frame per ring slot, read with nrsc5hip_l2_frame_get / nrsc5hip_batch_fetch_l2), and
+                                  so are the P3 / P4 frames and the frames of AM streams (nrsc5hip_batch_fetch_l2_px / _am);
                                   0: indexes only on request (nrsc5hip_l2_index) */
 } nrsc5hip_config;
 
@@ -249,6 +250,12 @@ int nrsc5hip_l2_index(nrsc5hip_engine *e, int njobs, const nrsc5hip_l2_job *jobs
 int nrsc5hip_l2_frame_get(nrsc5hip_engine *e, int stream, int slot, nrsc5hip_l2_frame *out);
 /* ... and of every P1 slot of the listed streams: out[nstreams][p1_slots] */
 int nrsc5hip_batch_fetch_l2(nrsc5hip_engine *e, int nstreams, const int *stream_ids, nrsc5hip_l2_frame *out);
+/* The same option also indexes, in the pipeline, the P3 / P4 frames of the extended sidebands -- out[nstreams][px_slots = 8 *
+ * p1_slots][2], entry [slot][0] = the P3 frame a REC_P3 record names in `sis`, [slot][1] its P4 frame (MP11) -- and, in engines
+ * created with am_enable, the frames of every AM L1 frame slot: out[nstreams][p1_slots][9], entries 0..7 = the P1 frame delivered
+ * at block 0..7 (REC_P1, p1_slot), 8 = the P3 frame (REC_P3).  Entries of slots no record names are stale or zero. */
+int nrsc5hip_batch_fetch_l2_px(nrsc5hip_engine *e, int nstreams, const int *stream_ids, nrsc5hip_l2_frame *out);
+int nrsc5hip_batch_fetch_l2_am(nrsc5hip_engine *e, int nstreams, const int *stream_ids, nrsc5hip_l2_frame *out);
 /* stage-level twin: nframes logical frames given as frame_push takes them (one bit per byte, nbits each) */
 int nrsc5hip_stage_l2_index(nrsc5hip_engine *e, const uint8_t *bits, int nbits, int nframes, nrsc5hip_l2_frame *out,
                             uint8_t *pdu_bytes, long long stride);

@@ -400,10 +400,18 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             if (hipMemset(db.px_mem, 0, S * 2 * PX_MEM) != hipSuccess || hipMemset(db.px_pair, 0, S * 4 * PX_MAX) != hipSuccess ||
                 hipMemset(db.px_job, 0xff, S * NWIN * 16 * sizeof(PxJob)) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "PX state init failed"); break; }
         }
-        db.l2_ring = nullptr;
+        db.l2_ring = nullptr; db.l2_px_ring = nullptr; db.l2_am_ring = nullptr;
         if (cfg->l2_index) {
             if ((rc = dev_alloc(e, &db.l2_ring, S * (size_t)cfg->p1_slots))) break;
             if (hipMemset(db.l2_ring, 0, S * (size_t)cfg->p1_slots * sizeof(nrsc5hip_l2_frame)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
+            // ... and of every P3 / P4 frame slot, and (AM engines) of the nine frames of every AM L1 frame slot
+            const size_t npx = S * (size_t)db.px_slots * 2, nam = cfg->am_enable ? S * (size_t)cfg->p1_slots * 9 : 0;
+            if ((rc = dev_alloc(e, &db.l2_px_ring, npx))) break;
+            if (hipMemset(db.l2_px_ring, 0, npx * sizeof(nrsc5hip_l2_frame)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
+            if (nam) {
+                if ((rc = dev_alloc(e, &db.l2_am_ring, nam))) break;
+                if (hipMemset(db.l2_am_ring, 0, nam * sizeof(nrsc5hip_l2_frame)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
+            }
         }
         db.am = nullptr; db.am_sym = nullptr; db.am_q = nullptr; db.am_vit = nullptr; db.am_dec = nullptr; db.am_job = nullptr; db.am_ber = nullptr; db.am_pids_stage = nullptr; db.am_pids_rec = nullptr; db.am_nvit = 1;
         if (cfg->am_enable) {
@@ -1131,6 +1139,27 @@ extern "C" int nrsc5hip_batch_fetch_l2(nrsc5hip_engine *e, int nstreams, const i
             HIPCHK(hipMemcpy(out + (size_t)k * per, e->db.l2_ring + (size_t)stream_ids[k] * per, per * sizeof(*out), hipMemcpyDeviceToHost));
     }
     return 0;
+}
+
+static int fetch_l2_ring(nrsc5hip_engine *e, const nrsc5hip_l2_frame *ring, size_t per, int nstreams, const int *stream_ids, nrsc5hip_l2_frame *out, const char *what)
+{
+    if (!e || !out || nstreams < 1) FAIL(NRSC5HIP_EINVAL, "bad argument");
+    if (!ring) FAIL(NRSC5HIP_EINVAL, "engine was created without l2_index%s", what);
+    HIPCHK(hipDeviceSynchronize());
+    for (int k = 0; k < nstreams; k++) {
+        const int s = stream_ids ? stream_ids[k] : k;
+        int rc = check_stream(e, s); if (rc) return rc;
+        HIPCHK(hipMemcpy(out + (size_t)k * per, ring + (size_t)s * per, per * sizeof(*out), hipMemcpyDeviceToHost));
+    }
+    return 0;
+}
+extern "C" int nrsc5hip_batch_fetch_l2_px(nrsc5hip_engine *e, int nstreams, const int *stream_ids, nrsc5hip_l2_frame *out)
+{
+    return fetch_l2_ring(e, e ? e->db.l2_px_ring : nullptr, e ? (size_t)e->db.px_slots * 2 : 0, nstreams, stream_ids, out, "");
+}
+extern "C" int nrsc5hip_batch_fetch_l2_am(nrsc5hip_engine *e, int nstreams, const int *stream_ids, nrsc5hip_l2_frame *out)
+{
+    return fetch_l2_ring(e, e ? e->db.l2_am_ring : nullptr, e ? (size_t)e->db.p1_slots * 9 : 0, nstreams, stream_ids, out, " and am_enable");
 }
 
 extern "C" int nrsc5hip_stage_l2_index(nrsc5hip_engine *e, const uint8_t *bits, int nbits, int nframes, nrsc5hip_l2_frame *out, uint8_t *pdu_bytes, long long stride)

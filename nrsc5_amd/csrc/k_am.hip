@@ -935,7 +935,7 @@ __global__ __launch_bounds__(1024) void k_am_interleave(DevTables tb, DevBuffers
             am.next_slot = stw.p1_count % db.p1_slots; stw.p1_count++;
             if (parity >= 0) {
                 AmJob &job = db.am_job[(size_t)s * NWIN + parity];
-                job.slot = am.next_slot; job.psmi = am.dec_psmi; job.rdbi = am.dec_rdbi; job.errors = 0; job.done = 0; job.epoch = stw.fine_epoch; job.valid = 1;
+                job.slot = am.next_slot; job.psmi = am.dec_psmi; job.rdbi = am.dec_rdbi; job.errors = 0; job.done = 0; job.pad = 0; job.epoch = stw.fine_epoch; job.valid = 1;
             }
         }
     }
@@ -1010,6 +1010,7 @@ __global__ __launch_bounds__(64) void k_am_decode(DevTables tb, DevBuffers db, c
             unsigned total = 8 * (AM_P1_LEN * 12 / 5);
             if (!job.rdbi) total += ma3 ? AM_P3_LEN_MA3 * 12 / 5 : AM_P3_LEN_MA1 * 3 / 2;
             db.am_ber[(size_t)s * db.p1_slots + job.slot] = (float)atomicAdd(&job.errors, 0u) / (float)total;
+            job.pad = db.l2_am_ring ? (job.rdbi ? 0xff : 0x1ff) : 0;      // frames k_l2_index_am_window owes their index
             job.valid = 0;
         }
     }
@@ -1018,6 +1019,7 @@ __global__ __launch_bounds__(64) void k_am_decode(DevTables tb, DevBuffers db, c
 void launch_am_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, int l2_feedback, hipStream_t st)
 {
     hipLaunchKernelGGL(k_am_decode, dim3(17, nstreams), dim3(64), 0, st, tb, db, stream_ids, parity, lane_id, l2_feedback);
+    if (db.l2_am_ring) launch_l2_index_am_window(db, nstreams, stream_ids, parity, st);
 }
 
 void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int l2_feedback, int pipeline_parity, int slot)
@@ -1025,7 +1027,10 @@ void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, con
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_am_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AmBlockSmem)); attr_set = true; }
     hipLaunchKernelGGL(k_am_block, dim3(nstreams), dim3(256), sizeof(AmBlockSmem), st, tb, db, stream_ids, pipeline_parity >= 0 ? 1 : 0, pipeline_parity, slot);
-    if (pipeline_parity < 0) hipLaunchKernelGGL(k_am_viterbi, dim3(2, nstreams), dim3(64), 0, st, tb, db, stream_ids, l2_feedback);
+    if (pipeline_parity < 0) {
+        hipLaunchKernelGGL(k_am_viterbi, dim3(2, nstreams), dim3(64), 0, st, tb, db, stream_ids, l2_feedback);
+        if (db.l2_am_ring) launch_l2_index_am_step(db, nstreams, stream_ids, st);
+    }
     hipLaunchKernelGGL(k_am_interleave, dim3(nstreams), dim3(1024), 0, st, tb, db, stream_ids, pipeline_parity);
 }
 

@@ -253,6 +253,65 @@ void launch_l2_index_window(const DevBuffers &db, int nstreams, const int *strea
     hipLaunchKernelGGL(k_l2_index_window, dim3(nstreams), dim3(256), 0, st, db, stream_ids, parity);
 }
 
+// P3 / P4 frames of the extended sidebands: k_px_decode leaves PxJob::pad = 1 on every frame it decoded in this window
+__global__ __launch_bounds__(256) void k_l2_index_px_window(DevBuffers db, const int *ids, int parity)
+{
+    __shared__ L2IndexSmem sm;
+    const int s = stream_of(ids, blockIdx.y), j = blockIdx.x, ch = j & 1;   // j = pair slot * 2 + channel
+    PxJob &job = db.px_job[((size_t)s * NWIN + parity) * 16 + j];
+    if (job.pad != 1) return;                                  // block-uniform (fresh entries are 0xff-filled)
+    const size_t fr = ((size_t)s * db.px_slots + job.slot) * 2 + ch;
+    l2_index_frame(sm, db.px_ring + fr * PX_WORDS, (unsigned)job.len, db.l2_px_ring[fr], nullptr);
+    if (threadIdx.x == 0) job.pad = 0;
+}
+
+void launch_l2_index_px_window(const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_l2_index_px_window, dim3(16, nstreams), dim3(256), 0, st, db, stream_ids, parity);
+}
+
+// AM: frame r = 0..7 is the P1 frame of block r (3750 bits), 8 the P3 frame (24000 / 30000 bits) of the L1 frame in `slot`
+__device__ inline void l2_index_am_frame(L2IndexSmem &sm, const DevBuffers &db, int s, int slot, int r, bool ma3)
+{
+    const uint32_t *words = db.p1_ring + ((size_t)s * db.p1_slots + slot) * P1_WORDS + (r < 8 ? r * AM_P1_WORDS : AM_P3_WORD0);
+    const unsigned nbits = r < 8 ? (unsigned)AM_P1_LEN : (unsigned)(ma3 ? AM_P3_LEN_MA3 : AM_P3_LEN_MA1);
+    l2_index_frame(sm, words, nbits, db.l2_am_ring[((size_t)s * db.p1_slots + slot) * 9 + r], nullptr);
+}
+
+// window pipeline: the last k_am_decode of an L1 frame leaves AmJob::pad = mask of the frames it produced
+__global__ __launch_bounds__(256) void k_l2_index_am_window(DevBuffers db, const int *ids, int parity)
+{
+    __shared__ L2IndexSmem sm;
+    const int s = stream_of(ids, blockIdx.y), r = blockIdx.x;
+    AmJob &job = db.am_job[(size_t)s * NWIN + parity];
+    if (!((job.pad >> r) & 1)) return;                         // block-uniform
+    l2_index_am_frame(sm, db, s, job.slot, r, job.psmi == AM_MA3);
+    if (threadIdx.x == 0) atomicAnd(&job.pad, ~(1 << r));
+}
+
+void launch_l2_index_am_window(const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_l2_index_am_window, dim3(9, nstreams), dim3(256), 0, st, db, stream_ids, parity);
+}
+
+// in order: what k_am_viterbi delivered in this step (same conditions)
+__global__ __launch_bounds__(256) void k_l2_index_am_step(DevBuffers db, const int *ids)
+{
+    __shared__ L2IndexSmem sm;
+    const int s = stream_of(ids, blockIdx.y);
+    const StreamState &st = db.state[s];
+    const AmStream &am = db.am[s];
+    if (!st.active || am.dec_bc < 0 || am.am_diversity_wait != 0) return;      // block-uniform
+    const int bc = am.dec_bc;
+    if (blockIdx.x == 1 && (bc != 7 || am.dec_rdbi)) return;
+    l2_index_am_frame(sm, db, s, am.frame_slot, blockIdx.x == 0 ? bc : 8, am.dec_psmi == AM_MA3);
+}
+
+void launch_l2_index_am_step(const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_l2_index_am_step, dim3(2, nstreams), dim3(256), 0, st, db, stream_ids);
+}
+
 void launch_l2_index(const L2Job *jobs, int njobs, nrsc5hip_l2_frame *frames, uint8_t *bytes_out, long long stride, hipStream_t st)
 {
     if (njobs < 1) return;

@@ -666,12 +666,13 @@ __global__ __launch_bounds__(64) void k_px_decode(DevTables tb, DevBuffers db, c
     __threadfence_block();
     __syncthreads();
     for (int w = threadIdx.x; w < len / 32; w += 64) out[w] ^= tb.scr_p1[w];
-    if (threadIdx.x == 0) job.rec = -1;
+    if (threadIdx.x == 0) { job.pad = db.l2_px_ring ? 1 : 0; job.rec = -1; }     // pad: k_l2_index_px_window owes this frame its index
 }
 
 void launch_px_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st)
 {
     hipLaunchKernelGGL(k_px_decode, dim3(16, nstreams), dim3(64), 0, st, tb, db, stream_ids, parity, lane_id);
+    if (db.l2_px_ring) launch_l2_index_px_window(db, nstreams, stream_ids, parity, st);
 }
 
 }  // namespace nrsc5

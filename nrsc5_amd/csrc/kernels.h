@@ -76,6 +76,8 @@ struct DevBuffers {
     int8_t *am_pids_stage;           // [S][NWIN][8][240]  window pipeline: PIDS trellis inputs awaiting k_am_decode
     int *am_pids_rec;                // [S][NWIN][8]       record index of each staged PIDS frame, -1 = empty
     nrsc5hip_l2_frame *l2_ring;      // [S][p1_slots]  engine option l2_index: audio-transport index of each P1 frame slot (else null)
+    nrsc5hip_l2_frame *l2_px_ring;   // [S][px_slots][2]  same for the P3 / P4 frames of the extended sidebands (else null)
+    nrsc5hip_l2_frame *l2_am_ring;   // [S][p1_slots][9]  same for the 8 P1 frames + the P3 frame of each AM L1 frame slot (else null)
 };
 
 // ---- K1 -------------------------------------------------------------------------------
@@ -122,6 +124,11 @@ struct L2Job { const uint32_t *words; int nbits; int pad; };        // packed fr
 void launch_l2_index(const L2Job *jobs, int njobs, nrsc5hip_l2_frame *frames, uint8_t *bytes_out, long long stride, hipStream_t st);
 // engine option l2_index: index the P1 frames k_p1_traceback finished in decode window `parity` (called by launch_p1_viterbi)
 void launch_l2_index_window(const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st);
+// ... the P3 / P4 frames k_px_decode just finished (called by launch_px_decode), and an AM L1 frame's frames: window pipeline
+// (called by launch_am_decode) or in order (called by launch_am_step: the frames k_am_viterbi delivered this step)
+void launch_l2_index_px_window(const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st);
+void launch_l2_index_am_window(const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st);
+void launch_l2_index_am_step(const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
 
 // ---- stage-level entry points (parity tests) ---------------------------------------------------
 void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st, int phases = 3);

@@ -127,6 +127,8 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.nrsc5hip_stage_l2_index.argtypes = [vp, vp, ci, ci, vp, vp, ctypes.c_longlong]
     lib.nrsc5hip_l2_frame_get.argtypes = [vp, ci, ci, vp]
     lib.nrsc5hip_batch_fetch_l2.argtypes = [vp, ci, vp, vp]
+    lib.nrsc5hip_batch_fetch_l2_px.argtypes = [vp, ci, vp, vp]
+    lib.nrsc5hip_batch_fetch_l2_am.argtypes = [vp, ci, vp, vp]
     lib.nrsc5hip_hdc_create.argtypes = [ci, ctypes.POINTER(vp)]
     lib.nrsc5hip_hdc_destroy.argtypes = [vp]
     lib.nrsc5hip_hdc_destroy.restype = None
@@ -150,7 +152,7 @@ EXPORTED_SYMBOLS = [
     "nrsc5hip_batch_append_cu8", "nrsc5hip_batch_append_cs16", "nrsc5hip_batch_process", "nrsc5hip_drain",
     "nrsc5hip_p1_frame_packed", "nrsc5hip_p1_frame_bits", "nrsc5hip_batch_fetch", "nrsc5hip_unpack_bits",
     "nrsc5hip_stage_halfband_fm_cu8", "nrsc5hip_stage_fft2048", "nrsc5hip_stage_viterbi_k7", "nrsc5hip_debug_fetch",
-    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_batch_fetch_view",
+    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_batch_fetch_view", "nrsc5hip_batch_fetch_l2_px", "nrsc5hip_batch_fetch_l2_am",
     "nrsc5hip_stream_set_mode", "nrsc5hip_am_frame_bits", "nrsc5hip_stage_viterbi_k9", "nrsc5hip_px_frame_bits",
     "nrsc5hip_batch_fetch_px", "nrsc5hip_debug_fetch_px", "nrsc5hip_stage_viterbi_k9_bench",
     "nrsc5hip_l2_index", "nrsc5hip_stage_l2_index", "nrsc5hip_l2_frame_get", "nrsc5hip_batch_fetch_l2",
@@ -365,6 +367,18 @@ class Engine:
         """[nstreams][p1_slots] L2Frame ctypes array for streams 0..nstreams-1."""
         out = ((L2Frame * self.p1_slots) * nstreams)()
         self._check(self.lib.nrsc5hip_batch_fetch_l2(self._h, nstreams, None, out))
+        return out
+
+    def batch_fetch_l2_px(self, nstreams: int):
+        """[nstreams][8 * p1_slots][2] L2Frame array: pipeline index of the P3 ([slot][0]) / P4 ([slot][1]) frames."""
+        out = (((L2Frame * 2) * (8 * self.p1_slots)) * nstreams)()
+        self._check(self.lib.nrsc5hip_batch_fetch_l2_px(self._h, nstreams, None, out))
+        return out
+
+    def batch_fetch_l2_am(self, nstreams: int):
+        """[nstreams][p1_slots][9] L2Frame array: pipeline index of the 8 P1 frames + the P3 frame of every AM L1 frame slot."""
+        out = (((L2Frame * 9) * self.p1_slots) * nstreams)()
+        self._check(self.lib.nrsc5hip_batch_fetch_l2_am(self._h, nstreams, None, out))
         return out
 
     def stage_l2_index(self, frames_bits: np.ndarray, want_bytes: bool = True):

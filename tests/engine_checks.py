@@ -605,15 +605,17 @@ def _l2_job_bits(E, job):
 
 def check_l2_index_end_to_end(lib, oracle, am=False, mode="MP3", p1_async=False):
     """IQ -> decoded frames -> nrsc5hip_l2_index on the frames still in HBM == the oracle's index of the same frames;
-    for the FM signal source every audio packet the transmitter built comes back with a good CRC-8."""
+    for the FM signal source every audio packet the transmitter built comes back with a good CRC-8.  The engine runs with the
+    l2_index option, so the same frames were also indexed inside the pipeline (P1, P3 / P4 and AM rings): those entries must be
+    the same structs."""
     from nrsc5_amd import synth_am
     if am:
         cap = synth_am.am_ma1_capture(9, seed=31, cfo_hz=2.0, offset=300)
-        E = eng.Engine(max_streams=1, q15_capacity=400000, record_capacity=512, p1_slots=16, lib_path=lib, am_enable=True, p1_async=p1_async)
+        E = eng.Engine(max_streams=1, q15_capacity=400000, record_capacity=512, p1_slots=16, lib_path=lib, am_enable=True, p1_async=p1_async, l2_index=True)
         E.set_mode(0, eng.MODE_AM)
     else:
         cap = synth.fm_mp1_capture(3, seed=52, cfo_hz=-40.0, offset=500, snr_db=25, mode=mode)
-        E = eng.Engine(max_streams=1, q15_capacity=cap.iq.size // 4 + 200000, record_capacity=512, p1_slots=8, lib_path=lib, p1_async=p1_async)
+        E = eng.Engine(max_streams=1, q15_capacity=cap.iq.size // 4 + 200000, record_capacity=512, p1_slots=8, lib_path=lib, p1_async=p1_async, l2_index=True)
     common.run_engine_streaming(E, 0, cap.iq, chunk=32768 * 8)
     recs = E.drain(0)
     jobs = eng.l2_jobs_from_records(0, recs, eng.MODE_AM if am else eng.MODE_FM)
@@ -628,6 +630,15 @@ def check_l2_index_end_to_end(lib, oracle, am=False, mode="MP3", p1_async=False)
         if not am and job[2] == eng.L2_FM_P1:
             assert gi["n_pdu"] == 1 and gi["pdus"][0]["nop"] == 32 and gi["pdus"][0]["crc_bad_lo"] == 0 and gi["lost_sync"] == 0
     assert len(kinds) >= 2, kinds
+    # the pipeline's own index of the same frames (engine option l2_index)
+    ring_p1, ring_px = E.batch_fetch_l2(1), E.batch_fetch_l2_px(1)
+    ring_am = E.batch_fetch_l2_am(1) if am else None
+    fused = set()
+    for (stream, slot, kind, which, nbits), (gi, _) in zip(jobs, got):
+        fr = ring_p1[0][slot] if kind == eng.L2_FM_P1 else ring_px[0][slot][which] if kind == eng.L2_FM_PX else ring_am[0][slot][which]
+        assert eng.l2_frame_to_dict(fr) == gi, ("fused", kind, slot, which)
+        fused.add(kind)
+    assert fused == ({eng.L2_AM} if am else {eng.L2_FM_P1, eng.L2_FM_PX}), fused
     # argument errors are reported, not executed
     for bad in ((0, 99, eng.L2_FM_P1, 0, 146176), (0, 0, 7, 0, 146176), (0, 0, eng.L2_FM_PX, 2, 4608), (0, 0, eng.L2_AM, 8, 3750)):
         try:

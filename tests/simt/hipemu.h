@@ -132,6 +132,7 @@ template <typename T> static inline T atomicMax(T *p, T v) { T o = *p; *p = std:
 template <typename T> static inline T atomicCAS(T *p, T c, T v) { T o = *p; if (o == c) *p = v; return o; }
 template <typename T> static inline T atomicMin(T *p, T v) { T o = *p; *p = std::min(o, v); return o; }
 template <typename T> static inline T atomicOr(T *p, T v) { T o = *p; *p = o | v; return o; }
+template <typename T> static inline T atomicAnd(T *p, T v) { T o = *p; *p = o & v; return o; }
 template <typename T> static inline T atomicExch(T *p, T v) { T o = *p; *p = v; return o; }
 static inline long long clock64() { return 0; }
 static inline void __threadfence() {}

@@ -143,6 +143,8 @@ def test_emu_l2_index_every_branch(emu_lib, oracle):
 def test_emu_l2_index_end_to_end(emu_lib, oracle):
     ec.check_l2_index_end_to_end(emu_lib, oracle, am=True)
     ec.check_l2_index_end_to_end(emu_lib, oracle, am=False, mode="MP3")
+    ec.check_l2_index_end_to_end(emu_lib, oracle, am=True, p1_async=True)          # fused index behind the deferred decodes
+    ec.check_l2_index_end_to_end(emu_lib, oracle, am=False, mode="MP11", p1_async=True)
 
 
 def test_emu_l2_index_fused_into_decode(emu_lib, oracle):
