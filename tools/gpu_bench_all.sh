@@ -1,7 +1,10 @@
 #!/bin/bash
-# every bench workload once (same JSON schema), then the PMC traffic of the headline workload
+# the PMC traffic of the headline workload first (so that the bench lines carry the counters of this very source), then every
+# bench workload once (same JSON schema)
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
 TAG=${1:-r02}
+bash tools/gpu_pmc.sh fm > gpurun_out/${TAG}_pmc.log 2>&1; tail -3 gpurun_out/${TAG}_pmc.log
+cp gpurun_out/traffic_fm.json profiles/traffic_latest.json
 for wl in fm am-cs16 am-cu8 mixed; do
   ( time timeout 400 python bench.py --workload $wl ) > gpurun_out/${TAG}_bench_${wl}.log 2>&1; echo "$wl rc=$?"
   grep "^{" gpurun_out/${TAG}_bench_${wl}.log | tail -1 > gpurun_out/${TAG}_bench_${wl}.json
@@ -17,4 +20,3 @@ except Exception as ex:
     print("no json", ex); print(open(f"gpurun_out/{sys.argv[1]}_bench_{sys.argv[2]}.log").read()[-1500:])
 PY
 done
-bash tools/gpu_pmc.sh fm; cat gpurun_out/traffic_fm.json | head -40
