@@ -149,8 +149,9 @@ void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, 
     hipLaunchKernelGGL(k_p1_deint, dim3(32, nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, lane_id);
     // wave priorities (s_setprio): the forward pass is long-running background work next to the step chain (priority 3);
     // raising it to 1 or 2 was measured again with the 6-instruction trellis: no gain (profiles/r02_naux.txt).  The traceback is
-    // the short kernel at the end of each decode chain: let it through (+1.5 %).
-    constexpr int prio_fwd = 0, prio_tb = 3;
+    // the short kernel at the end of each decode chain: one step above the trellis waves, but below the chain -- at the chain's
+    // own level (3) its 4096 waves per launch sit on the serial Costas loops of k_sync (profiles/r02_ab_prio_tb.txt).
+    constexpr int prio_fwd = 0, prio_tb = 1;
     hipLaunchKernelGGL(k_p1_forward, dim3((nstreams + FWD_WAVES - 1) / FWD_WAVES), dim3(64 * FWD_WAVES), 0, st, tb, db, stream_ids, parity, lane_id, prio_fwd, nstreams);
     hipLaunchKernelGGL(k_p1_traceback, dim3(nstreams), dim3(TB_THREADS), traceback_smem(P1_LEN), st, tb, db, stream_ids, parity, lane_id, l2_mode, prio_tb);
     if (db.l2_ring) launch_l2_index_window(db, nstreams, stream_ids, parity, st);

@@ -1,0 +1,24 @@
+"""Shader cycles per phase of k_sync for stream 0 INSIDE the 256-stream batch pass (decode streams running beside the chain).
+gpurun -- 'python tools/gpu_sync_phases_batch.py'"""
+import os, sys, types
+os.environ["NRSC5HIP_SYNC_PHASES"] = "1"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+sys.argv = ["bench.py", "--no-cpu-baseline"]
+args = bench.parse()
+dev = torch.device("cuda", 0)
+W = bench.Fm(args, dev, 0, list(range(256)))
+W.one_pass()
+W.E.debug_sync_phases()                                        # read + reset? (accumulates: take the difference)
+c0 = W.E.debug_sync_phases()
+steps, _ = W.one_pass()
+c1 = W.E.debug_sync_phases()
+names = ["sync_adjust", "costas", "coarse", "samperr/angle", "equalise+MER", "soft bits", "PIDS gather", "finish"]
+tot = 0
+for nm, a, b in zip(names, c0, c1):
+    d = (b - a) / 224.0
+    tot += d
+    print(f"{nm:16s} {d:9.0f} cycles/block")
+print(f"{'total':16s} {tot:9.0f} cycles/block over {steps} steps")
