@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         const int bc = st.bc;
         // The block that achieves lock keeps equalising with the partition count of the PREVIOUS service mode (computed at
         // the top of sync_process_fm, sync.c:343-358) but already routes PX soft bits by the new one (sync.c:537-596).
-        const int ppb_px = partitions_for_psmi(st.psmi);
+        const int ppb_px = routed_partitions_for_psmi(st.psmi);
         const bool px_on = ppb_px > PM_PART && (st.px_started || (bc & 1) == 0);   // decode_push_px1/2 (decode.c:393-437)
         for (int k = tid; k < nref * NSYM; k += 256) {
             const int r = k / NSYM, n = k % NSYM;

@@ -7,8 +7,8 @@
 
 namespace nrsc5 {
 
-// PSMI -> partitions per sideband (sync.c:29-35, 343-358)
-__device__ inline int partitions_for_psmi(int psmi)
+// PSMI -> compatibility mode (Table 6-4 of 1011s, sync.c:29-35)
+__device__ inline int compat_mode_for_psmi(int psmi)
 {
     const int m6 = psmi & 63, low = m6 & 15;
     // compatibility_mode[]: 0,1,2,3,1,5,6,5,6,1,2,11,1,5,6,5 then the same 16 entries repeating with [16k] = 6;
@@ -16,10 +16,28 @@ __device__ inline int partitions_for_psmi(int psmi)
     constexpr unsigned long long TAB16 = 0x5651B21656513210ull;
     int mode = (int)((TAB16 >> (4 * low)) & 15ull);
     if (low == 0 && m6 != 0) mode = 6;
-    switch (mode) {
+    return mode;
+}
+
+// ... -> partitions per sideband that sync_process_fm tracks, equalises and measures (sync.c:343-358)
+__device__ inline int partitions_for_psmi(int psmi)
+{
+    switch (compat_mode_for_psmi(psmi)) {
     case 2: return 11;
     case 3: return 12;
     case 5: case 6: case 11: return 14;
+    default: return 10;
+    }
+}
+
+// ... -> partitions per sideband whose soft bits are ROUTED (primary main + PX1 / PX2, sync.c:537-596): the compatibility modes
+// 5 and 6 equalise 14 partitions like MP11 but the reference hands none of their extended partitions to the decoder
+__device__ inline int routed_partitions_for_psmi(int psmi)
+{
+    switch (compat_mode_for_psmi(psmi)) {
+    case 2: return 11;
+    case 3: return 12;
+    case 11: return 14;
     default: return 10;
     }
 }
@@ -33,7 +51,7 @@ __device__ inline void prepare_block(const DevBuffers &db, StreamState &st, int 
 {
     if (st.active) return;                                     // already prepared (fused into the previous k_sync)
     if (st.sync_state != SYNC_FINE) atomicAdd(&db.counters[1], 1);   // host: keep launching acquisition
-    if (st.sync_state != SYNC_FINE || partitions_for_psmi(st.psmi) > PM_PART) atomicAdd(&db.counters[2], 1);   // ... and the PX kernels
+    if (st.sync_state != SYNC_FINE || routed_partitions_for_psmi(st.psmi) > PM_PART) atomicAdd(&db.counters[2], 1);   // ... and the PX kernels
     st.active = (window_ready(st) && (st.sync_state == SYNC_FINE || acq_ran)) ? 1 : 0;
     if (!st.active) {
         if (window_ready(st)) atomicAdd(&db.counters[0], 1);   // work is pending: the host must keep stepping

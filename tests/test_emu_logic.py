@@ -75,6 +75,13 @@ def test_emu_extended_sidebands_mp11(emu_lib, oracle):
     ec.check_oracle_end_to_end(emu_lib, oracle, kw, p1_async=True)
 
 
+def test_emu_compatibility_modes_5_6(emu_lib, oracle):
+    """PSMI 5 / 7 (compatibility modes 5 / 5): 14 partitions equalised and measured, no extended partition routed."""
+    for mode in ("MP5", "PSMI7"):
+        log = ec.check_oracle_end_to_end(emu_lib, oracle, dict(n_frames=0, n_blocks=50, seed=41, mode=mode, cfo_hz=35.0, offset=420, snr_db=22))
+        assert not [v for k, v in log if k == "frame" and v["lc"] != 0] and any(k == "mer" for k, _ in log)
+
+
 def test_emu_extended_sidebands_mp2(emu_lib, oracle):
     ec.check_oracle_end_to_end(emu_lib, oracle, dict(n_frames=0, n_blocks=40, seed=6, mode="MP2", cfo_hz=-20.0, offset=777, snr_db=20))
 

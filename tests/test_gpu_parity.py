@@ -192,6 +192,15 @@ def test_gpu_extended_sidebands_oracle(hip_lib, oracle, mode, kw, p1_async):
     assert (mode != "MP11") or sum(1 for k, v in log if k == "frame" and v["lc"] == 2) >= 2
 
 
+@pytest.mark.parametrize("mode", ["MP5", "MP6"])
+@pytest.mark.parametrize("p1_async", [False, True])
+def test_gpu_compatibility_modes_5_6_oracle(hip_lib, oracle, mode, p1_async):
+    """PSMI 5 / 6 (sync.c:343-358 maps them to 14 partitions): equalised and measured like MP11, nothing routed to PX1 / PX2."""
+    log = ec.check_oracle_end_to_end(hip_lib, oracle, dict(n_frames=0, n_blocks=50, seed=41, mode=mode, cfo_hz=35.0, offset=420, snr_db=22), p1_async=p1_async)
+    assert not [v for k, v in log if k == "frame" and v["lc"] != 0] and any(k == "mer" for k, _ in log)
+    assert sum(1 for k, v in log if k == "frame" and v["lc"] == 0) >= 1
+
+
 # ---- AM (config 5) --------------------------------------------------------------------------------------------------
 def test_gpu_am_viterbi_k9_exact(hip_lib, oracle):
     ec.check_viterbi_k9(hip_lib, oracle, lens=(80, 3750, 24000, 30000), frames=4)

@@ -121,6 +121,20 @@ def test_oracle_extended_sidebands_bit_identical_to_reference(mode, kw, oracle, 
     assert len(px) >= (4 if mode == "MP11" else 2)
 
 
+@pytest.mark.parametrize("mode", ["MP5", "MP6", "PSMI7"])
+def test_oracle_compatibility_modes_5_6_bit_identical_to_reference(mode, oracle, reflib):
+    """PSMI values whose compatibility mode is 5 or 6 (Table 6-4, sync.c:29-35): the reference tracks and equalises 14
+    partitions per sideband (MER over all of them) but routes none of the extended ones to the decoder -- no P3 / P4 frames."""
+    from oracle import ref, port
+    cap = synth.fm_mp1_capture(0, mode=mode, n_blocks=50, seed=41, cfo_hz=35.0, offset=420, snr_db=22)
+    rl, _, _ = reflib.run(cap.iq, taps=ref.TAP_SOFT)
+    ol, _, _ = oracle.run(cap.iq, taps=port.TAP_SOFT)
+    assert not common.compare_logs(rl, ol, rtol=0.0, skip_kinds=("hdc",))
+    assert [v["psmi"] for k, v in rl if k == "sync"] == [synth.MODES[mode][0]]
+    assert not [v for k, v in rl if k == "frame" and v["lc"] != 0]
+    assert sum(1 for k, v in rl if k == "frame" and v["lc"] == 0) >= 1 and any(k == "mer" for k, _ in rl)
+
+
 @pytest.mark.parametrize("name", ["fm_mp11_cs16", "fm_mp2_cu8"])
 def test_golden_px_frames_equal_transmitted_truth(name):
     g = _golden(name)
