@@ -413,7 +413,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
                 if (hipMemset(db.l2_am_ring, 0, nam * sizeof(nrsc5hip_l2_frame)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
             }
         }
-        db.am = nullptr; db.am_sym = nullptr; db.am_q = nullptr; db.am_vit = nullptr; db.am_dec = nullptr; db.am_job = nullptr; db.am_ber = nullptr; db.am_pids_stage = nullptr; db.am_pids_rec = nullptr; db.am_nvit = 1;
+        db.am = nullptr; db.am_sym = nullptr; db.am_q = nullptr; db.am_vit = nullptr; db.am_dec = nullptr; db.am_job = nullptr; db.am_ckpt = nullptr; db.am_ber = nullptr; db.am_pids_stage = nullptr; db.am_pids_rec = nullptr; db.am_nvit = 1;
         if (cfg->am_enable) {
             if ((rc = dev_alloc(e, &db.am, S))) break;
             if ((rc = dev_alloc(e, &db.am_sym, S * 4 * AM_SYMS))) break;
@@ -424,6 +424,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             if ((rc = dev_alloc(e, &db.am_dec, ndec * S * (size_t)(8 * AM_DEC_P1 + AM_DEC_P3)))) break;
             if ((rc = dev_alloc(e, &db.am_job, S * NWIN))) break;
             if ((rc = dev_alloc(e, &db.am_ber, S * (size_t)cfg->p1_slots))) break;
+            if (cfg->p1_async && cfg->l2_feedback && (rc = dev_alloc(e, &db.am_ckpt, S * NWIN * 8))) break;      // replay checkpoints, one per delivered P1 PDU
             if ((rc = dev_alloc(e, &db.am_pids_stage, S * NWIN * 8 * (size_t)(3 * PIDS_LEN)))) break;
             if ((rc = dev_alloc(e, &db.am_pids_rec, S * NWIN * 8))) break;
             if (hipMemset(db.am_pids_rec, 0xff, S * NWIN * 8 * sizeof(int)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
@@ -648,35 +649,54 @@ static int run_steps_am(nrsc5hip_engine *e, int n, const int *ids_dev, int max_s
 {
     nrsc5hip_engine::Lane &ln = e->lanes[0];
     const bool pipe = e->cfg.p1_async != 0;
+    const bool replay = ln.db.am_ckpt != nullptr;              // window pipeline with the on-device L2 feedback (k_replay.hip)
     int done = 0;
-    while (done < max_steps) {
-        HIPCHK(hipMemsetAsync(ln.counters_dev, 0, 4 * sizeof(int), ln.main));
-        int burst = 0;
-        for (; burst < check_every && done + burst < max_steps; burst++) {
-            const long long window = ln.am_step_count / 8;
-            const int parity = pipe ? (int)(window % NWIN) : -1, lane = (int)(window % e->naux_am);
-            if (pipe && (ln.am_step_count % 8) == 0 && ln.am_decoded_pending[parity]) {
-                HIPCHK(hipStreamWaitEvent(ln.main, ln.ev_decoded[parity], 0));   // the window that used these buffers NWIN windows ago
-                ln.am_decoded_pending[parity] = false;
+    for (;;) {
+        bool live = n > 0;
+        while (live && done < max_steps) {
+            HIPCHK(hipMemsetAsync(ln.counters_dev, 0, 4 * sizeof(int), ln.main));
+            int burst = 0;
+            for (; burst < check_every && done + burst < max_steps; burst++) {
+                const long long window = ln.am_step_count / 8;
+                const int parity = pipe ? (int)(window % NWIN) : -1, lane = (int)(window % e->naux_am);
+                if (pipe && (ln.am_step_count % 8) == 0 && ln.am_decoded_pending[parity]) {
+                    HIPCHK(hipStreamWaitEvent(ln.main, ln.ev_decoded[parity], 0));   // the window that used these buffers NWIN windows ago
+                    ln.am_decoded_pending[parity] = false;
+                }
+                { ProfScope p(e, NRSC5HIP_PROF_AM, ln.main); launch_am_step(e->tb, ln.db, n, ids_dev, ln.main, e->cfg.l2_feedback, parity, (int)(ln.am_step_count % 8), (int)window); }
+                if (pipe && (ln.am_step_count % 8) == 7) {
+                    hipStream_t ax = ln.aux[lane];
+                    HIPCHK(hipEventRecord(ln.ev_window[parity], ln.main));
+                    HIPCHK(hipStreamWaitEvent(ax, ln.ev_window[parity], 0));
+                    { ProfScope p(e, NRSC5HIP_PROF_AM_DECODE, ax); launch_am_decode(e->tb, ln.db, n, ids_dev, parity, lane, e->cfg.l2_feedback, ax); }
+                    HIPCHK(hipEventRecord(ln.ev_decoded[parity], ax));
+                    ln.am_decoded_pending[parity] = true;
+                }
+                ln.am_step_count++;
             }
-            { ProfScope p(e, NRSC5HIP_PROF_AM, ln.main); launch_am_step(e->tb, ln.db, n, ids_dev, ln.main, e->cfg.l2_feedback, parity, (int)(ln.am_step_count % 8)); }
-            if (pipe && (ln.am_step_count % 8) == 7) {
-                hipStream_t ax = ln.aux[lane];
-                HIPCHK(hipEventRecord(ln.ev_window[parity], ln.main));
-                HIPCHK(hipStreamWaitEvent(ax, ln.ev_window[parity], 0));
-                { ProfScope p(e, NRSC5HIP_PROF_AM_DECODE, ax); launch_am_decode(e->tb, ln.db, n, ids_dev, parity, lane, e->cfg.l2_feedback, ax); }
-                HIPCHK(hipEventRecord(ln.ev_decoded[parity], ax));
-                ln.am_decoded_pending[parity] = true;
+            if (replay && (ln.am_step_count % 8) == 0) {
+                // window boundary: take the first-header verdicts of the deferred decodes that have finished (the decode whose
+                // job slot the next window reuses must be among them)
+                const long long window = ln.am_step_count / 8;
+                const int parity = (int)(window % NWIN);
+                if (ln.am_decoded_pending[parity]) { HIPCHK(hipStreamWaitEvent(ln.main, ln.ev_decoded[parity], 0)); ln.am_decoded_pending[parity] = false; }
+                launch_rollback_am(ln.db, n, ids_dev, (int)window, e->verdict_lag, ln.main);
             }
-            ln.am_step_count++;
+            HIPCHK(hipMemcpyAsync(ln.counters_host, ln.counters_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, ln.main));
+            HIPCHK(hipStreamSynchronize(ln.main));
+            HIPCHK(hipGetLastError());
+            if (ln.counters_host[0] == 0) live = false;
+            else done += burst;
         }
+        { int rc = am_flush(e, ln, n, ids_dev); if (rc) return rc; }
+        if (!replay || done >= max_steps) break;
+        // every decode has finished: apply what is left of their verdicts; a rewound stream has work again
+        HIPCHK(hipMemsetAsync(ln.counters_dev, 0, 4 * sizeof(int), ln.main));
+        launch_rollback_am(ln.db, n, ids_dev, (int)(ln.am_step_count / 8), 0, ln.main);
         HIPCHK(hipMemcpyAsync(ln.counters_host, ln.counters_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, ln.main));
         HIPCHK(hipStreamSynchronize(ln.main));
-        HIPCHK(hipGetLastError());
-        if (ln.counters_host[0] == 0) break;
-        done += burst;
+        if (ln.counters_host[3] == 0) break;
     }
-    { int rc = am_flush(e, ln, n, ids_dev); if (rc) return rc; }
     HIPCHK(hipStreamSynchronize(ln.main));
     if (e->prof_on) prof_collect(e);
     if (steps_done) *steps_done = done;
@@ -988,7 +1008,7 @@ extern "C" int nrsc5hip_drain(nrsc5hip_engine *e, int stream, nrsc5hip_record *o
         if (n - n1 > 0) HIPCHK(hipMemcpy(out + n1, ring, (size_t)(n - n1) * sizeof(BlockRecord), hipMemcpyDeviceToHost));
     }
     e->drained[stream] += n;
-    if (e->db.ckpt) {                                          // replay: blocks that ran behind a failed P1 frame are void (k_replay.hip)
+    if (e->db.ckpt || e->db.am_ckpt) {                         // replay: blocks that ran behind a failed P1 frame are void (k_replay.hip)
         int m = 0;
         for (int k = 0; k < n; k++) if (!(out[k].flags & NRSC5HIP_REC_DISCARDED)) { if (m != k) out[m] = out[k]; m++; }
         n = m;
@@ -1506,7 +1526,7 @@ extern "C" int nrsc5hip_batch_fetch_view(nrsc5hip_engine *e, int nstreams, const
             FAIL(NRSC5HIP_EOVERFLOW, "stream %d: view needs an undrained, unwrapped record ring (%d records, capacity %d)", s, e->nblocks_host[s], e->db.rec_cap);
         int n = e->nblocks_host[s];
         e->drained[s] = n;
-        if (e->db.ckpt) {                                      // replay: squeeze the void records out, in place in the pinned buffer
+        if (e->db.ckpt || e->db.am_ckpt) {                     // replay: squeeze the void records out, in place in the pinned buffer
             BlockRecord *r = e->rec_host + (size_t)s * e->db.rec_cap;
             int m = 0;
             for (int k = 0; k < n; k++) if (!(r[k].flags & REC_DISCARDED)) { if (m != k) r[m] = r[k]; m++; }

@@ -387,6 +387,7 @@ struct AmBlockSmem {
     uint32_t pids_out[3];
     // block-uniform scalars produced by work-item 0
     int active, fine, samperr, ma3, refmask;
+    int deliver;                // replay: P1 PDU this block delivered (0..7), -1: none
     double theta, dtheta;
     float2 step270, step256;        // e^{i 270 dtheta}, e^{i 256 dtheta}
 };
@@ -478,11 +479,7 @@ __global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, c
     const bool ready = st.wr - st.rd >= AM_WIN;                 // block-uniform
     if (tid == 0) {
         am.dec_bc = -1; st.active = ready ? 1 : 0;
-        // late L2 feedback raised by a deferred decode (window pipeline): take it before this block, as input.c:172-188
-        if (const int req = ready ? st.force_none : 0) {       // requests of an earlier lock are stale (see k_sync)
-            if (st.sync_state == SYNC_FINE && req == st.fine_epoch + 1) st.sync_state = SYNC_NONE;
-            atomicCAS(&st.force_none, req, 0);
-        }
+        sm.deliver = -1;
     }
     __syncthreads();
     if (!ready) return;
@@ -800,13 +797,22 @@ __global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, c
             am.dec_bc = bc; am.dec_record = st.nblocks % db.rec_cap; am.dec_rdbi = am.rdbi; am.dec_psmi = st.psmi;
             if (bc == 0) {
                 am.am_errors = 0;
-                if (am.am_diversity_wait == 0) am.frame_slot = am.next_slot;
+                if (am.am_diversity_wait == 0) { am.frame_slot = am.next_slot; am.vit_parity = am.next_job; }
             }
             if (pipeline && am.am_diversity_wait == 0) {
                 // the frame's decodes run (or ran) on a decode stream from the trellis inputs of the previous L1 frame:
                 // this block only announces what decode_process_p1_p3_am delivers here (decode.c:507-554)
                 rec.flags |= REC_P1 | ((bc == 7 && !am.rdbi) ? (uint32_t)REC_P3 : 0u);
                 rec.p1_slot = am.frame_slot;
+                if (db.am_ckpt) {
+                    // frame_process judges this PDU's first header inside this very block (frame.c:535-540).  If the deferred
+                    // decode has already filed a failure, apply it now; else run on and let k_rollback_am rewind to the
+                    // checkpoint k_am_interleave takes at the end of this step (k_replay.hip)
+                    AmJob &dj = db.am_job[(size_t)s * NWIN + am.vit_parity];
+                    dj.deliver_abs[bc] = st.nblocks;
+                    sm.deliver = bc;
+                    if (atomicAdd(&dj.verdict[bc], 0) == 2) { dj.verdict[bc] = 3; st.sync_state = SYNC_NONE; rec.flags |= REC_LOST_SYNC; }
+                }
             }
             st.bc = (bc + 1) % 8;
         }
@@ -824,6 +830,20 @@ __global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, c
         rec.psmi = st.psmi; rec.cfo_wait = st.cfo_wait; rec.next_samperr = st.samperr;
         rec.prev_angle = st.prev_angle; rec.phase_re = (float)cos(th); rec.phase_im = (float)sin(th); rec.next_angle = 0.0f;
         st.nblocks++;
+    }
+    if (db.am_ckpt) {                                          // block-uniform: window pipeline with the on-device L2 feedback
+        // Replay checkpoint of a block that delivered a P1 PDU (k_replay.hip): the state as of now.  For block 7 the
+        // de-interleaver's bookkeeping (k_am_interleave, next) still belongs to the block: k_rollback_am adds it on restore.
+        __threadfence_block();
+        __syncthreads();
+        const int j = sm.deliver;
+        if (j >= 0) {
+            AmCkpt &ck = db.am_ckpt[((size_t)s * NWIN + am.vit_parity) * 8 + j];
+            const uint32_t *a = (const uint32_t *)&st, *b = (const uint32_t *)&am;
+            uint32_t *da = (uint32_t *)&ck.st, *dbp = (uint32_t *)&ck.am;
+            for (int k = tid; k < (int)(sizeof(StreamState) / 4); k += 256) da[k] = a[k];
+            for (int k = tid; k < (int)(sizeof(AmStream) / 4); k += 256) dbp[k] = b[k];
+        }
     }
 }
 
@@ -903,13 +923,10 @@ __device__ inline int8_t am_deint_one(uint2 e, const uint8_t *sym, uint8_t *q, i
     return bit ? 1 : -1;
 }
 
-__global__ __launch_bounds__(1024) void k_am_interleave(DevTables tb, DevBuffers db, const int *ids, int parity)
+__device__ inline void am_deinterleave_frame(const DevTables &tb, const DevBuffers &db, int s, int parity, int window)
 {
-    wave_set_priority_high();
-    const int s = stream_of(ids, blockIdx.x);
     const StreamState &st = db.state[s];
     AmStream &am = db.am[s];
-    if (!st.active || am.dec_bc != 7) return;                  // block-uniform
     const bool ma3 = am.dec_psmi == AM_MA3;
     const int tid = threadIdx.x;
     const int vslot = parity < 0 ? 0 : parity;                 // window pipeline: one set of trellis inputs per window in flight
@@ -935,10 +952,25 @@ __global__ __launch_bounds__(1024) void k_am_interleave(DevTables tb, DevBuffers
             am.next_slot = stw.p1_count % db.p1_slots; stw.p1_count++;
             if (parity >= 0) {
                 AmJob &job = db.am_job[(size_t)s * NWIN + parity];
-                job.slot = am.next_slot; job.psmi = am.dec_psmi; job.rdbi = am.dec_rdbi; job.errors = 0; job.done = 0; job.pad = 0; job.epoch = stw.fine_epoch; job.valid = 1;
+                job.slot = am.next_slot; job.psmi = am.dec_psmi; job.rdbi = am.dec_rdbi; job.errors = 0; job.done = 0; job.pad = 0; job.epoch = stw.fine_epoch;
+                for (int j = 0; j < 8; j++) { job.verdict[j] = 0; job.deliver_abs[j] = -1; }
+                job.window = window;
+                am.next_job = parity;
+                job.valid = 1;
             }
         }
     }
+}
+
+__global__ __launch_bounds__(1024) void k_am_interleave(DevTables tb, DevBuffers db, const int *ids, int parity, int window)
+{
+    wave_set_priority_high();
+    const int s = stream_of(ids, blockIdx.x);
+    const StreamState &st = db.state[s];
+    AmStream &am = db.am[s];
+    if (!st.active || am.dec_bc != 7) return;                  // block-uniform
+    const int tid = threadIdx.x;
+    am_deinterleave_frame(tb, db, s, parity, window);
 }
 
 // ---- window pipeline: all nine frames of an L1 frame decode concurrently on a decode stream ---------------------------
@@ -982,10 +1014,12 @@ __global__ __launch_bounds__(64) void k_am_decode(DevTables tb, DevBuffers db, c
             out[w] = (out[w] ^ tb.scr_p1[w]) & (w == AM_P1_WORDS - 1 ? (1u << (AM_P1_LEN & 31)) - 1u : 0xffffffffu);
         __threadfence_block();
         __syncthreads();
-        if (l2_feedback && threadIdx.x == 0) {                 // frame.c:535-540, applied by the next k_am_block of the stream
+        if (l2_feedback && threadIdx.x == 0) {                 // frame.c:535-540: file the verdict for the block that delivers this PDU
             L2Smem &l2 = *(L2Smem *)&k9;                       // the trellis scratch is dead by now
             l2_gf_init(l2);
-            if (!l2_first_header_ok_am(out, l2)) atomicMax(&db.state[s].force_none, job.epoch + 1);
+            const bool ok = l2_first_header_ok_am(out, l2);
+            __threadfence();
+            atomicExch(&job.verdict[role], ok ? 1 : 2);
         }
     } else {
         const int8_t *in = vit + AM_VIT;
@@ -1022,7 +1056,7 @@ void launch_am_decode(const DevTables &tb, const DevBuffers &db, int nstreams, c
     if (db.l2_am_ring) launch_l2_index_am_window(db, nstreams, stream_ids, parity, st);
 }
 
-void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int l2_feedback, int pipeline_parity, int slot)
+void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int l2_feedback, int pipeline_parity, int slot, int window)
 {
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_am_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AmBlockSmem)); attr_set = true; }
@@ -1031,7 +1065,7 @@ void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, con
         hipLaunchKernelGGL(k_am_viterbi, dim3(2, nstreams), dim3(64), 0, st, tb, db, stream_ids, l2_feedback);
         if (db.l2_am_ring) launch_l2_index_am_step(db, nstreams, stream_ids, st);
     }
-    hipLaunchKernelGGL(k_am_interleave, dim3(nstreams), dim3(1024), 0, st, tb, db, stream_ids, pipeline_parity);
+    hipLaunchKernelGGL(k_am_interleave, dim3(nstreams), dim3(1024), 0, st, tb, db, stream_ids, pipeline_parity, window);
 }
 
 // ---- stage-level entry: decode `nframes` independent K=9 frames (parity tests) ------------------------------------

@@ -68,6 +68,69 @@ __global__ __launch_bounds__(256) void k_rollback(DevBuffers db, const int *ids,
     }
 }
 
+// ---- AM ------------------------------------------------------------------------------------------------------------------
+// Every block of an AM L1 frame delivers one P1 PDU (decode_process_p1_p3_am, decode.c:507-554), each judged by frame_process
+// on its own, so the deferred decode of an L1 frame files eight verdicts (AmJob::verdict) and k_am_block keeps a checkpoint
+// per delivering block (DevBuffers::am_ckpt).  A verdict that is already there when its block runs is applied by k_am_block
+// itself; the others are taken here: the earliest failed PDU whose delivering block is still part of the stream's history wins.
+// As for FM nothing a speculated block produced is reused: frame slots and records are not rewound, the symbol matrices and the
+// diversity delay lines it touched are rewritten in full before the re-locked stream delivers again (am_diversity_wait = 4).
+__global__ __launch_bounds__(256) void k_rollback_am(DevBuffers db, const int *ids, int cur_window, int min_age)
+{
+    const int s = stream_of(ids, blockIdx.x);
+    StreamState &st = db.state[s];
+    AmStream &am = db.am[s];
+    BlockRecord *ring = db.records + (size_t)s * db.rec_cap;
+    __shared__ int sh_p, sh_j, sh_best;
+    const int tid = threadIdx.x;
+    if (tid == 0) { sh_best = 0x7fffffff; sh_p = -1; sh_j = 0; }
+    __syncthreads();
+    int mine = 0x7fffffff;
+    if (tid < NWIN * 8) {                                      // one work-item per (job, PDU)
+        const int p = tid >> 3, j = tid & 7;
+        AmJob &job = db.am_job[(size_t)s * NWIN + p];
+        if (cur_window - job.window >= min_age                 // min_age > 0: test hook, verdicts take effect late
+            && job.verdict[j] == 2 && job.deliver_abs[j] >= 0) {                   // failed, not applied yet, and delivered
+            job.verdict[j] = 3;                                                    // consumed
+            const int a = job.deliver_abs[j];
+            if (!(ring[a % db.rec_cap].flags & REC_DISCARDED)) { mine = a; atomicMin(&sh_best, a); }   // else: its block was rewound over already
+        }
+    }
+    __syncthreads();
+    if (tid < NWIN * 8 && mine != 0x7fffffff && mine == sh_best) { sh_p = tid >> 3; sh_j = tid & 7; }      // record indices are unique per stream
+    __syncthreads();
+    const int p = sh_p, j = sh_j;
+    if (p < 0) return;                                         // block-uniform
+    const AmCkpt &ck = db.am_ckpt[((size_t)s * NWIN + p) * 8 + j];
+    const int a = db.am_job[(size_t)s * NWIN + p].deliver_abs[j], n = st.nblocks;
+    for (int r = a + 1 + tid; r < n; r += 256) atomicOr(&ring[r % db.rec_cap].flags, (uint32_t)REC_DISCARDED);
+    if (tid < 31) st.fir_hist[tid] = ck.st.fir_hist[tid];
+    if (tid == 0) {
+        // tracking state as of the end of block a; the input side (wr, base, the 32:1 decimator's raw history) and the record /
+        // frame-slot counters keep their current values
+        st.rd = ck.st.rd;
+        st.prev_angle = ck.st.prev_angle; st.theta = ck.st.theta; st.keep_extra = ck.st.keep_extra; st.cfo = ck.st.cfo;
+        st.psmi = ck.st.psmi; st.cfo_wait = ck.st.cfo_wait; st.bc = ck.st.bc; st.samperr = ck.st.samperr; st.angle = ck.st.angle;
+        st.fine_epoch = ck.st.fine_epoch;
+        am.pli = ck.am.pli; am.hppi = ck.am.hppi; am.aabi = ck.am.aabi; am.rdbi = ck.am.rdbi; am.offset_history = ck.am.offset_history;
+        am.am_errors = ck.am.am_errors; am.am_diversity_wait = ck.am.am_diversity_wait;
+        am.q_head = j == 7 ? (ck.am.q_head + 1) % 3 : ck.am.q_head;       // block 7's checkpoint predates its de-interleaver pass (k_am_interleave)
+        am.frame_slot = ck.am.frame_slot; am.vit_parity = ck.am.vit_parity; am.next_job = ck.am.next_job;
+        am.dec_bc = -1;
+        st.sync_state = SYNC_NONE;                             // input_set_sync_state(NONE) at the end of block a
+        BlockRecord &rec = ring[a % db.rec_cap];
+        if (rec.state_after == SYNC_FINE) { rec.state_after = SYNC_NONE; rec.flags |= REC_LOST_SYNC; }
+        st.ndiscard += n - a - 1;
+        atomicAdd(&db.counters[3], 1);
+        atomicAdd(&db.counters[0], 1);                         // there is work again
+    }
+}
+
+void launch_rollback_am(const DevBuffers &db, int nstreams, const int *stream_ids, int cur_window, int min_age, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_rollback_am, dim3(nstreams), dim3(256), 0, st, db, stream_ids, cur_window, min_age);
+}
+
 void launch_rollback(const DevBuffers &db, int nstreams, const int *stream_ids, int cur_window, int min_age, hipStream_t st)
 {
     hipLaunchKernelGGL(k_rollback, dim3(nstreams), dim3(256), 0, st, db, stream_ids, cur_window, min_age);

@@ -72,6 +72,8 @@ struct DevBuffers {
     int am_nvit;
     unsigned long long *am_dec;      // [am_ndec][S][8 * AM_DEC_P1 + AM_DEC_P3]  survivor decisions (one set per decode stream)
     AmJob *am_job;                   // [S][NWIN]
+    AmCkpt *am_ckpt;                 // [S][NWIN][8]  replay: state after the block that delivered P1 PDU j of the job's frame; null unless
+                                     // p1_async && l2_feedback
     float *am_ber;                   // [S][p1_slots]  window pipeline: BER of the L1 frame in each ring slot
     int8_t *am_pids_stage;           // [S][NWIN][8][240]  window pipeline: PIDS trellis inputs awaiting k_am_decode
     int *am_pids_rec;                // [S][NWIN][8]       record index of each staged PIDS frame, -1 = empty
@@ -98,6 +100,7 @@ void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, cons
 void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, int window, hipStream_t st);
 // replay (k_replay.hip): apply the first-header verdicts of finished deferred P1 decodes -- rewind the stream to the failed frame
 void launch_rollback(const DevBuffers &db, int nstreams, const int *stream_ids, int cur_window, int min_age, hipStream_t st);
+void launch_rollback_am(const DevBuffers &db, int nstreams, const int *stream_ids, int cur_window, int min_age, hipStream_t st);
 void launch_pids_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int nslots, hipStream_t st);
 // extended sidebands: interleaver IV for streams whose block pair just completed (after k_sync), and the staged P3/P4 decodes
 void launch_px_deint(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, hipStream_t st);
@@ -110,7 +113,8 @@ void launch_am_decimate_cu8(const DevTables &tb, const DevBuffers &db, int nstre
                             const uint8_t *iq_base, long long iq_stride, const unsigned *nbytes, unsigned max_nbytes, hipStream_t st);
 // one block step: acquire (or track) -> 2 x 32 FFT-256 -> sync_process_am -> PIDS; then this block's P1 / P3 decodes
 // and, after block 7, the bit de-interleaver of the finished L1 frame
-void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int l2_feedback = 0, int pipeline_parity = -1, int slot = 0);
+void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int l2_feedback = 0, int pipeline_parity = -1, int slot = 0,
+                    int window = 0);
 // entry of the AM de-interleave tables: x = cell | bit << 13 | matrix << 16 | delayed << 18 | punctured << 19 | queue << 20, y = index in the delay line
 constexpr unsigned AMT_DELAYED = 1u << 18, AMT_PUNCT = 1u << 19;
 // window pipeline: the 8 P1 frames and the P3 frame of every L1 frame whose de-interleave happened in window `parity`

@@ -125,7 +125,7 @@ struct StreamState {
     // bookkeeping
     int nblocks;                // processed blocks so far (record index)
     int p1_count;               // P1 frames produced so far
-    int force_none;             // AM window pipeline: deferred L2 feedback, fine_epoch + 1 of the P1 frame whose first header failed (0 = none)
+    int force_none;             // (unused; kept for layout stability of the debug tools)
     int fine_epoch;             // number of transitions into SYNC_FINE so far: a request from an earlier lock is stale
     // per-step scratch written by k_prepare / acquisition
     int active;                 // this step processes a block for this stream
@@ -171,10 +171,19 @@ struct AmStream {
     int dec_rdbi, dec_psmi;
     int frame_slot;             // slot of the frame ring that receives this L1 frame's P1/P3 frames
     int next_slot;              // slot assigned (by the de-interleaver) to the frame whose trellis inputs it just produced
-    int vit_parity;             // in-order mode: always 0; window pipeline: vit buffer of the frame being delivered
+    int vit_parity;             // window pipeline: decode job (window parity) of the L1 frame being delivered
+    int next_job;               // ... and of the frame whose trellis inputs the de-interleaver just produced
 };
 
 // window pipeline: one L1 frame's worth of decodes (8 x P1 + P3) handed to k_am_decode
-struct AmJob { int valid, slot, psmi, rdbi; unsigned errors; int done; int epoch; int pad; };
+struct AmJob {
+    int valid, slot, psmi, rdbi; unsigned errors; int done; int epoch; int pad;
+    // replay (window pipeline + l2_feedback): verdict of frame_process's first-header check for each of the frame's eight P1 PDUs
+    // (0 unknown, 1 good, 2 failed, 3 failed and applied), the absolute index of the block record that delivered it (-1: not
+    // yet) and the decode window the job was filed in
+    int verdict[8], deliver_abs[8], window, pad2;
+};
+// replay checkpoint of an AM stream: everything k_rollback_am rewinds, as of the end of a block that delivered a P1 PDU
+struct AmCkpt { StreamState st; AmStream am; };
 
 }  // namespace nrsc5

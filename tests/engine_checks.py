@@ -729,6 +729,52 @@ def check_deferred_feedback_equals_reference(lib, oracle, n_blocks=96, verdict_l
     E.close()
 
 
+def check_am_deferred_feedback_equals_reference(lib, oracle, verdict_lag=0):
+    """AM twin of check_deferred_feedback_equals_reference: batch, 8-step decode windows, on-device L2 feedback.  Noise bursts
+    break the first header of some P1 PDUs; the verdict of the deferred decode rewinds the stream to the block that delivered
+    that PDU (k_rollback_am), so LOST_SYNC, the re-acquisition and everything after land on the reference's blocks."""
+    from nrsc5_amd import synth_am
+    kws = [dict(n_frames=16, seed=9, cfo_hz=2.0, offset=500, burst=(8.3, 0.5, 40.0)),
+           dict(n_frames=16, seed=10, cfo_hz=-3.0, offset=900, burst=(9.6, 0.3, 40.0)),
+           dict(n_frames=12, seed=11, cfo_hz=1.0, offset=100)]
+    caps = [synth_am.am_ma1_capture(**kw) for kw in kws]
+    n = len(caps)
+    stride = max(c.iq.size for c in caps); stride += (-stride) % 64
+    buf = np.zeros((n, stride), dtype=caps[0].iq.dtype)
+    for k, c in enumerate(caps):
+        buf[k, :c.iq.size] = c.iq
+    old = os.environ.get("NRSC5HIP_TEST_VERDICT_LAG")
+    os.environ["NRSC5HIP_TEST_VERDICT_LAG"] = str(verdict_lag)
+    try:
+        E = eng.Engine(max_streams=n, q15_capacity=stride // 2 + 1024, record_capacity=1024, p1_slots=48, lib_path=lib, am_enable=True, p1_async=True, l2_feedback=True)
+    finally:
+        if old is None:
+            del os.environ["NRSC5HIP_TEST_VERDICT_LAG"]
+        else:
+            os.environ["NRSC5HIP_TEST_VERDICT_LAG"] = old
+    for k in range(n):
+        E.set_mode(k, eng.MODE_AM)
+    dev = _to_device(E, buf)
+    E.batch_append_cs16(dev, stride, [c.iq.size - c.iq.size % 4 for c in caps])
+    E.batch_process(n)
+    recs, counts, frames = E.batch_fetch_view(n)
+    lost = 0
+    for k, c in enumerate(caps):
+        ol, _, _ = oracle.run(c.iq, mode=1, p1_hook=oracle.l2_hook())
+        r = recs[k, :counts[k]]
+        assert not (r["flags"] & eng.REC_DISCARDED).any()
+        log = eng.am_records_to_log(E, k, r, frames[k])
+        diffs = common.compare_logs(common.strip_states(ol), common.strip_states(log))
+        kept = [x for x in common.strip_states(ol) if x[0] not in ("hdc", "soft", "vit", "amsym", "pxsoft")]
+        bad = {i for i, (kk, v) in enumerate(kept) if kk == "ber" and v["cber"] > 0.02}
+        diffs = [d for d in diffs if not any(d.startswith(f"#{i} ") or d.startswith(f"#{i + 1} frame") or d.startswith(f"#{i - 1} frame") for i in bad)]
+        assert not diffs, (k, verdict_lag, diffs[:10])
+        lost += sum(1 for kk, _ in ol if kk == "lost_sync")
+    assert lost >= 2, "captures do not exercise the feedback"
+    _free_device(E, dev)
+    E.close()
+
+
 def check_hdc_consumer(lib, reflib, caps, p1_async=False):
     """IQ -> engine -> L2 index (device) -> nrsc5hip_hdc_* == the NRSC5_EVENT_HDC sequence of the unmodified reference."""
     from oracle import ref

@@ -2,6 +2,8 @@
 (tests/simt/) and checked against the oracle.  This validates kernel LOGIC in the GPU-less
 container; it is not a product path and proves nothing about gfx950 code generation -- the
 `-m gpu` twins in test_gpu_parity.py do that through the real library."""
+import pytest
+
 from tests import engine_checks as ec
 from nrsc5_amd import synth
 
@@ -87,6 +89,12 @@ def test_emu_extended_sidebands_mp2(emu_lib, oracle):
 
 
 # ---- AM ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("lag", [0, 3])
+def test_emu_am_replay_equals_reference(emu_lib, oracle, lag):
+    """AM window pipeline + on-device L2 feedback == the oracle with the restated frame_process decision (k_rollback_am)."""
+    ec.check_am_deferred_feedback_equals_reference(emu_lib, oracle, verdict_lag=lag)
+
+
 def test_emu_am_viterbi_k9(emu_lib, oracle):
     ec.check_viterbi_k9(emu_lib, oracle, lens=(80, 3750), frames=2)
 

@@ -261,6 +261,13 @@ def test_gpu_deferred_feedback_equals_reference(hip_lib, oracle, lag):
                                                 extra=((26, -120.0, 3333), (27, 250.0, 1234), (28, 0.0, 4000)))
 
 
+@pytest.mark.parametrize("lag", [0, 2, 5])
+def test_gpu_am_replay_equals_reference(hip_lib, oracle, lag):
+    """AM batch, 8-step decode windows, L2 feedback on the device: the log equals the oracle driven by the restated
+    frame_process decision however late the verdicts of the deferred decodes arrive (replay, k_rollback_am)."""
+    ec.check_am_deferred_feedback_equals_reference(hip_lib, oracle, verdict_lag=lag)
+
+
 def test_gpu_l2_feedback_deferred_recovers_false_locks(hip_lib):
     """Throughput mode: the feedback arrives when the deferred decode completes; falsely locked streams still re-acquire
     and then deliver the transmitted frames."""
