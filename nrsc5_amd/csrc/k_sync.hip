@@ -198,12 +198,19 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
     long long tstamp = (db.sync_phase_cycles && s == 0 && tid == 0) ? (long long)clock64() : 0;
 #define SYNC_MARK(i) do { if (db.sync_phase_cycles && s == 0 && tid == 0) { const long long now = (long long)clock64(); db.sync_phase_cycles[i] += now - tstamp; tstamp = now; } } while (0)
 
-    __shared__ float2 refz[NREF_MAX][NSYM];                   // derotated reference carriers
-    __shared__ float refph[NREF_MAX][NSYM];                   // loop phase per symbol (phases[][] of the reference)
-    __shared__ float2 refcs[NREF_MAX][NSYM];                  // e^{+i refph}
+    // One LDS region, two lives: the reference-carrier scratch of the tracking and equalising phases, then -- once the last
+    // equalised cell sits in a register (barrier after the MER sums) -- the block's soft-bit rows on their way to the matrix.
+    constexpr int OFF_REFPH = NREF_MAX * NSYM * (int)sizeof(float2), OFF_REFCS = OFF_REFPH + NREF_MAX * NSYM * (int)sizeof(float);
+    constexpr int OFF_CFO = OFF_REFCS + NREF_MAX * NSYM * (int)sizeof(float2), REF_BYTES = OFF_CFO + (CFO_HI - CFO_LO) * 22;
+    __shared__ __attribute__((aligned(16))) uint8_t lds_raw[REF_BYTES > PM_BLOCK ? REF_BYTES : PM_BLOCK];
+    float2 (*refz)[NSYM] = (float2 (*)[NSYM])lds_raw;                            // derotated reference carriers
+    float (*refph)[NSYM] = (float (*)[NSYM])(lds_raw + OFF_REFPH);               // loop phase per symbol (phases[][] of the reference)
+    float2 (*refcs)[NSYM] = (float2 (*)[NSYM])(lds_raw + OFF_REFCS);             // e^{+i refph}
+    int8_t (*cfo_offs)[22] = (int8_t (*)[22])(lds_raw + OFF_CFO);
+    int8_t *pm_tile = (int8_t *)lds_raw;                                         // MP1: this block's soft-bit rows (second life)
+    static_assert(PM_BLOCK % 16 == 0 && PM_FRAME % 16 == 0, "soft-bit rows leave in 16-byte pieces");
     __shared__ float smag[NREF_MAX];
     __shared__ int ref_ok[NREF_MAX], ref_bc[NREF_MAX], ref_psmi[NREF_MAX];
-    __shared__ int8_t cfo_offs[CFO_HI - CFO_LO][22];
     __shared__ int sh_i[8];
     __shared__ float sh_f[8];
     __shared__ double red[2][4];
@@ -452,13 +459,17 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         const int pm_slot = st.pm_slot;
         int8_t *pm_blk = db.pm + ((size_t)s * NPM + pm_slot) * PM_FRAME + (size_t)bc * PM_BLOCK;
         if (ppb == PM_PART) {
+            // the 11520 two-byte cells of the block's 32 x 720 soft-bit rows are assembled in LDS and leave in 16-byte rows:
+            // six coalesced stores per lane instead of 45 scattered two-byte ones
 #pragma unroll
             for (int i = 0; i < MP1C; i++) {
                 const int c = tid + 256 * i;
                 const float mult = c >= ncell / 2 ? mult_ub : mult_lb;              // cells of the upper sideband come second
                 char2 o; o.x = (signed char)soft_bit(cellv[i].x, mult); o.y = (signed char)soft_bit(cellv[i].y, mult);
-                *(char2 *)(pm_blk + tb.eq_out[c]) = o;
+                *(char2 *)(pm_tile + tb.eq_out[c]) = o;
             }
+            __syncthreads();
+            for (int q = tid; q < PM_BLOCK / 16; q += 256) ((uint4 *)pm_blk)[q] = ((const uint4 *)pm_tile)[q];
         } else {
             for (int c = tid; c < ncell; c += 256) {
                 int k, n, part, side;
@@ -483,7 +494,8 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         // ---- PIDS: gather + depuncture now (decode.c:324-342); the 80-bit Viterbi + descramble run in
         // k_pids_decode, off this kernel's critical path (results only feed the record, not the loops)
         int8_t *stage = db.pids_stage + (((size_t)s * NWIN + parity) * 16 + slot) * (3 * PIDS_LEN);
-        for (int n = tid; n < PIDS_CODED; n += 256) stage[n + n / 5] = pm_blk[tb.pids_gather[bc * PIDS_CODED + n]];
+        const int8_t *pm_src = ppb == PM_PART ? pm_tile : pm_blk;      // MP1: the rows are still in LDS
+        for (int n = tid; n < PIDS_CODED; n += 256) stage[n + n / 5] = pm_src[tb.pids_gather[bc * PIDS_CODED + n]];
         for (int n = tid; n < PIDS_CODED / 5; n += 256) stage[6 * n + 5] = 0;
         SYNC_MARK(6);
         if (tid == 0) {
