@@ -55,8 +55,7 @@ __device__ inline uint32_t costas_block(const float2 *src, int stride, float &fr
 #pragma unroll
     for (int n = 0; n < NSYM; n++) zin[n] = src[n * stride];   // 32 independent loads in flight
     float s1, c1; fast_sincos(phase, s1, c1);                  // cexpf(-I phase), see fastmath.h; the next symbol's at the end of each step
-#pragma unroll 4
-    for (int n = 0; n < NSYM; n++) {
+    auto step = [&](int n) __attribute__((always_inline)) {
         const float2 z = zin[n];
         const float s2 = 2.0f * s1 * c1, c2 = c1 * c1 - s1 * s1;                // e^{2i phase}
         const float2 w = make_float2(z.x * z.x - z.y * z.y, z.x * z.y + z.y * z.x);
@@ -88,6 +87,15 @@ __device__ inline uint32_t costas_block(const float2 *src, int stride, float &fr
             if ((double)phase < -M_PI) phase = (float)((double)phase + 2 * M_PI);
             fast_sincos(phase, s1, c1);
         }
+    };
+    if (STORE) {
+        // the tracking call: unrolled in full, so that the 32 prefetched bins live in registers (with a partial unroll the array
+        // is indexed dynamically and lands in scratch memory: a load per symbol on the serial chain)
+#pragma unroll
+        for (int n = 0; n < NSYM; n++) step(n);
+    } else {
+#pragma unroll 4
+        for (int n = 0; n < NSYM; n++) step(n);
     }
     if (x < 0) {                                               // off by pi: flip (sync.c:119-129)
         if (STORE) for (int n = 0; n < NSYM; n++) { phout[n] = (float)((double)phout[n] + M_PI); zout[n] = make_float2(-zout[n].x, -zout[n].y); }
