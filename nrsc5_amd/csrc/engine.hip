@@ -41,6 +41,8 @@ struct nrsc5hip_engine {
         hipStream_t main, aux[NAUX];
         hipEvent_t ev_window[NWIN], ev_decoded[NWIN];
         bool decoded_pending[NWIN];
+        int lane_parity[NAUX];         // window slot of the last decode each decode stream was given (-1: none yet)
+        bool thin;                     // the last burst advanced fewer than a quarter of the set's streams (the replaying stragglers' tail)
         bool acq_needed;               // some stream of the CURRENT stream set may be un-synchronised: launch the acquisition kernels
         bool px_needed;                // some stream is not FINE yet or runs a service mode with extended sidebands
         unsigned long long set_sig;    // identity of the stream set the two flags above were measured on (0 = none)
@@ -350,6 +352,8 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
                 ln.decoded_pending[k] = false;
             }
             ln.acq_needed = true; ln.px_needed = true; ln.set_sig = 0; ln.step_count = 0; ln.am_step_count = 0;
+            for (int k = 0; k < NAUX; k++) ln.lane_parity[k] = -1;
+            ln.thin = false;
             for (int k = 0; k < NWIN; k++) ln.am_decoded_pending[k] = false;
             if (!rc && hipHostMalloc((void **)&ln.counters_host, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) rc = NRSC5HIP_ENOMEM;
         }
@@ -498,6 +502,18 @@ static int check_stream(nrsc5hip_engine *e, int s)
 // One step = every listed stream whose 33-symbol window is complete advances by one block:
 //   [acquisition kernels if any stream may be un-synchronised] -> prepare -> mix+FFT -> sync (+PIDS)
 //   -> P1 de-interleave -> P1 Viterbi (in order, or deferred to the aux stream once per 16-step window).
+// Decode stream of a window: round robin over the `naux` streams that keep the chip busy without starving the chain.  A THIN
+// window (few streams advanced: the stragglers' tail of a pass) is latency- not throughput-bound -- a handful of one-wave
+// trellis passes -- so when its regular stream is still busy it may take one of the spare streams instead of queueing.
+static int pick_decode_lane(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, long long window)
+{
+    const int lane = (int)(window % e->naux);
+    auto busy = [&](int k) { return ln.lane_parity[k] >= 0 && hipEventQuery(ln.ev_decoded[ln.lane_parity[k]]) == hipErrorNotReady; };
+    if (ln.thin && busy(lane))
+        for (int k = e->naux; k < NAUX; k++) if (!busy(k)) return k;
+    return lane;
+}
+
 static int launch_window_decode(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const int *ids_dev, int parity, int lane)
 {
     // decode the window's PIDS frames and P1 frames on aux stream `lane`, overlapped with the next windows
@@ -510,6 +526,7 @@ static int launch_window_decode(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, i
     { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ax); launch_p1_viterbi(e->tb, ln.db, n, ids_dev, parity, lane, ax, e->cfg.l2_feedback ? 2 : 0); }
     HIPCHK(hipEventRecord(ln.ev_decoded[parity], ax));
     ln.decoded_pending[parity] = true;
+    ln.lane_parity[lane] = parity;
     return 0;
 }
 
@@ -518,7 +535,6 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
     const bool async = e->cfg.p1_async != 0;
     const long long window = ln.step_count / 16;
     const int parity = async ? (int)(window % NWIN) : 0;       // buffer slot of this decode window
-    const int lane = async ? (int)(window % e->naux) : 0;      // aux stream + decision scratch that will decode it
     if (async && (ln.step_count % 16) == 0 && ln.decoded_pending[parity]) {
         // the buffers of slot `parity` are about to be rewritten: the decoder launched NWIN windows ago must be done
         HIPCHK(hipStreamWaitEvent(ln.main, ln.ev_decoded[parity], 0));
@@ -549,7 +565,7 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
         ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ln.main);
         launch_p1_viterbi(e->tb, ln.db, n, ids_dev, parity, 0, ln.main, e->cfg.l2_feedback ? 1 : 0);
     } else if ((ln.step_count % 16) == 15) {
-        int rc = launch_window_decode(e, ln, n, ids_dev, parity, lane); if (rc) return rc;
+        int rc = launch_window_decode(e, ln, n, ids_dev, parity, pick_decode_lane(e, ln, window)); if (rc) return rc;
     }
     ln.step_count++;
     HIPCHK(hipGetLastError());
@@ -562,7 +578,7 @@ static int flush_p1(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const 
     if (!e->cfg.p1_async) return 0;
     if (ln.step_count % 16) {
         const long long window = ln.step_count / 16;
-        int rc = launch_window_decode(e, ln, n, ids_dev, (int)(window % NWIN), (int)(window % e->naux)); if (rc) return rc;
+        int rc = launch_window_decode(e, ln, n, ids_dev, (int)(window % NWIN), pick_decode_lane(e, ln, window)); if (rc) return rc;
         ln.step_count += 16 - (ln.step_count % 16);            // the next steps start a fresh window
     }
     for (int k = 0; k < NAUX; k++) HIPCHK(hipStreamSynchronize(ln.aux[k]));
@@ -597,6 +613,7 @@ static int run_steps(nrsc5hip_engine *e, int n, const int *ids_dev, unsigned lon
             HIPCHK(hipMemcpyAsync(ln.counters_host, ln.counters_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, ln.main));
             HIPCHK(hipStreamSynchronize(ln.main));
             ln.acq_needed = ln.counters_host[1] > 0;
+            ln.thin = ln.counters_host[0] * 4 < burst * n;
             ln.px_needed = ln.counters_host[2] > 0;
             if (ln.counters_host[0] == 0) live = false;        // nothing was processed (or is pending) in this burst
             else done += burst;
