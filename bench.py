@@ -527,6 +527,10 @@ class Mixed:
         return None
 
 
+KERNELS_OF_CLASS = {"p1_viterbi": "k_p1_forward (K=7 forward trellis pass of one decode window's P1 frames)", "p1_traceback": "k_p1_traceback (+ k_l2_index_window)",
+                    "p1_deint": "k_p1_deint", "mixfft": "k_mixfft", "sync": "k_sync (+ k_px_deint, k_px_commit)", "pids": "k_pids_decode (+ k_px_decode)",
+                    "am": "k_am_block + k_am_interleave", "am_decode": "k_am_decode (8 x P1 + P3 + 8 x PIDS trellis passes of one AM L1 frame per stream)",
+                    "acquire": "k_acq_list / _decimate / _fir / _corr / _peak", "prepare": "k_prepare, k_rollback", "decimate": "k_decimate_* / k_append_cs16 / k_attach_raw"}
 DOMINANT_DEFAULT = {"fm": "p1_viterbi", "mixed": "p1_viterbi", "am-cs16": "am_decode", "am-cu8": "am_decode"}
 
 
@@ -629,7 +633,7 @@ def main():
                     whole = {"hbm_bytes_per_pass": tj.get("whole_path_hbm_bytes_per_pass"), "over_algorithmic": tj.get("whole_path_over_algorithmic"), "file": os.path.relpath(args.traffic_json, ROOT)}
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        roofline = {"bound": "hbm", "kernel": dom, "kernel_functions": KERNELS_OF_CLASS.get(dom, dom), "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "whole_path_traffic": whole,
                     "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": dom_launches,
                     "avg_launch_ms_note": "HIP events on the kernel's own launch stream; up to three decode streams and the block-step chain run concurrently, so this is a per-launch latency under contention, not an exclusive-occupancy figure",

@@ -323,6 +323,7 @@ int nrsc5hip_reset_all(nrsc5hip_engine *e);
 enum {
     NRSC5HIP_PROF_DECIMATE = 0, NRSC5HIP_PROF_ACQUIRE, NRSC5HIP_PROF_PREPARE, NRSC5HIP_PROF_MIXFFT,
     NRSC5HIP_PROF_SYNC, NRSC5HIP_PROF_P1_DEINT, NRSC5HIP_PROF_P1_VITERBI, NRSC5HIP_PROF_PIDS, NRSC5HIP_PROF_AM /* block steps */, NRSC5HIP_PROF_AM_DECODE /* window pipeline: the deferred decodes */,
+    NRSC5HIP_PROF_P1_TRACEBACK /* P1_DEINT / P1_VITERBI (the forward trellis pass) / P1_TRACEBACK: the three stages of a P1 decode */,
     NRSC5HIP_PROF_CLASSES
 };
 int nrsc5hip_profile(nrsc5hip_engine *e, int enable, double *total_ms, long long *launches);

@@ -144,15 +144,24 @@ __global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBu
 
 static size_t traceback_smem(int len) { const int nchunks = len / 64 + 1; return (size_t)((nchunks + TB_SEG - 1) / TB_SEG) * 64 + nchunks; }
 
-void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st, int l2_mode)
+// The three stages of a window's P1 decode, launched back to back on the window's decode stream (separate entry points so that
+// the engine can time the trellis pass -- the dominant kernel of the whole path -- on its own).
+// Wave priorities (s_setprio): the forward pass is long-running background work next to the step chain (priority 3); raising it
+// to 1 or 2 was measured again with the 6-instruction trellis: no gain (profiles/r02_naux.txt).  The traceback is the short
+// kernel at the end of each decode chain: one step above the trellis waves, but below the chain -- at the chain's own level
+// (3) its 4096 waves per launch sit on the serial Costas loops of k_sync (profiles/r02_ab_prio_tb.txt).
+void launch_p1_deint(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st)
 {
     hipLaunchKernelGGL(k_p1_deint, dim3(32, nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, lane_id);
-    // wave priorities (s_setprio): the forward pass is long-running background work next to the step chain (priority 3);
-    // raising it to 1 or 2 was measured again with the 6-instruction trellis: no gain (profiles/r02_naux.txt).  The traceback is
-    // the short kernel at the end of each decode chain: one step above the trellis waves, but below the chain -- at the chain's
-    // own level (3) its 4096 waves per launch sit on the serial Costas loops of k_sync (profiles/r02_ab_prio_tb.txt).
-    constexpr int prio_fwd = 0, prio_tb = 1;
+}
+void launch_p1_forward(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st)
+{
+    constexpr int prio_fwd = 0;
     hipLaunchKernelGGL(k_p1_forward, dim3((nstreams + FWD_WAVES - 1) / FWD_WAVES), dim3(64 * FWD_WAVES), 0, st, tb, db, stream_ids, parity, lane_id, prio_fwd, nstreams);
+}
+void launch_p1_traceback(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st, int l2_mode)
+{
+    constexpr int prio_tb = 1;
     hipLaunchKernelGGL(k_p1_traceback, dim3(nstreams), dim3(TB_THREADS), traceback_smem(P1_LEN), st, tb, db, stream_ids, parity, lane_id, l2_mode, prio_tb);
     if (db.l2_ring) launch_l2_index_window(db, nstreams, stream_ids, parity, st);
 }

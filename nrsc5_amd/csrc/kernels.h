@@ -105,7 +105,10 @@ void launch_pids_decode(const DevTables &tb, const DevBuffers &db, int nstreams,
 // extended sidebands: interleaver IV for streams whose block pair just completed (after k_sync), and the staged P3/P4 decodes
 void launch_px_deint(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, hipStream_t st);
 void launch_px_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st);
-void launch_p1_viterbi(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st, int l2_mode = 0);
+// a window's P1 decode: de-interleave -> forward trellis pass -> traceback + BER + descramble + first-header verdict (+ fused L2 index)
+void launch_p1_deint(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st);
+void launch_p1_forward(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st);
+void launch_p1_traceback(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st, int l2_mode = 0);
 
 // ---- AM path (k_am.hip) -------------------------------------------------------------------------
 // cu8 -> five cascaded half-bands 32:1, any nbytes % 4 == 0 per stream (stage phases carry over)
@@ -126,7 +129,7 @@ void launch_viterbi_k9_frames(const int8_t *coded, int len, int nframes, unsigne
 constexpr int L2_MAX_BYTES = 18269;
 struct L2Job { const uint32_t *words; int nbits; int pad; };        // packed frame (bit i at words[i / 32] bit i % 32)
 void launch_l2_index(const L2Job *jobs, int njobs, nrsc5hip_l2_frame *frames, uint8_t *bytes_out, long long stride, hipStream_t st);
-// engine option l2_index: index the P1 frames k_p1_traceback finished in decode window `parity` (called by launch_p1_viterbi)
+// engine option l2_index: index the P1 frames k_p1_traceback finished in decode window `parity` (called by launch_p1_traceback)
 void launch_l2_index_window(const DevBuffers &db, int nstreams, const int *stream_ids, int parity, hipStream_t st);
 // ... the P3 / P4 frames k_px_decode just finished (called by launch_px_decode), and an AM L1 frame's frames: window pipeline
 // (called by launch_am_decode) or in order (called by launch_am_step: the frames k_am_viterbi delivered this step)

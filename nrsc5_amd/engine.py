@@ -215,7 +215,7 @@ class Engine:
     def reset_all(self):
         self._check(self.lib.nrsc5hip_reset_all(self._h))
 
-    PROF_CLASSES = ("decimate", "acquire", "prepare", "mixfft", "sync", "p1_deint", "p1_viterbi", "pids", "am", "am_decode")
+    PROF_CLASSES = ("decimate", "acquire", "prepare", "mixfft", "sync", "p1_deint", "p1_viterbi", "pids", "am", "am_decode", "p1_traceback")
 
     def profile(self, enable: int = -1):
         """Per-kernel-class {name: (total_ms, launches)} from HIP events; enable 1/0 starts/stops, a class name starts timing
