@@ -106,11 +106,11 @@ typedef struct nrsc5hip_config {
                                   overlapped with the next window (throughput mode) */
     int l2_feedback;           /* 1: the engine itself applies the L2 -> L1 feedback of frame_process (frame.c:516-540): a P1 frame
                                   whose first L2 header fails the RS(255,247) check drops the stream to SYNC_NONE (REC_LOST_SYNC)
-                                  before its next block, as in the reference.  With p1_async = 1 (FM) the verdict of a deferred decode
-                                  arrives windows later: the stream is then rewound to the end of the frame's block and re-run from
-                                  there, so the delivered records and frames are the reference's all the same (needs the samples since
-                                  that block still in the FIFO: batch use, or pushes whose records are drained after each call; and
-                                  record_capacity >= 256).  AM with p1_async = 1: applied when the deferred decode completes.
+                                  before its next block, as in the reference.  With p1_async = 1 (FM and AM) the verdict of a deferred
+                                  decode arrives windows later: the stream is then rewound to the end of the block that delivered the
+                                  frame and re-run from there, so the delivered records and frames are the reference's all the same
+                                  (needs the samples since that block still in the FIFO: batch use, or pushes whose records are
+                                  drained after each call; and record_capacity >= 256).
                                   0: the host does it through nrsc5hip_force_resync (the drop-in shim). */
     int am_enable;             /* allocate the AM buffers (1.4 MB per stream) so that streams may be switched to
                                   NRSC5HIP_MODE_AM */
