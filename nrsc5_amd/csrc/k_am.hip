@@ -381,7 +381,7 @@ struct AmBlockSmem {
     float marg[2][AM_PW];
     float2 carrier[NSYM];
     float magsum[2 * 53 + 1];
-    float red_mag[4]; int red_idx[4]; float2 red_v[4];
+    float red_mag[16]; int red_idx[16]; float2 red_v[16];
     uint8_t pids_sym[2 * NSYM];
     int8_t pids_coded[3 * PIDS_LEN];
     uint32_t pids_out[3];
@@ -422,26 +422,31 @@ __device__ inline float half_turn_diff(float a, float b)   // phase_diff, sync.c
 // order for the in-place radix-2 transform.  Work-item j owns input slot j of every symbol.
 __device__ inline void am_fold(AmBlockSmem &sm, const c16 *win, int samperr, double theta, float2 step270, float2 step256)
 {
-    const int j = threadIdx.x;
-    float2 p;
-    {
-        double th = theta + sm.dtheta * (double)j;
-        th -= 2 * M_PI * rint(th / (2 * M_PI));
-        float sn, cs; sincosf((float)th, &sn, &cs);
-        p = make_float2(cs, sn);
-    }
+    // work-item (j, g): sample j of the eight symbols of group g; the phasor is evaluated in closed form at the head of every
+    // group and advanced by recurrence inside it, whatever the block size (256 work-items take the four groups in turn, 1024
+    // one each), so that both launch shapes produce the same bits
+    const int j = threadIdx.x & 255;
     const unsigned slot = bitrev8((unsigned)(j + (AM_FFT - AM_CP) / 2) & 255u);
-    for (int i = 0; i < NSYM; i++) {
-        const c16 a = win[i * AM_SYM + j + samperr];
-        float2 v = cmulf(p, make_float2((float)a.r / 32767.0f, (float)a.i / 32767.0f));    // cq15_to_cf, defines.h:106
-        if (j < AM_CP) {
-            const c16 c = win[i * AM_SYM + j + AM_FFT + samperr];
-            const float2 w = cmulf(cmulf(p, step256), make_float2((float)c.r / 32767.0f, (float)c.i / 32767.0f));
-            const float sa = sm.shape[j], sb = sm.shape[j + AM_FFT];
-            v = make_float2(sa * v.x + sb * w.x, sa * v.y + sb * w.y);
+    for (int g = (int)threadIdx.x >> 8; g < NSYM / 8; g += (int)blockDim.x >> 8) {
+        float2 p;
+        {
+            double th = theta + sm.dtheta * (double)(j + g * 8 * AM_SYM);
+            th -= 2 * M_PI * rint(th / (2 * M_PI));
+            float sn, cs; sincosf((float)th, &sn, &cs);
+            p = make_float2(cs, sn);
         }
-        sm.X[i * AM_FFT + slot] = v;
-        p = cmulf(p, step270);
+        for (int i = 8 * g; i < 8 * g + 8; i++) {
+            const c16 a = win[i * AM_SYM + j + samperr];
+            float2 v = cmulf(p, make_float2((float)a.r / 32767.0f, (float)a.i / 32767.0f));    // cq15_to_cf, defines.h:106
+            if (j < AM_CP) {
+                const c16 c = win[i * AM_SYM + j + AM_FFT + samperr];
+                const float2 w = cmulf(cmulf(p, step256), make_float2((float)c.r / 32767.0f, (float)c.i / 32767.0f));
+                const float sa = sm.shape[j], sb = sm.shape[j + AM_FFT];
+                v = make_float2(sa * v.x + sb * w.x, sa * v.y + sb * w.y);
+            }
+            sm.X[i * AM_FFT + slot] = v;
+            p = cmulf(p, step270);
+        }
     }
 }
 
@@ -451,7 +456,7 @@ __device__ inline void am_fft_all(AmBlockSmem &sm)
     for (int lg = 1; lg <= 8; lg++) {
         __syncthreads();
         const int half = 1 << (lg - 1);
-        for (int id = threadIdx.x; id < NSYM * 128; id += 256) {
+        for (int id = threadIdx.x; id < NSYM * 128; id += (int)blockDim.x) {
             const int n = id >> 7, q = id & 127;
             const int pos = q & (half - 1), i0 = ((q >> (lg - 1)) << lg) + pos, i1 = i0 + half;
             const float2 w = sm.tw[pos << (8 - lg)];
@@ -467,6 +472,9 @@ __device__ inline void am_fft_all(AmBlockSmem &sm)
 // spectrum bin `off` relative to the carrier (fftshift folded into the index), symbol n
 __device__ inline float2 &am_bin(AmBlockSmem &sm, int off, int n) { return sm.X[n * AM_FFT + (off & 255)]; }
 
+// 256 work-items per stream (the in-order K=9 PIDS trellis below owns one state per work-item).  Every wide phase strides by the
+// block size, but 1024 work-items were measured SLOWER in the window pipeline (am-cs16 88.6 -> 108.4 ms): a 16-wave workgroup with
+// 64 KB of LDS waits for a whole CU's worth of slots while the decode streams keep the chip full of long one-wave trellis passes.
 __global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, const int *ids, int pipeline, int parity, int slot)
 {
     wave_set_priority_high();                                  // block-step chain = critical path; the decode waves run at priority 0
@@ -475,7 +483,7 @@ __global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, c
     AmStream &am = db.am[s];
     HIP_DYNAMIC_SHARED(uint8_t, smem_raw)
     AmBlockSmem &sm = *(AmBlockSmem *)smem_raw;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, NT = (int)blockDim.x;
     const bool ready = st.wr - st.rd >= AM_WIN;                 // block-uniform
     if (tid == 0) {
         am.dec_bc = -1; st.active = ready ? 1 : 0;
@@ -486,14 +494,14 @@ __global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, c
     const c16 *win = db.q15 + (size_t)s * db.q15_cap + (st.rd - st.base);
     const int state_before = st.sync_state;
 
-    for (int k = tid; k < AM_FFT / 2; k += 256) sm.tw[k] = tb.am_twiddle[k];
-    for (int k = tid; k < AM_SYM; k += 256) sm.shape[k] = tb.am_shape[k];
+    for (int k = tid; k < AM_FFT / 2; k += NT) sm.tw[k] = tb.am_twiddle[k];
+    for (int k = tid; k < AM_SYM; k += NT) sm.shape[k] = tb.am_shape[k];
 
     // ---- coarse acquisition while not FINE (acquire.c:120-158 with the AM filter / geometry) ------------------
     if (state_before != SYNC_FINE) {
         c16 *filt = (c16 *)sm.X;                               // [AM_WIN]
         float2 *sums = (float2 *)(filt + AM_WIN + 2);          // [AM_SYM], 8-byte aligned (AM_WIN even)
-        for (int t = tid; t < AM_WIN; t += 256) {
+        for (int t = tid; t < AM_WIN; t += NT) {
             int sr = 0, si = 0;
 #pragma unroll
             for (int i = 1; i < 16; i++) {
@@ -513,7 +521,7 @@ __global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, c
             filt[t] = y;
         }
         __syncthreads();
-        for (int i = tid; i < AM_SYM; i += 256) {
+        for (int i = tid; i < AM_SYM; i += NT) {
             float sr = 0.0f, si = 0.0f;
             for (int j = 0; j < NSYM; j++) {
                 const c16 qa = filt[i + j * AM_SYM], qb = filt[i + j * AM_SYM + AM_FFT];
@@ -525,7 +533,7 @@ __global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, c
         }
         __syncthreads();
         float best_mag = -1.0f; int best_i = 0x7fffffff; float2 best_v = make_float2(0.0f, 0.0f);
-        for (int i = tid; i < AM_SYM; i += 256) {
+        for (int i = tid; i < AM_SYM; i += NT) {
             float vr = 0.0f, vi = 0.0f;
             int k = i;
             for (int j = 0; j < AM_CP; j++) {
@@ -545,7 +553,7 @@ __global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, c
         if ((tid & 63) == 0) { sm.red_mag[tid >> 6] = best_mag; sm.red_idx[tid >> 6] = best_i; sm.red_v[tid >> 6] = best_v; }
         __syncthreads();
         if (tid == 0) {
-            for (int w = 1; w < 4; w++)
+            for (int w = 1; w < NT / 64; w++)
                 if (sm.red_mag[w] > best_mag || (sm.red_mag[w] == best_mag && sm.red_idx[w] < best_i)) { best_mag = sm.red_mag[w]; best_i = sm.red_idx[w]; best_v = sm.red_v[w]; }
             st.coarse_samperr = (best_i + AM_SYM - 15) % AM_SYM;       // FILTER_DELAY, acquire.c:149
             st.coarse_re = best_v.x; st.coarse_im = best_v.y;
@@ -600,7 +608,7 @@ __global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, c
     if (fine_at_top) {
         // only the carrier bin is needed: sum of the folded inputs (bin 0 before fftshift)
         __syncthreads();
-        {
+        if (tid < 256) {
             const int n = tid >> 3, part = tid & 7;            // 8 work-items per symbol, 32 inputs each
             float sr = 0.0f, si = 0.0f;
             for (int k = 0; k < 32; k++) { const float2 v = sm.X[n * AM_FFT + part * 32 + k]; sr += v.x; si += v.y; }
@@ -651,7 +659,7 @@ __global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, c
     am_fft_all(sm);
 
     // lower sideband: z = -conj(z); complementary sidebands of the hybrid waveform add coherently (sync.c:616-633)
-    for (int id = tid; id < NSYM * AM_IDX_MAX; id += 256) {
+    for (int id = tid; id < NSYM * AM_IDX_MAX; id += (int)blockDim.x) {
         const int n = id / AM_IDX_MAX, i = 1 + id % AM_IDX_MAX;
         float2 &lo = am_bin(sm, -i, n);
         lo = make_float2(-lo.x, lo.y);
@@ -746,7 +754,7 @@ __global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, c
         }
         // equalise and slice the four partitions: hard symbols of this block go to the frame matrices (decode.c:439-449)
         uint8_t *symbase = db.am_sym + (size_t)s * 4 * AM_SYMS;
-        for (int id = tid; id < 4 * NSYM * AM_PW; id += 256) {
+        for (int id = tid; id < 4 * NSYM * AM_PW; id += (int)blockDim.x) {
             const int part = id / (NSYM * AM_PW), r = id % (NSYM * AM_PW), n = r / AM_PW, col = r % AM_PW;
             const int pri = ma3 ? 2 : 57, ter = ma3 ? 28 : 2;
             int off;
@@ -841,8 +849,8 @@ __global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, c
             AmCkpt &ck = db.am_ckpt[((size_t)s * NWIN + am.vit_parity) * 8 + j];
             const uint32_t *a = (const uint32_t *)&st, *b = (const uint32_t *)&am;
             uint32_t *da = (uint32_t *)&ck.st, *dbp = (uint32_t *)&ck.am;
-            for (int k = tid; k < (int)(sizeof(StreamState) / 4); k += 256) da[k] = a[k];
-            for (int k = tid; k < (int)(sizeof(AmStream) / 4); k += 256) dbp[k] = b[k];
+            for (int k = tid; k < (int)(sizeof(StreamState) / 4); k += NT) da[k] = a[k];
+            for (int k = tid; k < (int)(sizeof(AmStream) / 4); k += NT) dbp[k] = b[k];
         }
     }
 }
@@ -935,7 +943,15 @@ __device__ inline void am_deinterleave_frame(const DevTables &tb, const DevBuffe
         if (!am.dec_rdbi) total += ma3 ? AM_P3_LEN_MA3 * 12 / 5 : AM_P3_LEN_MA1 * 3 / 2;
         db.records[(size_t)s * db.rec_cap + am.dec_record].ber = (float)am.am_errors / (float)total;
     }
-    const uint8_t *sym = db.am_sym + (size_t)s * 4 * AM_SYMS;  // [pl, pu, s, t][8 blocks][32][25]
+    // the frame's four hard-symbol matrices (25.6 KB) are gathered from byte by byte in interleaver order: stage them in LDS
+    // first (the scattered byte loads were what the kernel waited for)
+    __shared__ __attribute__((aligned(16))) uint8_t sym[4 * AM_SYMS];   // [pl, pu, s, t][8 blocks][32][25]
+    static_assert((4 * AM_SYMS) % 16 == 0, "symbol matrices are copied in 16-byte pieces");
+    {
+        const uint4 *src = (const uint4 *)(db.am_sym + (size_t)s * 4 * AM_SYMS);
+        for (int k = tid; k < 4 * AM_SYMS / 16; k += 1024) ((uint4 *)sym)[k] = src[k];
+    }
+    __syncthreads();
     uint8_t *q = db.am_q + (size_t)s * 4 * 3 * 18000;         // [ml, mu, eml, emu][3][18000]
     const int head = am.q_head;
     int8_t *v1 = db.am_vit + ((size_t)s * db.am_nvit + vslot) * 2 * AM_VIT, *v3 = v1 + AM_VIT;
