@@ -125,7 +125,6 @@ struct StreamState {
     // bookkeeping
     int nblocks;                // processed blocks so far (record index)
     int p1_count;               // P1 frames produced so far
-    int force_none;             // (unused; kept for layout stability of the debug tools)
     int fine_epoch;             // number of transitions into SYNC_FINE so far: a request from an earlier lock is stale
     // per-step scratch written by k_prepare / acquisition
     int active;                 // this step processes a block for this stream
