@@ -682,12 +682,12 @@ def check_deferred_feedback_recovers(lib, n_blocks=256):
 FALSE_LOCK_CASES = ((23, 0.0, 1234), (24, 10.0, 2208), (25, 10.0, 777))     # seeds 23 / 24: the reference algorithm locks falsely first
 
 
-def check_deferred_feedback_equals_reference(lib, oracle, n_blocks=96, verdict_lag=0, extra=()):
+def check_deferred_feedback_equals_reference(lib, oracle, n_blocks=96, verdict_lag=0, extra=(), cases=FALSE_LOCK_CASES):
     """THE benchmarked mode (batch, window pipeline, on-device L2 feedback) against the oracle driven by the restated
     frame_process decision (itself pinned against the unmodified reference incl. its L2): the complete ordered log --
     LOST_SYNC on the reference's block, re-acquisition, every PIDS / P1 frame, SYNC / MER / BER -- must be equal, no matter
     how late the verdict of the deferred decode arrives (verdict_lag forces it `lag` windows late: deep speculation)."""
-    caps = [synth.fm_mp1_capture(0, seed=sd, cfo_hz=c, offset=o, snr_db=20, n_blocks=n_blocks) for sd, c, o in FALSE_LOCK_CASES + tuple(extra)]
+    caps = [synth.fm_mp1_capture(0, seed=sd, cfo_hz=c, offset=o, snr_db=20, n_blocks=n_blocks) for sd, c, o in tuple(cases) + tuple(extra)]
     n = len(caps)
     stride = max(c.iq.size for c in caps); stride += (-stride) % 256
     buf = np.zeros((n, stride), dtype=np.uint8)
