@@ -631,6 +631,10 @@ def main():
                 if tj.get("source_sha") == source_fingerprint() and tj.get("workload") == args.workload:
                     traffic = tj.get("per_class_hbm_bytes_per_launch", {}).get(dom)
                     whole = {"hbm_bytes_per_pass": tj.get("whole_path_hbm_bytes_per_pass"), "over_algorithmic": tj.get("whole_path_over_algorithmic"), "file": os.path.relpath(args.traffic_json, ROOT)}
+                    if whole["hbm_bytes_per_pass"]:
+                        # counter bytes of one pass (all nrsc5 kernels) over this run's time per pass: what the path really pulls from HBM
+                        whole["counter_GBps"] = round(whole["hbm_bytes_per_pass"] / (dt / args.steps) / 1e9, 1)
+                        whole["counter_frac_of_peak"] = round(whole["counter_GBps"] / HBM_PEAK_GBPS, 4)
             except Exception:
                 traffic = None
         roofline = {"bound": "hbm", "kernel": dom, "kernel_functions": KERNELS_OF_CLASS.get(dom, dom), "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
