@@ -66,6 +66,8 @@ def parse():
     ap.add_argument("--cpu-processes", type=int, default=0, help="processes of the N-core CPU aggregate (default: all host cores, at most 64)")
     ap.add_argument("--oracle-streams", type=int, default=4, help="fm parity block: how many falsely-locking streams of the last pass are compared with the oracle (plus half as many others)")
     ap.add_argument("--launch-check", action="store_true", help="only start the ranks, form the process group (RCCL; gloo without a GPU) and print what it sees -- no workload")
+    ap.add_argument("--ingest", choices=("local", "scatter"), default="local",
+                    help="fm, --gpus N: local = every rank synthesises its own captures; scatter = rank 0 synthesises all of them and sends each rank its shard (RCCL point-to-point, before the timed region)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="PMC-derived HBM bytes (profiles/collect_pmc.py); used only if it was collected from THIS source tree")
     return ap.parse_args()
@@ -146,9 +148,11 @@ def launch_check(args):
     if cuda:
         torch.cuda.set_device(dev)
     shard.barrier(dev)
-    ranks = shard.sum_over_ranks([1.0, float(rank)], dev)
+    # the ingest scatter of --ingest scatter in miniature: rank 0 makes every rank's rows, each rank must receive its own
+    got = shard.scatter_rows(lambda r: torch.full((2, 4), r, dtype=torch.uint8, device=dev), 2, (4,), torch.uint8, dev)
+    ranks = shard.sum_over_ranks([1.0, float(rank), float(bool((got == rank).all()))], dev)
     if rank == 0:
-        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_in_process_group": int(ranks[0]), "rank_sum": int(ranks[1]),
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_in_process_group": int(ranks[0]), "rank_sum": int(ranks[1]), "ingest_scatter_ok": int(ranks[2]),
                           "backend": "nccl(RCCL)" if cuda else "gloo", "launched_by": os.environ.get("NRSC5_BENCH_LAUNCHER", "external torchrun" if world > 1 else "single process")}))
 
 
@@ -171,12 +175,25 @@ class Fm:
         nsig = self.pool[0][1].shape[0]
         tail = 8640
         self.stride = (2 * (4320 + nsig + tail) + 255) // 256 * 256
-        self.iq = torch.zeros((S, self.stride), dtype=torch.uint8, device=dev)
-        self.nbytes = np.zeros(S, dtype=np.uint32)
-        for k, gs in enumerate(my_streams):
-            prm = stt.stream_params(gs)
-            out = stt.channel_cu8(self.pool[gs % args.payloads][1], prm["cfo_hz"], prm["offset"], prm["snr_db"], prm["seed"], tail=tail, out=self.iq[k])
-            self.nbytes[k] = out.shape[0] - out.shape[0] % 4
+        def generate(streams):
+            iq = torch.zeros((len(streams), self.stride), dtype=torch.uint8, device=dev)
+            nb = torch.zeros((len(streams), 1), dtype=torch.int64, device=dev)
+            for k, gs in enumerate(streams):
+                prm = stt.stream_params(gs)
+                out = stt.channel_cu8(self.pool[gs % args.payloads][1], prm["cfo_hz"], prm["offset"], prm["snr_db"], prm["seed"], tail=tail, out=iq[k])
+                nb[k, 0] = out.shape[0] - out.shape[0] % 4
+            return iq, nb
+        if args.ingest == "scatter":
+            # the captures arrive on rank 0 and go out root -> peer, one shard per point-to-point send (untimed set-up)
+            from nrsc5_amd import shard
+            import torch.distributed as dist
+            world = dist.get_world_size() if dist.is_initialized() else 1
+            total = S * world
+            self.iq, nb = shard.scatter_shards(lambda r: generate(list(shard.stream_range(total, world, r))),
+                                               [((S, self.stride), torch.uint8), ((S, 1), torch.int64)], dev)
+        else:
+            self.iq, nb = generate(my_streams)
+        self.nbytes = nb[:, 0].cpu().numpy().astype(np.uint32)
         torch.cuda.synchronize()
         self.samples = float(self.nbytes.astype(np.float64).sum() / 2)
         self.signal_seconds = self.samples / FS
@@ -211,7 +228,7 @@ class Fm:
                 "streams_per_gpu": self.S, "seconds_per_stream": round(float(self.nbytes[0]) / 2 / FS, 3),
                 "p1_decode": "in-order" if a.sync_p1 else "windowed-overlap", "l2_feedback": "on-device" if a.l2_feedback else "off",
                 "input": "read in place (half-band fused into the symbol kernel)" if self.zero_copy else "decimated copy in the Q15 FIFO",
-                "block_steps_per_pass": int(steps), "distinct_payloads": a.payloads, "hbm_resident_input_GB": round(float(self.nbytes.sum()) / 1e9, 2)}
+                "block_steps_per_pass": int(steps), "ingest": a.ingest, "distinct_payloads": a.payloads, "hbm_resident_input_GB": round(float(self.nbytes.sum()) / 1e9, 2)}
 
     def verify(self, recs, counts, frames):
         """last pass vs the transmitted truth: per stream [id, blocks, P1 frames, exact frames, PIDS frames, FINE blocks, CRC of frames]"""

@@ -1,7 +1,8 @@
 """Multi-GPU layout: one process per GPU, streams are independent units, zero exchange on the
 data path.  torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" in the CPU
-tests) is used only for the barrier around the timed region, the max-over-ranks wall time and the
-gather of fixed-size per-stream result summaries."""
+tests) is used only for the barrier around the timed region, the max-over-ranks wall time, the
+gather of fixed-size per-stream result summaries and -- optionally, before the timed region -- the
+ingest scatter for captures that arrive on one rank (scatter_rows)."""
 from __future__ import annotations
 
 import os
@@ -102,3 +103,34 @@ def gather_summaries(local: np.ndarray, device) -> np.ndarray:
     dist.all_gather(out, pad)
     rows = [o[:int(s.item())].cpu().numpy() for o, s in zip(out, sizes)]
     return np.concatenate(rows, axis=0)
+
+
+def scatter_shards(shard_for_rank, specs, device, src: int = 0):
+    """Ingest scatter: the captures arrive on rank `src`, every rank ends up with its own contiguous range.
+    shard_for_rank(r) -> list of tensors (one per spec) on `device` is only called on `src`, one destination at a time (so
+    the root never holds more than one foreign shard), and every tensor goes out as ONE point-to-point send -- root to peer
+    over that peer's own xGMI link with RCCL, not a ring.  specs = [(shape, dtype), ...] of THIS rank's tensors.
+    Returns this rank's list of tensors."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return list(shard_for_rank(0))
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if rank != src:
+        out = [torch.empty(tuple(shape), dtype=dtype, device=device) for shape, dtype in specs]
+        for t in out:
+            dist.recv(t, src=src)
+        return out
+    mine = None
+    for r in range(world):
+        tensors = [t.contiguous() for t in shard_for_rank(r)]
+        if r == src:
+            mine = tensors
+        else:
+            for t in tensors:
+                dist.send(t, dst=r)
+            del tensors
+    return mine
+
+
+def scatter_rows(rows_for_rank, n_local: int, row_shape, dtype, device, src: int = 0) -> torch.Tensor:
+    """scatter_shards for a single [n, *row_shape] tensor per rank."""
+    return scatter_shards(lambda r: [rows_for_rank(r)], [((n_local,) + tuple(row_shape), dtype)], device, src)[0]

@@ -24,12 +24,13 @@ def test_bench_spawns_its_own_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(lines) == 1, r.stdout                    # rank 0 only
     assert lines[0]["n_gpus"] == 2 and lines[0]["ranks_in_process_group"] == 2 and lines[0]["rank_sum"] == 1
+    assert lines[0]["ingest_scatter_ok"] == 2             # both ranks received their own shard from rank 0 (point-to-point)
     assert lines[0]["launched_by"] == "bench.py"
 
 
 def test_bench_single_rank_is_one_process():
     r, lines = _run(["--gpus", "1", "--launch-check"])
-    assert r.returncode == 0 and lines == [{"launch_check": True, "n_gpus": 1, "ranks_in_process_group": 1, "rank_sum": 0,
+    assert r.returncode == 0 and lines == [{"launch_check": True, "n_gpus": 1, "ranks_in_process_group": 1, "rank_sum": 0, "ingest_scatter_ok": 1,
                                             "backend": "gloo", "launched_by": "single process"}], r.stdout + r.stderr[-1000:]
 
 

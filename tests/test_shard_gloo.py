@@ -23,6 +23,12 @@ def _worker(rank, world, port, total, q):
     allrows = shard.gather_summaries(rows, dev)
     t = shard.max_over_ranks(1.0 + r, dev)
     tot = shard.sum_over_ranks([len(mine)], dev)
+    # ingest scatter: rank 0 holds every stream's "capture" (row s = s, s + 1, ...), each rank receives its own range
+    def rows_for_rank(k):
+        rng = shard.stream_range(total, w, k)
+        return torch.tensor([[s + c for c in range(5)] for s in rng], dtype=torch.uint8)
+    got = shard.scatter_rows(rows_for_rank, len(mine), (5,), torch.uint8, dev)
+    assert got.tolist() == [[s + c for c in range(5)] for s in mine], (r, got.tolist())
     q.put((r, list(mine), allrows.tolist(), t, float(tot[0])))
     dist.destroy_process_group()
 
