@@ -7,12 +7,18 @@ reset stream state -> per 32-symbol block {acquire | half-band + mix + FFT | syn
 
 Workloads (`--workload`), all with the same JSON schema:
   fm        BASELINE.json configs[2] (default, the headline metric): `--streams` (256) independent hybrid-FM MP1 cu8 streams
-            @1.488375 MS/s per GPU; with --gpus N the configs[3] family (256 per GPU, weak scaling)
+            @1.488375 MS/s per GPU; with --gpus N the configs[3] family: 256 per GPU (weak scaling, default) or
+            `--scaling strong --total-streams 2048` (a fixed set of streams split over the ranks)
   am-cs16   configs[4], AM half: 256 hybrid-AM MA1 cs16 streams @46511.71875 S/s, 61 s each
   am-cu8    configs[4], AM half through the 5-stage 32:1 decimator: 128 MA1 cu8 streams @1.488375 MS/s
   mixed     configs[4]: 128 FM cu8 + 64 AM cs16 + 64 AM cu8 streams in one engine
-configs[1] (one FM stream) is reported inside the fm line (`single_stream`), next to the in-order (reference event timing)
-figure of the same batch (`in_order`).
+The default fm line also carries: configs[1] (one FM stream, `single_stream`), the in-order (reference event timing) figure of
+the same batch (`in_order`), compact configs[4] legs (`config4`: am-cs16 and mixed, 3 passes each) and the DROP-IN as a user of
+`nrsc5 -r` sees it (`dropin`: the reference's public pipe API on libnrsc5_hipdropin.so vs the plain reference).
+
+Parity is enforced, not reported: every stream that lost sync in the last pass plus `--oracle-streams` others is compared with
+the UNMODIFIED reference (oracle/_ref, its own L2) -- complete ordered log, frames bit-exact -- and the process exits non-zero
+when any compared log differs or a checker leg raises (the JSON line is still printed, with the failure in it).
 
 `python bench.py --gpus N` starts its N ranks itself (one process per GPU, torch.distributed over RCCL) unless it already
 runs under torchrun.  Prints ONE JSON line on rank 0 with `roofline` and `cpu_baseline`.
@@ -22,6 +28,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import re
 import sys
 import time
 import zlib
@@ -32,25 +39,31 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # the engine drives 1 main + 3-4 decode streams next to torch's: give each its own hardware queue
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# dmabuf IPC: RCCL across processes needs it on this driver -- also when an external torchrun started the ranks without it
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 FS = 1488375.0
 FS_AM = 46511.71875
 HBM_PEAK_GBPS = 8000.0                  # MI355X_MICROARCH.md: 8 TB/s spec
+N_SIMD = 1024                           # 256 CUs x 4 SIMDs
 BLOCK_SAMPLES = 138240                  # cu8 complex samples per 32-symbol FM block
 FRAME_SAMPLES = 16 * BLOCK_SAMPLES
 # algorithmic bytes per input complex sample: input bytes + packed decoded bits
 ALG_FM_CU8 = 2.0 + 18432.0 / FRAME_SAMPLES                      # 2.008
 ALG_AM_CS16 = 4.0 + 6830.0 / 69120.0                            # 4.10
 ALG_AM_CU8 = 2.0 + 6830.0 / (69120.0 * 32)                      # 2.003
+FAILURES = []                            # parity / checker failures: the line is printed, then the process exits 3
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--workload", default="fm", choices=["fm", "am-cs16", "am-cu8", "mixed"])
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: 256; am-cu8: 128)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="--gpus N: weak = --streams per GPU; strong = --total-streams split over the ranks (configs[3]: 2048)")
+    ap.add_argument("--total-streams", type=int, default=2048, help="--scaling strong: streams of the whole job")
     ap.add_argument("--seconds", type=float, default=20.0, help="FM capture length per stream (SURVEY 8d: 20 s)")
     ap.add_argument("--am-frames", type=int, default=41, help="AM L1 frames per stream (41 = 61 s)")
     ap.add_argument("--payloads", type=int, default=8, help="distinct FM transmissions shared by the streams (each stream has its own CFO/offset/noise)")
@@ -58,38 +71,49 @@ def parse():
     ap.add_argument("--l2-feedback", type=int, default=1, help="1: the engine applies the reference's L2 -> L1 sync-loss feedback itself (RS check of the first L2 header on the device), as the CPU baseline's frame.c does; 0: off")
     ap.add_argument("--copy-input", action="store_true", help="fm: decimate the captures into the engine's Q15 FIFO first (K1 as its own kernel) instead of reading them in place")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no HIP-event kernel timing inside the timed region (roofline fields become 0)")
-    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every checker leg that runs on the host cores (CPU baseline, oracle equality)")
-    ap.add_argument("--no-extra-legs", action="store_true", help="fm: skip the single-stream (configs[1]) and in-order measurements")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every checker leg that runs on the host cores (CPU baseline, reference equality)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="fm: skip the single-stream (configs[1]), in-order, configs[4] and drop-in legs")
     ap.add_argument("--l2-index-inline", action="store_true", help="fm: engine option l2_index: index every P1 frame on the decode streams inside the timed region (default: untimed post-pass)")
     ap.add_argument("--no-l2-index", action="store_true", help="fm: skip the (untimed) L2 audio-index property check of the decoded frames")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-processes", type=int, default=0, help="processes of the N-core CPU aggregate (default: all host cores, at most 64)")
-    ap.add_argument("--oracle-streams", type=int, default=4, help="fm parity block: how many falsely-locking streams of the last pass are compared with the oracle (plus half as many others)")
+    ap.add_argument("--oracle-streams", type=int, default=8, help="parity block: streams that did NOT lose sync compared with the reference (every stream that lost sync is compared)")
+    ap.add_argument("--oracle-lost-max", type=int, default=64, help="parity block: upper bound on the lost-sync streams compared (reported when it bites)")
+    ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE", help="nrsc5hip_debug_tune before the run: decode_streams / am_decode_streams = 1..5")
     ap.add_argument("--launch-check", action="store_true", help="only start the ranks, form the process group (RCCL; gloo without a GPU) and print what it sees -- no workload")
     ap.add_argument("--ingest", choices=("local", "scatter"), default="local",
                     help="fm, --gpus N: local = every rank synthesises its own captures; scatter = rank 0 synthesises all of them and sends each rank its shard (RCCL point-to-point, before the timed region)")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="PMC-derived HBM bytes (profiles/collect_pmc.py); used only if it was collected from THIS source tree")
-    return ap.parse_args()
+    ap.add_argument("--sq-json", default=os.path.join(ROOT, "profiles", "sq_latest.json"),
+                    help="PMC-derived VALU issue statistics (profiles/collect_sq.py); used only if collected from THIS source tree")
+    args = ap.parse_args(argv)
+    if args.ingest == "scatter" and args.workload != "fm":
+        ap.error("--ingest scatter is implemented for --workload fm only")
+    return args
 
 
-# ---- CPU baseline (checker leg): the unmodified reference (oracle/_ref, SSE build) or the restatement ----------------
-def _cpu_runner(mode: int):
+# ---- checker legs: the unmodified reference (oracle/_ref, SSE build, its own L2) or, where that is absent, the restatement -----
+def _checker(mode: int, with_l2: bool):
+    """(run(iq) -> ordered log, kind).  kind "reference": oracle/_ref/libnrsc5_ref_sse.so = the reference's own translation units
+    incl. frame.c, so the L2 -> L1 sync-loss feedback is the reference's; kind "port": oracle/ restatement (+ restated decision)."""
     from oracle import ref, port
     if ref.available(sse=True):
         try:
             R = ref.RefLib(sse=True)
-            return (lambda iq: R.run(iq, mode=mode)), "reference"
+            return (lambda iq: R.run(iq, mode=mode)[0]), "reference"
         except OSError:
             pass
     O = port.Oracle()
-    return (lambda iq: O.run(iq, mode=mode)), "port"
+    if with_l2:
+        return (lambda iq: O.run(iq, mode=mode, p1_hook=O.l2_hook())[0]), "port"
+    return (lambda iq: O.run(iq, mode=mode)[0]), "port"
 
 
 def _cpu_worker(path: str, mode: int, reps: int, q):
     sys.path.insert(0, ROOT)
     iq = np.load(path, mmap_mode="r")
-    run, _ = _cpu_runner(mode)
+    run, _ = _checker(mode, False)
     iq = np.ascontiguousarray(iq)
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -102,7 +126,7 @@ def cpu_baseline(stream_iq: np.ndarray, fs: float, mode: int, budget_s: float, n
     (a) one host core, (b) one process per host core, each with its own session and the same stream (aggregate)."""
     import multiprocessing as mp
     import tempfile
-    run, kind = _cpu_runner(mode)
+    run, kind = _checker(mode, False)
     t0 = time.perf_counter(); run(stream_iq); dt1 = time.perf_counter() - t0
     reps = max(1, min(64, int(0.5 * budget_s / max(dt1, 1e-3))))
     t0 = time.perf_counter()
@@ -133,8 +157,71 @@ def cpu_baseline(stream_iq: np.ndarray, fs: float, mode: int, budget_s: float, n
             os.unlink(path)
             out["all_cores"] = {"value": round(n * per * nsamp / max(times) / 1e6, 2), "unit": "IQ MS/s", "x_realtime": round(n * per * nsamp / max(times) / fs, 1),
                                 "cores": n, "host_cores": ncpu, "sample": f"{n} processes x {per} passes of that stream, one session each; slowest process {max(times):.1f} s (wall incl. start-up {wall:.1f} s)"}
-        except Exception as ex:                           # a baseline, never allowed to take the bench line down
+        except Exception as ex:                           # the aggregate is a side figure of a baseline: reported, not fatal
             out["all_cores"] = {"error": repr(ex)}
+    return out
+
+
+_DIFF_RE = re.compile(r"#(\d+) (\w+)\.(\w+): (?:(\d+) elements differ)?")
+
+
+def compare_with_reference(ref_log, got_log, am: bool):
+    """Complete ordered log of one stream against the checker's.  Frames the reference decodes while falsely locked (its own
+    BER estimate cber > 0.02: Viterbi output on noise, which fails its L2 header on both sides and produces no HDC) are the one
+    documented exemption: their bits and BER are compared loosely and COUNTED here instead of being filtered silently.
+    -> (remaining diffs, exempt frames, largest number of differing bits in an exempt frame)"""
+    from tests import common
+    exp, got = common.strip_states(ref_log), common.strip_states(got_log)
+    diffs = common.compare_logs(exp, got)
+    kept = [x for x in exp if x[0] not in ("hdc", "soft", "vit", "amsym", "pxsoft", "station")]
+    bad = {i for i, (k, v) in enumerate(kept) if k == "ber" and v["cber"] > 0.02}
+    remaining, max_bits = [], 0
+    for d in diffs:
+        m = _DIFF_RE.match(d)
+        if m:
+            idx, kind = int(m.group(1)), m.group(2)
+            # FM: "ber" then the frame; AM: the P3 frame then "ber" (after block 7)
+            if (kind == "ber" and idx in bad) or (kind == "frame" and ((idx - 1) in bad or (am and (idx + 1) in bad))):
+                if m.group(4):
+                    max_bits = max(max_bits, int(m.group(4)))
+                continue
+        remaining.append(d)
+    return remaining, len(bad), max_bits
+
+
+def reference_equality(W, recs, counts, frames, to_log, am: bool):
+    """Every stream that lost sync in the last pass (bounded by --oracle-lost-max) + --oracle-streams others against the checker."""
+    eng, a = W.eng, W.args
+    run, kind = _checker(1 if am else 0, True)
+    lost = [k for k in W.checkable if ((recs[k, :counts[k]]["flags"] & eng.REC_LOST_SYNC) != 0).any()]
+    others = [k for k in W.checkable if k not in set(lost)]
+    # spread the others over the batch (different CFO / offset / SNR classes)
+    pick = others[::max(1, len(others) // max(a.oracle_streams, 1))][:a.oracle_streams]
+    lost_checked = lost[:a.oracle_lost_max]
+    t0 = time.perf_counter()
+    eq_lost = eq_other = exempt = max_bits = 0
+    first_diffs = []
+    for k in lost_checked + pick:
+        ref_log = run(W.stream_iq(k))
+        diffs, nex, mb = compare_with_reference(ref_log, to_log(k, recs[k, :counts[k]], frames[k]), am)
+        exempt += nex; max_bits = max(max_bits, mb)
+        if not diffs:
+            if k in lost_checked:
+                eq_lost += 1
+            else:
+                eq_other += 1
+        elif len(first_diffs) < 4:
+            first_diffs.append({"stream": int(W.my_streams[k]), "diffs": diffs[:3]})
+    out = {"kind": kind, "checker": "oracle/_ref/libnrsc5_ref_sse.so: the unmodified reference incl. its L2 (frame.c)" if kind == "reference" else "oracle/ restatement + restated frame_process decision (oracle/_ref not present)",
+           "streams_with_lost_sync_this_pass": len(lost), "lost_sync_streams_checked": len(lost_checked), "lost_sync_streams_equal": eq_lost,
+           "other_streams_checked": len(pick), "other_streams_equal": eq_other,
+           "frames_exempt_cber": exempt, "exempt_max_bit_differences": max_bits, "first_diffs": first_diffs, "seconds": round(time.perf_counter() - t0, 1),
+           "compared": "complete ordered log: sync / lost-sync blocks, every PIDS / P1 (/ P3) frame bit-exact, integers exact, floats 1e-4 (tests/common.py); "
+                       "frames_exempt_cber = frames the reference itself decodes while falsely locked (cber > 0.02, no HDC on either side): compared loosely, counted here"}
+    if len(lost) > len(lost_checked):
+        out["lost_sync_streams_not_checked"] = len(lost) - len(lost_checked)
+    if eq_lost != len(lost_checked) or eq_other != len(pick):
+        FAILURES.append(f"{W.name}: {len(lost_checked) - eq_lost} lost-sync + {len(pick) - eq_other} other stream logs differ from the {kind}")
     return out
 
 
@@ -151,15 +238,29 @@ def launch_check(args):
     # the ingest scatter of --ingest scatter in miniature: rank 0 makes every rank's rows, each rank must receive its own
     got = shard.scatter_rows(lambda r: torch.full((2, 4), r, dtype=torch.uint8, device=dev), 2, (4,), torch.uint8, dev)
     ranks = shard.sum_over_ranks([1.0, float(rank), float(bool((got == rank).all()))], dev)
+    mine = my_stream_ids(args, world, rank)
+    per_rank = shard.gather_floats(float(len(mine)), dev)
     if rank == 0:
         print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_in_process_group": int(ranks[0]), "rank_sum": int(ranks[1]), "ingest_scatter_ok": int(ranks[2]),
+                          "scaling": args.scaling, "streams_per_rank": [int(x) for x in per_rank], "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                           "backend": "nccl(RCCL)" if cuda else "gloo", "launched_by": os.environ.get("NRSC5_BENCH_LAUNCHER", "external torchrun" if world > 1 else "single process")}))
+        sys.stdout.flush()
+    shard.shutdown(dev)
+
+
+def my_stream_ids(args, world, rank):
+    """contiguous stream ranges per rank, no data-path collective: weak = --streams per GPU, strong = --total-streams over all ranks"""
+    from nrsc5_amd import shard
+    if args.scaling == "strong":
+        return list(shard.stream_range(args.total_streams, world, rank))
+    S = args.streams or (128 if args.workload == "am-cu8" else 256)
+    return list(shard.stream_range(S * world, world, rank))
 
 
 # ---- workloads ----------------------------------------------------------------------------------------------------------
 class Fm:
     """configs[2] / configs[3]: hybrid-FM MP1 cu8 streams (seed 1000+k, CFO +-300 Hz, offset [0, 4320), SNR 15/20/25 dB)"""
-    fs, mode, alg = FS, 0, ALG_FM_CU8
+    name, fs, mode, alg = "fm", FS, 0, ALG_FM_CU8
     dtype = "exact float32 half-band (== int16 Q15) / f32 OFDM + sync / int32 Viterbi metrics"
 
     def __init__(self, args, dev, local, my_streams):
@@ -167,6 +268,7 @@ class Fm:
         from nrsc5_amd import engine as eng, synth_torch as stt
         self.args, self.dev, self.eng, self.my_streams = args, dev, eng, my_streams
         S = self.S = len(my_streams)
+        self.checkable = list(range(S))
         self.n_frames = n_frames = max(2, int(np.ceil(args.seconds * FS / FRAME_SAMPLES)))
         self.pool = []
         for p in range(args.payloads):
@@ -188,8 +290,7 @@ class Fm:
             from nrsc5_amd import shard
             import torch.distributed as dist
             world = dist.get_world_size() if dist.is_initialized() else 1
-            total = S * world
-            self.iq, nb = shard.scatter_shards(lambda r: generate(list(shard.stream_range(total, world, r))),
+            self.iq, nb = shard.scatter_shards(lambda r: generate(my_stream_ids(args, world, r)),
                                                [((S, self.stride), torch.uint8), ((S, 1), torch.int64)], dev)
         else:
             self.iq, nb = generate(my_streams)
@@ -205,9 +306,11 @@ class Fm:
         # replay (window pipeline + L2 feedback): blocks that ran behind a failed P1 frame keep their records / ring slots
         # (marked void, never delivered), so both rings carry head-room for the speculated stretch.  Zero-copy: the captures
         # are read where they are, so the FIFO stays at its minimum size.
-        return self.eng.Engine(max_streams=S, q15_capacity=2 * 71280 if self.zero_copy else int(self.stride // 4 + 1024),
-                               record_capacity=max(512, 2 * 16 * self.n_frames + 64), p1_slots=self.n_frames + 12, p1_async=not in_order, device=local,
-                               l2_feedback=bool(a.l2_feedback), l2_index=bool(a.l2_index_inline), batch_zero_copy=self.zero_copy)
+        E = self.eng.Engine(max_streams=S, q15_capacity=2 * 71280 if self.zero_copy else int(self.stride // 4 + 1024),
+                            record_capacity=max(512, 2 * 16 * self.n_frames + 64), p1_slots=self.n_frames + 12, p1_async=not in_order, device=local,
+                            l2_feedback=bool(a.l2_feedback), l2_index=bool(a.l2_index_inline), batch_zero_copy=self.zero_copy)
+        apply_tune(E, a)
+        return E
 
     def one_pass(self, E=None, S=None, host_ms=None):
         E = E or self.E; S = S or self.S
@@ -228,7 +331,9 @@ class Fm:
                 "streams_per_gpu": self.S, "seconds_per_stream": round(float(self.nbytes[0]) / 2 / FS, 3),
                 "p1_decode": "in-order" if a.sync_p1 else "windowed-overlap", "l2_feedback": "on-device" if a.l2_feedback else "off",
                 "input": "read in place (half-band fused into the symbol kernel)" if self.zero_copy else "decimated copy in the Q15 FIFO",
-                "block_steps_per_pass": int(steps), "ingest": a.ingest, "distinct_payloads": a.payloads, "hbm_resident_input_GB": round(float(self.nbytes.sum()) / 1e9, 2)}
+                "block_steps_per_pass": int(steps), "ingest": a.ingest, "distinct_payloads": a.payloads,
+                "payload_note": f"{a.payloads} transmitted payloads shared by the streams; CFO / timing offset / noise realisation are per stream (seed 1000 + stream id)",
+                "hbm_resident_input_GB": round(float(self.nbytes.sum()) / 1e9, 2)}
 
     def verify(self, recs, counts, frames):
         """last pass vs the transmitted truth: per stream [id, blocks, P1 frames, exact frames, PIDS frames, FINE blocks, CRC of frames]"""
@@ -263,40 +368,23 @@ class Fm:
                 "p1_frames_decoded": int(allrows[:, 2].sum()), "p1_frames_bit_exact_vs_truth": int(allrows[:, 3].sum()),
                 "pids_frames_decoded": int(allrows[:, 4].sum()),
                 "note": "streams whose timing offset falls in the reference algorithm's false-lock zone (sync.c phase-slope ambiguity, ~6 % of uniform offsets) "
-                        "decode one garbage frame in the reference too, whose L2 then forces a re-acquisition; with l2_feedback the engine does the same on the "
-                        "device: the verdict of the deferred decode rewinds the stream to the end of that frame's block (k_replay.hip), so LOST_SYNC and the "
-                        "re-acquisition land on the reference's blocks"}
+                        "decode one garbage frame in the reference too (not a transmitted frame: decoded - bit_exact_vs_truth = those), whose L2 then forces a "
+                        "re-acquisition; with l2_feedback the engine does the same on the device: the verdict of the deferred decode rewinds the stream to the "
+                        "end of that frame's block (k_replay.hip), so LOST_SYNC and the re-acquisition land on the reference's blocks"}
+
+    def stream_iq(self, k):
+        return self.iq[k, :int(self.nbytes[k])].cpu().numpy()
 
     def cpu_sample(self):
-        return self.iq[0, :int(self.nbytes[0])].cpu().numpy()
+        return self.stream_iq(0)
 
-    # ---- fm-only checker / side legs (rank 0, N = 1) ----------------------------------------------------------------------
-    def reference_equality(self, recs, counts, frames):
-        """Streams the reference algorithm first locks falsely on (their log has LOST_SYNC) + the first streams that did not:
-        the complete ordered log -- sync / lost-sync blocks, every PIDS and P1 frame, MER / BER / CFO -- against the oracle
-        driven by the restated frame_process decision."""
-        from oracle import port
-        from tests import common
-        eng, O = self.eng, port.Oracle()
-        lost = [k for k in range(self.S) if ((recs[k, :counts[k]]["flags"] & eng.REC_LOST_SYNC) != 0).any()]
-        n = self.args.oracle_streams
-        sample = lost[:n] + [k for k in range(self.S) if k not in lost][:max(1, n // 2)]
-        t0 = time.perf_counter()
-        equal, first_diffs = 0, []
-        for k in sample:
-            ol, _, _ = O.run(self.iq[k, :int(self.nbytes[k])].cpu().numpy(), p1_hook=O.l2_hook())
-            log = eng.records_to_log(self.E, k, recs[k, :counts[k]], frames[k])
-            diffs = common.compare_logs(common.strip_states(ol), common.strip_states(log))
-            kept = [x for x in common.strip_states(ol) if x[0] not in ("hdc", "soft", "vit", "amsym", "pxsoft")]
-            bad = {i for i, (kk, v) in enumerate(kept) if kk == "ber" and v["cber"] > 0.02}     # frames decoded while falsely locked: noise in, noise out
-            diffs = [d for d in diffs if not any(d.startswith(f"#{i} ber") or d.startswith(f"#{i + 1} frame") for i in bad)]
-            equal += not diffs
-            if diffs and len(first_diffs) < 3:
-                first_diffs.append({"stream": int(self.my_streams[k]), "diff": diffs[0]})
-        return {"streams_with_lost_sync_this_pass": len(lost), "streams_checked": len(sample), "of_which_with_lost_sync": len([k for k in sample if k in lost]),
-                "logs_equal_to_oracle_with_l2_hook": int(equal), "first_diffs": first_diffs, "seconds": round(time.perf_counter() - t0, 1),
-                "compared": "ordered log: state/sync/lost_sync blocks, PIDS + P1 frames bit-exact (frames with cber > 0.02 = decoded while falsely locked excepted), floats 1e-4"}
+    def to_log(self, k, r, fr):
+        return self.eng.records_to_log(self.E, k, r, fr)
 
+    def is_am(self, k):
+        return False
+
+    # ---- fm-only side legs (rank 0, N = 1) ---------------------------------------------------------------------------------
     def l2_property(self):
         """full-size property check on the device: the L2 audio index of every decoded P1 frame (frame_push + RS header + CRC-8 of
         all 32 audio packets, k_l2_index) must be clean exactly for the frames that equal the transmitted bits"""
@@ -309,11 +397,14 @@ class Fm:
             idx = self.E.l2_index(self.l2_jobs, want_bytes=False)
         dt = time.perf_counter() - t0
         clean = [int(d["n_pdu"] == 1 and d["pdus"][0]["nop"] == 32 and d["pdus"][0]["crc_bad_lo"] == 0 and d["lost_sync"] == 0) for d, _ in idx]
-        return {"where": "decode streams, inside the timed region" if a.l2_index_inline else "post-pass, untimed",
-                "frames_indexed": len(idx), "host_ms_incl_copies": round(dt * 1e3, 2),
-                "audio_packets_crc_ok": int(sum(sum(p["nop"] - bin(p["crc_bad_lo"] | (p["crc_bad_hi"] << 32)).count("1") for p in d["pdus"]) for d, _ in idx)),
-                "frames_clean": int(sum(clean)), "clean_and_bit_exact": int(sum(c & e for c, e in zip(clean, self.l2_exact))),
-                "bit_exact": int(sum(self.l2_exact)), "frames_flagged_lost_sync": int(sum(d["lost_sync"] for d, _ in idx))}
+        out = {"where": "decode streams, inside the timed region" if a.l2_index_inline else "post-pass, untimed",
+               "frames_indexed": len(idx), "host_ms_incl_copies": round(dt * 1e3, 2),
+               "audio_packets_crc_ok": int(sum(sum(p["nop"] - bin(p["crc_bad_lo"] | (p["crc_bad_hi"] << 32)).count("1") for p in d["pdus"]) for d, _ in idx)),
+               "frames_clean": int(sum(clean)), "clean_and_bit_exact": int(sum(c & e for c, e in zip(clean, self.l2_exact))),
+               "bit_exact": int(sum(self.l2_exact)), "frames_flagged_lost_sync": int(sum(d["lost_sync"] for d, _ in idx))}
+        if not (out["frames_clean"] == out["clean_and_bit_exact"] == out["bit_exact"]):
+            FAILURES.append("fm: L2 index property (clean <=> bit-exact) violated")
+        return out
 
     def extra_legs(self, local):
         """configs[1] (one stream through the same engine build) and the in-order mode (reference event timing) of the whole batch"""
@@ -328,7 +419,7 @@ class Fm:
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 5
         n1 = float(self.nbytes[0]) / 2
         p1 = int(((recs[0, :counts[0]]["flags"] & self.eng.REC_P1) != 0).sum())
-        out["single_stream"] = {"workload": "configs[1]: stream 0 of the batch alone on the GPU (window pipeline, L2 feedback, zero-copy)",
+        out["single_stream"] = {"workload": "configs[1]: stream 0 of the batch alone on the GPU (batch API: capture resident in HBM, window pipeline, L2 feedback, zero-copy)",
                                 "ms_per_pass": round(dt * 1e3, 3), "x_realtime": round(n1 / FS / dt, 1), "value_MSps": round(n1 / dt / 1e6, 2),
                                 "us_per_block": round(dt * 1e6 / max(int(counts[0]), 1), 1), "blocks": int(counts[0]), "p1_frames": p1}
         E1.close()
@@ -346,9 +437,44 @@ class Fm:
         return out
 
 
+def am_batch(args, dev, streams, fmt, n_frames, signal_seed):
+    """Per-stream receivers of ONE clean hybrid-AM MA1 transmission: own CFO, timing offset, noise realisation and level (seed
+    5000 + stream id); every 16th stream is hit by an interference burst that breaks first L2 headers (the reference drops to
+    SYNC_STATE_NONE there: the replay path).  -> (iq [S, stride] on the device, sizes in elements, truth)"""
+    import torch
+    from nrsc5_amd import synth_am, synth_torch as stt
+    sig, p1, p3, _ = synth_am.am_ma1_signal(n_frames, seed=signal_seed, fmt=fmt)
+    sd = torch.from_numpy(sig.astype(np.complex64)).to(dev)
+    over = 1 if fmt == "cs16" else 32
+    stride = (2 * (9 * 270 * over + sig.shape[0] + 1080 * over) + 255) // 256 * 256
+    iq = torch.zeros((len(streams), stride), dtype=torch.int16 if fmt == "cs16" else torch.uint8, device=dev)
+    sizes = np.zeros(len(streams), dtype=np.uint32)
+    for k, gs in enumerate(streams):
+        prm = stt.am_stream_params(gs, n_frames)
+        out = stt.channel_am(sd, prm["cfo_hz"], prm["offset"] * over, prm["noise"], prm["seed"], fmt, burst=prm["burst"], out=iq[k])
+        sizes[k] = out.shape[0] - out.shape[0] % 4
+    truth1 = {np.packbits(b, bitorder="little").tobytes() for fr in p1 for b in fr}
+    truth3 = {np.packbits(b, bitorder="little").tobytes() for b in p3}
+    del sd
+    return iq, stride, sizes, truth1, truth3
+
+
+def am_frame_truth_check(eng, r, frames_k, truth1, truth3):
+    n1 = ok1 = n3 = ok3 = 0
+    for rr in r:
+        fl, slot, bc = int(rr["flags"]), int(rr["p1_slot"]), int(rr["bc_decoded"])
+        if fl & eng.REC_P1:
+            n1 += 1
+            ok1 += np.packbits(eng.unpack_bits(frames_k[slot, bc * 118:(bc + 1) * 118], 3750), bitorder="little").tobytes() in truth1
+        if fl & eng.REC_P3:
+            n3 += 1
+            ok3 += np.packbits(eng.unpack_bits(frames_k[slot, 944:944 + 750], 24000), bitorder="little").tobytes() in truth3
+    return n1, ok1, n3, ok3
+
+
 class Am:
-    """configs[4], AM half: hybrid-AM MA1 streams, cs16 @46511.71875 S/s or cu8 @1.488375 MS/s (32:1 cascade), one transmission,
-    streams staggered in time"""
+    """configs[4], AM half: hybrid-AM MA1 streams, cs16 @46511.71875 S/s or cu8 @1.488375 MS/s (32:1 cascade); one transmission seen
+    by per-stream receivers (CFO +-100 Hz, timing offset over 9 OFDM symbols, three noise levels, interference bursts on every 16th)"""
     mode = 1
     dtype = "int16 Q15 decimator (cu8) / f32 OFDM + sync / int32 K=9 Viterbi metrics"
 
@@ -356,22 +482,18 @@ class Am:
         import torch
         from nrsc5_amd import engine as eng, synth_am
         self.args, self.dev, self.eng, self.my_streams, self.fmt = args, dev, eng, my_streams, fmt
+        self.name = "am-" + fmt
         S = self.S = len(my_streams)
+        self.checkable = list(range(S))
         self.fs = synth_am.FS_CS16 if fmt == "cs16" else synth_am.FS_CU8
         self.alg = ALG_AM_CS16 if fmt == "cs16" else ALG_AM_CU8
-        self.cap = cap = synth_am.am_ma1_capture(args.am_frames, seed=77, cfo_hz=4.0, offset=3000 * (32 if fmt == "cu8" else 1), fmt=fmt)
-        base = torch.from_numpy(cap.iq).to(dev)
-        per = 4 if fmt == "cs16" else 64
-        self.n = n = (cap.iq.size - 2 * per * 97) // 4 * 4
-        self.iq = torch.empty((S, n), dtype=base.dtype, device=dev)
-        for k, gs in enumerate(my_streams):
-            self.iq[k] = base[2 * per * (gs % 97): 2 * per * (gs % 97) + n]
+        self.iq, self.stride, self.sizes, self._t1, self._t3 = am_batch(args, dev, my_streams, fmt, args.am_frames, 77)
         torch.cuda.synchronize()
-        self.samples = S * n / 2.0
+        self.samples = float(self.sizes.astype(np.float64).sum()) / 2.0
         self.signal_seconds = self.samples / self.fs
-        self.sizes = np.full(S, n, dtype=np.uint32)
-        self.E = eng.Engine(max_streams=S, q15_capacity=int(n / 2 / (1 if fmt == "cs16" else 32)) + 4096, record_capacity=8 * args.am_frames + 16,
-                            p1_slots=args.am_frames, am_enable=True, p1_async=not args.sync_p1, l2_feedback=bool(args.l2_feedback), device=local)
+        self.E = eng.Engine(max_streams=S, q15_capacity=int(self.stride / 2 / (1 if fmt == "cs16" else 32)) + 4096, record_capacity=max(512, 2 * 8 * args.am_frames + 64),
+                            p1_slots=args.am_frames + 12, am_enable=True, p1_async=not args.sync_p1, l2_feedback=bool(args.l2_feedback), device=local)
+        apply_tune(self.E, args)
         for k in range(S):
             self.E.set_mode(k, eng.MODE_AM)
 
@@ -380,9 +502,9 @@ class Am:
         t = [time.perf_counter()]
         E.reset_all(); t.append(time.perf_counter())
         if self.fmt == "cs16":
-            E.batch_append_cs16(self.iq.data_ptr(), self.n, self.sizes)
+            E.batch_append_cs16(self.iq.data_ptr(), self.stride, self.sizes)
         else:
-            E.batch_append_cu8(self.iq.data_ptr(), self.n, self.sizes)
+            E.batch_append_cu8(self.iq.data_ptr(), self.stride, self.sizes)
         t.append(time.perf_counter())
         steps = E.batch_process(self.S); t.append(time.perf_counter())
         out = E.batch_fetch(self.S) if self.args.sync_p1 else E.batch_fetch_view(self.S); t.append(time.perf_counter())
@@ -392,31 +514,22 @@ class Am:
         return steps, out
 
     def describe(self, steps):
-        return {"workload": f"configs[4], AM half: batch={self.S} hybrid-AM MA1 {self.fmt} streams @{self.fs:.5f} S/s per GPU, {self.n / 2 / self.fs:.1f} s each "
-                            f"({self.args.am_frames} L1 frames), one transmission staggered in time" + (", through the 5-stage 32:1 decimator" if self.fmt == "cu8" else ""),
-                "streams_per_gpu": self.S, "seconds_per_stream": round(self.n / 2 / self.fs, 2), "p1_decode": "in-order" if self.args.sync_p1 else "windowed-overlap",
+        return {"workload": f"configs[4], AM half: batch={self.S} hybrid-AM MA1 {self.fmt} streams @{self.fs:.5f} S/s per GPU, {self.sizes[0] / 2 / self.fs:.1f} s each "
+                            f"({self.args.am_frames} L1 frames), per-stream CFO +-100 Hz / timing offset / noise (seed 5000 + stream id), interference bursts on every 16th stream"
+                            + (", through the 5-stage 32:1 decimator" if self.fmt == "cu8" else ""),
+                "streams_per_gpu": self.S, "seconds_per_stream": round(float(self.sizes[0]) / 2 / self.fs, 2), "p1_decode": "in-order" if self.args.sync_p1 else "windowed-overlap",
                 "l2_feedback": "on-device" if self.args.l2_feedback else "off", "block_steps_per_pass": int(steps), "hbm_resident_input_GB": round(self.iq.numel() * self.iq.element_size() / 1e9, 2)}
 
     def verify(self, recs, counts, frames):
-        eng, cap = self.eng, self.cap
-        if not hasattr(self, "_t1"):
-            self._t1 = {np.packbits(b, bitorder="little").tobytes() for fr in cap.p1_frames for b in fr}
-            self._t3 = {np.packbits(b, bitorder="little").tobytes() for b in cap.p3_frames}
+        eng = self.eng
         rows = []
         for k, gs in enumerate(self.my_streams):
             r = recs[k, :counts[k]]
-            n1 = ok1 = n3 = ok3 = 0
             check = (k % max(1, self.S // 16)) == 0             # frame-by-frame truth check on every 16th stream; counts on all
-            for rr in r:
-                fl, slot, bc = int(rr["flags"]), int(rr["p1_slot"]), int(rr["bc_decoded"])
-                if fl & eng.REC_P1:
-                    n1 += 1
-                    if check:
-                        ok1 += np.packbits(eng.unpack_bits(frames[k, slot, bc * 118:(bc + 1) * 118], 3750), bitorder="little").tobytes() in self._t1
-                if fl & eng.REC_P3:
-                    n3 += 1
-                    if check:
-                        ok3 += np.packbits(eng.unpack_bits(frames[k, slot, 944:944 + 750], 24000), bitorder="little").tobytes() in self._t3
+            if check:
+                n1, ok1, n3, ok3 = am_frame_truth_check(eng, r, frames[k], self._t1, self._t3)
+            else:
+                n1 = int(((r["flags"] & eng.REC_P1) != 0).sum()); n3 = int(((r["flags"] & eng.REC_P3) != 0).sum()); ok1 = ok3 = 0
             rows.append([gs, len(r), n1 + n3, (ok1 + ok3) if check else -1, int(((r["flags"] & eng.REC_PIDS) != 0).sum()), int((r["state_after"] == eng.SYNC_FINE).sum()), n3])
         return rows
 
@@ -426,41 +539,31 @@ class Am:
                 "pids_frames_decoded": int(allrows[:, 4].sum()), "streams_checked_frame_by_frame": int(chk.shape[0]),
                 "frames_checked": int(chk[:, 2].sum()), "frames_equal_transmitted_bits": int(chk[:, 3].sum())}
 
-    def cpu_sample(self):
-        return np.ascontiguousarray(self.cap.iq[:self.n])
+    def stream_iq(self, k):
+        return self.iq[k, :int(self.sizes[k])].cpu().numpy()
 
-    def reference_equality(self, recs, counts, frames):
-        """A sample of streams (those that lost sync first): the complete ordered log against the oracle driven by the restated
-        frame_process decision.  The AM window pipeline applies a failed first header late (no replay yet), so equality holds
-        only while no stream loses sync -- the count is part of the block."""
-        from oracle import port
-        from tests import common
-        eng, O = self.eng, port.Oracle()
-        lost = [k for k in range(self.S) if ((recs[k, :counts[k]]["flags"] & eng.REC_LOST_SYNC) != 0).any()]
-        sample = lost[:2] + [k for k in range(self.S) if k not in lost][:2]
-        t0 = time.perf_counter()
-        equal, first_diffs = 0, []
-        for k in sample:
-            ol, _, _ = O.run(self.iq[k].cpu().numpy(), mode=1, p1_hook=O.l2_hook())
-            log = eng.am_records_to_log(self.E, k, recs[k, :counts[k]], frames[k])
-            diffs = common.compare_logs(common.strip_states(ol), common.strip_states(log))
-            equal += not diffs
-            if diffs and len(first_diffs) < 3:
-                first_diffs.append({"stream": int(self.my_streams[k]), "diff": diffs[0]})
-        return {"streams_with_lost_sync_this_pass": len(lost), "streams_checked": len(sample), "logs_equal_to_oracle_with_l2_hook": int(equal),
-                "first_diffs": first_diffs, "seconds": round(time.perf_counter() - t0, 1),
-                "compared": "ordered log: state/sync blocks, PIDS + P1 + P3 frames bit-exact, floats 1e-4"}
+    def cpu_sample(self):
+        return self.stream_iq(0)
+
+    def to_log(self, k, r, fr):
+        return self.eng.am_records_to_log(self.E, k, r, fr)
+
+    def is_am(self, k):
+        return True
 
 
 class Mixed:
     """configs[4]: 128 FM cu8 + 64 AM cs16 + 64 AM cu8 streams in ONE engine (the FM and AM halves run back to back)"""
+    name = "mixed"
     dtype = "as the fm and am workloads"
+    mode = None
 
     def __init__(self, args, dev, local, my_streams):
         import torch
         from nrsc5_amd import engine as eng, synth_am, synth_torch as stt
         self.args, self.dev, self.eng, self.my_streams = args, dev, eng, my_streams
         S = self.S = len(my_streams)
+        self.checkable = list(range(S))
         self.nfm = nfm = S // 2
         nam = S - nfm
         self.n16, self.n8 = nam // 2, nam - nam // 2
@@ -477,24 +580,20 @@ class Mixed:
             prm = stt.stream_params(my_streams[k])
             out = stt.channel_cu8(self.pool[k % 4][1], prm["cfo_hz"], prm["offset"], prm["snr_db"], prm["seed"], tail=tail, out=self.fm[k])
             self.fm_bytes[k] = out.shape[0] - out.shape[0] % 4
-        c16 = synth_am.am_ma1_capture(args.am_frames, seed=77, cfo_hz=4.0, offset=3000, fmt="cs16")
-        c8 = synth_am.am_ma1_capture(args.am_frames, seed=78, cfo_hz=-3.0, offset=3000 * 32, fmt="cu8")
-        b16, b8 = torch.from_numpy(c16.iq).to(dev), torch.from_numpy(c8.iq).to(dev)
-        self.len16 = (c16.iq.size - 8 * 97) // 4 * 4
-        self.len8 = (c8.iq.size - 128 * 97) // 4 * 4
-        self.am16 = torch.stack([b16[8 * (k % 97): 8 * (k % 97) + self.len16] for k in range(self.n16)])
-        self.am8 = torch.stack([b8[128 * (k % 97): 128 * (k % 97) + self.len8] for k in range(self.n8)])
-        self.cap8 = c8
+        self.am16, self.len16, self.sizes16, self._t1_16, self._t3_16 = am_batch(args, dev, [my_streams[nfm + k] for k in range(self.n16)], "cs16", args.am_frames, 77)
+        self.am8, self.len8, self.sizes8, self._t1_8, self._t3_8 = am_batch(args, dev, [my_streams[nfm + self.n16 + k] for k in range(self.n8)], "cu8", args.am_frames, 78)
         torch.cuda.synchronize()
-        self.samples = float(self.fm_bytes.sum()) / 2 + self.n16 * self.len16 / 2 + self.n8 * self.len8 / 2
-        self.signal_seconds = float(self.fm_bytes.sum()) / 2 / FS + self.n16 * (self.len16 / 2) / synth_am.FS_CS16 + self.n8 * (self.len8 / 2) / synth_am.FS_CU8
-        self.alg_bytes = float(self.fm_bytes.sum()) / 2 * ALG_FM_CU8 + self.n16 * self.len16 / 2 * ALG_AM_CS16 + self.n8 * self.len8 / 2 * ALG_AM_CU8
+        s16, s8 = float(self.sizes16.astype(np.float64).sum()) / 2, float(self.sizes8.astype(np.float64).sum()) / 2
+        self.samples = float(self.fm_bytes.sum()) / 2 + s16 + s8
+        self.signal_seconds = float(self.fm_bytes.sum()) / 2 / FS + s16 / synth_am.FS_CS16 + s8 / synth_am.FS_CU8
+        self.alg_bytes = float(self.fm_bytes.sum()) / 2 * ALG_FM_CU8 + s16 * ALG_AM_CS16 + s8 * ALG_AM_CU8
         self.alg = self.alg_bytes / self.samples
         self.fs = self.samples / self.signal_seconds            # for the x real-time of the line
         cap = max(self.len16 // 2, self.len8 // 64, 2 * 71280) + 4096
-        self.E = eng.Engine(max_streams=S, q15_capacity=int(cap), record_capacity=max(2 * 16 * n_frames + 64, 8 * args.am_frames + 32, 512),
-                            p1_slots=max(n_frames + 12, args.am_frames), p1_async=True, am_enable=True, l2_feedback=bool(args.l2_feedback),
+        self.E = eng.Engine(max_streams=S, q15_capacity=int(cap), record_capacity=max(2 * 16 * n_frames + 64, 2 * 8 * args.am_frames + 64, 512),
+                            p1_slots=max(n_frames, args.am_frames) + 12, p1_async=True, am_enable=True, l2_feedback=bool(args.l2_feedback),
                             batch_zero_copy=True, device=local)
+        apply_tune(self.E, args)
         self.ids_fm = np.arange(nfm, dtype=np.int32)
         self.ids16 = np.arange(nfm, nfm + self.n16, dtype=np.int32)
         self.ids8 = np.arange(nfm + self.n16, S, dtype=np.int32)
@@ -506,8 +605,8 @@ class Mixed:
         t = [time.perf_counter()]
         E.reset_all(); t.append(time.perf_counter())
         E.batch_append_cu8(self.fm.data_ptr(), self.stride_fm, self.fm_bytes, stream_ids=self.ids_fm)
-        E.batch_append_cs16(self.am16.data_ptr(), self.len16, np.full(self.n16, self.len16, dtype=np.uint32), stream_ids=self.ids16)
-        E.batch_append_cu8(self.am8.data_ptr(), self.len8, np.full(self.n8, self.len8, dtype=np.uint32), stream_ids=self.ids8)
+        E.batch_append_cs16(self.am16.data_ptr(), self.len16, self.sizes16, stream_ids=self.ids16)
+        E.batch_append_cu8(self.am8.data_ptr(), self.len8, self.sizes8, stream_ids=self.ids8)
         t.append(time.perf_counter())
         steps = E.batch_process(self.S); t.append(time.perf_counter())
         out = E.batch_fetch_view(self.S); t.append(time.perf_counter())
@@ -518,7 +617,7 @@ class Mixed:
 
     def describe(self, steps):
         return {"workload": f"configs[4]: mixed batch of {self.nfm} hybrid-FM MP1 cu8 streams ({self.n_frames} L1 frames each, read in place) + {self.n16} AM MA1 cs16 + "
-                            f"{self.n8} AM MA1 cu8 streams ({self.args.am_frames} L1 frames each) in one engine",
+                            f"{self.n8} AM MA1 cu8 streams ({self.args.am_frames} L1 frames each) in one engine; per-stream CFO / offset / noise everywhere",
                 "streams_per_gpu": self.S, "signal_seconds_per_pass": round(self.signal_seconds, 1), "p1_decode": "windowed-overlap",
                 "l2_feedback": "on-device" if self.args.l2_feedback else "off", "block_steps_per_pass": int(steps)}
 
@@ -532,16 +631,100 @@ class Mixed:
             if k < self.nfm:
                 truth = {t.tobytes() for t in self.pool[k % 4][0]}
                 ok = sum(1 for rr in r if (int(rr["flags"]) & eng.REC_P1) and frames[k, int(rr["p1_slot"])].view(np.uint8).tobytes() in truth)
+            elif (k - self.nfm) % 8 == 0:
+                t1, t3 = (self._t1_16, self._t3_16) if k < self.nfm + self.n16 else (self._t1_8, self._t3_8)
+                n1, ok1, n3, ok3 = am_frame_truth_check(eng, r, frames[k], t1, t3)
+                ok = ok1
             rows.append([gs, len(r), nfr, ok, int(((r["flags"] & eng.REC_PIDS) != 0).sum()), int((r["state_after"] == eng.SYNC_FINE).sum()), int(k < self.nfm)])
         return rows
 
     def parity(self, allrows):
         fm = allrows[allrows[:, 6] == 1]; am = allrows[allrows[:, 6] == 0]
+        amc = am[am[:, 3] >= 0]
         return {"streams": int(allrows.shape[0]), "fm_p1_frames_decoded": int(fm[:, 2].sum()), "fm_p1_frames_bit_exact_vs_truth": int(fm[:, 3].sum()),
-                "am_p1_frames_decoded": int(am[:, 2].sum()), "pids_frames_decoded": int(allrows[:, 4].sum())}
+                "am_p1_frames_decoded": int(am[:, 2].sum()), "am_streams_checked_frame_by_frame": int(amc.shape[0]), "am_p1_frames_checked": int(amc[:, 2].sum()),
+                "am_p1_frames_equal_transmitted_bits": int(amc[:, 3].sum()), "pids_frames_decoded": int(allrows[:, 4].sum())}
+
+    def stream_iq(self, k):
+        if k < self.nfm:
+            return self.fm[k, :int(self.fm_bytes[k])].cpu().numpy()
+        if k < self.nfm + self.n16:
+            j = k - self.nfm
+            return self.am16[j, :int(self.sizes16[j])].cpu().numpy()
+        j = k - self.nfm - self.n16
+        return self.am8[j, :int(self.sizes8[j])].cpu().numpy()
 
     def cpu_sample(self):
         return None
+
+    def to_log(self, k, r, fr):
+        return self.eng.am_records_to_log(self.E, k, r, fr) if k >= self.nfm else self.eng.records_to_log(self.E, k, r, fr)
+
+    def is_am(self, k):
+        return k >= self.nfm
+
+
+TUNE_KNOBS = {"decode_streams": 0, "am_decode_streams": 1}
+
+
+def apply_tune(E, args):
+    for kv in args.tune:
+        k, v = kv.split("=")
+        E.tune(TUNE_KNOBS[k], int(v))
+
+
+def mixed_reference_equality(W, recs, counts, frames):
+    """Mixed batch: the FM and the AM members are checked by their own checker sessions"""
+    out = {}
+    for label, am in (("fm", False), ("am", True)):
+        sub = type("Sub", (), {})()
+        sub.eng, sub.args, sub.my_streams, sub.name = W.eng, W.args, W.my_streams, f"mixed/{label}"
+        sub.checkable = [k for k in range(W.S) if W.is_am(k) == am]
+        sub.stream_iq = W.stream_iq
+        out[label] = reference_equality(sub, recs, counts, frames, W.to_log, am)
+    return out
+
+
+def dropin_leg(iq: np.ndarray, fs: float):
+    """configs[0]/[1] as a user of `nrsc5 -r` sees them: one capture through the reference's PUBLIC pipe API (nrsc5_open_pipe,
+    nrsc5_pipe_samples_cu8 in 32768-byte calls: src/main.c:1095-1121) on the drop-in (integration/input_hip.c + libnrsc5hip.so
+    under the reference's untouched L4 / L2 code) and on the plain reference build; events must be equal."""
+    import ctypes
+    from oracle import ref
+    from tests import common
+    paths = {"dropin": os.path.join(ROOT, "integration", "_build", "libnrsc5_hipdropin.so"), "plain": os.path.join(ROOT, "oracle", "_ref", "libnrsc5_plain.so")}
+    if not all(os.path.exists(p) for p in paths.values()):
+        return {"skipped": "integration/_build/libnrsc5_hipdropin.so or oracle/_ref/libnrsc5_plain.so not prebuilt (need /root/reference in the build container)"}
+    out, logs = {"feed": "nrsc5_pipe_samples_cu8, 32768-byte calls (src/main.c:1095-1121)", "seconds_of_signal": round(iq.size / 2 / fs, 2)}, {}
+    for name, path in paths.items():
+        lib = ctypes.CDLL(path)
+        lib.pipe_run.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        lib.pipe_run.restype = ctypes.c_size_t
+        lib.pipe_last_feed_seconds.restype = ctypes.c_double
+        best, wall = None, None
+        for rep in range(3 if name == "dropin" else 2):
+            p = ctypes.c_void_p()
+            t0 = time.perf_counter()
+            n = lib.pipe_run(iq.ctypes.data, iq.size, 32768, 0, 0, ctypes.byref(p))
+            w = time.perf_counter() - t0
+            f = float(lib.pipe_last_feed_seconds())
+            if best is None or f < best:
+                best, wall = f, w
+        logs[name] = ref.parse_log(ctypes.string_at(p, n))
+        out[name] = {"feed_seconds": round(best, 4), "x_realtime": round(iq.size / 2 / fs / best, 1), "wall_seconds_incl_open_close": round(wall, 3)}
+    exp, got = logs["plain"], logs["dropin"]
+    same = [k for k, _ in exp] == [k for k, _ in got]
+    if same:
+        for (k, a), (_, b) in zip(exp, got):
+            if k == "hdc":
+                same = same and a["program"] == b["program"] and a["flags"] == b["flags"] and a["data"] == b["data"]
+            elif k in ("sync", "mer", "ber"):
+                same = same and all(abs(a[f] - b[f]) <= max(common.FLOAT_RTOL * max(1.0, abs(a[f])), common.EITHER_ABS.get(f, 0.0)) for f in a)
+    out["events"] = len(exp); out["hdc_packets"] = sum(k == "hdc" for k, _ in exp); out["events_equal"] = bool(same)
+    out["speedup_vs_plain"] = round(out["plain"]["feed_seconds"] / out["dropin"]["feed_seconds"], 2)
+    if not same:
+        FAILURES.append("dropin: public-API event log differs from the plain reference")
+    return out
 
 
 KERNELS_OF_CLASS = {"p1_viterbi": "k_p1_forward (K=7 forward trellis pass of one decode window's P1 frames)", "p1_traceback": "k_p1_traceback (+ k_l2_index_window)",
@@ -554,6 +737,51 @@ DOMINANT_DEFAULT = {"fm": "p1_viterbi", "mixed": "p1_viterbi", "am-cs16": "am_de
 def source_fingerprint():
     from nrsc5_amd import build
     return build.source_sha()
+
+
+def make_workload(name, args, dev, local, my_streams):
+    if name == "fm":
+        return Fm(args, dev, local, my_streams)
+    if name == "mixed":
+        return Mixed(args, dev, local, my_streams)
+    return Am(args, dev, local, my_streams, name.split("-")[1])
+
+
+def checked_parity(W, recs, counts, frames, allrows, checker: bool):
+    parity = W.parity(allrows)
+    if checker:
+        try:
+            if isinstance(W, Mixed):
+                parity["reference_equality_rank0"] = mixed_reference_equality(W, recs, counts, frames)
+            else:
+                parity["reference_equality_rank0"] = reference_equality(W, recs, counts, frames, W.to_log, W.mode == 1)
+        except Exception as ex:
+            parity["reference_equality_rank0"] = {"error": repr(ex)}
+            FAILURES.append(f"{W.name}: reference-equality leg raised {ex!r}")
+    return parity
+
+
+def compact_leg(name, args, dev, local, steps=3):
+    """One configs[4] workload inside the default fm line: 1 warm-up + `steps` timed passes, truth + reference equality."""
+    import torch
+    a = argparse.Namespace(**vars(args)); a.workload = name; a.sync_p1 = False; a.ingest = "local"
+    S = 128 if name == "am-cu8" else 256
+    t0 = time.perf_counter()
+    W = make_workload(name, a, dev, local, list(range(S)))
+    gen = time.perf_counter() - t0
+    W.one_pass()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        block_steps, (recs, counts, frames) = W.one_pass()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+    rows = np.array(W.verify(recs, counts, frames), dtype=np.int64)
+    parity = checked_parity(W, recs, counts, frames, rows, not args.no_cpu_baseline)
+    out = {"config": W.describe(block_steps), "steps": steps, "ms_per_step": round(dt * 1e3, 3), "value_MSps": round(W.samples / dt / 1e6, 2),
+           "x_realtime": round(W.signal_seconds / dt, 1), "parity": parity, "gen_seconds": round(gen, 1)}
+    W.E.close()
+    del W
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -573,15 +801,9 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    S = args.streams or (128 if args.workload == "am-cu8" else 256)
-    my_streams = list(shard.stream_range(S * world, world, rank))      # contiguous stream ranges per rank: no data-path collective
+    my_streams = my_stream_ids(args, world, rank)
     t_gen = time.perf_counter()
-    if args.workload == "fm":
-        W = Fm(args, dev, local, my_streams)
-    elif args.workload == "mixed":
-        W = Mixed(args, dev, local, my_streams)
-    else:
-        W = Am(args, dev, local, my_streams, args.workload.split("-")[1])
+    W = make_workload(args.workload, args, dev, local, my_streams)
     t_gen = time.perf_counter() - t_gen
     E = W.E
 
@@ -606,30 +828,28 @@ def main():
     for _ in range(args.steps):
         block_steps, (recs, counts, frames) = W.one_pass(host_ms=host_ms)
     torch.cuda.synchronize()
+    dt_rank = time.perf_counter() - t0
     shard.barrier(dev)
     dt = time.perf_counter() - t0
     prof = E.profile(0)
     dt = shard.max_over_ranks(dt, dev)
+    per_rank_ms = [round(x / args.steps * 1e3, 3) for x in shard.gather_floats(dt_rank, dev)]
     tot = shard.sum_over_ranks([W.samples, W.signal_seconds, 1.0], dev)
     total_samples, total_seconds, ranks_seen = float(tot[0]), float(tot[1]), int(tot[2])     # ranks_seen: counted through the collective itself
 
     rows = W.verify(recs, counts, frames)
     allrows = shard.gather_summaries(np.array(rows, dtype=np.int64), dev)
+    shard.shutdown(dev)                  # every collective of the run is behind us: the ranks leave the group together
     if rank != 0:
         return
-    parity = W.parity(allrows)
     checker = not args.no_cpu_baseline and world == 1
-    if checker and hasattr(W, "reference_equality"):
+    parity = checked_parity(W, recs, counts, frames, allrows, checker)
+    if args.workload == "fm" and not args.no_l2_index:
         try:
-            parity["reference_equality_rank0"] = W.reference_equality(recs, counts, frames)
+            parity["l2_index_rank0"] = W.l2_property()
         except Exception as ex:
-            parity["reference_equality_rank0"] = {"error": repr(ex)}
-    if args.workload == "fm":
-        if not args.no_l2_index:
-            try:
-                parity["l2_index_rank0"] = W.l2_property()
-            except Exception as ex:                       # informational, never allowed to take the bench line down
-                parity["l2_index_rank0"] = {"error": repr(ex)}
+            parity["l2_index_rank0"] = {"error": repr(ex)}
+            FAILURES.append(f"fm: L2 index leg raised {ex!r}")
 
     value = total_samples * args.steps / dt / 1e6
     # ---- roofline of the dominant kernel class (by device time, HIP events on its launch stream) --------------------------
@@ -641,21 +861,37 @@ def main():
         alg_bytes_per_launch = W.samples * W.alg * args.steps / max(dom_launches, 1)
         avg_launch_s = dom_ms / 1e3 / max(dom_launches, 1)
         achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
-        traffic, whole = None, None
+        traffic, whole, valu = None, None, None
+        fp = source_fingerprint()
         if os.path.exists(args.traffic_json):
             try:
                 tj = json.load(open(args.traffic_json))
-                if tj.get("source_sha") == source_fingerprint() and tj.get("workload") == args.workload:
+                if tj.get("source_sha") == fp and tj.get("workload") == args.workload:
                     traffic = tj.get("per_class_hbm_bytes_per_launch", {}).get(dom)
-                    whole = {"hbm_bytes_per_pass": tj.get("whole_path_hbm_bytes_per_pass"), "over_algorithmic": tj.get("whole_path_over_algorithmic"), "file": os.path.relpath(args.traffic_json, ROOT)}
+                    whole = {"hbm_bytes_per_pass": tj.get("whole_path_hbm_bytes_per_pass"), "over_algorithmic": tj.get("whole_path_over_algorithmic"),
+                             "fetch_correction": tj.get("fetch_correction"), "file": os.path.relpath(args.traffic_json, ROOT)}
                     if whole["hbm_bytes_per_pass"]:
-                        # counter bytes of one pass (all nrsc5 kernels) over this run's time per pass: what the path really pulls from HBM
+                        # counter bytes of one pass (all nrsc5 kernels, reads corrected as the guide prescribes) over this run's time per pass
                         whole["counter_GBps"] = round(whole["hbm_bytes_per_pass"] / (dt / args.steps) / 1e9, 1)
                         whole["counter_frac_of_peak"] = round(whole["counter_GBps"] / HBM_PEAK_GBPS, 4)
             except Exception:
                 traffic = None
+        if os.path.exists(args.sq_json):
+            try:
+                sj = json.load(open(args.sq_json))
+                if sj.get("source_sha") == fp and sj.get("workload") == args.workload:
+                    # VALU roofline: SIMD cycles in which a VALU instruction issued (SQ_ACTIVE_INST_VALU x 4: the counter ticks in quad-cycles),
+                    # summed over every kernel of one pass, over the SIMD cycles the chip has in this run's pass time
+                    clk = sj["clock_ghz"]
+                    avail = N_SIMD * clk * 1e9 * (dt / args.steps)
+                    valu = {"issued_valu_simd_cycles_per_pass": sj["valu_simd_cycles_per_pass"], "simd_cycles_in_pass": round(avail), "frac": round(sj["valu_simd_cycles_per_pass"] / avail, 4),
+                            "clock_ghz": clk, "clock_note": sj.get("clock_note"), "per_class_frac_of_pass": {k: round(v / avail, 4) for k, v in sj.get("per_class_valu_simd_cycles", {}).items()},
+                            "per_class_valu_busy_while_resident": sj.get("per_class_valu_busy_while_resident"), "file": os.path.relpath(args.sq_json, ROOT)}
+            except Exception:
+                valu = None
         roofline = {"bound": "hbm", "kernel": dom, "kernel_functions": KERNELS_OF_CLASS.get(dom, dom), "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "whole_path_traffic": whole,
+                    "practical_bound": "valu issue + the trellis' serial dependency chain (SURVEY 8d): see `valu`", "valu": valu,
                     "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": dom_launches,
                     "avg_launch_ms_note": "HIP events on the kernel's own launch stream; up to three decode streams and the block-step chain run concurrently, so this is a per-launch latency under contention, not an exclusive-occupancy figure",
                     "alg_bytes_per_launch": int(alg_bytes_per_launch), "alg_bytes_per_sample": round(W.alg, 4),
@@ -671,22 +907,38 @@ def main():
                 cpu = cpu_baseline(sample, W.fs, W.mode, args.cpu_baseline_seconds, args.cpu_processes)
             except Exception as ex:
                 cpu = {"error": repr(ex)}
+                FAILURES.append(f"cpu baseline leg raised {ex!r}")
     extra = {}
     if args.workload == "fm" and world == 1 and not args.no_extra_legs:
         try:
+            sample = W.stream_iq(0)
             extra = W.extra_legs(local)
+            del W.iq, W.pool
+            torch.cuda.empty_cache()
+            extra["dropin"] = dropin_leg(np.ascontiguousarray(sample), FS)
+            extra["config4"] = {"am_cs16": compact_leg("am-cs16", args, dev, local), "mixed": compact_leg("mixed", args, dev, local)}
         except Exception as ex:
-            extra = {"extra_legs_error": repr(ex)}
+            extra["extra_legs_error"] = repr(ex)
+            FAILURES.append(f"extra legs raised {ex!r}")
+    config = W.describe(block_steps)
+    if world > 1:
+        config["parallelism"] = f"{world} ranks x {len(my_streams)} streams ({args.scaling} scaling), no data-path collective"
+        config["total_streams"] = int(allrows.shape[0])
     line = {
         "metric": "IQ MS/s demod+decoded", "value": round(value, 2), "unit": "IQ MS/s",
         "x_realtime": round(total_seconds * args.steps / dt, 1), "n_gpus": world, "ranks_in_process_group": ranks_seen, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "per_rank_ms_per_step": per_rank_ms, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": W.dtype, "data": "synthetic",
-        "config": W.describe(block_steps), "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
+        "config": config, "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         "gen_seconds": round(t_gen, 1),
     }
     line.update(extra)
+    line["parity_failures"] = list(FAILURES)
     print(json.dumps(line))
+    sys.stdout.flush()
+    if FAILURES:
+        print("PARITY / CHECKER FAILURE: " + "; ".join(FAILURES), file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -305,7 +305,15 @@ int nrsc5hip_stage_viterbi_k7_debug(nrsc5hip_engine *e, const int8_t *soft, int 
 /* micro-benchmark of the Viterbi kernel on random frames: phases bit0 = forward, bit1 = traceback */
 int nrsc5hip_stage_viterbi_bench(nrsc5hip_engine *e, int len, int nframes, int phases, int reps, float *ms_per_launch);
 int nrsc5hip_stage_viterbi_k9_bench(nrsc5hip_engine *e, int len, int nframes, int phases, int reps, float *ms_per_launch);
-/* accumulated shader cycles per phase of the sync kernel for stream 0 (engine created with NRSC5HIP_SYNC_PHASES=1) */
+/* Tuning knobs and test hooks (the library reads nothing from the environment).  Call on an idle engine. */
+enum {
+    NRSC5HIP_TUNE_DECODE_STREAMS = 0,    /* FM window pipeline: HIP streams that decode windows concurrently (1..5, default 3) */
+    NRSC5HIP_TUNE_AM_DECODE_STREAMS,     /* same for the AM window pipeline (default 4) */
+    NRSC5HIP_TUNE_VERDICT_LAG,           /* TEST HOOK: the replay takes first-header verdicts this many windows late (0..8): deep speculation */
+    NRSC5HIP_TUNE_SYNC_PHASES            /* 1: k_sync accumulates shader cycles per phase for stream 0 (nrsc5hip_debug_sync_phases) */
+};
+int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value);
+/* accumulated shader cycles per phase of the sync kernel for stream 0 (after nrsc5hip_debug_tune(e, NRSC5HIP_TUNE_SYNC_PHASES, 1)) */
 int nrsc5hip_debug_sync_phases(nrsc5hip_engine *e, long long *cycles8);
 /* debugging aid: soft-bit matrix (16 x 23040 int8) and live FFT bins of a stream's latest block */
 int nrsc5hip_debug_fetch(nrsc5hip_engine *e, int stream, int8_t *pm /* [368640] or NULL */, float *bins /* [32][534][2] or NULL */);

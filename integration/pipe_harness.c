@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 #include <nrsc5.h>
 
 typedef struct { uint8_t *p; size_t len, cap; } gbuf;
@@ -36,6 +37,11 @@ static void on_event(const nrsc5_event_t *evt, void *opaque)
     }
 }
 
+static double g_feed_seconds;
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec + 1e-9 * t.tv_nsec; }
+/* wall time of the nrsc5_pipe_samples_* loop of the last pipe_run (session open / close excluded): what `nrsc5 -r` spends per capture */
+double pipe_last_feed_seconds(void) { return g_feed_seconds; }
+
 /* mode: NRSC5_MODE_FM / NRSC5_MODE_AM; cs16 != 0: iq holds n int16 values, else n bytes of cu8 */
 size_t pipe_run(const void *iq, size_t n, unsigned chunk, int mode, int cs16, const uint8_t **out)
 {
@@ -44,11 +50,13 @@ size_t pipe_run(const void *iq, size_t n, unsigned chunk, int mode, int cs16, co
     if (nrsc5_open_pipe(&radio) != 0) return 0;
     nrsc5_set_mode(radio, mode);
     nrsc5_set_callback(radio, on_event, NULL);
+    const double t0 = now_s();
     for (size_t off = 0; off < n; off += chunk) {
         unsigned k = (n - off < chunk) ? (unsigned)(n - off) : chunk;
         if (cs16) nrsc5_pipe_samples_cs16(radio, (const int16_t *)iq + off, k);
         else nrsc5_pipe_samples_cu8(radio, (const uint8_t *)iq + off, k);
     }
+    g_feed_seconds = now_s() - t0;
     nrsc5_close(radio);
     *out = g_log.p;
     return g_log.len;

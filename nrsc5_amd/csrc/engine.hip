@@ -57,7 +57,7 @@ struct nrsc5hip_engine {
     int nlanes;
     int naux;                          // decode streams in use (<= NAUX)
     int naux_am;                       // ... by the AM window pipeline (its decodes are longer and thinner: 4 measured best)
-    int verdict_lag;                   // test hook (NRSC5HIP_TEST_VERDICT_LAG at create): replay takes verdicts this many windows late
+    int verdict_lag;                   // test hook (nrsc5hip_debug_tune): replay takes verdicts this many windows late
     hipStream_t main;                  // = lanes[0].main
     std::vector<void *> allocs;
     // host mirrors
@@ -328,18 +328,8 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
     do {
         {
             e->nlanes = 1;
-            const char *ea = getenv("NRSC5HIP_NAUX");
-            e->naux = ea ? atoi(ea) : 3;
-            if (e->naux < 1) e->naux = 1;
-            if (e->naux > NAUX) e->naux = NAUX;
-            const char *elag = getenv("NRSC5HIP_TEST_VERDICT_LAG");
-            e->verdict_lag = elag ? atoi(elag) : 0;
-            if (e->verdict_lag < 0) e->verdict_lag = 0;
-            if (e->verdict_lag > NWIN) e->verdict_lag = NWIN;
-            const char *eam = getenv("NRSC5HIP_NAUX_AM");
-            e->naux_am = eam ? atoi(eam) : 4;
-            if (e->naux_am < 1) e->naux_am = 1;
-            if (e->naux_am > NAUX) e->naux_am = NAUX;
+            e->naux = 3; e->naux_am = 4;   // decode streams in use (measured: profiles/r02_naux.txt); nrsc5hip_debug_tune changes them
+            e->verdict_lag = 0;
         }
         for (int l = 0; l < e->nlanes && !rc; l++) {
             nrsc5hip_engine::Lane &ln = e->lanes[l];
@@ -439,11 +429,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
                 hipMemset(db.am_q, 0, S * 4 * 3 * 18000) != hipSuccess || hipMemset(db.am_vit, 0, S * db.am_nvit * 2 * AM_VIT) != hipSuccess ||
                 hipMemset(db.am_sym, 0, S * 4 * AM_SYMS) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "AM state init failed"); break; }
         }
-        db.sync_phase_cycles = nullptr;
-        if (getenv("NRSC5HIP_SYNC_PHASES")) {
-            if ((rc = dev_alloc(e, &db.sync_phase_cycles, 8))) break;
-            (void)hipMemset(db.sync_phase_cycles, 0, 8 * sizeof(long long));
-        }
+        db.sync_phase_cycles = nullptr;        // nrsc5hip_debug_tune(NRSC5HIP_TUNE_SYNC_PHASES) turns the instrumentation on
         e->stage_bytes = 4u << 20;
         if ((rc = dev_alloc(e, &e->stage_dev, e->stage_bytes))) break;
         if ((rc = dev_alloc(e, &e->ids_dev, S))) break;
@@ -623,14 +609,16 @@ static int run_steps(nrsc5hip_engine *e, int n, const int *ids_dev, unsigned lon
         }
         if (e->dec_chunk) { HIPCHK(hipStreamSynchronize(e->dec_stream)); e->dec_chunk = 0; }
         { int rc = flush_p1(e, ln, n, ids_dev); if (rc) return rc; }
-        if (!replay || done >= max_steps) break;
-        // every decode has finished: apply what is left of their verdicts; a rewound stream has work again
+        if (!replay) break;
+        // every decode has finished: apply what is left of their verdicts (also when the step budget is used up -- the caller
+        // must never see records of blocks that ran behind a failed frame); a rewound stream has work again
         HIPCHK(hipMemsetAsync(ln.counters_dev, 0, 4 * sizeof(int), ln.main));
         launch_rollback(ln.db, n, ids_dev, (int)(ln.step_count / 16), 0, ln.main);
         HIPCHK(hipMemcpyAsync(ln.counters_host, ln.counters_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, ln.main));
         HIPCHK(hipStreamSynchronize(ln.main));
         if (ln.counters_host[3] == 0) break;
         ln.acq_needed = true; ln.prepared_by_sync = false;
+        if (done >= max_steps) break;                              // out of budget: the rewound streams resume on the next call
     }
     HIPCHK(hipStreamSynchronize(ln.main));
     if (e->prof_on) prof_collect(e);
@@ -709,13 +697,14 @@ static int run_steps_am(nrsc5hip_engine *e, int n, const int *ids_dev, int max_s
             else done += burst;
         }
         { int rc = am_flush(e, ln, n, ids_dev); if (rc) return rc; }
-        if (!replay || done >= max_steps) break;
-        // every decode has finished: apply what is left of their verdicts; a rewound stream has work again
+        if (!replay) break;
+        // every decode has finished: apply what is left of their verdicts (also when the step budget is used up); a rewound
+        // stream has work again
         HIPCHK(hipMemsetAsync(ln.counters_dev, 0, 4 * sizeof(int), ln.main));
         launch_rollback_am(ln.db, n, ids_dev, (int)(ln.am_step_count / 8), 0, ln.main);
         HIPCHK(hipMemcpyAsync(ln.counters_host, ln.counters_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, ln.main));
         HIPCHK(hipStreamSynchronize(ln.main));
-        if (ln.counters_host[3] == 0) break;
+        if (ln.counters_host[3] == 0 || done >= max_steps) break;
     }
     HIPCHK(hipStreamSynchronize(ln.main));
     if (e->prof_on) prof_collect(e);
@@ -952,6 +941,7 @@ extern "C" int nrsc5hip_batch_append_cs16(nrsc5hip_engine *e, int nstreams, cons
     for (int k = 0; k < nstreams; k++) {
         const int s = stream_ids ? stream_ids[k] : k;
         if (nelems[k] % 2) FAIL(NRSC5HIP_EINVAL, "chunk %d: odd cs16 length", k);
+        if (e->attached[s]) FAIL(NRSC5HIP_EINVAL, "stream %d reads a zero-copy capture: reset it before appending samples", s);
         if (e->wr_host[s] - e->base_host[s] + nelems[k] / 2 > e->db.q15_cap)
             FAIL(NRSC5HIP_EOVERFLOW, "stream %d: q15_capacity %lld too small for this batch", s, e->db.q15_cap);
         if (nelems[k] > mx) mx = nelems[k];
@@ -1017,20 +1007,22 @@ extern "C" int nrsc5hip_drain(nrsc5hip_engine *e, int stream, nrsc5hip_record *o
     HIPCHK(hipStreamSynchronize(e->main));
     int nb = 0;
     if ((rc = fetch_nblocks(e, stream, &nb))) return rc;
-    int avail = nb - e->drained[stream];
-    if (avail > e->db.rec_cap) FAIL(NRSC5HIP_EOVERFLOW, "stream %d: %d records overwrote the ring (capacity %d)", stream, avail, e->db.rec_cap);
-    int n = avail < max ? avail : max;
-    {   // at most two contiguous pieces of the ring
-        const int first = e->drained[stream] % e->db.rec_cap;
-        const int n1 = (first + n <= e->db.rec_cap) ? n : e->db.rec_cap - first;
+    if (nb - e->drained[stream] > e->db.rec_cap) FAIL(NRSC5HIP_EOVERFLOW, "stream %d: %d records overwrote the ring (capacity %d)", stream, nb - e->drained[stream], e->db.rec_cap);
+    const bool replay = e->db.ckpt || e->db.am_ckpt;
+    int n = 0;
+    // Replay: blocks that ran behind a failed P1 frame are void (k_replay.hip) and never delivered.  A rewind can void up to
+    // NWIN * 16 records in a row, so keep reading until `max` valid records are collected or the ring is empty -- a caller that
+    // loops "until fewer than max came back" must not stop at a chunk of void records.
+    while (n < max && e->drained[stream] < nb) {
+        const int want = std::min(max - n, nb - e->drained[stream]);
+        const int first = e->drained[stream] % e->db.rec_cap;      // at most two contiguous pieces of the ring
+        const int n1 = (first + want <= e->db.rec_cap) ? want : e->db.rec_cap - first;
         const BlockRecord *ring = e->db.records + (size_t)stream * e->db.rec_cap;
-        if (n1 > 0) HIPCHK(hipMemcpy(out, ring + first, (size_t)n1 * sizeof(BlockRecord), hipMemcpyDeviceToHost));
-        if (n - n1 > 0) HIPCHK(hipMemcpy(out + n1, ring, (size_t)(n - n1) * sizeof(BlockRecord), hipMemcpyDeviceToHost));
-    }
-    e->drained[stream] += n;
-    if (e->db.ckpt || e->db.am_ckpt) {                         // replay: blocks that ran behind a failed P1 frame are void (k_replay.hip)
-        int m = 0;
-        for (int k = 0; k < n; k++) if (!(out[k].flags & NRSC5HIP_REC_DISCARDED)) { if (m != k) out[m] = out[k]; m++; }
+        HIPCHK(hipMemcpy(out + n, ring + first, (size_t)n1 * sizeof(BlockRecord), hipMemcpyDeviceToHost));
+        if (want - n1 > 0) HIPCHK(hipMemcpy(out + n + n1, ring, (size_t)(want - n1) * sizeof(BlockRecord), hipMemcpyDeviceToHost));
+        e->drained[stream] += want;
+        int m = n;
+        for (int k = n; k < n + want; k++) if (!replay || !(out[k].flags & NRSC5HIP_REC_DISCARDED)) { if (m != k) out[m] = out[k]; m++; }
         n = m;
     }
     *n_out = n;
@@ -1478,10 +1470,31 @@ extern "C" int nrsc5hip_stage_viterbi_k9_bench(nrsc5hip_engine *e, int len, int 
     return 0;
 }
 
+// Tuning knobs and test hooks: an explicit entry point, nothing is read from the environment.
+extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
+{
+    if (!e) FAIL(NRSC5HIP_EINVAL, "null engine");
+    HIPCHK(hipDeviceSynchronize());
+    switch (knob) {
+    case NRSC5HIP_TUNE_DECODE_STREAMS:    e->naux = std::min(std::max(value, 1), NAUX); break;
+    case NRSC5HIP_TUNE_AM_DECODE_STREAMS: e->naux_am = std::min(std::max(value, 1), NAUX); break;
+    case NRSC5HIP_TUNE_VERDICT_LAG:       e->verdict_lag = std::min(std::max(value, 0), NWIN); break;
+    case NRSC5HIP_TUNE_SYNC_PHASES:
+        if (value && !e->db.sync_phase_cycles) {
+            int rc = dev_alloc(e, &e->db.sync_phase_cycles, 8); if (rc) return rc;
+            HIPCHK(hipMemset(e->db.sync_phase_cycles, 0, 8 * sizeof(long long)));
+        }
+        for (int l = 0; l < e->nlanes; l++) e->lanes[l].db.sync_phase_cycles = value ? e->db.sync_phase_cycles : nullptr;
+        break;
+    default: FAIL(NRSC5HIP_EINVAL, "unknown knob %d", knob);
+    }
+    return 0;
+}
+
 extern "C" int nrsc5hip_debug_sync_phases(nrsc5hip_engine *e, long long *cycles8)
 {
     if (!e || !cycles8) FAIL(NRSC5HIP_EINVAL, "null argument");
-    if (!e->db.sync_phase_cycles) FAIL(NRSC5HIP_EINVAL, "set NRSC5HIP_SYNC_PHASES=1 before creating the engine");
+    if (!e->db.sync_phase_cycles) FAIL(NRSC5HIP_EINVAL, "turn the instrumentation on first: nrsc5hip_debug_tune(e, NRSC5HIP_TUNE_SYNC_PHASES, 1)");
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(cycles8, e->db.sync_phase_cycles, 8 * sizeof(long long), hipMemcpyDeviceToHost));
     return 0;

@@ -149,6 +149,12 @@ extern "C" int nrsc5hip_hdc_push_frame(nrsc5hip_hdc *h, int stream, int lc, cons
     Stream &st = h->streams[stream];
     const nrsc5hip_l2_frame *ix = ix_in;
     std::unique_ptr<nrsc5hip_l2_frame> cut;
+    if ((ix_in->pci & 0xFFFFFCu) == (0x3634CEu & 0xFFFFFCu)) {
+        // PCI_FIXED: has_fixed() but !has_audio() (frame.c:138-151) -- frame_process still runs process_fixed_data on it (sync width
+        // tracking, CCC messages, fixed_ready) before it returns, and later audio + fixed frames of the channel depend on that state
+        (void)nrsc5hip_hdc_fixed_audio_end(h, stream, lc, pdu_bytes, ix_in->nbytes);
+        return NRSC5HIP_OK;
+    }
     if (NRSC5HIP_L2_PCI_HAS_FIXED(ix_in->pci)) {
         const unsigned audio_end = nrsc5hip_hdc_fixed_audio_end(h, stream, lc, pdu_bytes, ix_in->nbytes);
         cut.reset(new nrsc5hip_l2_frame(*ix_in));

@@ -60,6 +60,7 @@ class L2Job(ctypes.Structure):
 
 
 L2_FM_P1, L2_FM_PX, L2_AM = 0, 1, 2
+TUNE_DECODE_STREAMS, TUNE_AM_DECODE_STREAMS, TUNE_VERDICT_LAG, TUNE_SYNC_PHASES = 0, 1, 2, 3
 L2_STATUS = ("end", "no_audio", "fixed_data", "header_rs", "bad_locators", "too_many_pdus", "hef_overrun", "bad_stream", "bad_length", "audio_end")
 
 
@@ -120,6 +121,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.nrsc5hip_stage_viterbi_k7_debug.argtypes = [vp, vp, ci, vp, vp]
     lib.nrsc5hip_stage_viterbi_bench.argtypes = [vp, ci, ci, ci, ci, ctypes.POINTER(ctypes.c_float)]
     lib.nrsc5hip_debug_sync_phases.argtypes = [vp, vp]
+    lib.nrsc5hip_debug_tune.argtypes = [vp, ci, ci]
     lib.nrsc5hip_batch_fetch_view.argtypes = [vp, ci, ctypes.POINTER(vp), vp, ctypes.POINTER(vp)]
     lib.nrsc5hip_reset_all.argtypes = [vp]
     lib.nrsc5hip_profile.argtypes = [vp, ci, vp, vp]
@@ -152,7 +154,7 @@ EXPORTED_SYMBOLS = [
     "nrsc5hip_batch_append_cu8", "nrsc5hip_batch_append_cs16", "nrsc5hip_batch_process", "nrsc5hip_drain",
     "nrsc5hip_p1_frame_packed", "nrsc5hip_p1_frame_bits", "nrsc5hip_batch_fetch", "nrsc5hip_unpack_bits",
     "nrsc5hip_stage_halfband_fm_cu8", "nrsc5hip_stage_fft2048", "nrsc5hip_stage_viterbi_k7", "nrsc5hip_debug_fetch",
-    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_batch_fetch_view", "nrsc5hip_batch_fetch_l2_px", "nrsc5hip_batch_fetch_l2_am",
+    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_debug_tune", "nrsc5hip_batch_fetch_view", "nrsc5hip_batch_fetch_l2_px", "nrsc5hip_batch_fetch_l2_am",
     "nrsc5hip_stream_set_mode", "nrsc5hip_am_frame_bits", "nrsc5hip_stage_viterbi_k9", "nrsc5hip_px_frame_bits",
     "nrsc5hip_batch_fetch_px", "nrsc5hip_debug_fetch_px", "nrsc5hip_stage_viterbi_k9_bench",
     "nrsc5hip_l2_index", "nrsc5hip_stage_l2_index", "nrsc5hip_l2_frame_get", "nrsc5hip_batch_fetch_l2",
@@ -180,6 +182,10 @@ class Engine:
     def _check(self, rc: int):
         if rc != 0:
             raise Nrsc5HipError(f"libnrsc5hip error {rc}: {self.lib.nrsc5hip_last_error().decode()}")
+
+    def tune(self, knob: int, value: int):
+        """nrsc5hip_debug_tune: TUNE_DECODE_STREAMS / TUNE_AM_DECODE_STREAMS / TUNE_VERDICT_LAG (test hook) / TUNE_SYNC_PHASES"""
+        self._check(self.lib.nrsc5hip_debug_tune(self._h, knob, value))
 
     def close(self):
         if self._h:

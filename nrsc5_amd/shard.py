@@ -28,6 +28,8 @@ def init_from_env(backend: str | None = None, expect_world: int | None = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # dmabuf IPC (this driver supports nothing else): also when an external torchrun started the ranks without it
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -43,25 +45,27 @@ def launched_by_torchrun() -> bool:
     return "WORLD_SIZE" in os.environ and "RANK" in os.environ
 
 
-def free_port() -> int:
-    import socket
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(("127.0.0.1", 0))
-        return s.getsockname()[1]
-
-
 def launch_ranks(script: str, argv, nproc: int, extra_env: dict | None = None) -> int:
-    """Start `nproc` ranks of `script argv` on this node -- one process per GPU -- exactly as the driver does:
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P script argv.
-    Returns the launcher's exit code; the ranks inherit stdout / stderr (rank 0 prints the result line)."""
+    """Start `nproc` ranks of `script argv` on this node -- one process per GPU -- with torch's own launcher, as the driver does
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... script argv`).  The rendezvous is torchrun's standalone
+    c10d store on 127.0.0.1: the launcher binds the port itself (no bind-close-reuse window in which a concurrent launch on
+    the node could take it).  Returns the launcher's exit code; the ranks inherit stdout / stderr (rank 0 prints the result
+    line)."""
     import subprocess
     import sys
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL across processes needs it on this driver
     env.update(extra_env or {})
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script] + list(argv)
+           "--standalone", "--local-addr", "127.0.0.1", script] + list(argv)
     return subprocess.call(cmd, env=env)
+
+
+def shutdown(device=None):
+    """Leave the process group in step: a rank that exits while its peers still talk to it aborts them (gloo) or hangs them (RCCL)."""
+    if dist.is_initialized():
+        barrier(device)
+        dist.destroy_process_group()
 
 
 def barrier(device=None):
@@ -78,6 +82,16 @@ def max_over_ranks(value: float, device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_floats(value: float, device) -> list:
+    """one float per rank, in rank order (per-rank pass times, stream counts)"""
+    if not dist.is_initialized():
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return [float(o.item()) for o in out]
 
 
 def sum_over_ranks(values, device) -> np.ndarray:

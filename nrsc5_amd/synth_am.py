@@ -280,14 +280,11 @@ class AmCapture:
     seed: int
 
 
-def am_ma1_capture(n_frames: int, seed: int = 1, cfo_hz: float = 3.0, offset: int = 1000, noise: float = 0.5,
-                   fmt: str = "cs16", tail_samples: int = 1080, unit_lsb: float | None = None, mode: str = "MA1",
-                   burst: tuple | None = None) -> AmCapture:
-    """Hybrid-AM MA1 capture of n_frames L1 frames (8 blocks x 32 symbols each).  `noise` = per-sample complex
-    noise sigma in primary QAM64 grid units; `unit_lsb` = LSBs per grid unit (default 100 for cs16, 0.8 for cu8)."""
-    rng = np.random.default_rng(seed)
+def am_ma1_signal(n_frames: int, seed: int = 1, fmt: str = "cs16", mode: str = "MA1"):
+    """The clean transmission of am_ma1_capture (no CFO, offset, noise): complex128 baseband at the capture's sample rate and
+    the transmitted truth (P1 frames, P3 frames, PIDS frames).  bench.py puts many receivers' channels on one such signal
+    (synth_torch.channel_am)."""
     oversample = 1 if fmt == "cs16" else 32
-    fs = FS_CS16 if fmt == "cs16" else FS_CU8
     coded_p1, coded_p3, p1_list, p3_list, pids_list, chunks = [], [], [], [], [], []
     ma3 = mode == "MA3"
     for f in range(n_frames):
@@ -330,7 +327,18 @@ def am_ma1_capture(n_frames: int, seed: int = 1, cfo_hz: float = 3.0, offset: in
             chunks.append(ofdm_modulate(spec(pl[bc], pu[bc], s[bc], t[bc], s1, s2, bc), oversample))
             pids_list.append(pids[bc])
         p1_list.append(p1); p3_list.append(p3)
-    sig = np.concatenate(chunks)
+    return np.concatenate(chunks), p1_list, p3_list, pids_list
+
+
+def am_ma1_capture(n_frames: int, seed: int = 1, cfo_hz: float = 3.0, offset: int = 1000, noise: float = 0.5,
+                   fmt: str = "cs16", tail_samples: int = 1080, unit_lsb: float | None = None, mode: str = "MA1",
+                   burst: tuple | None = None) -> AmCapture:
+    """Hybrid-AM MA1 capture of n_frames L1 frames (8 blocks x 32 symbols each).  `noise` = per-sample complex
+    noise sigma in primary QAM64 grid units; `unit_lsb` = LSBs per grid unit (default 100 for cs16, 0.8 for cu8)."""
+    rng = np.random.default_rng(seed)
+    oversample = 1 if fmt == "cs16" else 32
+    fs = FS_CS16 if fmt == "cs16" else FS_CU8
+    sig, p1_list, p3_list, pids_list = am_ma1_signal(n_frames, seed, fmt, mode)
     n = sig.shape[0]
     if cfo_hz:
         sig *= np.exp(2j * np.pi * cfo_hz / fs * np.arange(n))

@@ -284,12 +284,13 @@ def psd_sequence(seed: int = 0, nbits: int = 146176, n_frames: int = 6):
     return frames
 
 
-def fixed_data_session(seed: int = 0, nbits: int = 146176, n_frames: int = 7, sub_len: int = 4000, sync_byte: int = 0x88):
+def fixed_data_session(seed: int = 0, nbits: int = 146176, n_frames: int = 7, sub_len: int = 4000, sync_byte: int = 0x88, fixed_only=()):
     """Frames that carry fixed-data sub-channels next to audio (PCI_AUDIO_FIXED / _OPP, frame.c:138-151,458-514): the last
     byte is the sync byte (0x88: 16 CCC bytes per frame in front of it), the CCC bytes carry an HDLC message announcing one
     sub-channel of `sub_len` bytes, and five audio PDUs fill the frame -- so that audio_end is length - 1 for the first two
     frames (sync not yet confirmed), length - 17 while the CCC message is incomplete, and length - 17 - sub_len after it:
-    the last PDUs then lie in the fixed-data region and the reference's walk stops in front of them."""
+    the last PDUs then lie in the fixed-data region and the reference's walk stops in front of them.  Frames listed in
+    `fixed_only` carry PCI_FIXED (no audio): frame_process still runs process_fixed_data on them before it returns."""
     rng = np.random.default_rng(7000 + seed)
     n = pdu_bytes_of(nbits)
     width = (sync_byte & 0xF) * 2 if sync_byte else 1
@@ -307,5 +308,5 @@ def fixed_data_session(seed: int = 0, nbits: int = 146176, n_frames: int = 7, su
         body[n - 1] = sync_byte
         body[n - 1 - width:n - 1] = ccc[pos:pos + width]
         pos += width
-        frames.append(frame_from_bytes(bytes(body), nbits, pci=PCI_AUDIO_FIXED if fi % 2 == 0 else PCI_AUDIO_FIXED_OPP))
+        frames.append(frame_from_bytes(bytes(body), nbits, pci=PCI_FIXED if fi in fixed_only else PCI_AUDIO_FIXED if fi % 2 == 0 else PCI_AUDIO_FIXED_OPP))
     return frames

@@ -98,3 +98,57 @@ def stream_params(k: int):
     rng = np.random.default_rng(1000 + k)
     return dict(cfo_hz=float(rng.uniform(-300, 300)), offset=int(rng.integers(0, 4320)),
                 snr_db=(15.0, 20.0, 25.0)[k % 3], seed=1000 + k)
+
+
+def channel_am(sig: torch.Tensor, cfo_hz: float, offset: int, noise: float, seed: int, fmt: str = "cs16", tail: int = 1080,
+               burst: tuple | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+    """One receiver's view of a clean hybrid-AM transmission (synth_am.am_ma1_signal, complex64 on the device): CFO -> timing
+    offset -> AWGN (+ an optional interference burst (first L1 frame, frames, sigma)) -> cs16 (100 LSB per grid unit) or cu8
+    (0.8 LSB per grid unit, sample rate x 32) -- the channel of synth_am.am_ma1_capture with a per-stream torch generator."""
+    from . import synth_am
+    dev = sig.device
+    over = 1 if fmt == "cs16" else 32
+    fs = synth_am.FS_CS16 if fmt == "cs16" else synth_am.FS_CU8
+    n = sig.shape[0]
+    total = offset + n + tail * over
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    sigma = noise * np.sqrt(over) / np.sqrt(2)
+    re = torch.randn(total, generator=g, device=dev, dtype=torch.float32) * sigma
+    im = torch.randn(total, generator=g, device=dev, dtype=torch.float32) * sigma
+    if burst is not None:
+        f0, nf, bs = burst
+        per = 8 * 32 * synth_am.SYM * over
+        a = offset + int(f0 * per); b = min(total, a + int(nf * per))
+        if b > a:
+            re[a:b] += torch.randn(b - a, generator=g, device=dev, dtype=torch.float32) * (bs * np.sqrt(over) / np.sqrt(2))
+            im[a:b] += torch.randn(b - a, generator=g, device=dev, dtype=torch.float32) * (bs * np.sqrt(over) / np.sqrt(2))
+    ph = torch.arange(n, device=dev, dtype=torch.float64) * (2 * np.pi * cfo_hz / fs)
+    ph = torch.remainder(ph, 2 * np.pi).to(torch.float32)
+    rot = sig * torch.complex(torch.cos(ph), torch.sin(ph))
+    re[offset:offset + n] += rot.real
+    im[offset:offset + n] += rot.imag
+    if fmt == "cs16":
+        if out is None:
+            out = torch.empty(2 * total, dtype=torch.int16, device=dev)
+        v = out[:2 * total].view(total, 2)
+        v[:, 0] = torch.clamp(torch.round(100.0 * re), -32768, 32767).to(torch.int16)
+        v[:, 1] = torch.clamp(torch.round(100.0 * im), -32768, 32767).to(torch.int16)
+    else:
+        if out is None:
+            out = torch.empty(2 * total, dtype=torch.uint8, device=dev)
+        v = out[:2 * total].view(total, 2)
+        v[:, 0] = torch.clamp(torch.round(127 + 0.8 * re), 0, 255).to(torch.uint8)
+        v[:, 1] = torch.clamp(torch.round(127 + 0.8 * im), 0, 255).to(torch.uint8)
+    return out[:2 * total]
+
+
+def am_stream_params(k: int, n_frames: int):
+    """configs[4] family: seed 5000+k, CFO uniform +-100 Hz, timing offset anywhere in an OFDM symbol (cs16 samples; x 32 for
+    cu8) plus up to 8 symbols, noise 0.4 / 0.6 / 0.8 grid units; every 16th stream is hit by an interference burst that breaks
+    the first L2 header of some P1 PDUs (the reference then drops to SYNC_STATE_NONE and re-acquires: frame.c:535-540)."""
+    rng = np.random.default_rng(5000 + k)
+    prm = dict(cfo_hz=float(rng.uniform(-100, 100)), offset=int(rng.integers(0, 9 * 270)), noise=(0.4, 0.6, 0.8)[k % 3], seed=5000 + k, burst=None)
+    if k % 16 == 5 and n_frames >= 12:
+        prm["burst"] = (float(rng.uniform(5.0, n_frames - 6.0)), float(rng.uniform(0.2, 0.6)), 40.0)
+    return prm

@@ -693,15 +693,8 @@ def check_deferred_feedback_equals_reference(lib, oracle, n_blocks=96, verdict_l
     buf = np.zeros((n, stride), dtype=np.uint8)
     for k, c in enumerate(caps):
         buf[k, :c.iq.size] = c.iq
-    old = os.environ.get("NRSC5HIP_TEST_VERDICT_LAG")
-    os.environ["NRSC5HIP_TEST_VERDICT_LAG"] = str(verdict_lag)
-    try:
-        E = eng.Engine(max_streams=n, q15_capacity=stride // 4 + 1024, record_capacity=1024, p1_slots=48, p1_async=True, l2_feedback=True, lib_path=lib)
-    finally:
-        if old is None:
-            del os.environ["NRSC5HIP_TEST_VERDICT_LAG"]
-        else:
-            os.environ["NRSC5HIP_TEST_VERDICT_LAG"] = old
+    E = eng.Engine(max_streams=n, q15_capacity=stride // 4 + 1024, record_capacity=1024, p1_slots=48, p1_async=True, l2_feedback=True, lib_path=lib)
+    E.tune(eng.TUNE_VERDICT_LAG, verdict_lag)
     dev = _to_device(E, buf)
     E.batch_append_cu8(dev, stride, [c.iq.size - c.iq.size % 4 for c in caps])
     E.batch_process(n)
@@ -743,15 +736,8 @@ def check_am_deferred_feedback_equals_reference(lib, oracle, verdict_lag=0):
     buf = np.zeros((n, stride), dtype=caps[0].iq.dtype)
     for k, c in enumerate(caps):
         buf[k, :c.iq.size] = c.iq
-    old = os.environ.get("NRSC5HIP_TEST_VERDICT_LAG")
-    os.environ["NRSC5HIP_TEST_VERDICT_LAG"] = str(verdict_lag)
-    try:
-        E = eng.Engine(max_streams=n, q15_capacity=stride // 2 + 1024, record_capacity=1024, p1_slots=48, lib_path=lib, am_enable=True, p1_async=True, l2_feedback=True)
-    finally:
-        if old is None:
-            del os.environ["NRSC5HIP_TEST_VERDICT_LAG"]
-        else:
-            os.environ["NRSC5HIP_TEST_VERDICT_LAG"] = old
+    E = eng.Engine(max_streams=n, q15_capacity=stride // 2 + 1024, record_capacity=1024, p1_slots=48, lib_path=lib, am_enable=True, p1_async=True, l2_feedback=True)
+    E.tune(eng.TUNE_VERDICT_LAG, verdict_lag)
     for k in range(n):
         E.set_mode(k, eng.MODE_AM)
     dev = _to_device(E, buf)

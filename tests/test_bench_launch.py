@@ -31,6 +31,7 @@ def test_bench_spawns_its_own_ranks():
 def test_bench_single_rank_is_one_process():
     r, lines = _run(["--gpus", "1", "--launch-check"])
     assert r.returncode == 0 and lines == [{"launch_check": True, "n_gpus": 1, "ranks_in_process_group": 1, "rank_sum": 0, "ingest_scatter_ok": 1,
+                                            "scaling": "weak", "streams_per_rank": [256], "ipc_mode_legacy": "0",
                                             "backend": "gloo", "launched_by": "single process"}], r.stdout + r.stderr[-1000:]
 
 
@@ -39,3 +40,26 @@ def test_world_size_mismatch_is_an_error():
     from nrsc5_amd import shard
     rc = shard.launch_ranks(os.path.join(ROOT, "bench.py"), ["--gpus", "4", "--launch-check"], 2)
     assert rc != 0
+
+
+def test_eight_ranks_strong_scaling_split():
+    """The first 8-GPU driver run must need no code change: 8 ranks (gloo here), configs[3]'s fixed 2048 streams split into
+    contiguous ranges of 256, every rank in the process group, dmabuf IPC mode set for the ranks."""
+    r, lines = _run(["--gpus", "8", "--launch-check", "--scaling", "strong", "--total-streams", "2048"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1 and lines[0]["n_gpus"] == 8 and lines[0]["ranks_in_process_group"] == 8 and lines[0]["rank_sum"] == 28
+    assert lines[0]["scaling"] == "strong" and lines[0]["streams_per_rank"] == [256] * 8 and lines[0]["ingest_scatter_ok"] == 8
+    assert lines[0]["ipc_mode_legacy"] == "0"
+
+
+def test_driver_style_torchrun_line_without_ipc_env():
+    """The driver starts the ranks with its own torchrun line; if HSA_ENABLE_IPC_MODE_LEGACY is not in that environment the
+    ranks must set it themselves before the first HIP call (RCCL needs dmabuf IPC on this driver)."""
+    e = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--standalone", "--local-addr", "127.0.0.1",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--launch-check"], env=e, capture_output=True, text=True, timeout=600)
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, r.stderr[-2000:]
+    assert lines[0]["ipc_mode_legacy"] == "0" and lines[0]["launched_by"] == "external torchrun" and lines[0]["streams_per_rank"] == [256, 256]

@@ -1,7 +1,7 @@
 """`-m gpu`: the DROP-IN seen from the reference's own public API (nrsc5.h): the reference's L4/L2/L1' code,
 unmodified, linked with integration/input_hip.c + libnrsc5hip.so, against the plain reference library.
 Both are driven only through nrsc5_open_pipe / nrsc5_set_mode / nrsc5_set_callback / nrsc5_pipe_samples_cu8.
-The libraries are prebuilt in the build container (integration/Makefile needs /root/reference)."""
+The libraries are prebuilt in the build container (integration/Makefile / oracle/Makefile need /root/reference)."""
 import ctypes
 import os
 
@@ -12,13 +12,13 @@ from tests import common
 from oracle import ref
 
 pytestmark = pytest.mark.gpu
-BUILD = os.path.join(common.ROOT, "integration", "_build")
+BUILD = {"libnrsc5_hipdropin.so": os.path.join(common.ROOT, "integration", "_build"), "libnrsc5_plain.so": os.path.join(common.ROOT, "oracle", "_ref")}
 
 
 def _run(libname, iq, chunk=32768, mode=0):
-    path = os.path.join(BUILD, libname)
+    path = os.path.join(BUILD[libname], libname)
     if not os.path.exists(path):
-        pytest.skip(f"{libname} not prebuilt (integration/Makefile needs /root/reference)")
+        pytest.skip(f"{libname} not prebuilt (integration/Makefile / oracle/Makefile need /root/reference)")
     lib = ctypes.CDLL(path)
     lib.pipe_run.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
     lib.pipe_run.restype = ctypes.c_size_t

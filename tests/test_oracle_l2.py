@@ -169,3 +169,33 @@ def test_fixed_data_frames_index_cut_back_equals_reference(oracle, reflib, emu_l
     indexed = reflib.l2_frames_indexed(items)
     for a, b in zip(direct, indexed):
         assert _all_l2_taps(a) == _all_l2_taps(b)
+
+
+def test_fixed_only_frames_advance_the_ccc_state(oracle, reflib, emu_lib):
+    """PCI_FIXED frames (has_fixed && !has_audio, frame.c:138-151): frame_process runs process_fixed_data on them before it
+    returns, so the sync-width count, the CCC message and fixed_ready advance on frames that deliver no audio.  A channel that
+    mixes fixed-only and audio + fixed frames must be cut at the reference's audio_end afterwards: nrsc5hip_hdc_push_frame does
+    the state update for the fixed-only frames."""
+    import ctypes
+    from nrsc5_amd import engine as eng
+    frames = synth_l2.fixed_data_session(seed=2, fixed_only=(1, 3))
+    direct = reflib.l2_frames(frames)
+    lib = eng.load_library(emu_lib)
+    H = eng.HdcConsumer(1, lib=lib)
+    ends = []
+    for fi, (bits, log) in enumerate(zip(frames, direct)):
+        fr, by = oracle.l2_index_struct(bits)
+        b = np.frombuffer(by, dtype=np.uint8)
+        if fi in (1, 3):
+            assert fr.status == port.L2_STATUS.index("no_audio") and reference_taps(log) == []
+            H.push_frame(0, fr, b, 0)                            # state update only
+            continue
+        audio_end = H.fixed_audio_end(0, 0, b[:fr.nbytes])
+        cut = eng.L2Frame.from_buffer_copy(fr)
+        assert lib.nrsc5hip_l2_apply_audio_end(ctypes.byref(cut), audio_end) >= 0
+        ends.append(audio_end)
+        assert expected_taps(eng.l2_frame_to_dict(cut), b) == reference_taps(log), fi
+    nb = (146176 - 24) // 8
+    # frame 0 and the fixed-only frame 1 confirm the sync byte: frame 2 already sees the CCC region, frame 4 the sub-channel
+    assert ends[0] == nb - 1 and ends[1] == nb - 17 and ends[-1] == nb - 17 - 4000, ends
+    H.close()

@@ -1,7 +1,6 @@
 """Shader cycles per phase of k_sync for stream 0 INSIDE the 256-stream batch pass (decode streams running beside the chain).
 gpurun -- 'python tools/gpu_sync_phases_batch.py'"""
 import os, sys, types
-os.environ["NRSC5HIP_SYNC_PHASES"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
@@ -10,6 +9,8 @@ sys.argv = ["bench.py", "--no-cpu-baseline"]
 args = bench.parse()
 dev = torch.device("cuda", 0)
 W = bench.Fm(args, dev, 0, list(range(256)))
+from nrsc5_amd import engine as _eng
+W.E.tune(_eng.TUNE_SYNC_PHASES, 1)
 W.one_pass()
 W.E.debug_sync_phases()                                        # read + reset? (accumulates: take the difference)
 c0 = W.E.debug_sync_phases()
