@@ -136,7 +136,10 @@ void *nrsc5hip_engine_hip_stream(nrsc5hip_engine *e);
 
 /* ---- streaming seam (host buffers), one stream at a time --------------------------------------- */
 /* input_push_cu8 (input.c:96-117): nbytes % 4 == 0.  Decimates, appends, and processes every block
- * whose 33-symbol window is complete; records are then available through nrsc5hip_drain. */
+ * whose 33-symbol window is complete; records are then available through nrsc5hip_drain.  With p1_async = 0 the host keeps a
+ * mirror of the FIFO read position: a push that completes no block is one memcpy into pinned staging + one async H2D + the
+ * decimator launch (no synchronisation); a push that completes one ends with a single stream sync, the block's record already in
+ * host memory. */
 int nrsc5hip_push_cu8(nrsc5hip_engine *e, int stream, const uint8_t *iq, uint32_t nbytes);
 /* input_push_cs16 (input.c:119-124): n = number of int16 values, n % 2 == 0 */
 int nrsc5hip_push_cs16(nrsc5hip_engine *e, int stream, const int16_t *iq, uint32_t n);
@@ -149,6 +152,11 @@ int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream);
 int nrsc5hip_stream_set_mode(nrsc5hip_engine *e, int stream, int mode);
 /* L2 feedback (frame.c:535-540): the stream drops to SYNC_NONE before its next block */
 int nrsc5hip_force_resync(nrsc5hip_engine *e, int stream);
+/* Input bytes of this format (cu8 != 0: cu8, else cs16) whose push completes the stream's next 32-symbol block.  A caller that
+ * applies the L2 feedback itself (frame.c through nrsc5hip_force_resync: the drop-in) pushes at most this much per call, so the
+ * frames of one block reach L2 before the next block is processed -- the reference's event order for any push size.  -1: not
+ * known (p1_async engines, or a stream that the batch entry points touched since its reset): push <= 17280 bytes per call. */
+long long nrsc5hip_bytes_to_next_block(nrsc5hip_engine *e, int stream, int cu8);
 
 /* ---- batch path (device buffers) ------------------------------------------------------------------ */
 /* Decimate + append one cu8 chunk per listed stream.  dev_iq: device pointer, chunk k at

@@ -31,14 +31,20 @@
 
 #include "nrsc5hip.h"
 
-/* one engine per session; stream 0.  acquire_t's otherwise unused FFTW slots carry the handle so that
- * input_t keeps the reference's exact layout. */
+/* one engine per session (any number of sessions per process and GPU; each has its own HIP streams and buffers); stream 0.
+ * acquire_t's otherwise unused FFTW slots carry the handle and the failure mark so that input_t keeps the reference's exact
+ * layout. */
 #define ENGINE(st) ((nrsc5hip_engine *)(st)->acq.fftin)
+#define FAILED(st) ((st)->acq.fftout != NULL)
 
-static void die(const char *what)
+/* The pipe API cannot report errors (nrsc5.c:624 always returns 0) and a library must not take the host application down:
+ * a HIP / engine failure is reported once on stderr and the session goes inert -- it accepts samples and delivers nothing
+ * more, like a receiver that lost its signal -- until it is closed. */
+static void fail(input_t *st, const char *what)
 {
-    fprintf(stderr, "nrsc5hip: %s: %s\n", what, nrsc5hip_last_error());
-    abort();   /* the pipe API cannot report errors (nrsc5.c:624 always returns 0); fail loudly */
+    if (!FAILED(st))
+        fprintf(stderr, "nrsc5hip: %s failed: %s -- this session delivers no further events\n", what, nrsc5hip_last_error());
+    st->acq.fftout = (void *)st;
 }
 
 static void deliver(input_t *st)
@@ -52,7 +58,7 @@ static void deliver(input_t *st)
 
     do
     {
-        if (nrsc5hip_drain(ENGINE(st), 0, rec, 64, &n) != 0) die("drain");
+        if (nrsc5hip_drain(ENGINE(st), 0, rec, 64, &n) != 0) { fail(st, "drain"); return; }
         for (int k = 0; k < n; k++)
         {
             const nrsc5hip_record *r = &rec[k];
@@ -83,13 +89,13 @@ static void deliver(input_t *st)
             {
                 if (r->flags & NRSC5HIP_REC_P1)
                 {
-                    if (nrsc5hip_am_frame_bits(ENGINE(st), 0, r->p1_slot, r->bc_decoded, P1_FRAME_LEN_AM, bits) != 0) die("am_frame_bits");
+                    if (nrsc5hip_am_frame_bits(ENGINE(st), 0, r->p1_slot, r->bc_decoded, P1_FRAME_LEN_AM, bits) != 0) { fail(st, "am_frame_bits"); return; }
                     frame_push(&st->frame, bits, P1_FRAME_LEN_AM, P1_LOGICAL_CHANNEL);   /* may call input_set_sync_state(NONE) */
                 }
                 if (r->flags & NRSC5HIP_REC_P3)
                 {
                     const int n3 = (r->psmi == SERVICE_MODE_MA3) ? P3_FRAME_LEN_MA3 : P3_FRAME_LEN_MA1;
-                    if (nrsc5hip_am_frame_bits(ENGINE(st), 0, r->p1_slot, 8, n3, bits) != 0) die("am_frame_bits");
+                    if (nrsc5hip_am_frame_bits(ENGINE(st), 0, r->p1_slot, 8, n3, bits) != 0) { fail(st, "am_frame_bits"); return; }
                     frame_push(&st->frame, bits, n3, P3_LOGICAL_CHANNEL);
                 }
                 if ((r->flags & NRSC5HIP_REC_P1) && r->bc_decoded == 7)
@@ -98,7 +104,7 @@ static void deliver(input_t *st)
             else if (r->flags & NRSC5HIP_REC_P1)
             {
                 nrsc5_report_ber(st->radio, r->ber);
-                if (nrsc5hip_p1_frame_bits(ENGINE(st), 0, r->p1_slot, bits) != 0) die("p1_frame_bits");
+                if (nrsc5hip_p1_frame_bits(ENGINE(st), 0, r->p1_slot, bits) != 0) { fail(st, "p1_frame_bits"); return; }
                 frame_push(&st->frame, bits, P1_FRAME_LEN_FM, P1_LOGICAL_CHANNEL);   /* may call input_set_sync_state(NONE) */
             }
             if (!am && (r->flags & (NRSC5HIP_REC_P3 | NRSC5HIP_REC_P4)))
@@ -108,7 +114,7 @@ static void deliver(input_t *st)
                 for (int ch = 0; ch < 2; ch++)
                 {
                     if (!(r->flags & (ch ? NRSC5HIP_REC_P4 : NRSC5HIP_REC_P3))) continue;
-                    if (nrsc5hip_px_frame_bits(ENGINE(st), 0, (int)r->sis, ch, nbits, bits) != 0) die("px_frame_bits");
+                    if (nrsc5hip_px_frame_bits(ENGINE(st), 0, (int)r->sis, ch, nbits, bits) != 0) { fail(st, "px_frame_bits"); return; }
                     frame_push(&st->frame, bits, nbits, ch ? P4_LOGICAL_CHANNEL : P3_LOGICAL_CHANNEL);
                 }
             }
@@ -116,18 +122,25 @@ static void deliver(input_t *st)
     } while (n == 64);
 }
 
+/* Feed the engine up to the end of the next block, deliver that block's events (frame_push may answer with
+ * input_set_sync_state(NONE)), then go on: the L2 feedback of a frame reaches the engine before the next block, exactly as in
+ * the reference (FINE -> NONE only comes from frame_process), for any push size. */
+static uint32_t next_piece(input_t *st, uint32_t left, int cu8)
+{
+    long long room = nrsc5hip_bytes_to_next_block(ENGINE(st), 0, cu8);
+    if (room < 0) room = 4 * 4320;                              /* engine cannot tell: two OFDM symbols never complete two blocks */
+    return left < (uint32_t)room ? left : (uint32_t)room;
+}
+
 void input_push_cu8(input_t *st, const uint8_t *buf, const uint32_t len)
 {
     nrsc5_report_iq(st->radio, buf, len);
     assert(len % 4 == 0);
-    /* feed block-sized pieces so that the L2 feedback of a frame reaches the engine before the next block,
-       exactly as in the reference (FINE -> NONE only comes from frame_process) */
     uint32_t consumed = 0;
-    while (consumed < len)
+    while (consumed < len && !FAILED(st))
     {
-        uint32_t piece = len - consumed;
-        if (piece > 4 * 4320) piece = 4 * 4320;
-        if (nrsc5hip_push_cu8(ENGINE(st), 0, buf + consumed, piece) != 0) die("push_cu8");
+        const uint32_t piece = next_piece(st, len - consumed, 1);
+        if (nrsc5hip_push_cu8(ENGINE(st), 0, buf + consumed, piece) != 0) { fail(st, "push_cu8"); return; }
         deliver(st);
         consumed += piece;
     }
@@ -136,12 +149,11 @@ void input_push_cu8(input_t *st, const uint8_t *buf, const uint32_t len)
 void input_push_cs16(input_t *st, const int16_t *buf, const uint32_t len)
 {
     assert(len % 2 == 0);
-    uint32_t consumed = 0;
-    while (consumed < len)
+    uint32_t consumed = 0;                                      /* int16 values */
+    while (consumed < len && !FAILED(st))
     {
-        uint32_t piece = len - consumed;
-        if (piece > 2 * 4320) piece = 2 * 4320;
-        if (nrsc5hip_push_cs16(ENGINE(st), 0, buf + consumed, piece) != 0) die("push_cs16");
+        const uint32_t piece = next_piece(st, (len - consumed) * 2, 0) / 2;
+        if (nrsc5hip_push_cs16(ENGINE(st), 0, buf + consumed, piece) != 0) { fail(st, "push_cs16"); return; }
         deliver(st);
         consumed += piece;
     }
@@ -153,15 +165,15 @@ void input_set_sync_state(input_t *st, unsigned int new_state)
         return;
     if (st->sync_state == SYNC_STATE_FINE)
         nrsc5_report_lost_sync(st->radio);
-    if (new_state == SYNC_STATE_NONE && ENGINE(st))
-        if (nrsc5hip_force_resync(ENGINE(st), 0) != 0) die("force_resync");
+    if (new_state == SYNC_STATE_NONE && ENGINE(st) && !FAILED(st))
+        if (nrsc5hip_force_resync(ENGINE(st), 0) != 0) fail(st, "force_resync");
     st->sync_state = new_state;
 }
 
 void input_reset(input_t *st)
 {
     input_set_sync_state(st, SYNC_STATE_NONE);
-    if (nrsc5hip_stream_reset(ENGINE(st), 0) != 0) die("stream_reset");
+    if (ENGINE(st) && !FAILED(st) && nrsc5hip_stream_reset(ENGINE(st), 0) != 0) fail(st, "stream_reset");
     pids_init(&st->decode.pids, st);
     frame_reset(&st->frame);
     st->sync.psmi = 1;
@@ -177,7 +189,7 @@ void input_init(input_t *st, nrsc5_t *radio, output_t *output)
     st->radio = radio;
     st->output = output;
     st->sync_state = SYNC_STATE_NONE;
-    if (nrsc5hip_engine_create(&cfg, &e) != 0) die("engine_create");
+    if (nrsc5hip_engine_create(&cfg, &e) != 0) { e = NULL; fail(st, "engine_create"); }
     st->acq.fftin = (void *)e;
     st->decode.input = st;
     frame_init(&st->frame, st);
@@ -186,8 +198,8 @@ void input_init(input_t *st, nrsc5_t *radio, output_t *output)
 
 void input_set_mode(input_t *st)
 {
-    if (nrsc5hip_stream_set_mode(ENGINE(st), 0, st->radio->mode == NRSC5_MODE_AM ? NRSC5HIP_MODE_AM : NRSC5HIP_MODE_FM) != 0)
-        die("stream_set_mode");
+    if (ENGINE(st) && !FAILED(st) && nrsc5hip_stream_set_mode(ENGINE(st), 0, st->radio->mode == NRSC5_MODE_AM ? NRSC5HIP_MODE_AM : NRSC5HIP_MODE_FM) != 0)
+        fail(st, "stream_set_mode");
     input_reset(st);
 }
 

@@ -8,31 +8,31 @@
 #include <nrsc5.h>
 
 typedef struct { uint8_t *p; size_t len, cap; } gbuf;
-static gbuf g_log;
+static gbuf g_log, g_log2;
 
-static void put(const void *src, size_t n)
+static void put(gbuf *g, const void *src, size_t n)
 {
-    if (g_log.len + n > g_log.cap) { size_t nc = g_log.cap ? g_log.cap * 2 : 1 << 20; while (nc < g_log.len + n) nc *= 2; g_log.p = realloc(g_log.p, nc); g_log.cap = nc; }
-    memcpy(g_log.p + g_log.len, src, n); g_log.len += n;
+    if (g->len + n > g->cap) { size_t nc = g->cap ? g->cap * 2 : 1 << 20; while (nc < g->len + n) nc *= 2; g->p = realloc(g->p, nc); g->cap = nc; }
+    memcpy(g->p + g->len, src, n); g->len += n;
 }
-static void rec(uint32_t kind, const void *payload, uint32_t n)
+static void rec(gbuf *g, uint32_t kind, const void *payload, uint32_t n)
 {
     uint32_t hdr[2] = { kind, n }, z = 0, pad = (4 - (n & 3)) & 3;
-    put(hdr, 8); if (n) put(payload, n); if (pad) put(&z, pad);
+    put(g, hdr, 8); if (n) put(g, payload, n); if (pad) put(g, &z, pad);
 }
 static void on_event(const nrsc5_event_t *evt, void *opaque)
 {
-    (void)opaque;
+    gbuf *g = (gbuf *)opaque;
     switch (evt->event) {
-    case NRSC5_EVENT_SYNC: { struct { float f; int32_t a[5]; } r = { evt->sync.freq_offset, { evt->sync.psmi, evt->sync.pli, evt->sync.hppi, evt->sync.aabi, evt->sync.rdbi } }; rec(6, &r, sizeof(r)); break; }
-    case NRSC5_EVENT_LOST_SYNC: rec(7, NULL, 0); break;
-    case NRSC5_EVENT_MER: { float r[2] = { evt->mer.lower, evt->mer.upper }; rec(8, r, sizeof(r)); break; }
-    case NRSC5_EVENT_BER: { float r = evt->ber.cber; rec(9, &r, sizeof(r)); break; }
+    case NRSC5_EVENT_SYNC: { struct { float f; int32_t a[5]; } r = { evt->sync.freq_offset, { evt->sync.psmi, evt->sync.pli, evt->sync.hppi, evt->sync.aabi, evt->sync.rdbi } }; rec(g, 6, &r, sizeof(r)); break; }
+    case NRSC5_EVENT_LOST_SYNC: rec(g, 7, NULL, 0); break;
+    case NRSC5_EVENT_MER: { float r[2] = { evt->mer.lower, evt->mer.upper }; rec(g, 8, r, sizeof(r)); break; }
+    case NRSC5_EVENT_BER: { float r = evt->ber.cber; rec(g, 9, &r, sizeof(r)); break; }
     case NRSC5_EVENT_HDC: {
         uint8_t *tmp = malloc(12 + evt->hdc.count);
         uint32_t h[3] = { evt->hdc.program, (uint32_t)evt->hdc.count, evt->hdc.flags };
         memcpy(tmp, h, 12); if (evt->hdc.count) memcpy(tmp + 12, evt->hdc.data, evt->hdc.count);
-        rec(10, tmp, 12 + (uint32_t)evt->hdc.count); free(tmp); break; }
+        rec(g, 10, tmp, 12 + (uint32_t)evt->hdc.count); free(tmp); break; }
     default: break;
     }
 }
@@ -49,7 +49,7 @@ size_t pipe_run(const void *iq, size_t n, unsigned chunk, int mode, int cs16, co
     g_log.len = 0;
     if (nrsc5_open_pipe(&radio) != 0) return 0;
     nrsc5_set_mode(radio, mode);
-    nrsc5_set_callback(radio, on_event, NULL);
+    nrsc5_set_callback(radio, on_event, &g_log);
     const double t0 = now_s();
     for (size_t off = 0; off < n; off += chunk) {
         unsigned k = (n - off < chunk) ? (unsigned)(n - off) : chunk;
@@ -65,4 +65,23 @@ size_t pipe_run(const void *iq, size_t n, unsigned chunk, int mode, int cs16, co
 size_t pipe_run_cu8(const uint8_t *iq, size_t nbytes, unsigned chunk, const uint8_t **out)
 {
     return pipe_run(iq, nbytes, chunk, NRSC5_MODE_FM, 0, out);
+}
+
+/* Two sessions of ONE process fed alternately, chunk by chunk (cu8 FM): each must see exactly the events it sees alone. */
+int pipe_run_pair(const uint8_t *iq0, size_t n0, const uint8_t *iq1, size_t n1, unsigned chunk,
+                  const uint8_t **out0, size_t *len0, const uint8_t **out1, size_t *len1)
+{
+    nrsc5_t *r0 = NULL, *r1 = NULL;
+    g_log.len = 0; g_log2.len = 0;
+    if (nrsc5_open_pipe(&r0) != 0) return -1;
+    if (nrsc5_open_pipe(&r1) != 0) { nrsc5_close(r0); return -1; }
+    nrsc5_set_callback(r0, on_event, &g_log);
+    nrsc5_set_callback(r1, on_event, &g_log2);
+    for (size_t off = 0; off < n0 || off < n1; off += chunk) {
+        if (off < n0) nrsc5_pipe_samples_cu8(r0, iq0 + off, (n0 - off < chunk) ? (unsigned)(n0 - off) : chunk);
+        if (off < n1) nrsc5_pipe_samples_cu8(r1, iq1 + off, (n1 - off < chunk) ? (unsigned)(n1 - off) : chunk);
+    }
+    nrsc5_close(r0); nrsc5_close(r1);
+    *out0 = g_log.p; *len0 = g_log.len; *out1 = g_log2.p; *len1 = g_log2.len;
+    return 0;
 }

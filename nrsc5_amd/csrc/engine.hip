@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <deque>
 #include <new>
 #include <vector>
 #include "nrsc5hip.h"
@@ -66,6 +67,17 @@ struct nrsc5hip_engine {
     std::vector<int> mode_host;        // MODE_FM / MODE_AM per stream
     std::vector<long long> raw_host;   // AM cu8: raw input samples consumed (32:1 decimator phase)
     std::vector<char> attached;        // zero-copy batch: the stream reads the caller's capture (one append per reset)
+    // Fast streaming seam (p1_async = 0): the host mirrors the stream's FIFO read position, so a push that cannot complete a
+    // block costs one host memcpy into pinned memory, one async H2D and the K1 launch -- no synchronisation at all -- and a
+    // push that does complete one ends with ONE sync, after a report kernel has posted the counters, the new read position and
+    // the block's record straight into pinned host memory.
+    struct StreamReport { int counters[4]; long long rd; int nblocks; int nrec; BlockRecord rec[4]; };
+    uint8_t *stage_pin[2], *stage_dev2[2]; hipEvent_t stage_ev[2]; bool stage_busy[2]; int stage_slot;
+    StreamReport *report_host, *report_dev;    // one pinned, device-mapped report
+    std::vector<long long> rd_host;            // FIFO read position (absolute decimated samples) as of the last report
+    std::vector<int> fetched;                  // records of the stream copied to `pending` so far (absolute index)
+    std::vector<char> mirror_ok;               // rd_host / pending are exact: only the streaming seam touched the stream since its reset
+    std::vector<std::deque<BlockRecord>> pending;   // records reported but not yet drained
     // staging
     uint8_t *stage_dev; size_t stage_bytes;
     int *ids_dev; unsigned *nbytes_dev;
@@ -432,6 +444,21 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         db.sync_phase_cycles = nullptr;        // nrsc5hip_debug_tune(NRSC5HIP_TUNE_SYNC_PHASES) turns the instrumentation on
         e->stage_bytes = 4u << 20;
         if ((rc = dev_alloc(e, &e->stage_dev, e->stage_bytes))) break;
+        if (!cfg->p1_async) {
+            for (int k = 0; k < 2 && !rc; k++) {
+                if ((rc = dev_alloc(e, &e->stage_dev2[k], e->stage_bytes + 16))) break;
+                if (hipHostMalloc((void **)&e->stage_pin[k], e->stage_bytes + 16, hipHostMallocDefault) != hipSuccess ||
+                    hipEventCreateWithFlags(&e->stage_ev[k], hipEventDisableTiming) != hipSuccess) { rc = NRSC5HIP_ENOMEM; snprintf(g_err, sizeof(g_err), "pinned staging allocation failed"); }
+                e->stage_busy[k] = false;
+            }
+            if (rc) break;
+            void *dp = nullptr;
+            if (hipHostMalloc((void **)&e->report_host, sizeof(*e->report_host), hipHostMallocMapped) != hipSuccess ||
+                hipHostGetDevicePointer(&dp, e->report_host, 0) != hipSuccess) { rc = NRSC5HIP_ENOMEM; snprintf(g_err, sizeof(g_err), "pinned report allocation failed"); break; }
+            e->report_dev = (nrsc5hip_engine::StreamReport *)dp;
+            memset(e->report_host, 0, sizeof(*e->report_host));
+        }
+        e->stage_slot = 0;
         if ((rc = dev_alloc(e, &e->ids_dev, S))) break;
         if ((rc = dev_alloc(e, &e->nbytes_dev, S))) break;
         if ((rc = dev_alloc(e, &e->all_ids_dev, S))) break;
@@ -444,6 +471,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             hipMemset(db.pm, 0, S * NPM * PM_FRAME) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "state init copy failed"); break; }
         e->wr_host.assign(S, 0); e->base_host.assign(S, 0); e->drained.assign(S, 0);
         e->mode_host.assign(S, MODE_FM); e->raw_host.assign(S, 0); e->attached.assign(S, 0);
+        e->rd_host.assign(S, 0); e->fetched.assign(S, 0); e->mirror_ok.assign(S, cfg->p1_async ? 0 : 1); e->pending.assign(S, {});
         for (int l = 0; l < e->nlanes; l++) { e->lanes[l].db = db; e->lanes[l].counters_dev = db.counters + 4 * l; e->lanes[l].db.counters = db.counters + 4 * l; }
         e->prof_on = false; e->prof_only = -1;
         for (int k = 0; k < NRSC5HIP_PROF_CLASSES; k++) { e->prof_ms[k] = 0; e->prof_launches[k] = 0; }
@@ -463,6 +491,8 @@ extern "C" void nrsc5hip_engine_destroy(nrsc5hip_engine *e)
     if (e->rec_host) (void)hipHostFree(e->rec_host);
     if (e->frames_host) (void)hipHostFree(e->frames_host);
     if (e->nblocks_host) (void)hipHostFree(e->nblocks_host);
+    for (int k = 0; k < 2; k++) { if (e->stage_pin[k]) (void)hipHostFree(e->stage_pin[k]); if (e->stage_ev[k]) (void)hipEventDestroy(e->stage_ev[k]); }
+    if (e->report_host) (void)hipHostFree(e->report_host);
     for (auto &sp : e->prof_spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (hipEvent_t ev : e->prof_pool) (void)hipEventDestroy(ev);
     for (int l = 0; l < e->nlanes; l++) {
@@ -734,13 +764,86 @@ static int ensure_space(nrsc5hip_engine *e, int s, long long incoming)
 {
     if (e->wr_host[s] - e->base_host[s] + incoming <= e->db.q15_cap) return 0;
     hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, e->main, e->db, s);
-    long long base = 0;
-    HIPCHK(hipMemcpyAsync(&base, (const char *)(e->db.state + s) + offsetof(StreamState, base), sizeof(long long), hipMemcpyDeviceToHost, e->main));
-    HIPCHK(hipStreamSynchronize(e->main));
-    e->base_host[s] = base;
+    if (e->mirror_ok[s]) {
+        e->base_host[s] = e->rd_host[s];                       // k_compact sets base = rd, and the mirror IS the device's rd
+    } else {
+        long long base = 0;
+        HIPCHK(hipMemcpyAsync(&base, (const char *)(e->db.state + s) + offsetof(StreamState, base), sizeof(long long), hipMemcpyDeviceToHost, e->main));
+        HIPCHK(hipStreamSynchronize(e->main));
+        e->base_host[s] = base;
+    }
     if (e->wr_host[s] - e->base_host[s] + incoming > e->db.q15_cap)
         FAIL(NRSC5HIP_EOVERFLOW, "stream %d: FIFO capacity %lld too small for %lld more samples", s, e->db.q15_cap, incoming);
     return 0;
+}
+
+// ---- streaming seam ---------------------------------------------------------------------------------------
+// posts what the host needs after a block step of ONE stream into pinned host memory: the step's counters, the FIFO read position
+// and the records [first_rec, nblocks) (in-order mode: a block's record is final when its step ends)
+__global__ void k_stream_report(DevBuffers db, int s, int first_rec, nrsc5hip_engine::StreamReport *out)
+{
+    const StreamState &st = db.state[s];
+    const int n = min(max(st.nblocks - first_rec, 0), 4);
+    const int t = threadIdx.x;
+    constexpr int RW = sizeof(BlockRecord) / 4;
+    if (t < n * RW) {
+        const int k = t / RW, w = t % RW;
+        ((uint32_t *)&out->rec[k])[w] = ((const uint32_t *)&db.records[(size_t)s * db.rec_cap + ((first_rec + k) % db.rec_cap)])[w];
+    }
+    if (t < 4) out->counters[t] = db.counters[t];
+    if (t == 0) { out->rd = st.rd; out->nblocks = st.nblocks; out->nrec = n; }
+    __threadfence_system();
+}
+
+static int window_of(const nrsc5hip_engine *e, int s) { return e->mode_host[s] == MODE_AM ? AM_WIN : WIN_N; }
+
+// Fast seam: block steps of one stream while the host mirror says a window is complete; one sync per step.
+static int stream_steps(nrsc5hip_engine *e, int s)
+{
+    nrsc5hip_engine::Lane &ln = e->lanes[0];
+    const int *ids_dev = e->all_ids_dev + s;                   // identity list: entry s is s
+    const bool am = e->mode_host[s] == MODE_AM;
+    const unsigned long long sig = set_signature(1, &s);
+    if (sig != ln.set_sig) { ln.acq_needed = true; ln.px_needed = true; ln.set_sig = sig; }
+    ln.prepared_by_sync = false;
+    int guard = 0;
+    while (e->wr_host[s] - e->rd_host[s] >= window_of(e, s)) {
+        HIPCHK(hipMemsetAsync(ln.counters_dev, 0, 4 * sizeof(int), ln.main));
+        if (am) {
+            ProfScope p(e, NRSC5HIP_PROF_AM, ln.main);
+            launch_am_step(e->tb, ln.db, 1, ids_dev, ln.main, e->cfg.l2_feedback, -1, (int)(ln.am_step_count % 8), (int)(ln.am_step_count / 8));
+            ln.am_step_count++;
+        } else {
+            int rc = issue_step(e, ln, 1, ids_dev); if (rc) return rc;
+        }
+        hipLaunchKernelGGL(k_stream_report, dim3(1), dim3(128), 0, ln.main, ln.db, s, e->fetched[s], e->report_dev);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(ln.main));
+        const nrsc5hip_engine::StreamReport &rp = *e->report_host;
+        ln.acq_needed = rp.counters[1] > 0;
+        ln.px_needed = rp.counters[2] > 0;
+        e->rd_host[s] = rp.rd;
+        for (int k = 0; k < rp.nrec; k++) e->pending[s].push_back(rp.rec[k]);
+        e->fetched[s] += rp.nrec;
+        if (rp.nblocks != e->fetched[s]) FAIL(NRSC5HIP_EOVERFLOW, "stream %d: %d records behind the report", s, rp.nblocks - e->fetched[s]);
+        if (rp.counters[0] == 0 || ++guard > 64) break;        // nothing was processed or is pending
+    }
+    if (e->prof_on) prof_collect(e);
+    return 0;
+}
+
+// how many input BYTES of this format complete the stream's next block (the drop-in pushes exactly that much, so that the L2
+// feedback of the block's frames reaches the engine before the next block); -1: not known (the stream is not driven by the
+// streaming seam alone, or p1_async)
+extern "C" long long nrsc5hip_bytes_to_next_block(nrsc5hip_engine *e, int stream, int cu8)
+{
+    if (!e || stream < 0 || stream >= e->cfg.max_streams || !e->mirror_ok[stream]) return -1;
+    long long need = window_of(e, stream) - (e->wr_host[stream] - e->rd_host[stream]);     // decimated samples
+    if (need < 1) need = 1;
+    if (!cu8) return need * 4;                                                             // cs16: 4 bytes per complex sample
+    if (e->mode_host[stream] != MODE_AM) return need * 4;                                  // FM cu8: 2 raw samples of 2 bytes each
+    const long long raw = e->raw_host[stream];                                             // AM cu8: output k appears with raw sample 32 k + 31
+    return 2 * ((raw / 32 + need) * 32 - raw);
 }
 
 // ---- streaming seam ---------------------------------------------------------------------------------------
@@ -752,23 +855,42 @@ static int push_common(nrsc5hip_engine *e, int s, const void *host, size_t nbyte
     if (nbytes_total % unit) FAIL(NRSC5HIP_EINVAL, "length must be a multiple of %zu bytes", unit);
     const bool am = e->mode_host[s] == MODE_AM;
     if (e->attached[s]) FAIL(NRSC5HIP_EINVAL, "stream %d reads a zero-copy capture: reset it before pushing samples", s);
+    const bool fast = !e->cfg.p1_async && e->mirror_ok[s];
     while (nbytes_total) {
         const size_t chunk = nbytes_total > e->stage_bytes ? e->stage_bytes : nbytes_total;
         long long nq15 = (long long)chunk / 4;                  // FM cu8: 2:1; cs16: one complex sample per 4 bytes
         if (am && cu8) nq15 = (e->raw_host[s] + (long long)chunk / 2) / 32 - e->raw_host[s] / 32;
         if ((rc = ensure_space(e, s, nq15))) return rc;
         const unsigned count = cu8 ? (unsigned)chunk : (unsigned)(chunk / 2);
-        HIPCHK(hipMemcpyAsync(e->stage_dev, src, chunk, hipMemcpyHostToDevice, e->main));
-        HIPCHK(hipMemcpyAsync(e->ids_dev, &s, sizeof(int), hipMemcpyHostToDevice, e->main));
-        HIPCHK(hipMemcpyAsync(e->nbytes_dev, &count, sizeof(unsigned), hipMemcpyHostToDevice, e->main));
-        HIPCHK(hipStreamSynchronize(e->main));                 // &s / &count are stack temporaries
-        if (cu8 && am) { launch_am_decimate_cu8(e->tb, e->db, 1, e->ids_dev, e->stage_dev, 0, e->nbytes_dev, count, e->main); e->raw_host[s] += (long long)chunk / 2; }
-        else if (cu8) launch_decimate_fm_cu8(e->tb, e->db, 1, e->ids_dev, e->stage_dev, 0, e->nbytes_dev, count, e->main);
-        else launch_append_cs16(e->db, 1, e->ids_dev, (const int16_t *)e->stage_dev, 0, e->nbytes_dev, count, e->main);
-        e->wr_host[s] += nq15;
-        int steps = 0;
-        if (am) { if ((rc = run_steps_am(e, 1, e->ids_dev, 1 << 30, 1, &steps))) return rc; }
-        else if ((rc = run_steps(e, 1, e->ids_dev, set_signature(1, &s), 1 << 30, 1, &steps))) return rc;
+        const int *ids_dev; const unsigned *count_dev; const uint8_t *data_dev;
+        if (fast) {
+            // pinned double-buffered staging: [count (u32), pad to 16][samples]; one async H2D, nothing to wait for
+            const int slot = e->stage_slot; e->stage_slot ^= 1;
+            if (e->stage_busy[slot]) { HIPCHK(hipEventSynchronize(e->stage_ev[slot])); e->stage_busy[slot] = false; }
+            memcpy(e->stage_pin[slot], &count, sizeof(count));
+            memcpy(e->stage_pin[slot] + 16, src, chunk);
+            HIPCHK(hipMemcpyAsync(e->stage_dev2[slot], e->stage_pin[slot], chunk + 16, hipMemcpyHostToDevice, e->main));
+            ids_dev = e->all_ids_dev + s; count_dev = (const unsigned *)e->stage_dev2[slot]; data_dev = e->stage_dev2[slot] + 16;
+            if (cu8 && am) { launch_am_decimate_cu8(e->tb, e->db, 1, ids_dev, data_dev, 0, count_dev, count, e->main); e->raw_host[s] += (long long)chunk / 2; }
+            else if (cu8) launch_decimate_fm_cu8(e->tb, e->db, 1, ids_dev, data_dev, 0, count_dev, count, e->main);
+            else launch_append_cs16(e->db, 1, ids_dev, (const int16_t *)data_dev, 0, count_dev, count, e->main);
+            HIPCHK(hipEventRecord(e->stage_ev[slot], e->main)); e->stage_busy[slot] = true;
+            e->wr_host[s] += nq15;
+            if ((rc = stream_steps(e, s))) return rc;
+        } else {
+            e->mirror_ok[s] = 0; e->pending[s].clear(); e->fetched[s] = e->drained[s];
+            HIPCHK(hipMemcpyAsync(e->stage_dev, src, chunk, hipMemcpyHostToDevice, e->main));
+            HIPCHK(hipMemcpyAsync(e->ids_dev, &s, sizeof(int), hipMemcpyHostToDevice, e->main));
+            HIPCHK(hipMemcpyAsync(e->nbytes_dev, &count, sizeof(unsigned), hipMemcpyHostToDevice, e->main));
+            HIPCHK(hipStreamSynchronize(e->main));                 // &s / &count are stack temporaries
+            if (cu8 && am) { launch_am_decimate_cu8(e->tb, e->db, 1, e->ids_dev, e->stage_dev, 0, e->nbytes_dev, count, e->main); e->raw_host[s] += (long long)chunk / 2; }
+            else if (cu8) launch_decimate_fm_cu8(e->tb, e->db, 1, e->ids_dev, e->stage_dev, 0, e->nbytes_dev, count, e->main);
+            else launch_append_cs16(e->db, 1, e->ids_dev, (const int16_t *)e->stage_dev, 0, e->nbytes_dev, count, e->main);
+            e->wr_host[s] += nq15;
+            int steps = 0;
+            if (am) { if ((rc = run_steps_am(e, 1, e->ids_dev, 1 << 30, 1, &steps))) return rc; }
+            else if ((rc = run_steps(e, 1, e->ids_dev, set_signature(1, &s), 1 << 30, 1, &steps))) return rc;
+        }
         src += chunk; nbytes_total -= chunk;
     }
     return 0;
@@ -787,7 +909,9 @@ extern "C" int nrsc5hip_push_cs16(nrsc5hip_engine *e, int stream, const int16_t 
 extern "C" int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream)
 {
     int rc = check_stream(e, stream); if (rc) return rc;
-    HIPCHK(hipDeviceSynchronize());
+    // this engine's queues only (another session of the process keeps running)
+    HIPCHK(hipStreamSynchronize(e->main));
+    if (e->cfg.p1_async) { for (int k = 0; k < NAUX; k++) HIPCHK(hipStreamSynchronize(e->lanes[0].aux[k])); HIPCHK(hipStreamSynchronize(e->dec_stream)); }
     StreamState st; init_state(st, e->mode_host[stream]);
     HIPCHK(hipMemcpy(e->db.state + stream, &st, sizeof(st), hipMemcpyHostToDevice));
     if (e->db.am) {
@@ -797,6 +921,7 @@ extern "C" int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream)
         HIPCHK(hipMemset(e->db.am_pids_rec + (size_t)stream * NWIN * 8, 0xff, NWIN * 8 * sizeof(int)));
     }
     e->wr_host[stream] = 0; e->base_host[stream] = 0; e->drained[stream] = 0; e->raw_host[stream] = 0; e->attached[stream] = 0;
+    e->rd_host[stream] = 0; e->fetched[stream] = 0; e->pending[stream].clear(); e->mirror_ok[stream] = e->cfg.p1_async ? 0 : 1;
     for (int l = 0; l < e->nlanes; l++) { e->lanes[l].acq_needed = true; e->lanes[l].px_needed = true; e->lanes[l].set_sig = 0; }
     return 0;
 }
@@ -824,6 +949,16 @@ extern "C" int nrsc5hip_force_resync(nrsc5hip_engine *e, int stream)
 }
 
 // ---- batch path ----------------------------------------------------------------------------------------------
+// the batch entry points move a stream's FIFO without the host mirror of the fast streaming seam: records are read from the device again
+static void leave_mirror(nrsc5hip_engine *e, int n, const int *ids)
+{
+    for (int k = 0; k < n; k++) {
+        const int s = ids ? ids[k] : k;
+        if (s < 0 || s >= e->cfg.max_streams || !e->mirror_ok[s]) continue;
+        e->mirror_ok[s] = 0; e->pending[s].clear(); e->fetched[s] = e->drained[s];
+    }
+}
+
 static int upload_ids(nrsc5hip_engine *e, int n, const int *ids, const uint32_t *counts, const int **ids_dev)
 {
     if (n < 1 || n > e->cfg.max_streams) FAIL(NRSC5HIP_EINVAL, "nstreams %d out of range", n);
@@ -843,6 +978,7 @@ extern "C" int nrsc5hip_batch_append_cu8(nrsc5hip_engine *e, int nstreams, const
 {
     if (!e || !dev_iq || !nbytes) FAIL(NRSC5HIP_EINVAL, "null argument");
     const int *ids_dev; int rc = upload_ids(e, nstreams, stream_ids, nbytes, &ids_dev); if (rc) return rc;
+    leave_mirror(e, nstreams, stream_ids);
     unsigned mx = 0;
     {
         int nam = 0;
@@ -937,6 +1073,7 @@ extern "C" int nrsc5hip_batch_append_cs16(nrsc5hip_engine *e, int nstreams, cons
 {
     if (!e || !dev_iq || !nelems) FAIL(NRSC5HIP_EINVAL, "null argument");
     const int *ids_dev; int rc = upload_ids(e, nstreams, stream_ids, nelems, &ids_dev); if (rc) return rc;
+    leave_mirror(e, nstreams, stream_ids);
     unsigned mx = 0;
     for (int k = 0; k < nstreams; k++) {
         const int s = stream_ids ? stream_ids[k] : k;
@@ -956,6 +1093,8 @@ extern "C" int nrsc5hip_batch_process(nrsc5hip_engine *e, int nstreams, const in
 {
     if (!e) FAIL(NRSC5HIP_EINVAL, "null engine");
     if (nstreams < 1 || nstreams > e->cfg.max_streams) FAIL(NRSC5HIP_EINVAL, "nstreams %d out of range", nstreams);
+    if (stream_ids) for (int k = 0; k < nstreams; k++) if (stream_ids[k] < 0 || stream_ids[k] >= e->cfg.max_streams) FAIL(NRSC5HIP_EINVAL, "stream id %d out of range", stream_ids[k]);
+    leave_mirror(e, nstreams, stream_ids);
     {   // AM streams advance through their own fused block kernel; split a mixed list by mode
         std::vector<int> fm, am;
         for (int k = 0; k < nstreams; k++) {
@@ -1004,6 +1143,15 @@ extern "C" int nrsc5hip_drain(nrsc5hip_engine *e, int stream, nrsc5hip_record *o
 {
     int rc = check_stream(e, stream); if (rc) return rc;
     if (!out || !n_out) FAIL(NRSC5HIP_EINVAL, "null argument");
+    if (e->mirror_ok[stream]) {
+        // fast streaming seam: every record of a finished block step is on the host already (k_stream_report)
+        std::deque<BlockRecord> &q = e->pending[stream];
+        int n = 0;
+        for (; n < max && !q.empty(); n++) { memcpy(&out[n], &q.front(), sizeof(BlockRecord)); q.pop_front(); }
+        e->drained[stream] += n;
+        *n_out = n;
+        return 0;
+    }
     HIPCHK(hipStreamSynchronize(e->main));
     int nb = 0;
     if ((rc = fetch_nblocks(e, stream, &nb))) return rc;
@@ -1359,6 +1507,10 @@ extern "C" int nrsc5hip_reset_all(nrsc5hip_engine *e)
     std::fill(e->wr_host.begin(), e->wr_host.end(), 0);
     std::fill(e->base_host.begin(), e->base_host.end(), 0);
     std::fill(e->drained.begin(), e->drained.end(), 0);
+    std::fill(e->rd_host.begin(), e->rd_host.end(), 0);
+    std::fill(e->fetched.begin(), e->fetched.end(), 0);
+    std::fill(e->mirror_ok.begin(), e->mirror_ok.end(), (char)(e->cfg.p1_async ? 0 : 1));
+    for (auto &q : e->pending) q.clear();
     HIPCHK(hipMemset(e->db.pids_rec, 0xff, S * NWIN * 16 * sizeof(int)));
     HIPCHK(hipMemset(e->db.px_job, 0xff, S * NWIN * 16 * sizeof(PxJob)));
     for (int l = 0; l < e->nlanes; l++) {
@@ -1507,6 +1659,7 @@ extern "C" int nrsc5hip_batch_fetch_view(nrsc5hip_engine *e, int nstreams, const
 {
     if (!e || !records || !counts) FAIL(NRSC5HIP_EINVAL, "null argument");
     if (nstreams < 1 || nstreams > e->cfg.max_streams) FAIL(NRSC5HIP_EINVAL, "nstreams out of range");
+    leave_mirror(e, nstreams, nullptr);
     const size_t S = e->cfg.max_streams;
     if (!e->rec_host) {
         HIPCHK(hipHostMalloc((void **)&e->rec_host, S * e->db.rec_cap * sizeof(BlockRecord), hipHostMallocDefault));

@@ -99,6 +99,8 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.nrsc5hip_push_cs16.argtypes = [vp, ci, vp, ctypes.c_uint32]
     lib.nrsc5hip_stream_reset.argtypes = [vp, ci]
     lib.nrsc5hip_force_resync.argtypes = [vp, ci]
+    lib.nrsc5hip_bytes_to_next_block.argtypes = [vp, ci, ci]
+    lib.nrsc5hip_bytes_to_next_block.restype = ctypes.c_longlong
     lib.nrsc5hip_px_frame_bits.argtypes = [vp, ci, ci, ci, ci, vp]
     lib.nrsc5hip_batch_fetch_px.argtypes = [vp, ci, vp, vp]
     lib.nrsc5hip_stream_set_mode.argtypes = [vp, ci, ci]
@@ -150,7 +152,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
 
 EXPORTED_SYMBOLS = [
     "nrsc5hip_engine_create", "nrsc5hip_engine_destroy", "nrsc5hip_last_error", "nrsc5hip_engine_hip_stream",
-    "nrsc5hip_push_cu8", "nrsc5hip_push_cs16", "nrsc5hip_stream_reset", "nrsc5hip_force_resync",
+    "nrsc5hip_push_cu8", "nrsc5hip_push_cs16", "nrsc5hip_stream_reset", "nrsc5hip_force_resync", "nrsc5hip_bytes_to_next_block",
     "nrsc5hip_batch_append_cu8", "nrsc5hip_batch_append_cs16", "nrsc5hip_batch_process", "nrsc5hip_drain",
     "nrsc5hip_p1_frame_packed", "nrsc5hip_p1_frame_bits", "nrsc5hip_batch_fetch", "nrsc5hip_unpack_bits",
     "nrsc5hip_stage_halfband_fm_cu8", "nrsc5hip_stage_fft2048", "nrsc5hip_stage_viterbi_k7", "nrsc5hip_debug_fetch",
@@ -232,6 +234,9 @@ class Engine:
         n = np.zeros(len(self.PROF_CLASSES), dtype=np.int64)
         self._check(self.lib.nrsc5hip_profile(self._h, enable, ms.ctypes.data, n.ctypes.data))
         return {k: (float(a), int(b)) for k, a, b in zip(self.PROF_CLASSES, ms, n)}
+
+    def bytes_to_next_block(self, stream: int, cu8: bool = True) -> int:
+        return int(self.lib.nrsc5hip_bytes_to_next_block(self._h, stream, int(cu8)))
 
     def force_resync(self, stream: int):
         self._check(self.lib.nrsc5hip_force_resync(self._h, stream))

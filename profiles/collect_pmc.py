@@ -4,9 +4,11 @@
 (bench.py ignores the file when that differs from the tree it runs in).
 
 gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE / WRITE_SIZE are in KiB-units of 1024 B
-(hbm_bytes = counter * 1024) and FETCH_SIZE under-reports wide coalesced streaming reads by 2x (128-B requests
-tallied at 64 B).  Both the raw and the 2x-corrected read figures are recorded; the per-launch / whole-path figures use the
-raw read count + writes (a lower bound on traffic)."""
+(hbm_bytes = counter * 1024) and FETCH_SIZE reports exactly 1/2 of the bytes of wide coalesced streaming reads (128-B requests
+tallied at 64 B): doubled here before it is compared with a byte count.  The correction is CALIBRATED on this path's own access
+pattern: k_mixfft reads the cu8 captures exactly once (the algorithmic input bytes of the pass) and nothing else of that size, so
+its corrected fetch over the capture bytes must come out near 1 (recorded as `fetch_calibration`).  WRITE_SIZE is taken as is.
+Per-launch / whole-path figures use the corrected reads + writes; the raw read count is kept beside them."""
 import csv
 import glob
 import json
@@ -42,23 +44,30 @@ def main(fetch_dir, write_dir, workload, alg_bytes_per_pass, out):
     ft, fc = load(fetch_dir, "FETCH_SIZE")
     wt, wc = load(write_dir, "WRITE_SIZE")
     per_class, per_class_detail = {}, {}
+    FX = 2.0                                                   # the guide's correction for wide coalesced reads
     for cls, frags in CLASSES.items():
         rd = sum(v for k, v in ft.items() if any(k.startswith(x) for x in frags)) * 1024
         wr = sum(v for k, v in wt.items() if any(k.startswith(x) for x in frags)) * 1024
         launches = sum(c for k, c in fc.items() if k.startswith(LEAD[cls]))
         if launches:
-            per_class[cls] = (rd + wr) / launches
-            per_class_detail[cls] = {"launches": launches, "fetch_bytes_raw": rd, "fetch_bytes_x2": 2 * rd, "write_bytes": wr}
+            per_class[cls] = (FX * rd + wr) / launches
+            per_class_detail[cls] = {"launches": launches, "fetch_bytes_raw": rd, "fetch_bytes_corrected": FX * rd, "write_bytes": wr}
     rd_all, wr_all = sum(ft.values()) * 1024, sum(wt.values()) * 1024
+    cal = None
+    if workload == "fm" and ft.get("k_mixfft"):
+        in_bytes = float(alg_bytes_per_pass) * 2.0 / (2.0 + 18432.0 / 2211840.0)      # the cu8 input share of the algorithmic bytes
+        cal = {"kernel": "k_mixfft", "corrected_fetch_bytes": FX * ft["k_mixfft"] * 1024, "capture_bytes_read_once": in_bytes,
+               "ratio": FX * ft["k_mixfft"] * 1024 / in_bytes}
     res = {"source_sha": build.source_sha(), "workload": workload, "passes": 1,
+           "fetch_correction": "FETCH_SIZE x 2 (MI355X_MICROARCH.md, HBM: 128-B requests tallied at 64 B), calibrated on k_mixfft", "fetch_calibration": cal,
            "per_class_hbm_bytes_per_launch": per_class, "per_class": per_class_detail,
-           "whole_path_fetch_bytes_raw": rd_all, "whole_path_fetch_bytes_x2": 2 * rd_all, "whole_path_write_bytes": wr_all,
-           "whole_path_hbm_bytes_per_pass": rd_all + wr_all, "algorithmic_bytes_per_pass": float(alg_bytes_per_pass),
-           "whole_path_over_algorithmic": (rd_all + wr_all) / float(alg_bytes_per_pass),
-           "per_kernel_fetch_MB": {k: round(v * 1024 / 1e6, 1) for k, v in sorted(ft.items(), key=lambda kv: -kv[1])[:12]},
+           "whole_path_fetch_bytes_raw": rd_all, "whole_path_fetch_bytes_corrected": FX * rd_all, "whole_path_write_bytes": wr_all,
+           "whole_path_hbm_bytes_per_pass": FX * rd_all + wr_all, "algorithmic_bytes_per_pass": float(alg_bytes_per_pass),
+           "whole_path_over_algorithmic": (FX * rd_all + wr_all) / float(alg_bytes_per_pass),
+           "per_kernel_fetch_MB_raw": {k: round(v * 1024 / 1e6, 1) for k, v in sorted(ft.items(), key=lambda kv: -kv[1])[:12]},
            "per_kernel_write_MB": {k: round(v * 1024 / 1e6, 1) for k, v in sorted(wt.items(), key=lambda kv: -kv[1])[:12]}}
     json.dump(res, open(out, "w"), indent=1)
-    print(json.dumps({k: res[k] for k in ("source_sha", "whole_path_hbm_bytes_per_pass", "whole_path_over_algorithmic", "per_class_hbm_bytes_per_launch")}))
+    print(json.dumps({k: res[k] for k in ("source_sha", "fetch_calibration", "whole_path_hbm_bytes_per_pass", "whole_path_over_algorithmic", "per_class_hbm_bytes_per_launch")}))
 
 
 if __name__ == "__main__":

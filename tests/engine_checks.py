@@ -866,3 +866,50 @@ def check_frame_push_indexed_with_device_index(lib, reflib):
             n_pkt += sum(1 for t in ta if t[0] == "l2pkt"); n_aas += sum(1 for t in ta if t[0] == "l2aas")
     assert n_pkt >= 400 and n_aas >= 8, (n_pkt, n_aas)
     E.close()
+
+
+def check_block_exact_pushes(lib, oracle, am=False):
+    """The drop-in's feeding rule (integration/input_hip.c): every nrsc5_pipe_samples call (32768 bytes) is handed to the engine in
+    pieces that end where nrsc5hip_bytes_to_next_block says the next block completes, so at most ONE block is processed per push
+    -- also right after a CFO search, when the reference keeps up to 31 symbols (acquire_keep_extra) and the next window needs only
+    two symbols of new samples -- and the L2 feedback of a block reaches the engine before the next one.  Engine: in-order P1,
+    feedback applied by the engine's own in-order L2 check (== the reference's); log == oracle with the L2 hook."""
+    if am:
+        from nrsc5_amd import synth_am
+        caps = [synth_am.am_ma1_capture(n_frames=9, seed=31, cfo_hz=-40.0, offset=1700, fmt="cu8"), synth_am.am_ma1_capture(n_frames=9, seed=32, cfo_hz=5.0, offset=300)]
+    else:
+        caps = [synth.fm_mp1_capture(**common.GOLDEN_CASES["fm_cu8_cfo-2400"]), synth.fm_mp1_capture(0, seed=23, cfo_hz=0.0, offset=1234, snr_db=20, n_blocks=50),
+                synth.fm_mp1_capture(**common.GOLDEN_CASES["fm_cs16_cfo60"])]
+    for cap in caps:
+        cu8 = cap.iq.dtype == np.uint8
+        E = eng.Engine(max_streams=1, q15_capacity=200000, record_capacity=256, p1_slots=8, lib_path=lib, am_enable=am, l2_feedback=True)
+        if am:
+            E.set_mode(0, eng.MODE_AM)
+        item = 1 if cu8 else 2
+        recs, pieces, most = [], 0, 0
+        for off in range(0, cap.iq.size * item, 32768):
+            call = cap.iq.view(np.uint8)[off:off + 32768]
+            call = call[:call.size - call.size % 4]
+            done = 0
+            while done < call.size:
+                room = E.bytes_to_next_block(0, cu8)
+                assert room >= 4 and room % 4 == 0
+                piece = call[done:done + room]
+                if cu8:
+                    E.push_cu8(0, piece)
+                else:
+                    E.push_cs16(0, piece.view(np.int16))
+                new = E.drain(0)
+                most = max(most, len(new)); recs.append(new); pieces += 1
+                done += piece.size
+        assert most == 1, most                                   # never two blocks in one push
+        recs = np.concatenate(recs)
+        assert pieces < 2 * (cap.iq.size * item // 32768 + 1) + len(recs) + 2     # ~one piece per call + one per block
+        log = (eng.am_records_to_log if am else eng.records_to_log)(E, 0, recs)
+        ol, _, _ = oracle.run(cap.iq, mode=1 if am else 0, p1_hook=oracle.l2_hook())
+        diffs = common.compare_logs(common.strip_states(ol), common.strip_states(log))
+        kept = [x for x in common.strip_states(ol) if x[0] not in ("hdc", "soft", "vit", "amsym", "pxsoft")]
+        bad = {i for i, (kk, v) in enumerate(kept) if kk == "ber" and v["cber"] > 0.02}
+        diffs = [d for d in diffs if not any(d.startswith(f"#{i} ber") or d.startswith(f"#{i + 1} frame") for i in bad)]
+        assert not diffs, diffs[:8]
+        E.close()

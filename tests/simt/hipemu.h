@@ -137,6 +137,7 @@ template <typename T> static inline T atomicExch(T *p, T v) { T o = *p; *p = v; 
 static inline long long clock64() { return 0; }
 static inline void __threadfence() {}
 static inline void __threadfence_block() {}
+static inline void __threadfence_system() {}
 
 static inline void sincosf_emu(float x, float *s, float *c) { *s = sinf(x); *c = cosf(x); }
 #define __sincosf(x, s, c) sincosf_emu((x), (s), (c))
@@ -179,6 +180,8 @@ static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 static inline const char *hipGetErrorString(hipError_t) { return "hipemu"; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = 0; return hipSuccess; }
+#define hipEventDisableTiming 2u
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = 0; return hipSuccess; }
 static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = 0) { return hipSuccess; }

@@ -171,3 +171,7 @@ def test_emu_l2_index_vs_reference_golden(emu_lib):
 
 def test_emu_frame_push_indexed_with_device_index(emu_lib, reflib):
     ec.check_frame_push_indexed_with_device_index(emu_lib, reflib)
+
+
+def test_emu_block_exact_pushes(emu_lib, oracle):
+    ec.check_block_exact_pushes(emu_lib, oracle)

@@ -64,3 +64,22 @@ def test_dropin_public_api_events_match_reference(name, captures):
             for f in a:
                 va, vb = a[f], b[f]
                 assert abs(va - vb) <= common.FLOAT_RTOL * max(1.0, abs(va)), (k, f, va, vb)
+
+
+def test_two_dropin_sessions_in_one_process(captures):
+    """Two nrsc5_open_pipe sessions of one process (one engine each: own HIP streams, staging and state) fed alternately in
+    32768-byte calls: each delivers exactly the events it delivers alone (= the plain reference's)."""
+    a = np.ascontiguousarray(captures("fm_cu8_cfo137").iq)
+    b = np.ascontiguousarray(captures("fm_cu8_cfo-2400").iq)
+    lib = ctypes.CDLL(os.path.join(BUILD["libnrsc5_hipdropin.so"], "libnrsc5_hipdropin.so"))
+    if not hasattr(lib, "pipe_run_pair"):
+        pytest.skip("drop-in not prebuilt with pipe_run_pair")
+    vp, sz = ctypes.c_void_p, ctypes.c_size_t
+    lib.pipe_run_pair.argtypes = [vp, sz, vp, sz, ctypes.c_uint, ctypes.POINTER(vp), ctypes.POINTER(sz), ctypes.POINTER(vp), ctypes.POINTER(sz)]
+    p0, p1, n0, n1 = vp(), vp(), sz(), sz()
+    assert lib.pipe_run_pair(a.ctypes.data, a.size, b.ctypes.data, b.size, 32768, ctypes.byref(p0), ctypes.byref(n0), ctypes.byref(p1), ctypes.byref(n1)) == 0
+    got = [ref.parse_log(ctypes.string_at(p0, n0.value)), ref.parse_log(ctypes.string_at(p1, n1.value))]
+    for iq, g in zip((a, b), got):
+        exp = _run("libnrsc5_plain.so", iq)
+        assert len(exp) > 10
+        _compare_events(exp, g)

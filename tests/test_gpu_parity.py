@@ -331,3 +331,8 @@ def test_gpu_hdc_consumer_equals_reference_events(hip_lib, reflib, p1_async):
             synth.fm_mp1_capture(0, n_blocks=70, seed=23, cfo_hz=0.0, offset=1234, snr_db=20),
             synth.fm_mp1_capture(3, seed=52, cfo_hz=-40.0, offset=500, snr_db=25, mode="MP3")]
     assert ec.check_hdc_consumer(hip_lib, reflib, caps, p1_async=p1_async) >= 200
+
+
+@pytest.mark.parametrize("am", [False, True])
+def test_gpu_block_exact_pushes(hip_lib, oracle, am):
+    ec.check_block_exact_pushes(hip_lib, oracle, am=am)
