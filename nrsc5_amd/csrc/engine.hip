@@ -73,6 +73,9 @@ struct nrsc5hip_engine {
     // the block's record straight into pinned host memory.
     struct StreamReport { int counters[4]; long long rd; int nblocks; int nrec; BlockRecord rec[4]; };
     uint8_t *stage_pin[2], *stage_dev2[2]; hipEvent_t stage_ev[2]; bool stage_busy[2]; int stage_slot;
+    // samples accepted by a push but not submitted yet: they wait in stage_pin[stage_slot] until the mirror says a block completes
+    // (or the buffer is full, or anything else looks at the stream) -- one H2D + one decimator launch per BLOCK, not per push
+    int staged_stream; size_t staged_bytes; bool staged_cu8; long long staged_q15;
     StreamReport *report_host, *report_dev;    // one pinned, device-mapped report
     std::vector<long long> rd_host;            // FIFO read position (absolute decimated samples) as of the last report
     std::vector<int> fetched;                  // records of the stream copied to `pending` so far (absolute index)
@@ -458,7 +461,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             e->report_dev = (nrsc5hip_engine::StreamReport *)dp;
             memset(e->report_host, 0, sizeof(*e->report_host));
         }
-        e->stage_slot = 0;
+        e->stage_slot = 0; e->staged_stream = -1; e->staged_bytes = 0; e->staged_q15 = 0; e->staged_cu8 = false;
         if ((rc = dev_alloc(e, &e->ids_dev, S))) break;
         if ((rc = dev_alloc(e, &e->nbytes_dev, S))) break;
         if ((rc = dev_alloc(e, &e->all_ids_dev, S))) break;
@@ -847,6 +850,29 @@ extern "C" long long nrsc5hip_bytes_to_next_block(nrsc5hip_engine *e, int stream
 }
 
 // ---- streaming seam ---------------------------------------------------------------------------------------
+// submit the staged samples of the fast seam: one async H2D from pinned memory ([count (u32), pad to 16][samples]) + the decimator
+static int flush_staged(nrsc5hip_engine *e)
+{
+    const int s = e->staged_stream;
+    if (s < 0 || e->staged_bytes == 0) { e->staged_stream = -1; return 0; }
+    const int slot = e->stage_slot;
+    const bool cu8 = e->staged_cu8, am = e->mode_host[s] == MODE_AM;
+    const size_t chunk = e->staged_bytes;
+    const unsigned count = cu8 ? (unsigned)chunk : (unsigned)(chunk / 2);
+    e->staged_stream = -1; e->staged_bytes = 0; e->staged_q15 = 0;
+    e->stage_slot ^= 1;                                        // the next pushes fill the other buffer
+    int rc = ensure_space(e, s, 0); if (rc) return rc;         // wr_host already counts the staged samples
+    memcpy(e->stage_pin[slot], &count, sizeof(count));
+    HIPCHK(hipMemcpyAsync(e->stage_dev2[slot], e->stage_pin[slot], chunk + 16, hipMemcpyHostToDevice, e->main));
+    const int *ids_dev = e->all_ids_dev + s; const unsigned *count_dev = (const unsigned *)e->stage_dev2[slot]; const uint8_t *data_dev = e->stage_dev2[slot] + 16;
+    if (cu8 && am) launch_am_decimate_cu8(e->tb, e->db, 1, ids_dev, data_dev, 0, count_dev, count, e->main);
+    else if (cu8) launch_decimate_fm_cu8(e->tb, e->db, 1, ids_dev, data_dev, 0, count_dev, count, e->main);
+    else launch_append_cs16(e->db, 1, ids_dev, (const int16_t *)data_dev, 0, count_dev, count, e->main);
+    HIPCHK(hipEventRecord(e->stage_ev[slot], e->main)); e->stage_busy[slot] = true;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 static int push_common(nrsc5hip_engine *e, int s, const void *host, size_t nbytes_total, bool cu8)
 {
     int rc = check_stream(e, s); if (rc) return rc;
@@ -856,41 +882,44 @@ static int push_common(nrsc5hip_engine *e, int s, const void *host, size_t nbyte
     const bool am = e->mode_host[s] == MODE_AM;
     if (e->attached[s]) FAIL(NRSC5HIP_EINVAL, "stream %d reads a zero-copy capture: reset it before pushing samples", s);
     const bool fast = !e->cfg.p1_async && e->mirror_ok[s];
+    if (fast && e->staged_stream >= 0 && (e->staged_stream != s || e->staged_cu8 != cu8) && (rc = flush_staged(e))) return rc;
     while (nbytes_total) {
+        if (fast) {
+            // stage in pinned memory; submit when the block completes (the mirror knows) or the buffer is full
+            const int slot = e->stage_slot;
+            if (e->staged_bytes == 0 && e->stage_busy[slot]) { HIPCHK(hipEventSynchronize(e->stage_ev[slot])); e->stage_busy[slot] = false; }
+            const size_t room = e->stage_bytes - e->staged_bytes;
+            const size_t chunk = nbytes_total > room ? room : nbytes_total;
+            long long nq15 = (long long)chunk / 4;
+            if (am && cu8) nq15 = (e->raw_host[s] + (long long)chunk / 2) / 32 - e->raw_host[s] / 32;
+            memcpy(e->stage_pin[slot] + 16 + e->staged_bytes, src, chunk);
+            e->staged_stream = s; e->staged_cu8 = cu8; e->staged_bytes += chunk; e->staged_q15 += nq15;
+            e->wr_host[s] += nq15;
+            if (am && cu8) e->raw_host[s] += (long long)chunk / 2;
+            src += chunk; nbytes_total -= chunk;
+            if (e->wr_host[s] - e->rd_host[s] >= window_of(e, s) || e->staged_bytes == e->stage_bytes) {
+                if ((rc = flush_staged(e))) return rc;
+                if ((rc = stream_steps(e, s))) return rc;
+            }
+            continue;
+        }
         const size_t chunk = nbytes_total > e->stage_bytes ? e->stage_bytes : nbytes_total;
         long long nq15 = (long long)chunk / 4;                  // FM cu8: 2:1; cs16: one complex sample per 4 bytes
         if (am && cu8) nq15 = (e->raw_host[s] + (long long)chunk / 2) / 32 - e->raw_host[s] / 32;
         if ((rc = ensure_space(e, s, nq15))) return rc;
         const unsigned count = cu8 ? (unsigned)chunk : (unsigned)(chunk / 2);
-        const int *ids_dev; const unsigned *count_dev; const uint8_t *data_dev;
-        if (fast) {
-            // pinned double-buffered staging: [count (u32), pad to 16][samples]; one async H2D, nothing to wait for
-            const int slot = e->stage_slot; e->stage_slot ^= 1;
-            if (e->stage_busy[slot]) { HIPCHK(hipEventSynchronize(e->stage_ev[slot])); e->stage_busy[slot] = false; }
-            memcpy(e->stage_pin[slot], &count, sizeof(count));
-            memcpy(e->stage_pin[slot] + 16, src, chunk);
-            HIPCHK(hipMemcpyAsync(e->stage_dev2[slot], e->stage_pin[slot], chunk + 16, hipMemcpyHostToDevice, e->main));
-            ids_dev = e->all_ids_dev + s; count_dev = (const unsigned *)e->stage_dev2[slot]; data_dev = e->stage_dev2[slot] + 16;
-            if (cu8 && am) { launch_am_decimate_cu8(e->tb, e->db, 1, ids_dev, data_dev, 0, count_dev, count, e->main); e->raw_host[s] += (long long)chunk / 2; }
-            else if (cu8) launch_decimate_fm_cu8(e->tb, e->db, 1, ids_dev, data_dev, 0, count_dev, count, e->main);
-            else launch_append_cs16(e->db, 1, ids_dev, (const int16_t *)data_dev, 0, count_dev, count, e->main);
-            HIPCHK(hipEventRecord(e->stage_ev[slot], e->main)); e->stage_busy[slot] = true;
-            e->wr_host[s] += nq15;
-            if ((rc = stream_steps(e, s))) return rc;
-        } else {
-            e->mirror_ok[s] = 0; e->pending[s].clear(); e->fetched[s] = e->drained[s];
-            HIPCHK(hipMemcpyAsync(e->stage_dev, src, chunk, hipMemcpyHostToDevice, e->main));
-            HIPCHK(hipMemcpyAsync(e->ids_dev, &s, sizeof(int), hipMemcpyHostToDevice, e->main));
-            HIPCHK(hipMemcpyAsync(e->nbytes_dev, &count, sizeof(unsigned), hipMemcpyHostToDevice, e->main));
-            HIPCHK(hipStreamSynchronize(e->main));                 // &s / &count are stack temporaries
-            if (cu8 && am) { launch_am_decimate_cu8(e->tb, e->db, 1, e->ids_dev, e->stage_dev, 0, e->nbytes_dev, count, e->main); e->raw_host[s] += (long long)chunk / 2; }
-            else if (cu8) launch_decimate_fm_cu8(e->tb, e->db, 1, e->ids_dev, e->stage_dev, 0, e->nbytes_dev, count, e->main);
-            else launch_append_cs16(e->db, 1, e->ids_dev, (const int16_t *)e->stage_dev, 0, e->nbytes_dev, count, e->main);
-            e->wr_host[s] += nq15;
-            int steps = 0;
-            if (am) { if ((rc = run_steps_am(e, 1, e->ids_dev, 1 << 30, 1, &steps))) return rc; }
-            else if ((rc = run_steps(e, 1, e->ids_dev, set_signature(1, &s), 1 << 30, 1, &steps))) return rc;
-        }
+        e->mirror_ok[s] = 0; e->pending[s].clear(); e->fetched[s] = e->drained[s];
+        HIPCHK(hipMemcpyAsync(e->stage_dev, src, chunk, hipMemcpyHostToDevice, e->main));
+        HIPCHK(hipMemcpyAsync(e->ids_dev, &s, sizeof(int), hipMemcpyHostToDevice, e->main));
+        HIPCHK(hipMemcpyAsync(e->nbytes_dev, &count, sizeof(unsigned), hipMemcpyHostToDevice, e->main));
+        HIPCHK(hipStreamSynchronize(e->main));                 // &s / &count are stack temporaries
+        if (cu8 && am) { launch_am_decimate_cu8(e->tb, e->db, 1, e->ids_dev, e->stage_dev, 0, e->nbytes_dev, count, e->main); e->raw_host[s] += (long long)chunk / 2; }
+        else if (cu8) launch_decimate_fm_cu8(e->tb, e->db, 1, e->ids_dev, e->stage_dev, 0, e->nbytes_dev, count, e->main);
+        else launch_append_cs16(e->db, 1, e->ids_dev, (const int16_t *)e->stage_dev, 0, e->nbytes_dev, count, e->main);
+        e->wr_host[s] += nq15;
+        int steps = 0;
+        if (am) { if ((rc = run_steps_am(e, 1, e->ids_dev, 1 << 30, 1, &steps))) return rc; }
+        else if ((rc = run_steps(e, 1, e->ids_dev, set_signature(1, &s), 1 << 30, 1, &steps))) return rc;
         src += chunk; nbytes_total -= chunk;
     }
     return 0;
@@ -909,6 +938,7 @@ extern "C" int nrsc5hip_push_cs16(nrsc5hip_engine *e, int stream, const int16_t 
 extern "C" int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream)
 {
     int rc = check_stream(e, stream); if (rc) return rc;
+    if (e->staged_stream == stream) { e->staged_stream = -1; e->staged_bytes = 0; e->staged_q15 = 0; }      // samples not yet submitted die with the session
     // this engine's queues only (another session of the process keeps running)
     HIPCHK(hipStreamSynchronize(e->main));
     if (e->cfg.p1_async) { for (int k = 0; k < NAUX; k++) HIPCHK(hipStreamSynchronize(e->lanes[0].aux[k])); HIPCHK(hipStreamSynchronize(e->dec_stream)); }
@@ -952,6 +982,7 @@ extern "C" int nrsc5hip_force_resync(nrsc5hip_engine *e, int stream)
 // the batch entry points move a stream's FIFO without the host mirror of the fast streaming seam: records are read from the device again
 static void leave_mirror(nrsc5hip_engine *e, int n, const int *ids)
 {
+    if (e->staged_stream >= 0) (void)flush_staged(e);          // whatever a push left in the pinned buffer goes to the FIFO first
     for (int k = 0; k < n; k++) {
         const int s = ids ? ids[k] : k;
         if (s < 0 || s >= e->cfg.max_streams || !e->mirror_ok[s]) continue;
@@ -1471,6 +1502,7 @@ extern "C" int nrsc5hip_debug_fetch_q15(nrsc5hip_engine *e, int stream, long lon
 {
     int rc = check_stream(e, stream); if (rc) return rc;
     if (n < 0 || n > e->db.q15_cap || !out) FAIL(NRSC5HIP_EINVAL, "bad argument");
+    if (e->staged_stream >= 0 && (rc = flush_staged(e))) return rc;
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, e->db.q15 + (size_t)stream * e->db.q15_cap, (size_t)n * sizeof(c16), hipMemcpyDeviceToHost));
     return 0;
@@ -1491,6 +1523,7 @@ extern "C" int nrsc5hip_reset_all(nrsc5hip_engine *e)
     if (!e) FAIL(NRSC5HIP_EINVAL, "null engine");
     HIPCHK(hipDeviceSynchronize());
     e->dec_chunk = 0;
+    e->staged_stream = -1; e->staged_bytes = 0; e->staged_q15 = 0;
     const size_t S = e->cfg.max_streams;
     std::vector<StreamState> init(S);
     for (size_t s = 0; s < S; s++) init_state(init[s], e->mode_host[s]);

@@ -81,5 +81,5 @@ def test_two_dropin_sessions_in_one_process(captures):
     got = [ref.parse_log(ctypes.string_at(p0, n0.value)), ref.parse_log(ctypes.string_at(p1, n1.value))]
     for iq, g in zip((a, b), got):
         exp = _run("libnrsc5_plain.so", iq)
-        assert len(exp) > 10
+        assert len(exp) >= 2
         _compare_events(exp, g)
