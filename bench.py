@@ -79,7 +79,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-processes", type=int, default=0, help="processes of the N-core CPU aggregate (default: all host cores, at most 64)")
     ap.add_argument("--oracle-streams", type=int, default=8, help="parity block: streams that did NOT lose sync compared with the reference (every stream that lost sync is compared)")
     ap.add_argument("--oracle-lost-max", type=int, default=64, help="parity block: upper bound on the lost-sync streams compared (reported when it bites)")
-    ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE", help="nrsc5hip_debug_tune before the run: decode_streams / am_decode_streams = 1..5")
+    ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE", help="nrsc5hip_debug_tune before the run: decode_streams / am_decode_streams = 1..5, fwd_segments = 0..16")
     ap.add_argument("--launch-check", action="store_true", help="only start the ranks, form the process group (RCCL; gloo without a GPU) and print what it sees -- no workload")
     ap.add_argument("--ingest", choices=("local", "scatter"), default="local",
                     help="fm, --gpus N: local = every rank synthesises its own captures; scatter = rank 0 synthesises all of them and sends each rank its shard (RCCL point-to-point, before the timed region)")
@@ -664,7 +664,7 @@ class Mixed:
         return k >= self.nfm
 
 
-TUNE_KNOBS = {"decode_streams": 0, "am_decode_streams": 1}
+TUNE_KNOBS = {"decode_streams": 0, "am_decode_streams": 1, "fwd_segments": 4}
 
 
 def apply_tune(E, args):
@@ -832,6 +832,7 @@ def main():
     shard.barrier(dev)
     dt = time.perf_counter() - t0
     prof = E.profile(0)
+    fwd_checked, fwd_repaired = E.fwd_stats() if hasattr(E, "fwd_stats") else (0, 0)
     dt = shard.max_over_ranks(dt, dev)
     per_rank_ms = [round(x / args.steps * 1e3, 3) for x in shard.gather_floats(dt_rank, dev)]
     tot = shard.sum_over_ranks([W.samples, W.signal_seconds, 1.0], dev)
@@ -931,6 +932,8 @@ def main():
         "vs_baseline": None, "dtype": W.dtype, "data": "synthetic",
         "config": config, "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         "gen_seconds": round(t_gen, 1),
+        "forward_pass_segments": {"boundaries_checked": fwd_checked, "segments_repaired": fwd_repaired,
+                                  "what": "K=7 forward trellis pass cut into concurrently running segment waves per frame (speculative start, verified, repaired when wrong: viterbi_v3.h); counts since the engine was created, rank 0"},
     }
     line.update(extra)
     line["parity_failures"] = list(FAILURES)

@@ -318,8 +318,15 @@ enum {
     NRSC5HIP_TUNE_DECODE_STREAMS = 0,    /* FM window pipeline: HIP streams that decode windows concurrently (1..5, default 3) */
     NRSC5HIP_TUNE_AM_DECODE_STREAMS,     /* same for the AM window pipeline (default 4) */
     NRSC5HIP_TUNE_VERDICT_LAG,           /* TEST HOOK: the replay takes first-header verdicts this many windows late (0..8): deep speculation */
-    NRSC5HIP_TUNE_SYNC_PHASES            /* 1: k_sync accumulates shader cycles per phase for stream 0 (nrsc5hip_debug_sync_phases) */
+    NRSC5HIP_TUNE_SYNC_PHASES,           /* 1: k_sync accumulates shader cycles per phase for stream 0 (nrsc5hip_debug_sync_phases) */
+    NRSC5HIP_TUNE_FWD_SEGMENTS           /* waves per frame of the K=7 forward trellis pass (1..16; 0 = chosen from the size of the stream set).  Any value
+                                            gives the sequential decoder's decisions bit for bit: segments start speculatively and are verified /
+                                            repaired (viterbi_v3.h).  Also used by nrsc5hip_stage_viterbi_k7 / _bench. */
+    , NRSC5HIP_TUNE_FWD_WARM               /* TEST HOOK: 0 = the segments start cold (no speculative warm-up), so that the speculation fails wherever the
+                                            input carries information and every segment takes the repair path; 1 = normal */
 };
+/* segmented forward pass: segment boundaries checked / segments that had to be re-run since the engine was created */
+int nrsc5hip_debug_fwd_stats(nrsc5hip_engine *e, int stats[2]);
 int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value);
 /* accumulated shader cycles per phase of the sync kernel for stream 0 (after nrsc5hip_debug_tune(e, NRSC5HIP_TUNE_SYNC_PHASES, 1)) */
 int nrsc5hip_debug_sync_phases(nrsc5hip_engine *e, long long *cycles8);

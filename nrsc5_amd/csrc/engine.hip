@@ -59,6 +59,8 @@ struct nrsc5hip_engine {
     int naux;                          // decode streams in use (<= NAUX)
     int naux_am;                       // ... by the AM window pipeline (its decodes are longer and thinner: 4 measured best)
     int verdict_lag;                   // test hook (nrsc5hip_debug_tune): replay takes verdicts this many windows late
+    int fwd_warm;                      // test hook: speculative warm-up trips of a forward segment (2; 0 makes every speculation fail -> repair path)
+    int fwd_segments;                  // waves per frame of the P1 forward pass; 0 = pick from the size of the stream set (fwd_segments_for)
     hipStream_t main;                  // = lanes[0].main
     std::vector<void *> allocs;
     // host mirrors
@@ -344,7 +346,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         {
             e->nlanes = 1;
             e->naux = 3; e->naux_am = 4;   // decode streams in use (measured: profiles/r02_naux.txt); nrsc5hip_debug_tune changes them
-            e->verdict_lag = 0;
+            e->verdict_lag = 0; e->fwd_segments = 0; e->fwd_warm = 2;
         }
         for (int l = 0; l < e->nlanes && !rc; l++) {
             nrsc5hip_engine::Lane &ln = e->lanes[l];
@@ -390,6 +392,9 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if ((rc = dev_alloc(e, &db.coded, (size_t)(cfg->p1_async ? NAUX : 1) * S * P1_LEN))) break;
         if ((rc = dev_alloc(e, &db.dec, (size_t)(cfg->p1_async ? NAUX : 1) * S * (size_t)(2 * (P1_LEN + 64))))) break;
         if ((rc = dev_alloc(e, &db.tbmap, (size_t)(cfg->p1_async ? NAUX : 1) * S * (size_t)(P1_LEN / 64 + 1) * 64))) break;
+        if ((rc = dev_alloc(e, &db.fwd_meta, (size_t)(cfg->p1_async ? NAUX : 1) * S * (size_t)(16 * 512)))) break;
+        if ((rc = dev_alloc(e, &db.fwd_stats, 2))) break;
+        if (hipMemset(db.fwd_stats, 0, 2 * sizeof(int)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
         if ((rc = dev_alloc(e, &db.pids_stage, S * NWIN * 16 * 3 * PIDS_LEN))) break;
         if ((rc = dev_alloc(e, &db.pids_rec, S * NWIN * 16))) break;
         if (hipMemset(db.pids_rec, 0xff, S * NWIN * 16 * sizeof(int)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
@@ -533,6 +538,17 @@ static int pick_decode_lane(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, long 
     return lane;
 }
 
+// Waves per frame of the forward trellis pass: a window of a stream set of n streams holds ~n frames; give every frame as many
+// segment waves as keeps the launch within one wave per SIMD (1024) -- up to 16.  Thin windows (the stragglers' tail) and
+// small sets are latency-bound: 16.
+static int fwd_segments_for(const nrsc5hip_engine *e, const nrsc5hip_engine::Lane &ln, int n)
+{
+    if (e->fwd_segments > 0) return e->fwd_segments;
+    if (ln.thin) return 16;
+    const int g = 1024 / (n > 0 ? n : 1);
+    return g < 1 ? 1 : g > 16 ? 16 : g;
+}
+
 static int launch_window_decode(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const int *ids_dev, int parity, int lane)
 {
     // decode the window's PIDS frames and P1 frames on aux stream `lane`, overlapped with the next windows
@@ -543,7 +559,7 @@ static int launch_window_decode(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, i
     { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_pids_decode(e->tb, ln.db, n, ids_dev, parity, 16, ax); }
     if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_px_decode(e->tb, ln.db, n, ids_dev, parity, lane, ax); }
     { ProfScope p(e, NRSC5HIP_PROF_P1_DEINT, ax); launch_p1_deint(e->tb, ln.db, n, ids_dev, parity, lane, ax); }
-    { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ax); launch_p1_forward(e->tb, ln.db, n, ids_dev, parity, lane, ax); }
+    { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ax); launch_p1_forward(e->tb, ln.db, n, ids_dev, parity, lane, ax, fwd_segments_for(e, ln, n), e->fwd_warm); }
     { ProfScope p(e, NRSC5HIP_PROF_P1_TRACEBACK, ax); launch_p1_traceback(e->tb, ln.db, n, ids_dev, parity, lane, ax, e->cfg.l2_feedback ? 2 : 0); }
     HIPCHK(hipEventRecord(ln.ev_decoded[parity], ax));
     ln.decoded_pending[parity] = true;
@@ -584,7 +600,7 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
         { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_pids_decode(e->tb, ln.db, n, ids_dev, parity, 1, ln.main); }
         if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_px_decode(e->tb, ln.db, n, ids_dev, parity, 0, ln.main); }
         { ProfScope p(e, NRSC5HIP_PROF_P1_DEINT, ln.main); launch_p1_deint(e->tb, ln.db, n, ids_dev, parity, 0, ln.main); }
-        { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ln.main); launch_p1_forward(e->tb, ln.db, n, ids_dev, parity, 0, ln.main); }
+        { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ln.main); launch_p1_forward(e->tb, ln.db, n, ids_dev, parity, 0, ln.main, fwd_segments_for(e, ln, n), e->fwd_warm); }
         { ProfScope p(e, NRSC5HIP_PROF_P1_TRACEBACK, ln.main); launch_p1_traceback(e->tb, ln.db, n, ids_dev, parity, 0, ln.main, e->cfg.l2_feedback ? 1 : 0); }
     } else if ((ln.step_count % 16) == 15) {
         int rc = launch_window_decode(e, ln, n, ids_dev, parity, pick_decode_lane(e, ln, window)); if (rc) return rc;
@@ -1467,7 +1483,7 @@ extern "C" int nrsc5hip_stage_viterbi_k7(nrsc5hip_engine *e, const int8_t *soft,
     HIPCHK(hipMalloc((void **)&ddec, (size_t)nframes * (len + 64) * sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void **)&dout, (size_t)nframes * words * sizeof(uint32_t)));
     HIPCHK(hipMemcpy(dsoft, soft, (size_t)nframes * 3 * len, hipMemcpyHostToDevice));
-    launch_viterbi_frames(dsoft, len, nframes, ddec, dout, e->main);
+    launch_viterbi_frames(dsoft, len, nframes, ddec, dout, e->main, 3, e->fwd_segments > 0 ? e->fwd_segments : 16, e->db.fwd_stats, e->fwd_warm);
     HIPCHK(hipStreamSynchronize(e->main));
     std::vector<uint32_t> w((size_t)nframes * words);
     HIPCHK(hipMemcpy(w.data(), dout, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1612,12 +1628,13 @@ extern "C" int nrsc5hip_stage_viterbi_bench(nrsc5hip_engine *e, int len, int nfr
     HIPCHK(hipMemcpy(dsoft, h.data(), h.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemset(ddec, 0x55, (size_t)nframes * (len + 64) * sizeof(unsigned long long)));
     hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-    launch_viterbi_frames(dsoft, len, nframes, ddec, dout, e->main, phases | 1);      // warm-up; packs the soft words and leaves decisions behind
+    const int seg = e->fwd_segments > 0 ? e->fwd_segments : 1;
+    launch_viterbi_frames(dsoft, len, nframes, ddec, dout, e->main, phases | 1, seg);      // warm-up; packs the soft words and leaves decisions behind
     HIPCHK(hipEventRecord(a, e->main));
     for (int r = 0; r < reps; r++) {
         // a traceback-only measurement consumes the decisions in place: re-run the (untimed-irrelevant) forward pass is not possible
         // without timing it, so phases == 2 measures forward + traceback minus nothing -- callers subtract the forward figure
-        launch_viterbi_frames(dsoft, len, nframes, ddec, dout, e->main, ((phases & 2) ? (phases | 1) : phases) | 8);
+        launch_viterbi_frames(dsoft, len, nframes, ddec, dout, e->main, ((phases & 2) ? (phases | 1) : phases) | 8, seg);
     }
     HIPCHK(hipEventRecord(b, e->main));
     HIPCHK(hipEventSynchronize(b));
@@ -1664,6 +1681,8 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
     case NRSC5HIP_TUNE_DECODE_STREAMS:    e->naux = std::min(std::max(value, 1), NAUX); break;
     case NRSC5HIP_TUNE_AM_DECODE_STREAMS: e->naux_am = std::min(std::max(value, 1), NAUX); break;
     case NRSC5HIP_TUNE_VERDICT_LAG:       e->verdict_lag = std::min(std::max(value, 0), NWIN); break;
+    case NRSC5HIP_TUNE_FWD_SEGMENTS:      e->fwd_segments = std::min(std::max(value, 0), 16); break;
+    case NRSC5HIP_TUNE_FWD_WARM:          e->fwd_warm = value > 0 ? 2 : 0; break;
     case NRSC5HIP_TUNE_SYNC_PHASES:
         if (value && !e->db.sync_phase_cycles) {
             int rc = dev_alloc(e, &e->db.sync_phase_cycles, 8); if (rc) return rc;
@@ -1673,6 +1692,14 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
         break;
     default: FAIL(NRSC5HIP_EINVAL, "unknown knob %d", knob);
     }
+    return 0;
+}
+
+extern "C" int nrsc5hip_debug_fwd_stats(nrsc5hip_engine *e, int stats[2])
+{
+    if (!e || !stats) FAIL(NRSC5HIP_EINVAL, "null argument");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(stats, e->db.fwd_stats, 2 * sizeof(int), hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -79,7 +79,25 @@ __device__ inline int bit_errors_k7_partial(const int *soft, const uint32_t *bit
 // passes of a launch share a SIMD (with one-wave workgroups the dispatcher sometimes stacks them, and the launch lasts as long
 // as its slowest wave).
 constexpr int FWD_WAVES = 4;
-__global__ __launch_bounds__(64 * FWD_WAVES) void k_p1_forward(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id, int prio, int nstreams)
+// G segment waves per frame run concurrently (viterbi_v3.h: speculative start, verified and repaired by k_p1_fix): the launch
+// lasts 1 / G of the serial chain when the chip has the SIMDs to spare -- thin windows, the single stream, the in-order seam.
+__global__ __launch_bounds__(64 * FWD_WAVES) void k_p1_forward(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id, int prio, int nstreams, int G, int warm)
+{
+    wave_set_priority(prio);
+    const int widx = wave_uniform((int)(blockIdx.x * FWD_WAVES + (threadIdx.x >> 6)));
+    if (widx >= nstreams * G) return;                          // wave-uniform
+    const int sidx = widx / G, g = widx % G;
+    const int s = wave_uniform(stream_of(ids, sidx));
+    StreamState &st = db.state[s];
+    if (!st.p1_pending[parity]) return;                        // wave-uniform
+    const size_t slot = (size_t)lane_id * db.nstreams_alloc + s;
+    const int *soft = db.coded + slot * P1_LEN;
+    uint32_t *dec = db.dec + slot * (size_t)(2 * (P1_LEN + 64));
+    viterbi3_forward_segment(soft, P1_LEN, dec, db.fwd_meta + slot * (size_t)(VIT3_GMAX * VIT3_META), g, G, warm);
+}
+
+// one wave per frame: check the segment boundaries of k_p1_forward, re-run what the speculation got wrong, pick the end state
+__global__ __launch_bounds__(64 * FWD_WAVES) void k_p1_fix(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id, int prio, int nstreams, int G)
 {
     wave_set_priority(prio);
     const int sidx = wave_uniform((int)(blockIdx.x * FWD_WAVES + (threadIdx.x >> 6)));
@@ -87,9 +105,9 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_p1_forward(DevTables tb, Dev
     const int s = wave_uniform(stream_of(ids, sidx));
     StreamState &st = db.state[s];
     if (!st.p1_pending[parity]) return;                        // wave-uniform
-    const int *soft = db.coded + ((size_t)lane_id * db.nstreams_alloc + s) * P1_LEN;
-    uint32_t *dec = db.dec + ((size_t)lane_id * db.nstreams_alloc + s) * (size_t)(2 * (P1_LEN + 64));
-    const int endlane = viterbi3_forward(soft, P1_LEN, dec);
+    const size_t slot = (size_t)lane_id * db.nstreams_alloc + s;
+    const int endlane = viterbi3_forward_fix(db.coded + slot * P1_LEN, P1_LEN, db.dec + slot * (size_t)(2 * (P1_LEN + 64)),
+                                             db.fwd_meta + slot * (size_t)(VIT3_GMAX * VIT3_META), G, db.fwd_stats);
     if ((threadIdx.x & 63) == 0) st.p1_endlane[parity] = endlane;
 }
 
@@ -154,10 +172,12 @@ void launch_p1_deint(const DevTables &tb, const DevBuffers &db, int nstreams, co
 {
     hipLaunchKernelGGL(k_p1_deint, dim3(32, nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, lane_id);
 }
-void launch_p1_forward(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st)
+void launch_p1_forward(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st, int segments, int warm)
 {
     constexpr int prio_fwd = 0;
-    hipLaunchKernelGGL(k_p1_forward, dim3((nstreams + FWD_WAVES - 1) / FWD_WAVES), dim3(64 * FWD_WAVES), 0, st, tb, db, stream_ids, parity, lane_id, prio_fwd, nstreams);
+    const int G = vit3_segments(P1_LEN, segments);
+    hipLaunchKernelGGL(k_p1_forward, dim3((nstreams * G + FWD_WAVES - 1) / FWD_WAVES), dim3(64 * FWD_WAVES), 0, st, tb, db, stream_ids, parity, lane_id, prio_fwd, nstreams, G, warm);
+    hipLaunchKernelGGL(k_p1_fix, dim3((nstreams + FWD_WAVES - 1) / FWD_WAVES), dim3(64 * FWD_WAVES), 0, st, tb, db, stream_ids, parity, lane_id, prio_fwd, nstreams, G);
 }
 void launch_p1_traceback(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st, int l2_mode)
 {
@@ -180,10 +200,15 @@ __global__ void k_pack_soft3(const int8_t *coded, int *soft, size_t nsteps)
     if (i >= nsteps) return;
     soft[i] = (int)(uint8_t)coded[3 * i] | ((int)(uint8_t)coded[3 * i + 1] << 8) | ((int)(uint8_t)coded[3 * i + 2] << 16);
 }
-__global__ __launch_bounds__(64) void k_viterbi_frames_fwd(const int *soft, int len, uint32_t *dec, int *endlane)
+__global__ __launch_bounds__(64) void k_viterbi_frames_fwd(const int *soft, int len, uint32_t *dec, int *meta, int G, int warm)
+{
+    const int f = blockIdx.x / G, g = blockIdx.x % G;
+    viterbi3_forward_segment(soft + (size_t)f * len, len, dec + (size_t)f * 2 * (len + 64), meta + (size_t)f * VIT3_GMAX * VIT3_META, g, G, warm);
+}
+__global__ __launch_bounds__(64) void k_viterbi_frames_fix(const int *soft, int len, uint32_t *dec, int *meta, int G, int *endlane, int *stats)
 {
     const int f = blockIdx.x;
-    const int e = viterbi3_forward(soft + (size_t)f * len, len, dec + (size_t)f * 2 * (len + 64));
+    const int e = viterbi3_forward_fix(soft + (size_t)f * len, len, dec + (size_t)f * 2 * (len + 64), meta + (size_t)f * VIT3_GMAX * VIT3_META, G, stats);
     if ((threadIdx.x & 63) == 0) endlane[f] = e;
 }
 __global__ __launch_bounds__(TB_THREADS) void k_viterbi_frames_tb(uint32_t *dec, int len, const int *endlane, uint32_t *out, uint8_t *gmap)
@@ -193,12 +218,13 @@ __global__ __launch_bounds__(TB_THREADS) void k_viterbi_frames_tb(uint32_t *dec,
     viterbi3_traceback_block(dec + (size_t)f * 2 * (len + 64), len, endlane[f], out + (size_t)f * ((len + 31) / 32), gmap + (size_t)f * (len / 64 + 1) * 64, smem);
 }
 
-void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st, int phases)
+void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st, int phases, int segments, int *stats, int warm)
 {
-    if ((len & 63) == 0 && !(phases & 4)) {                    // production split: forward wave + parallel traceback (viterbi_v3.h)
+    if ((len & 63) == 0 && !(phases & 4)) {                    // production split: forward segment waves + fix + parallel traceback (viterbi_v3.h)
         static int *endlane = nullptr; static int cap = 0; static uint8_t *gmap = nullptr; static size_t gcap = 0;
-        static int *soft = nullptr; static size_t scap = 0;
+        static int *soft = nullptr; static size_t scap = 0; static int *meta = nullptr; static int mcap = 0;
         if (cap < nframes) { if (endlane) (void)hipFree(endlane); (void)hipMalloc((void **)&endlane, sizeof(int) * nframes); cap = nframes; (void)hipMemset(endlane, 0, sizeof(int) * nframes); }
+        if (mcap < nframes) { if (meta) (void)hipFree(meta); (void)hipMalloc((void **)&meta, sizeof(int) * (size_t)nframes * VIT3_GMAX * VIT3_META); mcap = nframes; }
         const size_t gneed = (size_t)nframes * (len / 64 + 1) * 64;
         if (gcap < gneed) { if (gmap) (void)hipFree(gmap); (void)hipMalloc((void **)&gmap, gneed); gcap = gneed; }
         const size_t nsteps = (size_t)nframes * len;
@@ -206,7 +232,9 @@ void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned l
         if (phases & 1) {
             if (!(phases & 8))                                 // bit 3 (micro-benchmark): the soft words of this input are packed already
                 hipLaunchKernelGGL(k_pack_soft3, dim3((unsigned)((nsteps + 255) / 256)), dim3(256), 0, st, coded, soft, nsteps);
-            hipLaunchKernelGGL(k_viterbi_frames_fwd, dim3(nframes), dim3(64), 0, st, (const int *)soft, len, (uint32_t *)dec, endlane);
+            const int G = vit3_segments(len, segments);
+            hipLaunchKernelGGL(k_viterbi_frames_fwd, dim3(nframes * G), dim3(64), 0, st, (const int *)soft, len, (uint32_t *)dec, meta, G, warm);
+            hipLaunchKernelGGL(k_viterbi_frames_fix, dim3(nframes), dim3(64), 0, st, (const int *)soft, len, (uint32_t *)dec, meta, G, endlane, stats);
         }
         if (phases & 2) hipLaunchKernelGGL(k_viterbi_frames_tb, dim3(nframes), dim3(TB_THREADS), traceback_smem(len), st, (uint32_t *)dec, len, (const int *)endlane, out, gmap);
         return;

@@ -47,6 +47,9 @@ struct DevBuffers {
     uint32_t *dec;                   // [NAUX][S][2 * (P1_LEN + 64)]  survivor decisions: per 32 steps one history word per lane (viterbi_v3.h)
     int nstreams_alloc;              // S
     uint8_t *tbmap;                  // [NAUX][S][2285 * 64]  traceback chunk maps (start lane per end lane)
+    int *fwd_meta;                   // [NAUX][S][16][512]  segmented forward pass: per segment the metric snapshot [64], end metrics [64] and the
+                                     //                     history scratch of its speculative warm-up [384] (viterbi_v3.h)
+    int *fwd_stats;                  // [2] segment boundaries checked / segments repaired since the engine was created
     uint32_t *p1_ring;               // [S][p1_slots][P1_WORDS]
     uint32_t *p1_mirror;             // same layout in pinned host memory (device-visible), written beside p1_ring by the FM traceback once
                                      // nrsc5hip_batch_fetch_view has set it up; null before
@@ -107,7 +110,8 @@ void launch_px_deint(const DevTables &tb, const DevBuffers &db, int nstreams, co
 void launch_px_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st);
 // a window's P1 decode: de-interleave -> forward trellis pass -> traceback + BER + descramble + first-header verdict (+ fused L2 index)
 void launch_p1_deint(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st);
-void launch_p1_forward(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st);
+// segments: waves per frame of the forward pass (1..16; clamped to what the frame length allows), see viterbi_v3.h
+void launch_p1_forward(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st, int segments, int warm = 2);
 void launch_p1_traceback(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st, int l2_mode = 0);
 
 // ---- AM path (k_am.hip) -------------------------------------------------------------------------
@@ -138,7 +142,7 @@ void launch_l2_index_am_window(const DevBuffers &db, int nstreams, const int *st
 void launch_l2_index_am_step(const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
 
 // ---- stage-level entry points (parity tests) ---------------------------------------------------
-void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st, int phases = 3);
+void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st, int phases = 3, int segments = 1, int *stats = nullptr, int warm = 2);
 void launch_selftest(int *fail_count, hipStream_t st);
 void launch_fft2048(const DevTables &tb, const float2 *in, float2 *out, int nffts, hipStream_t st);
 

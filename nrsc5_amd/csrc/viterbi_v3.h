@@ -193,25 +193,61 @@ __device__ __forceinline__ void vit3_word(int &u, int &hist, int &nsp, const v16
     dec_word += 64;
 }
 
-// Forward pass of one frame by one wave (len % 64 == 0).  soft: len dwords; dec: 2 * (len / 64 + 1) history words per lane,
-// word i of LOGICAL lane L at dec[64 i + L] (bit j = decision of step 32 i + j for the state that lane then held).
-// Returns the logical lane of the winning end state (wave-uniform).
-__device__ __forceinline__ int viterbi3_forward(const int *soft, int len, uint32_t *dec)
+// ---- forward pass, in SEGMENTS ------------------------------------------------------------------------------------------
+// The trellis of a frame is one serial chain of len + 64 steps (2.0 ms for a P1 frame at 13.75 ns per step, however many
+// SIMDs idle beside it).  It is cut at "trip" boundaries (3 chunks = 192 steps: the phase pattern and the register roles
+// repeat there) into G segments, one wave each, running CONCURRENTLY:
+//   * segment 0 starts from the tail-biting reset (all-zero metrics), as the reference does;
+//   * segment g > 0 starts VIT3_WARM_TRIPS trips early from all-zero metrics (a speculation: its history words go to a scratch
+//     line), snapshots its metrics where its own steps begin, then runs them for real;
+//   * every segment leaves its end metrics.
+// EXACTNESS is not left to chance: the state of the recursion is the vector of metric DIFFERENCES (the decisions of all later
+// steps are a function of them and of the input alone -- max / add / subtract only, int32 never overflows, the parity bits are
+// positional).  So segment g's decisions are the sequential decoder's iff the differences of its snapshot equal the differences
+// of segment g-1's end metrics, and g-1's are themselves right.  viterbi3_forward_fix walks that chain: a segment whose check
+// fails is run again from the true end metrics of its predecessor (sequentially, by the one fixing wave).  With decodable
+// input the survivors merge long before 384 steps and no segment is ever repaired; on pure noise or the all-erasure frame the
+// repair brings back exactly the sequential result at, in the worst case, the sequential cost.
+constexpr int VIT3_WARM_TRIPS = 2;                             // speculative warm-up of a segment: 384 steps ~ 55 constraint lengths
+constexpr int VIT3_GMAX = 16;                                  // segments per frame at most
+constexpr int VIT3_META = 128 + 384;                           // ints per segment: snapshot [64], end metrics [64], warm-up history scratch [384]
+
+__device__ __host__ inline int vit3_trips(int len) { return (len / 64 + 1) / 3; }
+// segments a frame of `len` steps can be cut into: every segment but the first needs room for its warm-up behind it
+__device__ __host__ inline int vit3_segments(int len, int want)
+{
+    const int T = vit3_trips(len);
+    int g = want < 1 ? 1 : want > VIT3_GMAX ? VIT3_GMAX : want;
+    while (g > 1 && T / g < VIT3_WARM_TRIPS + 1) g--;
+    return g;
+}
+
+// Trips [trip0, trip1) of one frame by one wave (+ the frame's last 1..2 chunks when `last`), history words into dec.
+// warm > 0: `warm` speculative trips first, from all-zero metrics, history to `scratch`, metrics then to snap[64];
+// warm == 0: start from this lane's metric u0 (end metric of the predecessor) when have_u0, else from the tail-biting reset.
+// uend[64] (may be null) receives the metrics after the last step.  Metric arrays are indexed by LOGICAL lane.  Returns u.
+__device__ __forceinline__ int viterbi3_forward_span(const int *soft, int len, uint32_t *dec, uint32_t *scratch, int trip0, int trip1, int warm,
+                                                      bool last, bool have_u0, int u0, int *snap, int *uend)
 {
     const unsigned phys = threadIdx.x & 63u, L = vit3_logical_lane(phys);
     const Vit3Const k = vit3_consts(phys);
     const int nchunks = len / 64 + 1;
-    int u = k.s0[0], hist = 0, nsp = 0;                        // reset_decoder: all-zero metrics for tail biting
-    int jn = len - VIT_EXTRA;                                  // step t reads soft[(len - 32 + t) % len] (conv_dec.c:407-412)
-    v16i a0 = vit3_load16(soft + jn), a1 = vit3_load16(soft + jn + 16), b0, b1;
-    jn = 0;
+    const int tstart = trip0 - warm;
+    int u = (have_u0 && !warm) ? u0 : k.s0[0], hist = 0, nsp = 0;  // reset_decoder: all-zero metrics for tail biting
+    int jn = (len - VIT_EXTRA + 192 * tstart) % len;           // step t reads soft[(len - 32 + t) % len] (conv_dec.c:407-412)
     // L2 warm-up: the scalar loads have one word (~900 cycles) of cover, enough for an L2 / Infinity Cache hit but not for
     // HBM; one vector load per 3 chunks touches the 768 bytes that will be needed VIT3_WARM chunks from now
-    int jw = (64 * VIT3_WARM - VIT_EXTRA) % len, warm = 0;
-    uint32_t *w = dec + L;
+    int jw = (jn + 64 * VIT3_WARM) % len, warmv = 0;
+    v16i a0 = vit3_load16(soft + jn), a1 = vit3_load16(soft + jn + 16), b0, b1;
+    jn += 32; if (jn >= len) jn -= len;
+    uint32_t *w = dec + (size_t)384 * trip0 + L;
     // 3 chunks = 192 steps = 6 history words per trip: the phase pattern (0, 2, 4, 0, 2, 4) and the roles of the two
     // soft-word register sets repeat exactly, so the loop carries no register shuffles
-    for (int it = nchunks / 3; it > 0; it--) {
+    for (int t = tstart; t < trip1; t++) {
+        if (warm) {                                            // wave-uniform
+            if (t < trip0) w = scratch + L;
+            else if (t == trip0) { snap[L] = u; w = dec + (size_t)384 * trip0 + L; }
+        }
         int jl = jw + (int)phys; if (jl >= len) jl -= len;
         const int w0 = soft[jl], w1 = soft[jl + 64 < len ? jl + 64 : jl + 64 - len], w2 = soft[jl + 128 < len ? jl + 128 : jl + 128 - len];
         jw += 192; if (jw >= len) jw -= len;
@@ -221,24 +257,78 @@ __device__ __forceinline__ int viterbi3_forward(const int *soft, int len, uint32
         vit3_word<0>(u, hist, nsp, b0, b1, a0, a1, soft, len, jn, k, w);
         vit3_word<2>(u, hist, nsp, a0, a1, b0, b1, soft, len, jn, k, w);
         vit3_word<4>(u, hist, nsp, b0, b1, a0, a1, soft, len, jn, k, w);
-        warm ^= w0 ^ w1 ^ w2;                                  // consumed at the end of the trip: their vmcnt wait is free by then
+        warmv ^= w0 ^ w1 ^ w2;                                 // consumed at the end of the trip: their vmcnt wait is free by then
     }
-    const int rest = nchunks % 3;                              // 1 or 2 chunks more (phases 0, then 4)
-    if (rest >= 1) {
-        vit3_word<0>(u, hist, nsp, a0, a1, b0, b1, soft, len, jn, k, w);
-        vit3_word<2>(u, hist, nsp, b0, b1, a0, a1, soft, len, jn, k, w);
+    if (last) {
+        const int rest = nchunks % 3;                          // 1 or 2 chunks more (phases 0, then 4)
+        if (rest >= 1) {
+            vit3_word<0>(u, hist, nsp, a0, a1, b0, b1, soft, len, jn, k, w);
+            vit3_word<2>(u, hist, nsp, b0, b1, a0, a1, soft, len, jn, k, w);
+        }
+        if (rest == 2) {
+            vit3_word<4>(u, hist, nsp, a0, a1, b0, b1, soft, len, jn, k, w);
+            vit3_word<0>(u, hist, nsp, b0, b1, a0, a1, soft, len, jn, k, w);
+        }
     }
-    if (rest == 2) {
-        vit3_word<4>(u, hist, nsp, a0, a1, b0, b1, soft, len, jn, k, w);
-        vit3_word<0>(u, hist, nsp, b0, b1, a0, a1, soft, len, jn, k, w);
-    }
-    vit3_keep(warm);
-    // end state: first maximum in STATE order (conv_dec.c:310-318); logical lane L holds state rotr6^steps(L)
+    vit3_keep(warmv);
+    if (uend) uend[L] = u;
+    return u;
+}
+
+// end state: first maximum in STATE order (conv_dec.c:310-318); logical lane L holds state rotr6^steps(L).  Returns the logical
+// lane of the winning end state (wave-uniform).
+__device__ __forceinline__ int vit3_end_lane(int u, int len)
+{
+    const unsigned L = vit3_logical_lane(threadIdx.x & 63u);
+    const int nchunks = len / 64 + 1;
     const int rend = (64 * nchunks) % 6;
     const int pm = u >> 1;
     const int best = wave_max_i32(pm);
     const int smin = wave_min_i32(pm == best ? (int)rotr6(L, rend) : 64);
     return wave_uniform((int)rotl6((unsigned)smin, rend));
+}
+
+// segment g of G of a frame: meta = the frame's VIT3_GMAX x VIT3_META ints.  warm: speculative warm-up trips of the segments
+// g > 0 (VIT3_WARM_TRIPS; the test hook passes 0: the speculation is then wrong wherever the input carries information, and every
+// segment goes through the repair)
+__device__ __forceinline__ void viterbi3_forward_segment(const int *soft, int len, uint32_t *dec, int *meta, int g, int G, int warm)
+{
+    const int T = vit3_trips(len);
+    int *m = meta + (size_t)g * VIT3_META;
+    if (g && !warm) m[vit3_logical_lane(threadIdx.x & 63u)] = (int)(rotr6(vit3_logical_lane(threadIdx.x & 63u), 0) & 1u);   // the snapshot of a cold start: u = s0
+    viterbi3_forward_span(soft, len, dec, (uint32_t *)(m + 128), g * T / G, (g + 1) * T / G, g ? warm : 0, g == G - 1, false, 0, m, m + 64);
+}
+
+// One wave per frame, after all G segment waves are done: verify the chain of segment boundaries, repair what the speculation got
+// wrong, return the logical lane of the winning end state.  stats (may be null): [0] boundaries checked, [1] segments repaired.
+__device__ __forceinline__ int viterbi3_forward_fix(const int *soft, int len, uint32_t *dec, int *meta, int G, int *stats)
+{
+    const unsigned L = vit3_logical_lane(threadIdx.x & 63u);
+    const int T = vit3_trips(len);
+    int repaired = 0;
+    int ue = meta[64 + L];                                     // true end metrics of the segment before the boundary (segment 0: by construction)
+    for (int g = 1; g < G; g++) {
+        int *m = meta + (size_t)g * VIT3_META;
+        const int sn = m[L];
+        const int d = (ue - wave_uniform(ue)) - (sn - wave_uniform(sn));
+        if (wave_max_i32(d < 0 ? -d : d) != 0) {              // wave-uniform
+            ue = viterbi3_forward_span(soft, len, dec, nullptr, g * T / G, (g + 1) * T / G, 0, g == G - 1, true, ue, nullptr, m + 64);
+            repaired++;
+        } else {
+            ue = m[64 + L];
+        }
+    }
+    if (stats && (threadIdx.x & 63) == 0) { atomicAdd(&stats[0], G - 1); if (repaired) atomicAdd(&stats[1], repaired); }
+    return vit3_end_lane(ue, len);
+}
+
+// Forward pass of one frame by ONE wave, start to end (len % 64 == 0).  soft: len dwords; dec: 2 * (len / 64 + 1) history
+// words per lane, word i of LOGICAL lane L at dec[64 i + L] (bit j = decision of step 32 i + j for the state that lane then
+// held).  Returns the logical lane of the winning end state (wave-uniform).
+__device__ __forceinline__ int viterbi3_forward(const int *soft, int len, uint32_t *dec)
+{
+    const int u = viterbi3_forward_span(soft, len, dec, nullptr, 0, vit3_trips(len), 0, true, false, 0, nullptr, nullptr);
+    return vit3_end_lane(u, len);
 }
 
 // h <<= 1, returning the mask of the lanes whose bit 31 was set: v_add_co_u32's carry-out IS that ballot

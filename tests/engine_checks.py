@@ -913,3 +913,34 @@ def check_block_exact_pushes(lib, oracle, am=False):
         diffs = [d for d in diffs if not any(d.startswith(f"#{i} ber") or d.startswith(f"#{i + 1} frame") for i in bad)]
         assert not diffs, diffs[:8]
         E.close()
+
+
+def check_viterbi_segmented(lib, oracle, lens=(2304, 4608), segments=(1, 2, 4, 16), seed=12):
+    """Segmented forward pass (viterbi_v3.h): any number of segment waves gives the sequential decoder's bits -- on noise, on
+    decodable frames, on the all-erasure frame (every ACS a tie) and on saturated input; and again with the warm-up of the
+    segments switched off (test hook), when every speculative start on informative input is wrong and the segments must be
+    REPAIRED (counted by the engine): the repair path, not luck, is what makes the result exact."""
+    rng = np.random.default_rng(seed)
+    E = eng.Engine(max_streams=1, q15_capacity=2 * 71280, lib_path=lib)
+    for L in lens:
+        soft = rng.integers(-127, 128, size=(5, 3 * L), dtype=np.int8)
+        soft[0] = 0
+        soft[1, :] = 127
+        msg = rng.integers(0, 2, size=(1, L), dtype=np.uint8)
+        coded = synth.conv_encode_k7(msg).reshape(3 * L).astype(np.int16) * 2 - 1
+        soft[2] = np.clip(np.rint(coded * 40 + rng.normal(0, 14, size=coded.shape)), -127, 127).astype(np.int8)
+        soft[:, 5::6] = 0
+        exp = np.stack([oracle.viterbi_k7(s) for s in soft])
+        for warm in (1, 0):
+            E.tune(eng.TUNE_FWD_WARM, warm)
+            for G in segments:
+                E.tune(eng.TUNE_FWD_SEGMENTS, G)
+                c0, r0 = E.fwd_stats()
+                got = E.stage_viterbi_k7(soft, L)
+                c1, r1 = E.fwd_stats()
+                assert np.array_equal(got, exp), f"segmented Viterbi mismatch at len {L}, {G} segments, warm {warm}"
+                if G > 1 and L >= 4608:
+                    assert c1 > c0
+                    if not warm:
+                        assert r1 - r0 >= 3, (L, G, c1 - c0, r1 - r0)     # cold starts on informative frames were repaired, not trusted
+    E.close()

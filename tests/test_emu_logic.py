@@ -175,3 +175,7 @@ def test_emu_frame_push_indexed_with_device_index(emu_lib, reflib):
 
 def test_emu_block_exact_pushes(emu_lib, oracle):
     ec.check_block_exact_pushes(emu_lib, oracle)
+
+
+def test_emu_viterbi_segmented(emu_lib, oracle):
+    ec.check_viterbi_segmented(emu_lib, oracle, lens=(4608,), segments=(1, 3, 8))

@@ -336,3 +336,7 @@ def test_gpu_hdc_consumer_equals_reference_events(hip_lib, reflib, p1_async):
 @pytest.mark.parametrize("am", [False, True])
 def test_gpu_block_exact_pushes(hip_lib, oracle, am):
     ec.check_block_exact_pushes(hip_lib, oracle, am=am)
+
+
+def test_gpu_viterbi_segmented_exact(hip_lib, oracle):
+    ec.check_viterbi_segmented(hip_lib, oracle, lens=(2304, 4608, 146176), segments=(1, 2, 5, 16))
