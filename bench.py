@@ -696,6 +696,8 @@ def dropin_leg(iq: np.ndarray, fs: float):
     if not all(os.path.exists(p) for p in paths.values()):
         return {"skipped": "integration/_build/libnrsc5_hipdropin.so or oracle/_ref/libnrsc5_plain.so not prebuilt (need /root/reference in the build container)"}
     out, logs = {"feed": "nrsc5_pipe_samples_cu8, 32768-byte calls (src/main.c:1095-1121)", "seconds_of_signal": round(iq.size / 2 / fs, 2)}, {}
+    from nrsc5_amd import engine as eng
+    hip = eng.load_library()                                 # the same loaded libnrsc5hip.so the drop-in is linked with
     for name, path in paths.items():
         lib = ctypes.CDLL(path)
         lib.pipe_run.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
@@ -704,12 +706,23 @@ def dropin_leg(iq: np.ndarray, fs: float):
         best, wall = None, None
         for rep in range(3 if name == "dropin" else 2):
             p = ctypes.c_void_p()
+            hip.nrsc5hip_debug_seam_totals(None, 1)
             t0 = time.perf_counter()
             n = lib.pipe_run(iq.ctypes.data, iq.size, 32768, 0, 0, ctypes.byref(p))
             w = time.perf_counter() - t0
             f = float(lib.pipe_last_feed_seconds())
             if best is None or f < best:
                 best, wall = f, w
+                if name == "dropin":
+                    tot = (ctypes.c_double * 8)()
+                    hip.nrsc5hip_debug_seam_totals(tot, 0)
+                    blocks = max(tot[6], 1.0)
+                    out["breakdown"] = {"blocks": int(tot[6]), "pushes": int(tot[4]), "submissions_h2d_plus_decimator": int(tot[5]),
+                                        "us_per_block": {"host_copy_into_pinned_staging": round(tot[0] / blocks * 1e6, 1), "host_enqueue_h2d_and_decimator": round(tot[1] / blocks * 1e6, 1),
+                                                         "host_enqueue_block_step": round(tot[2] / blocks * 1e6, 1), "wait_for_device_one_sync_per_block": round(tot[3] / blocks * 1e6, 1),
+                                                         "fetch_p1_frames": round(tot[7] / blocks * 1e6, 1),
+                                                         "reference_host_code_L2_and_callbacks_and_rest": round((f - tot[0] - tot[1] - tot[2] - tot[3] - tot[7]) / blocks * 1e6, 1)},
+                                        "total_us_per_block": round(f / blocks * 1e6, 1)}
         logs[name] = ref.parse_log(ctypes.string_at(p, n))
         out[name] = {"feed_seconds": round(best, 4), "x_realtime": round(iq.size / 2 / fs / best, 1), "wall_seconds_incl_open_close": round(wall, 3)}
     exp, got = logs["plain"], logs["dropin"]

@@ -325,6 +325,10 @@ enum {
     , NRSC5HIP_TUNE_FWD_WARM               /* TEST HOOK: 0 = the segments start cold (no speculative warm-up), so that the speculation fails wherever the
                                             input carries information and every segment takes the repair path; 1 = normal */
 };
+/* process-wide wall-clock totals of the streaming seam with p1_async = 0 (what the drop-in uses): [0] s copying pushes into pinned
+ * staging, [1] s enqueueing H2D + decimator, [2] s enqueueing block steps, [3] s waiting for the device (one sync per block),
+ * [4] pushes, [5] submissions, [6] block steps, [7] s fetching P1 frames */
+void nrsc5hip_debug_seam_totals(double out[8], int reset);
 /* segmented forward pass: segment boundaries checked / segments that had to be re-run since the engine was created */
 int nrsc5hip_debug_fwd_stats(nrsc5hip_engine *e, int stats[2]);
 int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value);

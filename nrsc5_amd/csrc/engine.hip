@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <chrono>
 #include <deque>
 #include <new>
 #include <vector>
@@ -20,6 +21,19 @@ static_assert(sizeof(nrsc5hip_record) == sizeof(BlockRecord), "record ABI mismat
 static_assert(sizeof(BlockRecord) % 8 == 0, "record alignment");
 
 static thread_local char g_err[512] = "";
+
+// process-wide wall-clock totals of the fast streaming seam (nrsc5hip_debug_seam_totals): where a drop-in session's time goes
+static double g_seam[8];   // [0] s copying pushes into pinned staging, [1] s enqueueing H2D + decimator, [2] s enqueueing block steps,
+                           // [3] s waiting for the device (the one sync per block), [4] pushes, [5] submissions, [6] block steps, [7] s in drain / frame fetches
+struct SeamClock {
+    int slot; std::chrono::steady_clock::time_point t0;
+    explicit SeamClock(int s) : slot(s), t0(std::chrono::steady_clock::now()) {}
+    ~SeamClock() { g_seam[slot] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+extern "C" void nrsc5hip_debug_seam_totals(double out[8], int reset)
+{
+    for (int k = 0; k < 8; k++) { if (out) out[k] = g_seam[k]; if (reset) g_seam[k] = 0; }
+}
 extern "C" const char *nrsc5hip_last_error(void) { return g_err; }
 
 #define HIPCHK(expr)                                                                                   \
@@ -827,6 +841,7 @@ static int stream_steps(nrsc5hip_engine *e, int s)
     ln.prepared_by_sync = false;
     int guard = 0;
     while (e->wr_host[s] - e->rd_host[s] >= window_of(e, s)) {
+        auto t_enq = std::chrono::steady_clock::now();
         HIPCHK(hipMemsetAsync(ln.counters_dev, 0, 4 * sizeof(int), ln.main));
         if (am) {
             ProfScope p(e, NRSC5HIP_PROF_AM, ln.main);
@@ -837,7 +852,11 @@ static int stream_steps(nrsc5hip_engine *e, int s)
         }
         hipLaunchKernelGGL(k_stream_report, dim3(1), dim3(128), 0, ln.main, ln.db, s, e->fetched[s], e->report_dev);
         HIPCHK(hipGetLastError());
+        auto t_wait = std::chrono::steady_clock::now();
         HIPCHK(hipStreamSynchronize(ln.main));
+        g_seam[2] += std::chrono::duration<double>(t_wait - t_enq).count();
+        g_seam[3] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count();
+        g_seam[6] += 1;
         const nrsc5hip_engine::StreamReport &rp = *e->report_host;
         ln.acq_needed = rp.counters[1] > 0;
         ln.px_needed = rp.counters[2] > 0;
@@ -871,6 +890,7 @@ static int flush_staged(nrsc5hip_engine *e)
 {
     const int s = e->staged_stream;
     if (s < 0 || e->staged_bytes == 0) { e->staged_stream = -1; return 0; }
+    SeamClock clk(1); g_seam[5] += 1;
     const int slot = e->stage_slot;
     const bool cu8 = e->staged_cu8, am = e->mode_host[s] == MODE_AM;
     const size_t chunk = e->staged_bytes;
@@ -908,7 +928,8 @@ static int push_common(nrsc5hip_engine *e, int s, const void *host, size_t nbyte
             const size_t chunk = nbytes_total > room ? room : nbytes_total;
             long long nq15 = (long long)chunk / 4;
             if (am && cu8) nq15 = (e->raw_host[s] + (long long)chunk / 2) / 32 - e->raw_host[s] / 32;
-            memcpy(e->stage_pin[slot] + 16 + e->staged_bytes, src, chunk);
+            { SeamClock clk(0); memcpy(e->stage_pin[slot] + 16 + e->staged_bytes, src, chunk); }
+            g_seam[4] += 1;
             e->staged_stream = s; e->staged_cu8 = cu8; e->staged_bytes += chunk; e->staged_q15 += nq15;
             e->wr_host[s] += nq15;
             if (am && cu8) e->raw_host[s] += (long long)chunk / 2;
@@ -1227,6 +1248,7 @@ extern "C" int nrsc5hip_drain(nrsc5hip_engine *e, int stream, nrsc5hip_record *o
 
 extern "C" int nrsc5hip_p1_frame_packed(nrsc5hip_engine *e, int stream, int slot, uint32_t *words)
 {
+    SeamClock clk(7);
     int rc = check_stream(e, stream); if (rc) return rc;
     if (slot < 0 || slot >= e->db.p1_slots || !words) FAIL(NRSC5HIP_EINVAL, "bad slot/argument");
     HIPCHK(hipStreamSynchronize(e->main));

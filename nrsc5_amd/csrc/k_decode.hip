@@ -160,7 +160,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBu
     }
 }
 
-static size_t traceback_smem(int len) { const int nchunks = len / 64 + 1; return (size_t)((nchunks + TB_SEG - 1) / TB_SEG) * 64 + nchunks; }
+static size_t traceback_smem(int len) { return vit3_traceback_smem(len); }
 
 // The three stages of a window's P1 decode, launched back to back on the window's decode stream (separate entry points so that
 // the engine can time the trellis pass -- the dominant kernel of the whole path -- on its own).

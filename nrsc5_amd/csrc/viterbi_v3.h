@@ -331,62 +331,96 @@ __device__ __forceinline__ int viterbi3_forward(const int *soft, int len, uint32
     return vit3_end_lane(u, len);
 }
 
-// h <<= 1, returning the mask of the lanes whose bit 31 was set: v_add_co_u32's carry-out IS that ballot
-__device__ __forceinline__ unsigned long long vit3_shift_out(unsigned &h)
+// ---- block-parallel traceback ---------------------------------------------------------------------------------------------
+// value of `v` in lane (l4 >> 2): ds_bpermute_b32 (the LDS crossbar; no LDS storage involved)
+__device__ __forceinline__ unsigned vit3_fetch_lane(unsigned l4, unsigned v)
 {
 #ifdef HIPEMU
-    const unsigned long long w = __ballot((int)h < 0);
-    h <<= 1;
-    return w;
+    return (unsigned)__shfl((int)v, (int)(l4 >> 2));
 #else
-    unsigned long long w;
-    unsigned hn;
-    // gfx940-class hazard: VALU writes an SGPR -> VALU reads it as a constant needs 2 wait states, and the compiler
-    // cannot see that this asm is such a writer
-    asm("v_add_co_u32 %0, %1, %2, %2\n\ts_nop 1" : "=v"(hn), "=s"(w) : "v"(h));
-    h = hn;
-    return w;
+    return (unsigned)__builtin_amdgcn_ds_bpermute((int)l4, (int)v);
 #endif
 }
 
-// 64 steps of traceback for ALL 64 candidate end lanes of a chunk at once (lane = candidate, logical numbering):
-// d = decision of the candidate's lane; the bit emitted at a step is bit R of the lane; then bit R <- d, which is the
-// lane that held the surviving predecessor 2b + d (its state's bit 0 is lane bit R in this phase).
-template <int PH0, int S> struct Vit3Map {
-    static __device__ __forceinline__ void run(unsigned &l, unsigned &h0, unsigned &h1, unsigned &ohi, unsigned &olo)
+// 64 steps of traceback for ALL 64 candidate end lanes of a chunk at once (lane = candidate, logical numbering), two independent
+// chunks per call so that the two dependency chains hide each other's crossbar latency.  Per step and chunk: the candidate sits
+// in lane l; d = the decision that lane took at this step = bit (S & 31) of ITS history word (ds_bpermute + v_bfe); then bit R of
+// l <- d: that is the lane that held the surviving predecessor 2b + d (its state's bit 0 is lane bit R in this phase).
+// l4 = l << 2, the byte address form ds_bpermute wants.  acc collects the d of 32 steps.  Four VALU + one LDS-crossbar
+// instruction per step and chunk (the second generation: 7.7 VALU + a VALU->SGPR hazard stall).
+template <int PHA, int PHB, int S> struct Vit3Map2 {
+    static __device__ __forceinline__ void run(unsigned &la, unsigned h0a, unsigned h1a, unsigned &ahia, unsigned &aloa,
+                                               unsigned &lb, unsigned h0b, unsigned h1b, unsigned &ahib, unsigned &alob)
     {
-        constexpr int R = (PH0 + S) % 6;
-        const unsigned long long w = vit3_shift_out(S >= 32 ? h1 : h0);
-        const unsigned d = (unsigned)(w >> l) & 1u;
-        if (S >= 32) ohi = (ohi << 1) | ((l >> R) & 1u); else olo = (olo << 1) | ((l >> R) & 1u);
-        l = (l & ~(1u << R)) | (d << R);
-        Vit3Map<PH0, S - 1>::run(l, h0, h1, ohi, olo);
+        constexpr int RA = (PHA + S) % 6, RB = (PHB + S) % 6;
+        const unsigned va = vit3_fetch_lane(la, S >= 32 ? h1a : h0a), vb = vit3_fetch_lane(lb, S >= 32 ? h1b : h0b);
+        const unsigned da = (va >> (S & 31)) & 1u, db = (vb >> (S & 31)) & 1u;
+        if (S >= 32) { ahia = (ahia << 1) | da; ahib = (ahib << 1) | db; } else { aloa = (aloa << 1) | da; alob = (alob << 1) | db; }
+        la = (la & ~(4u << RA)) | (da << (RA + 2));
+        lb = (lb & ~(4u << RB)) | (db << (RB + 2));
+        Vit3Map2<PHA, PHB, S - 1>::run(la, h0a, h1a, ahia, aloa, lb, h0b, h1b, ahib, alob);
     }
 };
-template <int PH0> struct Vit3Map<PH0, -1> {
-    static __device__ __forceinline__ void run(unsigned &, unsigned &, unsigned &, unsigned &, unsigned &) {}
+template <int PHA, int PHB> struct Vit3Map2<PHA, PHB, -1> {
+    static __device__ __forceinline__ void run(unsigned &, unsigned, unsigned, unsigned &, unsigned &, unsigned &, unsigned, unsigned, unsigned &, unsigned &) {}
 };
 
-// Block-parallel traceback over the history words of viterbi3_forward (blockDim.x a multiple of 64); same five passes
-// and LDS budget as viterbi_fast_traceback_block: chunk maps for all 64 candidate end lanes, segmented composition,
-// candidate outputs written in place over the chunk's history words.
+// The decoded bit of a step is the state bit the step shifts out; in this shift-register trellis that is the decision taken SIX
+// steps later on the same path (K - 1 = 6 state bits), and for the last six steps of a chunk it is a bit of the candidate's end
+// lane itself.  So the 64 output bits of a candidate are its 64 decisions shifted by six, topped up from the lane index:
+// out bit S = d[S + 6] (S <= 57), = bit (PH + S) % 6 of the end lane (S >= 58).  PH = phase of the chunk's first step.
+template <int PH>
+__device__ __forceinline__ void vit3_outputs(unsigned lane, unsigned ahi, unsigned alo, unsigned &ohi, unsigned &olo)
+{
+    unsigned top = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) top |= ((lane >> ((PH + 58 + k) % 6)) & 1u) << k;
+    ohi = (ahi >> 6) | (top << 26);
+    olo = (alo >> 6) | (ahi << 26);
+}
+
+__device__ __host__ inline size_t vit3_traceback_smem(int len)
+{
+    const int nchunks = len / 64 + 1, nseg = (nchunks + TB_SEG - 1) / TB_SEG;
+    return (size_t)nseg * 64 + (size_t)nchunks;
+}
+
+// Block-parallel traceback over the history words of the forward pass (blockDim.x a multiple of 64):
+//   1  chunk maps AND the 64 output bits of all 64 candidate end lanes (two chunks per wave at a time); the candidate outputs
+//      replace the chunk's history words in place                                           -> gmap[c][64], dec
+//   2  per segment of TB_SEG chunks: composition of its maps, all 64 candidates             -> segmap[sg][64]
+//   3  the true end lane of every segment, last to first (one thread)
+//   4  per segment: the chosen end lane of each of its chunks (one thread per segment)      -> chosen[c]
+//   5  per chunk: the output words of its chosen candidate
+// (Keeping all chunk maps of a frame in LDS -- 146 KB -- was measured: the composition gets faster, but a workgroup that owns a
+// CU's LDS keeps the block-step kernels off that CU and the whole pass loses 20 %: profiles/r03_traceback_variants.txt.)
 __device__ inline void viterbi3_traceback_block(uint32_t *dec, int len, int endlane, uint32_t *out, uint8_t *gmap, uint8_t *smem)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     const int nchunks = len / 64 + 1, nseg = (nchunks + TB_SEG - 1) / TB_SEG;
     uint8_t *segmap = smem, *chosen = smem + (size_t)nseg * 64;
     __shared__ uint8_t segend[64];                             // end lane of each segment (nseg <= 64: len <= 524224)
-    for (int c = wave; c < nchunks; c += nwaves) {
-        unsigned h0 = dec[(size_t)(2 * c) * 64 + lane], h1 = dec[(size_t)(2 * c + 1) * 64 + lane];
-        unsigned l = (unsigned)lane, ohi = 0, olo = 0;
-        switch (c % 3) {
-        case 0: Vit3Map<0, 63>::run(l, h0, h1, ohi, olo); break;
-        case 1: Vit3Map<4, 63>::run(l, h0, h1, ohi, olo); break;
-        default: Vit3Map<2, 63>::run(l, h0, h1, ohi, olo); break;
+    // pass 1: a wave takes chunks in adjacent pairs; the phase of a chunk's first step is (64 c) % 6 = 0, 4, 2 for c % 3 = 0, 1, 2
+    for (int ca = 2 * wave; ca < nchunks; ca += 2 * nwaves) {
+        const int cb = ca + 1;
+        const bool two = cb < nchunks;
+        const unsigned h0a = dec[(size_t)(2 * ca) * 64 + lane], h1a = dec[(size_t)(2 * ca + 1) * 64 + lane];
+        const unsigned h0b = two ? dec[(size_t)(2 * cb) * 64 + lane] : 0u, h1b = two ? dec[(size_t)(2 * cb + 1) * 64 + lane] : 0u;
+        unsigned la = (unsigned)lane << 2, lb = la, ahia = 0, aloa = 0, ahib = 0, alob = 0, ohia, oloa, ohib, olob;
+        switch (ca % 3) {                                       // wave-uniform
+        case 0: Vit3Map2<0, 4, 63>::run(la, h0a, h1a, ahia, aloa, lb, h0b, h1b, ahib, alob);
+                vit3_outputs<0>((unsigned)lane, ahia, aloa, ohia, oloa); vit3_outputs<4>((unsigned)lane, ahib, alob, ohib, olob); break;
+        case 1: Vit3Map2<4, 2, 63>::run(la, h0a, h1a, ahia, aloa, lb, h0b, h1b, ahib, alob);
+                vit3_outputs<4>((unsigned)lane, ahia, aloa, ohia, oloa); vit3_outputs<2>((unsigned)lane, ahib, alob, ohib, olob); break;
+        default: Vit3Map2<2, 0, 63>::run(la, h0a, h1a, ahia, aloa, lb, h0b, h1b, ahib, alob);
+                vit3_outputs<2>((unsigned)lane, ahia, aloa, ohia, oloa); vit3_outputs<0>((unsigned)lane, ahib, alob, ohib, olob); break;
         }
-        gmap[64 * c + lane] = (uint8_t)l;
-        dec[(size_t)(2 * c) * 64 + lane] = olo;
-        dec[(size_t)(2 * c + 1) * 64 + lane] = ohi;
+        gmap[64 * ca + lane] = (uint8_t)(la >> 2);
+        dec[(size_t)(2 * ca) * 64 + lane] = oloa; dec[(size_t)(2 * ca + 1) * 64 + lane] = ohia;
+        if (two) {
+            gmap[64 * cb + lane] = (uint8_t)(lb >> 2);
+            dec[(size_t)(2 * cb) * 64 + lane] = olob; dec[(size_t)(2 * cb + 1) * 64 + lane] = ohib;
+        }
     }
     __threadfence_block();
     __syncthreads();
