@@ -813,6 +813,8 @@ def main():
     rank, world, local = shard.init_from_env(expect_world=args.gpus)
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    from nrsc5_amd import engine as _eng
+    _eng.check_fresh()                                           # never measure a library that was built from other sources
 
     my_streams = my_stream_ids(args, world, rank)
     t_gen = time.perf_counter()

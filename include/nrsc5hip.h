@@ -131,6 +131,9 @@ typedef struct nrsc5hip_engine nrsc5hip_engine;
 int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engine **out);
 void nrsc5hip_engine_destroy(nrsc5hip_engine *e);
 const char *nrsc5hip_last_error(void);
+/* fingerprint of the device sources this library was built from (nrsc5_amd/build.py: source_sha) -- measurements are only taken
+ * with a library that matches the tree */
+const char *nrsc5hip_source_sha(void);
 /* hipStream_t the engine launches on, as void* (so that callers can order their own work) */
 void *nrsc5hip_engine_hip_stream(nrsc5hip_engine *e);
 

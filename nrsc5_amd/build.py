@@ -45,6 +45,7 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     if force or _stale(LIB, _deps()):
         srcs = [os.path.join(CSRC, f) for f in HIP_SOURCES if os.path.exists(os.path.join(CSRC, f))]
         cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+               '-DNRSC5HIP_SOURCE_SHA="%s"' % source_sha(),        # nrsc5hip_source_sha(): callers can tell a stale build from the tree they run in
                "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", LIB] + srcs
         if verbose:
             print(" ".join(cmd))
@@ -57,7 +58,7 @@ def build_emu(force: bool = False) -> str:
     deps = _deps() + [os.path.join(simt, "hipemu.h"), os.path.join(simt, "hipemu.cpp")]
     if force or _stale(EMU_LIB, deps):
         srcs = [os.path.join(CSRC, f) for f in HIP_SOURCES if os.path.exists(os.path.join(CSRC, f))]
-        cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-w",
+        cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-w", '-DNRSC5HIP_SOURCE_SHA="%s"' % source_sha(),
                "-I" + simt, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", EMU_LIB,
                os.path.join(simt, "hipemu.cpp")]
         for s in srcs:

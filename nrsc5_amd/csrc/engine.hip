@@ -35,6 +35,10 @@ extern "C" void nrsc5hip_debug_seam_totals(double out[8], int reset)
     for (int k = 0; k < 8; k++) { if (out) out[k] = g_seam[k]; if (reset) g_seam[k] = 0; }
 }
 extern "C" const char *nrsc5hip_last_error(void) { return g_err; }
+#ifndef NRSC5HIP_SOURCE_SHA
+#define NRSC5HIP_SOURCE_SHA "unknown"
+#endif
+extern "C" const char *nrsc5hip_source_sha(void) { return NRSC5HIP_SOURCE_SHA; }
 
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \

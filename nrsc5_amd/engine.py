@@ -93,6 +93,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.nrsc5hip_engine_destroy.argtypes = [vp]
     lib.nrsc5hip_engine_destroy.restype = None
     lib.nrsc5hip_last_error.restype = ctypes.c_char_p
+    lib.nrsc5hip_source_sha.restype = ctypes.c_char_p
     lib.nrsc5hip_engine_hip_stream.argtypes = [vp]
     lib.nrsc5hip_engine_hip_stream.restype = vp
     lib.nrsc5hip_push_cu8.argtypes = [vp, ci, vp, ctypes.c_uint32]
@@ -154,7 +155,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
 
 
 EXPORTED_SYMBOLS = [
-    "nrsc5hip_engine_create", "nrsc5hip_engine_destroy", "nrsc5hip_last_error", "nrsc5hip_engine_hip_stream",
+    "nrsc5hip_engine_create", "nrsc5hip_engine_destroy", "nrsc5hip_last_error", "nrsc5hip_source_sha", "nrsc5hip_engine_hip_stream",
     "nrsc5hip_push_cu8", "nrsc5hip_push_cs16", "nrsc5hip_stream_reset", "nrsc5hip_force_resync", "nrsc5hip_bytes_to_next_block",
     "nrsc5hip_batch_append_cu8", "nrsc5hip_batch_append_cs16", "nrsc5hip_batch_process", "nrsc5hip_drain",
     "nrsc5hip_p1_frame_packed", "nrsc5hip_p1_frame_bits", "nrsc5hip_batch_fetch", "nrsc5hip_unpack_bits",
@@ -165,6 +166,15 @@ EXPORTED_SYMBOLS = [
     "nrsc5hip_l2_index", "nrsc5hip_stage_l2_index", "nrsc5hip_l2_frame_get", "nrsc5hip_batch_fetch_l2",
     "nrsc5hip_hdc_create", "nrsc5hip_hdc_destroy", "nrsc5hip_hdc_reset", "nrsc5hip_hdc_push_frame", "nrsc5hip_hdc_advance",
     "nrsc5hip_hdc_adts", "nrsc5hip_hdc_host_bytes", "nrsc5hip_hdc_fixed_audio_end", "nrsc5hip_l2_apply_audio_end", "nrsc5hip_hdc_frame_reset"]
+
+
+def check_fresh(path: str | None = None):
+    """Raise unless the library was built from the device sources of THIS tree (a stale .so silently measures / tests old code)."""
+    from . import build
+    got = load_library(path).nrsc5hip_source_sha().decode()
+    want = build.source_sha()
+    if got != want:
+        raise Nrsc5HipError(f"{path or DEFAULT_LIB} was built from other sources (library {got}, tree {want}): run `python -m nrsc5_amd.build`")
 
 
 def unpack_bits(words: np.ndarray, nbits: int) -> np.ndarray:

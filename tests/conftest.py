@@ -41,6 +41,11 @@ def hip_lib():
     """The real gfx950 library; GPU tests must run THIS, so a missing build is an error."""
     from nrsc5_amd import build, engine
     build.build_hip()                                          # rebuilds only when a source is newer than the library
+    try:
+        engine.check_fresh()
+    except engine.Nrsc5HipError:                               # same mtimes, other content (a checkout): rebuild
+        build.build_hip(force=True)
+        engine.check_fresh()
     return engine.DEFAULT_LIB
 
 
