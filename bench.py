@@ -732,7 +732,7 @@ def dropin_leg(iq: np.ndarray, fs: float):
             if k == "hdc":
                 same = same and a["program"] == b["program"] and a["flags"] == b["flags"] and a["data"] == b["data"]
             elif k in ("sync", "mer", "ber"):
-                same = same and all(abs(a[f] - b[f]) <= max(common.FLOAT_RTOL * max(1.0, abs(a[f])), common.EITHER_ABS.get(f, 0.0)) for f in a)
+                same = same and all(common.float_close(f, float(a[f]), float(b[f])) for f in a)
     out["events"] = len(exp); out["hdc_packets"] = sum(k == "hdc" for k, _ in exp); out["events_equal"] = bool(same)
     out["speedup_vs_plain"] = round(out["plain"]["feed_seconds"] / out["dropin"]["feed_seconds"], 2)
     if not same:

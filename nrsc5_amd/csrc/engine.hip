@@ -578,7 +578,7 @@ static int launch_window_decode(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, i
     if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_px_decode(e->tb, ln.db, n, ids_dev, parity, lane, ax); }
     { ProfScope p(e, NRSC5HIP_PROF_P1_DEINT, ax); launch_p1_deint(e->tb, ln.db, n, ids_dev, parity, lane, ax); }
     { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ax); launch_p1_forward(e->tb, ln.db, n, ids_dev, parity, lane, ax, fwd_segments_for(e, ln, n), e->fwd_warm); }
-    { ProfScope p(e, NRSC5HIP_PROF_P1_TRACEBACK, ax); launch_p1_traceback(e->tb, ln.db, n, ids_dev, parity, lane, ax, e->cfg.l2_feedback ? 2 : 0); }
+    { ProfScope p(e, NRSC5HIP_PROF_P1_TRACEBACK, ax); launch_p1_traceback(e->tb, ln.db, n, ids_dev, parity, lane, ax, e->cfg.l2_feedback ? 2 : 0, fwd_segments_for(e, ln, n)); }
     HIPCHK(hipEventRecord(ln.ev_decoded[parity], ax));
     ln.decoded_pending[parity] = true;
     ln.lane_parity[lane] = parity;
@@ -619,7 +619,7 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
         if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_px_decode(e->tb, ln.db, n, ids_dev, parity, 0, ln.main); }
         { ProfScope p(e, NRSC5HIP_PROF_P1_DEINT, ln.main); launch_p1_deint(e->tb, ln.db, n, ids_dev, parity, 0, ln.main); }
         { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ln.main); launch_p1_forward(e->tb, ln.db, n, ids_dev, parity, 0, ln.main, fwd_segments_for(e, ln, n), e->fwd_warm); }
-        { ProfScope p(e, NRSC5HIP_PROF_P1_TRACEBACK, ln.main); launch_p1_traceback(e->tb, ln.db, n, ids_dev, parity, 0, ln.main, e->cfg.l2_feedback ? 1 : 0); }
+        { ProfScope p(e, NRSC5HIP_PROF_P1_TRACEBACK, ln.main); launch_p1_traceback(e->tb, ln.db, n, ids_dev, parity, 0, ln.main, e->cfg.l2_feedback ? 1 : 0, fwd_segments_for(e, ln, n)); }
     } else if ((ln.step_count % 16) == 15) {
         int rc = launch_window_decode(e, ln, n, ids_dev, parity, pick_decode_lane(e, ln, window)); if (rc) return rc;
     }

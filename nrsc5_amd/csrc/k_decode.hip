@@ -112,8 +112,21 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void k_p1_fix(DevTables tb, DevBuff
 }
 
 constexpr int TB_THREADS = 1024;
+constexpr int TBM_WAVES = 4;
 
-__global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id, int l2_mode, int prio)
+// pass 1 of the traceback (chunk maps + candidate outputs) as its own launch: `parts` workgroups of 4 waves per frame
+__global__ __launch_bounds__(64 * TBM_WAVES) void k_p1_tbmap(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id, int prio, int parts)
+{
+    wave_set_priority(prio);
+    const int s = stream_of(ids, blockIdx.y);
+    StreamState &st = db.state[s];
+    if (!st.p1_pending[parity]) return;                        // block-uniform
+    const size_t slot = (size_t)lane_id * db.nstreams_alloc + s;
+    viterbi3_traceback_maps(db.dec + slot * (size_t)(2 * (P1_LEN + 64)), P1_LEN, db.tbmap + slot * ((size_t)(P1_LEN / 64 + 1) * 64),
+                            (int)(blockIdx.x * TBM_WAVES + (threadIdx.x >> 6)), parts * TBM_WAVES);
+}
+
+__global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id, int l2_mode, int prio, int maps_done)
 {
     wave_set_priority(prio);
     const int s = stream_of(ids, blockIdx.x);
@@ -127,7 +140,7 @@ __global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBu
     uint32_t *out = db.p1_ring + ((size_t)s * db.p1_slots + st.p1_slot[parity]) * P1_WORDS;
     if (tid == 0) err_total = 0;
     uint8_t *gmap = db.tbmap + ((size_t)lane_id * db.nstreams_alloc + s) * ((size_t)(P1_LEN / 64 + 1) * 64);
-    viterbi3_traceback_block(dec, P1_LEN, st.p1_endlane[parity], out, gmap, smem);
+    viterbi3_traceback_block(dec, P1_LEN, st.p1_endlane[parity], out, gmap, smem, maps_done != 0);
     __threadfence_block();
     __syncthreads();
     const int errors = wave_sum_i32(bit_errors_k7_partial(soft, out, P1_LEN));
@@ -179,10 +192,16 @@ void launch_p1_forward(const DevTables &tb, const DevBuffers &db, int nstreams, 
     hipLaunchKernelGGL(k_p1_forward, dim3((nstreams * G + FWD_WAVES - 1) / FWD_WAVES), dim3(64 * FWD_WAVES), 0, st, tb, db, stream_ids, parity, lane_id, prio_fwd, nstreams, G, warm);
     hipLaunchKernelGGL(k_p1_fix, dim3((nstreams + FWD_WAVES - 1) / FWD_WAVES), dim3(64 * FWD_WAVES), 0, st, tb, db, stream_ids, parity, lane_id, prio_fwd, nstreams, G);
 }
-void launch_p1_traceback(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st, int l2_mode)
+void launch_p1_traceback(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st, int l2_mode, int parts)
 {
     constexpr int prio_tb = 1;
-    hipLaunchKernelGGL(k_p1_traceback, dim3(nstreams), dim3(TB_THREADS), traceback_smem(P1_LEN), st, tb, db, stream_ids, parity, lane_id, l2_mode, prio_tb);
+    // Thin windows / small stream sets (parts = 16): pass 1 of the traceback as its own launch over `parts` workgroups per frame,
+    // so that a handful of frames spread over the chip (one frame: 0.48 -> 0.11 ms).  Full windows keep it inside the 16-wave
+    // traceback workgroup: 1024 small workgroups at once crowd the block-step kernels off the SIMDs (measured: k_sync 14 -> 25 ms
+    // per pass, the pass 36 -> 50 ms; profiles/r03_traceback_variants.txt).
+    const int split = parts >= 16 ? 16 : 0;
+    if (split) hipLaunchKernelGGL(k_p1_tbmap, dim3(split, nstreams), dim3(64 * TBM_WAVES), 0, st, tb, db, stream_ids, parity, lane_id, prio_tb, split);
+    hipLaunchKernelGGL(k_p1_traceback, dim3(nstreams), dim3(TB_THREADS), traceback_smem(P1_LEN), st, tb, db, stream_ids, parity, lane_id, l2_mode, prio_tb, split ? 1 : 0);
     if (db.l2_ring) launch_l2_index_window(db, nstreams, stream_ids, parity, st);
 }
 
@@ -211,11 +230,16 @@ __global__ __launch_bounds__(64) void k_viterbi_frames_fix(const int *soft, int 
     const int e = viterbi3_forward_fix(soft + (size_t)f * len, len, dec + (size_t)f * 2 * (len + 64), meta + (size_t)f * VIT3_GMAX * VIT3_META, G, stats);
     if ((threadIdx.x & 63) == 0) endlane[f] = e;
 }
-__global__ __launch_bounds__(TB_THREADS) void k_viterbi_frames_tb(uint32_t *dec, int len, const int *endlane, uint32_t *out, uint8_t *gmap)
+__global__ __launch_bounds__(64 * TBM_WAVES) void k_viterbi_frames_tbmap(uint32_t *dec, int len, uint8_t *gmap, int parts)
+{
+    const int f = blockIdx.y;
+    viterbi3_traceback_maps(dec + (size_t)f * 2 * (len + 64), len, gmap + (size_t)f * (len / 64 + 1) * 64, (int)(blockIdx.x * TBM_WAVES + (threadIdx.x >> 6)), parts * TBM_WAVES);
+}
+__global__ __launch_bounds__(TB_THREADS) void k_viterbi_frames_tb(uint32_t *dec, int len, const int *endlane, uint32_t *out, uint8_t *gmap, int maps_done)
 {
     HIP_DYNAMIC_SHARED(uint8_t, smem)
     const int f = blockIdx.x;
-    viterbi3_traceback_block(dec + (size_t)f * 2 * (len + 64), len, endlane[f], out + (size_t)f * ((len + 31) / 32), gmap + (size_t)f * (len / 64 + 1) * 64, smem);
+    viterbi3_traceback_block(dec + (size_t)f * 2 * (len + 64), len, endlane[f], out + (size_t)f * ((len + 31) / 32), gmap + (size_t)f * (len / 64 + 1) * 64, smem, maps_done != 0);
 }
 
 void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st, int phases, int segments, int *stats, int warm)
@@ -236,7 +260,11 @@ void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned l
             hipLaunchKernelGGL(k_viterbi_frames_fwd, dim3(nframes * G), dim3(64), 0, st, (const int *)soft, len, (uint32_t *)dec, meta, G, warm);
             hipLaunchKernelGGL(k_viterbi_frames_fix, dim3(nframes), dim3(64), 0, st, (const int *)soft, len, (uint32_t *)dec, meta, G, endlane, stats);
         }
-        if (phases & 2) hipLaunchKernelGGL(k_viterbi_frames_tb, dim3(nframes), dim3(TB_THREADS), traceback_smem(len), st, (uint32_t *)dec, len, (const int *)endlane, out, gmap);
+        if (phases & 2) {
+            const int split = segments >= 16 ? 16 : 0;      // as launch_p1_traceback
+            if (split) hipLaunchKernelGGL(k_viterbi_frames_tbmap, dim3(split, nframes), dim3(64 * TBM_WAVES), 0, st, (uint32_t *)dec, len, gmap, split);
+            hipLaunchKernelGGL(k_viterbi_frames_tb, dim3(nframes), dim3(TB_THREADS), traceback_smem(len), st, (uint32_t *)dec, len, (const int *)endlane, out, gmap, split ? 1 : 0);
+        }
         return;
     }
     hipLaunchKernelGGL(k_viterbi_frames, dim3(nframes), dim3(64), 0, st, coded, len, dec, out, phases & 3);

@@ -112,7 +112,8 @@ void launch_px_decode(const DevTables &tb, const DevBuffers &db, int nstreams, c
 void launch_p1_deint(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st);
 // segments: waves per frame of the forward pass (1..16; clamped to what the frame length allows), see viterbi_v3.h
 void launch_p1_forward(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st, int segments, int warm = 2);
-void launch_p1_traceback(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st, int l2_mode = 0);
+// parts: workgroups per frame of the traceback's first pass (k_p1_tbmap), 1..16
+void launch_p1_traceback(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st, int l2_mode = 0, int parts = 4);
 
 // ---- AM path (k_am.hip) -------------------------------------------------------------------------
 // cu8 -> five cascaded half-bands 32:1, any nbytes % 4 == 0 per stream (stage phases carry over)

@@ -388,20 +388,21 @@ __device__ __host__ inline size_t vit3_traceback_smem(int len)
 // Block-parallel traceback over the history words of the forward pass (blockDim.x a multiple of 64):
 //   1  chunk maps AND the 64 output bits of all 64 candidate end lanes (two chunks per wave at a time); the candidate outputs
 //      replace the chunk's history words in place                                           -> gmap[c][64], dec
+//      (the engine runs this pass as its own launch, k_p1_tbmap, with as many workgroups per frame as keeps the chip busy: a thin
+//      window's few frames then spread over many CUs instead of queueing 2285 chunks on one)
 //   2  per segment of TB_SEG chunks: composition of its maps, all 64 candidates             -> segmap[sg][64]
 //   3  the true end lane of every segment, last to first (one thread)
 //   4  per segment: the chosen end lane of each of its chunks (one thread per segment)      -> chosen[c]
 //   5  per chunk: the output words of its chosen candidate
 // (Keeping all chunk maps of a frame in LDS -- 146 KB -- was measured: the composition gets faster, but a workgroup that owns a
 // CU's LDS keeps the block-step kernels off that CU and the whole pass loses 20 %: profiles/r03_traceback_variants.txt.)
-__device__ inline void viterbi3_traceback_block(uint32_t *dec, int len, int endlane, uint32_t *out, uint8_t *gmap, uint8_t *smem)
+// pass 1 of the traceback for the chunk pairs wave `gw` of `nw` owns (any number of workgroups per frame: the chunks are independent)
+__device__ __forceinline__ void viterbi3_traceback_maps(uint32_t *dec, int len, uint8_t *gmap, int gw, int nw)
 {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
-    const int nchunks = len / 64 + 1, nseg = (nchunks + TB_SEG - 1) / TB_SEG;
-    uint8_t *segmap = smem, *chosen = smem + (size_t)nseg * 64;
-    __shared__ uint8_t segend[64];                             // end lane of each segment (nseg <= 64: len <= 524224)
-    // pass 1: a wave takes chunks in adjacent pairs; the phase of a chunk's first step is (64 c) % 6 = 0, 4, 2 for c % 3 = 0, 1, 2
-    for (int ca = 2 * wave; ca < nchunks; ca += 2 * nwaves) {
+    const int lane = threadIdx.x & 63;
+    const int nchunks = len / 64 + 1;
+    // a wave takes chunks in adjacent pairs; the phase of a chunk's first step is (64 c) % 6 = 0, 4, 2 for c % 3 = 0, 1, 2
+    for (int ca = 2 * gw; ca < nchunks; ca += 2 * nw) {
         const int cb = ca + 1;
         const bool two = cb < nchunks;
         const unsigned h0a = dec[(size_t)(2 * ca) * 64 + lane], h1a = dec[(size_t)(2 * ca + 1) * 64 + lane];
@@ -422,6 +423,16 @@ __device__ inline void viterbi3_traceback_block(uint32_t *dec, int len, int endl
             dec[(size_t)(2 * cb) * 64 + lane] = olob; dec[(size_t)(2 * cb + 1) * 64 + lane] = ohib;
         }
     }
+}
+
+// passes 1 (unless maps_done: an earlier launch ran viterbi3_traceback_maps over all chunks) .. 5
+__device__ inline void viterbi3_traceback_block(uint32_t *dec, int len, int endlane, uint32_t *out, uint8_t *gmap, uint8_t *smem, bool maps_done = false)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int nchunks = len / 64 + 1, nseg = (nchunks + TB_SEG - 1) / TB_SEG;
+    uint8_t *segmap = smem, *chosen = smem + (size_t)nseg * 64;
+    __shared__ uint8_t segend[64];                             // end lane of each segment (nseg <= 64)
+    if (!maps_done) viterbi3_traceback_maps(dec, len, gmap, wave, nwaves);
     __threadfence_block();
     __syncthreads();
     for (int sg = wave; sg < nseg; sg += nwaves) {             // pass 2

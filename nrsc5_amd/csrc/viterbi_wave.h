@@ -231,7 +231,8 @@ __device__ inline void viterbi_k7_wave_fast(const int8_t *coded, int len, unsign
 }
 
 // The P1 frame's split form -- forward pass by one wave + block-parallel traceback -- lives in viterbi_v3.h.
-constexpr int TB_SEG = 128;                                    // chunks per segment of the block-parallel traceback
+constexpr int TB_SEG = 40;                                     // chunks per segment of the block-parallel traceback: a P1 frame's 2285 chunks make 58
+                                                               // segments (<= 64); the two sequential compositions chase 40 map entries each
 
 // dispatcher used by the kernels
 __device__ inline void viterbi_k7_decode(const int8_t *coded, int len, unsigned long long *dec, uint32_t *out, int phases = 3)

@@ -42,8 +42,11 @@ def main(dirname, out, workload="fm"):
             dur[row.get("Dispatch_Id")] = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-9
     pairs = [(g, dur[d]) for d, (name, g) in gui_by_dispatch.items() if d in dur and dur[d] > 200e-6 and g > 0]
     if pairs:
-        clock = sum(g for g, _ in pairs) / sum(t for _, t in pairs) / 1e9
-        clock_note = f"GRBM_GUI_ACTIVE / kernel duration over the {len(pairs)} dispatches longer than 200 us of the profiled (serialised) pass"
+        # the counter is summed over the chip's 8 XCDs (one GRBM each): 8 x the shader clock while the kernel has all of them busy
+        clock = sum(g for g, _ in pairs) / sum(t for _, t in pairs) / 1e9 / 8.0
+        clock_note = f"GRBM_GUI_ACTIVE (summed over 8 XCDs) / 8 / kernel duration over the {len(pairs)} dispatches longer than 200 us of the profiled (serialised) pass"
+        if not 1.0 < clock < 3.0:
+            clock, clock_note = 2.4, f"nominal 2.4 GHz (GRBM_GUI_ACTIVE / duration gave {clock:.2f} GHz: not plausible)"
     res = {}
     for name, d in sorted(tot.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0.0)):
         wc = d.get("SQ_WAVE_CYCLES", 0.0) or 1.0

@@ -11,19 +11,42 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-FLOAT_RTOL = 1e-4   # north_star: CFO / sync estimates within 1e-4 relative
-# The NCO phase (acquire_t.phase, acquire.c:166-250) is the running integral of the CFO estimate, not an
-# estimate itself: two libm implementations whose per-block `angle` agree to 1e-7 still random-walk apart
-# in this integral (33.75 rad of NCO phase per rad of angle per block), and only NCO phase + Costas phase
-# is observable.  It is logged for diagnosis and compared with an absolute bound instead.
-LOOSE_ABS = {"phase_re": 5e-3, "phase_im": 5e-3}
-# EVENT_MER is 10 log10 of a ratio whose denominator the reference accumulates sequentially in float32 over up to
-# 16 x 16128 cells (sync.c:465-483).  When a few huge terms dominate (the blocks right after lock in MP2/3/11, whose
-# new reference carriers are still pulling in) that sum itself is only good to ~1e-4, so MER values may also agree
-# to 2e-3 dB absolute instead of 1e-4 relative.
-# EVENT_SYNC.freq_offset is in Hz (prev_angle x 57.8): near 0 Hz the relative bound degenerates, 0.01 Hz = 1e-4 of the
-# +-100 Hz range the tracking loop works in.
-EITHER_ABS = {"lower": 2e-3, "upper": 2e-3, "freq_offset": 1e-2}
+FLOAT_RTOL = 1e-4   # north_star: CFO / sync estimates within 1e-4 relative -- RELATIVE to the value itself, no floor
+# Measured margins on the MI355X (profiles/r03_float_margins.txt, tools/gpu_float_margins.py: 21 captures, engine vs oracle):
+#   prev_angle 2.4e-6 relative, freq_offset 1.0e-7, MER 6.4e-6 (8.6e-5 dB), BER 1.1e-5 absolute, next_angle 4.0e-6 absolute,
+#   NCO phase 1.2e-4 absolute.
+# Fields that are not estimates of a physical quantity but signals around zero get an ABSOLUTE bound instead, 2.5 x what was measured:
+#  * next_angle (sync.c:458) is the residual CFO error signal of the tracking loop: it hovers around 0 (|x| down to 2e-7), so a
+#    relative bound is meaningless; 5e-5 rad (measured: 4.0e-6 at SNR >= 15 dB, 2.8e-5 on MP11 at 14 dB) -- half the bound of round 2.
+#  * The NCO phase (acquire_t.phase, acquire.c:166-250) is the running integral of the CFO estimate, not an estimate itself: two libm
+#    implementations whose per-block `angle` agree to 1e-7 still random-walk apart in this integral (33.75 rad of NCO phase per rad
+#    of angle per block), and only NCO phase + Costas phase is observable.
+#  * BER is a count of re-encoding disagreements over 365440 bits: 2e-5 = 7 counts (differences only occur on frames decoded from
+#    noise while falsely locked; decodable frames agree exactly).
+#  * prev_angle (rad per 2048 samples; x 57.8 = Hz): relative 1e-4, or 5e-5 rad (= 2.9e-3 Hz) when the CFO itself is near 0:
+#    the value is then the loop's own noise, and how far two float implementations drift apart in it grows with the channel noise
+#    (measured: 5.7e-6 rad at 20 dB SNR and CFO = 0 Hz exactly, 2.0e-5 rad on MP11 at 14 dB while its extended carriers pull in).
+#    freq_offset: relative 1e-4 or 1e-3 Hz.
+#  * While the reference is FALSELY LOCKED (a sync -> lost-sync stretch whose frame has cber > 0.02: MER < 0 dB, the loops track
+#    noise) its float state is chaotic in the last ulp of libm, and the acquisition that follows inherits it (prev_angle seeds the
+#    next coarse estimate, acquire.c:153-158): measured after such a stretch at CFO ~ 0 Hz, prev_angle differs by up to 4.3e-5 rad
+#    (2.5e-3 Hz), next_angle 8.5e-5, freq_offset 5.9e-4 Hz, NCO phase 1.5e-3, MER 5.5e-4 dB -- far below the estimator's own noise,
+#    but not 1e-4 of a value that is itself ~0.  From the first falsely locked stretch of a capture onwards the floats keep the old
+#    bound (1e-4 with a floor of 1; NCO phase 5e-3); integers, frames and events stay exact.  compare_logs marks those records.
+ABS_ONLY = {"next_angle": 5e-5, "phase_re": 1e-3, "phase_im": 1e-3, "cber": 2e-5}
+EITHER_ABS = {"freq_offset": 1e-3, "prev_angle": 5e-5}
+LOOSE_IN_FALSE_LOCK = {"phase_re": 5e-3, "phase_im": 5e-3, "freq_offset": 1e-2, "lower": 2e-3, "upper": 2e-3}
+
+
+def float_close(key: str, va: float, vb: float, rtol: float = FLOAT_RTOL, false_lock: bool = False) -> bool:
+    if false_lock and rtol > 0:
+        return abs(va - vb) <= LOOSE_IN_FALSE_LOCK.get(key, rtol * max(1.0, abs(va)))
+    if key in ABS_ONLY and rtol > 0:
+        return abs(va - vb) <= ABS_ONLY[key]
+    if abs(va - vb) <= rtol * abs(va):
+        return True
+    return rtol > 0 and key in EITHER_ABS and abs(va - vb) <= EITHER_ABS[key]
+
 
 # golden capture definitions: name -> synth.fm_mp1_capture kwargs
 GOLDEN_CASES = {
@@ -49,7 +72,8 @@ def sha256(a: np.ndarray) -> str:
 
 
 def compare_logs(expected, got, rtol: float = FLOAT_RTOL, skip_kinds=("hdc", "soft", "vit", "amsym", "pxsoft", "station")):
-    """Ordered-record comparison: integers/bit arrays exact, floats within rtol (relative, floor 1).
+    """Ordered-record comparison: integers/bit arrays exact, floats within rtol RELATIVE to the value (float_close: no floor;
+    the loop error signal, the NCO phase and the BER count have measured absolute bounds instead).
     Returns a list of human-readable differences (empty = parity)."""
     exp = [r for r in expected if r[0] not in skip_kinds]
     g = [r for r in got if r[0] not in skip_kinds]
@@ -58,6 +82,13 @@ def compare_logs(expected, got, rtol: float = FLOAT_RTOL, skip_kinds=("hdc", "so
         diffs.append(f"record kinds differ: expected {len(exp)} records, got {len(g)}; first mismatch at "
                      f"{next((i for i, (a, b) in enumerate(zip(exp, g)) if a[0] != b[0]), min(len(exp), len(g)))}")
         return diffs
+    # from the lock that precedes the first frame of cber > 0.02 (the reference is falsely locked there) to the end of the log:
+    # loose float bounds (see above)
+    loose = set()
+    first_bad = next((i for i, (k, v) in enumerate(exp) if k == "ber" and v["cber"] > 0.02), None)
+    if first_bad is not None:
+        start = max([i for i, (k, _) in enumerate(exp[:first_bad]) if k == "sync"], default=0)
+        loose = set(range(start, len(exp)))
     for i, (a, b) in enumerate(zip(exp, g)):
         for k, va in a[1].items():
             vb = b[1][k]
@@ -65,12 +96,8 @@ def compare_logs(expected, got, rtol: float = FLOAT_RTOL, skip_kinds=("hdc", "so
                 if not np.array_equal(va, vb):
                     diffs.append(f"#{i} {a[0]}.{k}: {int((np.asarray(va) != np.asarray(vb)).sum())} elements differ")
             elif isinstance(va, float):
-                if k in LOOSE_ABS and rtol > 0:
-                    if not abs(va - vb) <= LOOSE_ABS[k]:
-                        diffs.append(f"#{i} {a[0]}.{k}: expected {va!r} got {vb!r} (loose)")
-                elif not abs(va - vb) <= rtol * max(1.0, abs(va)):
-                    if not (rtol > 0 and k in EITHER_ABS and abs(va - vb) <= EITHER_ABS[k]):
-                        diffs.append(f"#{i} {a[0]}.{k}: expected {va!r} got {vb!r}")
+                if not float_close(k, va, vb, rtol, false_lock=i in loose):
+                    diffs.append(f"#{i} {a[0]}.{k}: expected {va!r} got {vb!r}")
             elif va != vb:
                 diffs.append(f"#{i} {a[0]}.{k}: expected {va!r} got {vb!r}")
     return diffs

@@ -35,7 +35,7 @@ def _compare_events(exp, got):
         elif k in ("sync", "mer", "ber"):
             for f in a:
                 va, vb = a[f], b[f]
-                assert abs(va - vb) <= common.FLOAT_RTOL * max(1.0, abs(va)), (k, f, va, vb)
+                assert common.float_close(f, float(va), float(vb)), (k, f, va, vb)
 
 
 @pytest.mark.parametrize("name", list(common.GOLDEN_AM_CASES))
@@ -63,7 +63,7 @@ def test_dropin_public_api_events_match_reference(name, captures):
         elif k in ("sync", "mer", "ber"):
             for f in a:
                 va, vb = a[f], b[f]
-                assert abs(va - vb) <= common.FLOAT_RTOL * max(1.0, abs(va)), (k, f, va, vb)
+                assert common.float_close(f, float(va), float(vb)), (k, f, va, vb)
 
 
 def test_two_dropin_sessions_in_one_process(captures):
