@@ -340,6 +340,10 @@ int nrsc5hip_debug_sync_phases(nrsc5hip_engine *e, long long *cycles8);
 /* debugging aid: soft-bit matrix (16 x 23040 int8) and live FFT bins of a stream's latest block */
 int nrsc5hip_debug_fetch(nrsc5hip_engine *e, int stream, int8_t *pm /* [368640] or NULL */, float *bins /* [32][534][2] or NULL */);
 
+/* debugging aid: Costas loop state (sync_t.costas_freq / costas_phase) of the 534 live bins (2 x 267: lower sideband bins 478..744,
+ * upper 1304..1570) of a stream */
+int nrsc5hip_debug_fetch_costas(nrsc5hip_engine *e, int stream, float *freq /* [534] */, float *phase /* [534] */);
+
 /* debugging aid: PX1 / PX2 soft bits of the stream's current block pair, [2 channels][2 blocks][4608] int8 */
 int nrsc5hip_debug_fetch_px(nrsc5hip_engine *e, int stream, int8_t *pair /* [18432] */);
 

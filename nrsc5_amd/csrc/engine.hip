@@ -1531,6 +1531,17 @@ extern "C" int nrsc5hip_debug_fetch(nrsc5hip_engine *e, int stream, int8_t *pm, 
     return 0;
 }
 
+extern "C" int nrsc5hip_debug_fetch_costas(nrsc5hip_engine *e, int stream, float *freq, float *phase)
+{
+    int rc = check_stream(e, stream); if (rc) return rc;
+    if (!freq || !phase) FAIL(NRSC5HIP_EINVAL, "null argument");
+    if (e->staged_stream >= 0 && (rc = flush_staged(e))) return rc;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(freq, (const char *)(e->db.state + stream) + offsetof(StreamState, costas_freq), LIVE_N * sizeof(float), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(phase, (const char *)(e->db.state + stream) + offsetof(StreamState, costas_phase), LIVE_N * sizeof(float), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int nrsc5hip_debug_fetch_px(nrsc5hip_engine *e, int stream, int8_t *pair)
 {
     int rc = check_stream(e, stream); if (rc) return rc;

@@ -120,6 +120,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.nrsc5hip_stage_fft2048.argtypes = [vp, vp, vp, ci]
     lib.nrsc5hip_stage_viterbi_k7.argtypes = [vp, vp, ci, ci, vp]
     lib.nrsc5hip_debug_fetch.argtypes = [vp, ci, vp, vp]
+    lib.nrsc5hip_debug_fetch_costas.argtypes = [vp, ci, vp, vp]
     lib.nrsc5hip_stage_selftest.argtypes = [vp, ctypes.POINTER(ci)]
     lib.nrsc5hip_stage_viterbi_k7_debug.argtypes = [vp, vp, ci, vp, vp]
     lib.nrsc5hip_stage_viterbi_bench.argtypes = [vp, ci, ci, ci, ci, ctypes.POINTER(ctypes.c_float)]
@@ -159,7 +160,7 @@ EXPORTED_SYMBOLS = [
     "nrsc5hip_push_cu8", "nrsc5hip_push_cs16", "nrsc5hip_stream_reset", "nrsc5hip_force_resync", "nrsc5hip_bytes_to_next_block",
     "nrsc5hip_batch_append_cu8", "nrsc5hip_batch_append_cs16", "nrsc5hip_batch_process", "nrsc5hip_drain",
     "nrsc5hip_p1_frame_packed", "nrsc5hip_p1_frame_bits", "nrsc5hip_batch_fetch", "nrsc5hip_unpack_bits",
-    "nrsc5hip_stage_halfband_fm_cu8", "nrsc5hip_stage_fft2048", "nrsc5hip_stage_viterbi_k7", "nrsc5hip_debug_fetch",
+    "nrsc5hip_stage_halfband_fm_cu8", "nrsc5hip_stage_fft2048", "nrsc5hip_stage_viterbi_k7", "nrsc5hip_debug_fetch", "nrsc5hip_debug_fetch_costas",
     "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_debug_tune", "nrsc5hip_debug_fwd_stats", "nrsc5hip_debug_seam_totals", "nrsc5hip_batch_fetch_view", "nrsc5hip_batch_fetch_l2_px", "nrsc5hip_batch_fetch_l2_am",
     "nrsc5hip_stream_set_mode", "nrsc5hip_am_frame_bits", "nrsc5hip_stage_viterbi_k9", "nrsc5hip_px_frame_bits",
     "nrsc5hip_batch_fetch_px", "nrsc5hip_debug_fetch_px", "nrsc5hip_stage_viterbi_k9_bench",
@@ -461,6 +462,11 @@ class Engine:
         n = ctypes.c_int(-1)
         self._check(self.lib.nrsc5hip_stage_selftest(self._h, ctypes.byref(n)))
         return n.value
+
+    def debug_fetch_costas(self, stream: int):
+        f = np.zeros(534, dtype=np.float32); p = np.zeros(534, dtype=np.float32)
+        self._check(self.lib.nrsc5hip_debug_fetch_costas(self._h, stream, f.ctypes.data, p.ctypes.data))
+        return f, p
 
     def debug_fetch_px(self, stream: int) -> np.ndarray:
         out = np.zeros((2, 2, 4608), dtype=np.int8)
