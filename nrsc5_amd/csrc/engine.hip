@@ -16,7 +16,9 @@
 
 using namespace nrsc5;
 
-constexpr int MAX_LANES = 1;   // one scheduler lane: a block step is latency-bound, stream groups on separate HIP streams gained nothing
+// ONE block-step chain per engine.  Cutting the stream set into half-sets on two chain queues was built and measured in round 3
+// (profiles/r03_chain_lanes.txt: 49 vs 38 ms per pass -- the chip is occupancy-bound inside k_mixfft, a second queue only splits
+// the same slots) and in round 1 (stream groups on separate HIP streams: nothing gained); the scaffolding for it is gone.
 static_assert(sizeof(nrsc5hip_record) == sizeof(BlockRecord), "record ABI mismatch");
 static_assert(sizeof(BlockRecord) % 8 == 0, "record alignment");
 
@@ -54,8 +56,7 @@ struct nrsc5hip_engine {
     nrsc5hip_config cfg;
     DevTables tb;
     DevBuffers db;
-    // Scheduler lanes: each lane advances its own subset of the streams on its own HIP streams, so the
-    // latency-bound per-block kernels of different lanes overlap (lane 0 also serves the streaming seam).
+    // The block-step chain: its HIP stream, the decode streams of the window pipeline and their bookkeeping.
     struct Lane {
         hipStream_t main, aux[NAUX];
         hipEvent_t ev_window[NWIN], ev_decoded[NWIN];
@@ -72,14 +73,13 @@ struct nrsc5hip_engine {
         bool am_decoded_pending[NWIN];
         int *counters_dev, *counters_host;
         DevBuffers db;                 // engine buffers with this lane's counters
-    } lanes[MAX_LANES];
-    int nlanes;
+    } lane;
     int naux;                          // decode streams in use (<= NAUX)
     int naux_am;                       // ... by the AM window pipeline (its decodes are longer and thinner: 4 measured best)
     int verdict_lag;                   // test hook (nrsc5hip_debug_tune): replay takes verdicts this many windows late
     int fwd_warm;                      // test hook: speculative warm-up trips of a forward segment (2; 0 makes every speculation fail -> repair path)
     int fwd_segments;                  // waves per frame of the P1 forward pass; 0 = pick from the size of the stream set (fwd_segments_for)
-    hipStream_t main;                  // = lanes[0].main
+    hipStream_t main;                  // = lane.main
     std::vector<void *> allocs;
     // host mirrors
     std::vector<long long> wr_host, base_host;
@@ -362,12 +362,11 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
     int rc = 0;
     do {
         {
-            e->nlanes = 1;
             e->naux = 3; e->naux_am = 4;   // decode streams in use (measured: profiles/r02_naux.txt); nrsc5hip_debug_tune changes them
             e->verdict_lag = 0; e->fwd_segments = 0; e->fwd_warm = 2;
         }
-        for (int l = 0; l < e->nlanes && !rc; l++) {
-            nrsc5hip_engine::Lane &ln = e->lanes[l];
+        {
+            nrsc5hip_engine::Lane &ln = e->lane;
             // (queue priorities -- chain stream high, decode streams low -- were measured: nothing for the batch, +15 % per block for
             // a lone stream, profiles/r02_ab_prio_demod.txt)
             if (hipStreamCreate(&ln.main) != hipSuccess) rc = NRSC5HIP_EHIP;
@@ -383,7 +382,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             if (!rc && hipHostMalloc((void **)&ln.counters_host, 4 * sizeof(int), hipHostMallocDefault) != hipSuccess) rc = NRSC5HIP_ENOMEM;
         }
         if (rc) { snprintf(g_err, sizeof(g_err), "stream/event creation failed"); break; }
-        e->main = e->lanes[0].main;
+        e->main = e->lane.main;
         // K1 of the copying batch path runs ahead of the block steps on this stream (confining it to a slice of the CUs
         // with hipExtStreamCreateWithCUMask was measured: no gain, profiles/r02_k1cus.txt -- it is the HBM traffic itself that
         // slows the latency-bound step kernels; the zero-copy batch path has no K1 at all)
@@ -419,7 +418,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if ((rc = dev_alloc(e, &db.p1_ring, S * db.p1_slots * P1_WORDS))) break;
         db.p1_mirror = nullptr;
         if ((rc = dev_alloc(e, &db.records, S * db.rec_cap))) break;
-        if ((rc = dev_alloc(e, &db.counters, 4 * MAX_LANES))) break;
+        if ((rc = dev_alloc(e, &db.counters, 4))) break;
         {
             const size_t nax = cfg->p1_async ? NAUX : 1;
             db.px_slots = 8 * cfg->p1_slots;
@@ -498,7 +497,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         e->wr_host.assign(S, 0); e->base_host.assign(S, 0); e->drained.assign(S, 0);
         e->mode_host.assign(S, MODE_FM); e->raw_host.assign(S, 0); e->attached.assign(S, 0);
         e->rd_host.assign(S, 0); e->fetched.assign(S, 0); e->mirror_ok.assign(S, cfg->p1_async ? 0 : 1); e->pending.assign(S, {});
-        for (int l = 0; l < e->nlanes; l++) { e->lanes[l].db = db; e->lanes[l].counters_dev = db.counters + 4 * l; e->lanes[l].db.counters = db.counters + 4 * l; }
+        e->lane.db = db; e->lane.counters_dev = db.counters;
         e->prof_on = false; e->prof_only = -1;
         for (int k = 0; k < NRSC5HIP_PROF_CLASSES; k++) { e->prof_ms[k] = 0; e->prof_launches[k] = 0; }
     } while (0);
@@ -521,8 +520,8 @@ extern "C" void nrsc5hip_engine_destroy(nrsc5hip_engine *e)
     if (e->report_host) (void)hipHostFree(e->report_host);
     for (auto &sp : e->prof_spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (hipEvent_t ev : e->prof_pool) (void)hipEventDestroy(ev);
-    for (int l = 0; l < e->nlanes; l++) {
-        nrsc5hip_engine::Lane &ln = e->lanes[l];
+    {
+        nrsc5hip_engine::Lane &ln = e->lane;
         if (ln.counters_host) (void)hipHostFree(ln.counters_host);
         for (int k = 0; k < NWIN; k++) { if (ln.ev_window[k]) (void)hipEventDestroy(ln.ev_window[k]); if (ln.ev_decoded[k]) (void)hipEventDestroy(ln.ev_decoded[k]); }
         if (ln.main) (void)hipStreamDestroy(ln.main);
@@ -646,7 +645,7 @@ static int flush_p1(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const 
 // `set_sig` identifies the stream set: the acquisition / PX launch flags measured on one set say nothing about another.
 static int run_steps(nrsc5hip_engine *e, int n, const int *ids_dev, unsigned long long set_sig, int max_steps, int check_every, int *steps_done)
 {
-    nrsc5hip_engine::Lane &ln = e->lanes[0];
+    nrsc5hip_engine::Lane &ln = e->lane;
     if (set_sig != ln.set_sig) { ln.acq_needed = true; ln.px_needed = true; ln.set_sig = set_sig; }
     ln.prepared_by_sync = false;
     const bool replay = e->db.ckpt != nullptr;
@@ -722,7 +721,7 @@ static int am_flush(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const 
 
 static int run_steps_am(nrsc5hip_engine *e, int n, const int *ids_dev, int max_steps, int check_every, int *steps_done)
 {
-    nrsc5hip_engine::Lane &ln = e->lanes[0];
+    nrsc5hip_engine::Lane &ln = e->lane;
     const bool pipe = e->cfg.p1_async != 0;
     const bool replay = ln.db.am_ckpt != nullptr;              // window pipeline with the on-device L2 feedback (k_replay.hip)
     int done = 0;
@@ -837,7 +836,7 @@ static int window_of(const nrsc5hip_engine *e, int s) { return e->mode_host[s] =
 // Fast seam: block steps of one stream while the host mirror says a window is complete; one sync per step.
 static int stream_steps(nrsc5hip_engine *e, int s)
 {
-    nrsc5hip_engine::Lane &ln = e->lanes[0];
+    nrsc5hip_engine::Lane &ln = e->lane;
     const int *ids_dev = e->all_ids_dev + s;                   // identity list: entry s is s
     const bool am = e->mode_host[s] == MODE_AM;
     const unsigned long long sig = set_signature(1, &s);
@@ -982,7 +981,7 @@ extern "C" int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream)
     if (e->staged_stream == stream) { e->staged_stream = -1; e->staged_bytes = 0; e->staged_q15 = 0; }      // samples not yet submitted die with the session
     // this engine's queues only (another session of the process keeps running)
     HIPCHK(hipStreamSynchronize(e->main));
-    if (e->cfg.p1_async) { for (int k = 0; k < NAUX; k++) HIPCHK(hipStreamSynchronize(e->lanes[0].aux[k])); HIPCHK(hipStreamSynchronize(e->dec_stream)); }
+    if (e->cfg.p1_async) { for (int k = 0; k < NAUX; k++) HIPCHK(hipStreamSynchronize(e->lane.aux[k])); HIPCHK(hipStreamSynchronize(e->dec_stream)); }
     StreamState st; init_state(st, e->mode_host[stream]);
     HIPCHK(hipMemcpy(e->db.state + stream, &st, sizeof(st), hipMemcpyHostToDevice));
     if (e->db.am) {
@@ -993,7 +992,7 @@ extern "C" int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream)
     }
     e->wr_host[stream] = 0; e->base_host[stream] = 0; e->drained[stream] = 0; e->raw_host[stream] = 0; e->attached[stream] = 0;
     e->rd_host[stream] = 0; e->fetched[stream] = 0; e->pending[stream].clear(); e->mirror_ok[stream] = e->cfg.p1_async ? 0 : 1;
-    for (int l = 0; l < e->nlanes; l++) { e->lanes[l].acq_needed = true; e->lanes[l].px_needed = true; e->lanes[l].set_sig = 0; }
+    e->lane.acq_needed = true; e->lane.px_needed = true; e->lane.set_sig = 0;
     return 0;
 }
 
@@ -1014,7 +1013,7 @@ extern "C" int nrsc5hip_force_resync(nrsc5hip_engine *e, int stream)
 {
     int rc = check_stream(e, stream); if (rc) return rc;
     hipLaunchKernelGGL(k_force_none, dim3(1), dim3(1), 0, e->main, e->db, stream);
-    for (int l = 0; l < e->nlanes; l++) { e->lanes[l].acq_needed = true; e->lanes[l].px_needed = true; e->lanes[l].set_sig = 0; }
+    e->lane.acq_needed = true; e->lane.px_needed = true; e->lane.set_sig = 0;
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1100,7 +1099,7 @@ extern "C" int nrsc5hip_batch_append_cu8(nrsc5hip_engine *e, int nstreams, const
     }
     bool fresh = e->cfg.p1_async != 0 && stream_ids == nullptr && nstreams == e->cfg.max_streams;
     for (int k = 0; k < nstreams && fresh; k++) fresh = e->wr_host[k] == 0;
-    for (int l = 0; l < e->nlanes && fresh; l++) fresh = e->lanes[l].step_count == 0;
+    fresh = fresh && e->lane.step_count == 0;
     const long long CH = 16 * 70199LL;                         // one decode window's worth of output samples
     if (fresh && (long long)mx / 4 > 3 * CH) {
         // Fresh batch in the pipelined mode: decimate window-sized chunks on a side stream so that K1 (HBM-bound)
@@ -1130,7 +1129,7 @@ extern "C" int nrsc5hip_batch_append_cu8(nrsc5hip_engine *e, int nstreams, const
             HIPCHK(hipEventRecord(e->dec_events[c], e->dec_stream));
         }
         e->dec_chunk = CH;
-        for (int l = 0; l < e->nlanes; l++) e->lanes[l].dec_waited = 0;
+        e->lane.dec_waited = 0;
     } else {
         ProfScope p(e, NRSC5HIP_PROF_DECIMATE, e->main);
         launch_decimate_fm_cu8(e->tb, e->db, nstreams, ids_dev, dev_iq, stride_bytes, e->nbytes_dev, mx, e->main);
@@ -1599,11 +1598,8 @@ extern "C" int nrsc5hip_reset_all(nrsc5hip_engine *e)
     for (auto &q : e->pending) q.clear();
     HIPCHK(hipMemset(e->db.pids_rec, 0xff, S * NWIN * 16 * sizeof(int)));
     HIPCHK(hipMemset(e->db.px_job, 0xff, S * NWIN * 16 * sizeof(PxJob)));
-    for (int l = 0; l < e->nlanes; l++) {
-        e->lanes[l].acq_needed = true; e->lanes[l].px_needed = true; e->lanes[l].set_sig = 0; e->lanes[l].step_count = 0; e->lanes[l].am_step_count = 0;
-        for (int k = 0; k < NWIN; k++) e->lanes[l].am_decoded_pending[k] = false;
-        for (int k = 0; k < NWIN; k++) e->lanes[l].decoded_pending[k] = false;
-    }
+    e->lane.acq_needed = true; e->lane.px_needed = true; e->lane.set_sig = 0; e->lane.step_count = 0; e->lane.am_step_count = 0;
+    for (int k = 0; k < NWIN; k++) { e->lane.am_decoded_pending[k] = false; e->lane.decoded_pending[k] = false; }
     return 0;
 }
 
@@ -1725,7 +1721,7 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
             int rc = dev_alloc(e, &e->db.sync_phase_cycles, 8); if (rc) return rc;
             HIPCHK(hipMemset(e->db.sync_phase_cycles, 0, 8 * sizeof(long long)));
         }
-        for (int l = 0; l < e->nlanes; l++) e->lanes[l].db.sync_phase_cycles = value ? e->db.sync_phase_cycles : nullptr;
+        e->lane.db.sync_phase_cycles = value ? e->db.sync_phase_cycles : nullptr;
         break;
     default: FAIL(NRSC5HIP_EINVAL, "unknown knob %d", knob);
     }
@@ -1785,7 +1781,7 @@ extern "C" int nrsc5hip_batch_fetch_view(nrsc5hip_engine *e, int nstreams, const
             void *dp = nullptr;
             HIPCHK(hipHostGetDevicePointer(&dp, e->frames_host, 0));
             e->db.p1_mirror = (uint32_t *)dp;
-            for (int l = 0; l < e->nlanes; l++) e->lanes[l].db.p1_mirror = (uint32_t *)dp;
+            e->lane.db.p1_mirror = (uint32_t *)dp;
         } else if (any_am) {
             HIPCHK(hipMemcpyAsync(e->frames_host, e->db.p1_ring, (size_t)nstreams * nwords * sizeof(uint32_t), hipMemcpyDeviceToHost, e->main));
         }

@@ -931,14 +931,20 @@ __device__ inline int8_t am_deint_one(uint2 e, const uint8_t *sym, uint8_t *q, i
     return bit ? 1 : -1;
 }
 
-__device__ inline void am_deinterleave_frame(const DevTables &tb, const DevBuffers &db, int s, int parity, int window)
+// The 162 000 (MA1) / 180 000 (MA3) trellis inputs of an L1 frame are independent table look-ups (every cell of the diversity delay
+// lines is visited by exactly one of them), so the frame is cut into AM_IL_PARTS slices, one workgroup each: with diverse streams an
+// eighth of the batch finishes an L1 frame in any one step, and one workgroup per stream left 7 of 8 CUs idle for the 90 us such a
+// step then took.  The bookkeeping that ends the frame -- delay-line head, ring slot and decode job of the next frame -- runs after
+// ALL slices, in k_am_interleave_commit.
+constexpr int AM_IL_PARTS = 8;
+
+__device__ inline void am_deinterleave_slice(const DevTables &tb, const DevBuffers &db, int s, int parity, int part)
 {
-    const StreamState &st = db.state[s];
     AmStream &am = db.am[s];
     const bool ma3 = am.dec_psmi == AM_MA3;
     const int tid = threadIdx.x;
     const int vslot = parity < 0 ? 0 : parity;                 // window pipeline: one set of trellis inputs per window in flight
-    if (tid == 0 && parity < 0 && am.am_diversity_wait == 0) {
+    if (part == 0 && tid == 0 && parity < 0 && am.am_diversity_wait == 0) {
         unsigned total = 8 * (AM_P1_LEN * 12 / 5);
         if (!am.dec_rdbi) total += ma3 ? AM_P3_LEN_MA3 * 12 / 5 : AM_P3_LEN_MA1 * 3 / 2;
         db.records[(size_t)s * db.rec_cap + am.dec_record].ber = (float)am.am_errors / (float)total;
@@ -955,38 +961,50 @@ __device__ inline void am_deinterleave_frame(const DevTables &tb, const DevBuffe
     uint8_t *q = db.am_q + (size_t)s * 4 * 3 * 18000;         // [ml, mu, eml, emu][3][18000]
     const int head = am.q_head;
     int8_t *v1 = db.am_vit + ((size_t)s * db.am_nvit + vslot) * 2 * AM_VIT, *v3 = v1 + AM_VIT;
-    for (int i = tid; i < AM_VIT; i += 1024) v1[i] = am_deint_one(tb.am_deint_p1[i], sym, q, head);
-    if (!ma3) for (int i = tid; i < 3 * AM_P3_LEN_MA1; i += 1024) v3[i] = am_deint_one(tb.am_deint_p3_ma1[i], sym, q, head);
-    else for (int i = tid; i < AM_VIT; i += 1024) v3[i] = am_deint_one(tb.am_deint_p3_ma3[i], sym, q, head);
-    __syncthreads();
-    if (tid == 0) {
-        am.q_head = (head + 1) % 3;
-        if (am.am_diversity_wait > 0) am.am_diversity_wait--;
-        if (am.am_diversity_wait == 0) {
-            // the next L1 frame delivers what these trellis inputs decode to: reserve its ring slot now
-            StreamState &stw = db.state[s];
-            am.next_slot = stw.p1_count % db.p1_slots; stw.p1_count++;
-            if (parity >= 0) {
-                AmJob &job = db.am_job[(size_t)s * NWIN + parity];
-                job.slot = am.next_slot; job.psmi = am.dec_psmi; job.rdbi = am.dec_rdbi; job.errors = 0; job.done = 0; job.pad = 0; job.epoch = stw.fine_epoch;
-                for (int j = 0; j < 8; j++) { job.verdict[j] = 0; job.deliver_abs[j] = -1; }
-                job.window = window;
-                am.next_job = parity;
-                job.valid = 1;
-            }
+    const int i0 = part * 1024 + tid, step = 1024 * AM_IL_PARTS;
+    for (int i = i0; i < AM_VIT; i += step) v1[i] = am_deint_one(tb.am_deint_p1[i], sym, q, head);
+    if (!ma3) for (int i = i0; i < 3 * AM_P3_LEN_MA1; i += step) v3[i] = am_deint_one(tb.am_deint_p3_ma1[i], sym, q, head);
+    else for (int i = i0; i < AM_VIT; i += step) v3[i] = am_deint_one(tb.am_deint_p3_ma3[i], sym, q, head);
+}
+
+// after every slice of the frame: advance the delay lines, reserve the ring slot and the decode job of the next L1 frame
+__device__ inline void am_deinterleave_commit(const DevBuffers &db, int s, int parity, int window)
+{
+    AmStream &am = db.am[s];
+    am.q_head = (am.q_head + 1) % 3;
+    if (am.am_diversity_wait > 0) am.am_diversity_wait--;
+    if (am.am_diversity_wait == 0) {
+        // the next L1 frame delivers what these trellis inputs decode to: reserve its ring slot now
+        StreamState &stw = db.state[s];
+        am.next_slot = stw.p1_count % db.p1_slots; stw.p1_count++;
+        if (parity >= 0) {
+            AmJob &job = db.am_job[(size_t)s * NWIN + parity];
+            job.slot = am.next_slot; job.psmi = am.dec_psmi; job.rdbi = am.dec_rdbi; job.errors = 0; job.done = 0; job.pad = 0; job.epoch = stw.fine_epoch;
+            for (int j = 0; j < 8; j++) { job.verdict[j] = 0; job.deliver_abs[j] = -1; }
+            job.window = window;
+            am.next_job = parity;
+            job.valid = 1;
         }
     }
 }
 
-__global__ __launch_bounds__(1024) void k_am_interleave(DevTables tb, DevBuffers db, const int *ids, int parity, int window)
+__global__ __launch_bounds__(1024) void k_am_interleave(DevTables tb, DevBuffers db, const int *ids, int parity)
 {
     wave_set_priority_high();
-    const int s = stream_of(ids, blockIdx.x);
+    const int s = stream_of(ids, blockIdx.y);
     const StreamState &st = db.state[s];
-    AmStream &am = db.am[s];
+    const AmStream &am = db.am[s];
     if (!st.active || am.dec_bc != 7) return;                  // block-uniform
-    const int tid = threadIdx.x;
-    am_deinterleave_frame(tb, db, s, parity, window);
+    am_deinterleave_slice(tb, db, s, parity, (int)blockIdx.x);
+}
+
+__global__ __launch_bounds__(64) void k_am_interleave_commit(DevBuffers db, const int *ids, int nstreams, int parity, int window)
+{
+    const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= nstreams) return;
+    const int s = stream_of(ids, sidx);
+    if (!db.state[s].active || db.am[s].dec_bc != 7) return;
+    am_deinterleave_commit(db, s, parity, window);
 }
 
 // ---- window pipeline: all nine frames of an L1 frame decode concurrently on a decode stream ---------------------------
@@ -1081,7 +1099,8 @@ void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, con
         hipLaunchKernelGGL(k_am_viterbi, dim3(2, nstreams), dim3(64), 0, st, tb, db, stream_ids, l2_feedback);
         if (db.l2_am_ring) launch_l2_index_am_step(db, nstreams, stream_ids, st);
     }
-    hipLaunchKernelGGL(k_am_interleave, dim3(nstreams), dim3(1024), 0, st, tb, db, stream_ids, pipeline_parity, window);
+    hipLaunchKernelGGL(k_am_interleave, dim3(AM_IL_PARTS, nstreams), dim3(1024), 0, st, tb, db, stream_ids, pipeline_parity);
+    hipLaunchKernelGGL(k_am_interleave_commit, dim3((nstreams + 63) / 64), dim3(64), 0, st, db, stream_ids, nstreams, pipeline_parity, window);
 }
 
 // ---- stage-level entry: decode `nframes` independent K=9 frames (parity tests) ------------------------------------
