@@ -696,7 +696,7 @@ class Mixed:
         return k >= self.nfm
 
 
-TUNE_KNOBS = {"decode_streams": 0, "am_decode_streams": 1, "fwd_segments": 4}
+TUNE_KNOBS = {"decode_streams": 0, "am_decode_streams": 1, "fwd_segments": 4, "am_segments": 6, "decode_cus": 7, "decode_priority": 8}
 
 
 def apply_tune(E, args):

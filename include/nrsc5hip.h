@@ -319,7 +319,7 @@ int nrsc5hip_stage_viterbi_k9_bench(nrsc5hip_engine *e, int len, int nframes, in
 /* Tuning knobs and test hooks (the library reads nothing from the environment).  Call on an idle engine. */
 enum {
     NRSC5HIP_TUNE_DECODE_STREAMS = 0,    /* FM window pipeline: HIP streams that decode windows concurrently (1..5, default 3) */
-    NRSC5HIP_TUNE_AM_DECODE_STREAMS,     /* same for the AM window pipeline (default 4) */
+    NRSC5HIP_TUNE_AM_DECODE_STREAMS,     /* same for the AM window pipeline (default 2) */
     NRSC5HIP_TUNE_VERDICT_LAG,           /* TEST HOOK: the replay takes first-header verdicts this many windows late (0..8): deep speculation */
     NRSC5HIP_TUNE_SYNC_PHASES,           /* 1: k_sync accumulates shader cycles per phase for stream 0 (nrsc5hip_debug_sync_phases) */
     NRSC5HIP_TUNE_FWD_SEGMENTS           /* waves per frame of the K=7 forward trellis pass (1..16; 0 = chosen from the size of the stream set).  Any value
@@ -327,6 +327,12 @@ enum {
                                             repaired (viterbi_v3.h).  Also used by nrsc5hip_stage_viterbi_k7 / _bench. */
     , NRSC5HIP_TUNE_FWD_WARM               /* TEST HOOK: 0 = the segments start cold (no speculative warm-up), so that the speculation fails wherever the
                                             input carries information and every segment takes the repair path; 1 = normal */
+    , NRSC5HIP_TUNE_AM_SEGMENTS            /* waves per P3 frame of the K=9 decode in the AM window pipeline (1..8, default 8); forward pass AND traceback
+                                            run in segment waves, both verified / repaired: any value gives the sequential decoder's bits.  Also used by
+                                            nrsc5hip_stage_viterbi_k9 / _bench (1 = the single-wave form). */
+    , NRSC5HIP_TUNE_DECODE_CUS             /* decode streams confined to value / 32 of every XCD's CUs (8, 16, 24; 32 = all, the default) */
+    , NRSC5HIP_TUNE_DECODE_PRIORITY        /* 1: decode streams at the lowest queue priority (default 0: all queues equal) */
+    , NRSC5HIP_TUNE_AM_WARM                /* TEST HOOK: 0 = no forward warm-up and no traceback run-in (every boundary takes the repair path); 1 = normal */
 };
 /* process-wide wall-clock totals of the streaming seam with p1_async = 0 (what the drop-in uses): [0] s copying pushes into pinned
  * staging, [1] s enqueueing H2D + decimator, [2] s enqueueing block steps, [3] s waiting for the device (one sync per block),
@@ -334,6 +340,8 @@ enum {
 void nrsc5hip_debug_seam_totals(double out[8], int reset);
 /* segmented forward pass: segment boundaries checked / segments that had to be re-run since the engine was created */
 int nrsc5hip_debug_fwd_stats(nrsc5hip_engine *e, int stats[2]);
+/* K=9 decode in segment waves: [0] forward boundaries checked, [1] segments re-run, [2] traceback boundaries checked, [3] segments re-walked */
+int nrsc5hip_debug_k9_stats(nrsc5hip_engine *e, int stats[4]);
 int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value);
 /* accumulated shader cycles per phase of the sync kernel for stream 0 (after nrsc5hip_debug_tune(e, NRSC5HIP_TUNE_SYNC_PHASES, 1)) */
 int nrsc5hip_debug_sync_phases(nrsc5hip_engine *e, long long *cycles8);

@@ -75,8 +75,9 @@ struct nrsc5hip_engine {
         DevBuffers db;                 // engine buffers with this lane's counters
     } lane;
     int naux;                          // decode streams in use (<= NAUX)
-    int naux_am;                       // ... by the AM window pipeline (its decodes are longer and thinner: 4 measured best)
+    int naux_am;                       // ... by the AM window pipeline (2 measured best once the P3 frame decodes in segment waves)
     int verdict_lag;                   // test hook (nrsc5hip_debug_tune): replay takes verdicts this many windows late
+    int am_segments, am_warm, am_runin;   // K=9 decode of the AM P3 frame: segment waves per frame (8), their forward warm-up / traceback run-in (test hooks: 0)
     int fwd_warm;                      // test hook: speculative warm-up trips of a forward segment (2; 0 makes every speculation fail -> repair path)
     int fwd_segments;                  // waves per frame of the P1 forward pass; 0 = pick from the size of the stream set (fwd_segments_for)
     hipStream_t main;                  // = lane.main
@@ -362,8 +363,9 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
     int rc = 0;
     do {
         {
-            e->naux = 3; e->naux_am = 4;   // decode streams in use (measured: profiles/r02_naux.txt); nrsc5hip_debug_tune changes them
+            e->naux = 3; e->naux_am = 2;   // decode streams in use (measured: profiles/r02_naux.txt, r03_am_decode.txt); nrsc5hip_debug_tune changes them
             e->verdict_lag = 0; e->fwd_segments = 0; e->fwd_warm = 2;
+            e->am_segments = K9_GMAX; e->am_warm = K9_WARM; e->am_runin = K9_TB_RUNIN;
         }
         {
             nrsc5hip_engine::Lane &ln = e->lane;
@@ -412,6 +414,8 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if ((rc = dev_alloc(e, &db.fwd_meta, (size_t)(cfg->p1_async ? NAUX : 1) * S * (size_t)(16 * 512)))) break;
         if ((rc = dev_alloc(e, &db.fwd_stats, 2))) break;
         if (hipMemset(db.fwd_stats, 0, 2 * sizeof(int)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
+        if ((rc = dev_alloc(e, &db.am_k9stats, 4))) break;
+        if (hipMemset(db.am_k9stats, 0, 4 * sizeof(unsigned)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
         if ((rc = dev_alloc(e, &db.pids_stage, S * NWIN * 16 * 3 * PIDS_LEN))) break;
         if ((rc = dev_alloc(e, &db.pids_rec, S * NWIN * 16))) break;
         if (hipMemset(db.pids_rec, 0xff, S * NWIN * 16 * sizeof(int)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
@@ -444,7 +448,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
                 if (hipMemset(db.l2_am_ring, 0, nam * sizeof(nrsc5hip_l2_frame)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
             }
         }
-        db.am = nullptr; db.am_sym = nullptr; db.am_q = nullptr; db.am_vit = nullptr; db.am_dec = nullptr; db.am_job = nullptr; db.am_ckpt = nullptr; db.am_ber = nullptr; db.am_pids_stage = nullptr; db.am_pids_rec = nullptr; db.am_nvit = 1;
+        db.am = nullptr; db.am_sym = nullptr; db.am_q = nullptr; db.am_vit = nullptr; db.am_dec = nullptr; db.am_k9meta = nullptr; db.am_job = nullptr; db.am_ckpt = nullptr; db.am_ber = nullptr; db.am_pids_stage = nullptr; db.am_pids_rec = nullptr; db.am_nvit = 1;
         if (cfg->am_enable) {
             if ((rc = dev_alloc(e, &db.am, S))) break;
             if ((rc = dev_alloc(e, &db.am_sym, S * 4 * AM_SYMS))) break;
@@ -453,6 +457,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             const size_t ndec = cfg->p1_async ? NAUX : 1;
             if ((rc = dev_alloc(e, &db.am_vit, S * db.am_nvit * 2 * AM_VIT))) break;
             if ((rc = dev_alloc(e, &db.am_dec, ndec * S * (size_t)(8 * AM_DEC_P1 + AM_DEC_P3)))) break;
+            if (cfg->p1_async && (rc = dev_alloc(e, &db.am_k9meta, ndec * S))) break;
             if ((rc = dev_alloc(e, &db.am_job, S * NWIN))) break;
             if ((rc = dev_alloc(e, &db.am_ber, S * (size_t)cfg->p1_slots))) break;
             if (cfg->p1_async && cfg->l2_feedback && (rc = dev_alloc(e, &db.am_ckpt, S * NWIN * 8))) break;      // replay checkpoints, one per delivered P1 PDU
@@ -711,7 +716,7 @@ static int am_flush(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const 
         hipStream_t ax = ln.aux[lane];
         HIPCHK(hipEventRecord(ln.ev_window[parity], ln.main));
         HIPCHK(hipStreamWaitEvent(ax, ln.ev_window[parity], 0));
-        { ProfScope p(e, NRSC5HIP_PROF_AM_DECODE, ax); launch_am_decode(e->tb, ln.db, n, ids_dev, parity, lane, e->cfg.l2_feedback, ax); }
+        { ProfScope p(e, NRSC5HIP_PROF_AM_DECODE, ax); launch_am_decode(e->tb, ln.db, n, ids_dev, parity, lane, e->cfg.l2_feedback, ax, e->am_segments, e->am_warm, e->am_runin); }
         ln.am_step_count += 8 - (ln.am_step_count % 8);
     }
     for (int k = 0; k < NAUX; k++) HIPCHK(hipStreamSynchronize(ln.aux[k]));
@@ -733,28 +738,23 @@ static int run_steps_am(nrsc5hip_engine *e, int n, const int *ids_dev, int max_s
             for (; burst < check_every && done + burst < max_steps; burst++) {
                 const long long window = ln.am_step_count / 8;
                 const int parity = pipe ? (int)(window % NWIN) : -1, lane = (int)(window % e->naux_am);
-                if (pipe && (ln.am_step_count % 8) == 0 && ln.am_decoded_pending[parity]) {
-                    HIPCHK(hipStreamWaitEvent(ln.main, ln.ev_decoded[parity], 0));   // the window that used these buffers NWIN windows ago
-                    ln.am_decoded_pending[parity] = false;
+                if (pipe && (ln.am_step_count % 8) == 0) {
+                    // window boundary: the decode that used this window's buffers NWIN windows ago must have finished; with the
+                    // replay, take the first-header verdicts of every deferred decode that has (its job slot is reused next) --
+                    // no host round trip: the burst runs on across window boundaries
+                    if (ln.am_decoded_pending[parity]) { HIPCHK(hipStreamWaitEvent(ln.main, ln.ev_decoded[parity], 0)); ln.am_decoded_pending[parity] = false; }
+                    if (replay && ln.am_step_count > 0) launch_rollback_am(ln.db, n, ids_dev, (int)window, e->verdict_lag, ln.main);
                 }
                 { ProfScope p(e, NRSC5HIP_PROF_AM, ln.main); launch_am_step(e->tb, ln.db, n, ids_dev, ln.main, e->cfg.l2_feedback, parity, (int)(ln.am_step_count % 8), (int)window); }
                 if (pipe && (ln.am_step_count % 8) == 7) {
                     hipStream_t ax = ln.aux[lane];
                     HIPCHK(hipEventRecord(ln.ev_window[parity], ln.main));
                     HIPCHK(hipStreamWaitEvent(ax, ln.ev_window[parity], 0));
-                    { ProfScope p(e, NRSC5HIP_PROF_AM_DECODE, ax); launch_am_decode(e->tb, ln.db, n, ids_dev, parity, lane, e->cfg.l2_feedback, ax); }
+                    { ProfScope p(e, NRSC5HIP_PROF_AM_DECODE, ax); launch_am_decode(e->tb, ln.db, n, ids_dev, parity, lane, e->cfg.l2_feedback, ax, e->am_segments, e->am_warm, e->am_runin); }
                     HIPCHK(hipEventRecord(ln.ev_decoded[parity], ax));
                     ln.am_decoded_pending[parity] = true;
                 }
                 ln.am_step_count++;
-            }
-            if (replay && (ln.am_step_count % 8) == 0) {
-                // window boundary: take the first-header verdicts of the deferred decodes that have finished (the decode whose
-                // job slot the next window reuses must be among them)
-                const long long window = ln.am_step_count / 8;
-                const int parity = (int)(window % NWIN);
-                if (ln.am_decoded_pending[parity]) { HIPCHK(hipStreamWaitEvent(ln.main, ln.ev_decoded[parity], 0)); ln.am_decoded_pending[parity] = false; }
-                launch_rollback_am(ln.db, n, ids_dev, (int)window, e->verdict_lag, ln.main);
             }
             HIPCHK(hipMemcpyAsync(ln.counters_host, ln.counters_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, ln.main));
             HIPCHK(hipStreamSynchronize(ln.main));
@@ -1176,7 +1176,7 @@ extern "C" int nrsc5hip_batch_process(nrsc5hip_engine *e, int nstreams, const in
         if (!am.empty()) {
             int done_am = 0, done_fm = 0;
             HIPCHK(hipMemcpy(e->ids_dev, am.data(), am.size() * sizeof(int), hipMemcpyHostToDevice));
-            int rc = run_steps_am(e, (int)am.size(), e->ids_dev, max_steps > 0 ? max_steps : (1 << 30), 8, &done_am);
+            int rc = run_steps_am(e, (int)am.size(), e->ids_dev, max_steps > 0 ? max_steps : (1 << 30), e->cfg.p1_async ? 32 : 8, &done_am);
             if (rc) return rc;
             if (!fm.empty()) { rc = nrsc5hip_batch_process(e, (int)fm.size(), fm.data(), max_steps, &done_fm); if (rc) return rc; }
             if (steps_done) *steps_done = done_am > done_fm ? done_am : done_fm;
@@ -1439,8 +1439,11 @@ extern "C" int nrsc5hip_stage_viterbi_k9(nrsc5hip_engine *e, const int8_t *soft,
     HIPCHK(hipMalloc((void **)&ddec, (size_t)nframes * 4 * (len + 64) * sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void **)&dout, (size_t)nframes * words * sizeof(uint32_t)));
     HIPCHK(hipMemcpy(dsoft, soft, (size_t)nframes * 3 * len, hipMemcpyHostToDevice));
-    launch_viterbi_k9_frames(dsoft, len, nframes, gens[0], gens[1], gens[2], ddec, dout, e->main);
+    K9Meta *dmeta = nullptr;                                   // segment waves (the window pipeline's form) unless tuned down to one
+    if (e->am_segments > 1 && len > 80) HIPCHK(hipMalloc((void **)&dmeta, (size_t)nframes * sizeof(K9Meta)));
+    launch_viterbi_k9_frames(dsoft, len, nframes, gens[0], gens[1], gens[2], ddec, dout, e->main, 3, dmeta, e->am_segments, e->am_warm, e->am_runin, e->db.am_k9stats);
     HIPCHK(hipStreamSynchronize(e->main));
+    if (dmeta) (void)hipFree(dmeta);
     std::vector<uint32_t> w((size_t)nframes * words);
     HIPCHK(hipMemcpy(w.data(), dout, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
     for (int f = 0; f < nframes; f++) nrsc5hip_unpack_bits(w.data() + (size_t)f * words, len, bits + (size_t)f * len);
@@ -1684,20 +1687,39 @@ extern "C" int nrsc5hip_stage_viterbi_k9_bench(nrsc5hip_engine *e, int len, int 
     if (!e || !ms_per_launch || len < 128 || nframes < 1 || reps < 1) FAIL(NRSC5HIP_EINVAL, "bad argument");
     int8_t *dsoft = nullptr; unsigned long long *ddec = nullptr; uint32_t *dout = nullptr;
     const int words = (len + 31) / 32;
+    // tail-biting code words of random payloads (generators 0561 / 0753 / 0711, bit 8 - k of the register = payload bit i - k),
+    // one sign in 16 flipped: what the decoder sees on a healthy channel (pure noise would make every segment speculation fail)
     std::vector<int8_t> h((size_t)nframes * 3 * len);
+    std::vector<uint8_t> pay((size_t)len);
+    const unsigned gens[3] = { 0561, 0753, 0711 };
     unsigned x = 4321;
-    for (auto &v : h) { x = x * 1664525u + 1013904223u; v = (int8_t)((int)((x >> 24) % 3) - 1); }
+    for (int f = 0; f < nframes; f++) {
+        for (auto &v : pay) { x = x * 1664525u + 1013904223u; v = (uint8_t)((x >> 24) & 1u); }
+        for (int i = 0; i < len; i++) {
+            unsigned r = 0;
+            for (int k = 0; k < 9; k++) r |= (unsigned)pay[(size_t)((i - k + len) % len)] << (8 - k);
+            for (int j = 0; j < 3; j++) {
+                x = x * 1664525u + 1013904223u;
+                int v = (__builtin_popcount(r & gens[j]) & 1) ? 1 : -1;
+                if (((x >> 20) & 15u) == 0) v = -v;
+                h[((size_t)f * len + i) * 3 + j] = (int8_t)v;
+            }
+        }
+    }
     HIPCHK(hipMalloc((void **)&dsoft, h.size()));
     HIPCHK(hipMalloc((void **)&ddec, (size_t)nframes * 4 * (len + 64) * sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void **)&dout, (size_t)nframes * words * sizeof(uint32_t)));
     HIPCHK(hipMemcpy(dsoft, h.data(), h.size(), hipMemcpyHostToDevice));
     HIPCHK(hipMemset(ddec, 0x55, (size_t)nframes * 4 * (len + 64) * sizeof(unsigned long long)));
+    K9Meta *dmeta = nullptr;
+    if (e->am_segments > 1) HIPCHK(hipMalloc((void **)&dmeta, (size_t)nframes * sizeof(K9Meta)));
     hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-    launch_viterbi_k9_frames(dsoft, len, nframes, 0561, 0753, 0711, ddec, dout, e->main, phases);
+    launch_viterbi_k9_frames(dsoft, len, nframes, 0561, 0753, 0711, ddec, dout, e->main, 3, dmeta, e->am_segments, e->am_warm, e->am_runin, e->db.am_k9stats);
     HIPCHK(hipEventRecord(a, e->main));
-    for (int r = 0; r < reps; r++) launch_viterbi_k9_frames(dsoft, len, nframes, 0561, 0753, 0711, ddec, dout, e->main, phases);
+    for (int r = 0; r < reps; r++) launch_viterbi_k9_frames(dsoft, len, nframes, 0561, 0753, 0711, ddec, dout, e->main, phases, dmeta, e->am_segments, e->am_warm, e->am_runin, e->db.am_k9stats);
     HIPCHK(hipEventRecord(b, e->main));
     HIPCHK(hipEventSynchronize(b));
+    if (dmeta) (void)hipFree(dmeta);
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, a, b));
     *ms_per_launch = ms / reps;
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
@@ -1716,6 +1738,32 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
     case NRSC5HIP_TUNE_VERDICT_LAG:       e->verdict_lag = std::min(std::max(value, 0), NWIN); break;
     case NRSC5HIP_TUNE_FWD_SEGMENTS:      e->fwd_segments = std::min(std::max(value, 0), 16); break;
     case NRSC5HIP_TUNE_FWD_WARM:          e->fwd_warm = value > 0 ? 2 : 0; break;
+    case NRSC5HIP_TUNE_DECODE_CUS: {
+        // decode streams confined to value / 32 of the CUs (the pattern keeps that share of every XCD whichever way mask bits map to CUs)
+        const int k = std::min(std::max(value, 8), 32) & ~7;
+        hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, e->cfg.device));
+        const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+        std::vector<uint32_t> mask((size_t)words, 0u);
+        for (int i = 0; i < ncu; i++) if ((i % 32) < k) mask[(size_t)i / 32] |= 1u << (i % 32);
+        for (int a = 0; a < NAUX; a++) {
+            HIPCHK(hipStreamDestroy(e->lane.aux[a]));
+            if (k >= 32) HIPCHK(hipStreamCreate(&e->lane.aux[a]));
+            else HIPCHK(hipExtStreamCreateWithCUMask(&e->lane.aux[a], (uint32_t)words, mask.data()));
+        }
+        break;
+    }
+    case NRSC5HIP_TUNE_DECODE_PRIORITY: {
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        for (int a = 0; a < NAUX; a++) {
+            HIPCHK(hipStreamDestroy(e->lane.aux[a]));
+            if (value) HIPCHK(hipStreamCreateWithPriority(&e->lane.aux[a], hipStreamDefault, least));
+            else HIPCHK(hipStreamCreate(&e->lane.aux[a]));
+        }
+        break;
+    }
+    case NRSC5HIP_TUNE_AM_SEGMENTS:       e->am_segments = std::min(std::max(value, 1), K9_GMAX); break;
+    case NRSC5HIP_TUNE_AM_WARM:           e->am_warm = value > 0 ? K9_WARM : 0; e->am_runin = value > 0 ? K9_TB_RUNIN : 0; break;
     case NRSC5HIP_TUNE_SYNC_PHASES:
         if (value && !e->db.sync_phase_cycles) {
             int rc = dev_alloc(e, &e->db.sync_phase_cycles, 8); if (rc) return rc;
@@ -1733,6 +1781,14 @@ extern "C" int nrsc5hip_debug_fwd_stats(nrsc5hip_engine *e, int stats[2])
     if (!e || !stats) FAIL(NRSC5HIP_EINVAL, "null argument");
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(stats, e->db.fwd_stats, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int nrsc5hip_debug_k9_stats(nrsc5hip_engine *e, int stats[4])
+{
+    if (!e || !stats) FAIL(NRSC5HIP_EINVAL, "null argument");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(stats, e->db.am_k9stats, 4 * sizeof(int), hipMemcpyDeviceToHost));
     return 0;
 }
 

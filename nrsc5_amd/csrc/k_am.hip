@@ -248,19 +248,34 @@ __device__ inline int k9_soft_word(const int8_t *coded, int j)
     return (coded[3 * j] & 0xff) | ((coded[3 * j + 1] & 0xff) << 8) | ((coded[3 * j + 2] & 0xff) << 16);
 }
 
-__device__ inline void viterbi_k9_wave(const int8_t *coded, int len, unsigned g0, unsigned g1, unsigned g2,
-                                       unsigned long long *dec, uint32_t *out, K9WSmem &sm, int phases = 3)
+struct K9Signs { int a, b, c, d; };
+__device__ inline K9Signs k9_signs(int lane, unsigned g0, unsigned g1, unsigned g2)
+{
+    K9Signs sg;
+    sg.a = k9_sign_word(2u * lane, g0, g1, g2); sg.b = k9_sign_word(2u * lane + 1u, g0, g1, g2);             // step t: b = 2L + xh
+    sg.c = k9_sign_word((unsigned)lane, g0, g1, g2); sg.d = k9_sign_word((unsigned)lane + 64u, g0, g1, g2);   // step t+1: b = (i0 << 6) | L
+    return sg;
+}
+
+// A frame is steps = len + 2 * VIT_EXTRA trellis steps (even for every frame length of the AM path) = npairs step pairs, walked
+// forward in chunks of 64 step pairs and backward in chunks of 32.
+__host__ __device__ inline int k9_pairs(int len) { return (len + 2 * VIT_EXTRA) >> 1; }
+__host__ __device__ inline int k9_chunks(int len) { return (k9_pairs(len) + 63) >> 6; }
+
+// Forward pass over the chunks [c0, c1): the metrics are in sm.metric[0] on entry (every chunk but the frame's last is an even
+// number of step pairs, so a chunk boundary always finds them there); returns the half that holds them after the last pair.
+// Decisions are written for chunks >= cstore only (a segment wave's warm-up chunks belong to its predecessor), and the metrics
+// the wave enters chunk `cstore` with go to `snap` (k9_forward_fix checks them against the predecessor's end metrics).
+__device__ inline int k9_forward_chunks(const int8_t *coded, int len, const K9Signs &sg, unsigned long long *dec, K9WSmem &sm,
+                                        int c0, int c1, int cstore, int *snap)
 {
     const int lane = threadIdx.x & 63;
-    const int sgA = k9_sign_word(2u * lane, g0, g1, g2), sgB = k9_sign_word(2u * lane + 1u, g0, g1, g2);   // step t: b = 2L + xh
-    const int sgC = k9_sign_word((unsigned)lane, g0, g1, g2), sgD = k9_sign_word((unsigned)lane + 64u, g0, g1, g2);   // step t+1: b = (i0 << 6) | L
-    const int steps = len + 2 * VIT_EXTRA, j0 = len - VIT_EXTRA;       // even: every frame length of the AM path is even
-    const int npairs = steps >> 1, nchunks = (npairs + 63) >> 6;
+    const int j0 = len - VIT_EXTRA, npairs = k9_pairs(len);
     int cur = 0;
-    for (int k = 0; k < 4; k++) sm.metric[0][4 * lane + k] = 0;
-    WAVE_LDS_SYNC();
-    for (int c = 0; c < ((phases & 1) ? nchunks : 0); c++) {
+    for (int c = c0; c < c1; c++) {
         const int p0 = c << 6, np = min(64, npairs - p0);
+        if (snap && c == cstore) *(int4 *)&snap[4 * lane] = *(const int4 *)&sm.metric[cur][4 * lane];
+        const bool store = c >= cstore;                        // wave-uniform
         int aw0 = 0, aw1 = 0;                                   // this lane's step pair of the chunk
         if (lane < np) {
             const int t = 2 * (p0 + lane);
@@ -269,7 +284,7 @@ __device__ inline void viterbi_k9_wave(const int8_t *coded, int len, unsigned g0
         }
         for (int s = 0; s < np; s++) {
             const int a0 = wave_readlane(aw0, s), a1 = wave_readlane(aw1, s);
-            const int mA = dot4_i8(a0, sgA, 0), mB = dot4_i8(a0, sgB, 0), nC = dot4_i8(a1, sgC, 0), nD = dot4_i8(a1, sgD, 0);
+            const int mA = dot4_i8(a0, sg.a, 0), mB = dot4_i8(a0, sg.b, 0), nC = dot4_i8(a1, sg.c, 0), nD = dot4_i8(a1, sg.d, 0);
             const int4 old = *(const int4 *)&sm.metric[cur][4 * lane];
             // step t
             const int e00 = old.x + mA, o00 = old.y - mA, e10 = old.x - mA, o10 = old.y + mA;   // xh = 0: i0 = 0, i0 = 1
@@ -288,33 +303,43 @@ __device__ inline void viterbi_k9_wave(const int8_t *coded, int len, unsigned g0
             // this lane's eight decisions of the step pair in one byte: bit i0*2+xh for step t, bit 4+i1*2+i0 for step t+1
             const unsigned dbyte = (t00 ? 0u : 1u) | (t01 ? 0u : 2u) | (t10 ? 0u : 4u) | (t11 ? 0u : 8u)
                                  | (r00 ? 0u : 16u) | (r01 ? 0u : 32u) | (r10 ? 0u : 64u) | (r11 ? 0u : 128u);
-            ((uint8_t *)dec)[(size_t)(p0 + s) * 64 + lane] = (uint8_t)dbyte;     // one 64-byte row per step pair, fire and forget
+            if (store) ((uint8_t *)dec)[(size_t)(p0 + s) * 64 + lane] = (uint8_t)dbyte;     // one 64-byte row per step pair, fire and forget
             cur ^= 1;
             WAVE_LDS_SYNC();
         }
     }
-    // end state: first maximum in state order (conv_dec.c:310-318)
-    unsigned state;
-    {
-        const int4 m = *(const int4 *)&sm.metric[cur][4 * lane];
-        int v = m.x, idx = 4 * lane;
-        if (m.y > v) { v = m.y; idx = 4 * lane + 1; }
-        if (m.z > v) { v = m.z; idx = 4 * lane + 2; }
-        if (m.w > v) { v = m.w; idx = 4 * lane + 3; }
-        for (int k = 32; k >= 1; k >>= 1) {
-            const int ov = __shfl_xor(v, k), oi = __shfl_xor(idx, k);
-            if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
-        }
-        state = (unsigned)wave_uniform(idx);
+    return cur;
+}
+
+// end state: first maximum in state order (conv_dec.c:310-318); m = this lane's metrics of states 4L .. 4L+3
+__device__ inline unsigned k9_end_state(int4 m)
+{
+    const int lane = threadIdx.x & 63;
+    int v = m.x, idx = 4 * lane;
+    if (m.y > v) { v = m.y; idx = 4 * lane + 1; }
+    if (m.z > v) { v = m.z; idx = 4 * lane + 2; }
+    if (m.w > v) { v = m.w; idx = 4 * lane + 3; }
+    for (int k = 32; k >= 1; k >>= 1) {
+        const int ov = __shfl_xor(v, k), oi = __shfl_xor(idx, k);
+        if (ov > v || (ov == v && oi < idx)) { v = ov; idx = oi; }
     }
-    __threadfence_block();
-    __syncthreads();
-    // traceback, two steps per iteration; 32 step pairs of decisions at a time are staged in LDS and looked up at a
-    // wave-uniform address
-    unsigned long long *stage = (unsigned long long *)&sm.metric[0][0];      // the metrics are dead: 2 KB = 32 step pairs of decisions
+    return (unsigned)wave_uniform(idx);
+}
+
+// Traceback over the 32-pair chunks c_hi - 1 .. c_lo (downwards) from `state`, two steps per iteration; a chunk's decisions are
+// staged in LDS (the metrics are dead: 2 KB = 32 step pairs) and looked up at a wave-uniform address.  Output words are written for
+// chunks < c_out only (the chunks above are a segment wave's run-in); `arrive` = the state on entering chunk c_out - 1.
+// Chunk c holds steps 64 c .. 64 c + 63 = frame bits 64 c - 32 .. 64 c + 31: words 2c - 1 (low half) and 2c (high half), and no
+// other chunk writes those words.
+__device__ inline unsigned k9_traceback_chunks(const unsigned long long *dec, int len, K9WSmem &sm, unsigned state, int c_hi, int c_lo, int c_out,
+                                               uint32_t *out, unsigned &arrive)
+{
+    const int lane = threadIdx.x & 63;
+    const int steps = len + 2 * VIT_EXTRA, npairs = k9_pairs(len);
+    unsigned long long *stage = (unsigned long long *)&sm.metric[0][0];
     const uint8_t *db8 = (const uint8_t *)stage;
-    const int ntb = (npairs + 31) >> 5;
-    for (int c = ((phases & 2) ? ntb - 1 : -1); c >= 0; c--) {
+    for (int c = c_hi - 1; c >= c_lo; c--) {
+        if (c == c_out - 1) arrive = state;
         const int p0 = c << 5, np = min(32, npairs - p0);
         for (int k = lane; k < 8 * np; k += 64) stage[k] = dec[(size_t)p0 * 8 + k];
         WAVE_LDS_SYNC();
@@ -328,13 +353,117 @@ __device__ inline void viterbi_k9_wave(const int8_t *coded, int len, unsigned g0
             state = (unsigned)wave_uniform((int)((L << 2) | (xh << 1) | xl));
         }
         WAVE_LDS_SYNC();
-        // steps 64 c .. 64 c + 63 are frame bits 64 c - 32 .. 64 c + 31: words 2c - 1 (low half) and 2c (high half)
-        if (lane == 0) {
+        if (lane == 0 && c < c_out) {
             const int wl = 2 * c - 1, wh = 2 * c;
             if (wl >= 0 && wl * 32 < len) out[wl] = (uint32_t)obits;
             if (wh * 32 < len && 2 * p0 + 32 < steps) out[wh] = (uint32_t)(obits >> 32);
         }
     }
+    return state;
+}
+
+__device__ inline void viterbi_k9_wave(const int8_t *coded, int len, unsigned g0, unsigned g1, unsigned g2,
+                                       unsigned long long *dec, uint32_t *out, K9WSmem &sm, int phases = 3)
+{
+    const int lane = threadIdx.x & 63;
+    const K9Signs sg = k9_signs(lane, g0, g1, g2);
+    const int npairs = k9_pairs(len), nchunks = k9_chunks(len);
+    for (int k = 0; k < 4; k++) sm.metric[0][4 * lane + k] = 0;   // reset_decoder: all-zero for tail biting
+    WAVE_LDS_SYNC();
+    const int cur = (phases & 1) ? k9_forward_chunks(coded, len, sg, dec, sm, 0, nchunks, 0, nullptr) : 0;
+    unsigned state = k9_end_state(*(const int4 *)&sm.metric[cur][4 * lane]);
+    __threadfence_block();
+    __syncthreads();
+    unsigned arrive = 0;
+    if (phases & 2) k9_traceback_chunks(dec, len, sm, state, (npairs + 31) >> 5, 0, (npairs + 31) >> 5, out, arrive);
+    __threadfence_block();
+    __syncthreads();
+}
+
+// ---- the same decode in segment waves ---------------------------------------------------------------------------------
+// FORWARD.  The chunks of a frame are cut into up to K9_GMAX segments, one wave each, all running at once.  Segment g > 0 cannot
+// know the metrics its first step starts from, so it starts `warm` chunks early from all-zero metrics -- survivor paths merge
+// within a few constraint lengths, after which metric DIFFERENCES no longer depend on where the wave started -- and notes the
+// metrics it reaches its first own step with (snap).  Decisions depend on metric differences only (int32 sums, no saturation,
+// no normalisation): k9_forward_fix walks the boundaries in order and accepts segment g iff snap[g] - snap[g][0] equals the TRUE
+// end metrics of segment g - 1 minus their element 0; otherwise it re-runs segment g from those.  Exact for any segment count and
+// any warm-up, including 0 (the test hook that forces every repair).
+// TRACEBACK.  Segment g < last starts K9_TB_RUNIN chunks above its own chunks from state 0 -- survivors merge going backwards
+// too -- and notes the state it enters its own chunks with (arrive) and leaves them with (leave); the last segment starts from
+// the true end state.  k9_traceback_fix walks down from the last segment: segment g is accepted iff arrive[g] is the state the
+// segment above truly left with, else it is walked again from that state.  Output words are per chunk, so a repair rewrites
+// exactly the words of its segment.
+// K9_GMAX, K9_WARM (chunks of 64 step pairs) and K9_TB_RUNIN (chunks of 32 step pairs): nrsc5_dev.h
+
+__host__ __device__ inline int k9_seg_chunks(int len, int G) { return (k9_chunks(len) + G - 1) / G; }
+__host__ __device__ inline int k9_seg_count(int len, int G) { const int per = k9_seg_chunks(len, G); return (k9_chunks(len) + per - 1) / per; }
+
+__device__ inline void k9_forward_segment(const int8_t *coded, int len, unsigned g0, unsigned g1, unsigned g2, unsigned long long *dec,
+                                          K9Meta &meta, K9WSmem &sm, int g, int G, int warm)
+{
+    const int lane = threadIdx.x & 63;
+    const int nch = k9_chunks(len), per = k9_seg_chunks(len, G);
+    const int c0 = g * per, c1 = min(nch, c0 + per);
+    if (c0 >= nch) return;                                     // wave-uniform
+    const K9Signs sg = k9_signs(lane, g0, g1, g2);
+    for (int k = 0; k < 4; k++) sm.metric[0][4 * lane + k] = 0;
+    WAVE_LDS_SYNC();
+    const int cur = k9_forward_chunks(coded, len, sg, dec, sm, g ? max(0, c0 - warm) : 0, c1, c0, g ? meta.snap[g] : nullptr);
+    *(int4 *)&meta.uend[g][4 * lane] = *(const int4 *)&sm.metric[cur][4 * lane];
+}
+
+// one wave per frame, after every segment wave has finished: returns the end state of the frame
+__device__ inline unsigned k9_forward_fix(const int8_t *coded, int len, unsigned g0, unsigned g1, unsigned g2, unsigned long long *dec,
+                                          K9Meta &meta, K9WSmem &sm, int G, unsigned *stats)
+{
+    const int lane = threadIdx.x & 63;
+    const int nch = k9_chunks(len), per = k9_seg_chunks(len, G), nseg = k9_seg_count(len, G);
+    const K9Signs sg = k9_signs(lane, g0, g1, g2);
+    int4 tend = *(const int4 *)&meta.uend[0][4 * lane];        // true end metrics of the segment below, up to a constant
+    unsigned repairs = 0;
+    for (int g = 1; g < nseg; g++) {
+        const int4 a = *(const int4 *)&meta.snap[g][4 * lane];
+        const int a0 = wave_readlane(a.x, 0), b0 = wave_readlane(tend.x, 0);
+        const bool same = a.x - a0 == tend.x - b0 && a.y - a0 == tend.y - b0 && a.z - a0 == tend.z - b0 && a.w - a0 == tend.w - b0;
+        if (__all(same)) { tend = *(const int4 *)&meta.uend[g][4 * lane]; continue; }
+        *(int4 *)&sm.metric[0][4 * lane] = tend;
+        WAVE_LDS_SYNC();
+        const int c0 = g * per, c1 = min(nch, c0 + per);
+        const int cur = k9_forward_chunks(coded, len, sg, dec, sm, c0, c1, c0, nullptr);
+        tend = *(const int4 *)&sm.metric[cur][4 * lane];
+        WAVE_LDS_SYNC();
+        repairs++;
+    }
+    if (stats && lane == 0) { atomicAdd(&stats[0], (unsigned)(nseg - 1)); if (repairs) atomicAdd(&stats[1], repairs); }
+    return k9_end_state(tend);
+}
+
+__device__ inline void k9_traceback_segment(const unsigned long long *dec, int len, K9Meta &meta, K9WSmem &sm, uint32_t *out, int g, int G, int runin)
+{
+    const int nch = k9_chunks(len), per = k9_seg_chunks(len, G), nseg = k9_seg_count(len, G);
+    if (g >= nseg) return;                                     // wave-uniform
+    const int ntb = (k9_pairs(len) + 31) >> 5;
+    const int lo = 2 * g * per, hi = min(ntb, 2 * min(nch, (g + 1) * per));
+    const bool last = g == nseg - 1;
+    unsigned arrive = last ? meta.end_state : 0u;
+    const unsigned leave = k9_traceback_chunks(dec, len, sm, arrive, last ? hi : min(ntb, hi + runin), lo, hi, out, arrive);
+    if ((threadIdx.x & 63) == 0) { meta.arrive[g] = arrive; meta.leave[g] = leave; }
+}
+
+// one wave per frame, after every traceback segment wave has finished
+__device__ inline void k9_traceback_fix(const unsigned long long *dec, int len, K9Meta &meta, K9WSmem &sm, uint32_t *out, int G, unsigned *stats)
+{
+    const int nch = k9_chunks(len), per = k9_seg_chunks(len, G), nseg = k9_seg_count(len, G);
+    const int ntb = (k9_pairs(len) + 31) >> 5;
+    unsigned truth = (unsigned)wave_uniform((int)meta.leave[nseg - 1]), repairs = 0;
+    for (int g = nseg - 2; g >= 0; g--) {
+        if ((unsigned)wave_uniform((int)meta.arrive[g]) == truth) { truth = (unsigned)wave_uniform((int)meta.leave[g]); continue; }
+        const int lo = 2 * g * per, hi = min(ntb, 2 * min(nch, (g + 1) * per));
+        unsigned arrive = 0;
+        truth = k9_traceback_chunks(dec, len, sm, truth, hi, lo, hi, out, arrive);
+        repairs++;
+    }
+    if (stats && (threadIdx.x & 63) == 0) { atomicAdd(&stats[2], (unsigned)(nseg - 1)); if (repairs) atomicAdd(&stats[3], repairs); }
     __threadfence_block();
     __syncthreads();
 }
@@ -879,17 +1008,15 @@ __global__ __launch_bounds__(64) void k_am_viterbi(DevTables tb, DevBuffers db, 
             out[w] = (out[w] ^ tb.scr_p1[w]) & (w == AM_P1_WORDS - 1 ? (1u << (AM_P1_LEN & 31)) - 1u : 0xffffffffu);
         __threadfence_block();
         __syncthreads();
+        static_assert(sizeof(L2Smem) <= sizeof(K9WSmem), "L2 scratch aliases the trellis scratch");
+        L2Smem &l2 = *(L2Smem *)&k9;                           // the trellis scratch is dead by now
+        const bool hdr_ok = l2_feedback ? l2_first_header_ok_am_block(out, l2) : true;     // frame.c:535-540 for the 466-byte AM PDU
         if (threadIdx.x == 0) {
             atomicAdd(&am.am_errors, (unsigned)err);
             atomicOr(&rec.flags, (uint32_t)REC_P1);
             rec.p1_slot = am.frame_slot;
-            if (l2_feedback) {                                 // frame.c:535-540 for the 466-byte AM PDU
-                static_assert(sizeof(L2Smem) <= sizeof(K9WSmem), "L2 scratch aliases the trellis scratch");
-                L2Smem &l2 = *(L2Smem *)&k9;                   // the trellis scratch is dead by now
-                l2_gf_init(l2);
-                StreamState &stw = db.state[s];
-                if (!l2_first_header_ok_am(out, l2) && stw.sync_state == SYNC_FINE) { stw.sync_state = SYNC_NONE; rec.state_after = SYNC_NONE; atomicOr(&rec.flags, (uint32_t)REC_LOST_SYNC); }
-            }
+            StreamState &stw = db.state[s];
+            if (!hdr_ok && stw.sync_state == SYNC_FINE) { stw.sync_state = SYNC_NONE; rec.state_after = SYNC_NONE; atomicOr(&rec.flags, (uint32_t)REC_LOST_SYNC); }
         }
     } else {
         const int8_t *in = db.am_vit + (size_t)s * db.am_nvit * 2 * AM_VIT + AM_VIT;
@@ -934,8 +1061,8 @@ __device__ inline int8_t am_deint_one(uint2 e, const uint8_t *sym, uint8_t *q, i
 // The 162 000 (MA1) / 180 000 (MA3) trellis inputs of an L1 frame are independent table look-ups (every cell of the diversity delay
 // lines is visited by exactly one of them), so the frame is cut into AM_IL_PARTS slices, one workgroup each: with diverse streams an
 // eighth of the batch finishes an L1 frame in any one step, and one workgroup per stream left 7 of 8 CUs idle for the 90 us such a
-// step then took.  The bookkeeping that ends the frame -- delay-line head, ring slot and decode job of the next frame -- runs after
-// ALL slices, in k_am_interleave_commit.
+// step then took.  The bookkeeping that ends the frame -- delay-line head, ring slot and decode job of the next frame -- is done by
+// the slice that finishes last (AmStream::il_done counts them).
 constexpr int AM_IL_PARTS = 8;
 
 __device__ inline void am_deinterleave_slice(const DevTables &tb, const DevBuffers &db, int s, int parity, int part)
@@ -967,7 +1094,7 @@ __device__ inline void am_deinterleave_slice(const DevTables &tb, const DevBuffe
     else for (int i = i0; i < AM_VIT; i += step) v3[i] = am_deint_one(tb.am_deint_p3_ma3[i], sym, q, head);
 }
 
-// after every slice of the frame: advance the delay lines, reserve the ring slot and the decode job of the next L1 frame
+// after EVERY slice of the frame: advance the delay lines, reserve the ring slot and the decode job of the next L1 frame
 __device__ inline void am_deinterleave_commit(const DevBuffers &db, int s, int parity, int window)
 {
     AmStream &am = db.am[s];
@@ -988,39 +1115,82 @@ __device__ inline void am_deinterleave_commit(const DevBuffers &db, int s, int p
     }
 }
 
-__global__ __launch_bounds__(1024) void k_am_interleave(DevTables tb, DevBuffers db, const int *ids, int parity)
+__global__ __launch_bounds__(1024) void k_am_interleave(DevTables tb, DevBuffers db, const int *ids, int parity, int window)
 {
     wave_set_priority_high();
     const int s = stream_of(ids, blockIdx.y);
     const StreamState &st = db.state[s];
-    const AmStream &am = db.am[s];
+    AmStream &am = db.am[s];
     if (!st.active || am.dec_bc != 7) return;                  // block-uniform
     am_deinterleave_slice(tb, db, s, parity, (int)blockIdx.x);
-}
-
-__global__ __launch_bounds__(64) void k_am_interleave_commit(DevBuffers db, const int *ids, int nstreams, int parity, int window)
-{
-    const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sidx >= nstreams) return;
-    const int s = stream_of(ids, sidx);
-    if (!db.state[s].active || db.am[s].dec_bc != 7) return;
-    am_deinterleave_commit(db, s, parity, window);
+    // the slice that finishes last commits the frame: every other slice has read q_head / dec_* by then (their loads completed
+    // before the barrier below; no fence -- an agent-scope fence per work-item writes back and invalidates L2 two million times a
+    // launch, measured: the pass 98 -> 143 ms)
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(&am.il_done, 1u) == (unsigned)(AM_IL_PARTS - 1)) {
+        am.il_done = 0;
+        am_deinterleave_commit(db, s, parity, window);
+    }
 }
 
 // ---- window pipeline: all nine frames of an L1 frame decode concurrently on a decode stream ---------------------------
-__global__ __launch_bounds__(64) void k_am_decode(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id, int l2_feedback)
+// Four launches (the P3 frame is 6.4 / 8 times a P1 frame: as ONE wave it kept the launch -- and a decode stream -- alive for
+// 4-5 ms after the P1 waves had gone; in K9_GMAX segment waves every wave of the launch is about one P1 frame long):
+//   k_am_decode_fwd     forward pass: 8 P1 waves, G P3 segment waves, 8 PIDS frames (whole: 144 steps)
+//   k_am_decode_fix     P3: segment boundaries checked / re-run, end state
+//   k_am_decode_tb      traceback: P1 frames whole + BER, descramble, first-header verdict; P3 in G segment waves
+//   k_am_decode_finish  P3: traceback boundaries checked / re-walked, BER, descramble; frame accounting
+struct AmDecodeFrame { const int8_t *in; uint32_t *out; unsigned long long *dec; int len; unsigned g0, g1, g2; };
+
+__device__ inline AmDecodeFrame am_decode_frame(const DevBuffers &db, const AmJob &job, int s, int parity, int lane_id, int role)
 {
-    const int s = stream_of(ids, blockIdx.y), role = blockIdx.x;           // 0..7: P1 frame of that block, 8: P3, 9..16: PIDS frames
+    AmDecodeFrame f;
+    const int8_t *vit = db.am_vit + ((size_t)s * db.am_nvit + parity) * 2 * AM_VIT;
+    uint32_t *slot = db.p1_ring + ((size_t)s * db.p1_slots + job.slot) * P1_WORDS;
+    unsigned long long *dec = db.am_dec + ((size_t)lane_id * db.nstreams_alloc + s) * (size_t)(8 * AM_DEC_P1 + AM_DEC_P3);
+    if (role < 8) {
+        f.in = vit + (size_t)role * AM_P1_LEN * 3; f.out = slot + role * AM_P1_WORDS; f.dec = dec + (size_t)role * AM_DEC_P1;
+        f.len = AM_P1_LEN; f.g0 = GEN_E1_0; f.g1 = GEN_E1_1; f.g2 = GEN_E1_2;
+    } else {
+        const bool ma3 = job.psmi == AM_MA3;
+        f.in = vit + AM_VIT; f.out = slot + AM_P3_WORD0; f.dec = dec + (size_t)8 * AM_DEC_P1;
+        f.len = ma3 ? AM_P3_LEN_MA3 : AM_P3_LEN_MA1;
+        f.g0 = ma3 ? GEN_E1_0 : GEN_E2_0; f.g1 = ma3 ? GEN_E1_1 : GEN_E2_1; f.g2 = ma3 ? GEN_E1_2 : GEN_E2_2;
+    }
+    return f;
+}
+
+// the frame is decoded: count it, and the last of the L1 frame's decodes closes the job (nrsc5_report_ber's value, decode.c:545)
+__device__ inline void am_decode_account(const DevBuffers &db, AmJob &job, int s, int err)
+{
+    if (threadIdx.x != 0) return;
+    atomicAdd(&job.errors, (unsigned)err);
+    __threadfence();
+    const int expected = job.rdbi ? 8 : 9;
+    if (atomicAdd(&job.done, 1) == expected - 1) {
+        const bool ma3 = job.psmi == AM_MA3;
+        unsigned total = 8 * (AM_P1_LEN * 12 / 5);
+        if (!job.rdbi) total += ma3 ? AM_P3_LEN_MA3 * 12 / 5 : AM_P3_LEN_MA1 * 3 / 2;
+        db.am_ber[(size_t)s * db.p1_slots + job.slot] = (float)atomicAdd(&job.errors, 0u) / (float)total;
+        job.pad = db.l2_am_ring ? (job.rdbi ? 0xff : 0x1ff) : 0;      // frames k_l2_index_am_window owes their index
+        job.valid = 0;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_am_decode_fwd(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id, int G, int warm)
+{
+    const int s = stream_of(ids, blockIdx.y), role = blockIdx.x;           // 0..7: P1 frame of that block, 8..8+G-1: P3 segment, then 8 PIDS frames
     __shared__ K9WSmem k9;
-    if (role >= 9) {
-        // decode_process_pids_am's trellis (decode.c:502-504) for the block processed in step `role - 9` of this window
-        int *recp = db.am_pids_rec + ((size_t)s * NWIN + parity) * 8 + (role - 9);
+    if (role >= 8 + G) {
+        // decode_process_pids_am's trellis (decode.c:502-504) for the block processed in step `pb` of this window
+        const int pb = role - 8 - G;
+        int *recp = db.am_pids_rec + ((size_t)s * NWIN + parity) * 8 + pb;
         const int r = *recp;
         if (r < 0) return;                                                 // wave-uniform
         __shared__ uint32_t pout[4];
-        const int8_t *stage = db.am_pids_stage + (((size_t)s * NWIN + parity) * 8 + (role - 9)) * (3 * PIDS_LEN);
+        const int8_t *stage = db.am_pids_stage + (((size_t)s * NWIN + parity) * 8 + pb) * (3 * PIDS_LEN);
         unsigned long long *pdec = db.am_dec + ((size_t)lane_id * db.nstreams_alloc + s) * (size_t)(8 * AM_DEC_P1 + AM_DEC_P3)
-                                 + (size_t)8 * AM_DEC_P1 + AM_DEC_P3 - (size_t)(9 - (role - 9)) * 4 * (PIDS_LEN + 64);   // tail of the P3 scratch: its frame is shorter than AM_P3_LEN_MA3 + 64 only by the slack reserved here
+                                 + (size_t)8 * AM_DEC_P1 + AM_DEC_P3 - (size_t)(9 - pb) * 4 * (PIDS_LEN + 64);   // tail of the P3 scratch: its frame is shorter than AM_P3_LEN_MA3 + 64 only by the slack reserved here
         viterbi_k9_wave(stage, PIDS_LEN, GEN_E2_0, GEN_E2_1, GEN_E2_2, pdec, pout, k9);
         if (threadIdx.x == 0) {
             BlockRecord &rec = db.records[(size_t)s * db.rec_cap + r];
@@ -1030,63 +1200,93 @@ __global__ __launch_bounds__(64) void k_am_decode(DevTables tb, DevBuffers db, c
         }
         return;
     }
-    AmJob &job = db.am_job[(size_t)s * NWIN + parity];
+    const AmJob &job = db.am_job[(size_t)s * NWIN + parity];
     if (!job.valid) return;                                                // wave-uniform
-    if (role == 8 && job.rdbi) return;
-    __shared__ int red[4];
-    const bool ma3 = job.psmi == AM_MA3;
-    const int8_t *vit = db.am_vit + ((size_t)s * db.am_nvit + parity) * 2 * AM_VIT;
-    uint32_t *slot = db.p1_ring + ((size_t)s * db.p1_slots + job.slot) * P1_WORDS;
-    unsigned long long *dec = db.am_dec + ((size_t)lane_id * db.nstreams_alloc + s) * (size_t)(8 * AM_DEC_P1 + AM_DEC_P3);
-    int err;
+    if (role >= 8 && job.rdbi) return;
+    K9Meta &meta = db.am_k9meta[(size_t)lane_id * db.nstreams_alloc + s];
+    const AmDecodeFrame f = am_decode_frame(db, job, s, parity, lane_id, role);
     if (role < 8) {
-        const int8_t *in = vit + (size_t)role * AM_P1_LEN * 3;
-        uint32_t *out = slot + role * AM_P1_WORDS;
-        viterbi_k9_wave(in, AM_P1_LEN, GEN_E1_0, GEN_E1_1, GEN_E1_2, dec + (size_t)role * AM_DEC_P1, out, k9);
-        err = am_bit_errors(in, out, AM_P1_LEN, GEN_E1_0, GEN_E1_1, GEN_E1_2, PUNCT_E1, 15, red);
-        for (int w = threadIdx.x; w < AM_P1_WORDS; w += 64)
-            out[w] = (out[w] ^ tb.scr_p1[w]) & (w == AM_P1_WORDS - 1 ? (1u << (AM_P1_LEN & 31)) - 1u : 0xffffffffu);
-        __threadfence_block();
-        __syncthreads();
-        if (l2_feedback && threadIdx.x == 0) {                 // frame.c:535-540: file the verdict for the block that delivers this PDU
-            L2Smem &l2 = *(L2Smem *)&k9;                       // the trellis scratch is dead by now
-            l2_gf_init(l2);
-            const bool ok = l2_first_header_ok_am(out, l2);
-            __threadfence();
-            atomicExch(&job.verdict[role], ok ? 1 : 2);
-        }
+        const int lane = threadIdx.x;
+        const K9Signs sg = k9_signs(lane, f.g0, f.g1, f.g2);
+        for (int k = 0; k < 4; k++) k9.metric[0][4 * lane + k] = 0;
+        WAVE_LDS_SYNC();
+        const int cur = k9_forward_chunks(f.in, f.len, sg, f.dec, k9, 0, k9_chunks(f.len), 0, nullptr);
+        const unsigned end = k9_end_state(*(const int4 *)&k9.metric[cur][4 * lane]);
+        if (lane == 0) meta.p1_end[role] = end;
     } else {
-        const int8_t *in = vit + AM_VIT;
-        uint32_t *out = slot + AM_P3_WORD0;
-        const int len = ma3 ? AM_P3_LEN_MA3 : AM_P3_LEN_MA1;
-        if (!ma3) {
-            viterbi_k9_wave(in, len, GEN_E2_0, GEN_E2_1, GEN_E2_2, dec + (size_t)8 * AM_DEC_P1, out, k9);
-            err = am_bit_errors(in, out, len, GEN_E2_0, GEN_E2_1, GEN_E2_2, PUNCT_E2, 6, red);
-        } else {
-            viterbi_k9_wave(in, len, GEN_E1_0, GEN_E1_1, GEN_E1_2, dec + (size_t)8 * AM_DEC_P1, out, k9);
-            err = am_bit_errors(in, out, len, GEN_E1_0, GEN_E1_1, GEN_E1_2, PUNCT_E1, 15, red);
-        }
-        const int words = (len + 31) / 32;
-        const uint32_t tailmask = (len & 31) ? (1u << (len & 31)) - 1u : 0xffffffffu;
-        for (int w = threadIdx.x; w < words; w += 64) out[w] = (out[w] ^ tb.scr_p1[w]) & (w == words - 1 ? tailmask : 0xffffffffu);
-    }
-    if (threadIdx.x == 0) {
-        atomicAdd(&job.errors, (unsigned)err);
-        __threadfence();
-        const int expected = job.rdbi ? 8 : 9;
-        if (atomicAdd(&job.done, 1) == expected - 1) {         // last of the frame's decodes: nrsc5_report_ber's value (decode.c:545)
-            unsigned total = 8 * (AM_P1_LEN * 12 / 5);
-            if (!job.rdbi) total += ma3 ? AM_P3_LEN_MA3 * 12 / 5 : AM_P3_LEN_MA1 * 3 / 2;
-            db.am_ber[(size_t)s * db.p1_slots + job.slot] = (float)atomicAdd(&job.errors, 0u) / (float)total;
-            job.pad = db.l2_am_ring ? (job.rdbi ? 0xff : 0x1ff) : 0;      // frames k_l2_index_am_window owes their index
-            job.valid = 0;
-        }
+        k9_forward_segment(f.in, f.len, f.g0, f.g1, f.g2, f.dec, meta, k9, role - 8, G, warm);
     }
 }
 
-void launch_am_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, int l2_feedback, hipStream_t st)
+__global__ __launch_bounds__(64) void k_am_decode_fix(DevBuffers db, const int *ids, int parity, int lane_id, int G)
 {
-    hipLaunchKernelGGL(k_am_decode, dim3(17, nstreams), dim3(64), 0, st, tb, db, stream_ids, parity, lane_id, l2_feedback);
+    const int s = stream_of(ids, blockIdx.x);
+    const AmJob &job = db.am_job[(size_t)s * NWIN + parity];
+    if (!job.valid || job.rdbi) return;                                    // wave-uniform
+    __shared__ K9WSmem k9;
+    K9Meta &meta = db.am_k9meta[(size_t)lane_id * db.nstreams_alloc + s];
+    const AmDecodeFrame f = am_decode_frame(db, job, s, parity, lane_id, 8);
+    const unsigned end = k9_forward_fix(f.in, f.len, f.g0, f.g1, f.g2, f.dec, meta, k9, G, db.am_k9stats);
+    if (threadIdx.x == 0) meta.end_state = end;
+}
+
+__global__ __launch_bounds__(64) void k_am_decode_tb(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id, int G, int runin, int l2_feedback)
+{
+    const int s = stream_of(ids, blockIdx.y), role = blockIdx.x;           // 0..7: P1 frame of that block, 8..8+G-1: P3 segment
+    AmJob &job = db.am_job[(size_t)s * NWIN + parity];
+    if (!job.valid) return;                                                // wave-uniform
+    if (role >= 8 && job.rdbi) return;
+    __shared__ K9WSmem k9;
+    __shared__ int red[4];
+    K9Meta &meta = db.am_k9meta[(size_t)lane_id * db.nstreams_alloc + s];
+    const AmDecodeFrame f = am_decode_frame(db, job, s, parity, lane_id, role);
+    if (role >= 8) { k9_traceback_segment(f.dec, f.len, meta, k9, f.out, role - 8, G, runin); return; }
+    unsigned arrive = 0;
+    const int ntb = (k9_pairs(f.len) + 31) >> 5;
+    k9_traceback_chunks(f.dec, f.len, k9, (unsigned)wave_uniform((int)meta.p1_end[role]), ntb, 0, ntb, f.out, arrive);
+    __threadfence_block();
+    __syncthreads();
+    uint32_t *out = f.out;
+    const int err = am_bit_errors(f.in, out, AM_P1_LEN, GEN_E1_0, GEN_E1_1, GEN_E1_2, PUNCT_E1, 15, red);
+    for (int w = threadIdx.x; w < AM_P1_WORDS; w += 64)
+        out[w] = (out[w] ^ tb.scr_p1[w]) & (w == AM_P1_WORDS - 1 ? (1u << (AM_P1_LEN & 31)) - 1u : 0xffffffffu);
+    __threadfence_block();
+    __syncthreads();
+    if (l2_feedback) {                                         // frame.c:535-540: file the verdict for the block that delivers this PDU
+        L2Smem &l2 = *(L2Smem *)&k9;                           // the trellis scratch is dead by now
+        const bool ok = l2_first_header_ok_am_block(out, l2);
+        if (threadIdx.x == 0) { __threadfence(); atomicExch(&job.verdict[role], ok ? 1 : 2); }
+    }
+    am_decode_account(db, job, s, err);
+}
+
+__global__ __launch_bounds__(64) void k_am_decode_finish(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id, int G)
+{
+    const int s = stream_of(ids, blockIdx.x);
+    AmJob &job = db.am_job[(size_t)s * NWIN + parity];
+    if (!job.valid || job.rdbi) return;                                    // wave-uniform
+    __shared__ K9WSmem k9;
+    __shared__ int red[4];
+    K9Meta &meta = db.am_k9meta[(size_t)lane_id * db.nstreams_alloc + s];
+    const AmDecodeFrame f = am_decode_frame(db, job, s, parity, lane_id, 8);
+    k9_traceback_fix(f.dec, f.len, meta, k9, f.out, G, db.am_k9stats);
+    const bool ma3 = job.psmi == AM_MA3;
+    const int err = ma3 ? am_bit_errors(f.in, f.out, f.len, GEN_E1_0, GEN_E1_1, GEN_E1_2, PUNCT_E1, 15, red)
+                        : am_bit_errors(f.in, f.out, f.len, GEN_E2_0, GEN_E2_1, GEN_E2_2, PUNCT_E2, 6, red);
+    const int words = (f.len + 31) / 32;
+    const uint32_t tailmask = (f.len & 31) ? (1u << (f.len & 31)) - 1u : 0xffffffffu;
+    for (int w = threadIdx.x; w < words; w += 64) f.out[w] = (f.out[w] ^ tb.scr_p1[w]) & (w == words - 1 ? tailmask : 0xffffffffu);
+    am_decode_account(db, job, s, err);
+}
+
+void launch_am_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, int l2_feedback, hipStream_t st,
+                      int segments, int warm, int runin)
+{
+    const int G = segments < 1 ? 1 : segments > K9_GMAX ? K9_GMAX : segments;
+    hipLaunchKernelGGL(k_am_decode_fwd, dim3(8 + G + 8, nstreams), dim3(64), 0, st, tb, db, stream_ids, parity, lane_id, G, warm);
+    hipLaunchKernelGGL(k_am_decode_fix, dim3(nstreams), dim3(64), 0, st, db, stream_ids, parity, lane_id, G);
+    hipLaunchKernelGGL(k_am_decode_tb, dim3(8 + G, nstreams), dim3(64), 0, st, tb, db, stream_ids, parity, lane_id, G, runin, l2_feedback);
+    hipLaunchKernelGGL(k_am_decode_finish, dim3(nstreams), dim3(64), 0, st, tb, db, stream_ids, parity, lane_id, G);
     if (db.l2_am_ring) launch_l2_index_am_window(db, nstreams, stream_ids, parity, st);
 }
 
@@ -1099,8 +1299,7 @@ void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, con
         hipLaunchKernelGGL(k_am_viterbi, dim3(2, nstreams), dim3(64), 0, st, tb, db, stream_ids, l2_feedback);
         if (db.l2_am_ring) launch_l2_index_am_step(db, nstreams, stream_ids, st);
     }
-    hipLaunchKernelGGL(k_am_interleave, dim3(AM_IL_PARTS, nstreams), dim3(1024), 0, st, tb, db, stream_ids, pipeline_parity);
-    hipLaunchKernelGGL(k_am_interleave_commit, dim3((nstreams + 63) / 64), dim3(64), 0, st, db, stream_ids, nstreams, pipeline_parity, window);
+    hipLaunchKernelGGL(k_am_interleave, dim3(AM_IL_PARTS, nstreams), dim3(1024), 0, st, tb, db, stream_ids, pipeline_parity, window);
 }
 
 // ---- stage-level entry: decode `nframes` independent K=9 frames (parity tests) ------------------------------------
@@ -1118,12 +1317,50 @@ __global__ __launch_bounds__(64) void k_viterbi_k9_frames_wave(const int8_t *cod
     const int f = blockIdx.x;
     viterbi_k9_wave(coded + (size_t)f * 3 * len, len, g0, g1, g2, dec + (size_t)f * 4 * (len + 64), out + (size_t)f * ((len + 31) / 32), k9, phases);
 }
+// the segment-wave form, one launch per stage (what k_am_decode_* do for the P3 frame)
+__global__ __launch_bounds__(64) void k_k9seg_fwd(const int8_t *coded, int len, unsigned g0, unsigned g1, unsigned g2, unsigned long long *dec, K9Meta *meta, int G, int warm)
+{
+    __shared__ K9WSmem k9;
+    const int f = blockIdx.y;
+    k9_forward_segment(coded + (size_t)f * 3 * len, len, g0, g1, g2, dec + (size_t)f * 4 * (len + 64), meta[f], k9, (int)blockIdx.x, G, warm);
+}
+__global__ __launch_bounds__(64) void k_k9seg_fix(const int8_t *coded, int len, unsigned g0, unsigned g1, unsigned g2, unsigned long long *dec, K9Meta *meta, int G, unsigned *stats)
+{
+    __shared__ K9WSmem k9;
+    const int f = blockIdx.x;
+    const unsigned end = k9_forward_fix(coded + (size_t)f * 3 * len, len, g0, g1, g2, dec + (size_t)f * 4 * (len + 64), meta[f], k9, G, stats);
+    if (threadIdx.x == 0) meta[f].end_state = end;
+}
+__global__ __launch_bounds__(64) void k_k9seg_tb(const unsigned long long *dec, int len, K9Meta *meta, uint32_t *out, int G, int runin)
+{
+    __shared__ K9WSmem k9;
+    const int f = blockIdx.y;
+    k9_traceback_segment(dec + (size_t)f * 4 * (len + 64), len, meta[f], k9, out + (size_t)f * ((len + 31) / 32), (int)blockIdx.x, G, runin);
+}
+__global__ __launch_bounds__(64) void k_k9seg_finish(const unsigned long long *dec, int len, K9Meta *meta, uint32_t *out, int G, unsigned *stats)
+{
+    __shared__ K9WSmem k9;
+    const int f = blockIdx.x;
+    k9_traceback_fix(dec + (size_t)f * 4 * (len + 64), len, meta[f], k9, out + (size_t)f * ((len + 31) / 32), G, stats);
+}
 
 void launch_viterbi_k9_frames(const int8_t *coded, int len, int nframes, unsigned g0, unsigned g1, unsigned g2,
-                              unsigned long long *dec, uint32_t *out, hipStream_t st, int phases)
+                              unsigned long long *dec, uint32_t *out, hipStream_t st, int phases, K9Meta *meta, int segments, int warm, int runin, unsigned *stats)
 {
-    // frames longer than a PIDS frame take the production single-wave form; 80-bit frames the 256-work-item form
-    if (len > 80) hipLaunchKernelGGL(k_viterbi_k9_frames_wave, dim3(nframes), dim3(64), 0, st, coded, len, g0, g1, g2, dec, out, phases);
+    // frames longer than a PIDS frame take the production wave form (in segment waves when `meta` is given); 80-bit frames the
+    // 256-work-item form
+    if (len > 80 && meta) {
+        const int G = segments < 1 ? 1 : segments > K9_GMAX ? K9_GMAX : segments;
+        if (phases & 1) {
+            hipLaunchKernelGGL(k_k9seg_fwd, dim3(G, nframes), dim3(64), 0, st, coded, len, g0, g1, g2, dec, meta, G, warm);
+            hipLaunchKernelGGL(k_k9seg_fix, dim3(nframes), dim3(64), 0, st, coded, len, g0, g1, g2, dec, meta, G, stats);
+        }
+        if (phases & 2) {
+            hipLaunchKernelGGL(k_k9seg_tb, dim3(G, nframes), dim3(64), 0, st, dec, len, meta, out, G, runin);
+            hipLaunchKernelGGL(k_k9seg_finish, dim3(nframes), dim3(64), 0, st, dec, len, meta, out, G, stats);
+        }
+    }
+    else if (len > 80) hipLaunchKernelGGL(k_viterbi_k9_frames_wave, dim3(nframes), dim3(64), 0, st, coded, len, g0, g1, g2, dec, out, phases);
     else hipLaunchKernelGGL(k_viterbi_k9_frames, dim3(nframes), dim3(256), 0, st, coded, len, g0, g1, g2, dec, out);
 }
 

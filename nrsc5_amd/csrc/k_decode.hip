@@ -154,20 +154,17 @@ __global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBu
     }
     __threadfence_block();
     __syncthreads();
+    // frame_process -> input_set_sync_state(NONE) when the first L2 header does not decode (frame.c:535-540).
+    // l2_mode 1: in-order decode on the main stream -> the very next block starts from NONE, as in the reference;
+    // l2_mode 2: deferred decode -> file the verdict; k_rollback (k_replay.hip) rewinds the stream to the end of the
+    //            frame's block and restarts it from NONE there, so the outcome is the reference's all the same
+    __shared__ L2Smem l2;
+    const bool ok = l2_mode ? l2_first_header_ok_fm_block(out, l2) : true;     // block-uniform; the whole workgroup takes part
     if (tid == 0) {
         BlockRecord &rec = db.records[(size_t)s * db.rec_cap + st.p1_record[parity]];
         rec.ber = (float)err_total / P1_CODED;                 // decode.c:458
-        if (l2_mode) {
-            // frame_process -> input_set_sync_state(NONE) when the first L2 header does not decode (frame.c:535-540).
-            // l2_mode 1: in-order decode on the main stream -> the very next block starts from NONE, as in the reference;
-            // l2_mode 2: deferred decode -> file the verdict; k_rollback (k_replay.hip) rewinds the stream to the end of the
-            //            frame's block and restarts it from NONE there, so the outcome is the reference's all the same
-            __shared__ L2Smem l2;
-            l2_gf_init(l2);
-            const bool ok = l2_first_header_ok_fm(out, l2);
-            if (l2_mode == 1) { if (!ok && st.sync_state == SYNC_FINE) { st.sync_state = SYNC_NONE; rec.state_after = SYNC_NONE; rec.flags |= REC_LOST_SYNC; } }
-            else { __threadfence(); st.p1_verdict[parity] = ok ? 1 : 2; }
-        }
+        if (l2_mode == 1) { if (!ok && st.sync_state == SYNC_FINE) { st.sync_state = SYNC_NONE; rec.state_after = SYNC_NONE; rec.flags |= REC_LOST_SYNC; } }
+        else if (l2_mode) { __threadfence(); st.p1_verdict[parity] = ok ? 1 : 2; }
         if (db.l2_ring) st.p1_l2slot[parity] = st.p1_slot[parity] + 1;
         st.p1_pending[parity] = 0;
     }

@@ -74,6 +74,8 @@ struct DevBuffers {
     int8_t *am_vit;                  // [S][am_nvit][2][AM_VIT]  depunctured trellis inputs: 8 x P1, P3 (am_nvit = NWIN in the window pipeline, else 1)
     int am_nvit;
     unsigned long long *am_dec;      // [am_ndec][S][8 * AM_DEC_P1 + AM_DEC_P3]  survivor decisions (one set per decode stream)
+    K9Meta *am_k9meta;               // [am_ndec][S]  window pipeline: segment boundaries of the P3 frame, end states of the P1 frames
+    unsigned *am_k9stats;            // [4] forward boundaries checked / re-run, traceback boundaries checked / re-walked
     AmJob *am_job;                   // [S][NWIN]
     AmCkpt *am_ckpt;                 // [S][NWIN][8]  replay: state after the block that delivered P1 PDU j of the job's frame; null unless
                                      // p1_async && l2_feedback
@@ -126,9 +128,11 @@ void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, con
 // entry of the AM de-interleave tables: x = cell | bit << 13 | matrix << 16 | delayed << 18 | punctured << 19 | queue << 20, y = index in the delay line
 constexpr unsigned AMT_DELAYED = 1u << 18, AMT_PUNCT = 1u << 19;
 // window pipeline: the 8 P1 frames and the P3 frame of every L1 frame whose de-interleave happened in window `parity`
-void launch_am_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, int l2_feedback, hipStream_t st);
+void launch_am_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, int l2_feedback, hipStream_t st,
+                      int segments, int warm, int runin);
 void launch_viterbi_k9_frames(const int8_t *coded, int len, int nframes, unsigned g0, unsigned g1, unsigned g2,
-                              unsigned long long *dec, uint32_t *out, hipStream_t st, int phases = 3);
+                              unsigned long long *dec, uint32_t *out, hipStream_t st, int phases = 3,
+                              K9Meta *meta = nullptr, int segments = 1, int warm = K9_WARM, int runin = K9_TB_RUNIN, unsigned *stats = nullptr);
 
 // ---- L2 audio transport index (k_l2.hip): one workgroup per decoded frame --------------------------------------
 constexpr int L2_MAX_BYTES = 18269;

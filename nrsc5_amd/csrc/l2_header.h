@@ -14,7 +14,20 @@
 
 namespace nrsc5 {
 
-struct L2Smem { uint8_t gexp[512], glog[256], r[255], pdu[96]; };
+struct L2Smem { uint8_t gexp[512], glog[256], r[255], pdu[96]; int ok; };
+
+// GF(256), x^8 + x^4 + x^3 + x^2 + 1, as compile-time tables (the block-cooperative check below copies them into LDS)
+struct GfTables { uint8_t gexp[512], glog[256]; };
+constexpr GfTables gf_make_tables()
+{
+    GfTables t{};
+    unsigned x = 1;
+    for (int i = 0; i < 255; i++) { t.gexp[i] = (uint8_t)x; t.glog[x] = (uint8_t)i; x <<= 1; if (x & 0x100u) x ^= 0x11du; }
+    for (int i = 255; i < 512; i++) t.gexp[i] = t.gexp[i - 255];
+    t.glog[0] = 0;
+    return t;
+}
+static __device__ const GfTables GF_TABLES = gf_make_tables();
 
 __device__ inline void l2_gf_init(L2Smem &g)                 // GF(256), x^8 + x^4 + x^3 + x^2 + 1
 {
@@ -129,6 +142,77 @@ __device__ inline bool l2_first_header_ok_am(const uint32_t *w, L2Smem &g)
     }
     if (!l2_pci_wants_check(pci)) return true;
     return l2_header_codeword_ok(g);
+}
+
+// ---- the same check by a whole workgroup ---------------------------------------------------------------------------
+// As single work-item code the check was ~0.2 ms at the end of every P1 decode (table build, bit unpacking, 8 x 254 dependent
+// GF multiplies for the syndromes) with the rest of the workgroup waiting.  Here EVERY work-item of the block calls; the first
+// wave computes the eight syndromes S_i = sum_q pdu[q] alpha^((i+1) q) one or two PDU bytes per lane.  All zero (the usual case):
+// the code word is accepted as rs255_247_decode accepts it (no correction, the zero padding untouched).  Otherwise work-item 0
+// runs the serial decoder above -- same accept / reject decisions by construction.
+__device__ inline void l2_gf_init_block(L2Smem &g)
+{
+    for (int k = threadIdx.x; k < 512; k += blockDim.x) g.gexp[k] = GF_TABLES.gexp[k];
+    for (int k = threadIdx.x; k < 256; k += blockDim.x) g.glog[k] = GF_TABLES.glog[k];
+}
+
+// g.pdu, the tables and `pci` (wave 0) are in place and the block has synchronised; returns the verdict in every work-item
+__device__ inline bool l2_header_verdict_block(L2Smem &g, unsigned pci)
+{
+    if (threadIdx.x < 64) {
+        unsigned lo = 0, hi = 0;                               // S_0..S_3 / S_4..S_7, one byte each
+        for (unsigned q = threadIdx.x; q < 96; q += 64) {
+            const unsigned v = g.pdu[q];
+            if (!v) continue;
+            const unsigned lg = g.glog[v];
+            for (unsigned i = 0; i < 4; i++) {
+                lo ^= (unsigned)g.gexp[(lg + (i + 1) * q) % 255u] << (8 * i);
+                hi ^= (unsigned)g.gexp[(lg + (i + 5) * q) % 255u] << (8 * i);
+            }
+        }
+        for (int m = 32; m >= 1; m >>= 1) { lo ^= (unsigned)__shfl_xor((int)lo, m); hi ^= (unsigned)__shfl_xor((int)hi, m); }
+        if (threadIdx.x == 0) g.ok = !l2_pci_wants_check(pci) ? 1 : !(lo | hi) ? 1 : l2_header_codeword_ok(g) ? 1 : 0;
+    }
+    __syncthreads();
+    return g.ok != 0;
+}
+
+__device__ inline bool l2_first_header_ok_fm_block(const uint32_t *w, L2Smem &g)
+{
+    l2_gf_init_block(g);
+    unsigned pci = 0;
+    if (threadIdx.x < 64) {
+        unsigned bit = 0;
+        if (threadIdx.x < 24) { const unsigned i = 116176u + 1248u * threadIdx.x; bit = l2_bit(w, (i & ~7u) + 7u - (i & 7u)); }
+        pci = __brev((unsigned)__ballot((int)bit)) >> 8;       // lane h -> bit 23 - h
+    }
+    for (int q = threadIdx.x; q < 96; q += blockDim.x) g.pdu[q] = (uint8_t)(w[q >> 2] >> (8 * (q & 3)));
+    __syncthreads();
+    return l2_header_verdict_block(g, pci);
+}
+
+__device__ inline unsigned l2_am_bit(const uint32_t *w, unsigned i)      // frame_push's per-byte bit reversal (the last byte of the 3750 bits is short)
+{
+    const unsigned len = 3750, b0 = i & ~7u, blen = (len - b0 < 8) ? len - b0 : 8;
+    return l2_bit(w, b0 + blen - 1 - (i & 7));
+}
+
+__device__ inline bool l2_first_header_ok_am_block(const uint32_t *w, L2Smem &g)
+{
+    l2_gf_init_block(g);
+    unsigned pci = 0;
+    if (threadIdx.x < 64) {
+        const unsigned bit = threadIdx.x < 22 ? l2_am_bit(w, 120u + 160u * threadIdx.x) : 0u;
+        pci = __brev((unsigned)__ballot((int)bit)) >> 8;
+    }
+    // PDU byte q = data bits 8q .. 8q+7; data bit k sits at frame bit k + (PCI bits before it): 120 + 160 h are PCI positions
+    for (unsigned q = threadIdx.x; q < 96; q += blockDim.x) {
+        unsigned val = 0;
+        for (unsigned j = 0; j < 8; j++) { const unsigned k = 8 * q + j, i = k < 120 ? k : k + (k - 120) / 159 + 1; val |= l2_am_bit(w, i) << (7 - j); }
+        g.pdu[q] = (uint8_t)val;
+    }
+    __syncthreads();
+    return l2_header_verdict_block(g, pci);
 }
 
 // pids_frame_push's acceptance test (pids.c:52-86, 1032-1050) on the 80 descrambled bits packed LSB-first in w[0..2]:

@@ -172,6 +172,7 @@ struct AmStream {
     int next_slot;              // slot assigned (by the de-interleaver) to the frame whose trellis inputs it just produced
     int vit_parity;             // window pipeline: decode job (window parity) of the L1 frame being delivered
     int next_job;               // ... and of the frame whose trellis inputs the de-interleaver just produced
+    unsigned il_done;           // slices of k_am_interleave that have finished this frame (the last one commits); 0 between launches
 };
 
 // window pipeline: one L1 frame's worth of decodes (8 x P1 + P3) handed to k_am_decode
@@ -181,6 +182,19 @@ struct AmJob {
     // (0 unknown, 1 good, 2 failed, 3 failed and applied), the absolute index of the block record that delivered it (-1: not
     // yet) and the decode window the job was filed in
     int verdict[8], deliver_abs[8], window, pad2;
+};
+// K=9 decode in segment waves (k_am.hip): what the segment waves of one P3 frame leave for the wave that checks their boundaries,
+// and the end states of the L1 frame's eight P1 frames (forward and traceback are separate launches)
+constexpr int K9_GMAX = 8;            // segment waves per frame at most
+constexpr int K9_WARM = 3;            // forward warm-up of a segment wave: chunks of 64 step pairs (384 trellis steps)
+constexpr int K9_TB_RUNIN = 4;        // traceback run-in of a segment wave: chunks of 32 step pairs (256 trellis steps)
+struct K9Meta {
+    int snap[K9_GMAX][256];            // forward: metrics segment g enters its first own chunk with (after its warm-up)
+    int uend[K9_GMAX][256];            // ... and leaves its last chunk with
+    unsigned end_state;                // of the P3 frame (k_am_decode_fix)
+    unsigned arrive[K9_GMAX], leave[K9_GMAX];   // traceback: state segment g enters / leaves its own chunks with
+    unsigned p1_end[8];
+    unsigned pad[7];
 };
 // replay checkpoint of an AM stream: everything k_rollback_am rewinds, as of the end of a block that delivered a P1 PDU
 struct AmCkpt { StreamState st; AmStream am; };

@@ -392,6 +392,52 @@ def check_viterbi_k9(lib, oracle, lens=(80, 3750), frames=3, seed=4):
     E.close()
 
 
+def conv_encode_k9(bits: np.ndarray, gens) -> np.ndarray:
+    """Tail-biting rate-1/3 K=9 code words as decode.c's bit_errors() re-encodes them: register bit 8 - k = bits[i - k]."""
+    L = len(bits)
+    reg = np.zeros(L, dtype=np.uint32)
+    for k in range(9):
+        reg |= np.roll(bits, k).astype(np.uint32) << (8 - k)
+    par = lambda v: np.array([bin(int(x)).count("1") & 1 for x in v], dtype=np.int8)
+    return np.stack([par(reg & g) for g in gens], axis=1).reshape(3 * L)
+
+
+def check_viterbi_k9_segmented(lib, oracle, lens=(3750, 24000), segments=(2, 3, 8), seed=14):
+    """K=9 decode in segment waves (k_am.hip: forward pass AND traceback speculate across segment boundaries, a checking wave accepts
+    or re-runs each segment): the sequential decoder's bits for any segment count -- on noise, on the all-erasure frame (every ACS a
+    tie), on constant input and on noisy code words; and again with warm-up and run-in switched off (test hook), when the
+    speculation is wrong at nearly every boundary of an informative frame and the result rests on the repairs (counted)."""
+    rng = np.random.default_rng(seed)
+    E = eng.Engine(max_streams=1, q15_capacity=2 * 71280, lib_path=lib)
+    for L in lens:
+        for gens in (E1_GENS, E2_GENS):
+            soft = rng.integers(-1, 2, size=(5, 3 * L), dtype=np.int8)
+            soft[0] = 0
+            soft[1] = 1
+            for f in (2, 3):
+                msg = rng.integers(0, 2, size=L, dtype=np.uint8)
+                cw = conv_encode_k9(msg, gens).astype(np.int8) * 2 - 1
+                flip = rng.random(3 * L) < (0.04 if f == 2 else 0.12)
+                soft[f] = np.where(flip, -cw, cw)
+                soft[f, 4::5] = 0                                                  # punctured positions
+            exp = np.stack([oracle.viterbi(s, 9, gens) for s in soft])
+            for warm in (1, 0):
+                E.tune(eng.TUNE_AM_WARM, warm)
+                for G in segments:
+                    E.tune(eng.TUNE_AM_SEGMENTS, G)
+                    a = E.k9_stats()
+                    got = E.stage_viterbi_k9(soft, L, gens)
+                    b = E.k9_stats()
+                    assert np.array_equal(got, exp), f"segmented K=9 Viterbi mismatch at len {L} gens {gens}, {G} segments, warm {warm}"
+                    assert b[0] - a[0] > 0 and b[2] - a[2] > 0, (a, b)
+                    if not warm:
+                        assert b[1] - a[1] >= 2 and b[3] - a[3] >= 2, (L, G, a, b)   # cold starts on informative frames were repaired, not trusted
+    E.tune(eng.TUNE_AM_SEGMENTS, 1)                                                # the single-wave form (in-order mode) still agrees
+    soft = rng.integers(-1, 2, size=(2, 3 * 3750), dtype=np.int8)
+    assert np.array_equal(E.stage_viterbi_k9(soft, 3750, E1_GENS), np.stack([oracle.viterbi(s, 9, E1_GENS) for s in soft]))
+    E.close()
+
+
 def check_am_decimator(lib, oracle, seed=5):
     """cu8 -> 32:1 cascade, ragged pushes (stage phases and the raw history carry over), exact."""
     rng = np.random.default_rng(seed)
