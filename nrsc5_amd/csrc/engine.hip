@@ -271,12 +271,14 @@ static int build_tables(nrsc5hip_engine *e)
         static const int j12[12] = { 2, 1, 0, 1, 0, 2, 1, 2, 1, 2, 0, 0 };
         static const int rank15[15] = { 0, -1, 1, 2, -1, 3, 4, -1, 5, 6, 7, 8, 9, 10, 11 };   // E1 puncture {1,0,1,1,0,1,1,0,1,1,1,1,1,1,1}
         auto cell_of = [](int b, int k) { const int col = (9 * k) % 25, row = (11 * col + 16 * (k / 25) + 11 * (k / 50)) % 32; return 25 * (b * 32 + row) + col; };
-        auto entry = [](int cell, int bit, int matrix, int delayed, int queue, int n) {
-            uint2 v; v.x = (unsigned)cell | ((unsigned)bit << 13) | ((unsigned)matrix << 16) | (delayed ? AMT_DELAYED : 0u) | ((unsigned)queue << 20); v.y = (unsigned)n; return v; };
-        std::vector<uint2> t1(AM_VIT), t3b(AM_VIT), t3a(3 * AM_P3_LEN_MA1);
+        // (the delay-line cell of a delayed input is keyed by the input's own index -- DevBuffers::am_q -- so the reference's queue /
+        // position arguments only document which line it is)
+        auto entry = [](int cell, int bit, int matrix, int delayed, int /*queue*/, int /*n*/) {
+            return (uint32_t)((unsigned)cell | ((unsigned)bit << 13) | ((unsigned)matrix << 16) | (delayed ? AMT_DELAYED : 0u)); };
+        std::vector<uint32_t> t1(AM_VIT), t3b(AM_VIT), t3a(3 * AM_P3_LEN_MA1);
         for (int i = 0; i < AM_VIT; i++) {
             const int rk = rank15[i % 15];
-            if (rk < 0) { t1[i].x = AMT_PUNCT; t1[i].y = 0; t3b[i] = t1[i]; continue; }
+            if (rk < 0) { t1[i] = AMT_PUNCT; t3b[i] = t1[i]; continue; }
             const int o = (i / 15) * 12 + rk, g = o / 12, pos = o % 12, n = g * 3 + j12[pos];
             switch (src12[pos]) {       // matrices: 0 pl, 1 pu, 2 s, 3 t
             case 0: t1[i] = entry(cell_of(n / 2250, (n + n / 750 + 1) % 750), n % 3, 0, 0, 0, 0);                 // bl
@@ -291,7 +293,7 @@ static int build_tables(nrsc5hip_engine *e)
         }
         for (int i = 0; i < 3 * AM_P3_LEN_MA1; i++) {             // E2 puncture {1,0,1,1,0,0}; 6-bit groups: el {0,1}, eu {2,3,5,4}
             const int r6 = i % 6;
-            if (!(r6 == 0 || r6 == 2 || r6 == 3)) { t3a[i].x = AMT_PUNCT; t3a[i].y = 0; continue; }
+            if (!(r6 == 0 || r6 == 2 || r6 == 3)) { t3a[i] = AMT_PUNCT; continue; }
             const int o = (i / 6) * 3 + (r6 == 0 ? 0 : r6 - 1), g = o / 6, pos = o % 6;
             if (pos < 2) { const int n = g * 2 + pos; t3a[i] = entry(cell_of((3 * n + n / 3000) % 8, (n + n / 6000) % 750), n % 2, 3, 0, 0, 0); }
             else {
@@ -452,7 +454,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if (cfg->am_enable) {
             if ((rc = dev_alloc(e, &db.am, S))) break;
             if ((rc = dev_alloc(e, &db.am_sym, S * 4 * AM_SYMS))) break;
-            if ((rc = dev_alloc(e, &db.am_q, S * 4 * 3 * 18000))) break;
+            if ((rc = dev_alloc(e, &db.am_q, S * 3 * 2 * (size_t)AM_VIT))) break;
             db.am_nvit = cfg->p1_async ? NWIN : 1;
             const size_t ndec = cfg->p1_async ? NAUX : 1;
             if ((rc = dev_alloc(e, &db.am_vit, S * db.am_nvit * 2 * AM_VIT))) break;
@@ -468,7 +470,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             std::vector<AmStream> ainit(S);
             for (size_t k = 0; k < S; k++) init_am_state(ainit[k]);
             if (hipMemcpy(db.am, ainit.data(), S * sizeof(AmStream), hipMemcpyHostToDevice) != hipSuccess ||
-                hipMemset(db.am_q, 0, S * 4 * 3 * 18000) != hipSuccess || hipMemset(db.am_vit, 0, S * db.am_nvit * 2 * AM_VIT) != hipSuccess ||
+                hipMemset(db.am_q, 0, S * 3 * 2 * (size_t)AM_VIT) != hipSuccess || hipMemset(db.am_vit, 0, S * db.am_nvit * 2 * AM_VIT) != hipSuccess ||
                 hipMemset(db.am_sym, 0, S * 4 * AM_SYMS) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "AM state init failed"); break; }
         }
         db.sync_phase_cycles = nullptr;        // nrsc5hip_debug_tune(NRSC5HIP_TUNE_SYNC_PHASES) turns the instrumentation on

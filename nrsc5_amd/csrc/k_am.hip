@@ -1043,19 +1043,35 @@ __global__ __launch_bounds__(64) void k_am_viterbi(DevTables tb, DevBuffers db, 
 // ---- after block 7: BER of the frame just decoded, then interleaver_ma1 for the frame just received -------------
 // Output-centric and table-driven: every depunctured trellis input looks up which bit of which hard-symbol matrix it is
 // (DevTables::am_deint_*, built from decode.c:66-231 by engine.hip), the main (m*) bits pass through the 3-frame
-// diversity delay lines -- a 3-slot ring whose oldest slot is read and refilled in place by the same work-item.
-__device__ inline int8_t am_deint_one(uint2 e, const uint8_t *sym, uint8_t *q, int head)
+// diversity delay lines -- a 3-slot ring with one cell per trellis input, whose oldest slot is read and refilled in place by the
+// same work-item (consecutive work-items, consecutive bytes).
+// Four inputs per work-item and trip: the table entries AND the delay cells (their address does not depend on the entry -- a cell
+// that is not a delayed input's is simply not used) are requested together, then the LDS look-ups, then the stores; one input per
+// trip left the kernel waiting for three dependent round trips per input.
+__device__ inline void am_deint_span(const uint32_t *tab, int n, const uint8_t *sym, uint8_t *q, int8_t *v, int i0, int step)
 {
-    if (e.x & AMT_PUNCT) return 0;
-    const uint8_t *m = sym + (size_t)((e.x >> 16) & 3u) * AM_SYMS;
-    int bit = (m[e.x & 0x1fffu] >> ((e.x >> 13) & 7u)) & 1;
-    if (e.x & AMT_DELAYED) {
-        uint8_t *cell = q + (((e.x >> 20) & 3u) * 3 + head) * 18000 + e.y;
-        const int old = *cell;
-        *cell = (uint8_t)bit;
-        bit = old;
+    for (int i = i0; i < n; i += 4 * step) {
+        uint32_t e[4]; uint8_t old[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int k = i + u * step;
+            e[u] = k < n ? tab[k] : AMT_PUNCT;
+            old[u] = k < n ? q[k] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int k = i + u * step;
+            if (k >= n) break;
+            int8_t out = 0;
+            if (!(e[u] & AMT_PUNCT)) {
+                const uint8_t *m = sym + (size_t)((e[u] >> 16) & 3u) * AM_SYMS;
+                int bit = (m[e[u] & 0x1fffu] >> ((e[u] >> 13) & 7u)) & 1;
+                if (e[u] & AMT_DELAYED) { q[k] = (uint8_t)bit; bit = old[u]; }
+                out = bit ? 1 : -1;
+            }
+            v[k] = out;
+        }
     }
-    return bit ? 1 : -1;
 }
 
 // The 162 000 (MA1) / 180 000 (MA3) trellis inputs of an L1 frame are independent table look-ups (every cell of the diversity delay
@@ -1063,7 +1079,8 @@ __device__ inline int8_t am_deint_one(uint2 e, const uint8_t *sym, uint8_t *q, i
 // eighth of the batch finishes an L1 frame in any one step, and one workgroup per stream left 7 of 8 CUs idle for the 90 us such a
 // step then took.  The bookkeeping that ends the frame -- delay-line head, ring slot and decode job of the next frame -- is done by
 // the slice that finishes last (AmStream::il_done counts them).
-constexpr int AM_IL_PARTS = 8;
+constexpr int AM_IL_PARTS = 32;
+constexpr int AM_IL_THREADS = 256;          // 4-wave workgroups find room between the decode waves; 16-wave ones wait for it
 
 __device__ inline void am_deinterleave_slice(const DevTables &tb, const DevBuffers &db, int s, int parity, int part)
 {
@@ -1082,16 +1099,15 @@ __device__ inline void am_deinterleave_slice(const DevTables &tb, const DevBuffe
     static_assert((4 * AM_SYMS) % 16 == 0, "symbol matrices are copied in 16-byte pieces");
     {
         const uint4 *src = (const uint4 *)(db.am_sym + (size_t)s * 4 * AM_SYMS);
-        for (int k = tid; k < 4 * AM_SYMS / 16; k += 1024) ((uint4 *)sym)[k] = src[k];
+        for (int k = tid; k < 4 * AM_SYMS / 16; k += AM_IL_THREADS) ((uint4 *)sym)[k] = src[k];
     }
     __syncthreads();
-    uint8_t *q = db.am_q + (size_t)s * 4 * 3 * 18000;         // [ml, mu, eml, emu][3][18000]
-    const int head = am.q_head;
+    uint8_t *q1 = db.am_q + ((size_t)s * 3 + am.q_head) * 2 * AM_VIT, *q3 = q1 + AM_VIT;   // the oldest of the three frames in the delay lines
     int8_t *v1 = db.am_vit + ((size_t)s * db.am_nvit + vslot) * 2 * AM_VIT, *v3 = v1 + AM_VIT;
-    const int i0 = part * 1024 + tid, step = 1024 * AM_IL_PARTS;
-    for (int i = i0; i < AM_VIT; i += step) v1[i] = am_deint_one(tb.am_deint_p1[i], sym, q, head);
-    if (!ma3) for (int i = i0; i < 3 * AM_P3_LEN_MA1; i += step) v3[i] = am_deint_one(tb.am_deint_p3_ma1[i], sym, q, head);
-    else for (int i = i0; i < AM_VIT; i += step) v3[i] = am_deint_one(tb.am_deint_p3_ma3[i], sym, q, head);
+    const int i0 = part * AM_IL_THREADS + tid, step = AM_IL_THREADS * AM_IL_PARTS;
+    am_deint_span(tb.am_deint_p1, AM_VIT, sym, q1, v1, i0, step);
+    if (!ma3) am_deint_span(tb.am_deint_p3_ma1, 3 * AM_P3_LEN_MA1, sym, q3, v3, i0, step);
+    else am_deint_span(tb.am_deint_p3_ma3, AM_VIT, sym, q3, v3, i0, step);
 }
 
 // after EVERY slice of the frame: advance the delay lines, reserve the ring slot and the decode job of the next L1 frame
@@ -1115,7 +1131,7 @@ __device__ inline void am_deinterleave_commit(const DevBuffers &db, int s, int p
     }
 }
 
-__global__ __launch_bounds__(1024) void k_am_interleave(DevTables tb, DevBuffers db, const int *ids, int parity, int window)
+__global__ __launch_bounds__(AM_IL_THREADS) void k_am_interleave(DevTables tb, DevBuffers db, const int *ids, int parity, int window)
 {
     wave_set_priority_high();
     const int s = stream_of(ids, blockIdx.y);
@@ -1299,7 +1315,7 @@ void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, con
         hipLaunchKernelGGL(k_am_viterbi, dim3(2, nstreams), dim3(64), 0, st, tb, db, stream_ids, l2_feedback);
         if (db.l2_am_ring) launch_l2_index_am_step(db, nstreams, stream_ids, st);
     }
-    hipLaunchKernelGGL(k_am_interleave, dim3(AM_IL_PARTS, nstreams), dim3(1024), 0, st, tb, db, stream_ids, pipeline_parity, window);
+    hipLaunchKernelGGL(k_am_interleave, dim3(AM_IL_PARTS, nstreams), dim3(AM_IL_THREADS), 0, st, tb, db, stream_ids, pipeline_parity, window);
 }
 
 // ---- stage-level entry: decode `nframes` independent K=9 frames (parity tests) ------------------------------------

@@ -20,9 +20,9 @@ struct DevTables {
     const int16_t *acq_q15;          // [17] acquisition FIR taps, [1..16] used
     const uint32_t *px_delay_wide;   // [9216] interleaver IV write-to-read delay per position of a block pair, MP3 / MP11
     const uint32_t *px_delay_narrow; // [4608] same for MP2
-    const uint2 *am_deint_p1;        // [90000] source of every P1 trellis input (interleaver_ma1 folded into a table, see build_tables)
-    const uint2 *am_deint_p3_ma3;    // [90000] same for the MA3 P3 code word
-    const uint2 *am_deint_p3_ma1;    // [72000] same for the MA1 P3 code word
+    const uint32_t *am_deint_p1;        // [90000] source of every P1 trellis input (interleaver_ma1 folded into a table, see build_tables)
+    const uint32_t *am_deint_p3_ma3;    // [90000] same for the MA3 P3 code word
+    const uint32_t *am_deint_p3_ma1;    // [72000] same for the MA1 P3 code word
     const int16_t *am_acq_q15;       // [17] AM acquisition FIR taps (acquire.c:63-96)
     const float *am_shape;           // [270] AM pulse shape (acquire.c:333-342)
     const float2 *am_twiddle;        // [256] e^{-2 pi i k / 256}
@@ -70,7 +70,7 @@ struct DevBuffers {
     // AM (null unless the engine was created with am_enable)
     AmStream *am;                    // [S]
     uint8_t *am_sym;                 // [S][4][AM_SYMS]   hard symbols of the current L1 frame: pl, pu, s, t
-    uint8_t *am_q;                   // [S][4][3][18000]  diversity delay lines ml, mu, eml, emu (3 frames each)
+    uint8_t *am_q;                   // [S][3][2][AM_VIT]  3-frame diversity delay of the ml / mu (/ eml / emu) bits: one cell per trellis input of the P1 / P3 code word, keyed by the input's index (coalesced; the reference's line / position numbering is only a numbering)
     int8_t *am_vit;                  // [S][am_nvit][2][AM_VIT]  depunctured trellis inputs: 8 x P1, P3 (am_nvit = NWIN in the window pipeline, else 1)
     int am_nvit;
     unsigned long long *am_dec;      // [am_ndec][S][8 * AM_DEC_P1 + AM_DEC_P3]  survivor decisions (one set per decode stream)
@@ -125,7 +125,7 @@ void launch_am_decimate_cu8(const DevTables &tb, const DevBuffers &db, int nstre
 // and, after block 7, the bit de-interleaver of the finished L1 frame
 void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int l2_feedback = 0, int pipeline_parity = -1, int slot = 0,
                     int window = 0);
-// entry of the AM de-interleave tables: x = cell | bit << 13 | matrix << 16 | delayed << 18 | punctured << 19 | queue << 20, y = index in the delay line
+// entry of the AM de-interleave tables: cell | bit << 13 | matrix << 16 | delayed << 18 | punctured << 19
 constexpr unsigned AMT_DELAYED = 1u << 18, AMT_PUNCT = 1u << 19;
 // window pipeline: the 8 P1 frames and the P3 frame of every L1 frame whose de-interleave happened in window `parity`
 void launch_am_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, int l2_feedback, hipStream_t st,
