@@ -604,7 +604,7 @@ __device__ inline float2 &am_bin(AmBlockSmem &sm, int off, int n) { return sm.X[
 // 256 work-items per stream (the in-order K=9 PIDS trellis below owns one state per work-item).  Every wide phase strides by the
 // block size, but 1024 work-items were measured SLOWER in the window pipeline (am-cs16 88.6 -> 108.4 ms): a 16-wave workgroup with
 // 64 KB of LDS waits for a whole CU's worth of slots while the decode streams keep the chip full of long one-wave trellis passes.
-__global__ __launch_bounds__(256) void k_am_block(DevTables tb, DevBuffers db, const int *ids, int pipeline, int parity, int slot)
+__global__ __launch_bounds__(512) void k_am_block(DevTables tb, DevBuffers db, const int *ids, int pipeline, int parity, int slot)
 {
     wave_set_priority_high();                                  // block-step chain = critical path; the decode waves run at priority 0
     const int s = stream_of(ids, blockIdx.x);
@@ -1310,7 +1310,7 @@ void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, con
 {
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_am_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AmBlockSmem)); attr_set = true; }
-    hipLaunchKernelGGL(k_am_block, dim3(nstreams), dim3(256), sizeof(AmBlockSmem), st, tb, db, stream_ids, pipeline_parity >= 0 ? 1 : 0, pipeline_parity, slot);
+    hipLaunchKernelGGL(k_am_block, dim3(nstreams), dim3(pipeline_parity >= 0 ? 512 : 256), sizeof(AmBlockSmem), st, tb, db, stream_ids, pipeline_parity >= 0 ? 1 : 0, pipeline_parity, slot);
     if (pipeline_parity < 0) {
         hipLaunchKernelGGL(k_am_viterbi, dim3(2, nstreams), dim3(64), 0, st, tb, db, stream_ids, l2_feedback);
         if (db.l2_am_ring) launch_l2_index_am_step(db, nstreams, stream_ids, st);

@@ -115,41 +115,16 @@ __device__ inline bool l2_header_codeword_ok(L2Smem &g)       // fix_header on g
 
 __device__ inline unsigned l2_bit(const uint32_t *w, unsigned i) { return (w[i >> 5] >> (i & 31)) & 1u; }
 
-// FM P1 frame (146176 descrambled bits, packed LSB-first): the 24 PCI bits sit at 116176 + 1248 h, far behind the
-// first 96 PDU bytes, and frame_push's per-byte bit reversal turns PDU byte q into byte q of the packed frame.
-__device__ inline bool l2_first_header_ok_fm(const uint32_t *w, L2Smem &g)
-{
-    unsigned pci = 0;
-    for (unsigned h = 0; h < 24; h++) { const unsigned i = 116176u + 1248u * h; pci |= l2_bit(w, (i & ~7u) + 7u - (i & 7u)) << (23 - h); }
-    if (!l2_pci_wants_check(pci)) return true;
-    for (int q = 0; q < 96; q++) g.pdu[q] = (uint8_t)(w[q >> 2] >> (8 * (q & 3)));
-    return l2_header_codeword_ok(g);
-}
+// FM P1 frame (146176 descrambled bits, packed LSB-first): the 24 PCI bits sit at 116176 + 1248 h, far behind the first 96 PDU
+// bytes, and frame_push's per-byte bit reversal turns PDU byte q into byte q of the packed frame.
+// AM P1 frame (3750 bits): 22 PCI bits at 120 + 160 h are interleaved with the first PDU bytes.
 
-// AM P1 frame (3750 bits): 22 PCI bits at 120 + 160 h are interleaved with the first PDU bytes -> generic unpacking
-__device__ inline bool l2_first_header_ok_am(const uint32_t *w, L2Smem &g)
-{
-    const unsigned len = 3750;
-    unsigned nbytes = 0, j = 0, h = 0, val = 0, pci = 0;
-    for (unsigned i = 0; i < len; i++) {
-        const unsigned b0 = (i >> 3) << 3, blen = (len - b0 < 8) ? len - b0 : 8;
-        const unsigned bit = l2_bit(w, b0 + blen - 1 - (i & 7));
-        if (i >= 120 && ((i - 120) % 160) == 0 && h < 22) { pci |= bit << (23 - h); ++h; }
-        else {
-            val |= bit << (7 - j);
-            if (++j == 8) { if (nbytes < 96) g.pdu[nbytes] = (uint8_t)val; nbytes++; val = 0; j = 0; }
-        }
-    }
-    if (!l2_pci_wants_check(pci)) return true;
-    return l2_header_codeword_ok(g);
-}
-
-// ---- the same check by a whole workgroup ---------------------------------------------------------------------------
+// ---- the check by a whole workgroup ---------------------------------------------------------------------------
 // As single work-item code the check was ~0.2 ms at the end of every P1 decode (table build, bit unpacking, 8 x 254 dependent
 // GF multiplies for the syndromes) with the rest of the workgroup waiting.  Here EVERY work-item of the block calls; the first
 // wave computes the eight syndromes S_i = sum_q pdu[q] alpha^((i+1) q) one or two PDU bytes per lane.  All zero (the usual case):
 // the code word is accepted as rs255_247_decode accepts it (no correction, the zero padding untouched).  Otherwise work-item 0
-// runs the serial decoder above -- same accept / reject decisions by construction.
+// runs the serial decoder above (l2_header_codeword_ok) -- same accept / reject decisions by construction.
 __device__ inline void l2_gf_init_block(L2Smem &g)
 {
     for (int k = threadIdx.x; k < 512; k += blockDim.x) g.gexp[k] = GF_TABLES.gexp[k];
