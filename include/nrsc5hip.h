@@ -307,6 +307,10 @@ int nrsc5hip_stage_fft2048(nrsc5hip_engine *e, const float *in /* [n][2048][2] *
 int nrsc5hip_stage_viterbi_k7(nrsc5hip_engine *e, const int8_t *soft /* [nframes][3*len] */, int len, int nframes,
                               uint8_t *bits /* [nframes][len] */);
 /* K=9 codes of the AM path (nrsc5_conv_decode_e1 / _e2_e3, conv_dec.c:469-478): gens = {0561,0657,0711} or {0561,0753,0711} */
+/* frame_process's first-header check (frame.c:516-540: RS(255,247) over the first 96 PDU bytes unless the PCI says "no audio") as the
+ * decode kernels run it on a finished P1 frame: `bits` = nframes descrambled frames of nbits (146176 FM / 3750 AM) bits, one per byte;
+ * `threads` = workgroup size (64 ... 1024); ok[f] = 1 when the reference would keep the receiver synchronised */
+int nrsc5hip_stage_first_header(nrsc5hip_engine *e, const uint8_t *bits, int nbits, int nframes, int threads, int *ok);
 int nrsc5hip_stage_viterbi_k9(nrsc5hip_engine *e, const int8_t *soft /* [nframes][3*len] */, int len, int nframes,
                               const unsigned gens[3], uint8_t *bits /* [nframes][len] */);
 /* device check of the DPP / v_permlane / v_writelane / v_dot4 helpers against generic shuffles: *failures == 0 */

@@ -1432,6 +1432,24 @@ extern "C" int nrsc5hip_stage_l2_index(nrsc5hip_engine *e, const uint8_t *bits, 
     return l2_run(e, dj, out, pdu_bytes, stride);
 }
 
+extern "C" int nrsc5hip_stage_first_header(nrsc5hip_engine *e, const uint8_t *bits, int nbits, int nframes, int threads, int *ok)
+{
+    if (!e || !bits || !ok || nframes < 1 || (nbits != P1_LEN && nbits != AM_P1_LEN) || threads < 64 || threads > 1024 || (threads & 63)) FAIL(NRSC5HIP_EINVAL, "bad argument");
+    const int words = (nbits + 31) / 32;
+    std::vector<uint32_t> w((size_t)nframes * words, 0u);
+    for (int f = 0; f < nframes; f++)
+        for (int i = 0; i < nbits; i++) if (bits[(size_t)f * nbits + i] & 1) w[(size_t)f * words + (i >> 5)] |= 1u << (i & 31);
+    uint32_t *dw = nullptr; int *dok = nullptr;
+    HIPCHK(hipMalloc((void **)&dw, w.size() * sizeof(uint32_t)));
+    HIPCHK(hipMalloc((void **)&dok, (size_t)nframes * sizeof(int)));
+    HIPCHK(hipMemcpy(dw, w.data(), w.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    launch_stage_first_header(dw, words, nframes, nbits == AM_P1_LEN ? 1 : 0, threads, dok, e->main);
+    HIPCHK(hipStreamSynchronize(e->main));
+    HIPCHK(hipMemcpy(ok, dok, (size_t)nframes * sizeof(int), hipMemcpyDeviceToHost));
+    (void)hipFree(dw); (void)hipFree(dok);
+    return 0;
+}
+
 extern "C" int nrsc5hip_stage_viterbi_k9(nrsc5hip_engine *e, const int8_t *soft, int len, int nframes, const unsigned gens[3], uint8_t *bits)
 {
     if (!e || !soft || !bits || !gens || len < 64 || nframes < 1) FAIL(NRSC5HIP_EINVAL, "bad argument");

@@ -202,6 +202,19 @@ void launch_p1_traceback(const DevTables &tb, const DevBuffers &db, int nstreams
     if (db.l2_ring) launch_l2_index_window(db, nstreams, stream_ids, parity, st);
 }
 
+// ---- stage-level entry: the first-header check (l2_header.h) on packed, descrambled frames, one workgroup per frame -------------
+__global__ void k_stage_first_header(const uint32_t *words, int nwords, int am, int *ok)
+{
+    __shared__ L2Smem l2;
+    const uint32_t *w = words + (size_t)blockIdx.x * nwords;
+    const bool v = am ? l2_first_header_ok_am_block(w, l2) : l2_first_header_ok_fm_block(w, l2);
+    if (threadIdx.x == 0) ok[blockIdx.x] = v ? 1 : 0;
+}
+void launch_stage_first_header(const uint32_t *words, int nwords, int nframes, int am, int threads, int *ok, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_stage_first_header, dim3(nframes), dim3(threads), 0, st, words, nwords, am, ok);
+}
+
 // ---- stage-level entry: decode `nframes` independent frames of equal length (parity tests) ----------
 // phases (micro-benchmark): bit0 forward, bit1 traceback; bit2 selects the single-wave sequential traceback.
 __global__ __launch_bounds__(64) void k_viterbi_frames(const int8_t *coded, int len, unsigned long long *dec, uint32_t *out, int phases)

@@ -130,6 +130,7 @@ constexpr unsigned AMT_DELAYED = 1u << 18, AMT_PUNCT = 1u << 19;
 // window pipeline: the 8 P1 frames and the P3 frame of every L1 frame whose de-interleave happened in window `parity`
 void launch_am_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, int l2_feedback, hipStream_t st,
                       int segments, int warm, int runin);
+void launch_stage_first_header(const uint32_t *words, int nwords, int nframes, int am, int threads, int *ok, hipStream_t st);
 void launch_viterbi_k9_frames(const int8_t *coded, int len, int nframes, unsigned g0, unsigned g1, unsigned g2,
                               unsigned long long *dec, uint32_t *out, hipStream_t st, int phases = 3,
                               K9Meta *meta = nullptr, int segments = 1, int warm = K9_WARM, int runin = K9_TB_RUNIN, unsigned *stats = nullptr);

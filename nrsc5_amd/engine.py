@@ -128,6 +128,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.nrsc5hip_debug_tune.argtypes = [vp, ci, ci]
     lib.nrsc5hip_debug_fwd_stats.argtypes = [vp, vp]
     lib.nrsc5hip_debug_k9_stats.argtypes = [vp, vp]
+    lib.nrsc5hip_stage_first_header.argtypes = [vp, vp, ci, ci, ci, vp]
     lib.nrsc5hip_debug_seam_totals.argtypes = [vp, ci]
     lib.nrsc5hip_debug_seam_totals.restype = None
     lib.nrsc5hip_batch_fetch_view.argtypes = [vp, ci, ctypes.POINTER(vp), vp, ctypes.POINTER(vp)]
@@ -162,7 +163,7 @@ EXPORTED_SYMBOLS = [
     "nrsc5hip_batch_append_cu8", "nrsc5hip_batch_append_cs16", "nrsc5hip_batch_process", "nrsc5hip_drain",
     "nrsc5hip_p1_frame_packed", "nrsc5hip_p1_frame_bits", "nrsc5hip_batch_fetch", "nrsc5hip_unpack_bits",
     "nrsc5hip_stage_halfband_fm_cu8", "nrsc5hip_stage_fft2048", "nrsc5hip_stage_viterbi_k7", "nrsc5hip_debug_fetch", "nrsc5hip_debug_fetch_costas",
-    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_debug_tune", "nrsc5hip_debug_fwd_stats", "nrsc5hip_debug_k9_stats", "nrsc5hip_debug_seam_totals", "nrsc5hip_batch_fetch_view", "nrsc5hip_batch_fetch_l2_px", "nrsc5hip_batch_fetch_l2_am",
+    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_debug_tune", "nrsc5hip_debug_fwd_stats", "nrsc5hip_debug_k9_stats", "nrsc5hip_stage_first_header", "nrsc5hip_debug_seam_totals", "nrsc5hip_batch_fetch_view", "nrsc5hip_batch_fetch_l2_px", "nrsc5hip_batch_fetch_l2_am",
     "nrsc5hip_stream_set_mode", "nrsc5hip_am_frame_bits", "nrsc5hip_stage_viterbi_k9", "nrsc5hip_px_frame_bits",
     "nrsc5hip_batch_fetch_px", "nrsc5hip_debug_fetch_px", "nrsc5hip_stage_viterbi_k9_bench",
     "nrsc5hip_l2_index", "nrsc5hip_stage_l2_index", "nrsc5hip_l2_frame_get", "nrsc5hip_batch_fetch_l2",
@@ -453,6 +454,13 @@ class Engine:
         st = (ctypes.c_int * 2)()
         self._check(self.lib.nrsc5hip_debug_fwd_stats(self._h, st))
         return int(st[0]), int(st[1])
+
+    def stage_first_header(self, bits: np.ndarray, threads: int = 64) -> np.ndarray:
+        """First-header verdicts (1 = the reference stays synchronised) of descrambled P1 frames, bits[nframes][146176 or 3750]."""
+        bits = np.ascontiguousarray(bits, dtype=np.uint8)
+        ok = np.zeros(bits.shape[0], dtype=np.int32)
+        self._check(self.lib.nrsc5hip_stage_first_header(self._h, bits.ctypes.data, bits.shape[1], bits.shape[0], threads, ok.ctypes.data))
+        return ok
 
     def k9_stats(self):
         """K=9 decode in segment waves: (forward boundaries checked, segments re-run, traceback boundaries checked, segments re-walked)"""

@@ -392,6 +392,31 @@ def check_viterbi_k9(lib, oracle, lens=(80, 3750), frames=3, seed=4):
     E.close()
 
 
+def check_first_header(lib, oracle, seeds=(5, 6)):
+    """The workgroup form of frame_process's first-header check (l2_header.h: parallel syndromes, serial RS decoder only when they
+    are non-zero) against the oracle's restatement of frame.c:516-540 on every case of synth_l2.test_frames -- clean headers, 1 / 4
+    (correctable) and 5 / 9 (not) byte errors, every PCI, garbage -- plus a sweep of 0..6 errors; FM and AM frames; one wave and
+    several per workgroup."""
+    from nrsc5_amd import synth_l2
+    E = eng.Engine(max_streams=1, q15_capacity=2 * 71280, lib_path=lib)
+    for nbits in (146176, 3750):
+        frames = []
+        for seed in seeds:
+            frames += [bits for _, bits, _ in synth_l2.test_frames(nbits, seed=seed)]
+        rng = np.random.default_rng(nbits)
+        body = synth_l2.make_pdu(rng, synth_l2.pdu_bytes_of(nbits), nop=2)
+        for k in range(7):
+            for _ in range(3):
+                frames.append(synth_l2.frame_from_bytes(synth_l2.corrupt(body, rng.choice(96, size=k, replace=False), rng), nbits))
+        bits = np.stack(frames).astype(np.uint8)
+        exp = np.array([1 if oracle.l2_first_header_ok(b) else 0 for b in bits], dtype=np.int32)
+        assert 0 < exp.sum() < len(exp)
+        for threads in (64, 256):
+            got = E.stage_first_header(bits, threads)
+            assert np.array_equal(got, exp), (nbits, threads, np.nonzero(got != exp)[0][:8])
+    E.close()
+
+
 def conv_encode_k9(bits: np.ndarray, gens) -> np.ndarray:
     """Tail-biting rate-1/3 K=9 code words as decode.c's bit_errors() re-encodes them: register bit 8 - k = bits[i - k]."""
     L = len(bits)

@@ -99,6 +99,10 @@ def test_emu_am_viterbi_k9(emu_lib, oracle):
     ec.check_viterbi_k9(emu_lib, oracle, lens=(80, 3750), frames=2)
 
 
+def test_emu_first_header_check(emu_lib, oracle):
+    ec.check_first_header(emu_lib, oracle, seeds=(5,))
+
+
 def test_emu_am_viterbi_k9_segmented(emu_lib, oracle):
     ec.check_viterbi_k9_segmented(emu_lib, oracle, lens=(3750,), segments=(2, 5))
 

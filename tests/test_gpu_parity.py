@@ -206,6 +206,10 @@ def test_gpu_am_viterbi_k9_exact(hip_lib, oracle):
     ec.check_viterbi_k9(hip_lib, oracle, lens=(80, 3750, 24000, 30000), frames=4)
 
 
+def test_gpu_first_header_check(hip_lib, oracle):
+    ec.check_first_header(hip_lib, oracle)
+
+
 def test_gpu_am_viterbi_k9_segmented_exact(hip_lib, oracle):
     ec.check_viterbi_k9_segmented(hip_lib, oracle, lens=(3750, 24000, 30000), segments=(2, 3, 8))
 
