@@ -793,7 +793,7 @@ def check_deferred_feedback_equals_reference(lib, oracle, n_blocks=96, verdict_l
     E.close()
 
 
-def check_am_deferred_feedback_equals_reference(lib, oracle, verdict_lag=0):
+def check_am_deferred_feedback_equals_reference(lib, oracle, verdict_lag=0, tunes=(), expect_k9_repairs=False):
     """AM twin of check_deferred_feedback_equals_reference: batch, 8-step decode windows, on-device L2 feedback.  Noise bursts
     break the first header of some P1 PDUs; the verdict of the deferred decode rewinds the stream to the block that delivered
     that PDU (k_rollback_am), so LOST_SYNC, the re-acquisition and everything after land on the reference's blocks."""
@@ -809,6 +809,8 @@ def check_am_deferred_feedback_equals_reference(lib, oracle, verdict_lag=0):
         buf[k, :c.iq.size] = c.iq
     E = eng.Engine(max_streams=n, q15_capacity=stride // 2 + 1024, record_capacity=1024, p1_slots=48, lib_path=lib, am_enable=True, p1_async=True, l2_feedback=True)
     E.tune(eng.TUNE_VERDICT_LAG, verdict_lag)
+    for knob, value in tunes:
+        E.tune(knob, value)
     for k in range(n):
         E.set_mode(k, eng.MODE_AM)
     dev = _to_device(E, buf)
@@ -828,6 +830,10 @@ def check_am_deferred_feedback_equals_reference(lib, oracle, verdict_lag=0):
         assert not diffs, (k, verdict_lag, diffs[:10])
         lost += sum(1 for kk, _ in ol if kk == "lost_sync")
     assert lost >= 2, "captures do not exercise the feedback"
+    st = E.k9_stats()
+    assert st[0] > 0 and st[2] > 0, st                         # the P3 frames went through segment waves
+    if expect_k9_repairs:
+        assert st[1] > 0 and st[3] > 0, st                     # ... and cold segment starts were re-run, in the production kernels
     _free_device(E, dev)
     E.close()
 

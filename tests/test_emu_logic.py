@@ -95,6 +95,12 @@ def test_emu_am_replay_equals_reference(emu_lib, oracle, lag):
     ec.check_am_deferred_feedback_equals_reference(emu_lib, oracle, verdict_lag=lag)
 
 
+def test_emu_am_replay_with_cold_segments(emu_lib, oracle):
+    """the window pipeline's own decode kernels with warm-up and run-in switched off: every P3 segment boundary takes the repair path"""
+    from nrsc5_amd import engine as eng
+    ec.check_am_deferred_feedback_equals_reference(emu_lib, oracle, tunes=((eng.TUNE_AM_WARM, 0), (eng.TUNE_AM_SEGMENTS, 5)), expect_k9_repairs=True)
+
+
 def test_emu_am_viterbi_k9(emu_lib, oracle):
     ec.check_viterbi_k9(emu_lib, oracle, lens=(80, 3750), frames=2)
 

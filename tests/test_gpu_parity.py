@@ -276,6 +276,18 @@ def test_gpu_am_replay_equals_reference(hip_lib, oracle, lag):
     ec.check_am_deferred_feedback_equals_reference(hip_lib, oracle, verdict_lag=lag)
 
 
+@pytest.mark.parametrize("case", ["cold_segments", "knobs"])
+def test_gpu_am_replay_under_decode_knobs(hip_lib, oracle, case):
+    """The window pipeline's own decode kernels (a) with warm-up and run-in switched off -- every P3 segment boundary takes the repair
+    path -- and (b) with 3 segments on one decode stream confined to half the CUs at the lowest queue priority: the reference's log."""
+    from nrsc5_amd import engine as eng
+    if case == "cold_segments":
+        ec.check_am_deferred_feedback_equals_reference(hip_lib, oracle, tunes=((eng.TUNE_AM_SEGMENTS, 5), (eng.TUNE_AM_WARM, 0)), expect_k9_repairs=True)
+    else:
+        ec.check_am_deferred_feedback_equals_reference(hip_lib, oracle, tunes=((eng.TUNE_AM_SEGMENTS, 3), (eng.TUNE_AM_DECODE_STREAMS, 1),
+                                                                                 (eng.TUNE_DECODE_CUS, 16), (eng.TUNE_DECODE_PRIORITY, 1)))
+
+
 def test_gpu_l2_feedback_deferred_recovers_false_locks(hip_lib):
     """Throughput mode: the feedback arrives when the deferred decode completes; falsely locked streams still re-acquire
     and then deliver the transmitted frames."""
