@@ -838,6 +838,49 @@ def check_am_deferred_feedback_equals_reference(lib, oracle, verdict_lag=0, tune
     E.close()
 
 
+def check_mixed_batch_pipeline(lib, oracle, passes=2):
+    """ONE engine, FM and AM streams with interleaved ids in one batch_process call (window pipeline + L2 feedback on the device, both
+    replays active): every stream's log must equal the oracle's as if it had been alone; further passes over the same engine
+    (reset_all) must give the same again."""
+    from nrsc5_amd import synth_am
+    fm_caps = [synth.fm_mp1_capture(0, seed=sd, cfo_hz=c, offset=o, snr_db=20, n_blocks=64) for sd, c, o in FALSE_LOCK_CASES[:1] + ((31, 80.0, 700),)]
+    am_caps = [synth_am.am_ma1_capture(n_frames=12, seed=9, cfo_hz=2.0, offset=500, burst=(8.3, 0.5, 40.0)),
+               synth_am.am_ma1_capture(n_frames=10, seed=11, cfo_hz=1.0, offset=100)]
+    nf, na = len(fm_caps), len(am_caps)
+    sf = max(c.iq.size for c in fm_caps); sf += (-sf) % 256
+    sa = max(c.iq.size for c in am_caps); sa += (-sa) % 64
+    bf = np.zeros((nf, sf), dtype=np.uint8); ba = np.zeros((na, sa), dtype=am_caps[0].iq.dtype)
+    for k, c in enumerate(fm_caps): bf[k, :c.iq.size] = c.iq
+    for k, c in enumerate(am_caps): ba[k, :c.iq.size] = c.iq
+    E = eng.Engine(max_streams=nf + na, q15_capacity=max(sf // 4, sa // 2) + 1024, record_capacity=1024, p1_slots=48, lib_path=lib, am_enable=True, p1_async=True, l2_feedback=True)
+    ids_f, ids_a = [0, 2][:nf], [1, 3][:na]                    # interleaved ids: the split by mode is the engine's job
+    for s_ in ids_a:
+        E.set_mode(s_, eng.MODE_AM)
+    df, da = _to_device(E, bf), _to_device(E, ba)
+    want = {}
+    for k, c in enumerate(fm_caps):
+        want[ids_f[k]] = (common.strip_states(oracle.run(c.iq, p1_hook=oracle.l2_hook())[0]), False)
+    for k, c in enumerate(am_caps):
+        want[ids_a[k]] = (common.strip_states(oracle.run(c.iq, mode=1, p1_hook=oracle.l2_hook())[0]), True)
+    for _ in range(passes):
+        E.reset_all()
+        E.batch_append_cu8(df, sf, [c.iq.size - c.iq.size % 4 for c in fm_caps], stream_ids=ids_f)
+        E.batch_append_cs16(da, sa, [c.iq.size - c.iq.size % 4 for c in am_caps], stream_ids=ids_a)
+        E.batch_process(nf + na)
+        recs, counts, frames = E.batch_fetch_view(nf + na)
+        for s_, (ol, am) in want.items():
+            r = recs[s_, :counts[s_]]
+            assert not (r["flags"] & eng.REC_DISCARDED).any()
+            log = (eng.am_records_to_log if am else eng.records_to_log)(E, s_, r, frames[s_])
+            diffs = common.compare_logs(ol, common.strip_states(log))
+            kept = [x for x in ol if x[0] not in ("hdc", "soft", "vit", "amsym", "pxsoft")]
+            bad = {i for i, (kk, v) in enumerate(kept) if kk == "ber" and v["cber"] > 0.02}
+            diffs = [d for d in diffs if not any(d.startswith(f"#{i} ") or d.startswith(f"#{i + 1} frame") or d.startswith(f"#{i - 1} frame") for i in bad)]
+            assert not diffs, (s_, am, diffs[:8])
+    _free_device(E, df); _free_device(E, da)
+    E.close()
+
+
 def check_hdc_consumer(lib, reflib, caps, p1_async=False):
     """IQ -> engine -> L2 index (device) -> nrsc5hip_hdc_* == the NRSC5_EVENT_HDC sequence of the unmodified reference."""
     from oracle import ref

@@ -95,6 +95,10 @@ def test_emu_am_replay_equals_reference(emu_lib, oracle, lag):
     ec.check_am_deferred_feedback_equals_reference(emu_lib, oracle, verdict_lag=lag)
 
 
+def test_emu_mixed_batch_pipeline(emu_lib, oracle):
+    ec.check_mixed_batch_pipeline(emu_lib, oracle, passes=1)
+
+
 def test_emu_am_replay_with_cold_segments(emu_lib, oracle):
     """the window pipeline's own decode kernels with warm-up and run-in switched off: every P3 segment boundary takes the repair path"""
     from nrsc5_amd import engine as eng

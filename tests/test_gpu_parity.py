@@ -276,6 +276,10 @@ def test_gpu_am_replay_equals_reference(hip_lib, oracle, lag):
     ec.check_am_deferred_feedback_equals_reference(hip_lib, oracle, verdict_lag=lag)
 
 
+def test_gpu_mixed_batch_pipeline(hip_lib, oracle):
+    ec.check_mixed_batch_pipeline(hip_lib, oracle, passes=3)
+
+
 @pytest.mark.parametrize("case", ["cold_segments", "knobs"])
 def test_gpu_am_replay_under_decode_knobs(hip_lib, oracle, case):
     """The window pipeline's own decode kernels (a) with warm-up and run-in switched off -- every P3 segment boundary takes the repair
