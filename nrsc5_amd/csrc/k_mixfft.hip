@@ -21,29 +21,52 @@ namespace nrsc5 {
 
 __device__ inline int stream_of(const int *ids, int idx) { return ids ? ids[idx] : idx; }
 
-__device__ inline float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ inline float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ inline float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ inline float2 mul_mj(float2 a) { return make_float2(a.y, -a.x); }      // a * (-j)
+// Complex values as a native 2-vector: the compiler then keeps them in aligned register pairs and every complex add / subtract /
+// scale is ONE packed instruction (v_pk_add_f32 / v_pk_mul_f32, the swaps and sign flips of a complex product riding in op_sel /
+// neg modifiers) -- written on a struct of two floats the same arithmetic came out with 18 % of the kernel's VALU instructions
+// being v_mov_b32 that only built register pairs (16-point DFT + twiddles: 336 -> 240 VALU instructions).  Same IEEE operations
+// in the same order either way (no contraction): the bits do not change.  The CPU emulator build keeps the struct.
+#ifdef HIPEMU
+struct cf { float x, y; };
+__device__ inline cf cf_make(float x, float y) { cf r; r.x = x; r.y = y; return r; }
+__device__ inline cf cadd(cf a, cf b) { return cf_make(a.x + b.x, a.y + b.y); }
+__device__ inline cf csub(cf a, cf b) { return cf_make(a.x - b.x, a.y - b.y); }
+__device__ inline cf emul(cf a, cf b) { return cf_make(a.x * b.x, a.y * b.y); }                 // element by element
+__device__ inline cf cmul(cf a, cf b) { return cf_make(a.x * b.x - a.y * b.y, a.y * b.x + a.x * b.y); }
+__device__ inline cf mul_mj(cf a) { return cf_make(a.y, -a.x); }                                // a * (-j)
+__device__ inline cf cf_swap(cf a) { return cf_make(a.y, a.x); }
+__device__ inline cf cf_neg_x(cf a) { return cf_make(-a.x, a.y); }
+#else
+typedef float cf __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ cf cf_make(float x, float y) { cf r; r.x = x; r.y = y; return r; }
+__device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
+__device__ __forceinline__ cf emul(cf a, cf b) { return a * b; }
+__device__ __forceinline__ cf cmul(cf a, cf b) { const cf t = a.yx * b.yy; return a * b.xx + cf_make(-t.x, t.y); }
+__device__ __forceinline__ cf mul_mj(cf a) { return cf_make(a.y, -a.x); }
+__device__ __forceinline__ cf cf_swap(cf a) { return a.yx; }
+__device__ __forceinline__ cf cf_neg_x(cf a) { return cf_make(-a.x, a.y); }
+#endif
+__device__ inline cf cf_of(float2 a) { return cf_make(a.x, a.y); }
 
 // forward 4-point DFT in place, natural order out
-__device__ inline void dft4(float2 &a0, float2 &a1, float2 &a2, float2 &a3)
+__device__ inline void dft4(cf &a0, cf &a1, cf &a2, cf &a3)
 {
-    const float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mj(csub(a1, a3));
+    const cf t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = mul_mj(csub(a1, a3));
     a0 = cadd(t0, t2); a1 = cadd(t1, t3); a2 = csub(t0, t2); a3 = csub(t1, t3);
 }
 
 // forward 8-point DFT, natural order in v[0..7] -> natural order out
-__device__ inline void dft8(float2 *v)
+__device__ inline void dft8(cf *v)
 {
-    float2 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
-    float2 o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
+    cf e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6];
+    cf o0 = v[1], o1 = v[3], o2 = v[5], o3 = v[7];
     dft4(e0, e1, e2, e3);
     dft4(o0, o1, o2, o3);
     const float c = 0.70710678118654752440f;
-    o1 = make_float2(c * (o1.x + o1.y), c * (o1.y - o1.x));          // * W8^1 = c(1 - j)
+    o1 = emul(cadd(o1, mul_mj(o1)), cf_make(c, c));                  // * W8^1 = c(1 - j): (c (x + y), c (y - x))
     o2 = mul_mj(o2);                                                  // * W8^2 = -j
-    o3 = make_float2(c * (o3.y - o3.x), -c * (o3.x + o3.y));         // * W8^3 = -c(1 + j)
+    o3 = emul(cadd(cf_swap(o3), cf_neg_x(o3)), cf_make(c, -c));      // * W8^3 = -c(1 + j): (c (y - x), -c (x + y))
     v[0] = cadd(e0, o0); v[4] = csub(e0, o0);
     v[1] = cadd(e1, o1); v[5] = csub(e1, o1);
     v[2] = cadd(e2, o2); v[6] = csub(e2, o2);
@@ -51,21 +74,21 @@ __device__ inline void dft8(float2 *v)
 }
 
 // forward 16-point DFT in place; output X[a + 4b] lands in v[4a + b]
-__device__ inline void dft16(float2 *v)
+__device__ inline void dft16(cf *v)
 {
 #pragma unroll
     for (int n2 = 0; n2 < 4; n2++) dft4(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);   // v[4k1+n2] = Y[k1][n2]
     const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, c2 = 0.70710678118654752440f;
     // W16^m, m = n2*k1
-    v[5]  = cmul(v[5],  make_float2(c1, -s1));    // m=1
-    v[6]  = cmul(v[6],  make_float2(c2, -c2));    // m=2
-    v[7]  = cmul(v[7],  make_float2(s1, -c1));    // m=3
-    v[9]  = cmul(v[9],  make_float2(c2, -c2));    // m=2
+    v[5]  = cmul(v[5],  cf_make(c1, -s1));    // m=1
+    v[6]  = cmul(v[6],  cf_make(c2, -c2));    // m=2
+    v[7]  = cmul(v[7],  cf_make(s1, -c1));    // m=3
+    v[9]  = cmul(v[9],  cf_make(c2, -c2));    // m=2
     v[10] = mul_mj(v[10]);                        // m=4
-    v[11] = cmul(v[11], make_float2(-c2, -c2));   // m=6
-    v[13] = cmul(v[13], make_float2(s1, -c1));    // m=3
-    v[14] = cmul(v[14], make_float2(-c2, -c2));   // m=6
-    v[15] = cmul(v[15], make_float2(-c1, s1));    // m=9
+    v[11] = cmul(v[11], cf_make(-c2, -c2));   // m=6
+    v[13] = cmul(v[13], cf_make(s1, -c1));    // m=3
+    v[14] = cmul(v[14], cf_make(-c2, -c2));   // m=6
+    v[15] = cmul(v[15], cf_make(-c1, s1));    // m=9
 #pragma unroll
     for (int k1 = 0; k1 < 4; k1++) dft4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
 }
@@ -74,31 +97,31 @@ __device__ inline void dft16(float2 *v)
 // m = 2, 3, 4 (upper sideband) and 11, 12, 13 (lower sideband) -- the other ten lie outside sync.c:785-789's 2 x 267 live bins
 // for every (k1, k2).  Same first stage and twiddles as dft16; of the second stage's 4-point transforms only the wanted
 // outputs: v[8] = X[2], v[12] = X[3], v[1] = X[4], v[14] = X[11], v[3] = X[12], v[7] = X[13].
-__device__ inline void dft16_live(float2 *v)
+__device__ inline void dft16_live(cf *v)
 {
 #pragma unroll
     for (int n2 = 0; n2 < 4; n2++) dft4(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
     const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, c2 = 0.70710678118654752440f;
-    v[5]  = cmul(v[5],  make_float2(c1, -s1));
-    v[6]  = cmul(v[6],  make_float2(c2, -c2));
-    v[7]  = cmul(v[7],  make_float2(s1, -c1));
-    v[9]  = cmul(v[9],  make_float2(c2, -c2));
+    v[5]  = cmul(v[5],  cf_make(c1, -s1));
+    v[6]  = cmul(v[6],  cf_make(c2, -c2));
+    v[7]  = cmul(v[7],  cf_make(s1, -c1));
+    v[9]  = cmul(v[9],  cf_make(c2, -c2));
     v[10] = mul_mj(v[10]);
-    v[11] = cmul(v[11], make_float2(-c2, -c2));
-    v[13] = cmul(v[13], make_float2(s1, -c1));
-    v[14] = cmul(v[14], make_float2(-c2, -c2));
-    v[15] = cmul(v[15], make_float2(-c1, s1));
+    v[11] = cmul(v[11], cf_make(-c2, -c2));
+    v[13] = cmul(v[13], cf_make(s1, -c1));
+    v[14] = cmul(v[14], cf_make(-c2, -c2));
+    v[15] = cmul(v[15], cf_make(-c1, s1));
     {   // a = 0: outputs b = 1 (X[4]) and b = 3 (X[12])
-        const float2 t1 = csub(v[0], v[2]), t3 = mul_mj(csub(v[1], v[3]));
+        const cf t1 = csub(v[0], v[2]), t3 = mul_mj(csub(v[1], v[3]));
         v[1] = cadd(t1, t3); v[3] = csub(t1, t3);
     }
     {   // a = 1: b = 3 (X[13])
-        const float2 t1 = csub(v[4], v[6]), t3 = mul_mj(csub(v[5], v[7]));
+        const cf t1 = csub(v[4], v[6]), t3 = mul_mj(csub(v[5], v[7]));
         v[7] = csub(t1, t3);
     }
     v[8] = cadd(cadd(v[8], v[10]), cadd(v[9], v[11]));         // a = 2: b = 0 (X[2])
     {   // a = 3: b = 0 (X[3]) and b = 2 (X[11])
-        const float2 t0 = cadd(v[12], v[14]), t2 = cadd(v[13], v[15]);
+        const cf t0 = cadd(v[12], v[14]), t2 = cadd(v[13], v[15]);
         v[12] = cadd(t0, t2); v[14] = csub(t0, t2);
     }
 }
@@ -112,7 +135,7 @@ constexpr int PITCH_B = 17;    // per r2 row inside a k1 row of the second layou
 //  out: x[4a+b]  = bin  k1 + 8*k2 + 128*(a + 4b)   with k1 = tid >> 4, k2 = tid & 15
 //  LIVE: only x[1], x[3], x[7], x[8], x[12], x[14] are produced (dft16_live)
 template <bool LIVE>
-__device__ inline void fft2048_wg(float2 *x, float2 *lds, const float2 *tw)
+__device__ inline void fft2048_wg(cf *x, cf *lds, const float2 *tw)
 {
     const int tid = threadIdx.x;
     // stage A: two radix-8 butterflies, twiddle W2048^(k1*r), scatter to [k1][r]
@@ -122,8 +145,8 @@ __device__ inline void fft2048_wg(float2 *x, float2 *lds, const float2 *tw)
         dft8(x + 8 * h);
 #pragma unroll
         for (int k1 = 0; k1 < 8; k1++) {
-            float2 v = x[8 * h + k1];
-            if (k1) v = cmul(v, tw[(k1 * r) & 2047]);
+            cf v = x[8 * h + k1];
+            if (k1) v = cmul(v, cf_of(tw[(k1 * r) & 2047]));
             lds[k1 * PITCH_A + r] = v;
         }
     }
@@ -138,8 +161,8 @@ __device__ inline void fft2048_wg(float2 *x, float2 *lds, const float2 *tw)
 #pragma unroll
         for (int i = 0; i < 16; i++) {
             const int k2 = (i >> 2) + 4 * (i & 3);
-            float2 v = x[i];
-            if (r2) v = cmul(v, tw[(8 * r2 * k2) & 2047]);
+            cf v = x[i];
+            if (r2) v = cmul(v, cf_of(tw[(8 * r2 * k2) & 2047]));
             lds[k1 * PITCH_A + r2 * PITCH_B + k2] = v;
         }
     }
@@ -162,7 +185,7 @@ __device__ inline void fft2048_wg(float2 *x, float2 *lds, const float2 *tw)
 // every pair is even and one odd, so the -127 offsets of both (x' = byte - 127) are applied as -254 to the even-indexed E
 // only; the centre sample's -127 * 64 goes into the accumulator's start value.  The tile receives the Q15 INTEGERS
 // (imaginary part negated: the FM receiver's spectrum flip); sample() below divides by 32767 on the way out.
-__device__ inline void decimate_symbol_raw(const uint8_t *raw, long long a0, float2 *tile, const HbTaps &taps)
+__device__ inline void decimate_symbol_raw(const uint8_t *raw, long long a0, cf *tile, const HbTaps &taps)
 {
     const int m0 = 17 * (int)threadIdx.x;
     const int nout = min(17, SYM_N - m0);                      // 17 for work-items 0..126, 1 for the last
@@ -206,7 +229,7 @@ __device__ inline void decimate_symbol_raw(const uint8_t *raw, long long a0, flo
         for (int j = 0; j < 4; j++) p[j] = hb_add(E[i + j], E[i + 7 - j]);
     };
     auto park = [&](int i, hb_v2 acc) {
-        tile[m0 + i] = make_float2(acc.x - HB_BIAS, HB_BIAS - acc.y);      // the last work-item's spare outputs land in the tile's unused tail
+        tile[m0 + i] = cf_make(acc.x - HB_BIAS, HB_BIAS - acc.y);      // the last work-item's spare outputs land in the tile's unused tail
     };
     hb_round_down();
 #pragma unroll
@@ -230,7 +253,7 @@ __device__ inline void decimate_symbol_raw(const uint8_t *raw, long long a0, flo
 // RAW: the stream reads its cu8 capture in place (zero-copy batch) -- else its samples come from the Q15 FIFO.  Block-uniform, so
 // the two forms are separate instantiations rather than a test per sample.
 template <bool RAW>
-__device__ __forceinline__ void mixfft_symbol(const DevTables &tb, const DevBuffers &db, const StreamState &st, int s, float2 *lds)
+__device__ __forceinline__ void mixfft_symbol(const DevTables &tb, const DevBuffers &db, const StreamState &st, int s, cf *lds)
 {
     const int sym = blockIdx.x, tid = threadIdx.x;
     const long long a0 = (st.rd - st.base) + sym * SYM_N + st.samperr_cur;     // first sample of the symbol in the decimated stream
@@ -247,31 +270,34 @@ __device__ __forceinline__ void mixfft_symbol(const DevTables &tb, const DevBuff
     a0p -= 2 * M_PI * rint(a0p * (1.0 / (2 * M_PI)));
     double a1 = 128.0 * dth;
     a1 -= 2 * M_PI * rint(a1 * (1.0 / (2 * M_PI)));
-    float2 ph, stp;
-    fast_sincos_reduced((float)a0p, ph.y, ph.x);               // both angles were reduced to [-pi, pi] in double above
-    fast_sincos_reduced((float)a1, stp.y, stp.x);
+    cf ph, stp;
+    {
+        float sn, cs;
+        fast_sincos_reduced((float)a0p, sn, cs); ph = cf_make(cs, sn);      // both angles were reduced to [-pi, pi] in double above
+        fast_sincos_reduced((float)a1, sn, cs); stp = cf_make(cs, sn);
+    }
     const c16 *win = db.q15 + (size_t)s * db.q15_cap + a0;     // FIFO path (streaming seam, cs16 input)
 
-    auto sample = [&](int j) -> float2 {
-        if (RAW) { const float2 y = lds[j]; return make_float2(q15_to_float(y.x), q15_to_float(y.y)); }   // the tile holds Q15 integers, conjugated
+    auto sample = [&](int j) -> cf {
+        if (RAW) { const cf y = lds[j]; return cf_make(q15_to_float(y.x), q15_to_float(y.y)); }   // the tile holds Q15 integers, conjugated
         const c16 s16 = win[j];
-        return make_float2(q15_to_float((float)s16.r), -q15_to_float((float)s16.i));   // cq15_to_cf_conj, defines.h:111
+        return cf_make(q15_to_float((float)s16.r), -q15_to_float((float)s16.i));   // cq15_to_cf_conj, defines.h:111
     };
-    float2 x[16];
+    cf x[16];
 #pragma unroll
     for (int q = 0; q < 16; q++) {
         const int h = q & 1, n1 = q >> 1;
         const int j = tid + 128 * q;
-        float2 m = cmul(ph, sample(j));
-        if (q == 0 && tid < CP_N) { const float w = tb.shape[tid]; m.x *= w; m.y *= w; }
+        cf m = cmul(ph, sample(j));
+        if (q == 0 && tid < CP_N) { const float w = tb.shape[tid]; m = emul(m, cf_make(w, w)); }
         x[8 * h + n1] = m;
         ph = cmul(ph, stp);
     }
     if (tid < CP_N) {                                          // fold the cyclic extension back (acquire.c:246-247)
         const int j = FFT_N + tid;
-        const float2 m = cmul(ph, sample(j));                  // ph = phasor of sample tid + 2048
+        const cf m = cmul(ph, sample(j));                      // ph = phasor of sample tid + 2048
         const float w = tb.shape[j];
-        x[0].x += w * m.x; x[0].y += w * m.y;
+        x[0] = cadd(x[0], emul(cf_make(w, w), m));
     }
     if (RAW) __syncthreads();                                  // every work-item has its samples: the tile becomes the FFT's
 
@@ -279,7 +305,7 @@ __device__ __forceinline__ void mixfft_symbol(const DevTables &tb, const DevBuff
 
     // fftshift (bin 1024 = DC) and the live-bin cut: x[4a + b] = bin kbase + 128 (a + 4 b); after the shift the work-item's
     // six candidates sit at kbase + 128 m', m' = 10, 11, 12 (upper sideband, bins 1304 .. 1570) and 3, 4, 5 (lower, 478 .. 744)
-    float2 *out = db.bins + ((size_t)s * NSYM + sym) * LIVE_N;
+    cf *out = (cf *)(db.bins + ((size_t)s * NSYM + sym) * LIVE_N);
     const int kbase = (tid >> 4) + 8 * (tid & 15);
     static_assert(LB0 == 478 && UB0 == 1304 && UB1 == 1570 && LIVE_HALF == 267, "the six-output cut below is laid out for these edges");
     if (kbase >= LB0 - 384) out[kbase + 384 - LB0] = x[14];                    // m' = 3  (X[11])
@@ -290,13 +316,16 @@ __device__ __forceinline__ void mixfft_symbol(const DevTables &tb, const DevBuff
     if (kbase + 1536 <= UB1) out[LIVE_HALF + kbase + 1536 - UB0] = x[1];       // m' = 12 (X[4])
 }
 
+// (Held to 96 VGPRs for a fifth wave per SIMD -- amdgpu_waves_per_eu(5, 5), 7 dwords spilled -- the kernel was measured SLOWER,
+// 17.2 vs 16.1 ms per pass, and the decode waves beside it lose their room: k_p1_forward 12 -> 21 ms of device time.)
 __global__ __launch_bounds__(128) void k_mixfft(DevTables tb, DevBuffers db, const int *ids)
 {
     wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
     const int s = stream_of(ids, blockIdx.y);
     const StreamState &st = db.state[s];
     if (!st.active) return;                                    // block-uniform
-    __shared__ float2 lds[8 * PITCH_A];
+    __shared__ cf lds[8 * PITCH_A];
+    static_assert(sizeof(cf) == sizeof(float2), "a complex value is two floats either way");
     static_assert(8 * PITCH_A >= 17 * 128 && 17 * 127 < SYM_N, "17 decimated samples per work-item fit in the FFT tile");
     if (st.raw) mixfft_symbol<true>(tb, db, st, s, lds);
     else mixfft_symbol<false>(tb, db, st, s, lds);
@@ -310,11 +339,11 @@ void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, cons
 // ---- stage-level entry: plain 2048-point FFTs, natural order in and out (parity tests) ----------------
 __global__ __launch_bounds__(128) void k_fft2048(DevTables tb, const float2 *in, float2 *out)
 {
-    __shared__ float2 lds[8 * PITCH_A];
+    __shared__ cf lds[8 * PITCH_A];
     const int tid = threadIdx.x;
-    const float2 *src = in + (size_t)blockIdx.x * FFT_N;
-    float2 *dst = out + (size_t)blockIdx.x * FFT_N;
-    float2 x[16];
+    const cf *src = (const cf *)(in + (size_t)blockIdx.x * FFT_N);
+    cf *dst = (cf *)(out + (size_t)blockIdx.x * FFT_N);
+    cf x[16];
 #pragma unroll
     for (int h = 0; h < 2; h++)
 #pragma unroll
