@@ -42,12 +42,27 @@ __device__ __forceinline__ cf cf_make(float x, float y) { cf r; r.x = x; r.y = y
 __device__ __forceinline__ cf cadd(cf a, cf b) { return a + b; }
 __device__ __forceinline__ cf csub(cf a, cf b) { return a - b; }
 __device__ __forceinline__ cf emul(cf a, cf b) { return a * b; }
-__device__ __forceinline__ cf cmul(cf a, cf b) { const cf t = a.yx * b.yy; return a * b.xx + cf_make(-t.x, t.y); }
+// (a.x b.x - a.y b.y, a.y b.x + a.x b.y): the second product joins through fma(t, (-1, 1), p) = p -+ t, rounded once like the
+// subtraction / addition it replaces (t * +-1 is exact) -- 3 packed instructions; written as p + (-t.x, t.y) the compiler negated
+// BOTH halves and moved one back
+__device__ __forceinline__ cf cmul(cf a, cf b) { const cf t = a.yx * b.yy, sg = {-1.0f, 1.0f}; return __builtin_elementwise_fma(t, sg, a * b.xx); }
 __device__ __forceinline__ cf mul_mj(cf a) { return cf_make(a.y, -a.x); }
 __device__ __forceinline__ cf cf_swap(cf a) { return a.yx; }
 __device__ __forceinline__ cf cf_neg_x(cf a) { return cf_make(-a.x, a.y); }
 #endif
 __device__ inline cf cf_of(float2 a) { return cf_make(a.x, a.y); }
+// q15_to_float (halfband_raw.h) on both components at once: the same three roundings per component
+__device__ __forceinline__ cf q15_to_cf(cf x)
+{
+#ifdef HIPEMU
+    return cf_make(q15_to_float(x.x), q15_to_float(x.y));
+#else
+    const cf r = {1.0f / 32767.0f, 1.0f / 32767.0f}, d = {32767.0f, 32767.0f};
+    const cf q0 = x * r;
+    const cf e = __builtin_elementwise_fma(-q0, d, x);
+    return __builtin_elementwise_fma(e, r, q0);
+#endif
+}
 
 // forward 4-point DFT in place, natural order out
 __device__ inline void dft4(cf &a0, cf &a1, cf &a2, cf &a3)
@@ -279,9 +294,9 @@ __device__ __forceinline__ void mixfft_symbol(const DevTables &tb, const DevBuff
     const c16 *win = db.q15 + (size_t)s * db.q15_cap + a0;     // FIFO path (streaming seam, cs16 input)
 
     auto sample = [&](int j) -> cf {
-        if (RAW) { const cf y = lds[j]; return cf_make(q15_to_float(y.x), q15_to_float(y.y)); }   // the tile holds Q15 integers, conjugated
+        if (RAW) return q15_to_cf(lds[j]);                     // the tile holds Q15 integers, conjugated
         const c16 s16 = win[j];
-        return cf_make(q15_to_float((float)s16.r), -q15_to_float((float)s16.i));   // cq15_to_cf_conj, defines.h:111
+        return q15_to_cf(cf_make((float)s16.r, -(float)s16.i));   // cq15_to_cf_conj, defines.h:111 (the quotient is odd in its argument)
     };
     cf x[16];
 #pragma unroll
