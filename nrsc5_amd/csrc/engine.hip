@@ -243,6 +243,12 @@ static int build_tables(nrsc5hip_engine *e)
     if ((rc = dev_upload(e, &e->tb.scr_p1, scr))) return rc;
     if ((rc = dev_upload(e, &e->tb.scr_pids, scr_pids))) return rc;
     if ((rc = dev_upload(e, &e->tb.twiddle, tw))) return rc;
+    {   // k_mixfft's first exchange: work-item r multiplies its k1-th output by W2048^(k1 r) -- from the plain table a gather with stride
+        // k1 (up to 28 cache lines per wave and load), from this copy 256 consecutive entries per k1
+        std::vector<float2> twa(7 * 256);
+        for (int k1 = 1; k1 < 8; k1++) for (int r = 0; r < 256; r++) twa[(k1 - 1) * 256 + r] = tw[(k1 * r) & 2047];
+        if ((rc = dev_upload(e, &e->tb.twiddle_a, twa))) return rc;
+    }
     if ((rc = dev_upload(e, &e->tb.shape, shape))) return rc;
     if ((rc = dev_upload(e, &e->tb.hb_q15, hbq))) return rc;
     if ((rc = dev_upload(e, &e->tb.acq_q15, acq))) return rc;

@@ -141,6 +141,11 @@ __device__ inline void dft16_live(cf *v)
     }
 }
 
+__device__ inline void fft_stage_b_twiddles(cf *twB, const float2 *tw)
+{
+    for (int m = threadIdx.x; m < 256; m += blockDim.x) twB[m] = cf_of(tw[8 * m]);
+}
+
 constexpr int PITCH_A = 272;   // floats2 per k1 row (256 + 16: rows of one half-wave land on disjoint banks)
 constexpr int PITCH_B = 17;    // per r2 row inside a k1 row of the second layout (16 + 1)
 
@@ -149,8 +154,11 @@ constexpr int PITCH_B = 17;    // per r2 row inside a k1 row of the second layou
 //       x[8..15] = samples r + 256*n1 for r = tid + 128
 //  out: x[4a+b]  = bin  k1 + 8*k2 + 128*(a + 4b)   with k1 = tid >> 4, k2 = tid & 15
 //  LIVE: only x[1], x[3], x[7], x[8], x[12], x[14] are produced (dft16_live)
+// twB = W256^m, m = 0..255 (= tw[8 m]) in LDS, filled by fft_stage_b_twiddles before the first barrier the caller passes: the second
+// exchange's twiddles are the same 256 values for every workgroup, and as gathers from the global table they were 15 load
+// instructions of 16 cache lines each per wave on top of the first exchange's 14
 template <bool LIVE>
-__device__ inline void fft2048_wg(cf *x, cf *lds, const float2 *tw)
+__device__ inline void fft2048_wg(cf *x, cf *lds, const float2 *twA, const cf *twB)
 {
     const int tid = threadIdx.x;
     // stage A: two radix-8 butterflies, twiddle W2048^(k1*r), scatter to [k1][r]
@@ -161,7 +169,7 @@ __device__ inline void fft2048_wg(cf *x, cf *lds, const float2 *tw)
 #pragma unroll
         for (int k1 = 0; k1 < 8; k1++) {
             cf v = x[8 * h + k1];
-            if (k1) v = cmul(v, cf_of(tw[(k1 * r) & 2047]));
+            if (k1) v = cmul(v, cf_of(twA[(k1 - 1) * 256 + r]));   // = twiddle[(k1 r) & 2047], consecutive work-items consecutive entries
             lds[k1 * PITCH_A + r] = v;
         }
     }
@@ -177,7 +185,7 @@ __device__ inline void fft2048_wg(cf *x, cf *lds, const float2 *tw)
         for (int i = 0; i < 16; i++) {
             const int k2 = (i >> 2) + 4 * (i & 3);
             cf v = x[i];
-            if (r2) v = cmul(v, cf_of(tw[(8 * r2 * k2) & 2047]));
+            if (r2) v = cmul(v, twB[(r2 * k2) & 255]);
             lds[k1 * PITCH_A + r2 * PITCH_B + k2] = v;
         }
     }
@@ -268,8 +276,9 @@ __device__ inline void decimate_symbol_raw(const uint8_t *raw, long long a0, cf 
 // RAW: the stream reads its cu8 capture in place (zero-copy batch) -- else its samples come from the Q15 FIFO.  Block-uniform, so
 // the two forms are separate instantiations rather than a test per sample.
 template <bool RAW>
-__device__ __forceinline__ void mixfft_symbol(const DevTables &tb, const DevBuffers &db, const StreamState &st, int s, cf *lds)
+__device__ __forceinline__ void mixfft_symbol(const DevTables &tb, const DevBuffers &db, const StreamState &st, int s, cf *lds, cf *twB)
 {
+    fft_stage_b_twiddles(twB, tb.twiddle);                     // in flight beside the sample loads; first read two barriers from here
     const int sym = blockIdx.x, tid = threadIdx.x;
     const long long a0 = (st.rd - st.base) + sym * SYM_N + st.samperr_cur;     // first sample of the symbol in the decimated stream
     const double dth = st.dtheta;
@@ -316,10 +325,12 @@ __device__ __forceinline__ void mixfft_symbol(const DevTables &tb, const DevBuff
     }
     if (RAW) __syncthreads();                                  // every work-item has its samples: the tile becomes the FFT's
 
-    fft2048_wg<true>(x, lds, tb.twiddle);
+    fft2048_wg<true>(x, lds, tb.twiddle_a, twB);
 
     // fftshift (bin 1024 = DC) and the live-bin cut: x[4a + b] = bin kbase + 128 (a + 4 b); after the shift the work-item's
     // six candidates sit at kbase + 128 m', m' = 10, 11, 12 (upper sideband, bins 1304 .. 1570) and 3, 4, 5 (lower, 478 .. 744)
+    // (Gathering the six outputs in the idle LDS tile and storing 534 consecutive values instead -- two more barriers -- was measured:
+    // no gain for the kernel, 34.6 -> 35.3 ms for the pass.)
     cf *out = (cf *)(db.bins + ((size_t)s * NSYM + sym) * LIVE_N);
     const int kbase = (tid >> 4) + 8 * (tid & 15);
     static_assert(LB0 == 478 && UB0 == 1304 && UB1 == 1570 && LIVE_HALF == 267, "the six-output cut below is laid out for these edges");
@@ -342,8 +353,9 @@ __global__ __launch_bounds__(128) void k_mixfft(DevTables tb, DevBuffers db, con
     __shared__ cf lds[8 * PITCH_A];
     static_assert(sizeof(cf) == sizeof(float2), "a complex value is two floats either way");
     static_assert(8 * PITCH_A >= 17 * 128 && 17 * 127 < SYM_N, "17 decimated samples per work-item fit in the FFT tile");
-    if (st.raw) mixfft_symbol<true>(tb, db, st, s, lds);
-    else mixfft_symbol<false>(tb, db, st, s, lds);
+    __shared__ cf twB[256];
+    if (st.raw) mixfft_symbol<true>(tb, db, st, s, lds, twB);
+    else mixfft_symbol<false>(tb, db, st, s, lds, twB);
 }
 
 void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st)
@@ -363,7 +375,9 @@ __global__ __launch_bounds__(128) void k_fft2048(DevTables tb, const float2 *in,
     for (int h = 0; h < 2; h++)
 #pragma unroll
         for (int n1 = 0; n1 < 8; n1++) x[8 * h + n1] = src[tid + 128 * h + 256 * n1];
-    fft2048_wg<false>(x, lds, tb.twiddle);
+    __shared__ cf twB[256];
+    fft_stage_b_twiddles(twB, tb.twiddle);
+    fft2048_wg<false>(x, lds, tb.twiddle_a, twB);
     const int kbase = (tid >> 4) + 8 * (tid & 15);
 #pragma unroll
     for (int i = 0; i < 16; i++) dst[kbase + 128 * ((i >> 2) + 4 * (i & 3))] = x[i];

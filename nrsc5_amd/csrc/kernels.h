@@ -15,6 +15,7 @@ struct DevTables {
     const uint32_t *scr_p1;          // [P1_WORDS] packed scrambler stream (decode.c:279-294)
     const uint32_t *scr_pids;        // [3]
     const float2 *twiddle;           // [2048] e^{-2 pi i k / 2048}
+    const float2 *twiddle_a;         // [7][256] the same values in the order the FFT's first exchange reads them: [k1 - 1][r] = twiddle[(k1 r) & 2047]
     const float *shape;              // [2160] pulse shape (acquire.c:322-331)
     const int16_t *hb_q15;           // [4]  half-band taps, window order
     const int16_t *acq_q15;          // [17] acquisition FIR taps, [1..16] used
