@@ -667,8 +667,17 @@ static int run_steps(nrsc5hip_engine *e, int n, const int *ids_dev, unsigned lon
         bool live = n > 0;
         while (live && done < max_steps) {
             HIPCHK(hipMemsetAsync(ln.counters_dev, 0, 4 * sizeof(int), ln.main));
+            // While the acquisition kernels are being launched the host looks again after 4 steps instead of a whole window: they are
+            // eight thin launches per step (~38 us of a ~135 us step) for as long as the LAST look saw a stream that was not FINE,
+            // and every stream of a batch is past that point a few blocks after its (re-)acquisition.
+            // Bursts end on window boundaries (the rollback below is launched there).
+            int every = check_every;
+            if (check_every == 16) {
+                const int to_boundary = 16 - (int)(ln.step_count % 16);
+                every = ln.acq_needed ? std::min(4, to_boundary) : to_boundary;   // 2 measured: the same
+            }
             int burst = 0;
-            for (; burst < check_every && done + burst < max_steps; burst++) { int rc = issue_step(e, ln, n, ids_dev); if (rc) return rc; }
+            for (; burst < every && done + burst < max_steps; burst++) { int rc = issue_step(e, ln, n, ids_dev); if (rc) return rc; }
             if (replay && (ln.step_count % 16) == 0) {
                 // Window boundary: take the first-header verdicts of the deferred decodes that have finished.  The decode whose
                 // job slot the next window reuses (launched NWIN windows before it) must be among them.
