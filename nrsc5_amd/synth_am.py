@@ -175,7 +175,7 @@ def _qpsk(code):
     return ((code & 1) - 0.5) + 1j * ((code >> 1) - 0.5)
 
 
-def block_spectrum_ma3(pl, pu, s, t, pids1, pids2, bc: int) -> np.ndarray:
+def block_spectrum_ma3(pl, pu, s, t, pids1, pids2, bc: int, rdbi: int = 0) -> np.ndarray:
     """All-digital MA3 layout (sync.c:612-767 with psmi == 2): nothing is complementary; primary = +-(2..26), secondary =
     +(28..52), tertiary = -(28..52), PIDS at -27 / +27, everything QAM64 except PIDS (QAM16)."""
     x = np.zeros((BLKSZ, FFT), dtype=np.complex128)
@@ -193,18 +193,20 @@ def block_spectrum_ma3(pl, pu, s, t, pids1, pids2, bc: int) -> np.ndarray:
     filler = ((((col * 7 + 3) % 4) & 1) - 0.5) + 1j * ((((col * 7 + 3) % 4) >> 1) - 0.5)
     x[:, c + 57 + col] = 2.0 * filler
     x[:, c - 57 - col] = 2.0 * np.conj(filler)
-    ref = 1j * LEVEL_REF * (reference_bits(bc, psmi=2).astype(np.float64) * 2 - 1)
+    ref = 1j * LEVEL_REF * (reference_bits(bc, psmi=2, rdbi=rdbi).astype(np.float64) * 2 - 1)
     x[:, c + 1] = ref
     x[:, c - 1] = -np.conj(ref)
     x[:, c] = LEVEL_CARRIER
     return x
 
 
-def reference_bits(bc: int, psmi: int = 1) -> np.ndarray:
+def reference_bits(bc: int, psmi: int = 1, rdbi: int = 0) -> np.ndarray:
     """32 BPSK bits of the AM reference carrier for block `bc` (find_block_am, sync.c:209-238)."""
     d = np.zeros(32, dtype=np.uint8)
     d[[1, 2, 5, 9, 21, 22]] = 1
-    # d7 = pli = 0 (d8 = d7), d11 = hppi, d12 = aabi, d15 = rdbi: all 0
+    # d7 = pli = 0 (d8 = d7), d11 = hppi, d12 = aabi: all 0; d15 = rdbi (reduced digital bandwidth: the receiver skips the P3 frame,
+    # decode.c:524)
+    d[15] = rdbi & 1
     d[17], d[18], d[19] = (bc >> 2) & 1, (bc >> 1) & 1, bc & 1
     d[20] = d[15] ^ d[16] ^ d[17] ^ d[18] ^ d[19]
     for k in range(5):
@@ -232,7 +234,7 @@ def pids_symbols(pids_bits80: np.ndarray):
     return s1, s2
 
 
-def block_spectrum(pl, pu, s, t, pids1, pids2, bc: int) -> np.ndarray:
+def block_spectrum(pl, pu, s, t, pids1, pids2, bc: int, rdbi: int = 0) -> np.ndarray:
     """One block of symbol codes [32][25] x4 + PIDS + reference -> X[32 symbols, 256 bins] (bin 128 = carrier)."""
     x = np.zeros((BLKSZ, FFT), dtype=np.complex128)
     c = FFT // 2
@@ -248,7 +250,7 @@ def block_spectrum(pl, pu, s, t, pids1, pids2, bc: int) -> np.ndarray:
     comp(2 + col, LEVEL_TERTIARY * _qpsk(t))
     comp(27, LEVEL_PIDS * _qam16(pids1))
     comp(53, LEVEL_PIDS * _qam16(pids2))
-    comp(1, 1j * LEVEL_REF * (reference_bits(bc).astype(np.float64) * 2 - 1))
+    comp(1, 1j * LEVEL_REF * (reference_bits(bc, rdbi=rdbi).astype(np.float64) * 2 - 1))
     x[:, c] = LEVEL_CARRIER
     return x
 
@@ -280,7 +282,7 @@ class AmCapture:
     seed: int
 
 
-def am_ma1_signal(n_frames: int, seed: int = 1, fmt: str = "cs16", mode: str = "MA1"):
+def am_ma1_signal(n_frames: int, seed: int = 1, fmt: str = "cs16", mode: str = "MA1", rdbi: int = 0):
     """The clean transmission of am_ma1_capture (no CFO, offset, noise): complex128 baseband at the capture's sample rate and
     the transmitted truth (P1 frames, P3 frames, PIDS frames).  bench.py puts many receivers' channels on one such signal
     (synth_torch.channel_am)."""
@@ -324,7 +326,7 @@ def am_ma1_signal(n_frames: int, seed: int = 1, fmt: str = "cs16", mode: str = "
         for bc in range(BLOCKS_PER_FRAME):
             s1, s2 = pids_symbols(pids[bc])
             spec = block_spectrum_ma3 if ma3 else block_spectrum
-            chunks.append(ofdm_modulate(spec(pl[bc], pu[bc], s[bc], t[bc], s1, s2, bc), oversample))
+            chunks.append(ofdm_modulate(spec(pl[bc], pu[bc], s[bc], t[bc], s1, s2, bc, rdbi), oversample))
             pids_list.append(pids[bc])
         p1_list.append(p1); p3_list.append(p3)
     return np.concatenate(chunks), p1_list, p3_list, pids_list
@@ -332,13 +334,13 @@ def am_ma1_signal(n_frames: int, seed: int = 1, fmt: str = "cs16", mode: str = "
 
 def am_ma1_capture(n_frames: int, seed: int = 1, cfo_hz: float = 3.0, offset: int = 1000, noise: float = 0.5,
                    fmt: str = "cs16", tail_samples: int = 1080, unit_lsb: float | None = None, mode: str = "MA1",
-                   burst: tuple | None = None) -> AmCapture:
+                   burst: tuple | None = None, rdbi: int = 0) -> AmCapture:
     """Hybrid-AM MA1 capture of n_frames L1 frames (8 blocks x 32 symbols each).  `noise` = per-sample complex
     noise sigma in primary QAM64 grid units; `unit_lsb` = LSBs per grid unit (default 100 for cs16, 0.8 for cu8)."""
     rng = np.random.default_rng(seed)
     oversample = 1 if fmt == "cs16" else 32
     fs = FS_CS16 if fmt == "cs16" else FS_CU8
-    sig, p1_list, p3_list, pids_list = am_ma1_signal(n_frames, seed, fmt, mode)
+    sig, p1_list, p3_list, pids_list = am_ma1_signal(n_frames, seed, fmt, mode, rdbi)
     n = sig.shape[0]
     if cfo_hz:
         sig *= np.exp(2j * np.pi * cfo_hz / fs * np.arange(n))

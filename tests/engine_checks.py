@@ -555,6 +555,20 @@ def check_am_batch_equals_streaming(lib, kws, p1_async=False):
     E.close()
 
 
+def check_am_reduced_bandwidth(lib, oracle):
+    """RDBI = 1 (system control bit 15 of the AM reference carrier): the receiver decodes the eight P1 frames of an L1 frame and NO P3
+    frame, and the frame's BER is over the P1 bits only (decode.c:520-545) -- in order, and in the window pipeline where the P3 segment
+    waves, their checks and the frame accounting have to stand down (k_am_decode_*)."""
+    from nrsc5_amd import synth_am
+    kw = dict(n_frames=11, seed=21, cfo_hz=1.5, offset=700, rdbi=1)
+    check_am_oracle_end_to_end(lib, oracle, kw)
+    cap = synth_am.am_ma1_capture(**kw)
+    ol, _, _ = oracle.run(cap.iq, mode=1)
+    assert sum(1 for k, v in ol if k == "frame" and v["lc"] == 0) >= 16 and not any(k == "frame" and v["lc"] == 1 for k, v in ol)
+    assert [v["rdbi"] for k, v in ol if k == "sync"] == [1]
+    check_am_batch_equals_streaming(lib, [kw, dict(n_frames=9, seed=7, cfo_hz=2.0, offset=600)], p1_async=True)
+
+
 def check_l2_feedback(lib, oracle, kw, am=False):
     """Engine-side L2 -> L1 feedback (RS(255,247) first-header check on the device, in-order decode) == the oracle driven
     by the restated frame_process decision, which itself is pinned against the unmodified reference incl. its L2."""

@@ -95,6 +95,10 @@ def test_emu_am_replay_equals_reference(emu_lib, oracle, lag):
     ec.check_am_deferred_feedback_equals_reference(emu_lib, oracle, verdict_lag=lag)
 
 
+def test_emu_am_reduced_bandwidth(emu_lib, oracle):
+    ec.check_am_reduced_bandwidth(emu_lib, oracle)
+
+
 def test_emu_mixed_batch_pipeline(emu_lib, oracle):
     ec.check_mixed_batch_pipeline(emu_lib, oracle, passes=1)
 

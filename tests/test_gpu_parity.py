@@ -276,6 +276,10 @@ def test_gpu_am_replay_equals_reference(hip_lib, oracle, lag):
     ec.check_am_deferred_feedback_equals_reference(hip_lib, oracle, verdict_lag=lag)
 
 
+def test_gpu_am_reduced_bandwidth(hip_lib, oracle):
+    ec.check_am_reduced_bandwidth(hip_lib, oracle)
+
+
 def test_gpu_mixed_batch_pipeline(hip_lib, oracle):
     ec.check_mixed_batch_pipeline(hip_lib, oracle, passes=3)
 

@@ -60,7 +60,8 @@ def test_am_oracle_bit_identical_to_reference(sse, oracle):
                dict(n_frames=7, seed=4, cfo_hz=200.0, offset=0),
                dict(n_frames=7, seed=5, cfo_hz=-40.0, offset=9000, noise=2.0),
                dict(n_frames=2, seed=6, cfo_hz=10.0, offset=64 * 300 + 12, fmt="cu8"),
-               dict(n_frames=9, seed=8, cfo_hz=-6.0, offset=2000, mode="MA3")):
+               dict(n_frames=9, seed=8, cfo_hz=-6.0, offset=2000, mode="MA3"),
+               dict(n_frames=10, seed=21, cfo_hz=1.5, offset=700, rdbi=1)):          # reduced digital bandwidth: no P3 frame (decode.c:524)
         cap = synth_am.am_ma1_capture(**kw)
         rl, rq, rf = R.run(cap.iq, mode=ref.MODE_AM, taps=ref.TAP_Q15 | ref.TAP_SOFT | ref.TAP_FFT, fft_blocks=2)
         ol, oq, of = oracle.run(cap.iq, mode=1, taps=port.TAP_Q15 | port.TAP_SOFT | port.TAP_FFT, fft_blocks=2)
