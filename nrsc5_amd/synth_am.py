@@ -334,13 +334,16 @@ def am_ma1_signal(n_frames: int, seed: int = 1, fmt: str = "cs16", mode: str = "
 
 def am_ma1_capture(n_frames: int, seed: int = 1, cfo_hz: float = 3.0, offset: int = 1000, noise: float = 0.5,
                    fmt: str = "cs16", tail_samples: int = 1080, unit_lsb: float | None = None, mode: str = "MA1",
-                   burst: tuple | None = None, rdbi: int = 0) -> AmCapture:
+                   burst: tuple | None = None, rdbi: int = 0, chan=None) -> AmCapture:
     """Hybrid-AM MA1 capture of n_frames L1 frames (8 blocks x 32 symbols each).  `noise` = per-sample complex
     noise sigma in primary QAM64 grid units; `unit_lsb` = LSBs per grid unit (default 100 for cs16, 0.8 for cu8)."""
     rng = np.random.default_rng(seed)
     oversample = 1 if fmt == "cs16" else 32
     fs = FS_CS16 if fmt == "cs16" else FS_CU8
     sig, p1_list, p3_list, pids_list = am_ma1_signal(n_frames, seed, fmt, mode, rdbi)
+    if chan is not None and chan.active():                     # channel.Impairments: sample-clock error, echoes, fading
+        from . import channel
+        sig = channel.apply(sig, fs, chan)
     n = sig.shape[0]
     if cfo_hz:
         sig *= np.exp(2j * np.pi * cfo_hz / fs * np.arange(n))

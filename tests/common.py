@@ -33,23 +33,48 @@ FLOAT_RTOL = 1e-4   # north_star: CFO / sync estimates within 1e-4 relative -- R
 #    (2.5e-3 Hz), next_angle 8.5e-5, freq_offset 5.9e-4 Hz, NCO phase 1.5e-3, MER 5.5e-4 dB -- far below the estimator's own noise,
 #    but not 1e-4 of a value that is itself ~0.  From the first falsely locked stretch of a capture onwards the floats keep the old
 #    bound (1e-4 with a floor of 1; NCO phase 5e-3); integers, frames and events stay exact.  compare_logs marks those records.
+#  * MER is reported in dB (sync.c:470-487: 10 log10 of signal over error power): 1e-4 relative to a dB VALUE is meaningless where
+#    the value crosses 0 dB (the first report after a lock under a sample-clock error: -0.73 dB vs -0.7343 dB is 5.6e-5 of the power
+#    ratio).  The bound is therefore 1e-4 of the dB value OR 1e-4 of the power RATIO, 10 log10(1 + 1e-4) = 4.4e-4 dB.
+#    A report BELOW 0 dB (error power above signal power: an interference burst, a false lock) is a sum dominated by a few
+#    near-singular equaliser cells -- adjust_data divides by k smag19 e^{j phi_u} + (19 - k) smag0 e^{j phi_l} (sync.c:263-282), which
+#    cancels to ~0 where the reference carriers are noise -- so the last ulp of sine / cosine decides the third digit: measured
+#    -11.6527 (reference, libm) vs -11.6550 dB (MI355X and the CPU emulator of the same kernels agree to 5e-5) during a burst 20 dB
+#    above the signal.  Such reports are compared to 0.01 dB and COUNTED (EXEMPT["mer_below_0db"]); nothing above 0 dB is exempt.
+import collections
+EXEMPT = collections.Counter()
+MER_BELOW_0DB_ABS = 0.01
 ABS_ONLY = {"next_angle": 5e-5, "phase_re": 1e-3, "phase_im": 1e-3, "cber": 2e-5}
-EITHER_ABS = {"freq_offset": 1e-3, "prev_angle": 5e-5}
+EITHER_ABS = {"freq_offset": 1e-3, "prev_angle": 5e-5, "lower": 4.4e-4, "upper": 4.4e-4}
 LOOSE_IN_FALSE_LOCK = {"phase_re": 5e-3, "phase_im": 5e-3, "freq_offset": 1e-2, "lower": 2e-3, "upper": 2e-3}
 
 
 def float_close(key: str, va: float, vb: float, rtol: float = FLOAT_RTOL, false_lock: bool = False) -> bool:
-    if false_lock and rtol > 0:
-        return abs(va - vb) <= LOOSE_IN_FALSE_LOCK.get(key, rtol * max(1.0, abs(va)))
+    if false_lock and rtol > 0 and abs(va - vb) <= LOOSE_IN_FALSE_LOCK.get(key, rtol * max(1.0, abs(va))):
+        return True
     if key in ABS_ONLY and rtol > 0:
         return abs(va - vb) <= ABS_ONLY[key]
     if abs(va - vb) <= rtol * abs(va):
         return True
-    return rtol > 0 and key in EITHER_ABS and abs(va - vb) <= EITHER_ABS[key]
+    if rtol > 0 and key in EITHER_ABS and abs(va - vb) <= EITHER_ABS[key]:
+        return True
+    if rtol > 0 and key in ("lower", "upper") and va < 0.0 and abs(va - vb) <= MER_BELOW_0DB_ABS:
+        EXEMPT["mer_below_0db"] += 1
+        return True
+    return False
+
+
+def _imp(**kw):
+    from nrsc5_amd import channel
+    return channel.Impairments(**kw)
 
 
 # golden capture definitions: name -> synth.fm_mp1_capture kwargs
 GOLDEN_CASES = {
+    # round 4: impaired channels (nrsc5_amd/channel.py) -- sample-clock error (timing feedback on every FINE block), analog host, echo
+    "fm_cu8_ppm60_host": dict(n_frames=0, n_blocks=40, seed=16, cfo_hz=-95.0, offset=2222, snr_db=24.0, rms_lsb=9.0, chan=_imp(ppm=60.0, host_db=20.0)),
+    "fm_cs16_ppm-85_echo": dict(n_frames=0, n_blocks=40, seed=17, cfo_hz=210.0, offset=640, snr_db=22.0, fmt="cs16",
+                                chan=_imp(ppm=-85.0, paths=((18e-6, -5.0, 0.7, 1.0),))),
     "fm_mp11_cs16": dict(n_frames=0, n_blocks=56, seed=14, cfo_hz=-30.0, offset=900, snr_db=24.0, fmt="cs16", mode="MP11"),
     "fm_mp2_cu8": dict(n_frames=0, n_blocks=56, seed=15, cfo_hz=80.0, offset=1500, snr_db=22.0, fmt="cu8", mode="MP2"),
     "fm_cu8_cfo137": dict(n_frames=0, n_blocks=40, seed=11, cfo_hz=137.0, offset=777, snr_db=20.0, fmt="cu8"),
@@ -60,11 +85,41 @@ GOLDEN_CASES = {
 
 # AM golden captures: name -> synth_am.am_ma1_capture kwargs
 GOLDEN_AM_CASES = {
+    "am_cs16_ppm12_echo": dict(n_frames=12, seed=24, cfo_hz=4.0, offset=1500, chan=_imp(ppm=12.0, paths=((90e-6, -8.0, 0.3, 1.0),))),
     "am_cs16_cfo3": dict(n_frames=11, seed=21, cfo_hz=3.0, offset=777, fmt="cs16"),
     "am_cu8_cfo-150": dict(n_frames=10, seed=22, cfo_hz=-150.0, offset=40000, fmt="cu8"),
     "am_ma3_cs16": dict(n_frames=8, seed=23, cfo_hz=-6.0, offset=2000, fmt="cs16", mode="MA3"),
 }
 AM_FRAME_BITS = {0: 3750, 1: 24000}
+
+
+# ---- impaired channels (nrsc5_amd/channel.py): what a real capture does to the receiver on EVERY block ---------------------------
+# name -> synth.fm_mp1_capture kwargs.  Sample-clock error makes sync.samperr != 0 in FINE (sync.c:455 -> acquire.c:112,259 ->
+# sync_adjust); echoes give adjust_data unequal reference magnitudes; the analog host fills the middle of the spectrum and, at
+# rms_lsb 17, drives the 8-bit quantiser into its rails; fading moves the MER-scaled soft-bit gain.
+IMPAIRED_FM_CASES = {
+    "ppm+60": dict(n_frames=0, n_blocks=36, seed=31, cfo_hz=-211.0, offset=1234, snr_db=22.0, chan=_imp(ppm=60.0)),
+    "ppm-85_cs16": dict(n_frames=0, n_blocks=36, seed=32, cfo_hz=95.0, offset=333, snr_db=20.0, fmt="cs16", chan=_imp(ppm=-85.0)),
+    "ppm+100_cfo_search": dict(n_frames=0, n_blocks=36, seed=33, cfo_hz=2950.0, offset=2017, snr_db=18.0, chan=_imp(ppm=100.0)),
+    "echoes": dict(n_frames=0, n_blocks=24, seed=34, cfo_hz=40.0, offset=901, snr_db=22.0,
+                   chan=_imp(paths=((18e-6, -5.0, 0.7, 1.0), (33e-6, -9.0, -1.3, 2.0)))),
+    "host20": dict(n_frames=0, n_blocks=24, seed=35, cfo_hz=-60.0, offset=1500, snr_db=24.0, rms_lsb=8.0, chan=_imp(host_db=20.0)),
+    "host_clip_ppm": dict(n_frames=0, n_blocks=24, seed=36, cfo_hz=130.0, offset=4000, snr_db=24.0, rms_lsb=17.0, chan=_imp(host_db=20.0, ppm=30.0)),
+    "fade_ppm": dict(n_frames=0, n_blocks=36, seed=37, cfo_hz=-211.0, offset=1234, snr_db=22.0, chan=_imp(fade_db=12.0, fade_period_s=1.3, ppm=-40.0)),
+    "all_mp11_cs16": dict(n_frames=0, n_blocks=44, seed=38, cfo_hz=25.0, offset=500, snr_db=26.0, fmt="cs16", mode="MP11",
+                          chan=_imp(ppm=47.0, paths=((12e-6, -8.0, 0.4, 0.3),), fade_db=4.0, fade_period_s=2.2)),
+}
+# name -> synth_am.am_ma1_capture kwargs (one block is 186 ms, 270 samples per symbol: 100 ppm = 0.86 samples per block).  The
+# reference's AM receiver corrects timing in whole samples only (sync.c:738-767), so between two corrections the outer carriers
+# rotate by up to 2 pi 81 / 256 * 0.5 rad: its own coded BER on a NOISELESS capture is 0.009 at 20 ppm, 0.029 at 30 ppm and it
+# loses frames beyond -- measured on the unmodified reference; the cases below span that range.
+IMPAIRED_AM_CASES = {
+    "am_ppm+18": dict(n_frames=12, seed=41, cfo_hz=3.0, offset=1234, chan=_imp(ppm=18.0)),
+    "am_ppm+30": dict(n_frames=12, seed=41, cfo_hz=3.0, offset=1234, chan=_imp(ppm=30.0)),
+    "am_ppm-50": dict(n_frames=12, seed=42, cfo_hz=-8.0, offset=700, chan=_imp(ppm=-50.0)),
+    "am_echo_fade": dict(n_frames=10, seed=43, cfo_hz=1.5, offset=2100, chan=_imp(paths=((90e-6, -6.0, 0.3, 1.0),), fade_db=6.0, fade_period_s=2.9)),
+    "am_cu8_ppm-70": dict(n_frames=5, seed=44, cfo_hz=20.0, offset=64 * 300 + 12, fmt="cu8", chan=_imp(ppm=-70.0)),
+}
 
 
 def sha256(a: np.ndarray) -> str:

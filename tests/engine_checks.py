@@ -767,12 +767,22 @@ def check_deferred_feedback_recovers(lib, n_blocks=256):
 FALSE_LOCK_CASES = ((23, 0.0, 1234), (24, 10.0, 2208), (25, 10.0, 777))     # seeds 23 / 24: the reference algorithm locks falsely first
 
 
-def check_deferred_feedback_equals_reference(lib, oracle, n_blocks=96, verdict_lag=0, extra=(), cases=FALSE_LOCK_CASES):
+def drift_replay_captures(n_blocks=96):
+    """Streams that lose sync in the MIDDLE of a tracked stretch while the sample clock drifts (an interference burst over 10-12
+    blocks breaks one P1 frame's first header): the replay checkpoint then holds a FIFO read position, a timing pick and 534
+    loop phases that have been walking for 30-50 blocks (acquire.c:110-119,259; sync.c:455,769-777)."""
+    from nrsc5_amd import channel
+    return [synth.fm_mp1_capture(0, seed=sd, cfo_hz=c, offset=o, snr_db=20, n_blocks=n_blocks, chan=channel.Impairments(ppm=ppm), burst=burst)
+            for sd, c, o, ppm, burst in ((51, 30.0, 1234, 55.0, (18.3, 12, 10.0)), (52, -120.0, 2208, -70.0, (34.0, 11, 8.0)), (54, 5.0, 700, 25.0, (33.5, 10.0, 6.0)))]
+
+
+def check_deferred_feedback_equals_reference(lib, oracle, n_blocks=96, verdict_lag=0, extra=(), cases=FALSE_LOCK_CASES, caps=None):
     """THE benchmarked mode (batch, window pipeline, on-device L2 feedback) against the oracle driven by the restated
     frame_process decision (itself pinned against the unmodified reference incl. its L2): the complete ordered log --
     LOST_SYNC on the reference's block, re-acquisition, every PIDS / P1 frame, SYNC / MER / BER -- must be equal, no matter
     how late the verdict of the deferred decode arrives (verdict_lag forces it `lag` windows late: deep speculation)."""
-    caps = [synth.fm_mp1_capture(0, seed=sd, cfo_hz=c, offset=o, snr_db=20, n_blocks=n_blocks) for sd, c, o in tuple(cases) + tuple(extra)]
+    if caps is None:
+        caps = [synth.fm_mp1_capture(0, seed=sd, cfo_hz=c, offset=o, snr_db=20, n_blocks=n_blocks) for sd, c, o in tuple(cases) + tuple(extra)]
     n = len(caps)
     stride = max(c.iq.size for c in caps); stride += (-stride) % 256
     buf = np.zeros((n, stride), dtype=np.uint8)
@@ -807,14 +817,15 @@ def check_deferred_feedback_equals_reference(lib, oracle, n_blocks=96, verdict_l
     E.close()
 
 
-def check_am_deferred_feedback_equals_reference(lib, oracle, verdict_lag=0, tunes=(), expect_k9_repairs=False):
+def check_am_deferred_feedback_equals_reference(lib, oracle, verdict_lag=0, tunes=(), expect_k9_repairs=False, kws=None, min_lost=2):
     """AM twin of check_deferred_feedback_equals_reference: batch, 8-step decode windows, on-device L2 feedback.  Noise bursts
     break the first header of some P1 PDUs; the verdict of the deferred decode rewinds the stream to the block that delivered
     that PDU (k_rollback_am), so LOST_SYNC, the re-acquisition and everything after land on the reference's blocks."""
     from nrsc5_amd import synth_am
-    kws = [dict(n_frames=16, seed=9, cfo_hz=2.0, offset=500, burst=(8.3, 0.5, 40.0)),
-           dict(n_frames=16, seed=10, cfo_hz=-3.0, offset=900, burst=(9.6, 0.3, 40.0)),
-           dict(n_frames=12, seed=11, cfo_hz=1.0, offset=100)]
+    if kws is None:
+        kws = [dict(n_frames=16, seed=9, cfo_hz=2.0, offset=500, burst=(8.3, 0.5, 40.0)),
+               dict(n_frames=16, seed=10, cfo_hz=-3.0, offset=900, burst=(9.6, 0.3, 40.0)),
+               dict(n_frames=12, seed=11, cfo_hz=1.0, offset=100)]
     caps = [synth_am.am_ma1_capture(**kw) for kw in kws]
     n = len(caps)
     stride = max(c.iq.size for c in caps); stride += (-stride) % 64
@@ -843,7 +854,7 @@ def check_am_deferred_feedback_equals_reference(lib, oracle, verdict_lag=0, tune
         diffs = [d for d in diffs if not any(d.startswith(f"#{i} ") or d.startswith(f"#{i + 1} frame") or d.startswith(f"#{i - 1} frame") for i in bad)]
         assert not diffs, (k, verdict_lag, diffs[:10])
         lost += sum(1 for kk, _ in ol if kk == "lost_sync")
-    assert lost >= 2, "captures do not exercise the feedback"
+    assert lost >= min_lost, "captures do not exercise the feedback"
     st = E.k9_stats()
     assert st[0] > 0 and st[2] > 0, st                         # the P3 frames went through segment waves
     if expect_k9_repairs:

@@ -201,3 +201,27 @@ def test_emu_block_exact_pushes(emu_lib, oracle):
 
 def test_emu_viterbi_segmented(emu_lib, oracle):
     ec.check_viterbi_segmented(emu_lib, oracle, lens=(4608,), segments=(1, 3, 8))
+
+
+# ---- impaired channels (nrsc5_amd/channel.py): the FINE-state timing feedback at work on every block ----------------------------
+@pytest.mark.parametrize("name", ["ppm+60", "ppm-85_cs16", "host_clip_ppm"])
+def test_emu_impaired_channel_streaming(emu_lib, oracle, name):
+    from tests import common
+    ec.check_oracle_end_to_end(emu_lib, oracle, common.IMPAIRED_FM_CASES[name])
+
+
+def test_emu_impaired_channel_zero_copy_batch(emu_lib):
+    """samperr != 0 in FINE moves `keep`, i.e. the position the fused half-band reads the capture from (k_mixfft a0 / st.rd)."""
+    from tests import common
+    caps = [synth.fm_mp1_capture(**common.IMPAIRED_FM_CASES[n]) for n in ("ppm+100_cfo_search", "fade_ppm", "echoes")]
+    ec.check_zero_copy_batch(emu_lib, caps, p1_async=True, l2_feedback=True)
+
+
+def test_emu_replay_under_drift(emu_lib, oracle):
+    """Sync loss 30-50 blocks into a drifting stream, verdict 3 windows late: the checkpoint restores a walked FIFO position."""
+    ec.check_deferred_feedback_equals_reference(emu_lib, oracle, n_blocks=96, verdict_lag=3, caps=ec.drift_replay_captures())
+
+
+def test_emu_am_impaired_channel(emu_lib, oracle):
+    from tests import common
+    ec.check_am_oracle_end_to_end(emu_lib, oracle, common.IMPAIRED_AM_CASES["am_ppm-50"])

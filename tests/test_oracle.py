@@ -62,6 +62,43 @@ def test_oracle_bit_identical_to_reference(sse, oracle):
         assert not common.compare_logs(rl, ol, rtol=0.0, skip_kinds=("hdc",))
 
 
+@pytest.mark.parametrize("name", list(common.IMPAIRED_FM_CASES))
+def test_oracle_impaired_channel_bit_identical_to_reference(name, oracle):
+    """Sample-clock error, echoes, analog host, clipping, fading (nrsc5_amd/channel.py): the FINE-state timing feedback
+    (sync.c:426-463 -> acquire.c:110-119,259 -> sync_adjust sync.c:769-777) works on every block of these captures.  Restatement
+    == both builds of the UNMODIFIED reference incl. its L2 decision, 0 tolerance: Q15 stream, soft bits, every float."""
+    from oracle import ref, port
+    if not ref.available(False):
+        pytest.skip("reference build absent")
+    cap = synth.fm_mp1_capture(**common.IMPAIRED_FM_CASES[name])
+    ol, oq, _ = oracle.run(cap.iq, taps=port.TAP_Q15 | port.TAP_SOFT, p1_hook=oracle.l2_hook())
+    for sse in (False, True):
+        rl, rq, _ = ref.RefLib(sse=sse).run(cap.iq, taps=ref.TAP_Q15 | ref.TAP_SOFT)
+        assert np.array_equal(rq, oq)
+        assert not common.compare_logs(rl, ol, rtol=0.0, skip_kinds=("hdc",))
+    blocks = [v for k, v in ol if k == "block"]
+    fine = [b for b in blocks if b["state_before"] == 2]
+    if cap_has_drift(common.IMPAIRED_FM_CASES[name]):
+        assert sum(1 for b in fine if b["samperr"] != 1080) >= len(fine) // 2, "the capture does not exercise the timing feedback"
+    assert any(k == "frame" for k, _ in ol)
+
+
+def cap_has_drift(kw) -> bool:
+    return abs(kw["chan"].ppm) >= 25.0
+
+
+def test_oracle_sync_loss_under_drift_bit_identical_to_reference(oracle, reflib):
+    """A burst breaks a P1 frame's first header 30-50 blocks into a drifting, tracked stream: LOST_SYNC, the re-acquisition from
+    prev_angle != 0 and everything after it (frame.c:535-540, acquire.c:110-158)."""
+    from tests import engine_checks as ec
+    for cap in ec.drift_replay_captures():
+        rl, _, _ = reflib.run(cap.iq)
+        ol, _, _ = oracle.run(cap.iq, p1_hook=oracle.l2_hook())
+        assert not common.compare_logs(rl, ol, rtol=0.0)
+        kinds = [k for k, _ in ol]
+        assert "lost_sync" in kinds and max(i for i, k in enumerate(kinds) if k == "lost_sync") > 60    # deep into the tracked stretch
+
+
 def test_oracle_noise_only_stays_unsynchronised(oracle, reflib):
     rng = np.random.default_rng(1)
     iq = rng.integers(100, 156, size=2 * 1488375, dtype=np.uint8)   # 1 s of noise

@@ -41,12 +41,29 @@ def test_am_golden_frames_equal_transmitted_truth(name):
     4.. (3-frame diversity delay + am_diversity_wait), P3 frames are not delayed."""
     g = _golden(name)
     n1, n3 = g["p1"].shape[0], g["p3"].shape[0]
-    assert n1 >= 16 and n3 >= 2 and np.all(g["ber"] == 0)
+    # a drifting sample clock costs the reference coded-bit errors even without noise (whole-sample timing corrections only); the
+    # decoded frames are still the transmitted ones
+    assert n1 >= 16 and n3 >= 2 and np.all(g["ber"] <= (0.01 if "ppm" in name else 0.0))
     first = next(i for i in range(g["truth_p1"].shape[0]) if np.array_equal(g["truth_p1"][i], g["p1"][0]))
     assert first % 8 == 0 and np.array_equal(g["p1"], g["truth_p1"][first:first + n1])
     # MA1: the P3 code word is not diversity-delayed (decoded frame = the one just received); MA3: it is, like P1
     f3 = first // 8 + (0 if name == "am_ma3_cs16" else 3)
     assert np.array_equal(g["p3"], g["truth_p3"][f3:f3 + n3])
+
+
+@pytest.mark.parametrize("name", list(common.IMPAIRED_AM_CASES))
+def test_am_oracle_impaired_channel_bit_identical_to_reference(name, oracle):
+    """AM twin of test_oracle_impaired_channel_bit_identical_to_reference: sample-clock error, an echo inside the cyclic prefix,
+    fading.  Restatement == both builds of the unmodified reference incl. its L2 decision, 0 tolerance."""
+    from oracle import ref, port
+    if not ref.available(False):
+        pytest.skip("reference build absent")
+    cap = synth_am.am_ma1_capture(**common.IMPAIRED_AM_CASES[name])
+    ol, oq, _ = oracle.run(cap.iq, taps=port.TAP_Q15 | port.TAP_SOFT, mode=1, p1_hook=oracle.l2_hook())
+    for sse in (False, True):
+        rl, rq, _ = ref.RefLib(sse=sse).run(cap.iq, mode=ref.MODE_AM, taps=ref.TAP_Q15 | ref.TAP_SOFT)
+        assert np.array_equal(rq, oq)
+        assert not common.compare_logs(rl, ol, rtol=0.0, skip_kinds=("hdc",))
 
 
 @pytest.mark.parametrize("sse", [False, True])
