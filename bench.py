@@ -59,14 +59,14 @@ def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--workload", default="fm", choices=["fm", "am-cs16", "am-cu8", "mixed"])
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10, help="timed passes (SURVEY 8d: median of >= 10 next to the mean)")
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: 256; am-cu8: 128)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="--gpus N: weak = --streams per GPU; strong = --total-streams split over the ranks (configs[3]: 2048)")
     ap.add_argument("--total-streams", type=int, default=2048, help="--scaling strong: streams of the whole job")
     ap.add_argument("--seconds", type=float, default=20.0, help="FM capture length per stream (SURVEY 8d: 20 s)")
     ap.add_argument("--am-frames", type=int, default=41, help="AM L1 frames per stream (41 = 61 s)")
-    ap.add_argument("--payloads", type=int, default=8, help="distinct FM transmissions shared by the streams (each stream has its own CFO/offset/noise)")
+    ap.add_argument("--payloads", type=int, default=64, help="distinct FM transmissions shared by the streams (each stream has its own CFO/offset/noise)")
     ap.add_argument("--sync-p1", action="store_true", help="decode frames in order on the main stream (reference event timing) instead of the overlapped window pipeline")
     ap.add_argument("--l2-feedback", type=int, default=1, help="1: the engine applies the reference's L2 -> L1 sync-loss feedback itself (RS check of the first L2 header on the device), as the CPU baseline's frame.c does; 0: off")
     ap.add_argument("--copy-input", action="store_true", help="fm: decimate the captures into the engine's Q15 FIFO first (K1 as its own kernel) instead of reading them in place")
@@ -77,7 +77,7 @@ def parse(argv=None):
     ap.add_argument("--no-l2-index", action="store_true", help="fm: skip the (untimed) L2 audio-index property check of the decoded frames")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     ap.add_argument("--cpu-processes", type=int, default=0, help="processes of the N-core CPU aggregate (default: all host cores, at most 64)")
-    ap.add_argument("--oracle-streams", type=int, default=24, help="parity block: streams that did NOT lose sync compared with the reference (every stream that lost sync is compared)")
+    ap.add_argument("--oracle-streams", type=int, default=64, help="parity block: streams that did NOT lose sync compared with the reference (every stream that lost sync is compared)")
     ap.add_argument("--oracle-lost-max", type=int, default=64, help="parity block: upper bound on the lost-sync streams compared (reported when it bites)")
     ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE", help="nrsc5hip_debug_tune before the run: decode_streams / am_decode_streams = 1..5, fwd_segments = 0..16")
     ap.add_argument("--launch-check", action="store_true", help="only start the ranks, form the process group (RCCL; gloo without a GPU) and print what it sees -- no workload")
@@ -177,6 +177,7 @@ _DIFF_RE = re.compile(r"#(\d+) (\w+)\.(\w+): (?:(\d+) elements differ)?(?:expect
 # rule, 6 with transient deviations -- 4 roundf() flips, 2 CFO-search locks: MER 0.24 dB, prev_angle 3.6e-4 -- 0 with anything else.)
 TRANSIENT_INT = {"samperr", "keep", "next_samperr"}
 TRANSIENT_ABS = {"next_angle": 5e-3, "phase_re": 5e-2, "phase_im": 5e-2}
+TRANSIENT_STREAM_BUDGET_PCT = 5      # measured: 6 of 256 streams (2.3 %); more than 5 % of the compared streams fails the run
 AFTER_LOCK, AFTER_LOCK_ABS, AFTER_LOCK_REL = 40, {"lower": 0.5, "upper": 0.5}, {"prev_angle": 1e-3}
 
 
@@ -222,16 +223,25 @@ def reference_equality(W, recs, counts, frames, to_log, am: bool):
     run, kind = _checker(1 if am else 0, True)
     lost = [k for k in W.checkable if ((recs[k, :counts[k]]["flags"] & eng.REC_LOST_SYNC) != 0).any()]
     others = [k for k in W.checkable if k not in set(lost)]
-    # spread the others over the batch (different CFO / offset / SNR classes)
-    pick = others[::max(1, len(others) // max(a.oracle_streams, 1))][:a.oracle_streams]
+    # spread the others over the batch (different CFO / offset / SNR classes); half of them from the streams with an impaired
+    # channel (sample-clock error + echoes / analog host / fading: synth_torch.stream_params, am_stream_params)
+    imp = [k for k in others if W.impaired(k)]
+    clean = [k for k in others if not W.impaired(k)]
+    n_imp = min(len(imp), a.oracle_streams // 2)
+    n_clean = min(len(clean), a.oracle_streams - n_imp)
+    spread = lambda xs, n: [xs[int(i * len(xs) / n)] for i in range(n)] if n else []
+    pick = spread(imp, n_imp) + spread(clean, n_clean)
     lost_checked = lost[:a.oracle_lost_max]
     t0 = time.perf_counter()
-    eq_lost = eq_other = strict = exempt = max_bits = tr_streams = tr_fields = 0
+    eq_lost = eq_other = strict = exempt = max_bits = tr_streams = tr_fields = imp_checked = imp_equal = 0
     first_diffs = []
+    from tests import common as _common
+    mer_exempt0 = _common.EXEMPT["mer_below_0db"]
     for k in lost_checked + pick:
         ref_log = run(W.stream_iq(k))
         diffs, nex, mb, ntr = compare_with_reference(ref_log, to_log(k, recs[k, :counts[k]], frames[k]), am)
         exempt += nex; max_bits = max(max_bits, mb); tr_streams += ntr > 0; tr_fields += ntr; strict += (not diffs and ntr == 0)
+        imp_checked += W.impaired(k); imp_equal += (W.impaired(k) and not diffs)
         if not diffs:
             if k in lost_checked:
                 eq_lost += 1
@@ -242,14 +252,20 @@ def reference_equality(W, recs, counts, frames, to_log, am: bool):
     out = {"kind": kind, "checker": "oracle/_ref/libnrsc5_ref_sse.so: the unmodified reference incl. its L2 (frame.c)" if kind == "reference" else "oracle/ restatement + restated frame_process decision (oracle/_ref not present)",
            "streams_with_lost_sync_this_pass": len(lost), "lost_sync_streams_checked": len(lost_checked), "lost_sync_streams_equal": eq_lost,
            "other_streams_checked": len(pick), "other_streams_equal": eq_other,
+           "impaired_channel_streams_checked": int(imp_checked), "impaired_channel_streams_equal": int(imp_equal),
+           "mer_reports_below_0db_compared_to_0.01dB": int(_common.EXEMPT["mer_below_0db"] - mer_exempt0),
            "frames_exempt_cber": exempt, "exempt_max_bit_differences": max_bits,
            "streams_equal_under_the_strict_rule": strict,
            "streams_with_transient_loop_state_deviation": tr_streams, "transient_loop_state_fields": tr_fields,
            "first_diffs": first_diffs, "seconds": round(time.perf_counter() - t0, 1),
-           "compared": "complete ordered log: sync / lost-sync blocks, every PIDS / P1 (/ P3) frame bit-exact, integers exact, floats 1e-4 (tests/common.py); "
-                       "frames_exempt_cber = frames the reference itself decodes while falsely locked (cber > 0.02, no HDC on either side): compared loosely, counted here; "
-                       "transient_loop_state = loop-internal fields only (residual error signal next_angle, NCO phase, the +-1 integer timing pick) outside the test tolerance "
-                       "for a few blocks after a CFO-search lock or a roundf() threshold flip -- frames, events, freq_offset, prev_angle, MER, BER of those streams are within the strict rule"}
+           "compared": "complete ordered log: sync / lost-sync blocks, every PIDS / P1 (/ P3) frame bit-exact, integers exact, floats 1e-4 (tests/common.py). Exemptions, all COUNTED above: "
+                       "frames_exempt_cber = frames the reference itself decodes while falsely locked (cber > 0.02, no HDC on either side): bits and BER compared loosely; "
+                       "transient_loop_state = block fields samperr / keep / next_samperr off by at most 1 sample, next_angle by at most 5e-3, the NCO phase by at most 5e-2, and -- only within 40 "
+                       "records after a SYNC event -- a MER report by at most 0.5 dB and prev_angle by at most 1e-3 relative (a CFO-search lock or a roundf() threshold flip, DESIGN (c) limit 2); "
+                       "mer_reports_below_0db = MER values under 0 dB compared to 0.01 dB (near-singular equaliser cells). The run FAILS when more than "
+                       f"{TRANSIENT_STREAM_BUDGET_PCT} % of the compared streams carry a transient deviation."}
+    if tr_streams * 100 > TRANSIENT_STREAM_BUDGET_PCT * max(1, len(lost_checked) + len(pick)):
+        FAILURES.append(f"{W.name}: {tr_streams} of {len(lost_checked) + len(pick)} compared streams with transient loop-state deviations (budget {TRANSIENT_STREAM_BUDGET_PCT} %)")
     if len(lost) > len(lost_checked):
         out["lost_sync_streams_not_checked"] = len(lost) - len(lost_checked)
     if eq_lost != len(lost_checked) or eq_other != len(pick):
@@ -308,13 +324,12 @@ class Fm:
             self.pool.append((np.packbits(p1, axis=1, bitorder="little"), stt.modulate(m, dev)))
         nsig = self.pool[0][1].shape[0]
         tail = 8640
-        self.stride = (2 * (4320 + nsig + tail) + 255) // 256 * 256
+        self.stride = (2 * (4320 + nsig + stt.STRIDE_SLACK + tail) + 255) // 256 * 256
         def generate(streams):
             iq = torch.zeros((len(streams), self.stride), dtype=torch.uint8, device=dev)
             nb = torch.zeros((len(streams), 1), dtype=torch.int64, device=dev)
             for k, gs in enumerate(streams):
-                prm = stt.stream_params(gs)
-                out = stt.channel_cu8(self.pool[gs % args.payloads][1], prm["cfo_hz"], prm["offset"], prm["snr_db"], prm["seed"], tail=tail, out=iq[k])
+                out = stt.receive_cu8(self.pool[gs % args.payloads][1], stt.stream_params(gs), tail=tail, out=iq[k])
                 nb[k, 0] = out.shape[0] - out.shape[0] % 4
             return iq, nb
         if args.ingest == "scatter":
@@ -331,6 +346,8 @@ class Fm:
         self.samples = float(self.nbytes.astype(np.float64).sum() / 2)
         self.signal_seconds = self.samples / FS
         self.zero_copy = not args.copy_input
+        self.pass_no = 0
+        self.perm = np.arange(S, dtype=np.int32)
         self.E = self.make_engine(S, local, in_order=args.sync_p1)
 
     def make_engine(self, S, local, in_order):
@@ -345,10 +362,15 @@ class Fm:
         return E
 
     def one_pass(self, E=None, S=None, host_ms=None):
+        """Capture row r goes to engine stream (r + pass number) mod S: every pass decodes every stream slot from ANOTHER capture
+        (its neighbour carries another payload), so a frame or record left over from the previous pass can never satisfy verify()
+        -- the rings and the pinned host mirror are not cleared between passes (that memset would cost more than the pass)."""
         E = E or self.E; S = S or self.S
+        self.perm = ((np.arange(S) + self.pass_no) % S).astype(np.int32)
+        self.pass_no += 1
         t = [time.perf_counter()]
         E.reset_all(); t.append(time.perf_counter())
-        E.batch_append_cu8(self.iq.data_ptr(), self.stride, self.nbytes[:S]); t.append(time.perf_counter())
+        E.batch_append_cu8(self.iq.data_ptr(), self.stride, self.nbytes[:S], stream_ids=self.perm); t.append(time.perf_counter())
         steps = E.batch_process(S); t.append(time.perf_counter())
         out = E.batch_fetch_view(S) if E.cfg.p1_async else E.batch_fetch(S); t.append(time.perf_counter())
         if host_ms is not None:
@@ -359,12 +381,15 @@ class Fm:
     def describe(self, steps):
         a = self.args
         return {"workload": f"configs[2]: batch={self.S} independent hybrid-FM MP1 cu8 streams @1.488375 MS/s per GPU, "
-                            f"{self.nbytes[0] / 2 / FS:.2f} s each ({self.n_frames} L1 frames), CFO +-300 Hz, offset [0,4320), SNR 15/20/25 dB",
+                            f"{self.nbytes[0] / 2 / FS:.2f} s each ({self.n_frames} L1 frames), CFO +-300 Hz, offset [0,4320), SNR 15/20/25 dB; every 4th stream through an "
+                            f"impaired channel: sample clock +-20...+-100 ppm, and by turns echoes / an analog FM host at +20 dB / 8 dB fading (synth_torch.stream_params)",
+                "impaired_channel_streams": int(sum(1 for gs in self.my_streams if gs % 4 == 1)),
                 "streams_per_gpu": self.S, "seconds_per_stream": round(float(self.nbytes[0]) / 2 / FS, 3),
                 "p1_decode": "in-order" if a.sync_p1 else "windowed-overlap", "l2_feedback": "on-device" if a.l2_feedback else "off",
                 "input": "read in place (half-band fused into the symbol kernel)" if self.zero_copy else "decimated copy in the Q15 FIFO",
                 "block_steps_per_pass": int(steps), "ingest": a.ingest, "distinct_payloads": a.payloads,
-                "payload_note": f"{a.payloads} transmitted payloads shared by the streams; CFO / timing offset / noise realisation are per stream (seed 1000 + stream id)",
+                "payload_note": f"{a.payloads} transmitted payloads shared by the streams; CFO / timing offset / noise realisation / channel are per stream (seed 1000 + stream id)",
+                "stale_result_guard": "capture row r feeds engine stream (r + pass number) mod S: a slot's previous-pass frames belong to another payload and cannot satisfy the truth check",
                 "hbm_resident_input_GB": round(float(self.nbytes.sum()) / 1e9, 2)}
 
     def verify(self, recs, counts, frames):
@@ -390,7 +415,7 @@ class Fm:
                     idx = first + j
                     exact = int(0 <= idx < truth.shape[0] and np.array_equal(truth[idx], b))
                 ok += exact
-                self.l2_jobs.append((k, int(rr["p1_slot"]), eng.L2_FM_P1, 0, eng.P1_BITS)); self.l2_exact.append(exact)
+                self.l2_jobs.append((int(self.perm[k]), int(rr["p1_slot"]), eng.L2_FM_P1, 0, eng.P1_BITS)); self.l2_exact.append(exact)
             rows.append([gs, len(r), len(p1r), ok, int(((r["flags"] & eng.REC_PIDS) != 0).sum()), int((r["state_after"] == eng.SYNC_FINE).sum()), h])
         return rows
 
@@ -411,10 +436,17 @@ class Fm:
         return self.stream_iq(0)
 
     def to_log(self, k, r, fr):
-        return self.eng.records_to_log(self.E, k, r, fr)
+        return self.eng.records_to_log(self.E, int(self.perm[k]), r, fr)
+
+    def unpermute(self, recs, counts, frames):
+        """row order (capture k) from engine-stream order; untimed"""
+        return recs[self.perm], counts[self.perm], frames[self.perm]
 
     def is_am(self, k):
         return False
+
+    def impaired(self, k):
+        return self.my_streams[k] % 4 == 1
 
     # ---- fm-only side legs (rank 0, N = 1) ---------------------------------------------------------------------------------
     def l2_property(self):
@@ -478,12 +510,14 @@ def am_batch(args, dev, streams, fmt, n_frames, signal_seed):
     sig, p1, p3, _ = synth_am.am_ma1_signal(n_frames, seed=signal_seed, fmt=fmt)
     sd = torch.from_numpy(sig.astype(np.complex64)).to(dev)
     over = 1 if fmt == "cs16" else 32
-    stride = (2 * (9 * 270 * over + sig.shape[0] + 1080 * over) + 255) // 256 * 256
+    from nrsc5_amd import channel
+    stride = (2 * (9 * 270 * over + sig.shape[0] + 128 * over + 1080 * over) + 255) // 256 * 256     # + 128: +20 ppm stretch 61 s by 57 samples
     iq = torch.zeros((len(streams), stride), dtype=torch.int16 if fmt == "cs16" else torch.uint8, device=dev)
     sizes = np.zeros(len(streams), dtype=np.uint32)
     for k, gs in enumerate(streams):
         prm = stt.am_stream_params(gs, n_frames)
-        out = stt.channel_am(sd, prm["cfo_hz"], prm["offset"] * over, prm["noise"], prm["seed"], fmt, burst=prm["burst"], out=iq[k])
+        rx = channel.apply_torch(sd, synth_am.FS_CS16 if fmt == "cs16" else synth_am.FS_CU8, prm["chan"])
+        out = stt.channel_am(rx, prm["cfo_hz"], prm["offset"] * over, prm["noise"], prm["seed"], fmt, burst=prm["burst"], out=iq[k])
         sizes[k] = out.shape[0] - out.shape[0] % 4
     truth1 = {np.packbits(b, bitorder="little").tobytes() for fr in p1 for b in fr}
     truth3 = {np.packbits(b, bitorder="little").tobytes() for b in p3}
@@ -583,6 +617,9 @@ class Am:
     def is_am(self, k):
         return True
 
+    def impaired(self, k):
+        return self.my_streams[k] % 4 == 2
+
 
 class Mixed:
     """configs[4]: 128 FM cu8 + 64 AM cs16 + 64 AM cu8 streams in ONE engine (the FM and AM halves run back to back)"""
@@ -605,12 +642,11 @@ class Mixed:
             p1, pids, m = stt.payload_stream(n_frames, seed=p)
             self.pool.append((np.packbits(p1, axis=1, bitorder="little"), stt.modulate(m, dev)))
         tail = 8640
-        self.stride_fm = (2 * (4320 + self.pool[0][1].shape[0] + tail) + 255) // 256 * 256
+        self.stride_fm = (2 * (4320 + self.pool[0][1].shape[0] + stt.STRIDE_SLACK + tail) + 255) // 256 * 256
         self.fm = torch.zeros((nfm, self.stride_fm), dtype=torch.uint8, device=dev)
         self.fm_bytes = np.zeros(nfm, dtype=np.uint32)
         for k in range(nfm):
-            prm = stt.stream_params(my_streams[k])
-            out = stt.channel_cu8(self.pool[k % 4][1], prm["cfo_hz"], prm["offset"], prm["snr_db"], prm["seed"], tail=tail, out=self.fm[k])
+            out = stt.receive_cu8(self.pool[k % 4][1], stt.stream_params(my_streams[k]), tail=tail, out=self.fm[k])
             self.fm_bytes[k] = out.shape[0] - out.shape[0] % 4
         self.am16, self.len16, self.sizes16, self._t1_16, self._t3_16 = am_batch(args, dev, [my_streams[nfm + k] for k in range(self.n16)], "cs16", args.am_frames, 77)
         self.am8, self.len8, self.sizes8, self._t1_8, self._t3_8 = am_batch(args, dev, [my_streams[nfm + self.n16 + k] for k in range(self.n8)], "cu8", args.am_frames, 78)
@@ -695,6 +731,9 @@ class Mixed:
     def is_am(self, k):
         return k >= self.nfm
 
+    def impaired(self, k):
+        return self.my_streams[k] % 4 == (2 if k >= self.nfm else 1)
+
 
 TUNE_KNOBS = {"decode_streams": 0, "am_decode_streams": 1, "fwd_segments": 4, "am_segments": 6, "decode_cus": 7, "decode_priority": 8}
 
@@ -713,6 +752,7 @@ def mixed_reference_equality(W, recs, counts, frames):
         sub.eng, sub.args, sub.my_streams, sub.name = W.eng, W.args, W.my_streams, f"mixed/{label}"
         sub.checkable = [k for k in range(W.S) if W.is_am(k) == am]
         sub.stream_iq = W.stream_iq
+        sub.impaired = W.impaired
         out[label] = reference_equality(sub, recs, counts, frames, W.to_log, am)
     return out
 
@@ -815,10 +855,16 @@ def compact_leg(name, args, dev, local, steps=3):
     W = make_workload(name, a, dev, local, list(range(S)))
     gen = time.perf_counter() - t0
     W.one_pass()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
+    dt = 0.0
     for _ in range(steps):
+        W.E.poison_results()             # untimed: frame / record rings and their host mirrors get a pattern no decode produces, so the
+        torch.cuda.synchronize()         # checks below can only pass on what the LAST pass wrote (every AM stream carries the same payload)
+        t0 = time.perf_counter()
         block_steps, (recs, counts, frames) = W.one_pass()
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / steps
+        torch.cuda.synchronize(); dt += time.perf_counter() - t0
+    dt /= steps
+    if hasattr(W, "unpermute"):
+        recs, counts, frames = W.unpermute(recs, counts, frames)
     rows = np.array(W.verify(recs, counts, frames), dtype=np.int64)
     parity = checked_parity(W, recs, counts, frames, rows, not args.no_cpu_baseline)
     out = {"config": W.describe(block_steps), "steps": steps, "ms_per_step": round(dt * 1e3, 3), "value_MSps": round(W.samples / dt / 1e6, 2),
@@ -872,8 +918,10 @@ def main():
     shard.barrier(dev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    pass_ms, tp = [], t0
     for _ in range(args.steps):
         block_steps, (recs, counts, frames) = W.one_pass(host_ms=host_ms)
+        tn = time.perf_counter(); pass_ms.append((tn - tp) * 1e3); tp = tn      # a pass ends with its results on the host
     torch.cuda.synchronize()
     dt_rank = time.perf_counter() - t0
     shard.barrier(dev)
@@ -885,6 +933,8 @@ def main():
     tot = shard.sum_over_ranks([W.samples, W.signal_seconds, 1.0], dev)
     total_samples, total_seconds, ranks_seen = float(tot[0]), float(tot[1]), int(tot[2])     # ranks_seen: counted through the collective itself
 
+    if hasattr(W, "unpermute"):
+        recs, counts, frames = W.unpermute(recs, counts, frames)
     rows = W.verify(recs, counts, frames)
     allrows = shard.gather_summaries(np.array(rows, dtype=np.int64), dev)
     shard.shutdown(dev)                  # every collective of the run is behind us: the ranks leave the group together
@@ -975,7 +1025,8 @@ def main():
     line = {
         "metric": "IQ MS/s demod+decoded", "value": round(value, 2), "unit": "IQ MS/s",
         "x_realtime": round(total_seconds * args.steps / dt, 1), "n_gpus": world, "ranks_in_process_group": ranks_seen, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(dt / args.steps * 1e3, 3), "per_rank_ms_per_step": per_rank_ms, "higher_is_better": True, "scaling": args.scaling,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "ms_per_step_median": round(float(np.median(pass_ms)), 3),
+        "ms_per_step_min_max": [round(min(pass_ms), 3), round(max(pass_ms), 3)], "per_rank_ms_per_step": per_rank_ms, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": W.dtype, "data": "synthetic",
         "config": config, "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         "gen_seconds": round(t_gen, 1),

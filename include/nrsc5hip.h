@@ -128,6 +128,15 @@ typedef struct nrsc5hip_config {
 
 typedef struct nrsc5hip_engine nrsc5hip_engine;
 
+/* Devices and threads.  An engine lives on cfg.device; EVERY entry point that takes an engine switches the calling thread to that
+ * device for the duration of the call and restores the thread's previous current device on return, so one process may own one
+ * engine per GPU (integration/batch_shard.c: N host threads x one engine per visible GPU) whatever hipSetDevice the caller last
+ * made.  An engine is NOT re-entrant: at most one thread may be inside calls on the SAME engine at a time (give each thread its
+ * own engine, or serialise); different engines -- on the same or on different devices -- may be driven concurrently from different
+ * threads: nothing is shared between engines (no process-global scratch, per-thread error string and seam counters).
+ * nrsc5hip_last_error() returns the calling thread's last message.  Device pointers handed to the batch entry points must belong
+ * to the engine's device.  The window pipeline (p1_async = 1) needs GPU_MAX_HW_QUEUES >= 8 in the environment before the HIP runtime
+ * initialises (one hardware queue per chain / decode stream); engine creation warns on stderr when it is lower. */
 int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engine **out);
 void nrsc5hip_engine_destroy(nrsc5hip_engine *e);
 const char *nrsc5hip_last_error(void);
@@ -136,6 +145,12 @@ const char *nrsc5hip_last_error(void);
 const char *nrsc5hip_source_sha(void);
 /* hipStream_t the engine launches on, as void* (so that callers can order their own work) */
 void *nrsc5hip_engine_hip_stream(nrsc5hip_engine *e);
+
+/* Device helpers for hosts that do not link the HIP runtime themselves: number of visible GPUs; a device buffer on `device` filled
+ * from host memory (host may be NULL: allocation only); its release.  The pointers are what the batch entry points take. */
+int nrsc5hip_device_count(int *n);
+int nrsc5hip_device_upload(int device, const void *host, size_t nbytes, void **dev_out);
+int nrsc5hip_device_free(int device, void *dev);
 
 /* ---- streaming seam (host buffers), one stream at a time --------------------------------------- */
 /* input_push_cu8 (input.c:96-117): nbytes % 4 == 0.  Decimates, appends, and processes every block
@@ -341,7 +356,10 @@ enum {
 /* process-wide wall-clock totals of the streaming seam with p1_async = 0 (what the drop-in uses): [0] s copying pushes into pinned
  * staging, [1] s enqueueing H2D + decimator, [2] s enqueueing block steps, [3] s waiting for the device (one sync per block),
  * [4] pushes, [5] submissions, [6] block steps, [7] s fetching P1 frames */
-void nrsc5hip_debug_seam_totals(double out[8], int reset);
+void nrsc5hip_debug_seam_totals(double out[8], int reset);   /* totals of the CALLING THREAD's sessions */
+/* test / bench hygiene: overwrite every result buffer a pass writes (frame rings on the device and their pinned host mirror, record
+ * rings) with a pattern no decode produces -- a check after the next pass can then only pass on bits written by that pass */
+int nrsc5hip_debug_poison_results(nrsc5hip_engine *e);
 /* segmented forward pass: segment boundaries checked / segments that had to be re-run since the engine was created */
 int nrsc5hip_debug_fwd_stats(nrsc5hip_engine *e, int stats[2]);
 /* K=9 decode in segment waves: [0] forward boundaries checked, [1] segments re-run, [2] traceback boundaries checked, [3] segments re-walked */

@@ -24,8 +24,9 @@ static_assert(sizeof(BlockRecord) % 8 == 0, "record alignment");
 
 static thread_local char g_err[512] = "";
 
-// process-wide wall-clock totals of the fast streaming seam (nrsc5hip_debug_seam_totals): where a drop-in session's time goes
-static double g_seam[8];   // [0] s copying pushes into pinned staging, [1] s enqueueing H2D + decimator, [2] s enqueueing block steps,
+// wall-clock totals of the fast streaming seam of the CALLING THREAD's sessions (nrsc5hip_debug_seam_totals): where a drop-in
+// session's time goes.  Thread-local: sessions driven from different threads never share a counter.
+static thread_local double g_seam[8];   // [0] s copying pushes into pinned staging, [1] s enqueueing H2D + decimator, [2] s enqueueing block steps,
                            // [3] s waiting for the device (the one sync per block), [4] pushes, [5] submissions, [6] block steps, [7] s in drain / frame fetches
 struct SeamClock {
     int slot; std::chrono::steady_clock::time_point t0;
@@ -51,6 +52,15 @@ extern "C" const char *nrsc5hip_source_sha(void) { return NRSC5HIP_SOURCE_SHA; }
         }                                                                                              \
     } while (0)
 #define FAIL(code, ...) do { snprintf(g_err, sizeof(g_err), __VA_ARGS__); return (code); } while (0)
+
+// Every entry point runs on ITS ENGINE's device, whatever the calling thread's current device is (one process may own one engine
+// per GPU, each driven by its own thread or all by one): the guard switches on entry and restores on exit.
+struct DeviceGuard {
+    int prev = -1, want = -1;
+    explicit DeviceGuard(int dev) : want(dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != want) (void)hipSetDevice(want); }
+    ~DeviceGuard() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
+};
+#define ON_ENGINE_DEVICE(e) DeviceGuard _device_guard((e) ? (e)->cfg.device : 0); if (!(e)) FAIL(NRSC5HIP_EINVAL, "null engine")
 
 struct nrsc5hip_engine {
     nrsc5hip_config cfg;
@@ -121,6 +131,7 @@ struct nrsc5hip_engine {
     std::vector<hipEvent_t> prof_pool;
     double prof_ms[NRSC5HIP_PROF_CLASSES];
     long long prof_launches[NRSC5HIP_PROF_CLASSES];
+    VitScratch vit_scratch;            // scratch of the nrsc5hip_stage_viterbi_* entry points (per engine: nothing process-global)
 };
 
 static hipEvent_t prof_event(nrsc5hip_engine *e)
@@ -363,11 +374,22 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
     int ndev = 0;
     HIPCHK(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev) FAIL(NRSC5HIP_EINVAL, "device %d out of range (%d devices)", cfg->device, ndev);
-    HIPCHK(hipSetDevice(cfg->device));
+    DeviceGuard guard(cfg->device);                            // the caller's current device is restored on return
     nrsc5hip_engine *e = new (std::nothrow) nrsc5hip_engine();
     if (!e) FAIL(NRSC5HIP_ENOMEM, "out of host memory");
     e->cfg = *cfg;
     const size_t S = cfg->max_streams;
+    if (cfg->p1_async) {
+        // the window pipeline drives 1 chain + 3 decode streams (+ the caller's): with the HIP runtime's default of 4 hardware
+        // queues they share queues and the decode / chain overlap is lost silently
+        const char *q = getenv("GPU_MAX_HW_QUEUES");
+        static bool warned = false;
+        if (!warned && (!q || atoi(q) < 8)) {
+            warned = true;
+            fprintf(stderr, "libnrsc5hip: warning: p1_async engine with GPU_MAX_HW_QUEUES=%s (< 8): decode streams will share hardware queues with "
+                            "the block-step chain; export GPU_MAX_HW_QUEUES=8 before the HIP runtime initialises\n", q ? q : "unset (default 4)");
+        }
+    }
     int rc = 0;
     do {
         {
@@ -522,7 +544,9 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
 extern "C" void nrsc5hip_engine_destroy(nrsc5hip_engine *e)
 {
     if (!e) return;
+    DeviceGuard guard(e->cfg.device);
     (void)hipDeviceSynchronize();
+    vit_scratch_free(e->vit_scratch);
     for (void *p : e->allocs) (void)hipFree(p);
     for (hipEvent_t ev : e->dec_events) (void)hipEventDestroy(ev);
     if (e->dec_stream) (void)hipStreamDestroy(e->dec_stream);
@@ -945,7 +969,11 @@ static int push_common(nrsc5hip_engine *e, int s, const void *host, size_t nbyte
             const int slot = e->stage_slot;
             if (e->staged_bytes == 0 && e->stage_busy[slot]) { HIPCHK(hipEventSynchronize(e->stage_ev[slot])); e->stage_busy[slot] = false; }
             const size_t room = e->stage_bytes - e->staged_bytes;
-            const size_t chunk = nbytes_total > room ? room : nbytes_total;
+            size_t chunk = nbytes_total > room ? room : nbytes_total;
+            // never stage past the sample that completes the stream's next block: a large push is then processed block by block and
+            // the FIFO never holds more than one window plus the carry of the last block, whatever q15_capacity is (>= 2 windows)
+            const long long to_block = nrsc5hip_bytes_to_next_block(e, s, cu8 ? 1 : 0);
+            if (to_block > 0 && (size_t)to_block < chunk) chunk = (size_t)to_block;
             long long nq15 = (long long)chunk / 4;
             if (am && cu8) nq15 = (e->raw_host[s] + (long long)chunk / 2) / 32 - e->raw_host[s] / 32;
             { SeamClock clk(0); memcpy(e->stage_pin[slot] + 16 + e->staged_bytes, src, chunk); }
@@ -984,16 +1012,19 @@ static int push_common(nrsc5hip_engine *e, int s, const void *host, size_t nbyte
 
 extern "C" int nrsc5hip_push_cu8(nrsc5hip_engine *e, int stream, const uint8_t *iq, uint32_t nbytes)
 {
+    ON_ENGINE_DEVICE(e);
     return push_common(e, stream, iq, nbytes, true);
 }
 extern "C" int nrsc5hip_push_cs16(nrsc5hip_engine *e, int stream, const int16_t *iq, uint32_t n)
 {
+    ON_ENGINE_DEVICE(e);
     if (n % 2) FAIL(NRSC5HIP_EINVAL, "cs16 length must be even");
     return push_common(e, stream, iq, (size_t)n * 2, false);
 }
 
 extern "C" int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream)
 {
+    ON_ENGINE_DEVICE(e);
     int rc = check_stream(e, stream); if (rc) return rc;
     if (e->staged_stream == stream) { e->staged_stream = -1; e->staged_bytes = 0; e->staged_q15 = 0; }      // samples not yet submitted die with the session
     // this engine's queues only (another session of the process keeps running)
@@ -1016,6 +1047,7 @@ extern "C" int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream)
 // nrsc5_set_mode -> input_set_mode (input.c:158-162): switch the stream's waveform and reset it
 extern "C" int nrsc5hip_stream_set_mode(nrsc5hip_engine *e, int stream, int mode)
 {
+    ON_ENGINE_DEVICE(e);
     int rc = check_stream(e, stream); if (rc) return rc;
     if (mode != NRSC5HIP_MODE_FM && mode != NRSC5HIP_MODE_AM) FAIL(NRSC5HIP_EINVAL, "unknown mode %d", mode);
     if (mode == NRSC5HIP_MODE_AM && !e->db.am) FAIL(NRSC5HIP_EINVAL, "engine was created without am_enable");
@@ -1028,6 +1060,7 @@ __global__ void k_force_none(DevBuffers db, int s) { db.state[s].sync_state = SY
 
 extern "C" int nrsc5hip_force_resync(nrsc5hip_engine *e, int stream)
 {
+    ON_ENGINE_DEVICE(e);
     int rc = check_stream(e, stream); if (rc) return rc;
     hipLaunchKernelGGL(k_force_none, dim3(1), dim3(1), 0, e->main, e->db, stream);
     e->lane.acq_needed = true; e->lane.px_needed = true; e->lane.set_sig = 0;
@@ -1037,14 +1070,15 @@ extern "C" int nrsc5hip_force_resync(nrsc5hip_engine *e, int stream)
 
 // ---- batch path ----------------------------------------------------------------------------------------------
 // the batch entry points move a stream's FIFO without the host mirror of the fast streaming seam: records are read from the device again
-static void leave_mirror(nrsc5hip_engine *e, int n, const int *ids)
+static int leave_mirror(nrsc5hip_engine *e, int n, const int *ids)
 {
-    if (e->staged_stream >= 0) (void)flush_staged(e);          // whatever a push left in the pinned buffer goes to the FIFO first
+    if (e->staged_stream >= 0) { int rc = flush_staged(e); if (rc) return rc; }   // whatever a push left in the pinned buffer goes to the FIFO first
     for (int k = 0; k < n; k++) {
         const int s = ids ? ids[k] : k;
         if (s < 0 || s >= e->cfg.max_streams || !e->mirror_ok[s]) continue;
         e->mirror_ok[s] = 0; e->pending[s].clear(); e->fetched[s] = e->drained[s];
     }
+    return 0;
 }
 
 static int upload_ids(nrsc5hip_engine *e, int n, const int *ids, const uint32_t *counts, const int **ids_dev)
@@ -1064,9 +1098,10 @@ static int upload_ids(nrsc5hip_engine *e, int n, const int *ids, const uint32_t 
 extern "C" int nrsc5hip_batch_append_cu8(nrsc5hip_engine *e, int nstreams, const int *stream_ids,
                                          const uint8_t *dev_iq, long long stride_bytes, const uint32_t *nbytes)
 {
+    ON_ENGINE_DEVICE(e);
     if (!e || !dev_iq || !nbytes) FAIL(NRSC5HIP_EINVAL, "null argument");
     const int *ids_dev; int rc = upload_ids(e, nstreams, stream_ids, nbytes, &ids_dev); if (rc) return rc;
-    leave_mirror(e, nstreams, stream_ids);
+    if ((rc = leave_mirror(e, nstreams, stream_ids))) return rc;
     unsigned mx = 0;
     {
         int nam = 0;
@@ -1159,9 +1194,10 @@ extern "C" int nrsc5hip_batch_append_cu8(nrsc5hip_engine *e, int nstreams, const
 extern "C" int nrsc5hip_batch_append_cs16(nrsc5hip_engine *e, int nstreams, const int *stream_ids,
                                           const int16_t *dev_iq, long long stride_elems, const uint32_t *nelems)
 {
+    ON_ENGINE_DEVICE(e);
     if (!e || !dev_iq || !nelems) FAIL(NRSC5HIP_EINVAL, "null argument");
     const int *ids_dev; int rc = upload_ids(e, nstreams, stream_ids, nelems, &ids_dev); if (rc) return rc;
-    leave_mirror(e, nstreams, stream_ids);
+    if ((rc = leave_mirror(e, nstreams, stream_ids))) return rc;
     unsigned mx = 0;
     for (int k = 0; k < nstreams; k++) {
         const int s = stream_ids ? stream_ids[k] : k;
@@ -1179,10 +1215,11 @@ extern "C" int nrsc5hip_batch_append_cs16(nrsc5hip_engine *e, int nstreams, cons
 
 extern "C" int nrsc5hip_batch_process(nrsc5hip_engine *e, int nstreams, const int *stream_ids, int max_steps, int *steps_done)
 {
+    ON_ENGINE_DEVICE(e);
     if (!e) FAIL(NRSC5HIP_EINVAL, "null engine");
     if (nstreams < 1 || nstreams > e->cfg.max_streams) FAIL(NRSC5HIP_EINVAL, "nstreams %d out of range", nstreams);
     if (stream_ids) for (int k = 0; k < nstreams; k++) if (stream_ids[k] < 0 || stream_ids[k] >= e->cfg.max_streams) FAIL(NRSC5HIP_EINVAL, "stream id %d out of range", stream_ids[k]);
-    leave_mirror(e, nstreams, stream_ids);
+    { int rc = leave_mirror(e, nstreams, stream_ids); if (rc) return rc; }
     {   // AM streams advance through their own fused block kernel; split a mixed list by mode
         std::vector<int> fm, am;
         for (int k = 0; k < nstreams; k++) {
@@ -1229,6 +1266,7 @@ static int patch_am_ber(nrsc5hip_engine *e, int stream, nrsc5hip_record *recs, i
 
 extern "C" int nrsc5hip_drain(nrsc5hip_engine *e, int stream, nrsc5hip_record *out, int max, int *n_out)
 {
+    ON_ENGINE_DEVICE(e);
     int rc = check_stream(e, stream); if (rc) return rc;
     if (!out || !n_out) FAIL(NRSC5HIP_EINVAL, "null argument");
     if (e->mirror_ok[stream]) {
@@ -1268,6 +1306,7 @@ extern "C" int nrsc5hip_drain(nrsc5hip_engine *e, int stream, nrsc5hip_record *o
 
 extern "C" int nrsc5hip_p1_frame_packed(nrsc5hip_engine *e, int stream, int slot, uint32_t *words)
 {
+    ON_ENGINE_DEVICE(e);
     SeamClock clk(7);
     int rc = check_stream(e, stream); if (rc) return rc;
     if (slot < 0 || slot >= e->db.p1_slots || !words) FAIL(NRSC5HIP_EINVAL, "bad slot/argument");
@@ -1283,6 +1322,7 @@ extern "C" void nrsc5hip_unpack_bits(const uint32_t *words, int nbits, uint8_t *
 
 extern "C" int nrsc5hip_p1_frame_bits(nrsc5hip_engine *e, int stream, int slot, uint8_t *bits)
 {
+    ON_ENGINE_DEVICE(e);
     std::vector<uint32_t> w(P1_WORDS);
     int rc = nrsc5hip_p1_frame_packed(e, stream, slot, w.data()); if (rc) return rc;
     nrsc5hip_unpack_bits(w.data(), P1_LEN, bits);
@@ -1292,6 +1332,7 @@ extern "C" int nrsc5hip_p1_frame_bits(nrsc5hip_engine *e, int stream, int slot, 
 // FM extended sidebands: P3 (channel 0) / P4 (channel 1) frame of a REC_P3 / REC_P4 record; slot = record.sis
 extern "C" int nrsc5hip_px_frame_bits(nrsc5hip_engine *e, int stream, int slot, int channel, int nbits, uint8_t *bits)
 {
+    ON_ENGINE_DEVICE(e);
     int rc = check_stream(e, stream); if (rc) return rc;
     if (slot < 0 || slot >= e->db.px_slots || channel < 0 || channel > 1 || !bits || (nbits != 2304 && nbits != 4608)) FAIL(NRSC5HIP_EINVAL, "bad slot/argument");
     uint32_t w[PX_WORDS];
@@ -1304,6 +1345,7 @@ extern "C" int nrsc5hip_px_frame_bits(nrsc5hip_engine *e, int stream, int slot, 
 // bulk variant: all P3/P4 slots of the listed streams, [nstreams][8 * p1_slots][2][144] words
 extern "C" int nrsc5hip_batch_fetch_px(nrsc5hip_engine *e, int nstreams, const int *stream_ids, uint32_t *frames)
 {
+    ON_ENGINE_DEVICE(e);
     if (!e || !frames) FAIL(NRSC5HIP_EINVAL, "null argument");
     HIPCHK(hipDeviceSynchronize());
     const size_t per = (size_t)e->db.px_slots * 2 * PX_WORDS;
@@ -1318,6 +1360,7 @@ extern "C" int nrsc5hip_batch_fetch_px(nrsc5hip_engine *e, int nstreams, const i
 // AM: frames of one L1 frame share a ring slot: P1 frame of block b at word b * 118, the P3 frame at word 944
 extern "C" int nrsc5hip_am_frame_bits(nrsc5hip_engine *e, int stream, int slot, int which, int nbits, uint8_t *bits)
 {
+    ON_ENGINE_DEVICE(e);
     int rc = check_stream(e, stream); if (rc) return rc;
     if (slot < 0 || slot >= e->db.p1_slots || !bits || which < 0 || which > 8) FAIL(NRSC5HIP_EINVAL, "bad slot/argument");
     const int maxbits = which < 8 ? AM_P1_LEN : AM_P3_LEN_MA3;
@@ -1355,6 +1398,7 @@ static int l2_run(nrsc5hip_engine *e, const std::vector<L2Job> &jobs, nrsc5hip_l
 
 extern "C" int nrsc5hip_l2_index(nrsc5hip_engine *e, int njobs, const nrsc5hip_l2_job *jobs, nrsc5hip_l2_frame *out, uint8_t *pdu_bytes, long long stride)
 {
+    ON_ENGINE_DEVICE(e);
     if (!e || !jobs || !out || njobs < 1) FAIL(NRSC5HIP_EINVAL, "bad argument");
     std::vector<L2Job> dj((size_t)njobs);
     for (int k = 0; k < njobs; k++) {
@@ -1381,6 +1425,7 @@ extern "C" int nrsc5hip_l2_index(nrsc5hip_engine *e, int njobs, const nrsc5hip_l
 
 extern "C" int nrsc5hip_l2_frame_get(nrsc5hip_engine *e, int stream, int slot, nrsc5hip_l2_frame *out)
 {
+    ON_ENGINE_DEVICE(e);
     int rc = check_stream(e, stream); if (rc) return rc;
     if (!e->db.l2_ring) FAIL(NRSC5HIP_EINVAL, "engine was created without l2_index");
     if (slot < 0 || slot >= e->db.p1_slots || !out) FAIL(NRSC5HIP_EINVAL, "bad slot/argument");
@@ -1391,6 +1436,7 @@ extern "C" int nrsc5hip_l2_frame_get(nrsc5hip_engine *e, int stream, int slot, n
 
 extern "C" int nrsc5hip_batch_fetch_l2(nrsc5hip_engine *e, int nstreams, const int *stream_ids, nrsc5hip_l2_frame *out)
 {
+    ON_ENGINE_DEVICE(e);
     if (!e || !out || nstreams < 1) FAIL(NRSC5HIP_EINVAL, "bad argument");
     if (!e->db.l2_ring) FAIL(NRSC5HIP_EINVAL, "engine was created without l2_index");
     HIPCHK(hipDeviceSynchronize());
@@ -1424,15 +1470,18 @@ static int fetch_l2_ring(nrsc5hip_engine *e, const nrsc5hip_l2_frame *ring, size
 }
 extern "C" int nrsc5hip_batch_fetch_l2_px(nrsc5hip_engine *e, int nstreams, const int *stream_ids, nrsc5hip_l2_frame *out)
 {
+    ON_ENGINE_DEVICE(e);
     return fetch_l2_ring(e, e ? e->db.l2_px_ring : nullptr, e ? (size_t)e->db.px_slots * 2 : 0, nstreams, stream_ids, out, "");
 }
 extern "C" int nrsc5hip_batch_fetch_l2_am(nrsc5hip_engine *e, int nstreams, const int *stream_ids, nrsc5hip_l2_frame *out)
 {
+    ON_ENGINE_DEVICE(e);
     return fetch_l2_ring(e, e ? e->db.l2_am_ring : nullptr, e ? (size_t)e->db.p1_slots * 9 : 0, nstreams, stream_ids, out, " and am_enable");
 }
 
 extern "C" int nrsc5hip_stage_l2_index(nrsc5hip_engine *e, const uint8_t *bits, int nbits, int nframes, nrsc5hip_l2_frame *out, uint8_t *pdu_bytes, long long stride)
 {
+    ON_ENGINE_DEVICE(e);
     if (!e || !bits || !out || nbits < 1 || nframes < 1) FAIL(NRSC5HIP_EINVAL, "bad argument");
     const int words = (nbits + 31) / 32;
     std::vector<uint32_t> w((size_t)words * nframes, 0u);
@@ -1449,6 +1498,7 @@ extern "C" int nrsc5hip_stage_l2_index(nrsc5hip_engine *e, const uint8_t *bits, 
 
 extern "C" int nrsc5hip_stage_first_header(nrsc5hip_engine *e, const uint8_t *bits, int nbits, int nframes, int threads, int *ok)
 {
+    ON_ENGINE_DEVICE(e);
     if (!e || !bits || !ok || nframes < 1 || (nbits != P1_LEN && nbits != AM_P1_LEN) || threads < 64 || threads > 1024 || (threads & 63)) FAIL(NRSC5HIP_EINVAL, "bad argument");
     const int words = (nbits + 31) / 32;
     std::vector<uint32_t> w((size_t)nframes * words, 0u);
@@ -1467,6 +1517,7 @@ extern "C" int nrsc5hip_stage_first_header(nrsc5hip_engine *e, const uint8_t *bi
 
 extern "C" int nrsc5hip_stage_viterbi_k9(nrsc5hip_engine *e, const int8_t *soft, int len, int nframes, const unsigned gens[3], uint8_t *bits)
 {
+    ON_ENGINE_DEVICE(e);
     if (!e || !soft || !bits || !gens || len < 64 || nframes < 1) FAIL(NRSC5HIP_EINVAL, "bad argument");
     int8_t *dsoft = nullptr; unsigned long long *ddec = nullptr; uint32_t *dout = nullptr;
     const int words = (len + 31) / 32;
@@ -1489,6 +1540,7 @@ extern "C" int nrsc5hip_stage_viterbi_k9(nrsc5hip_engine *e, const int8_t *soft,
 extern "C" int nrsc5hip_batch_fetch(nrsc5hip_engine *e, int nstreams, const int *stream_ids, nrsc5hip_record *records,
                                     int max_records, int *counts, uint32_t *frames)
 {
+    ON_ENGINE_DEVICE(e);
     if (!e || !records || !counts) FAIL(NRSC5HIP_EINVAL, "null argument");
     HIPCHK(hipStreamSynchronize(e->main));
     std::vector<StreamState> *dummy = nullptr; (void)dummy;
@@ -1508,6 +1560,7 @@ extern "C" int nrsc5hip_batch_fetch(nrsc5hip_engine *e, int nstreams, const int 
 // ---- stage-level entry points ----------------------------------------------------------------------------------------
 extern "C" int nrsc5hip_stage_halfband_fm_cu8(nrsc5hip_engine *e, const uint8_t *iq, uint32_t nbytes, int16_t *out)
 {
+    ON_ENGINE_DEVICE(e);
     // runs the production K1 kernel on stream 0 of a scratch state: requires a freshly reset stream 0
     int rc = check_stream(e, 0); if (rc) return rc;
     if (nbytes % 4 || nbytes > e->stage_bytes || nbytes / 4 > e->db.q15_cap) FAIL(NRSC5HIP_EINVAL, "bad length");
@@ -1524,6 +1577,7 @@ extern "C" int nrsc5hip_stage_halfband_fm_cu8(nrsc5hip_engine *e, const uint8_t 
 
 extern "C" int nrsc5hip_stage_fft2048(nrsc5hip_engine *e, const float *in, float *out, int n)
 {
+    ON_ENGINE_DEVICE(e);
     if (!e || !in || !out || n < 1) FAIL(NRSC5HIP_EINVAL, "bad argument");
     float2 *din = nullptr, *dout = nullptr;
     const size_t bytes = (size_t)n * FFT_N * sizeof(float2);
@@ -1539,6 +1593,7 @@ extern "C" int nrsc5hip_stage_fft2048(nrsc5hip_engine *e, const float *in, float
 
 extern "C" int nrsc5hip_stage_viterbi_k7(nrsc5hip_engine *e, const int8_t *soft, int len, int nframes, uint8_t *bits)
 {
+    ON_ENGINE_DEVICE(e);
     if (!e || !soft || !bits || len < 64 || nframes < 1) FAIL(NRSC5HIP_EINVAL, "bad argument");
     int8_t *dsoft = nullptr; unsigned long long *ddec = nullptr; uint32_t *dout = nullptr;
     const int words = (len + 31) / 32;
@@ -1546,7 +1601,7 @@ extern "C" int nrsc5hip_stage_viterbi_k7(nrsc5hip_engine *e, const int8_t *soft,
     HIPCHK(hipMalloc((void **)&ddec, (size_t)nframes * (len + 64) * sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void **)&dout, (size_t)nframes * words * sizeof(uint32_t)));
     HIPCHK(hipMemcpy(dsoft, soft, (size_t)nframes * 3 * len, hipMemcpyHostToDevice));
-    launch_viterbi_frames(dsoft, len, nframes, ddec, dout, e->main, 3, e->fwd_segments > 0 ? e->fwd_segments : 16, e->db.fwd_stats, e->fwd_warm);
+    if (launch_viterbi_frames(e->vit_scratch, dsoft, len, nframes, ddec, dout, e->main, 3, e->fwd_segments > 0 ? e->fwd_segments : 16, e->db.fwd_stats, e->fwd_warm)) FAIL(NRSC5HIP_EINVAL, "frame length %d not supported or out of device memory", len);
     HIPCHK(hipStreamSynchronize(e->main));
     std::vector<uint32_t> w((size_t)nframes * words);
     HIPCHK(hipMemcpy(w.data(), dout, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1557,6 +1612,7 @@ extern "C" int nrsc5hip_stage_viterbi_k7(nrsc5hip_engine *e, const int8_t *soft,
 
 extern "C" int nrsc5hip_debug_fetch(nrsc5hip_engine *e, int stream, int8_t *pm, float *bins)
 {
+    ON_ENGINE_DEVICE(e);
     int rc = check_stream(e, stream); if (rc) return rc;
     HIPCHK(hipDeviceSynchronize());
     if (pm) {
@@ -1570,6 +1626,7 @@ extern "C" int nrsc5hip_debug_fetch(nrsc5hip_engine *e, int stream, int8_t *pm, 
 
 extern "C" int nrsc5hip_debug_fetch_costas(nrsc5hip_engine *e, int stream, float *freq, float *phase)
 {
+    ON_ENGINE_DEVICE(e);
     int rc = check_stream(e, stream); if (rc) return rc;
     if (!freq || !phase) FAIL(NRSC5HIP_EINVAL, "null argument");
     if (e->staged_stream >= 0 && (rc = flush_staged(e))) return rc;
@@ -1581,6 +1638,7 @@ extern "C" int nrsc5hip_debug_fetch_costas(nrsc5hip_engine *e, int stream, float
 
 extern "C" int nrsc5hip_debug_fetch_px(nrsc5hip_engine *e, int stream, int8_t *pair)
 {
+    ON_ENGINE_DEVICE(e);
     int rc = check_stream(e, stream); if (rc) return rc;
     if (!pair) FAIL(NRSC5HIP_EINVAL, "null argument");
     HIPCHK(hipDeviceSynchronize());
@@ -1590,11 +1648,37 @@ extern "C" int nrsc5hip_debug_fetch_px(nrsc5hip_engine *e, int stream, int8_t *p
 
 extern "C" int nrsc5hip_debug_fetch_q15(nrsc5hip_engine *e, int stream, long long n, int16_t *out)
 {
+    ON_ENGINE_DEVICE(e);
     int rc = check_stream(e, stream); if (rc) return rc;
     if (n < 0 || n > e->db.q15_cap || !out) FAIL(NRSC5HIP_EINVAL, "bad argument");
     if (e->staged_stream >= 0 && (rc = flush_staged(e))) return rc;
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, e->db.q15 + (size_t)stream * e->db.q15_cap, (size_t)n * sizeof(c16), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+// ---- device helpers for C hosts that do not link the HIP runtime themselves (integration/batch_shard.c) ------------------------------
+extern "C" int nrsc5hip_device_count(int *n)
+{
+    if (!n) FAIL(NRSC5HIP_EINVAL, "null argument");
+    HIPCHK(hipGetDeviceCount(n));
+    return 0;
+}
+extern "C" int nrsc5hip_device_upload(int device, const void *host, size_t nbytes, void **dev_out)
+{
+    if (!dev_out) FAIL(NRSC5HIP_EINVAL, "null argument");
+    *dev_out = nullptr;
+    DeviceGuard guard(device);
+    void *d = nullptr;
+    if (hipMalloc(&d, nbytes ? nbytes : 1) != hipSuccess) FAIL(NRSC5HIP_ENOMEM, "hipMalloc(%zu bytes) on device %d failed", nbytes, device);
+    if (host) { hipError_t err = hipMemcpy(d, host, nbytes, hipMemcpyHostToDevice); if (err != hipSuccess) { (void)hipFree(d); FAIL(NRSC5HIP_EHIP, "upload failed: %s", hipGetErrorString(err)); } }
+    *dev_out = d;
+    return 0;
+}
+extern "C" int nrsc5hip_device_free(int device, void *dev)
+{
+    DeviceGuard guard(device);
+    HIPCHK(hipFree(dev));
     return 0;
 }
 
@@ -1610,6 +1694,7 @@ extern "C" void nrsc5hip_debug_free(void *dev) { (void)hipFree(dev); }
 
 extern "C" int nrsc5hip_reset_all(nrsc5hip_engine *e)
 {
+    ON_ENGINE_DEVICE(e);
     if (!e) FAIL(NRSC5HIP_EINVAL, "null engine");
     HIPCHK(hipDeviceSynchronize());
     e->dec_chunk = 0;
@@ -1641,8 +1726,24 @@ extern "C" int nrsc5hip_reset_all(nrsc5hip_engine *e)
     return 0;
 }
 
+// Test / bench hygiene: overwrite every result buffer a pass writes (decoded-frame rings on the device, their pinned host mirror,
+// the record rings) with a pattern no decode produces, so that a check after the next pass can only pass on bits written by it.
+extern "C" int nrsc5hip_debug_poison_results(nrsc5hip_engine *e)
+{
+    ON_ENGINE_DEVICE(e);
+    HIPCHK(hipDeviceSynchronize());
+    const size_t S = e->cfg.max_streams;
+    HIPCHK(hipMemset(e->db.p1_ring, 0xA5, S * e->db.p1_slots * (size_t)P1_WORDS * sizeof(uint32_t)));
+    HIPCHK(hipMemset(e->db.records, 0, S * e->db.rec_cap * sizeof(BlockRecord)));
+    HIPCHK(hipMemset(e->db.px_ring, 0xA5, S * (size_t)e->db.px_slots * 2 * PX_WORDS * sizeof(uint32_t)));
+    if (e->frames_host) memset(e->frames_host, 0xA5, S * e->db.p1_slots * (size_t)P1_WORDS * sizeof(uint32_t));
+    if (e->rec_host) memset(e->rec_host, 0, S * e->db.rec_cap * sizeof(BlockRecord));
+    return 0;
+}
+
 extern "C" int nrsc5hip_profile(nrsc5hip_engine *e, int enable, double *total_ms, long long *launches)
 {
+    ON_ENGINE_DEVICE(e);
     if (!e) FAIL(NRSC5HIP_EINVAL, "null engine");
     HIPCHK(hipDeviceSynchronize());
     if (e->prof_on) prof_collect(e);
@@ -1657,6 +1758,7 @@ extern "C" int nrsc5hip_profile(nrsc5hip_engine *e, int enable, double *total_ms
 
 extern "C" int nrsc5hip_stage_selftest(nrsc5hip_engine *e, int *failures)
 {
+    ON_ENGINE_DEVICE(e);
     if (!e || !failures) FAIL(NRSC5HIP_EINVAL, "null argument");
     HIPCHK(hipMemsetAsync(e->db.counters + 2, 0, sizeof(int), e->main));
     launch_selftest(e->db.counters + 2, e->main);
@@ -1667,6 +1769,7 @@ extern "C" int nrsc5hip_stage_selftest(nrsc5hip_engine *e, int *failures)
 
 extern "C" int nrsc5hip_stage_viterbi_k7_debug(nrsc5hip_engine *e, const int8_t *soft, int len, uint8_t *bits, unsigned long long *dec_out)
 {
+    ON_ENGINE_DEVICE(e);
     if (!e || !soft || !bits || !dec_out || len < 64) FAIL(NRSC5HIP_EINVAL, "bad argument");
     int8_t *dsoft = nullptr; unsigned long long *ddec = nullptr; uint32_t *dout = nullptr;
     const int words = (len + 31) / 32;
@@ -1674,7 +1777,7 @@ extern "C" int nrsc5hip_stage_viterbi_k7_debug(nrsc5hip_engine *e, const int8_t 
     HIPCHK(hipMalloc((void **)&ddec, (size_t)(len + 64) * sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void **)&dout, (size_t)words * sizeof(uint32_t)));
     HIPCHK(hipMemcpy(dsoft, soft, (size_t)3 * len, hipMemcpyHostToDevice));
-    launch_viterbi_frames(dsoft, len, 1, ddec, dout, e->main);
+    if (launch_viterbi_frames(e->vit_scratch, dsoft, len, 1, ddec, dout, e->main)) FAIL(NRSC5HIP_EINVAL, "frame length %d not supported or out of device memory", len);
     HIPCHK(hipStreamSynchronize(e->main));
     std::vector<uint32_t> w(words);
     HIPCHK(hipMemcpy(w.data(), dout, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1687,6 +1790,7 @@ extern "C" int nrsc5hip_stage_viterbi_k7_debug(nrsc5hip_engine *e, const int8_t 
 // micro-benchmark: nframes random frames, `phases` bit0 = forward pass, bit1 = traceback; ms per launch
 extern "C" int nrsc5hip_stage_viterbi_bench(nrsc5hip_engine *e, int len, int nframes, int phases, int reps, float *ms_per_launch)
 {
+    ON_ENGINE_DEVICE(e);
     if (!e || !ms_per_launch || len < 64 || nframes < 1 || reps < 1) FAIL(NRSC5HIP_EINVAL, "bad argument");
     int8_t *dsoft = nullptr; unsigned long long *ddec = nullptr; uint32_t *dout = nullptr;
     const int words = (len + 31) / 32;
@@ -1700,12 +1804,12 @@ extern "C" int nrsc5hip_stage_viterbi_bench(nrsc5hip_engine *e, int len, int nfr
     HIPCHK(hipMemset(ddec, 0x55, (size_t)nframes * (len + 64) * sizeof(unsigned long long)));
     hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
     const int seg = e->fwd_segments > 0 ? e->fwd_segments : 1;
-    launch_viterbi_frames(dsoft, len, nframes, ddec, dout, e->main, phases | 1, seg);      // warm-up; packs the soft words and leaves decisions behind
+    if (launch_viterbi_frames(e->vit_scratch, dsoft, len, nframes, ddec, dout, e->main, phases | 1, seg)) FAIL(NRSC5HIP_EINVAL, "frame length %d not supported or out of device memory", len);      // warm-up; packs the soft words and leaves decisions behind
     HIPCHK(hipEventRecord(a, e->main));
     for (int r = 0; r < reps; r++) {
         // a traceback-only measurement consumes the decisions in place: re-run the (untimed-irrelevant) forward pass is not possible
         // without timing it, so phases == 2 measures forward + traceback minus nothing -- callers subtract the forward figure
-        launch_viterbi_frames(dsoft, len, nframes, ddec, dout, e->main, ((phases & 2) ? (phases | 1) : phases) | 8, seg);
+        (void)launch_viterbi_frames(e->vit_scratch, dsoft, len, nframes, ddec, dout, e->main, ((phases & 2) ? (phases | 1) : phases) | 8, seg);
     }
     HIPCHK(hipEventRecord(b, e->main));
     HIPCHK(hipEventSynchronize(b));
@@ -1719,6 +1823,7 @@ extern "C" int nrsc5hip_stage_viterbi_bench(nrsc5hip_engine *e, int len, int nfr
 // micro-benchmark of the K=9 trellis kernel (E2 code) on random hard-decision frames: phases bit0 = forward, bit1 = traceback
 extern "C" int nrsc5hip_stage_viterbi_k9_bench(nrsc5hip_engine *e, int len, int nframes, int phases, int reps, float *ms_per_launch)
 {
+    ON_ENGINE_DEVICE(e);
     if (!e || !ms_per_launch || len < 128 || nframes < 1 || reps < 1) FAIL(NRSC5HIP_EINVAL, "bad argument");
     int8_t *dsoft = nullptr; unsigned long long *ddec = nullptr; uint32_t *dout = nullptr;
     const int words = (len + 31) / 32;
@@ -1765,6 +1870,7 @@ extern "C" int nrsc5hip_stage_viterbi_k9_bench(nrsc5hip_engine *e, int len, int 
 // Tuning knobs and test hooks: an explicit entry point, nothing is read from the environment.
 extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
 {
+    ON_ENGINE_DEVICE(e);
     if (!e) FAIL(NRSC5HIP_EINVAL, "null engine");
     HIPCHK(hipDeviceSynchronize());
     switch (knob) {
@@ -1780,10 +1886,12 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
         const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
         std::vector<uint32_t> mask((size_t)words, 0u);
         for (int i = 0; i < ncu; i++) if ((i % 32) < k) mask[(size_t)i / 32] |= 1u << (i % 32);
-        for (int a = 0; a < NAUX; a++) {
-            HIPCHK(hipStreamDestroy(e->lane.aux[a]));
-            if (k >= 32) HIPCHK(hipStreamCreate(&e->lane.aux[a]));
-            else HIPCHK(hipExtStreamCreateWithCUMask(&e->lane.aux[a], (uint32_t)words, mask.data()));
+        for (int a = 0; a < NAUX; a++) {                       // the new stream first; the old one is destroyed only once it exists
+            hipStream_t fresh = nullptr;
+            if (k >= 32) HIPCHK(hipStreamCreate(&fresh));
+            else HIPCHK(hipExtStreamCreateWithCUMask(&fresh, (uint32_t)words, mask.data()));
+            (void)hipStreamDestroy(e->lane.aux[a]);
+            e->lane.aux[a] = fresh;
         }
         break;
     }
@@ -1791,9 +1899,11 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
         int least = 0, greatest = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         for (int a = 0; a < NAUX; a++) {
-            HIPCHK(hipStreamDestroy(e->lane.aux[a]));
-            if (value) HIPCHK(hipStreamCreateWithPriority(&e->lane.aux[a], hipStreamDefault, least));
-            else HIPCHK(hipStreamCreate(&e->lane.aux[a]));
+            hipStream_t fresh = nullptr;
+            if (value) HIPCHK(hipStreamCreateWithPriority(&fresh, hipStreamDefault, least));
+            else HIPCHK(hipStreamCreate(&fresh));
+            (void)hipStreamDestroy(e->lane.aux[a]);
+            e->lane.aux[a] = fresh;
         }
         break;
     }
@@ -1813,6 +1923,7 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
 
 extern "C" int nrsc5hip_debug_fwd_stats(nrsc5hip_engine *e, int stats[2])
 {
+    ON_ENGINE_DEVICE(e);
     if (!e || !stats) FAIL(NRSC5HIP_EINVAL, "null argument");
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(stats, e->db.fwd_stats, 2 * sizeof(int), hipMemcpyDeviceToHost));
@@ -1821,6 +1932,7 @@ extern "C" int nrsc5hip_debug_fwd_stats(nrsc5hip_engine *e, int stats[2])
 
 extern "C" int nrsc5hip_debug_k9_stats(nrsc5hip_engine *e, int stats[4])
 {
+    ON_ENGINE_DEVICE(e);
     if (!e || !stats) FAIL(NRSC5HIP_EINVAL, "null argument");
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(stats, e->db.am_k9stats, 4 * sizeof(int), hipMemcpyDeviceToHost));
@@ -1829,6 +1941,7 @@ extern "C" int nrsc5hip_debug_k9_stats(nrsc5hip_engine *e, int stats[4])
 
 extern "C" int nrsc5hip_debug_sync_phases(nrsc5hip_engine *e, long long *cycles8)
 {
+    ON_ENGINE_DEVICE(e);
     if (!e || !cycles8) FAIL(NRSC5HIP_EINVAL, "null argument");
     if (!e->db.sync_phase_cycles) FAIL(NRSC5HIP_EINVAL, "turn the instrumentation on first: nrsc5hip_debug_tune(e, NRSC5HIP_TUNE_SYNC_PHASES, 1)");
     HIPCHK(hipDeviceSynchronize());
@@ -1841,9 +1954,10 @@ extern "C" int nrsc5hip_debug_sync_phases(nrsc5hip_engine *e, long long *cycles8
 // frames: [nstreams][p1_slots][4568].  Requires that nothing was drained since the last reset.
 extern "C" int nrsc5hip_batch_fetch_view(nrsc5hip_engine *e, int nstreams, const nrsc5hip_record **records, int *counts, const uint32_t **frames)
 {
+    ON_ENGINE_DEVICE(e);
     if (!e || !records || !counts) FAIL(NRSC5HIP_EINVAL, "null argument");
     if (nstreams < 1 || nstreams > e->cfg.max_streams) FAIL(NRSC5HIP_EINVAL, "nstreams out of range");
-    leave_mirror(e, nstreams, nullptr);
+    { int rc = leave_mirror(e, nstreams, nullptr); if (rc) return rc; }
     const size_t S = e->cfg.max_streams;
     if (!e->rec_host) {
         HIPCHK(hipHostMalloc((void **)&e->rec_host, S * e->db.rec_cap * sizeof(BlockRecord), hipHostMallocDefault));

@@ -252,17 +252,40 @@ __global__ __launch_bounds__(TB_THREADS) void k_viterbi_frames_tb(uint32_t *dec,
     viterbi3_traceback_block(dec + (size_t)f * 2 * (len + 64), len, endlane[f], out + (size_t)f * ((len + 31) / 32), gmap + (size_t)f * (len / 64 + 1) * 64, smem, maps_done != 0);
 }
 
-void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st, int phases, int segments, int *stats, int warm)
+void vit_scratch_free(VitScratch &sc)
+{
+    if (sc.endlane) (void)hipFree(sc.endlane);
+    if (sc.gmap) (void)hipFree(sc.gmap);
+    if (sc.soft) (void)hipFree(sc.soft);
+    if (sc.meta) (void)hipFree(sc.meta);
+    sc = VitScratch();
+}
+
+template <typename T, typename N> static bool vit_grow(T *&p, N &cap, N need, size_t elem)
+{
+    if (cap >= need) return true;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    if (hipMalloc((void **)&p, elem * (size_t)need) != hipSuccess) { p = nullptr; return false; }
+    cap = need;
+    return true;
+}
+
+// the block-parallel traceback keeps one end lane per segment of TB_SEG chunks in a fixed 64-entry LDS array (viterbi_v3.h)
+static_assert((P1_LEN / 64 + 1 + TB_SEG - 1) / TB_SEG <= 64, "P1 frame exceeds the traceback's segment table");
+constexpr int VIT3_MAX_LEN = (64 * TB_SEG - 1) * 64;
+
+int launch_viterbi_frames(VitScratch &sc, const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st, int phases, int segments, int *stats, int warm)
 {
     if ((len & 63) == 0 && !(phases & 4)) {                    // production split: forward segment waves + fix + parallel traceback (viterbi_v3.h)
-        static int *endlane = nullptr; static int cap = 0; static uint8_t *gmap = nullptr; static size_t gcap = 0;
-        static int *soft = nullptr; static size_t scap = 0; static int *meta = nullptr; static int mcap = 0;
-        if (cap < nframes) { if (endlane) (void)hipFree(endlane); (void)hipMalloc((void **)&endlane, sizeof(int) * nframes); cap = nframes; (void)hipMemset(endlane, 0, sizeof(int) * nframes); }
-        if (mcap < nframes) { if (meta) (void)hipFree(meta); (void)hipMalloc((void **)&meta, sizeof(int) * (size_t)nframes * VIT3_GMAX * VIT3_META); mcap = nframes; }
-        const size_t gneed = (size_t)nframes * (len / 64 + 1) * 64;
-        if (gcap < gneed) { if (gmap) (void)hipFree(gmap); (void)hipMalloc((void **)&gmap, gneed); gcap = gneed; }
+        if (len > VIT3_MAX_LEN) return -1;
+        int *&endlane = sc.endlane; uint8_t *&gmap = sc.gmap; int *&soft = sc.soft; int *&meta = sc.meta;
+        const int cap_before = sc.cap;
+        if (!vit_grow(endlane, sc.cap, nframes, sizeof(int))) return -1;
+        if (sc.cap != cap_before) (void)hipMemsetAsync(endlane, 0, sizeof(int) * nframes, st);
+        if (!vit_grow(meta, sc.mcap, nframes, sizeof(int) * (size_t)VIT3_GMAX * VIT3_META)) return -1;
+        if (!vit_grow(gmap, sc.gcap, (size_t)nframes * (len / 64 + 1) * 64, 1)) return -1;
+        if (!vit_grow(soft, sc.scap, (size_t)nframes * len, sizeof(int))) return -1;
         const size_t nsteps = (size_t)nframes * len;
-        if (scap < nsteps) { if (soft) (void)hipFree(soft); (void)hipMalloc((void **)&soft, nsteps * sizeof(int)); scap = nsteps; }
         if (phases & 1) {
             if (!(phases & 8))                                 // bit 3 (micro-benchmark): the soft words of this input are packed already
                 hipLaunchKernelGGL(k_pack_soft3, dim3((unsigned)((nsteps + 255) / 256)), dim3(256), 0, st, coded, soft, nsteps);
@@ -275,9 +298,10 @@ void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned l
             if (split) hipLaunchKernelGGL(k_viterbi_frames_tbmap, dim3(split, nframes), dim3(64 * TBM_WAVES), 0, st, (uint32_t *)dec, len, gmap, split);
             hipLaunchKernelGGL(k_viterbi_frames_tb, dim3(nframes), dim3(TB_THREADS), traceback_smem(len), st, (uint32_t *)dec, len, (const int *)endlane, out, gmap, split ? 1 : 0);
         }
-        return;
+        return 0;
     }
     hipLaunchKernelGGL(k_viterbi_frames, dim3(nframes), dim3(64), 0, st, coded, len, dec, out, phases & 3);
+    return 0;
 }
 
 // ---- device self-test of the register-file lane exchanges against the generic shuffle ----------------

@@ -149,7 +149,11 @@ void launch_l2_index_am_window(const DevBuffers &db, int nstreams, const int *st
 void launch_l2_index_am_step(const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
 
 // ---- stage-level entry points (parity tests) ---------------------------------------------------
-void launch_viterbi_frames(const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st, int phases = 3, int segments = 1, int *stats = nullptr, int warm = 2);
+// scratch of the stage-level K=7 decode (end lanes, chunk maps, packed soft words, segment metadata): owned by the engine that calls it
+struct VitScratch { int *endlane = nullptr; int cap = 0; uint8_t *gmap = nullptr; size_t gcap = 0; int *soft = nullptr; size_t scap = 0; int *meta = nullptr; int mcap = 0; };
+void vit_scratch_free(VitScratch &sc);
+// -> 0, or -1: frame too long for the block-parallel traceback (viterbi3_traceback_block: at most 64 segments of TB_SEG chunks) / out of device memory
+int launch_viterbi_frames(VitScratch &sc, const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st, int phases = 3, int segments = 1, int *stats = nullptr, int warm = 2);
 void launch_selftest(int *fail_count, hipStream_t st);
 void launch_fft2048(const DevTables &tb, const float2 *in, float2 *out, int nffts, hipStream_t st);
 

@@ -94,10 +94,43 @@ def channel_cu8(sig: torch.Tensor, cfo_hz: float, offset: int, snr_db: float, se
 
 
 def stream_params(k: int):
-    """Config-3 family of SURVEY.md 8d: seed 1000+k, CFO uniform +-300 Hz, offset [0,4320), SNR 15/20/25 dB."""
+    """Config-3 family of SURVEY.md 8d: seed 1000+k, CFO uniform +-300 Hz, offset [0,4320), SNR 15/20/25 dB.  Every stream with
+    k % 4 == 1 (64 of 256) additionally sees an impaired channel (nrsc5_amd/channel.py): a receiver sample clock off by +-20 ...
+    +-100 ppm -- the FINE-state timing feedback then works on every block (sync.c:455 -> acquire.c:112,259 -> sync_adjust) --
+    and, by k % 16: 1 = the clock error alone, 5 = + two echoes inside the cyclic prefix with slow Doppler, 9 = + an analog FM host
+    20 dB above the digital sidebands (digital level 9 LSB rms so that the host fits the 8-bit range), 13 = + 8 dB block-scale
+    fading.  -> kwargs of channel_cu8 (+ "chan")."""
     rng = np.random.default_rng(1000 + k)
-    return dict(cfo_hz=float(rng.uniform(-300, 300)), offset=int(rng.integers(0, 4320)),
-                snr_db=(15.0, 20.0, 25.0)[k % 3], seed=1000 + k)
+    prm = dict(cfo_hz=float(rng.uniform(-300, 300)), offset=int(rng.integers(0, 4320)),
+               snr_db=(15.0, 20.0, 25.0)[k % 3], seed=1000 + k, chan=None, rms_lsb=20.0)
+    if k % 4 == 1:
+        from .channel import Impairments
+        crng = np.random.default_rng(77000 + k)
+        ppm = float(crng.uniform(20.0, 100.0) * (1 if crng.integers(0, 2) else -1))
+        kind = k % 16
+        if kind == 1:
+            prm["chan"] = Impairments(ppm=ppm)
+        elif kind == 5:
+            prm["chan"] = Impairments(ppm=ppm, paths=((float(crng.uniform(5e-6, 40e-6)), float(crng.uniform(-10.0, -3.0)), float(crng.uniform(-2.0, 2.0)), float(crng.uniform(0, 6.28))),
+                                                      (float(crng.uniform(5e-6, 40e-6)), float(crng.uniform(-12.0, -6.0)), float(crng.uniform(-2.0, 2.0)), float(crng.uniform(0, 6.28)))))
+        elif kind == 9:
+            prm["chan"] = Impairments(ppm=ppm, host_db=20.0)
+            prm["rms_lsb"] = 9.0
+        else:
+            prm["chan"] = Impairments(ppm=ppm, fade_db=8.0, fade_period_s=float(crng.uniform(0.7, 3.0)))
+    return prm
+
+
+def receive_cu8(clean: torch.Tensor, prm: dict, tail: int = 8640, out: torch.Tensor | None = None) -> torch.Tensor:
+    """One receiver's cu8 capture of a clean transmission: stream_params' channel (impairments first, then CFO / offset / AWGN / 8 bits)."""
+    sig = clean
+    if prm.get("chan") is not None:
+        from . import channel
+        sig = channel.apply_torch(clean, synth.FS_CU8, prm["chan"])
+    return channel_cu8(sig, prm["cfo_hz"], prm["offset"], prm["snr_db"], prm["seed"], rms_lsb=prm.get("rms_lsb", 20.0), tail=tail, out=out)
+
+
+STRIDE_SLACK = 4096          # samples: +100 ppm stretch a 20.8-s capture by 3100 samples
 
 
 def channel_am(sig: torch.Tensor, cfo_hz: float, offset: int, noise: float, seed: int, fmt: str = "cs16", tail: int = 1080,
@@ -148,7 +181,14 @@ def am_stream_params(k: int, n_frames: int):
     cu8) plus up to 8 symbols, noise 0.4 / 0.6 / 0.8 grid units; every 16th stream is hit by an interference burst that breaks
     the first L2 header of some P1 PDUs (the reference then drops to SYNC_STATE_NONE and re-acquires: frame.c:535-540)."""
     rng = np.random.default_rng(5000 + k)
-    prm = dict(cfo_hz=float(rng.uniform(-100, 100)), offset=int(rng.integers(0, 9 * 270)), noise=(0.4, 0.6, 0.8)[k % 3], seed=5000 + k, burst=None)
+    prm = dict(cfo_hz=float(rng.uniform(-100, 100)), offset=int(rng.integers(0, 9 * 270)), noise=(0.4, 0.6, 0.8)[k % 3], seed=5000 + k, burst=None, chan=None)
     if k % 16 == 5 and n_frames >= 12:
         prm["burst"] = (float(rng.uniform(5.0, n_frames - 6.0)), float(rng.uniform(0.2, 0.6)), 40.0)
+    if k % 4 == 2:
+        # a quarter of the receivers: sample clock off by +-5 ... +-20 ppm (the reference's AM receiver corrects timing in whole
+        # samples only and loses frames beyond ~30 ppm: tests/common.py IMPAIRED_AM_CASES), every other one with an echo
+        from .channel import Impairments
+        crng = np.random.default_rng(78000 + k)
+        ppm = float(crng.uniform(5.0, 20.0) * (1 if crng.integers(0, 2) else -1))
+        prm["chan"] = Impairments(ppm=ppm, paths=((float(crng.uniform(40e-6, 150e-6)), float(crng.uniform(-12.0, -6.0)), float(crng.uniform(-0.5, 0.5)), float(crng.uniform(0, 6.28))),) if k % 8 == 2 else ())
     return prm

@@ -358,6 +358,22 @@ def check_api_edges(lib):
     E.close()
 
 
+def check_large_push_minimum_fifo(lib, oracle):
+    """ONE push of a whole capture into an engine whose FIFO is at the legal minimum (2 windows): the fast seam stages at most up to
+    the sample that completes the next block, so the push is processed block by block, never overflows and leaves the host mirror
+    exact (round 3: EOVERFLOW with the samples dropped but counted).  Log == oracle; bytes_to_next_block stays consistent."""
+    cap = synth.fm_mp1_capture(0, seed=61, cfo_hz=33.0, offset=1999, snr_db=20, n_blocks=10)
+    ol, _, _ = oracle.run(cap.iq)
+    E = eng.Engine(max_streams=1, q15_capacity=2 * 71280, lib_path=lib)
+    E.push_cu8(0, cap.iq[:cap.iq.size - cap.iq.size % 4])                   # ~2.8 MB in one call
+    log = eng.records_to_log(E, 0, E.drain(0))
+    diffs = common.compare_logs(common.strip_states(ol), common.strip_states(log))
+    assert not diffs, diffs[:5]
+    nb = E.lib.nrsc5hip_bytes_to_next_block(E._h, 0, 1)
+    assert 0 < nb <= 4 * 71280
+    E.close()
+
+
 def check_cs16_batch(lib, captures):
     """cs16 captures through the batch path (bypasses K1) == golden."""
     g = golden("fm_cs16_cfo60")

@@ -70,6 +70,10 @@ def test_emu_api_edges(emu_lib):
     ec.check_api_edges(emu_lib)
 
 
+def test_emu_large_push_into_minimum_fifo(emu_lib, oracle):
+    ec.check_large_push_minimum_fifo(emu_lib, oracle)
+
+
 def test_emu_extended_sidebands_mp11(emu_lib, oracle):
     """PX1 / PX2 -> interleaver IV -> P3 / P4 (MP11), in-order and through the deferred decode windows."""
     kw = dict(n_frames=0, n_blocks=44, seed=5, mode="MP11", cfo_hz=50.0, offset=500, snr_db=25, fmt="cs16")

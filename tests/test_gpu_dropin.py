@@ -83,3 +83,52 @@ def test_two_dropin_sessions_in_one_process(captures):
         exp = _run("libnrsc5_plain.so", iq)
         assert len(exp) >= 2
         _compare_events(exp, g)
+
+
+def test_batch_shard_c_host_equals_python_path(tmp_path):
+    """integration/batch_shard.c -- plain C, one host thread and one engine per visible GPU over the C ABI, stream k -> GPU k mod N --
+    prints per stream the summary bench.py's ranks gather (blocks, P1 / PIDS counts, crc32 over the packed P1 frames in record
+    order); here with N = 1 against the same captures through the Python binding."""
+    import subprocess
+    import zlib
+    from nrsc5_amd import engine as eng, synth, channel
+    from tests import engine_checks as ec
+    exe = os.path.join(common.ROOT, "integration", "_build", "batch_shard")
+    if not os.path.exists(exe):
+        pytest.skip("integration/_build/batch_shard not prebuilt")
+    caps = [synth.fm_mp1_capture(0, seed=80 + k, cfo_hz=c, offset=o, snr_db=20, n_blocks=40, chan=ch)
+            for k, (c, o, ch) in enumerate([(40.0, 123, None), (-130.0, 3001, channel.Impairments(ppm=70.0)), (10.0, 1700, None), (250.0, 9, channel.Impairments(ppm=-45.0))])]
+    per = min(c.iq.size for c in caps); per -= per % 4
+    path = tmp_path / "caps.cu8"
+    with open(path, "wb") as f:
+        for c in caps:
+            f.write(c.iq[:per].tobytes())
+    out = subprocess.run([exe, str(path), str(len(caps)), str(per)], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, GPU_MAX_HW_QUEUES="8"))
+    assert out.returncode == 0, out.stderr
+    lines = [ln.split() for ln in out.stdout.strip().splitlines()]
+    assert len(lines) == len(caps)
+    # the Python path: same engine configuration, same entry points
+    n = len(caps)
+    stride = per + (-per) % 256
+    buf = np.zeros((n, stride), dtype=np.uint8)
+    for k, c in enumerate(caps):
+        buf[k, :per] = c.iq[:per]
+    nframes = per // (16 * 276480) + 1
+    E = eng.Engine(max_streams=n, q15_capacity=2 * 71280, record_capacity=max(512, 2 * 16 * nframes + 64), p1_slots=nframes + 12, p1_async=True, l2_feedback=True, batch_zero_copy=True)
+    dev = ec._to_device(E, buf)
+    E.batch_append_cu8(dev, stride, [per] * n)
+    E.batch_process(n)
+    recs, counts, frames = E.batch_fetch_view(n)
+    for k in range(n):
+        r = recs[k, :counts[k]]
+        h, p1 = 0, 0
+        for x in r:
+            if int(x["flags"]) & eng.REC_P1:
+                h = zlib.crc32(frames[k, int(x["p1_slot"])].tobytes(), h); p1 += 1
+        want = ["stream", str(k), "gpu", "0", "blocks", str(len(r)), "p1", str(p1), "pids", str(int(((r["flags"] & eng.REC_PIDS) != 0).sum())),
+                "fine", str(int((r["state_after"] == eng.SYNC_FINE).sum())), "crc32", "%08x" % h]
+        assert lines[k] == want, (lines[k], want)
+        assert p1 >= 1
+    ec._free_device(E, dev)
+    E.close()

@@ -120,6 +120,35 @@ def test_gpu_api_edges(hip_lib):
     ec.check_api_edges(hip_lib)
 
 
+def test_gpu_large_push_into_minimum_fifo(hip_lib, oracle):
+    ec.check_large_push_minimum_fifo(hip_lib, oracle)
+
+
+def test_gpu_poisoned_results_are_rewritten(hip_lib):
+    """nrsc5hip_debug_poison_results between two passes over one engine: the second pass's frames must be written by THAT pass
+    (a skipped traceback would leave the 0xA5 pattern in the ring and its pinned host mirror)."""
+    cap = synth.fm_mp1_capture(0, seed=62, cfo_hz=-50.0, offset=700, snr_db=22, n_blocks=36)
+    stride = cap.iq.size + (-cap.iq.size) % 256
+    buf = np.zeros((1, stride), dtype=np.uint8); buf[0, :cap.iq.size] = cap.iq
+    E = eng.Engine(max_streams=1, q15_capacity=2 * 71280, record_capacity=512, p1_slots=8, p1_async=True, l2_feedback=True, batch_zero_copy=True, lib_path=hip_lib)
+    dev = ec._to_device(E, buf)
+    got = []
+    for _ in range(2):
+        E.reset_all()
+        E.batch_append_cu8(dev, stride, [cap.iq.size - cap.iq.size % 4])
+        E.batch_process(1)
+        recs, counts, frames = E.batch_fetch_view(1)
+        r = recs[0, :counts[0]]
+        fr = [frames[0, int(x["p1_slot"])].copy() for x in r if int(x["flags"]) & eng.REC_P1]
+        assert len(fr) == 1 and not (fr[0] == 0xA5A5A5A5).any()
+        got.append(fr[0])
+        E.poison_results()
+        assert (frames[0] == 0xA5A5A5A5).all()                  # the view IS the pinned mirror
+    assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], np.packbits(cap.p1_frames[1], bitorder="little").view(np.uint32))
+    ec._free_device(E, dev)
+    E.close()
+
+
 def test_gpu_cs16_batch(hip_lib, captures):
     ec.check_cs16_batch(hip_lib, captures)
 
