@@ -352,6 +352,7 @@ enum {
     , NRSC5HIP_TUNE_DECODE_CUS             /* decode streams confined to value / 32 of every XCD's CUs (8, 16, 24; 32 = all, the default) */
     , NRSC5HIP_TUNE_DECODE_PRIORITY        /* 1: decode streams at the lowest queue priority (default 0: all queues equal) */
     , NRSC5HIP_TUNE_AM_WARM                /* TEST HOOK: 0 = no forward warm-up and no traceback run-in (every boundary takes the repair path); 1 = normal */
+    , NRSC5HIP_TUNE_MIXFFT_SYMS            /* OFDM symbols per k_mixfft workgroup: 1 (default), 2, 4, 8 -- any value gives identical bins */
 };
 /* process-wide wall-clock totals of the streaming seam with p1_async = 0 (what the drop-in uses): [0] s copying pushes into pinned
  * staging, [1] s enqueueing H2D + decimator, [2] s enqueueing block steps, [3] s waiting for the device (one sync per block),

@@ -89,6 +89,7 @@ struct nrsc5hip_engine {
     int verdict_lag;                   // test hook (nrsc5hip_debug_tune): replay takes verdicts this many windows late
     int am_segments, am_warm, am_runin;   // K=9 decode of the AM P3 frame: segment waves per frame (8), their forward warm-up / traceback run-in (test hooks: 0)
     int fwd_warm;                      // test hook: speculative warm-up trips of a forward segment (2; 0 makes every speculation fail -> repair path)
+    int mixfft_syms;                   // symbols per k_mixfft workgroup (1, 2, 4, 8)
     int fwd_segments;                  // waves per frame of the P1 forward pass; 0 = pick from the size of the stream set (fwd_segments_for)
     hipStream_t main;                  // = lane.main
     std::vector<void *> allocs;
@@ -394,7 +395,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
     do {
         {
             e->naux = 3; e->naux_am = 2;   // decode streams in use (measured: profiles/r02_naux.txt, r03_am_decode.txt); nrsc5hip_debug_tune changes them
-            e->verdict_lag = 0; e->fwd_segments = 0; e->fwd_warm = 2;
+            e->verdict_lag = 0; e->fwd_segments = 0; e->fwd_warm = 2; e->mixfft_syms = 1;      // measured: profiles/r04_mixfft_persistent.txt
             e->am_segments = K9_GMAX; e->am_warm = K9_WARM; e->am_runin = K9_TB_RUNIN;
         }
         {
@@ -643,7 +644,7 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
     // prepare_block is idempotent for a stream the previous k_sync already prepared; a stream that is not FINE is only
     // prepared here, on a step that ran the acquisition kernels for its current window
     if (!ln.prepared_by_sync || ln.acq_needed) { ProfScope p(e, NRSC5HIP_PROF_PREPARE, ln.main); launch_prepare(ln.db, n, ids_dev, ln.acq_needed ? 1 : 0, ln.main); }
-    { ProfScope p(e, NRSC5HIP_PROF_MIXFFT, ln.main); launch_mixfft(e->tb, ln.db, n, ids_dev, ln.main); }
+    { ProfScope p(e, NRSC5HIP_PROF_MIXFFT, ln.main); launch_mixfft(e->tb, ln.db, n, ids_dev, ln.main, e->mixfft_syms); }
     const int slot = async ? (int)(ln.step_count % 16) : 0;
     // batch pipeline: once every stream of the set is FINE, the next block's bookkeeping rides in k_sync's tail
     const int fuse = (async && !ln.acq_needed) ? 1 : 0;
@@ -1907,6 +1908,7 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
         }
         break;
     }
+    case NRSC5HIP_TUNE_MIXFFT_SYMS:       e->mixfft_syms = (value == 2 || value == 4 || value == 8) ? value : 1; break;
     case NRSC5HIP_TUNE_AM_SEGMENTS:       e->am_segments = std::min(std::max(value, 1), K9_GMAX); break;
     case NRSC5HIP_TUNE_AM_WARM:           e->am_warm = value > 0 ? K9_WARM : 0; e->am_runin = value > 0 ? K9_TB_RUNIN : 0; break;
     case NRSC5HIP_TUNE_SYNC_PHASES:

@@ -208,13 +208,14 @@ __device__ inline void fft2048_wg(cf *x, cf *lds, const float2 *twA, const cf *t
 // every pair is even and one odd, so the -127 offsets of both (x' = byte - 127) are applied as -254 to the even-indexed E
 // only; the centre sample's -127 * 64 goes into the accumulator's start value.  The tile receives the Q15 INTEGERS
 // (imaginary part negated: the FM receiver's spectrum flip); sample() below divides by 32767 on the way out.
-__device__ inline void decimate_symbol_raw(const uint8_t *raw, long long a0, cf *tile, const HbTaps &taps)
+// the 24 consecutive dwords of the capture work-item t needs for the symbol whose first decimated sample is a0: six dwordx4
+// loads, issued and NOT waited for here -- the caller overlaps them with the previous symbol's FFT
+__device__ __forceinline__ void raw_symbol_load(const uint8_t *raw, long long a0, uint32_t (&W)[24], int tid)
 {
-    const int m0 = 17 * (int)threadIdx.x;
+    const int m0 = 17 * tid;
     const int nout = min(17, SYM_N - m0);                      // 17 for work-items 0..126, 1 for the last
     const uint32_t *rw = (const uint32_t *)raw;
     const long long d0 = a0 + m0 - 7;
-    uint32_t W[24];
     if (a0 >= 7) {                                             // block-uniform: all but a stream's very first symbol
 #ifdef HIPEMU
         struct u32x4 { uint32_t x, y, z, w; };
@@ -237,6 +238,11 @@ __device__ inline void decimate_symbol_raw(const uint8_t *raw, long long a0, cf 
 #pragma unroll
         for (int k = 0; k < 24; k++) W[k] = (k < nout + 7) ? hb_raw_dword(rw, d0 + k) : 0x7f7f7f7fu;
     }
+}
+
+__device__ inline void raw_symbol_halfband(const uint32_t (&W)[24], cf *tile, const HbTaps &taps, int tid)
+{
+    const int m0 = 17 * tid;
     const hb_v2 T[4] = {hb_make(taps.t0, taps.t0), hb_make(taps.t1, taps.t1), hb_make(taps.t2, taps.t2), hb_make(taps.t3, taps.t3)};
     const hb_v2 off = hb_make(-254.0f, -254.0f);
     hb_v2 E[24];
@@ -277,76 +283,117 @@ __device__ inline void decimate_symbol_raw(const uint8_t *raw, long long a0, cf 
 
 // RAW: the stream reads its cu8 capture in place (zero-copy batch) -- else its samples come from the Q15 FIFO.  Block-uniform, so
 // the two forms are separate instantiations rather than a test per sample.
-template <bool RAW>
-__device__ __forceinline__ void mixfft_symbol(const DevTables &tb, const DevBuffers &db, const StreamState &st, int s, cf *lds, cf *twB)
+// A uniform pointer the optimiser cannot see through: loads through it are NOT hoisted out of the symbol loop (the 14 stage-A
+// twiddles and the pulse-shape values of a work-item are loop-invariant; kept in registers across the loop they cost 32 VGPRs
+// and the fourth wave per SIMD)
+template <typename T> __device__ __forceinline__ const T *per_symbol(const T *p)
 {
-    fft_stage_b_twiddles(twB, tb.twiddle);                     // in flight beside the sample loads; first read two barriers from here
-    const int sym = blockIdx.x, tid = threadIdx.x;
-    const long long a0 = (st.rd - st.base) + sym * SYM_N + st.samperr_cur;     // first sample of the symbol in the decimated stream
-    const double dth = st.dtheta;
-    const double th0 = st.theta + (double)sym * SYM_N * dth;
-    if (RAW) {
-        decimate_symbol_raw(st.raw, a0, lds, hb_taps(tb.hb_q15));
-        __syncthreads();
-    }
+#ifndef HIPEMU
+    asm volatile("" : "+s"(p));
+#endif
+    return p;
+}
 
-    // NCO phasor of sample j = tid + 128 q (q = 0..16): one accurate evaluation at q = 0 and one of the
-    // 128-sample step, then a 16-step complex recurrence (error ~1e-6, far inside the float pipeline's own)
-    double a0p = th0 + (double)tid * dth;
-    a0p -= 2 * M_PI * rint(a0p * (1.0 / (2 * M_PI)));
+template <bool RAW, int SPW>
+__device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuffers &db, const StreamState &st, int s, cf *lds, cf *twB)
+{
+    // SPW consecutive symbols of one stream per workgroup: the stage-B twiddles, the half-band taps and the NCO step are set up
+    // once, and symbol n + 1's capture loads (24 dwords per work-item) are in flight while symbol n goes through mix and FFT --
+    // with one symbol per workgroup every workgroup began its life waiting for HBM with nothing else to do (17 % VALU-busy).
+    fft_stage_b_twiddles(twB, tb.twiddle);                     // first read two barriers from here
+    const int sym0 = blockIdx.x * SPW;
+    const long long a00 = (st.rd - st.base) + st.samperr_cur;  // first sample of symbol 0 in the decimated stream
+    const double dth = st.dtheta;
+    const HbTaps taps = hb_taps(tb.hb_q15);
     double a1 = 128.0 * dth;
     a1 -= 2 * M_PI * rint(a1 * (1.0 / (2 * M_PI)));
-    cf ph, stp;
+    cf stp;
     {
-        float sn, cs;
-        fast_sincos_reduced((float)a0p, sn, cs); ph = cf_make(cs, sn);      // both angles were reduced to [-pi, pi] in double above
-        fast_sincos_reduced((float)a1, sn, cs); stp = cf_make(cs, sn);
+        float sn, cs; fast_sincos_reduced((float)a1, sn, cs);
+#ifndef HIPEMU
+        if (SPW > 1) {                                         // the same value in every lane: held in a scalar register pair across the symbol loop
+            sn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sn)));
+            cs = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cs)));
+        }
+#endif
+        stp = cf_make(cs, sn);
     }
-    const c16 *win = db.q15 + (size_t)s * db.q15_cap + a0;     // FIFO path (streaming seam, cs16 input)
+    uint32_t W[24];
+    if (RAW) raw_symbol_load(st.raw, a00 + (long long)sym0 * SYM_N, W, threadIdx.x);
+#pragma unroll 1
+    for (int i = 0; i < SPW; i++) {
+        const int sym = sym0 + i;
+        const long long a0 = a00 + (long long)sym * SYM_N;
+        int tid = threadIdx.x;
+#ifndef HIPEMU
+        if (SPW > 1) asm volatile("" : "+v"(tid));                 // addresses derived from it are recomputed per symbol, not held across the loop
+#endif
+        const float2 *twA = SPW > 1 ? per_symbol(tb.twiddle_a) : tb.twiddle_a;
+        const float *shape = SPW > 1 ? per_symbol(tb.shape) : tb.shape;
+        if (RAW) {
+            raw_symbol_halfband(W, lds, taps, tid);
+            __syncthreads();
+            if (i + 1 < SPW) raw_symbol_load(st.raw, a0 + SYM_N, W, tid);      // the next symbol's samples: needed one FFT from now
+        }
+        // NCO phasor of sample j = tid + 128 q (q = 0..16): one accurate evaluation at q = 0 and one of the
+        // 128-sample step, then a 16-step complex recurrence (error ~1e-6, far inside the float pipeline's own)
+        double a0p = st.theta + (double)sym * SYM_N * dth + (double)tid * dth;
+        a0p -= 2 * M_PI * rint(a0p * (1.0 / (2 * M_PI)));
+        cf ph;
+        { float sn, cs; fast_sincos_reduced((float)a0p, sn, cs); ph = cf_make(cs, sn); }     // reduced to [-pi, pi] in double above
+        const c16 *win = db.q15 + (size_t)s * db.q15_cap + a0;     // FIFO path (streaming seam, cs16 input)
 
-    auto sample = [&](int j) -> cf {
-        if (RAW) return q15_to_cf(lds[j]);                     // the tile holds Q15 integers, conjugated
-        const c16 s16 = win[j];
-        return q15_to_cf(cf_make((float)s16.r, -(float)s16.i));   // cq15_to_cf_conj, defines.h:111 (the quotient is odd in its argument)
-    };
-    cf x[16];
+        auto sample = [&](int j) -> cf {
+            if (RAW) return q15_to_cf(lds[j]);                     // the tile holds Q15 integers, conjugated
+            const c16 s16 = win[j];
+            return q15_to_cf(cf_make((float)s16.r, -(float)s16.i));   // cq15_to_cf_conj, defines.h:111 (the quotient is odd in its argument)
+        };
+        cf x[16];
 #pragma unroll
-    for (int q = 0; q < 16; q++) {
-        const int h = q & 1, n1 = q >> 1;
-        const int j = tid + 128 * q;
-        cf m = cmul(ph, sample(j));
-        if (q == 0 && tid < CP_N) { const float w = tb.shape[tid]; m = emul(m, cf_make(w, w)); }
-        x[8 * h + n1] = m;
-        ph = cmul(ph, stp);
-    }
-    if (tid < CP_N) {                                          // fold the cyclic extension back (acquire.c:246-247)
-        const int j = FFT_N + tid;
-        const cf m = cmul(ph, sample(j));                      // ph = phasor of sample tid + 2048
-        const float w = tb.shape[j];
-        x[0] = cadd(x[0], emul(cf_make(w, w), m));
-    }
-    if (RAW) __syncthreads();                                  // every work-item has its samples: the tile becomes the FFT's
+        for (int q = 0; q < 16; q++) {
+            const int h = q & 1, n1 = q >> 1;
+            const int j = tid + 128 * q;
+            cf m = cmul(ph, sample(j));
+            if (q == 0 && tid < CP_N) { const float w = shape[tid]; m = emul(m, cf_make(w, w)); }
+            x[8 * h + n1] = m;
+            ph = cmul(ph, stp);
+        }
+        if (tid < CP_N) {                                          // fold the cyclic extension back (acquire.c:246-247)
+            const int j = FFT_N + tid;
+            const cf m = cmul(ph, sample(j));                      // ph = phasor of sample tid + 2048
+            const float w = shape[j];
+            x[0] = cadd(x[0], emul(cf_make(w, w), m));
+        }
+        if (RAW) __syncthreads();                                  // every work-item has its samples: the tile becomes the FFT's
 
-    fft2048_wg<true>(x, lds, tb.twiddle_a, twB);
+        fft2048_wg<true>(x, lds, twA, twB);
+        if (SPW > 1) __syncthreads();                              // stage C has read the tile: the next symbol may park its samples there
 
-    // fftshift (bin 1024 = DC) and the live-bin cut: x[4a + b] = bin kbase + 128 (a + 4 b); after the shift the work-item's
-    // six candidates sit at kbase + 128 m', m' = 10, 11, 12 (upper sideband, bins 1304 .. 1570) and 3, 4, 5 (lower, 478 .. 744)
-    // (Gathering the six outputs in the idle LDS tile and storing 534 consecutive values instead -- two more barriers -- was measured:
-    // no gain for the kernel, 34.6 -> 35.3 ms for the pass.)
-    cf *out = (cf *)(db.bins + ((size_t)s * NSYM + sym) * LIVE_N);
-    const int kbase = (tid >> 4) + 8 * (tid & 15);
-    static_assert(LB0 == 478 && UB0 == 1304 && UB1 == 1570 && LIVE_HALF == 267, "the six-output cut below is laid out for these edges");
-    if (kbase >= LB0 - 384) out[kbase + 384 - LB0] = x[14];                    // m' = 3  (X[11])
-    out[kbase + 512 - LB0] = x[3];                                             // m' = 4  (X[12])
-    if (kbase + 640 < LB0 + LIVE_HALF) out[kbase + 640 - LB0] = x[7];          // m' = 5  (X[13])
-    if (kbase + 1280 >= UB0) out[LIVE_HALF + kbase + 1280 - UB0] = x[8];       // m' = 10 (X[2])
-    out[LIVE_HALF + kbase + 1408 - UB0] = x[12];                               // m' = 11 (X[3])
-    if (kbase + 1536 <= UB1) out[LIVE_HALF + kbase + 1536 - UB0] = x[1];       // m' = 12 (X[4])
+        // fftshift (bin 1024 = DC) and the live-bin cut: x[4a + b] = bin kbase + 128 (a + 4 b); after the shift the work-item's
+        // six candidates sit at kbase + 128 m', m' = 10, 11, 12 (upper sideband, bins 1304 .. 1570) and 3, 4, 5 (lower, 478 .. 744)
+        // (Gathering the six outputs in the idle LDS tile and storing 534 consecutive values instead -- two more barriers -- was measured:
+        // no gain for the kernel, 34.6 -> 35.3 ms for the pass.)
+        cf *out = (cf *)(db.bins + ((size_t)s * NSYM + sym) * LIVE_N);
+        const int kbase = (tid >> 4) + 8 * (tid & 15);
+        static_assert(LB0 == 478 && UB0 == 1304 && UB1 == 1570 && LIVE_HALF == 267, "the six-output cut below is laid out for these edges");
+        if (kbase >= LB0 - 384) out[kbase + 384 - LB0] = x[14];                    // m' = 3  (X[11])
+        out[kbase + 512 - LB0] = x[3];                                             // m' = 4  (X[12])
+        if (kbase + 640 < LB0 + LIVE_HALF) out[kbase + 640 - LB0] = x[7];          // m' = 5  (X[13])
+        if (kbase + 1280 >= UB0) out[LIVE_HALF + kbase + 1280 - UB0] = x[8];       // m' = 10 (X[2])
+        out[LIVE_HALF + kbase + 1408 - UB0] = x[12];                               // m' = 11 (X[3])
+        if (kbase + 1536 <= UB1) out[LIVE_HALF + kbase + 1536 - UB0] = x[1];       // m' = 12 (X[4])
+    }
 }
 
 // (Held to 96 VGPRs for a fifth wave per SIMD -- amdgpu_waves_per_eu(5, 5), 7 dwords spilled -- the kernel was measured SLOWER,
 // 17.2 vs 16.1 ms per pass, and the decode waves beside it lose their room: k_p1_forward 12 -> 21 ms of device time.)
-__global__ __launch_bounds__(128) void k_mixfft(DevTables tb, DevBuffers db, const int *ids)
+#ifndef HIPEMU
+#define MIXFFT_OCCUPANCY __attribute__((amdgpu_waves_per_eu(4, 4)))     // 128 VGPRs: four waves per SIMD, eight workgroups per CU (the LDS limit)
+#else
+#define MIXFFT_OCCUPANCY
+#endif
+template <int SPW>
+__global__ __launch_bounds__(128) MIXFFT_OCCUPANCY void k_mixfft(DevTables tb, DevBuffers db, const int *ids)
 {
     wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
     const int s = stream_of(ids, blockIdx.y);
@@ -355,14 +402,25 @@ __global__ __launch_bounds__(128) void k_mixfft(DevTables tb, DevBuffers db, con
     __shared__ cf lds[8 * PITCH_A];
     static_assert(sizeof(cf) == sizeof(float2), "a complex value is two floats either way");
     static_assert(8 * PITCH_A >= 17 * 128 && 17 * 127 < SYM_N, "17 decimated samples per work-item fit in the FFT tile");
+    static_assert(NSYM % SPW == 0, "whole workgroups per block");
     __shared__ cf twB[256];
-    if (st.raw) mixfft_symbol<true>(tb, db, st, s, lds, twB);
-    else mixfft_symbol<false>(tb, db, st, s, lds, twB);
+    if (st.raw) mixfft_symbols<true, SPW>(tb, db, st, s, lds, twB);
+    else mixfft_symbols<false, SPW>(tb, db, st, s, lds, twB);
 }
 
-void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st)
+// Symbols per workgroup (nrsc5hip_debug_tune NRSC5HIP_TUNE_MIXFFT_SYMS).  The persistent forms -- 2 / 4 / 8 symbols per workgroup, the
+// next symbol's 24 capture dwords in flight during the current FFT, 128 VGPRs without a spill, 4 -> one round of 8 workgroups per CU
+// at 256 streams -- were MEASURED SLOWER than one symbol per workgroup (profiles/r04_mixfft_persistent.txt: 74 vs 63 us per launch,
+// pass 36.0 vs 33.0 ms): the stage-A twiddle loads, which the one-symbol kernel issues at its very start beside the capture loads,
+// cannot be held across the loop (28 VGPRs) and are exposed once per symbol behind a barrier.  Default: 1.
+void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int syms_per_wg)
 {
-    hipLaunchKernelGGL(k_mixfft, dim3(NSYM, nstreams), dim3(128), 0, st, tb, db, stream_ids);
+    switch (syms_per_wg) {
+    case 2: hipLaunchKernelGGL(k_mixfft<2>, dim3(NSYM / 2, nstreams), dim3(128), 0, st, tb, db, stream_ids); break;
+    case 4: hipLaunchKernelGGL(k_mixfft<4>, dim3(NSYM / 4, nstreams), dim3(128), 0, st, tb, db, stream_ids); break;
+    case 8: hipLaunchKernelGGL(k_mixfft<8>, dim3(NSYM / 8, nstreams), dim3(128), 0, st, tb, db, stream_ids); break;
+    default: hipLaunchKernelGGL(k_mixfft<1>, dim3(NSYM, nstreams), dim3(128), 0, st, tb, db, stream_ids); break;
+    }
 }
 
 // ---- stage-level entry: plain 2048-point FFTs, natural order in and out (parity tests) ----------------

@@ -140,11 +140,12 @@ def test_gpu_poisoned_results_are_rewritten(hip_lib):
         recs, counts, frames = E.batch_fetch_view(1)
         r = recs[0, :counts[0]]
         fr = [frames[0, int(x["p1_slot"])].copy() for x in r if int(x["flags"]) & eng.REC_P1]
-        assert len(fr) == 1 and not (fr[0] == 0xA5A5A5A5).any()
-        got.append(fr[0])
+        assert len(fr) >= 1 and not any((f == 0xA5A5A5A5).any() for f in fr)
+        got.append(fr)
         E.poison_results()
         assert (frames[0] == 0xA5A5A5A5).all()                  # the view IS the pinned mirror
-    assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], np.packbits(cap.p1_frames[1], bitorder="little").view(np.uint32))
+    truth = {np.packbits(f, bitorder="little").tobytes() for f in cap.p1_frames}
+    assert len(got[0]) == len(got[1]) and all(np.array_equal(a, b) and a.tobytes() in truth for a, b in zip(got[0], got[1]))
     ec._free_device(E, dev)
     E.close()
 
