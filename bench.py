@@ -783,7 +783,7 @@ def dropin_leg(iq: np.ndarray, fs: float):
         best, wall = None, None
         for rep in range(3 if name == "dropin" else 2):
             p = ctypes.c_void_p()
-            hip.nrsc5hip_debug_seam_totals(None, 1)
+            hip.nrsc5hip_debug_seam_totals(None, 1); hip.nrsc5hip_debug_seam_counts(None, 1)
             t0 = time.perf_counter()
             n = lib.pipe_run(iq.ctypes.data, iq.size, 32768, 0, 0, ctypes.byref(p))
             w = time.perf_counter() - t0
@@ -794,9 +794,13 @@ def dropin_leg(iq: np.ndarray, fs: float):
                     tot = (ctypes.c_double * 8)()
                     hip.nrsc5hip_debug_seam_totals(tot, 0)
                     blocks = max(tot[6], 1.0)
+                    cnt = (ctypes.c_double * 4)()
+                    hip.nrsc5hip_debug_seam_counts(cnt, 0)
                     out["breakdown"] = {"blocks": int(tot[6]), "pushes": int(tot[4]), "submissions_h2d_plus_decimator": int(tot[5]),
+                                        "block_steps_left_in_flight_deferred_wait": int(cnt[0]), "read_positions_mispredicted": int(cnt[1]),
+                                        "block_steps_without_p1_decode_launches": int(cnt[2]), "p1_decodes_launched_late": int(cnt[3]),
                                         "us_per_block": {"host_copy_into_pinned_staging": round(tot[0] / blocks * 1e6, 1), "host_enqueue_h2d_and_decimator": round(tot[1] / blocks * 1e6, 1),
-                                                         "host_enqueue_block_step": round(tot[2] / blocks * 1e6, 1), "wait_for_device_one_sync_per_block": round(tot[3] / blocks * 1e6, 1),
+                                                         "host_enqueue_block_step": round(tot[2] / blocks * 1e6, 1), "wait_for_device": round(tot[3] / blocks * 1e6, 1),
                                                          "fetch_p1_frames": round(tot[7] / blocks * 1e6, 1),
                                                          "reference_host_code_L2_and_callbacks_and_rest": round((f - tot[0] - tot[1] - tot[2] - tot[3] - tot[7]) / blocks * 1e6, 1)},
                                         "total_us_per_block": round(f / blocks * 1e6, 1)}

@@ -175,6 +175,21 @@ int nrsc5hip_force_resync(nrsc5hip_engine *e, int stream);
  * frames of one block reach L2 before the next block is processed -- the reference's event order for any push size.  -1: not
  * known (p1_async engines, or a stream that the batch entry points touched since its reset): push <= 17280 bytes per call. */
 long long nrsc5hip_bytes_to_next_block(nrsc5hip_engine *e, int stream, int cu8);
+/* Deferred wait (p1_async = 0).  A block that starts in SYNC_FINE consumes a number of samples the host can compute from the
+ * previous block's record (keep = 2160 - next_samperr, acquire.c:112,259), so the push that completes such a block returns with
+ * the block step still running: the device works on block n while the caller reads and pushes the samples of block n + 1.
+ * nrsc5hip_bytes_to_next_block stays exact.  Every other entry point (nrsc5hip_drain first of all) waits for the step before it
+ * does anything, so a caller that never heard of this sees the old behaviour; a caller that wants the overlap polls with
+ * nrsc5hip_drain_ready, which hands out what has been reported so far and never waits.
+ *
+ * Manual stepping lets the L2 feedback of block n (frame.c -> nrsc5hip_force_resync) reach the engine before block n + 1 is
+ * STEPPED while the samples of block n + 1 are already on their way into the FIFO: with it set, a push that completes a block
+ * submits the samples (H2D + decimator) and returns; the caller then drains block n (nrsc5hip_drain, waits), feeds L2, and calls
+ * nrsc5hip_stream_step.  integration/input_hip.c does exactly that.  (A push that finds an unstepped complete block steps it
+ * itself: forgetting the call costs speed, never samples.) */
+int nrsc5hip_drain_ready(nrsc5hip_engine *e, int stream, nrsc5hip_record *out, int max, int *n_out);
+int nrsc5hip_stream_set_manual_step(nrsc5hip_engine *e, int stream, int on);
+int nrsc5hip_stream_step(nrsc5hip_engine *e, int stream);
 
 /* ---- batch path (device buffers) ------------------------------------------------------------------ */
 /* Decimate + append one cu8 chunk per listed stream.  dev_iq: device pointer, chunk k at
@@ -353,11 +368,16 @@ enum {
     , NRSC5HIP_TUNE_DECODE_PRIORITY        /* 1: decode streams at the lowest queue priority (default 0: all queues equal) */
     , NRSC5HIP_TUNE_AM_WARM                /* TEST HOOK: 0 = no forward warm-up and no traceback run-in (every boundary takes the repair path); 1 = normal */
     , NRSC5HIP_TUNE_MIXFFT_SYMS            /* OFDM symbols per k_mixfft workgroup: 1 (default), 2, 4, 8 -- any value gives identical bins */
+    , NRSC5HIP_TUNE_DEFER_WAIT             /* fast streaming seam: 1 (default) = a block step whose FIFO consumption the host can compute in advance stays in
+                                             flight when the push returns; 0 = every step is waited for at once (round 3's behaviour) */
 };
 /* process-wide wall-clock totals of the streaming seam with p1_async = 0 (what the drop-in uses): [0] s copying pushes into pinned
  * staging, [1] s enqueueing H2D + decimator, [2] s enqueueing block steps, [3] s waiting for the device (one sync per block),
  * [4] pushes, [5] submissions, [6] block steps, [7] s fetching P1 frames */
 void nrsc5hip_debug_seam_totals(double out[8], int reset);   /* totals of the CALLING THREAD's sessions */
+/* ... [0] block steps left in flight (deferred wait), [1] read positions the host predicted wrongly (expected: 0), [2] steps submitted
+ * without the P1 decode launches (no frame could complete), [3] P1 decodes launched after the fact (expected: 0) */
+void nrsc5hip_debug_seam_counts(double out[4], int reset);
 /* test / bench hygiene: overwrite every result buffer a pass writes (frame rings on the device and their pinned host mirror, record
  * rings) with a pattern no decode produces -- a check after the next pass can then only pass on bits written by that pass */
 int nrsc5hip_debug_poison_results(nrsc5hip_engine *e);

@@ -47,7 +47,10 @@ static void fail(input_t *st, const char *what)
     st->acq.fftout = (void *)st;
 }
 
-static void deliver(input_t *st)
+/* wait = 1: every block the engine has been given is delivered (nrsc5hip_drain waits for a block step that is still running);
+ * wait = 0: only what has been reported so far (nrsc5hip_drain_ready) -- the device keeps working on block n while the caller
+ * fetches and pushes the samples of block n + 1. */
+static void deliver(input_t *st, int wait)
 {
     /* frame bits as frame_push takes them: the session's own descrambler buffer (decode.h, P1_FRAME_LEN_FM bytes, unused
      * here because descrambling happens on the device) -- per session, so concurrent sessions of one process do not share it */
@@ -58,7 +61,7 @@ static void deliver(input_t *st)
 
     do
     {
-        if (nrsc5hip_drain(ENGINE(st), 0, rec, 64, &n) != 0) { fail(st, "drain"); return; }
+        if ((wait ? nrsc5hip_drain(ENGINE(st), 0, rec, 64, &n) : nrsc5hip_drain_ready(ENGINE(st), 0, rec, 64, &n)) != 0) { fail(st, "drain"); return; }
         for (int k = 0; k < n; k++)
         {
             const nrsc5hip_record *r = &rec[k];
@@ -122,41 +125,59 @@ static void deliver(input_t *st)
     } while (n == 64);
 }
 
-/* Feed the engine up to the end of the next block, deliver that block's events (frame_push may answer with
- * input_set_sync_state(NONE)), then go on: the L2 feedback of a frame reaches the engine before the next block, exactly as in
- * the reference (FINE -> NONE only comes from frame_process), for any push size. */
-static uint32_t next_piece(input_t *st, uint32_t left, int cu8)
+/* Feed the engine up to the end of the next block, deliver the events of the block before it (frame_push may answer with
+ * input_set_sync_state(NONE)), step, go on: the L2 feedback of a frame reaches the engine before the next block is PROCESSED,
+ * exactly as in the reference (FINE -> NONE only comes from frame_process), for any push size -- while the samples of
+ * that next block are already being copied and decimated, and while the device is still busy with the block the previous call
+ * submitted (deferred wait, include/nrsc5hip.h).  Events of a block therefore reach the application during the first call after
+ * the device has finished it -- at the latest in the call that completes the following block, in a zero-length
+ * nrsc5_pipe_samples_* call (a flush), or at input_free / input_reset;
+ * NRSC5HIP_SYNC_DELIVERY=1 in the environment restores delivery inside the completing call (and the waiting that goes with it). */
+static int sync_delivery(void)
 {
-    long long room = nrsc5hip_bytes_to_next_block(ENGINE(st), 0, cu8);
-    if (room < 0) room = 4 * 4320;                              /* engine cannot tell: two OFDM symbols never complete two blocks */
-    return left < (uint32_t)room ? left : (uint32_t)room;
+    static int v = -1;
+    if (v < 0) { const char *e = getenv("NRSC5HIP_SYNC_DELIVERY"); v = (e && atoi(e) > 0) ? 1 : 0; }
+    return v;
+}
+
+static void push_pieces(input_t *st, const uint8_t *buf, uint32_t nbytes, int cu8)
+{
+    uint32_t consumed = 0;
+    if (nbytes == 0 && !FAILED(st)) deliver(st, 1);             /* nrsc5_pipe_samples_*(radio, buf, 0): flush -- every pending event, now */
+    while (consumed < nbytes && !FAILED(st))
+    {
+        long long room = nrsc5hip_bytes_to_next_block(ENGINE(st), 0, cu8);
+        const int known = room >= 0;
+        if (!known) room = 4 * 4320;                            /* engine cannot tell: two OFDM symbols never complete two blocks */
+        const uint32_t left = nbytes - consumed;
+        const uint32_t piece = left < (uint32_t)room ? left : (uint32_t)room;
+        const int completes = known && (long long)piece >= room;
+        int rc = cu8 ? nrsc5hip_push_cu8(ENGINE(st), 0, buf + consumed, piece) : nrsc5hip_push_cs16(ENGINE(st), 0, (const int16_t *)(buf + consumed), piece / 2);
+        if (rc != 0) { fail(st, cu8 ? "push_cu8" : "push_cs16"); return; }
+        consumed += piece;
+        if (completes)
+        {
+            deliver(st, 1);                                     /* the block before: its frames reach frame.c now ... */
+            if (FAILED(st)) return;
+            if (nrsc5hip_stream_step(ENGINE(st), 0) != 0) { fail(st, "stream_step"); return; }   /* ... and only then is this one processed */
+            deliver(st, sync_delivery());
+        }
+        else
+            deliver(st, known ? 0 : 1);
+    }
 }
 
 void input_push_cu8(input_t *st, const uint8_t *buf, const uint32_t len)
 {
     nrsc5_report_iq(st->radio, buf, len);
     assert(len % 4 == 0);
-    uint32_t consumed = 0;
-    while (consumed < len && !FAILED(st))
-    {
-        const uint32_t piece = next_piece(st, len - consumed, 1);
-        if (nrsc5hip_push_cu8(ENGINE(st), 0, buf + consumed, piece) != 0) { fail(st, "push_cu8"); return; }
-        deliver(st);
-        consumed += piece;
-    }
+    push_pieces(st, buf, len, 1);
 }
 
 void input_push_cs16(input_t *st, const int16_t *buf, const uint32_t len)
 {
     assert(len % 2 == 0);
-    uint32_t consumed = 0;                                      /* int16 values */
-    while (consumed < len && !FAILED(st))
-    {
-        const uint32_t piece = next_piece(st, (len - consumed) * 2, 0) / 2;
-        if (nrsc5hip_push_cs16(ENGINE(st), 0, buf + consumed, piece) != 0) { fail(st, "push_cs16"); return; }
-        deliver(st);
-        consumed += piece;
-    }
+    push_pieces(st, (const uint8_t *)buf, len * 2, 0);
 }
 
 void input_set_sync_state(input_t *st, unsigned int new_state)
@@ -172,6 +193,7 @@ void input_set_sync_state(input_t *st, unsigned int new_state)
 
 void input_reset(input_t *st)
 {
+    if (ENGINE(st) && !FAILED(st)) deliver(st, 1);              /* a block still in flight belongs to the session that ends here */
     input_set_sync_state(st, SYNC_STATE_NONE);
     if (ENGINE(st) && !FAILED(st) && nrsc5hip_stream_reset(ENGINE(st), 0) != 0) fail(st, "stream_reset");
     pids_init(&st->decode.pids, st);
@@ -190,6 +212,7 @@ void input_init(input_t *st, nrsc5_t *radio, output_t *output)
     st->output = output;
     st->sync_state = SYNC_STATE_NONE;
     if (nrsc5hip_engine_create(&cfg, &e) != 0) { e = NULL; fail(st, "engine_create"); }
+    else if (nrsc5hip_stream_set_manual_step(e, 0, 1) != 0) fail(st, "stream_set_manual_step");
     st->acq.fftin = (void *)e;
     st->decode.input = st;
     frame_init(&st->frame, st);
@@ -205,6 +228,7 @@ void input_set_mode(input_t *st)
 
 void input_free(input_t *st)
 {
+    if (ENGINE(st) && !FAILED(st)) deliver(st, 1);              /* the last block's events */
     frame_free(&st->frame);
     nrsc5hip_engine_destroy(ENGINE(st));
     st->acq.fftin = NULL;

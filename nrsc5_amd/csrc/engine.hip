@@ -26,8 +26,10 @@ static thread_local char g_err[512] = "";
 
 // wall-clock totals of the fast streaming seam of the CALLING THREAD's sessions (nrsc5hip_debug_seam_totals): where a drop-in
 // session's time goes.  Thread-local: sessions driven from different threads never share a counter.
-static thread_local double g_seam[8];   // [0] s copying pushes into pinned staging, [1] s enqueueing H2D + decimator, [2] s enqueueing block steps,
-                           // [3] s waiting for the device (the one sync per block), [4] pushes, [5] submissions, [6] block steps, [7] s in drain / frame fetches
+static thread_local double g_seam[12];  // [0] s copying pushes into pinned staging, [1] s enqueueing H2D + decimator, [2] s enqueueing block steps,
+                           // [3] s waiting for the device (the one sync per block), [4] pushes, [5] submissions, [6] block steps, [7] s in drain / frame fetches,
+                           // [8] block steps whose wait was deferred, [9] read positions mispredicted, [10] steps without the P1 decode launches,
+                           // [11] P1 decodes launched after the fact (the prediction said no frame could complete)
 struct SeamClock {
     int slot; std::chrono::steady_clock::time_point t0;
     explicit SeamClock(int s) : slot(s), t0(std::chrono::steady_clock::now()) {}
@@ -37,11 +39,18 @@ extern "C" void nrsc5hip_debug_seam_totals(double out[8], int reset)
 {
     for (int k = 0; k < 8; k++) { if (out) out[k] = g_seam[k]; if (reset) g_seam[k] = 0; }
 }
+extern "C" void nrsc5hip_debug_seam_counts(double out[4], int reset)
+{
+    for (int k = 0; k < 4; k++) { if (out) out[k] = g_seam[8 + k]; if (reset) g_seam[8 + k] = 0; }
+}
 extern "C" const char *nrsc5hip_last_error(void) { return g_err; }
 #ifndef NRSC5HIP_SOURCE_SHA
 #define NRSC5HIP_SOURCE_SHA "unknown"
 #endif
-extern "C" const char *nrsc5hip_source_sha(void) { return NRSC5HIP_SOURCE_SHA; }
+// the fingerprint behind a marker, so that a build can be identified from the FILE (nrsc5_amd.engine.check_fresh reads the bytes:
+// a library that is already mapped into the process keeps answering for the old build after the file has been replaced)
+static const char g_source_sha_marker[] = "NRSC5HIP_SOURCE_SHA=" NRSC5HIP_SOURCE_SHA;
+extern "C" const char *nrsc5hip_source_sha(void) { return g_source_sha_marker + 20; }
 
 #define HIPCHK(expr)                                                                                   \
     do {                                                                                               \
@@ -60,7 +69,11 @@ struct DeviceGuard {
     explicit DeviceGuard(int dev) : want(dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != want) (void)hipSetDevice(want); }
     ~DeviceGuard() { if (prev >= 0 && prev != want) (void)hipSetDevice(prev); }
 };
-#define ON_ENGINE_DEVICE(e) DeviceGuard _device_guard((e) ? (e)->cfg.device : 0); if (!(e)) FAIL(NRSC5HIP_EINVAL, "null engine")
+#define ON_ENGINE_DEVICE_FAST(e) DeviceGuard _device_guard((e) ? (e)->cfg.device : 0); if (!(e)) FAIL(NRSC5HIP_EINVAL, "null engine")
+// ... and, for every entry but the fast streaming seam's own, with no block step in flight (deferred wait, see nrsc5hip_engine)
+#define ON_ENGINE_DEVICE(e) ON_ENGINE_DEVICE_FAST(e); do { int _rc = settle(e); if (_rc) return _rc; } while (0)
+struct nrsc5hip_engine;
+static int settle(nrsc5hip_engine *e);
 
 struct nrsc5hip_engine {
     nrsc5hip_config cfg;
@@ -103,7 +116,7 @@ struct nrsc5hip_engine {
     // block costs one host memcpy into pinned memory, one async H2D and the K1 launch -- no synchronisation at all -- and a
     // push that does complete one ends with ONE sync, after a report kernel has posted the counters, the new read position and
     // the block's record straight into pinned host memory.
-    struct StreamReport { int counters[4]; long long rd; int nblocks; int nrec; BlockRecord rec[4]; };
+    struct StreamReport { int counters[4]; long long rd; int nblocks; int nrec; BlockRecord rec[4]; unsigned seq; unsigned pad; };
     uint8_t *stage_pin[2], *stage_dev2[2]; hipEvent_t stage_ev[2]; bool stage_busy[2]; int stage_slot;
     // samples accepted by a push but not submitted yet: they wait in stage_pin[stage_slot] until the mirror says a block completes
     // (or the buffer is full, or anything else looks at the stream) -- one H2D + one decimator launch per BLOCK, not per push
@@ -113,6 +126,20 @@ struct nrsc5hip_engine {
     std::vector<int> fetched;                  // records of the stream copied to `pending` so far (absolute index)
     std::vector<char> mirror_ok;               // rd_host / pending are exact: only the streaming seam touched the stream since its reset
     std::vector<std::deque<BlockRecord>> pending;   // records reported but not yet drained
+    // Deferred wait (round 4).  A block that starts in FINE consumes a number of samples the host can compute in advance
+    // (keep = 2160 - the timing feedback of the previous block, acquire.c:112,259; both are in that block's record), so the mirror
+    // is advanced at SUBMISSION and the wait for the step's report moves to the next call that needs its results: the device works
+    // on block n while the host copies the pushes of block n + 1 into staging.  At most one step per engine is in flight.
+    int inflight_stream;               // stream whose block step is submitted but not harvested (-1: none)
+    unsigned report_seq;               // sequence number the most recently launched report kernel posts when it is done
+    long long inflight_rd_pred;        // the read position predicted for the step in flight (-1: no prediction, the mirror waits)
+    bool inflight_decoded;             // the step in flight carried the P1 de-interleave / trellis / traceback launches
+    bool inflight_progress;            // the last harvested step processed (or left pending) a block
+    bool defer_wait;                   // 1 (default): predictable steps stay in flight; 0 (NRSC5HIP_TUNE_DEFER_WAIT): every step is waited for at once
+    bool counters_clean;               // the step counters are zero: the last kernel that touched them was a report kernel
+    std::vector<char> pred_ok;         // the stream's last harvested record left it FINE and nothing else touched it since
+    std::vector<int> pred_samperr, pred_bc;    // ... that record's next_samperr and block count
+    std::vector<char> manual_step;     // nrsc5hip_stream_set_manual_step: pushes stage and submit samples, the caller steps
     // staging
     uint8_t *stage_dev; size_t stage_bytes;
     int *ids_dev; unsigned *nbytes_dev;
@@ -533,6 +560,9 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         e->wr_host.assign(S, 0); e->base_host.assign(S, 0); e->drained.assign(S, 0);
         e->mode_host.assign(S, MODE_FM); e->raw_host.assign(S, 0); e->attached.assign(S, 0);
         e->rd_host.assign(S, 0); e->fetched.assign(S, 0); e->mirror_ok.assign(S, cfg->p1_async ? 0 : 1); e->pending.assign(S, {});
+        e->pred_ok.assign(S, 0); e->pred_samperr.assign(S, 0); e->pred_bc.assign(S, 0); e->manual_step.assign(S, 0);
+        e->inflight_stream = -1; e->report_seq = 0; e->inflight_rd_pred = -1; e->inflight_decoded = true; e->inflight_progress = false;
+        e->defer_wait = true; e->counters_clean = false;
         e->lane.db = db; e->lane.counters_dev = db.counters;
         e->prof_on = false; e->prof_only = -1;
         for (int k = 0; k < NRSC5HIP_PROF_CLASSES; k++) { e->prof_ms[k] = 0; e->prof_launches[k] = 0; }
@@ -622,7 +652,17 @@ static int launch_window_decode(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, i
     return 0;
 }
 
-static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const int *ids_dev)
+// in-order mode: the P1 frames the step's blocks completed (the kernels leave at once for a stream without one)
+static int launch_inorder_p1(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const int *ids_dev)
+{
+    { ProfScope p(e, NRSC5HIP_PROF_P1_DEINT, ln.main); launch_p1_deint(e->tb, ln.db, n, ids_dev, 0, 0, ln.main); }
+    { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ln.main); launch_p1_forward(e->tb, ln.db, n, ids_dev, 0, 0, ln.main, fwd_segments_for(e, ln, n), e->fwd_warm); }
+    { ProfScope p(e, NRSC5HIP_PROF_P1_TRACEBACK, ln.main); launch_p1_traceback(e->tb, ln.db, n, ids_dev, 0, 0, ln.main, e->cfg.l2_feedback ? 1 : 0, fwd_segments_for(e, ln, n)); }
+    return 0;
+}
+
+// decode_p1 = false (fast streaming seam only): the caller KNOWS that no listed stream can complete a P1 frame in this step
+static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const int *ids_dev, bool decode_p1 = true)
 {
     const bool async = e->cfg.p1_async != 0;
     const long long window = ln.step_count / 16;
@@ -654,9 +694,7 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
     if (!async) {
         { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_pids_decode(e->tb, ln.db, n, ids_dev, parity, 1, ln.main); }
         if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_px_decode(e->tb, ln.db, n, ids_dev, parity, 0, ln.main); }
-        { ProfScope p(e, NRSC5HIP_PROF_P1_DEINT, ln.main); launch_p1_deint(e->tb, ln.db, n, ids_dev, parity, 0, ln.main); }
-        { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ln.main); launch_p1_forward(e->tb, ln.db, n, ids_dev, parity, 0, ln.main, fwd_segments_for(e, ln, n), e->fwd_warm); }
-        { ProfScope p(e, NRSC5HIP_PROF_P1_TRACEBACK, ln.main); launch_p1_traceback(e->tb, ln.db, n, ids_dev, parity, 0, ln.main, e->cfg.l2_feedback ? 1 : 0, fwd_segments_for(e, ln, n)); }
+        if (decode_p1) { int rc = launch_inorder_p1(e, ln, n, ids_dev); if (rc) return rc; }
     } else if ((ln.step_count % 16) == 15) {
         int rc = launch_window_decode(e, ln, n, ids_dev, parity, pick_decode_lane(e, ln, window)); if (rc) return rc;
     }
@@ -857,8 +895,9 @@ static int ensure_space(nrsc5hip_engine *e, int s, long long incoming)
 
 // ---- streaming seam ---------------------------------------------------------------------------------------
 // posts what the host needs after a block step of ONE stream into pinned host memory: the step's counters, the FIFO read position
-// and the records [first_rec, nblocks) (in-order mode: a block's record is final when its step ends)
-__global__ void k_stream_report(DevBuffers db, int s, int first_rec, nrsc5hip_engine::StreamReport *out)
+// and the records [first_rec, nblocks) (in-order mode: a block's record is final when its step ends) -- and, last of all, the
+// sequence number the host is waiting for.  Leaves the step counters at zero for the next step (no memset per block).
+__global__ void k_stream_report(DevBuffers db, int s, int first_rec, nrsc5hip_engine::StreamReport *out, unsigned seq)
 {
     const StreamState &st = db.state[s];
     const int n = min(max(st.nblocks - first_rec, 0), 4);
@@ -868,15 +907,90 @@ __global__ void k_stream_report(DevBuffers db, int s, int first_rec, nrsc5hip_en
         const int k = t / RW, w = t % RW;
         ((uint32_t *)&out->rec[k])[w] = ((const uint32_t *)&db.records[(size_t)s * db.rec_cap + ((first_rec + k) % db.rec_cap)])[w];
     }
-    if (t < 4) out->counters[t] = db.counters[t];
+    if (t < 4) { out->counters[t] = db.counters[t]; db.counters[t] = 0; }
     if (t == 0) { out->rd = st.rd; out->nblocks = st.nblocks; out->nrec = n; }
     __threadfence_system();
+    __syncthreads();
+    if (t == 0) { *(volatile unsigned *)&out->seq = seq; __threadfence_system(); }
 }
 
 static int window_of(const nrsc5hip_engine *e, int s) { return e->mode_host[s] == MODE_AM ? AM_WIN : WIN_N; }
 
-// Fast seam: block steps of one stream while the host mirror says a window is complete; one sync per step.
-static int stream_steps(nrsc5hip_engine *e, int s)
+static void forget_prediction(nrsc5hip_engine *e, int s) { e->pred_ok[s] = 0; }
+
+// Wait for the report with sequence number `seq`: the kernel's last store is that number into mapped pinned memory, so the
+// host spins on it (a stream synchronisation returns ~5-10 us after the kernel has ended); bounded, then the ordinary wait.
+static int wait_report(nrsc5hip_engine *e, unsigned seq, bool block)
+{
+    const volatile unsigned *p = &e->report_host->seq;
+    if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == seq) return 1;
+    if (!block) return 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (int spins = 0;; spins++) {
+        if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == seq) return 1;
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#endif
+        if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+    }
+    HIPCHK(hipStreamSynchronize(e->lane.main));
+    if (__atomic_load_n(p, __ATOMIC_ACQUIRE) != seq) FAIL(NRSC5HIP_EHIP, "stream report %u never arrived (have %u)", seq, *p);
+    return 1;
+}
+
+static int launch_report(nrsc5hip_engine *e, int s)
+{
+    e->report_seq++;
+    if (e->report_seq == 0) e->report_seq = 1;                 // 0 = the freshly cleared report
+    hipLaunchKernelGGL(k_stream_report, dim3(1), dim3(128), 0, e->lane.main, e->lane.db, s, e->fetched[s], e->report_dev, e->report_seq);
+    e->counters_clean = true;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// Take the report of the step in flight (if any).  block = false: only if it has arrived.  Returns < 0 on error.
+static int harvest(nrsc5hip_engine *e, bool block)
+{
+    const int s = e->inflight_stream;
+    if (s < 0) return 0;
+    nrsc5hip_engine::Lane &ln = e->lane;
+    {
+        const auto t_wait = std::chrono::steady_clock::now();
+        const int got = wait_report(e, e->report_seq, block);
+        if (got < 0) return got;
+        if (!got) return 0;
+        if (block) g_seam[3] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count();
+    }
+    e->inflight_stream = -1;
+    const nrsc5hip_engine::StreamReport *rp = e->report_host;
+    bool p1_missing = false;
+    for (int k = 0; k < rp->nrec; k++) if ((rp->rec[k].flags & REC_P1) && e->mode_host[s] != MODE_AM && !e->inflight_decoded) p1_missing = true;
+    if (p1_missing) {
+        // the prediction said no P1 frame could complete in this block and one did: decode it now, take the record again
+        g_seam[11] += 1;
+        int rc = launch_inorder_p1(e, ln, 1, e->all_ids_dev + s); if (rc) return rc;
+        if ((rc = launch_report(e, s))) return rc;
+        if ((rc = wait_report(e, e->report_seq, true)) < 0) return rc;
+    }
+    ln.acq_needed = rp->counters[1] > 0;
+    ln.px_needed = rp->counters[2] > 0;
+    if (e->inflight_rd_pred >= 0 && e->inflight_rd_pred != rp->rd) g_seam[9] += 1;      // never seen; the mirror is put right below
+    e->rd_host[s] = rp->rd;
+    for (int k = 0; k < rp->nrec; k++) e->pending[s].push_back(rp->rec[k]);
+    e->fetched[s] += rp->nrec;
+    if (rp->nblocks != e->fetched[s]) FAIL(NRSC5HIP_EOVERFLOW, "stream %d: %d records behind the report", s, rp->nblocks - e->fetched[s]);
+    if (rp->nrec > 0) {
+        const BlockRecord &r = rp->rec[rp->nrec - 1];
+        e->pred_ok[s] = (r.state_after == SYNC_FINE && !(r.flags & REC_LOST_SYNC)) ? 1 : 0;
+        e->pred_samperr[s] = r.next_samperr; e->pred_bc[s] = r.bc;
+    }
+    e->inflight_progress = rp->counters[0] != 0;
+    if (e->prof_on) { HIPCHK(hipStreamSynchronize(ln.main)); prof_collect(e); }
+    return 0;
+}
+
+// Submit one block step of stream s (its window is complete by the mirror) and the report kernel behind it.
+static int submit_step(nrsc5hip_engine *e, int s)
 {
     nrsc5hip_engine::Lane &ln = e->lane;
     const int *ids_dev = e->all_ids_dev + s;                   // identity list: entry s is s
@@ -884,36 +998,52 @@ static int stream_steps(nrsc5hip_engine *e, int s)
     const unsigned long long sig = set_signature(1, &s);
     if (sig != ln.set_sig) { ln.acq_needed = true; ln.px_needed = true; ln.set_sig = sig; }
     ln.prepared_by_sync = false;
-    int guard = 0;
-    while (e->wr_host[s] - e->rd_host[s] >= window_of(e, s)) {
-        auto t_enq = std::chrono::steady_clock::now();
-        HIPCHK(hipMemsetAsync(ln.counters_dev, 0, 4 * sizeof(int), ln.main));
-        if (am) {
-            ProfScope p(e, NRSC5HIP_PROF_AM, ln.main);
-            launch_am_step(e->tb, ln.db, 1, ids_dev, ln.main, e->cfg.l2_feedback, -1, (int)(ln.am_step_count % 8), (int)(ln.am_step_count / 8));
-            ln.am_step_count++;
-        } else {
-            int rc = issue_step(e, ln, 1, ids_dev); if (rc) return rc;
-        }
-        hipLaunchKernelGGL(k_stream_report, dim3(1), dim3(128), 0, ln.main, ln.db, s, e->fetched[s], e->report_dev);
-        HIPCHK(hipGetLastError());
-        auto t_wait = std::chrono::steady_clock::now();
-        HIPCHK(hipStreamSynchronize(ln.main));
-        g_seam[2] += std::chrono::duration<double>(t_wait - t_enq).count();
-        g_seam[3] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count();
-        g_seam[6] += 1;
-        const nrsc5hip_engine::StreamReport &rp = *e->report_host;
-        ln.acq_needed = rp.counters[1] > 0;
-        ln.px_needed = rp.counters[2] > 0;
-        e->rd_host[s] = rp.rd;
-        for (int k = 0; k < rp.nrec; k++) e->pending[s].push_back(rp.rec[k]);
-        e->fetched[s] += rp.nrec;
-        if (rp.nblocks != e->fetched[s]) FAIL(NRSC5HIP_EOVERFLOW, "stream %d: %d records behind the report", s, rp.nblocks - e->fetched[s]);
-        if (rp.counters[0] == 0 || ++guard > 64) break;        // nothing was processed or is pending
+    const auto t_enq = std::chrono::steady_clock::now();
+    if (!e->counters_clean) HIPCHK(hipMemsetAsync(ln.counters_dev, 0, 4 * sizeof(int), ln.main));
+    // A P1 frame completes only in a block that starts FINE with block count 15 (k_sync: started_pm && bc == 15; a block that
+    // locks restarts the frame): when the stream's last record says otherwise the three decode launches are left out.
+    const bool known = e->pred_ok[s] && !e->cfg.l2_feedback;
+    bool decode = true;
+    if (am) {
+        ProfScope p(e, NRSC5HIP_PROF_AM, ln.main);
+        launch_am_step(e->tb, ln.db, 1, ids_dev, ln.main, e->cfg.l2_feedback, -1, (int)(ln.am_step_count % 8), (int)(ln.am_step_count / 8));
+        ln.am_step_count++;
+    } else {
+        decode = !(known && e->pred_bc[s] != 15);
+        if (!decode) g_seam[10] += 1;
+        int rc = issue_step(e, ln, 1, ids_dev, decode); if (rc) return rc;
     }
-    if (e->prof_on) prof_collect(e);
+    { int rc = launch_report(e, s); if (rc) return rc; }
+    g_seam[2] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enq).count();
+    g_seam[6] += 1;
+    e->inflight_stream = s; e->inflight_decoded = decode; e->inflight_rd_pred = -1;
+    if (!am && known && e->defer_wait) {
+        // the block starts FINE: samperr = 1080 + the previous block's feedback, keep = 2160 + (1080 - samperr), no keep_extra
+        // (acquire.c:112,259; k_sync's tail): the mirror moves now, the report is taken when somebody needs it
+        e->inflight_rd_pred = e->rd_host[s] + WIN_N - SYM_N + e->pred_samperr[s];
+        e->rd_host[s] = e->inflight_rd_pred;
+        g_seam[8] += 1;
+    }
     return 0;
 }
+
+// Fast seam: block steps of one stream while the host mirror says a window is complete.  A step whose outcome the mirror can
+// predict stays in flight when this returns (harvest takes it); any other is waited for here, as before.
+static int stream_steps(nrsc5hip_engine *e, int s)
+{
+    int guard = 0;
+    while (e->wr_host[s] - e->rd_host[s] >= window_of(e, s)) {
+        int rc = harvest(e, true); if (rc) return rc;          // one step in flight per engine
+        if (e->wr_host[s] - e->rd_host[s] < window_of(e, s)) break;
+        if ((rc = submit_step(e, s))) return rc;
+        if (e->inflight_rd_pred >= 0) continue;                // deferred: the mirror already shows the block consumed
+        if ((rc = harvest(e, true))) return rc;
+        if (!e->inflight_progress || ++guard > 64) break;      // nothing was processed or is pending
+    }
+    return 0;
+}
+
+static int settle(nrsc5hip_engine *e) { return (e && e->inflight_stream >= 0) ? harvest(e, true) : 0; }
 
 // how many input BYTES of this format complete the stream's next block (the drop-in pushes exactly that much, so that the L2
 // feedback of the block's frames reaches the engine before the next block); -1: not known (the stream is not driven by the
@@ -963,7 +1093,9 @@ static int push_common(nrsc5hip_engine *e, int s, const void *host, size_t nbyte
     const bool am = e->mode_host[s] == MODE_AM;
     if (e->attached[s]) FAIL(NRSC5HIP_EINVAL, "stream %d reads a zero-copy capture: reset it before pushing samples", s);
     const bool fast = !e->cfg.p1_async && e->mirror_ok[s];
+    if (e->inflight_stream >= 0 && (!fast || e->inflight_stream != s) && (rc = harvest(e, true))) return rc;
     if (fast && e->staged_stream >= 0 && (e->staged_stream != s || e->staged_cu8 != cu8) && (rc = flush_staged(e))) return rc;
+    if (fast && e->manual_step[s] && e->wr_host[s] - e->rd_host[s] >= window_of(e, s) && (rc = stream_steps(e, s))) return rc;   // the caller did not step
     while (nbytes_total) {
         if (fast) {
             // stage in pinned memory; submit when the block completes (the mirror knows) or the buffer is full
@@ -985,6 +1117,7 @@ static int push_common(nrsc5hip_engine *e, int s, const void *host, size_t nbyte
             src += chunk; nbytes_total -= chunk;
             if (e->wr_host[s] - e->rd_host[s] >= window_of(e, s) || e->staged_bytes == e->stage_bytes) {
                 if ((rc = flush_staged(e))) return rc;
+                if (e->manual_step[s] && nbytes_total == 0) break;     // samples are on their way to the FIFO; nrsc5hip_stream_step runs the block
                 if ((rc = stream_steps(e, s))) return rc;
             }
             continue;
@@ -994,7 +1127,7 @@ static int push_common(nrsc5hip_engine *e, int s, const void *host, size_t nbyte
         if (am && cu8) nq15 = (e->raw_host[s] + (long long)chunk / 2) / 32 - e->raw_host[s] / 32;
         if ((rc = ensure_space(e, s, nq15))) return rc;
         const unsigned count = cu8 ? (unsigned)chunk : (unsigned)(chunk / 2);
-        e->mirror_ok[s] = 0; e->pending[s].clear(); e->fetched[s] = e->drained[s];
+        e->mirror_ok[s] = 0; e->pending[s].clear(); e->fetched[s] = e->drained[s]; forget_prediction(e, s); e->counters_clean = false;
         HIPCHK(hipMemcpyAsync(e->stage_dev, src, chunk, hipMemcpyHostToDevice, e->main));
         HIPCHK(hipMemcpyAsync(e->ids_dev, &s, sizeof(int), hipMemcpyHostToDevice, e->main));
         HIPCHK(hipMemcpyAsync(e->nbytes_dev, &count, sizeof(unsigned), hipMemcpyHostToDevice, e->main));
@@ -1013,12 +1146,12 @@ static int push_common(nrsc5hip_engine *e, int s, const void *host, size_t nbyte
 
 extern "C" int nrsc5hip_push_cu8(nrsc5hip_engine *e, int stream, const uint8_t *iq, uint32_t nbytes)
 {
-    ON_ENGINE_DEVICE(e);
+    ON_ENGINE_DEVICE_FAST(e);
     return push_common(e, stream, iq, nbytes, true);
 }
 extern "C" int nrsc5hip_push_cs16(nrsc5hip_engine *e, int stream, const int16_t *iq, uint32_t n)
 {
-    ON_ENGINE_DEVICE(e);
+    ON_ENGINE_DEVICE_FAST(e);
     if (n % 2) FAIL(NRSC5HIP_EINVAL, "cs16 length must be even");
     return push_common(e, stream, iq, (size_t)n * 2, false);
 }
@@ -1041,6 +1174,7 @@ extern "C" int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream)
     }
     e->wr_host[stream] = 0; e->base_host[stream] = 0; e->drained[stream] = 0; e->raw_host[stream] = 0; e->attached[stream] = 0;
     e->rd_host[stream] = 0; e->fetched[stream] = 0; e->pending[stream].clear(); e->mirror_ok[stream] = e->cfg.p1_async ? 0 : 1;
+    forget_prediction(e, stream);
     e->lane.acq_needed = true; e->lane.px_needed = true; e->lane.set_sig = 0;
     return 0;
 }
@@ -1064,6 +1198,7 @@ extern "C" int nrsc5hip_force_resync(nrsc5hip_engine *e, int stream)
     ON_ENGINE_DEVICE(e);
     int rc = check_stream(e, stream); if (rc) return rc;
     hipLaunchKernelGGL(k_force_none, dim3(1), dim3(1), 0, e->main, e->db, stream);
+    forget_prediction(e, stream);
     e->lane.acq_needed = true; e->lane.px_needed = true; e->lane.set_sig = 0;
     HIPCHK(hipGetLastError());
     return 0;
@@ -1078,7 +1213,9 @@ static int leave_mirror(nrsc5hip_engine *e, int n, const int *ids)
         const int s = ids ? ids[k] : k;
         if (s < 0 || s >= e->cfg.max_streams || !e->mirror_ok[s]) continue;
         e->mirror_ok[s] = 0; e->pending[s].clear(); e->fetched[s] = e->drained[s];
+        forget_prediction(e, s);
     }
+    e->counters_clean = false;
     return 0;
 }
 
@@ -1303,6 +1440,42 @@ extern "C" int nrsc5hip_drain(nrsc5hip_engine *e, int stream, nrsc5hip_record *o
     *n_out = n;
     if (e->cfg.p1_async && e->db.am && e->mode_host[stream] == MODE_AM && n > 0) return patch_am_ber(e, stream, out, n, nullptr);
     return 0;
+}
+
+// The drop-in's form of drain: whatever has been reported so far, without waiting for a block step that is still running
+extern "C" int nrsc5hip_drain_ready(nrsc5hip_engine *e, int stream, nrsc5hip_record *out, int max, int *n_out)
+{
+    ON_ENGINE_DEVICE_FAST(e);
+    int rc = check_stream(e, stream); if (rc) return rc;
+    if (!out || !n_out) FAIL(NRSC5HIP_EINVAL, "null argument");
+    if (!e->mirror_ok[stream]) return nrsc5hip_drain(e, stream, out, max, n_out);
+    if (e->inflight_stream >= 0 && (rc = harvest(e, false))) return rc;
+    std::deque<BlockRecord> &q = e->pending[stream];
+    int n = 0;
+    for (; n < max && !q.empty(); n++) { memcpy(&out[n], &q.front(), sizeof(BlockRecord)); q.pop_front(); }
+    e->drained[stream] += n;
+    *n_out = n;
+    return 0;
+}
+
+extern "C" int nrsc5hip_stream_set_manual_step(nrsc5hip_engine *e, int stream, int on)
+{
+    ON_ENGINE_DEVICE(e);
+    int rc = check_stream(e, stream); if (rc) return rc;
+    e->manual_step[stream] = on ? 1 : 0;
+    return 0;
+}
+
+// manual-step streams: run the block(s) whose window the pushes so far completed (the step may stay in flight: drain waits for it,
+// drain_ready does not)
+extern "C" int nrsc5hip_stream_step(nrsc5hip_engine *e, int stream)
+{
+    ON_ENGINE_DEVICE_FAST(e);
+    int rc = check_stream(e, stream); if (rc) return rc;
+    if (e->cfg.p1_async || !e->mirror_ok[stream]) FAIL(NRSC5HIP_EINVAL, "stream %d is not driven by the fast streaming seam", stream);
+    if (e->inflight_stream >= 0 && e->inflight_stream != stream && (rc = harvest(e, true))) return rc;
+    if (e->staged_stream == stream && (rc = flush_staged(e))) return rc;
+    return stream_steps(e, stream);
 }
 
 extern "C" int nrsc5hip_p1_frame_packed(nrsc5hip_engine *e, int stream, int slot, uint32_t *words)
@@ -1719,6 +1892,7 @@ extern "C" int nrsc5hip_reset_all(nrsc5hip_engine *e)
     std::fill(e->rd_host.begin(), e->rd_host.end(), 0);
     std::fill(e->fetched.begin(), e->fetched.end(), 0);
     std::fill(e->mirror_ok.begin(), e->mirror_ok.end(), (char)(e->cfg.p1_async ? 0 : 1));
+    std::fill(e->pred_ok.begin(), e->pred_ok.end(), 0); e->counters_clean = false;
     for (auto &q : e->pending) q.clear();
     HIPCHK(hipMemset(e->db.pids_rec, 0xff, S * NWIN * 16 * sizeof(int)));
     HIPCHK(hipMemset(e->db.px_job, 0xff, S * NWIN * 16 * sizeof(PxJob)));
@@ -1908,6 +2082,7 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
         }
         break;
     }
+    case NRSC5HIP_TUNE_DEFER_WAIT:        e->defer_wait = value != 0; break;
     case NRSC5HIP_TUNE_MIXFFT_SYMS:       e->mixfft_syms = (value == 2 || value == 4 || value == 8) ? value : 1; break;
     case NRSC5HIP_TUNE_AM_SEGMENTS:       e->am_segments = std::min(std::max(value, 1), K9_GMAX); break;
     case NRSC5HIP_TUNE_AM_WARM:           e->am_warm = value > 0 ? K9_WARM : 0; e->am_runin = value > 0 ? K9_TB_RUNIN : 0; break;

@@ -60,7 +60,7 @@ class L2Job(ctypes.Structure):
 
 
 L2_FM_P1, L2_FM_PX, L2_AM = 0, 1, 2
-TUNE_DECODE_STREAMS, TUNE_AM_DECODE_STREAMS, TUNE_VERDICT_LAG, TUNE_SYNC_PHASES, TUNE_FWD_SEGMENTS, TUNE_FWD_WARM, TUNE_AM_SEGMENTS, TUNE_DECODE_CUS, TUNE_DECODE_PRIORITY, TUNE_AM_WARM, TUNE_MIXFFT_SYMS = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10
+TUNE_DECODE_STREAMS, TUNE_AM_DECODE_STREAMS, TUNE_VERDICT_LAG, TUNE_SYNC_PHASES, TUNE_FWD_SEGMENTS, TUNE_FWD_WARM, TUNE_AM_SEGMENTS, TUNE_DECODE_CUS, TUNE_DECODE_PRIORITY, TUNE_AM_WARM, TUNE_MIXFFT_SYMS, TUNE_DEFER_WAIT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11
 L2_STATUS = ("end", "no_audio", "fixed_data", "header_rs", "bad_locators", "too_many_pdus", "hef_overrun", "bad_stream", "bad_length", "audio_end")
 
 
@@ -132,6 +132,11 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.nrsc5hip_debug_poison_results.argtypes = [vp]
     lib.nrsc5hip_debug_seam_totals.argtypes = [vp, ci]
     lib.nrsc5hip_debug_seam_totals.restype = None
+    lib.nrsc5hip_debug_seam_counts.argtypes = [vp, ci]
+    lib.nrsc5hip_debug_seam_counts.restype = None
+    lib.nrsc5hip_drain_ready.argtypes = [vp, ci, vp, ci, ctypes.POINTER(ci)]
+    lib.nrsc5hip_stream_set_manual_step.argtypes = [vp, ci, ci]
+    lib.nrsc5hip_stream_step.argtypes = [vp, ci]
     lib.nrsc5hip_batch_fetch_view.argtypes = [vp, ci, ctypes.POINTER(vp), vp, ctypes.POINTER(vp)]
     lib.nrsc5hip_reset_all.argtypes = [vp]
     lib.nrsc5hip_profile.argtypes = [vp, ci, vp, vp]
@@ -164,7 +169,7 @@ EXPORTED_SYMBOLS = [
     "nrsc5hip_batch_append_cu8", "nrsc5hip_batch_append_cs16", "nrsc5hip_batch_process", "nrsc5hip_drain",
     "nrsc5hip_p1_frame_packed", "nrsc5hip_p1_frame_bits", "nrsc5hip_batch_fetch", "nrsc5hip_unpack_bits",
     "nrsc5hip_stage_halfband_fm_cu8", "nrsc5hip_stage_fft2048", "nrsc5hip_stage_viterbi_k7", "nrsc5hip_debug_fetch", "nrsc5hip_debug_fetch_costas",
-    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_debug_tune", "nrsc5hip_debug_fwd_stats", "nrsc5hip_debug_k9_stats", "nrsc5hip_stage_first_header", "nrsc5hip_debug_seam_totals", "nrsc5hip_debug_poison_results", "nrsc5hip_device_count", "nrsc5hip_device_upload", "nrsc5hip_device_free", "nrsc5hip_batch_fetch_view", "nrsc5hip_batch_fetch_l2_px", "nrsc5hip_batch_fetch_l2_am",
+    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_debug_tune", "nrsc5hip_debug_fwd_stats", "nrsc5hip_debug_k9_stats", "nrsc5hip_stage_first_header", "nrsc5hip_debug_seam_totals", "nrsc5hip_debug_seam_counts", "nrsc5hip_drain_ready", "nrsc5hip_stream_set_manual_step", "nrsc5hip_stream_step", "nrsc5hip_debug_poison_results", "nrsc5hip_device_count", "nrsc5hip_device_upload", "nrsc5hip_device_free", "nrsc5hip_batch_fetch_view", "nrsc5hip_batch_fetch_l2_px", "nrsc5hip_batch_fetch_l2_am",
     "nrsc5hip_stream_set_mode", "nrsc5hip_am_frame_bits", "nrsc5hip_stage_viterbi_k9", "nrsc5hip_px_frame_bits",
     "nrsc5hip_batch_fetch_px", "nrsc5hip_debug_fetch_px", "nrsc5hip_stage_viterbi_k9_bench",
     "nrsc5hip_l2_index", "nrsc5hip_stage_l2_index", "nrsc5hip_l2_frame_get", "nrsc5hip_batch_fetch_l2",
@@ -172,10 +177,25 @@ EXPORTED_SYMBOLS = [
     "nrsc5hip_hdc_adts", "nrsc5hip_hdc_host_bytes", "nrsc5hip_hdc_fixed_audio_end", "nrsc5hip_l2_apply_audio_end", "nrsc5hip_hdc_frame_reset"]
 
 
+def library_sha(path: str | None = None) -> str:
+    """Source fingerprint of the library FILE, read from its bytes -- not through dlopen: a library this process has already
+    mapped keeps reporting the old build after the file was rebuilt (dlopen hands back the mapped handle)."""
+    path = path or DEFAULT_LIB
+    if not os.path.exists(path):
+        raise Nrsc5HipError(f"{path} not found: build it with `python -m nrsc5_amd.build` (hipcc, gfx950). There is no CPU fallback.")
+    data = open(path, "rb").read()
+    marker = b"NRSC5HIP_SOURCE_SHA="
+    k = data.find(marker)
+    if k < 0:
+        return "unmarked"
+    return data[k + len(marker):k + len(marker) + 16].split(b"\0")[0].decode(errors="replace")
+
+
 def check_fresh(path: str | None = None):
-    """Raise unless the library was built from the device sources of THIS tree (a stale .so silently measures / tests old code)."""
+    """Raise unless the library was built from the device sources of THIS tree (a stale .so silently measures / tests old code).
+    Looks at the file only, so that a caller can rebuild and check again in the same process."""
     from . import build
-    got = load_library(path).nrsc5hip_source_sha().decode()
+    got = library_sha(path)
     want = build.source_sha()
     if got != want:
         raise Nrsc5HipError(f"{path or DEFAULT_LIB} was built from other sources (library {got}, tree {want}): run `python -m nrsc5_amd.build`")
@@ -289,6 +309,26 @@ class Engine:
         n = ctypes.c_int()
         self._check(self.lib.nrsc5hip_drain(self._h, stream, out.ctypes.data, mx, ctypes.byref(n)))
         return out[:n.value]
+
+    def drain_ready(self, stream: int, max_records: int | None = None) -> np.ndarray:
+        """nrsc5hip_drain_ready: the records reported so far; never waits for a block step that is still running"""
+        mx = max_records or self.record_capacity
+        out = np.zeros(mx, dtype=RECORD_DTYPE)
+        n = ctypes.c_int()
+        self._check(self.lib.nrsc5hip_drain_ready(self._h, stream, out.ctypes.data, mx, ctypes.byref(n)))
+        return out[:n.value]
+
+    def set_manual_step(self, stream: int, on: bool = True):
+        self._check(self.lib.nrsc5hip_stream_set_manual_step(self._h, stream, int(on)))
+
+    def stream_step(self, stream: int):
+        self._check(self.lib.nrsc5hip_stream_step(self._h, stream))
+
+    def seam_counts(self, reset: bool = False) -> dict:
+        """deferred steps / mispredicted read positions / steps without P1 decode launches / late P1 decodes (calling thread)"""
+        out = np.zeros(4, dtype=np.float64)
+        self.lib.nrsc5hip_debug_seam_counts(out.ctypes.data, int(reset))
+        return dict(zip(("deferred_steps", "mispredicted_rd", "steps_without_p1_launches", "late_p1_decodes"), (int(x) for x in out)))
 
     def p1_frame_bits(self, stream: int, slot: int) -> np.ndarray:
         bits = np.zeros(P1_BITS, dtype=np.uint8)

@@ -1105,3 +1105,68 @@ def check_viterbi_segmented(lib, oracle, lens=(2304, 4608), segments=(1, 2, 4, 1
                     if not warm:
                         assert r1 - r0 >= 3, (L, G, c1 - c0, r1 - r0)     # cold starts on informative frames were repaired, not trusted
     E.close()
+
+
+def check_deferred_seam(lib, names=("ppm+60", "ppm-85_cs16", "ppm+100_cfo_search")):
+    """Round 4's streaming seam.  (1) deferred wait: a block that starts FINE consumes 71280 - 2160 + next_samperr samples, so the
+    host moves its mirror when it SUBMITS the step and takes the report later -- under a sample-clock error next_samperr != 0 on
+    most blocks, so the prediction is really exercised (and counted: never wrong); (2) no P1 decode launches on blocks that cannot
+    complete a frame (never a frame without its decode); (3) the drop-in's flow -- manual step: push the completing piece, drain
+    the block before (waits), step, poll with drain_ready on every other call.  All three must leave the records bit-identical to
+    the synchronous seam (NRSC5HIP_TUNE_DEFER_WAIT = 0, drain after every push)."""
+    for name in names:
+        cap = synth.fm_mp1_capture(**common.IMPAIRED_FM_CASES[name])
+        cu8 = cap.iq.dtype == np.uint8
+        raw = cap.iq.view(np.uint8)
+        raw = raw[:raw.size - raw.size % 4]
+
+        def push(E, piece):
+            if cu8:
+                E.push_cu8(0, piece)
+            else:
+                E.push_cs16(0, piece.view(np.int16))
+
+        def run(mode):
+            E = eng.Engine(max_streams=1, q15_capacity=200000, record_capacity=256, p1_slots=8, lib_path=lib)
+            E.seam_counts(reset=True)
+            if mode == "sync":
+                E.tune(eng.TUNE_DEFER_WAIT, 0)
+            if mode == "dropin":
+                E.set_manual_step(0, True)
+            recs, frames = [], []
+
+            def take(new):
+                for r in new:
+                    if int(r["flags"]) & eng.REC_P1:
+                        frames.append(E.p1_frame_bits(0, int(r["p1_slot"])).copy())
+                recs.append(new)
+            for off in range(0, raw.size, 32768):
+                call = raw[off:off + 32768]
+                done = 0
+                while done < call.size:
+                    room = E.bytes_to_next_block(0, cu8)
+                    assert room >= 4 and room % 4 == 0
+                    piece = call[done:done + room]
+                    push(E, piece)
+                    done += piece.size
+                    if mode == "dropin":
+                        if piece.size >= room:
+                            take(E.drain(0)); E.stream_step(0); take(E.drain_ready(0))
+                        else:
+                            take(E.drain_ready(0))
+                    else:
+                        take(E.drain(0))
+            take(E.drain(0))
+            counts = E.seam_counts()
+            E.close()
+            return np.concatenate(recs), frames, counts
+        ref, ref_frames, c0 = run("sync")
+        assert c0["deferred_steps"] == 0 and len(ref) >= 30 and len(ref_frames) >= 1
+        fine = sum(1 for r in ref[:-1] if int(r["state_after"]) == 2)
+        assert sum(1 for r in ref if int(r["state_before"]) == 2 and int(r["samperr"]) != 1080) >= 5, "the capture does not move the timing pick"
+        for mode in ("deferred", "dropin"):
+            got, frames, c = run(mode)
+            assert got.tobytes() == ref.tobytes(), (name, mode)
+            assert len(frames) == len(ref_frames) and all(np.array_equal(a, b) for a, b in zip(frames, ref_frames))
+            assert c["mispredicted_rd"] == 0 and c["late_p1_decodes"] == 0, c
+            assert c["deferred_steps"] >= fine - 1 and c["steps_without_p1_launches"] >= fine - 1 - len(ref_frames), (c, fine)

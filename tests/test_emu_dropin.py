@@ -1,0 +1,64 @@
+"""CPU (`-m "not gpu"`): the drop-in translation unit (integration/input_hip.c) under the reference's untouched L4 / L2 code, over
+the CPU-EMULATED twin of the library (tests/simt: same .hip sources compiled with g++) -- the shim's control flow (block-exact
+pieces, deliver-before-step order, polling, the zero-length flush) against the plain reference build through the public pipe API.
+Needs /root/reference (build container); the `-m gpu` twin with the real library is tests/test_gpu_dropin.py."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import common
+from oracle import ref
+
+INTEG = os.path.join(common.ROOT, "integration")
+
+
+@pytest.fixture(scope="module")
+def emu_dropin(emu_lib):
+    if not os.path.isdir("/root/reference/src"):
+        pytest.skip("needs /root/reference")
+    if not os.path.exists(os.path.join(common.ROOT, "oracle", "_ref", "libnrsc5_plain.so")):
+        pytest.skip("oracle/_ref/libnrsc5_plain.so not built")
+    subprocess.check_call(["make", "-C", INTEG, "emu"], stdout=subprocess.DEVNULL)
+    return os.path.join(INTEG, "_build", "libnrsc5_emudropin.so")
+
+
+def _run(path, iq, chunk=32768, mode=0):
+    lib = ctypes.CDLL(path)
+    lib.pipe_run.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    lib.pipe_run.restype = ctypes.c_size_t
+    p = ctypes.c_void_p()
+    n = lib.pipe_run(iq.ctypes.data, iq.size, chunk, mode, int(iq.dtype == np.int16), ctypes.byref(p))
+    return ref.parse_log(ctypes.string_at(p, n))
+
+
+def _compare_events(exp, got):
+    assert [k for k, _ in exp] == [k for k, _ in got]
+    for (k, a), (_, b) in zip(exp, got):
+        if k == "hdc":
+            assert a["program"] == b["program"] and a["flags"] == b["flags"] and a["data"] == b["data"]
+        elif k in ("sync", "mer", "ber"):
+            for f in a:
+                assert common.float_close(f, float(a[f]), float(b[f])), (k, f, a[f], b[f])
+
+
+@pytest.mark.parametrize("name,chunk", [("fm_cu8_cfo137", 32768), ("fm_cu8_cfo-2400", 32768), ("fm_cu8_cfo137", 1 << 20)])
+def test_emu_dropin_events_match_reference(emu_dropin, captures, name, chunk):
+    """FM: a capture whose first lock is false (LOST_SYNC through frame.c -> input_set_sync_state -> nrsc5hip_force_resync while the
+    engine runs with deferred waits and manual steps), one with a CFO search, and one fed in calls that span many blocks."""
+    iq = np.ascontiguousarray(captures(name).iq)
+    exp = _run(os.path.join(common.ROOT, "oracle", "_ref", "libnrsc5_plain.so"), iq, chunk)
+    got = _run(emu_dropin, iq, chunk)
+    assert len(exp) >= 2
+    _compare_events(exp, got)
+
+
+def test_emu_dropin_am(emu_dropin, captures):
+    name = next(iter(common.GOLDEN_AM_CASES))
+    iq = np.ascontiguousarray(captures(name).iq)
+    exp = _run(os.path.join(common.ROOT, "oracle", "_ref", "libnrsc5_plain.so"), iq, mode=1)
+    got = _run(emu_dropin, iq, mode=1)
+    assert any(k == "ber" for k, _ in exp)
+    _compare_events(exp, got)

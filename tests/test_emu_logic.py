@@ -229,3 +229,7 @@ def test_emu_replay_under_drift(emu_lib, oracle):
 def test_emu_am_impaired_channel(emu_lib, oracle):
     from tests import common
     ec.check_am_oracle_end_to_end(emu_lib, oracle, common.IMPAIRED_AM_CASES["am_ppm-50"])
+
+
+def test_emu_deferred_seam_equals_synchronous(emu_lib):
+    ec.check_deferred_seam(emu_lib)
