@@ -356,7 +356,7 @@ enum {
     NRSC5HIP_TUNE_AM_DECODE_STREAMS,     /* same for the AM window pipeline (default 2) */
     NRSC5HIP_TUNE_VERDICT_LAG,           /* TEST HOOK: the replay takes first-header verdicts this many windows late (0..8): deep speculation */
     NRSC5HIP_TUNE_SYNC_PHASES,           /* 1: k_sync accumulates shader cycles per phase for stream 0 (nrsc5hip_debug_sync_phases) */
-    NRSC5HIP_TUNE_FWD_SEGMENTS           /* waves per frame of the K=7 forward trellis pass (1..16; 0 = chosen from the size of the stream set).  Any value
+    NRSC5HIP_TUNE_FWD_SEGMENTS           /* waves per frame of the K=7 forward trellis pass (1..64; 0 = chosen from the size of the stream set).  Any value
                                             gives the sequential decoder's decisions bit for bit: segments start speculatively and are verified /
                                             repaired (viterbi_v3.h).  Also used by nrsc5hip_stage_viterbi_k7 / _bench. */
     , NRSC5HIP_TUNE_FWD_WARM               /* TEST HOOK: 0 = the segments start cold (no speculative warm-up), so that the speculation fails wherever the
@@ -370,6 +370,11 @@ enum {
     , NRSC5HIP_TUNE_MIXFFT_SYMS            /* OFDM symbols per k_mixfft workgroup: 1 (default), 2, 4, 8 -- any value gives identical bins */
     , NRSC5HIP_TUNE_DEFER_WAIT             /* fast streaming seam: 1 (default) = a block step whose FIFO consumption the host can compute in advance stays in
                                              flight when the push returns; 0 = every step is waited for at once (round 3's behaviour) */
+    , NRSC5HIP_TUNE_SYNC_LANES             /* work-items per stream of the sync kernel: 256, 768, 0 = chosen from the size of the stream set (default) */
+    , NRSC5HIP_TUNE_DIRECT_DECIMATE        /* fast streaming seam, FM cu8: 1 (default) = the decimator reads the pinned staging buffer across PCIe itself (one
+                                             launch per chunk); 0 = hipMemcpyAsync into a device buffer, decimator, commit kernel (round 3's chain) */
+    , NRSC5HIP_TUNE_EARLY_FLUSH_KB         /* fast streaming seam with the direct decimator: staged KiB at which a chunk is submitted (on the engine's ingest stream,
+                                             beside the running block step) before its block is complete; 0 = only at the block's end.  Default 96 */
 };
 /* process-wide wall-clock totals of the streaming seam with p1_async = 0 (what the drop-in uses): [0] s copying pushes into pinned
  * staging, [1] s enqueueing H2D + decimator, [2] s enqueueing block steps, [3] s waiting for the device (one sync per block),

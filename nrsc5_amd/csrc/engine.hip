@@ -103,6 +103,7 @@ struct nrsc5hip_engine {
     int am_segments, am_warm, am_runin;   // K=9 decode of the AM P3 frame: segment waves per frame (8), their forward warm-up / traceback run-in (test hooks: 0)
     int fwd_warm;                      // test hook: speculative warm-up trips of a forward segment (2; 0 makes every speculation fail -> repair path)
     int mixfft_syms;                   // symbols per k_mixfft workgroup (1, 2, 4, 8)
+    int sync_lanes;                    // work-items per stream of k_sync: 0 = by the size of the stream set, 256, 768
     int fwd_segments;                  // waves per frame of the P1 forward pass; 0 = pick from the size of the stream set (fwd_segments_for)
     hipStream_t main;                  // = lane.main
     std::vector<void *> allocs;
@@ -116,8 +117,17 @@ struct nrsc5hip_engine {
     // block costs one host memcpy into pinned memory, one async H2D and the K1 launch -- no synchronisation at all -- and a
     // push that does complete one ends with ONE sync, after a report kernel has posted the counters, the new read position and
     // the block's record straight into pinned host memory.
-    struct StreamReport { int counters[4]; long long rd; int nblocks; int nrec; BlockRecord rec[4]; unsigned seq; unsigned pad; };
-    uint8_t *stage_pin[2], *stage_dev2[2]; hipEvent_t stage_ev[2]; bool stage_busy[2]; int stage_slot;
+    uint8_t *stage_pin[2], *stage_pin_dev[2], *stage_dev2[2]; hipEvent_t stage_ev[2]; bool stage_busy[2]; int stage_slot;
+    unsigned *decim_ticket;            // k_decimate_fm_cu8_stream: workgroups of the running launch that have finished
+    // Ingest stream (round 4): the direct decimator runs on its own HIP stream, beside the block step on `main` (which keeps ONE CU
+    // busy): chunks are submitted as they fill (early_flush bytes), so that when the push that completes a block arrives only the
+    // remainder is left to decimate and nothing of it sits on the step chain.  Order between the two streams: a step waits for the
+    // ingest work submitted before it (ev_ingest); a FIFO compaction on the ingest stream waits for the steps submitted before it
+    // (ev_main: it needs the final read position); anything else that touches the stream synchronises both (settle).
+    hipStream_t ingest; hipEvent_t ev_ingest, ev_main;
+    bool ingest_dirty;                 // work on the ingest stream that `main` has not been ordered behind yet
+    bool main_stepped;                 // block steps on `main` that the ingest stream has not been ordered behind yet
+    size_t early_flush;                // staged bytes at which a chunk is submitted before its block is complete (0: never)
     // samples accepted by a push but not submitted yet: they wait in stage_pin[stage_slot] until the mirror says a block completes
     // (or the buffer is full, or anything else looks at the stream) -- one H2D + one decimator launch per BLOCK, not per push
     int staged_stream; size_t staged_bytes; bool staged_cu8; long long staged_q15;
@@ -135,6 +145,7 @@ struct nrsc5hip_engine {
     long long inflight_rd_pred;        // the read position predicted for the step in flight (-1: no prediction, the mirror waits)
     bool inflight_decoded;             // the step in flight carried the P1 de-interleave / trellis / traceback launches
     bool inflight_progress;            // the last harvested step processed (or left pending) a block
+    bool direct_decimate;              // 1 (default): FM cu8 pushes are decimated straight from the pinned staging buffer; 0 (NRSC5HIP_TUNE_DIRECT_DECIMATE): H2D copy first
     bool defer_wait;                   // 1 (default): predictable steps stay in flight; 0 (NRSC5HIP_TUNE_DEFER_WAIT): every step is waited for at once
     bool counters_clean;               // the step counters are zero: the last kernel that touched them was a report kernel
     std::vector<char> pred_ok;         // the stream's last harvested record left it FINE and nothing else touched it since
@@ -422,7 +433,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
     do {
         {
             e->naux = 3; e->naux_am = 2;   // decode streams in use (measured: profiles/r02_naux.txt, r03_am_decode.txt); nrsc5hip_debug_tune changes them
-            e->verdict_lag = 0; e->fwd_segments = 0; e->fwd_warm = 2; e->mixfft_syms = 1;      // measured: profiles/r04_mixfft_persistent.txt
+            e->verdict_lag = 0; e->fwd_segments = 0; e->fwd_warm = 2; e->mixfft_syms = 1; e->sync_lanes = 0;      // measured: profiles/r04_mixfft_persistent.txt
             e->am_segments = K9_GMAX; e->am_warm = K9_WARM; e->am_runin = K9_TB_RUNIN;
         }
         {
@@ -469,7 +480,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if ((rc = dev_alloc(e, &db.coded, (size_t)(cfg->p1_async ? NAUX : 1) * S * P1_LEN))) break;
         if ((rc = dev_alloc(e, &db.dec, (size_t)(cfg->p1_async ? NAUX : 1) * S * (size_t)(2 * (P1_LEN + 64))))) break;
         if ((rc = dev_alloc(e, &db.tbmap, (size_t)(cfg->p1_async ? NAUX : 1) * S * (size_t)(P1_LEN / 64 + 1) * 64))) break;
-        if ((rc = dev_alloc(e, &db.fwd_meta, (size_t)(cfg->p1_async ? NAUX : 1) * S * (size_t)(16 * 512)))) break;
+        if ((rc = dev_alloc(e, &db.fwd_meta, (size_t)(cfg->p1_async ? NAUX : 1) * S * (size_t)(VIT3_GMAX * VIT3_META)))) break;
         if ((rc = dev_alloc(e, &db.fwd_stats, 2))) break;
         if (hipMemset(db.fwd_stats, 0, 2 * sizeof(int)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
         if ((rc = dev_alloc(e, &db.am_k9stats, 4))) break;
@@ -535,15 +546,33 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if (!cfg->p1_async) {
             for (int k = 0; k < 2 && !rc; k++) {
                 if ((rc = dev_alloc(e, &e->stage_dev2[k], e->stage_bytes + 16))) break;
-                if (hipHostMalloc((void **)&e->stage_pin[k], e->stage_bytes + 16, hipHostMallocDefault) != hipSuccess ||
+                void *sp = nullptr;
+                if (hipHostMalloc((void **)&e->stage_pin[k], e->stage_bytes + 16, hipHostMallocMapped) != hipSuccess ||
+                    hipHostGetDevicePointer(&sp, e->stage_pin[k], 0) != hipSuccess ||
                     hipEventCreateWithFlags(&e->stage_ev[k], hipEventDisableTiming) != hipSuccess) { rc = NRSC5HIP_ENOMEM; snprintf(g_err, sizeof(g_err), "pinned staging allocation failed"); }
+                e->stage_pin_dev[k] = (uint8_t *)sp;
                 e->stage_busy[k] = false;
             }
             if (rc) break;
+            if (S * (size_t)cfg->p1_slots <= 64) {
+                // the fast seam's P1 frames reach the host by the traceback's own stores (k_p1_traceback writes the pinned mirror beside the
+                // device ring): nrsc5hip_p1_frame_packed then copies 18 KB of host memory instead of synchronising and issuing a D2H copy
+                const size_t nw = S * (size_t)cfg->p1_slots * P1_WORDS;
+                void *mp = nullptr;
+                if (hipHostMalloc((void **)&e->frames_host, nw * sizeof(uint32_t), hipHostMallocMapped) != hipSuccess ||
+                    hipHostGetDevicePointer(&mp, e->frames_host, 0) != hipSuccess) { rc = NRSC5HIP_ENOMEM; snprintf(g_err, sizeof(g_err), "pinned frame mirror allocation failed"); break; }
+                memset(e->frames_host, 0, nw * sizeof(uint32_t));
+                db.p1_mirror = (uint32_t *)mp;
+            }
+            if (hipStreamCreate(&e->ingest) != hipSuccess || hipEventCreateWithFlags(&e->ev_ingest, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "ingest stream creation failed"); break; }
+            e->ingest_dirty = false; e->main_stepped = false; e->early_flush = 96u << 10;
+            if ((rc = dev_alloc(e, &e->decim_ticket, 1))) break;
+            if (hipMemset(e->decim_ticket, 0, sizeof(unsigned)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
             void *dp = nullptr;
             if (hipHostMalloc((void **)&e->report_host, sizeof(*e->report_host), hipHostMallocMapped) != hipSuccess ||
                 hipHostGetDevicePointer(&dp, e->report_host, 0) != hipSuccess) { rc = NRSC5HIP_ENOMEM; snprintf(g_err, sizeof(g_err), "pinned report allocation failed"); break; }
-            e->report_dev = (nrsc5hip_engine::StreamReport *)dp;
+            e->report_dev = (StreamReport *)dp;
             memset(e->report_host, 0, sizeof(*e->report_host));
         }
         e->stage_slot = 0; e->staged_stream = -1; e->staged_bytes = 0; e->staged_q15 = 0; e->staged_cu8 = false;
@@ -562,7 +591,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         e->rd_host.assign(S, 0); e->fetched.assign(S, 0); e->mirror_ok.assign(S, cfg->p1_async ? 0 : 1); e->pending.assign(S, {});
         e->pred_ok.assign(S, 0); e->pred_samperr.assign(S, 0); e->pred_bc.assign(S, 0); e->manual_step.assign(S, 0);
         e->inflight_stream = -1; e->report_seq = 0; e->inflight_rd_pred = -1; e->inflight_decoded = true; e->inflight_progress = false;
-        e->defer_wait = true; e->counters_clean = false;
+        e->defer_wait = true; e->direct_decimate = true; e->counters_clean = false;
         e->lane.db = db; e->lane.counters_dev = db.counters;
         e->prof_on = false; e->prof_only = -1;
         for (int k = 0; k < NRSC5HIP_PROF_CLASSES; k++) { e->prof_ms[k] = 0; e->prof_launches[k] = 0; }
@@ -586,6 +615,9 @@ extern "C" void nrsc5hip_engine_destroy(nrsc5hip_engine *e)
     if (e->nblocks_host) (void)hipHostFree(e->nblocks_host);
     for (int k = 0; k < 2; k++) { if (e->stage_pin[k]) (void)hipHostFree(e->stage_pin[k]); if (e->stage_ev[k]) (void)hipEventDestroy(e->stage_ev[k]); }
     if (e->report_host) (void)hipHostFree(e->report_host);
+    if (e->ingest) (void)hipStreamDestroy(e->ingest);
+    if (e->ev_ingest) (void)hipEventDestroy(e->ev_ingest);
+    if (e->ev_main) (void)hipEventDestroy(e->ev_main);
     for (auto &sp : e->prof_spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (hipEvent_t ev : e->prof_pool) (void)hipEventDestroy(ev);
     {
@@ -631,7 +663,7 @@ static int fwd_segments_for(const nrsc5hip_engine *e, const nrsc5hip_engine::Lan
     if (e->fwd_segments > 0) return e->fwd_segments;
     if (ln.thin) return 16;
     const int g = 1024 / (n > 0 ? n : 1);
-    return g < 1 ? 1 : g > 16 ? 16 : g;
+    return g < 1 ? 1 : g > VIT3_GMAX ? VIT3_GMAX : g;          // a lone stream (the in-order seam, the drop-in): 64 segment waves
 }
 
 static int launch_window_decode(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const int *ids_dev, int parity, int lane)
@@ -662,7 +694,7 @@ static int launch_inorder_p1(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int 
 }
 
 // decode_p1 = false (fast streaming seam only): the caller KNOWS that no listed stream can complete a P1 frame in this step
-static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const int *ids_dev, bool decode_p1 = true)
+static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const int *ids_dev, bool decode_p1 = true, bool decode_pids = true)
 {
     const bool async = e->cfg.p1_async != 0;
     const long long window = ln.step_count / 16;
@@ -688,11 +720,11 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
     const int slot = async ? (int)(ln.step_count % 16) : 0;
     // batch pipeline: once every stream of the set is FINE, the next block's bookkeeping rides in k_sync's tail
     const int fuse = (async && !ln.acq_needed) ? 1 : 0;
-    { ProfScope p(e, NRSC5HIP_PROF_SYNC, ln.main); launch_sync(e->tb, ln.db, n, ids_dev, parity, slot, fuse, (int)window, ln.main); }
+    { ProfScope p(e, NRSC5HIP_PROF_SYNC, ln.main); launch_sync(e->tb, ln.db, n, ids_dev, parity, slot, fuse, (int)window, ln.main, e->sync_lanes); }
     ln.prepared_by_sync = fuse != 0;
     if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_px_deint(e->tb, ln.db, n, ids_dev, parity, slot, ln.main); }
     if (!async) {
-        { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_pids_decode(e->tb, ln.db, n, ids_dev, parity, 1, ln.main); }
+        if (decode_pids) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_pids_decode(e->tb, ln.db, n, ids_dev, parity, 1, ln.main); }
         if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_px_decode(e->tb, ln.db, n, ids_dev, parity, 0, ln.main); }
         if (decode_p1) { int rc = launch_inorder_p1(e, ln, n, ids_dev); if (rc) return rc; }
     } else if ((ln.step_count % 16) == 15) {
@@ -876,10 +908,15 @@ __global__ void k_compact(DevBuffers db, int s)
     if (threadIdx.x == 0) st.base = st.rd;
 }
 
-static int ensure_space(nrsc5hip_engine *e, int s, long long incoming)
+static int ensure_space(nrsc5hip_engine *e, int s, long long incoming, bool on_ingest = false)
 {
     if (e->wr_host[s] - e->base_host[s] + incoming <= e->db.q15_cap) return 0;
-    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, e->main, e->db, s);
+    if (on_ingest && e->main_stepped) {                        // the compaction moves [rd, wr): the steps submitted so far must have left their final rd
+        HIPCHK(hipEventRecord(e->ev_main, e->main));
+        HIPCHK(hipStreamWaitEvent(e->ingest, e->ev_main, 0));
+        e->main_stepped = false;
+    }
+    hipLaunchKernelGGL(k_compact, dim3(1), dim3(1024), 0, on_ingest ? e->ingest : e->main, e->db, s);
     if (e->mirror_ok[s]) {
         e->base_host[s] = e->rd_host[s];                       // k_compact sets base = rd, and the mirror IS the device's rd
     } else {
@@ -894,26 +931,7 @@ static int ensure_space(nrsc5hip_engine *e, int s, long long incoming)
 }
 
 // ---- streaming seam ---------------------------------------------------------------------------------------
-// posts what the host needs after a block step of ONE stream into pinned host memory: the step's counters, the FIFO read position
-// and the records [first_rec, nblocks) (in-order mode: a block's record is final when its step ends) -- and, last of all, the
-// sequence number the host is waiting for.  Leaves the step counters at zero for the next step (no memset per block).
-__global__ void k_stream_report(DevBuffers db, int s, int first_rec, nrsc5hip_engine::StreamReport *out, unsigned seq)
-{
-    const StreamState &st = db.state[s];
-    const int n = min(max(st.nblocks - first_rec, 0), 4);
-    const int t = threadIdx.x;
-    constexpr int RW = sizeof(BlockRecord) / 4;
-    if (t < n * RW) {
-        const int k = t / RW, w = t % RW;
-        ((uint32_t *)&out->rec[k])[w] = ((const uint32_t *)&db.records[(size_t)s * db.rec_cap + ((first_rec + k) % db.rec_cap)])[w];
-    }
-    if (t < 4) { out->counters[t] = db.counters[t]; db.counters[t] = 0; }
-    if (t == 0) { out->rd = st.rd; out->nblocks = st.nblocks; out->nrec = n; }
-    __threadfence_system();
-    __syncthreads();
-    if (t == 0) { *(volatile unsigned *)&out->seq = seq; __threadfence_system(); }
-}
-
+// (the report itself is the tail of the step's last kernel: k_stream_tail, k_sync.hip)
 static int window_of(const nrsc5hip_engine *e, int s) { return e->mode_host[s] == MODE_AM ? AM_WIN : WIN_N; }
 
 static void forget_prediction(nrsc5hip_engine *e, int s) { e->pred_ok[s] = 0; }
@@ -938,11 +956,11 @@ static int wait_report(nrsc5hip_engine *e, unsigned seq, bool block)
     return 1;
 }
 
-static int launch_report(nrsc5hip_engine *e, int s)
+static int launch_report(nrsc5hip_engine *e, int s, bool with_pids)
 {
     e->report_seq++;
     if (e->report_seq == 0) e->report_seq = 1;                 // 0 = the freshly cleared report
-    hipLaunchKernelGGL(k_stream_report, dim3(1), dim3(128), 0, e->lane.main, e->lane.db, s, e->fetched[s], e->report_dev, e->report_seq);
+    launch_stream_tail(e->tb, e->lane.db, s, e->fetched[s], e->report_dev, e->report_seq, with_pids ? 1 : 0, e->lane.main);
     e->counters_clean = true;
     HIPCHK(hipGetLastError());
     return 0;
@@ -962,14 +980,14 @@ static int harvest(nrsc5hip_engine *e, bool block)
         if (block) g_seam[3] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count();
     }
     e->inflight_stream = -1;
-    const nrsc5hip_engine::StreamReport *rp = e->report_host;
+    const StreamReport *rp = e->report_host;
     bool p1_missing = false;
     for (int k = 0; k < rp->nrec; k++) if ((rp->rec[k].flags & REC_P1) && e->mode_host[s] != MODE_AM && !e->inflight_decoded) p1_missing = true;
     if (p1_missing) {
         // the prediction said no P1 frame could complete in this block and one did: decode it now, take the record again
         g_seam[11] += 1;
         int rc = launch_inorder_p1(e, ln, 1, e->all_ids_dev + s); if (rc) return rc;
-        if ((rc = launch_report(e, s))) return rc;
+        if ((rc = launch_report(e, s, false))) return rc;
         if ((rc = wait_report(e, e->report_seq, true)) < 0) return rc;
     }
     ln.acq_needed = rp->counters[1] > 0;
@@ -999,6 +1017,8 @@ static int submit_step(nrsc5hip_engine *e, int s)
     if (sig != ln.set_sig) { ln.acq_needed = true; ln.px_needed = true; ln.set_sig = sig; }
     ln.prepared_by_sync = false;
     const auto t_enq = std::chrono::steady_clock::now();
+    if (e->ingest_dirty) { HIPCHK(hipEventRecord(e->ev_ingest, e->ingest)); HIPCHK(hipStreamWaitEvent(ln.main, e->ev_ingest, 0)); e->ingest_dirty = false; }
+    e->main_stepped = true;
     if (!e->counters_clean) HIPCHK(hipMemsetAsync(ln.counters_dev, 0, 4 * sizeof(int), ln.main));
     // A P1 frame completes only in a block that starts FINE with block count 15 (k_sync: started_pm && bc == 15; a block that
     // locks restarts the frame): when the stream's last record says otherwise the three decode launches are left out.
@@ -1011,9 +1031,9 @@ static int submit_step(nrsc5hip_engine *e, int s)
     } else {
         decode = !(known && e->pred_bc[s] != 15);
         if (!decode) g_seam[10] += 1;
-        int rc = issue_step(e, ln, 1, ids_dev, decode); if (rc) return rc;
+        int rc = issue_step(e, ln, 1, ids_dev, decode, false); if (rc) return rc;      // the PIDS frame is decoded by the report kernel
     }
-    { int rc = launch_report(e, s); if (rc) return rc; }
+    { int rc = launch_report(e, s, !am); if (rc) return rc; }
     g_seam[2] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enq).count();
     g_seam[6] += 1;
     e->inflight_stream = s; e->inflight_decoded = decode; e->inflight_rd_pred = -1;
@@ -1043,7 +1063,13 @@ static int stream_steps(nrsc5hip_engine *e, int s)
     return 0;
 }
 
-static int settle(nrsc5hip_engine *e) { return (e && e->inflight_stream >= 0) ? harvest(e, true) : 0; }
+static int settle(nrsc5hip_engine *e)
+{
+    if (!e) return 0;
+    if (e->inflight_stream >= 0) { int rc = harvest(e, true); if (rc) return rc; }
+    if (e->ingest_dirty) { HIPCHK(hipStreamSynchronize(e->ingest)); e->ingest_dirty = false; }    // whatever follows runs on `main` (or the host) alone
+    return 0;
+}
 
 // how many input BYTES of this format complete the stream's next block (the drop-in pushes exactly that much, so that the L2
 // feedback of the block's frames reaches the engine before the next block); -1: not known (the stream is not driven by the
@@ -1072,14 +1098,26 @@ static int flush_staged(nrsc5hip_engine *e)
     const unsigned count = cu8 ? (unsigned)chunk : (unsigned)(chunk / 2);
     e->staged_stream = -1; e->staged_bytes = 0; e->staged_q15 = 0;
     e->stage_slot ^= 1;                                        // the next pushes fill the other buffer
-    int rc = ensure_space(e, s, 0); if (rc) return rc;         // wr_host already counts the staged samples
+    const bool direct = cu8 && !am && e->direct_decimate;
+    if (!direct && e->ingest_dirty) {                          // the FIFO is appended to in submission order whichever stream does it
+        HIPCHK(hipEventRecord(e->ev_ingest, e->ingest)); HIPCHK(hipStreamWaitEvent(e->main, e->ev_ingest, 0)); e->ingest_dirty = false;
+    }
+    int rc = ensure_space(e, s, 0, direct); if (rc) return rc; // wr_host already counts the staged samples
     memcpy(e->stage_pin[slot], &count, sizeof(count));
-    HIPCHK(hipMemcpyAsync(e->stage_dev2[slot], e->stage_pin[slot], chunk + 16, hipMemcpyHostToDevice, e->main));
-    const int *ids_dev = e->all_ids_dev + s; const unsigned *count_dev = (const unsigned *)e->stage_dev2[slot]; const uint8_t *data_dev = e->stage_dev2[slot] + 16;
-    if (cu8 && am) launch_am_decimate_cu8(e->tb, e->db, 1, ids_dev, data_dev, 0, count_dev, count, e->main);
-    else if (cu8) launch_decimate_fm_cu8(e->tb, e->db, 1, ids_dev, data_dev, 0, count_dev, count, e->main);
-    else launch_append_cs16(e->db, 1, ids_dev, (const int16_t *)data_dev, 0, count_dev, count, e->main);
-    HIPCHK(hipEventRecord(e->stage_ev[slot], e->main)); e->stage_busy[slot] = true;
+    hipStream_t used = e->main;
+    if (direct) {
+        // FM cu8: the decimator reads the pinned buffer itself (one launch: no copy, no commit kernel), on the ingest stream
+        used = e->ingest;
+        launch_decimate_fm_cu8_stream(e->tb, e->db, s, e->stage_pin_dev[slot] + 16, (const unsigned *)e->stage_pin_dev[slot], count, e->decim_ticket, used);
+        e->ingest_dirty = true;
+    } else {
+        HIPCHK(hipMemcpyAsync(e->stage_dev2[slot], e->stage_pin[slot], chunk + 16, hipMemcpyHostToDevice, e->main));
+        const int *ids_dev = e->all_ids_dev + s; const unsigned *count_dev = (const unsigned *)e->stage_dev2[slot]; const uint8_t *data_dev = e->stage_dev2[slot] + 16;
+        if (cu8 && am) launch_am_decimate_cu8(e->tb, e->db, 1, ids_dev, data_dev, 0, count_dev, count, e->main);
+        else if (cu8) launch_decimate_fm_cu8(e->tb, e->db, 1, ids_dev, data_dev, 0, count_dev, count, e->main);
+        else launch_append_cs16(e->db, 1, ids_dev, (const int16_t *)data_dev, 0, count_dev, count, e->main);
+    }
+    HIPCHK(hipEventRecord(e->stage_ev[slot], used)); e->stage_busy[slot] = true;
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1119,6 +1157,8 @@ static int push_common(nrsc5hip_engine *e, int s, const void *host, size_t nbyte
                 if ((rc = flush_staged(e))) return rc;
                 if (e->manual_step[s] && nbytes_total == 0) break;     // samples are on their way to the FIFO; nrsc5hip_stream_step runs the block
                 if ((rc = stream_steps(e, s))) return rc;
+            } else if (e->early_flush && e->staged_bytes >= e->early_flush && cu8 && !am && e->direct_decimate) {
+                if ((rc = flush_staged(e))) return rc;         // ahead of the block's end, beside the step that is running
             }
             continue;
         }
@@ -1484,6 +1524,12 @@ extern "C" int nrsc5hip_p1_frame_packed(nrsc5hip_engine *e, int stream, int slot
     SeamClock clk(7);
     int rc = check_stream(e, stream); if (rc) return rc;
     if (slot < 0 || slot >= e->db.p1_slots || !words) FAIL(NRSC5HIP_EINVAL, "bad slot/argument");
+    if (e->mirror_ok[stream] && e->db.p1_mirror && e->frames_host && e->mode_host[stream] != MODE_AM) {
+        // fast seam (FM): the step that decoded the frame has been harvested (ON_ENGINE_DEVICE settles), and its traceback wrote the frame
+        // into the pinned mirror before the report kernel that the harvest waited for
+        memcpy(words, e->frames_host + ((size_t)stream * e->db.p1_slots + slot) * P1_WORDS, P1_WORDS * sizeof(uint32_t));
+        return 0;
+    }
     HIPCHK(hipStreamSynchronize(e->main));
     HIPCHK(hipMemcpy(words, e->db.p1_ring + ((size_t)stream * e->db.p1_slots + slot) * P1_WORDS, P1_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return 0;
@@ -1491,7 +1537,13 @@ extern "C" int nrsc5hip_p1_frame_packed(nrsc5hip_engine *e, int stream, int slot
 
 extern "C" void nrsc5hip_unpack_bits(const uint32_t *words, int nbits, uint8_t *bits)
 {
-    for (int i = 0; i < nbits; i++) bits[i] = (words[i >> 5] >> (i & 31)) & 1u;
+    // one byte of packed bits -> eight bytes through a table (a P1 frame is 146 176 bits: bit by bit this was ~0.1 ms of the drop-in's
+    // host time per frame)
+    static const struct Lut { uint64_t v[256]; Lut() { for (int b = 0; b < 256; b++) { uint64_t x = 0; for (int k = 0; k < 8; k++) x |= (uint64_t)((b >> k) & 1) << (8 * k); v[b] = x; } } } lut;
+    const uint8_t *src = (const uint8_t *)words;               // little-endian host: bit i of the frame = bit i % 8 of byte i / 8
+    int i = 0;
+    for (; i + 8 <= nbits; i += 8) memcpy(bits + i, &lut.v[src[i >> 3]], 8);
+    for (; i < nbits; i++) bits[i] = (words[i >> 5] >> (i & 31)) & 1u;
 }
 
 extern "C" int nrsc5hip_p1_frame_bits(nrsc5hip_engine *e, int stream, int slot, uint8_t *bits)
@@ -2052,7 +2104,7 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
     case NRSC5HIP_TUNE_DECODE_STREAMS:    e->naux = std::min(std::max(value, 1), NAUX); break;
     case NRSC5HIP_TUNE_AM_DECODE_STREAMS: e->naux_am = std::min(std::max(value, 1), NAUX); break;
     case NRSC5HIP_TUNE_VERDICT_LAG:       e->verdict_lag = std::min(std::max(value, 0), NWIN); break;
-    case NRSC5HIP_TUNE_FWD_SEGMENTS:      e->fwd_segments = std::min(std::max(value, 0), 16); break;
+    case NRSC5HIP_TUNE_FWD_SEGMENTS:      e->fwd_segments = std::min(std::max(value, 0), VIT3_GMAX); break;
     case NRSC5HIP_TUNE_FWD_WARM:          e->fwd_warm = value > 0 ? 2 : 0; break;
     case NRSC5HIP_TUNE_DECODE_CUS: {
         // decode streams confined to value / 32 of the CUs (the pattern keeps that share of every XCD whichever way mask bits map to CUs)
@@ -2082,7 +2134,10 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
         }
         break;
     }
+    case NRSC5HIP_TUNE_SYNC_LANES:        e->sync_lanes = (value == 256 || value == 768) ? value : 0; break;
+    case NRSC5HIP_TUNE_EARLY_FLUSH_KB:    e->early_flush = (size_t)std::max(value, 0) << 10; break;
     case NRSC5HIP_TUNE_DEFER_WAIT:        e->defer_wait = value != 0; break;
+    case NRSC5HIP_TUNE_DIRECT_DECIMATE:   e->direct_decimate = value != 0; break;
     case NRSC5HIP_TUNE_MIXFFT_SYMS:       e->mixfft_syms = (value == 2 || value == 4 || value == 8) ? value : 1; break;
     case NRSC5HIP_TUNE_AM_SEGMENTS:       e->am_segments = std::min(std::max(value, 1), K9_GMAX); break;
     case NRSC5HIP_TUNE_AM_WARM:           e->am_warm = value > 0 ? K9_WARM : 0; e->am_runin = value > 0 ? K9_TB_RUNIN : 0; break;

@@ -98,6 +98,81 @@ __global__ void k_decimate_commit(DevBuffers db, const int *ids, const uint8_t *
     st.wr += nsamp / 2;
 }
 
+// Streaming seam, one stream: the chunk is read WHERE THE HOST STAGED IT -- pinned, device-visible memory; a load from it crosses
+// PCIe, so every 16-byte word is fetched exactly once (by the lane that owns it, plus a two-word halo per workgroup) and handed
+// to its two right-hand neighbours through LDS.  No copy engine in the chain (hipMemcpyAsync + the dependency between the SDMA queue
+// and the compute queue cost ~10 us + 2 x ~9 us per block, profiles/r04_dropin_timeline.txt), no second device buffer.  The
+// workgroup that finishes LAST rolls the 14-sample history and publishes the new write position (k_decimate_commit's job: every
+// other workgroup has read st.wr / st.hb_hist by then), so the chunk costs one launch.
+__global__ __launch_bounds__(256) void k_decimate_fm_cu8_stream(DevTables tb, DevBuffers db, int s, const uint8_t *iq, const unsigned *nbytes, unsigned *ticket)
+{
+    StreamState &st = db.state[s];
+    const unsigned nb = *nbytes;
+    const unsigned nout = nb / 4;                              // outputs in this chunk
+    const unsigned g0 = blockIdx.x * 256u, g = g0 + threadIdx.x;   // group of 4 outputs = input word g (16 bytes: samples 8g .. 8g+7)
+    __shared__ uint4 tile[256 + 2];
+    __shared__ int last_block;
+    const uint4 *v = (const uint4 *)iq;
+    const bool whole = 16ull * (g + 1) <= nb;                  // the word lies inside the chunk
+    if (whole) tile[threadIdx.x + 2] = v[g];
+    if (threadIdx.x < 2 && g0 >= 2) tile[threadIdx.x] = v[g0 - 2 + threadIdx.x];
+    __syncthreads();
+    if (4u * g < nout) {
+        c16 *out = db.q15 + (size_t)s * db.q15_cap + (st.wr - st.base);
+        const int t0 = tb.hb_q15[0], t1 = tb.hb_q15[1], t2 = tb.hb_q15[2], t3 = tb.hb_q15[3];
+        int wr_[21], wi_[21];
+        if (g >= 2 && whole) {
+            const uint4 a = tile[threadIdx.x], b = tile[threadIdx.x + 1], c = tile[threadIdx.x + 2];   // samples 8g-16 .. 8g+7
+            const unsigned w[12] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w };
+#pragma unroll
+            for (int k = 0; k < 21; k++) {                     // sample 8g-14+k = word-stream sample k+2
+                const int q = k + 2;
+                const unsigned pair = (w[q >> 1] >> ((q & 1) * 16)) & 0xffffu;
+                wr_[k] = q15_of_u8(pair & 0xff); wi_[k] = q15_of_u8(pair >> 8);
+            }
+        } else {                                               // the chunk's first two groups (history) and a ragged last one
+#pragma unroll
+            for (int k = 0; k < 21; k++) {
+                long long idx = (long long)8 * g - 14 + k;
+                if (idx < (long long)2 * nout) fetch_q15(iq, st.hb_hist, idx, wr_[k], wi_[k]);
+                else { wr_[k] = 0; wi_[k] = 0; }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            if (4u * g + m < nout) {
+                c16 y;
+                y.r = (int16_t)hb_dot(wr_ + 2 * m, t0, t1, t2, t3);
+                y.i = (int16_t)hb_dot(wi_ + 2 * m, t0, t1, t2, t3);
+                out[4 * g + m] = y;
+            }
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) last_block = (atomicAdd(ticket, 1u) == gridDim.x - 1) ? 1 : 0;
+    __syncthreads();
+    if (!last_block || threadIdx.x != 0) return;
+    __threadfence();
+    *ticket = 0;
+    const long long nsamp = nb / 2;                            // complex input samples (even)
+    if (nsamp == 0) return;
+    c16 nh[14];
+    for (int k = 0; k < 14; k++) {
+        int r, i;
+        fetch_q15(iq, st.hb_hist, nsamp - 14 + k, r, i);
+        nh[k].r = (int16_t)r; nh[k].i = (int16_t)i;
+    }
+    for (int k = 0; k < 14; k++) st.hb_hist[k] = nh[k];
+    st.wr += nsamp / 2;
+}
+
+void launch_decimate_fm_cu8_stream(const DevTables &tb, const DevBuffers &db, int s, const uint8_t *iq, const unsigned *nbytes, unsigned max_nbytes, unsigned *ticket, hipStream_t st)
+{
+    const unsigned groups = (max_nbytes / 4 + 3) / 4;
+    hipLaunchKernelGGL(k_decimate_fm_cu8_stream, dim3(groups ? (groups + 255) / 256 : 1), dim3(256), 0, st, tb, db, s, iq, nbytes, ticket);
+}
+
 void launch_decimate_fm_cu8(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids,
                             const uint8_t *iq_base, long long iq_stride, const unsigned *nbytes, unsigned max_nbytes,
                             hipStream_t st)

@@ -51,12 +51,18 @@ __device__ inline uint32_t costas_block(const float2 *src, int stride, float &fr
     const float cfo_freq = (float)(2 * M_PI * cfo * CP_N / FFT_N);
     uint32_t pos = 0, neg = 0;
     float x = 0.0f;
-    float2 zin[NSYM];
+    // STORE (the tracking call): the carrier's 32 bins wait in LDS -- the workgroup brought them in together, into the very cells
+    // that receive the derotated values (zout == src, stride 1) -- and the loop, unrolled in full, reads one symbol ahead: as 32
+    // prefetched registers per lane they made this the kernel's register peak (120 VGPRs x 3 waves per SIMD: the 12-wave workgroup
+    // no longer fitted beside the decode waves that share its CU).  The search variant keeps four bins in flight in four named
+    // registers and a rolled loop: indexed dynamically an array lands in scratch memory -- a load per symbol on the serial chain,
+    // and a private segment that every launch of the kernel pays for.
+    constexpr int NZ = STORE ? 1 : 4;
+    float2 zin[NZ];
 #pragma unroll
-    for (int n = 0; n < NSYM; n++) zin[n] = src[n * stride];   // 32 independent loads in flight
+    for (int n = 0; n < NZ; n++) zin[n] = src[n * stride];     // independent loads in flight
     float s1, c1; fast_sincos(phase, s1, c1);                  // cexpf(-I phase), see fastmath.h; the next symbol's at the end of each step
-    auto step = [&](int n) __attribute__((always_inline)) {
-        const float2 z = zin[n];
+    auto step = [&](int n, const float2 z) __attribute__((always_inline)) {
         const float s2 = 2.0f * s1 * c1, c2 = c1 * c1 - s1 * s1;                // e^{2i phase}
         const float2 w = make_float2(z.x * z.x - z.y * z.y, z.x * z.y + z.y * z.x);
         const float ur = w.x * c2 + w.y * s2, ui = w.y * c2 - w.x * s2;         // w * e^{-2i phase}
@@ -65,8 +71,10 @@ __device__ inline uint32_t costas_block(const float2 *src, int stride, float &fr
         if (STORE) { zout[n] = zr; phout[n] = phase; }
         if (zr.x > 0) pos |= 1u << n;
         if (zr.x < 0) neg |= 1u << n;
-        const float sgn = ((PAT_POS >> n) & 1u) ? 1.0f : (((PAT_NEG >> n) & 1u) ? -1.0f : 0.0f);
-        x += zr.x * sgn;
+        if (!STORE) {
+            const float sgn = ((PAT_POS >> n) & 1u) ? 1.0f : (((PAT_NEG >> n) & 1u) ? -1.0f : 0.0f);
+            x += zr.x * sgn;
+        }
         freq += g.beta * error;
         if (freq > 0.5f) freq = 0.5f;
         if (freq < -0.5f) freq = -0.5f;
@@ -89,13 +97,29 @@ __device__ inline uint32_t costas_block(const float2 *src, int stride, float &fr
         }
     };
     if (STORE) {
-        // the tracking call: unrolled in full, so that the 32 prefetched bins live in registers (with a partial unroll the array
-        // is indexed dynamically and lands in scratch memory: a load per symbol on the serial chain)
 #pragma unroll
-        for (int n = 0; n < NSYM; n++) step(n);
+        for (int n = 0; n < NSYM; n++) {
+            const float2 z = zin[0];
+            if (n + 1 < NSYM) zin[0] = src[(n + 1) * stride];  // before this step's store to zout[n]: the next symbol's bin
+            step(n, z);
+        }
+        // the sync-word correlation from the stored values, same terms in the same order (a zero weight adds +-0 to a sum that
+        // starts at +0): accumulated inside the unrolled loop the compiler kept the 15 operands alive to the end -- in scratch
+#pragma unroll
+        for (int n = 0; n < NSYM; n++) {
+            if ((PAT_POS >> n) & 1u) x += zout[n].x;
+            else if ((PAT_NEG >> n) & 1u) x -= zout[n].x;
+        }
     } else {
-#pragma unroll 4
-        for (int n = 0; n < NSYM; n++) step(n);
+#pragma unroll 1
+        for (int n = 0; n < NSYM; n += 4) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float2 z = zin[j];
+                if (n + 4 < NSYM) zin[j] = src[(n + 4 + j) * stride];     // four symbols ahead
+                step(n + j, z);
+            }
+        }
     }
     if (x < 0) {                                               // off by pi: flip (sync.c:119-129)
         if (STORE) for (int n = 0; n < NSYM; n++) { phout[n] = (float)((double)phout[n] + M_PI); zout[n] = make_float2(-zout[n].x, -zout[n].y); }
@@ -191,10 +215,25 @@ __device__ __forceinline__ void store_px(int8_t *pair, float2 v, int side, int p
     *(char2 *)(pair + (size_t)ch * 2 * PX_MAX + odd * len + n * per_sym + idx) = o;
 }
 
-__global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare, int window)
+// Work-items per stream (template parameter; launch_sync picks).  768 = 12 waves, three per SIMD: the equaliser cells of MP1 divide
+// evenly (11520 = 768 x 15) and the three resident waves hide each other's LDS / memory latency -- with 256 (one wave per SIMD, 45
+// cells each) the equalising and soft-bit phases ran at the latency of one dependent chain: 24 k + 11 k shader cycles per block
+// for ~6 k of issue work; a lone stream's block went from 38 to 25 us.  Inside a full batch the 12-wave workgroup has to find three
+// free wave slots on every SIMD of a CU beside the decode waves (a 16-wave traceback workgroup + the forward pass' waves): it
+// often waits -- the workgroup itself needs 30 us there, the launch 62 (profiles/r04_sync_lanes.txt) -- so large stream sets keep
+// the narrow form, which fits anywhere.
+// <= 80 VGPRs for the wide form (six waves per SIMD's worth): three of its waves and four traceback waves (64 VGPRs each) share a
+// SIMD's 512 registers.
+#ifndef HIPEMU
+#define SYNC_OCCUPANCY(NT) __attribute__((amdgpu_waves_per_eu((NT) > 512 ? 6 : 1, (NT) > 512 ? 6 : 8)))
+#else
+#define SYNC_OCCUPANCY(NT)
+#endif
+template <int SYNC_NT>
+__global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare, int window)
 {
     wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
-    const int s = stream_of(ids, blockIdx.x);
+    const int s = wave_uniform(stream_of(ids, blockIdx.x));    // in a scalar register: every address derived from it stays off the VGPR budget
     StreamState &st = db.state[s];
     if (!st.active) {                                          // block-uniform
         // no block this step; with the fused pipeline the stream may have become ready since (new samples).  Fused steps
@@ -202,9 +241,13 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         if (fuse_prepare && threadIdx.x == 0) prepare_block(db, st, s, false);
         return;
     }
+    constexpr int SYNC_NW = SYNC_NT / 64;
     const int tid = threadIdx.x;
-    long long tstamp = (db.sync_phase_cycles && s == 0 && tid == 0) ? (long long)clock64() : 0;
-#define SYNC_MARK(i) do { if (db.sync_phase_cycles && s == 0 && tid == 0) { const long long now = (long long)clock64(); db.sync_phase_cycles[i] += now - tstamp; tstamp = now; } } while (0)
+    // phase instrumentation (nrsc5hip_debug_sync_phases): the running time stamp lives in LDS -- as a variable it was a register pair
+    // alive across the whole kernel, spilled and reloaded around every barrier
+    __shared__ long long sh_tstamp;
+    if (db.sync_phase_cycles && s == 0 && tid == 0) sh_tstamp = (long long)clock64();
+#define SYNC_MARK(i) do { if (db.sync_phase_cycles && s == 0 && tid == 0) { const long long now = (long long)clock64(); db.sync_phase_cycles[i] += now - sh_tstamp; sh_tstamp = now; } } while (0)
 
     // One LDS region, two lives: the reference-carrier scratch of the tracking and equalising phases, then -- once the last
     // equalised cell sits in a register (barrier after the MER sums) -- the block's soft-bit rows on their way to the matrix.
@@ -221,7 +264,9 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
     __shared__ int ref_ok[NREF_MAX], ref_bc[NREF_MAX], ref_psmi[NREF_MAX];
     __shared__ int sh_i[8];
     __shared__ float sh_f[8];
-    __shared__ double red[2][4];
+    __shared__ double red[2][SYNC_NW];
+    __shared__ float sh_diff[2 * 14];
+    __shared__ int sh_seen[16 + 64];
     __shared__ float ref_freq[NREF_MAX];
     if (tid == 0) sh_i[2] = 0;                                 // set when this block completes a P1 frame (replay checkpoint below)
 
@@ -235,11 +280,13 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
     // ---- sync_adjust (sync.c:769-777): timing pick moved by adj samples -> rotate every loop phase
     {
         const int adj = SYM_N / 2 - samperr;
-        for (int l = tid; l < LIVE_N; l += 256) {
+        for (int l = tid; l < LIVE_N; l += SYNC_NT) {
             const int b = live_to_bin(l);
             st.costas_phase[l] = (float)((double)st.costas_phase[l] - (adj * (b - FFT_N / 2)) * 2 * M_PI / FFT_N);
         }
     }
+    // the active reference carriers' bins -> refz[r][n] (the Costas loops below derotate them in place)
+    for (int k = tid; k < nref * NSYM; k += SYNC_NT) refz[k / NSYM][k % NSYM] = bins[(k % NSYM) * LIVE_N + bin_to_live(ref_bin(k / NSYM))];
     __syncthreads();
     SYNC_MARK(0);
 
@@ -247,8 +294,12 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
     if (tid < nref) {
         const int l = bin_to_live(ref_bin(tid));
         float f = st.costas_freq[l], p = st.costas_phase[l];
-        costas_block<true>(bins + l, LIVE_N, f, p, 0, g, refz[tid], refph[tid]);
-        st.costas_freq[l] = f; st.costas_phase[l] = p;
+        costas_block<true>(refz[tid], 1, f, p, 0, g, refz[tid], refph[tid]);     // in place: refz holds the carrier's raw bins
+        int l2 = l;
+#ifndef HIPEMU
+        asm volatile("" : "+v"(l2));                           // the address is computed again instead of surviving the loops in a (spilled) register pair
+#endif
+        st.costas_freq[l2] = f; st.costas_phase[l2] = p;
         ref_freq[tid] = f;
     }
     __syncthreads();
@@ -269,7 +320,8 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         }
         __syncthreads();
         if (tid == 0) {
-            int good = 0, seen_bc[16], seen_psmi[64];
+            int good = 0;
+            int *seen_bc = sh_seen, *seen_psmi = sh_seen + 16;  // LDS: indexed by decoded values (as private arrays they were scratch memory)
             for (int k = 0; k < 16; k++) seen_bc[k] = 0;
             for (int k = 0; k < 64; k++) seen_psmi[k] = 0;
             for (int r = 0; r < nref; r++) if (ref_ok[r]) { good++; seen_bc[ref_bc[r]]++; seen_psmi[ref_psmi[r]]++; }
@@ -300,59 +352,55 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
             // ---- detect_cfo (sync.c:292-337): every candidate offset x every reference position.
             // Lane = live bin; a bin is visited by at most 11 (cfo, i) pairs, in ascending cfo order,
             // and each visit advances that bin's loop state exactly as adjust_ref does.
-            for (int k = tid; k < (CFO_HI - CFO_LO) * 22; k += 256) (&cfo_offs[0][0])[k] = -1;
+            for (int k = tid; k < (CFO_HI - CFO_LO) * 22; k += SYNC_NT) (&cfo_offs[0][0])[k] = -1;
             __syncthreads();
-            float snap_f[3][11], snap_p[3][11];
-            int snap_cfo[3][11], snap_n[3];
-            for (int pass = 0; pass < 3; pass++) {
-                const int l = tid + 256 * pass;
-                snap_n[pass] = 0;
-                if (l >= LIVE_N) continue;
-                const int b = live_to_bin(l);
-                const bool lower = l < LIVE_HALF;
-                float f = st.costas_freq[l], p = st.costas_phase[l];
-                // is this bin one of the already-derotated active references?
-                int rslot = -1;
-                if (lower) { if ((b - LB0) % PW == 0 && (b - LB0) / PW <= ppb) rslot = 2 * ((b - LB0) / PW); }
-                else { if ((UB1 - b) % PW == 0 && (UB1 - b) / PW <= ppb) rslot = 2 * ((UB1 - b) / PW) + 1; }
-                for (int q = 0; q <= PM_PART; q++) {
-                    const int i = lower ? (PM_PART - q) : q;   // ascending cfo
-                    const int cfo = lower ? (b - LB0 - PW * i) : (b - UB1 + PW * i);
-                    if (cfo < CFO_LO || cfo >= CFO_HI) continue;
-                    uint32_t d;
-                    if (rslot >= 0) d = costas_block<false>(&refz[rslot][0], 1, f, p, cfo, g, nullptr, nullptr);
-                    else d = costas_block<false>(bins + l, LIVE_N, f, p, cfo, g, nullptr, nullptr);
-                    cfo_offs[cfo - CFO_LO][2 * i + (lower ? 0 : 1)] = (int8_t)needle_search(d, (30 - i) & 3);
-                    const int k = snap_n[pass]++;
-                    snap_f[pass][k] = f; snap_p[pass][k] = p; snap_cfo[pass][k] = cfo;
-                }
-            }
-            __syncthreads();
-            if (tid == 0) {
-                int found = 0x7fffffff;
-                for (int c = 0; c < CFO_HI - CFO_LO && found == 0x7fffffff; c++) {
-                    int count[NSYM];
-                    for (int k = 0; k < NSYM; k++) count[k] = 0;
-                    for (int r = 0; r < 22; r++) if (cfo_offs[c][r] >= 0) count[cfo_offs[c][r]]++;
-                    int best = -1, best_count = 0;
-                    for (int k = 0; k < NSYM; k++) if (count[k] > best_count) { best = k; best_count = count[k]; }
-                    if (best >= 0 && best_count >= 3) {
-                        st.keep_extra = ((NSYM - best) % NSYM) * SYM_N;      // acquire_keep_extra
-                        st.cfo += c + CFO_LO;                                 // acquire_cfo_adjust
-                        st.cfo_wait = 8;
-                        found = c + CFO_LO;
+            // Two passes over the same visits instead of a snapshot per visit (snapshots indexed by a running count lived in scratch
+            // memory, and the private segment was paid for by EVERY launch of this kernel): pass 0 files the needle offsets and the
+            // first workgroup-wide match decides where the search stops; pass 1 repeats the visits up to that candidate from the
+            // saved loop state -- the search runs a handful of times per acquisition.
+            for (int pass = 0; pass < 2; pass++) {
+                const int last_cfo = pass ? sh_i[1] : 0x7fffffff;  // pass 1: visits with cfo <= last_cfo happened
+                for (int l = tid; l < LIVE_N; l += SYNC_NT) {
+                    const int b = live_to_bin(l);
+                    const bool lower = l < LIVE_HALF;
+                    float f = st.costas_freq[l], p = st.costas_phase[l];   // untouched by pass 0
+                    // is this bin one of the already-derotated active references?
+                    int rslot = -1;
+                    if (lower) { if ((b - LB0) % PW == 0 && (b - LB0) / PW <= ppb) rslot = 2 * ((b - LB0) / PW); }
+                    else { if ((UB1 - b) % PW == 0 && (UB1 - b) / PW <= ppb) rslot = 2 * ((UB1 - b) / PW) + 1; }
+                    const float2 *src = rslot >= 0 ? (const float2 *)&refz[rslot][0] : (const float2 *)(bins + l);
+                    const int stride = rslot >= 0 ? 1 : LIVE_N;
+                    bool visited = false;
+                    for (int q = 0; q <= PM_PART; q++) {
+                        const int i = lower ? (PM_PART - q) : q;   // ascending cfo
+                        const int cfo = lower ? (b - LB0 - PW * i) : (b - UB1 + PW * i);
+                        if (cfo < CFO_LO || cfo >= CFO_HI || cfo > last_cfo) continue;
+                        const uint32_t d = costas_block<false>(src, stride, f, p, cfo, g, nullptr, nullptr);
+                        visited = true;
+                        if (pass == 0) cfo_offs[cfo - CFO_LO][2 * i + (lower ? 0 : 1)] = (int8_t)needle_search(d, (30 - i) & 3);
                     }
+                    if (pass == 1 && visited) { st.costas_freq[l] = f; st.costas_phase[l] = p; }
                 }
-                sh_i[1] = found;
-            }
-            __syncthreads();
-            const int last_cfo = sh_i[1];                      // visits with cfo <= last_cfo happened
-            for (int pass = 0; pass < 3; pass++) {
-                const int l = tid + 256 * pass;
-                if (l >= LIVE_N) continue;
-                int k = snap_n[pass] - 1;
-                while (k >= 0 && snap_cfo[pass][k] > last_cfo) k--;
-                if (k >= 0) { st.costas_freq[l] = snap_f[pass][k]; st.costas_phase[l] = snap_p[pass][k]; }
+                if (pass == 1) break;
+                __syncthreads();
+                if (tid == 0) {
+                    int found = 0x7fffffff;
+                    for (int c = 0; c < CFO_HI - CFO_LO && found == 0x7fffffff; c++) {
+                        int *count = sh_seen;
+                        for (int k = 0; k < NSYM; k++) count[k] = 0;
+                        for (int r = 0; r < 22; r++) if (cfo_offs[c][r] >= 0) count[cfo_offs[c][r]]++;
+                        int best = -1, best_count = 0;
+                        for (int k = 0; k < NSYM; k++) if (count[k] > best_count) { best = k; best_count = count[k]; }
+                        if (best >= 0 && best_count >= 3) {
+                            st.keep_extra = ((NSYM - best) % NSYM) * SYM_N;      // acquire_keep_extra
+                            st.cfo += c + CFO_LO;                                 // acquire_cfo_adjust
+                            st.cfo_wait = 8;
+                            found = c + CFO_LO;
+                        }
+                    }
+                    sh_i[1] = found;
+                }
+                __syncthreads();
             }
         }
         __syncthreads();
@@ -366,7 +414,7 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         // the top of sync_process_fm, sync.c:343-358) but already routes PX soft bits by the new one (sync.c:537-596).
         const int ppb_px = routed_partitions_for_psmi(st.psmi);
         const bool px_on = ppb_px > PM_PART && (st.px_started || (bc & 1) == 0);   // decode_push_px1/2 (decode.c:393-437)
-        for (int k = tid; k < nref * NSYM; k += 256) {
+        for (int k = tid; k < nref * NSYM; k += SYNC_NT) {
             const int r = k / NSYM, n = k % NSYM;
             float sn, cs; fast_sincos(refph[r][n], sn, cs);
             refcs[r][n] = make_float2(cs, sn);
@@ -376,16 +424,18 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
             for (int n = 0; n < NSYM; n++) sum += fabsf(refz[tid][n].x);
             smag[tid] = sum / NSYM;
         }
+        if (tid >= 64 && tid < 64 + ppb) {                     // the phase differences of the timing estimate below, one partition per lane
+            const int i = tid - 64;
+            sh_diff[2 * i] = half_turn_diff(refph[2 * i][0], refph[2 * (i + 1)][0]);
+            sh_diff[2 * i + 1] = half_turn_diff(refph[2 * (i + 1) + 1][0], refph[2 * i + 1][0]);
+        }
         __syncthreads();
 
         if (tid == 0) {
             // timing error from the phase slope across each partition, residual CFO from the loop
             // frequencies (sync.c:426-463); same summation order as the reference
             float se = 0.0f, angle = 0.0f, sum_xy = 0.0f, sum_x2 = 0.0f;
-            for (int i = 0; i < ppb; i++) {
-                se += half_turn_diff(refph[2 * i][0], refph[2 * (i + 1)][0]);
-                se += half_turn_diff(refph[2 * (i + 1) + 1][0], refph[2 * i + 1][0]);
-            }
+            for (int i = 0; i < 2 * ppb; i++) se += sh_diff[i];
             se = (float)(se / (ppb * 2) * FFT_N / PW / (2 * M_PI));
             for (int i = 0; i <= ppb; i++) {
                 float x = (float)(LB0 + PW * i - FFT_N / 2), y = ref_freq[2 * i];
@@ -404,17 +454,20 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         SYNC_MARK(3);
 
         // cell (side, part, n, k): data carrier k = 1..18 of partition `part` (counted from the band edge);
-        // lane tid owns cells c = tid + 256 i.  MP1 (10 partitions, 45 cells per lane) keeps the equalised values
+        // lane tid owns cells c = tid + SYNC_NT i.  MP1 (10 partitions, 15 or 45 cells per lane) keeps the equalised values
         // in registers between the MER pass and the soft-bit pass; the wider service modes recompute them.
         const int ncell = 2 * ppb * NSYM * 18;
-        constexpr int MP1C = 2 * PM_PART * NSYM * 18 / 256;                     // 45 exactly
+        constexpr int MP1C = 2 * PM_PART * NSYM * 18 / SYNC_NT;                 // 15 (768 work-items) or 45 (256)
+        static_assert(MP1C * SYNC_NT == 2 * PM_PART * NSYM * 18, "the MP1 cells divide evenly over the work-items");
         float2 cellv[MP1C];
         double e_lb = 0.0, e_ub = 0.0;
         if (ppb == PM_PART) {
-            // operands from the cell table (DevTables::eq_cell), all 45 bins of the lane requested before the first is used
+            // operands from the cell table (DevTables::eq_cell), all 15 bins of the lane requested before the first is used.
+            // (Requested before the Costas loops and held across them they cost 30 VGPRs that the 80-register budget does not
+            // have: the compiler spilled every one of them.)
             uint32_t cw[MP1C];
 #pragma unroll
-            for (int i = 0; i < MP1C; i++) cw[i] = tb.eq_cell[tid + 256 * i];
+            for (int i = 0; i < MP1C; i++) cw[i] = tb.eq_cell[tid + SYNC_NT * i];
 #pragma unroll
             for (int i = 0; i < MP1C; i++) cellv[i] = bins[((cw[i] >> 10) & 31u) * LIVE_N + (cw[i] & 1023u)];
 #pragma unroll
@@ -432,7 +485,7 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
                 if (w >> 30) e_ub += e; else e_lb += e;
             }
         } else {
-            for (int c = tid; c < ncell; c += 256) {
+            for (int c = tid; c < ncell; c += SYNC_NT) {
                 int side;
                 const float e = cell_error(equalise_cell<0>(c, ppb, bins, refcs, smag, side));
                 if (side) e_ub += e; else e_lb += e;
@@ -442,8 +495,9 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         if ((tid & 63) == 0) { red[0][tid >> 6] = e_lb; red[1][tid >> 6] = e_ub; }
         __syncthreads();
         if (tid == 0) {
-            const float error_lb = (float)(red[0][0] + red[0][1] + red[0][2] + red[0][3]);
-            const float error_ub = (float)(red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+            double sl = 0.0, su = 0.0;
+            for (int w = 0; w < SYNC_NW; w++) { sl += red[0][w]; su += red[1][w]; }
+            const float error_lb = (float)sl, error_ub = (float)su;
             st.error_lb += error_lb; st.error_ub += error_ub;
             if (++st.mer_cnt == 16) {                          // EVENT_MER every 16 blocks (sync.c:490-501)
                 const float signal = (float)(2 * NSYM * (ppb * 18) * st.mer_cnt);
@@ -471,15 +525,15 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
             // six coalesced stores per lane instead of 45 scattered two-byte ones
 #pragma unroll
             for (int i = 0; i < MP1C; i++) {
-                const int c = tid + 256 * i;
+                const int c = tid + SYNC_NT * i;
                 const float mult = c >= ncell / 2 ? mult_ub : mult_lb;              // cells of the upper sideband come second
                 char2 o; o.x = (signed char)soft_bit(cellv[i].x, mult); o.y = (signed char)soft_bit(cellv[i].y, mult);
                 *(char2 *)(pm_tile + tb.eq_out[c]) = o;
             }
             __syncthreads();
-            for (int q = tid; q < PM_BLOCK / 16; q += 256) ((uint4 *)pm_blk)[q] = ((const uint4 *)pm_tile)[q];
+            for (int q = tid; q < PM_BLOCK / 16; q += SYNC_NT) ((uint4 *)pm_blk)[q] = ((const uint4 *)pm_tile)[q];
         } else {
-            for (int c = tid; c < ncell; c += 256) {
+            for (int c = tid; c < ncell; c += SYNC_NT) {
                 int k, n, part, side;
                 cell_coords<0>(c, ppb, side, part, n, k);
                 if (part < PM_PART) store_soft(pm_blk, equalise_cell<0>(c, ppb, bins, refcs, smag, side), side, part, n, k, mult_lb, mult_ub);
@@ -489,7 +543,7 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         if (px_on && ppb_px > ppb) {
             // lock block only: extended partitions that were not equalised yet -- the reference demodulates the raw bins
             const int p0 = ppb > PM_PART ? ppb : PM_PART, np = ppb_px - p0;
-            for (int c = tid; c < 2 * np * NSYM * 18; c += 256) {
+            for (int c = tid; c < 2 * np * NSYM * 18; c += SYNC_NT) {
                 const int k = 1 + c % 18, n = (c / 18) % NSYM, part = p0 + (c / (18 * NSYM)) % np, side = c / (18 * NSYM * np);
                 const int b = (side ? UB1 - PW * (part + 1) : LB0 + PW * part) + k;
                 store_px(db.px_pair + (size_t)s * 4 * PX_MAX, bins[n * LIVE_N + bin_to_live(b)], side, part, n, k, ppb_px, bc & 1, mult_lb, mult_ub);
@@ -503,8 +557,8 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         // k_pids_decode, off this kernel's critical path (results only feed the record, not the loops)
         int8_t *stage = db.pids_stage + (((size_t)s * NWIN + parity) * 16 + slot) * (3 * PIDS_LEN);
         const int8_t *pm_src = ppb == PM_PART ? pm_tile : pm_blk;      // MP1: the rows are still in LDS
-        for (int n = tid; n < PIDS_CODED; n += 256) stage[n + n / 5] = pm_src[tb.pids_gather[bc * PIDS_CODED + n]];
-        for (int n = tid; n < PIDS_CODED / 5; n += 256) stage[6 * n + 5] = 0;
+        for (int n = tid; n < PIDS_CODED; n += SYNC_NT) stage[n + n / 5] = pm_src[tb.pids_gather[bc * PIDS_CODED + n]];
+        for (int n = tid; n < PIDS_CODED / 5; n += SYNC_NT) stage[6 * n + 5] = 0;
         SYNC_MARK(6);
         if (tid == 0) {
             db.pids_rec[((size_t)s * NWIN + parity) * 16 + slot] = st.nblocks % db.rec_cap;
@@ -541,21 +595,30 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
     }
     __syncthreads();
 
-    // ---- end of acquire_process (acquire.c:259-262) + record
-    if (tid == 0) {
-        const int keep = SYM_N + (SYM_N / 2 - samperr) + st.keep_extra;
-        st.keep_extra = 0;
-        st.rd += WIN_N - keep;
+    // ---- end of acquire_process (acquire.c:259-262) + record.  Two lanes of different waves share the work: the NCO phase with
+    // its double-precision sine / cosine (a diagnostic of the record) on one, the FIFO / counters / record on the other, each with
+    // its state loads issued together (a load behind every store of the other kind cost an L2 round trip apiece)
+    if (tid == 64) {
         double th = st.theta + (double)NSYM * SYM_N * st.dtheta;
         th -= 2 * M_PI * rint(th / (2 * M_PI));
         st.theta = th;
-        rec.state_after = st.sync_state; rec.samperr = samperr; rec.cfo = st.cfo; rec.keep = keep;
-        rec.bc = st.bc; rec.psmi = st.psmi; rec.cfo_wait = st.cfo_wait; rec.next_samperr = st.samperr;
-        rec.prev_angle = st.prev_angle; rec.phase_re = (float)cos(th); rec.phase_im = (float)sin(th);
-        rec.next_angle = st.angle;
-        st.nblocks++;
+        rec.phase_re = (float)cos(th); rec.phase_im = (float)sin(th);
+    }
+    if (tid == 0) {
+        const int keep_extra = st.keep_extra, state = st.sync_state, cfo = st.cfo, bc_now = st.bc, psmi = st.psmi, cfo_wait = st.cfo_wait, next_samperr = st.samperr, nblocks = st.nblocks;
+        const long long rd = st.rd;
+        const float prev_angle = st.prev_angle, next_angle = st.angle;
+        const int keep = SYM_N + (SYM_N / 2 - samperr) + keep_extra;
+        st.keep_extra = 0;
+        st.rd = rd + (WIN_N - keep);
+        rec.state_after = state; rec.samperr = samperr; rec.cfo = cfo; rec.keep = keep;
+        rec.bc = bc_now; rec.psmi = psmi; rec.cfo_wait = cfo_wait; rec.next_samperr = next_samperr;
+        rec.prev_angle = prev_angle;
+        rec.next_angle = next_angle;
+        st.nblocks = nblocks + 1;
         st.active = 0;
     }
+    if (fuse_prepare && !db.ckpt) { __threadfence_block(); __syncthreads(); }     // block-uniform: the next block's bookkeeping reads the NCO phase
     if (db.ckpt) {                                             // block-uniform: window pipeline with the on-device L2 feedback
         // Replay checkpoint.  The reference judges a P1 frame's first L2 header inside this block (frame.c:535-540) and starts
         // the next one from SYNC_STATE_NONE when it fails; here the verdict comes from the deferred decode, windows later.
@@ -565,7 +628,7 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
         if (sh_i[2]) {
             const uint32_t *src = (const uint32_t *)&st;
             uint32_t *dst = (uint32_t *)(db.ckpt + (size_t)s * NWIN + parity);
-            for (int k = tid; k < (int)(sizeof(StreamState) / 4); k += 256) dst[k] = src[k];
+            for (int k = tid; k < (int)(sizeof(StreamState) / 4); k += SYNC_NT) dst[k] = src[k];
         }
         __syncthreads();
     }
@@ -573,27 +636,27 @@ __global__ __launch_bounds__(256) void k_sync(DevTables tb, DevBuffers db, const
     SYNC_MARK(7);
 }
 
-void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, int window, hipStream_t st)
+void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, int window, hipStream_t st, int lanes)
 {
-    hipLaunchKernelGGL(k_sync, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window);
+    // lanes: 0 = by the size of the stream set (see SYNC_OCCUPANCY above), else 256 / 768 (nrsc5hip_debug_tune NRSC5HIP_TUNE_SYNC_LANES)
+    const int nt = lanes ? lanes : (nstreams <= 64 ? 768 : 256);
+    if (nt == 768) hipLaunchKernelGGL(k_sync<768>, dim3(nstreams), dim3(768), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window);
+    else hipLaunchKernelGGL(k_sync<256>, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window);
 }
 
 // ---- deferred PIDS decode: one wave per (slot, stream) with a staged frame -----------------------------------
-__global__ __launch_bounds__(64) void k_pids_decode(DevTables tb, DevBuffers db, const int *ids, int parity)
+// called by the 64 lanes of one wave; LDS scratch from the caller
+__device__ __forceinline__ void pids_decode_wave(const DevTables &tb, const DevBuffers &db, int s, int parity, int slot, int8_t *coded, unsigned long long *dec, uint32_t *out)
 {
-    const int s = stream_of(ids, blockIdx.y), slot = blockIdx.x;
     int *recp = db.pids_rec + ((size_t)s * NWIN + parity) * 16 + slot;
     const int r = *recp;
     if (r < 0) return;                                         // wave-uniform
-    __shared__ int8_t coded[3 * PIDS_LEN];
-    __shared__ unsigned long long dec[PIDS_LEN + 64];
-    __shared__ uint32_t out[4];
     const int8_t *stage = db.pids_stage + (((size_t)s * NWIN + parity) * 16 + slot) * (3 * PIDS_LEN);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     for (int n = lane; n < 3 * PIDS_LEN; n += 64) coded[n] = stage[n];
-    __syncthreads();
-    viterbi_k7_wave(coded, PIDS_LEN, dec, out);
-    __syncthreads();
+    WAVE_LDS_SYNC();
+    viterbi_k7_decode(coded, PIDS_LEN, dec, out);              // 80 bits: the rotating-layout trellis with a 16-step last chunk
+    WAVE_LDS_SYNC();
     if (lane == 0) {
         BlockRecord &rec = db.records[(size_t)s * db.rec_cap + r];
         rec.pids[0] = out[0] ^ tb.scr_pids[0];                 // descramble (decode.c:470)
@@ -602,6 +665,48 @@ __global__ __launch_bounds__(64) void k_pids_decode(DevTables tb, DevBuffers db,
         if (pids_crc_ok(rec.pids)) atomicOr(&rec.flags, (uint32_t)REC_PIDS_CRC);
         *recp = -1;
     }
+}
+
+__global__ __launch_bounds__(64) void k_pids_decode(DevTables tb, DevBuffers db, const int *ids, int parity)
+{
+    const int s = stream_of(ids, blockIdx.y), slot = blockIdx.x;
+    __shared__ int8_t coded[3 * PIDS_LEN];
+    __shared__ unsigned long long dec[PIDS_LEN + 64];
+    __shared__ uint32_t out[4];
+    pids_decode_wave(tb, db, s, parity, slot, coded, dec, out);
+}
+
+// Streaming seam: the tail of ONE stream's block step in one launch -- the block's PIDS frame (in-order mode files it in slot 0 of
+// window slot 0), then what the host needs into pinned host memory: the step's counters, the FIFO read position and the records
+// [first_rec, nblocks) (a block's record is final when its step ends) and, last of all, the sequence number the host is waiting
+// for.  Leaves the step counters at zero for the next step.  (As two launches, k_pids_decode + the report: one more ~4 us dispatch
+// on a chain the host waits for.)
+__global__ __launch_bounds__(64) void k_stream_tail(DevTables tb, DevBuffers db, int s, int first_rec, StreamReport *out, unsigned seq, int do_pids)
+{
+    __shared__ int8_t coded[3 * PIDS_LEN];
+    __shared__ unsigned long long dec[PIDS_LEN + 64];
+    __shared__ uint32_t bits[4];
+    const int t = threadIdx.x;
+    if (do_pids) pids_decode_wave(tb, db, s, 0, 0, coded, dec, bits);       // one wave: the whole workgroup
+    __threadfence();
+    __syncthreads();
+    const StreamState &st = db.state[s];
+    const int n = min(max(st.nblocks - first_rec, 0), 4);
+    constexpr int RW = sizeof(BlockRecord) / 4;
+    for (int q = t; q < n * RW; q += 64) {
+        const int k = q / RW, w = q % RW;
+        ((uint32_t *)&out->rec[k])[w] = ((const uint32_t *)&db.records[(size_t)s * db.rec_cap + ((first_rec + k) % db.rec_cap)])[w];
+    }
+    if (t < 4) { out->counters[t] = db.counters[t]; db.counters[t] = 0; }
+    if (t == 0) { out->rd = st.rd; out->nblocks = st.nblocks; out->nrec = n; }
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) { *(volatile unsigned *)&out->seq = seq; __threadfence_system(); }
+}
+
+void launch_stream_tail(const DevTables &tb, const DevBuffers &db, int s, int first_rec, StreamReport *out, unsigned seq, int do_pids, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_stream_tail, dim3(1), dim3(64), 0, st, tb, db, s, first_rec, out, seq, do_pids);
 }
 
 void launch_pids_decode(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int nslots, hipStream_t st)

@@ -48,7 +48,7 @@ struct DevBuffers {
     uint32_t *dec;                   // [NAUX][S][2 * (P1_LEN + 64)]  survivor decisions: per 32 steps one history word per lane (viterbi_v3.h)
     int nstreams_alloc;              // S
     uint8_t *tbmap;                  // [NAUX][S][2285 * 64]  traceback chunk maps (start lane per end lane)
-    int *fwd_meta;                   // [NAUX][S][16][512]  segmented forward pass: per segment the metric snapshot [64], end metrics [64] and the
+    int *fwd_meta;                   // [NAUX][S][VIT3_GMAX][512]  segmented forward pass: per segment the metric snapshot [64], end metrics [64] and the
                                      //                     history scratch of its speculative warm-up [384] (viterbi_v3.h)
     int *fwd_stats;                  // [2] segment boundaries checked / segments repaired since the engine was created
     uint32_t *p1_ring;               // [S][p1_slots][P1_WORDS]
@@ -90,6 +90,14 @@ struct DevBuffers {
 
 // ---- K1 -------------------------------------------------------------------------------
 // cu8 -> Q15 half-band 2:1 for one chunk per stream.  iq[s] = base + s*stride, nbytes[s] each.
+// what a block step of the fast streaming seam posts into pinned host memory (engine.hip: harvest)
+struct StreamReport { int counters[4]; long long rd; int nblocks; int nrec; BlockRecord rec[4]; unsigned seq; unsigned pad; };
+// streaming seam, ONE stream: the chunk is read where the host staged it (pinned, device-visible: no copy engine, no second buffer),
+// every input byte once; the workgroup that finishes last rolls the decimator history and publishes the new write position
+void launch_decimate_fm_cu8_stream(const DevTables &tb, const DevBuffers &db, int s, const uint8_t *iq, const unsigned *nbytes, unsigned max_nbytes, unsigned *ticket, hipStream_t st);
+// streaming seam, ONE stream: the block's PIDS frame (do_pids) and then the report
+void launch_stream_tail(const DevTables &tb, const DevBuffers &db, int s, int first_rec, StreamReport *out, unsigned seq, int do_pids, hipStream_t st);
+
 void launch_decimate_fm_cu8(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids,
                             const uint8_t *iq_base, long long iq_stride, const unsigned *nbytes, unsigned max_nbytes,
                             hipStream_t st);
@@ -103,7 +111,7 @@ void launch_append_cs16(const DevBuffers &db, int nstreams, const int *stream_id
 void launch_acquire(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
 void launch_prepare(const DevBuffers &db, int nstreams, const int *stream_ids, int acq_on, hipStream_t st);
 void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int syms_per_wg = 1);
-void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, int window, hipStream_t st);
+void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, int window, hipStream_t st, int lanes = 0);
 // replay (k_replay.hip): apply the first-header verdicts of finished deferred P1 decodes -- rewind the stream to the failed frame
 void launch_rollback(const DevBuffers &db, int nstreams, const int *stream_ids, int cur_window, int min_age, hipStream_t st);
 void launch_rollback_am(const DevBuffers &db, int nstreams, const int *stream_ids, int cur_window, int min_age, hipStream_t st);

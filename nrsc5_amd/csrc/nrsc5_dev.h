@@ -26,6 +26,9 @@ constexpr int P1_DEPUNCT = 3 * P1_LEN; // 438528
 constexpr int PIDS_LEN = 80;
 constexpr int PIDS_CODED = 200;
 constexpr int VIT_EXTRA = 32;          // TAIL_BITING_EXTRA, conv_dec.c:43
+// segmented forward trellis pass (viterbi_v3.h)
+constexpr int VIT3_GMAX = 64;          // segments per frame at most (64 x ~12 trips + warm-up: a lone P1 frame's forward pass in ~40 us)
+constexpr int VIT3_META = 128 + 384;   // ints per segment: snapshot [64], end metrics [64], warm-up history scratch [384]
 constexpr int P1_WORDS = P1_LEN / 32;  // packed output words per P1 frame (4568)
 constexpr int NWIN = 8;                // decode windows (16 block steps each) that may be in flight: buffers indexed w % NWIN
 constexpr int NPM = NWIN + 3;           // soft-bit matrices per stream: a frame's matrix must outlive its (deferred) decode

@@ -209,8 +209,7 @@ __device__ __forceinline__ void vit3_word(int &u, int &hist, int &nsp, const v16
 // input the survivors merge long before 384 steps and no segment is ever repaired; on pure noise or the all-erasure frame the
 // repair brings back exactly the sequential result at, in the worst case, the sequential cost.
 constexpr int VIT3_WARM_TRIPS = 2;                             // speculative warm-up of a segment: 384 steps ~ 55 constraint lengths
-constexpr int VIT3_GMAX = 16;                                  // segments per frame at most
-constexpr int VIT3_META = 128 + 384;                           // ints per segment: snapshot [64], end metrics [64], warm-up history scratch [384]
+// (VIT3_GMAX, VIT3_META: nrsc5_dev.h -- the engine sizes the segment metadata with them)
 
 __device__ __host__ inline int vit3_trips(int len) { return (len / 64 + 1) / 3; }
 // segments a frame of `len` steps can be cut into: every segment but the first needs room for its warm-up behind it

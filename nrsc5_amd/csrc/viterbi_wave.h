@@ -10,6 +10,7 @@
 //     (1.17 MB per P1 frame instead of the reference's 18.7 MB int16 path matrix),
 //   * ties pick predecessor 2b+1 exactly as `if (sum0 > sum1)` does (conv_gen.h:47-53).
 #pragma once
+#include <type_traits>
 #include "nrsc5_dev.h"
 #include "wave_ops.h"
 
@@ -230,6 +231,73 @@ __device__ inline void viterbi_k7_wave_fast(const int8_t *coded, int len, unsign
     }
 }
 
+// The same trellis in COMPACT form for short frames whose len + 64 steps are a multiple of six (the PIDS frame: 80 bits, 144 steps):
+// a rolled loop over groups of six steps -- one per phase of the rotating layout, so the lane exchanges stay compile-time DPP /
+// permlane forms -- instead of 64-step unrolled instruction streams.  Identical metrics, tie rule, tail-biting schedule and
+// decision words, hence identical output.  Why: the PIDS decode sits on the streaming seam's block-step chain.  On the reference-
+// shaped ds_bpermute form (`viterbi_k7_wave`: two crossbar round trips per step on the serial chain) it took 22.7 us per block; the
+// unrolled fast path with a 16-step last chunk 19 us -- ~19 KB of straight-line code executed once per launch, all of it
+// instruction-cache misses (profiles/r04_dropin_timeline.txt).  This form is ~1 KB.
+__device__ inline void viterbi_k7_wave_compact(const int8_t *coded, int len, unsigned long long *dec, uint32_t *out)
+{
+    const int lane = threadIdx.x & 63;
+    const VitFastConst k = vit_fast_consts(lane);
+    const int steps = len + 2 * VIT_EXTRA;                     // <= 192, % 6 == 0 (the dispatcher checks)
+    const int aw0 = vit_load_soft(coded, len, lane);
+    const int aw1 = (64 + lane < steps) ? vit_load_soft(coded, len, 64 + lane) : 0;
+    const int aw2 = (128 + lane < steps) ? vit_load_soft(coded, len, 128 + lane) : 0;
+    int pm = 0;
+    auto fwd = [&](auto R, int t) __attribute__((always_inline)) {
+        constexpr int r = decltype(R)::value;
+        const int aw = t < 64 ? aw0 : (t < 128 ? aw1 : aw2);   // wave-uniform choice
+        const int m = dot4_i8(wave_readlane(aw, t & 63), k.sgw[r], 0);
+        const int X = pm + m;
+        const int Y = lane_xor<(1 << r)>(pm) - m;
+        const bool own = X + k.s0[r] > Y;                      // own-wins; ties as the reference's `if (sum0 > sum1)`
+        pm = own ? X : Y;
+        const unsigned long long b = __ballot(own);
+        if (lane == 0) dec[t] = b;
+    };
+#pragma unroll 1
+    for (int t = 0; t < steps; t += 6) {
+        fwd(std::integral_constant<int, 0>{}, t);     fwd(std::integral_constant<int, 1>{}, t + 1); fwd(std::integral_constant<int, 2>{}, t + 2);
+        fwd(std::integral_constant<int, 3>{}, t + 3); fwd(std::integral_constant<int, 4>{}, t + 4); fwd(std::integral_constant<int, 5>{}, t + 5);
+    }
+    WAVE_LDS_SYNC();
+    // end state: first maximum in STATE order (conv_dec.c:310-318); lane L holds state rotr6^steps(L) = L
+    const int best = wave_max_i32(pm);
+    const int smin = wave_min_i32(pm == best ? lane : 64);
+    unsigned l = (unsigned)wave_uniform(smin);                 // lane of the survivor, kept in an SGPR
+    uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0;
+#pragma unroll 1
+    for (int t0 = steps - 6; t0 >= 0; t0 -= 6) {
+        unsigned long long w[6];
+#pragma unroll
+        for (int r = 0; r < 6; r++) w[r] = dec[t0 + r];        // six broadcast reads in flight, then the chase on the scalar ALU
+#pragma unroll
+        for (int r = 5; r >= 0; r--) {
+            const int t = t0 + r;
+            const unsigned long long wr = ((unsigned long long)(uint32_t)wave_uniform((int)(uint32_t)(w[r] >> 32)) << 32) | (uint32_t)wave_uniform((int)(uint32_t)w[r]);
+            const unsigned own = (unsigned)(wr >> l) & 1u;
+            const unsigned bit = (l >> r) & 1u;                // the decoded bit of step t
+            const int ob = t - VIT_EXTRA;                      // its place in the frame
+            if (ob >= 0 && ob < len) {
+                const uint32_t v = bit << (ob & 31);
+                if (ob < 32) o0 |= v; else if (ob < 64) o1 |= v; else if (ob < 96) o2 |= v; else if (ob < 128) o3 |= v; else o4 |= v;
+            }
+            l ^= own ? 0u : (1u << r);
+        }
+    }
+    if (lane == 0) {
+        const int nwords = (len + 31) / 32;
+        out[0] = o0;
+        if (nwords > 1) out[1] = o1;
+        if (nwords > 2) out[2] = o2;
+        if (nwords > 3) out[3] = o3;
+        if (nwords > 4) out[4] = o4;
+    }
+}
+
 // The P1 frame's split form -- forward pass by one wave + block-parallel traceback -- lives in viterbi_v3.h.
 constexpr int TB_SEG = 40;                                     // chunks per segment of the block-parallel traceback: a P1 frame's 2285 chunks make 58
                                                                // segments (<= 64); the two sequential compositions chase 40 map entries each
@@ -238,6 +306,7 @@ constexpr int TB_SEG = 40;                                     // chunks per seg
 __device__ inline void viterbi_k7_decode(const int8_t *coded, int len, unsigned long long *dec, uint32_t *out, int phases = 3)
 {
     if ((len & 63) == 0) viterbi_k7_wave_fast(coded, len, dec, out, phases);
+    else if (len <= 128 && (len + 2 * VIT_EXTRA) % 6 == 0) viterbi_k7_wave_compact(coded, len, dec, out);   // PIDS: 80 bits
     else viterbi_k7_wave(coded, len, dec, out);
 }
 

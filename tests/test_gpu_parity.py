@@ -400,7 +400,7 @@ def test_gpu_block_exact_pushes(hip_lib, oracle, am):
 
 
 def test_gpu_viterbi_segmented_exact(hip_lib, oracle):
-    ec.check_viterbi_segmented(hip_lib, oracle, lens=(2304, 4608, 146176), segments=(1, 2, 5, 16))
+    ec.check_viterbi_segmented(hip_lib, oracle, lens=(2304, 4608, 146176), segments=(1, 2, 5, 16, 64))
 
 
 def test_gpu_deferred_seam_equals_synchronous(hip_lib):
