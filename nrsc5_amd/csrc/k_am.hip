@@ -924,9 +924,10 @@ __global__ __launch_bounds__(512) void k_am_block(DevTables tb, DevBuffers db, c
         }
         if (tid == 0) {
             if (!pipeline) {
-                for (int w = 0; w < 3; w++) rec.pids[w] = sm.pids_out[w] ^ tb.scr_pids[w];
-                rec.pids[2] &= 0xffffu;
-                rec.flags |= pids_crc_ok(rec.pids) ? (uint32_t)REC_PIDS_CRC : 0u;
+                // (CRC over a local copy: on the record itself every one of its 80 bits was a round trip to global memory)
+                const uint32_t p[3] = { sm.pids_out[0] ^ tb.scr_pids[0], sm.pids_out[1] ^ tb.scr_pids[1], (sm.pids_out[2] ^ tb.scr_pids[2]) & 0xffffu };
+                rec.pids[0] = p[0]; rec.pids[1] = p[1]; rec.pids[2] = p[2];
+                rec.flags |= pids_crc_ok(p) ? (uint32_t)REC_PIDS_CRC : 0u;
             }
             rec.flags |= REC_PIDS;
             rec.bc_decoded = bc;
@@ -1210,8 +1211,9 @@ __global__ __launch_bounds__(64) void k_am_decode_fwd(DevTables tb, DevBuffers d
         viterbi_k9_wave(stage, PIDS_LEN, GEN_E2_0, GEN_E2_1, GEN_E2_2, pdec, pout, k9);
         if (threadIdx.x == 0) {
             BlockRecord &rec = db.records[(size_t)s * db.rec_cap + r];
-            rec.pids[0] = pout[0] ^ tb.scr_pids[0]; rec.pids[1] = pout[1] ^ tb.scr_pids[1]; rec.pids[2] = (pout[2] ^ tb.scr_pids[2]) & 0xffffu;
-            if (pids_crc_ok(rec.pids)) atomicOr(&rec.flags, (uint32_t)REC_PIDS_CRC);
+            const uint32_t p[3] = { pout[0] ^ tb.scr_pids[0], pout[1] ^ tb.scr_pids[1], (pout[2] ^ tb.scr_pids[2]) & 0xffffu };
+            rec.pids[0] = p[0]; rec.pids[1] = p[1]; rec.pids[2] = p[2];
+            if (pids_crc_ok(p)) atomicOr(&rec.flags, (uint32_t)REC_PIDS_CRC);
             *recp = -1;
         }
         return;

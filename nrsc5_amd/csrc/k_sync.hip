@@ -219,11 +219,10 @@ __device__ __forceinline__ void store_px(int8_t *pair, float2 v, int side, int p
 // evenly (11520 = 768 x 15) and the three resident waves hide each other's LDS / memory latency -- with 256 (one wave per SIMD, 45
 // cells each) the equalising and soft-bit phases ran at the latency of one dependent chain: 24 k + 11 k shader cycles per block
 // for ~6 k of issue work; a lone stream's block went from 38 to 25 us.  Inside a full batch the 12-wave workgroup has to find three
-// free wave slots on every SIMD of a CU beside the decode waves (a 16-wave traceback workgroup + the forward pass' waves): it
-// often waits -- the workgroup itself needs 30 us there, the launch 62 (profiles/r04_sync_lanes.txt) -- so large stream sets keep
-// the narrow form, which fits anywhere.
-// <= 80 VGPRs for the wide form (six waves per SIMD's worth): three of its waves and four traceback waves (64 VGPRs each) share a
-// SIMD's 512 registers.
+// free wave slots on every SIMD of a CU beside the decode waves (a 16-wave traceback workgroup + the forward pass' waves): at 120
+// VGPRs it waited for them to drain (the workgroup itself needed 30 us, the launch 75); held to <= 80 VGPRs (six waves per SIMD's
+// worth: three of its waves and four traceback waves of 64 VGPRs share a SIMD's 512 registers) the wide form is the faster one
+// there too, by a little (profiles/r04_sync_lanes.txt).  The narrow form stays selectable (NRSC5HIP_TUNE_SYNC_LANES).
 #ifndef HIPEMU
 #define SYNC_OCCUPANCY(NT) __attribute__((amdgpu_waves_per_eu((NT) > 512 ? 6 : 1, (NT) > 512 ? 6 : 8)))
 #else
@@ -639,7 +638,7 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
 void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, int window, hipStream_t st, int lanes)
 {
     // lanes: 0 = by the size of the stream set (see SYNC_OCCUPANCY above), else 256 / 768 (nrsc5hip_debug_tune NRSC5HIP_TUNE_SYNC_LANES)
-    const int nt = lanes ? lanes : (nstreams <= 64 ? 768 : 256);
+    const int nt = lanes ? lanes : 768;                        // measured at 256 streams: 32.8 ms per pass with 768, 33.8 with 256 (profiles/r04_sync_lanes.txt)
     if (nt == 768) hipLaunchKernelGGL(k_sync<768>, dim3(nstreams), dim3(768), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window);
     else hipLaunchKernelGGL(k_sync<256>, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window);
 }
@@ -659,10 +658,11 @@ __device__ __forceinline__ void pids_decode_wave(const DevTables &tb, const DevB
     WAVE_LDS_SYNC();
     if (lane == 0) {
         BlockRecord &rec = db.records[(size_t)s * db.rec_cap + r];
-        rec.pids[0] = out[0] ^ tb.scr_pids[0];                 // descramble (decode.c:470)
-        rec.pids[1] = out[1] ^ tb.scr_pids[1];
-        rec.pids[2] = (out[2] ^ tb.scr_pids[2]) & 0xffffu;
-        if (pids_crc_ok(rec.pids)) atomicOr(&rec.flags, (uint32_t)REC_PIDS_CRC);
+        // (the CRC runs over a local copy: handed the record itself it re-read the words from global memory for each of its 80 bits --
+        // ~17 us of the 22.7 us this decode used to take)
+        const uint32_t p[3] = { out[0] ^ tb.scr_pids[0], out[1] ^ tb.scr_pids[1], (out[2] ^ tb.scr_pids[2]) & 0xffffu };   // descramble (decode.c:470)
+        rec.pids[0] = p[0]; rec.pids[1] = p[1]; rec.pids[2] = p[2];
+        if (pids_crc_ok(p)) atomicOr(&rec.flags, (uint32_t)REC_PIDS_CRC);
         *recp = -1;
     }
 }

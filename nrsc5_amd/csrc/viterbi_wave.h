@@ -238,63 +238,75 @@ __device__ inline void viterbi_k7_wave_fast(const int8_t *coded, int len, unsign
 // shaped ds_bpermute form (`viterbi_k7_wave`: two crossbar round trips per step on the serial chain) it took 22.7 us per block; the
 // unrolled fast path with a 16-step last chunk 19 us -- ~19 KB of straight-line code executed once per launch, all of it
 // instruction-cache misses (profiles/r04_dropin_timeline.txt).  This form is ~1 KB.
+// Decisions stay in the lane: a lane's own-wins bits of 30 steps per VGPR (the fast path parks 64-lane ballots instead: a ballot
+// store per step); the traceback fetches the word of the survivor's lane with v_readlane and runs on the scalar ALU.  `dec` serves
+// as len + 64 bytes of scratch for the decoded bits.
 __device__ inline void viterbi_k7_wave_compact(const int8_t *coded, int len, unsigned long long *dec, uint32_t *out)
 {
     const int lane = threadIdx.x & 63;
     const VitFastConst k = vit_fast_consts(lane);
-    const int steps = len + 2 * VIT_EXTRA;                     // <= 192, % 6 == 0 (the dispatcher checks)
-    const int aw0 = vit_load_soft(coded, len, lane);
-    const int aw1 = (64 + lane < steps) ? vit_load_soft(coded, len, 64 + lane) : 0;
-    const int aw2 = (128 + lane < steps) ? vit_load_soft(coded, len, 128 + lane) : 0;
+    const int steps = len + 2 * VIT_EXTRA;                     // <= 150, % 6 == 0 (the dispatcher checks)
+    // soft inputs: lane i of word c holds step 60 c + i (60 = ten groups of six: a group never straddles two words)
+    int aw[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) aw[c] = (60 * c + lane < steps) ? vit_load_soft(coded, len, 60 * c + lane) : 0;
     int pm = 0;
-    auto fwd = [&](auto R, int t) __attribute__((always_inline)) {
+    uint32_t hist[5] = {0, 0, 0, 0, 0};                        // word j: steps 30 j .. 30 j + 29, bit = step - 30 j
+    auto fwd = [&](auto R, int awc, int i, uint32_t &h, int bitpos) __attribute__((always_inline)) {
         constexpr int r = decltype(R)::value;
-        const int aw = t < 64 ? aw0 : (t < 128 ? aw1 : aw2);   // wave-uniform choice
-        const int m = dot4_i8(wave_readlane(aw, t & 63), k.sgw[r], 0);
+        const int m = dot4_i8(wave_readlane(awc, i), k.sgw[r], 0);
         const int X = pm + m;
         const int Y = lane_xor<(1 << r)>(pm) - m;
         const bool own = X + k.s0[r] > Y;                      // own-wins; ties as the reference's `if (sum0 > sum1)`
         pm = own ? X : Y;
-        const unsigned long long b = __ballot(own);
-        if (lane == 0) dec[t] = b;
+        h |= (own ? 1u : 0u) << bitpos;
     };
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const int awc = aw[j >> 1], i0 = 30 * (j & 1);
 #pragma unroll 1
-    for (int t = 0; t < steps; t += 6) {
-        fwd(std::integral_constant<int, 0>{}, t);     fwd(std::integral_constant<int, 1>{}, t + 1); fwd(std::integral_constant<int, 2>{}, t + 2);
-        fwd(std::integral_constant<int, 3>{}, t + 3); fwd(std::integral_constant<int, 4>{}, t + 4); fwd(std::integral_constant<int, 5>{}, t + 5);
+        for (int g = 0; g < 5; g++) {
+            if (30 * j + 6 * g >= steps) break;                // wave-uniform (the last word of a 144-step frame holds 24 steps)
+            const int i = i0 + 6 * g, bp = 6 * g;
+            fwd(std::integral_constant<int, 0>{}, awc, i, hist[j], bp);         fwd(std::integral_constant<int, 1>{}, awc, i + 1, hist[j], bp + 1);
+            fwd(std::integral_constant<int, 2>{}, awc, i + 2, hist[j], bp + 2); fwd(std::integral_constant<int, 3>{}, awc, i + 3, hist[j], bp + 3);
+            fwd(std::integral_constant<int, 4>{}, awc, i + 4, hist[j], bp + 4); fwd(std::integral_constant<int, 5>{}, awc, i + 5, hist[j], bp + 5);
+        }
     }
-    WAVE_LDS_SYNC();
     // end state: first maximum in STATE order (conv_dec.c:310-318); lane L holds state rotr6^steps(L) = L
     const int best = wave_max_i32(pm);
     const int smin = wave_min_i32(pm == best ? lane : 64);
     unsigned l = (unsigned)wave_uniform(smin);                 // lane of the survivor, kept in an SGPR
-    uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, o4 = 0;
+    // the decoded bits of a group of six steps are the survivor's lane bits at the group's last step (bit r at step r of the group:
+    // each step only rewrites its own bit afterwards); parked as one byte per group, the frame's words are ballots over them
+    uint8_t *park = (uint8_t *)dec;                            // byte g: steps 6 g .. 6 g + 5
+#pragma unroll
+    for (int j = 4; j >= 0; j--) {
 #pragma unroll 1
-    for (int t0 = steps - 6; t0 >= 0; t0 -= 6) {
-        unsigned long long w[6];
+        for (int g = 4; g >= 0; g--) {
+            if (30 * j + 6 * g >= steps) continue;             // wave-uniform
+            const unsigned six = l & 63u;
+            const uint32_t h = (uint32_t)wave_readlane((int)hist[j], (int)l) >> (6 * g);    // the chase below only flips bits of l: the lane's word is re-read per step
+            unsigned lw = l;
 #pragma unroll
-        for (int r = 0; r < 6; r++) w[r] = dec[t0 + r];        // six broadcast reads in flight, then the chase on the scalar ALU
-#pragma unroll
-        for (int r = 5; r >= 0; r--) {
-            const int t = t0 + r;
-            const unsigned long long wr = ((unsigned long long)(uint32_t)wave_uniform((int)(uint32_t)(w[r] >> 32)) << 32) | (uint32_t)wave_uniform((int)(uint32_t)w[r]);
-            const unsigned own = (unsigned)(wr >> l) & 1u;
-            const unsigned bit = (l >> r) & 1u;                // the decoded bit of step t
-            const int ob = t - VIT_EXTRA;                      // its place in the frame
-            if (ob >= 0 && ob < len) {
-                const uint32_t v = bit << (ob & 31);
-                if (ob < 32) o0 |= v; else if (ob < 64) o1 |= v; else if (ob < 96) o2 |= v; else if (ob < 128) o3 |= v; else o4 |= v;
+            for (int r = 5; r >= 0; r--) {
+                const uint32_t hw = (r == 5) ? h : (uint32_t)wave_readlane((int)hist[j], (int)lw) >> (6 * g);
+                const unsigned own = (hw >> r) & 1u;
+                lw ^= own ? 0u : (1u << r);
             }
-            l ^= own ? 0u : (1u << r);
+            l = lw;
+            if (lane == 0) park[5 * j + g] = (uint8_t)six;
         }
     }
-    if (lane == 0) {
-        const int nwords = (len + 31) / 32;
-        out[0] = o0;
-        if (nwords > 1) out[1] = o1;
-        if (nwords > 2) out[2] = o2;
-        if (nwords > 3) out[3] = o3;
-        if (nwords > 4) out[4] = o4;
+    WAVE_LDS_SYNC();
+    const int nwords = (len + 31) / 32;
+    for (int base = 0; base < len; base += 64) {               // output bit ob <-> step ob + VIT_EXTRA
+        const int ob = base + lane, t = ob + VIT_EXTRA;
+        const unsigned long long b = __ballot(ob < len && ((park[t / 6] >> (t % 6)) & 1u) != 0);
+        if (lane == 0) {
+            out[base >> 5] = (uint32_t)b;
+            if ((base >> 5) + 1 < nwords) out[(base >> 5) + 1] = (uint32_t)(b >> 32);
+        }
     }
 }
 
@@ -306,7 +318,7 @@ constexpr int TB_SEG = 40;                                     // chunks per seg
 __device__ inline void viterbi_k7_decode(const int8_t *coded, int len, unsigned long long *dec, uint32_t *out, int phases = 3)
 {
     if ((len & 63) == 0) viterbi_k7_wave_fast(coded, len, dec, out, phases);
-    else if (len <= 128 && (len + 2 * VIT_EXTRA) % 6 == 0) viterbi_k7_wave_compact(coded, len, dec, out);   // PIDS: 80 bits
+    else if (len + 2 * VIT_EXTRA <= 150 && (len + 2 * VIT_EXTRA) % 6 == 0) viterbi_k7_wave_compact(coded, len, dec, out);   // PIDS: 80 bits
     else viterbi_k7_wave(coded, len, dec, out);
 }
 
