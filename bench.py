@@ -740,7 +740,7 @@ class Mixed:
         return self.my_streams[k] % 4 == (2 if k >= self.nfm else 1)
 
 
-TUNE_KNOBS = {"decode_streams": 0, "am_decode_streams": 1, "fwd_segments": 4, "am_segments": 6, "decode_cus": 7, "decode_priority": 8, "mixfft_syms": 10, "sync_lanes": 12}
+TUNE_KNOBS = {"decode_streams": 0, "am_decode_streams": 1, "fwd_segments": 4, "am_segments": 6, "decode_cus": 7, "decode_priority": 8, "mixfft_syms": 10, "traceback_walk": 12, "sync_lanes": 13}
 
 
 def apply_tune(E, args):
@@ -937,6 +937,7 @@ def main():
     dt = time.perf_counter() - t0
     prof = E.profile(0)
     fwd_checked, fwd_repaired = E.fwd_stats() if hasattr(E, "fwd_stats") else (0, 0)
+    tb_checked, tb_rewalked = E.tb_stats() if hasattr(E, "tb_stats") else (0, 0)
     dt = shard.max_over_ranks(dt, dev)
     per_rank_ms = [round(x / args.steps * 1e3, 3) for x in shard.gather_floats(dt_rank, dev)]
     tot = shard.sum_over_ranks([W.samples, W.signal_seconds, 1.0], dev)
@@ -1039,6 +1040,8 @@ def main():
         "vs_baseline": None, "dtype": W.dtype, "data": "synthetic",
         "config": config, "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
         "gen_seconds": round(t_gen, 1),
+        "traceback_walk": {"chunk_boundaries_checked": tb_checked, "chunks_rewalked": tb_rewalked,
+                           "what": "single-path traceback: every 64-step chunk walked once after a 64-step run-in through the chunk above (speculative), the chain of chunk boundaries verified, wrong chunks re-walked (viterbi_v3.h); counts since the engine was created, rank 0"},
         "forward_pass_segments": {"boundaries_checked": fwd_checked, "segments_repaired": fwd_repaired,
                                   "what": "K=7 forward trellis pass cut into concurrently running segment waves per frame (speculative start, verified, repaired when wrong: viterbi_v3.h); counts since the engine was created, rank 0"},
     }

@@ -370,6 +370,8 @@ enum {
     , NRSC5HIP_TUNE_MIXFFT_SYMS            /* OFDM symbols per k_mixfft workgroup: 1 (default), 2, 4, 8 -- any value gives identical bins */
     , NRSC5HIP_TUNE_DEFER_WAIT             /* fast streaming seam: 1 (default) = a block step whose FIFO consumption the host can compute in advance stays in
                                              flight when the push returns; 0 = every step is waited for at once (round 3's behaviour) */
+    , NRSC5HIP_TUNE_TRACEBACK_WALK         /* 1 (default): single-path traceback of the K=7 frames (one speculative walk per chunk, verified, re-walked where wrong);
+                                             0: round 3's block-parallel traceback (all 64 candidates per chunk).  Identical output either way */
     , NRSC5HIP_TUNE_SYNC_LANES             /* work-items per stream of the sync kernel: 256, 768, 0 = chosen from the size of the stream set (default) */
     , NRSC5HIP_TUNE_DIRECT_DECIMATE        /* fast streaming seam, FM cu8: 1 (default) = the decimator reads the pinned staging buffer across PCIe itself (one
                                              launch per chunk); 0 = hipMemcpyAsync into a device buffer, decimator, commit kernel (round 3's chain) */
@@ -389,6 +391,8 @@ int nrsc5hip_debug_poison_results(nrsc5hip_engine *e);
 /* segmented forward pass: segment boundaries checked / segments that had to be re-run since the engine was created */
 int nrsc5hip_debug_fwd_stats(nrsc5hip_engine *e, int stats[2]);
 /* K=9 decode in segment waves: [0] forward boundaries checked, [1] segments re-run, [2] traceback boundaries checked, [3] segments re-walked */
+/* single-path traceback: [0] chunk boundaries checked, [1] chunks re-walked since the engine was created */
+int nrsc5hip_debug_tb_stats(nrsc5hip_engine *e, int stats[2]);
 int nrsc5hip_debug_k9_stats(nrsc5hip_engine *e, int stats[4]);
 int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value);
 /* accumulated shader cycles per phase of the sync kernel for stream 0 (after nrsc5hip_debug_tune(e, NRSC5HIP_TUNE_SYNC_PHASES, 1)) */

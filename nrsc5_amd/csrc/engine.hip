@@ -104,6 +104,7 @@ struct nrsc5hip_engine {
     int fwd_warm;                      // test hook: speculative warm-up trips of a forward segment (2; 0 makes every speculation fail -> repair path)
     int mixfft_syms;                   // symbols per k_mixfft workgroup (1, 2, 4, 8)
     int sync_lanes;                    // work-items per stream of k_sync: 0 = by the size of the stream set, 256, 768
+    int tb_walk;                       // 1 (default): single-path traceback (k_p1_tbwalk + check); 0: the block-parallel one of round 3
     int fwd_segments;                  // waves per frame of the P1 forward pass; 0 = pick from the size of the stream set (fwd_segments_for)
     hipStream_t main;                  // = lane.main
     std::vector<void *> allocs;
@@ -433,7 +434,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
     do {
         {
             e->naux = 3; e->naux_am = 2;   // decode streams in use (measured: profiles/r02_naux.txt, r03_am_decode.txt); nrsc5hip_debug_tune changes them
-            e->verdict_lag = 0; e->fwd_segments = 0; e->fwd_warm = 2; e->mixfft_syms = 1; e->sync_lanes = 0;      // measured: profiles/r04_mixfft_persistent.txt
+            e->verdict_lag = 0; e->fwd_segments = 0; e->fwd_warm = 2; e->mixfft_syms = 1; e->sync_lanes = 0; e->tb_walk = 1;      // measured: profiles/r04_mixfft_persistent.txt
             e->am_segments = K9_GMAX; e->am_warm = K9_WARM; e->am_runin = K9_TB_RUNIN;
         }
         {
@@ -481,8 +482,9 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if ((rc = dev_alloc(e, &db.dec, (size_t)(cfg->p1_async ? NAUX : 1) * S * (size_t)(2 * (P1_LEN + 64))))) break;
         if ((rc = dev_alloc(e, &db.tbmap, (size_t)(cfg->p1_async ? NAUX : 1) * S * (size_t)(P1_LEN / 64 + 1) * 64))) break;
         if ((rc = dev_alloc(e, &db.fwd_meta, (size_t)(cfg->p1_async ? NAUX : 1) * S * (size_t)(VIT3_GMAX * VIT3_META)))) break;
-        if ((rc = dev_alloc(e, &db.fwd_stats, 2))) break;
-        if (hipMemset(db.fwd_stats, 0, 2 * sizeof(int)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
+        if ((rc = dev_alloc(e, &db.fwd_stats, 4))) break;
+        if (hipMemset(db.fwd_stats, 0, 4 * sizeof(int)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
+        db.tb_stats = db.fwd_stats + 2;
         if ((rc = dev_alloc(e, &db.am_k9stats, 4))) break;
         if (hipMemset(db.am_k9stats, 0, 4 * sizeof(unsigned)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
         if ((rc = dev_alloc(e, &db.pids_stage, S * NWIN * 16 * 3 * PIDS_LEN))) break;
@@ -677,7 +679,7 @@ static int launch_window_decode(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, i
     if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ax); launch_px_decode(e->tb, ln.db, n, ids_dev, parity, lane, ax); }
     { ProfScope p(e, NRSC5HIP_PROF_P1_DEINT, ax); launch_p1_deint(e->tb, ln.db, n, ids_dev, parity, lane, ax); }
     { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ax); launch_p1_forward(e->tb, ln.db, n, ids_dev, parity, lane, ax, fwd_segments_for(e, ln, n), e->fwd_warm); }
-    { ProfScope p(e, NRSC5HIP_PROF_P1_TRACEBACK, ax); launch_p1_traceback(e->tb, ln.db, n, ids_dev, parity, lane, ax, e->cfg.l2_feedback ? 2 : 0, fwd_segments_for(e, ln, n)); }
+    { ProfScope p(e, NRSC5HIP_PROF_P1_TRACEBACK, ax); launch_p1_traceback(e->tb, ln.db, n, ids_dev, parity, lane, ax, e->cfg.l2_feedback ? 2 : 0, fwd_segments_for(e, ln, n), e->tb_walk); }
     HIPCHK(hipEventRecord(ln.ev_decoded[parity], ax));
     ln.decoded_pending[parity] = true;
     ln.lane_parity[lane] = parity;
@@ -689,7 +691,7 @@ static int launch_inorder_p1(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int 
 {
     { ProfScope p(e, NRSC5HIP_PROF_P1_DEINT, ln.main); launch_p1_deint(e->tb, ln.db, n, ids_dev, 0, 0, ln.main); }
     { ProfScope p(e, NRSC5HIP_PROF_P1_VITERBI, ln.main); launch_p1_forward(e->tb, ln.db, n, ids_dev, 0, 0, ln.main, fwd_segments_for(e, ln, n), e->fwd_warm); }
-    { ProfScope p(e, NRSC5HIP_PROF_P1_TRACEBACK, ln.main); launch_p1_traceback(e->tb, ln.db, n, ids_dev, 0, 0, ln.main, e->cfg.l2_feedback ? 1 : 0, fwd_segments_for(e, ln, n)); }
+    { ProfScope p(e, NRSC5HIP_PROF_P1_TRACEBACK, ln.main); launch_p1_traceback(e->tb, ln.db, n, ids_dev, 0, 0, ln.main, e->cfg.l2_feedback ? 1 : 0, fwd_segments_for(e, ln, n), e->tb_walk); }
     return 0;
 }
 
@@ -1827,7 +1829,7 @@ extern "C" int nrsc5hip_stage_viterbi_k7(nrsc5hip_engine *e, const int8_t *soft,
     HIPCHK(hipMalloc((void **)&ddec, (size_t)nframes * (len + 64) * sizeof(unsigned long long)));
     HIPCHK(hipMalloc((void **)&dout, (size_t)nframes * words * sizeof(uint32_t)));
     HIPCHK(hipMemcpy(dsoft, soft, (size_t)nframes * 3 * len, hipMemcpyHostToDevice));
-    if (launch_viterbi_frames(e->vit_scratch, dsoft, len, nframes, ddec, dout, e->main, 3, e->fwd_segments > 0 ? e->fwd_segments : 16, e->db.fwd_stats, e->fwd_warm)) FAIL(NRSC5HIP_EINVAL, "frame length %d not supported or out of device memory", len);
+    if (launch_viterbi_frames(e->vit_scratch, dsoft, len, nframes, ddec, dout, e->main, 3 | (e->tb_walk ? 0 : 16), e->fwd_segments > 0 ? e->fwd_segments : 16, e->db.fwd_stats, e->fwd_warm)) FAIL(NRSC5HIP_EINVAL, "frame length %d not supported or out of device memory", len);
     HIPCHK(hipStreamSynchronize(e->main));
     std::vector<uint32_t> w((size_t)nframes * words);
     HIPCHK(hipMemcpy(w.data(), dout, w.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -2031,12 +2033,12 @@ extern "C" int nrsc5hip_stage_viterbi_bench(nrsc5hip_engine *e, int len, int nfr
     HIPCHK(hipMemset(ddec, 0x55, (size_t)nframes * (len + 64) * sizeof(unsigned long long)));
     hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
     const int seg = e->fwd_segments > 0 ? e->fwd_segments : 1;
-    if (launch_viterbi_frames(e->vit_scratch, dsoft, len, nframes, ddec, dout, e->main, phases | 1, seg)) FAIL(NRSC5HIP_EINVAL, "frame length %d not supported or out of device memory", len);      // warm-up; packs the soft words and leaves decisions behind
+    if (launch_viterbi_frames(e->vit_scratch, dsoft, len, nframes, ddec, dout, e->main, phases | 1 | (e->tb_walk ? 0 : 16), seg)) FAIL(NRSC5HIP_EINVAL, "frame length %d not supported or out of device memory", len);      // warm-up; packs the soft words and leaves decisions behind
     HIPCHK(hipEventRecord(a, e->main));
     for (int r = 0; r < reps; r++) {
         // a traceback-only measurement consumes the decisions in place: re-run the (untimed-irrelevant) forward pass is not possible
         // without timing it, so phases == 2 measures forward + traceback minus nothing -- callers subtract the forward figure
-        (void)launch_viterbi_frames(e->vit_scratch, dsoft, len, nframes, ddec, dout, e->main, ((phases & 2) ? (phases | 1) : phases) | 8, seg);
+        (void)launch_viterbi_frames(e->vit_scratch, dsoft, len, nframes, ddec, dout, e->main, ((phases & 2) ? (phases | 1) : phases) | 8 | (e->tb_walk ? 0 : 16), seg);
     }
     HIPCHK(hipEventRecord(b, e->main));
     HIPCHK(hipEventSynchronize(b));
@@ -2134,6 +2136,7 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
         }
         break;
     }
+    case NRSC5HIP_TUNE_TRACEBACK_WALK:    e->tb_walk = value != 0; break;
     case NRSC5HIP_TUNE_SYNC_LANES:        e->sync_lanes = (value == 256 || value == 768) ? value : 0; break;
     case NRSC5HIP_TUNE_EARLY_FLUSH_KB:    e->early_flush = (size_t)std::max(value, 0) << 10; break;
     case NRSC5HIP_TUNE_DEFER_WAIT:        e->defer_wait = value != 0; break;
@@ -2159,6 +2162,15 @@ extern "C" int nrsc5hip_debug_fwd_stats(nrsc5hip_engine *e, int stats[2])
     if (!e || !stats) FAIL(NRSC5HIP_EINVAL, "null argument");
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(stats, e->db.fwd_stats, 2 * sizeof(int), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int nrsc5hip_debug_tb_stats(nrsc5hip_engine *e, int stats[2])
+{
+    ON_ENGINE_DEVICE(e);
+    if (!stats) FAIL(NRSC5HIP_EINVAL, "null argument");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(stats, e->db.tb_stats, 2 * sizeof(int), hipMemcpyDeviceToHost));
     return 0;
 }
 

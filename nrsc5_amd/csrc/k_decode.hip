@@ -126,6 +126,23 @@ __global__ __launch_bounds__(64 * TBM_WAVES) void k_p1_tbmap(DevTables tb, DevBu
                             (int)(blockIdx.x * TBM_WAVES + (threadIdx.x >> 6)), parts * TBM_WAVES);
 }
 
+// Round 4: the single-path traceback (viterbi_v3.h: lane = chunk, run-in through the chunk above, verified by k_p1_traceback).
+// 36 one-wave workgroups per frame, 33 KB of LDS each (four per CU).
+__global__ __launch_bounds__(64) void k_p1_tbwalk(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id, int prio)
+{
+    wave_set_priority(prio);
+    const int s = wave_uniform(stream_of(ids, blockIdx.y));
+    StreamState &st = db.state[s];
+    if (!st.p1_pending[parity]) return;                        // block-uniform
+    __shared__ uint32_t lds[TB2_LDS_WORDS];
+    const size_t slot = (size_t)lane_id * db.nstreams_alloc + s;
+    uint32_t *out = db.p1_ring + ((size_t)s * db.p1_slots + st.p1_slot[parity]) * P1_WORDS;
+    viterbi3_traceback_walk(db.dec + slot * (size_t)(2 * (P1_LEN + 64)), P1_LEN, st.p1_endlane[parity], out,
+                            db.tbmap + slot * ((size_t)(P1_LEN / 64 + 1) * 64), (int)blockIdx.x, lds);
+}
+
+// maps_done: 0 = the block-parallel traceback runs all its passes here; 1 = k_p1_tbmap ran pass 1; 2 = k_p1_tbwalk has written the
+// frame speculatively: verify / repair only
 __global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id, int l2_mode, int prio, int maps_done)
 {
     wave_set_priority(prio);
@@ -140,7 +157,8 @@ __global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBu
     uint32_t *out = db.p1_ring + ((size_t)s * db.p1_slots + st.p1_slot[parity]) * P1_WORDS;
     if (tid == 0) err_total = 0;
     uint8_t *gmap = db.tbmap + ((size_t)lane_id * db.nstreams_alloc + s) * ((size_t)(P1_LEN / 64 + 1) * 64);
-    viterbi3_traceback_block(dec, P1_LEN, st.p1_endlane[parity], out, gmap, smem, maps_done != 0);
+    if (maps_done == 2) viterbi3_traceback_check(dec, P1_LEN, out, gmap, db.tb_stats);
+    else viterbi3_traceback_block(dec, P1_LEN, st.p1_endlane[parity], out, gmap, smem, maps_done != 0);
     __threadfence_block();
     __syncthreads();
     const int errors = wave_sum_i32(bit_errors_k7_partial(soft, out, P1_LEN));
@@ -189,16 +207,21 @@ void launch_p1_forward(const DevTables &tb, const DevBuffers &db, int nstreams, 
     hipLaunchKernelGGL(k_p1_forward, dim3((nstreams * G + FWD_WAVES - 1) / FWD_WAVES), dim3(64 * FWD_WAVES), 0, st, tb, db, stream_ids, parity, lane_id, prio_fwd, nstreams, G, warm);
     hipLaunchKernelGGL(k_p1_fix, dim3((nstreams + FWD_WAVES - 1) / FWD_WAVES), dim3(64 * FWD_WAVES), 0, st, tb, db, stream_ids, parity, lane_id, prio_fwd, nstreams, G);
 }
-void launch_p1_traceback(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st, int l2_mode, int parts)
+void launch_p1_traceback(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st, int l2_mode, int parts, int walk)
 {
     constexpr int prio_tb = 1;
     // Thin windows / small stream sets (parts = 16): pass 1 of the traceback as its own launch over `parts` workgroups per frame,
     // so that a handful of frames spread over the chip (one frame: 0.48 -> 0.11 ms).  Full windows keep it inside the 16-wave
     // traceback workgroup: 1024 small workgroups at once crowd the block-step kernels off the SIMDs (measured: k_sync 14 -> 25 ms
     // per pass, the pass 36 -> 50 ms; profiles/r03_traceback_variants.txt).
-    const int split = parts >= 16 ? 16 : 0;
-    if (split) hipLaunchKernelGGL(k_p1_tbmap, dim3(split, nstreams), dim3(64 * TBM_WAVES), 0, st, tb, db, stream_ids, parity, lane_id, prio_tb, split);
-    hipLaunchKernelGGL(k_p1_traceback, dim3(nstreams), dim3(TB_THREADS), traceback_smem(P1_LEN), st, tb, db, stream_ids, parity, lane_id, l2_mode, prio_tb, split ? 1 : 0);
+    if (walk) {
+        hipLaunchKernelGGL(k_p1_tbwalk, dim3(vit3_tb2_waves(P1_LEN), nstreams), dim3(64), 0, st, tb, db, stream_ids, parity, lane_id, prio_tb);
+        hipLaunchKernelGGL(k_p1_traceback, dim3(nstreams), dim3(TB_THREADS), traceback_smem(P1_LEN), st, tb, db, stream_ids, parity, lane_id, l2_mode, prio_tb, 2);
+    } else {
+        const int split = parts >= 16 ? 16 : 0;
+        if (split) hipLaunchKernelGGL(k_p1_tbmap, dim3(split, nstreams), dim3(64 * TBM_WAVES), 0, st, tb, db, stream_ids, parity, lane_id, prio_tb, split);
+        hipLaunchKernelGGL(k_p1_traceback, dim3(nstreams), dim3(TB_THREADS), traceback_smem(P1_LEN), st, tb, db, stream_ids, parity, lane_id, l2_mode, prio_tb, split ? 1 : 0);
+    }
     if (db.l2_ring) launch_l2_index_window(db, nstreams, stream_ids, parity, st);
 }
 
@@ -252,6 +275,18 @@ __global__ __launch_bounds__(TB_THREADS) void k_viterbi_frames_tb(uint32_t *dec,
     viterbi3_traceback_block(dec + (size_t)f * 2 * (len + 64), len, endlane[f], out + (size_t)f * ((len + 31) / 32), gmap + (size_t)f * (len / 64 + 1) * 64, smem, maps_done != 0);
 }
 
+__global__ __launch_bounds__(64) void k_viterbi_frames_tbwalk(const uint32_t *dec, int len, const int *endlane, uint32_t *out, uint8_t *gmap)
+{
+    __shared__ uint32_t lds[TB2_LDS_WORDS];
+    const int f = blockIdx.y;
+    viterbi3_traceback_walk(dec + (size_t)f * 2 * (len + 64), len, endlane[f], out + (size_t)f * ((len + 31) / 32), gmap + (size_t)f * (len / 64 + 1) * 64, (int)blockIdx.x, lds);
+}
+__global__ __launch_bounds__(TB_THREADS) void k_viterbi_frames_tbcheck(const uint32_t *dec, int len, uint32_t *out, uint8_t *gmap, int *stats)
+{
+    const int f = blockIdx.x;
+    viterbi3_traceback_check(dec + (size_t)f * 2 * (len + 64), len, out + (size_t)f * ((len + 31) / 32), gmap + (size_t)f * (len / 64 + 1) * 64, stats);
+}
+
 void vit_scratch_free(VitScratch &sc)
 {
     if (sc.endlane) (void)hipFree(sc.endlane);
@@ -293,7 +328,10 @@ int launch_viterbi_frames(VitScratch &sc, const int8_t *coded, int len, int nfra
             hipLaunchKernelGGL(k_viterbi_frames_fwd, dim3(nframes * G), dim3(64), 0, st, (const int *)soft, len, (uint32_t *)dec, meta, G, warm);
             hipLaunchKernelGGL(k_viterbi_frames_fix, dim3(nframes), dim3(64), 0, st, (const int *)soft, len, (uint32_t *)dec, meta, G, endlane, stats);
         }
-        if (phases & 2) {
+        if ((phases & 2) && !(phases & 16)) {               // the single-path traceback (production default); bit 4 selects the block-parallel one
+            hipLaunchKernelGGL(k_viterbi_frames_tbwalk, dim3(vit3_tb2_waves(len), nframes), dim3(64), 0, st, (const uint32_t *)dec, len, (const int *)endlane, out, gmap);
+            hipLaunchKernelGGL(k_viterbi_frames_tbcheck, dim3(nframes), dim3(TB_THREADS), 0, st, (const uint32_t *)dec, len, out, gmap, stats ? stats + 2 : nullptr);
+        } else if (phases & 2) {
             const int split = segments >= 16 ? 16 : 0;      // as launch_p1_traceback
             if (split) hipLaunchKernelGGL(k_viterbi_frames_tbmap, dim3(split, nframes), dim3(64 * TBM_WAVES), 0, st, (uint32_t *)dec, len, gmap, split);
             hipLaunchKernelGGL(k_viterbi_frames_tb, dim3(nframes), dim3(TB_THREADS), traceback_smem(len), st, (uint32_t *)dec, len, (const int *)endlane, out, gmap, split ? 1 : 0);

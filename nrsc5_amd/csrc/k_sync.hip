@@ -652,9 +652,10 @@ __device__ __forceinline__ void pids_decode_wave(const DevTables &tb, const DevB
     if (r < 0) return;                                         // wave-uniform
     const int8_t *stage = db.pids_stage + (((size_t)s * NWIN + parity) * 16 + slot) * (3 * PIDS_LEN);
     const int lane = threadIdx.x & 63;
-    for (int n = lane; n < 3 * PIDS_LEN; n += 64) coded[n] = stage[n];
+    static_assert((3 * PIDS_LEN) % 4 == 0 && 3 * PIDS_LEN / 4 <= 64, "the staged frame is one dword per lane");
+    if (lane < 3 * PIDS_LEN / 4) ((uint32_t *)coded)[lane] = ((const uint32_t *)stage)[lane];
     WAVE_LDS_SYNC();
-    viterbi_k7_decode(coded, PIDS_LEN, dec, out);              // 80 bits: the rotating-layout trellis with a 16-step last chunk
+    viterbi_k7_wave_compact<PIDS_LEN>(coded, dec, out);        // the rotating-layout trellis in its compact form, inlined with the frame length a constant
     WAVE_LDS_SYNC();
     if (lane == 0) {
         BlockRecord &rec = db.records[(size_t)s * db.rec_cap + r];
@@ -670,7 +671,7 @@ __device__ __forceinline__ void pids_decode_wave(const DevTables &tb, const DevB
 __global__ __launch_bounds__(64) void k_pids_decode(DevTables tb, DevBuffers db, const int *ids, int parity)
 {
     const int s = stream_of(ids, blockIdx.y), slot = blockIdx.x;
-    __shared__ int8_t coded[3 * PIDS_LEN];
+    __shared__ __attribute__((aligned(16))) int8_t coded[3 * PIDS_LEN];
     __shared__ unsigned long long dec[PIDS_LEN + 64];
     __shared__ uint32_t out[4];
     pids_decode_wave(tb, db, s, parity, slot, coded, dec, out);
@@ -683,7 +684,7 @@ __global__ __launch_bounds__(64) void k_pids_decode(DevTables tb, DevBuffers db,
 // on a chain the host waits for.)
 __global__ __launch_bounds__(64) void k_stream_tail(DevTables tb, DevBuffers db, int s, int first_rec, StreamReport *out, unsigned seq, int do_pids)
 {
-    __shared__ int8_t coded[3 * PIDS_LEN];
+    __shared__ __attribute__((aligned(16))) int8_t coded[3 * PIDS_LEN];
     __shared__ unsigned long long dec[PIDS_LEN + 64];
     __shared__ uint32_t bits[4];
     const int t = threadIdx.x;

@@ -51,6 +51,7 @@ struct DevBuffers {
     int *fwd_meta;                   // [NAUX][S][VIT3_GMAX][512]  segmented forward pass: per segment the metric snapshot [64], end metrics [64] and the
                                      //                     history scratch of its speculative warm-up [384] (viterbi_v3.h)
     int *fwd_stats;                  // [2] segment boundaries checked / segments repaired since the engine was created
+    int *tb_stats;                   // [2] single-path traceback: chunk boundaries checked / chunks re-walked since the engine was created
     uint32_t *p1_ring;               // [S][p1_slots][P1_WORDS]
     uint32_t *p1_mirror;             // same layout in pinned host memory (device-visible), written beside p1_ring by the FM traceback once
                                      // nrsc5hip_batch_fetch_view has set it up; null before
@@ -124,7 +125,7 @@ void launch_p1_deint(const DevTables &tb, const DevBuffers &db, int nstreams, co
 // segments: waves per frame of the forward pass (1..16; clamped to what the frame length allows), see viterbi_v3.h
 void launch_p1_forward(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st, int segments, int warm = 2);
 // parts: workgroups per frame of the traceback's first pass (k_p1_tbmap), 1..16
-void launch_p1_traceback(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st, int l2_mode = 0, int parts = 4);
+void launch_p1_traceback(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int lane_id, hipStream_t st, int l2_mode = 0, int parts = 4, int walk = 1);
 
 // ---- AM path (k_am.hip) -------------------------------------------------------------------------
 // cu8 -> five cascaded half-bands 32:1, any nbytes % 4 == 0 per stream (stage phases carry over)

@@ -458,4 +458,140 @@ __device__ inline void viterbi3_traceback_block(uint32_t *dec, int len, int endl
     }
 }
 
+// ---- single-path traceback, lane = chunk (round 4) --------------------------------------------------------------------------
+// The block-parallel traceback above follows ALL 64 candidate end lanes through every chunk (4 VALU + one crossbar round trip per
+// step and chunk, 64 candidate outputs written over the history words): 12 G SIMD-cycles and 13.8 GB of HBM traffic per pass to
+// emit 63 MB of decoded bits.  But survivors merge: a few constraint lengths back from ANY state the paths are one path.  So every
+// chunk is walked ONCE, speculatively: lane j of a wave owns chunk c0 + j, starts from lane 0 at the END of chunk c + 1, walks that
+// chunk as a run-in (64 steps = 9 constraint lengths) and arrives at chunk c's last step on what is almost surely the true
+// survivor; then walks its own 64 steps, emits the chunk's two output words and notes the lane it entered its chunk with and the
+// lane it left it with.  Exactness is not left to the speculation (as with the forward segments): the walk of chunk c is right iff
+// it entered with the lane the walk of chunk c + 1 left with, and chunk c + 1 is itself right; the frame's last chunk starts from
+// the true end lane.  viterbi3_traceback_check verifies that chain for every chunk at once and re-walks what fails, round by round
+// until nothing does -- worst case the sequential cost, result always the sequential decoder's.
+// One wave per 64 chunks; the history words of its 65 chunks (33 KB) are staged in LDS, each chunk's row rotated by the chunk's
+// phase so that the bit a step rewrites is the same lane bit (step % 6) for every lane of the wave.
+constexpr int TB2_CHUNKS = 64;
+constexpr int TB2_LDS_WORDS = (TB2_CHUNKS + 1) * 128;
+__device__ __host__ inline int vit3_tb2_waves(int len) { return ((len / 64 + 1) + TB2_CHUNKS - 1) / TB2_CHUNKS; }
+// per frame: entry lane [nchunks] then exit lane [nchunks] of every chunk's walk (logical lane numbers)
+__device__ __host__ inline size_t vit3_tb2_meta_bytes(int len) { return (size_t)2 * (len / 64 + 1); }
+
+// 64 steps back through one chunk whose rows lie in LDS in rotated order (row word h of rotated lane q at rows[64 h + q]);
+// q = rotated lane at the chunk's last step on entry, at its first step on return; ahi / alo: decisions of steps 32..63 / 0..31
+__device__ __forceinline__ void vit3_walk_rotated(const uint32_t *rows, unsigned &q, unsigned &ahi, unsigned &alo)
+{
+    ahi = 0; alo = 0;
+#pragma unroll
+    for (int S = 63; S >= 0; S--) {
+        const int u = S % 6;                                   // the lane bit this step rewrites, in the rotated numbering
+        const unsigned v = rows[(S >= 32 ? 64 : 0) + q];
+        const unsigned d = (v >> (S & 31)) & 1u;
+        if (S >= 32) ahi |= d << (S & 31); else alo |= d << (S & 31);
+        q = (q & ~(1u << u)) | (d << u);
+    }
+}
+
+// the two output words of a chunk from its 64 decisions and the ROTATED lane it was entered with (see vit3_outputs: the last six
+// bits are lane bits (PH + 58 + k) % 6 = rotated bits (58 + k) % 6)
+__device__ __forceinline__ void vit3_outputs_rotated(unsigned qend, unsigned ahi, unsigned alo, unsigned &ohi, unsigned &olo)
+{
+    unsigned top = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) top |= ((qend >> ((58 + k) % 6)) & 1u) << k;
+    ohi = (ahi >> 6) | (top << 26);
+    olo = (alo >> 6) | (ahi << 26);
+}
+
+// one wave: chunks [64 w, 64 w + 64) of a frame.  lds: TB2_LDS_WORDS dwords.  endlane: the frame's true end lane (logical).
+__device__ __forceinline__ void viterbi3_traceback_walk(const uint32_t *dec, int len, int endlane, uint32_t *out, uint8_t *meta, int w, uint32_t *lds)
+{
+    const int lane = threadIdx.x & 63;
+    const int nchunks = len / 64 + 1;
+    const int c0 = w * TB2_CHUNKS, nrows = min(TB2_CHUNKS + 1, nchunks - c0);   // chunks staged: own + the run-in chunk of the last lane
+    // stage: history word h of logical lane L of chunk c0 + k -> lds[128 k + 64 h + rotr6(L, ph)], ph = phase of the chunk's first step
+    for (int i = lane; i < nrows * 128; i += 64) {
+        const int k = i >> 7, h = (i >> 6) & 1, L = i & 63;
+        const int ph = (4 * ((c0 + k) % 3)) % 6;               // (64 c) % 6
+        lds[128 * k + 64 * h + (int)rotr6((unsigned)L, ph)] = dec[(size_t)(2 * (c0 + k) + h) * 64 + L];
+    }
+    WAVE_LDS_SYNC();
+    const int c = c0 + lane;
+    if (c >= nchunks) return;
+    const int ph = (4 * (c % 3)) % 6;
+    unsigned q, ahi, alo;
+    if (c == nchunks - 1) {
+        q = rotr6((unsigned)endlane, ph);
+    } else {
+        // run-in through chunk c + 1 from (rotated) lane 0 at its last step; its first step's lane is where chunk c ends.
+        // rotated numbering of chunk c = that of chunk c + 1 rotated left by 4 (ph(c + 1) - ph(c) = 4 mod 6)
+        unsigned qa = 0, t0, t1;
+        vit3_walk_rotated(lds + 128 * (lane + 1), qa, t0, t1);
+        q = rotl6(qa, 4);
+    }
+    const unsigned qend = q;
+    vit3_walk_rotated(lds + 128 * lane, q, ahi, alo);
+    unsigned ohi, olo;
+    vit3_outputs_rotated(qend, ahi, alo, ohi, olo);
+    if (c < nchunks - 1) out[2 * c] = ohi;                     // steps 64c+32 .. 64c+63
+    if (c >= 1) out[2 * c - 1] = olo;                          // steps 64c .. 64c+31
+    meta[c] = (uint8_t)rotl6(qend, ph);                        // entered with (logical lane at the chunk's last step)
+    meta[nchunks + c] = (uint8_t)rotl6(q, ph);                 // left with (logical lane at its first step)
+}
+
+// one chunk walked from logical lane `e`, history words straight from global memory (the repair path)
+__device__ inline unsigned vit3_rewalk(const uint32_t *dec, int c, unsigned e, unsigned &ohi, unsigned &olo)
+{
+    const int ph = (4 * (c % 3)) % 6;
+    unsigned l = e, ahi = 0, alo = 0;
+    for (int S = 63; S >= 0; S--) {
+        const int R = (ph + S) % 6;
+        const unsigned v = dec[(size_t)(2 * c + (S >> 5)) * 64 + l];
+        const unsigned d = (v >> (S & 31)) & 1u;
+        if (S >= 32) ahi |= d << (S & 31); else alo |= d << (S & 31);
+        l = (l & ~(1u << R)) | (d << R);
+    }
+    unsigned top = 0;
+    for (int k = 0; k < 6; k++) top |= ((e >> ((ph + 58 + k) % 6)) & 1u) << k;
+    ohi = (ahi >> 6) | (top << 26);
+    olo = (alo >> 6) | (ahi << 26);
+    return l;
+}
+
+// whole workgroup, after every wave of viterbi3_traceback_walk of the frame is done (a later launch): verify the chain of chunk
+// boundaries and re-walk what the speculation got wrong.  stats (may be null): [0] boundaries checked, [1] chunks re-walked.
+__device__ inline void viterbi3_traceback_check(const uint32_t *dec, int len, uint32_t *out, uint8_t *meta, int *stats)
+{
+    const int nchunks = len / 64 + 1;
+    __shared__ int tb2_bad;
+    int rewalked = 0;
+    for (int round = 0; round <= nchunks; round++) {
+        if (threadIdx.x == 0) tb2_bad = 0;
+        __syncthreads();
+        // phase A: who entered with the wrong lane?  (reads only)
+        int mine[4]; unsigned want[4]; int nm = 0;
+        for (int c = threadIdx.x; c < nchunks - 1; c += blockDim.x) {
+            const unsigned w = meta[nchunks + c + 1];
+            if (meta[c] != w && nm < 4) { mine[nm] = c; want[nm] = w; nm++; }
+        }
+        if (nm) tb2_bad = 1;
+        __syncthreads();
+        if (!tb2_bad) break;                                   // block-uniform
+        // phase B: re-walk them from the lane their upper neighbour left with (right if that neighbour is right: the topmost wrong
+        // chunk of every run is settled for good in this round)
+        for (int k = 0; k < nm; k++) {
+            const int c = mine[k];
+            unsigned ohi, olo;
+            const unsigned l = vit3_rewalk(dec, c, want[k], ohi, olo);
+            out[2 * c] = ohi;
+            if (c >= 1) out[2 * c - 1] = olo;
+            meta[c] = (uint8_t)want[k]; meta[nchunks + c] = (uint8_t)l;
+            rewalked++;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (stats) { if (threadIdx.x == 0) atomicAdd(&stats[0], nchunks - 1); if (rewalked) atomicAdd(&stats[1], rewalked); }
+}
+
 }  // namespace nrsc5

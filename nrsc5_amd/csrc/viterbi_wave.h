@@ -241,11 +241,13 @@ __device__ inline void viterbi_k7_wave_fast(const int8_t *coded, int len, unsign
 // Decisions stay in the lane: a lane's own-wins bits of 30 steps per VGPR (the fast path parks 64-lane ballots instead: a ballot
 // store per step); the traceback fetches the word of the survivor's lane with v_readlane and runs on the scalar ALU.  `dec` serves
 // as len + 64 bytes of scratch for the decoded bits.
-__device__ inline void viterbi_k7_wave_compact(const int8_t *coded, int len, unsigned long long *dec, uint32_t *out)
+template <int len>
+__device__ __forceinline__ void viterbi_k7_wave_compact(const int8_t *coded, unsigned long long *dec, uint32_t *out)
 {
+    static_assert(len + 2 * VIT_EXTRA <= 150 && (len + 2 * VIT_EXTRA) % 6 == 0, "five history words of 30 steps, whole groups of six");
     const int lane = threadIdx.x & 63;
     const VitFastConst k = vit_fast_consts(lane);
-    const int steps = len + 2 * VIT_EXTRA;                     // <= 150, % 6 == 0 (the dispatcher checks)
+    constexpr int steps = len + 2 * VIT_EXTRA;
     // soft inputs: lane i of word c holds step 60 c + i (60 = ten groups of six: a group never straddles two words)
     int aw[3];
 #pragma unroll
@@ -299,7 +301,8 @@ __device__ inline void viterbi_k7_wave_compact(const int8_t *coded, int len, uns
         }
     }
     WAVE_LDS_SYNC();
-    const int nwords = (len + 31) / 32;
+    constexpr int nwords = (len + 31) / 32;
+#pragma unroll
     for (int base = 0; base < len; base += 64) {               // output bit ob <-> step ob + VIT_EXTRA
         const int ob = base + lane, t = ob + VIT_EXTRA;
         const unsigned long long b = __ballot(ob < len && ((park[t / 6] >> (t % 6)) & 1u) != 0);
@@ -318,7 +321,7 @@ constexpr int TB_SEG = 40;                                     // chunks per seg
 __device__ inline void viterbi_k7_decode(const int8_t *coded, int len, unsigned long long *dec, uint32_t *out, int phases = 3)
 {
     if ((len & 63) == 0) viterbi_k7_wave_fast(coded, len, dec, out, phases);
-    else if (len + 2 * VIT_EXTRA <= 150 && (len + 2 * VIT_EXTRA) % 6 == 0) viterbi_k7_wave_compact(coded, len, dec, out);   // PIDS: 80 bits
+    else if (len == PIDS_LEN) viterbi_k7_wave_compact<PIDS_LEN>(coded, dec, out);
     else viterbi_k7_wave(coded, len, dec, out);
 }
 
