@@ -118,7 +118,10 @@ struct nrsc5hip_engine {
     // block costs one host memcpy into pinned memory, one async H2D and the K1 launch -- no synchronisation at all -- and a
     // push that does complete one ends with ONE sync, after a report kernel has posted the counters, the new read position and
     // the block's record straight into pinned host memory.
-    uint8_t *stage_pin[2], *stage_pin_dev[2], *stage_dev2[2]; hipEvent_t stage_ev[2]; bool stage_busy[2]; int stage_slot;
+    // NSTAGE pinned staging buffers used round robin (a buffer is refilled NSTAGE submissions after it was handed to the device: with
+    // two, and three submissions per block, the host waited ~30 us per block for the decimator of the submission before last)
+    static constexpr int NSTAGE = 8;
+    uint8_t *stage_pin[NSTAGE], *stage_pin_dev[NSTAGE], *stage_dev2[NSTAGE]; hipEvent_t stage_ev[NSTAGE]; bool stage_busy[NSTAGE]; int stage_slot;
     unsigned *decim_ticket;            // k_decimate_fm_cu8_stream: workgroups of the running launch that have finished
     // Ingest stream (round 4): the direct decimator runs on its own HIP stream, beside the block step on `main` (which keeps ONE CU
     // busy): chunks are submitted as they fill (early_flush bytes), so that when the push that completes a block arrives only the
@@ -154,6 +157,7 @@ struct nrsc5hip_engine {
     std::vector<char> manual_step;     // nrsc5hip_stream_set_manual_step: pushes stage and submit samples, the caller steps
     // staging
     uint8_t *stage_dev; size_t stage_bytes;
+    size_t stage_ring_bytes;           // size of each of the NSTAGE staging buffers of the fast seam (a block of either mode fits)
     int *ids_dev; unsigned *nbytes_dev;
     int *all_ids_dev;                  // identity list 0..S-1
     // chunked K1 running ahead of the block steps on its own stream (fresh batches in the async pipeline)
@@ -543,13 +547,13 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
                 hipMemset(db.am_sym, 0, S * 4 * AM_SYMS) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "AM state init failed"); break; }
         }
         db.sync_phase_cycles = nullptr;        // nrsc5hip_debug_tune(NRSC5HIP_TUNE_SYNC_PHASES) turns the instrumentation on
-        e->stage_bytes = 4u << 20;
+        e->stage_bytes = 4u << 20; e->stage_ring_bytes = 1u << 20;
         if ((rc = dev_alloc(e, &e->stage_dev, e->stage_bytes))) break;
         if (!cfg->p1_async) {
-            for (int k = 0; k < 2 && !rc; k++) {
-                if ((rc = dev_alloc(e, &e->stage_dev2[k], e->stage_bytes + 16))) break;
+            for (int k = 0; k < nrsc5hip_engine::NSTAGE && !rc; k++) {
+                if ((rc = dev_alloc(e, &e->stage_dev2[k], e->stage_ring_bytes + 16))) break;
                 void *sp = nullptr;
-                if (hipHostMalloc((void **)&e->stage_pin[k], e->stage_bytes + 16, hipHostMallocMapped) != hipSuccess ||
+                if (hipHostMalloc((void **)&e->stage_pin[k], e->stage_ring_bytes + 16, hipHostMallocMapped) != hipSuccess ||
                     hipHostGetDevicePointer(&sp, e->stage_pin[k], 0) != hipSuccess ||
                     hipEventCreateWithFlags(&e->stage_ev[k], hipEventDisableTiming) != hipSuccess) { rc = NRSC5HIP_ENOMEM; snprintf(g_err, sizeof(g_err), "pinned staging allocation failed"); }
                 e->stage_pin_dev[k] = (uint8_t *)sp;
@@ -615,7 +619,7 @@ extern "C" void nrsc5hip_engine_destroy(nrsc5hip_engine *e)
     if (e->rec_host) (void)hipHostFree(e->rec_host);
     if (e->frames_host) (void)hipHostFree(e->frames_host);
     if (e->nblocks_host) (void)hipHostFree(e->nblocks_host);
-    for (int k = 0; k < 2; k++) { if (e->stage_pin[k]) (void)hipHostFree(e->stage_pin[k]); if (e->stage_ev[k]) (void)hipEventDestroy(e->stage_ev[k]); }
+    for (int k = 0; k < nrsc5hip_engine::NSTAGE; k++) { if (e->stage_pin[k]) (void)hipHostFree(e->stage_pin[k]); if (e->stage_ev[k]) (void)hipEventDestroy(e->stage_ev[k]); }
     if (e->report_host) (void)hipHostFree(e->report_host);
     if (e->ingest) (void)hipStreamDestroy(e->ingest);
     if (e->ev_ingest) (void)hipEventDestroy(e->ev_ingest);
@@ -722,7 +726,7 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
     const int slot = async ? (int)(ln.step_count % 16) : 0;
     // batch pipeline: once every stream of the set is FINE, the next block's bookkeeping rides in k_sync's tail
     const int fuse = (async && !ln.acq_needed) ? 1 : 0;
-    { ProfScope p(e, NRSC5HIP_PROF_SYNC, ln.main); launch_sync(e->tb, ln.db, n, ids_dev, parity, slot, fuse, (int)window, ln.main, e->sync_lanes); }
+    { ProfScope p(e, NRSC5HIP_PROF_SYNC, ln.main); launch_sync(e->tb, ln.db, n, ids_dev, parity, slot, fuse, (int)window, ln.main, e->sync_lanes, decode_pids ? 0 : 1); }
     ln.prepared_by_sync = fuse != 0;
     if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_px_deint(e->tb, ln.db, n, ids_dev, parity, slot, ln.main); }
     if (!async) {
@@ -1033,9 +1037,9 @@ static int submit_step(nrsc5hip_engine *e, int s)
     } else {
         decode = !(known && e->pred_bc[s] != 15);
         if (!decode) g_seam[10] += 1;
-        int rc = issue_step(e, ln, 1, ids_dev, decode, false); if (rc) return rc;      // the PIDS frame is decoded by the report kernel
+        int rc = issue_step(e, ln, 1, ids_dev, decode, false); if (rc) return rc;      // the PIDS frame is decoded inside k_sync (pids_inline)
     }
-    { int rc = launch_report(e, s, !am); if (rc) return rc; }
+    { int rc = launch_report(e, s, false); if (rc) return rc; }    // FM: the PIDS frame was decoded inside k_sync; AM: inside its block kernel
     g_seam[2] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enq).count();
     g_seam[6] += 1;
     e->inflight_stream = s; e->inflight_decoded = decode; e->inflight_rd_pred = -1;
@@ -1099,7 +1103,7 @@ static int flush_staged(nrsc5hip_engine *e)
     const size_t chunk = e->staged_bytes;
     const unsigned count = cu8 ? (unsigned)chunk : (unsigned)(chunk / 2);
     e->staged_stream = -1; e->staged_bytes = 0; e->staged_q15 = 0;
-    e->stage_slot ^= 1;                                        // the next pushes fill the other buffer
+    e->stage_slot = (slot + 1) % nrsc5hip_engine::NSTAGE;     // the next pushes fill the next buffer
     const bool direct = cu8 && !am && e->direct_decimate;
     if (!direct && e->ingest_dirty) {                          // the FIFO is appended to in submission order whichever stream does it
         HIPCHK(hipEventRecord(e->ev_ingest, e->ingest)); HIPCHK(hipStreamWaitEvent(e->main, e->ev_ingest, 0)); e->ingest_dirty = false;
@@ -1140,8 +1144,8 @@ static int push_common(nrsc5hip_engine *e, int s, const void *host, size_t nbyte
         if (fast) {
             // stage in pinned memory; submit when the block completes (the mirror knows) or the buffer is full
             const int slot = e->stage_slot;
-            if (e->staged_bytes == 0 && e->stage_busy[slot]) { HIPCHK(hipEventSynchronize(e->stage_ev[slot])); e->stage_busy[slot] = false; }
-            const size_t room = e->stage_bytes - e->staged_bytes;
+            if (e->staged_bytes == 0 && e->stage_busy[slot]) { SeamClock clk(1); HIPCHK(hipEventSynchronize(e->stage_ev[slot])); e->stage_busy[slot] = false; }
+            const size_t room = e->stage_ring_bytes - e->staged_bytes;
             size_t chunk = nbytes_total > room ? room : nbytes_total;
             // never stage past the sample that completes the stream's next block: a large push is then processed block by block and
             // the FIFO never holds more than one window plus the carry of the last block, whatever q15_capacity is (>= 2 windows)
@@ -1155,7 +1159,7 @@ static int push_common(nrsc5hip_engine *e, int s, const void *host, size_t nbyte
             e->wr_host[s] += nq15;
             if (am && cu8) e->raw_host[s] += (long long)chunk / 2;
             src += chunk; nbytes_total -= chunk;
-            if (e->wr_host[s] - e->rd_host[s] >= window_of(e, s) || e->staged_bytes == e->stage_bytes) {
+            if (e->wr_host[s] - e->rd_host[s] >= window_of(e, s) || e->staged_bytes == e->stage_ring_bytes) {
                 if ((rc = flush_staged(e))) return rc;
                 if (e->manual_step[s] && nbytes_total == 0) break;     // samples are on their way to the FIFO; nrsc5hip_stream_step runs the block
                 if ((rc = stream_steps(e, s))) return rc;

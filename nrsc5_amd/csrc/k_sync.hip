@@ -229,7 +229,7 @@ __device__ __forceinline__ void store_px(int8_t *pair, float2 v, int side, int p
 #define SYNC_OCCUPANCY(NT)
 #endif
 template <int SYNC_NT>
-__global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare, int window)
+__global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare, int window, int pids_inline)
 {
     wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
     const int s = wave_uniform(stream_of(ids, blockIdx.x));    // in a scalar register: every address derived from it stays off the VGPR budget
@@ -265,9 +265,11 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
     __shared__ float sh_f[8];
     __shared__ double red[2][SYNC_NW];
     __shared__ float sh_diff[2 * 14];
+    __shared__ __attribute__((aligned(16))) int8_t sh_pids_coded[3 * PIDS_LEN];
+    __shared__ uint32_t sh_pids_out[4];
     __shared__ int sh_seen[16 + 64];
     __shared__ float ref_freq[NREF_MAX];
-    if (tid == 0) sh_i[2] = 0;                                 // set when this block completes a P1 frame (replay checkpoint below)
+    if (tid == 0) { sh_i[2] = 0; sh_i[3] = 0; }                // [2] set when this block completes a P1 frame (replay checkpoint below), [3] when a PIDS frame was decoded here
 
     float2 *bins = db.bins + (size_t)s * NSYM * LIVE_N;       // [sym][live]
     BlockRecord &rec = db.records[(size_t)s * db.rec_cap + (st.nblocks % db.rec_cap)];
@@ -556,11 +558,30 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
         // k_pids_decode, off this kernel's critical path (results only feed the record, not the loops)
         int8_t *stage = db.pids_stage + (((size_t)s * NWIN + parity) * 16 + slot) * (3 * PIDS_LEN);
         const int8_t *pm_src = ppb == PM_PART ? pm_tile : pm_blk;      // MP1: the rows are still in LDS
-        for (int n = tid; n < PIDS_CODED; n += SYNC_NT) stage[n + n / 5] = pm_src[tb.pids_gather[bc * PIDS_CODED + n]];
-        for (int n = tid; n < PIDS_CODED / 5; n += SYNC_NT) stage[6 * n + 5] = 0;
+        if (pids_inline) {
+            // streaming seam (block-uniform): the 80-bit frame is decoded right here, by the second wave, while the first lane does the
+            // block's bookkeeping and the record -- as its own launch (or in the report kernel) it was 10-20 us on a chain the host
+            // waits for
+            for (int n = tid; n < PIDS_CODED; n += SYNC_NT) sh_pids_coded[n + n / 5] = pm_src[tb.pids_gather[bc * PIDS_CODED + n]];
+            for (int n = tid; n < PIDS_CODED / 5; n += SYNC_NT) sh_pids_coded[6 * n + 5] = 0;
+            __syncthreads();
+            if ((tid >> 6) == 1) {
+                uint32_t *out = sh_pids_out;
+                viterbi_k7_wave_compact<PIDS_LEN>(sh_pids_coded, nullptr, out);
+                WAVE_LDS_FENCE();
+                if (tid == 64) {
+                    const uint32_t p[3] = { out[0] ^ tb.scr_pids[0], out[1] ^ tb.scr_pids[1], (out[2] ^ tb.scr_pids[2]) & 0xffffu };   // descramble (decode.c:470)
+                    out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; out[3] = pids_crc_ok(p) ? 1u : 0u;
+                }
+            }
+        } else {
+            for (int n = tid; n < PIDS_CODED; n += SYNC_NT) stage[n + n / 5] = pm_src[tb.pids_gather[bc * PIDS_CODED + n]];
+            for (int n = tid; n < PIDS_CODED / 5; n += SYNC_NT) stage[6 * n + 5] = 0;
+        }
         SYNC_MARK(6);
         if (tid == 0) {
-            db.pids_rec[((size_t)s * NWIN + parity) * 16 + slot] = st.nblocks % db.rec_cap;
+            if (!pids_inline) db.pids_rec[((size_t)s * NWIN + parity) * 16 + slot] = st.nblocks % db.rec_cap;
+            else sh_i[3] = 1;                                  // the tail files the frame
             rec.flags |= REC_PIDS;
             rec.bc_decoded = bc;
             if (bc == 0) st.started_pm = 1;                    // decode.c:383-390
@@ -614,6 +635,10 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
         rec.bc = bc_now; rec.psmi = psmi; rec.cfo_wait = cfo_wait; rec.next_samperr = next_samperr;
         rec.prev_angle = prev_angle;
         rec.next_angle = next_angle;
+        if (sh_i[3]) {                                         // the PIDS frame wave 1 decoded (streaming seam)
+            rec.pids[0] = sh_pids_out[0]; rec.pids[1] = sh_pids_out[1]; rec.pids[2] = sh_pids_out[2];
+            if (sh_pids_out[3]) rec.flags |= REC_PIDS_CRC;
+        }
         st.nblocks = nblocks + 1;
         st.active = 0;
     }
@@ -635,12 +660,12 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
     SYNC_MARK(7);
 }
 
-void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, int window, hipStream_t st, int lanes)
+void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, int window, hipStream_t st, int lanes, int pids_inline)
 {
     // lanes: 0 = by the size of the stream set (see SYNC_OCCUPANCY above), else 256 / 768 (nrsc5hip_debug_tune NRSC5HIP_TUNE_SYNC_LANES)
     const int nt = lanes ? lanes : 768;                        // measured at 256 streams: 32.8 ms per pass with 768, 33.8 with 256 (profiles/r04_sync_lanes.txt)
-    if (nt == 768) hipLaunchKernelGGL(k_sync<768>, dim3(nstreams), dim3(768), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window);
-    else hipLaunchKernelGGL(k_sync<256>, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window);
+    if (nt == 768) hipLaunchKernelGGL(k_sync<768>, dim3(nstreams), dim3(768), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window, pids_inline);
+    else hipLaunchKernelGGL(k_sync<256>, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window, pids_inline);
 }
 
 // ---- deferred PIDS decode: one wave per (slot, stream) with a staged frame -----------------------------------

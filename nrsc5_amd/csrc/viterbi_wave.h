@@ -239,8 +239,8 @@ __device__ inline void viterbi_k7_wave_fast(const int8_t *coded, int len, unsign
 // unrolled fast path with a 16-step last chunk 19 us -- ~19 KB of straight-line code executed once per launch, all of it
 // instruction-cache misses (profiles/r04_dropin_timeline.txt).  This form is ~1 KB.
 // Decisions stay in the lane: a lane's own-wins bits of 30 steps per VGPR (the fast path parks 64-lane ballots instead: a ballot
-// store per step); the traceback fetches the word of the survivor's lane with v_readlane and runs on the scalar ALU.  `dec` serves
-// as len + 64 bytes of scratch for the decoded bits.
+// store per step); the traceback fetches the word of the survivor's lane with v_readlane and runs on the scalar ALU.  `dec` is
+// not used.
 template <int len>
 __device__ __forceinline__ void viterbi_k7_wave_compact(const int8_t *coded, unsigned long long *dec, uint32_t *out)
 {
@@ -280,36 +280,34 @@ __device__ __forceinline__ void viterbi_k7_wave_compact(const int8_t *coded, uns
     const int smin = wave_min_i32(pm == best ? lane : 64);
     unsigned l = (unsigned)wave_uniform(smin);                 // lane of the survivor, kept in an SGPR
     // the decoded bits of a group of six steps are the survivor's lane bits at the group's last step (bit r at step r of the group:
-    // each step only rewrites its own bit afterwards); parked as one byte per group, the frame's words are ballots over them
-    uint8_t *park = (uint8_t *)dec;                            // byte g: steps 6 g .. 6 g + 5
+    // each step only rewrites its own bit afterwards); the traceback is unrolled in full, so every group lands in the output words
+    // with constant shifts -- no memory, no barrier: the decoder can run on one wave of a larger workgroup
+    uint32_t o[5] = {0, 0, 0, 0, 0};
 #pragma unroll
     for (int j = 4; j >= 0; j--) {
-#pragma unroll 1
+#pragma unroll
         for (int g = 4; g >= 0; g--) {
-            if (30 * j + 6 * g >= steps) continue;             // wave-uniform
+            if (30 * j + 6 * g >= steps) continue;             // compile-time
             const unsigned six = l & 63u;
-            const uint32_t h = (uint32_t)wave_readlane((int)hist[j], (int)l) >> (6 * g);    // the chase below only flips bits of l: the lane's word is re-read per step
             unsigned lw = l;
 #pragma unroll
             for (int r = 5; r >= 0; r--) {
-                const uint32_t hw = (r == 5) ? h : (uint32_t)wave_readlane((int)hist[j], (int)lw) >> (6 * g);
-                const unsigned own = (hw >> r) & 1u;
+                const uint32_t hw = (uint32_t)wave_readlane((int)hist[j], (int)lw);      // the word of the lane the survivor sits in now
+                const unsigned own = (hw >> (6 * g + r)) & 1u;
                 lw ^= own ? 0u : (1u << r);
             }
             l = lw;
-            if (lane == 0) park[5 * j + g] = (uint8_t)six;
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                const int ob = 30 * j + 6 * g + r - VIT_EXTRA;  // the frame bit step 30 j + 6 g + r decodes
+                if (ob >= 0 && ob < len) o[ob >> 5] |= ((six >> r) & 1u) << (ob & 31);
+            }
         }
     }
-    WAVE_LDS_SYNC();
-    constexpr int nwords = (len + 31) / 32;
+    (void)dec;
+    if (lane == 0) {
 #pragma unroll
-    for (int base = 0; base < len; base += 64) {               // output bit ob <-> step ob + VIT_EXTRA
-        const int ob = base + lane, t = ob + VIT_EXTRA;
-        const unsigned long long b = __ballot(ob < len && ((park[t / 6] >> (t % 6)) & 1u) != 0);
-        if (lane == 0) {
-            out[base >> 5] = (uint32_t)b;
-            if ((base >> 5) + 1 < nwords) out[(base >> 5) + 1] = (uint32_t)(b >> 32);
-        }
+        for (int w = 0; w < (len + 31) / 32; w++) out[w] = o[w];
     }
 }
 

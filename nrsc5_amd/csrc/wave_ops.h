@@ -20,6 +20,13 @@ __device__ __forceinline__ int wave_readlane(int v, int lane) { return __builtin
 #else
 #define WAVE_LDS_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 #endif
+// the same ordering without the wave barrier's HIPEMU stand-in (a workgroup barrier): for code that only one wave of a larger
+// workgroup executes
+#ifdef HIPEMU
+#define WAVE_LDS_FENCE() do { } while (0)
+#else
+#define WAVE_LDS_FENCE() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+#endif
 // Raise this wave's issue priority (s_setprio): the per-block kernels are a serial chain of 224 steps per pass, the
 // trellis passes that share their SIMDs are long-running background work.
 #ifdef HIPEMU
