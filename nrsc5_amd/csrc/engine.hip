@@ -1450,9 +1450,13 @@ static int patch_am_ber(nrsc5hip_engine *e, int stream, nrsc5hip_record *recs, i
 
 extern "C" int nrsc5hip_drain(nrsc5hip_engine *e, int stream, nrsc5hip_record *out, int max, int *n_out)
 {
-    ON_ENGINE_DEVICE(e);
+    ON_ENGINE_DEVICE_FAST(e);
     int rc = check_stream(e, stream); if (rc) return rc;
     if (!out || !n_out) FAIL(NRSC5HIP_EINVAL, "null argument");
+    // the block step in flight is waited for; samples that are still being decimated on the ingest stream are not (a drop-in session
+    // drains right after it has submitted the last chunk of the next block: waiting for that kernel was ~20 us per block)
+    if (e->inflight_stream >= 0 && (rc = harvest(e, true))) return rc;
+    if (!e->mirror_ok[stream] && (rc = settle(e))) return rc;
     if (e->mirror_ok[stream]) {
         // fast streaming seam: every record of a finished block step is on the host already (k_stream_report)
         std::deque<BlockRecord> &q = e->pending[stream];
@@ -1526,16 +1530,18 @@ extern "C" int nrsc5hip_stream_step(nrsc5hip_engine *e, int stream)
 
 extern "C" int nrsc5hip_p1_frame_packed(nrsc5hip_engine *e, int stream, int slot, uint32_t *words)
 {
-    ON_ENGINE_DEVICE(e);
+    ON_ENGINE_DEVICE_FAST(e);
     SeamClock clk(7);
     int rc = check_stream(e, stream); if (rc) return rc;
     if (slot < 0 || slot >= e->db.p1_slots || !words) FAIL(NRSC5HIP_EINVAL, "bad slot/argument");
+    if (e->inflight_stream >= 0 && (rc = harvest(e, true))) return rc;
     if (e->mirror_ok[stream] && e->db.p1_mirror && e->frames_host && e->mode_host[stream] != MODE_AM) {
-        // fast seam (FM): the step that decoded the frame has been harvested (ON_ENGINE_DEVICE settles), and its traceback wrote the frame
-        // into the pinned mirror before the report kernel that the harvest waited for
+        // fast seam (FM): the step that decoded the frame has been harvested, and its traceback wrote the frame into the pinned
+        // mirror before the report kernel that the harvest waited for
         memcpy(words, e->frames_host + ((size_t)stream * e->db.p1_slots + slot) * P1_WORDS, P1_WORDS * sizeof(uint32_t));
         return 0;
     }
+    if ((rc = settle(e))) return rc;
     HIPCHK(hipStreamSynchronize(e->main));
     HIPCHK(hipMemcpy(words, e->db.p1_ring + ((size_t)stream * e->db.p1_slots + slot) * P1_WORDS, P1_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return 0;
@@ -1554,7 +1560,7 @@ extern "C" void nrsc5hip_unpack_bits(const uint32_t *words, int nbits, uint8_t *
 
 extern "C" int nrsc5hip_p1_frame_bits(nrsc5hip_engine *e, int stream, int slot, uint8_t *bits)
 {
-    ON_ENGINE_DEVICE(e);
+    ON_ENGINE_DEVICE_FAST(e);
     std::vector<uint32_t> w(P1_WORDS);
     int rc = nrsc5hip_p1_frame_packed(e, stream, slot, w.data()); if (rc) return rc;
     nrsc5hip_unpack_bits(w.data(), P1_LEN, bits);

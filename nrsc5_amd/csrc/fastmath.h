@@ -57,4 +57,44 @@ __device__ __forceinline__ float fast_atan2(float y, float x)
 #endif
 }
 
+// Double-precision cosine / sine / arc tangent of SMALL arguments by their Taylor series (Horner), for the NCO step of the next
+// block (prepare_block: the single lane that runs it sits at the end of the block-step chain; the device libm's three calls were
+// ~5 k of the sync kernel's ~11 k "finish" cycles).  |x| <= 0.25: the series are cut where the next term is below 1e-20 of the
+// result, the evaluation error is a few ulps of a double -- the callers round the results to float or use them as a phase
+// increment whose own uncertainty is twelve orders of magnitude larger.
+__device__ __forceinline__ void small_cos_sin(double x, double &c, double &s)
+{
+    const double w = x * x;
+    // cos: 1 - w/2! + w^2/4! - ... + w^9/18!
+    double pc = 1.0 / 6402373705728000.0;
+    pc = pc * w - 1.0 / 20922789888000.0;
+    pc = pc * w + 1.0 / 87178291200.0;
+    pc = pc * w - 1.0 / 479001600.0;
+    pc = pc * w + 1.0 / 3628800.0;
+    pc = pc * w - 1.0 / 40320.0;
+    pc = pc * w + 1.0 / 720.0;
+    pc = pc * w - 1.0 / 24.0;
+    pc = pc * w + 0.5;
+    c = 1.0 - w * pc;
+    // sin: x (1 - w/3! + w^2/5! - ... - w^9/19!)
+    double ps = -1.0 / 121645100408832000.0;
+    ps = ps * w + 1.0 / 355687428096000.0;
+    ps = ps * w - 1.0 / 1307674368000.0;
+    ps = ps * w + 1.0 / 6227020800.0;
+    ps = ps * w - 1.0 / 39916800.0;
+    ps = ps * w + 1.0 / 362880.0;
+    ps = ps * w - 1.0 / 5040.0;
+    ps = ps * w + 1.0 / 120.0;
+    ps = ps * w - 1.0 / 6.0;
+    s = x + x * (w * ps);
+}
+__device__ __forceinline__ double small_atan(double t)         // |t| <= 0.26: t (1 - w/3 + w^2/5 - ... + w^14/29), w = t^2
+{
+    const double u = -(t * t);
+    double q = 1.0 / 29.0;
+#pragma unroll
+    for (int k = 13; k >= 0; k--) q = q * u + 1.0 / (double)(2 * k + 1);
+    return t * q;
+}
+
 }  // namespace nrsc5

@@ -280,7 +280,8 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
 
     // ---- sync_adjust (sync.c:769-777): timing pick moved by adj samples -> rotate every loop phase
     {
-        const int adj = SYM_N / 2 - samperr;
+        const int adj = SYM_N / 2 - samperr;                   // block-uniform; 0 (nothing to rotate: x - 0.0 == x) on most blocks of a
+        if (adj != 0)                                          // stream without a sample-clock error
         for (int l = tid; l < LIVE_N; l += SYNC_NT) {
             const int b = live_to_bin(l);
             st.costas_phase[l] = (float)((double)st.costas_phase[l] - (adj * (b - FFT_N / 2)) * 2 * M_PI / FFT_N);

@@ -4,6 +4,7 @@
 // tiny kernel (k_prepare) or, in the batch pipeline, in the tail of the previous block's k_sync.
 #pragma once
 #include "kernels.h"
+#include "fastmath.h"
 
 namespace nrsc5 {
 
@@ -90,8 +91,15 @@ __device__ inline void prepare_block(const DevBuffers &db, StreamState &st, int 
     const float dtheta = angle / FFT_N;
     // The reference rotates by the float pair (cosf, sinf)(dtheta) once per sample (acquire.c:168,250);
     // the angle of that rounded unit vector, not dtheta itself, is its effective NCO step.
-    const float inc_c = (float)cos((double)dtheta), inc_s = (float)sin((double)dtheta);
-    st.dtheta = atan2((double)inc_s, (double)inc_c);
+    float inc_c, inc_s;
+    if (fabsf(dtheta) < 0.25f) {                               // |integer CFO| up to 80 bins: always, in practice
+        double c, sn; small_cos_sin((double)dtheta, c, sn);
+        inc_c = (float)c; inc_s = (float)sn;
+        st.dtheta = small_atan((double)inc_s / (double)inc_c);
+    } else {
+        inc_c = (float)cos((double)dtheta); inc_s = (float)sin((double)dtheta);
+        st.dtheta = atan2((double)inc_s, (double)inc_c);
+    }
     // phase *= e^{-i (1080 - samperr) angle / 2048}            (acquire.c:166)
     double th = st.theta + (double)(-(float)(SYM_N / 2 - samperr) * angle / FFT_N);
     th -= 2 * M_PI * rint(th / (2 * M_PI));
