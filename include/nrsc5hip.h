@@ -190,6 +190,12 @@ long long nrsc5hip_bytes_to_next_block(nrsc5hip_engine *e, int stream, int cu8);
 int nrsc5hip_drain_ready(nrsc5hip_engine *e, int stream, nrsc5hip_record *out, int max, int *n_out);
 int nrsc5hip_stream_set_manual_step(nrsc5hip_engine *e, int stream, int on);
 int nrsc5hip_stream_step(nrsc5hip_engine *e, int stream);
+/* One step further: when the block step still in flight started in SYNC_FINE and cannot complete a P1 frame (15 of 16 blocks), nothing
+ * its delivery tells the host can change what the next block does -- frame_process's only way back into L1 is the first header of a
+ * P1 frame (frame.c:535-540) -- so the next block's step may be queued BEHIND it before the host has even looked at it:
+ * nrsc5hip_stream_step_ahead does that if it is safe and says so in *submitted; the nrsc5hip_drain that follows waits for the older
+ * step only.  The device then runs block n + 1 while the host hands block n to L2. */
+int nrsc5hip_stream_step_ahead(nrsc5hip_engine *e, int stream, int *submitted);
 
 /* ---- batch path (device buffers) ------------------------------------------------------------------ */
 /* Decimate + append one cu8 chunk per listed stream.  dev_iq: device pointer, chunk k at
@@ -384,7 +390,7 @@ enum {
 void nrsc5hip_debug_seam_totals(double out[8], int reset);   /* totals of the CALLING THREAD's sessions */
 /* ... [0] block steps left in flight (deferred wait), [1] read positions the host predicted wrongly (expected: 0), [2] steps submitted
  * without the P1 decode launches (no frame could complete), [3] P1 decodes launched after the fact (expected: 0) */
-void nrsc5hip_debug_seam_counts(double out[4], int reset);
+void nrsc5hip_debug_seam_counts(double out[6], int reset);   /* ... [4] block steps submitted ahead of the previous block's delivery, [5] reserved */
 /* test / bench hygiene: overwrite every result buffer a pass writes (frame rings on the device and their pinned host mirror, record
  * rings) with a pattern no decode produces -- a check after the next pass can then only pass on bits written by that pass */
 int nrsc5hip_debug_poison_results(nrsc5hip_engine *e);

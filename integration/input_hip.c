@@ -157,9 +157,13 @@ static void push_pieces(input_t *st, const uint8_t *buf, uint32_t nbytes, int cu
         consumed += piece;
         if (completes)
         {
+            /* 15 of 16 blocks cannot end a P1 frame: nothing their delivery tells frame.c can send the receiver back to NONE, so the
+             * step of THIS block is queued behind them before they are even looked at (the engine decides; include/nrsc5hip.h) */
+            int ahead = 0;
+            if (!sync_delivery() && nrsc5hip_stream_step_ahead(ENGINE(st), 0, &ahead) != 0) { fail(st, "stream_step_ahead"); return; }
             deliver(st, 1);                                     /* the block before: its frames reach frame.c now ... */
             if (FAILED(st)) return;
-            if (nrsc5hip_stream_step(ENGINE(st), 0) != 0) { fail(st, "stream_step"); return; }   /* ... and only then is this one processed */
+            if (!ahead && nrsc5hip_stream_step(ENGINE(st), 0) != 0) { fail(st, "stream_step"); return; }   /* ... and only then is this one processed */
             deliver(st, sync_delivery());
         }
         else

@@ -26,10 +26,11 @@ static thread_local char g_err[512] = "";
 
 // wall-clock totals of the fast streaming seam of the CALLING THREAD's sessions (nrsc5hip_debug_seam_totals): where a drop-in
 // session's time goes.  Thread-local: sessions driven from different threads never share a counter.
-static thread_local double g_seam[12];  // [0] s copying pushes into pinned staging, [1] s enqueueing H2D + decimator, [2] s enqueueing block steps,
+static thread_local double g_seam[14];  // [0] s copying pushes into pinned staging, [1] s enqueueing H2D + decimator, [2] s enqueueing block steps,
                            // [3] s waiting for the device (the one sync per block), [4] pushes, [5] submissions, [6] block steps, [7] s in drain / frame fetches,
                            // [8] block steps whose wait was deferred, [9] read positions mispredicted, [10] steps without the P1 decode launches,
-                           // [11] P1 decodes launched after the fact (the prediction said no frame could complete)
+                           // [11] P1 decodes launched after the fact (the prediction said no frame could complete),
+                           // [12] block steps submitted ahead of the previous block's delivery
 struct SeamClock {
     int slot; std::chrono::steady_clock::time_point t0;
     explicit SeamClock(int s) : slot(s), t0(std::chrono::steady_clock::now()) {}
@@ -39,9 +40,9 @@ extern "C" void nrsc5hip_debug_seam_totals(double out[8], int reset)
 {
     for (int k = 0; k < 8; k++) { if (out) out[k] = g_seam[k]; if (reset) g_seam[k] = 0; }
 }
-extern "C" void nrsc5hip_debug_seam_counts(double out[4], int reset)
+extern "C" void nrsc5hip_debug_seam_counts(double out[6], int reset)
 {
-    for (int k = 0; k < 4; k++) { if (out) out[k] = g_seam[8 + k]; if (reset) g_seam[8 + k] = 0; }
+    for (int k = 0; k < 6; k++) { if (out) out[k] = g_seam[8 + k]; if (reset) g_seam[8 + k] = 0; }
 }
 extern "C" const char *nrsc5hip_last_error(void) { return g_err; }
 #ifndef NRSC5HIP_SOURCE_SHA
@@ -135,7 +136,7 @@ struct nrsc5hip_engine {
     // samples accepted by a push but not submitted yet: they wait in stage_pin[stage_slot] until the mirror says a block completes
     // (or the buffer is full, or anything else looks at the stream) -- one H2D + one decimator launch per BLOCK, not per push
     int staged_stream; size_t staged_bytes; bool staged_cu8; long long staged_q15;
-    StreamReport *report_host, *report_dev;    // one pinned, device-mapped report
+    StreamReport *report_host[2], *report_dev[2];   // pinned, device-mapped reports: the step with sequence number q posts into [q & 1]
     std::vector<long long> rd_host;            // FIFO read position (absolute decimated samples) as of the last report
     std::vector<int> fetched;                  // records of the stream copied to `pending` so far (absolute index)
     std::vector<char> mirror_ok;               // rd_host / pending are exact: only the streaming seam touched the stream since its reset
@@ -148,6 +149,12 @@ struct nrsc5hip_engine {
     unsigned report_seq;               // sequence number the most recently launched report kernel posts when it is done
     long long inflight_rd_pred;        // the read position predicted for the step in flight (-1: no prediction, the mirror waits)
     bool inflight_decoded;             // the step in flight carried the P1 de-interleave / trellis / traceback launches
+    unsigned inflight_seq;             // its report's sequence number
+    // A second step, submitted AHEAD of the delivery of the one in flight (nrsc5hip_stream_step_ahead): allowed when the block in
+    // flight starts FINE and cannot complete a P1 frame -- nothing its delivery tells the host can change what the next block does
+    // (frame.c's only way back into L1 is the first header of a P1 frame, frame.c:535-540) -- so the device runs block n + 1 while
+    // the host still hands block n to L2.  Its read-position prediction needs block n's record: it is made when that is harvested.
+    struct Ahead { bool valid; int stream; unsigned seq; bool decoded; } ahead;
     bool inflight_progress;            // the last harvested step processed (or left pending) a block
     bool direct_decimate;              // 1 (default): FM cu8 pushes are decimated straight from the pinned staging buffer; 0 (NRSC5HIP_TUNE_DIRECT_DECIMATE): H2D copy first
     bool defer_wait;                   // 1 (default): predictable steps stay in flight; 0 (NRSC5HIP_TUNE_DEFER_WAIT): every step is waited for at once
@@ -575,11 +582,14 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             e->ingest_dirty = false; e->main_stepped = false; e->early_flush = 96u << 10;
             if ((rc = dev_alloc(e, &e->decim_ticket, 1))) break;
             if (hipMemset(e->decim_ticket, 0, sizeof(unsigned)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
-            void *dp = nullptr;
-            if (hipHostMalloc((void **)&e->report_host, sizeof(*e->report_host), hipHostMallocMapped) != hipSuccess ||
-                hipHostGetDevicePointer(&dp, e->report_host, 0) != hipSuccess) { rc = NRSC5HIP_ENOMEM; snprintf(g_err, sizeof(g_err), "pinned report allocation failed"); break; }
-            e->report_dev = (StreamReport *)dp;
-            memset(e->report_host, 0, sizeof(*e->report_host));
+            for (int k = 0; k < 2 && !rc; k++) {
+                void *dp = nullptr;
+                if (hipHostMalloc((void **)&e->report_host[k], sizeof(StreamReport), hipHostMallocMapped) != hipSuccess ||
+                    hipHostGetDevicePointer(&dp, e->report_host[k], 0) != hipSuccess) { rc = NRSC5HIP_ENOMEM; snprintf(g_err, sizeof(g_err), "pinned report allocation failed"); break; }
+                e->report_dev[k] = (StreamReport *)dp;
+                memset(e->report_host[k], 0, sizeof(StreamReport));
+            }
+            if (rc) break;
         }
         e->stage_slot = 0; e->staged_stream = -1; e->staged_bytes = 0; e->staged_q15 = 0; e->staged_cu8 = false;
         if ((rc = dev_alloc(e, &e->ids_dev, S))) break;
@@ -596,7 +606,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         e->mode_host.assign(S, MODE_FM); e->raw_host.assign(S, 0); e->attached.assign(S, 0);
         e->rd_host.assign(S, 0); e->fetched.assign(S, 0); e->mirror_ok.assign(S, cfg->p1_async ? 0 : 1); e->pending.assign(S, {});
         e->pred_ok.assign(S, 0); e->pred_samperr.assign(S, 0); e->pred_bc.assign(S, 0); e->manual_step.assign(S, 0);
-        e->inflight_stream = -1; e->report_seq = 0; e->inflight_rd_pred = -1; e->inflight_decoded = true; e->inflight_progress = false;
+        e->inflight_stream = -1; e->report_seq = 0; e->inflight_rd_pred = -1; e->inflight_decoded = true; e->inflight_progress = false; e->inflight_seq = 0; e->ahead.valid = false;
         e->defer_wait = true; e->direct_decimate = true; e->counters_clean = false;
         e->lane.db = db; e->lane.counters_dev = db.counters;
         e->prof_on = false; e->prof_only = -1;
@@ -620,7 +630,7 @@ extern "C" void nrsc5hip_engine_destroy(nrsc5hip_engine *e)
     if (e->frames_host) (void)hipHostFree(e->frames_host);
     if (e->nblocks_host) (void)hipHostFree(e->nblocks_host);
     for (int k = 0; k < nrsc5hip_engine::NSTAGE; k++) { if (e->stage_pin[k]) (void)hipHostFree(e->stage_pin[k]); if (e->stage_ev[k]) (void)hipEventDestroy(e->stage_ev[k]); }
-    if (e->report_host) (void)hipHostFree(e->report_host);
+    for (int k = 0; k < 2; k++) if (e->report_host[k]) (void)hipHostFree(e->report_host[k]);
     if (e->ingest) (void)hipStreamDestroy(e->ingest);
     if (e->ev_ingest) (void)hipEventDestroy(e->ev_ingest);
     if (e->ev_main) (void)hipEventDestroy(e->ev_main);
@@ -946,7 +956,7 @@ static void forget_prediction(nrsc5hip_engine *e, int s) { e->pred_ok[s] = 0; }
 // host spins on it (a stream synchronisation returns ~5-10 us after the kernel has ended); bounded, then the ordinary wait.
 static int wait_report(nrsc5hip_engine *e, unsigned seq, bool block)
 {
-    const volatile unsigned *p = &e->report_host->seq;
+    const volatile unsigned *p = &e->report_host[seq & 1]->seq;
     if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == seq) return 1;
     if (!block) return 0;
     const auto t0 = std::chrono::steady_clock::now();
@@ -966,7 +976,9 @@ static int launch_report(nrsc5hip_engine *e, int s, bool with_pids)
 {
     e->report_seq++;
     if (e->report_seq == 0) e->report_seq = 1;                 // 0 = the freshly cleared report
-    launch_stream_tail(e->tb, e->lane.db, s, e->fetched[s], e->report_dev, e->report_seq, with_pids ? 1 : 0, e->lane.main);
+    // records to post: from the first one the host has not seen -- the block of a step still in flight is not this step's to report
+    const int first_rec = e->fetched[s] + ((e->inflight_stream == s) ? 1 : 0);
+    launch_stream_tail(e->tb, e->lane.db, s, first_rec, e->report_dev[e->report_seq & 1], e->report_seq, with_pids ? 1 : 0, e->lane.main);
     e->counters_clean = true;
     HIPCHK(hipGetLastError());
     return 0;
@@ -980,21 +992,23 @@ static int harvest(nrsc5hip_engine *e, bool block)
     nrsc5hip_engine::Lane &ln = e->lane;
     {
         const auto t_wait = std::chrono::steady_clock::now();
-        const int got = wait_report(e, e->report_seq, block);
+        const int got = wait_report(e, e->inflight_seq, block);
         if (got < 0) return got;
         if (!got) return 0;
         if (block) g_seam[3] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_wait).count();
     }
     e->inflight_stream = -1;
-    const StreamReport *rp = e->report_host;
+    const StreamReport *rp = e->report_host[e->inflight_seq & 1];
     bool p1_missing = false;
     for (int k = 0; k < rp->nrec; k++) if ((rp->rec[k].flags & REC_P1) && e->mode_host[s] != MODE_AM && !e->inflight_decoded) p1_missing = true;
     if (p1_missing) {
         // the prediction said no P1 frame could complete in this block and one did: decode it now, take the record again
         g_seam[11] += 1;
+        if (e->ahead.valid) FAIL(NRSC5HIP_EHIP, "stream %d: a block submitted without its P1 decode completed a frame, and the next block is already running", s);
         int rc = launch_inorder_p1(e, ln, 1, e->all_ids_dev + s); if (rc) return rc;
         if ((rc = launch_report(e, s, false))) return rc;
         if ((rc = wait_report(e, e->report_seq, true)) < 0) return rc;
+        rp = e->report_host[e->report_seq & 1];
     }
     ln.acq_needed = rp->counters[1] > 0;
     ln.px_needed = rp->counters[2] > 0;
@@ -1009,12 +1023,27 @@ static int harvest(nrsc5hip_engine *e, bool block)
         e->pred_samperr[s] = r.next_samperr; e->pred_bc[s] = r.bc;
     }
     e->inflight_progress = rp->counters[0] != 0;
+    if (e->ahead.valid) {
+        // the step submitted ahead becomes the step in flight; now that its predecessor's record is here, so does its prediction
+        const int s2 = e->ahead.stream;
+        e->ahead.valid = false;
+        e->inflight_stream = s2; e->inflight_seq = e->ahead.seq; e->inflight_decoded = e->ahead.decoded; e->inflight_rd_pred = -1;
+        if (e->pred_ok[s2] && !e->cfg.l2_feedback && e->defer_wait) {
+            e->inflight_rd_pred = e->rd_host[s2] + WIN_N - SYM_N + e->pred_samperr[s2];
+            e->rd_host[s2] = e->inflight_rd_pred;
+            g_seam[8] += 1;
+        } else {
+            return harvest(e, true);                           // not predictable after all: wait for it now
+        }
+        return 0;
+    }
     if (e->prof_on) { HIPCHK(hipStreamSynchronize(ln.main)); prof_collect(e); }
     return 0;
 }
 
 // Submit one block step of stream s (its window is complete by the mirror) and the report kernel behind it.
-static int submit_step(nrsc5hip_engine *e, int s)
+// ahead: a step of the same stream is still in flight (FINE at its start, no P1 decode): this one is queued behind it.
+static int submit_step(nrsc5hip_engine *e, int s, bool ahead = false)
 {
     nrsc5hip_engine::Lane &ln = e->lane;
     const int *ids_dev = e->all_ids_dev + s;                   // identity list: entry s is s
@@ -1035,14 +1064,17 @@ static int submit_step(nrsc5hip_engine *e, int s)
         launch_am_step(e->tb, ln.db, 1, ids_dev, ln.main, e->cfg.l2_feedback, -1, (int)(ln.am_step_count % 8), (int)(ln.am_step_count / 8));
         ln.am_step_count++;
     } else {
-        decode = !(known && e->pred_bc[s] != 15);
+        // (ahead: the block in flight runs FINE with block count pred_bc and ends no frame, so this one runs with pred_bc + 1)
+        const int bc = ahead ? (e->pred_bc[s] + 1) % 16 : e->pred_bc[s];
+        decode = !(known && bc != 15);
         if (!decode) g_seam[10] += 1;
         int rc = issue_step(e, ln, 1, ids_dev, decode, false); if (rc) return rc;      // the PIDS frame is decoded inside k_sync (pids_inline)
     }
     { int rc = launch_report(e, s, false); if (rc) return rc; }    // FM: the PIDS frame was decoded inside k_sync; AM: inside its block kernel
     g_seam[2] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enq).count();
     g_seam[6] += 1;
-    e->inflight_stream = s; e->inflight_decoded = decode; e->inflight_rd_pred = -1;
+    if (ahead) { e->ahead.valid = true; e->ahead.stream = s; e->ahead.seq = e->report_seq; e->ahead.decoded = decode; g_seam[12] += 1; return 0; }
+    e->inflight_stream = s; e->inflight_decoded = decode; e->inflight_rd_pred = -1; e->inflight_seq = e->report_seq;
     if (!am && known && e->defer_wait) {
         // the block starts FINE: samperr = 1080 + the previous block's feedback, keep = 2160 + (1080 - samperr), no keep_extra
         // (acquire.c:112,259; k_sync's tail): the mirror moves now, the report is taken when somebody needs it
@@ -1059,7 +1091,8 @@ static int stream_steps(nrsc5hip_engine *e, int s)
 {
     int guard = 0;
     while (e->wr_host[s] - e->rd_host[s] >= window_of(e, s)) {
-        int rc = harvest(e, true); if (rc) return rc;          // one step in flight per engine
+        int rc = 0;
+        while (e->inflight_stream >= 0) if ((rc = harvest(e, true))) return rc;     // nothing in flight when a step is submitted here
         if (e->wr_host[s] - e->rd_host[s] < window_of(e, s)) break;
         if ((rc = submit_step(e, s))) return rc;
         if (e->inflight_rd_pred >= 0) continue;                // deferred: the mirror already shows the block consumed
@@ -1072,7 +1105,7 @@ static int stream_steps(nrsc5hip_engine *e, int s)
 static int settle(nrsc5hip_engine *e)
 {
     if (!e) return 0;
-    if (e->inflight_stream >= 0) { int rc = harvest(e, true); if (rc) return rc; }
+    while (e->inflight_stream >= 0) { int rc = harvest(e, true); if (rc) return rc; }
     if (e->ingest_dirty) { HIPCHK(hipStreamSynchronize(e->ingest)); e->ingest_dirty = false; }    // whatever follows runs on `main` (or the host) alone
     return 0;
 }
@@ -1083,6 +1116,7 @@ static int settle(nrsc5hip_engine *e)
 extern "C" long long nrsc5hip_bytes_to_next_block(nrsc5hip_engine *e, int stream, int cu8)
 {
     if (!e || stream < 0 || stream >= e->cfg.max_streams || !e->mirror_ok[stream]) return -1;
+    if (e->ahead.valid) { DeviceGuard guard(e->cfg.device); if (harvest(e, true)) return -1; }     // the mirror lacks the step submitted ahead until its predecessor is harvested
     long long need = window_of(e, stream) - (e->wr_host[stream] - e->rd_host[stream]);     // decimated samples
     if (need < 1) need = 1;
     if (!cu8) return need * 4;                                                             // cs16: 4 bytes per complex sample
@@ -1137,7 +1171,8 @@ static int push_common(nrsc5hip_engine *e, int s, const void *host, size_t nbyte
     const bool am = e->mode_host[s] == MODE_AM;
     if (e->attached[s]) FAIL(NRSC5HIP_EINVAL, "stream %d reads a zero-copy capture: reset it before pushing samples", s);
     const bool fast = !e->cfg.p1_async && e->mirror_ok[s];
-    if (e->inflight_stream >= 0 && (!fast || e->inflight_stream != s) && (rc = harvest(e, true))) return rc;
+    if (e->ahead.valid && (rc = harvest(e, true))) return rc;  // the mirror lacks a step submitted ahead until its predecessor is harvested
+    while (e->inflight_stream >= 0 && (!fast || e->inflight_stream != s)) if ((rc = harvest(e, true))) return rc;
     if (fast && e->staged_stream >= 0 && (e->staged_stream != s || e->staged_cu8 != cu8) && (rc = flush_staged(e))) return rc;
     if (fast && e->manual_step[s] && e->wr_host[s] - e->rd_host[s] >= window_of(e, s) && (rc = stream_steps(e, s))) return rc;   // the caller did not step
     while (nbytes_total) {
@@ -1526,6 +1561,25 @@ extern "C" int nrsc5hip_stream_step(nrsc5hip_engine *e, int stream)
     if (e->inflight_stream >= 0 && e->inflight_stream != stream && (rc = harvest(e, true))) return rc;
     if (e->staged_stream == stream && (rc = flush_staged(e))) return rc;
     return stream_steps(e, stream);
+}
+
+// manual-step streams: submit the block the pushes so far completed BEHIND the step still in flight, if that is safe; *submitted
+// tells.  0: the caller drains, feeds L2 and calls nrsc5hip_stream_step as usual.
+extern "C" int nrsc5hip_stream_step_ahead(nrsc5hip_engine *e, int stream, int *submitted)
+{
+    ON_ENGINE_DEVICE_FAST(e);
+    int rc = check_stream(e, stream); if (rc) return rc;
+    if (!submitted) FAIL(NRSC5HIP_EINVAL, "null argument");
+    *submitted = 0;
+    if (e->cfg.p1_async || !e->mirror_ok[stream] || !e->manual_step[stream] || !e->defer_wait || e->cfg.l2_feedback || e->prof_on) return 0;
+    if (e->mode_host[stream] == MODE_AM || e->ahead.valid) return 0;
+    // the step in flight: same stream, started FINE (predicted), no P1 decode -> its delivery cannot send the stream back to NONE
+    if (e->inflight_stream != stream || e->inflight_rd_pred < 0 || e->inflight_decoded || !e->pred_ok[stream]) return 0;
+    if (e->staged_stream == stream && (rc = flush_staged(e))) return rc;
+    if (e->wr_host[stream] - e->rd_host[stream] < window_of(e, stream)) return 0;
+    if ((rc = submit_step(e, stream, true))) return rc;
+    *submitted = 1;
+    return 0;
 }
 
 extern "C" int nrsc5hip_p1_frame_packed(nrsc5hip_engine *e, int stream, int slot, uint32_t *words)

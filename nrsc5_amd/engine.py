@@ -138,6 +138,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.nrsc5hip_drain_ready.argtypes = [vp, ci, vp, ci, ctypes.POINTER(ci)]
     lib.nrsc5hip_stream_set_manual_step.argtypes = [vp, ci, ci]
     lib.nrsc5hip_stream_step.argtypes = [vp, ci]
+    lib.nrsc5hip_stream_step_ahead.argtypes = [vp, ci, ctypes.POINTER(ci)]
     lib.nrsc5hip_batch_fetch_view.argtypes = [vp, ci, ctypes.POINTER(vp), vp, ctypes.POINTER(vp)]
     lib.nrsc5hip_reset_all.argtypes = [vp]
     lib.nrsc5hip_profile.argtypes = [vp, ci, vp, vp]
@@ -170,7 +171,7 @@ EXPORTED_SYMBOLS = [
     "nrsc5hip_batch_append_cu8", "nrsc5hip_batch_append_cs16", "nrsc5hip_batch_process", "nrsc5hip_drain",
     "nrsc5hip_p1_frame_packed", "nrsc5hip_p1_frame_bits", "nrsc5hip_batch_fetch", "nrsc5hip_unpack_bits",
     "nrsc5hip_stage_halfband_fm_cu8", "nrsc5hip_stage_fft2048", "nrsc5hip_stage_viterbi_k7", "nrsc5hip_debug_fetch", "nrsc5hip_debug_fetch_costas",
-    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_debug_tune", "nrsc5hip_debug_fwd_stats", "nrsc5hip_debug_tb_stats", "nrsc5hip_debug_k9_stats", "nrsc5hip_stage_first_header", "nrsc5hip_debug_seam_totals", "nrsc5hip_debug_seam_counts", "nrsc5hip_drain_ready", "nrsc5hip_stream_set_manual_step", "nrsc5hip_stream_step", "nrsc5hip_debug_poison_results", "nrsc5hip_device_count", "nrsc5hip_device_upload", "nrsc5hip_device_free", "nrsc5hip_batch_fetch_view", "nrsc5hip_batch_fetch_l2_px", "nrsc5hip_batch_fetch_l2_am",
+    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_debug_tune", "nrsc5hip_debug_fwd_stats", "nrsc5hip_debug_tb_stats", "nrsc5hip_debug_k9_stats", "nrsc5hip_stage_first_header", "nrsc5hip_debug_seam_totals", "nrsc5hip_debug_seam_counts", "nrsc5hip_drain_ready", "nrsc5hip_stream_set_manual_step", "nrsc5hip_stream_step", "nrsc5hip_stream_step_ahead", "nrsc5hip_debug_poison_results", "nrsc5hip_device_count", "nrsc5hip_device_upload", "nrsc5hip_device_free", "nrsc5hip_batch_fetch_view", "nrsc5hip_batch_fetch_l2_px", "nrsc5hip_batch_fetch_l2_am",
     "nrsc5hip_stream_set_mode", "nrsc5hip_am_frame_bits", "nrsc5hip_stage_viterbi_k9", "nrsc5hip_px_frame_bits",
     "nrsc5hip_batch_fetch_px", "nrsc5hip_debug_fetch_px", "nrsc5hip_stage_viterbi_k9_bench",
     "nrsc5hip_l2_index", "nrsc5hip_stage_l2_index", "nrsc5hip_l2_frame_get", "nrsc5hip_batch_fetch_l2",
@@ -325,11 +326,17 @@ class Engine:
     def stream_step(self, stream: int):
         self._check(self.lib.nrsc5hip_stream_step(self._h, stream))
 
+    def stream_step_ahead(self, stream: int) -> bool:
+        """nrsc5hip_stream_step_ahead: True if the next block's step was queued behind the one in flight"""
+        done = ctypes.c_int()
+        self._check(self.lib.nrsc5hip_stream_step_ahead(self._h, stream, ctypes.byref(done)))
+        return bool(done.value)
+
     def seam_counts(self, reset: bool = False) -> dict:
         """deferred steps / mispredicted read positions / steps without P1 decode launches / late P1 decodes (calling thread)"""
-        out = np.zeros(4, dtype=np.float64)
+        out = np.zeros(6, dtype=np.float64)
         self.lib.nrsc5hip_debug_seam_counts(out.ctypes.data, int(reset))
-        return dict(zip(("deferred_steps", "mispredicted_rd", "steps_without_p1_launches", "late_p1_decodes"), (int(x) for x in out)))
+        return dict(zip(("deferred_steps", "mispredicted_rd", "steps_without_p1_launches", "late_p1_decodes", "steps_ahead"), (int(x) for x in out)))
 
     def p1_frame_bits(self, stream: int, slot: int) -> np.ndarray:
         bits = np.zeros(P1_BITS, dtype=np.uint8)

@@ -1112,7 +1112,9 @@ def check_deferred_seam(lib, names=("ppm+60", "ppm-85_cs16", "ppm+100_cfo_search
     host moves its mirror when it SUBMITS the step and takes the report later -- under a sample-clock error next_samperr != 0 on
     most blocks, so the prediction is really exercised (and counted: never wrong); (2) no P1 decode launches on blocks that cannot
     complete a frame (never a frame without its decode); (3) the drop-in's flow -- manual step: push the completing piece, drain
-    the block before (waits), step, poll with drain_ready on every other call.  All three must leave the records bit-identical to
+    the block before (waits), step, poll with drain_ready on every other call; (4) the same without polling, so that every step
+    finds its predecessor still in flight and is queued AHEAD of that block's delivery wherever that is safe
+    (nrsc5hip_stream_step_ahead).  All must leave the records bit-identical to
     the synchronous seam (NRSC5HIP_TUNE_DEFER_WAIT = 0, drain after every push)."""
     for name in names:
         cap = synth.fm_mp1_capture(**common.IMPAIRED_FM_CASES[name])
@@ -1131,7 +1133,7 @@ def check_deferred_seam(lib, names=("ppm+60", "ppm-85_cs16", "ppm+100_cfo_search
             E.seam_counts(reset=True)
             if mode == "sync":
                 E.tune(eng.TUNE_DEFER_WAIT, 0)
-            if mode == "dropin":
+            if mode in ("dropin", "ahead"):
                 E.set_manual_step(0, True)
             recs, frames = [], []
 
@@ -1149,11 +1151,17 @@ def check_deferred_seam(lib, names=("ppm+60", "ppm-85_cs16", "ppm+100_cfo_search
                     piece = call[done:done + room]
                     push(E, piece)
                     done += piece.size
-                    if mode == "dropin":
+                    if mode in ("dropin", "ahead"):
                         if piece.size >= room:
-                            take(E.drain(0)); E.stream_step(0); take(E.drain_ready(0))
-                        else:
-                            take(E.drain_ready(0))
+                            ahead = E.stream_step_ahead(0)
+                            take(E.drain(0))
+                            if not ahead:
+                                E.stream_step(0)
+                            if mode == "dropin":
+                                take(E.drain_ready(0))
+                        elif mode == "dropin":
+                            take(E.drain_ready(0))               # (mode "ahead": no polling -- on the emulator a poll always finds the step done,
+                                                                 # and the path that queues a step behind one in flight would never run)
                     else:
                         take(E.drain(0))
             take(E.drain(0))
@@ -1164,9 +1172,11 @@ def check_deferred_seam(lib, names=("ppm+60", "ppm-85_cs16", "ppm+100_cfo_search
         assert c0["deferred_steps"] == 0 and len(ref) >= 30 and len(ref_frames) >= 1
         fine = sum(1 for r in ref[:-1] if int(r["state_after"]) == 2)
         assert sum(1 for r in ref if int(r["state_before"]) == 2 and int(r["samperr"]) != 1080) >= 5, "the capture does not move the timing pick"
-        for mode in ("deferred", "dropin"):
+        for mode in ("deferred", "dropin", "ahead"):
             got, frames, c = run(mode)
             assert got.tobytes() == ref.tobytes(), (name, mode)
             assert len(frames) == len(ref_frames) and all(np.array_equal(a, b) for a, b in zip(frames, ref_frames))
             assert c["mispredicted_rd"] == 0 and c["late_p1_decodes"] == 0, c
             assert c["deferred_steps"] >= fine - 1 and c["steps_without_p1_launches"] >= fine - 1 - len(ref_frames), (c, fine)
+            if mode == "ahead":                                  # every block behind a FINE block without a P1 decode was queued ahead
+                assert c["steps_ahead"] >= fine - 2 - 2 * len(ref_frames), (c, fine)
