@@ -129,9 +129,10 @@ struct nrsc5hip_engine {
     // remainder is left to decimate and nothing of it sits on the step chain.  Order between the two streams: a step waits for the
     // ingest work submitted before it (ev_ingest); a FIFO compaction on the ingest stream waits for the steps submitted before it
     // (ev_main: it needs the final read position); anything else that touches the stream synchronises both (settle).
-    hipStream_t ingest; hipEvent_t ev_ingest, ev_main;
+    hipStream_t ingest; hipEvent_t ev_ingest, ev_main, ev_appended;
     bool ingest_dirty;                 // work on the ingest stream that `main` has not been ordered behind yet
     bool main_stepped;                 // block steps on `main` that the ingest stream has not been ordered behind yet
+    bool main_appended;                // FIFO appends on `main` (a block's last chunk) that the ingest stream has not been ordered behind yet
     size_t early_flush;                // staged bytes at which a chunk is submitted before its block is complete (0: never)
     // samples accepted by a push but not submitted yet: they wait in stage_pin[stage_slot] until the mirror says a block completes
     // (or the buffer is full, or anything else looks at the stream) -- one H2D + one decimator launch per BLOCK, not per push
@@ -578,8 +579,9 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
                 db.p1_mirror = (uint32_t *)mp;
             }
             if (hipStreamCreate(&e->ingest) != hipSuccess || hipEventCreateWithFlags(&e->ev_ingest, hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "ingest stream creation failed"); break; }
-            e->ingest_dirty = false; e->main_stepped = false; e->early_flush = 96u << 10;
+                hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&e->ev_appended, hipEventDisableTiming) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "ingest stream creation failed"); break; }
+            e->ingest_dirty = false; e->main_stepped = false; e->main_appended = false; e->early_flush = 128u << 10;     // a block is 270 KB of cu8: 128 + 128 + a last chunk of ~14 KB
             if ((rc = dev_alloc(e, &e->decim_ticket, 1))) break;
             if (hipMemset(e->decim_ticket, 0, sizeof(unsigned)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
             for (int k = 0; k < 2 && !rc; k++) {
@@ -634,6 +636,7 @@ extern "C" void nrsc5hip_engine_destroy(nrsc5hip_engine *e)
     if (e->ingest) (void)hipStreamDestroy(e->ingest);
     if (e->ev_ingest) (void)hipEventDestroy(e->ev_ingest);
     if (e->ev_main) (void)hipEventDestroy(e->ev_main);
+    if (e->ev_appended) (void)hipEventDestroy(e->ev_appended);
     for (auto &sp : e->prof_spans) { (void)hipEventDestroy(sp.a); (void)hipEventDestroy(sp.b); }
     for (hipEvent_t ev : e->prof_pool) (void)hipEventDestroy(ev);
     {
@@ -1139,17 +1142,23 @@ static int flush_staged(nrsc5hip_engine *e)
     e->staged_stream = -1; e->staged_bytes = 0; e->staged_q15 = 0;
     e->stage_slot = (slot + 1) % nrsc5hip_engine::NSTAGE;     // the next pushes fill the next buffer
     const bool direct = cu8 && !am && e->direct_decimate;
-    if (!direct && e->ingest_dirty) {                          // the FIFO is appended to in submission order whichever stream does it
+    // The chunk that COMPLETES a block goes on the block-step stream itself: the step waits for it in stream order -- a dependency
+    // across two queues costs ~15 us between the decimator's end and the step's first kernel (profiles/r04_dropin_timeline.txt), and
+    // with the early chunks gone ahead the last one is small.  Early chunks (the block is not complete yet) go on the ingest stream.
+    const bool on_ingest = direct && e->wr_host[s] - e->rd_host[s] < window_of(e, s);
+    if (!on_ingest && e->ingest_dirty) {                       // the FIFO is appended to in submission order whichever stream does it
         HIPCHK(hipEventRecord(e->ev_ingest, e->ingest)); HIPCHK(hipStreamWaitEvent(e->main, e->ev_ingest, 0)); e->ingest_dirty = false;
     }
-    int rc = ensure_space(e, s, 0, direct); if (rc) return rc; // wr_host already counts the staged samples
+    if (on_ingest && e->main_appended) {                       // ... and the next block's first chunk goes behind this block's last
+        HIPCHK(hipStreamWaitEvent(e->ingest, e->ev_appended, 0)); e->main_appended = false;   // (recorded right behind that chunk: not behind the step that followed it)
+    }
+    int rc = ensure_space(e, s, 0, on_ingest); if (rc) return rc; // wr_host already counts the staged samples
     memcpy(e->stage_pin[slot], &count, sizeof(count));
     hipStream_t used = e->main;
     if (direct) {
-        // FM cu8: the decimator reads the pinned buffer itself (one launch: no copy, no commit kernel), on the ingest stream
-        used = e->ingest;
+        // FM cu8: the decimator reads the pinned buffer itself (one launch: no copy, no commit kernel)
+        if (on_ingest) { used = e->ingest; e->ingest_dirty = true; }
         launch_decimate_fm_cu8_stream(e->tb, e->db, s, e->stage_pin_dev[slot] + 16, (const unsigned *)e->stage_pin_dev[slot], count, e->decim_ticket, used);
-        e->ingest_dirty = true;
     } else {
         HIPCHK(hipMemcpyAsync(e->stage_dev2[slot], e->stage_pin[slot], chunk + 16, hipMemcpyHostToDevice, e->main));
         const int *ids_dev = e->all_ids_dev + s; const unsigned *count_dev = (const unsigned *)e->stage_dev2[slot]; const uint8_t *data_dev = e->stage_dev2[slot] + 16;
@@ -1157,6 +1166,7 @@ static int flush_staged(nrsc5hip_engine *e)
         else if (cu8) launch_decimate_fm_cu8(e->tb, e->db, 1, ids_dev, data_dev, 0, count_dev, count, e->main);
         else launch_append_cs16(e->db, 1, ids_dev, (const int16_t *)data_dev, 0, count_dev, count, e->main);
     }
+    if (!on_ingest) { HIPCHK(hipEventRecord(e->ev_appended, e->main)); e->main_appended = true; }
     HIPCHK(hipEventRecord(e->stage_ev[slot], used)); e->stage_busy[slot] = true;
     HIPCHK(hipGetLastError());
     return 0;
