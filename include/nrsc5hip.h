@@ -383,6 +383,8 @@ enum {
                                              launch per chunk); 0 = hipMemcpyAsync into a device buffer, decimator, commit kernel (round 3's chain) */
     , NRSC5HIP_TUNE_EARLY_FLUSH_KB         /* fast streaming seam with the direct decimator: staged KiB at which a chunk is submitted (on the engine's ingest stream,
                                              beside the running block step) before its block is complete; 0 = only at the block's end.  Default 128 */
+    , NRSC5HIP_TUNE_SEAM_PREPARE           /* fast streaming seam, FINE stream: 1 (default) = the block's bookkeeping is computed by the symbol kernel for itself and
+                                             committed by the sync kernel; 0 = k_prepare as a launch of its own in front of them */
 };
 /* process-wide wall-clock totals of the streaming seam with p1_async = 0 (what the drop-in uses): [0] s copying pushes into pinned
  * staging, [1] s enqueueing H2D + decimator, [2] s enqueueing block steps, [3] s waiting for the device (one sync per block),

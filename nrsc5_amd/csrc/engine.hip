@@ -105,6 +105,7 @@ struct nrsc5hip_engine {
     int fwd_warm;                      // test hook: speculative warm-up trips of a forward segment (2; 0 makes every speculation fail -> repair path)
     int mixfft_syms;                   // symbols per k_mixfft workgroup (1, 2, 4, 8)
     int sync_lanes;                    // work-items per stream of k_sync: 0 = by the size of the stream set, 256, 768
+    int fuse_seam_prepare;             // 1 (default): fast seam, FINE stream: no k_prepare launch (NRSC5HIP_TUNE_SEAM_PREPARE = 0: separate launch)
     int tb_walk;                       // 1 (default): single-path traceback (k_p1_tbwalk + check); 0: the block-parallel one of round 3
     int fwd_segments;                  // waves per frame of the P1 forward pass; 0 = pick from the size of the stream set (fwd_segments_for)
     hipStream_t main;                  // = lane.main
@@ -446,7 +447,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
     do {
         {
             e->naux = 3; e->naux_am = 2;   // decode streams in use (measured: profiles/r02_naux.txt, r03_am_decode.txt); nrsc5hip_debug_tune changes them
-            e->verdict_lag = 0; e->fwd_segments = 0; e->fwd_warm = 2; e->mixfft_syms = 1; e->sync_lanes = 0; e->tb_walk = 1;      // measured: profiles/r04_mixfft_persistent.txt
+            e->verdict_lag = 0; e->fwd_segments = 0; e->fwd_warm = 2; e->mixfft_syms = 1; e->sync_lanes = 0; e->tb_walk = 1; e->fuse_seam_prepare = 1;      // measured: profiles/r04_mixfft_persistent.txt
             e->am_segments = K9_GMAX; e->am_warm = K9_WARM; e->am_runin = K9_TB_RUNIN;
         }
         {
@@ -713,7 +714,9 @@ static int launch_inorder_p1(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int 
 }
 
 // decode_p1 = false (fast streaming seam only): the caller KNOWS that no listed stream can complete a P1 frame in this step
-static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const int *ids_dev, bool decode_p1 = true, bool decode_pids = true)
+// local_prepare (fast streaming seam, stream known to be FINE): no k_prepare launch -- the symbol kernel computes the block's
+// bookkeeping for itself and the sync kernel commits it
+static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const int *ids_dev, bool decode_p1 = true, bool decode_pids = true, bool local_prepare = false)
 {
     const bool async = e->cfg.p1_async != 0;
     const long long window = ln.step_count / 16;
@@ -734,12 +737,13 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
     if (ln.acq_needed) { ProfScope p(e, NRSC5HIP_PROF_ACQUIRE, ln.main); launch_acquire(e->tb, ln.db, n, ids_dev, ln.main); }
     // prepare_block is idempotent for a stream the previous k_sync already prepared; a stream that is not FINE is only
     // prepared here, on a step that ran the acquisition kernels for its current window
-    if (!ln.prepared_by_sync || ln.acq_needed) { ProfScope p(e, NRSC5HIP_PROF_PREPARE, ln.main); launch_prepare(ln.db, n, ids_dev, ln.acq_needed ? 1 : 0, ln.main); }
-    { ProfScope p(e, NRSC5HIP_PROF_MIXFFT, ln.main); launch_mixfft(e->tb, ln.db, n, ids_dev, ln.main, e->mixfft_syms); }
+    const bool fused_prepare = local_prepare && !ln.acq_needed && !async;
+    if (!fused_prepare && (!ln.prepared_by_sync || ln.acq_needed)) { ProfScope p(e, NRSC5HIP_PROF_PREPARE, ln.main); launch_prepare(ln.db, n, ids_dev, ln.acq_needed ? 1 : 0, ln.main); }
+    { ProfScope p(e, NRSC5HIP_PROF_MIXFFT, ln.main); launch_mixfft(e->tb, ln.db, n, ids_dev, ln.main, e->mixfft_syms, fused_prepare ? 1 : 0); }
     const int slot = async ? (int)(ln.step_count % 16) : 0;
     // batch pipeline: once every stream of the set is FINE, the next block's bookkeeping rides in k_sync's tail
     const int fuse = (async && !ln.acq_needed) ? 1 : 0;
-    { ProfScope p(e, NRSC5HIP_PROF_SYNC, ln.main); launch_sync(e->tb, ln.db, n, ids_dev, parity, slot, fuse, (int)window, ln.main, e->sync_lanes, decode_pids ? 0 : 1); }
+    { ProfScope p(e, NRSC5HIP_PROF_SYNC, ln.main); launch_sync(e->tb, ln.db, n, ids_dev, parity, slot, fuse, (int)window, ln.main, e->sync_lanes, decode_pids ? 0 : 1, fused_prepare ? 1 : 0); }
     ln.prepared_by_sync = fuse != 0;
     if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_px_deint(e->tb, ln.db, n, ids_dev, parity, slot, ln.main); }
     if (!async) {
@@ -1071,7 +1075,7 @@ static int submit_step(nrsc5hip_engine *e, int s, bool ahead = false)
         const int bc = ahead ? (e->pred_bc[s] + 1) % 16 : e->pred_bc[s];
         decode = !(known && bc != 15);
         if (!decode) g_seam[10] += 1;
-        int rc = issue_step(e, ln, 1, ids_dev, decode, false); if (rc) return rc;      // the PIDS frame is decoded inside k_sync (pids_inline)
+        int rc = issue_step(e, ln, 1, ids_dev, decode, false, known && e->fuse_seam_prepare); if (rc) return rc;   // PIDS frame: inside k_sync (pids_inline)
     }
     { int rc = launch_report(e, s, false); if (rc) return rc; }    // FM: the PIDS frame was decoded inside k_sync; AM: inside its block kernel
     g_seam[2] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enq).count();
@@ -1142,10 +1146,10 @@ static int flush_staged(nrsc5hip_engine *e)
     e->staged_stream = -1; e->staged_bytes = 0; e->staged_q15 = 0;
     e->stage_slot = (slot + 1) % nrsc5hip_engine::NSTAGE;     // the next pushes fill the next buffer
     const bool direct = cu8 && !am && e->direct_decimate;
-    // The chunk that COMPLETES a block goes on the block-step stream itself: the step waits for it in stream order -- a dependency
-    // across two queues costs ~15 us between the decimator's end and the step's first kernel (profiles/r04_dropin_timeline.txt), and
-    // with the early chunks gone ahead the last one is small.  Early chunks (the block is not complete yet) go on the ingest stream.
-    const bool on_ingest = direct && e->wr_host[s] - e->rd_host[s] < window_of(e, s);
+    // (measured, profiles/r04_dropin_timeline.txt: with the block's last chunk on the step stream instead -- no dependency across two
+    // queues in front of the step -- the decimator's own ~11 us of PCIe round trips sit on the chain and the drop-in is slower, 870 x
+    // against 990 x; every chunk of the direct decimator goes on the ingest stream)
+    const bool on_ingest = direct;
     if (!on_ingest && e->ingest_dirty) {                       // the FIFO is appended to in submission order whichever stream does it
         HIPCHK(hipEventRecord(e->ev_ingest, e->ingest)); HIPCHK(hipStreamWaitEvent(e->main, e->ev_ingest, 0)); e->ingest_dirty = false;
     }
@@ -1158,7 +1162,7 @@ static int flush_staged(nrsc5hip_engine *e)
     if (direct) {
         // FM cu8: the decimator reads the pinned buffer itself (one launch: no copy, no commit kernel)
         if (on_ingest) { used = e->ingest; e->ingest_dirty = true; }
-        launch_decimate_fm_cu8_stream(e->tb, e->db, s, e->stage_pin_dev[slot] + 16, (const unsigned *)e->stage_pin_dev[slot], count, e->decim_ticket, used);
+        launch_decimate_fm_cu8_stream(e->tb, e->db, s, e->stage_pin_dev[slot] + 16, count, e->decim_ticket, used);
     } else {
         HIPCHK(hipMemcpyAsync(e->stage_dev2[slot], e->stage_pin[slot], chunk + 16, hipMemcpyHostToDevice, e->main));
         const int *ids_dev = e->all_ids_dev + s; const unsigned *count_dev = (const unsigned *)e->stage_dev2[slot]; const uint8_t *data_dev = e->stage_dev2[slot] + 16;
@@ -2212,6 +2216,7 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
     }
     case NRSC5HIP_TUNE_TRACEBACK_WALK:    e->tb_walk = value != 0; break;
     case NRSC5HIP_TUNE_SYNC_LANES:        e->sync_lanes = (value == 256 || value == 768) ? value : 0; break;
+    case NRSC5HIP_TUNE_SEAM_PREPARE:      e->fuse_seam_prepare = value != 0; break;
     case NRSC5HIP_TUNE_EARLY_FLUSH_KB:    e->early_flush = (size_t)std::max(value, 0) << 10; break;
     case NRSC5HIP_TUNE_DEFER_WAIT:        e->defer_wait = value != 0; break;
     case NRSC5HIP_TUNE_DIRECT_DECIMATE:   e->direct_decimate = value != 0; break;

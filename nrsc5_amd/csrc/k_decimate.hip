@@ -104,10 +104,10 @@ __global__ void k_decimate_commit(DevBuffers db, const int *ids, const uint8_t *
 // and the compute queue cost ~10 us + 2 x ~9 us per block, profiles/r04_dropin_timeline.txt), no second device buffer.  The
 // workgroup that finishes LAST rolls the 14-sample history and publishes the new write position (k_decimate_commit's job: every
 // other workgroup has read st.wr / st.hb_hist by then), so the chunk costs one launch.
-__global__ __launch_bounds__(256) void k_decimate_fm_cu8_stream(DevTables tb, DevBuffers db, int s, const uint8_t *iq, const unsigned *nbytes, unsigned *ticket)
+// (the byte count is a kernel argument: read from the pinned header it was one more PCIe round trip in front of every load)
+__global__ __launch_bounds__(256) void k_decimate_fm_cu8_stream(DevTables tb, DevBuffers db, int s, const uint8_t *iq, unsigned nb, unsigned *ticket)
 {
     StreamState &st = db.state[s];
-    const unsigned nb = *nbytes;
     const unsigned nout = nb / 4;                              // outputs in this chunk
     const unsigned g0 = blockIdx.x * 256u, g = g0 + threadIdx.x;   // group of 4 outputs = input word g (16 bytes: samples 8g .. 8g+7)
     __shared__ uint4 tile[256 + 2];
@@ -167,9 +167,9 @@ __global__ __launch_bounds__(256) void k_decimate_fm_cu8_stream(DevTables tb, De
     st.wr += nsamp / 2;
 }
 
-void launch_decimate_fm_cu8_stream(const DevTables &tb, const DevBuffers &db, int s, const uint8_t *iq, const unsigned *nbytes, unsigned max_nbytes, unsigned *ticket, hipStream_t st)
+void launch_decimate_fm_cu8_stream(const DevTables &tb, const DevBuffers &db, int s, const uint8_t *iq, unsigned nbytes, unsigned *ticket, hipStream_t st)
 {
-    const unsigned groups = (max_nbytes / 4 + 3) / 4;
+    const unsigned groups = (nbytes / 4 + 3) / 4;
     hipLaunchKernelGGL(k_decimate_fm_cu8_stream, dim3(groups ? (groups + 255) / 256 : 1), dim3(256), 0, st, tb, db, s, iq, nbytes, ticket);
 }
 

@@ -16,6 +16,7 @@
 #include "wave_ops.h"
 #include "fastmath.h"
 #include "halfband_raw.h"
+#include "prepare_block.h"
 
 namespace nrsc5 {
 
@@ -294,16 +295,20 @@ template <typename T> __device__ __forceinline__ const T *per_symbol(const T *p)
     return p;
 }
 
+// what a workgroup needs of the block's bookkeeping: from the stream state (k_prepare or the previous k_sync wrote it) or, in the fast
+// streaming seam, computed here from the state the sync kernel will commit it to (prepare_values, prepare_block.h)
+struct SymParams { long long a00; double dtheta, theta; int active; };
+
 template <bool RAW, int SPW>
-__device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuffers &db, const StreamState &st, int s, cf *lds, cf *twB)
+__device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuffers &db, const StreamState &st, const SymParams &sp, int s, cf *lds, cf *twB)
 {
     // SPW consecutive symbols of one stream per workgroup: the stage-B twiddles, the half-band taps and the NCO step are set up
     // once, and symbol n + 1's capture loads (24 dwords per work-item) are in flight while symbol n goes through mix and FFT --
     // with one symbol per workgroup every workgroup began its life waiting for HBM with nothing else to do (17 % VALU-busy).
     fft_stage_b_twiddles(twB, tb.twiddle);                     // first read two barriers from here
     const int sym0 = blockIdx.x * SPW;
-    const long long a00 = (st.rd - st.base) + st.samperr_cur;  // first sample of symbol 0 in the decimated stream
-    const double dth = st.dtheta;
+    const long long a00 = sp.a00;                              // first sample of symbol 0 in the decimated stream
+    const double dth = sp.dtheta;
     const HbTaps taps = hb_taps(tb.hb_q15);
     double a1 = 128.0 * dth;
     a1 -= 2 * M_PI * rint(a1 * (1.0 / (2 * M_PI)));
@@ -337,7 +342,7 @@ __device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuf
         }
         // NCO phasor of sample j = tid + 128 q (q = 0..16): one accurate evaluation at q = 0 and one of the
         // 128-sample step, then a 16-step complex recurrence (error ~1e-6, far inside the float pipeline's own)
-        double a0p = st.theta + (double)sym * SYM_N * dth + (double)tid * dth;
+        double a0p = sp.theta + (double)sym * SYM_N * dth + (double)tid * dth;
         a0p -= 2 * M_PI * rint(a0p * (1.0 / (2 * M_PI)));
         cf ph;
         { float sn, cs; fast_sincos_reduced((float)a0p, sn, cs); ph = cf_make(cs, sn); }     // reduced to [-pi, pi] in double above
@@ -393,19 +398,31 @@ __device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuf
 #define MIXFFT_OCCUPANCY
 #endif
 template <int SPW>
-__global__ __launch_bounds__(128) MIXFFT_OCCUPANCY void k_mixfft(DevTables tb, DevBuffers db, const int *ids)
+__global__ __launch_bounds__(128) MIXFFT_OCCUPANCY void k_mixfft(DevTables tb, DevBuffers db, const int *ids, int local_prepare)
 {
     wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
     const int s = stream_of(ids, blockIdx.y);
     const StreamState &st = db.state[s];
-    if (!st.active) return;                                    // block-uniform
+    SymParams sp;
+    if (local_prepare) {                                       // block-uniform (fast streaming seam: no k_prepare launch in front of this kernel)
+        __shared__ SymParams sh_sp;
+        if (threadIdx.x == 0) {
+            const Prepared p = prepare_values(st, false);
+            sh_sp.active = p.active; sh_sp.a00 = (st.rd - st.base) + p.samperr; sh_sp.dtheta = p.dtheta; sh_sp.theta = p.theta;
+        }
+        __syncthreads();
+        sp = sh_sp;
+    } else {
+        sp.active = st.active; sp.a00 = (st.rd - st.base) + st.samperr_cur; sp.dtheta = st.dtheta; sp.theta = st.theta;
+    }
+    if (!sp.active) return;                                    // block-uniform
     __shared__ cf lds[8 * PITCH_A];
     static_assert(sizeof(cf) == sizeof(float2), "a complex value is two floats either way");
     static_assert(8 * PITCH_A >= 17 * 128 && 17 * 127 < SYM_N, "17 decimated samples per work-item fit in the FFT tile");
     static_assert(NSYM % SPW == 0, "whole workgroups per block");
     __shared__ cf twB[256];
-    if (st.raw) mixfft_symbols<true, SPW>(tb, db, st, s, lds, twB);
-    else mixfft_symbols<false, SPW>(tb, db, st, s, lds, twB);
+    if (st.raw) mixfft_symbols<true, SPW>(tb, db, st, sp, s, lds, twB);
+    else mixfft_symbols<false, SPW>(tb, db, st, sp, s, lds, twB);
 }
 
 // Symbols per workgroup (nrsc5hip_debug_tune NRSC5HIP_TUNE_MIXFFT_SYMS).  The persistent forms -- 2 / 4 / 8 symbols per workgroup, the
@@ -413,13 +430,13 @@ __global__ __launch_bounds__(128) MIXFFT_OCCUPANCY void k_mixfft(DevTables tb, D
 // at 256 streams -- were MEASURED SLOWER than one symbol per workgroup (profiles/r04_mixfft_persistent.txt: 74 vs 63 us per launch,
 // pass 36.0 vs 33.0 ms): the stage-A twiddle loads, which the one-symbol kernel issues at its very start beside the capture loads,
 // cannot be held across the loop (28 VGPRs) and are exposed once per symbol behind a barrier.  Default: 1.
-void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int syms_per_wg)
+void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int syms_per_wg, int local_prepare)
 {
     switch (syms_per_wg) {
-    case 2: hipLaunchKernelGGL(k_mixfft<2>, dim3(NSYM / 2, nstreams), dim3(128), 0, st, tb, db, stream_ids); break;
-    case 4: hipLaunchKernelGGL(k_mixfft<4>, dim3(NSYM / 4, nstreams), dim3(128), 0, st, tb, db, stream_ids); break;
-    case 8: hipLaunchKernelGGL(k_mixfft<8>, dim3(NSYM / 8, nstreams), dim3(128), 0, st, tb, db, stream_ids); break;
-    default: hipLaunchKernelGGL(k_mixfft<1>, dim3(NSYM, nstreams), dim3(128), 0, st, tb, db, stream_ids); break;
+    case 2: hipLaunchKernelGGL(k_mixfft<2>, dim3(NSYM / 2, nstreams), dim3(128), 0, st, tb, db, stream_ids, local_prepare); break;
+    case 4: hipLaunchKernelGGL(k_mixfft<4>, dim3(NSYM / 4, nstreams), dim3(128), 0, st, tb, db, stream_ids, local_prepare); break;
+    case 8: hipLaunchKernelGGL(k_mixfft<8>, dim3(NSYM / 8, nstreams), dim3(128), 0, st, tb, db, stream_ids, local_prepare); break;
+    default: hipLaunchKernelGGL(k_mixfft<1>, dim3(NSYM, nstreams), dim3(128), 0, st, tb, db, stream_ids, local_prepare); break;
     }
 }
 

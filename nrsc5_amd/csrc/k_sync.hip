@@ -229,11 +229,16 @@ __device__ __forceinline__ void store_px(int8_t *pair, float2 v, int side, int p
 #define SYNC_OCCUPANCY(NT)
 #endif
 template <int SYNC_NT>
-__global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare, int window, int pids_inline)
+__global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare, int window, int pids_inline, int do_prepare)
 {
     wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
     const int s = wave_uniform(stream_of(ids, blockIdx.x));    // in a scalar register: every address derived from it stays off the VGPR budget
     StreamState &st = db.state[s];
+    if (do_prepare) {                                          // block-uniform (fast streaming seam): this block's bookkeeping is committed here -- the
+        if (threadIdx.x == 0) prepare_block(db, st, s, false); // symbol kernel computed the same values for itself (prepare_values)
+        __threadfence_block();
+        __syncthreads();
+    }
     if (!st.active) {                                          // block-uniform
         // no block this step; with the fused pipeline the stream may have become ready since (new samples).  Fused steps
         // run without the acquisition kernels, so only FINE streams can be prepared here (prepare_block.h).
@@ -661,12 +666,12 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
     SYNC_MARK(7);
 }
 
-void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, int window, hipStream_t st, int lanes, int pids_inline)
+void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, int window, hipStream_t st, int lanes, int pids_inline, int do_prepare)
 {
     // lanes: 0 = by the size of the stream set (see SYNC_OCCUPANCY above), else 256 / 768 (nrsc5hip_debug_tune NRSC5HIP_TUNE_SYNC_LANES)
     const int nt = lanes ? lanes : 768;                        // measured at 256 streams: 32.8 ms per pass with 768, 33.8 with 256 (profiles/r04_sync_lanes.txt)
-    if (nt == 768) hipLaunchKernelGGL(k_sync<768>, dim3(nstreams), dim3(768), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window, pids_inline);
-    else hipLaunchKernelGGL(k_sync<256>, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window, pids_inline);
+    if (nt == 768) hipLaunchKernelGGL(k_sync<768>, dim3(nstreams), dim3(768), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window, pids_inline, do_prepare);
+    else hipLaunchKernelGGL(k_sync<256>, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window, pids_inline, do_prepare);
 }
 
 // ---- deferred PIDS decode: one wave per (slot, stream) with a staged frame -----------------------------------

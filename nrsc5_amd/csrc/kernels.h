@@ -95,7 +95,7 @@ struct DevBuffers {
 struct StreamReport { int counters[4]; long long rd; int nblocks; int nrec; BlockRecord rec[4]; unsigned seq; unsigned pad; };
 // streaming seam, ONE stream: the chunk is read where the host staged it (pinned, device-visible: no copy engine, no second buffer),
 // every input byte once; the workgroup that finishes last rolls the decimator history and publishes the new write position
-void launch_decimate_fm_cu8_stream(const DevTables &tb, const DevBuffers &db, int s, const uint8_t *iq, const unsigned *nbytes, unsigned max_nbytes, unsigned *ticket, hipStream_t st);
+void launch_decimate_fm_cu8_stream(const DevTables &tb, const DevBuffers &db, int s, const uint8_t *iq, unsigned nbytes, unsigned *ticket, hipStream_t st);
 // streaming seam, ONE stream: the block's PIDS frame (do_pids) and then the report
 void launch_stream_tail(const DevTables &tb, const DevBuffers &db, int s, int first_rec, StreamReport *out, unsigned seq, int do_pids, hipStream_t st);
 
@@ -111,8 +111,8 @@ void launch_append_cs16(const DevBuffers &db, int nstreams, const int *stream_id
 // ---- one block step for a set of streams ----------------------------------------------------
 void launch_acquire(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
 void launch_prepare(const DevBuffers &db, int nstreams, const int *stream_ids, int acq_on, hipStream_t st);
-void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int syms_per_wg = 1);
-void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, int window, hipStream_t st, int lanes = 0, int pids_inline = 0);
+void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int syms_per_wg = 1, int local_prepare = 0);
+void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, int window, hipStream_t st, int lanes = 0, int pids_inline = 0, int do_prepare = 0);
 // replay (k_replay.hip): apply the first-header verdicts of finished deferred P1 decodes -- rewind the stream to the failed frame
 void launch_rollback(const DevBuffers &db, int nstreams, const int *stream_ids, int cur_window, int min_age, hipStream_t st);
 void launch_rollback_am(const DevBuffers &db, int nstreams, const int *stream_ids, int cur_window, int min_age, hipStream_t st);

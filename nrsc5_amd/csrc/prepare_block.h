@@ -45,17 +45,74 @@ __device__ inline int routed_partitions_for_psmi(int psmi)
 
 __device__ inline bool window_ready(const StreamState &st) { return st.wr - st.rd >= WIN_N; }
 
+// What the top of acquire_process decides for the block at st.rd, as values (nothing is written): the symbol kernel of the fast
+// streaming seam computes them for itself -- every workgroup from the same unchanged state -- and the sync kernel that follows
+// commits them with prepare_block; as a launch of its own (k_prepare) the bookkeeping was ~5 us of a chain the host waits for.
+struct Prepared {
+    int active, pending;        // process a block this step / a complete window is waiting (for the acquisition kernels)
+    int samperr;                // timing pick
+    float prev_angle;           // carrier angle after this block's update
+    int to_coarse;              // the block moves the stream from NONE to COARSE
+    double dtheta, theta;       // NCO step and start phase of the block
+};
+
 // acq_ran: the acquisition kernels ran in this step, i.e. coarse_samperr / coarse_re / coarse_im belong to the window at
 // st.rd.  A stream that is not FINE only advances on such steps (the host launches them whenever counters[1] > 0 at the
 // last burst boundary); anywhere else it waits -- never a block on stale coarse results.
+__device__ inline Prepared prepare_values(const StreamState &st, bool acq_ran)
+{
+    Prepared p;
+    const bool ready = window_ready(st);
+    p.active = (ready && (st.sync_state == SYNC_FINE || acq_ran)) ? 1 : 0;
+    p.pending = ready ? 1 : 0;
+    p.samperr = 0; p.prev_angle = st.prev_angle; p.to_coarse = 0; p.dtheta = st.dtheta; p.theta = st.theta;
+    if (!p.active) return p;
+    float angle;
+    if (st.sync_state == SYNC_FINE) {
+        p.samperr = SYM_N / 2 + st.samperr;                    // acquire.c:112-113
+        const float angle_diff = -st.angle;
+        angle = st.prev_angle + angle_diff;
+    } else {
+        p.samperr = st.coarse_samperr;
+        // angle_diff = arg(max_v * e^{-i prev_angle})        (acquire.c:153)
+        float sn, cs; sincosf(-st.prev_angle, &sn, &cs);
+        const float pr = st.coarse_re * cs - st.coarse_im * sn;
+        const float pi = st.coarse_re * sn + st.coarse_im * cs;
+        const float angle_diff = atan2f(pi, pr);
+        const float angle_factor = (st.prev_angle != 0.0f) ? 0.25f : 1.0f;
+        angle = st.prev_angle + (angle_diff * angle_factor);
+        p.to_coarse = st.sync_state != SYNC_COARSE;
+    }
+    p.prev_angle = angle;
+    angle = (float)((double)angle - 2 * M_PI * st.cfo);        // acquire.c:164
+    const float dtheta = angle / FFT_N;
+    // The reference rotates by the float pair (cosf, sinf)(dtheta) once per sample (acquire.c:168,250);
+    // the angle of that rounded unit vector, not dtheta itself, is its effective NCO step.
+    float inc_c, inc_s;
+    if (fabsf(dtheta) < 0.25f) {                               // |integer CFO| up to 80 bins: always, in practice
+        double c, sn; small_cos_sin((double)dtheta, c, sn);
+        inc_c = (float)c; inc_s = (float)sn;
+        p.dtheta = small_atan((double)inc_s / (double)inc_c);
+    } else {
+        inc_c = (float)cos((double)dtheta); inc_s = (float)sin((double)dtheta);
+        p.dtheta = atan2((double)inc_s, (double)inc_c);
+    }
+    // phase *= e^{-i (1080 - samperr) angle / 2048}            (acquire.c:166)
+    double th = st.theta + (double)(-(float)(SYM_N / 2 - p.samperr) * angle / FFT_N);
+    th -= 2 * M_PI * rint(th / (2 * M_PI));
+    p.theta = th;
+    return p;
+}
+
 __device__ inline void prepare_block(const DevBuffers &db, StreamState &st, int s, bool acq_ran)
 {
     if (st.active) return;                                     // already prepared (fused into the previous k_sync)
     if (st.sync_state != SYNC_FINE) atomicAdd(&db.counters[1], 1);   // host: keep launching acquisition
     if (st.sync_state != SYNC_FINE || routed_partitions_for_psmi(st.psmi) > PM_PART) atomicAdd(&db.counters[2], 1);   // ... and the PX kernels
-    st.active = (window_ready(st) && (st.sync_state == SYNC_FINE || acq_ran)) ? 1 : 0;
-    if (!st.active) {
-        if (window_ready(st)) atomicAdd(&db.counters[0], 1);   // work is pending: the host must keep stepping
+    const Prepared p = prepare_values(st, acq_ran);
+    st.active = p.active;
+    if (!p.active) {
+        if (p.pending) atomicAdd(&db.counters[0], 1);          // work is pending: the host must keep stepping
         return;
     }
     atomicAdd(&db.counters[0], 1);
@@ -66,44 +123,13 @@ __device__ inline void prepare_block(const DevBuffers &db, StreamState &st, int 
     r.samperr = 0; r.cfo = 0; r.keep = 0; r.bc = 0; r.psmi = 0; r.cfo_wait = 0; r.next_samperr = 0;
     r.prev_angle = 0; r.phase_re = 0; r.phase_im = 0; r.next_angle = 0; r.freq_offset = 0; r.mer_lb = 0; r.mer_ub = 0;
     r.ber = 0; r.p1_slot = -1; r.bc_decoded = -1; r.pids[0] = r.pids[1] = r.pids[2] = 0; r.sis = 0;
-
-    int samperr; float angle;
-    if (st.sync_state == SYNC_FINE) {
-        samperr = SYM_N / 2 + st.samperr; st.samperr = 0;      // acquire.c:112-113
-        const float angle_diff = -st.angle; st.angle = 0;
-        angle = st.prev_angle + angle_diff;
-        st.prev_angle = angle;
-    } else {
-        samperr = st.coarse_samperr;
-        // angle_diff = arg(max_v * e^{-i prev_angle})        (acquire.c:153)
-        float sn, cs; sincosf(-st.prev_angle, &sn, &cs);
-        const float pr = st.coarse_re * cs - st.coarse_im * sn;
-        const float pi = st.coarse_re * sn + st.coarse_im * cs;
-        const float angle_diff = atan2f(pi, pr);
-        const float angle_factor = (st.prev_angle != 0.0f) ? 0.25f : 1.0f;
-        angle = st.prev_angle + (angle_diff * angle_factor);
-        st.prev_angle = angle;
-        if (st.sync_state != SYNC_COARSE) { r.flags |= REC_TO_COARSE; st.sync_state = SYNC_COARSE; }
-    }
+    if (st.sync_state == SYNC_FINE) { st.samperr = 0; st.angle = 0; }
+    else if (p.to_coarse) { r.flags |= REC_TO_COARSE; st.sync_state = SYNC_COARSE; }
+    st.prev_angle = p.prev_angle;
     rec = r;
-    st.samperr_cur = samperr;
-    angle = (float)((double)angle - 2 * M_PI * st.cfo);        // acquire.c:164
-    const float dtheta = angle / FFT_N;
-    // The reference rotates by the float pair (cosf, sinf)(dtheta) once per sample (acquire.c:168,250);
-    // the angle of that rounded unit vector, not dtheta itself, is its effective NCO step.
-    float inc_c, inc_s;
-    if (fabsf(dtheta) < 0.25f) {                               // |integer CFO| up to 80 bins: always, in practice
-        double c, sn; small_cos_sin((double)dtheta, c, sn);
-        inc_c = (float)c; inc_s = (float)sn;
-        st.dtheta = small_atan((double)inc_s / (double)inc_c);
-    } else {
-        inc_c = (float)cos((double)dtheta); inc_s = (float)sin((double)dtheta);
-        st.dtheta = atan2((double)inc_s, (double)inc_c);
-    }
-    // phase *= e^{-i (1080 - samperr) angle / 2048}            (acquire.c:166)
-    double th = st.theta + (double)(-(float)(SYM_N / 2 - samperr) * angle / FFT_N);
-    th -= 2 * M_PI * rint(th / (2 * M_PI));
-    st.theta = th;
+    st.samperr_cur = p.samperr;
+    st.dtheta = p.dtheta;
+    st.theta = p.theta;
 }
 
 }  // namespace nrsc5

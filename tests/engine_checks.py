@@ -1131,8 +1131,8 @@ def check_deferred_seam(lib, names=("ppm+60", "ppm-85_cs16", "ppm+100_cfo_search
         def run(mode):
             E = eng.Engine(max_streams=1, q15_capacity=200000, record_capacity=256, p1_slots=8, lib_path=lib)
             E.seam_counts(reset=True)
-            if mode == "sync":
-                E.tune(eng.TUNE_DEFER_WAIT, 0)
+            if mode == "sync":                                   # round 3's seam: wait at once, H2D copy + decimator + commit, k_prepare as its own launch
+                E.tune(eng.TUNE_DEFER_WAIT, 0); E.tune(eng.TUNE_DIRECT_DECIMATE, 0); E.tune(eng.TUNE_SEAM_PREPARE, 0)
             if mode in ("dropin", "ahead"):
                 E.set_manual_step(0, True)
             recs, frames = [], []
