@@ -475,18 +475,11 @@ __device__ inline int am_bit_errors(const int8_t *coded, const uint32_t *bits, i
 {
     int errors = 0;
     for (int i = threadIdx.x; i < len; i += blockDim.x) {
-        unsigned r = 0;                                        // r bit 8-k = bits[i-k]: the 9-bit field at bit i - 8
-        if (i >= 8) {                                          // two word loads instead of nine bit picks
-            const int q0 = i - 8;
-            const uint32_t w0 = bits[q0 >> 5], w1 = bits[i >> 5];
-            const unsigned long long win = ((i >> 5) != (q0 >> 5)) ? (((unsigned long long)w1 << 32) | w0) : (unsigned long long)w0;
-            r = (unsigned)(win >> (q0 & 31)) & 0x1ffu;
-        } else {
+        unsigned r = 0;                                        // r bit 8-k = bits[i-k]
 #pragma unroll
-            for (int k = 0; k < 9; k++) {
-                int q = i - k; if (q < 0) q += len;
-                r |= ((bits[q >> 5] >> (q & 31)) & 1u) << (8 - k);
-            }
+        for (int k = 0; k < 9; k++) {
+            int q = i - k; if (q < 0) q += len;
+            r |= ((bits[q >> 5] >> (q & 31)) & 1u) << (8 - k);
         }
         const int j = 3 * i;
         if (((pmask >> (j % plen)) & 1u) && ((coded[j] > 0) != (int)(__popc(r & g0) & 1))) errors++;

@@ -58,20 +58,11 @@ __device__ inline int bit_errors_k7_partial(const int *soft, const uint32_t *bit
 {
     int errors = 0;
     for (int i = threadIdx.x; i < len; i += blockDim.x) {
-        unsigned r = 0;                                        // r bit 6 = bits[i], bit 6-k = bits[i-k]: the 7-bit field at bit i - 6
-        if (i >= 6) {
-            // two word loads instead of seven bit picks: a 1024-thread workgroup's 18 k wave-level loads of this loop were most of the
-            // kernel (one CU's load pipe: ~100 of its ~107 us for a frame)
-            const int q0 = i - 6;
-            const uint32_t w0 = bits[q0 >> 5], w1 = bits[i >> 5];
-            const unsigned long long win = ((i >> 5) != (q0 >> 5)) ? (((unsigned long long)w1 << 32) | w0) : (unsigned long long)w0;
-            r = (unsigned)(win >> (q0 & 31)) & 0x7fu;
-        } else {
+        unsigned r = 0;                                        // r bit 6 = bits[i], bit 6-k = bits[i-k]
 #pragma unroll
-            for (int k = 0; k < 7; k++) {
-                int q = i - k; if (q < 0) q += len;            // tail biting
-                r |= ((bits[q >> 5] >> (q & 31)) & 1u) << (6 - k);
-            }
+        for (int k = 0; k < 7; k++) {
+            int q = i - k; if (q < 0) q += len;                // tail biting
+            r |= ((bits[q >> 5] >> (q & 31)) & 1u) << (6 - k);
         }
         const int w = soft[i];
         const int c0 = (int8_t)w, c1 = (int8_t)(w >> 8), c2 = (int8_t)(w >> 16);
