@@ -161,7 +161,7 @@ constexpr int PITCH_B = 17;    // per r2 row inside a k1 row of the second layou
 template <bool LIVE>
 __device__ inline void fft2048_wg(cf *x, cf *lds, const float2 *twA, const cf *twB)
 {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x & 127;                         // (two symbols may share a 256-lane workgroup: k_mixfft's NPAR)
     // stage A: two radix-8 butterflies, twiddle W2048^(k1*r), scatter to [k1][r]
 #pragma unroll
     for (int h = 0; h < 2; h++) {
@@ -306,7 +306,7 @@ __device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuf
     // once, and symbol n + 1's capture loads (24 dwords per work-item) are in flight while symbol n goes through mix and FFT --
     // with one symbol per workgroup every workgroup began its life waiting for HBM with nothing else to do (17 % VALU-busy).
     fft_stage_b_twiddles(twB, tb.twiddle);                     // first read two barriers from here
-    const int sym0 = blockIdx.x * SPW;
+    const int sym0 = (int)(blockIdx.x * (blockDim.x >> 7) + (threadIdx.x >> 7)) * SPW;
     const long long a00 = sp.a00;                              // first sample of symbol 0 in the decimated stream
     const double dth = sp.dtheta;
     const HbTaps taps = hb_taps(tb.hb_q15);
@@ -324,12 +324,12 @@ __device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuf
         stp = cf_make(cs, sn);
     }
     uint32_t W[24];
-    if (RAW) raw_symbol_load(st.raw, a00 + (long long)sym0 * SYM_N, W, threadIdx.x);
+    if (RAW) raw_symbol_load(st.raw, a00 + (long long)sym0 * SYM_N, W, threadIdx.x & 127);
 #pragma unroll 1
     for (int i = 0; i < SPW; i++) {
         const int sym = sym0 + i;
         const long long a0 = a00 + (long long)sym * SYM_N;
-        int tid = threadIdx.x;
+        int tid = threadIdx.x & 127;
 #ifndef HIPEMU
         if (SPW > 1) asm volatile("" : "+v"(tid));                 // addresses derived from it are recomputed per symbol, not held across the loop
 #endif
@@ -397,8 +397,10 @@ __device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuf
 #else
 #define MIXFFT_OCCUPANCY
 #endif
-template <int SPW>
-__global__ __launch_bounds__(128) MIXFFT_OCCUPANCY void k_mixfft(DevTables tb, DevBuffers db, const int *ids, int local_prepare)
+// NPAR = 2: two symbols of the stream side by side in one 256-lane workgroup (each half its own tile; the stage-B twiddle table, the
+// dispatch and the wave launch shared) -- half as many workgroups per launch at the same waves per SIMD
+template <int SPW, int NPAR>
+__global__ __launch_bounds__(128 * NPAR) MIXFFT_OCCUPANCY void k_mixfft(DevTables tb, DevBuffers db, const int *ids, int local_prepare)
 {
     wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
     const int s = stream_of(ids, blockIdx.y);
@@ -416,10 +418,11 @@ __global__ __launch_bounds__(128) MIXFFT_OCCUPANCY void k_mixfft(DevTables tb, D
         sp.active = st.active; sp.a00 = (st.rd - st.base) + st.samperr_cur; sp.dtheta = st.dtheta; sp.theta = st.theta;
     }
     if (!sp.active) return;                                    // block-uniform
-    __shared__ cf lds[8 * PITCH_A];
+    __shared__ cf lds_all[NPAR * 8 * PITCH_A];
+    cf *lds = lds_all + (threadIdx.x >> 7) * (8 * PITCH_A);
     static_assert(sizeof(cf) == sizeof(float2), "a complex value is two floats either way");
     static_assert(8 * PITCH_A >= 17 * 128 && 17 * 127 < SYM_N, "17 decimated samples per work-item fit in the FFT tile");
-    static_assert(NSYM % SPW == 0, "whole workgroups per block");
+    static_assert(NSYM % (SPW * NPAR) == 0, "whole workgroups per block");
     __shared__ cf twB[256];
     if (st.raw) mixfft_symbols<true, SPW>(tb, db, st, sp, s, lds, twB);
     else mixfft_symbols<false, SPW>(tb, db, st, sp, s, lds, twB);
@@ -432,11 +435,12 @@ __global__ __launch_bounds__(128) MIXFFT_OCCUPANCY void k_mixfft(DevTables tb, D
 // cannot be held across the loop (28 VGPRs) and are exposed once per symbol behind a barrier.  Default: 1.
 void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int syms_per_wg, int local_prepare)
 {
+    if (syms_per_wg == 16) { hipLaunchKernelGGL((k_mixfft<1, 2>), dim3(NSYM / 2, nstreams), dim3(256), 0, st, tb, db, stream_ids, local_prepare); return; }   // knob value 16: NPAR = 2
     switch (syms_per_wg) {
-    case 2: hipLaunchKernelGGL(k_mixfft<2>, dim3(NSYM / 2, nstreams), dim3(128), 0, st, tb, db, stream_ids, local_prepare); break;
-    case 4: hipLaunchKernelGGL(k_mixfft<4>, dim3(NSYM / 4, nstreams), dim3(128), 0, st, tb, db, stream_ids, local_prepare); break;
-    case 8: hipLaunchKernelGGL(k_mixfft<8>, dim3(NSYM / 8, nstreams), dim3(128), 0, st, tb, db, stream_ids, local_prepare); break;
-    default: hipLaunchKernelGGL(k_mixfft<1>, dim3(NSYM, nstreams), dim3(128), 0, st, tb, db, stream_ids, local_prepare); break;
+    case 2: hipLaunchKernelGGL((k_mixfft<2, 1>), dim3(NSYM / 2, nstreams), dim3(128), 0, st, tb, db, stream_ids, local_prepare); break;
+    case 4: hipLaunchKernelGGL((k_mixfft<4, 1>), dim3(NSYM / 4, nstreams), dim3(128), 0, st, tb, db, stream_ids, local_prepare); break;
+    case 8: hipLaunchKernelGGL((k_mixfft<8, 1>), dim3(NSYM / 8, nstreams), dim3(128), 0, st, tb, db, stream_ids, local_prepare); break;
+    default: hipLaunchKernelGGL((k_mixfft<1, 1>), dim3(NSYM, nstreams), dim3(128), 0, st, tb, db, stream_ids, local_prepare); break;
     }
 }
 

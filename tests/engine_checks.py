@@ -216,7 +216,7 @@ def check_batch_equals_streaming(lib, caps, p1_async):
     return steps
 
 
-def check_zero_copy_batch(lib, caps, p1_async=True, l2_feedback=False):
+def check_zero_copy_batch(lib, caps, p1_async=True, l2_feedback=False, mixfft_syms=0):
     """Engine option batch_zero_copy (K1 fused into the symbol kernel, captures read in place) == the copying batch path
     == the streaming seam, record for record; plus the error behaviour of the attached state."""
     import pytest
@@ -232,6 +232,8 @@ def check_zero_copy_batch(lib, caps, p1_async=True, l2_feedback=False):
         host[k, :c.iq.size] = c.iq
     E = eng.Engine(max_streams=n, q15_capacity=2 * 71280, record_capacity=512, p1_slots=8, p1_async=p1_async, l2_feedback=l2_feedback,
                    batch_zero_copy=True, lib_path=lib)                           # FIFO at its minimum: nothing is copied into it
+    if mixfft_syms:
+        E.tune(eng.TUNE_MIXFFT_SYMS, mixfft_syms)                                   # symbol-kernel variants: identical bins
     dev = _to_device(E, host)
     sizes = [c.iq.size - c.iq.size % 4 for c in caps]
     E.batch_append_cu8(dev, stride, sizes)

@@ -408,3 +408,10 @@ def test_gpu_deferred_seam_equals_synchronous(hip_lib):
     P1 decode launches on blocks that cannot complete a frame, the drop-in's manual-step flow -- records and frames bit-identical
     to the synchronous seam, never a misprediction (tests/engine_checks.py: check_deferred_seam)"""
     ec.check_deferred_seam(hip_lib)
+
+
+@pytest.mark.parametrize("syms", [4, 16])
+def test_gpu_symbol_kernel_variants(hip_lib, syms):
+    """k_mixfft's knob forms (4 symbols in a row per workgroup; 16 = two symbols side by side in a 256-lane workgroup): identical records"""
+    caps = [synth.fm_mp1_capture(0, seed=71, cfo_hz=33.0, offset=400, snr_db=22, n_blocks=20), synth.fm_mp1_capture(0, seed=72, cfo_hz=-120.0, offset=1500, snr_db=20, n_blocks=20)]
+    ec.check_zero_copy_batch(hip_lib, caps, p1_async=True, l2_feedback=False, mixfft_syms=syms)
