@@ -54,6 +54,21 @@ __global__ __launch_bounds__(256) void k_p1_deint(DevTables tb, DevBuffers db, c
 // Re-encode the decoded (still scrambled) bits and count sign disagreements with the received soft
 // bits at unpunctured positions (decode.c:234-265).  Block-stride over the frame; returns this
 // thread's partial count.
+// one frame bit's contribution
+__device__ inline int bit_errors_k7_at(const int *soft, const uint32_t *bits, int len, int i)
+{
+    unsigned r = 0;                                            // r bit 6 = bits[i], bit 6-k = bits[i-k]
+#pragma unroll
+    for (int k = 0; k < 7; k++) {
+        int q = i - k; if (q < 0) q += len;                    // tail biting
+        r |= ((bits[q >> 5] >> (q & 31)) & 1u) << (6 - k);
+    }
+    const int w = soft[i];
+    const int c0 = (int8_t)w, c1 = (int8_t)(w >> 8), c2 = (int8_t)(w >> 16);
+    const int p0 = __popc(r & 0133u) & 1, p1 = __popc(r & 0171u) & 1, p2 = __popc(r & 0165u) & 1;
+    return ((c0 > 0) != p0) + ((c1 > 0) != p1) + (((i & 1) == 0) && ((c2 > 0) != p2));
+}
+
 __device__ inline int bit_errors_k7_partial(const int *soft, const uint32_t *bits, int len)
 {
     int errors = 0;
@@ -138,7 +153,7 @@ __global__ __launch_bounds__(64) void k_p1_tbwalk(DevTables tb, DevBuffers db, c
     const size_t slot = (size_t)lane_id * db.nstreams_alloc + s;
     uint32_t *out = db.p1_ring + ((size_t)s * db.p1_slots + st.p1_slot[parity]) * P1_WORDS;
     viterbi3_traceback_walk(db.dec + slot * (size_t)(2 * (P1_LEN + 64)), P1_LEN, st.p1_endlane[parity], out,
-                            db.tbmap + slot * ((size_t)(P1_LEN / 64 + 1) * 64), (int)blockIdx.x, lds);
+                            db.tbmap + slot * ((size_t)(P1_LEN / 64 + 1) * 64), (int)blockIdx.x, lds, db.coded + slot * P1_LEN);
 }
 
 // maps_done: 0 = the block-parallel traceback runs all its passes here; 1 = k_p1_tbmap ran pass 1; 2 = k_p1_tbwalk has written the
@@ -157,11 +172,22 @@ __global__ __launch_bounds__(TB_THREADS) void k_p1_traceback(DevTables tb, DevBu
     uint32_t *out = db.p1_ring + ((size_t)s * db.p1_slots + st.p1_slot[parity]) * P1_WORDS;
     if (tid == 0) err_total = 0;
     uint8_t *gmap = db.tbmap + ((size_t)lane_id * db.nstreams_alloc + s) * ((size_t)(P1_LEN / 64 + 1) * 64);
-    if (maps_done == 2) viterbi3_traceback_check(dec, P1_LEN, out, gmap, db.tb_stats);
+    if (maps_done == 2) viterbi3_traceback_check(dec, P1_LEN, out, gmap, db.tb_stats, soft);
     else viterbi3_traceback_block(dec, P1_LEN, st.p1_endlane[parity], out, gmap, smem, maps_done != 0);
     __threadfence_block();
     __syncthreads();
-    const int errors = wave_sum_i32(bit_errors_k7_partial(soft, out, P1_LEN));
+    int errors;
+    if (maps_done == 2) {
+        // every chunk's walk filed its own re-encode disagreements (36 workgroups per frame did the counting: as one workgroup's loop
+        // over the frame it was most of this kernel); what is left are the frame's first six bits, whose window wraps to its last ones
+        constexpr int NCH = P1_LEN / 64 + 1;
+        errors = 0;
+        for (int c = tid; c < NCH; c += blockDim.x) errors += gmap[2 * NCH + c];
+        if (tid < 6) errors += bit_errors_k7_at(soft, out, P1_LEN, tid);
+        errors = wave_sum_i32(errors);
+    } else {
+        errors = wave_sum_i32(bit_errors_k7_partial(soft, out, P1_LEN));
+    }
     if ((tid & 63) == 0) atomicAdd(&err_total, errors);
     __syncthreads();
     uint32_t *mirror = db.p1_mirror ? db.p1_mirror + ((size_t)s * db.p1_slots + st.p1_slot[parity]) * P1_WORDS : nullptr;

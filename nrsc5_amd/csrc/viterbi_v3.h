@@ -475,7 +475,7 @@ constexpr int TB2_CHUNKS = 64;
 constexpr int TB2_LDS_WORDS = (TB2_CHUNKS + 1) * 128;
 __device__ __host__ inline int vit3_tb2_waves(int len) { return ((len / 64 + 1) + TB2_CHUNKS - 1) / TB2_CHUNKS; }
 // per frame: entry lane [nchunks] then exit lane [nchunks] of every chunk's walk (logical lane numbers)
-__device__ __host__ inline size_t vit3_tb2_meta_bytes(int len) { return (size_t)2 * (len / 64 + 1); }
+__device__ __host__ inline size_t vit3_tb2_meta_bytes(int len) { return (size_t)3 * (len / 64 + 1); }   // + the chunk's re-encode disagreements
 
 // 64 steps back through one chunk whose rows lie in LDS in rotated order (row word h of rotated lane q at rows[64 h + q]);
 // q = rotated lane at the chunk's last step on entry, at its first step on return; ahi / alo: decisions of steps 32..63 / 0..31
@@ -503,8 +503,39 @@ __device__ __forceinline__ void vit3_outputs_rotated(unsigned qend, unsigned ahi
     olo = (alo >> 6) | (ahi << 26);
 }
 
+// Re-encode check of ONE chunk (decode.c:234-265 for its 64 steps): the decoded bits of steps 64c .. 64c+63 (olo, ohi) and of the six
+// steps before them (prev6: bit k = step -6 + k, the last outputs of the chunk below -- which are bits of THAT chunk's end lane, i.e. of
+// the lane this chunk's walk left with) against the signs of the received soft bits; frame bit i = step - 32.  Frame bits 0..5 need the
+// frame's LAST bits (tail biting) and are left to the caller.  -> disagreements at unpunctured positions (<= 160)
+__device__ __forceinline__ unsigned vit3_chunk_errors(const int *soft, int len, int c, unsigned prev6, unsigned olo, unsigned ohi)
+{
+    const unsigned long long wlo = (unsigned long long)prev6 | ((unsigned long long)olo << 6) | ((unsigned long long)ohi << 38);
+    const unsigned whi = ohi >> 26;
+    unsigned errors = 0;
+    for (int S = 0; S < 64; S++) {
+        const int i = 64 * c + S - VIT_EXTRA;
+        if (i < 6 || i >= len) continue;
+        const unsigned r = (unsigned)((S <= 57 ? (wlo >> S) : ((wlo >> S) | ((unsigned long long)whi << (64 - S)))) & 0x7full);   // bit 6 = bit i, bit 0 = bit i - 6
+        const int w = soft[i];
+        const int c0 = (int8_t)w, c1 = (int8_t)(w >> 8), c2 = (int8_t)(w >> 16);
+        const int p0 = __popc(r & 0133u) & 1, p1 = __popc(r & 0171u) & 1, p2 = __popc(r & 0165u) & 1;
+        errors += ((c0 > 0) != p0) + ((c1 > 0) != p1) + (((i & 1) == 0) && ((c2 > 0) != p2));   // odd i: the third bit is punctured [1,1,1,1,1,0]
+    }
+    return errors;
+}
+// the six outputs in front of chunk c from the LOGICAL lane its walk left with: step 58 + k of chunk c - 1 is bit (ph(c-1) + 58 + k) % 6
+__device__ __forceinline__ unsigned vit3_prev6(int c, unsigned exit_lane)
+{
+    const int php = (4 * ((c + 2) % 3)) % 6;                  // phase of chunk c - 1's first step
+    unsigned v = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) v |= ((exit_lane >> ((php + 58 + k) % 6)) & 1u) << k;
+    return v;
+}
+
 // one wave: chunks [64 w, 64 w + 64) of a frame.  lds: TB2_LDS_WORDS dwords.  endlane: the frame's true end lane (logical).
-__device__ __forceinline__ void viterbi3_traceback_walk(const uint32_t *dec, int len, int endlane, uint32_t *out, uint8_t *meta, int w, uint32_t *lds)
+// soft (may be null): the frame's trellis inputs -- each lane then also files the re-encode disagreements of its chunk (meta[2 n + c])
+__device__ __forceinline__ void viterbi3_traceback_walk(const uint32_t *dec, int len, int endlane, uint32_t *out, uint8_t *meta, int w, uint32_t *lds, const int *soft = nullptr)
 {
     const int lane = threadIdx.x & 63;
     const int nchunks = len / 64 + 1;
@@ -536,12 +567,14 @@ __device__ __forceinline__ void viterbi3_traceback_walk(const uint32_t *dec, int
     if (c < nchunks - 1) out[2 * c] = ohi;                     // steps 64c+32 .. 64c+63
     if (c >= 1) out[2 * c - 1] = olo;                          // steps 64c .. 64c+31
     meta[c] = (uint8_t)rotl6(qend, ph);                        // entered with (logical lane at the chunk's last step)
-    meta[nchunks + c] = (uint8_t)rotl6(q, ph);                 // left with (logical lane at its first step)
+    const unsigned lexit = rotl6(q, ph);
+    meta[nchunks + c] = (uint8_t)lexit;                        // left with (logical lane at its first step)
+    if (soft) meta[2 * nchunks + c] = (uint8_t)vit3_chunk_errors(soft, len, c, vit3_prev6(c, lexit), olo, ohi);
 }
 
 // one chunk walked from logical lane `e`, history words straight from global memory (the repair path)
 __device__ inline unsigned vit3_rewalk(const uint32_t *dec, int c, unsigned e, unsigned &ohi, unsigned &olo)
-{
+{   // (the caller re-counts the chunk's disagreements from l, olo, ohi: vit3_chunk_errors)
     const int ph = (4 * (c % 3)) % 6;
     unsigned l = e, ahi = 0, alo = 0;
     for (int S = 63; S >= 0; S--) {
@@ -560,7 +593,7 @@ __device__ inline unsigned vit3_rewalk(const uint32_t *dec, int c, unsigned e, u
 
 // whole workgroup, after every wave of viterbi3_traceback_walk of the frame is done (a later launch): verify the chain of chunk
 // boundaries and re-walk what the speculation got wrong.  stats (may be null): [0] boundaries checked, [1] chunks re-walked.
-__device__ inline void viterbi3_traceback_check(const uint32_t *dec, int len, uint32_t *out, uint8_t *meta, int *stats)
+__device__ inline void viterbi3_traceback_check(const uint32_t *dec, int len, uint32_t *out, uint8_t *meta, int *stats, const int *soft = nullptr)
 {
     const int nchunks = len / 64 + 1;
     __shared__ int tb2_bad;
@@ -586,6 +619,7 @@ __device__ inline void viterbi3_traceback_check(const uint32_t *dec, int len, ui
             out[2 * c] = ohi;
             if (c >= 1) out[2 * c - 1] = olo;
             meta[c] = (uint8_t)want[k]; meta[nchunks + c] = (uint8_t)l;
+            if (soft) meta[2 * nchunks + c] = (uint8_t)vit3_chunk_errors(soft, len, c, vit3_prev6(c, l), olo, ohi);
             rewalked++;
         }
         __threadfence_block();

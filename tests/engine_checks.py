@@ -1182,3 +1182,24 @@ def check_deferred_seam(lib, names=("ppm+60", "ppm-85_cs16", "ppm+100_cfo_search
             assert c["deferred_steps"] >= fine - 1 and c["steps_without_p1_launches"] >= fine - 1 - len(ref_frames), (c, fine)
             if mode == "ahead":                                  # every block behind a FINE block without a P1 decode was queued ahead
                 assert c["steps_ahead"] >= fine - 2 - 2 * len(ref_frames), (c, fine)
+
+
+def check_traceback_variants(lib):
+    """The single-path traceback (every chunk walked once after a one-chunk run-in, the chain of chunk boundaries verified, wrong chunks
+    re-walked; re-encode disagreements counted per chunk by the walk) against round 3's block-parallel one (all 64 candidates per chunk,
+    one workgroup's loop for the BER): identical records -- the BER count to the last disagreement -- and frames, on a capture whose
+    first lock is false: that frame is Viterbi output on noise (BER 0.136), where survivors merge slowly and hundreds of chunks must
+    be re-walked."""
+    cap = synth.fm_mp1_capture(0, seed=62, cfo_hz=-50.0, offset=700, snr_db=22, n_blocks=36)
+    res = {}
+    for walk in (0, 1):
+        E = eng.Engine(max_streams=1, q15_capacity=1 << 20, record_capacity=256, p1_slots=8, lib_path=lib)
+        E.tune(eng.TUNE_TRACEBACK_WALK, walk)
+        common.run_engine_streaming(E, 0, cap.iq, chunk=32768 * 8)
+        r = E.drain(0)
+        frames = [E.p1_frame_bits(0, int(x["p1_slot"])).copy() for x in r if int(x["flags"]) & eng.REC_P1]
+        res[walk] = (r.tobytes(), frames, E.tb_stats())
+        E.close()
+    assert res[0][0] == res[1][0] and len(res[0][1]) == len(res[1][1]) == 2
+    assert all(np.array_equal(a, b) for a, b in zip(res[0][1], res[1][1]))
+    assert res[0][2] == (0, 0) and res[1][2][0] == 2 * 2284 and 20 <= res[1][2][1] <= 2000, res[1][2]

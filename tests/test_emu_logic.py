@@ -241,3 +241,7 @@ def test_emu_symbol_kernel_variants(emu_lib, syms):
     workgroup -- leave every record as the default form does (zero-copy batch == streaming, rtol 0)"""
     caps = [synth.fm_mp1_capture(0, seed=71, cfo_hz=33.0, offset=400, snr_db=22, n_blocks=20), synth.fm_mp1_capture(0, seed=72, cfo_hz=-120.0, offset=1500, snr_db=20, n_blocks=20)]
     ec.check_zero_copy_batch(emu_lib, caps, p1_async=True, l2_feedback=False, mixfft_syms=syms)
+
+
+def test_emu_traceback_variants(emu_lib):
+    ec.check_traceback_variants(emu_lib)

@@ -415,3 +415,8 @@ def test_gpu_symbol_kernel_variants(hip_lib, syms):
     """k_mixfft's knob forms (4 symbols in a row per workgroup; 16 = two symbols side by side in a 256-lane workgroup): identical records"""
     caps = [synth.fm_mp1_capture(0, seed=71, cfo_hz=33.0, offset=400, snr_db=22, n_blocks=20), synth.fm_mp1_capture(0, seed=72, cfo_hz=-120.0, offset=1500, snr_db=20, n_blocks=20)]
     ec.check_zero_copy_batch(hip_lib, caps, p1_async=True, l2_feedback=False, mixfft_syms=syms)
+
+
+def test_gpu_traceback_variants(hip_lib):
+    """single-path traceback == block-parallel traceback (records incl. the BER count, frames) on a capture with a noise frame"""
+    ec.check_traceback_variants(hip_lib)
