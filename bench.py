@@ -72,7 +72,6 @@ def parse(argv=None):
     ap.add_argument("--copy-input", action="store_true", help="fm: decimate the captures into the engine's Q15 FIFO first (K1 as its own kernel) instead of reading them in place")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no HIP-event kernel timing inside the timed region (roofline fields become 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip every checker leg that runs on the host cores (CPU baseline, reference equality)")
-    ap.add_argument("--no-numa-bind", action="store_true", help="do not pin the rank to the CPUs of its GPU's NUMA node (default: pinned -- one process per GPU on the GPU's socket, the usual deployment; the host side of every launch and report crosses the fabric otherwise)")
     ap.add_argument("--no-extra-legs", action="store_true", help="fm: skip the single-stream (configs[1]), in-order, configs[4] and drop-in legs")
     ap.add_argument("--l2-index-inline", action="store_true", help="fm: engine option l2_index: index every P1 frame on the decode streams inside the timed region (default: untimed post-pass)")
     ap.add_argument("--no-l2-index", action="store_true", help="fm: skip the (untimed) L2 audio-index property check of the decoded frames")
@@ -128,16 +127,6 @@ def cpu_baseline(stream_iq: np.ndarray, fs: float, mode: int, budget_s: float, n
     import multiprocessing as mp
     import tempfile
     run, kind = _checker(mode, False)
-    bound = os.sched_getaffinity(0)
-    if ALL_CPUS:
-        os.sched_setaffinity(0, ALL_CPUS)                      # the CPU baseline owns the whole host, not one NUMA node (the workers inherit this)
-    try:
-        return _cpu_baseline(stream_iq, fs, mode, budget_s, nproc, run, kind, mp, tempfile)
-    finally:
-        os.sched_setaffinity(0, bound)
-
-
-def _cpu_baseline(stream_iq, fs, mode, budget_s, nproc, run, kind, mp, tempfile):
     t0 = time.perf_counter(); run(stream_iq); dt1 = time.perf_counter() - t0
     reps = max(1, min(64, int(0.5 * budget_s / max(dt1, 1e-3))))
     t0 = time.perf_counter()
@@ -832,7 +821,6 @@ def dropin_leg(iq: np.ndarray, fs: float):
     return out
 
 
-HOST_BINDING, ALL_CPUS = {"bound": False}, None
 KERNELS_OF_CLASS = {"p1_viterbi": "k_p1_forward (K=7 forward trellis pass of one decode window's P1 frames)", "p1_traceback": "k_p1_traceback (+ k_l2_index_window)",
                     "p1_deint": "k_p1_deint", "mixfft": "k_mixfft", "sync": "k_sync (+ k_px_deint, k_px_commit)", "pids": "k_pids_decode (+ k_px_decode)",
                     "am": "k_am_block + k_am_interleave", "am_decode": "k_am_decode (8 x P1 + P3 + 8 x PIDS trellis passes of one AM L1 frame per stream)",
@@ -914,9 +902,6 @@ def main():
     torch.cuda.set_device(dev)
     from nrsc5_amd import engine as _eng
     _eng.check_fresh()                                           # never measure a library that was built from other sources
-    global HOST_BINDING, ALL_CPUS
-    ALL_CPUS = os.sched_getaffinity(0)
-    HOST_BINDING = {"bound": False, "why": "--no-numa-bind"} if args.no_numa_bind else _eng.bind_to_device_numa(local)
 
     my_streams = my_stream_ids(args, world, rank)
     t_gen = time.perf_counter()
@@ -1054,7 +1039,6 @@ def main():
         "ms_per_step_min_max": [round(min(pass_ms), 3), round(max(pass_ms), 3)], "per_rank_ms_per_step": per_rank_ms, "higher_is_better": True, "scaling": args.scaling,
         "vs_baseline": None, "dtype": W.dtype, "data": "synthetic",
         "config": config, "roofline": roofline, "cpu_baseline": cpu, "parity": parity,
-        "host_binding": dict(HOST_BINDING, what="the rank's threads are pinned to the CPUs of its GPU's NUMA node (nrsc5hip_device_numa); the CPU-baseline legs run on all CPUs"),
         "gen_seconds": round(t_gen, 1),
         "traceback_walk": {"chunk_boundaries_checked": tb_checked, "chunks_rewalked": tb_rewalked,
                            "what": "single-path traceback: every 64-step chunk walked once after a 64-step run-in through the chunk above (speculative), the chain of chunk boundaries verified, wrong chunks re-walked (viterbi_v3.h); counts since the engine was created, rank 0"},

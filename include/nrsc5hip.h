@@ -149,10 +149,6 @@ void *nrsc5hip_engine_hip_stream(nrsc5hip_engine *e);
 /* Device helpers for hosts that do not link the HIP runtime themselves: number of visible GPUs; a device buffer on `device` filled
  * from host memory (host may be NULL: allocation only); its release.  The pointers are what the batch entry points take. */
 int nrsc5hip_device_count(int *n);
-/* NUMA node of the device's PCIe slot (-1: unknown) and that node's CPU list as sysfs prints it ("64-127,192-255").  Run the threads that
- * drive an engine there (sched_setaffinity / numactl --cpunodebind): every launch and every report crosses the fabric otherwise --
- * measured on the drop-in: 1110 x real time on the GPU's node, 820 x on the other socket. */
-int nrsc5hip_device_numa(int device, int *node, char *cpulist, size_t cpulist_len);
 int nrsc5hip_device_upload(int device, const void *host, size_t nbytes, void **dev_out);
 int nrsc5hip_device_free(int device, void *dev);
 

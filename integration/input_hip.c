@@ -21,7 +21,6 @@
 #include "config.h"
 
 #include <assert.h>
-#include <sched.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -206,31 +205,6 @@ void input_reset(input_t *st)
     st->sync.psmi = 1;
 }
 
-/* NRSC5HIP_BIND_NUMA=1: pin the calling thread (the one that opens the session feeds it, in nrsc5 -r and in the pipe API) to the CPUs
- * of the GPU's NUMA node -- every launch is a doorbell write and every report a read across the fabric; measured with one capture
- * through nrsc5_pipe_samples_cu8: 1110 x real time on the GPU's socket, 820 x on the other.  Opt-in: a library does not move its
- * caller's threads unasked. */
-static void bind_near_device(int device)
-{
-    const char *want = getenv("NRSC5HIP_BIND_NUMA");
-    char list[512];
-    int node = -1;
-    if (!want || atoi(want) <= 0 || nrsc5hip_device_numa(device, &node, list, sizeof(list)) != 0 || node < 0) return;
-    cpu_set_t set;
-    CPU_ZERO(&set);
-    for (char *p = list; *p;)
-    {
-        char *end;
-        long a = strtol(p, &end, 10), b = a;
-        if (end == p) break;
-        if (*end == '-') b = strtol(end + 1, &end, 10);
-        for (long c = a; c <= b && c < CPU_SETSIZE; c++) CPU_SET((int)c, &set);
-        p = (*end == ',') ? end + 1 : end;
-        if (*end != ',' && *end != 0) break;
-    }
-    if (CPU_COUNT(&set) > 0) (void)sched_setaffinity(0, sizeof(set), &set);
-}
-
 void input_init(input_t *st, nrsc5_t *radio, output_t *output)
 {
     const char *dev = getenv("NRSC5HIP_DEVICE");
@@ -241,7 +215,6 @@ void input_init(input_t *st, nrsc5_t *radio, output_t *output)
     st->radio = radio;
     st->output = output;
     st->sync_state = SYNC_STATE_NONE;
-    bind_near_device(cfg.device);
     if (nrsc5hip_engine_create(&cfg, &e) != 0) { e = NULL; fail(st, "engine_create"); }
     else if (nrsc5hip_stream_set_manual_step(e, 0, 1) != 0) fail(st, "stream_set_manual_step");
     st->acq.fftin = (void *)e;

@@ -1976,38 +1976,6 @@ extern "C" int nrsc5hip_device_count(int *n)
     HIPCHK(hipGetDeviceCount(n));
     return 0;
 }
-// Where the host threads that drive `device` should run: the NUMA node its PCIe slot hangs off and that node's CPU list (sysfs).
-// Every launch is a doorbell write and every report a read across the fabric: the drop-in session of a capture ran at 1110 x real time
-// with its thread on the GPU's node and at 820 x on the other socket of the same box (profiles/r04_dropin_timeline.txt).
-// *node = -1 and an empty list when the platform does not say.
-extern "C" int nrsc5hip_device_numa(int device, int *node, char *cpulist, size_t cpulist_len)
-{
-    if (!node) FAIL(NRSC5HIP_EINVAL, "null argument");
-    *node = -1;
-    if (cpulist && cpulist_len) cpulist[0] = 0;
-#ifndef HIPEMU
-    char bdf[64] = "";
-    HIPCHK(hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device));
-    for (char *c = bdf; *c; c++) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');     // sysfs spells the address in lower case
-    char path[160];
-    snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bdf);
-    FILE *f = fopen(path, "r");
-    if (!f) return 0;
-    int n = -1;
-    if (fscanf(f, "%d", &n) != 1) n = -1;
-    fclose(f);
-    *node = n;
-    if (n < 0 || !cpulist || !cpulist_len) return 0;
-    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", n);
-    f = fopen(path, "r");
-    if (!f) return 0;
-    if (!fgets(cpulist, (int)cpulist_len, f)) cpulist[0] = 0;
-    fclose(f);
-    for (char *c = cpulist; *c; c++) if (*c == '\n') *c = 0;
-#endif
-    return 0;
-}
-
 extern "C" int nrsc5hip_device_upload(int device, const void *host, size_t nbytes, void **dev_out)
 {
     if (!dev_out) FAIL(NRSC5HIP_EINVAL, "null argument");

@@ -129,7 +129,6 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.nrsc5hip_debug_fwd_stats.argtypes = [vp, vp]
     lib.nrsc5hip_debug_k9_stats.argtypes = [vp, vp]
     lib.nrsc5hip_debug_tb_stats.argtypes = [vp, vp]
-    lib.nrsc5hip_device_numa.argtypes = [ci, ctypes.POINTER(ci), ctypes.c_char_p, ctypes.c_size_t]
     lib.nrsc5hip_stage_first_header.argtypes = [vp, vp, ci, ci, ci, vp]
     lib.nrsc5hip_debug_poison_results.argtypes = [vp]
     lib.nrsc5hip_debug_seam_totals.argtypes = [vp, ci]
@@ -172,7 +171,7 @@ EXPORTED_SYMBOLS = [
     "nrsc5hip_batch_append_cu8", "nrsc5hip_batch_append_cs16", "nrsc5hip_batch_process", "nrsc5hip_drain",
     "nrsc5hip_p1_frame_packed", "nrsc5hip_p1_frame_bits", "nrsc5hip_batch_fetch", "nrsc5hip_unpack_bits",
     "nrsc5hip_stage_halfband_fm_cu8", "nrsc5hip_stage_fft2048", "nrsc5hip_stage_viterbi_k7", "nrsc5hip_debug_fetch", "nrsc5hip_debug_fetch_costas",
-    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_debug_tune", "nrsc5hip_debug_fwd_stats", "nrsc5hip_debug_tb_stats", "nrsc5hip_debug_k9_stats", "nrsc5hip_stage_first_header", "nrsc5hip_debug_seam_totals", "nrsc5hip_debug_seam_counts", "nrsc5hip_drain_ready", "nrsc5hip_stream_set_manual_step", "nrsc5hip_stream_step", "nrsc5hip_stream_step_ahead", "nrsc5hip_debug_poison_results", "nrsc5hip_device_count", "nrsc5hip_device_numa", "nrsc5hip_device_upload", "nrsc5hip_device_free", "nrsc5hip_batch_fetch_view", "nrsc5hip_batch_fetch_l2_px", "nrsc5hip_batch_fetch_l2_am",
+    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_debug_tune", "nrsc5hip_debug_fwd_stats", "nrsc5hip_debug_tb_stats", "nrsc5hip_debug_k9_stats", "nrsc5hip_stage_first_header", "nrsc5hip_debug_seam_totals", "nrsc5hip_debug_seam_counts", "nrsc5hip_drain_ready", "nrsc5hip_stream_set_manual_step", "nrsc5hip_stream_step", "nrsc5hip_stream_step_ahead", "nrsc5hip_debug_poison_results", "nrsc5hip_device_count", "nrsc5hip_device_upload", "nrsc5hip_device_free", "nrsc5hip_batch_fetch_view", "nrsc5hip_batch_fetch_l2_px", "nrsc5hip_batch_fetch_l2_am",
     "nrsc5hip_stream_set_mode", "nrsc5hip_am_frame_bits", "nrsc5hip_stage_viterbi_k9", "nrsc5hip_px_frame_bits",
     "nrsc5hip_batch_fetch_px", "nrsc5hip_debug_fetch_px", "nrsc5hip_stage_viterbi_k9_bench",
     "nrsc5hip_l2_index", "nrsc5hip_stage_l2_index", "nrsc5hip_l2_frame_get", "nrsc5hip_batch_fetch_l2",
@@ -202,38 +201,6 @@ def check_fresh(path: str | None = None):
     want = build.source_sha()
     if got != want:
         raise Nrsc5HipError(f"{path or DEFAULT_LIB} was built from other sources (library {got}, tree {want}): run `python -m nrsc5_amd.build`")
-
-
-def device_numa(device: int = 0, lib_path: str | None = None):
-    """(NUMA node of the device's PCIe slot or -1, its CPUs as a set) -- nrsc5hip_device_numa"""
-    lib = load_library(lib_path)
-    node = ctypes.c_int(-1)
-    buf = ctypes.create_string_buffer(512)
-    if lib.nrsc5hip_device_numa(device, ctypes.byref(node), buf, len(buf)) != 0:
-        return -1, set()
-    cpus = set()
-    for part in buf.value.decode().split(","):
-        part = part.strip()
-        if not part:
-            continue
-        a, _, b = part.partition("-")
-        cpus.update(range(int(a), int(b or a) + 1))
-    return node.value, cpus
-
-
-def bind_to_device_numa(device: int = 0, lib_path: str | None = None) -> dict:
-    """Pin the calling process to the CPUs of the device's NUMA node (one process per GPU: the usual deployment).  Returns what it did."""
-    node, cpus = device_numa(device, lib_path)
-    if node < 0 or not cpus:
-        return {"numa_node": node, "bound": False}
-    try:
-        allowed = os.sched_getaffinity(0) & cpus
-        if allowed:
-            os.sched_setaffinity(0, allowed)
-            return {"numa_node": node, "bound": True, "cpus": len(allowed)}
-    except OSError:
-        pass
-    return {"numa_node": node, "bound": False}
 
 
 def unpack_bits(words: np.ndarray, nbits: int) -> np.ndarray:

@@ -7,7 +7,6 @@ import numpy as np, torch
 import bench
 from nrsc5_amd import engine as eng
 eng.check_fresh()
-print("host binding:", {"skipped": "NRSC5_NO_BIND"} if os.environ.get("NRSC5_NO_BIND") else eng.bind_to_device_numa(0), flush=True)
 args = bench.parse(["--no-cpu-baseline"])
 W = bench.Fm(args, torch.device("cuda", 0), 0, [0])
 iq = np.ascontiguousarray(W.stream_iq(0))
