@@ -27,13 +27,22 @@ LEAD = {"decimate": "k_decimate_fm_cu8", "acquire": "k_acq_fir", "prepare": "k_p
         "p1_deint": "k_p1_deint", "p1_viterbi": "k_p1_forward", "p1_traceback": "k_p1_traceback", "pids": "k_pids_decode", "am": "k_am_block", "am_decode": "k_am_decode"}
 
 
+def kernel_base(kernel_name: str) -> str:
+    """'void nrsc5::k_sync<768>(nrsc5::DevTables, ...)' -> 'k_sync' (template instances print with their return type and arguments)"""
+    n = kernel_name.split("(")[0].strip()
+    if n.startswith("void "):
+        n = n[5:]
+    n = n.split("<")[0]
+    return n.replace("nrsc5::", "")
+
+
 def load(dirname, counter):
     tot, calls = {}, {}
     for f in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             if row.get("Counter_Name") != counter or "nrsc5::" not in row["Kernel_Name"]:
                 continue
-            name = row["Kernel_Name"].split("(")[0].replace("nrsc5::", "")
+            name = kernel_base(row["Kernel_Name"])
             tot[name] = tot.get(name, 0.0) + float(row["Counter_Value"])
             calls[name] = calls.get(name, 0) + 1
     return tot, calls

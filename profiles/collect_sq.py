@@ -16,7 +16,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 COUNTERS = ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_INSTS_VALU", "SQ_WAVES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE")
-from profiles.collect_pmc import CLASSES                                  # kernel-name fragments -> the classes of nrsc5hip_profile
+from profiles.collect_pmc import CLASSES, kernel_base                                  # kernel-name fragments -> the classes of nrsc5hip_profile
 
 
 def main(dirname, out, workload="fm"):
@@ -24,9 +24,9 @@ def main(dirname, out, workload="fm"):
     tot, calls, gui_by_dispatch = {}, {}, {}
     for f in glob.glob(os.path.join(dirname, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
-            name = row["Kernel_Name"].split("(")[0]
-            if not name.startswith("nrsc5::"):
+            if "nrsc5::" not in row["Kernel_Name"].split("(")[0]:
                 continue
+            name = "nrsc5::" + kernel_base(row["Kernel_Name"])
             c = row["Counter_Name"]
             d = tot.setdefault(name, {})
             d[c] = d.get(c, 0.0) + float(row["Counter_Value"])

@@ -1,0 +1,25 @@
+#!/bin/bash
+# everything the round's records need from ONE box: GPU tests, rocprofv3 kernel stats (fm, am-cs16), PMC traffic, SQ counters, the timeline
+# -- then, with the stamped PMC / SQ summaries of THIS tree in place, the default bench line.   gpurun --timeout 2400 -- 'bash tools/gpu_final.sh TAG'
+cd "${GRAFT_REPO_ROOT:-.}"; R=$PWD; export TMPDIR=/tmp; mkdir -p gpurun_out
+TAG=${1:-r04z}
+( time timeout 900 python -m pytest tests -m gpu -x -q ) > gpurun_out/${TAG}_tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/${TAG}_tests.log
+for WL in fm am-cs16; do
+rm -rf gpurun_out/${TAG}_prof_$WL
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof_$WL -o p -- python $R/bench.py --workload $WL --no-cpu-baseline --no-extra-legs --steps 3 --warmup 1 ) > gpurun_out/${TAG}_prof_$WL.log 2>&1; echo "prof $WL rc=$?"
+f=$(find gpurun_out/${TAG}_prof_$WL -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${TAG}_kernel_stats_$WL.csv && head -6 "$f" | cut -c1-160
+rm -rf gpurun_out/${TAG}_prof_$WL
+done
+bash tools/gpu_pmc.sh fm 2>&1 | tail -2 | cut -c1-400
+bash tools/gpu_sq.sh fm 2>&1 | tail -3 | cut -c1-300
+cp gpurun_out/traffic_fm.json profiles/traffic_latest.json; cp gpurun_out/sq_fm.json profiles/sq_latest.json
+bash tools/gpu_trace.sh ${TAG}_trace > /dev/null 2>&1; head -8 gpurun_out/${TAG}_trace_summary.txt
+( time timeout 600 python bench.py ) > gpurun_out/${TAG}_bench.log 2>&1; echo "bench rc=$?"
+grep "^{" gpurun_out/${TAG}_bench.log | tail -1 > gpurun_out/${TAG}_bench.json
+python - "$TAG" <<'PY'
+import json, sys
+d = json.load(open(f"gpurun_out/{sys.argv[1]}_bench.json")); r = d["roofline"]
+print(d["ms_per_step"], d["x_realtime"], r["kernel"], r["frac"], r["traffic"], (r.get("valu") or {}).get("frac"), d["parity_failures"])
+print("single", d["single_stream"]["x_realtime"], "dropin", d["dropin"]["dropin"]["x_realtime"], d["dropin"]["events_equal"], "inorder", d["in_order"]["ms_per_step"])
+for k, v in d["config4"].items(): print(k, v["ms_per_step"], v["x_realtime"])
+PY

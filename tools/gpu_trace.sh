@@ -11,7 +11,7 @@ tag = sys.argv[1]
 f = glob.glob(f"gpurun_out/{tag}_raw/**/*kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f)) if "nrsc5::" in r["Kernel_Name"]]
 for r in rows:
-    r["n"] = r["Kernel_Name"].split("(")[0].replace("nrsc5::", ""); r["s"] = int(r["Start_Timestamp"]); r["e"] = int(r["End_Timestamp"])
+    r["n"] = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0].replace("nrsc5::", ""); r["s"] = int(r["Start_Timestamp"]); r["e"] = int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
 # the last pass starts at the last k_decimate_fm_cu8 burst: find the last big gap before a decimate kernel
 dec = [r for r in rows if r["n"] in ("k_decimate_fm_cu8", "k_attach_raw")]
