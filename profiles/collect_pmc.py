@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 # kernel-name fragments -> the classes of nrsc5hip_profile (include/nrsc5hip.h)
 CLASSES = {"decimate": ("k_decimate_fm_cu8", "k_decimate_commit", "k_append_cs16", "k_attach_raw", "k_am_decimate"),
            "acquire": ("k_acq_",), "prepare": ("k_prepare", "k_rollback"), "mixfft": ("k_mixfft",), "sync": ("k_sync", "k_px_deint", "k_px_commit"),
-           "p1_deint": ("k_p1_deint",), "p1_viterbi": ("k_p1_forward",), "p1_traceback": ("k_p1_traceback", "k_l2_index_window"), "pids": ("k_pids_decode", "k_px_decode"),
+           "p1_deint": ("k_p1_deint",), "p1_viterbi": ("k_p1_forward", "k_p1_fix"), "p1_traceback": ("k_p1_traceback", "k_p1_tbwalk", "k_p1_tbmap", "k_l2_index_window"), "pids": ("k_pids_decode", "k_px_decode"),
            "am": ("k_am_block", "k_am_viterbi", "k_am_interleave"), "am_decode": ("k_am_decode",)}
 LEAD = {"decimate": "k_decimate_fm_cu8", "acquire": "k_acq_fir", "prepare": "k_prepare", "mixfft": "k_mixfft", "sync": "k_sync",
         "p1_deint": "k_p1_deint", "p1_viterbi": "k_p1_forward", "p1_traceback": "k_p1_traceback", "pids": "k_pids_decode", "am": "k_am_block", "am_decode": "k_am_decode"}
