@@ -821,6 +821,27 @@ def dropin_leg(iq: np.ndarray, fs: float):
     return out
 
 
+def rocprof_fraction(args, dom, alg_bytes_per_launch):
+    """The same roofline fraction with the launch duration rocprofv3 measured (no HIP-event overhead), when profiles/ carries a kernel-stats
+    summary of THIS tree (profiles/kernel_stats_latest.json, written by tools/stamp_kernel_stats.py from a `rocprofv3 --kernel-trace --stats`
+    CSV of this command); None otherwise."""
+    path = os.path.join(ROOT, "profiles", "kernel_stats_latest.json")
+    try:
+        ks = json.load(open(path))
+        if ks.get("source_sha") != source_fingerprint() or ks.get("workload") != args.workload:
+            return None
+        k = ks["kernels"].get(LEAD_KERNEL.get(dom, ""))
+        if not k:
+            return None
+        avg_s = k["average_ns"] * 1e-9
+        ach = alg_bytes_per_launch / avg_s / 1e9
+        return {"kernel": LEAD_KERNEL[dom], "avg_launch_us": round(avg_s * 1e6, 2), "calls": k["calls"], "achieved_GBps": round(ach, 1), "frac": round(ach / HBM_PEAK_GBPS, 4),
+                "file": "profiles/kernel_stats_latest.json (from " + ks.get("csv", "?") + ")"}
+    except Exception:
+        return None
+
+
+LEAD_KERNEL = {"mixfft": "k_mixfft", "sync": "k_sync", "p1_viterbi": "k_p1_forward", "p1_traceback": "k_p1_tbwalk", "am": "k_am_block", "am_decode": "k_am_decode_fwd"}
 KERNELS_OF_CLASS = {"p1_viterbi": "k_p1_forward (K=7 forward trellis pass of one decode window's P1 frames)", "p1_traceback": "k_p1_traceback (+ k_l2_index_window)",
                     "p1_deint": "k_p1_deint", "mixfft": "k_mixfft", "sync": "k_sync (+ k_px_deint, k_px_commit)", "pids": "k_pids_decode (+ k_px_decode)",
                     "am": "k_am_block + k_am_interleave", "am_decode": "k_am_decode (8 x P1 + P3 + 8 x PIDS trellis passes of one AM L1 frame per stream)",
@@ -1000,6 +1021,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom, "kernel_functions": KERNELS_OF_CLASS.get(dom, dom), "achieved": round(achieved, 3), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 6), "traffic": traffic, "whole_path_traffic": whole,
                     "practical_bound": "valu issue + the trellis' serial dependency chain (SURVEY 8d): see `valu`", "valu": valu,
+                    "rocprof": rocprof_fraction(args, dom, alg_bytes_per_launch),
                     "avg_launch_ms": round(avg_launch_s * 1e3, 4), "launches": dom_launches,
                     "avg_launch_ms_note": "HIP events on the kernel's own launch stream; up to three decode streams and the block-step chain run concurrently, so this is a per-launch latency under contention, not an exclusive-occupancy figure",
                     "alg_bytes_per_launch": int(alg_bytes_per_launch), "alg_bytes_per_sample": round(W.alg, 4),
