@@ -403,8 +403,9 @@ int nrsc5hip_debug_fwd_stats(nrsc5hip_engine *e, int stats[2]);
 int nrsc5hip_debug_tb_stats(nrsc5hip_engine *e, int stats[2]);
 int nrsc5hip_debug_k9_stats(nrsc5hip_engine *e, int stats[4]);
 int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value);
-/* accumulated shader cycles per phase of the sync kernel for stream 0 (after nrsc5hip_debug_tune(e, NRSC5HIP_TUNE_SYNC_PHASES, 1)) */
-int nrsc5hip_debug_sync_phases(nrsc5hip_engine *e, long long *cycles8);
+/* accumulated shader cycles per phase of the sync kernel for stream 0 (after nrsc5hip_debug_tune(e, NRSC5HIP_TUNE_SYNC_PHASES, 1)) in [0..7];
+ * [8..15]: phases of the symbol kernel, filled only by a diagnostic build of the library (-DNRSC5HIP_MIXFFT_PHASES), else zero */
+int nrsc5hip_debug_sync_phases(nrsc5hip_engine *e, long long *cycles16);
 /* debugging aid: soft-bit matrix (16 x 23040 int8) and live FFT bins of a stream's latest block */
 int nrsc5hip_debug_fetch(nrsc5hip_engine *e, int stream, int8_t *pm /* [368640] or NULL */, float *bins /* [32][534][2] or NULL */);
 

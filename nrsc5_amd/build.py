@@ -53,6 +53,17 @@ def build_hip(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_hip_diag(flags, out_name: str) -> str:
+    """A diagnostic twin of the library with extra -D flags (e.g. -DNRSC5HIP_MIXFFT_PHASES: k_mixfft's phase timers), same sources and
+    fingerprint, written next to the release library under its own name; tools/ scripts load it by path."""
+    out = os.path.join(ROOT, "nrsc5_amd", out_name)
+    srcs = [os.path.join(CSRC, f) for f in HIP_SOURCES if os.path.exists(os.path.join(CSRC, f))]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", '-DNRSC5HIP_SOURCE_SHA="%s"' % source_sha(),
+           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", out] + list(flags) + srcs
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_emu(force: bool = False) -> str:
     simt = os.path.join(ROOT, "tests", "simt")
     deps = _deps() + [os.path.join(simt, "hipemu.h"), os.path.join(simt, "hipemu.cpp")]
@@ -70,5 +81,7 @@ def build_emu(force: bool = False) -> str:
 if __name__ == "__main__":
     if "--emu" in sys.argv:
         print(build_emu(force=True))
+    elif "--mixfft-phases" in sys.argv:
+        print(build_hip_diag(["-DNRSC5HIP_MIXFFT_PHASES"], "libnrsc5hip_mixphases.so"))
     else:
         print(build_hip(force=True, verbose=True))

@@ -1896,7 +1896,7 @@ extern "C" int nrsc5hip_stage_fft2048(nrsc5hip_engine *e, const float *in, float
     HIPCHK(hipMalloc((void **)&din, bytes));
     HIPCHK(hipMalloc((void **)&dout, bytes));
     HIPCHK(hipMemcpy(din, in, bytes, hipMemcpyHostToDevice));
-    launch_fft2048(e->tb, din, dout, n, e->main);
+    launch_fft2048(e->tb, din, dout, n, e->main, e->mixfft_syms);
     HIPCHK(hipStreamSynchronize(e->main));
     HIPCHK(hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost));
     (void)hipFree(din); (void)hipFree(dout);
@@ -2226,13 +2226,13 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
     case NRSC5HIP_TUNE_EARLY_FLUSH_KB:    e->early_flush = (size_t)std::max(value, 0) << 10; break;
     case NRSC5HIP_TUNE_DEFER_WAIT:        e->defer_wait = value != 0; break;
     case NRSC5HIP_TUNE_DIRECT_DECIMATE:   e->direct_decimate = value != 0; break;
-    case NRSC5HIP_TUNE_MIXFFT_SYMS:       e->mixfft_syms = (value == 2 || value == 4 || value == 8 || value == 16) ? value : 1; break;   // 16: two symbols side by side per workgroup
+    case NRSC5HIP_TUNE_MIXFFT_SYMS:       e->mixfft_syms = (value == 2 || value == 4 || value == 8 || value == 16 || value == 32) ? value : 1; break;   // 16: two symbols side by side per workgroup; 32: the 256-lane kernel
     case NRSC5HIP_TUNE_AM_SEGMENTS:       e->am_segments = std::min(std::max(value, 1), K9_GMAX); break;
     case NRSC5HIP_TUNE_AM_WARM:           e->am_warm = value > 0 ? K9_WARM : 0; e->am_runin = value > 0 ? K9_TB_RUNIN : 0; break;
     case NRSC5HIP_TUNE_SYNC_PHASES:
         if (value && !e->db.sync_phase_cycles) {
-            int rc = dev_alloc(e, &e->db.sync_phase_cycles, 8); if (rc) return rc;
-            HIPCHK(hipMemset(e->db.sync_phase_cycles, 0, 8 * sizeof(long long)));
+            int rc = dev_alloc(e, &e->db.sync_phase_cycles, 16); if (rc) return rc;
+            HIPCHK(hipMemset(e->db.sync_phase_cycles, 0, 16 * sizeof(long long)));
         }
         e->lane.db.sync_phase_cycles = value ? e->db.sync_phase_cycles : nullptr;
         break;
@@ -2268,13 +2268,13 @@ extern "C" int nrsc5hip_debug_k9_stats(nrsc5hip_engine *e, int stats[4])
     return 0;
 }
 
-extern "C" int nrsc5hip_debug_sync_phases(nrsc5hip_engine *e, long long *cycles8)
+extern "C" int nrsc5hip_debug_sync_phases(nrsc5hip_engine *e, long long *cycles16)
 {
     ON_ENGINE_DEVICE(e);
-    if (!e || !cycles8) FAIL(NRSC5HIP_EINVAL, "null argument");
+    if (!e || !cycles16) FAIL(NRSC5HIP_EINVAL, "null argument");
     if (!e->db.sync_phase_cycles) FAIL(NRSC5HIP_EINVAL, "turn the instrumentation on first: nrsc5hip_debug_tune(e, NRSC5HIP_TUNE_SYNC_PHASES, 1)");
     HIPCHK(hipDeviceSynchronize());
-    HIPCHK(hipMemcpy(cycles8, e->db.sync_phase_cycles, 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cycles16, e->db.sync_phase_cycles, 16 * sizeof(long long), hipMemcpyDeviceToHost));
     return 0;
 }
 

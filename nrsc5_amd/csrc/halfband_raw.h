@@ -87,6 +87,8 @@ __device__ __forceinline__ void hb_fma4(hb_v2 &a, const hb_v2 *pa, const hb_v2 *
 {
     for (int i = 0; i < 4; i++) { a.x += floorf(pa[i].x * t[i].x); a.y += floorf(pa[i].y * t[i].y); }
 }
+__device__ __forceinline__ void hb_fma4x2_s(hb_v2 &a, hb_v2 &b, const hb_v2 *pa, const hb_v2 *pb, const hb_v2 *t) { hb_fma4x2(a, b, pa, pb, t); }
+__device__ __forceinline__ void hb_fma4_s(hb_v2 &a, const hb_v2 *pa, const hb_v2 *t) { hb_fma4(a, pa, t); }
 #else
 typedef float hb_v2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ hb_v2 hb_make(float x, float y) { hb_v2 r; r.x = x; r.y = y; return r; }
@@ -128,6 +130,31 @@ __device__ __forceinline__ void hb_fma4x2(hb_v2 &a, hb_v2 &b, const hb_v2 *pa, c
                  : "+v"(a), "+v"(b)
                  : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pb[0]), "v"(pb[1]), "v"(pb[2]), "v"(pb[3]),
                    "v"(t[0]), "v"(t[1]), "v"(t[2]), "v"(t[3]));
+}
+// the same with the taps in scalar register pairs (wave-uniform; one SGPR source per instruction is what the constant bus allows):
+// eight VGPRs less for the 64-VGPR kernel
+__device__ __forceinline__ void hb_fma4x2_s(hb_v2 &a, hb_v2 &b, const hb_v2 *pa, const hb_v2 *pb, const hb_v2 *t)
+{
+    asm volatile("v_pk_fma_f32 %0, %2, %10, %0\n\t"
+                 "v_pk_fma_f32 %1, %6, %10, %1\n\t"
+                 "v_pk_fma_f32 %0, %3, %11, %0\n\t"
+                 "v_pk_fma_f32 %1, %7, %11, %1\n\t"
+                 "v_pk_fma_f32 %0, %4, %12, %0\n\t"
+                 "v_pk_fma_f32 %1, %8, %12, %1\n\t"
+                 "v_pk_fma_f32 %0, %5, %13, %0\n\t"
+                 "v_pk_fma_f32 %1, %9, %13, %1"
+                 : "+v"(a), "+v"(b)
+                 : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "v"(pb[0]), "v"(pb[1]), "v"(pb[2]), "v"(pb[3]),
+                   "s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]));
+}
+__device__ __forceinline__ void hb_fma4_s(hb_v2 &a, const hb_v2 *pa, const hb_v2 *t)
+{
+    asm volatile("v_pk_fma_f32 %0, %1, %5, %0\n\t"
+                 "v_pk_fma_f32 %0, %2, %6, %0\n\t"
+                 "v_pk_fma_f32 %0, %3, %7, %0\n\t"
+                 "v_pk_fma_f32 %0, %4, %8, %0"
+                 : "+v"(a)
+                 : "v"(pa[0]), "v"(pa[1]), "v"(pa[2]), "v"(pa[3]), "s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]));
 }
 __device__ __forceinline__ void hb_fma4(hb_v2 &a, const hb_v2 *pa, const hb_v2 *t)
 {

@@ -142,9 +142,25 @@ __device__ inline void dft16_live(cf *v)
     }
 }
 
-__device__ inline void fft_stage_b_twiddles(cf *twB, const float2 *tw)
+// (block size as a constant: read as blockDim.x it is two DEPENDENT global loads -- implicit-argument pointer, then the dispatch packet -- in
+// front of everything that uses it; profiles/r04_mixfft_phases.txt)
+template <int NT> struct StageBTwiddles {
+    static_assert(256 % NT == 0, "whole rounds");
+    float2 v[256 / NT];
+    __device__ __forceinline__ void load(const float2 *tw)      // issued with the kernel's first burst of loads ...
+    {
+#pragma unroll
+        for (int k = 0; k < 256 / NT; k++) v[k] = tw[8 * ((int)threadIdx.x + NT * k)];
+    }
+    __device__ __forceinline__ void park(cf *twB) const         // ... written to LDS once the capture loads are under way
+    {
+#pragma unroll
+        for (int k = 0; k < 256 / NT; k++) twB[(int)threadIdx.x + NT * k] = cf_of(v[k]);
+    }
+};
+template <int NT> __device__ __forceinline__ void fft_stage_b_twiddles(cf *twB, const float2 *tw)
 {
-    for (int m = threadIdx.x; m < 256; m += blockDim.x) twB[m] = cf_of(tw[8 * m]);
+    StageBTwiddles<NT> t; t.load(tw); t.park(twB);
 }
 
 constexpr int PITCH_A = 272;   // floats2 per k1 row (256 + 16: rows of one half-wave land on disjoint banks)
@@ -158,8 +174,10 @@ constexpr int PITCH_B = 17;    // per r2 row inside a k1 row of the second layou
 // twB = W256^m, m = 0..255 (= tw[8 m]) in LDS, filled by fft_stage_b_twiddles before the first barrier the caller passes: the second
 // exchange's twiddles are the same 256 values for every workgroup, and as gathers from the global table they were 15 load
 // instructions of 16 cache lines each per wave on top of the first exchange's 14
-template <bool LIVE>
-__device__ inline void fft2048_wg(cf *x, cf *lds, const float2 *twA, const cf *twB)
+// ta (PRELOADED): the work-item's fourteen stage-A twiddles, loaded by the caller BEFORE its last barrier -- issued behind it (where they are
+// used) they were an L2 round trip at the head of every FFT
+template <bool LIVE, bool PRELOADED = false>
+__device__ inline void fft2048_wg(cf *x, cf *lds, const float2 *twA, const cf *twB, const cf *ta = nullptr)
 {
     const int tid = threadIdx.x & 127;                         // (two symbols may share a 256-lane workgroup: k_mixfft's NPAR)
     // stage A: two radix-8 butterflies, twiddle W2048^(k1*r), scatter to [k1][r]
@@ -170,7 +188,7 @@ __device__ inline void fft2048_wg(cf *x, cf *lds, const float2 *twA, const cf *t
 #pragma unroll
         for (int k1 = 0; k1 < 8; k1++) {
             cf v = x[8 * h + k1];
-            if (k1) v = cmul(v, cf_of(twA[(k1 - 1) * 256 + r]));   // = twiddle[(k1 r) & 2047], consecutive work-items consecutive entries
+            if (k1) v = cmul(v, PRELOADED ? ta[7 * h + k1 - 1] : cf_of(twA[(k1 - 1) * 256 + r]));   // = twiddle[(k1 r) & 2047], consecutive work-items consecutive entries
             lds[k1 * PITCH_A + r] = v;
         }
     }
@@ -227,10 +245,14 @@ __device__ __forceinline__ void raw_symbol_load(const uint8_t *raw, long long a0
         typedef u32x4 u32x4_dw __attribute__((aligned(4)));
         const __attribute__((address_space(1))) uint32_t *gw = (const __attribute__((address_space(1))) uint32_t *)rw;   // captures live in HBM: global_load, not flat
 #endif
+        // Six loads, no branch between them: predicated on "the last work-item stops at the symbol's end" they came out as two loads, a wait
+        // for BOTH, then four more -- the capture's HBM latency paid twice per workgroup (profiles/r04_mixfft_phases.txt).  The last work-item
+        // (one real output, 8 dwords) re-reads its second quad for k >= 2: inside the symbol, and what it computes from them lands in the tile's
+        // unused tail.
+        const int kmax = nout + 7 > 20 ? 5 : 1;
 #pragma unroll
         for (int k = 0; k < 6; k++) {
-            u32x4 v = {0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu};
-            if (4 * k < nout + 7) v = *(const u32x4_dw *)(gw + d0 + 4 * k);       // the last work-item stops at the symbol's end
+            const u32x4 v = *(const u32x4_dw *)(gw + d0 + 4 * (k < kmax ? k : kmax));
             // (each of these loads touches 34 cache lines per wave -- 64 lanes 68 bytes apart; reading the wave's 4.4 KB once, 16
             // consecutive bytes per lane, and handing the dwords out through LDS was measured: no difference, 15.2 ms either way)
             W[4 * k] = v.x; W[4 * k + 1] = v.y; W[4 * k + 2] = v.z; W[4 * k + 3] = v.w;
@@ -295,21 +317,66 @@ template <typename T> __device__ __forceinline__ const T *per_symbol(const T *p)
     return p;
 }
 
+// a value every lane holds alike, moved to scalar registers (addresses and block parameters derived from it then cost no VGPRs)
+template <typename T> __device__ __forceinline__ T uniform64(T v)
+{
+#ifndef HIPEMU
+    static_assert(sizeof(T) == 8, "two dwords");
+    unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+    u = ((unsigned long long)hi << 32) | lo;
+    return __builtin_bit_cast(T, u);
+#else
+    return v;
+#endif
+}
+
 // what a workgroup needs of the block's bookkeeping: from the stream state (k_prepare or the previous k_sync wrote it) or, in the fast
 // streaming seam, computed here from the state the sync kernel will commit it to (prepare_values, prepare_block.h)
 struct SymParams { long long a00; double dtheta, theta; int active; };
 
-template <bool RAW, int SPW>
-__device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuffers &db, const StreamState &st, const SymParams &sp, int s, cf *lds, cf *twB)
+// diagnostic build only (-DNRSC5HIP_MIXFFT_PHASES, tools/gpu_mixfft_phases.py): shader cycles of wave 0 of stream 0's workgroups between the
+// marks, accumulated in db.sync_phase_cycles[8..15]; the release kernel carries none of this
+#ifdef NRSC5HIP_MIXFFT_PHASES
+#define MIX_MARK_BEGIN long long mix_t0 = (long long)clock64()
+#define MIX_MARK(i, wait) do { if (wait) { __builtin_amdgcn_s_waitcnt(0); } if (db.sync_phase_cycles && s == 0 && threadIdx.x == 0) { const long long now = (long long)clock64(); \
+    atomicAdd((unsigned long long *)&db.sync_phase_cycles[8 + (i)], (unsigned long long)(now - mix_t0)); mix_t0 = now; } } while (0)
+#else
+#define MIX_MARK_BEGIN do { } while (0)
+#define MIX_MARK(i, wait) do { } while (0)
+#endif
+
+// The loads of a workgroup's prologue that depend on nothing but the kernel arguments -- half-band taps, the stage-B twiddles, the two
+// pulse-shape values of a work-item -- issued in ONE burst beside the stream-state loads, before anything is waited for.  As the code stood
+// (each where it is used) a workgroup began with six DEPENDENT trips to memory: state, capture pointer, twiddle loop (one trip per iteration),
+// block size (two), capture; profiles/r04_mixfft_phases.txt.
+template <int NT> struct SymPrologue {
+    StageBTwiddles<NT> twb;
+    HbTaps taps;
+    float w0, w1;                                              // shape[tid] (head of the symbol), shape[2048 + tid] (its cyclic extension; tid < CP_N)
+    __device__ __forceinline__ void load(const DevTables &tb, int tid)
+    {
+        twb.load(tb.twiddle);
+        taps = hb_taps(tb.hb_q15);
+        w0 = tb.shape[tid];
+        w1 = tb.shape[min(FFT_N + tid, SYM_N - 1)];            // (no branch: work-items >= CP_N never use theirs)
+    }
+};
+
+template <bool RAW, int SPW, int NPAR>
+__device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuffers &db, const uint8_t *raw, const SymParams &sp, int s, cf *lds, cf *twB, const SymPrologue<128 * NPAR> &pro)
 {
     // SPW consecutive symbols of one stream per workgroup: the stage-B twiddles, the half-band taps and the NCO step are set up
     // once, and symbol n + 1's capture loads (24 dwords per work-item) are in flight while symbol n goes through mix and FFT --
     // with one symbol per workgroup every workgroup began its life waiting for HBM with nothing else to do (17 % VALU-busy).
-    fft_stage_b_twiddles(twB, tb.twiddle);                     // first read two barriers from here
-    const int sym0 = (int)(blockIdx.x * (blockDim.x >> 7) + (threadIdx.x >> 7)) * SPW;
+    MIX_MARK_BEGIN;
+    const int sym0 = (int)(blockIdx.x * NPAR + (threadIdx.x >> 7)) * SPW;
     const long long a00 = sp.a00;                              // first sample of symbol 0 in the decimated stream
+    uint32_t W[24];
+    if (RAW) raw_symbol_load(raw, a00 + (long long)sym0 * SYM_N, W, threadIdx.x & 127);      // first thing once the position is known
+    pro.twb.park(twB);                                         // first read two barriers from here
     const double dth = sp.dtheta;
-    const HbTaps taps = hb_taps(tb.hb_q15);
+    const HbTaps taps = pro.taps;
     double a1 = 128.0 * dth;
     a1 -= 2 * M_PI * rint(a1 * (1.0 / (2 * M_PI)));
     cf stp;
@@ -323,8 +390,6 @@ __device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuf
 #endif
         stp = cf_make(cs, sn);
     }
-    uint32_t W[24];
-    if (RAW) raw_symbol_load(st.raw, a00 + (long long)sym0 * SYM_N, W, threadIdx.x & 127);
 #pragma unroll 1
     for (int i = 0; i < SPW; i++) {
         const int sym = sym0 + i;
@@ -335,17 +400,19 @@ __device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuf
 #endif
         const float2 *twA = SPW > 1 ? per_symbol(tb.twiddle_a) : tb.twiddle_a;
         const float *shape = SPW > 1 ? per_symbol(tb.shape) : tb.shape;
-        if (RAW) {
-            raw_symbol_halfband(W, lds, taps, tid);
-            __syncthreads();
-            if (i + 1 < SPW) raw_symbol_load(st.raw, a0 + SYM_N, W, tid);      // the next symbol's samples: needed one FFT from now
-        }
         // NCO phasor of sample j = tid + 128 q (q = 0..16): one accurate evaluation at q = 0 and one of the
         // 128-sample step, then a 16-step complex recurrence (error ~1e-6, far inside the float pipeline's own)
         double a0p = sp.theta + (double)sym * SYM_N * dth + (double)tid * dth;
         a0p -= 2 * M_PI * rint(a0p * (1.0 / (2 * M_PI)));
         cf ph;
         { float sn, cs; fast_sincos_reduced((float)a0p, sn, cs); ph = cf_make(cs, sn); }     // reduced to [-pi, pi] in double above
+        MIX_MARK(1, 1);                                            // set-up + the capture loads' latency
+        if (RAW) {
+            raw_symbol_halfband(W, lds, taps, tid);
+            __syncthreads();
+            if (i + 1 < SPW) raw_symbol_load(raw, a0 + SYM_N, W, tid);         // the next symbol's samples: needed one FFT from now
+        }
+        MIX_MARK(2, 0);                                            // half-band + barrier
         const c16 *win = db.q15 + (size_t)s * db.q15_cap + a0;     // FIFO path (streaming seam, cs16 input)
 
         auto sample = [&](int j) -> cf {
@@ -353,26 +420,35 @@ __device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuf
             const c16 s16 = win[j];
             return q15_to_cf(cf_make((float)s16.r, -(float)s16.i));   // cq15_to_cf_conj, defines.h:111 (the quotient is odd in its argument)
         };
+        const float w0 = SPW > 1 ? shape[tid] : pro.w0, w1 = SPW > 1 ? shape[min(FFT_N + tid, SYM_N - 1)] : pro.w1;
+        cf ta[14];
+        if (SPW == 1) {                                            // in flight while the mix runs
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int k1 = 1; k1 < 8; k1++) ta[7 * h + k1 - 1] = cf_of(twA[(k1 - 1) * 256 + tid + 128 * h]);
+        }
         cf x[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int h = q & 1, n1 = q >> 1;
             const int j = tid + 128 * q;
             cf m = cmul(ph, sample(j));
-            if (q == 0 && tid < CP_N) { const float w = shape[tid]; m = emul(m, cf_make(w, w)); }
+            if (q == 0 && tid < CP_N) m = emul(m, cf_make(w0, w0));
             x[8 * h + n1] = m;
             ph = cmul(ph, stp);
         }
         if (tid < CP_N) {                                          // fold the cyclic extension back (acquire.c:246-247)
             const int j = FFT_N + tid;
             const cf m = cmul(ph, sample(j));                      // ph = phasor of sample tid + 2048
-            const float w = shape[j];
-            x[0] = cadd(x[0], emul(cf_make(w, w), m));
+            x[0] = cadd(x[0], emul(cf_make(w1, w1), m));
         }
         if (RAW) __syncthreads();                                  // every work-item has its samples: the tile becomes the FFT's
+        MIX_MARK(3, 0);                                            // NCO, mix, fold + barrier
 
-        fft2048_wg<true>(x, lds, twA, twB);
+        fft2048_wg<true, SPW == 1>(x, lds, twA, twB, ta);
         if (SPW > 1) __syncthreads();                              // stage C has read the tile: the next symbol may park its samples there
+        MIX_MARK(4, 0);                                            // the FFT (three barriers)
 
         // fftshift (bin 1024 = DC) and the live-bin cut: x[4a + b] = bin kbase + 128 (a + 4 b); after the shift the work-item's
         // six candidates sit at kbase + 128 m', m' = 10, 11, 12 (upper sideband, bins 1304 .. 1570) and 3, 4, 5 (lower, 478 .. 744)
@@ -387,6 +463,7 @@ __device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuf
         if (kbase + 1280 >= UB0) out[LIVE_HALF + kbase + 1280 - UB0] = x[8];       // m' = 10 (X[2])
         out[LIVE_HALF + kbase + 1408 - UB0] = x[12];                               // m' = 11 (X[3])
         if (kbase + 1536 <= UB1) out[LIVE_HALF + kbase + 1536 - UB0] = x[1];       // m' = 12 (X[4])
+        MIX_MARK(5, 1);                                            // the stores, waited for
     }
 }
 
@@ -403,8 +480,15 @@ template <int SPW, int NPAR>
 __global__ __launch_bounds__(128 * NPAR) MIXFFT_OCCUPANCY void k_mixfft(DevTables tb, DevBuffers db, const int *ids, int local_prepare)
 {
     wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
-    const int s = stream_of(ids, blockIdx.y);
+#ifdef NRSC5HIP_MIXFFT_PHASES
+    const long long mix_entry = (long long)clock64();
+#endif
+    const int s = wave_uniform(stream_of(ids, blockIdx.y));
     const StreamState &st = db.state[s];
+    // first burst: everything that needs no stream state, then the state itself -- all in flight before the first wait
+    SymPrologue<128 * NPAR> pro;
+    pro.load(tb, threadIdx.x & 127);
+    const uint8_t *raw = st.raw;                               // (read here, not behind the test of `active`: one trip to memory, not two)
     SymParams sp;
     if (local_prepare) {                                       // block-uniform (fast streaming seam: no k_prepare launch in front of this kernel)
         __shared__ SymParams sh_sp;
@@ -417,15 +501,280 @@ __global__ __launch_bounds__(128 * NPAR) MIXFFT_OCCUPANCY void k_mixfft(DevTable
     } else {
         sp.active = st.active; sp.a00 = (st.rd - st.base) + st.samperr_cur; sp.dtheta = st.dtheta; sp.theta = st.theta;
     }
+    sp.active = wave_uniform(sp.active); sp.a00 = uniform64(sp.a00); sp.dtheta = uniform64(sp.dtheta); sp.theta = uniform64(sp.theta);   // scalar registers
     if (!sp.active) return;                                    // block-uniform
+#ifdef NRSC5HIP_MIXFFT_PHASES
+    if (db.sync_phase_cycles && s == 0 && threadIdx.x == 0) atomicAdd((unsigned long long *)&db.sync_phase_cycles[8], (unsigned long long)((long long)clock64() - mix_entry));
+#endif
     __shared__ cf lds_all[NPAR * 8 * PITCH_A];
     cf *lds = lds_all + (threadIdx.x >> 7) * (8 * PITCH_A);
     static_assert(sizeof(cf) == sizeof(float2), "a complex value is two floats either way");
     static_assert(8 * PITCH_A >= 17 * 128 && 17 * 127 < SYM_N, "17 decimated samples per work-item fit in the FFT tile");
     static_assert(NSYM % (SPW * NPAR) == 0, "whole workgroups per block");
     __shared__ cf twB[256];
-    if (st.raw) mixfft_symbols<true, SPW>(tb, db, st, sp, s, lds, twB);
-    else mixfft_symbols<false, SPW>(tb, db, st, sp, s, lds, twB);
+    if (raw) mixfft_symbols<true, SPW, NPAR>(tb, db, raw, sp, s, lds, twB, pro);
+    else mixfft_symbols<false, SPW, NPAR>(tb, db, raw, sp, s, lds, twB, pro);
+}
+
+// =====================================================================================================================
+// The 256-lane form (knob value mixfft_syms = 32): FFT 2048 = 8 x 8 x 8 x 4, EIGHT complex points per work-item, so that the kernel
+// fits 64 VGPRs and eight waves per SIMD stay resident at the same LDS per workgroup.
+//   n = r + 256 n1,  r = r2 + 32 r1,  r2 = r4 + 4 r3;     bin k = k1 + 8 k2 + 64 k3 + 512 k4
+//   stage A  lane r:            DFT-8 over n1 -> k1, twiddle W2048^(k1 r), LDS [k1][r]
+//   stage B  lane (k1, r2):     DFT-8 over r1 -> k2, twiddle W256^(r2 k2),  LDS [k1][k2][r2]
+//   stage C  lane (k1, k2, r4): DFT-8 over r3 -> k3, twiddle W32^(r4 k3)
+//   stage D  DFT-4 over r4 = the four lanes of a quad: two butterflies through DPP quad_perm, no third LDS exchange; lane q of the quad
+//            ends up with k4 = bit-reversed q for all eight k3
+// LDS: rows of 288 complex values per k1 (8 x 36: the second layout's k2 pitch 36 puts the eight k2 rows a stage-C lane group reads on
+// disjoint banks; every other access of either exchange is 16 / 32 consecutive values) = 18 KB, + 224 stage-B/C twiddles.
+constexpr int P8_ROW = 288;
+constexpr int P8_K2 = 36;
+constexpr int TW8_N = 224;     // W256^m for m <= 31 * 7 = 217 (stage B); stage C reads W32^(r4 k3) = W256^(8 r4 k3), 8 * 21 = 168
+
+template <int M> __device__ __forceinline__ cf cf_lane_xor(cf v)
+{
+#ifdef HIPEMU
+    return cf_make(__shfl_xor(v.x, M), __shfl_xor(v.y, M));
+#else
+    // (through float temporaries: __builtin_bit_cast applied to the vector-element expression v.y itself reads element 0 with this compiler)
+    const float vx = v.x, vy = v.y;
+    return cf_make(__builtin_bit_cast(float, lane_xor<M>(__builtin_bit_cast(int, vx))), __builtin_bit_cast(float, lane_xor<M>(__builtin_bit_cast(int, vy))));
+#endif
+}
+
+__device__ inline void fft8_stage_b_twiddles(cf *twB, const float2 *tw)
+{
+    for (int m = threadIdx.x; m < TW8_N; m += blockDim.x) twB[m] = cf_of(tw[8 * m]);
+}
+
+//  in : x[n1] = sample tid + 256 n1
+//  out: x[k3] = bin (tid >> 5) + 8 ((tid >> 2) & 7) + 64 k3 + 512 k4,  k4 = 2 (tid & 1) + ((tid >> 1) & 1)
+__device__ inline void fft2048_wg8(cf *x, cf *lds, const float2 *twA, const cf *twB)
+{
+    const int tid = threadIdx.x;
+    dft8(x);
+#pragma unroll
+    for (int k1 = 0; k1 < 8; k1++) {
+        cf v = x[k1];
+        if (k1) v = cmul(v, cf_of(twA[(k1 - 1) * 256 + tid]));
+        lds[k1 * P8_ROW + tid] = v;
+    }
+    __syncthreads();
+    {
+        const int k1 = tid >> 5, r2 = tid & 31;
+#pragma unroll
+        for (int r1 = 0; r1 < 8; r1++) x[r1] = lds[k1 * P8_ROW + r2 + 32 * r1];
+        dft8(x);
+        __syncthreads();
+#pragma unroll
+        for (int k2 = 0; k2 < 8; k2++) {
+            cf v = x[k2];
+            if (k2) v = cmul(v, twB[r2 * k2]);
+            lds[k1 * P8_ROW + k2 * P8_K2 + r2] = v;
+        }
+    }
+    __syncthreads();
+    const int q = tid & 3;
+    {
+        const int k1 = tid >> 5, k2 = (tid >> 2) & 7;
+#pragma unroll
+        for (int r3 = 0; r3 < 8; r3++) x[r3] = lds[k1 * P8_ROW + k2 * P8_K2 + q + 4 * r3];
+        dft8(x);
+#pragma unroll
+        for (int k3 = 1; k3 < 8; k3++) x[k3] = cmul(x[k3], twB[8 * q * k3]);
+    }
+    // stage D: u = the quad's four values of one k3.  Butterfly 1 (partner = lane ^ 2): lanes 0, 1 <- u_q + u_(q+2), lanes 2, 3 <- u_(q-2) - u_q.
+    // Lane 3 turns its difference by -j; butterfly 2 (partner = lane ^ 1): even lanes <- own + partner, odd lanes <- partner - own:
+    // lane 0: X[0], lane 1: X[2], lane 2: X[1], lane 3: X[3].
+    const float s1 = (q & 2) ? -1.0f : 1.0f, s2 = (q & 1) ? -1.0f : 1.0f;
+    const bool turn = q == 3;
+#pragma unroll
+    for (int k3 = 0; k3 < 8; k3++) {
+        const cf a = cadd(cf_lane_xor<2>(x[k3]), emul(x[k3], cf_make(s1, s1)));
+        const cf w = turn ? mul_mj(a) : a;
+        x[k3] = cadd(cf_lane_xor<1>(w), emul(w, cf_make(s2, s2)));
+    }
+}
+
+// the 16 consecutive dwords of the capture work-item t < 240 needs: its nine outputs 9 t .. 9 t + 8 (240 x 9 = 2160 = one symbol)
+__device__ __forceinline__ void raw_symbol_load8(const uint8_t *raw, long long a0, uint32_t (&W)[16], int tid)
+{
+    const uint32_t *rw = (const uint32_t *)raw;
+    const long long d0 = a0 + 9 * tid - 7;
+    const bool live = tid < 240;
+    if (a0 >= 7) {
+#ifdef HIPEMU
+        struct u32x4 { uint32_t x, y, z, w; };
+        typedef u32x4 u32x4_dw;
+        const uint32_t *gw = rw;
+#else
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef u32x4 u32x4_dw __attribute__((aligned(4)));
+        const __attribute__((address_space(1))) uint32_t *gw = (const __attribute__((address_space(1))) uint32_t *)rw;
+#endif
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32x4 v = {0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu, 0x7f7f7f7fu};
+            if (live) v = *(const u32x4_dw *)(gw + d0 + 4 * k);
+            W[4 * k] = v.x; W[4 * k + 1] = v.y; W[4 * k + 2] = v.z; W[4 * k + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 16; k++) W[k] = live ? hb_raw_dword(rw, d0 + k) : 0x7f7f7f7fu;
+    }
+}
+
+// as raw_symbol_halfband, nine outputs per work-item (work-items 240 .. 255 park nothing that is read: their slots are the tile's tail).
+// In two halves -- outputs 0..3 from E[0..10], outputs 4..8 from E[4..15], the seven shared samples unpacked twice -- with a
+// scheduling fence between them: unpacked all at once the sixteen samples (32 VGPRs) beside the raw dwords pushed the kernel to 80 VGPRs.
+template <int I0, int NOUT>
+__device__ __forceinline__ void raw_halfband8_part(const uint32_t (&W)[16], cf *tile, const hb_v2 *T, int m0)
+{
+    const hb_v2 off = hb_make(-254.0f, -254.0f);
+    hb_v2 E[NOUT + 7];                                          // E[k] = even sample I0 + k
+#pragma unroll
+    for (int k = 0; k < NOUT + 7; k++) {
+        E[k] = hb_make(hb_byte(W[I0 + k], 0), hb_byte(W[I0 + k], 1));
+        if (!((I0 + k) & 1)) E[k] = hb_add(E[k], off);
+    }
+    auto start = [&](int i) -> hb_v2 {
+        const float c = HB_BIAS - 127.0f * 64.0f;
+        return hb_make(__builtin_fmaf(hb_byte(W[I0 + i + 3], 2), 64.0f, c), __builtin_fmaf(hb_byte(W[I0 + i + 3], 3), 64.0f, c));
+    };
+    auto pairs = [&](int i, hb_v2 *p) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) p[j] = hb_add(E[i + j], E[i + 7 - j]);
+    };
+    auto park = [&](int i, hb_v2 acc) { tile[m0 + I0 + i] = cf_make(acc.x - HB_BIAS, HB_BIAS - acc.y); };
+#pragma unroll
+    for (int i = 0; i + 1 < NOUT; i += 2) {
+        hb_v2 pa[4], pb[4];
+        pairs(i, pa); pairs(i + 1, pb);
+        hb_v2 a = start(i), b = start(i + 1);
+        hb_fma4x2_s(a, b, pa, pb, T);
+        park(i, a); park(i + 1, b);
+    }
+    if (NOUT & 1) {
+        hb_v2 pa[4];
+        pairs(NOUT - 1, pa);
+        hb_v2 a = start(NOUT - 1);
+        hb_fma4_s(a, pa, T);
+        park(NOUT - 1, a);
+    }
+}
+
+__device__ inline void raw_symbol_halfband8(const uint32_t (&W)[16], cf *tile, const HbTaps &taps, int tid)
+{
+    auto uni = [](float f) -> float {
+#ifndef HIPEMU
+        return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, f)));   // the taps ride in scalar register pairs
+#else
+        return f;
+#endif
+    };
+    const float t0 = uni(taps.t0), t1 = uni(taps.t1), t2 = uni(taps.t2), t3 = uni(taps.t3);
+    const hb_v2 T[4] = {hb_make(t0, t0), hb_make(t1, t1), hb_make(t2, t2), hb_make(t3, t3)};
+    hb_round_down();
+    raw_halfband8_part<0, 4>(W, tile, T, 9 * tid);
+#ifndef HIPEMU
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    raw_halfband8_part<4, 5>(W, tile, T, 9 * tid);
+    hb_round_nearest();
+}
+
+template <bool RAW>
+__device__ __forceinline__ void mixfft_symbol8(const DevTables &tb, const DevBuffers &db, const StreamState &st, const SymParams &sp, int s, cf *lds, cf *twB)
+{
+    const int tid = threadIdx.x, sym = blockIdx.x;
+    const long long a0 = sp.a00 + (long long)sym * SYM_N;
+    uint32_t W[16];
+    if (RAW) raw_symbol_load8(st.raw, a0, W, tid);
+    fft8_stage_b_twiddles(twB, tb.twiddle);                    // first read two barriers from here
+    const double dth = sp.dtheta;
+    double a1 = 256.0 * dth;
+    a1 -= 2 * M_PI * rint(a1 * (1.0 / (2 * M_PI)));
+    double a0p = sp.theta + (double)sym * SYM_N * dth + (double)tid * dth;
+    a0p -= 2 * M_PI * rint(a0p * (1.0 / (2 * M_PI)));
+    float a1f = (float)a1, a0f = (float)a0p;                   // the double-precision part runs under the capture loads; only two floats cross the half-band
+#ifndef HIPEMU
+    asm volatile("" : "+v"(a1f), "+v"(a0f));                   // (finished HERE, not sunk behind the half-band with their double-precision inputs)
+#endif
+    if (RAW) {
+        raw_symbol_halfband8(W, lds, hb_taps(tb.hb_q15), tid);
+        __syncthreads();
+    }
+    cf stp, ph;
+    { float sn, cs; fast_sincos_reduced(a1f, sn, cs); stp = cf_make(cs, sn); }
+    { float sn, cs; fast_sincos_reduced(a0f, sn, cs); ph = cf_make(cs, sn); }
+    const c16 *win = db.q15 + (size_t)s * db.q15_cap + a0;
+    auto sample = [&](int j) -> cf {
+        if (RAW) return q15_to_cf(lds[j]);
+        const c16 s16 = win[j];
+        return q15_to_cf(cf_make((float)s16.r, -(float)s16.i));
+    };
+    // NCO phasor of sample tid + 256 q: one accurate evaluation at q = 0 and one of the 256-sample step, then an 8-step recurrence
+    cf x[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        cf m = cmul(ph, sample(tid + 256 * q));
+        if (q == 0 && tid < CP_N) { const float w = tb.shape[tid]; m = emul(m, cf_make(w, w)); }
+        x[q] = m;
+        ph = cmul(ph, stp);
+    }
+    if (tid < CP_N) {                                          // fold the cyclic extension back (acquire.c:246-247)
+        const cf m = cmul(ph, sample(FFT_N + tid));
+        const float w = tb.shape[FFT_N + tid];
+        x[0] = cadd(x[0], emul(cf_make(w, w), m));
+    }
+    if (RAW) __syncthreads();
+
+    fft2048_wg8(x, lds, tb.twiddle_a, twB);
+
+    // fftshift + live-bin cut on the UNSHIFTED index k: upper sideband = k in [UB0 - 1024, UB1 - 1024], lower = k in [LB0 + 1024, LB0 + 1024 + 266].
+    // Lane q holds k4 = 0, 2, 1, 3 (q = 0..3): of its eight k3 only 4..7 (k4 = 0, 2) or 0..3 (k4 = 1, 3) can be live.
+    cf *out = (cf *)(db.bins + ((size_t)s * NSYM + sym) * LIVE_N);
+    const int q = tid & 3, k4 = 2 * (q & 1) + (q >> 1);
+    const bool hi = q < 2;
+    const int kb = (tid >> 5) + 8 * ((tid >> 2) & 7) + 512 * k4 + (hi ? 256 : 0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const cf v = hi ? x[4 + i] : x[i];
+        const int k = kb + 64 * i;
+        if (k >= UB0 - 1024 && k <= UB1 - 1024) out[LIVE_HALF + k - (UB0 - 1024)] = v;
+        else if (k >= LB0 + 1024 && k < LB0 + 1024 + LIVE_HALF) out[k - (LB0 + 1024)] = v;
+    }
+}
+
+#ifndef HIPEMU
+#define MIXFFT8_OCCUPANCY __attribute__((amdgpu_waves_per_eu(8, 8)))
+#else
+#define MIXFFT8_OCCUPANCY
+#endif
+__global__ __launch_bounds__(256) MIXFFT8_OCCUPANCY void k_mixfft8(DevTables tb, DevBuffers db, const int *ids, int local_prepare)
+{
+    wave_set_priority_high();
+    const int s = wave_uniform(stream_of(ids, blockIdx.y));
+    const StreamState &st = db.state[s];
+    SymParams sp;
+    if (local_prepare) {
+        __shared__ SymParams sh_sp;
+        if (threadIdx.x == 0) {
+            const Prepared p = prepare_values(st, false);
+            sh_sp.active = p.active; sh_sp.a00 = (st.rd - st.base) + p.samperr; sh_sp.dtheta = p.dtheta; sh_sp.theta = p.theta;
+        }
+        __syncthreads();
+        sp = sh_sp;
+    } else {
+        sp.active = st.active; sp.a00 = (st.rd - st.base) + st.samperr_cur; sp.dtheta = st.dtheta; sp.theta = st.theta;
+    }
+    sp.active = wave_uniform(sp.active); sp.a00 = uniform64(sp.a00); sp.dtheta = uniform64(sp.dtheta); sp.theta = uniform64(sp.theta);
+    if (!sp.active) return;
+    __shared__ cf lds[8 * P8_ROW];
+    static_assert(8 * P8_ROW >= 9 * 256 && 9 * 240 == SYM_N, "nine decimated samples per work-item fit in the FFT tile");
+    __shared__ cf twB[TW8_N];
+    if (st.raw) mixfft_symbol8<true>(tb, db, st, sp, s, lds, twB);
+    else mixfft_symbol8<false>(tb, db, st, sp, s, lds, twB);
 }
 
 // Symbols per workgroup (nrsc5hip_debug_tune NRSC5HIP_TUNE_MIXFFT_SYMS).  The persistent forms -- 2 / 4 / 8 symbols per workgroup, the
@@ -435,6 +784,7 @@ __global__ __launch_bounds__(128 * NPAR) MIXFFT_OCCUPANCY void k_mixfft(DevTable
 // cannot be held across the loop (28 VGPRs) and are exposed once per symbol behind a barrier.  Default: 1.
 void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int syms_per_wg, int local_prepare)
 {
+    if (syms_per_wg == 32) { hipLaunchKernelGGL(k_mixfft8, dim3(NSYM, nstreams), dim3(256), 0, st, tb, db, stream_ids, local_prepare); return; }   // the 256-lane form
     if (syms_per_wg == 16) { hipLaunchKernelGGL((k_mixfft<1, 2>), dim3(NSYM / 2, nstreams), dim3(256), 0, st, tb, db, stream_ids, local_prepare); return; }   // knob value 16: NPAR = 2
     switch (syms_per_wg) {
     case 2: hipLaunchKernelGGL((k_mixfft<2, 1>), dim3(NSYM / 2, nstreams), dim3(128), 0, st, tb, db, stream_ids, local_prepare); break;
@@ -457,16 +807,34 @@ __global__ __launch_bounds__(128) void k_fft2048(DevTables tb, const float2 *in,
 #pragma unroll
         for (int n1 = 0; n1 < 8; n1++) x[8 * h + n1] = src[tid + 128 * h + 256 * n1];
     __shared__ cf twB[256];
-    fft_stage_b_twiddles(twB, tb.twiddle);
+    fft_stage_b_twiddles<128>(twB, tb.twiddle);
     fft2048_wg<false>(x, lds, tb.twiddle_a, twB);
     const int kbase = (tid >> 4) + 8 * (tid & 15);
 #pragma unroll
     for (int i = 0; i < 16; i++) dst[kbase + 128 * ((i >> 2) + 4 * (i & 3))] = x[i];
 }
 
-void launch_fft2048(const DevTables &tb, const float2 *in, float2 *out, int nffts, hipStream_t st)
+__global__ __launch_bounds__(256) void k_fft2048_8(DevTables tb, const float2 *in, float2 *out)
 {
-    hipLaunchKernelGGL(k_fft2048, dim3(nffts), dim3(128), 0, st, tb, in, out);
+    __shared__ cf lds[8 * P8_ROW];
+    __shared__ cf twB[TW8_N];
+    const int tid = threadIdx.x;
+    const cf *src = (const cf *)(in + (size_t)blockIdx.x * FFT_N);
+    cf *dst = (cf *)(out + (size_t)blockIdx.x * FFT_N);
+    cf x[8];
+#pragma unroll
+    for (int n1 = 0; n1 < 8; n1++) x[n1] = src[tid + 256 * n1];
+    fft8_stage_b_twiddles(twB, tb.twiddle);
+    fft2048_wg8(x, lds, tb.twiddle_a, twB);
+    const int q = tid & 3, kb = (tid >> 5) + 8 * ((tid >> 2) & 7) + 512 * (2 * (q & 1) + (q >> 1));
+#pragma unroll
+    for (int k3 = 0; k3 < 8; k3++) dst[kb + 64 * k3] = x[k3];
+}
+
+void launch_fft2048(const DevTables &tb, const float2 *in, float2 *out, int nffts, hipStream_t st, int form)
+{
+    if (form == 32) hipLaunchKernelGGL(k_fft2048_8, dim3(nffts), dim3(256), 0, st, tb, in, out);
+    else hipLaunchKernelGGL(k_fft2048, dim3(nffts), dim3(128), 0, st, tb, in, out);
 }
 
 }  // namespace nrsc5

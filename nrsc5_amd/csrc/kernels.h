@@ -60,7 +60,7 @@ struct DevBuffers {
     int rec_cap;
     int *counters;                   // per burst: [0] blocks prepared, [1] not-FINE streams seen (host: keep launching the acquisition kernels),
                                      // [2] streams that need the PX kernels, [3] streams rewound by k_rollback
-    long long *sync_phase_cycles;    // [8] optional: accumulated shader cycles per k_sync phase (stream 0 only), or null
+    long long *sync_phase_cycles;    // [16] optional: accumulated shader cycles per k_sync phase (stream 0 only) in [0..7]; [8..15]: k_mixfft's phases in the diagnostic build; or null
     // extended sidebands
     int8_t *px_mem;                  // [S][2][PX_MEM]           interleaver IV memories of PX1, PX2
     int8_t *px_pair;                 // [S][2][2 * PX_MAX]       soft bits of the current block pair
@@ -164,6 +164,6 @@ void vit_scratch_free(VitScratch &sc);
 // -> 0, or -1: frame too long for the block-parallel traceback (viterbi3_traceback_block: at most 64 segments of TB_SEG chunks) / out of device memory
 int launch_viterbi_frames(VitScratch &sc, const int8_t *coded, int len, int nframes, unsigned long long *dec, uint32_t *out, hipStream_t st, int phases = 3, int segments = 1, int *stats = nullptr, int warm = 2);
 void launch_selftest(int *fail_count, hipStream_t st);
-void launch_fft2048(const DevTables &tb, const float2 *in, float2 *out, int nffts, hipStream_t st);
+void launch_fft2048(const DevTables &tb, const float2 *in, float2 *out, int nffts, hipStream_t st, int form = 1);   // form 32: the 256-lane FFT
 
 }  // namespace nrsc5

@@ -528,7 +528,7 @@ class Engine:
         return tuple(int(v) for v in st)
 
     def debug_sync_phases(self) -> np.ndarray:
-        c = np.zeros(8, dtype=np.int64)
+        c = np.zeros(16, dtype=np.int64)                        # [0..7] k_sync, [8..15] k_mixfft (diagnostic build only)
         self._check(self.lib.nrsc5hip_debug_sync_phases(self._h, c.ctypes.data))
         return c
 

@@ -63,9 +63,11 @@ def _fetch_q15(E, n):
     return out
 
 
-def check_fft(lib, oracle, n=4, seed=1):
+def check_fft(lib, oracle, n=4, seed=1, form=0):
     rng = np.random.default_rng(seed)
     E = eng.Engine(max_streams=1, q15_capacity=2 * 71280, lib_path=lib)
+    if form:
+        E.tune(eng.TUNE_MIXFFT_SYMS, form)                      # 32: the 256-lane FFT (8 x 8 x 8 x 4)
     x = (rng.standard_normal((n, 2048)) + 1j * rng.standard_normal((n, 2048))).astype(np.complex64)
     x[0] = 0; x[0, 5] = 1.0                                   # impulse: every twiddle path
     got = E.stage_fft2048(x)
@@ -107,20 +109,22 @@ def check_viterbi_roundtrip(lib, L=4608, frames=4, seed=9, flip=0.004):
     E.close()
 
 
-def run_capture(lib, cap, p1_async=False, chunk=32768 * 8, l2_feedback=False):
+def run_capture(lib, cap, p1_async=False, chunk=32768 * 8, l2_feedback=False, tune=()):
     E = eng.Engine(max_streams=1, q15_capacity=max(2 * 71280 + chunk, 400000), lib_path=lib, p1_async=p1_async, l2_feedback=l2_feedback)
+    for knob, value in tune:
+        E.tune(knob, value)
     common.run_engine_streaming(E, 0, cap.iq, chunk=chunk)
     recs = E.drain(0)
     log = eng.records_to_log(E, 0, recs)
     return E, recs, log
 
 
-def check_golden_end_to_end(lib, name, captures):
+def check_golden_end_to_end(lib, name, captures, tune=()):
     """Streaming seam vs the golden trace of the unmodified reference: frames exact, floats 1e-4."""
     g = golden(name)
     cap = captures(name)
     assert common.sha256(cap.iq) == str(g["iq_sha"])
-    E, recs, log = run_capture(lib, cap)
+    E, recs, log = run_capture(lib, cap, tune=tune)
     diffs = common.compare_logs(common.arrays_to_log(g), common.strip_states(log))
     assert not diffs, diffs[:10]
     E.close()
@@ -216,14 +220,14 @@ def check_batch_equals_streaming(lib, caps, p1_async):
     return steps
 
 
-def check_zero_copy_batch(lib, caps, p1_async=True, l2_feedback=False, mixfft_syms=0):
+def check_zero_copy_batch(lib, caps, p1_async=True, l2_feedback=False, mixfft_syms=0, rtol=0.0, singles_tuned=False):
     """Engine option batch_zero_copy (K1 fused into the symbol kernel, captures read in place) == the copying batch path
     == the streaming seam, record for record; plus the error behaviour of the attached state."""
     import pytest
     n = len(caps)
     singles = []
     for cap in caps:
-        E, recs, log = run_capture(lib, cap, l2_feedback=l2_feedback)
+        E, recs, log = run_capture(lib, cap, l2_feedback=l2_feedback, tune=((eng.TUNE_MIXFFT_SYMS, mixfft_syms),) if singles_tuned else ())
         singles.append(log)
         E.close()
     stride = max(c.iq.size for c in caps); stride += (-stride) % 16
@@ -245,7 +249,7 @@ def check_zero_copy_batch(lib, caps, p1_async=True, l2_feedback=False, mixfft_sy
     recs, counts, frames = E.batch_fetch_view(n) if p1_async else E.batch_fetch(n)
     for k in range(n):
         log = eng.records_to_log(E, k, recs[k, :counts[k]], frames[k])
-        diffs = common.compare_logs(singles[k], log, rtol=0.0)
+        diffs = common.compare_logs(singles[k], log, rtol=rtol)
         assert not diffs, (k, diffs[:10])
     # reset detaches: the same engine then takes the streaming seam again
     E.reset_all()

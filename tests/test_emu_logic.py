@@ -243,5 +243,14 @@ def test_emu_symbol_kernel_variants(emu_lib, syms):
     ec.check_zero_copy_batch(emu_lib, caps, p1_async=True, l2_feedback=False, mixfft_syms=syms)
 
 
+def test_emu_symbol_kernel_256_lanes(emu_lib, oracle, captures):
+    """k_mixfft8 (knob 32): the 256-lane symbol kernel -- FFT 2048 = 8 x 8 x 8 x 4 with the last radix across DPP quads -- as an FFT against
+    float64, in the zero-copy batch against its own streaming form (rtol 0), and end to end against the reference's golden trace"""
+    ec.check_fft(emu_lib, oracle, n=3, form=32)
+    caps = [synth.fm_mp1_capture(0, seed=71, cfo_hz=33.0, offset=400, snr_db=22, n_blocks=20), synth.fm_mp1_capture(0, seed=72, cfo_hz=-120.0, offset=1500, snr_db=20, n_blocks=20)]
+    ec.check_zero_copy_batch(emu_lib, caps, p1_async=True, l2_feedback=False, mixfft_syms=32, singles_tuned=True)
+    ec.check_golden_end_to_end(emu_lib, "fm_cu8_cfo137", captures, tune=((ec.eng.TUNE_MIXFFT_SYMS, 32),))
+
+
 def test_emu_traceback_variants(emu_lib):
     ec.check_traceback_variants(emu_lib)

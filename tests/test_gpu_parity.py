@@ -417,6 +417,16 @@ def test_gpu_symbol_kernel_variants(hip_lib, syms):
     ec.check_zero_copy_batch(hip_lib, caps, p1_async=True, l2_feedback=False, mixfft_syms=syms)
 
 
+def test_gpu_symbol_kernel_256_lanes(hip_lib, oracle, captures):
+    """k_mixfft8 (knob 32), the 256-lane symbol kernel: FFT against float64 / the oracle, zero-copy batch == its own streaming form (rtol 0),
+    golden traces of the unmodified reference end to end (frames exact, floats 1e-4)"""
+    ec.check_fft(hip_lib, oracle, n=4, form=32)
+    caps = [synth.fm_mp1_capture(0, seed=71, cfo_hz=33.0, offset=400, snr_db=22, n_blocks=20), synth.fm_mp1_capture(0, seed=72, cfo_hz=-120.0, offset=1500, snr_db=20, n_blocks=20)]
+    ec.check_zero_copy_batch(hip_lib, caps, p1_async=True, l2_feedback=False, mixfft_syms=32, singles_tuned=True)
+    for name in ("fm_cu8_cfo137", "fm_cu8_cfo-2400", "fm_cs16_cfo60", "fm_cu8_ppm60_host"):
+        ec.check_golden_end_to_end(hip_lib, name, captures, tune=((ec.eng.TUNE_MIXFFT_SYMS, 32),))
+
+
 def test_gpu_traceback_variants(hip_lib):
     """single-path traceback == block-parallel traceback (records incl. the BER count, frames) on a capture with a noise frame"""
     ec.check_traceback_variants(hip_lib)
