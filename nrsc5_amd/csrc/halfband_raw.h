@@ -97,6 +97,9 @@ __device__ __forceinline__ hb_v2 hb_add(hb_v2 a, hb_v2 b) { return a + b; }
 // themselves) and the sched_barrier keeps the machine scheduler from moving anything else across the switch.
 __device__ __forceinline__ void hb_round_down()
 {
+    // fenced on BOTH sides: with the fence behind it only, the scheduler moved the switch itself up across ~150 instructions of the code in front of it --
+    // the NCO's v_sin / v_cos among them, which then ran rounding down and made the zero-copy batch differ from the streaming seam in the last bit
+    __builtin_amdgcn_sched_barrier(0);
     asm volatile("s_setreg_imm32_b32 hwreg(HW_REG_MODE, 0, 2), 2\n\ts_nop 1" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
 }

@@ -34,6 +34,7 @@ __device__ inline cf cadd(cf a, cf b) { return cf_make(a.x + b.x, a.y + b.y); }
 __device__ inline cf csub(cf a, cf b) { return cf_make(a.x - b.x, a.y - b.y); }
 __device__ inline cf emul(cf a, cf b) { return cf_make(a.x * b.x, a.y * b.y); }                 // element by element
 __device__ inline cf cmul(cf a, cf b) { return cf_make(a.x * b.x - a.y * b.y, a.y * b.x + a.x * b.y); }
+__device__ inline cf cmul_k(cf a, cf b) { return cmul(a, b); }
 __device__ inline cf mul_mj(cf a) { return cf_make(a.y, -a.x); }                                // a * (-j)
 __device__ inline cf cf_swap(cf a) { return cf_make(a.y, a.x); }
 __device__ inline cf cf_neg_x(cf a) { return cf_make(-a.x, a.y); }
@@ -46,23 +47,40 @@ __device__ __forceinline__ cf emul(cf a, cf b) { return a * b; }
 // (a.x b.x - a.y b.y, a.y b.x + a.x b.y): the second product joins through fma(t, (-1, 1), p) = p -+ t, rounded once like the
 // subtraction / addition it replaces (t * +-1 is exact) -- 3 packed instructions; written as p + (-t.x, t.y) the compiler negated
 // BOTH halves and moved one back
-__device__ __forceinline__ cf cmul(cf a, cf b) { const cf t = a.yx * b.yy, sg = {-1.0f, 1.0f}; return __builtin_elementwise_fma(t, sg, a * b.xx); }
+__device__ __forceinline__ cf cmul3(cf a, cf b) { const cf t = a.yx * b.yy, sg = {-1.0f, 1.0f}; return __builtin_elementwise_fma(t, sg, a * b.xx); }
+// ... and in TWO: p = (a.x b.x, a.y b.x), then (-a.y b.y + p.x, a.x b.y + p.y) as ONE packed fma whose operand swaps and the sign of the low half ride in
+// op_sel / neg_lo.  The second product is no longer rounded before it is added (a fused multiply-add on each component): within half an ulp of the
+// three-instruction form, far inside the 1e-4 the float path is held to.  81 complex products per work-item and symbol.
+__device__ __forceinline__ cf cmul(cf a, cf b)
+{
+    cf p;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "+v"(p) : "v"(a), "v"(b));
+    return p;
+}
+// b a compile-time constant (or wave-uniform): a scalar register pair
+__device__ __forceinline__ cf cmul_k(cf a, cf b)
+{
+    cf p;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "v"(a), "s"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "+v"(p) : "v"(a), "s"(b));
+    return p;
+}
 __device__ __forceinline__ cf mul_mj(cf a) { return cf_make(a.y, -a.x); }
 __device__ __forceinline__ cf cf_swap(cf a) { return a.yx; }
 __device__ __forceinline__ cf cf_neg_x(cf a) { return cf_make(-a.x, a.y); }
 #endif
 __device__ inline cf cf_of(float2 a) { return cf_make(a.x, a.y); }
-// q15_to_float (halfband_raw.h) on both components at once: the same three roundings per component
-__device__ __forceinline__ cf q15_to_cf(cf x)
+// Unit phasor (cos x, sin x) for x in [-pi, pi].  v_sin / v_cos are transcendental-unit instructions: a VALU instruction reading their result needs one
+// wait state, which the compiler inserts for its own instructions but not in front of inline assembly -- and cmul IS inline assembly (its first use
+// right behind v_cos read a stale cosine: test_gpu_symbol_kernel_256_lanes).  The results therefore leave through a statement that owns the wait state.
+__device__ __forceinline__ cf unit_phasor(float x)
 {
-#ifdef HIPEMU
-    return cf_make(q15_to_float(x.x), q15_to_float(x.y));
-#else
-    const cf r = {1.0f / 32767.0f, 1.0f / 32767.0f}, d = {32767.0f, 32767.0f};
-    const cf q0 = x * r;
-    const cf e = __builtin_elementwise_fma(-q0, d, x);
-    return __builtin_elementwise_fma(e, r, q0);
+    float sn, cs; fast_sincos_reduced(x, sn, cs);
+#ifndef HIPEMU
+    asm("s_nop 0" : "+v"(sn), "+v"(cs));
 #endif
+    return cf_make(cs, sn);
 }
 
 // forward 4-point DFT in place, natural order out
@@ -96,15 +114,15 @@ __device__ inline void dft16(cf *v)
     for (int n2 = 0; n2 < 4; n2++) dft4(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);   // v[4k1+n2] = Y[k1][n2]
     const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, c2 = 0.70710678118654752440f;
     // W16^m, m = n2*k1
-    v[5]  = cmul(v[5],  cf_make(c1, -s1));    // m=1
-    v[6]  = cmul(v[6],  cf_make(c2, -c2));    // m=2
-    v[7]  = cmul(v[7],  cf_make(s1, -c1));    // m=3
-    v[9]  = cmul(v[9],  cf_make(c2, -c2));    // m=2
+    v[5]  = cmul_k(v[5],  cf_make(c1, -s1));    // m=1
+    v[6]  = cmul_k(v[6],  cf_make(c2, -c2));    // m=2
+    v[7]  = cmul_k(v[7],  cf_make(s1, -c1));    // m=3
+    v[9]  = cmul_k(v[9],  cf_make(c2, -c2));    // m=2
     v[10] = mul_mj(v[10]);                        // m=4
-    v[11] = cmul(v[11], cf_make(-c2, -c2));   // m=6
-    v[13] = cmul(v[13], cf_make(s1, -c1));    // m=3
-    v[14] = cmul(v[14], cf_make(-c2, -c2));   // m=6
-    v[15] = cmul(v[15], cf_make(-c1, s1));    // m=9
+    v[11] = cmul_k(v[11], cf_make(-c2, -c2));   // m=6
+    v[13] = cmul_k(v[13], cf_make(s1, -c1));    // m=3
+    v[14] = cmul_k(v[14], cf_make(-c2, -c2));   // m=6
+    v[15] = cmul_k(v[15], cf_make(-c1, s1));    // m=9
 #pragma unroll
     for (int k1 = 0; k1 < 4; k1++) dft4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
 }
@@ -118,15 +136,15 @@ __device__ inline void dft16_live(cf *v)
 #pragma unroll
     for (int n2 = 0; n2 < 4; n2++) dft4(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
     const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, c2 = 0.70710678118654752440f;
-    v[5]  = cmul(v[5],  cf_make(c1, -s1));
-    v[6]  = cmul(v[6],  cf_make(c2, -c2));
-    v[7]  = cmul(v[7],  cf_make(s1, -c1));
-    v[9]  = cmul(v[9],  cf_make(c2, -c2));
+    v[5]  = cmul_k(v[5],  cf_make(c1, -s1));
+    v[6]  = cmul_k(v[6],  cf_make(c2, -c2));
+    v[7]  = cmul_k(v[7],  cf_make(s1, -c1));
+    v[9]  = cmul_k(v[9],  cf_make(c2, -c2));
     v[10] = mul_mj(v[10]);
-    v[11] = cmul(v[11], cf_make(-c2, -c2));
-    v[13] = cmul(v[13], cf_make(s1, -c1));
-    v[14] = cmul(v[14], cf_make(-c2, -c2));
-    v[15] = cmul(v[15], cf_make(-c1, s1));
+    v[11] = cmul_k(v[11], cf_make(-c2, -c2));
+    v[13] = cmul_k(v[13], cf_make(s1, -c1));
+    v[14] = cmul_k(v[14], cf_make(-c2, -c2));
+    v[15] = cmul_k(v[15], cf_make(-c1, s1));
     {   // a = 0: outputs b = 1 (X[4]) and b = 3 (X[12])
         const cf t1 = csub(v[0], v[2]), t3 = mul_mj(csub(v[1], v[3]));
         v[1] = cadd(t1, t3); v[3] = csub(t1, t3);
@@ -176,8 +194,11 @@ constexpr int PITCH_B = 17;    // per r2 row inside a k1 row of the second layou
 // instructions of 16 cache lines each per wave on top of the first exchange's 14
 // ta (PRELOADED): the work-item's fourteen stage-A twiddles, loaded by the caller BEFORE its last barrier -- issued behind it (where they are
 // used) they were an L2 round trip at the head of every FFT
-template <bool LIVE, bool PRELOADED = false>
-__device__ inline void fft2048_wg(cf *x, cf *lds, const float2 *twA, const cf *twB, const cf *ta = nullptr)
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// after_a: called once stage A has written its LDS tile (its twiddles are dead, x is about to be re-read): the persistent forms issue the
+// NEXT symbol's capture loads there
+template <bool LIVE, bool PRELOADED = false, typename AfterA = NoHook>
+__device__ inline void fft2048_wg(cf *x, cf *lds, const float2 *twA, const cf *twB, const cf *ta = nullptr, AfterA after_a = AfterA())
 {
     const int tid = threadIdx.x & 127;                         // (two symbols may share a 256-lane workgroup: k_mixfft's NPAR)
     // stage A: two radix-8 butterflies, twiddle W2048^(k1*r), scatter to [k1][r]
@@ -192,6 +213,7 @@ __device__ inline void fft2048_wg(cf *x, cf *lds, const float2 *twA, const cf *t
             lds[k1 * PITCH_A + r] = v;
         }
     }
+    after_a();
     __syncthreads();
     // stage B: lane (k1, r2): 16-point DFT over r1 of [k1][r2 + 16 r1], twiddle W256^(r2*k2)
     {
@@ -381,7 +403,8 @@ __device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuf
     a1 -= 2 * M_PI * rint(a1 * (1.0 / (2 * M_PI)));
     cf stp;
     {
-        float sn, cs; fast_sincos_reduced((float)a1, sn, cs);
+        const cf u = unit_phasor((float)a1);
+        float sn = u.y, cs = u.x;
 #ifndef HIPEMU
         if (SPW > 1) {                                         // the same value in every lane: held in a scalar register pair across the symbol loop
             sn = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, sn)));
@@ -405,29 +428,30 @@ __device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuf
         double a0p = sp.theta + (double)sym * SYM_N * dth + (double)tid * dth;
         a0p -= 2 * M_PI * rint(a0p * (1.0 / (2 * M_PI)));
         cf ph;
-        { float sn, cs; fast_sincos_reduced((float)a0p, sn, cs); ph = cf_make(cs, sn); }     // reduced to [-pi, pi] in double above
+        // (reduced to [-pi, pi] in double above.)  The phasor carries the Q15 -> float scale 1 / 32767 (cq15_to_cf, defines.h:106-111) through
+        // its recurrence: the samples enter the mix as the integers they are -- three packed instructions per sample less than dividing each one
+        // as the reference does, and within an ulp of it
+        ph = emul(unit_phasor((float)a0p), cf_make(1.0f / 32767.0f, 1.0f / 32767.0f));
         MIX_MARK(1, 1);                                            // set-up + the capture loads' latency
         if (RAW) {
             raw_symbol_halfband(W, lds, taps, tid);
             __syncthreads();
-            if (i + 1 < SPW) raw_symbol_load(raw, a0 + SYM_N, W, tid);         // the next symbol's samples: needed one FFT from now
         }
         MIX_MARK(2, 0);                                            // half-band + barrier
         const c16 *win = db.q15 + (size_t)s * db.q15_cap + a0;     // FIFO path (streaming seam, cs16 input)
 
         auto sample = [&](int j) -> cf {
-            if (RAW) return q15_to_cf(lds[j]);                     // the tile holds Q15 integers, conjugated
+            if (RAW) return lds[j];                                // the tile holds Q15 integers, conjugated
             const c16 s16 = win[j];
-            return q15_to_cf(cf_make((float)s16.r, -(float)s16.i));   // cq15_to_cf_conj, defines.h:111 (the quotient is odd in its argument)
+            return cf_make((float)s16.r, -(float)s16.i);           // cq15_to_cf_conj, defines.h:111, less its scale (carried by the phasor)
         };
-        const float w0 = SPW > 1 ? shape[tid] : pro.w0, w1 = SPW > 1 ? shape[min(FFT_N + tid, SYM_N - 1)] : pro.w1;
-        cf ta[14];
-        if (SPW == 1) {                                            // in flight while the mix runs
+        const float w0 = pro.w0, w1 = pro.w1;
+        (void)shape;
+        cf ta[14];                                                 // in flight while the mix runs
 #pragma unroll
-            for (int h = 0; h < 2; h++)
+        for (int h = 0; h < 2; h++)
 #pragma unroll
-                for (int k1 = 1; k1 < 8; k1++) ta[7 * h + k1 - 1] = cf_of(twA[(k1 - 1) * 256 + tid + 128 * h]);
-        }
+            for (int k1 = 1; k1 < 8; k1++) ta[7 * h + k1 - 1] = cf_of(twA[(k1 - 1) * 256 + tid + 128 * h]);
         cf x[16];
 #pragma unroll
         for (int q = 0; q < 16; q++) {
@@ -446,7 +470,10 @@ __device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuf
         if (RAW) __syncthreads();                                  // every work-item has its samples: the tile becomes the FFT's
         MIX_MARK(3, 0);                                            // NCO, mix, fold + barrier
 
-        fft2048_wg<true, SPW == 1>(x, lds, twA, twB, ta);
+        // (the next symbol's samples: issued after stage A -- right after the half-band, beside the fourteen stage-A twiddles and the sixteen points,
+        // they pushed the persistent forms over 128 VGPRs)
+        auto next_loads = [&]() { if (RAW && i + 1 < SPW) raw_symbol_load(raw, a0 + SYM_N, W, tid); };
+        fft2048_wg<true, true>(x, lds, twA, twB, ta, next_loads);
         if (SPW > 1) __syncthreads();                              // stage C has read the tile: the next symbol may park its samples there
         MIX_MARK(4, 0);                                            // the FFT (three barriers)
 
@@ -705,13 +732,13 @@ __device__ __forceinline__ void mixfft_symbol8(const DevTables &tb, const DevBuf
         __syncthreads();
     }
     cf stp, ph;
-    { float sn, cs; fast_sincos_reduced(a1f, sn, cs); stp = cf_make(cs, sn); }
-    { float sn, cs; fast_sincos_reduced(a0f, sn, cs); ph = cf_make(cs, sn); }
+    stp = unit_phasor(a1f);
+    ph = emul(unit_phasor(a0f), cf_make(1.0f / 32767.0f, 1.0f / 32767.0f));   // carries the Q15 scale
     const c16 *win = db.q15 + (size_t)s * db.q15_cap + a0;
     auto sample = [&](int j) -> cf {
-        if (RAW) return q15_to_cf(lds[j]);
+        if (RAW) return lds[j];
         const c16 s16 = win[j];
-        return q15_to_cf(cf_make((float)s16.r, -(float)s16.i));
+        return cf_make((float)s16.r, -(float)s16.i);
     };
     // NCO phasor of sample tid + 256 q: one accurate evaluation at q = 0 and one of the 256-sample step, then an 8-step recurrence
     cf x[8];
