@@ -239,14 +239,31 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
         __threadfence_block();
         __syncthreads();
     }
-    if (!st.active) {                                          // block-uniform
+    // One burst of loads before the first wait: the state words the kernel starts from, the active reference carriers' bins (for the LARGEST carrier
+    // set: which of them are active depends on psmi, their addresses do not) and each Costas lane's loop state.  Read where they are used they were four
+    // DEPENDENT trips to memory -- active, then samperr / psmi / nblocks, then the bins, then the loop state behind a barrier -- at ~1 us apiece for data
+    // the previous kernel wrote on other XCDs (profiles/r04_mixfft_phases.txt has the same finding for the symbol kernel).
+    const int tid = threadIdx.x;
+    constexpr int NREFBIN = (NREF_MAX * NSYM + SYNC_NT - 1) / SYNC_NT;
+    const int e_active = st.active, e_nblocks = st.nblocks, e_samperr = st.samperr_cur, e_psmi = st.psmi;
+    float2 e_bin[NREFBIN];
+    {
+        const float2 *bins0 = db.bins + (size_t)s * NSYM * LIVE_N;
+#pragma unroll
+        for (int i = 0; i < NREFBIN; i++) {
+            const int k = min(tid + i * SYNC_NT, NREF_MAX * NSYM - 1);           // (clamped, not predicated: no branch between the loads)
+            e_bin[i] = bins0[(k % NSYM) * LIVE_N + bin_to_live(ref_bin(k / NSYM))];
+        }
+    }
+    const int e_l = bin_to_live(ref_bin(min(tid, NREF_MAX - 1)));
+    const float e_freq = st.costas_freq[e_l], e_phase = st.costas_phase[e_l];
+    if (!e_active) {                                           // block-uniform
         // no block this step; with the fused pipeline the stream may have become ready since (new samples).  Fused steps
         // run without the acquisition kernels, so only FINE streams can be prepared here (prepare_block.h).
         if (fuse_prepare && threadIdx.x == 0) prepare_block(db, st, s, false);
         return;
     }
     constexpr int SYNC_NW = SYNC_NT / 64;
-    const int tid = threadIdx.x;
     // phase instrumentation (nrsc5hip_debug_sync_phases): the running time stamp lives in LDS -- as a variable it was a register pair
     // alive across the whole kernel, spilled and reloaded around every barrier
     __shared__ long long sh_tstamp;
@@ -277,10 +294,10 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
     if (tid == 0) { sh_i[2] = 0; sh_i[3] = 0; }                // [2] set when this block completes a P1 frame (replay checkpoint below), [3] when a PIDS frame was decoded here
 
     float2 *bins = db.bins + (size_t)s * NSYM * LIVE_N;       // [sym][live]
-    BlockRecord &rec = db.records[(size_t)s * db.rec_cap + (st.nblocks % db.rec_cap)];
+    BlockRecord &rec = db.records[(size_t)s * db.rec_cap + (wave_uniform(e_nblocks) % db.rec_cap)];
     const LoopGains g = loop_gains();
-    const int samperr = st.samperr_cur;
-    const int ppb = partitions_for_psmi(st.psmi);
+    const int samperr = wave_uniform(e_samperr);
+    const int ppb = partitions_for_psmi(wave_uniform(e_psmi));
     const int nref = 2 * (ppb + 1);
 
     // ---- sync_adjust (sync.c:769-777): timing pick moved by adj samples -> rotate every loop phase
@@ -293,14 +310,19 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
         }
     }
     // the active reference carriers' bins -> refz[r][n] (the Costas loops below derotate them in place)
-    for (int k = tid; k < nref * NSYM; k += SYNC_NT) refz[k / NSYM][k % NSYM] = bins[(k % NSYM) * LIVE_N + bin_to_live(ref_bin(k / NSYM))];
+#pragma unroll
+    for (int i = 0; i < NREFBIN; i++) {
+        const int k = tid + i * SYNC_NT;
+        if (k < nref * NSYM) refz[k / NSYM][k % NSYM] = e_bin[i];
+    }
     __syncthreads();
     SYNC_MARK(0);
 
     // ---- Costas loops of the active reference carriers (sync.c:360-364)
     if (tid < nref) {
         const int l = bin_to_live(ref_bin(tid));
-        float f = st.costas_freq[l], p = st.costas_phase[l];
+        float f = e_freq, p = e_phase;
+        if (SYM_N / 2 - samperr != 0) p = st.costas_phase[l];  // block-uniform: sync_adjust above has just rotated the phases
         costas_block<true>(refz[tid], 1, f, p, 0, g, refz[tid], refph[tid]);     // in place: refz holds the carrier's raw bins
         int l2 = l;
 #ifndef HIPEMU

@@ -43,7 +43,24 @@ __device__ inline int routed_partitions_for_psmi(int psmi)
     }
 }
 
-__device__ inline bool window_ready(const StreamState &st) { return st.wr - st.rd >= WIN_N; }
+template <typename S> __device__ inline bool window_ready(const S &st) { return st.wr - st.rd >= WIN_N; }
+
+// The words of the stream state the bookkeeping reads, fetched in ONE burst.  Read through the state itself -- each field where the logic
+// first needs it, behind the branch that decides whether it is needed -- they were up to eight dependent round trips to L2 by the single
+// work-item that runs this, at the tail of every k_sync and at the head of every fast-seam k_mixfft.
+struct PrepView {
+    long long wr, rd;
+    int sync_state, samperr, cfo, coarse_samperr;
+    float angle, prev_angle, coarse_re, coarse_im;
+    double theta, dtheta;
+};
+__device__ __forceinline__ PrepView prep_view(const StreamState &st)
+{
+    PrepView v;
+    v.wr = st.wr; v.rd = st.rd; v.sync_state = st.sync_state; v.samperr = st.samperr; v.cfo = st.cfo; v.coarse_samperr = st.coarse_samperr;
+    v.angle = st.angle; v.prev_angle = st.prev_angle; v.coarse_re = st.coarse_re; v.coarse_im = st.coarse_im; v.theta = st.theta; v.dtheta = st.dtheta;
+    return v;
+}
 
 // What the top of acquire_process decides for the block at st.rd, as values (nothing is written): the symbol kernel of the fast
 // streaming seam computes them for itself -- every workgroup from the same unchanged state -- and the sync kernel that follows
@@ -59,7 +76,7 @@ struct Prepared {
 // acq_ran: the acquisition kernels ran in this step, i.e. coarse_samperr / coarse_re / coarse_im belong to the window at
 // st.rd.  A stream that is not FINE only advances on such steps (the host launches them whenever counters[1] > 0 at the
 // last burst boundary); anywhere else it waits -- never a block on stale coarse results.
-__device__ inline Prepared prepare_values(const StreamState &st, bool acq_ran)
+template <typename S> __device__ inline Prepared prepare_values_of(const S &st, bool acq_ran)
 {
     Prepared p;
     const bool ready = window_ready(st);
@@ -103,13 +120,16 @@ __device__ inline Prepared prepare_values(const StreamState &st, bool acq_ran)
     p.theta = th;
     return p;
 }
+__device__ inline Prepared prepare_values(const StreamState &st, bool acq_ran) { return prepare_values_of(prep_view(st), acq_ran); }
 
 __device__ inline void prepare_block(const DevBuffers &db, StreamState &st, int s, bool acq_ran)
 {
-    if (st.active) return;                                     // already prepared (fused into the previous k_sync)
-    if (st.sync_state != SYNC_FINE) atomicAdd(&db.counters[1], 1);   // host: keep launching acquisition
-    if (st.sync_state != SYNC_FINE || routed_partitions_for_psmi(st.psmi) > PM_PART) atomicAdd(&db.counters[2], 1);   // ... and the PX kernels
-    const Prepared p = prepare_values(st, acq_ran);
+    const int was_active = st.active, psmi = st.psmi, nblocks = st.nblocks;
+    const PrepView v = prep_view(st);                          // (with the three words above: one burst of loads)
+    if (was_active) return;                                    // already prepared (fused into the previous k_sync)
+    if (v.sync_state != SYNC_FINE) atomicAdd(&db.counters[1], 1);   // host: keep launching acquisition
+    if (v.sync_state != SYNC_FINE || routed_partitions_for_psmi(psmi) > PM_PART) atomicAdd(&db.counters[2], 1);   // ... and the PX kernels
+    const Prepared p = prepare_values_of(v, acq_ran);
     st.active = p.active;
     if (!p.active) {
         if (p.pending) atomicAdd(&db.counters[0], 1);          // work is pending: the host must keep stepping
@@ -117,13 +137,13 @@ __device__ inline void prepare_block(const DevBuffers &db, StreamState &st, int 
     }
     atomicAdd(&db.counters[0], 1);
 
-    BlockRecord &rec = db.records[(size_t)s * db.rec_cap + (st.nblocks % db.rec_cap)];
+    BlockRecord &rec = db.records[(size_t)s * db.rec_cap + (nblocks % db.rec_cap)];
     BlockRecord r;
-    r.flags = REC_PROCESSED; r.state_before = st.sync_state; r.state_after = 0;
+    r.flags = REC_PROCESSED; r.state_before = v.sync_state; r.state_after = 0;
     r.samperr = 0; r.cfo = 0; r.keep = 0; r.bc = 0; r.psmi = 0; r.cfo_wait = 0; r.next_samperr = 0;
     r.prev_angle = 0; r.phase_re = 0; r.phase_im = 0; r.next_angle = 0; r.freq_offset = 0; r.mer_lb = 0; r.mer_ub = 0;
     r.ber = 0; r.p1_slot = -1; r.bc_decoded = -1; r.pids[0] = r.pids[1] = r.pids[2] = 0; r.sis = 0;
-    if (st.sync_state == SYNC_FINE) { st.samperr = 0; st.angle = 0; }
+    if (v.sync_state == SYNC_FINE) { st.samperr = 0; st.angle = 0; }
     else if (p.to_coarse) { r.flags |= REC_TO_COARSE; st.sync_state = SYNC_COARSE; }
     st.prev_angle = p.prev_angle;
     rec = r;
