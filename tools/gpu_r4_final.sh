@@ -7,7 +7,9 @@ TAG=${1:-r04z}
 for WL in fm am-cs16; do
 rm -rf gpurun_out/${TAG}_prof_$WL
 ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof_$WL -o p -- python $R/bench.py --workload $WL --no-cpu-baseline --no-extra-legs --steps 3 --warmup 1 ) > gpurun_out/${TAG}_prof_$WL.log 2>&1; echo "prof $WL rc=$?"
-f=$(find gpurun_out/${TAG}_prof_$WL -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${TAG}_kernel_stats_$WL.csv && head -6 "$f" | cut -c1-160
+f=$(find gpurun_out/${TAG}_prof_$WL -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" gpurun_out/${TAG}_kernel_stats_$WL.csv && grep "nrsc5::" "$f" | head -4 | cut -c1-160
+# the FM summary, stamped with this tree's fingerprint, where the bench line looks for it (roofline.rocprof) -- and under the name it is committed as
+if [ "$WL" = fm ] && [ -f gpurun_out/${TAG}_kernel_stats_fm.csv ]; then cp gpurun_out/${TAG}_kernel_stats_fm.csv profiles/r04_kernel_stats_fm_256x20s.csv; python tools/stamp_kernel_stats.py profiles/r04_kernel_stats_fm_256x20s.csv fm; cp profiles/kernel_stats_latest.json gpurun_out/kernel_stats_latest.json; fi
 rm -rf gpurun_out/${TAG}_prof_$WL
 done
 bash tools/gpu_pmc.sh fm 2>&1 | tail -2 | cut -c1-400
