@@ -519,6 +519,9 @@ struct AmBlockSmem {
     int deliver;                // replay: P1 PDU this block delivered (0..7), -1: none
     double theta, dtheta;
     float2 step270, step256;        // e^{i 270 dtheta}, e^{i 256 dtheta}
+    float dphi[NSYM];           // carrier phase advance per symbol (line fit), one work-item each
+    double targ;                // argument handed from work-item 0 to the work-items that evaluate its cosine / sine
+    int bc_now, psmi_now, rdbi_now;   // the stream's block count / service mode / RDBI after the reference decode (block-uniform copies)
 };
 // the PIDS trellis runs after the spectra are consumed: its scratch aliases the head of X
 static_assert(sizeof(K9Smem) + 4 * (PIDS_LEN + 64) * sizeof(unsigned long long) <= sizeof(float2) * NSYM * AM_FFT, "PIDS scratch must fit in X");
@@ -549,14 +552,14 @@ __device__ inline float half_turn_diff(float a, float b)   // phase_diff, sync.c
 // Mix one block down with the NCO (phase theta + dtheta * sample), fold the cyclic prefix (rotated by 121 samples:
 // carrier phases are referenced to the symbol centre, acquire.c:239-247) and leave the 32 inputs in bit-reversed
 // order for the in-place radix-2 transform.  Work-item j owns input slot j of every symbol.
-__device__ inline void am_fold(AmBlockSmem &sm, const c16 *win, int samperr, double theta, float2 step270, float2 step256)
+template <int NT> __device__ inline void am_fold(AmBlockSmem &sm, const c16 *win, int samperr, double theta, float2 step270, float2 step256)
 {
     // work-item (j, g): sample j of the eight symbols of group g; the phasor is evaluated in closed form at the head of every
     // group and advanced by recurrence inside it, whatever the block size (256 work-items take the four groups in turn, 1024
     // one each), so that both launch shapes produce the same bits
     const int j = threadIdx.x & 255;
     const unsigned slot = bitrev8((unsigned)(j + (AM_FFT - AM_CP) / 2) & 255u);
-    for (int g = (int)threadIdx.x >> 8; g < NSYM / 8; g += (int)blockDim.x >> 8) {
+    for (int g = (int)threadIdx.x >> 8; g < NSYM / 8; g += NT >> 8) {
         float2 p;
         {
             double th = theta + sm.dtheta * (double)(j + g * 8 * AM_SYM);
@@ -580,12 +583,12 @@ __device__ inline void am_fold(AmBlockSmem &sm, const c16 *win, int samperr, dou
 }
 
 // 32 x 256-point forward FFT in LDS: radix-2 decimation in time, in place, natural-order output
-__device__ inline void am_fft_all(AmBlockSmem &sm)
+template <int NT> __device__ inline void am_fft_all(AmBlockSmem &sm)
 {
     for (int lg = 1; lg <= 8; lg++) {
         __syncthreads();
         const int half = 1 << (lg - 1);
-        for (int id = threadIdx.x; id < NSYM * 128; id += (int)blockDim.x) {
+        for (int id = threadIdx.x; id < NSYM * 128; id += NT) {
             const int n = id >> 7, q = id & 127;
             const int pos = q & (half - 1), i0 = ((q >> (lg - 1)) << lg) + pos, i1 = i0 + half;
             const float2 w = sm.tw[pos << (8 - lg)];
@@ -601,10 +604,27 @@ __device__ inline void am_fft_all(AmBlockSmem &sm)
 // spectrum bin `off` relative to the carrier (fftshift folded into the index), symbol n
 __device__ inline float2 &am_bin(AmBlockSmem &sm, int off, int n) { return sm.X[n * AM_FFT + (off & 255)]; }
 
+// e^{i 270 dtheta}, e^{i 256 dtheta} from sm.dtheta: four double-precision cosines / sines, one per wave (work-items 0, 64, 128, 192), instead of four in
+// a row on work-item 0.  Same functions of the same arguments: the same bits.  Callers put a barrier before (sm.dtheta) and after.
+__device__ __forceinline__ void am_nco_steps(AmBlockSmem &sm)
+{
+    const int tid = threadIdx.x;
+    if ((tid & 63) == 0 && tid < 256) {
+        const int w = tid >> 6;
+        const double x = sm.dtheta * (double)(w < 2 ? AM_SYM : AM_FFT);
+        const float v = (w & 1) ? (float)sin(x) : (float)cos(x);
+        float2 &dst = w < 2 ? sm.step270 : sm.step256;
+        if (w & 1) dst.y = v; else dst.x = v;
+    }
+}
+
 // 256 work-items per stream (the in-order K=9 PIDS trellis below owns one state per work-item).  Every wide phase strides by the
 // block size, but 1024 work-items were measured SLOWER in the window pipeline (am-cs16 88.6 -> 108.4 ms): a 16-wave workgroup with
 // 64 KB of LDS waits for a whole CU's worth of slots while the decode streams keep the chip full of long one-wave trellis passes.
-__global__ __launch_bounds__(512) void k_am_block(DevTables tb, DevBuffers db, const int *ids, int pipeline, int parity, int slot)
+// (NT, the block size, is a template constant: read as blockDim.x it is two dependent global loads -- implicit-argument pointer, dispatch packet -- in
+// front of the first loop that strides by it; profiles/r04_mixfft_phases.txt)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_am_block(DevTables tb, DevBuffers db, const int *ids, int pipeline, int parity, int slot)
 {
     wave_set_priority_high();                                  // block-step chain = critical path; the decode waves run at priority 0
     const int s = stream_of(ids, blockIdx.x);
@@ -612,7 +632,8 @@ __global__ __launch_bounds__(512) void k_am_block(DevTables tb, DevBuffers db, c
     AmStream &am = db.am[s];
     HIP_DYNAMIC_SHARED(uint8_t, smem_raw)
     AmBlockSmem &sm = *(AmBlockSmem *)smem_raw;
-    const int tid = threadIdx.x, NT = (int)blockDim.x;
+    const int tid = threadIdx.x;
+    static_assert(NT >= 256 && NT % 256 == 0, "four waves share the NCO's cosines / sines; the fold strides by groups of 256");
     const bool ready = st.wr - st.rd >= AM_WIN;                 // block-uniform
     if (tid == 0) {
         am.dec_bc = -1; st.active = ready ? 1 : 0;
@@ -700,40 +721,48 @@ __global__ __launch_bounds__(512) void k_am_block(DevTables tb, DevBuffers db, c
         r.samperr = 0; r.cfo = 0; r.keep = 0; r.bc = 0; r.psmi = 0; r.cfo_wait = 0; r.next_samperr = 0;
         r.prev_angle = 0; r.phase_re = 0; r.phase_im = 0; r.next_angle = 0; r.freq_offset = 0; r.mer_lb = 0; r.mer_ub = 0;
         r.ber = 0; r.p1_slot = -1; r.bc_decoded = -1; r.pids[0] = r.pids[1] = r.pids[2] = 0; r.sis = 0;
+        // the state words this section reads, in one burst (each behind the branch that needs it they were a chain of L2 round trips)
+        const int st_samperr = st.samperr, st_cfo = st.cfo, st_psmi = st.psmi, st_coarse_samperr = st.coarse_samperr;
+        int sync_state = st.sync_state;
+        const float st_prev_angle = st.prev_angle, st_coarse_re = st.coarse_re, st_coarse_im = st.coarse_im;
+        const double st_theta = st.theta;
         int samperr; float angle;
         if (state_before == SYNC_FINE) {
-            samperr = AM_SYM / 2 + st.samperr; st.samperr = 0;
-            angle = st.prev_angle;                             // sync_t.angle is only written by the FM path
+            samperr = AM_SYM / 2 + st_samperr; st.samperr = 0;
+            angle = st_prev_angle;                             // sync_t.angle is only written by the FM path
         } else {
-            samperr = st.coarse_samperr;
-            float sn, cs; sincosf(-st.prev_angle, &sn, &cs);
-            const float pr = st.coarse_re * cs - st.coarse_im * sn;
-            const float pi = st.coarse_re * sn + st.coarse_im * cs;
+            samperr = st_coarse_samperr;
+            float sn, cs; sincosf(-st_prev_angle, &sn, &cs);
+            const float pr = st_coarse_re * cs - st_coarse_im * sn;
+            const float pi = st_coarse_re * sn + st_coarse_im * cs;
             const float angle_diff = atan2f(pi, pr);
-            const float angle_factor = (st.prev_angle != 0.0f) ? 0.25f : 1.0f;
-            angle = st.prev_angle + (angle_diff * angle_factor);
+            const float angle_factor = (st_prev_angle != 0.0f) ? 0.25f : 1.0f;
+            angle = st_prev_angle + (angle_diff * angle_factor);
             st.prev_angle = angle;
-            if (st.sync_state != SYNC_COARSE) { r.flags |= REC_TO_COARSE; st.sync_state = SYNC_COARSE; }
+            if (sync_state != SYNC_COARSE) { r.flags |= REC_TO_COARSE; sync_state = SYNC_COARSE; st.sync_state = SYNC_COARSE; }
         }
         rec = r;
-        angle = (float)((double)angle - 2 * M_PI * st.cfo);    // acquire.c:164
+        angle = (float)((double)angle - 2 * M_PI * st_cfo);    // acquire.c:164
         const float dth = angle / AM_FFT;
-        const float inc_c = (float)cos((double)dth), inc_s = (float)sin((double)dth);      // cexpf(angle / fft * I)
-        double th = st.theta + (double)(-(float)(AM_SYM / 2 - samperr) * angle / AM_FFT);  // acquire.c:166
+        double th = st_theta + (double)(-(float)(AM_SYM / 2 - samperr) * angle / AM_FFT);  // acquire.c:166
         th -= 2 * M_PI * rint(th / (2 * M_PI));
-        sm.theta = th; sm.dtheta = atan2((double)inc_s, (double)inc_c);
-        sm.samperr = samperr; sm.fine = st.sync_state == SYNC_FINE; sm.ma3 = st.psmi == AM_MA3;
-        sm.step270 = make_float2((float)cos(sm.dtheta * AM_SYM), (float)sin(sm.dtheta * AM_SYM));
-        sm.step256 = make_float2((float)cos(sm.dtheta * AM_FFT), (float)sin(sm.dtheta * AM_FFT));
-        // keep the rounded increment for the slope correction below
-        sm.red_v[0] = make_float2(inc_c, inc_s);
+        sm.theta = th; sm.targ = (double)dth;
+        sm.samperr = samperr; sm.fine = sync_state == SYNC_FINE; sm.ma3 = st_psmi == AM_MA3;
     }
+    __syncthreads();
+    // cexpf(angle / fft * I), rounded to float (kept for the slope correction below): cosine and sine on two waves
+    if (tid == 0) sm.red_v[0].x = (float)cos(sm.targ);
+    if (tid == 64) sm.red_v[0].y = (float)sin(sm.targ);
+    __syncthreads();
+    if (tid == 0) sm.dtheta = atan2((double)sm.red_v[0].y, (double)sm.red_v[0].x);
+    __syncthreads();
+    am_nco_steps(sm);
     __syncthreads();
     const int samperr = sm.samperr;
     const bool fine_at_top = sm.fine != 0;
 
     // ---- pass 1: phase of the analog carrier per symbol, line fit over the block (acquire.c:170-235) -------------
-    am_fold(sm, win, samperr, sm.theta, sm.step270, sm.step256);
+    am_fold<NT>(sm, win, samperr, sm.theta, sm.step270, sm.step256);
     if (fine_at_top) {
         // only the carrier bin is needed: sum of the folded inputs (bin 0 before fftshift)
         __syncthreads();
@@ -745,7 +774,7 @@ __global__ __launch_bounds__(512) void k_am_block(DevTables tb, DevBuffers db, c
             if (part == 0) sm.carrier[n] = make_float2(sr, si);
         }
     } else {
-        am_fft_all(sm);
+        am_fft_all<NT>(sm);
         if (tid < NSYM) sm.carrier[tid] = am_bin(sm, 0, tid);
         if (tid <= 2 * 53) {                                   // |bins| summed over the block, carrier +-53
             float acc = 0.0f;
@@ -754,13 +783,23 @@ __global__ __launch_bounds__(512) void k_am_block(DevTables tb, DevBuffers db, c
         }
     }
     __syncthreads();
+    // The line fit (acquire.c:199-231).  The phase advance of every symbol -- a complex division and an arc tangent, 32 of them in a row on one
+    // work-item as the reference's loop is written -- is a function of two neighbouring carriers only: one work-item each; the running sums stay
+    // one sequential chain in the reference's order (same additions, same bits).
+    if (tid < NSYM) {
+        const float2 c = sm.carrier[tid];
+        float d;
+        if (tid == 0) d = atan2f(c.y, c.x);
+        else { const float2 q = cdivf(c, sm.carrier[tid - 1]); d = atan2f(q.y, q.x); }
+        sm.dphi[tid] = d;
+    }
+    __syncthreads();
     if (tid == 0) {
         float y = 0, sum_y = 0, sum_xy = 0, sum_x2 = 0;
         for (int i = 0; i < NSYM; i++) {
             const float x = AM_SYM * (i - (float)(NSYM - 1) / 2);
-            const float2 c = sm.carrier[i];
-            if (i == 0) y = atan2f(c.y, c.x);
-            else { const float2 q = cdivf(c, sm.carrier[i - 1]); y += atan2f(q.y, q.x); }
+            if (i == 0) y = sm.dphi[0];
+            else y += sm.dphi[i];
             sum_y += y; sum_xy += x * y; sum_x2 += x * x;
         }
         if (!fine_at_top) {
@@ -769,26 +808,33 @@ __global__ __launch_bounds__(512) void k_am_block(DevTables tb, DevBuffers db, c
             st.cfo += max_index - 53;                          // acquire_cfo_adjust: effective from the next block
         }
         const float slope = sum_xy / sum_x2;
-        // phase_increment *= cexpf(-slope I): float complex product of the two rounded unit vectors
-        const float rc = (float)cos((double)slope), rs = (float)sin(-(double)slope);
-        const float2 inc = sm.red_v[0];
-        const float2 inc2 = make_float2(inc.x * rc - inc.y * rs, inc.x * rs + inc.y * rc);
         const float a = -sum_y / NSYM + slope * NSYM * AM_SYM / 2;
         const float corr = (float)((double)a - 0.06);          // acquire.c:233-234
         double th = sm.theta + (double)corr;
         th -= 2 * M_PI * rint(th / (2 * M_PI));
-        sm.theta = th; sm.dtheta = atan2((double)inc2.y, (double)inc2.x);
-        sm.step270 = make_float2((float)cos(sm.dtheta * AM_SYM), (float)sin(sm.dtheta * AM_SYM));
-        sm.step256 = make_float2((float)cos(sm.dtheta * AM_FFT), (float)sin(sm.dtheta * AM_FFT));
+        sm.theta = th; sm.targ = (double)slope;
     }
+    __syncthreads();
+    // phase_increment *= cexpf(-slope I): float complex product of the two rounded unit vectors; cosine and sine on two waves
+    if (tid == 0) sm.red_v[1].x = (float)cos(sm.targ);
+    if (tid == 64) sm.red_v[1].y = (float)sin(-sm.targ);
+    __syncthreads();
+    if (tid == 0) {
+        const float rc = sm.red_v[1].x, rs = sm.red_v[1].y;
+        const float2 inc = sm.red_v[0];
+        const float2 inc2 = make_float2(inc.x * rc - inc.y * rs, inc.x * rs + inc.y * rc);
+        sm.dtheta = atan2((double)inc2.y, (double)inc2.x);
+    }
+    __syncthreads();
+    am_nco_steps(sm);
     __syncthreads();
 
     // ---- pass 2: the block's spectra (acquire.c:237-257) -> sync_process_am on the LDS tile --------------------
-    am_fold(sm, win, samperr, sm.theta, sm.step270, sm.step256);
-    am_fft_all(sm);
+    am_fold<NT>(sm, win, samperr, sm.theta, sm.step270, sm.step256);
+    am_fft_all<NT>(sm);
 
     // lower sideband: z = -conj(z); complementary sidebands of the hybrid waveform add coherently (sync.c:616-633)
-    for (int id = tid; id < NSYM * AM_IDX_MAX; id += (int)blockDim.x) {
+    for (int id = tid; id < NSYM * AM_IDX_MAX; id += NT) {
         const int n = id / AM_IDX_MAX, i = 1 + id % AM_IDX_MAX;
         float2 &lo = am_bin(sm, -i, n);
         lo = make_float2(-lo.x, lo.y);
@@ -802,9 +848,12 @@ __global__ __launch_bounds__(512) void k_am_block(DevTables tb, DevBuffers db, c
     __syncthreads();
     if (tid == 0) {
         const unsigned d = (unsigned)sm.refmask;
+        // the state words of this section in one burst, worked on as values, stored where they change (read through the state at every test they were
+        // a chain of dependent L2 round trips: every store in between forces the next read back to memory)
+        int sync_state = st.sync_state, cfo_wait = st.cfo_wait, psmi = st.psmi, bc_now = st.bc, rdbi = am.rdbi;
         // fixed part of the reference sequence (find_ref_am / find_block_am needles, sync.c:211-213,242-244)
         const unsigned care23 = 0x60427fu, val23 = 0x600226u;  // positions 0-6, 9, 14, 21, 22; ones at 1, 2, 5, 9, 21, 22
-        if (st.sync_state == SYNC_COARSE && st.cfo_wait == 0) {
+        if (sync_state == SYNC_COARSE && cfo_wait == 0) {
             int off = -1;
             for (int r = 0; r < NSYM && off < 0; r++) {
                 const unsigned rot = r ? ((d >> r) | (d << (32 - r))) : d;      // rot bit i = d[(r + i) % 32]
@@ -812,9 +861,9 @@ __global__ __launch_bounds__(512) void k_am_block(DevTables tb, DevBuffers db, c
             }
             if (off > 0) { st.keep_extra = ((NSYM - off) % NSYM) * AM_SYM; st.cfo_wait = 8; }
         } else {
-            st.cfo_wait--;
+            st.cfo_wait = cfo_wait - 1;
         }
-        if (st.sync_state == SYNC_COARSE) {
+        if (sync_state == SYNC_COARSE) {
             int bc = -1;
             auto bit = [&](int k) { return (d >> k) & 1u; };
             if ((d & care23) == val23
@@ -824,30 +873,33 @@ __global__ __launch_bounds__(512) void k_am_block(DevTables tb, DevBuffers db, c
                 && !(__popc(d & 0xff800000u) & 1)) {
                 bc = (int)((bit(17) << 2) | (bit(18) << 1) | bit(19));
                 if (bc == 0) {
-                    st.psmi = (int)((bit(26) << 4) | (bit(27) << 3) | (bit(28) << 2) | (bit(29) << 1) | bit(30));
-                    am.pli = bit(7); am.hppi = bit(11); am.aabi = bit(12); am.rdbi = bit(15);
+                    psmi = (int)((bit(26) << 4) | (bit(27) << 3) | (bit(28) << 2) | (bit(29) << 1) | bit(30));
+                    st.psmi = psmi;
+                    rdbi = (int)bit(15);
+                    am.pli = bit(7); am.hppi = bit(11); am.aabi = bit(12); am.rdbi = rdbi;
                 }
             }
-            if (bc == -1) am.offset_history = 0;
-            else am.offset_history = (am.offset_history << 4) | (unsigned)bc;
-            if ((am.offset_history & 0xffffu) == 0x5670u) {
-                st.bc = 0;
-                st.sync_state = SYNC_FINE; st.fine_epoch++;    // input_set_sync_state: EVENT_SYNC payload (input.c:179-185)
+            unsigned history = bc == -1 ? 0u : ((am.offset_history << 4) | (unsigned)bc);
+            if ((history & 0xffffu) == 0x5670u) {
+                bc_now = 0; st.bc = 0;
+                sync_state = SYNC_FINE; st.sync_state = SYNC_FINE; st.fine_epoch++;    // input_set_sync_state: EVENT_SYNC payload (input.c:179-185)
                 rec.flags |= REC_TO_FINE;
                 rec.freq_offset = (float)(((double)st.prev_angle - 2 * M_PI * st.cfo) * 46511.71875 / (2 * M_PI * AM_FFT));
-                rec.sis = (uint32_t)((am.pli & 1) | ((am.hppi & 1) << 1) | ((am.aabi & 1) << 2) | ((am.rdbi & 1) << 3) | 16);
+                rec.sis = (uint32_t)((am.pli & 1) | ((am.hppi & 1) << 1) | ((am.aabi & 1) << 2) | ((rdbi & 1) << 3) | 16);
                 am.am_errors = 0; am.am_diversity_wait = 4;    // decode_reset (decode.c:563-572)
-                am.offset_history = 0;
+                history = 0;
             }
+            am.offset_history = history;
         }
-        sm.fine = st.sync_state == SYNC_FINE;
-        sm.ma3 = st.psmi == AM_MA3;
+        sm.fine = sync_state == SYNC_FINE;
+        sm.ma3 = psmi == AM_MA3;
+        sm.bc_now = bc_now; sm.psmi_now = psmi; sm.rdbi_now = rdbi;
     }
     __syncthreads();
 
     if (sm.fine) {
         const bool ma3 = sm.ma3 != 0;
-        const int bc = st.bc;
+        const int bc = sm.bc_now;
         // PIDS carriers: normalise by the two training symbols (8 and 24), slice QAM16 (sync.c:661-678)
         if (tid < 2 * NSYM) {
             const int n = tid >> 1, which = tid & 1;
@@ -883,7 +935,7 @@ __global__ __launch_bounds__(512) void k_am_block(DevTables tb, DevBuffers db, c
         }
         // equalise and slice the four partitions: hard symbols of this block go to the frame matrices (decode.c:439-449)
         uint8_t *symbase = db.am_sym + (size_t)s * 4 * AM_SYMS;
-        for (int id = tid; id < 4 * NSYM * AM_PW; id += (int)blockDim.x) {
+        for (int id = tid; id < 4 * NSYM * AM_PW; id += NT) {
             const int part = id / (NSYM * AM_PW), r = id % (NSYM * AM_PW), n = r / AM_PW, col = r % AM_PW;
             const int pri = ma3 ? 2 : 57, ter = ma3 ? 28 : 2;
             int off;
@@ -907,7 +959,7 @@ __global__ __launch_bounds__(512) void k_am_block(DevTables tb, DevBuffers db, c
             const int i = n / 12, j = n % 12;
             const int il_pos[12] = { 0, 1, 12, 13, 6, 5, 18, 17, 11, 7, 23, 19 };      // decode.c:63-64
             const int iu_pos[12] = { 2, 4, 14, 16, 3, 8, 15, 20, 9, 10, 21, 22 };
-            const bool pids1_disabled = (st.psmi == 1) && am.rdbi;
+            const bool pids1_disabled = (sm.psmi_now == 1) && sm.rdbi_now;
             sm.pids_coded[i * 24 + il_pos[j]] = pids1_disabled ? 0 : (il ? 1 : -1);
             sm.pids_coded[i * 24 + iu_pos[j]] = iu ? 1 : -1;
         }
@@ -957,17 +1009,26 @@ __global__ __launch_bounds__(512) void k_am_block(DevTables tb, DevBuffers db, c
     }
 
     // ---- tail of acquire_process (acquire.c:259-262) + record -------------------------------------------------------
-    if (tid == 0) {
+    // Two work-items of different waves share it, as in k_sync: the NCO phase with its double-precision cosine / sine (a diagnostic of the record) on
+    // one, the FIFO position and the record on the other with its state loads issued together (a load behind every store of the other kind cost an
+    // L2 round trip apiece).
+    if (tid == 64) {
         double th = sm.theta + sm.dtheta * (double)(NSYM * AM_SYM);
         th -= 2 * M_PI * rint(th / (2 * M_PI));
         st.theta = th;
-        const int keep = AM_SYM + (AM_SYM / 2 - samperr) + st.keep_extra;
+        rec.phase_re = (float)cos(th); rec.phase_im = (float)sin(th);
+    }
+    if (tid == 0) {
+        const int keep_extra = st.keep_extra, state = st.sync_state, cfo = st.cfo, bc_now = st.bc, psmi = st.psmi, cfo_wait = st.cfo_wait, next_samperr = st.samperr, nblocks = st.nblocks;
+        const long long rd = st.rd;
+        const float prev_angle = st.prev_angle;
+        const int keep = AM_SYM + (AM_SYM / 2 - samperr) + keep_extra;
         st.keep_extra = 0;
-        st.rd += AM_WIN - keep;
-        rec.state_after = st.sync_state; rec.samperr = samperr; rec.cfo = st.cfo; rec.keep = keep; rec.bc = st.bc;
-        rec.psmi = st.psmi; rec.cfo_wait = st.cfo_wait; rec.next_samperr = st.samperr;
-        rec.prev_angle = st.prev_angle; rec.phase_re = (float)cos(th); rec.phase_im = (float)sin(th); rec.next_angle = 0.0f;
-        st.nblocks++;
+        st.rd = rd + (AM_WIN - keep);
+        rec.state_after = state; rec.samperr = samperr; rec.cfo = cfo; rec.keep = keep; rec.bc = bc_now;
+        rec.psmi = psmi; rec.cfo_wait = cfo_wait; rec.next_samperr = next_samperr;
+        rec.prev_angle = prev_angle; rec.next_angle = 0.0f;
+        st.nblocks = nblocks + 1;
     }
     if (db.am_ckpt) {                                          // block-uniform: window pipeline with the on-device L2 feedback
         // Replay checkpoint of a block that delivered a P1 PDU (k_replay.hip): the state as of now.  For block 7 the
@@ -1310,9 +1371,16 @@ void launch_am_decode(const DevTables &tb, const DevBuffers &db, int nstreams, c
 
 void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int l2_feedback, int pipeline_parity, int slot, int window)
 {
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_am_block, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AmBlockSmem)); attr_set = true; }
-    hipLaunchKernelGGL(k_am_block, dim3(nstreams), dim3(pipeline_parity >= 0 ? 512 : 256), sizeof(AmBlockSmem), st, tb, db, stream_ids, pipeline_parity >= 0 ? 1 : 0, pipeline_parity, slot);
+    // (per device: the attribute belongs to the function as loaded on the current device -- one process may drive several, include/nrsc5hip.h)
+    static bool attr_set[64] = {};
+    int dev = 0; (void)hipGetDevice(&dev);
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+        (void)hipFuncSetAttribute((const void *)k_am_block<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AmBlockSmem));
+        (void)hipFuncSetAttribute((const void *)k_am_block<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AmBlockSmem));
+        attr_set[dev] = true;
+    }
+    if (pipeline_parity >= 0) hipLaunchKernelGGL(k_am_block<512>, dim3(nstreams), dim3(512), sizeof(AmBlockSmem), st, tb, db, stream_ids, 1, pipeline_parity, slot);
+    else hipLaunchKernelGGL(k_am_block<256>, dim3(nstreams), dim3(256), sizeof(AmBlockSmem), st, tb, db, stream_ids, 0, pipeline_parity, slot);
     if (pipeline_parity < 0) {
         hipLaunchKernelGGL(k_am_viterbi, dim3(2, nstreams), dim3(64), 0, st, tb, db, stream_ids, l2_feedback);
         if (db.l2_am_ring) launch_l2_index_am_step(db, nstreams, stream_ids, st);
