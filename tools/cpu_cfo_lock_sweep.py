@@ -1,0 +1,60 @@
+"""CPU only: how often, and by how much, does a receiver whose float pipeline is NOT bit-identical to the reference's deviate from it at a lock after a CFO
+search (integer CFO != 0)?  Synthetic MP1 captures with |CFO| in (185, 300) Hz (integer CFO = +-1), random timing offsets, SNR 15 / 20 / 25 dB, 40 blocks each,
+through (a) the unmodified reference (oracle/_ref) and (b) the CPU-emulated twin of the library (tests/simt: the kernels' logic with glibc's libm and no fused
+multiply-adds -- a third float sequence beside the reference's and the GPU's); complete logs compared under the strict rule (tests/common.py: integers exact,
+floats 1e-4).  DESIGN.md (c) limit 2; result of the round-4 run: profiles/r04_cfo_lock_transients.txt.
+    python tools/cpu_cfo_lock_sweep.py [processes=8] [captures=900]"""
+import json, os, re, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def work(args):
+    seed, cfo, offset, snr = args
+    from nrsc5_amd import synth, build
+    from tests import common, engine_checks as ec
+    import bench
+    run, kind = bench._checker(0, True)
+    assert kind == "reference", "oracle/_ref is not built (python -c 'import __graft_entry__ as g; g.build()')"
+    cap = synth.fm_mp1_capture(0, seed=seed, cfo_hz=cfo, offset=offset, snr_db=snr, n_blocks=40)
+    ref_log = run(cap.iq)
+    E, recs, log = ec.run_capture(build.EMU_LIB, cap)
+    E.close()
+    exp, got = common.strip_states(ref_log), common.strip_states(log)
+    diffs = common.compare_logs(exp, got)
+    mer, dm, dsamp = [d for d in diffs if " mer." in d], 0.0, 0
+    for d in diffs:
+        m = re.search(r"(\w+)\.(\w+): expected (\S+) got (\S+)", d)
+        if not m:
+            continue
+        if m.group(1) == "mer":
+            dm = max(dm, abs(float(m.group(3)) - float(m.group(4))))
+        elif m.group(2) in ("samperr", "next_samperr", "keep"):
+            dsamp = max(dsamp, abs(int(float(m.group(3))) - int(float(m.group(4)))))
+    frames_equal = not any(d for d in diffs if " frame." in d or " pids." in d or " ber." in d)
+    sync_equal = not any(d for d in diffs if " sync." in d)
+    return seed, round(cfo, 1), len(diffs), len(mer), round(dm, 3), dsamp, frames_equal, sync_equal
+
+
+if __name__ == "__main__":
+    from multiprocessing import Pool
+    from nrsc5_amd import build
+    build.build_emu()
+    nproc = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 900
+    rng = np.random.default_rng(4242)
+    jobs = []
+    for i in range(n):
+        cfo = float(rng.uniform(185, 300)) * (1 if rng.integers(0, 2) else -1)
+        jobs.append((1000 + i, cfo, int(rng.integers(0, 4320)), (15.0, 20.0, 25.0)[i % 3]))
+    t = time.time()
+    with Pool(nproc) as p:
+        res = p.map(work, jobs, chunksize=4)
+    dev = [r for r in res if r[2]]
+    out = {"captures": len(res), "seconds": round(time.time() - t, 1), "with_any_difference": len(dev), "with_a_mer_difference": sum(1 for r in res if r[3]),
+           "mer_deviation_dB_sorted": sorted([r[4] for r in res if r[3]], reverse=True),
+           "timing_pick_deviation_samples_sorted": sorted([r[5] for r in dev], reverse=True),
+           "deviating_captures_with_frames_pids_ber_equal": sum(1 for r in dev if r[6]), "deviating_captures_with_sync_events_equal": sum(1 for r in dev if r[7]),
+           "worst (seed, cfo, diffs, mer diffs, max mer dB, max timing samples, frames equal, sync equal)": sorted(dev, key=lambda r: -r[4])[:8]}
+    print(json.dumps(out, indent=1))
