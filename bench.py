@@ -164,9 +164,10 @@ def cpu_baseline(stream_iq: np.ndarray, fs: float, mode: int, budget_s: float, n
 
 _DIFF_RE = re.compile(r"#(\d+) (\w+)\.(\w+): (?:(\d+) elements differ)?(?:expected (\S+) got (\S+))?")
 # Loop-internal state that is NOT an estimate north_star names: the tracking loop's residual error signal, the NCO phase (an
-# integrator) and the integer timing pick of a block (sub-sample timing is tracked by the phase slope).  A float FFT that is not
-# bit-identical to the reference's leaves ~1e-5 of a frame's energy as error in every bin; on a WEAK edge reference carrier that
-# is 3e-4 relative, and the CFO search (sync.c:292-337: three garbage-tracking Costas passes over that bin at phases of ~1000 rad)
+# integrator) and the integer timing pick of a block (sub-sample timing is tracked by the phase slope).  The symbol kernel evaluates the
+# NCO phase in closed form; the reference advances it by a float recurrence whose rounding drift (~3e-6 rad per symbol) is part of what it
+# hands to its FFT (measured in round 4 to be the trigger -- not the FFT: profiles/r04_cfo_lock_transients.txt).  On a WEAK edge reference
+# carrier that difference is a few 1e-4 relative, and the CFO search (sync.c:292-337: three garbage-tracking Costas passes over that bin at phases of ~1000 rad)
 # amplifies it chaotically: for a few blocks after a lock with integer CFO != 0 that one carrier's loop state differs, and about
 # once in 30 000 blocks a float lands within rounding distance of the threshold of roundf() (sync.c:455).  Frames, events, the CFO
 # estimates (freq_offset, prev_angle), MER and BER are unaffected and stay under the strict rule; these fields are COUNTED when they

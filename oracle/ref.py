@@ -27,8 +27,9 @@ def available(sse: bool = False) -> bool:
 
 
 class RefLib:
-    def __init__(self, sse: bool = False):
-        self.lib = ctypes.CDLL(lib_path(sse))
+    def __init__(self, sse: bool = False, path: str | None = None):
+        # path: another build of the unmodified reference (oracle/_ref/libnrsc5_ref_sse_dp.so: the same translation units on a different FFT)
+        self.lib = ctypes.CDLL(path or lib_path(sse))
         L = self.lib
         L.refh_open.argtypes = [ctypes.c_int, ctypes.c_uint, ctypes.c_uint]
         L.refh_run_cu8.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint]

@@ -3,11 +3,18 @@ search (integer CFO != 0)?  Synthetic MP1 captures with |CFO| in (185, 300) Hz (
 through (a) the unmodified reference (oracle/_ref) and (b) the CPU-emulated twin of the library (tests/simt: the kernels' logic with glibc's libm and no fused
 multiply-adds -- a third float sequence beside the reference's and the GPU's); complete logs compared under the strict rule (tests/common.py: integers exact,
 floats 1e-4).  DESIGN.md (c) limit 2; result of the round-4 run: profiles/r04_cfo_lock_transients.txt.
-    python tools/cpu_cfo_lock_sweep.py [processes=8] [captures=900]"""
+    python tools/cpu_cfo_lock_sweep.py [--self | --nco] [processes=8] [captures=900]
+--self: both sides are the unmodified reference, (b) linked with another FFT (oracle/_ref/libnrsc5_ref_sse_dp.so; `make -C oracle _ref/libnrsc5_ref_sse_dp.so`).
+--nco:  (b) is the reference with an ideal (double-precision) oscillator inside each symbol instead of its float recurrence (tools/build_ref_ideal_nco.py)."""
 import json, os, re, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# --self: the reference (Stockham radix-4 float FFT) against the reference on a double-precision FFT; --nco: ... against the reference with an ideal oscillator inside each
+# symbol (tools/build_ref_ideal_nco.py) -- instead of the reference against the library
+SELF = next((a for a in ("--self", "--nco") if a in sys.argv), "")
+if SELF:
+    sys.argv.remove(SELF)
 
 
 def work(args):
@@ -19,8 +26,14 @@ def work(args):
     assert kind == "reference", "oracle/_ref is not built (python -c 'import __graft_entry__ as g; g.build()')"
     cap = synth.fm_mp1_capture(0, seed=seed, cfo_hz=cfo, offset=offset, snr_db=snr, n_blocks=40)
     ref_log = run(cap.iq)
-    E, recs, log = ec.run_capture(build.EMU_LIB, cap)
-    E.close()
+    if SELF:
+        # the unmodified reference against ITSELF on a different FFT (oracle/cpu_fft_dp.c: double precision, rounded once)
+        from oracle import ref
+        R2 = ref.RefLib(path=os.path.join(ROOT, "oracle", "_ref", "libnrsc5_ref_sse_dp.so" if SELF == "--self" else "libnrsc5_ref_sse_nco.so"))
+        log = R2.run(cap.iq, mode=0)[0]
+    else:
+        E, recs, log = ec.run_capture(build.EMU_LIB, cap)
+        E.close()
     exp, got = common.strip_states(ref_log), common.strip_states(log)
     diffs = common.compare_logs(exp, got)
     mer, dm, dsamp = [d for d in diffs if " mer." in d], 0.0, 0
