@@ -1,0 +1,27 @@
+"""The checker's FFT is a stand-in (fftw3f is not in the image: oracle/cpu_fft.c).  Does its choice matter?  The UNMODIFIED reference linked with a SECOND, different
+FFT (oracle/cpu_fft_dp.c: double precision, rounded once -- bins 2e-7 apart from the Stockham float transform's) must produce the same logs under the strict rule, also
+through the CFO search, whose garbage-tracking Costas passes amplify whatever differs in the last bits (DESIGN.md (c) limit 2: 0 of 900 such captures differ,
+profiles/r04_cfo_lock_transients.txt; here a handful, every run).  This is what pins "parity unpinned at the FFT boundary"  as harmless for the checker."""
+import os
+
+import numpy as np
+import pytest
+
+from nrsc5_amd import synth
+from oracle import ref
+from tests import common
+
+DP = os.path.join(os.path.dirname(ref.__file__), "_ref", "libnrsc5_ref_sse_dp.so")
+pytestmark = pytest.mark.skipif(not (ref.available(sse=True) and os.path.exists(DP)), reason="oracle/_ref not built (needs /root/reference)")
+
+
+@pytest.mark.parametrize("seed,cfo,offset,snr", [(1370, 186.07, 2211, 20.0), (1493, 294.73, 977, 15.0), (7, -245.8, 3000, 25.0), (11, 40.0, 123, 20.0)])
+def test_reference_agrees_with_itself_on_another_fft(seed, cfo, offset, snr):
+    cap = synth.fm_mp1_capture(0, seed=seed, cfo_hz=cfo, offset=offset, snr_db=snr, n_blocks=40)
+    a = ref.RefLib(sse=True).run(cap.iq, taps=ref.TAP_FFT, fft_blocks=2)
+    b = ref.RefLib(path=DP).run(cap.iq, taps=ref.TAP_FFT, fft_blocks=2)
+    fa, fb = a[2], b[2]
+    assert fa.shape == fb.shape and fa.size and not np.array_equal(fa, fb)             # two different transforms ...
+    assert np.abs(fa - fb).max() <= 2e-6 * np.abs(fa).max()                             # ... a few ulp apart
+    diffs = common.compare_logs(common.strip_states(a[0]), common.strip_states(b[0]))
+    assert not diffs, diffs[:5]                                                          # ... and the same receiver
