@@ -15,7 +15,7 @@ DP = os.path.join(os.path.dirname(ref.__file__), "_ref", "libnrsc5_ref_sse_dp.so
 pytestmark = pytest.mark.skipif(not (ref.available(sse=True) and os.path.exists(DP)), reason="oracle/_ref not built (needs /root/reference)")
 
 
-@pytest.mark.parametrize("seed,cfo,offset,snr", [(1370, 186.07, 2211, 20.0), (1493, 294.73, 977, 15.0), (7, -245.8, 3000, 25.0), (11, 40.0, 123, 20.0)])
+@pytest.mark.parametrize("seed,cfo,offset,snr", [(1370, 186.07498555527155, 1634, 20.0), (1493, 294.72944310475714, 4311, 20.0), (7, -245.8, 3000, 25.0), (11, 40.0, 123, 20.0)])
 def test_reference_agrees_with_itself_on_another_fft(seed, cfo, offset, snr):
     cap = synth.fm_mp1_capture(0, seed=seed, cfo_hz=cfo, offset=offset, snr_db=snr, n_blocks=40)
     a = ref.RefLib(sse=True).run(cap.iq, taps=ref.TAP_FFT, fft_blocks=2)
