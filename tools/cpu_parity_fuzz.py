@@ -119,6 +119,48 @@ def work_batch(args):
     return out
 
 
+def work_batch_am(args):
+    """--am --batch: four AM cs16 captures per engine through the window pipeline (the nine trellis passes of an L1 frame on a decode stream) with the L2 -> L1 feedback and
+    replay on the device; a third of them with an interference burst that breaks a P1 PDU's first header."""
+    i, seed0 = args
+    from nrsc5_amd import synth_am, build, engine as eng
+    from tests import engine_checks as ec
+    import bench
+    run, kind = bench._checker(1, True)
+    assert kind == "reference"
+    caps, kws = [], []
+    for k in range(4):
+        kw = params_am(4 * i + k, seed0)
+        rng = np.random.default_rng(seed0 + 11 * (4 * i + k) + 5)
+        if rng.integers(0, 3) == 0:
+            kw["burst"] = (float(rng.uniform(5.5, 9.5)), float(rng.uniform(0.3, 0.6)), 40.0)      # (first L1 frame, frames, sigma): tests/engine_checks.py
+            kw["n_frames"] = max(kw["n_frames"], 13)
+        caps.append(synth_am.am_ma1_capture(**kw)); kws.append(kw)
+    n = len(caps)
+    stride = max(c.iq.size for c in caps); stride += (-stride) % 64
+    E = eng.Engine(max_streams=n, q15_capacity=stride // 2 + 1024, record_capacity=1024, p1_slots=48, lib_path=build.EMU_LIB, am_enable=True, p1_async=True, l2_feedback=True)
+    for k in range(n):
+        E.set_mode(k, eng.MODE_AM)
+    buf = np.zeros((n, stride), dtype=np.int16)
+    for k, c in enumerate(caps):
+        buf[k, :c.iq.size] = c.iq
+    dev = ec._to_device(E, buf)
+    E.batch_append_cs16(dev, stride, [c.iq.size - c.iq.size % 4 for c in caps])
+    E.batch_process(n)
+    recs, counts, frames = E.batch_fetch_view(n)
+    out = []
+    for k in range(n):
+        ref_log = run(caps[k].iq)
+        log = eng.am_records_to_log(E, k, recs[k, :counts[k]], frames[k])
+        fatal, nex, max_bits, ntr = bench.compare_with_reference(ref_log, log, True)
+        lost = sum(1 for kk, _ in ref_log if kk == "lost_sync")
+        out.append((4 * i + k, {kk: (v if kk != "chan" else repr(v)) for kk, v in kws[k].items()}, fatal[:4], nex, max_bits, ntr, sum(1 for kk, _ in ref_log if kk == "frame"), lost,
+                    classify(ref_log, fatal) if fatal else None))
+    ec._free_device(E, dev)
+    E.close()
+    return out
+
+
 def work(args):
     i, seed0 = args
     from nrsc5_amd import synth, build, engine as eng
@@ -156,7 +198,9 @@ if __name__ == "__main__":
     seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 50000
     t = time.time()
     with Pool(nproc) as p:
-        if BATCH:
+        if BATCH and AM:
+            res = [r for rs in p.map(work_batch_am, [(i, seed0) for i in range(n // 4)], chunksize=1) for r in rs]
+        elif BATCH:
             res = [r for rs in p.map(work_batch, [(i, seed0) for i in range(n // 6)], chunksize=1) for r in rs]
         else:
             res = p.map(work, [(i, seed0) for i in range(n)], chunksize=2)
