@@ -3,7 +3,7 @@ search (integer CFO != 0)?  Synthetic MP1 captures with |CFO| in (185, 300) Hz (
 through (a) the unmodified reference (oracle/_ref) and (b) the CPU-emulated twin of the library (tests/simt: the kernels' logic with glibc's libm and no fused
 multiply-adds -- a third float sequence beside the reference's and the GPU's); complete logs compared under the strict rule (tests/common.py: integers exact,
 floats 1e-4).  DESIGN.md (c) limit 2; result of the round-4 run: profiles/r04_cfo_lock_transients.txt.
-    python tools/cpu_cfo_lock_sweep.py [--self | --nco] [processes=8] [captures=900]
+    python tools/cpu_cfo_lock_sweep.py [--self | --nco | --emu-lib PATH] [processes=8] [captures=900]
 --self: both sides are the unmodified reference, (b) linked with another FFT (oracle/_ref/libnrsc5_ref_sse_dp.so; `make -C oracle _ref/libnrsc5_ref_sse_dp.so`).
 --nco:  (b) is the reference with an ideal (double-precision) oscillator inside each symbol instead of its float recurrence (tools/build_ref_ideal_nco.py)."""
 import json, os, re, sys, time
@@ -15,6 +15,9 @@ sys.path.insert(0, ROOT)
 SELF = next((a for a in ("--self", "--nco") if a in sys.argv), "")
 if SELF:
     sys.argv.remove(SELF)
+EMU_OVERRIDE = None                         # --emu-lib PATH: another emulated twin (tools/build_emu_nco_growth.py) instead of tests/simt/libnrsc5hip_emu.so
+if "--emu-lib" in sys.argv:
+    k = sys.argv.index("--emu-lib"); EMU_OVERRIDE = sys.argv[k + 1]; del sys.argv[k:k + 2]
 
 
 def work(args):
@@ -32,7 +35,7 @@ def work(args):
         R2 = ref.RefLib(path=os.path.join(ROOT, "oracle", "_ref", "libnrsc5_ref_sse_dp.so" if SELF == "--self" else "libnrsc5_ref_sse_nco.so"))
         log = R2.run(cap.iq, mode=0)[0]
     else:
-        E, recs, log = ec.run_capture(build.EMU_LIB, cap)
+        E, recs, log = ec.run_capture(EMU_OVERRIDE or build.EMU_LIB, cap)
         E.close()
     exp, got = common.strip_states(ref_log), common.strip_states(log)
     diffs = common.compare_logs(exp, got)

@@ -9,6 +9,9 @@ sys.path.insert(0, ROOT)
 AM = "--am" in sys.argv                     # hybrid AM (MA1 / MA3, cs16) instead of FM
 if AM:
     sys.argv.remove("--am")
+EMU_OVERRIDE = None                         # --emu-lib PATH: another emulated twin (tools/build_emu_nco_growth.py) instead of tests/simt/libnrsc5hip_emu.so
+if "--emu-lib" in sys.argv:
+    _k = sys.argv.index("--emu-lib"); EMU_OVERRIDE = sys.argv[_k + 1]; del sys.argv[_k:_k + 2]
 BATCH = "--batch" in sys.argv               # FM through the zero-copy batch with the window pipeline and replay, six captures per engine
 if BATCH:
     sys.argv.remove("--batch")
@@ -101,7 +104,7 @@ def work_batch(args):
     host = np.zeros((n, stride), dtype=np.uint8)
     for k, c in enumerate(caps):
         host[k, :c.iq.size] = c.iq
-    E = eng.Engine(max_streams=n, q15_capacity=2 * 71280, record_capacity=512, p1_slots=8, p1_async=True, l2_feedback=True, batch_zero_copy=True, lib_path=build.EMU_LIB)
+    E = eng.Engine(max_streams=n, q15_capacity=2 * 71280, record_capacity=512, p1_slots=8, p1_async=True, l2_feedback=True, batch_zero_copy=True, lib_path=(EMU_OVERRIDE or build.EMU_LIB))
     dev = ec._to_device(E, host)
     E.batch_append_cu8(dev, stride, [c.iq.size - c.iq.size % 4 for c in caps])
     E.batch_process(n)
@@ -138,7 +141,7 @@ def work_batch_am(args):
         caps.append(synth_am.am_ma1_capture(**kw)); kws.append(kw)
     n = len(caps)
     stride = max(c.iq.size for c in caps); stride += (-stride) % 64
-    E = eng.Engine(max_streams=n, q15_capacity=stride // 2 + 1024, record_capacity=1024, p1_slots=48, lib_path=build.EMU_LIB, am_enable=True, p1_async=True, l2_feedback=True)
+    E = eng.Engine(max_streams=n, q15_capacity=stride // 2 + 1024, record_capacity=1024, p1_slots=48, lib_path=(EMU_OVERRIDE or build.EMU_LIB), am_enable=True, p1_async=True, l2_feedback=True)
     for k in range(n):
         E.set_mode(k, eng.MODE_AM)
     buf = np.zeros((n, stride), dtype=np.int16)
@@ -173,7 +176,7 @@ def work(args):
         kw = params_am(i, seed0)
         cap = synth_am.am_ma1_capture(**kw)
         ref_log = run(cap.iq)
-        E = eng.Engine(max_streams=1, q15_capacity=400000, record_capacity=512, p1_slots=16, lib_path=build.EMU_LIB, am_enable=True, l2_feedback=True)
+        E = eng.Engine(max_streams=1, q15_capacity=400000, record_capacity=512, p1_slots=16, lib_path=(EMU_OVERRIDE or build.EMU_LIB), am_enable=True, l2_feedback=True)
         E.set_mode(0, eng.MODE_AM)
         common.run_engine_streaming(E, 0, cap.iq, chunk=32768)
         log = eng.am_records_to_log(E, 0, E.drain(0))
@@ -182,7 +185,7 @@ def work(args):
         kw = params(i, seed0)
         cap = synth.fm_mp1_capture(0, **kw)
         ref_log = run(cap.iq)
-        E, recs, log = ec.run_capture(build.EMU_LIB, cap, l2_feedback=True)
+        E, recs, log = ec.run_capture((EMU_OVERRIDE or build.EMU_LIB), cap, l2_feedback=True)
         E.close()
     fatal, nex, max_bits, ntr = bench.compare_with_reference(ref_log, log, AM)
     nframes = sum(1 for k, _ in ref_log if k in ("frame", "p3"))
