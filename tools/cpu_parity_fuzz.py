@@ -216,6 +216,7 @@ if __name__ == "__main__":
         for k, v in (r[8] or {}).items():
             tot[k] = tot.get(k, 0) + v
     out["what_the_fatal_differences_are"] = tot
+    out["fatal_captures_classified"] = [(r[0], {k: v for k, v in (r[8] or {}).items() if v}) for r in bad]
     if BATCH:
         out["captures_with_lost_sync_in_the_reference"] = sum(1 for r in res if r[7]); out["lost_sync_events"] = sum(r[7] for r in res)
     print(json.dumps(out, indent=1, default=str))
