@@ -8,9 +8,14 @@
 // every ds_read/ds_write of a pass is bank-conflict-free).
 //
 // The reference advances the NCO with a sequential complex recurrence (69120 dependent steps per
-// block, acquire.c:250).  Here the phase of sample j is evaluated in closed form,
-// theta_sym + j * dtheta, in double precision: lanes are independent and the result is within
-// ~1e-5 rad of the recurrence (whose own rounding drift is of that order).
+// block, acquire.c:250), renormalised at the end of every symbol (acquire.c:252).  Here the phase of
+// sample j is evaluated in closed form, theta_sym + j * dtheta, in double precision: lanes are
+// independent and the result is within ~1e-5 rad of the recurrence (whose own rounding drift is of
+// that order).  What the recurrence does deterministically is reproduced: dtheta is the angle of the
+// ROUNDED increment (cosf, sinf) the reference multiplies by, and the phasor carries that increment's
+// length -- |inc| = 1 + g, |g| <= 6e-8, so the reference's amplitude runs as (1 + g)^j ~ 1 + j g
+// across a symbol, up to 1.3e-4 at sample 2159 (nco_ramp below; DESIGN.md (c) limit 2: without the
+// ramp 2 % of the locks after a CFO search deviated in loop-internal state, with it 0.5 %).
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 #include "wave_ops.h"
@@ -248,7 +253,7 @@ __device__ inline void fft2048_wg(cf *x, cf *lds, const float2 *twA, const cf *t
 // Even raw samples E[k] (dword a0 + 17 t - 7 + k, low half) pair up as (E[i + j], E[i + 7 - j]) for output i: one index of
 // every pair is even and one odd, so the -127 offsets of both (x' = byte - 127) are applied as -254 to the even-indexed E
 // only; the centre sample's -127 * 64 goes into the accumulator's start value.  The tile receives the Q15 INTEGERS
-// (imaginary part negated: the FM receiver's spectrum flip); sample() below divides by 32767 on the way out.
+// (imaginary part negated: the FM receiver's spectrum flip); the Q15 -> float scale 1 / 32767 rides on the NCO phasor they are mixed with.
 // the 24 consecutive dwords of the capture work-item t needs for the symbol whose first decimated sample is a0: six dwordx4
 // loads, issued and NOT waited for here -- the caller overlaps them with the previous symbol's FFT
 __device__ __forceinline__ void raw_symbol_load(const uint8_t *raw, long long a0, uint32_t (&W)[24], int tid)
@@ -355,7 +360,12 @@ template <typename T> __device__ __forceinline__ T uniform64(T v)
 
 // what a workgroup needs of the block's bookkeeping: from the stream state (k_prepare or the previous k_sync wrote it) or, in the fast
 // streaming seam, computed here from the state the sync kernel will commit it to (prepare_values, prepare_block.h)
-struct SymParams { long long a00; double dtheta, theta; int active; };
+struct SymParams { long long a00; double dtheta, theta; int active; double growth; };
+
+// The amplitude of the reference's oscillator at sample j of a symbol, (1 + g)^j, to first order (j g <= 1.3e-4, the second-order term 8e-9 is below
+// float resolution): the work-item's start phasor (sample tid) times 1 + tid g, its STEP-sample step times 1 + STEP g.  Two double-precision
+// fmas and two packed multiplies per work-item and symbol.
+__device__ __forceinline__ float nco_ramp(double g, int n) { return (float)(1.0 + (double)n * g); }
 
 // diagnostic build only (-DNRSC5HIP_MIXFFT_PHASES, tools/gpu_mixfft_phases.py): shader cycles of wave 0 of stream 0's workgroups between the
 // marks, accumulated in db.sync_phase_cycles[8..15]; the release kernel carries none of this
@@ -411,7 +421,8 @@ __device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuf
             cs = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cs)));
         }
 #endif
-        stp = cf_make(cs, sn);
+        const float g1 = nco_ramp(sp.growth, 128);             // wave-uniform: the step carries the ramp of 128 samples
+        stp = cf_make(cs * g1, sn * g1);
     }
 #pragma unroll 1
     for (int i = 0; i < SPW; i++) {
@@ -431,7 +442,10 @@ __device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuf
         // (reduced to [-pi, pi] in double above.)  The phasor carries the Q15 -> float scale 1 / 32767 (cq15_to_cf, defines.h:106-111) through
         // its recurrence: the samples enter the mix as the integers they are -- three packed instructions per sample less than dividing each one
         // as the reference does, and within an ulp of it
-        ph = emul(unit_phasor((float)a0p), cf_make(1.0f / 32767.0f, 1.0f / 32767.0f));
+        {
+            const float g0 = nco_ramp(sp.growth, tid) * (1.0f / 32767.0f);   // (the symbol starts renormalised: amplitude 1 at sample 0)
+            ph = emul(unit_phasor((float)a0p), cf_make(g0, g0));
+        }
         MIX_MARK(1, 1);                                            // set-up + the capture loads' latency
         if (RAW) {
             raw_symbol_halfband(W, lds, taps, tid);
@@ -521,14 +535,14 @@ __global__ __launch_bounds__(128 * NPAR) MIXFFT_OCCUPANCY void k_mixfft(DevTable
         __shared__ SymParams sh_sp;
         if (threadIdx.x == 0) {
             const Prepared p = prepare_values(st, false);
-            sh_sp.active = p.active; sh_sp.a00 = (st.rd - st.base) + p.samperr; sh_sp.dtheta = p.dtheta; sh_sp.theta = p.theta;
+            sh_sp.active = p.active; sh_sp.a00 = (st.rd - st.base) + p.samperr; sh_sp.dtheta = p.dtheta; sh_sp.theta = p.theta; sh_sp.growth = p.growth;
         }
         __syncthreads();
         sp = sh_sp;
     } else {
-        sp.active = st.active; sp.a00 = (st.rd - st.base) + st.samperr_cur; sp.dtheta = st.dtheta; sp.theta = st.theta;
+        sp.active = st.active; sp.a00 = (st.rd - st.base) + st.samperr_cur; sp.dtheta = st.dtheta; sp.theta = st.theta; sp.growth = st.growth;
     }
-    sp.active = wave_uniform(sp.active); sp.a00 = uniform64(sp.a00); sp.dtheta = uniform64(sp.dtheta); sp.theta = uniform64(sp.theta);   // scalar registers
+    sp.active = wave_uniform(sp.active); sp.a00 = uniform64(sp.a00); sp.dtheta = uniform64(sp.dtheta); sp.theta = uniform64(sp.theta); sp.growth = uniform64(sp.growth);   // scalar registers
     if (!sp.active) return;                                    // block-uniform
 #ifdef NRSC5HIP_MIXFFT_PHASES
     if (db.sync_phase_cycles && s == 0 && threadIdx.x == 0) atomicAdd((unsigned long long *)&db.sync_phase_cycles[8], (unsigned long long)((long long)clock64() - mix_entry));
@@ -732,8 +746,11 @@ __device__ __forceinline__ void mixfft_symbol8(const DevTables &tb, const DevBuf
         __syncthreads();
     }
     cf stp, ph;
-    stp = unit_phasor(a1f);
-    ph = emul(unit_phasor(a0f), cf_make(1.0f / 32767.0f, 1.0f / 32767.0f));   // carries the Q15 scale
+    {
+        const float g1 = nco_ramp(sp.growth, 256), g0 = nco_ramp(sp.growth, tid) * (1.0f / 32767.0f);
+        stp = emul(unit_phasor(a1f), cf_make(g1, g1));
+        ph = emul(unit_phasor(a0f), cf_make(g0, g0));          // carries the Q15 scale and the oscillator's amplitude at sample tid
+    }
     const c16 *win = db.q15 + (size_t)s * db.q15_cap + a0;
     auto sample = [&](int j) -> cf {
         if (RAW) return lds[j];
@@ -788,14 +805,14 @@ __global__ __launch_bounds__(256) MIXFFT8_OCCUPANCY void k_mixfft8(DevTables tb,
         __shared__ SymParams sh_sp;
         if (threadIdx.x == 0) {
             const Prepared p = prepare_values(st, false);
-            sh_sp.active = p.active; sh_sp.a00 = (st.rd - st.base) + p.samperr; sh_sp.dtheta = p.dtheta; sh_sp.theta = p.theta;
+            sh_sp.active = p.active; sh_sp.a00 = (st.rd - st.base) + p.samperr; sh_sp.dtheta = p.dtheta; sh_sp.theta = p.theta; sh_sp.growth = p.growth;
         }
         __syncthreads();
         sp = sh_sp;
     } else {
-        sp.active = st.active; sp.a00 = (st.rd - st.base) + st.samperr_cur; sp.dtheta = st.dtheta; sp.theta = st.theta;
+        sp.active = st.active; sp.a00 = (st.rd - st.base) + st.samperr_cur; sp.dtheta = st.dtheta; sp.theta = st.theta; sp.growth = st.growth;
     }
-    sp.active = wave_uniform(sp.active); sp.a00 = uniform64(sp.a00); sp.dtheta = uniform64(sp.dtheta); sp.theta = uniform64(sp.theta);
+    sp.active = wave_uniform(sp.active); sp.a00 = uniform64(sp.a00); sp.dtheta = uniform64(sp.dtheta); sp.theta = uniform64(sp.theta); sp.growth = uniform64(sp.growth);
     if (!sp.active) return;
     __shared__ cf lds[8 * P8_ROW];
     static_assert(8 * P8_ROW >= 9 * 256 && 9 * 240 == SYM_N, "nine decimated samples per work-item fit in the FFT tile");

@@ -133,6 +133,7 @@ struct StreamState {
     int active;                 // this step processes a block for this stream
     int samperr_cur; int pad0;
     double dtheta;              // effective NCO step (rad/sample) for the current block
+    double growth;              // |phase_increment| - 1 of the current block: the per-sample amplitude drift of the reference's oscillator (prepare_block.h)
     int coarse_samperr; float coarse_re, coarse_im;
     // P1 hand-off, one slot per in-flight decode window (see engine.hip: P1 pipeline); `parity` = window % NWIN
     int p1_pending[NWIN];          // 1: frame completed this step (gather it), 2: gathered into coded[s][parity]

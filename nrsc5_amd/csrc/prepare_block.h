@@ -52,13 +52,13 @@ struct PrepView {
     long long wr, rd;
     int sync_state, samperr, cfo, coarse_samperr;
     float angle, prev_angle, coarse_re, coarse_im;
-    double theta, dtheta;
+    double theta, dtheta, growth;
 };
 __device__ __forceinline__ PrepView prep_view(const StreamState &st)
 {
     PrepView v;
     v.wr = st.wr; v.rd = st.rd; v.sync_state = st.sync_state; v.samperr = st.samperr; v.cfo = st.cfo; v.coarse_samperr = st.coarse_samperr;
-    v.angle = st.angle; v.prev_angle = st.prev_angle; v.coarse_re = st.coarse_re; v.coarse_im = st.coarse_im; v.theta = st.theta; v.dtheta = st.dtheta;
+    v.angle = st.angle; v.prev_angle = st.prev_angle; v.coarse_re = st.coarse_re; v.coarse_im = st.coarse_im; v.theta = st.theta; v.dtheta = st.dtheta; v.growth = st.growth;
     return v;
 }
 
@@ -71,6 +71,7 @@ struct Prepared {
     float prev_angle;           // carrier angle after this block's update
     int to_coarse;              // the block moves the stream from NONE to COARSE
     double dtheta, theta;       // NCO step and start phase of the block
+    double growth;              // |phase_increment| - 1: the reference's oscillator grows / shrinks by this much per sample until it is renormalised at the symbol's end (acquire.c:250-252)
 };
 
 // acq_ran: the acquisition kernels ran in this step, i.e. coarse_samperr / coarse_re / coarse_im belong to the window at
@@ -82,7 +83,7 @@ template <typename S> __device__ inline Prepared prepare_values_of(const S &st, 
     const bool ready = window_ready(st);
     p.active = (ready && (st.sync_state == SYNC_FINE || acq_ran)) ? 1 : 0;
     p.pending = ready ? 1 : 0;
-    p.samperr = 0; p.prev_angle = st.prev_angle; p.to_coarse = 0; p.dtheta = st.dtheta; p.theta = st.theta;
+    p.samperr = 0; p.prev_angle = st.prev_angle; p.to_coarse = 0; p.dtheta = st.dtheta; p.theta = st.theta; p.growth = st.growth;
     if (!p.active) return p;
     float angle;
     if (st.sync_state == SYNC_FINE) {
@@ -114,6 +115,10 @@ template <typename S> __device__ inline Prepared prepare_values_of(const S &st, 
         inc_c = (float)cos((double)dtheta); inc_s = (float)sin((double)dtheta);
         p.dtheta = atan2((double)inc_s, (double)inc_c);
     }
+    // ... and its LENGTH, 1 + g with |g| up to 6e-8, is the oscillator's amplitude: phase *= phase_increment 2160 times between two
+    // renormalisations (acquire.c:250-252) makes the amplitude run as (1 + g)^j across the symbol, up to 1.3e-4 at its last sample -- deterministic,
+    // and 100 x the rounding noise of the recurrence.  The symbol kernel gives its closed-form phasor the same ramp (k_mixfft: nco_ramp).
+    p.growth = sqrt((double)inc_c * (double)inc_c + (double)inc_s * (double)inc_s) - 1.0;
     // phase *= e^{-i (1080 - samperr) angle / 2048}            (acquire.c:166)
     double th = st.theta + (double)(-(float)(SYM_N / 2 - p.samperr) * angle / FFT_N);
     th -= 2 * M_PI * rint(th / (2 * M_PI));
@@ -149,6 +154,7 @@ __device__ inline void prepare_block(const DevBuffers &db, StreamState &st, int 
     rec = r;
     st.samperr_cur = p.samperr;
     st.dtheta = p.dtheta;
+    st.growth = p.growth;
     st.theta = p.theta;
 }
 

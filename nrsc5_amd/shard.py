@@ -94,6 +94,16 @@ def gather_floats(value: float, device) -> list:
     return [float(o.item()) for o in out]
 
 
+def gather_vectors(values, device) -> np.ndarray:
+    """one fixed-length float64 vector per rank -> [world, len(values)] in rank order (per-rank parity verdicts)"""
+    t = torch.tensor(list(values), dtype=torch.float64, device=device)
+    if not dist.is_initialized():
+        return t.cpu().numpy()[None, :]
+    out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return np.stack([o.cpu().numpy() for o in out])
+
+
 def sum_over_ranks(values, device) -> np.ndarray:
     t = torch.tensor(list(values), dtype=torch.float64, device=device)
     if dist.is_initialized():

@@ -12,6 +12,32 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """The CPU suite (`-m "not gpu"`) is ~20 minutes of single-threaded work -- the SIMT emulator runs every kernel's logic on the
+    host -- and embarrassingly parallel: spread it over the cores with pytest-xdist unless the caller chose a worker count.  The GPU
+    suite (`-m gpu`) is left alone: its tests share one device.  (Round 4 did this with an early `-p tests.xdist_auto` plugin in
+    pytest.ini, which made a bare `pytest` fail to start: the package was not importable that early.  A conftest hook needs nothing.)"""
+    if hasattr(config, "workerinput") or os.environ.get("PYTEST_XDIST_WORKER"):
+        return
+    try:
+        import xdist  # noqa: F401
+    except Exception:
+        return
+    opt = config.option
+    if not hasattr(opt, "numprocesses") or opt.numprocesses is not None or getattr(opt, "dist", "no") != "no":
+        return
+    if (getattr(opt, "markexpr", "") or "").replace(" ", "") != "notgpu":
+        return
+    if getattr(opt, "usepdb", False) or getattr(opt, "collectonly", False):
+        return
+    n = min(8, os.cpu_count() or 1)
+    if n > 1:
+        opt.numprocesses = n
+        opt.dist = "load"
+        opt.tx = ["popen"] * n
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """CPU restatement (oracle/liboracle.so), compiled on demand with gcc."""
