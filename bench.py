@@ -62,6 +62,7 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=10, help="timed passes (SURVEY 8d: median of >= 10 next to the mean)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: 256; am-cu8: 128)")
+    ap.add_argument("--stream-base", type=int, default=0, help="first global stream id (a stream's CFO / offset / noise / channel are seeded by its id: another base = another batch)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="--gpus N: weak = --streams per GPU; strong = --total-streams split over the ranks (configs[3]: 2048)")
     ap.add_argument("--total-streams", type=int, default=2048, help="--scaling strong: streams of the whole job")
     ap.add_argument("--seconds", type=float, default=20.0, help="FM capture length per stream (SURVEY 8d: 20 s)")
@@ -246,7 +247,18 @@ class ParityPool:
         out, pending = {}, 0
         def take():
             nonlocal pending
-            r = self.results.get(timeout=900)
+            import queue
+            waited = 0.0
+            while True:
+                try:
+                    r = self.results.get(timeout=5.0)
+                    break
+                except queue.Empty:
+                    waited += 5.0
+                    if not any(p.is_alive() for p in self.procs):
+                        raise RuntimeError("parity checker: every worker process has exited with results outstanding")
+                    if waited > 900:
+                        raise RuntimeError("parity checker: no result for 900 s")
             out[r[0]] = r
             pending -= 1
         for key, iq, am, got_log in jobs:
@@ -435,10 +447,11 @@ def launch_check(args):
 def my_stream_ids(args, world, rank):
     """contiguous stream ranges per rank, no data-path collective: weak = --streams per GPU, strong = --total-streams over all ranks"""
     from nrsc5_amd import shard
+    b = args.stream_base
     if args.scaling == "strong":
-        return list(shard.stream_range(args.total_streams, world, rank))
+        return [b + k for k in shard.stream_range(args.total_streams, world, rank)]
     S = args.streams or (128 if args.workload == "am-cu8" else 256)
-    return list(shard.stream_range(S * world, world, rank))
+    return [b + k for k in shard.stream_range(S * world, world, rank)]
 
 
 # ---- workloads ----------------------------------------------------------------------------------------------------------
@@ -906,49 +919,86 @@ def dropin_leg(iq: np.ndarray, fs: float):
     out, logs = {"feed": "nrsc5_pipe_samples_cu8, 32768-byte calls (src/main.c:1095-1121)", "seconds_of_signal": round(iq.size / 2 / fs, 2)}, {}
     from nrsc5_amd import engine as eng
     hip = eng.load_library()                                 # the same loaded libnrsc5hip.so the drop-in is linked with
+    RUNS = 5
+
+    def timed_runs(lib, name, reps):
+        """reps x pipe_run -> (feed seconds of every run, wall of the median run, log of the last run, seam breakdown of the median run)"""
+        feeds, walls, brk, log = [], [], [], None
+        for rep in range(reps):
+            p = ctypes.c_void_p()
+            hip.nrsc5hip_debug_seam_totals(None, 1); hip.nrsc5hip_debug_seam_counts(None, 1)
+            t0 = time.perf_counter()
+            n = lib.pipe_run(iq.ctypes.data, iq.size, 32768, 0, 0, ctypes.byref(p))
+            walls.append(time.perf_counter() - t0)
+            f = float(lib.pipe_last_feed_seconds())
+            feeds.append(f)
+            log = ref.parse_log(ctypes.string_at(p, n))
+            if name != "plain":
+                tot = (ctypes.c_double * 8)()
+                hip.nrsc5hip_debug_seam_totals(tot, 0)
+                blocks = max(tot[6], 1.0)
+                cnt = (ctypes.c_double * 6)()
+                hip.nrsc5hip_debug_seam_counts(cnt, 0)
+                brk.append({"blocks": int(tot[6]), "pushes": int(tot[4]), "submissions_h2d_plus_decimator": int(tot[5]),
+                            "block_steps_left_in_flight_deferred_wait": int(cnt[0]), "read_positions_mispredicted": int(cnt[1]),
+                            "block_steps_without_p1_decode_launches": int(cnt[2]), "p1_decodes_launched_late": int(cnt[3]), "block_steps_queued_ahead_of_the_previous_delivery": int(cnt[4]),
+                            "us_per_block": {"host_copy_into_pinned_staging": round(tot[0] / blocks * 1e6, 1), "host_enqueue_h2d_and_decimator": round(tot[1] / blocks * 1e6, 1),
+                                             "host_enqueue_block_step": round(tot[2] / blocks * 1e6, 1), "wait_for_device": round(tot[3] / blocks * 1e6, 1),
+                                             "fetch_p1_frames": round(tot[7] / blocks * 1e6, 1),
+                                             "reference_host_code_L2_and_callbacks_and_rest": round((f - tot[0] - tot[1] - tot[2] - tot[3] - tot[7]) / blocks * 1e6, 1)},
+                            "total_us_per_block": round(f / blocks * 1e6, 1)})
+        med = int(np.argsort(feeds)[len(feeds) // 2])
+        return feeds, walls[med], log, (brk[med] if brk else None)
+
+    def entry(feeds, wall):
+        f = float(np.median(feeds))
+        return {"feed_seconds": round(f, 4), "x_realtime": round(iq.size / 2 / fs / f, 1), "runs": len(feeds), "statistic": "median",
+                "x_realtime_min_max": [round(iq.size / 2 / fs / max(feeds), 1), round(iq.size / 2 / fs / min(feeds), 1)], "wall_seconds_incl_open_close": round(wall, 3)}
+
+    libs = {}
     for name, path in paths.items():
         lib = ctypes.CDLL(path)
         lib.pipe_run.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
         lib.pipe_run.restype = ctypes.c_size_t
         lib.pipe_last_feed_seconds.restype = ctypes.c_double
-        best, wall = None, None
-        for rep in range(3 if name == "dropin" else 2):
-            p = ctypes.c_void_p()
-            hip.nrsc5hip_debug_seam_totals(None, 1); hip.nrsc5hip_debug_seam_counts(None, 1)
-            t0 = time.perf_counter()
-            n = lib.pipe_run(iq.ctypes.data, iq.size, 32768, 0, 0, ctypes.byref(p))
-            w = time.perf_counter() - t0
-            f = float(lib.pipe_last_feed_seconds())
-            if best is None or f < best:
-                best, wall = f, w
-                if name == "dropin":
-                    tot = (ctypes.c_double * 8)()
-                    hip.nrsc5hip_debug_seam_totals(tot, 0)
-                    blocks = max(tot[6], 1.0)
-                    cnt = (ctypes.c_double * 6)()
-                    hip.nrsc5hip_debug_seam_counts(cnt, 0)
-                    out["breakdown"] = {"blocks": int(tot[6]), "pushes": int(tot[4]), "submissions_h2d_plus_decimator": int(tot[5]),
-                                        "block_steps_left_in_flight_deferred_wait": int(cnt[0]), "read_positions_mispredicted": int(cnt[1]),
-                                        "block_steps_without_p1_decode_launches": int(cnt[2]), "p1_decodes_launched_late": int(cnt[3]), "block_steps_queued_ahead_of_the_previous_delivery": int(cnt[4]),
-                                        "us_per_block": {"host_copy_into_pinned_staging": round(tot[0] / blocks * 1e6, 1), "host_enqueue_h2d_and_decimator": round(tot[1] / blocks * 1e6, 1),
-                                                         "host_enqueue_block_step": round(tot[2] / blocks * 1e6, 1), "wait_for_device": round(tot[3] / blocks * 1e6, 1),
-                                                         "fetch_p1_frames": round(tot[7] / blocks * 1e6, 1),
-                                                         "reference_host_code_L2_and_callbacks_and_rest": round((f - tot[0] - tot[1] - tot[2] - tot[3] - tot[7]) / blocks * 1e6, 1)},
-                                        "total_us_per_block": round(f / blocks * 1e6, 1)}
-        logs[name] = ref.parse_log(ctypes.string_at(p, n))
-        out[name] = {"feed_seconds": round(best, 4), "x_realtime": round(iq.size / 2 / fs / best, 1), "wall_seconds_incl_open_close": round(wall, 3)}
-    exp, got = logs["plain"], logs["dropin"]
-    same = [k for k, _ in exp] == [k for k, _ in got]
-    if same:
-        for (k, a), (_, b) in zip(exp, got):
-            if k == "hdc":
-                same = same and a["program"] == b["program"] and a["flags"] == b["flags"] and a["data"] == b["data"]
-            elif k in ("sync", "mer", "ber"):
-                same = same and all(common.float_close(f, float(a[f]), float(b[f])) for f in a)
-    out["events"] = len(exp); out["hdc_packets"] = sum(k == "hdc" for k, _ in exp); out["events_equal"] = bool(same)
+        libs[name] = lib
+    env0 = os.environ.get("NRSC5HIP_SYNC_DELIVERY")
+    try:
+        # default: overlapped delivery (events of block n during the first call after the device has finished it, at the latest in the call that completes block n + 1 / a zero-length call / nrsc5_close)
+        os.environ["NRSC5HIP_SYNC_DELIVERY"] = "0"
+        feeds, wall, logs["dropin"], out["breakdown"] = timed_runs(libs["dropin"], "dropin", RUNS)
+        out["dropin"] = entry(feeds, wall)
+        out["dropin"]["delivery"] = "overlapped (default): a block's events arrive up to one block (93 ms of signal) after the call that completed it; order preserved; flushed by a zero-length call or nrsc5_close"
+        # strict: the reference's contract -- every event inside the nrsc5_pipe_samples_* call that completes its block
+        os.environ["NRSC5HIP_SYNC_DELIVERY"] = "1"
+        feeds, wall, logs["dropin_strict"], brk = timed_runs(libs["dropin"], "dropin_strict", RUNS)
+        out["dropin_strict_delivery"] = entry(feeds, wall)
+        out["dropin_strict_delivery"]["delivery"] = "NRSC5HIP_SYNC_DELIVERY=1: events inside the call that completes their block, as src/input.c delivers them"
+        out["dropin_strict_delivery"]["breakdown_us_per_block"] = brk["us_per_block"] if brk else None
+    finally:
+        if env0 is None:
+            os.environ.pop("NRSC5HIP_SYNC_DELIVERY", None)
+        else:
+            os.environ["NRSC5HIP_SYNC_DELIVERY"] = env0
+    feeds, wall, logs["plain"], _ = timed_runs(libs["plain"], "plain", 2)
+    out["plain"] = entry(feeds, wall)
+
+    def events_equal(exp, got):
+        same = [k for k, _ in exp] == [k for k, _ in got]
+        if same:
+            for (k, a), (_, b) in zip(exp, got):
+                if k == "hdc":
+                    same = same and a["program"] == b["program"] and a["flags"] == b["flags"] and a["data"] == b["data"]
+                elif k in ("sync", "mer", "ber"):
+                    same = same and all(common.float_close(f, float(a[f]), float(b[f])) for f in a)
+        return bool(same)
+    exp = logs["plain"]
+    same = events_equal(exp, logs["dropin"])
+    same_strict = events_equal(exp, logs["dropin_strict"])
+    out["events"] = len(exp); out["hdc_packets"] = sum(k == "hdc" for k, _ in exp); out["events_equal"] = same; out["events_equal_strict_delivery"] = same_strict
     out["speedup_vs_plain"] = round(out["plain"]["feed_seconds"] / out["dropin"]["feed_seconds"], 2)
-    if not same:
-        FAILURES.append("dropin: public-API event log differs from the plain reference")
+    if not same or not same_strict:
+        FAILURES.append("dropin: public-API event log differs from the plain reference" + ("" if same_strict else " (strict delivery)"))
     return out
 
 

@@ -135,14 +135,15 @@ static void deliver(input_t *st, int wait)
  * NRSC5HIP_SYNC_DELIVERY=1 in the environment restores delivery inside the completing call (and the waiting that goes with it). */
 static int sync_delivery(void)
 {
-    static int v = -1;
-    if (v < 0) { const char *e = getenv("NRSC5HIP_SYNC_DELIVERY"); v = (e && atoi(e) > 0) ? 1 : 0; }
-    return v;
+    /* read per call (a getenv is ~50 ns against a block's ~80 us): a host can switch between two sessions, and bench.py times both modes in one process */
+    const char *e = getenv("NRSC5HIP_SYNC_DELIVERY");
+    return (e && atoi(e) > 0) ? 1 : 0;
 }
 
 static void push_pieces(input_t *st, const uint8_t *buf, uint32_t nbytes, int cu8)
 {
     uint32_t consumed = 0;
+    const int strict = sync_delivery();
     if (nbytes == 0 && !FAILED(st)) deliver(st, 1);             /* nrsc5_pipe_samples_*(radio, buf, 0): flush -- every pending event, now */
     while (consumed < nbytes && !FAILED(st))
     {
@@ -160,11 +161,11 @@ static void push_pieces(input_t *st, const uint8_t *buf, uint32_t nbytes, int cu
             /* 15 of 16 blocks cannot end a P1 frame: nothing their delivery tells frame.c can send the receiver back to NONE, so the
              * step of THIS block is queued behind them before they are even looked at (the engine decides; include/nrsc5hip.h) */
             int ahead = 0;
-            if (!sync_delivery() && nrsc5hip_stream_step_ahead(ENGINE(st), 0, &ahead) != 0) { fail(st, "stream_step_ahead"); return; }
+            if (!strict && nrsc5hip_stream_step_ahead(ENGINE(st), 0, &ahead) != 0) { fail(st, "stream_step_ahead"); return; }
             deliver(st, 1);                                     /* the block before: its frames reach frame.c now ... */
             if (FAILED(st)) return;
             if (!ahead && nrsc5hip_stream_step(ENGINE(st), 0) != 0) { fail(st, "stream_step"); return; }   /* ... and only then is this one processed */
-            deliver(st, sync_delivery());
+            deliver(st, strict);
         }
         else
             deliver(st, known ? 0 : 1);

@@ -42,8 +42,18 @@ static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t
 /* wall time of the nrsc5_pipe_samples_* loop of the last pipe_run (session open / close excluded): what `nrsc5 -r` spends per capture */
 double pipe_last_feed_seconds(void) { return g_feed_seconds; }
 
-/* mode: NRSC5_MODE_FM / NRSC5_MODE_AM; cs16 != 0: iq holds n int16 values, else n bytes of cu8 */
+/* mode: NRSC5_MODE_FM / NRSC5_MODE_AM; cs16 != 0: iq holds n int16 values, else n bytes of cu8.
+ * flags & PIPE_NO_FLUSH: no zero-length call after the loop -- the way src/main.c:1095-1121 ends a file: it just calls nrsc5_close.  With the
+ * drop-in's default (overlapped) delivery the last block's events are then delivered by nrsc5_close (input_free); the log is read after the
+ * close either way.  events_at_loop_end (optional): how many bytes of the log existed when the feeding loop (incl. the flush, if any) ended. */
+#define PIPE_NO_FLUSH 1
+size_t pipe_run_opts(const void *iq, size_t n, unsigned chunk, int mode, int cs16, int flags, size_t *log_bytes_at_loop_end, const uint8_t **out);
 size_t pipe_run(const void *iq, size_t n, unsigned chunk, int mode, int cs16, const uint8_t **out)
+{
+    return pipe_run_opts(iq, n, chunk, mode, cs16, 0, NULL, out);
+}
+
+size_t pipe_run_opts(const void *iq, size_t n, unsigned chunk, int mode, int cs16, int flags, size_t *log_bytes_at_loop_end, const uint8_t **out)
 {
     nrsc5_t *radio = NULL;
     g_log.len = 0;
@@ -58,9 +68,12 @@ size_t pipe_run(const void *iq, size_t n, unsigned chunk, int mode, int cs16, co
     }
     /* a zero-length call: with the drop-in, "deliver what is still pending" (the last block may be on the device when the loop
      * ends); the plain reference has nothing pending and returns at once.  Inside the timed region: no work escapes the clock. */
-    if (cs16) nrsc5_pipe_samples_cs16(radio, (const int16_t *)iq, 0);
-    else nrsc5_pipe_samples_cu8(radio, (const uint8_t *)iq, 0);
+    if (!(flags & PIPE_NO_FLUSH)) {
+        if (cs16) nrsc5_pipe_samples_cs16(radio, (const int16_t *)iq, 0);
+        else nrsc5_pipe_samples_cu8(radio, (const uint8_t *)iq, 0);
+    }
     g_feed_seconds = now_s() - t0;
+    if (log_bytes_at_loop_end) *log_bytes_at_loop_end = g_log.len;
     nrsc5_close(radio);
     *out = g_log.p;
     return g_log.len;

@@ -62,3 +62,27 @@ def test_emu_dropin_am(emu_dropin, captures):
     got = _run(emu_dropin, iq, mode=1)
     assert any(k == "ber" for k, _ in exp)
     _compare_events(exp, got)
+
+
+def _run_opts(path, iq, flags, chunk=32768, mode=0):
+    lib = ctypes.CDLL(path)
+    lib.pipe_run_opts.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_void_p)]
+    lib.pipe_run_opts.restype = ctypes.c_size_t
+    p, at_end = ctypes.c_void_p(), ctypes.c_size_t()
+    n = lib.pipe_run_opts(iq.ctypes.data, iq.size, chunk, mode, int(iq.dtype == np.int16), flags, ctypes.byref(at_end), ctypes.byref(p))
+    return ref.parse_log(ctypes.string_at(p, n)), int(at_end.value), int(n)
+
+
+@pytest.mark.parametrize("strict", [0, 1])
+def test_emu_dropin_close_without_flush_delivers_the_last_block(emu_dropin, captures, strict, monkeypatch):
+    """src/main.c:1095-1121 ends a file by calling nrsc5_close -- no zero-length nrsc5_pipe_samples_* call.  With the drop-in's default
+    (overlapped) delivery the events of the block that was on the device when the loop ended must then come out of nrsc5_close
+    (input_free -> deliver); with NRSC5HIP_SYNC_DELIVERY=1 every event has been delivered inside the call that completed its block.
+    Either way the complete log equals the plain reference's."""
+    monkeypatch.setenv("NRSC5HIP_SYNC_DELIVERY", str(strict))
+    iq = np.ascontiguousarray(captures("fm_cu8_cfo137").iq)
+    exp = _run(os.path.join(common.ROOT, "oracle", "_ref", "libnrsc5_plain.so"), iq)
+    got, at_end, total = _run_opts(emu_dropin, iq, flags=1)
+    _compare_events(exp, got)
+    if strict:
+        assert at_end == total, "strict delivery: nothing may be left for nrsc5_close"

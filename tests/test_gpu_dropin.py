@@ -132,3 +132,25 @@ def test_batch_shard_c_host_equals_python_path(tmp_path):
         assert p1 >= 1
     ec._free_device(E, dev)
     E.close()
+
+
+@pytest.mark.parametrize("strict", [0, 1])
+def test_dropin_close_without_flush_delivers_the_last_block(captures, strict, monkeypatch):
+    """src/main.c:1095-1121 ends a file with nrsc5_close, no zero-length nrsc5_pipe_samples_* call: the events of a block that is still on
+    the device when the feeding loop ends must come out of nrsc5_close (default, overlapped delivery); with NRSC5HIP_SYNC_DELIVERY=1
+    nothing may be left for it.  The complete log equals the plain reference's in both modes."""
+    monkeypatch.setenv("NRSC5HIP_SYNC_DELIVERY", str(strict))
+    path = os.path.join(BUILD["libnrsc5_hipdropin.so"], "libnrsc5_hipdropin.so")
+    if not os.path.exists(path):
+        pytest.skip("libnrsc5_hipdropin.so not prebuilt")
+    iq = np.ascontiguousarray(captures("fm_cu8_cfo137").iq)
+    exp = _run("libnrsc5_plain.so", iq)
+    lib = ctypes.CDLL(path)
+    lib.pipe_run_opts.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_void_p)]
+    lib.pipe_run_opts.restype = ctypes.c_size_t
+    p, at_end = ctypes.c_void_p(), ctypes.c_size_t()
+    n = lib.pipe_run_opts(iq.ctypes.data, iq.size, 32768, 0, 0, 1, ctypes.byref(at_end), ctypes.byref(p))
+    got = ref.parse_log(ctypes.string_at(p, n))
+    _compare_events(exp, got)
+    if strict:
+        assert at_end.value == n, "strict delivery: nothing may be left for nrsc5_close"
