@@ -194,7 +194,13 @@ int nrsc5hip_stream_step(nrsc5hip_engine *e, int stream);
  * its delivery tells the host can change what the next block does -- frame_process's only way back into L1 is the first header of a
  * P1 frame (frame.c:535-540) -- so the next block's step may be queued BEHIND it before the host has even looked at it:
  * nrsc5hip_stream_step_ahead does that if it is safe and says so in *submitted; the nrsc5hip_drain that follows waits for the older
- * step only.  The device then runs block n + 1 while the host hands block n to L2. */
+ * step only.  The device then runs block n + 1 while the host hands block n to L2.
+ * CONTRACT: between a nrsc5hip_stream_step_ahead that reported *submitted = 1 and the nrsc5hip_drain that follows it, the caller must not issue
+ * anything that changes the stream's L1 state (nrsc5hip_force_resync, nrsc5hip_stream_reset, nrsc5hip_stream_set_mode): the block queued ahead has
+ * already been submitted with the old state, so the change would land one block late.  (integration/input_hip.c cannot violate it: those calls
+ * only come from frame.c during a delivery, and a delivery that can produce them -- a block that may end a P1 frame -- is never stepped ahead of.)
+ * Should the engine find its own prediction violated (a block submitted without its P1 decode completed a frame while the next one is running)
+ * it drops both steps' bookkeeping, marks the stream's host mirror invalid (the next push re-synchronises) and returns NRSC5HIP_EHIP. */
 int nrsc5hip_stream_step_ahead(nrsc5hip_engine *e, int stream, int *submitted);
 
 /* ---- batch path (device buffers) ------------------------------------------------------------------ */
@@ -373,7 +379,8 @@ enum {
     , NRSC5HIP_TUNE_DECODE_CUS             /* decode streams confined to value / 32 of every XCD's CUs (8, 16, 24; 32 = all, the default) */
     , NRSC5HIP_TUNE_DECODE_PRIORITY        /* 1: decode streams at the lowest queue priority (default 0: all queues equal) */
     , NRSC5HIP_TUNE_AM_WARM                /* TEST HOOK: 0 = no forward warm-up and no traceback run-in (every boundary takes the repair path); 1 = normal */
-    , NRSC5HIP_TUNE_MIXFFT_SYMS            /* OFDM symbols per k_mixfft workgroup: 1 (default), 2, 4, 8 -- any value gives identical bins */
+    , NRSC5HIP_TUNE_MIXFFT_SYMS            /* OFDM symbols per k_mixfft workgroup: 1 (default), 2, 4, 8 -- any value gives identical bins; 16 = two symbols side by side in a
+                                             256-lane workgroup (identical bins); 32 = the 256-lane x 8-point kernel k_mixfft8 (bins within float tolerance); anything else = 1 */
     , NRSC5HIP_TUNE_DEFER_WAIT             /* fast streaming seam: 1 (default) = a block step whose FIFO consumption the host can compute in advance stays in
                                              flight when the push returns; 0 = every step is waited for at once (round 3's behaviour) */
     , NRSC5HIP_TUNE_TRACEBACK_WALK         /* 1 (default): single-path traceback of the K=7 frames (one speculative walk per chunk, verified, re-walked where wrong);
@@ -385,6 +392,11 @@ enum {
                                              beside the running block step) before its block is complete; 0 = only at the block's end.  Default 128 */
     , NRSC5HIP_TUNE_SEAM_PREPARE           /* fast streaming seam, FINE stream: 1 (default) = the block's bookkeeping is computed by the symbol kernel for itself and
                                              committed by the sync kernel; 0 = k_prepare as a launch of its own in front of them */
+    , NRSC5HIP_TUNE_NCO_EXACT              /* which blocks of a freshly reset FM stream advance the NCO by the reference's own float recurrence (acquire.c:237-252: 69 120
+                                             dependent complex multiplications per block, ~0.4 ms of one lane per stream whatever the number of streams) instead of the
+                                             closed-form phasor: 0 = none, 1 (default) = the first block after a reset (the block the CFO search runs on), 2 = every block until the
+                                             stream is FINE, 3 = every block (diagnostic).  The float oscillator state is the reference's bit for bit for as long as every
+                                             block since the reset ran in this mode; the first closed-form block ends that until the next reset */
 };
 /* process-wide wall-clock totals of the streaming seam with p1_async = 0 (what the drop-in uses): [0] s copying pushes into pinned
  * staging, [1] s enqueueing H2D + decimator, [2] s enqueueing block steps, [3] s waiting for the device (one sync per block),

@@ -1,6 +1,7 @@
 // Host side of libnrsc5hip: engine object, device-resident per-stream state, the block-step
 // scheduler and the C ABI of include/nrsc5hip.h.  Mirrors the reference's src/input.c seam
 // (input_push_cu8/cs16, input_reset, input_set_sync_state) -- see include/nrsc5hip.h for the map.
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdio.h>
@@ -408,6 +409,7 @@ static void init_state(StreamState &st, int mode = MODE_FM)
     st.psmi = 1;                                               // sync_reset (sync.c:821)
     st.sync_state = SYNC_NONE;
     st.mode = mode;
+    st.nco_re = 1.0f; st.nco_im = 0.0f; st.nco_exact = 1;     // acquire_reset: phase = 1 (acquire.c:296) -- from here on the float state can be kept bit for bit
 }
 
 static void init_am_state(AmStream &am)
@@ -436,9 +438,8 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         // the window pipeline drives 1 chain + 3 decode streams (+ the caller's): with the HIP runtime's default of 4 hardware
         // queues they share queues and the decode / chain overlap is lost silently
         const char *q = getenv("GPU_MAX_HW_QUEUES");
-        static bool warned = false;
-        if (!warned && (!q || atoi(q) < 8)) {
-            warned = true;
+        static std::atomic<bool> warned{false};                // engines of one process share nothing else; this is a once-per-process notice
+        if ((!q || atoi(q) < 8) && !warned.exchange(true)) {
             fprintf(stderr, "libnrsc5hip: warning: p1_async engine with GPU_MAX_HW_QUEUES=%s (< 8): decode streams will share hardware queues with "
                             "the block-step chain; export GPU_MAX_HW_QUEUES=8 before the HIP runtime initialises\n", q ? q : "unset (default 4)");
         }
@@ -489,6 +490,9 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if ((rc = dev_alloc(e, &db.acq_list, S + 1))) break;
         if ((rc = dev_alloc(e, &db.acq_sums, S * SYM_N))) break;
         if ((rc = dev_alloc(e, &db.bins, S * NSYM * LIVE_N))) break;
+        // the reference's oscillator sample by sample for blocks in exact mode (553 KB per stream; k_nco_exact -> k_mixfft)
+        if ((rc = dev_alloc(e, &db.nco_tab, S * NSYM * SYM_N))) break;
+        db.nco_policy = NCO_EXACT_FIRST_BLOCK;
         if ((rc = dev_alloc(e, &db.pm, S * NPM * PM_FRAME))) break;
         db.nstreams_alloc = (int)S;
         if ((rc = dev_alloc(e, &db.coded, (size_t)(cfg->p1_async ? NAUX : 1) * S * P1_LEN))) break;
@@ -743,8 +747,11 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
     if (ln.acq_needed) { ProfScope p(e, NRSC5HIP_PROF_ACQUIRE, ln.main); launch_acquire(e->tb, ln.db, n, ids_dev, ln.main); }
     // prepare_block is idempotent for a stream the previous k_sync already prepared; a stream that is not FINE is only
     // prepared here, on a step that ran the acquisition kernels for its current window
-    const bool fused_prepare = local_prepare && !ln.acq_needed && !async;
+    const bool fused_prepare = local_prepare && !ln.acq_needed && !async && ln.db.nco_policy != NCO_EXACT_ALWAYS;
     if (!fused_prepare && (!ln.prepared_by_sync || ln.acq_needed)) { ProfScope p(e, NRSC5HIP_PROF_PREPARE, ln.main); launch_prepare(ln.db, n, ids_dev, ln.acq_needed ? 1 : 0, ln.main); }
+    // exact-oscillator blocks (a freshly reset stream up to its first lock): only a stream that is not FINE can be in that mode, and
+    // those only advance on steps that run the acquisition kernels
+    if (ln.db.nco_tab && (ln.acq_needed || ln.db.nco_policy == NCO_EXACT_ALWAYS)) { ProfScope p(e, NRSC5HIP_PROF_PREPARE, ln.main); launch_nco_exact(ln.db, n, ids_dev, ln.main); }
     { ProfScope p(e, NRSC5HIP_PROF_MIXFFT, ln.main); launch_mixfft(e->tb, ln.db, n, ids_dev, ln.main, e->mixfft_syms, fused_prepare ? 1 : 0); }
     const int slot = async ? (int)(ln.step_count % 16) : 0;
     // batch pipeline: once every stream of the set is FINE, the next block's bookkeeping rides in k_sync's tail
@@ -978,7 +985,7 @@ static int wait_report(nrsc5hip_engine *e, unsigned seq, bool block)
 #if defined(__x86_64__) || defined(__i386__)
         __builtin_ia32_pause();
 #endif
-        if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(20)) break;
+        if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;   // a block step is ~50 us: past 2 ms something else holds the queue -- stop burning a core, block
     }
     HIPCHK(hipStreamSynchronize(e->lane.main));
     if (__atomic_load_n(p, __ATOMIC_ACQUIRE) != seq) FAIL(NRSC5HIP_EHIP, "stream report %u never arrived (have %u)", seq, *p);
@@ -988,7 +995,7 @@ static int wait_report(nrsc5hip_engine *e, unsigned seq, bool block)
 static int launch_report(nrsc5hip_engine *e, int s, bool with_pids)
 {
     e->report_seq++;
-    if (e->report_seq == 0) e->report_seq = 1;                 // 0 = the freshly cleared report
+    if (e->report_seq == 0) e->report_seq = 2;                 // 0 = the freshly cleared report; 2, not 1: the step before the wrap posted into buffer 1 (seq & 1)
     // records to post: from the first one the host has not seen -- the block of a step still in flight is not this step's to report
     const int first_rec = e->fetched[s] + ((e->inflight_stream == s) ? 1 : 0);
     launch_stream_tail(e->tb, e->lane.db, s, first_rec, e->report_dev[e->report_seq & 1], e->report_seq, with_pids ? 1 : 0, e->lane.main);
@@ -1017,7 +1024,15 @@ static int harvest(nrsc5hip_engine *e, bool block)
     if (p1_missing) {
         // the prediction said no P1 frame could complete in this block and one did: decode it now, take the record again
         g_seam[11] += 1;
-        if (e->ahead.valid) FAIL(NRSC5HIP_EHIP, "stream %d: a block submitted without its P1 decode completed a frame, and the next block is already running", s);
+        if (e->ahead.valid) {
+            // cannot happen while the caller keeps the contract of nrsc5hip_stream_step_ahead (nothing that changes L1 state between it and the drain);
+            // if it does, leave the engine in a state every later call understands: nothing in flight, the stream's mirror invalid (its next push
+            // re-synchronises with the device), then report
+            e->ahead.valid = false; e->inflight_rd_pred = -1;
+            (void)hipStreamSynchronize(ln.main);
+            e->mirror_ok[s] = 0; forget_prediction(e, s);
+            FAIL(NRSC5HIP_EHIP, "stream %d: a block submitted without its P1 decode completed a frame, and the next block is already running", s);
+        }
         int rc = launch_inorder_p1(e, ln, 1, e->all_ids_dev + s); if (rc) return rc;
         if ((rc = launch_report(e, s, false))) return rc;
         if ((rc = wait_report(e, e->report_seq, true)) < 0) return rc;
@@ -2223,6 +2238,7 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
     case NRSC5HIP_TUNE_TRACEBACK_WALK:    e->tb_walk = value != 0; break;
     case NRSC5HIP_TUNE_SYNC_LANES:        e->sync_lanes = (value == 256 || value == 768) ? value : 0; break;
     case NRSC5HIP_TUNE_SEAM_PREPARE:      e->fuse_seam_prepare = value != 0; break;
+    case NRSC5HIP_TUNE_NCO_EXACT:         e->db.nco_policy = e->lane.db.nco_policy = e->db.nco_tab ? std::min(std::max(value, 0), (int)NCO_EXACT_ALWAYS) : (int)NCO_CLOSED_FORM; break;
     case NRSC5HIP_TUNE_EARLY_FLUSH_KB:    e->early_flush = (size_t)std::max(value, 0) << 10; break;
     case NRSC5HIP_TUNE_DEFER_WAIT:        e->defer_wait = value != 0; break;
     case NRSC5HIP_TUNE_DIRECT_DECIMATE:   e->direct_decimate = value != 0; break;

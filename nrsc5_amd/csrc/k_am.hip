@@ -9,6 +9,7 @@
 // The AM stream is 32 x slower than FM (46.5 kS/s), so one workgroup owns one stream for a whole block:
 // the 32 x 256-point FFTs, the carrier line fit and sync_process_am all run out of one 64 KB LDS tile and
 // only hard symbols (3.2 KB per block) go back to HBM.  The K=9 trellis has 256 states = one per work-item.
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include "kernels.h"
 #include "wave_ops.h"
@@ -1372,12 +1373,12 @@ void launch_am_decode(const DevTables &tb, const DevBuffers &db, int nstreams, c
 void launch_am_step(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int l2_feedback, int pipeline_parity, int slot, int window)
 {
     // (per device: the attribute belongs to the function as loaded on the current device -- one process may drive several, include/nrsc5hip.h)
-    static bool attr_set[64] = {};
+    static std::atomic<bool> attr_set[64];
     int dev = 0; (void)hipGetDevice(&dev);
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) {
+    if (dev < 0 || dev >= 64 || !attr_set[dev].load(std::memory_order_acquire)) {      // (a device index beyond the table: set it on every launch rather than never)
         (void)hipFuncSetAttribute((const void *)k_am_block<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AmBlockSmem));
         (void)hipFuncSetAttribute((const void *)k_am_block<256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(AmBlockSmem));
-        attr_set[dev] = true;
+        if (dev >= 0 && dev < 64) attr_set[dev].store(true, std::memory_order_release);
     }
     if (pipeline_parity >= 0) hipLaunchKernelGGL(k_am_block<512>, dim3(nstreams), dim3(512), sizeof(AmBlockSmem), st, tb, db, stream_ids, 1, pipeline_parity, slot);
     else hipLaunchKernelGGL(k_am_block<256>, dim3(nstreams), dim3(256), sizeof(AmBlockSmem), st, tb, db, stream_ids, 0, pipeline_parity, slot);

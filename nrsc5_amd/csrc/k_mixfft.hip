@@ -360,12 +360,33 @@ template <typename T> __device__ __forceinline__ T uniform64(T v)
 
 // what a workgroup needs of the block's bookkeeping: from the stream state (k_prepare or the previous k_sync wrote it) or, in the fast
 // streaming seam, computed here from the state the sync kernel will commit it to (prepare_values, prepare_block.h)
-struct SymParams { long long a00; double dtheta, theta; int active; double growth; };
+struct SymParams { long long a00; double dtheta, theta; int active; double growth; int nco_mode; };
 
 // The amplitude of the reference's oscillator at sample j of a symbol, (1 + g)^j, to first order (j g <= 1.3e-4, the second-order term 8e-9 is below
 // float resolution): the work-item's start phasor (sample tid) times 1 + tid g, its STEP-sample step times 1 + STEP g.  Two double-precision
 // fmas and two packed multiplies per work-item and symbol.
 __device__ __forceinline__ float nco_ramp(double g, int n) { return (float)(1.0 + (double)n * g); }
+
+// ---- exact-oscillator mode (StreamState::nco_mode; DESIGN.md (c) limit 2) --------------------------------------------------------------
+// The block where a freshly reset stream runs its CFO search (detect_cfo, sync.c:292-337) is the one place where the last bits of the FFT's
+// INPUT decide what the receiver does next: the search runs Costas loops over bins that hold no carrier, and whatever differs by 1e-5 rad
+// is amplified into a different loop state.  For such blocks the symbol kernel takes the oscillator from a table k_nco_exact filled with
+// the reference's own recurrence and mixes operation for operation as acquire.c:237-252 does -- the FFT's input is then the reference's, bit
+// for bit; what remains is the transform's own rounding (2e-7 of the largest bin: measured harmless, tests/test_oracle_fft_independence.py).
+__device__ __forceinline__ cf nco_tab_phasor(const DevBuffers &db, int s, int sym, int j)
+{
+    const float2 v = db.nco_tab[((size_t)s * NSYM + sym) * SYM_N + j];
+    return cf_make(v.x, v.y);
+}
+// phase * cq15_to_cf_conj(sample) (defines.h:111, acquire.c:241): q holds the Q15 integers (re, -im); the divisions and the four products / two
+// sums of the float complex multiplication each rounded as gcc -O3 compiles them (no contraction: -ffp-contract=off here too)
+__device__ __forceinline__ cf mix_exact(cf ph, cf q)
+{
+    const float a = ph.x, b = ph.y;
+    const float c = q.x / 32767.0f, dd = q.y / 32767.0f;
+    const float ac = a * c, bd = b * dd, ad = a * dd, bc = b * c;
+    return cf_make(ac - bd, ad + bc);
+}
 
 // diagnostic build only (-DNRSC5HIP_MIXFFT_PHASES, tools/gpu_mixfft_phases.py): shader cycles of wave 0 of stream 0's workgroups between the
 // marks, accumulated in db.sync_phase_cycles[8..15]; the release kernel carries none of this
@@ -395,7 +416,7 @@ template <int NT> struct SymPrologue {
     }
 };
 
-template <bool RAW, int SPW, int NPAR>
+template <bool RAW, int SPW, int NPAR, bool EXACT = false>
 __device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuffers &db, const uint8_t *raw, const SymParams &sp, int s, cf *lds, cf *twB, const SymPrologue<128 * NPAR> &pro)
 {
     // SPW consecutive symbols of one stream per workgroup: the stage-B twiddles, the half-band taps and the NCO step are set up
@@ -467,6 +488,21 @@ __device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuf
 #pragma unroll
             for (int k1 = 1; k1 < 8; k1++) ta[7 * h + k1 - 1] = cf_of(twA[(k1 - 1) * 256 + tid + 128 * h]);
         cf x[16];
+        if (EXACT) {                                               // the reference's oscillator from the table, its mix operation for operation
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const int h = q & 1, n1 = q >> 1;
+                const int j = tid + 128 * q;
+                cf m = mix_exact(nco_tab_phasor(db, s, sym, j), sample(j));
+                if (q == 0 && tid < CP_N) m = emul(m, cf_make(w0, w0));      // shape[j] * sample (acquire.c:243)
+                x[8 * h + n1] = m;
+            }
+            if (tid < CP_N) {
+                const int j = FFT_N + tid;
+                const cf m = mix_exact(nco_tab_phasor(db, s, sym, j), sample(j));
+                x[0] = cadd(x[0], emul(cf_make(w1, w1), m));       // fftin[j - 2048] += shape[j] * sample (acquire.c:247)
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < 16; q++) {
             const int h = q & 1, n1 = q >> 1;
@@ -480,6 +516,7 @@ __device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuf
             const int j = FFT_N + tid;
             const cf m = cmul(ph, sample(j));                      // ph = phasor of sample tid + 2048
             x[0] = cadd(x[0], emul(cf_make(w1, w1), m));
+        }
         }
         if (RAW) __syncthreads();                                  // every work-item has its samples: the tile becomes the FFT's
         MIX_MARK(3, 0);                                            // NCO, mix, fold + barrier
@@ -535,14 +572,14 @@ __global__ __launch_bounds__(128 * NPAR) MIXFFT_OCCUPANCY void k_mixfft(DevTable
         __shared__ SymParams sh_sp;
         if (threadIdx.x == 0) {
             const Prepared p = prepare_values(st, false);
-            sh_sp.active = p.active; sh_sp.a00 = (st.rd - st.base) + p.samperr; sh_sp.dtheta = p.dtheta; sh_sp.theta = p.theta; sh_sp.growth = p.growth;
+            sh_sp.active = p.active; sh_sp.a00 = (st.rd - st.base) + p.samperr; sh_sp.dtheta = p.dtheta; sh_sp.theta = p.theta; sh_sp.growth = p.growth; sh_sp.nco_mode = 0;   // (the fused seam runs FINE blocks only: closed form)
         }
         __syncthreads();
         sp = sh_sp;
     } else {
-        sp.active = st.active; sp.a00 = (st.rd - st.base) + st.samperr_cur; sp.dtheta = st.dtheta; sp.theta = st.theta; sp.growth = st.growth;
+        sp.active = st.active; sp.a00 = (st.rd - st.base) + st.samperr_cur; sp.dtheta = st.dtheta; sp.theta = st.theta; sp.growth = st.growth; sp.nco_mode = st.nco_mode;
     }
-    sp.active = wave_uniform(sp.active); sp.a00 = uniform64(sp.a00); sp.dtheta = uniform64(sp.dtheta); sp.theta = uniform64(sp.theta); sp.growth = uniform64(sp.growth);   // scalar registers
+    sp.active = wave_uniform(sp.active); sp.a00 = uniform64(sp.a00); sp.dtheta = uniform64(sp.dtheta); sp.theta = uniform64(sp.theta); sp.growth = uniform64(sp.growth); sp.nco_mode = wave_uniform(sp.nco_mode);   // scalar registers
     if (!sp.active) return;                                    // block-uniform
 #ifdef NRSC5HIP_MIXFFT_PHASES
     if (db.sync_phase_cycles && s == 0 && threadIdx.x == 0) atomicAdd((unsigned long long *)&db.sync_phase_cycles[8], (unsigned long long)((long long)clock64() - mix_entry));
@@ -553,6 +590,11 @@ __global__ __launch_bounds__(128 * NPAR) MIXFFT_OCCUPANCY void k_mixfft(DevTable
     static_assert(8 * PITCH_A >= 17 * 128 && 17 * 127 < SYM_N, "17 decimated samples per work-item fit in the FFT tile");
     static_assert(NSYM % (SPW * NPAR) == 0, "whole workgroups per block");
     __shared__ cf twB[256];
+    if (sp.nco_mode) {                                         // block-uniform, rare (a freshly reset stream's first blocks): its own instantiation
+        if (raw) mixfft_symbols<true, SPW, NPAR, true>(tb, db, raw, sp, s, lds, twB, pro);
+        else mixfft_symbols<false, SPW, NPAR, true>(tb, db, raw, sp, s, lds, twB, pro);
+        return;
+    }
     if (raw) mixfft_symbols<true, SPW, NPAR>(tb, db, raw, sp, s, lds, twB, pro);
     else mixfft_symbols<false, SPW, NPAR>(tb, db, raw, sp, s, lds, twB, pro);
 }
@@ -724,7 +766,7 @@ __device__ inline void raw_symbol_halfband8(const uint32_t (&W)[16], cf *tile, c
     hb_round_nearest();
 }
 
-template <bool RAW>
+template <bool RAW, bool EXACT = false>
 __device__ __forceinline__ void mixfft_symbol8(const DevTables &tb, const DevBuffers &db, const StreamState &st, const SymParams &sp, int s, cf *lds, cf *twB)
 {
     const int tid = threadIdx.x, sym = blockIdx.x;
@@ -761,13 +803,13 @@ __device__ __forceinline__ void mixfft_symbol8(const DevTables &tb, const DevBuf
     cf x[8];
 #pragma unroll
     for (int q = 0; q < 8; q++) {
-        cf m = cmul(ph, sample(tid + 256 * q));
+        cf m = EXACT ? mix_exact(nco_tab_phasor(db, s, sym, tid + 256 * q), sample(tid + 256 * q)) : cmul(ph, sample(tid + 256 * q));
         if (q == 0 && tid < CP_N) { const float w = tb.shape[tid]; m = emul(m, cf_make(w, w)); }
         x[q] = m;
         ph = cmul(ph, stp);
     }
     if (tid < CP_N) {                                          // fold the cyclic extension back (acquire.c:246-247)
-        const cf m = cmul(ph, sample(FFT_N + tid));
+        const cf m = EXACT ? mix_exact(nco_tab_phasor(db, s, sym, FFT_N + tid), sample(FFT_N + tid)) : cmul(ph, sample(FFT_N + tid));
         const float w = tb.shape[FFT_N + tid];
         x[0] = cadd(x[0], emul(cf_make(w, w), m));
     }
@@ -805,20 +847,81 @@ __global__ __launch_bounds__(256) MIXFFT8_OCCUPANCY void k_mixfft8(DevTables tb,
         __shared__ SymParams sh_sp;
         if (threadIdx.x == 0) {
             const Prepared p = prepare_values(st, false);
-            sh_sp.active = p.active; sh_sp.a00 = (st.rd - st.base) + p.samperr; sh_sp.dtheta = p.dtheta; sh_sp.theta = p.theta; sh_sp.growth = p.growth;
+            sh_sp.active = p.active; sh_sp.a00 = (st.rd - st.base) + p.samperr; sh_sp.dtheta = p.dtheta; sh_sp.theta = p.theta; sh_sp.growth = p.growth; sh_sp.nco_mode = 0;   // (the fused seam runs FINE blocks only: closed form)
         }
         __syncthreads();
         sp = sh_sp;
     } else {
-        sp.active = st.active; sp.a00 = (st.rd - st.base) + st.samperr_cur; sp.dtheta = st.dtheta; sp.theta = st.theta; sp.growth = st.growth;
+        sp.active = st.active; sp.a00 = (st.rd - st.base) + st.samperr_cur; sp.dtheta = st.dtheta; sp.theta = st.theta; sp.growth = st.growth; sp.nco_mode = st.nco_mode;
     }
-    sp.active = wave_uniform(sp.active); sp.a00 = uniform64(sp.a00); sp.dtheta = uniform64(sp.dtheta); sp.theta = uniform64(sp.theta); sp.growth = uniform64(sp.growth);
+    sp.active = wave_uniform(sp.active); sp.a00 = uniform64(sp.a00); sp.dtheta = uniform64(sp.dtheta); sp.theta = uniform64(sp.theta); sp.growth = uniform64(sp.growth); sp.nco_mode = wave_uniform(sp.nco_mode);
     if (!sp.active) return;
     __shared__ cf lds[8 * P8_ROW];
     static_assert(8 * P8_ROW >= 9 * 256 && 9 * 240 == SYM_N, "nine decimated samples per work-item fit in the FFT tile");
     __shared__ cf twB[TW8_N];
+    if (sp.nco_mode) {
+        if (st.raw) mixfft_symbol8<true, true>(tb, db, st, sp, s, lds, twB);
+        else mixfft_symbol8<false, true>(tb, db, st, sp, s, lds, twB);
+        return;
+    }
     if (st.raw) mixfft_symbol8<true>(tb, db, st, sp, s, lds, twB);
     else mixfft_symbol8<false>(tb, db, st, sp, s, lds, twB);
+}
+
+// The reference's oscillator for one block, sample by sample (acquire.c:237-252): phase *= phase_increment 2160 times per symbol as the float
+// complex product it is (four products, two sums, each rounded), phase /= cabsf(phase) at the symbol's end -- 69 120 DEPENDENT steps, so one
+// lane per stream walks them (three packed instructions a step: ~0.5 ms, whatever the number of streams) and leaves every sample's phasor in db.nco_tab for
+// the symbol kernel.  Launched only on steps that run the acquisition kernels, and it leaves at once for a stream whose block runs on the closed-form
+// phasor -- with the default policy (NCO_EXACT_UNTIL_FINE) that is every block after a stream's first lock.
+// cabsf: glibc's hypotf computes sqrt((double)x * x + (double)y * y) and rounds once to float (verified equal on 5e7 random pairs); the
+// divisions are IEEE float divisions (hipcc's default).
+// One WAVE per stream with one lane at work: as lane = stream the 64 lanes of a wave stored to 64 different cache lines per instruction and the
+// vector memory unit, one line per cycle, became the bound (measured: 1.8 ms for 256 streams instead of the chain's ~0.5 ms).
+__global__ __launch_bounds__(64) void k_nco_exact(DevBuffers db, const int *ids, int nstreams)
+{
+    const int idx = blockIdx.x;
+    if (idx >= nstreams || threadIdx.x != 0) return;
+    const int s = stream_of(ids, idx);
+    StreamState &st = db.state[s];
+    if (!st.active || !st.nco_mode) return;
+    float pr = st.nco_re, pi = st.nco_im;
+    const float c = st.inc_re, d = st.inc_im;
+    float2 *tab = db.nco_tab + (size_t)s * NSYM * SYM_N;
+    for (int sym = 0; sym < NSYM; sym++) {
+#ifdef HIPEMU
+        for (int j = 0; j < SYM_N; j++) {
+            tab[sym * SYM_N + j] = make_float2(pr, pi);
+            const float ac = pr * c, bd = pi * d, ad = pr * d, bc = pi * c;
+            pr = ac - bd; pi = ad + bc;
+        }
+#else
+        // THREE packed instructions per step -- (ac, ad), (bd, bc), then (ac - bd, ad + bc) with the sign of the low half in neg_lo -- the same
+        // six IEEE operations, each rounded once (the compiler's own vectorisation of the scalar form spends four: it forms the sum AND the
+        // difference of both halves); the chain is latency-bound at two dependent instructions per step
+        cf P = cf_make(pr, pi);
+        const cf K = cf_make(c, d);
+        cf *out = (cf *)(tab + sym * SYM_N);
+#pragma unroll 8
+        for (int j = 0; j < SYM_N; j++) {
+            out[j] = P;
+            cf t1, t2;                                             // (one statement: plain VALU dependencies are interlocked in hardware, and between separate
+                                                                   //  statements the compiler pads with s_nop it cannot know to be unnecessary)
+            asm("v_pk_mul_f32 %1, %0, %3 op_sel_hi:[0,1]\n\t"
+                "v_pk_mul_f32 %2, %0, %3 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+                "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "+v"(P), "=&v"(t1), "=&v"(t2) : "v"(K));
+        }
+        pr = P.x; pi = P.y;
+#endif
+        const float m = (float)sqrt((double)pr * (double)pr + (double)pi * (double)pi);
+        pr = pr / m; pi = pi / m;
+    }
+    st.nco_re = pr; st.nco_im = pi;                            // acquire_t.phase after the block
+}
+
+void launch_nco_exact(const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st)
+{
+    if (!db.nco_tab) return;
+    hipLaunchKernelGGL(k_nco_exact, dim3(nstreams), dim3(64), 0, st, db, stream_ids, nstreams);
 }
 
 // Symbols per workgroup (nrsc5hip_debug_tune NRSC5HIP_TUNE_MIXFFT_SYMS).  The persistent forms -- 2 / 4 / 8 symbols per workgroup, the

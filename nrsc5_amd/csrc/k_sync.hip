@@ -647,10 +647,18 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
     // its double-precision sine / cosine (a diagnostic of the record) on one, the FIFO / counters / record on the other, each with
     // its state loads issued together (a load behind every store of the other kind cost an L2 round trip apiece)
     if (tid == 64) {
-        double th = st.theta + (double)NSYM * SYM_N * st.dtheta;
-        th -= 2 * M_PI * rint(th / (2 * M_PI));
-        st.theta = th;
-        rec.phase_re = (float)cos(th); rec.phase_im = (float)sin(th);
+        if (st.nco_mode) {
+            // exact-oscillator block: k_nco_exact left acquire_t.phase as the reference has it after this block; a later closed-form
+            // block continues from its angle
+            const float pr = st.nco_re, pi = st.nco_im;
+            st.theta = atan2((double)pi, (double)pr);
+            rec.phase_re = pr; rec.phase_im = pi;
+        } else {
+            double th = st.theta + (double)NSYM * SYM_N * st.dtheta;
+            th -= 2 * M_PI * rint(th / (2 * M_PI));
+            st.theta = th;
+            rec.phase_re = (float)cos(th); rec.phase_im = (float)sin(th);
+        }
     }
     if (tid == 0) {
         const int keep_extra = st.keep_extra, state = st.sync_state, cfo = st.cfo, bc_now = st.bc, psmi = st.psmi, cfo_wait = st.cfo_wait, next_samperr = st.samperr, nblocks = st.nblocks;

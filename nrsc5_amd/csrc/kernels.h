@@ -41,6 +41,8 @@ struct DevBuffers {
     int *acq_list;                   // [S + 1]      streams that need the acquisition kernels this step (k_acq_list); [S] = how many
     float2 *acq_sums;                // [S][SYM_N]
     float2 *bins;                    // [S][NSYM][LIVE_N]
+    float2 *nco_tab;                 // [S][NSYM][SYM_N]  the reference's oscillator sample by sample for a block that runs in exact mode (k_nco_exact -> k_mixfft); null: closed form only
+    int nco_policy;                  // NCO_*: which blocks of a freshly reset stream advance the oscillator by the reference's float recurrence
     int8_t *pm;                      // [S][NPM][PM_FRAME]  soft-bit interleaver matrices (one per frame in flight)
     int8_t *pids_stage;              // [S][NWIN][16][240]  depunctured PIDS soft bits awaiting k_pids_decode
     int *pids_rec;                   // [S][NWIN][16]     record index of each staged PIDS frame, -1 = empty
@@ -111,6 +113,8 @@ void launch_append_cs16(const DevBuffers &db, int nstreams, const int *stream_id
 // ---- one block step for a set of streams ----------------------------------------------------
 void launch_acquire(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
 void launch_prepare(const DevBuffers &db, int nstreams, const int *stream_ids, int acq_on, hipStream_t st);
+// streams whose current block runs in exact-oscillator mode (StreamState::nco_mode): the reference's 69 120-step float recurrence, one lane per stream
+void launch_nco_exact(const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
 void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int syms_per_wg = 1, int local_prepare = 0);
 void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, int window, hipStream_t st, int lanes = 0, int pids_inline = 0, int do_prepare = 0);
 // replay (k_replay.hip): apply the first-header verdicts of finished deferred P1 decodes -- rewind the stream to the failed frame

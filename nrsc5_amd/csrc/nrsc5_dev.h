@@ -102,6 +102,8 @@ struct BlockRecord {
 // one staged P3 / P4 decode (filled by k_px_deint, consumed by k_px_decode)
 struct PxJob { int rec, slot, len, pad; };                      // rec < 0: empty
 
+enum { NCO_CLOSED_FORM = 0, NCO_EXACT_FIRST_BLOCK = 1, NCO_EXACT_UNTIL_FINE = 2, NCO_EXACT_ALWAYS = 3 };   // DevBuffers::nco_policy (include/nrsc5hip.h: NRSC5HIP_TUNE_NCO_EXACT)
+
 // Per-stream device-resident state ("the checkpoint").
 struct StreamState {
     // decimated Q15 FIFO: absolute sample counters; q15[(abs - base)] addresses the slab
@@ -134,6 +136,11 @@ struct StreamState {
     int samperr_cur; int pad0;
     double dtheta;              // effective NCO step (rad/sample) for the current block
     double growth;              // |phase_increment| - 1 of the current block: the per-sample amplitude drift of the reference's oscillator (prepare_block.h)
+    // The reference's oscillator as the float complex it is (acquire_t.phase, acquire.h:28), bit for bit, for as long as every block since the
+    // stream's reset has advanced it by the reference's own recurrence (k_nco_exact): nco_exact = 1.  The first block that runs on the
+    // closed-form phasor clears it for good (until the next reset).  nco_mode: the CURRENT block takes its phasors from db.nco_tab.
+    float nco_re, nco_im, inc_re, inc_im;
+    int nco_exact, nco_mode;
     int coarse_samperr; float coarse_re, coarse_im;
     // P1 hand-off, one slot per in-flight decode window (see engine.hip: P1 pipeline); `parity` = window % NWIN
     int p1_pending[NWIN];          // 1: frame completed this step (gather it), 2: gathered into coded[s][parity]

@@ -53,12 +53,15 @@ struct PrepView {
     int sync_state, samperr, cfo, coarse_samperr;
     float angle, prev_angle, coarse_re, coarse_im;
     double theta, dtheta, growth;
+    float nco_re, nco_im;
+    int nco_exact, nblocks;
 };
 __device__ __forceinline__ PrepView prep_view(const StreamState &st)
 {
     PrepView v;
     v.wr = st.wr; v.rd = st.rd; v.sync_state = st.sync_state; v.samperr = st.samperr; v.cfo = st.cfo; v.coarse_samperr = st.coarse_samperr;
     v.angle = st.angle; v.prev_angle = st.prev_angle; v.coarse_re = st.coarse_re; v.coarse_im = st.coarse_im; v.theta = st.theta; v.dtheta = st.dtheta; v.growth = st.growth;
+    v.nco_re = st.nco_re; v.nco_im = st.nco_im; v.nco_exact = st.nco_exact; v.nblocks = st.nblocks;
     return v;
 }
 
@@ -72,14 +75,25 @@ struct Prepared {
     int to_coarse;              // the block moves the stream from NONE to COARSE
     double dtheta, theta;       // NCO step and start phase of the block
     double growth;              // |phase_increment| - 1: the reference's oscillator grows / shrinks by this much per sample until it is renormalised at the symbol's end (acquire.c:250-252)
+    int nco_mode;               // 1: this block's phasors are the reference's own float recurrence (k_nco_exact), from the start state below
+    float ph_re, ph_im;         // ... acquire_t.phase after the block-start rotation (acquire.c:166), bit for bit
+    float inc_c, inc_s;         // phase_increment (acquire.c:168)
 };
 
 // acq_ran: the acquisition kernels ran in this step, i.e. coarse_samperr / coarse_re / coarse_im belong to the window at
 // st.rd.  A stream that is not FINE only advances on such steps (the host launches them whenever counters[1] > 0 at the
 // last burst boundary); anywhere else it waits -- never a block on stale coarse results.
-template <typename S> __device__ inline Prepared prepare_values_of(const S &st, bool acq_ran)
+// exact-oscillator mode for this block?  Only while the float state is still the reference's own (nco_exact: every block since the reset ran exact)
+template <typename S> __device__ inline bool nco_wants_exact(const S &st, int policy)
+{
+    if (!st.nco_exact) return false;
+    return policy == NCO_EXACT_ALWAYS || (policy == NCO_EXACT_UNTIL_FINE && st.sync_state != SYNC_FINE) || (policy == NCO_EXACT_FIRST_BLOCK && st.nblocks == 0);
+}
+
+template <typename S> __device__ inline Prepared prepare_values_of(const S &st, bool acq_ran, int nco_policy = NCO_CLOSED_FORM)
 {
     Prepared p;
+    p.nco_mode = 0; p.ph_re = 1.0f; p.ph_im = 0.0f; p.inc_c = 1.0f; p.inc_s = 0.0f;
     const bool ready = window_ready(st);
     p.active = (ready && (st.sync_state == SYNC_FINE || acq_ran)) ? 1 : 0;
     p.pending = ready ? 1 : 0;
@@ -120,12 +134,29 @@ template <typename S> __device__ inline Prepared prepare_values_of(const S &st, 
     // and 100 x the rounding noise of the recurrence.  The symbol kernel gives its closed-form phasor the same ramp (k_mixfft: nco_ramp).
     p.growth = sqrt((double)inc_c * (double)inc_c + (double)inc_s * (double)inc_s) - 1.0;
     // phase *= e^{-i (1080 - samperr) angle / 2048}            (acquire.c:166)
-    double th = st.theta + (double)(-(float)(SYM_N / 2 - p.samperr) * angle / FFT_N);
+    const float rot = -(float)(SYM_N / 2 - p.samperr) * angle / FFT_N;
+    double th = st.theta + (double)rot;
     th -= 2 * M_PI * rint(th / (2 * M_PI));
     p.theta = th;
+    p.inc_c = inc_c; p.inc_s = inc_s;
+    if (nco_wants_exact(st, nco_policy)) {
+        // st->phase *= cexpf(rot * I) as the reference computes it: glibc's cexpf is (cosf, sinf) of the float argument, the product the
+        // plain four-multiplication form in float (gcc -O3, no contraction; oracle/Makefile).  (float)cos((double)x) is cosf(x) except where
+        // glibc's own 0.56-ulp result is not the correctly rounded one: 1.3 % of arguments at |x| < 40, by one ulp = a constant phase
+        // offset of 6e-8 rad, below the FFT's rounding noise; the emulator build calls glibc itself.
+#ifdef HIPEMU
+        const float rc = cosf(rot), rs = sinf(rot);
+#else
+        const float rc = (float)cos((double)rot), rs = (float)sin((double)rot);
+#endif
+        const float a = st.nco_re, b = st.nco_im;
+        const float ac = a * rc, bd = b * rs, ad = a * rs, bc = b * rc;
+        p.ph_re = ac - bd; p.ph_im = ad + bc;
+        p.nco_mode = 1;
+    }
     return p;
 }
-__device__ inline Prepared prepare_values(const StreamState &st, bool acq_ran) { return prepare_values_of(prep_view(st), acq_ran); }
+__device__ inline Prepared prepare_values(const StreamState &st, bool acq_ran, int nco_policy = NCO_CLOSED_FORM) { return prepare_values_of(prep_view(st), acq_ran, nco_policy); }
 
 __device__ inline void prepare_block(const DevBuffers &db, StreamState &st, int s, bool acq_ran)
 {
@@ -134,7 +165,7 @@ __device__ inline void prepare_block(const DevBuffers &db, StreamState &st, int 
     if (was_active) return;                                    // already prepared (fused into the previous k_sync)
     if (v.sync_state != SYNC_FINE) atomicAdd(&db.counters[1], 1);   // host: keep launching acquisition
     if (v.sync_state != SYNC_FINE || routed_partitions_for_psmi(psmi) > PM_PART) atomicAdd(&db.counters[2], 1);   // ... and the PX kernels
-    const Prepared p = prepare_values_of(v, acq_ran);
+    const Prepared p = prepare_values_of(v, acq_ran, db.nco_tab ? db.nco_policy : NCO_CLOSED_FORM);
     st.active = p.active;
     if (!p.active) {
         if (p.pending) atomicAdd(&db.counters[0], 1);          // work is pending: the host must keep stepping
@@ -155,6 +186,9 @@ __device__ inline void prepare_block(const DevBuffers &db, StreamState &st, int 
     st.samperr_cur = p.samperr;
     st.dtheta = p.dtheta;
     st.growth = p.growth;
+    st.nco_mode = p.nco_mode;
+    if (p.nco_mode) { st.nco_re = p.ph_re; st.nco_im = p.ph_im; st.inc_re = p.inc_c; st.inc_im = p.inc_s; }
+    else st.nco_exact = 0;                                     // a block on the closed-form phasor: the float state is no longer the reference's
     st.theta = p.theta;
 }
 

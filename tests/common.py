@@ -53,6 +53,9 @@ LOOSE_IN_FALSE_LOCK = {"phase_re": 5e-3, "phase_im": 5e-3, "freq_offset": 1e-2, 
 
 
 def float_close(key: str, va: float, vb: float, rtol: float = FLOAT_RTOL, false_lock: bool = False) -> bool:
+    # false lock: the loose bound is an ADDITIONAL way to pass, not a replacement -- every rule below holds for any record (they bound what two
+    # correct float implementations differ by on a tracked signal), so a falsely locked record that happens to satisfy one of them is equal in the
+    # same sense; falling through cannot admit anything the rules would not admit on a clean record
     if false_lock and rtol > 0 and abs(va - vb) <= LOOSE_IN_FALSE_LOCK.get(key, rtol * max(1.0, abs(va))):
         return True
     if key in ABS_ONLY and rtol > 0:
@@ -147,6 +150,7 @@ def compare_logs(expected, got, rtol: float = FLOAT_RTOL, skip_kinds=("hdc", "so
     if first_bad is not None:
         start = max([i for i, (k, _) in enumerate(exp[:first_bad]) if k == "sync"], default=0)
         loose = set(range(start, len(exp)))
+    mer_exempt0 = EXEMPT["mer_within_0.01dB"]
     for i, (a, b) in enumerate(zip(exp, g)):
         for k, va in a[1].items():
             vb = b[1][k]
@@ -158,6 +162,13 @@ def compare_logs(expected, got, rtol: float = FLOAT_RTOL, skip_kinds=("hdc", "so
                     diffs.append(f"#{i} {a[0]}.{k}: expected {va!r} got {vb!r}")
             elif va != vb:
                 diffs.append(f"#{i} {a[0]}.{k}: expected {va!r} got {vb!r}")
+    # the counted MER exemption has a ceiling per log: it exists for a handful of reports with near-singular equaliser cells (a channel notch,
+    # an interference burst), not for an equaliser that is off by a few thousandths of a dB everywhere.  Measured on the device: 24 / 11 / 16 of the
+    # ~6 600 MER values of a 256-stream FM batch (three batch seeds, gpurun r05a), 0 of an AM batch.
+    n_mer = 2 * sum(1 for k, _ in exp if k == "mer")
+    used = EXEMPT["mer_within_0.01dB"] - mer_exempt0
+    if used > max(4, n_mer // 4):
+        diffs.append(f"#0 mer.exempt_count: expected {max(4, n_mer // 4)} got {used}")
     return diffs
 
 

@@ -1207,3 +1207,36 @@ def check_traceback_variants(lib):
     assert res[0][0] == res[1][0] and len(res[0][1]) == len(res[1][1]) == 2
     assert all(np.array_equal(a, b) for a, b in zip(res[0][1], res[1][1]))
     assert res[0][2] == (0, 0) and res[1][2][0] == 2 * 2284 and 20 <= res[1][2][1] <= 2000, res[1][2]
+
+
+def check_exact_oscillator_first_block(lib, reflib, bit_exact_min, policies=(0, 1, 2, 3), n=6):
+    """Exact-oscillator mode (NRSC5HIP_TUNE_NCO_EXACT, k_nco_exact; DESIGN.md (c) limit 2).  The first block after a reset -- the block the
+    CFO search runs on -- starts from acquire_t.phase = 1 and a coarse angle whose inputs the acquisition kernels reproduce bit for bit, so with
+    policy >= 1 the NCO state the block leaves behind (69 120 float complex multiplications and 32 renormalisations later) must be the UNMODIFIED
+    reference's, bit for bit, wherever the one libm call in between (atan2f of the coarse peak) returns the same float: always on the CPU emulator
+    (same glibc), in >= bit_exact_min of n captures on the device.  With policy 0 (closed form) it is not.  Every policy keeps the complete log
+    inside the float tolerances."""
+    exact = {p: 0 for p in policies}
+    worst = {p: 0.0 for p in policies}
+    for k in range(n):
+        cap = synth.fm_mp1_capture(0, seed=300 + k, cfo_hz=(-1, 1)[k & 1] * (190.0 + 17.0 * k), offset=211 * k + 5, snr_db=(15.0, 20.0, 25.0)[k % 3], n_blocks=20)
+        ref_log = reflib.run(cap.iq)[0]
+        rb = [v for kk, v in ref_log if kk == "block"]
+        for pol in policies:
+            E, recs, log = run_capture(lib, cap, tune=((eng.TUNE_NCO_EXACT, pol),))
+            E.close()
+            diffs = common.compare_logs(common.strip_states(ref_log), common.strip_states(log))
+            assert not [d for d in diffs if " frame." in d or " pids." in d or " sync." in d], (k, pol, diffs[:5])
+            gb = [v for kk, v in log if kk == "block"]
+            a, b = rb[0], gb[0]
+            same = np.float32(a["phase_re"]) == np.float32(b["phase_re"]) and np.float32(a["phase_im"]) == np.float32(b["phase_im"])
+            exact[pol] += int(same)
+            worst[pol] = max(worst[pol], abs(a["phase_re"] - b["phase_re"]), abs(a["phase_im"] - b["phase_im"]))
+    print("first-block NCO state bit-identical to the reference (of %d captures):" % n, exact, "largest |difference|:", {p: float("%.2g" % w) for p, w in worst.items()})
+    for pol in policies:
+        if pol >= 1:
+            assert exact[pol] >= bit_exact_min, (pol, exact, worst)
+            assert worst[pol] < 1e-4, (pol, worst)
+    if 0 in policies:
+        assert exact[0] < n, "the closed-form phasor cannot reproduce the recurrence's rounding drift"
+    return exact, worst

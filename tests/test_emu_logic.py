@@ -254,3 +254,7 @@ def test_emu_symbol_kernel_256_lanes(emu_lib, oracle, captures):
 
 def test_emu_traceback_variants(emu_lib):
     ec.check_traceback_variants(emu_lib)
+
+
+def test_emu_exact_oscillator_first_block_is_the_references(emu_lib, reflib):
+    ec.check_exact_oscillator_first_block(emu_lib, reflib, bit_exact_min=4, n=4)

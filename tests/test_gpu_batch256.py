@@ -24,7 +24,7 @@ def batch_params(k: int):
     return prm
 
 
-def run_batch_against_reference(lib, dev, streams, n_frames=N_FRAMES, payloads=8, processes=0):
+def run_batch_against_reference(lib, dev, streams, n_frames=N_FRAMES, payloads=8, processes=0, tune=()):
     """-> (bench.reference_equality-style summary, per-stream logs kept for diagnosis)"""
     import argparse
     import torch
@@ -44,6 +44,8 @@ def run_batch_against_reference(lib, dev, streams, n_frames=N_FRAMES, payloads=8
         nbytes[k] = out.shape[0] - out.shape[0] % 4
     E = eng.Engine(max_streams=S_, q15_capacity=2 * 71280, record_capacity=max(512, 2 * 16 * n_frames + 64), p1_slots=n_frames + 12, p1_async=True,
                    l2_feedback=True, batch_zero_copy=True, lib_path=lib)
+    for knob, value in tune:
+        E.tune(knob, value)
     E.batch_append_cu8(iq.data_ptr(), stride, nbytes)
     steps = E.batch_process(S_)
     recs, counts, frames = E.batch_fetch_view(S_)

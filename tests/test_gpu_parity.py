@@ -430,3 +430,9 @@ def test_gpu_symbol_kernel_256_lanes(hip_lib, oracle, captures):
 def test_gpu_traceback_variants(hip_lib):
     """single-path traceback == block-parallel traceback (records incl. the BER count, frames) on a capture with a noise frame"""
     ec.check_traceback_variants(hip_lib)
+
+
+def test_gpu_exact_oscillator_first_block_is_the_references(hip_lib, reflib):
+    """on the device the coarse angle goes through OCML's atan2f instead of glibc's (one ulp apart for ~16 % of arguments): bit-identical NCO
+    state in at least half of the captures, never more than 1e-4 away"""
+    ec.check_exact_oscillator_first_block(hip_lib, reflib, bit_exact_min=3, n=6)
