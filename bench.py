@@ -179,10 +179,12 @@ _DIFF_RE = re.compile(r"#(\d+) (\w+)\.(\w+): (?:(\d+) elements differ)?(?:expect
 # within AFTER_LOCK records of a SYNC event.  (Measured on the 256-stream batch, all streams compared: 250 streams equal under the strict
 # rule, 6 with transient deviations -- 4 roundf() flips, 2 CFO-search locks: MER 0.24 dB, prev_angle 3.6e-4 -- 0 with anything else.)
 TRANSIENT_INT = {"samperr", "keep", "next_samperr"}
-TRANSIENT_ABS = {"next_angle": 5e-3, "phase_re": 5e-2, "phase_im": 5e-2}
+TRANSIENT_ABS = {"next_angle": 3e-4, "phase_re": 7e-3, "phase_im": 7e-3}   # round 5: 2 x what ~800 CFO-search locks on the MI355X showed (1.2e-4 / 3.2e-3); round 4 had 5e-3 / 5e-2
 TRANSIENT_DETAILS = []                # the first deviations counted as transient, verbatim (per process)
 TRANSIENT_STREAM_BUDGET_PCT = 5      # measured: 6 of 256 streams (2.3 %); more than 5 % of the compared streams fails the run
-AFTER_LOCK, AFTER_LOCK_ABS, AFTER_LOCK_REL = 40, {"lower": 0.5, "upper": 0.5}, {"prev_angle": 1e-3}
+# round 5: 0.2 dB (0.5 in round 4): with the oscillator's amplitude and the exact first block on the device the largest first-MER deviation of a counted lock is
+# 0.078 dB in 2400 CFO-search locks on the CPU twin and 0.069 dB on the MI355X; the tail beyond (one lock in ~500 on the device: 0.57 dB, a timing pick by 3 samples) FAILS the run
+AFTER_LOCK, AFTER_LOCK_ABS, AFTER_LOCK_REL = 40, {"lower": 0.2, "upper": 0.2}, {"prev_angle": 1e-3}
 
 
 def compare_with_reference(ref_log, got_log, am: bool):
@@ -311,11 +313,11 @@ def _parity_worker(tasks, results):
             run, kind = checkers[am]
             ref_log = run(iq)
             del TRANSIENT_DETAILS[:]
-            e0 = common.EXEMPT["mer_within_0.01dB"]
+            e0, n0 = common.EXEMPT["mer_within_0.01dB"], common.EXEMPT["mer_below_0dB_within_0.1dB"]
             diffs, nex, mb, ntr = compare_with_reference(ref_log, got_log, am)
-            results.put((key, kind, diffs, nex, mb, ntr, int(common.EXEMPT["mer_within_0.01dB"] - e0), list(TRANSIENT_DETAILS)))
+            results.put((key, kind, diffs, nex, mb, ntr, (int(common.EXEMPT["mer_within_0.01dB"] - e0), int(common.EXEMPT["mer_below_0dB_within_0.1dB"] - n0)), list(TRANSIENT_DETAILS)))
         except Exception as ex:                                     # a checker that raises is a failure of the run, never a silent skip
-            results.put((key, "error", [f"checker raised {ex!r}"], 0, 0, 0, 0, []))
+            results.put((key, "error", [f"checker raised {ex!r}"], 0, 0, 0, (0, 0), []))
 
 
 _POOL = None
@@ -373,14 +375,14 @@ def reference_equality(W, recs, counts, frames, to_log, am: bool):
     pool = parity_pool(a)
     todo = lost_checked + pick
     res = pool.run((k, W.stream_iq(k), am, to_log(k, recs[k, :counts[k]], frames[k])) for k in todo)
-    eq_lost = eq_other = strict = exempt = max_bits = tr_streams = tr_fields = imp_checked = imp_equal = mer_exempt = 0
+    eq_lost = eq_other = strict = exempt = max_bits = tr_streams = tr_fields = imp_checked = imp_equal = mer_exempt = mer_noise = 0
     first_diffs, tr_details, classes, kind = [], [], {}, "reference"
     lost_set = set(lost_checked)
     for k in todo:
         _, knd, diffs, nex, mb, ntr, nmer, details = res[k]
         if knd != "error":
             kind = knd
-        exempt += nex; max_bits = max(max_bits, mb); tr_streams += ntr > 0; tr_fields += ntr; strict += (not diffs and ntr == 0); mer_exempt += nmer
+        exempt += nex; max_bits = max(max_bits, mb); tr_streams += ntr > 0; tr_fields += ntr; strict += (not diffs and ntr == 0); mer_exempt += nmer[0]; mer_noise += nmer[1]
         imp_checked += W.impaired(k); imp_equal += (W.impaired(k) and not diffs)
         tr_details += [f"stream {int(W.my_streams[k])}: {d}" for d in details[:3]]
         if not diffs:
@@ -398,7 +400,7 @@ def reference_equality(W, recs, counts, frames, to_log, am: bool):
            "streams_with_lost_sync_this_pass": len(lost), "lost_sync_streams_checked": len(lost_checked), "lost_sync_streams_equal": eq_lost,
            "other_streams_checked": len(pick), "other_streams_equal": eq_other,
            "impaired_channel_streams_checked": int(imp_checked), "impaired_channel_streams_equal": int(imp_equal),
-           "mer_reports_beyond_1e-4_within_0.01dB": int(mer_exempt),
+           "mer_reports_beyond_1e-4_within_0.01dB": int(mer_exempt), "mer_reports_below_0dB_within_0.1dB": int(mer_noise),
            "frames_exempt_cber": exempt, "exempt_max_bit_differences": max_bits,
            "streams_equal_under_the_strict_rule": strict,
            "streams_with_transient_loop_state_deviation": tr_streams, "transient_loop_state_fields": tr_fields,
@@ -409,7 +411,7 @@ def reference_equality(W, recs, counts, frames, to_log, am: bool):
                        f"transient_loop_state = block fields samperr / keep / next_samperr off by at most 1 sample, next_angle by at most {TRANSIENT_ABS['next_angle']:g}, the NCO phase by at most {TRANSIENT_ABS['phase_re']:g}, and -- only within {AFTER_LOCK} "
                        f"records after a SYNC event -- a MER report by at most {AFTER_LOCK_ABS['lower']:g} dB and prev_angle by at most {AFTER_LOCK_REL['prev_angle']:g} relative (a CFO-search lock or a roundf() threshold flip, DESIGN (c) limit 2); "
                        "mer_reports_beyond_1e-4_within_0.01dB = MER reports (a sum of squared equaliser errors, printed with one decimal by the reference) that differ by more than 1e-4 of the "
-                       "power ratio but less than 0.01 dB: near-singular equaliser cells in channel notches / interference (tests/common.py). The run FAILS when more than "
+                       "power ratio but less than 0.01 dB: near-singular equaliser cells in channel notches / interference (tests/common.py); mer_reports_below_0dB_within_0.1dB = reports of a sideband the reference itself rates below 0 dB (noise to the receiver), within 0.1 dB. The run FAILS when more than "
                        f"{TRANSIENT_STREAM_BUDGET_PCT} % of the compared streams carry a transient deviation; streams_failing_by_class names what a failing stream differs in "
                        "(p1_px_frame_bits / pids_frame_bits: a decoded frame; timing_pick_beyond_1_sample; <record>_<field>: a float beyond its bound)."}
     if tr_streams * 100 > TRANSIENT_STREAM_BUDGET_PCT * max(1, len(todo)):

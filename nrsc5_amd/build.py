@@ -81,6 +81,8 @@ def build_emu(force: bool = False) -> str:
 if __name__ == "__main__":
     if "--emu" in sys.argv:
         print(build_emu(force=True))
+    elif "--accurate-trig" in sys.argv:
+        print(build_hip_diag(["-DNRSC5HIP_ACCURATE_TRIG"], "libnrsc5hip_acctrig.so"))
     elif "--mixfft-phases" in sys.argv:
         print(build_hip_diag(["-DNRSC5HIP_MIXFFT_PHASES"], "libnrsc5hip_mixphases.so"))
     else:

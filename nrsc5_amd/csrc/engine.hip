@@ -1343,7 +1343,9 @@ static int upload_ids(nrsc5hip_engine *e, int n, const int *ids, const uint32_t 
         HIPCHK(hipMemcpy(e->ids_dev, ids, n * sizeof(int), hipMemcpyHostToDevice));
         *ids_dev = e->ids_dev;
     } else {
-        *ids_dev = e->all_ids_dev;
+        // the identity set: every kernel resolves `ids ? ids[i] : i` (stream_of), and without the list the stream index costs no trip to memory in
+        // front of the stream-state loads that depend on it (k_mixfft / k_sync begin with exactly that chain)
+        *ids_dev = nullptr;
     }
     if (counts) HIPCHK(hipMemcpy(e->nbytes_dev, counts, n * sizeof(unsigned), hipMemcpyHostToDevice));
     return 0;

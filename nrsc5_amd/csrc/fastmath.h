@@ -15,6 +15,8 @@ __device__ __forceinline__ void fast_sincos(float x, float &s, float &c)
 {
 #ifdef HIPEMU
     s = sinf(x); c = cosf(x);
+#elif defined(NRSC5HIP_ACCURATE_TRIG)                           // diagnostic build (tools/gpu_cfo_batch.py --accurate): double-precision libm, rounded once
+    s = (float)sin((double)x); c = (float)cos((double)x);
 #else
     const double t = (double)x * 0.15915494309189533577;       // revolutions
     const float f = (float)(t - rint(t));                      // [-0.5, 0.5], exact to float precision for any float x
@@ -28,6 +30,8 @@ __device__ __forceinline__ void fast_sincos_reduced(float x, float &s, float &c)
 {
 #ifdef HIPEMU
     s = sinf(x); c = cosf(x);
+#elif defined(NRSC5HIP_ACCURATE_TRIG)
+    s = (float)sin((double)x); c = (float)cos((double)x);
 #else
     const float f = x * 0.15915494309189533577f;
     s = __builtin_amdgcn_sinf(f);
@@ -39,6 +43,8 @@ __device__ __forceinline__ float fast_atan2(float y, float x)
 {
 #ifdef HIPEMU
     return atan2f(y, x);
+#elif defined(NRSC5HIP_ACCURATE_TRIG)
+    return (float)atan2((double)y, (double)x);
 #else
     const float ax = fabsf(x), ay = fabsf(y);
     const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);

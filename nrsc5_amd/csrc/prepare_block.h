@@ -107,10 +107,18 @@ template <typename S> __device__ inline Prepared prepare_values_of(const S &st, 
     } else {
         p.samperr = st.coarse_samperr;
         // angle_diff = arg(max_v * e^{-i prev_angle})        (acquire.c:153)
+#ifdef NRSC5HIP_ACCURATE_TRIG
+        const float sn = (float)sin((double)-st.prev_angle), cs = (float)cos((double)-st.prev_angle);
+#else
         float sn, cs; sincosf(-st.prev_angle, &sn, &cs);
+#endif
         const float pr = st.coarse_re * cs - st.coarse_im * sn;
         const float pi = st.coarse_re * sn + st.coarse_im * cs;
+#ifdef NRSC5HIP_ACCURATE_TRIG
+        const float angle_diff = (float)atan2((double)pi, (double)pr);
+#else
         const float angle_diff = atan2f(pi, pr);
+#endif
         const float angle_factor = (st.prev_angle != 0.0f) ? 0.25f : 1.0f;
         angle = st.prev_angle + (angle_diff * angle_factor);
         p.to_coarse = st.sync_state != SYNC_COARSE;

@@ -10,13 +10,17 @@ def main():
     import torch
     from nrsc5_amd import engine as eng
     from tests import test_gpu_batch256 as t
-    bases = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "0,256").split(",")]
-    pols = [int(x) for x in (sys.argv[2] if len(sys.argv) > 2 else "0,1,2,3").split(",")]
+    argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+    bases = [int(x) for x in (argv[0] if len(argv) > 0 else "0,256").split(",")]
+    pols = [int(x) for x in (argv[1] if len(argv) > 1 else "0,1,2,3").split(",")]
     dev = torch.device("cuda", 0)
+    lib = eng.DEFAULT_LIB
+    if "--accurate" in sys.argv:                                # diagnostic twin: double-precision sine / cosine / arc tangent in the Costas loops (python -m nrsc5_amd.build --accurate-trig)
+        lib = os.path.join(ROOT, "nrsc5_amd", "libnrsc5hip_acctrig.so")
     for b in bases:
         for p in pols:
             t0 = time.time()
-            out = t.run_batch_against_reference(eng.DEFAULT_LIB, dev, list(range(b, b + t.S)), tune=((eng.TUNE_NCO_EXACT, p),))
+            out = t.run_batch_against_reference(lib, dev, list(range(b, b + t.S)), tune=((eng.TUNE_NCO_EXACT, p),))
             print(json.dumps({"base": b, "policy": p, "cfo_search_locks": out["first_locks_with_integer_cfo"], "strict": out["streams_equal_under_the_strict_rule"],
                               "transient_streams": out["streams_with_transient_loop_state_deviation"], "failing_by_class": out["streams_failing_by_class"],
                               "block_steps": out["block_steps"], "seconds": round(time.time() - t0, 1),
