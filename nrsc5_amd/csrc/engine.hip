@@ -492,7 +492,11 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if ((rc = dev_alloc(e, &db.bins, S * NSYM * LIVE_N))) break;
         // the reference's oscillator sample by sample for blocks in exact mode (553 KB per stream; k_nco_exact -> k_mixfft)
         if ((rc = dev_alloc(e, &db.nco_tab, S * NSYM * SYM_N))) break;
-        db.nco_policy = NCO_EXACT_FIRST_BLOCK;
+        // Default: the closed-form phasor with the reference oscillator's amplitude ramp (NCO_CLOSED_FORM).  Measured (DESIGN.md (c) limit 2): on the CPU twin,
+        // whose libm is the reference's, the exact first block takes the locks after a CFO search that deviate in loop-internal state from 5 to 2 in 900 (18
+        // without the ramp); on the MI355X the deviating streams of two 256-stream CFO-search batches are the same under every policy (other last-bit
+        // differences of the device's arithmetic trigger them), while k_nco_exact costs 1.3 ms of a 29 ms pass.  nrsc5hip_debug_tune(NRSC5HIP_TUNE_NCO_EXACT) turns it on.
+        db.nco_policy = NCO_CLOSED_FORM;
         if ((rc = dev_alloc(e, &db.pm, S * NPM * PM_FRAME))) break;
         db.nstreams_alloc = (int)S;
         if ((rc = dev_alloc(e, &db.coded, (size_t)(cfg->p1_async ? NAUX : 1) * S * P1_LEN))) break;
@@ -756,7 +760,7 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
     const int slot = async ? (int)(ln.step_count % 16) : 0;
     // batch pipeline: once every stream of the set is FINE, the next block's bookkeeping rides in k_sync's tail
     const int fuse = (async && !ln.acq_needed) ? 1 : 0;
-    { ProfScope p(e, NRSC5HIP_PROF_SYNC, ln.main); launch_sync(e->tb, ln.db, n, ids_dev, parity, slot, fuse, (int)window, ln.main, e->sync_lanes, decode_pids ? 0 : 1, fused_prepare ? 1 : 0); }
+    { ProfScope p(e, NRSC5HIP_PROF_SYNC, ln.main); launch_sync(e->tb, ln.db, n, ids_dev, parity, slot, fuse, (int)window, ln.main, e->sync_lanes, decode_pids ? 0 : 1, fused_prepare ? 1 : 0, ln.px_needed ? 1 : 0); }
     ln.prepared_by_sync = fuse != 0;
     if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_px_deint(e->tb, ln.db, n, ids_dev, parity, slot, ln.main); }
     if (!async) {

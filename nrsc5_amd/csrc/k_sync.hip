@@ -229,7 +229,7 @@ __device__ __forceinline__ void store_px(int8_t *pair, float2 v, int side, int p
 #define SYNC_OCCUPANCY(NT)
 #endif
 template <int SYNC_NT>
-__global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare, int window, int pids_inline, int do_prepare)
+__global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare, int window, int pids_inline, int do_prepare, int ext_refs)
 {
     wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
     const int s = wave_uniform(stream_of(ids, blockIdx.x));    // in a scalar register: every address derived from it stays off the VGPR budget
@@ -246,12 +246,33 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
     const int tid = threadIdx.x;
     constexpr int NREFBIN = (NREF_MAX * NSYM + SYNC_NT - 1) / SYNC_NT;
     const int e_active = st.active, e_nblocks = st.nblocks, e_samperr = st.samperr_cur, e_psmi = st.psmi;
+    // (round 5) ... and the words the later phases used to fetch one dependent trip at a time (profiles/r04_sync_lanes.txt, "what is still exposed"): the
+    // tracking state and block count every work-item tests behind the barrier that opens the equalising phase, the frame hand-off words and the MER
+    // accumulators work-item 0 reads between its stores, the PIDS gather index of this block count.  A block that LOCKS rewrites some of them (work-item 0,
+    // COARSE section): it publishes the new values in LDS (sh_i[4..6]) and the copies below are replaced there.
+    // One word per work-item (work-items 0 .. PRE_N - 1), parked in LDS at the first barrier: held in registers across the kernel the ten values and the
+    // gather index cost 11 spilled VGPRs and 204 spilled SGPRs of the 80-register budget (the 12-wave workgroup must fit beside the decode waves).
+    enum { PRE_STATE, PRE_BC, PRE_PXS, PRE_STARTED_PM, PRE_P1_COUNT, PRE_FINE_EPOCH, PRE_PM_SLOT, PRE_MER_CNT, PRE_ERR_LB, PRE_ERR_UB, PRE_N };
+    int e_word = 0;
+    {
+        const int *w = &st.sync_state;
+        w = tid == PRE_BC ? &st.bc : tid == PRE_PXS ? &st.px_started : tid == PRE_STARTED_PM ? &st.started_pm : tid == PRE_P1_COUNT ? &st.p1_count : w;
+        w = tid == PRE_FINE_EPOCH ? &st.fine_epoch : tid == PRE_PM_SLOT ? &st.pm_slot : tid == PRE_MER_CNT ? &st.mer_cnt : w;
+        w = tid == PRE_ERR_LB ? (const int *)&st.error_lb : tid == PRE_ERR_UB ? (const int *)&st.error_ub : w;
+        if (tid < PRE_N) e_word = *w;
+    }
+    const int e_bc_v = st.bc;                                  // (every work-item: the gather index below needs it before anything is in LDS)
+    // ext_refs = 0: the host's last look at the counters found every stream FINE on 10 partitions per sideband (MP1: the engine's px_needed flag), so only
+    // the 22 carriers of that set are fetched here; a stream that turns out to need more (it re-locked on another service mode since that look) fetches
+    // the rest below, one dependent trip later.  With the largest set fetched for every stream the pass read 2.3 GB it never used (whole path 3.11 -> 3.25 x).
     float2 e_bin[NREFBIN];
+    constexpr int NCOMMON = 2 * (PM_PART + 1) * NSYM;          // 704 bins: the reference carriers of 10 partitions per sideband
     {
         const float2 *bins0 = db.bins + (size_t)s * NSYM * LIVE_N;
 #pragma unroll
         for (int i = 0; i < NREFBIN; i++) {
-            const int k = min(tid + i * SYNC_NT, NREF_MAX * NSYM - 1);           // (clamped, not predicated: no branch between the loads)
+            int k = min(tid + i * SYNC_NT, NREF_MAX * NSYM - 1);                  // (clamped, not predicated: no branch between the loads)
+            if (!ext_refs) k = min(k, NCOMMON - 1);                              // (block-uniform condition; the clamped lanes re-read a line that is fetched anyway)
             e_bin[i] = bins0[(k % NSYM) * LIVE_N + bin_to_live(ref_bin(k / NSYM))];
         }
     }
@@ -263,6 +284,9 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
         if (fuse_prepare && threadIdx.x == 0) prepare_block(db, st, s, false);
         return;
     }
+    // second burst (the first has arrived: e_active was needed): where this block count's PIDS cells sit in the soft-bit rows (decode.c:324-342) -- a table
+    // load that feeds an address, in flight from here to the first barrier instead of in front of the gather
+    const int e_gather = tb.pids_gather[(e_bc_v & 15) * PIDS_CODED + min(tid, PIDS_CODED - 1)];
     constexpr int SYNC_NW = SYNC_NT / 64;
     // phase instrumentation (nrsc5hip_debug_sync_phases): the running time stamp lives in LDS -- as a variable it was a register pair
     // alive across the whole kernel, spilled and reloaded around every barrier
@@ -291,10 +315,14 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
     __shared__ uint32_t sh_pids_out[4];
     __shared__ int sh_seen[16 + 64];
     __shared__ float ref_freq[NREF_MAX];
+    __shared__ int sh_pre[PRE_N];
+    __shared__ uint16_t sh_gather[PIDS_CODED];
+    static_assert(PM_BLOCK <= 65536, "a gather index fits 16 bits");
     if (tid == 0) { sh_i[2] = 0; sh_i[3] = 0; }                // [2] set when this block completes a P1 frame (replay checkpoint below), [3] when a PIDS frame was decoded here
 
     float2 *bins = db.bins + (size_t)s * NSYM * LIVE_N;       // [sym][live]
-    BlockRecord &rec = db.records[(size_t)s * db.rec_cap + (wave_uniform(e_nblocks) % db.rec_cap)];
+    const int nblocks0 = wave_uniform(e_nblocks);
+    BlockRecord &rec = db.records[(size_t)s * db.rec_cap + (nblocks0 % db.rec_cap)];
     const LoopGains g = loop_gains();
     const int samperr = wave_uniform(e_samperr);
     const int ppb = partitions_for_psmi(wave_uniform(e_psmi));
@@ -313,8 +341,13 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
 #pragma unroll
     for (int i = 0; i < NREFBIN; i++) {
         const int k = tid + i * SYNC_NT;
-        if (k < nref * NSYM) refz[k / NSYM][k % NSYM] = e_bin[i];
+        if (k < nref * NSYM) {
+            if (!ext_refs && k >= NCOMMON) e_bin[i] = bins[(k % NSYM) * LIVE_N + bin_to_live(ref_bin(k / NSYM))];   // the host's hint was stale for this stream
+            refz[k / NSYM][k % NSYM] = e_bin[i];
+        }
     }
+    if (tid < PRE_N) sh_pre[tid] = e_word;
+    if (tid < PIDS_CODED) sh_gather[tid] = (uint16_t)e_gather;
     __syncthreads();
     SYNC_MARK(0);
 
@@ -335,7 +368,7 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
     SYNC_MARK(1);
 
     // ---- COARSE: try to lock (sync.c:366-423)
-    if (st.sync_state == SYNC_COARSE) {
+    if (sh_pre[PRE_STATE] == SYNC_COARSE) {
         if (tid < nref) {
             // decode_ref_fm (sync.c:169-186)
             uint32_t d = 0;
@@ -367,6 +400,7 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
                     st.sync_state = SYNC_FINE; st.fine_epoch++;
                     st.started_pm = 0;                         // decode_reset (decode.c:563-572)
                     st.px_pos = 0; st.px_ready = 0; st.px_started = 0;   // interleaver_iv_reset
+                    sh_i[4] = maj_bc; sh_i[5] = maj_psmi;              // the copies of the head burst are stale from here on
                     action = 1;
                 }
             } else if (st.cfo_wait == 0) {
@@ -437,12 +471,17 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
 
     SYNC_MARK(2);
     // ---- FINE: equalise, measure, demodulate (sync.c:425-609)
-    if (st.sync_state == SYNC_FINE) {
-        const int bc = st.bc;
+    // (state / block count / service mode from the head burst -- unless this very block locked: then work-item 0 has just written them)
+    const bool locked_now = sh_pre[PRE_STATE] == SYNC_COARSE && sh_i[0] == 1;
+    const int state_now = locked_now ? (int)SYNC_FINE : sh_pre[PRE_STATE];
+    if (state_now == SYNC_FINE) {
+        const int bc = locked_now ? sh_i[4] : sh_pre[PRE_BC];
+        const int psmi_now = locked_now ? sh_i[5] : wave_uniform(e_psmi);
+        const int pxs_now = locked_now ? 0 : sh_pre[PRE_PXS];
         // The block that achieves lock keeps equalising with the partition count of the PREVIOUS service mode (computed at
         // the top of sync_process_fm, sync.c:343-358) but already routes PX soft bits by the new one (sync.c:537-596).
-        const int ppb_px = routed_partitions_for_psmi(st.psmi);
-        const bool px_on = ppb_px > PM_PART && (st.px_started || (bc & 1) == 0);   // decode_push_px1/2 (decode.c:393-437)
+        const int ppb_px = routed_partitions_for_psmi(psmi_now);
+        const bool px_on = ppb_px > PM_PART && (pxs_now || (bc & 1) == 0);   // decode_push_px1/2 (decode.c:393-437)
         for (int k = tid; k < nref * NSYM; k += SYNC_NT) {
             const int r = k / NSYM, n = k % NSYM;
             float sn, cs; fast_sincos(refph[r][n], sn, cs);
@@ -527,14 +566,17 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
             double sl = 0.0, su = 0.0;
             for (int w = 0; w < SYNC_NW; w++) { sl += red[0][w]; su += red[1][w]; }
             const float error_lb = (float)sl, error_ub = (float)su;
-            st.error_lb += error_lb; st.error_ub += error_ub;
-            if (++st.mer_cnt == 16) {                          // EVENT_MER every 16 blocks (sync.c:490-501)
-                const float signal = (float)(2 * NSYM * (ppb * 18) * st.mer_cnt);
-                rec.mer_lb = 10 * log10f(signal / st.error_lb);
-                rec.mer_ub = 10 * log10f(signal / st.error_ub);
+            // (accumulators and counter from the head burst: nothing else in this kernel writes them)
+            float acc_lb = __builtin_bit_cast(float, sh_pre[PRE_ERR_LB]) + error_lb, acc_ub = __builtin_bit_cast(float, sh_pre[PRE_ERR_UB]) + error_ub;
+            int cnt = sh_pre[PRE_MER_CNT] + 1;
+            if (cnt == 16) {                                   // EVENT_MER every 16 blocks (sync.c:490-501)
+                const float signal = (float)(2 * NSYM * (ppb * 18) * cnt);
+                rec.mer_lb = 10 * log10f(signal / acc_lb);
+                rec.mer_ub = 10 * log10f(signal / acc_ub);
                 rec.flags |= REC_MER;
-                st.mer_cnt = 0; st.error_lb = 0; st.error_ub = 0;
+                cnt = 0; acc_lb = 0; acc_ub = 0;
             }
+            st.error_lb = acc_lb; st.error_ub = acc_ub; st.mer_cnt = cnt;
             const float mer_lb = 2.0f * NSYM * (float)(ppb * 18) / error_lb;
             const float mer_ub = 2.0f * NSYM * (float)(ppb * 18) / error_ub;
             sh_f[1] = fmaxf(fminf(mer_lb * 10, 127.0f), 1.0f);
@@ -547,7 +589,7 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
         // primary-main soft bits -> row `bc` of the stream's 16 x 32 x 720 interleaver matrix (decode.c:380).
         // Partitions 0..9 = lower sideband from the edge; 10..19 = upper sideband in ascending frequency
         // (sync.c:514-536): the upper-sideband cell of partition `part` (from the edge) is matrix partition 19 - part.
-        const int pm_slot = st.pm_slot;
+        const int pm_slot = sh_pre[PRE_PM_SLOT];
         int8_t *pm_blk = db.pm + ((size_t)s * NPM + pm_slot) * PM_FRAME + (size_t)bc * PM_BLOCK;
         if (ppb == PM_PART) {
             // the 11520 two-byte cells of the block's 32 x 720 soft-bit rows are assembled in LDS and leave in 16-byte rows:
@@ -590,7 +632,7 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
             // streaming seam (block-uniform): the 80-bit frame is decoded right here, by the second wave, while the first lane does the
             // block's bookkeeping and the record -- as its own launch (or in the report kernel) it was 10-20 us on a chain the host
             // waits for
-            for (int n = tid; n < PIDS_CODED; n += SYNC_NT) sh_pids_coded[n + n / 5] = pm_src[tb.pids_gather[bc * PIDS_CODED + n]];
+            for (int n = tid; n < PIDS_CODED; n += SYNC_NT) sh_pids_coded[n + n / 5] = pm_src[!locked_now ? (int)sh_gather[n] : (int)tb.pids_gather[bc * PIDS_CODED + n]];
             for (int n = tid; n < PIDS_CODED / 5; n += SYNC_NT) sh_pids_coded[6 * n + 5] = 0;
             __syncthreads();
             if ((tid >> 6) == 1) {
@@ -603,32 +645,36 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
                 }
             }
         } else {
-            for (int n = tid; n < PIDS_CODED; n += SYNC_NT) stage[n + n / 5] = pm_src[tb.pids_gather[bc * PIDS_CODED + n]];
+            for (int n = tid; n < PIDS_CODED; n += SYNC_NT) stage[n + n / 5] = pm_src[!locked_now ? (int)sh_gather[n] : (int)tb.pids_gather[bc * PIDS_CODED + n]];
             for (int n = tid; n < PIDS_CODED / 5; n += SYNC_NT) stage[6 * n + 5] = 0;
         }
         SYNC_MARK(6);
         if (tid == 0) {
-            if (!pids_inline) db.pids_rec[((size_t)s * NWIN + parity) * 16 + slot] = st.nblocks % db.rec_cap;
+            // (hand-off words from the head burst: read here they were five loads, each behind the previous store)
+            int started_pm = locked_now ? 0 : sh_pre[PRE_STARTED_PM];    // decode_reset at the lock (above)
+            const int fine_epoch = sh_pre[PRE_FINE_EPOCH] + (locked_now ? 1 : 0);
+            const int e_p1_count = sh_pre[PRE_P1_COUNT];
+            if (!pids_inline) db.pids_rec[((size_t)s * NWIN + parity) * 16 + slot] = nblocks0 % db.rec_cap;
             else sh_i[3] = 1;                                  // the tail files the frame
             rec.flags |= REC_PIDS;
             rec.bc_decoded = bc;
-            if (bc == 0) st.started_pm = 1;                    // decode.c:383-390
-            if (st.started_pm && bc == 15) {
-                const int slot = st.p1_count % db.p1_slots;
-                st.p1_count++;
-                st.p1_pending[parity] = 1; st.p1_slot[parity] = slot; st.p1_record[parity] = st.nblocks % db.rec_cap; st.p1_epoch[parity] = st.fine_epoch;
+            if (bc == 0) { started_pm = 1; st.started_pm = 1; }   // decode.c:383-390
+            if (started_pm && bc == 15) {
+                const int slot = e_p1_count % db.p1_slots;
+                st.p1_count = e_p1_count + 1;
+                st.p1_pending[parity] = 1; st.p1_slot[parity] = slot; st.p1_record[parity] = nblocks0 % db.rec_cap; st.p1_epoch[parity] = fine_epoch;
                 st.p1_pmslot[parity] = pm_slot;
-                st.p1_verdict[parity] = 0; st.p1_recabs[parity] = st.nblocks; st.p1_window[parity] = window;
+                st.p1_verdict[parity] = 0; st.p1_recabs[parity] = nblocks0; st.p1_window[parity] = window;
                 sh_i[2] = 1;
                 rec.p1_slot = slot; rec.flags |= REC_P1;
             }
             if (ppb_px > PM_PART) {
                 if ((bc & 1) == 0) st.px_started = 1;
-                if (st.px_started && (bc & 1)) {
+                if ((pxs_now || (bc & 1) == 0) && (bc & 1)) {
                     // a block pair is complete: k_px_deint runs interleaver IV next; frames appear once it has wrapped
                     st.px_go = NSYM * 72 * (ppb_px == 11 ? 1 : 2);
                     st.px_nch = ppb_px == 14 ? 2 : 1;
-                    st.px_record = st.nblocks % db.rec_cap;
+                    st.px_record = nblocks0 % db.rec_cap;
                     if (st.px_ready || st.px_pos == 32 * st.px_go) {
                         st.px_slot = st.px_count % db.px_slots; st.px_count++;
                         rec.sis = (uint32_t)st.px_slot;
@@ -696,12 +742,12 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
     SYNC_MARK(7);
 }
 
-void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, int window, hipStream_t st, int lanes, int pids_inline, int do_prepare)
+void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, int window, hipStream_t st, int lanes, int pids_inline, int do_prepare, int ext_refs)
 {
     // lanes: 0 = by the size of the stream set (see SYNC_OCCUPANCY above), else 256 / 768 (nrsc5hip_debug_tune NRSC5HIP_TUNE_SYNC_LANES)
     const int nt = lanes ? lanes : 768;                        // measured at 256 streams: 32.8 ms per pass with 768, 33.8 with 256 (profiles/r04_sync_lanes.txt)
-    if (nt == 768) hipLaunchKernelGGL(k_sync<768>, dim3(nstreams), dim3(768), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window, pids_inline, do_prepare);
-    else hipLaunchKernelGGL(k_sync<256>, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window, pids_inline, do_prepare);
+    if (nt == 768) hipLaunchKernelGGL(k_sync<768>, dim3(nstreams), dim3(768), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window, pids_inline, do_prepare, ext_refs);
+    else hipLaunchKernelGGL(k_sync<256>, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window, pids_inline, do_prepare, ext_refs);
 }
 
 // ---- deferred PIDS decode: one wave per (slot, stream) with a staged frame -----------------------------------

@@ -9,6 +9,13 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "libnrsc5hip.so")
+# A/B measurements only (tools/gpu_r5_ab.sh): another build of the library -- e.g. one made from an earlier commit -- in place of the tree's own.  The
+# freshness check is then skipped WITH a notice on stderr; nothing measured this way may be recorded as this tree's result.
+_AB_LIB = os.environ.get("NRSC5HIP_AB_LIB")
+if _AB_LIB:
+    import sys as _sys
+    print(f"nrsc5_amd.engine: NRSC5HIP_AB_LIB={_AB_LIB}: running a library that is NOT built from this tree (A/B measurement)", file=_sys.stderr)
+    DEFAULT_LIB = _AB_LIB
 
 SYNC_NONE, SYNC_COARSE, SYNC_FINE = 0, 1, 2
 REC_PROCESSED, REC_TO_COARSE, REC_TO_FINE, REC_MER, REC_PIDS, REC_P1 = 1, 2, 4, 8, 16, 32
@@ -197,6 +204,8 @@ def check_fresh(path: str | None = None):
     """Raise unless the library was built from the device sources of THIS tree (a stale .so silently measures / tests old code).
     Looks at the file only, so that a caller can rebuild and check again in the same process."""
     from . import build
+    if _AB_LIB and (path is None or path == _AB_LIB):
+        return
     got = library_sha(path)
     want = build.source_sha()
     if got != want:

@@ -16,7 +16,7 @@ SELF = next((a for a in ("--self", "--nco") if a in sys.argv), "")
 if SELF:
     sys.argv.remove(SELF)
 EMU_OVERRIDE = None                         # --emu-lib PATH: another emulated twin (tools/build_emu_nco_growth.py) instead of tests/simt/libnrsc5hip_emu.so
-POLICY = None                               # --policy N: NRSC5HIP_TUNE_NCO_EXACT of the emulated twin (0 closed form, 1 first block exact [default], 2 until FINE, 3 always)
+POLICY = None                               # --policy N: NRSC5HIP_TUNE_NCO_EXACT of the emulated twin (0 closed form [default], 1 first block exact, 2 until FINE, 3 always)
 if "--policy" in sys.argv:
     k = sys.argv.index("--policy"); POLICY = int(sys.argv[k + 1]); del sys.argv[k:k + 2]
 if "--emu-lib" in sys.argv:
