@@ -551,16 +551,31 @@ __device__ inline float half_turn_diff(float a, float b)   // phase_diff, sync.c
 }
 
 // Mix one block down with the NCO (phase theta + dtheta * sample), fold the cyclic prefix (rotated by 121 samples:
-// carrier phases are referenced to the symbol centre, acquire.c:239-247) and leave the 32 inputs in bit-reversed
-// order for the in-place radix-2 transform.  Work-item j owns input slot j of every symbol.
+// carrier phases are referenced to the symbol centre, acquire.c:239-247) and leave the 32 inputs in NATURAL order for the
+// 16 x 16 transform below.  Work-item j owns input slot j of every symbol.
 template <int NT> __device__ inline void am_fold(AmBlockSmem &sm, const c16 *win, int samperr, double theta, float2 step270, float2 step256)
 {
     // work-item (j, g): sample j of the eight symbols of group g; the phasor is evaluated in closed form at the head of every
-    // group and advanced by recurrence inside it, whatever the block size (256 work-items take the four groups in turn, 1024
-    // one each), so that both launch shapes produce the same bits
+    // group and advanced by recurrence inside it, whatever the block size (256 work-items take the four groups in turn, 512
+    // two each), so that both launch shapes produce the same bits
     const int j = threadIdx.x & 255;
-    const unsigned slot = bitrev8((unsigned)(j + (AM_FFT - AM_CP) / 2) & 255u);
-    for (int g = (int)threadIdx.x >> 8; g < NSYM / 8; g += NT >> 8) {
+    const unsigned slot = (unsigned)(j + (AM_FFT - AM_CP) / 2) & 255u;
+    constexpr int NG = (NSYM / 8) / (NT >> 8);
+    // every sample this work-item will mix, requested before the first is used: one at a time behind the phasor recurrence the 16 loads of a
+    // work-item were 16 dependent trips to L2 / HBM (the first fold of a block: 33 k of its 139 k shader cycles; profiles/r05_am_phases.txt)
+    c16 a[NG][8], c[NG][8];
+#pragma unroll
+    for (int q = 0; q < NG; q++) {
+        const int g = ((int)threadIdx.x >> 8) + q * (NT >> 8);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            a[q][k] = win[(8 * g + k) * AM_SYM + j + samperr];
+            c[q][k] = win[(8 * g + k) * AM_SYM + (j < AM_CP ? j + AM_FFT : j) + samperr];      // (work-items >= AM_CP: the same line again, unused)
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NG; q++) {
+        const int g = ((int)threadIdx.x >> 8) + q * (NT >> 8);
         float2 p;
         {
             double th = theta + sm.dtheta * (double)(j + g * 8 * AM_SYM);
@@ -568,12 +583,12 @@ template <int NT> __device__ inline void am_fold(AmBlockSmem &sm, const c16 *win
             float sn, cs; sincosf((float)th, &sn, &cs);
             p = make_float2(cs, sn);
         }
-        for (int i = 8 * g; i < 8 * g + 8; i++) {
-            const c16 a = win[i * AM_SYM + j + samperr];
-            float2 v = cmulf(p, make_float2((float)a.r / 32767.0f, (float)a.i / 32767.0f));    // cq15_to_cf, defines.h:106
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = 8 * g + k;
+            float2 v = cmulf(p, make_float2((float)a[q][k].r / 32767.0f, (float)a[q][k].i / 32767.0f));    // cq15_to_cf, defines.h:106
             if (j < AM_CP) {
-                const c16 c = win[i * AM_SYM + j + AM_FFT + samperr];
-                const float2 w = cmulf(cmulf(p, step256), make_float2((float)c.r / 32767.0f, (float)c.i / 32767.0f));
+                const float2 w = cmulf(cmulf(p, step256), make_float2((float)c[q][k].r / 32767.0f, (float)c[q][k].i / 32767.0f));
                 const float sa = sm.shape[j], sb = sm.shape[j + AM_FFT];
                 v = make_float2(sa * v.x + sb * w.x, sa * v.y + sb * w.y);
             }
@@ -583,21 +598,70 @@ template <int NT> __device__ inline void am_fold(AmBlockSmem &sm, const c16 *win
     }
 }
 
-// 32 x 256-point forward FFT in LDS: radix-2 decimation in time, in place, natural-order output
+// forward 4-point DFT in place, natural order
+__device__ __forceinline__ void am_dft4(float2 &a0, float2 &a1, float2 &a2, float2 &a3)
+{
+    const float2 t0 = make_float2(a0.x + a2.x, a0.y + a2.y), t1 = make_float2(a0.x - a2.x, a0.y - a2.y);
+    const float2 t2 = make_float2(a1.x + a3.x, a1.y + a3.y), d = make_float2(a1.x - a3.x, a1.y - a3.y);
+    const float2 t3 = make_float2(d.y, -d.x);                  // (a1 - a3) * (-j)
+    a0 = make_float2(t0.x + t2.x, t0.y + t2.y); a1 = make_float2(t1.x + t3.x, t1.y + t3.y);
+    a2 = make_float2(t0.x - t2.x, t0.y - t2.y); a3 = make_float2(t1.x - t3.x, t1.y - t3.y);
+}
+// forward 16-point DFT in place: input v[n], output X[4 k1 + k2] in v[4 k2 + k1]
+__device__ __forceinline__ void am_dft16(float2 *v)
+{
+#pragma unroll
+    for (int n1 = 0; n1 < 4; n1++) am_dft4(v[n1], v[n1 + 4], v[n1 + 8], v[n1 + 12]);     // v[n1 + 4 k2] = Y[n1][k2]
+    const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, c2 = 0.70710678118654752440f;
+    // W16^(n1 k2) = e^{-2 pi i n1 k2 / 16}
+    v[5] = cmulf(v[5], make_float2(c1, -s1));     // 1
+    v[6] = cmulf(v[6], make_float2(c2, -c2));     // 2
+    v[7] = cmulf(v[7], make_float2(s1, -c1));     // 3
+    v[9] = cmulf(v[9], make_float2(c2, -c2));     // 2
+    v[10] = make_float2(v[10].y, -v[10].x);       // 4: -j
+    v[11] = cmulf(v[11], make_float2(-c2, -c2));  // 6
+    v[13] = cmulf(v[13], make_float2(s1, -c1));   // 3
+    v[14] = cmulf(v[14], make_float2(-c2, -c2));  // 6
+    v[15] = cmulf(v[15], make_float2(-c1, s1));   // 9
+#pragma unroll
+    for (int k2 = 0; k2 < 4; k2++) am_dft4(v[4 * k2], v[4 * k2 + 1], v[4 * k2 + 2], v[4 * k2 + 3]);
+}
+
+// 32 x 256-point forward FFT in LDS, natural order in and out: 256 = 16 x 16, sixteen points per work-item in registers, ONE exchange through the tile
+// (n = 16 a + b, k = c + 16 d: work-item (symbol, b) transforms over a and applies W256^(b c); work-item (symbol, c) transforms over b).  The
+// exchange is in place: Y[c][b] sits at c * 16 + (b ^ c), which keeps both the writes (b runs across the work-items) and the reads (c runs across
+// them: a plain row-major tile would put all sixteen on one bank) conflict-free without a second buffer.  Round 4's form -- eight radix-2 passes, each
+// a read-modify-write of the whole 64 KB tile behind a barrier -- was 21 k of the block's 139 k shader cycles.
 template <int NT> __device__ inline void am_fft_all(AmBlockSmem &sm)
 {
-    for (int lg = 1; lg <= 8; lg++) {
+    static_assert((NSYM * 16) % NT == 0, "whole rounds");
+    for (int id0 = 0; id0 < NSYM * 16; id0 += NT) {
+        const int id = id0 + (int)threadIdx.x, n = id >> 4, l = id & 15;
+        float2 *x = sm.X + n * AM_FFT;
+        float2 v[16];
         __syncthreads();
-        const int half = 1 << (lg - 1);
-        for (int id = threadIdx.x; id < NSYM * 128; id += NT) {
-            const int n = id >> 7, q = id & 127;
-            const int pos = q & (half - 1), i0 = ((q >> (lg - 1)) << lg) + pos, i1 = i0 + half;
-            const float2 w = sm.tw[pos << (8 - lg)];
-            float2 *x = sm.X + n * AM_FFT;
-            const float2 t = cmulf(w, x[i1]), u = x[i0];
-            x[i0] = make_float2(u.x + t.x, u.y + t.y);
-            x[i1] = make_float2(u.x - t.x, u.y - t.y);
-        }
+#pragma unroll
+        for (int a = 0; a < 16; a++) v[a] = x[16 * a + l];                        // b = l
+        am_dft16(v);
+        __syncthreads();
+#pragma unroll
+        for (int k2 = 0; k2 < 4; k2++)
+#pragma unroll
+            for (int k1 = 0; k1 < 4; k1++) {
+                const int c = 4 * k1 + k2, m = l * c;                             // W256^(b c), b c <= 225
+                float2 w = sm.tw[m & 127];
+                if (m & 128) w = make_float2(-w.x, -w.y);
+                x[c * 16 + (l ^ c)] = c ? cmulf(v[4 * k2 + k1], w) : v[4 * k2 + k1];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < 16; b++) v[b] = x[l * 16 + (b ^ l)];                  // c = l
+        am_dft16(v);
+        __syncthreads();
+#pragma unroll
+        for (int k2 = 0; k2 < 4; k2++)
+#pragma unroll
+            for (int k1 = 0; k1 < 4; k1++) x[l + 16 * (4 * k1 + k2)] = v[4 * k2 + k1];
     }
     __syncthreads();
 }
@@ -644,6 +708,10 @@ __global__ __launch_bounds__(NT) void k_am_block(DevTables tb, DevBuffers db, co
     if (!ready) return;
     const c16 *win = db.q15 + (size_t)s * db.q15_cap + (st.rd - st.base);
     const int state_before = st.sync_state;
+    // phase instrumentation (nrsc5hip_debug_tune NRSC5HIP_TUNE_SYNC_PHASES; tools/gpu_am_phases.py): shader cycles of stream 0's workgroup between the marks
+    __shared__ long long am_tstamp;
+    if (db.sync_phase_cycles && s == 0 && tid == 0) am_tstamp = (long long)clock64();
+#define AM_MARK(i) do { if (db.sync_phase_cycles && s == 0 && tid == 0) { const long long now = (long long)clock64(); db.sync_phase_cycles[i] += now - am_tstamp; am_tstamp = now; } } while (0)
 
     for (int k = tid; k < AM_FFT / 2; k += NT) sm.tw[k] = tb.am_twiddle[k];
     for (int k = tid; k < AM_SYM; k += NT) sm.shape[k] = tb.am_shape[k];
@@ -713,6 +781,7 @@ __global__ __launch_bounds__(NT) void k_am_block(DevTables tb, DevBuffers db, co
         __syncthreads();
     }
 
+    AM_MARK(0);                                                // tables + coarse acquisition (while not FINE)
     // ---- per-block bookkeeping (top of acquire_process, acquire.c:110-119,153-168) -------------------------------
     BlockRecord &rec = db.records[(size_t)s * db.rec_cap + (st.nblocks % db.rec_cap)];
     if (tid == 0) {
@@ -761,9 +830,11 @@ __global__ __launch_bounds__(NT) void k_am_block(DevTables tb, DevBuffers db, co
     __syncthreads();
     const int samperr = sm.samperr;
     const bool fine_at_top = sm.fine != 0;
+    AM_MARK(1);                                                // bookkeeping + NCO set-up (one work-item, double-precision trigonometry)
 
     // ---- pass 1: phase of the analog carrier per symbol, line fit over the block (acquire.c:170-235) -------------
     am_fold<NT>(sm, win, samperr, sm.theta, sm.step270, sm.step256);
+    AM_MARK(2);                                                // pass-1 fold
     if (fine_at_top) {
         // only the carrier bin is needed: sum of the folded inputs (bin 0 before fftshift)
         __syncthreads();
@@ -829,10 +900,13 @@ __global__ __launch_bounds__(NT) void k_am_block(DevTables tb, DevBuffers db, co
     __syncthreads();
     am_nco_steps(sm);
     __syncthreads();
+    AM_MARK(3);                                                // carrier (or FFT while not FINE) + line fit + NCO correction
 
     // ---- pass 2: the block's spectra (acquire.c:237-257) -> sync_process_am on the LDS tile --------------------
     am_fold<NT>(sm, win, samperr, sm.theta, sm.step270, sm.step256);
+    AM_MARK(4);                                                // pass-2 fold
     am_fft_all<NT>(sm);
+    AM_MARK(5);                                                // 32 x FFT-256
 
     // lower sideband: z = -conj(z); complementary sidebands of the hybrid waveform add coherently (sync.c:616-633)
     for (int id = tid; id < NSYM * AM_IDX_MAX; id += NT) {
@@ -897,6 +971,7 @@ __global__ __launch_bounds__(NT) void k_am_block(DevTables tb, DevBuffers db, co
         sm.bc_now = bc_now; sm.psmi_now = psmi; sm.rdbi_now = rdbi;
     }
     __syncthreads();
+    AM_MARK(6);                                                // sideband combine + reference-sequence decode (one work-item)
 
     if (sm.fine) {
         const bool ma3 = sm.ma3 != 0;
@@ -925,6 +1000,7 @@ __global__ __launch_bounds__(NT) void k_am_block(DevTables tb, DevBuffers db, co
             if (part < 2) sm.marg[part][col] = atan2f(m.y, m.x);
         }
         __syncthreads();
+        AM_MARK(7);                                            // PIDS carriers + equaliser taps
         if (tid == 0) {
             float se = 0;
             for (int col = 1; col < AM_PW; col++) {
@@ -950,6 +1026,7 @@ __global__ __launch_bounds__(NT) void k_am_block(DevTables tb, DevBuffers db, co
             symbase[(size_t)part * AM_SYMS + bc * (NSYM * AM_PW) + r] = (uint8_t)code;
         }
         __syncthreads();
+        AM_MARK(8);                                            // timing estimate + equalise / slice
         // PIDS: bit gather (decode.c:476-501), K=9 E2 decode, descramble
         if (tid < 120) {
             const int n = tid, p = n % 4;
@@ -1009,6 +1086,7 @@ __global__ __launch_bounds__(NT) void k_am_block(DevTables tb, DevBuffers db, co
         }
     }
 
+    AM_MARK(9);                                                // PIDS gather / stage + frame hand-off (one work-item)
     // ---- tail of acquire_process (acquire.c:259-262) + record -------------------------------------------------------
     // Two work-items of different waves share it, as in k_sync: the NCO phase with its double-precision cosine / sine (a diagnostic of the record) on
     // one, the FIFO position and the record on the other with its state loads issued together (a load behind every store of the other kind cost an
@@ -1031,6 +1109,7 @@ __global__ __launch_bounds__(NT) void k_am_block(DevTables tb, DevBuffers db, co
         rec.prev_angle = prev_angle; rec.next_angle = 0.0f;
         st.nblocks = nblocks + 1;
     }
+    AM_MARK(10);                                               // tail
     if (db.am_ckpt) {                                          // block-uniform: window pipeline with the on-device L2 feedback
         // Replay checkpoint of a block that delivered a P1 PDU (k_replay.hip): the state as of now.  For block 7 the
         // de-interleaver's bookkeeping (k_am_interleave, next) still belongs to the block: k_rollback_am adds it on restore.
