@@ -202,6 +202,10 @@ int nrsc5hip_stream_step(nrsc5hip_engine *e, int stream);
  * Should the engine find its own prediction violated (a block submitted without its P1 decode completed a frame while the next one is running)
  * it drops both steps' bookkeeping, marks the stream's host mirror invalid (the next push re-synchronises) and returns NRSC5HIP_EHIP. */
 int nrsc5hip_stream_step_ahead(nrsc5hip_engine *e, int stream, int *submitted);
+/* EVENT LATENCY of the drop-in built on these calls (integration/input_hip.c; INTEGRATION.md, first section): with deferred waits and steps queued ahead, the
+ * records of block n reach the caller during the first call after the device has finished it -- at the latest in the call that completes block n + 1, i.e. up to
+ * one block (92.9 ms of signal) later than src/input.c fires them -- or in a zero-length push (flush), nrsc5hip_drain (waits), stream reset / engine destruction
+ * paths of the shim.  NRSC5HIP_SYNC_DELIVERY=1 makes the shim wait inside the completing call (the reference's contract) at ~2 / 3 of the throughput. */
 
 /* ---- batch path (device buffers) ------------------------------------------------------------------ */
 /* Decimate + append one cu8 chunk per listed stream.  dev_iq: device pointer, chunk k at
@@ -364,7 +368,7 @@ int nrsc5hip_stage_viterbi_bench(nrsc5hip_engine *e, int len, int nframes, int p
 int nrsc5hip_stage_viterbi_k9_bench(nrsc5hip_engine *e, int len, int nframes, int phases, int reps, float *ms_per_launch);
 /* Tuning knobs and test hooks (the library reads nothing from the environment).  Call on an idle engine. */
 enum {
-    NRSC5HIP_TUNE_DECODE_STREAMS = 0,    /* FM window pipeline: HIP streams that decode windows concurrently (1..5, default 3) */
+    NRSC5HIP_TUNE_DECODE_STREAMS = 0,    /* FM window pipeline: HIP streams that decode windows concurrently (1..5; default 1 since round 5, 3 before) */
     NRSC5HIP_TUNE_AM_DECODE_STREAMS,     /* same for the AM window pipeline (default 2) */
     NRSC5HIP_TUNE_VERDICT_LAG,           /* TEST HOOK: the replay takes first-header verdicts this many windows late (0..8): deep speculation */
     NRSC5HIP_TUNE_SYNC_PHASES,           /* 1: k_sync accumulates shader cycles per phase for stream 0 (nrsc5hip_debug_sync_phases) */
@@ -383,8 +387,9 @@ enum {
                                              256-lane workgroup (identical bins); 32 = the 256-lane x 8-point kernel k_mixfft8 (bins within float tolerance); anything else = 1 */
     , NRSC5HIP_TUNE_DEFER_WAIT             /* fast streaming seam: 1 (default) = a block step whose FIFO consumption the host can compute in advance stays in
                                              flight when the push returns; 0 = every step is waited for at once (round 3's behaviour) */
-    , NRSC5HIP_TUNE_TRACEBACK_WALK         /* 1 (default): single-path traceback of the K=7 frames (one speculative walk per chunk, verified, re-walked where wrong);
-                                             0: round 3's block-parallel traceback (all 64 candidates per chunk).  Identical output either way */
+    , NRSC5HIP_TUNE_TRACEBACK_WALK         /* > 0: single-path traceback of the K=7 frames (one speculative walk per chunk, verified, re-walked where wrong): 1 = one workgroup per
+                                             (frame, part) as in round 4, N > 1 = a persistent grid of N one-wave workgroups (default 512: a launch that keeps thousands of workgroups
+                                             pending stalls the block-step kernels behind it); 0: round 3's block-parallel traceback (all 64 candidates per chunk).  Identical output */
     , NRSC5HIP_TUNE_SYNC_LANES             /* work-items per stream of the sync kernel: 256, 768, 0 = chosen from the size of the stream set (default) */
     , NRSC5HIP_TUNE_DIRECT_DECIMATE        /* fast streaming seam, FM cu8: 1 (default) = the decimator reads the pinned staging buffer across PCIe itself (one
                                              launch per chunk); 0 = hipMemcpyAsync into a device buffer, decimator, commit kernel (round 3's chain) */

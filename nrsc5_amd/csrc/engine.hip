@@ -107,7 +107,7 @@ struct nrsc5hip_engine {
     int mixfft_syms;                   // symbols per k_mixfft workgroup (1, 2, 4, 8)
     int sync_lanes;                    // work-items per stream of k_sync: 0 = by the size of the stream set, 256, 768
     int fuse_seam_prepare;             // 1 (default): fast seam, FINE stream: no k_prepare launch (NRSC5HIP_TUNE_SEAM_PREPARE = 0: separate launch)
-    int tb_walk;                       // 1 (default): single-path traceback (k_p1_tbwalk + check); 0: the block-parallel one of round 3
+    int tb_walk;                       // > 0: single-path traceback (k_p1_tbwalk + check): 1 = a workgroup per (frame, part), N > 1 = a persistent grid of N workgroups (default 512); 0: the block-parallel one of round 3
     int fwd_segments;                  // waves per frame of the P1 forward pass; 0 = pick from the size of the stream set (fwd_segments_for)
     hipStream_t main;                  // = lane.main
     std::vector<void *> allocs;
@@ -447,7 +447,11 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
     int rc = 0;
     do {
         {
-            e->naux = 3; e->naux_am = 2;   // decode streams in use (measured: profiles/r02_naux.txt, r03_am_decode.txt); nrsc5hip_debug_tune changes them
+            // decode streams in use; nrsc5hip_debug_tune changes them.  FM: ONE since round 5 (three in rounds 2 - 4, profiles/r02_naux.txt): with the segmented forward pass
+            // and the single-path traceback a window's decode (~1.6 ms) fits the 16 block steps of the next window (~1.7 ms) on one queue, and with two or three the
+            // forward pass of one window overlaps the traceback of another -- the k_sync launch that meets both lasts 370 - 790 us instead of 37 (one per window; tools/gpu_trace_sync.sh,
+            // profiles/r05_trace_sync.txt): 30.1 -> 29.2 ms per pass.  AM: two (profiles/r03_am_decode.txt)
+            e->naux = 1; e->naux_am = 2;
             e->verdict_lag = 0; e->fwd_segments = 0; e->fwd_warm = 2; e->mixfft_syms = 1; e->sync_lanes = 0; e->tb_walk = 1; e->fuse_seam_prepare = 1;      // measured: profiles/r04_mixfft_persistent.txt
             e->am_segments = K9_GMAX; e->am_warm = K9_WARM; e->am_runin = K9_TB_RUNIN;
         }
@@ -492,6 +496,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if ((rc = dev_alloc(e, &db.bins, S * NSYM * LIVE_N))) break;
         // the reference's oscillator sample by sample for blocks in exact mode (553 KB per stream; k_nco_exact -> k_mixfft)
         if ((rc = dev_alloc(e, &db.nco_tab, S * NSYM * SYM_N))) break;
+        if ((rc = dev_alloc(e, &db.cfo_snap, S * LIVE_N * (PM_PART + 1)))) break;
         // Default: the closed-form phasor with the reference oscillator's amplitude ramp (NCO_CLOSED_FORM).  Measured (DESIGN.md (c) limit 2): on the CPU twin,
         // whose libm is the reference's, the exact first block takes the locks after a CFO search that deviate in loop-internal state from 5 to 2 in 900 (18
         // without the ramp); on the MI355X the deviating streams of two 256-stream CFO-search batches are the same under every policy (other last-bit
@@ -2241,7 +2246,7 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
         }
         break;
     }
-    case NRSC5HIP_TUNE_TRACEBACK_WALK:    e->tb_walk = value != 0; break;
+    case NRSC5HIP_TUNE_TRACEBACK_WALK:    e->tb_walk = std::min(std::max(value, 0), 16384); break;
     case NRSC5HIP_TUNE_SYNC_LANES:        e->sync_lanes = (value == 256 || value == 768) ? value : 0; break;
     case NRSC5HIP_TUNE_SEAM_PREPARE:      e->fuse_seam_prepare = value != 0; break;
     case NRSC5HIP_TUNE_NCO_EXACT:         e->db.nco_policy = e->lane.db.nco_policy = e->db.nco_tab ? std::min(std::max(value, 0), (int)NCO_EXACT_ALWAYS) : (int)NCO_CLOSED_FORM; break;

@@ -143,17 +143,24 @@ __global__ __launch_bounds__(64 * TBM_WAVES) void k_p1_tbmap(DevTables tb, DevBu
 
 // Round 4: the single-path traceback (viterbi_v3.h: lane = chunk, run-in through the chunk above, verified by k_p1_traceback).
 // 36 one-wave workgroups per frame, 33 KB of LDS each (four per CU).
-__global__ __launch_bounds__(64) void k_p1_tbwalk(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id, int prio)
+// Round 5: a PERSISTENT grid.  As 36 x 256 = 9216 workgroups the launch kept thousands of workgroups PENDING in the dispatcher for its ~450 us (four fit a CU: 33 KB
+// of LDS each), and the block-step kernels of the chain queue waited behind them: the k_sync launch that coincided with a window's traceback lasted 370 - 550 us
+// instead of 37 (one per decode window: ~6 of the pass's 30 ms; profiles/r05_trace_sync.txt).  `ntasks` (part, stream) pairs are walked by gridDim.x resident
+// workgroups, parts of one frame by neighbouring workgroups.
+__global__ __launch_bounds__(64) void k_p1_tbwalk(DevTables tb, DevBuffers db, const int *ids, int parity, int lane_id, int prio, int nparts, int ntasks)
 {
     wave_set_priority(prio);
-    const int s = wave_uniform(stream_of(ids, blockIdx.y));
-    StreamState &st = db.state[s];
-    if (!st.p1_pending[parity]) return;                        // block-uniform
     __shared__ uint32_t lds[TB2_LDS_WORDS];
-    const size_t slot = (size_t)lane_id * db.nstreams_alloc + s;
-    uint32_t *out = db.p1_ring + ((size_t)s * db.p1_slots + st.p1_slot[parity]) * P1_WORDS;
-    viterbi3_traceback_walk(db.dec + slot * (size_t)(2 * (P1_LEN + 64)), P1_LEN, st.p1_endlane[parity], out,
-                            db.tbmap + slot * ((size_t)(P1_LEN / 64 + 1) * 64), (int)blockIdx.x, lds, db.coded + slot * P1_LEN);
+    for (int t = (int)blockIdx.x; t < ntasks; t += (int)gridDim.x) {
+        const int s = wave_uniform(stream_of(ids, t / nparts));
+        StreamState &st = db.state[s];
+        if (!st.p1_pending[parity]) continue;                  // wave-uniform (one wave per workgroup)
+        const size_t slot = (size_t)lane_id * db.nstreams_alloc + s;
+        uint32_t *out = db.p1_ring + ((size_t)s * db.p1_slots + st.p1_slot[parity]) * P1_WORDS;
+        viterbi3_traceback_walk(db.dec + slot * (size_t)(2 * (P1_LEN + 64)), P1_LEN, st.p1_endlane[parity], out,
+                                db.tbmap + slot * ((size_t)(P1_LEN / 64 + 1) * 64), t % nparts, lds, db.coded + slot * P1_LEN);
+        WAVE_LDS_FENCE();                                      // the next task refills the tile
+    }
 }
 
 // maps_done: 0 = the block-parallel traceback runs all its passes here; 1 = k_p1_tbmap ran pass 1; 2 = k_p1_tbwalk has written the
@@ -241,7 +248,10 @@ void launch_p1_traceback(const DevTables &tb, const DevBuffers &db, int nstreams
     // traceback workgroup: 1024 small workgroups at once crowd the block-step kernels off the SIMDs (measured: k_sync 14 -> 25 ms
     // per pass, the pass 36 -> 50 ms; profiles/r03_traceback_variants.txt).
     if (walk) {
-        hipLaunchKernelGGL(k_p1_tbwalk, dim3(vit3_tb2_waves(P1_LEN), nstreams), dim3(64), 0, st, tb, db, stream_ids, parity, lane_id, prio_tb);
+        // walk: 1 = one workgroup per task (round 4), N > 1 = a persistent grid of N workgroups
+        const int nparts = vit3_tb2_waves(P1_LEN), ntasks = nparts * nstreams;
+        const int grid = walk > 1 ? (walk < ntasks ? walk : ntasks) : ntasks;
+        hipLaunchKernelGGL(k_p1_tbwalk, dim3(grid), dim3(64), 0, st, tb, db, stream_ids, parity, lane_id, prio_tb, nparts, ntasks);
         hipLaunchKernelGGL(k_p1_traceback, dim3(nstreams), dim3(TB_THREADS), traceback_smem(P1_LEN), st, tb, db, stream_ids, parity, lane_id, l2_mode, prio_tb, 2);
     } else {
         const int split = parts >= 16 ? 16 : 0;

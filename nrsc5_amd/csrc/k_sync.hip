@@ -313,7 +313,7 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
     __shared__ float sh_diff[2 * 14];
     __shared__ __attribute__((aligned(16))) int8_t sh_pids_coded[3 * PIDS_LEN];
     __shared__ uint32_t sh_pids_out[4];
-    __shared__ int sh_seen[16 + 64];
+    __shared__ int sh_seen[16 + 80];                          // (the CFO search: [0..3] vote masks, [8..8 + 76) the candidates' best offsets)
     __shared__ float ref_freq[NREF_MAX];
     __shared__ int sh_pre[PRE_N];
     __shared__ uint16_t sh_gather[PIDS_CODED];
@@ -417,55 +417,134 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
             // and each visit advances that bin's loop state exactly as adjust_ref does.
             for (int k = tid; k < (CFO_HI - CFO_LO) * 22; k += SYNC_NT) (&cfo_offs[0][0])[k] = -1;
             __syncthreads();
-            // Two passes over the same visits instead of a snapshot per visit (snapshots indexed by a running count lived in scratch
-            // memory, and the private segment was paid for by EVERY launch of this kernel): pass 0 files the needle offsets and the
-            // first workgroup-wide match decides where the search stops; pass 1 repeats the visits up to that candidate from the
-            // saved loop state -- the search runs a handful of times per acquisition.
-            for (int pass = 0; pass < 2; pass++) {
-                const int last_cfo = pass ? sh_i[1] : 0x7fffffff;  // pass 1: visits with cfo <= last_cfo happened
-                for (int l = tid; l < LIVE_N; l += SYNC_NT) {
-                    const int b = live_to_bin(l);
-                    const bool lower = l < LIVE_HALF;
-                    float f = st.costas_freq[l], p = st.costas_phase[l];   // untouched by pass 0
-                    // is this bin one of the already-derotated active references?
-                    int rslot = -1;
-                    if (lower) { if ((b - LB0) % PW == 0 && (b - LB0) / PW <= ppb) rslot = 2 * ((b - LB0) / PW); }
-                    else { if ((UB1 - b) % PW == 0 && (UB1 - b) / PW <= ppb) rslot = 2 * ((UB1 - b) / PW) + 1; }
-                    const float2 *src = rslot >= 0 ? (const float2 *)&refz[rslot][0] : (const float2 *)(bins + l);
-                    const int stride = rslot >= 0 ? 1 : LIVE_N;
-                    bool visited = false;
-                    for (int q = 0; q <= PM_PART; q++) {
-                        const int i = lower ? (PM_PART - q) : q;   // ascending cfo
-                        const int cfo = lower ? (b - LB0 - PW * i) : (b - UB1 + PW * i);
-                        if (cfo < CFO_LO || cfo >= CFO_HI || cfo > last_cfo) continue;
-                        const uint32_t d = costas_block<false>(src, stride, f, p, cfo, g, nullptr, nullptr);
-                        visited = true;
-                        if (pass == 0) cfo_offs[cfo - CFO_LO][2 * i + (lower ? 0 : 1)] = (int8_t)needle_search(d, (30 - i) & 3);
-                    }
-                    if (pass == 1 && visited) { st.costas_freq[l] = f; st.costas_phase[l] = p; }
+            if constexpr (SYNC_NT >= LIVE_N) {
+                // ONE pass (round 5).  A work-item owns one live bin and files the loop state after each of its (at most 11) visits in a per-stream slab of
+                // global memory (db.cfo_snap: stores nobody waits for); the workgroup-wide vote then says where the search stopped and each work-item
+                // reads back the ONE snapshot of its last visit at or below that candidate and commits it.  (Round 3 kept the snapshots in a private array:
+                // scratch memory, paid for by every launch of the kernel; round 4 ran every visit twice instead; as named registers of an unrolled visit
+                // loop they cost 17 spilled VGPRs.)  The search is the straggler of the block-step chain: the launch of a step in which ONE stream searches
+                // lasted 230 - 535 us against 37 us for a step without (profiles/r05_trace_*.txt), two thirds of it the second pass and a 76-candidate vote
+                // on a single work-item.
+                const int l = tid < LIVE_N ? tid : LIVE_N - 1;
+                const bool mine = tid < LIVE_N;
+                const int b = live_to_bin(l);
+                const bool lower = l < LIVE_HALF;
+                float f = st.costas_freq[l], p = st.costas_phase[l];
+                int rslot = -1;
+                if (lower) { if ((b - LB0) % PW == 0 && (b - LB0) / PW <= ppb) rslot = 2 * ((b - LB0) / PW); }
+                else { if ((UB1 - b) % PW == 0 && (UB1 - b) / PW <= ppb) rslot = 2 * ((UB1 - b) / PW) + 1; }
+                const float2 *src = rslot >= 0 ? (const float2 *)&refz[rslot][0] : (const float2 *)(bins + l);
+                const int stride = rslot >= 0 ? 1 : LIVE_N;
+                float2 *snap = db.cfo_snap + ((size_t)s * LIVE_N + l) * (PM_PART + 1);
+                if (mine)
+                for (int q = 0; q <= PM_PART; q++) {
+                    const int i = lower ? (PM_PART - q) : q;   // ascending cfo
+                    const int cfo = lower ? (b - LB0 - PW * i) : (b - UB1 + PW * i);
+                    if (cfo < CFO_LO || cfo >= CFO_HI) continue;
+                    const uint32_t d = costas_block<false>(src, stride, f, p, cfo, g, nullptr, nullptr);
+                    cfo_offs[cfo - CFO_LO][2 * i + (lower ? 0 : 1)] = (int8_t)needle_search(d, (30 - i) & 3);
+                    snap[q] = make_float2(f, p);
                 }
-                if (pass == 1) break;
+                __syncthreads();
+                // the vote (sync.c:316-335), one candidate per work-item: the most frequent needle offset among the candidate's 22 reference positions, the
+                // smallest such offset on ties (the reference scans the offsets upwards with `>`), at least three of them
+                constexpr int NCAND = CFO_HI - CFO_LO;
+                static_assert(NCAND <= 128, "two waves vote");
+                int my_best = -1;
+                if (tid < NCAND) {
+                    int best = -1, best_count = 0;
+                    for (int r = 0; r < 22; r++) {
+                        const int v = cfo_offs[tid][r];
+                        if (v < 0) continue;
+                        int cnt = 0;
+                        for (int r2 = 0; r2 < 22; r2++) cnt += cfo_offs[tid][r2] == v;
+                        if (cnt > best_count || (cnt == best_count && v < best)) { best = v; best_count = cnt; }
+                    }
+                    if (best >= 0 && best_count >= 3) my_best = best;
+                }
+                if (tid < 128) {
+                    const unsigned long long m = __ballot(my_best >= 0);
+                    if ((tid & 63) == 0) { sh_seen[2 * (tid >> 6)] = (int)(uint32_t)m; sh_seen[2 * (tid >> 6) + 1] = (int)(uint32_t)(m >> 32); }
+                    if (tid < NCAND) sh_seen[8 + tid] = my_best;
+                }
                 __syncthreads();
                 if (tid == 0) {
                     int found = 0x7fffffff;
-                    for (int c = 0; c < CFO_HI - CFO_LO && found == 0x7fffffff; c++) {
-                        int *count = sh_seen;
-                        for (int k = 0; k < NSYM; k++) count[k] = 0;
-                        for (int r = 0; r < 22; r++) if (cfo_offs[c][r] >= 0) count[cfo_offs[c][r]]++;
-                        int best = -1, best_count = 0;
-                        for (int k = 0; k < NSYM; k++) if (count[k] > best_count) { best = k; best_count = count[k]; }
-                        if (best >= 0 && best_count >= 3) {
-                            st.keep_extra = ((NSYM - best) % NSYM) * SYM_N;      // acquire_keep_extra
-                            st.cfo += c + CFO_LO;                                 // acquire_cfo_adjust
-                            st.cfo_wait = 8;
-                            found = c + CFO_LO;
-                        }
+                    for (int w = 0; w < 4 && found == 0x7fffffff; w++) {
+                        const uint32_t m = (uint32_t)sh_seen[w];
+                        if (m) found = 32 * w + __ffs((int)m) - 1;
+                    }
+                    if (found != 0x7fffffff) {
+                        const int best = sh_seen[8 + found];
+                        st.keep_extra = ((NSYM - best) % NSYM) * SYM_N;          // acquire_keep_extra
+                        st.cfo += found + CFO_LO;                                 // acquire_cfo_adjust
+                        st.cfo_wait = 8;
+                        found += CFO_LO;
                     }
                     sh_i[1] = found;
                 }
                 __syncthreads();
-            }
+                {
+                    const int last_cfo = sh_i[1];
+                    int q_last = -1;                           // the visits ascend in cfo with q
+                    for (int q = 0; q <= PM_PART; q++) {
+                        const int i = lower ? (PM_PART - q) : q;
+                        const int cfo = lower ? (b - LB0 - PW * i) : (b - UB1 + PW * i);
+                        if (cfo >= CFO_LO && cfo < CFO_HI && cfo <= last_cfo) q_last = q;
+                    }
+                    if (mine && q_last >= 0) { const float2 v = snap[q_last]; st.costas_freq[l] = v.x; st.costas_phase[l] = v.y; }
+                }
+            } else {
+                // Two passes over the same visits instead of a snapshot per visit (snapshots indexed by a running count lived in scratch
+                // memory, and the private segment was paid for by EVERY launch of this kernel): pass 0 files the needle offsets and the
+                // first workgroup-wide match decides where the search stops; pass 1 repeats the visits up to that candidate from the
+                // saved loop state -- the search runs a handful of times per acquisition.
+                for (int pass = 0; pass < 2; pass++) {
+                    const int last_cfo = pass ? sh_i[1] : 0x7fffffff;  // pass 1: visits with cfo <= last_cfo happened
+                    for (int l = tid; l < LIVE_N; l += SYNC_NT) {
+                        const int b = live_to_bin(l);
+                        const bool lower = l < LIVE_HALF;
+                        float f = st.costas_freq[l], p = st.costas_phase[l];   // untouched by pass 0
+                        // is this bin one of the already-derotated active references?
+                        int rslot = -1;
+                        if (lower) { if ((b - LB0) % PW == 0 && (b - LB0) / PW <= ppb) rslot = 2 * ((b - LB0) / PW); }
+                        else { if ((UB1 - b) % PW == 0 && (UB1 - b) / PW <= ppb) rslot = 2 * ((UB1 - b) / PW) + 1; }
+                        const float2 *src = rslot >= 0 ? (const float2 *)&refz[rslot][0] : (const float2 *)(bins + l);
+                        const int stride = rslot >= 0 ? 1 : LIVE_N;
+                        bool visited = false;
+                        for (int q = 0; q <= PM_PART; q++) {
+                            const int i = lower ? (PM_PART - q) : q;   // ascending cfo
+                            const int cfo = lower ? (b - LB0 - PW * i) : (b - UB1 + PW * i);
+                            if (cfo < CFO_LO || cfo >= CFO_HI || cfo > last_cfo) continue;
+                            const uint32_t d = costas_block<false>(src, stride, f, p, cfo, g, nullptr, nullptr);
+                            visited = true;
+                            if (pass == 0) cfo_offs[cfo - CFO_LO][2 * i + (lower ? 0 : 1)] = (int8_t)needle_search(d, (30 - i) & 3);
+                        }
+                        if (pass == 1 && visited) { st.costas_freq[l] = f; st.costas_phase[l] = p; }
+                    }
+                    if (pass == 1) break;
+                    __syncthreads();
+                    if (tid == 0) {
+                        int found = 0x7fffffff;
+                        for (int c = 0; c < CFO_HI - CFO_LO && found == 0x7fffffff; c++) {
+                            int *count = sh_seen;
+                            for (int k = 0; k < NSYM; k++) count[k] = 0;
+                            for (int r = 0; r < 22; r++) if (cfo_offs[c][r] >= 0) count[cfo_offs[c][r]]++;
+                            int best = -1, best_count = 0;
+                            for (int k = 0; k < NSYM; k++) if (count[k] > best_count) { best = k; best_count = count[k]; }
+                            if (best >= 0 && best_count >= 3) {
+                                st.keep_extra = ((NSYM - best) % NSYM) * SYM_N;      // acquire_keep_extra
+                                st.cfo += c + CFO_LO;                                 // acquire_cfo_adjust
+                                st.cfo_wait = 8;
+                                found = c + CFO_LO;
+                            }
+                        }
+                        sh_i[1] = found;
+                    }
+                    __syncthreads();
+                }
         }
+            }
         __syncthreads();
     }
 

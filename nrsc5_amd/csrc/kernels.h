@@ -41,6 +41,7 @@ struct DevBuffers {
     int *acq_list;                   // [S + 1]      streams that need the acquisition kernels this step (k_acq_list); [S] = how many
     float2 *acq_sums;                // [S][SYM_N]
     float2 *bins;                    // [S][NSYM][LIVE_N]
+    float2 *cfo_snap;                // [S][LIVE_N][11]  the CFO search's loop-state snapshots (k_sync: one per visit of a live bin)
     float2 *nco_tab;                 // [S][NSYM][SYM_N]  the reference's oscillator sample by sample for a block that runs in exact mode (k_nco_exact -> k_mixfft); null: closed form only
     int nco_policy;                  // NCO_*: which blocks of a freshly reset stream advance the oscillator by the reference's float recurrence
     int8_t *pm;                      // [S][NPM][PM_FRAME]  soft-bit interleaver matrices (one per frame in flight)
