@@ -2253,7 +2253,7 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
     case NRSC5HIP_TUNE_EARLY_FLUSH_KB:    e->early_flush = (size_t)std::max(value, 0) << 10; break;
     case NRSC5HIP_TUNE_DEFER_WAIT:        e->defer_wait = value != 0; break;
     case NRSC5HIP_TUNE_DIRECT_DECIMATE:   e->direct_decimate = value != 0; break;
-    case NRSC5HIP_TUNE_MIXFFT_SYMS:       e->mixfft_syms = (value == 2 || value == 4 || value == 8 || value == 16 || value == 32) ? value : 1; break;   // 16: two symbols side by side per workgroup; 32: the 256-lane kernel
+    case NRSC5HIP_TUNE_MIXFFT_SYMS:       e->mixfft_syms = (value == 2 || value == 4 || value == 8 || value == 16 || value == 32 || (value >= 100 && value <= 140)) ? value : 1; break;   // 16: two symbols side by side per workgroup; 32: the 256-lane kernel
     case NRSC5HIP_TUNE_AM_SEGMENTS:       e->am_segments = std::min(std::max(value, 1), K9_GMAX); break;
     case NRSC5HIP_TUNE_AM_WARM:           e->am_warm = value > 0 ? K9_WARM : 0; e->am_runin = value > 0 ? K9_TB_RUNIN : 0; break;
     case NRSC5HIP_TUNE_SYNC_PHASES:

@@ -24,6 +24,11 @@
 #include "prepare_block.h"
 
 namespace nrsc5 {
+#ifdef NRSC5HIP_MIXFFT_NOLOAD
+constexpr bool DIAG_NOLOAD = true;
+#else
+constexpr bool DIAG_NOLOAD = false;
+#endif
 
 __device__ inline int stream_of(const int *ids, int idx) { return ids ? ids[idx] : idx; }
 
@@ -426,7 +431,8 @@ __device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuf
     const int sym0 = (int)(blockIdx.x * NPAR + (threadIdx.x >> 7)) * SPW;
     const long long a00 = sp.a00;                              // first sample of symbol 0 in the decimated stream
     uint32_t W[24];
-    if (RAW) raw_symbol_load(raw, a00 + (long long)sym0 * SYM_N, W, threadIdx.x & 127);      // first thing once the position is known
+    if (RAW && !DIAG_NOLOAD) raw_symbol_load(raw, a00 + (long long)sym0 * SYM_N, W, threadIdx.x & 127);      // first thing once the position is known
+    if (RAW && DIAG_NOLOAD) { for (int k = 0; k < 24; k++) W[k] = 0x7f7f7f7fu + (uint32_t)k * 0x01010101u * (threadIdx.x & 3); }   // DIAGNOSTIC (NRSC5HIP_MIXFFT_NOLOAD build): the kernel without its capture loads
     pro.twb.park(twB);                                         // first read two barriers from here
     const double dth = sp.dtheta;
     const HbTaps taps = pro.taps;
@@ -937,7 +943,7 @@ void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, cons
     case 2: hipLaunchKernelGGL((k_mixfft<2, 1>), dim3(NSYM / 2, nstreams), dim3(128), 0, st, tb, db, stream_ids, local_prepare); break;
     case 4: hipLaunchKernelGGL((k_mixfft<4, 1>), dim3(NSYM / 4, nstreams), dim3(128), 0, st, tb, db, stream_ids, local_prepare); break;
     case 8: hipLaunchKernelGGL((k_mixfft<8, 1>), dim3(NSYM / 8, nstreams), dim3(128), 0, st, tb, db, stream_ids, local_prepare); break;
-    default: hipLaunchKernelGGL((k_mixfft<1, 1>), dim3(NSYM, nstreams), dim3(128), 0, st, tb, db, stream_ids, local_prepare); break;
+    default: hipLaunchKernelGGL((k_mixfft<1, 1>), dim3(NSYM, nstreams), dim3(128), syms_per_wg >= 100 ? (size_t)(syms_per_wg - 100) << 10 : 0, st, tb, db, stream_ids, local_prepare); break;   // (>= 100: DIAGNOSTIC, that many KiB of unused dynamic LDS per workgroup -- fewer workgroups per CU)
     }
 }
 

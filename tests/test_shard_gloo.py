@@ -29,6 +29,9 @@ def _worker(rank, world, port, total, q):
         return torch.tensor([[s + c for c in range(5)] for s in rng], dtype=torch.uint8)
     got = shard.scatter_rows(rows_for_rank, len(mine), (5,), torch.uint8, dev)
     assert got.tolist() == [[s + c for c in range(5)] for s in mine], (r, got.tolist())
+    # per-rank parity verdicts (bench.py --gpus N): one fixed-length vector per rank, gathered in rank order
+    verdicts = shard.gather_vectors([float(r), float(len(mine)), float(len(mine)), float(len(mine)) - r, 0.0], dev)
+    assert verdicts.shape == (w, 5) and [int(v[0]) for v in verdicts] == list(range(w)) and int(verdicts[1][3]) == len(shard.stream_range(total, w, 1)) - 1
     q.put((r, list(mine), allrows.tolist(), t, float(tot[0])))
     dist.destroy_process_group()
 
