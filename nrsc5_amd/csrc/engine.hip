@@ -450,10 +450,11 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             // decode streams in use; nrsc5hip_debug_tune changes them.  FM: ONE since round 5 (three in rounds 2 - 4, profiles/r02_naux.txt): with the segmented forward pass
             // and the single-path traceback a window's decode (~1.6 ms) fits the 16 block steps of the next window (~1.7 ms) on one queue, and with two or three the
             // forward pass of one window overlaps the traceback of another -- the k_sync launch that meets both lasts 370 - 790 us instead of 37 (one per window; tools/gpu_trace_sync.sh,
-            // profiles/r05_trace_sync.txt): 30.1 -> 29.2 ms per pass.  AM: two (profiles/r03_am_decode.txt)
-            e->naux = 1; e->naux_am = 2;
+            // profiles/r05_trace_sync_decode_streams.txt): 30.1 -> 29.2 ms per pass.  AM: three, with four segment waves per P3 frame (round 5, on the
+            // rewritten block step: 70.4 ms with two streams x eight segments, 67.5 with three x eight, 65.7 with three x four, 91.3 with one: the K=9 decodes are ~80 ms of kernel time per pass)
+            e->naux = 1; e->naux_am = 3;
             e->verdict_lag = 0; e->fwd_segments = 0; e->fwd_warm = 2; e->mixfft_syms = 1; e->sync_lanes = 0; e->tb_walk = 1; e->fuse_seam_prepare = 1;      // measured: profiles/r04_mixfft_persistent.txt
-            e->am_segments = K9_GMAX; e->am_warm = K9_WARM; e->am_runin = K9_TB_RUNIN;
+            e->am_segments = 4; e->am_warm = K9_WARM; e->am_runin = K9_TB_RUNIN;
         }
         {
             nrsc5hip_engine::Lane &ln = e->lane;
