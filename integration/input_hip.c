@@ -218,9 +218,10 @@ void input_init(input_t *st, nrsc5_t *radio, output_t *output)
     st->sync_state = SYNC_STATE_NONE;
     if (nrsc5hip_engine_create(&cfg, &e) != 0) { e = NULL; fail(st, "engine_create"); }
     else if (nrsc5hip_stream_set_manual_step(e, 0, 1) != 0) fail(st, "stream_set_manual_step");
-    /* the first block after a reset -- the block the CFO search runs on -- with the reference's own oscillator recurrence (k_nco_exact: ~0.7 ms, once per
-     * session; DESIGN.md (c) limit 2): a single stream has nothing else to spend that time on, and it is the block where the last bits decide */
-    else if (nrsc5hip_debug_tune(e, NRSC5HIP_TUNE_NCO_EXACT, 1) != 0) fail(st, "debug_tune");
+    /* NRSC5HIP_NCO_EXACT=1 | 2 | 3 in the environment: the first block after a reset (the block the CFO search runs on) / every block until the first lock /
+     * every block with the reference's own oscillator recurrence (k_nco_exact: ~1.5 ms per such block; DESIGN.md (c) limit 2).  Default: the closed form with
+     * the oscillator's amplitude ramp, as in the batch API -- measured on the MI355X the exact form changes no event and costs a 20-s capture 5 % of its speed */
+    else { const char *x = getenv("NRSC5HIP_NCO_EXACT"); if (x && atoi(x) > 0 && nrsc5hip_debug_tune(e, NRSC5HIP_TUNE_NCO_EXACT, atoi(x)) != 0) fail(st, "debug_tune"); }
     st->acq.fftin = (void *)e;
     st->decode.input = st;
     frame_init(&st->frame, st);
