@@ -63,11 +63,7 @@ __device__ inline uint32_t costas_block(const float2 *src, int stride, float &fr
     for (int n = 0; n < NZ; n++) zin[n] = src[n * stride];     // independent loads in flight
     float s1, c1; fast_sincos(phase, s1, c1);                  // cexpf(-I phase), see fastmath.h; the next symbol's at the end of each step
     auto step = [&](int n, const float2 z) __attribute__((always_inline)) {
-#ifdef NRSC5HIP_COSTAS_DIRECT                                      // EXPERIMENT (DESIGN (h) 3): e^{2i phase} as the reference forms it, cexpf(-I * 2 * phase), not by the double-angle identities
-        float s2, c2; fast_sincos(2.0f * phase, s2, c2);
-#else
         const float s2 = 2.0f * s1 * c1, c2 = c1 * c1 - s1 * s1;                // e^{2i phase}
-#endif
         const float2 w = make_float2(z.x * z.x - z.y * z.y, z.x * z.y + z.y * z.x);
         const float ur = w.x * c2 + w.y * s2, ui = w.y * c2 - w.x * s2;         // w * e^{-2i phase}
         const float error = fast_atan2(ui, ur) * 0.5f;
