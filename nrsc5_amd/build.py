@@ -83,6 +83,8 @@ if __name__ == "__main__":
         print(build_emu(force=True))
     elif "--accurate-trig" in sys.argv:
         print(build_hip_diag(["-DNRSC5HIP_ACCURATE_TRIG"], "libnrsc5hip_acctrig.so"))
+    elif "--cmul-unfused" in sys.argv:
+        print(build_hip_diag(["-DNRSC5HIP_CMUL_UNFUSED"], "libnrsc5hip_unfused.so"))
     elif "--mixfft-noload" in sys.argv:
         print(build_hip_diag(["-DNRSC5HIP_MIXFFT_NOLOAD"], "libnrsc5hip_noload.so"))
     elif "--mixfft-phases" in sys.argv:

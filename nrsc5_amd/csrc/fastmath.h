@@ -63,6 +63,72 @@ __device__ __forceinline__ float fast_atan2(float y, float x)
 #endif
 }
 
+// cargf as the reference's libm computes it.  The coarse carrier angle of an acquisition block (acquire.c:153) and the AM receiver's carrier / equaliser phases go through
+// atan2f ONCE per block and their last bit matters: one ulp of the coarse angle is a phase ramp of 1.6e-5 rad across the block that runs the CFO search -- the size of the
+// oscillator's rounding drift (DESIGN.md (c) limit 2) -- and OCML's atan2f differs from glibc's in the last bit for 16 % of arguments.
+// fdlibm's float arc tangent (s_atanf.c / e_atan2f.c, as glibc 2.35 ships them for x86-64: no FMA variant exists for these two), restated: float operations only,
+// each rounded once -- the device reproduces glibc's atan2f bit for bit (tests/test_ref_atan2f.py: 2e7 arguments of four distributions against this container's libm, 0 mismatches; 1e8 when it was written).
+__device__ inline float ref_atanf(float x)
+{
+    const float atanhi[4] = { 4.6364760399e-01f, 7.8539812565e-01f, 9.8279368877e-01f, 1.5707962513e+00f };
+    const float atanlo[4] = { 5.0121582440e-09f, 3.7748947079e-08f, 3.4473217170e-08f, 7.5497894159e-08f };
+    const float aT[11] = { 3.3333334327e-01f, -2.0000000298e-01f, 1.4285714924e-01f, -1.1111110449e-01f, 9.0908870101e-02f, -7.6918758452e-02f,
+                           6.6610731184e-02f, -5.8335702866e-02f, 4.9768779427e-02f, -3.6531571299e-02f, 1.6285819933e-02f };
+    unsigned hxu; __builtin_memcpy(&hxu, &x, 4);
+    const int hx = (int)hxu, ix = hx & 0x7fffffff;
+    int id;
+    if (ix >= 0x4c000000) {                                    // |x| >= 2^25 (0x50800000 = 2^34 in older sources; glibc: 2^25)
+        if (ix > 0x7f800000) return x + x;                     // NaN
+        return hx > 0 ? atanhi[3] + atanlo[3] : -atanhi[3] - atanlo[3];
+    }
+    if (ix < 0x3ee00000) {                                     // |x| < 0.4375
+        if (ix < 0x31000000) return x;                         // |x| < 2^-29
+        id = -1;
+    } else {
+        x = __builtin_fabsf(x);
+        if (ix < 0x3f980000) {                                 // |x| < 1.1875
+            if (ix < 0x3f300000) { id = 0; x = (2.0f * x - 1.0f) / (2.0f + x); }      // 7/16 <= |x| < 11/16
+            else { id = 1; x = (x - 1.0f) / (x + 1.0f); }                              // 11/16 <= |x| < 19/16
+        } else {
+            if (ix < 0x401c0000) { id = 2; x = (x - 1.5f) / (1.0f + 1.5f * x); }      // |x| < 2.4375
+            else { id = 3; x = -1.0f / x; }
+        }
+    }
+    const float z = x * x, w = z * z;
+    const float s1 = z * (aT[0] + w * (aT[2] + w * (aT[4] + w * (aT[6] + w * (aT[8] + w * aT[10])))));
+    const float s2 = w * (aT[1] + w * (aT[3] + w * (aT[5] + w * (aT[7] + w * aT[9]))));
+    if (id < 0) return x - x * (s1 + s2);
+    const float r = atanhi[id] - ((x * (s1 + s2) - atanlo[id]) - x);
+    return hx < 0 ? -r : r;
+}
+__device__ inline float ref_atan2f(float y, float x)
+{
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f, pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    unsigned hxu, hyu; __builtin_memcpy(&hxu, &x, 4); __builtin_memcpy(&hyu, &y, 4);
+    const int hx = (int)hxu, hy = (int)hyu, ix = hx & 0x7fffffff, iy = hy & 0x7fffffff;
+    if (ix > 0x7f800000 || iy > 0x7f800000) return x + y;      // NaN
+    if (hx == 0x3f800000) return ref_atanf(y);                  // x = 1
+    const int m = ((hy >> 31) & 1) | ((hx >> 30) & 2);          // 2 * sign(x) + sign(y)
+    if (iy == 0) { switch (m) { case 0: case 1: return y; case 2: return pi + tiny; default: return -pi - tiny; } }
+    if (ix == 0) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000) {
+        if (iy == 0x7f800000) { switch (m) { case 0: return pi_o_4 + tiny; case 1: return -pi_o_4 - tiny; case 2: return 3.0f * pi_o_4 + tiny; default: return -3.0f * pi_o_4 - tiny; } }
+        switch (m) { case 0: return 0.0f; case 1: return -0.0f; case 2: return pi + tiny; default: return -pi - tiny; }
+    }
+    if (iy == 0x7f800000) return hy < 0 ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int k = (iy - ix) >> 23;
+    float z;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+    else if (hx < 0 && k < -60) z = 0.0f;
+    else z = ref_atanf(__builtin_fabsf(y / x));
+    switch (m) {
+    case 0: return z;
+    case 1: return -z;
+    case 2: return pi - (z - pi_lo);
+    default: return (z - pi_lo) - pi;
+    }
+}
+
 // Double-precision cosine / sine / arc tangent of SMALL arguments by their Taylor series (Horner), for the NCO step of the next
 // block (prepare_block: the single lane that runs it sits at the end of the block-step chain; the device libm's three calls were
 // ~5 k of the sync kernel's ~11 k "finish" cycles).  |x| <= 0.25: the series are cut where the next term is below 1e-20 of the

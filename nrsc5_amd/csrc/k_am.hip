@@ -12,6 +12,7 @@
 #include <atomic>
 #include <hip/hip_runtime.h>
 #include "kernels.h"
+#include "fastmath.h"
 #include "wave_ops.h"
 #include "l2_header.h"
 
@@ -805,7 +806,7 @@ __global__ __launch_bounds__(NT) void k_am_block(DevTables tb, DevBuffers db, co
             float sn, cs; sincosf(-st_prev_angle, &sn, &cs);
             const float pr = st_coarse_re * cs - st_coarse_im * sn;
             const float pi = st_coarse_re * sn + st_coarse_im * cs;
-            const float angle_diff = atan2f(pi, pr);
+            const float angle_diff = ref_atan2f(pi, pr);
             const float angle_factor = (st_prev_angle != 0.0f) ? 0.25f : 1.0f;
             angle = st_prev_angle + (angle_diff * angle_factor);
             st.prev_angle = angle;
@@ -861,8 +862,8 @@ __global__ __launch_bounds__(NT) void k_am_block(DevTables tb, DevBuffers db, co
     if (tid < NSYM) {
         const float2 c = sm.carrier[tid];
         float d;
-        if (tid == 0) d = atan2f(c.y, c.x);
-        else { const float2 q = cdivf(c, sm.carrier[tid - 1]); d = atan2f(q.y, q.x); }
+        if (tid == 0) d = ref_atan2f(c.y, c.x);
+        else { const float2 q = cdivf(c, sm.carrier[tid - 1]); d = ref_atan2f(q.y, q.x); }
         sm.dphi[tid] = d;
     }
     __syncthreads();
@@ -997,7 +998,7 @@ __global__ __launch_bounds__(NT) void k_am_block(DevTables tb, DevBuffers db, co
             const float2 a = am_bin(sm, off, t1), b2 = am_bin(sm, off, t2);
             const float2 m = cdivf(ideal, make_float2(a.x + b2.x, a.y + b2.y));
             sm.mult[part][col] = m;
-            if (part < 2) sm.marg[part][col] = atan2f(m.y, m.x);
+            if (part < 2) sm.marg[part][col] = ref_atan2f(m.y, m.x);
         }
         __syncthreads();
         AM_MARK(7);                                            // PIDS carriers + equaliser taps

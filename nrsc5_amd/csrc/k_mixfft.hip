@@ -63,6 +63,9 @@ __device__ __forceinline__ cf cmul3(cf a, cf b) { const cf t = a.yx * b.yy, sg =
 // three-instruction form, far inside the 1e-4 the float path is held to.  81 complex products per work-item and symbol.
 __device__ __forceinline__ cf cmul(cf a, cf b)
 {
+#ifdef NRSC5HIP_CMUL_UNFUSED                                       // diagnostic build (python -m nrsc5_amd.build --cmul-unfused): every product rounded before it is added, as the CPU twin does
+    return cmul3(a, b);
+#endif
     cf p;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "v"(a), "v"(b));
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "+v"(p) : "v"(a), "v"(b));
@@ -71,6 +74,9 @@ __device__ __forceinline__ cf cmul(cf a, cf b)
 // b a compile-time constant (or wave-uniform): a scalar register pair
 __device__ __forceinline__ cf cmul_k(cf a, cf b)
 {
+#ifdef NRSC5HIP_CMUL_UNFUSED
+    return cmul3(a, b);
+#endif
     cf p;
     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(p) : "v"(a), "s"(b));
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "+v"(p) : "v"(a), "s"(b));

@@ -117,7 +117,7 @@ template <typename S> __device__ inline Prepared prepare_values_of(const S &st, 
 #ifdef NRSC5HIP_ACCURATE_TRIG
         const float angle_diff = (float)atan2((double)pi, (double)pr);
 #else
-        const float angle_diff = atan2f(pi, pr);
+        const float angle_diff = ref_atan2f(pi, pr);
 #endif
         const float angle_factor = (st.prev_angle != 0.0f) ? 0.25f : 1.0f;
         angle = st.prev_angle + (angle_diff * angle_factor);

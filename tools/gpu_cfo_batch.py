@@ -15,6 +15,8 @@ def main():
     pols = [int(x) for x in (argv[1] if len(argv) > 1 else "0,1,2,3").split(",")]
     dev = torch.device("cuda", 0)
     lib = eng.DEFAULT_LIB
+    if "--unfused" in sys.argv:                                 # diagnostic twin: the FFT / mix complex products unfused (python -m nrsc5_amd.build --cmul-unfused)
+        lib = os.path.join(ROOT, "nrsc5_amd", "libnrsc5hip_unfused.so")
     if "--accurate" in sys.argv:                                # diagnostic twin: double-precision sine / cosine / arc tangent in the Costas loops (python -m nrsc5_amd.build --accurate-trig)
         lib = os.path.join(ROOT, "nrsc5_amd", "libnrsc5hip_acctrig.so")
     for b in bases:
