@@ -1112,11 +1112,15 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (MI355X); there is no CPU fallback")
-    if torch.cuda.device_count() < max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))):
+    share = os.environ.get("NRSC5_BENCH_SHARE_GPU") == "1"     # TEST MODE: every rank on GPU 0 (with NRSC5_SHARD_BACKEND=gloo): the N-rank flow on a one-GPU box; its numbers mean nothing
+    if not share and torch.cuda.device_count() < max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))):
         raise SystemExit(f"--gpus {args.gpus}: only {torch.cuda.device_count()} GPU(s) visible")
     rank, world, local = shard.init_from_env(expect_world=args.gpus)
+    if share:
+        local = 0
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    cdev = torch.device("cpu") if os.environ.get("NRSC5_SHARD_BACKEND") == "gloo" else dev      # where the collectives' tensors live
     from nrsc5_amd import engine as _eng
     _eng.check_fresh()                                           # never measure a library that was built from other sources
 
@@ -1141,7 +1145,7 @@ def main():
             if prof_all:
                 dom = dominant_class(prof_all)
     E.profile(0 if args.no_profile else dom)
-    shard.barrier(dev)
+    shard.barrier(cdev)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     pass_ms, tp = [], t0
@@ -1150,20 +1154,20 @@ def main():
         tn = time.perf_counter(); pass_ms.append((tn - tp) * 1e3); tp = tn      # a pass ends with its results on the host
     torch.cuda.synchronize()
     dt_rank = time.perf_counter() - t0
-    shard.barrier(dev)
+    shard.barrier(cdev)
     dt = time.perf_counter() - t0
     prof = E.profile(0)
     fwd_checked, fwd_repaired = E.fwd_stats() if hasattr(E, "fwd_stats") else (0, 0)
     tb_checked, tb_rewalked = E.tb_stats() if hasattr(E, "tb_stats") else (0, 0)
-    dt = shard.max_over_ranks(dt, dev)
-    per_rank_ms = [round(x / args.steps * 1e3, 3) for x in shard.gather_floats(dt_rank, dev)]
-    tot = shard.sum_over_ranks([W.samples, W.signal_seconds, 1.0], dev)
+    dt = shard.max_over_ranks(dt, cdev)
+    per_rank_ms = [round(x / args.steps * 1e3, 3) for x in shard.gather_floats(dt_rank, cdev)]
+    tot = shard.sum_over_ranks([W.samples, W.signal_seconds, 1.0], cdev)
     total_samples, total_seconds, ranks_seen = float(tot[0]), float(tot[1]), int(tot[2])     # ranks_seen: counted through the collective itself
 
     if hasattr(W, "unpermute"):
         recs, counts, frames = W.unpermute(recs, counts, frames)
     rows = W.verify(recs, counts, frames)
-    allrows = shard.gather_summaries(np.array(rows, dtype=np.int64), dev)
+    allrows = shard.gather_summaries(np.array(rows, dtype=np.int64), cdev)
     # Parity against the unmodified reference, on EVERY rank for its own streams (untimed): with --gpus N each rank fans its checker out
     # over its share of the host cores and the verdicts are gathered, so that one multi-GPU run proves all N x 256 streams, not rank 0's.
     checker = not args.no_cpu_baseline
@@ -1176,13 +1180,13 @@ def main():
         tot = lambda key: float(sum(x.get(key, 0) for x in subs))
         vec = [float(rank), float(len(my_streams)), tot("streams_compared"), tot("lost_sync_streams_equal") + tot("other_streams_equal"),
                tot("streams_equal_under_the_strict_rule"), tot("streams_with_transient_loop_state_deviation"), float(len(FAILURES) - n_fail0), float(bool(checker))]
-        g = shard.gather_vectors(vec, dev)
+        g = shard.gather_vectors(vec, cdev)
         per_rank_parity = [{"rank": int(r[0]), "streams": int(r[1]), "streams_compared": int(r[2]), "streams_equal": int(r[3]), "streams_equal_under_the_strict_rule": int(r[4]),
                             "streams_with_transient_loop_state_deviation": int(r[5]), "parity_failures": int(r[6]), "checker_ran": bool(r[7])} for r in g]
         # this rank's own verdict, one line on stderr (rank 0's stdout line carries all of them)
         print("rank-parity " + json.dumps(per_rank_parity[rank] | {"failures": FAILURES[n_fail0:]}), file=sys.stderr)
         sys.stderr.flush()
-    shard.shutdown(dev)                  # every collective of the run is behind us: the ranks leave the group together
+    shard.shutdown(cdev)                  # every collective of the run is behind us: the ranks leave the group together
     if rank != 0:
         if _POOL is not None:
             _POOL.close()

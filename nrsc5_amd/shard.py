@@ -33,6 +33,9 @@ def init_from_env(backend: str | None = None, expect_world: int | None = None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        # NRSC5_SHARD_BACKEND=gloo: TEST MODE of bench.py (with NRSC5_BENCH_SHARE_GPU=1: N ranks on ONE GPU, collectives on CPU tensors) -- the multi-rank
+        # flow incl. the per-rank parity gather on a single-GPU box; RCCL cannot put two ranks on one device
+        backend = backend or os.environ.get("NRSC5_SHARD_BACKEND")
         dist.init_process_group(backend=backend or ("nccl" if torch.cuda.is_available() else "gloo"),
                                 rank=rank, world_size=world)
     seen = dist.get_world_size() if dist.is_initialized() else 1
