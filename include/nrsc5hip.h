@@ -8,6 +8,7 @@
  *   nrsc5hip_push_cu8                        input_push_cu8      src/input.h:42, input.c:96-117
  *   nrsc5hip_push_cs16                       input_push_cs16     src/input.h:43, input.c:119-124
  *   nrsc5hip_stream_reset                    input_reset         src/input.h:39, input.c:126-138
+ *   nrsc5hip_stream_fresh                    nrsc5_close + nrsc5_open_pipe of one slot   src/nrsc5.c
  *   nrsc5hip_force_resync                    input_set_sync_state(st, SYNC_STATE_NONE) as called
  *                                            by frame_process    src/frame.c:535-540
  *   up-calls delivered as ordered records    output_advance (acquire.c:108), nrsc5_report_sync /
@@ -161,8 +162,15 @@ int nrsc5hip_device_free(int device, void *dev);
 int nrsc5hip_push_cu8(nrsc5hip_engine *e, int stream, const uint8_t *iq, uint32_t nbytes);
 /* input_push_cs16 (input.c:119-124): n = number of int16 values, n % 2 == 0 */
 int nrsc5hip_push_cs16(nrsc5hip_engine *e, int stream, const int16_t *iq, uint32_t n);
-/* input_reset (input.c:126-138), fresh-session semantics */
+/* input_reset (input.c:126-138) on a session that may have been used: like the reference's, the reset rewinds the FIR windows without clearing them
+ * (firdecim_q15_reset, firdecim_q15.c:53-56) -- the first 7 samples out of the FM half-band and the acquisition filter's first 31 outputs (filter_fm or
+ * filter_am, acquire.c:290-293) see the samples the window's last compaction left at its front, exactly as a second capture on one nrsc5_t does
+ * (tests: engine_checks.check_reset_keeps_fir_windows vs the unmodified reference).  Bytes of a partial push still staged on the host pass through the
+ * decimator first.  Not reproduced: stages 1-4 of the AM cu8 cascade start from zeros (their stage 0 is tracked, so an FM session that follows is exact);
+ * engines with batch_zero_copy treat every reset as a fresh session. */
 int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream);
+/* nrsc5_close + nrsc5_open_pipe on this slot: a fresh session (calloc'd windows), what nrsc5hip_reset_all does for every stream */
+int nrsc5hip_stream_fresh(nrsc5hip_engine *e, int stream);
 /* nrsc5_set_mode -> input_set_mode (nrsc5.h:754, input.c:158-162): NRSC5HIP_MODE_FM (default) or _AM; resets the stream.
  * AM: cu8 pushes go through the 5-stage 32:1 decimator, cs16 pushes are 46511.71875 S/s samples (input.c:70-91,119-124);
  * every FINE block yields a PIDS frame and (after the 4-frame diversity start-up) one 3750-bit P1 frame, block 7 also the

@@ -1282,15 +1282,30 @@ extern "C" int nrsc5hip_push_cs16(nrsc5hip_engine *e, int stream, const int16_t 
     return push_common(e, stream, iq, (size_t)n * 2, false);
 }
 
-extern "C" int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream)
+// input_reset (input.c:126-138).  keep_windows: the reference's reset of a USED session -- firdecim_q15_reset rewinds the index of every FIR window
+// and leaves its samples (firdecim_q15.c:53-56), so decim[0]'s first outputs and the acquisition filter's first 31 see what the last compaction of
+// their windows left there (StaleWindows, nrsc5_dev.h).  Otherwise a fresh session (nrsc5_open_pipe: calloc'd windows).
+static int reset_stream(nrsc5hip_engine *e, int stream, bool keep_windows)
 {
     ON_ENGINE_DEVICE(e);
     int rc = check_stream(e, stream); if (rc) return rc;
-    if (e->staged_stream == stream) { e->staged_stream = -1; e->staged_bytes = 0; e->staged_q15 = 0; }      // samples not yet submitted die with the session
+    if (e->staged_stream == stream) {
+        // samples not yet submitted die with the session -- but the reference's decimator has seen them (decimate_samples runs inside the push): when the
+        // windows are kept they go through the decimator first (no block step: wr alone moves, and the reset below forgets it)
+        if (keep_windows && e->staged_bytes && (rc = flush_staged(e))) return rc;
+        e->staged_stream = -1; e->staged_bytes = 0; e->staged_q15 = 0;
+    }
     // this engine's queues only (another session of the process keeps running)
+    if (e->ingest) HIPCHK(hipStreamSynchronize(e->ingest));
     HIPCHK(hipStreamSynchronize(e->main));
     if (e->cfg.p1_async) { for (int k = 0; k < NAUX; k++) HIPCHK(hipStreamSynchronize(e->lane.aux[k])); HIPCHK(hipStreamSynchronize(e->dec_stream)); }
     StreamState st; init_state(st, e->mode_host[stream]);
+    if (keep_windows && !e->cfg.batch_zero_copy) {             // (zero-copy engines: every attach is an independent recording, read in place with byte-valued history)
+        HIPCHK(hipMemcpy(&st.stale, (const char *)(e->db.state + stream) + offsetof(StreamState, stale), sizeof(st.stale), hipMemcpyDeviceToHost));
+        st.stale.hb_pushed = 0; st.stale.fir_pushed[0] = 0; st.stale.fir_pushed[1] = 0;
+        memcpy(st.hb_hist, st.stale.hb, sizeof(st.hb_hist));
+        memcpy(st.fir_hist, st.stale.fir[st.mode == MODE_AM ? MODE_AM : MODE_FM], sizeof(st.fir_hist));
+    }
     HIPCHK(hipMemcpy(e->db.state + stream, &st, sizeof(st), hipMemcpyHostToDevice));
     if (e->db.am) {
         AmStream am; init_am_state(am);
@@ -1305,6 +1320,9 @@ extern "C" int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream)
     return 0;
 }
 
+extern "C" int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream) { return reset_stream(e, stream, true); }
+extern "C" int nrsc5hip_stream_fresh(nrsc5hip_engine *e, int stream) { return reset_stream(e, stream, false); }
+
 // nrsc5_set_mode -> input_set_mode (input.c:158-162): switch the stream's waveform and reset it
 extern "C" int nrsc5hip_stream_set_mode(nrsc5hip_engine *e, int stream, int mode)
 {
@@ -1313,6 +1331,7 @@ extern "C" int nrsc5hip_stream_set_mode(nrsc5hip_engine *e, int stream, int mode
     if (mode != NRSC5HIP_MODE_FM && mode != NRSC5HIP_MODE_AM) FAIL(NRSC5HIP_EINVAL, "unknown mode %d", mode);
     if (mode == NRSC5HIP_MODE_AM && !e->db.am) FAIL(NRSC5HIP_EINVAL, "engine was created without am_enable");
     if (mode == NRSC5HIP_MODE_AM && e->db.q15_cap < 2 * AM_WIN) FAIL(NRSC5HIP_EINVAL, "q15_capacity too small");
+    if (e->staged_stream == stream && e->staged_bytes && (rc = flush_staged(e))) return rc;     // bytes pushed in the old mode pass through the old mode's decimator (reset_stream)
     e->mode_host[stream] = mode;
     return nrsc5hip_stream_reset(e, stream);
 }
@@ -1903,7 +1922,7 @@ extern "C" int nrsc5hip_stage_halfband_fm_cu8(nrsc5hip_engine *e, const uint8_t 
     // runs the production K1 kernel on stream 0 of a scratch state: requires a freshly reset stream 0
     int rc = check_stream(e, 0); if (rc) return rc;
     if (nbytes % 4 || nbytes > e->stage_bytes || nbytes / 4 > e->db.q15_cap) FAIL(NRSC5HIP_EINVAL, "bad length");
-    if ((rc = nrsc5hip_stream_reset(e, 0))) return rc;
+    if ((rc = nrsc5hip_stream_fresh(e, 0))) return rc;
     const int s = 0; const unsigned count = nbytes;
     HIPCHK(hipMemcpy(e->stage_dev, iq, nbytes, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(e->ids_dev, &s, sizeof(int), hipMemcpyHostToDevice));
@@ -1911,7 +1930,7 @@ extern "C" int nrsc5hip_stage_halfband_fm_cu8(nrsc5hip_engine *e, const uint8_t 
     launch_decimate_fm_cu8(e->tb, e->db, 1, e->ids_dev, e->stage_dev, 0, e->nbytes_dev, count, e->main);
     HIPCHK(hipStreamSynchronize(e->main));
     HIPCHK(hipMemcpy(out, e->db.q15, (size_t)(nbytes / 4) * sizeof(c16), hipMemcpyDeviceToHost));
-    return nrsc5hip_stream_reset(e, 0);
+    return nrsc5hip_stream_fresh(e, 0);
 }
 
 extern "C" int nrsc5hip_stage_fft2048(nrsc5hip_engine *e, const float *in, float *out, int n)

@@ -157,7 +157,14 @@ __global__ __launch_bounds__(256) void k_acq_peak(DevTables tb, DevBuffers db, c
         st.coarse_re = best_v.x; st.coarse_im = best_v.y;
     }
     // the FIR's sliding window now ends at the last sample of this acquire window
-    if (tid < 31) st.fir_hist[tid] = acq_window(db, st, s)[WIN_N - 31 + tid];
+    if (tid < 31) {
+        const c16 *win = acq_window(db, st, s);
+        st.fir_hist[tid] = win[WIN_N - 31 + tid];
+        const long long p = stale_start(st.stale.fir_pushed[MODE_FM], WIN_N, 31);          // filter_fm's last compaction inside this block (StaleWindows, nrsc5_dev.h)
+        if (p != STALE_NONE) st.stale.fir[MODE_FM][tid] = win[p + tid];
+    }
+    __syncthreads();
+    if (tid == 0) st.stale.fir_pushed[MODE_FM] += WIN_N;
 }
 
 void launch_acquire(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st)

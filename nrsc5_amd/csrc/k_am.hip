@@ -120,11 +120,20 @@ __global__ __launch_bounds__(256) void k_am_decimate_commit(DevBuffers db, const
         else if (r >= 0 && r >= am.raw_count - AM_RAW_HIST) { const long long h = r - (am.raw_count - AM_RAW_HIST); a = am.raw_hist[2 * h]; b = am.raw_hist[2 * h + 1]; }
         nh[2 * k] = a; nh[2 * k + 1] = b;
     }
+    // decim[0] takes every raw sample (>> 4) in this mode too: what its last compaction inside the chunk leaves at the front of the
+    // window is what an FM session after the next reset starts from (StaleWindows, nrsc5_dev.h; stages 1-4 are not tracked)
+    const long long p0 = stale_start(st.stale.hb_pushed, nraw, 14);
+    if (p0 != STALE_NONE && threadIdx.x < 14) {
+        int re, im;
+        am_raw_fetch(am, iq, am.raw_count + p0 + threadIdx.x, nraw, re, im);
+        st.stale.hb[threadIdx.x].r = (int16_t)re; st.stale.hb[threadIdx.x].i = (int16_t)im;
+    }
     __syncthreads();
     for (int k = threadIdx.x; k < 2 * AM_RAW_HIST; k += 256) am.raw_hist[k] = nh[k];
     if (threadIdx.x == 0) {
         st.wr += (am.raw_count + nraw) / 32 - am.raw_count / 32;
         am.raw_count += nraw;
+        st.stale.hb_pushed += nraw;
     }
 }
 
@@ -778,8 +787,13 @@ __global__ __launch_bounds__(NT) void k_am_block(DevTables tb, DevBuffers db, co
             st.coarse_samperr = (best_i + AM_SYM - 15) % AM_SYM;       // FILTER_DELAY, acquire.c:149
             st.coarse_re = best_v.x; st.coarse_im = best_v.y;
         }
-        if (tid < 31) st.fir_hist[tid] = win[AM_WIN - 31 + tid];
+        if (tid < 31) {
+            st.fir_hist[tid] = win[AM_WIN - 31 + tid];
+            const long long p = stale_start(st.stale.fir_pushed[MODE_AM], AM_WIN, 31);     // filter_am's compaction inside this block (>= 0: AM_WIN > 2 * 2017)
+            if (p != STALE_NONE) st.stale.fir[MODE_AM][tid] = win[p + tid];
+        }
         __syncthreads();
+        if (tid == 0) st.stale.fir_pushed[MODE_AM] += AM_WIN;
     }
 
     AM_MARK(0);                                                // tables + coarse acquisition (while not FINE)

@@ -33,6 +33,25 @@ __device__ inline void fetch_q15(const uint8_t *iq, const c16 *hist, long long k
     else { r = q15_of_u8(iq[2 * k]); i = q15_of_u8(iq[2 * k + 1]); }
 }
 
+// End of a chunk of nsamp complex input samples (one work-item per stream): note what decim[0]'s last compaction inside the chunk
+// leaves at the front of its window (StaleWindows, nrsc5_dev.h), then roll the 14-sample history.
+__device__ inline void hb_roll_history(StreamState &st, const uint8_t *iq, long long nsamp)
+{
+    const long long p = stale_start(st.stale.hb_pushed, nsamp, 14);
+    c16 nh[14], sw[14];
+    for (int k = 0; k < 14; k++) {
+        int r, i;
+        fetch_q15(iq, st.hb_hist, nsamp - 14 + k, r, i);
+        nh[k].r = (int16_t)r; nh[k].i = (int16_t)i;
+        if (p != STALE_NONE) { fetch_q15(iq, st.hb_hist, p + k, r, i); sw[k].r = (int16_t)r; sw[k].i = (int16_t)i; }
+    }
+    for (int k = 0; k < 14; k++) {
+        st.hb_hist[k] = nh[k];
+        if (p != STALE_NONE) st.stale.hb[k] = sw[k];
+    }
+    st.stale.hb_pushed += nsamp;
+}
+
 __global__ __launch_bounds__(256) void k_decimate_fm_cu8(DevTables tb, DevBuffers db, const int *ids,
                                                          const uint8_t *iq_base, long long iq_stride, const unsigned *nbytes)
 {
@@ -88,13 +107,7 @@ __global__ void k_decimate_commit(DevBuffers db, const int *ids, const uint8_t *
     const uint8_t *iq = iq_base + (size_t)sidx * iq_stride;
     const long long nsamp = nbytes[sidx] / 2;                  // complex input samples (even)
     if (nsamp == 0) return;
-    c16 nh[14];
-    for (int k = 0; k < 14; k++) {
-        int r, i;
-        fetch_q15(iq, st.hb_hist, nsamp - 14 + k, r, i);
-        nh[k].r = (int16_t)r; nh[k].i = (int16_t)i;
-    }
-    for (int k = 0; k < 14; k++) st.hb_hist[k] = nh[k];
+    hb_roll_history(st, iq, nsamp);
     st.wr += nsamp / 2;
 }
 
@@ -157,13 +170,7 @@ __global__ __launch_bounds__(256) void k_decimate_fm_cu8_stream(DevTables tb, De
     *ticket = 0;
     const long long nsamp = nb / 2;                            // complex input samples (even)
     if (nsamp == 0) return;
-    c16 nh[14];
-    for (int k = 0; k < 14; k++) {
-        int r, i;
-        fetch_q15(iq, st.hb_hist, nsamp - 14 + k, r, i);
-        nh[k].r = (int16_t)r; nh[k].i = (int16_t)i;
-    }
-    for (int k = 0; k < 14; k++) st.hb_hist[k] = nh[k];
+    hb_roll_history(st, iq, nsamp);
     st.wr += nsamp / 2;
 }
 

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void k_rollback(DevBuffers db, const int *ids,
     // tracking state as of the end of block a; the input side (wr, base, hb_hist), the record / ring-slot counters and the
     // per-window job descriptors keep their current values
     for (int l = tid; l < LIVE_N; l += 256) { st.costas_freq[l] = ck.costas_freq[l]; st.costas_phase[l] = ck.costas_phase[l]; }
-    if (tid < 31) st.fir_hist[tid] = ck.fir_hist[tid];
+    if (tid < 31) { st.fir_hist[tid] = ck.fir_hist[tid]; st.stale.fir[MODE_FM][tid] = ck.stale.fir[MODE_FM][tid]; }    // the acquisition filter's window as of block a
     if (tid == 0) {
         st.rd = ck.rd;
         st.prev_angle = ck.prev_angle; st.theta = ck.theta; st.keep_extra = ck.keep_extra; st.cfo = ck.cfo;
@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void k_rollback(DevBuffers db, const int *ids,
         st.started_pm = ck.started_pm; st.pm_slot = ck.pm_slot; st.last_pm_slot = ck.last_pm_slot;
         st.px_pos = ck.px_pos; st.px_ready = ck.px_ready; st.px_started = ck.px_started; st.px_go = 0;
         st.fine_epoch = ck.fine_epoch;
+        st.stale.fir_pushed[MODE_FM] = ck.stale.fir_pushed[MODE_FM];
         st.sync_state = SYNC_NONE;                             // input_set_sync_state(NONE) at the end of block a
         st.active = 0;                                         // a block the fused bookkeeping already opened is void
         BlockRecord &rec = ring[a % db.rec_cap];
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256) void k_rollback_am(DevBuffers db, const int *i
     const AmCkpt &ck = db.am_ckpt[((size_t)s * NWIN + p) * 8 + j];
     const int a = db.am_job[(size_t)s * NWIN + p].deliver_abs[j], n = st.nblocks;
     for (int r = a + 1 + tid; r < n; r += 256) atomicOr(&ring[r % db.rec_cap].flags, (uint32_t)REC_DISCARDED);
-    if (tid < 31) st.fir_hist[tid] = ck.st.fir_hist[tid];
+    if (tid < 31) { st.fir_hist[tid] = ck.st.fir_hist[tid]; st.stale.fir[MODE_AM][tid] = ck.st.stale.fir[MODE_AM][tid]; }
     if (tid == 0) {
         // tracking state as of the end of block a; the input side (wr, base, the 32:1 decimator's raw history) and the record /
         // frame-slot counters keep their current values
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(256) void k_rollback_am(DevBuffers db, const int *i
         st.prev_angle = ck.st.prev_angle; st.theta = ck.st.theta; st.keep_extra = ck.st.keep_extra; st.cfo = ck.st.cfo;
         st.psmi = ck.st.psmi; st.cfo_wait = ck.st.cfo_wait; st.bc = ck.st.bc; st.samperr = ck.st.samperr; st.angle = ck.st.angle;
         st.fine_epoch = ck.st.fine_epoch;
+        st.stale.fir_pushed[MODE_AM] = ck.st.stale.fir_pushed[MODE_AM];
         am.pli = ck.am.pli; am.hppi = ck.am.hppi; am.aabi = ck.am.aabi; am.rdbi = ck.am.rdbi; am.offset_history = ck.am.offset_history;
         am.am_errors = ck.am.am_errors; am.am_diversity_wait = ck.am.am_diversity_wait;
         am.q_head = j == 7 ? (ck.am.q_head + 1) % 3 : ck.am.q_head;       // block 7's checkpoint predates its de-interleaver pass (k_am_interleave)

@@ -68,6 +68,32 @@ __host__ __device__ inline int bin_to_live(int b) { return b < FFT_N / 2 ? b - L
 
 struct c16 { int16_t r, i; };
 
+// ---- what a reset leaves in the reference's FIR windows ------------------------------------------------------------
+// firdecim_q15_reset only rewinds the window index to ntaps - 1 (firdecim_q15.c:53-56); the samples below it stay.  push()
+// (firdecim_q15.c:58-67) copies the newest ntaps - 1 samples to the front of the 2048-sample window whenever the index reaches
+// its end, i.e. at push number k (2048 - (ntaps - 1)), k >= 1, counted from the filter's last reset -- so after input_reset
+// (input.c:126-138: the five decimator stages; acquire_reset, acquire.c:290-293: filter_fm and filter_am) the first outputs of a
+// USED session see, as their history, the ntaps - 1 samples that preceded the filter's LAST compaction (zeros for a fresh
+// session: calloc).  The engine keeps those samples per stream and nrsc5hip_stream_reset seeds hb_hist / fir_hist with them.
+constexpr int FIRDECIM_WINDOW = 2048;           // WINDOW_SIZE, firdecim_q15.c:16
+struct StaleWindows {
+    c16 hb[14];                                 // decim[0] (both modes push it: FM samples, AM samples >> 4)
+    c16 fir[2][31];                             // filter_fm, filter_am (acquire.c:312-313)
+    long long hb_pushed;                        // samples pushed since the reset
+    long long fir_pushed[2];
+};
+// a window that had taken `a` samples since its reset takes n more: position, relative to the first of the n, of the first of the
+// `hist` samples its last compaction inside this span moves to the front (>= -hist); STALE_NONE if the span holds no compaction
+constexpr long long STALE_NONE = -(1ll << 40);
+__host__ __device__ inline long long stale_start(long long a, long long n, int hist)
+{
+    const long long period = FIRDECIM_WINDOW - hist, b = a + n;
+    if (n <= 0) return STALE_NONE;
+    const long long kb = (b - 1) / period * period;            // the compaction runs inside push number kb (0-based), before it stores
+    if (kb < period || kb < a) return STALE_NONE;
+    return kb - a - hist;
+}
+
 // record flags
 enum : uint32_t {
     REC_PROCESSED   = 1u << 0,   // a block was processed in this slot
@@ -162,6 +188,7 @@ struct StreamState {
     int px_count;               // block pairs that produced frames so far (ring slot)
     int px_go;                  // this step: soft bits per block of a completed pair (0: nothing to de-interleave)
     int px_nch, px_slot, px_record;
+    StaleWindows stale;         // survives nrsc5hip_stream_reset (the reference's rewound windows); cleared by a fresh session
 };
 
 // AM-only per-stream state (allocated when the engine is created with am_enable)

@@ -106,6 +106,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.nrsc5hip_push_cu8.argtypes = [vp, ci, vp, ctypes.c_uint32]
     lib.nrsc5hip_push_cs16.argtypes = [vp, ci, vp, ctypes.c_uint32]
     lib.nrsc5hip_stream_reset.argtypes = [vp, ci]
+    lib.nrsc5hip_stream_fresh.argtypes = [vp, ci]
     lib.nrsc5hip_force_resync.argtypes = [vp, ci]
     lib.nrsc5hip_bytes_to_next_block.argtypes = [vp, ci, ci]
     lib.nrsc5hip_bytes_to_next_block.restype = ctypes.c_longlong
@@ -174,7 +175,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
 
 EXPORTED_SYMBOLS = [
     "nrsc5hip_engine_create", "nrsc5hip_engine_destroy", "nrsc5hip_last_error", "nrsc5hip_source_sha", "nrsc5hip_engine_hip_stream",
-    "nrsc5hip_push_cu8", "nrsc5hip_push_cs16", "nrsc5hip_stream_reset", "nrsc5hip_force_resync", "nrsc5hip_bytes_to_next_block",
+    "nrsc5hip_push_cu8", "nrsc5hip_push_cs16", "nrsc5hip_stream_reset", "nrsc5hip_stream_fresh", "nrsc5hip_force_resync", "nrsc5hip_bytes_to_next_block",
     "nrsc5hip_batch_append_cu8", "nrsc5hip_batch_append_cs16", "nrsc5hip_batch_process", "nrsc5hip_drain",
     "nrsc5hip_p1_frame_packed", "nrsc5hip_p1_frame_bits", "nrsc5hip_batch_fetch", "nrsc5hip_unpack_bits",
     "nrsc5hip_stage_halfband_fm_cu8", "nrsc5hip_stage_fft2048", "nrsc5hip_stage_viterbi_k7", "nrsc5hip_debug_fetch", "nrsc5hip_debug_fetch_costas",
@@ -266,7 +267,12 @@ class Engine:
         self._check(self.lib.nrsc5hip_push_cs16(self._h, stream, iq.ctypes.data, iq.size))
 
     def reset(self, stream: int):
+        """input_reset of a session that may have been used: the FIR windows are rewound, not cleared (include/nrsc5hip.h)"""
         self._check(self.lib.nrsc5hip_stream_reset(self._h, stream))
+
+    def fresh(self, stream: int):
+        """a new session on this slot (nrsc5_close + nrsc5_open_pipe)"""
+        self._check(self.lib.nrsc5hip_stream_fresh(self._h, stream))
 
     def set_mode(self, stream: int, mode: int):
         """nrsc5_set_mode for one stream (MODE_FM / MODE_AM); resets it."""

@@ -68,10 +68,10 @@ class RefLib:
             self.lib.refh_close()
         return parse_log(log), np.frombuffer(q15, dtype=np.int16).reshape(-1, 2), np.frombuffer(fft, dtype=np.complex64)
 
-    def run_with_mode_switch(self, iq_a: np.ndarray, iq_b: np.ndarray, mode: int = MODE_FM, taps: int = 0, chunk: int = 32768):
-        """One session: capture A, then nrsc5_set_mode(mode) on the live session (input_reset, input.c:126-138), then
-        capture B.  Returns (log of A, log of B, q15 of B) -- what the reference does after a reset of a USED session,
-        including firdecim_q15_reset leaving stale samples in its window (firdecim_q15.c:53-56)."""
+    def run_with_mode_switch(self, iq_a: np.ndarray, iq_b: np.ndarray, mode: int = MODE_FM, taps: int = 0, chunk: int = 32768, mode_b: int | None = None):
+        """One session: capture A in `mode`, then nrsc5_set_mode(mode_b, default: the same mode) on the live session (input_reset,
+        input.c:126-138), then capture B.  Returns (log of A, log of B, q15 of B) -- what the reference does after a reset of a
+        USED session, including firdecim_q15_reset leaving stale samples in its windows (firdecim_q15.c:53-56)."""
         L = self.lib
         L.refh_set_mode.restype = ctypes.c_size_t
         L.refh_q15_len.restype = ctypes.c_size_t
@@ -79,11 +79,10 @@ class RefLib:
             raise RuntimeError("refh_open failed")
         try:
             a = np.ascontiguousarray(iq_a); b = np.ascontiguousarray(iq_b)
-            run = L.refh_run_cu8 if a.dtype == np.uint8 else L.refh_run_cs16
-            run(a.ctypes.data, a.size, chunk)
+            (L.refh_run_cu8 if a.dtype == np.uint8 else L.refh_run_cs16)(a.ctypes.data, a.size, chunk)
             q_split = L.refh_q15_len()
-            split = L.refh_set_mode(mode)
-            run(b.ctypes.data, b.size, chunk)
+            split = L.refh_set_mode(mode if mode_b is None else mode_b)
+            (L.refh_run_cu8 if b.dtype == np.uint8 else L.refh_run_cs16)(b.ctypes.data, b.size, chunk)
             log, q15 = self._buf(0), self._buf(1)
         finally:
             L.refh_close()

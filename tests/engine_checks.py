@@ -644,6 +644,91 @@ def check_mode_switch(lib, oracle):
     E.close()
 
 
+def check_reset_keeps_fir_windows(lib, reflib, offsets=(0, 10)):
+    """nrsc5hip_stream_reset on a USED stream == input_reset on a used session of the unmodified reference (nrsc5_set_mode on a live
+    pipe session): firdecim_q15_reset rewinds the FIR windows without clearing them (firdecim_q15.c:53-56), so
+      * the half-band's first 7 outputs see the 14 samples its window's last compaction left at the front (Q15 samples bit for bit),
+      * the acquisition filter's first 31 outputs see 31 samples of the previous capture's last un-synchronised block -- visible in the
+        first block's timing pick / angle when the new capture's symbol boundary falls into the first samples of the window.
+    Capture A is full-scale noise (nothing locks: every block runs the acquisition filter), capture B a signal whose boundary sits at
+    sample ~0 / ~5 of the window: in the REFERENCE the used session's log differs from a fresh session's (asserted, so the check cannot
+    pass vacuously); the engine equals the used session after reset() and the fresh one after fresh()."""
+    from oracle import ref
+    rng = np.random.default_rng(5)
+    a = rng.integers(0, 256, size=4 * 71280 * 3 + 4 * 5000, dtype=np.uint8)
+    E = eng.Engine(max_streams=1, q15_capacity=400000, lib_path=lib)
+    differing = 0
+    for off in offsets:
+        b = synth.fm_mp1_capture(0, seed=82, cfo_hz=120.0, offset=off, snr_db=20, n_blocks=20).iq
+        b = b[:b.size - b.size % 4]
+        _, used_log, used_q15 = reflib.run_with_mode_switch(a, b, taps=ref.TAP_Q15)
+        fresh_log, fresh_q15, _ = reflib.run(b, taps=ref.TAP_Q15)
+        assert (used_q15[:7] != fresh_q15[:7]).any() and np.array_equal(used_q15[7:20000], fresh_q15[7:20000])
+        differing += bool(common.compare_logs(common.strip_states(fresh_log), common.strip_states(used_log)))
+        for how, exp_log, exp_q15 in (("reset", used_log, used_q15), ("fresh", fresh_log, fresh_q15)):
+            E.fresh(0)
+            common.run_engine_streaming(E, 0, a, chunk=32768)
+            E.drain(0)
+            getattr(E, how)(0)
+            E.push_cu8(0, b[:4 * 20000])                           # below one window: nothing is consumed, the FIFO starts at the reset
+            assert np.array_equal(_fetch_q15(E, 20000), exp_q15[:20000]), (off, how)
+            common.run_engine_streaming(E, 0, b[4 * 20000:], chunk=32768)
+            E.push_cu8(0, np.zeros(0, dtype=np.uint8))
+            log = eng.records_to_log(E, 0, E.drain(0))
+            diffs = common.compare_logs(common.strip_states(exp_log), common.strip_states(log))
+            assert not diffs, (off, how, diffs[:5])
+    assert differing >= 1, "the reference's used session no longer differs from a fresh one: the captures lost their point"
+    E.close()
+
+
+def check_reset_keeps_fir_windows_am(lib, reflib, offsets=(132, 138)):
+    """The same for filter_am (AM cs16: a noise capture, then a signal whose symbol boundary sits at the start of the window), and across a
+    mode switch: an AM cu8 capture pushes decim[0] with samples >> 4 (input.c:70-76) -- an FM session on the same nrsc5_t afterwards starts
+    its half-band from THOSE 14 samples, while its acquisition filter (filter_fm, never used so far) starts from zeros."""
+    from oracle import ref
+    from nrsc5_amd import synth_am
+    rng = np.random.default_rng(6)
+    a = rng.integers(-20000, 20000, size=2 * 8910 * 3 + 2 * 700, dtype=np.int16)
+    E = eng.Engine(max_streams=1, q15_capacity=400000, record_capacity=512, p1_slots=16, lib_path=lib, am_enable=True)
+    E.set_mode(0, eng.MODE_AM)
+    differing = 0
+    for off in offsets:
+        b = synth_am.am_ma1_capture(9, seed=72, cfo_hz=1.0, offset=off).iq
+        _, used_log, _ = reflib.run_with_mode_switch(a, b, mode=ref.MODE_AM)
+        fresh_log, _, _ = reflib.run(b, mode=ref.MODE_AM)
+        differing += bool(common.compare_logs(common.strip_states(fresh_log), common.strip_states(used_log)))
+        for how, exp_log in (("reset", used_log), ("fresh", fresh_log)):
+            E.fresh(0)
+            common.run_engine_streaming(E, 0, a, chunk=32768)
+            E.drain(0)
+            getattr(E, how)(0)
+            common.run_engine_streaming(E, 0, b, chunk=32768)
+            E.push_cs16(0, np.zeros(0, dtype=np.int16))
+            log = eng.am_records_to_log(E, 0, E.drain(0))
+            diffs = common.compare_logs(common.strip_states(exp_log), common.strip_states(log))
+            assert not diffs, (off, how, diffs[:5])
+    assert differing == len(offsets), "the reference's used AM session no longer differs from a fresh one"
+    # AM cu8 -> FM cu8 on one session
+    a8 = rng.integers(0, 256, size=4 * 40000, dtype=np.uint8)
+    b = synth.fm_mp1_capture(0, seed=82, cfo_hz=120.0, offset=0, snr_db=20, n_blocks=20).iq
+    b = b[:b.size - b.size % 4]
+    _, used_log, used_q15 = reflib.run_with_mode_switch(a8, b, mode=ref.MODE_AM, mode_b=ref.MODE_FM, taps=ref.TAP_Q15)
+    fresh_log, fresh_q15, _ = reflib.run(b, taps=ref.TAP_Q15)
+    assert (used_q15[:7] != fresh_q15[:7]).any() and np.array_equal(used_q15[7:20000], fresh_q15[7:20000])
+    E.fresh(0)
+    common.run_engine_streaming(E, 0, a8, chunk=32768)
+    E.drain(0)
+    E.set_mode(0, eng.MODE_FM)
+    E.push_cu8(0, b[:4 * 20000])
+    assert np.array_equal(_fetch_q15(E, 20000), used_q15[:20000])
+    common.run_engine_streaming(E, 0, b[4 * 20000:], chunk=32768)
+    E.push_cu8(0, np.zeros(0, dtype=np.uint8))
+    log = eng.records_to_log(E, 0, E.drain(0))
+    diffs = common.compare_logs(common.strip_states(used_log), common.strip_states(log))
+    assert not diffs, diffs[:5]
+    E.close()
+
+
 def check_pids_crc_flag(lib, oracle, am=False):
     """REC_PIDS_CRC == pids_frame_push's CRC-12 decision (restated in the oracle, pinned against the reference's
     STATION_ID events): frames with a fresh station id in every block, every fifth one with a broken CRC."""

@@ -170,6 +170,13 @@ def test_emu_mode_switch_on_live_stream(emu_lib, oracle):
     ec.check_mode_switch(emu_lib, oracle)
 
 
+def test_emu_reset_of_a_used_stream_keeps_the_fir_windows(emu_lib, reflib):
+    """nrsc5hip_stream_reset == the unmodified reference's input_reset on a used session (stale half-band and acquisition-filter windows);
+    nrsc5hip_stream_fresh == a new session"""
+    ec.check_reset_keeps_fir_windows(emu_lib, reflib)
+    ec.check_reset_keeps_fir_windows_am(emu_lib, reflib)
+
+
 def test_emu_pids_crc_flag(emu_lib, oracle):
     ec.check_pids_crc_flag(emu_lib, oracle)
     ec.check_pids_crc_flag(emu_lib, oracle, am=True)

@@ -258,9 +258,10 @@ def test_pids_crc_restatement_matches_reference_sis_events(oracle, reflib):
 def test_reset_of_a_used_session_stale_decimator_window_is_pinned(oracle, reflib):
     """input_reset on a USED session (nrsc5_set_mode on a live pipe session): firdecim_q15_reset only rewinds the window index
     (firdecim_q15.c:53-56), so the first outputs of the half-band see 14 stale samples of the previous capture where a fresh
-    session -- and the engine's nrsc5hip_stream_reset -- has zeros.  Pinned here: the deviation is confined to the first 7
-    decimated samples after the reset; every later sample and the complete event log of the second capture (timing picks,
-    sync state, PIDS / P1 frames exact; floats 1e-4) equal a fresh session's, which is what the engine delivers."""
+    session has zeros.  Pinned here for the ORACLE, which restates fresh sessions only: the deviation is confined to the first 7
+    decimated samples after the reset; for this pair of captures every later sample and the complete event log of the second one
+    equal a fresh session's.  (The ENGINE reproduces the used session: nrsc5hip_stream_reset keeps the windows, nrsc5hip_stream_fresh
+    is the new session -- engine_checks.check_reset_keeps_fir_windows, where the captures are chosen so that the logs differ.)"""
     from oracle import ref
     from nrsc5_amd import synth
     a = synth.fm_mp1_capture(0, seed=81, cfo_hz=-55.0, offset=2222, snr_db=20, n_blocks=6)
