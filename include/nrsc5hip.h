@@ -166,8 +166,8 @@ int nrsc5hip_push_cs16(nrsc5hip_engine *e, int stream, const int16_t *iq, uint32
  * (firdecim_q15_reset, firdecim_q15.c:53-56) -- the first 7 samples out of the FM half-band and the acquisition filter's first 31 outputs (filter_fm or
  * filter_am, acquire.c:290-293) see the samples the window's last compaction left at its front, exactly as a second capture on one nrsc5_t does
  * (tests: engine_checks.check_reset_keeps_fir_windows vs the unmodified reference).  Bytes of a partial push still staged on the host pass through the
- * decimator first.  Not reproduced: stages 1-4 of the AM cu8 cascade start from zeros (their stage 0 is tracked, so an FM session that follows is exact);
- * engines with batch_zero_copy treat every reset as a fresh session. */
+ * decimator first.  The five stages of the AM cu8 cascade (input.c:70-88) are covered as well.  Engines with batch_zero_copy treat every reset as a fresh
+ * session. */
 int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream);
 /* nrsc5_close + nrsc5_open_pipe on this slot: a fresh session (calloc'd windows), what nrsc5hip_reset_all does for every stream */
 int nrsc5hip_stream_fresh(nrsc5hip_engine *e, int stream);

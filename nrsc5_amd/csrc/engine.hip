@@ -1309,6 +1309,8 @@ static int reset_stream(nrsc5hip_engine *e, int stream, bool keep_windows)
     HIPCHK(hipMemcpy(e->db.state + stream, &st, sizeof(st), hipMemcpyHostToDevice));
     if (e->db.am) {
         AmStream am; init_am_state(am);
+        memcpy(am.seed[0], st.stale.hb, sizeof(am.seed[0]));   // zeros unless the windows were kept
+        memcpy(am.seed[1], st.stale.am_stage, sizeof(st.stale.am_stage));
         HIPCHK(hipMemcpy(e->db.am + stream, &am, sizeof(am), hipMemcpyHostToDevice));
         HIPCHK(hipMemset(e->db.am_job + (size_t)stream * NWIN, 0, NWIN * sizeof(AmJob)));
         HIPCHK(hipMemset(e->db.am_pids_rec + (size_t)stream * NWIN * 8, 0xff, NWIN * 8 * sizeof(int)));

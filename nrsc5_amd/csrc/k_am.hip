@@ -84,15 +84,30 @@ __global__ __launch_bounds__(256) void k_am_decimate_cu8(DevTables tb, DevBuffer
         am_raw_fetch(am, iq, lo0 + k, nraw, re, im);
         bufA[2 * k] = (int16_t)re; bufA[2 * k + 1] = (int16_t)im;
     }
+    // The first outputs after a reset: what lies in front of sample 0 of stage l's input is the window content the reset left there
+    // (AmStream::seed; zeros for a fresh session), not something computed from earlier raw samples.  Stage l's local sample k is its
+    // absolute sample base_l + k, base = lo0, 16 m0 - 210, 8 m0 - 98, 4 m0 - 42, 2 m0 - 14.
+    const bool edge = m0 < 14;                                 // block-uniform: only then does the cone reach below sample 0
+    if (edge) {
+        __syncthreads();
+        if (tid < 14 && -14 + tid - lo0 >= 0 && -14 + tid - lo0 < AMD_N0) { const int k = (int)(-14 + tid - lo0); bufA[2 * k] = am.seed[0][tid].r; bufA[2 * k + 1] = am.seed[0][tid].i; }
+    }
+#define AM_SEED_STAGE(buf, n, base, l) do { if (edge) { __syncthreads(); const long long kk = -14 + tid - (base); \
+        if (tid < 14 && kk >= 0 && kk < (n)) { (buf)[2 * kk] = am.seed[l][tid].r; (buf)[2 * kk + 1] = am.seed[l][tid].i; } } } while (0)
     __syncthreads();
     // local index jl of a stage's output reads the previous stage's local samples 2 jl .. 2 jl + 14
     for (int k = tid; k < 2 * AMD_N1; k += 256) bufB[k] = (int16_t)am_hb_dot(bufA + 4 * (k >> 1) + (k & 1), 2, t0, t1, t2, t3);
+    AM_SEED_STAGE(bufB, AMD_N1, 16 * m0 - 210, 1);
     __syncthreads();
     for (int k = tid; k < 2 * AMD_N2; k += 256) bufA[k] = (int16_t)am_hb_dot(bufB + 4 * (k >> 1) + (k & 1), 2, t0, t1, t2, t3);
+    AM_SEED_STAGE(bufA, AMD_N2, 8 * m0 - 98, 2);
     __syncthreads();
     for (int k = tid; k < 2 * AMD_N3; k += 256) bufB[k] = (int16_t)am_hb_dot(bufA + 4 * (k >> 1) + (k & 1), 2, t0, t1, t2, t3);
+    AM_SEED_STAGE(bufB, AMD_N3, 4 * m0 - 42, 3);
     __syncthreads();
     for (int k = tid; k < 2 * AMD_N4; k += 256) bufA[k] = (int16_t)am_hb_dot(bufB + 4 * (k >> 1) + (k & 1), 2, t0, t1, t2, t3);
+    AM_SEED_STAGE(bufA, AMD_N4, 2 * m0 - 14, 4);
+#undef AM_SEED_STAGE
     __syncthreads();
     if (tid < AMD_T && m0 + tid < m_end) {
         c16 y;
@@ -102,7 +117,7 @@ __global__ __launch_bounds__(256) void k_am_decimate_cu8(DevTables tb, DevBuffer
     }
 }
 
-__global__ __launch_bounds__(256) void k_am_decimate_commit(DevBuffers db, const int *ids, const uint8_t *iq_base, long long iq_stride, const unsigned *nbytes)
+__global__ __launch_bounds__(256) void k_am_decimate_commit(DevTables tb, DevBuffers db, const int *ids, const uint8_t *iq_base, long long iq_stride, const unsigned *nbytes)
 {
     const int sidx = blockIdx.x;
     const int s = stream_of(ids, sidx);
@@ -120,13 +135,44 @@ __global__ __launch_bounds__(256) void k_am_decimate_commit(DevBuffers db, const
         else if (r >= 0 && r >= am.raw_count - AM_RAW_HIST) { const long long h = r - (am.raw_count - AM_RAW_HIST); a = am.raw_hist[2 * h]; b = am.raw_hist[2 * h + 1]; }
         nh[2 * k] = a; nh[2 * k + 1] = b;
     }
-    // decim[0] takes every raw sample (>> 4) in this mode too: what its last compaction inside the chunk leaves at the front of the
-    // window is what an FM session after the next reset starts from (StaleWindows, nrsc5_dev.h; stages 1-4 are not tracked)
+    // What the last compaction of each stage's window inside this chunk leaves at its front (StaleWindows, nrsc5_dev.h).  decim[0] takes
+    // every raw sample (>> 4): an FM session after the next reset starts from these too.
     const long long p0 = stale_start(st.stale.hb_pushed, nraw, 14);
     if (p0 != STALE_NONE && threadIdx.x < 14) {
         int re, im;
         am_raw_fetch(am, iq, am.raw_count + p0 + threadIdx.x, nraw, re, im);
         st.stale.hb[threadIdx.x].r = (int16_t)re; st.stale.hb[threadIdx.x].i = (int16_t)im;
+    }
+    // decim[l], l = 1..4, has taken 2 floor(raw / 2^(l+1)) samples y_l (y_0 = raw >> 4, y_l[j] = half-band over y_(l-1)[2j-14 .. 2j]): the 14 in
+    // front of its last compaction are recomputed from raw samples -- 14 -> 41 -> 95 -> 203 -> 419, at most 465 raw samples back from the
+    // chunk's first (AM_RAW_HIST covers it)
+    {
+        __shared__ int16_t cA[2 * 419], cB[2 * 203];
+        const int t0 = tb.hb_q15[0], t1 = tb.hb_q15[1], t2 = tb.hb_q15[2], t3 = tb.hb_q15[3];
+        for (int l = 1; l <= 4; l++) {
+            const long long a_l = 2 * (am.raw_count >> (l + 1)), b_l = 2 * ((am.raw_count + nraw) >> (l + 1));
+            const long long p = stale_start(a_l, b_l - a_l, 14);
+            if (p == STALE_NONE) continue;                     // block-uniform
+            long long base[5]; int n[5];
+            base[l] = a_l + p; n[l] = 14;
+            for (int q = l; q >= 1; q--) { base[q - 1] = 2 * base[q] - 14; n[q - 1] = 2 * n[q] + 13; }
+            // level q is held in cA when l - q is even, in cB when odd: the 419 samples of l = 4 and the 203 of l = 3 land in the buffer that fits them
+            int16_t *cur = (l & 1) ? cB : cA;
+            for (int k = threadIdx.x; k < n[0]; k += 256) {
+                int re, im;
+                am_raw_fetch(am, iq, base[0] + k, nraw, re, im);
+                cur[2 * k] = (int16_t)re; cur[2 * k + 1] = (int16_t)im;
+            }
+            __syncthreads();
+            for (int q = 1; q <= l; q++) {
+                int16_t *nxt = ((l - q) & 1) ? cB : cA;
+                for (int k = threadIdx.x; k < 2 * n[q]; k += 256) nxt[k] = (int16_t)am_hb_dot(cur + 4 * (k >> 1) + (k & 1), 2, t0, t1, t2, t3);
+                __syncthreads();
+                cur = nxt;
+            }
+            if (threadIdx.x < 14) { st.stale.am_stage[l - 1][threadIdx.x].r = cur[2 * threadIdx.x]; st.stale.am_stage[l - 1][threadIdx.x].i = cur[2 * threadIdx.x + 1]; }
+            __syncthreads();
+        }
     }
     __syncthreads();
     for (int k = threadIdx.x; k < 2 * AM_RAW_HIST; k += 256) am.raw_hist[k] = nh[k];
@@ -142,7 +188,7 @@ void launch_am_decimate_cu8(const DevTables &tb, const DevBuffers &db, int nstre
 {
     const unsigned max_out = max_nbytes / 64 + 1;
     hipLaunchKernelGGL(k_am_decimate_cu8, dim3((max_out + AMD_T - 1) / AMD_T, nstreams), dim3(256), 0, st, tb, db, stream_ids, iq_base, iq_stride, nbytes);
-    hipLaunchKernelGGL(k_am_decimate_commit, dim3(nstreams), dim3(256), 0, st, db, stream_ids, iq_base, iq_stride, nbytes);
+    hipLaunchKernelGGL(k_am_decimate_commit, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, iq_base, iq_stride, nbytes);
 }
 
 // =====================================================================================================

@@ -74,11 +74,12 @@ struct c16 { int16_t r, i; };
 // its end, i.e. at push number k (2048 - (ntaps - 1)), k >= 1, counted from the filter's last reset -- so after input_reset
 // (input.c:126-138: the five decimator stages; acquire_reset, acquire.c:290-293: filter_fm and filter_am) the first outputs of a
 // USED session see, as their history, the ntaps - 1 samples that preceded the filter's LAST compaction (zeros for a fresh
-// session: calloc).  The engine keeps those samples per stream and nrsc5hip_stream_reset seeds hb_hist / fir_hist with them.
+// session: calloc).  The engine keeps those samples per stream and nrsc5hip_stream_reset seeds hb_hist / fir_hist / AmStream::seed with them.
 constexpr int FIRDECIM_WINDOW = 2048;           // WINDOW_SIZE, firdecim_q15.c:16
 struct StaleWindows {
     c16 hb[14];                                 // decim[0] (both modes push it: FM samples, AM samples >> 4)
     c16 fir[2][31];                             // filter_fm, filter_am (acquire.c:312-313)
+    c16 am_stage[4][14];                        // decim[1..4]: the AM cu8 cascade's later stages (input.c:76-88); their push counts follow from hb_pushed
     long long hb_pushed;                        // samples pushed since the reset
     long long fir_pushed[2];
 };
@@ -196,6 +197,7 @@ struct AmStream {
     // K1-AM: raw cu8 samples consumed so far and the newest AM_RAW_HIST of them (I,Q bytes, oldest first)
     long long raw_count;
     uint8_t raw_hist[2 * AM_RAW_HIST];
+    c16 seed[5][14];            // what the five stages' windows held in front of the first sample after the reset (StaleWindows; zeros for a fresh session)
     // system control bits latched from the reference carrier at block 0 (sync.h:17-21), bc history (sync.c:648-653)
     int pli, hppi, aabi, rdbi;
     unsigned offset_history;

@@ -708,6 +708,27 @@ def check_reset_keeps_fir_windows_am(lib, reflib, offsets=(132, 138)):
             diffs = common.compare_logs(common.strip_states(exp_log), common.strip_states(log))
             assert not diffs, (off, how, diffs[:5])
     assert differing == len(offsets), "the reference's used AM session no longer differs from a fresh one"
+    # AM cu8 -> AM cu8: all five stages of the 32:1 cascade (input.c:70-88) start from what their windows' last compactions left
+    a8 = rng.integers(0, 256, size=4 * 100000, dtype=np.uint8)                 # 200 000 raw samples: decim[4] has compacted (2034 x 16 = 32 544)
+    b = synth_am.am_ma1_capture(9, seed=72, cfo_hz=1.0, offset=132, fmt="cu8").iq
+    b = b[:b.size - b.size % 4]
+    _, used_log, used_q15 = reflib.run_with_mode_switch(a8, b, mode=ref.MODE_AM, taps=ref.TAP_Q15)
+    fresh_log, fresh_q15, _ = reflib.run(b, mode=ref.MODE_AM, taps=ref.TAP_Q15)
+    assert (used_q15[:7] != fresh_q15[:7]).any() and np.array_equal(used_q15[40:8000], fresh_q15[40:8000])
+    for how, exp_log, exp_q15 in (("reset", used_log, used_q15), ("fresh", fresh_log, fresh_q15)):
+        for first in (4 * 64000, 4 * 8, 4 * 200):                                  # the seeds are applied however the caller cuts its first pushes
+            E.fresh(0)
+            common.run_engine_streaming(E, 0, a8, chunk=32768)
+            E.drain(0)
+            getattr(E, how)(0)
+            E.push_cu8(0, b[:first])
+            E.push_cu8(0, b[first:4 * 64000])                                      # 4000 outputs: below one window, the FIFO starts at the reset
+            assert np.array_equal(_fetch_q15(E, 4000), exp_q15[:4000]), (how, first)
+        common.run_engine_streaming(E, 0, b[4 * 64000:], chunk=32768)
+        E.push_cu8(0, np.zeros(0, dtype=np.uint8))
+        log = eng.am_records_to_log(E, 0, E.drain(0))
+        diffs = common.compare_logs(common.strip_states(exp_log), common.strip_states(log))
+        assert not diffs, (how, diffs[:5])
     # AM cu8 -> FM cu8 on one session
     a8 = rng.integers(0, 256, size=4 * 40000, dtype=np.uint8)
     b = synth.fm_mp1_capture(0, seed=82, cfo_hz=120.0, offset=0, snr_db=20, n_blocks=20).iq
