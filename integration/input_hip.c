@@ -230,6 +230,7 @@ void input_init(input_t *st, nrsc5_t *radio, output_t *output)
 
 void input_set_mode(input_t *st)
 {
+    if (ENGINE(st) && !FAILED(st)) deliver(st, 1);              /* before the stream is reset: the events of a block still in flight belong to the session that ends here */
     if (ENGINE(st) && !FAILED(st) && nrsc5hip_stream_set_mode(ENGINE(st), 0, st->radio->mode == NRSC5_MODE_AM ? NRSC5HIP_MODE_AM : NRSC5HIP_MODE_FM) != 0)
         fail(st, "stream_set_mode");
     input_reset(st);

@@ -79,6 +79,33 @@ size_t pipe_run_opts(const void *iq, size_t n, unsigned chunk, int mode, int cs1
     return g_log.len;
 }
 
+/* ONE session, two captures: A, then nrsc5_set_mode(mode_b) on the live session (input_set_mode -> input_reset, input.c:126-162: the FIR windows are
+ * rewound, not cleared), then B.  *split = bytes of the log that belong to A (everything delivered before nrsc5_set_mode returned). */
+size_t pipe_run_two(const void *iq_a, size_t na, int mode_a, int cs16_a, const void *iq_b, size_t nb, int mode_b, int cs16_b, unsigned chunk,
+                    size_t *split, const uint8_t **out)
+{
+    nrsc5_t *radio = NULL;
+    g_log.len = 0;
+    if (nrsc5_open_pipe(&radio) != 0) return 0;
+    nrsc5_set_mode(radio, mode_a);
+    nrsc5_set_callback(radio, on_event, &g_log);
+    for (size_t off = 0; off < na; off += chunk) {
+        unsigned k = (na - off < chunk) ? (unsigned)(na - off) : chunk;
+        if (cs16_a) nrsc5_pipe_samples_cs16(radio, (const int16_t *)iq_a + off, k);
+        else nrsc5_pipe_samples_cu8(radio, (const uint8_t *)iq_a + off, k);
+    }
+    nrsc5_set_mode(radio, mode_b);
+    if (split) *split = g_log.len;
+    for (size_t off = 0; off < nb; off += chunk) {
+        unsigned k = (nb - off < chunk) ? (unsigned)(nb - off) : chunk;
+        if (cs16_b) nrsc5_pipe_samples_cs16(radio, (const int16_t *)iq_b + off, k);
+        else nrsc5_pipe_samples_cu8(radio, (const uint8_t *)iq_b + off, k);
+    }
+    nrsc5_close(radio);
+    *out = g_log.p;
+    return g_log.len;
+}
+
 size_t pipe_run_cu8(const uint8_t *iq, size_t nbytes, unsigned chunk, const uint8_t **out)
 {
     return pipe_run(iq, nbytes, chunk, NRSC5_MODE_FM, 0, out);

@@ -86,3 +86,41 @@ def test_emu_dropin_close_without_flush_delivers_the_last_block(emu_dropin, capt
     _compare_events(exp, got)
     if strict:
         assert at_end == total, "strict delivery: nothing may be left for nrsc5_close"
+
+
+def run_two(path, a, b, mode_a=0, mode_b=0, chunk=32768):
+    lib = ctypes.CDLL(path)
+    lib.pipe_run_two.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_uint,
+                                 ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_void_p)]
+    lib.pipe_run_two.restype = ctypes.c_size_t
+    p, split = ctypes.c_void_p(), ctypes.c_size_t()
+    n = lib.pipe_run_two(a.ctypes.data, a.size, mode_a, int(a.dtype == np.int16), b.ctypes.data, b.size, mode_b, int(b.dtype == np.int16), chunk, ctypes.byref(split), ctypes.byref(p))
+    raw = ctypes.string_at(p, n)
+    return ref.parse_log(raw[:split.value]), ref.parse_log(raw[split.value:])
+
+
+def check_dropin_set_mode_on_a_live_session(dropin):
+    """nrsc5_set_mode on a live pipe session, through the public API only: capture A (a real signal: SYNC, audio packets), the reset, then a
+    capture B whose symbol boundary sits in the first samples of the acquisition window -- the reference's acquisition filter and half-band
+    still hold samples of A there (firdecim_q15_reset, firdecim_q15.c:53-56), so B's events differ from a fresh session's (asserted on the
+    plain reference) and the drop-in must follow the USED session: nrsc5hip_stream_reset keeps the windows.  Also: every event of A is
+    delivered before nrsc5_set_mode returns (the block in flight on the device belongs to the session that ends there)."""
+    from nrsc5_amd import synth
+    plain = os.path.join(common.ROOT, "oracle", "_ref", "libnrsc5_plain.so")
+    rng = np.random.default_rng(5)
+    sig = synth.fm_mp1_capture(0, seed=81, cfo_hz=-55.0, offset=2222, snr_db=20, n_blocks=20).iq
+    a = np.concatenate([sig[:sig.size - sig.size % 4], rng.integers(0, 256, size=4 * 71280 * 2 + 4 * 5000, dtype=np.uint8)])    # ends un-synchronised, at full scale
+    b = synth.fm_mp1_capture(0, seed=82, cfo_hz=120.0, offset=0, snr_db=20, n_blocks=20).iq
+    b = b[:b.size - b.size % 4]
+    exp_a, exp_b = run_two(plain, a, b)
+    fresh_b = _run(plain, b)
+    got_a, got_b = run_two(dropin, a, b)
+    assert any(k == "sync" for k, _ in exp_a) and any(k == "sync" for k, _ in exp_b)
+    _compare_events(exp_a, got_a)
+    _compare_events(exp_b, got_b)
+    with pytest.raises(AssertionError):                            # the point of the captures: a fresh session is NOT what the reference does here
+        _compare_events(fresh_b, exp_b)
+
+
+def test_emu_dropin_set_mode_on_a_live_session(emu_dropin):
+    check_dropin_set_mode_on_a_live_session(emu_dropin)

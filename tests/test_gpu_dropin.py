@@ -154,3 +154,12 @@ def test_dropin_close_without_flush_delivers_the_last_block(captures, strict, mo
     _compare_events(exp, got)
     if strict:
         assert at_end.value == n, "strict delivery: nothing may be left for nrsc5_close"
+
+
+def test_dropin_set_mode_on_a_live_session():
+    """the reference's reset of a USED session (FIR windows rewound, not cleared) through the public API, on the real library"""
+    from tests import test_emu_dropin as emu
+    path = os.path.join(BUILD["libnrsc5_hipdropin.so"], "libnrsc5_hipdropin.so")
+    if not os.path.exists(path) or not os.path.exists(os.path.join(BUILD["libnrsc5_plain.so"], "libnrsc5_plain.so")):
+        pytest.skip("drop-in / plain reference libraries not prebuilt (need /root/reference)")
+    emu.check_dropin_set_mode_on_a_live_session(path)
