@@ -4,7 +4,8 @@
 # bench line (every stream of fm / am-cs16 / mixed against the unmodified reference) and the FM batch on two more seeds.
 #   gpurun --timeout 2700 -- 'bash tools/gpu_r5_final.sh TAG'
 cd "${GRAFT_REPO_ROOT:-.}"; R=$PWD; export TMPDIR=/tmp; mkdir -p gpurun_out; TAG=${1:-r05z}
-( time timeout 900 python -m pytest tests -m gpu -x -q ) > gpurun_out/${TAG}_tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/${TAG}_tests.log
+# (second argument "notests": the GPU suite has just run on this very tree in a call of its own)
+if [ "$2" != notests ]; then ( time timeout 900 python -m pytest tests -m gpu -x -q ) > gpurun_out/${TAG}_tests.log 2>&1; echo "tests rc=$?"; tail -3 gpurun_out/${TAG}_tests.log; fi
 for WL in fm am-cs16; do
   rm -rf gpurun_out/${TAG}_prof_$WL
   ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_prof_$WL -o p -- python $R/bench.py --workload $WL --no-cpu-baseline --no-extra-legs --steps 3 --warmup 1 ) > gpurun_out/${TAG}_prof_$WL.log 2>&1; echo "prof $WL rc=$?"
