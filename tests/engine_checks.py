@@ -750,6 +750,43 @@ def check_reset_keeps_fir_windows_am(lib, reflib, offsets=(132, 138)):
     E.close()
 
 
+def check_reset_window_boundaries(lib, reflib):
+    """push() compacts a FIR window at push number k (2048 - (ntaps - 1)) (firdecim_q15.c:58-67): captures whose raw length sits just below, at
+    and just above those counts -- for the FM half-band and for every stage of the AM cu8 cascade (stage l takes 2 floor(raw / 2^(l+1)) samples)
+    -- cut into pushes that end at, straddle or are far smaller than the boundary; the decimated samples after the reset equal the reference's."""
+    from oracle import ref
+    from nrsc5_amd import synth_am
+    rng = np.random.default_rng(11)
+    b = synth.fm_mp1_capture(0, seed=82, cfo_hz=120.0, offset=0, snr_db=20, n_blocks=1).iq[:4 * 3000]
+    E = eng.Engine(max_streams=1, q15_capacity=400000, record_capacity=512, p1_slots=16, lib_path=lib, am_enable=True)
+    for n in (20, 2032, 2034, 2036, 4068, 2034 * 5 + 2):
+        a = rng.integers(0, 256, size=2 * n, dtype=np.uint8)
+        _, _, used = reflib.run_with_mode_switch(a, b, taps=ref.TAP_Q15)
+        for cuts in ([], [4, 2 * n - 4], [2 * 2034], [2 * 2020, 2 * 2034 + 4], list(range(400, 2 * n, 400))):
+            E.fresh(0)
+            prev = 0
+            for c in [c for c in cuts if 0 < c < 2 * n and c % 4 == 0] + [2 * n]:
+                E.push_cu8(0, a[prev:c]); prev = c
+            E.reset(0)
+            E.push_cu8(0, b)
+            assert np.array_equal(_fetch_q15(E, 3000), used[:3000]), ("fm", n, cuts[:4])
+    bam = synth_am.am_ma1_capture(1, seed=72, cfo_hz=1.0, offset=132, fmt="cu8").iq[:4 * 32000]
+    E.set_mode(0, eng.MODE_AM)
+    for l in (1, 2, 3, 4):
+        for d in (-2, 0, 2):
+            n = 2034 * (1 << l) + d * (1 << l) + 64
+            a = rng.integers(0, 256, size=2 * n, dtype=np.uint8)
+            _, _, used = reflib.run_with_mode_switch(a, bam, mode=ref.MODE_AM, taps=ref.TAP_Q15)
+            for chunk in (2 * n, 1000):
+                E.fresh(0)
+                for off in range(0, 2 * n, chunk):
+                    E.push_cu8(0, a[off:off + chunk])
+                E.reset(0)
+                E.push_cu8(0, bam)
+                assert np.array_equal(_fetch_q15(E, 1000), used[:1000]), ("am", l, d, chunk)
+    E.close()
+
+
 def check_pids_crc_flag(lib, oracle, am=False):
     """REC_PIDS_CRC == pids_frame_push's CRC-12 decision (restated in the oracle, pinned against the reference's
     STATION_ID events): frames with a fresh station id in every block, every fifth one with a broken CRC."""

@@ -177,6 +177,10 @@ def test_emu_reset_of_a_used_stream_keeps_the_fir_windows(emu_lib, reflib):
     ec.check_reset_keeps_fir_windows_am(emu_lib, reflib)
 
 
+def test_emu_reset_window_compaction_boundaries(emu_lib, reflib):
+    ec.check_reset_window_boundaries(emu_lib, reflib)
+
+
 def test_emu_pids_crc_flag(emu_lib, oracle):
     ec.check_pids_crc_flag(emu_lib, oracle)
     ec.check_pids_crc_flag(emu_lib, oracle, am=True)

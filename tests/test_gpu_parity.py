@@ -352,6 +352,7 @@ def test_gpu_mode_switch_on_live_stream(hip_lib, oracle):
 
 
 def test_gpu_reset_of_a_used_stream_keeps_the_fir_windows(hip_lib, reflib):
+    ec.check_reset_window_boundaries(hip_lib, reflib)
     ec.check_reset_keeps_fir_windows(hip_lib, reflib)
     ec.check_reset_keeps_fir_windows_am(hip_lib, reflib)
 
