@@ -16,10 +16,10 @@ W.E.debug_sync_phases()                                        # read + reset? (
 c0 = W.E.debug_sync_phases()
 steps, _ = W.one_pass()
 c1 = W.E.debug_sync_phases()
-names = ["sync_adjust", "costas", "coarse", "samperr/angle", "equalise+MER", "soft bits", "PIDS gather", "finish"]
+names = ["head: state burst + refs", "costas", "coarse / CFO search", "samperr/angle", "equalise+MER", "soft bits", "PIDS gather", "finish + checkpoint"]
 tot = 0
 for nm, a, b in zip(names, c0, c1):
-    d = (b - a) / 224.0
+    d = (b - a) / float(steps)
     tot += d
     print(f"{nm:16s} {d:9.0f} cycles/block")
 print(f"{'total':16s} {tot:9.0f} cycles/block over {steps} steps")
