@@ -35,9 +35,9 @@ __device__ inline void fetch_q15(const uint8_t *iq, const c16 *hist, long long k
 
 // End of a chunk of nsamp complex input samples (one work-item per stream): note what decim[0]'s last compaction inside the chunk
 // leaves at the front of its window (StaleWindows, nrsc5_dev.h), then roll the 14-sample history.
-__device__ inline void hb_roll_history(StreamState &st, const uint8_t *iq, long long nsamp)
+__device__ inline void hb_roll_history(StreamState &st, const uint8_t *iq, long long nsamp, bool note_compaction = true)
 {
-    const long long p = stale_start(st.stale.hb_pushed, nsamp, 14);
+    const long long p = note_compaction ? stale_start(st.stale.hb_pushed, nsamp, 14) : STALE_NONE;
     c16 nh[14], sw[14];
     for (int k = 0; k < 14; k++) {
         int r, i;
@@ -130,6 +130,24 @@ __global__ __launch_bounds__(256) void k_decimate_fm_cu8_stream(DevTables tb, De
     if (whole) tile[threadIdx.x + 2] = v[g];
     if (threadIdx.x < 2 && g0 >= 2) tile[threadIdx.x] = v[g0 - 2 + threadIdx.x];
     __syncthreads();
+    {
+        // decim[0]'s last compaction inside this chunk (StaleWindows, nrsc5_dev.h): the 14 samples in front of it are taken where they already are -- in the tile of
+        // the workgroup that owns the last of them (its two-word halo reaches the first) -- rather than fetched across PCIe once more by the chunk's last workgroup
+        const long long p = stale_start(st.stale.hb_pushed, nb / 2, 14);
+        const long long q = p + 13;                            // the last of the 14, chunk-relative (>= -1)
+        const unsigned owner = (p == STALE_NONE || q < 0) ? 0u : (unsigned)(q >> 3) >> 8;
+        if (p != STALE_NONE && blockIdx.x == owner && threadIdx.x < 14) {
+            const long long k = p + threadIdx.x;
+            int r, i;
+            if (k < 0 || 16ull * ((k >> 3) + 1) > nb) fetch_q15(iq, st.hb_hist, k, r, i);      // history, or a ragged last word the tile does not hold
+            else {
+                const uint32_t *w = (const uint32_t *)&tile[(k >> 3) - g0 + 2];
+                const unsigned pair = (w[(k & 7) >> 1] >> ((k & 1) * 16)) & 0xffffu;
+                r = q15_of_u8(pair & 0xff); i = q15_of_u8(pair >> 8);
+            }
+            st.stale.hb[threadIdx.x].r = (int16_t)r; st.stale.hb[threadIdx.x].i = (int16_t)i;
+        }
+    }
     if (4u * g < nout) {
         c16 *out = db.q15 + (size_t)s * db.q15_cap + (st.wr - st.base);
         const int t0 = tb.hb_q15[0], t1 = tb.hb_q15[1], t2 = tb.hb_q15[2], t3 = tb.hb_q15[3];
@@ -170,7 +188,7 @@ __global__ __launch_bounds__(256) void k_decimate_fm_cu8_stream(DevTables tb, De
     *ticket = 0;
     const long long nsamp = nb / 2;                            // complex input samples (even)
     if (nsamp == 0) return;
-    hb_roll_history(st, iq, nsamp);
+    hb_roll_history(st, iq, nsamp, false);                    // (the compaction was noted above, from the tile)
     st.wr += nsamp / 2;
 }
 
