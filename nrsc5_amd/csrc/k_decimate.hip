@@ -35,9 +35,9 @@ __device__ inline void fetch_q15(const uint8_t *iq, const c16 *hist, long long k
 
 // End of a chunk of nsamp complex input samples (one work-item per stream): note what decim[0]'s last compaction inside the chunk
 // leaves at the front of its window (StaleWindows, nrsc5_dev.h), then roll the 14-sample history.
-__device__ inline void hb_roll_history(StreamState &st, const uint8_t *iq, long long nsamp, bool note_compaction = true)
+__device__ inline void hb_roll_history(StreamState &st, const uint8_t *iq, long long nsamp)
 {
-    const long long p = note_compaction ? stale_start(st.stale.hb_pushed, nsamp, 14) : STALE_NONE;
+    const long long p = stale_start(st.stale.hb_pushed, nsamp, 14);
     c16 nh[14], sw[14];
     for (int k = 0; k < 14; k++) {
         int r, i;
@@ -147,6 +147,20 @@ __global__ __launch_bounds__(256) void k_decimate_fm_cu8_stream(DevTables tb, De
             }
             st.stale.hb[threadIdx.x].r = (int16_t)r; st.stale.hb[threadIdx.x].i = (int16_t)i;
         }
+        // ... and the chunk's own last 14 samples (the next chunk's history) likewise: parked in hb_next by the workgroup whose tile holds them, moved to hb_hist by
+        // the chunk's last workgroup (hb_hist itself is still being read by workgroup 0)
+        const long long nsamp = nb / 2, ql = nsamp - 1;
+        if (nsamp > 0 && blockIdx.x == ((unsigned)(ql >> 3) >> 8) && threadIdx.x >= 32 && threadIdx.x < 46) {
+            const long long k = nsamp - 14 + (threadIdx.x - 32);
+            int r, i;
+            if (k < 0 || 16ull * ((k >> 3) + 1) > nb) fetch_q15(iq, st.hb_hist, k, r, i);
+            else {
+                const uint32_t *w = (const uint32_t *)&tile[(k >> 3) - g0 + 2];
+                const unsigned pair = (w[(k & 7) >> 1] >> ((k & 1) * 16)) & 0xffffu;
+                r = q15_of_u8(pair & 0xff); i = q15_of_u8(pair >> 8);
+            }
+            st.hb_next[threadIdx.x - 32].r = (int16_t)r; st.hb_next[threadIdx.x - 32].i = (int16_t)i;
+        }
     }
     if (4u * g < nout) {
         c16 *out = db.q15 + (size_t)s * db.q15_cap + (st.wr - st.base);
@@ -188,7 +202,8 @@ __global__ __launch_bounds__(256) void k_decimate_fm_cu8_stream(DevTables tb, De
     *ticket = 0;
     const long long nsamp = nb / 2;                            // complex input samples (even)
     if (nsamp == 0) return;
-    hb_roll_history(st, iq, nsamp, false);                    // (the compaction was noted above, from the tile)
+    for (int k = 0; k < 14; k++) st.hb_hist[k] = st.hb_next[k];   // (parked above, as the compaction was noted above: nothing crosses PCIe here)
+    st.stale.hb_pushed += nsamp;
     st.wr += nsamp / 2;
 }
 

@@ -189,6 +189,7 @@ struct StreamState {
     int px_count;               // block pairs that produced frames so far (ring slot)
     int px_go;                  // this step: soft bits per block of a completed pair (0: nothing to de-interleave)
     int px_nch, px_slot, px_record;
+    c16 hb_next[14];            // streaming decimator: the chunk's last 14 input samples, parked by the workgroup that holds them until the chunk's last workgroup rolls hb_hist
     StaleWindows stale;         // survives nrsc5hip_stream_reset (the reference's rewound windows); cleared by a fresh session
 };
 
