@@ -166,8 +166,10 @@ int nrsc5hip_push_cs16(nrsc5hip_engine *e, int stream, const int16_t *iq, uint32
  * (firdecim_q15_reset, firdecim_q15.c:53-56) -- the first 7 samples out of the FM half-band and the acquisition filter's first 31 outputs (filter_fm or
  * filter_am, acquire.c:290-293) see the samples the window's last compaction left at its front, exactly as a second capture on one nrsc5_t does
  * (tests: engine_checks.check_reset_keeps_fir_windows vs the unmodified reference).  Bytes of a partial push still staged on the host pass through the
- * decimator first.  The five stages of the AM cu8 cascade (input.c:70-88) are covered as well.  Engines with batch_zero_copy treat every reset as a fresh
- * session. */
+ * decimator first.  The five stages of the AM cu8 cascade (input.c:70-88) are covered as well, and so is what sync_reset (sync.c:810-830) leaves alone:
+ * sync_t.samperr, .angle and .bc keep their values -- visible in the block records of the next capture's un-synchronised blocks, and, because the AM path never
+ * writes .angle, in the angle of the first synchronised block of an AM session that follows an FM one (acquire.c:115-118).  A LOST_SYNC that the reference
+ * fires inside the reset (input_set_sync_state) is the caller's own doing and no record.  Engines with batch_zero_copy treat every reset as a fresh session. */
 int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream);
 /* nrsc5_close + nrsc5_open_pipe on this slot: a fresh session (calloc'd windows), what nrsc5hip_reset_all does for every stream */
 int nrsc5hip_stream_fresh(nrsc5hip_engine *e, int stream);

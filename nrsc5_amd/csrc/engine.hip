@@ -1302,6 +1302,12 @@ static int reset_stream(nrsc5hip_engine *e, int stream, bool keep_windows)
     StreamState st; init_state(st, e->mode_host[stream]);
     if (keep_windows && !e->cfg.batch_zero_copy) {             // (zero-copy engines: every attach is an independent recording, read in place with byte-valued history)
         HIPCHK(hipMemcpy(&st.stale, (const char *)(e->db.state + stream) + offsetof(StreamState, stale), sizeof(st.stale), hipMemcpyDeviceToHost));
+        // sync_reset (sync.c:810-830) leaves sync_t.samperr, .angle and .bc alone.  The FM path overwrites all three in the block that locks, before anything reads
+        // them; the AM path never writes .angle, so the first synchronised block of an AM session after an FM one turns by the FM session's last angle
+        // (acquire.c:115-118) -- and the block records of the un-synchronised blocks in between show the old values
+        HIPCHK(hipMemcpy(&st.samperr, (const char *)(e->db.state + stream) + offsetof(StreamState, samperr), sizeof(st.samperr), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&st.angle, (const char *)(e->db.state + stream) + offsetof(StreamState, angle), sizeof(st.angle), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&st.bc, (const char *)(e->db.state + stream) + offsetof(StreamState, bc), sizeof(st.bc), hipMemcpyDeviceToHost));
         st.stale.hb_pushed = 0; st.stale.fir_pushed[0] = 0; st.stale.fir_pushed[1] = 0;
         memcpy(st.hb_hist, st.stale.hb, sizeof(st.hb_hist));
         memcpy(st.fir_hist, st.stale.fir[st.mode == MODE_AM ? MODE_AM : MODE_FM], sizeof(st.fir_hist));

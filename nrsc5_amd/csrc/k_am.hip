@@ -860,7 +860,10 @@ __global__ __launch_bounds__(NT) void k_am_block(DevTables tb, DevBuffers db, co
         int samperr; float angle;
         if (state_before == SYNC_FINE) {
             samperr = AM_SYM / 2 + st_samperr; st.samperr = 0;
-            angle = st_prev_angle;                             // sync_t.angle is only written by the FM path
+            // sync_t.angle is only written by the FM path: zero, except in the first synchronised block after a reset that followed an FM session (nrsc5hip_stream_reset
+            // keeps it as sync_reset does) -- acquire.c:115-118 consumes it whatever the mode
+            angle = st_prev_angle + -st.angle;
+            st.angle = 0.0f; st.prev_angle = angle;
         } else {
             samperr = st_coarse_samperr;
             float sn, cs; sincosf(-st_prev_angle, &sn, &cs);
@@ -1161,13 +1164,13 @@ __global__ __launch_bounds__(NT) void k_am_block(DevTables tb, DevBuffers db, co
     if (tid == 0) {
         const int keep_extra = st.keep_extra, state = st.sync_state, cfo = st.cfo, bc_now = st.bc, psmi = st.psmi, cfo_wait = st.cfo_wait, next_samperr = st.samperr, nblocks = st.nblocks;
         const long long rd = st.rd;
-        const float prev_angle = st.prev_angle;
+        const float prev_angle = st.prev_angle, next_angle = st.angle;   // (sync_t.angle: zero in this mode unless a reset carried it over from an FM session)
         const int keep = AM_SYM + (AM_SYM / 2 - samperr) + keep_extra;
         st.keep_extra = 0;
         st.rd = rd + (AM_WIN - keep);
         rec.state_after = state; rec.samperr = samperr; rec.cfo = cfo; rec.keep = keep; rec.bc = bc_now;
         rec.psmi = psmi; rec.cfo_wait = cfo_wait; rec.next_samperr = next_samperr;
-        rec.prev_angle = prev_angle; rec.next_angle = 0.0f;
+        rec.prev_angle = prev_angle; rec.next_angle = next_angle;
         st.nblocks = nblocks + 1;
     }
     AM_MARK(10);                                               // tail

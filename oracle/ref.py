@@ -88,6 +88,29 @@ class RefLib:
             L.refh_close()
         return parse_log(log[:split]), parse_log(log[split:]), np.frombuffer(q15[q_split:], dtype=np.int16).reshape(-1, 2)
 
+    def run_epochs(self, epochs, taps: int = 0, chunk: int = 32768):
+        """One session, several captures: epochs = [(mode, iq), ...]; nrsc5_set_mode(mode) (input_reset, input.c:126-162) in front of every capture but the
+        first, whose mode the session is opened in.  Returns [(log, q15), ...] per epoch -- the reference's used-session behaviour over any history."""
+        L = self.lib
+        L.refh_set_mode.restype = ctypes.c_size_t
+        L.refh_q15_len.restype = ctypes.c_size_t
+        if L.refh_open(epochs[0][0], taps, 0) != 0:
+            raise RuntimeError("refh_open failed")
+        cuts = []
+        try:
+            for k, (mode, iq) in enumerate(epochs):
+                iq = np.ascontiguousarray(iq)
+                cuts.append((L.refh_set_mode(mode) if k else 0, L.refh_q15_len()))
+                (L.refh_run_cu8 if iq.dtype == np.uint8 else L.refh_run_cs16)(iq.ctypes.data, iq.size, chunk)
+            log, q15 = self._buf(0), self._buf(1)
+        finally:
+            L.refh_close()
+        out = []
+        for k, (l0, q0) in enumerate(cuts):
+            l1, q1 = cuts[k + 1] if k + 1 < len(cuts) else (len(log), len(q15))
+            out.append((parse_log(log[l0:l1]), np.frombuffer(q15[q0:q1], dtype=np.int16).reshape(-1, 2)))
+        return out
+
     def l2_frames(self, frames, mode: int = MODE_FM, lc: int = 0):
         """Hand logical frames (bit arrays as frame_push takes them) straight to the reference's L2 in one session;
         returns, per frame, the ordered taps: output_align / output_push calls, state changes, HDC events."""

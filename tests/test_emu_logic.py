@@ -2,6 +2,8 @@
 (tests/simt/) and checked against the oracle.  This validates kernel LOGIC in the GPU-less
 container; it is not a product path and proves nothing about gfx950 code generation -- the
 `-m gpu` twins in test_gpu_parity.py do that through the real library."""
+import os
+
 import pytest
 
 from tests import engine_checks as ec
@@ -166,8 +168,8 @@ def test_emu_deferred_feedback_equals_reference(emu_lib, oracle):
     ec.check_deferred_feedback_equals_reference(emu_lib, oracle, n_blocks=80, verdict_lag=3, cases=ec.FALSE_LOCK_CASES[:2])
 
 
-def test_emu_mode_switch_on_live_stream(emu_lib, oracle):
-    ec.check_mode_switch(emu_lib, oracle)
+def test_emu_mode_switch_on_live_stream(emu_lib, reflib):
+    ec.check_mode_switch(emu_lib, reflib)
 
 
 def test_emu_reset_of_a_used_stream_keeps_the_fir_windows(emu_lib, reflib):
@@ -175,6 +177,18 @@ def test_emu_reset_of_a_used_stream_keeps_the_fir_windows(emu_lib, reflib):
     nrsc5hip_stream_fresh == a new session"""
     ec.check_reset_keeps_fir_windows(emu_lib, reflib)
     ec.check_reset_keeps_fir_windows_am(emu_lib, reflib)
+
+
+def test_emu_randomised_sessions_of_several_captures(emu_lib, reflib):
+    """tools/cpu_session_fuzz.py on fixed seeds: 2 - 4 captures per session (FM cu8 / cs16, AM cs16 / cu8, noise or signal) with nrsc5_set_mode between them; after every
+    reset the first decimated samples and the whole log equal the unmodified reference's driven the same way (its FIR windows, sync_t.samperr / .angle / .bc survive
+    input_reset).  300 sessions / 885 captures of the tool: no difference that a fresh session of the same capture does not show as well."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import cpu_session_fuzz as fz
+    for seed in (70001, 70002, 70005, 71008):
+        kinds, problems = fz.run_session(emu_lib, reflib, seed)
+        assert not [p for p in problems if p[2] == "q15" or "ONLY AFTER" in p[2]], (seed, kinds, problems)
 
 
 def test_emu_reset_window_compaction_boundaries(emu_lib, reflib):

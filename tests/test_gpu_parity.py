@@ -347,8 +347,8 @@ def test_gpu_l2_feedback_deferred_with_concurrent_hw_queues(hip_lib):
     assert r.returncode == 0 and "deferred-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_gpu_mode_switch_on_live_stream(hip_lib, oracle):
-    ec.check_mode_switch(hip_lib, oracle)
+def test_gpu_mode_switch_on_live_stream(hip_lib, reflib):
+    ec.check_mode_switch(hip_lib, reflib)
 
 
 def test_gpu_reset_of_a_used_stream_keeps_the_fir_windows(hip_lib, reflib):
