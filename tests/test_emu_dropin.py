@@ -124,3 +124,19 @@ def check_dropin_set_mode_on_a_live_session(dropin):
 
 def test_emu_dropin_set_mode_on_a_live_session(emu_dropin):
     check_dropin_set_mode_on_a_live_session(emu_dropin)
+
+
+def test_emu_dropin_fm_then_am_on_one_session(emu_dropin):
+    """FM capture that ends synchronised, nrsc5_set_mode(AM), AM capture -- through the public API on the emulated twin: sync_reset leaves sync_t.angle alone and the AM
+    path never writes it, so the reference's first synchronised AM block turns by the FM session's last angle; the events of both captures (incl. the LOST_SYNC the reset
+    itself fires, delivered by the drop-in's input_set_sync_state) equal the plain reference's."""
+    from nrsc5_amd import synth, synth_am
+    plain = os.path.join(common.ROOT, "oracle", "_ref", "libnrsc5_plain.so")
+    a = synth.fm_mp1_capture(0, seed=71, cfo_hz=33.0, offset=640, snr_db=20, n_blocks=20).iq
+    a = a[:a.size - a.size % 4]
+    b = synth_am.am_ma1_capture(9, seed=72, cfo_hz=1.0, offset=900).iq
+    exp_a, exp_b = run_two(plain, a, b, mode_a=0, mode_b=1)
+    got_a, got_b = run_two(emu_dropin, a, b, mode_a=0, mode_b=1)
+    assert any(k == "sync" for k, _ in exp_a) and exp_a[-1][0] == "lost_sync" and any(k == "sync" for k, _ in exp_b)
+    _compare_events(exp_a, got_a)
+    _compare_events(exp_b, got_b)
