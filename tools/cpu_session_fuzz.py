@@ -12,7 +12,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def make_epoch(rng):
+def make_epoch(rng, long=False):
     from nrsc5_amd import synth, synth_am
     kind = ("fm_cu8_noise", "fm_cu8_sig", "fm_cs16_noise", "am_cs16_noise", "am_cs16_sig", "am_cu8_noise", "am_cu8_sig")[int(rng.integers(0, 7))]
     seed = int(rng.integers(1, 1 << 30))
@@ -25,10 +25,10 @@ def make_epoch(rng):
     if kind == "am_cu8_noise":
         return 1, np.random.default_rng(seed).integers(0, 256, size=4 * int(rng.integers(10, 300000)), dtype=np.uint8), kind
     if kind == "fm_cu8_sig":
-        iq = synth.fm_mp1_capture(0, seed=seed, cfo_hz=float(rng.uniform(-300, 300)), offset=int(rng.integers(0, 60)), snr_db=20, n_blocks=int(rng.integers(4, 20))).iq
+        iq = synth.fm_mp1_capture(0, seed=seed, cfo_hz=float(rng.uniform(-300, 300)), offset=int(rng.integers(0, 60)), snr_db=20, n_blocks=int(rng.integers(20, 44) if long else rng.integers(4, 20))).iq
         return 0, iq[:iq.size - iq.size % 4], kind
     fmt = "cs16" if kind == "am_cs16_sig" else "cu8"
-    iq = synth_am.am_ma1_capture(int(rng.integers(1, 3)), seed=seed, cfo_hz=float(rng.uniform(-5, 5)), offset=int(rng.integers(120, 150)), fmt=fmt).iq
+    iq = synth_am.am_ma1_capture(int(rng.integers(6, 10) if long else rng.integers(1, 3)), seed=seed, cfo_hz=float(rng.uniform(-5, 5)), offset=int(rng.integers(120, 150)), fmt=fmt).iq
     return 1, iq[:iq.size - iq.size % 4], kind
 
 
