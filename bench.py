@@ -183,6 +183,7 @@ TRANSIENT_INT = {"samperr", "keep", "next_samperr"}
 # the next largest 1.7e-4 / 4.4e-3), among ~800 on the MI355X 1.2e-4 / 3.2e-3 -- a heavy tail: the bounds are set just above the largest counted member, not at twice the typical one
 TRANSIENT_ABS = {"next_angle": 2e-3, "phase_re": 5e-2, "phase_im": 5e-2}
 TRANSIENT_DETAILS = []                # the first deviations counted as transient, verbatim (per process)
+MER_EXEMPT_BUDGET_PCT, MER_NOISE_BUDGET_PCT_X10 = 1, 5      # 1 % / 0.5 % of the MER values of the compared streams
 TRANSIENT_STREAM_BUDGET_PCT = 5      # measured: 6 of 256 streams (2.3 %); more than 5 % of the compared streams fails the run
 # round 5: 0.2 dB (0.5 in round 4): with the oscillator's amplitude and the exact first block on the device the largest first-MER deviation of a counted lock is
 # 0.078 dB in 2400 CFO-search locks on the CPU twin and 0.069 dB on the MI355X; the tail beyond (one lock in ~500 on the device: 0.57 dB, a timing pick by 3 samples) FAILS the run
@@ -317,9 +318,9 @@ def _parity_worker(tasks, results):
             del TRANSIENT_DETAILS[:]
             e0, n0 = common.EXEMPT["mer_within_0.01dB"], common.EXEMPT["mer_below_0dB_within_0.1dB"]
             diffs, nex, mb, ntr = compare_with_reference(ref_log, got_log, am)
-            results.put((key, kind, diffs, nex, mb, ntr, (int(common.EXEMPT["mer_within_0.01dB"] - e0), int(common.EXEMPT["mer_below_0dB_within_0.1dB"] - n0)), list(TRANSIENT_DETAILS)))
+            results.put((key, kind, diffs, nex, mb, ntr, (int(common.EXEMPT["mer_within_0.01dB"] - e0), int(common.EXEMPT["mer_below_0dB_within_0.1dB"] - n0), 2 * sum(1 for k_, _ in ref_log if k_ == "mer")), list(TRANSIENT_DETAILS)))
         except Exception as ex:                                     # a checker that raises is a failure of the run, never a silent skip
-            results.put((key, "error", [f"checker raised {ex!r}"], 0, 0, 0, (0, 0), []))
+            results.put((key, "error", [f"checker raised {ex!r}"], 0, 0, 0, (0, 0, 0), []))
 
 
 _POOL = None
@@ -355,6 +356,24 @@ def _diff_class(d: str) -> str:
     return kind
 
 
+def _maybe_broken(W, k, log):
+    """TEST HOOK (tests/test_gpu_two_ranks.py): NRSC5_BENCH_BREAK_STREAM=<rank>:<local stream> flips one bit of that stream's first decoded frame
+    (PIDS or P1) in the DEVICE log before the comparison -- the run must then fail, and say on which rank."""
+    spec = os.environ.get("NRSC5_BENCH_BREAK_STREAM")
+    if not spec:
+        return log
+    r, ks = spec.split(":")
+    if int(r) != int(os.environ.get("RANK", "0")) or int(ks) != int(k):
+        return log
+    for kind, v in log:
+        if kind in ("pids", "frame"):
+            bits = np.array(v["bits"], copy=True)
+            bits[3] ^= 1
+            v["bits"] = bits
+            break
+    return log
+
+
 def reference_equality(W, recs, counts, frames, to_log, am: bool):
     """EVERY stream of the workload (--oracle-streams -1, the default) -- or every stream that lost sync in the last pass (bounded by
     --oracle-lost-max) + --oracle-streams others -- against the checker, one reference session per host process."""
@@ -376,15 +395,15 @@ def reference_equality(W, recs, counts, frames, to_log, am: bool):
     t0 = time.perf_counter()
     pool = parity_pool(a)
     todo = lost_checked + pick
-    res = pool.run((k, W.stream_iq(k), am, to_log(k, recs[k, :counts[k]], frames[k])) for k in todo)
-    eq_lost = eq_other = strict = exempt = max_bits = tr_streams = tr_fields = imp_checked = imp_equal = mer_exempt = mer_noise = 0
+    res = pool.run((k, W.stream_iq(k), am, _maybe_broken(W, k, to_log(k, recs[k, :counts[k]], frames[k]))) for k in todo)
+    eq_lost = eq_other = strict = exempt = max_bits = tr_streams = tr_fields = imp_checked = imp_equal = mer_exempt = mer_noise = mer_values = 0
     first_diffs, tr_details, classes, kind = [], [], {}, "reference"
     lost_set = set(lost_checked)
     for k in todo:
         _, knd, diffs, nex, mb, ntr, nmer, details = res[k]
         if knd != "error":
             kind = knd
-        exempt += nex; max_bits = max(max_bits, mb); tr_streams += ntr > 0; tr_fields += ntr; strict += (not diffs and ntr == 0); mer_exempt += nmer[0]; mer_noise += nmer[1]
+        exempt += nex; max_bits = max(max_bits, mb); tr_streams += ntr > 0; tr_fields += ntr; strict += (not diffs and ntr == 0); mer_exempt += nmer[0]; mer_noise += nmer[1]; mer_values += nmer[2]
         imp_checked += W.impaired(k); imp_equal += (W.impaired(k) and not diffs)
         tr_details += [f"stream {int(W.my_streams[k])}: {d}" for d in details[:3]]
         if not diffs:
@@ -402,7 +421,8 @@ def reference_equality(W, recs, counts, frames, to_log, am: bool):
            "streams_with_lost_sync_this_pass": len(lost), "lost_sync_streams_checked": len(lost_checked), "lost_sync_streams_equal": eq_lost,
            "other_streams_checked": len(pick), "other_streams_equal": eq_other,
            "impaired_channel_streams_checked": int(imp_checked), "impaired_channel_streams_equal": int(imp_equal),
-           "mer_reports_beyond_1e-4_within_0.01dB": int(mer_exempt), "mer_reports_below_0dB_within_0.1dB": int(mer_noise),
+           "mer_values_compared": int(mer_values), "mer_reports_beyond_1e-4_within_0.01dB": int(mer_exempt), "mer_reports_below_0dB_within_0.1dB": int(mer_noise),
+           "mer_exemption_budgets": {"within_0.01dB": max(8, mer_values * MER_EXEMPT_BUDGET_PCT // 100), "below_0dB_within_0.1dB": max(4, mer_values * MER_NOISE_BUDGET_PCT_X10 // 1000)},
            "frames_exempt_cber": exempt, "exempt_max_bit_differences": max_bits,
            "streams_equal_under_the_strict_rule": strict,
            "streams_with_transient_loop_state_deviation": tr_streams, "transient_loop_state_fields": tr_fields,
@@ -416,6 +436,12 @@ def reference_equality(W, recs, counts, frames, to_log, am: bool):
                        "power ratio but less than 0.01 dB: near-singular equaliser cells in channel notches / interference (tests/common.py); mer_reports_below_0dB_within_0.1dB = reports of a sideband the reference itself rates below 0 dB (noise to the receiver), within 0.1 dB. The run FAILS when more than "
                        f"{TRANSIENT_STREAM_BUDGET_PCT} % of the compared streams carry a transient deviation; streams_failing_by_class names what a failing stream differs in "
                        "(p1_px_frame_bits / pids_frame_bits: a decoded frame; timing_pick_beyond_1_sample; <record>_<field>: a float beyond its bound)."}
+    # the counted MER exemptions have budgets over the whole batch as well as per log (tests/common.py): measured 24 / 11 / 16 of ~6 600 values (0.36 %) within
+    # 0.01 dB and 14 of ~13 000 (0.11 %) below 0 dB within 0.1 dB -- an equaliser that is a little off everywhere exceeds both at once
+    if mer_exempt > max(8, mer_values * MER_EXEMPT_BUDGET_PCT // 100):
+        FAILURES.append(f"{W.name}: {mer_exempt} of {mer_values} MER values needed the 0.01 dB bound (budget {MER_EXEMPT_BUDGET_PCT} %)")
+    if mer_noise > max(4, mer_values * MER_NOISE_BUDGET_PCT_X10 // 1000):
+        FAILURES.append(f"{W.name}: {mer_noise} of {mer_values} MER values needed the 0.1 dB below-0-dB bound (budget {MER_NOISE_BUDGET_PCT_X10 / 10} %)")
     if tr_streams * 100 > TRANSIENT_STREAM_BUDGET_PCT * max(1, len(todo)):
         FAILURES.append(f"{W.name}: {tr_streams} of {len(todo)} compared streams with transient loop-state deviations (budget {TRANSIENT_STREAM_BUDGET_PCT} %)")
     if len(lost) > len(lost_checked):
@@ -1183,8 +1209,20 @@ def main():
         g = shard.gather_vectors(vec, cdev)
         per_rank_parity = [{"rank": int(r[0]), "streams": int(r[1]), "streams_compared": int(r[2]), "streams_equal": int(r[3]), "streams_equal_under_the_strict_rule": int(r[4]),
                             "streams_with_transient_loop_state_deviation": int(r[5]), "parity_failures": int(r[6]), "checker_ran": bool(r[7])} for r in g]
-        # this rank's own verdict, one line on stderr (rank 0's stdout line carries all of them)
-        print("rank-parity " + json.dumps(per_rank_parity[rank] | {"failures": FAILURES[n_fail0:]}), file=sys.stderr)
+        # every rank's own list of failures travels through the process group too: rank 0's stdout line carries ALL verdicts verbatim (a line on a
+        # stderr shared with the launcher, the peers and their checker processes can be lost or torn: GPUTEST_r05)
+        texts = shard.gather_texts(json.dumps(FAILURES[n_fail0:]), cdev)
+        for r_, t_ in zip(per_rank_parity, texts):
+            r_["failures"] = json.loads(t_)
+        # ... and, where asked for, into a file of this rank's own (NRSC5_BENCH_VERDICT_DIR/rank-parity-<rank>.json, written whole then renamed)
+        vdir = os.environ.get("NRSC5_BENCH_VERDICT_DIR")
+        if vdir:
+            os.makedirs(vdir, exist_ok=True)
+            tmp = os.path.join(vdir, f".rank-parity-{rank}.json.{os.getpid()}")
+            with open(tmp, "w") as f:
+                json.dump(per_rank_parity[rank], f)
+            os.replace(tmp, os.path.join(vdir, f"rank-parity-{rank}.json"))
+        print("rank-parity " + json.dumps(per_rank_parity[rank]), file=sys.stderr)     # informational only
         sys.stderr.flush()
     shard.shutdown(cdev)                  # every collective of the run is behind us: the ranks leave the group together
     if rank != 0:
@@ -1195,7 +1233,7 @@ def main():
         parity["per_rank_reference_equality"] = per_rank_parity
         for r in per_rank_parity[1:]:
             if r["parity_failures"] or (checker and r["streams_compared"] != r["streams"]):
-                FAILURES.append(f"rank {r['rank']}: {r['parity_failures']} parity failure(s), {r['streams_compared']} of {r['streams']} streams compared (see that rank's `rank-parity` line on stderr)")
+                FAILURES.append(f"rank {r['rank']}: {r['parity_failures']} parity failure(s), {r['streams_compared']} of {r['streams']} streams compared: {r['failures'][:3]}")
     checker = checker and world == 1     # the host-core legs below (CPU baseline, drop-in, configs[4]) belong to the single-GPU line
     if args.workload == "fm" and not args.no_l2_index:
         try:

@@ -107,6 +107,25 @@ def gather_vectors(values, device) -> np.ndarray:
     return np.stack([o.cpu().numpy() for o in out])
 
 
+def gather_texts(text: str, device) -> list:
+    """one UTF-8 string per rank, in rank order (each rank's own list of failures, as JSON): lengths first, then the bytes padded to the
+    longest -- so that rank 0's result line carries every rank's verdict verbatim and nobody has to find it on a shared stderr"""
+    if not dist.is_initialized():
+        return [text]
+    raw = np.frombuffer(text.encode("utf-8"), dtype=np.uint8)
+    world = dist.get_world_size()
+    n = torch.tensor([raw.size], dtype=torch.int64, device=device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(sizes, n)
+    mx = max(1, int(max(s.item() for s in sizes)))
+    pad = torch.zeros(mx, dtype=torch.uint8, device=device)
+    if raw.size:
+        pad[:raw.size] = torch.from_numpy(raw.copy()).to(device)
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad)
+    return [bytes(o[:int(s.item())].cpu().numpy()).decode("utf-8") for o, s in zip(out, sizes)]
+
+
 def sum_over_ranks(values, device) -> np.ndarray:
     t = torch.tensor(list(values), dtype=torch.float64, device=device)
     if dist.is_initialized():

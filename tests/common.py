@@ -162,7 +162,7 @@ def compare_logs(expected, got, rtol: float = FLOAT_RTOL, skip_kinds=("hdc", "so
     if first_bad is not None:
         start = max([i for i, (k, _) in enumerate(exp[:first_bad]) if k == "sync"], default=0)
         loose = set(range(start, len(exp)))
-    mer_exempt0 = EXEMPT["mer_within_0.01dB"]
+    mer_exempt0, mer_noise0 = EXEMPT["mer_within_0.01dB"], EXEMPT["mer_below_0dB_within_0.1dB"]
     for i, (a, b) in enumerate(zip(exp, g)):
         for k, va in a[1].items():
             vb = b[1][k]
@@ -181,6 +181,11 @@ def compare_logs(expected, got, rtol: float = FLOAT_RTOL, skip_kinds=("hdc", "so
     used = EXEMPT["mer_within_0.01dB"] - mer_exempt0
     if used > max(4, n_mer // 4):
         diffs.append(f"#0 mer.exempt_count: expected {max(4, n_mer // 4)} got {used}")
+    # the 0.1 dB bound for reports the reference itself rates below 0 dB has a ceiling too: measured 14 such reports in ~780 locks
+    # of ~13 000 MER values -- at most 2 per log, or an eighth of its values
+    used_noise = EXEMPT["mer_below_0dB_within_0.1dB"] - mer_noise0
+    if used_noise > max(2, n_mer // 8):
+        diffs.append(f"#0 mer.noise_exempt_count: expected {max(2, n_mer // 8)} got {used_noise}")
     return diffs
 
 

@@ -32,6 +32,10 @@ def _worker(rank, world, port, total, q):
     # per-rank parity verdicts (bench.py --gpus N): one fixed-length vector per rank, gathered in rank order
     verdicts = shard.gather_vectors([float(r), float(len(mine)), float(len(mine)), float(len(mine)) - r, 0.0], dev)
     assert verdicts.shape == (w, 5) and [int(v[0]) for v in verdicts] == list(range(w)) and int(verdicts[1][3]) == len(shard.stream_range(total, w, 1)) - 1
+    # ... and each rank's list of failure strings, verbatim (ragged lengths incl. an empty one; non-ASCII survives)
+    import json
+    texts = shard.gather_texts(json.dumps([] if r == 0 else [f"fm: stream {mine[0]} differs \u2260 reference" * 3]), dev)
+    assert len(texts) == w and json.loads(texts[0]) == [] and json.loads(texts[1])[0].startswith(f"fm: stream {shard.stream_range(total, w, 1)[0]} differs \u2260")
     q.put((r, list(mine), allrows.tolist(), t, float(tot[0])))
     dist.destroy_process_group()
 
