@@ -82,6 +82,7 @@ def parse(argv=None):
     ap.add_argument("--parity-processes", type=int, default=0, help="host processes of the parity checker (default: host cores / ranks on this node, at most 64)")
     ap.add_argument("--oracle-lost-max", type=int, default=64, help="parity block: upper bound on the lost-sync streams compared (reported when it bites)")
     ap.add_argument("--tune", action="append", default=[], metavar="KNOB=VALUE", help="nrsc5hip_debug_tune before the run: decode_streams / am_decode_streams = 1..5, fwd_segments = 0..16")
+    ap.add_argument("--force-process-group", action="store_true", help="with --launch-check: form a process group for a single rank too (a one-rank RCCL group on a 1-GPU box)")
     ap.add_argument("--launch-check", action="store_true", help="only start the ranks, form the process group (RCCL; gloo without a GPU) and print what it sees -- no workload")
     ap.add_argument("--ingest", choices=("local", "scatter"), default="local",
                     help="fm, --gpus N: local = every rank synthesises its own captures; scatter = rank 0 synthesises all of them and sends each rank its shard (RCCL point-to-point, before the timed region)")
@@ -455,19 +456,28 @@ def launch_check(args):
     """--launch-check: the multi-rank start-up of --gpus N without the workload (runs on CPU with gloo too)."""
     import torch
     from nrsc5_amd import shard
-    rank, world, local = shard.init_from_env(expect_world=args.gpus)
     cuda = torch.cuda.is_available()
-    dev = torch.device("cuda", local) if cuda else torch.device("cpu")
     if cuda:
-        torch.cuda.set_device(dev)
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    rank, world, local = shard.init_from_env(expect_world=args.gpus, always=args.force_process_group)
+    dev = torch.device("cuda", local) if cuda else torch.device("cpu")
     shard.barrier(dev)
     # the ingest scatter of --ingest scatter in miniature: rank 0 makes every rank's rows, each rank must receive its own
     got = shard.scatter_rows(lambda r: torch.full((2, 4), r, dtype=torch.uint8, device=dev), 2, (4,), torch.uint8, dev)
     ranks = shard.sum_over_ranks([1.0, float(rank), float(bool((got == rank).all()))], dev)
     mine = my_stream_ids(args, world, rank)
     per_rank = shard.gather_floats(float(len(mine)), dev)
+    # every collective the real run uses, on this backend's tensors (RCCL: device tensors): the max / gather of the timing, the per-rank verdict vectors and
+    # failure texts, the per-stream summary rows
+    tmax = shard.max_over_ranks(1.0 + rank, dev)
+    vec = shard.gather_vectors([float(rank), float(len(mine))], dev)
+    texts = shard.gather_texts(json.dumps([f"rank {rank} \u2713"]), dev)
+    rows = shard.gather_summaries(np.array([[s, 1, 2, 2, 3, 4, 1000 + s] for s in mine[:3]], dtype=np.int64), dev)
+    collectives_ok = (tmax == float(world) and vec.shape == (world, 2) and [int(v[0]) for v in vec] == list(range(world))
+                      and [json.loads(t) for t in texts] == [[f"rank {r} \u2713"] for r in range(world)] and rows.shape == (3 * world, len(shard.SUMMARY_FIELDS))
+                      and bool((rows[:, 6] == 1000 + rows[:, 0]).all()))
     if rank == 0:
-        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_in_process_group": int(ranks[0]), "rank_sum": int(ranks[1]), "ingest_scatter_ok": int(ranks[2]),
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks_in_process_group": int(ranks[0]), "rank_sum": int(ranks[1]), "ingest_scatter_ok": int(ranks[2]), "collectives_ok": bool(collectives_ok),
                           "scaling": args.scaling, "streams_per_rank": [int(x) for x in per_rank], "ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
                           "backend": "nccl(RCCL)" if cuda else "gloo", "launched_by": os.environ.get("NRSC5_BENCH_LAUNCHER", "external torchrun" if world > 1 else "single process")}))
         sys.stdout.flush()

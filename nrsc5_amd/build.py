@@ -64,12 +64,22 @@ def build_hip_diag(flags, out_name: str) -> str:
     return out
 
 
+def _host_has_fma() -> bool:
+    try:
+        flags = next(l for l in open("/proc/cpuinfo") if l.startswith("flags")).split()
+    except (OSError, StopIteration):
+        return False
+    return "fma" in flags
+
+
 def build_emu(force: bool = False) -> str:
     simt = os.path.join(ROOT, "tests", "simt")
     deps = _deps() + [os.path.join(simt, "hipemu.h"), os.path.join(simt, "hipemu.cpp")]
     if force or _stale(EMU_LIB, deps):
         srcs = [os.path.join(CSRC, f) for f in HIP_SOURCES if os.path.exists(os.path.join(CSRC, f))]
-        cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-w", '-DNRSC5HIP_SOURCE_SHA="%s"' % source_sha(),
+        # -mfma (where the host has it): __builtin_fma of ref_sincosf becomes the instruction instead of a libm call; -ffp-contract=off keeps every other a * b + c unfused
+        fma = ["-mfma"] if _host_has_fma() else []
+        cmd = ["g++", "-O2", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-w"] + fma + ['-DNRSC5HIP_SOURCE_SHA="%s"' % source_sha(),
                "-I" + simt, "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-o", EMU_LIB,
                os.path.join(simt, "hipemu.cpp")]
         for s in srcs:

@@ -129,6 +129,62 @@ __device__ inline float ref_atan2f(float y, float x)
     }
 }
 
+// cexpf(I y) as the reference's libm computes it: glibc's cexpf (s_cexp_template.c) is expf(+-0) = 1 times sincosf(y), and sincosf is the single-precision
+// routine of glibc >= 2.28 (sysdeps/ieee754/flt-32/s_sincosf.c + s_sincosf.h, from Arm's optimized routines): reduction and a degree-7 / degree-8 polynomial pair in
+// DOUBLE, rounded to float once -- a 0.56-ulp function that neither OCML's sincosf, nor v_sin_f32 / v_cos_f32, nor a correctly rounded double sine reproduces to the
+// last bit (1.3 % of arguments differ).  Restated here operation for operation, INCLUDING which multiply-adds are fused: on every x86-64 host with FMA + AVX2 glibc's
+// ifunc picks `__sincosf_fma` (the same source built with -mfma -mavx2, contraction on), and in that build (Ubuntu glibc 2.35-0ubuntu3.x, the image of this container and
+// of the GPU box; read from its disassembly) EVERY a + b * c of the polynomial and the `x - n * hpi` of the fast reduction is one fused operation, the products x * s,
+// x * x, x2 * x, x2 * x2, x3 * x2, x4 * x2 and x * hpi_inv are plain.  tests/test_ref_sincosf.py compares with this container's libm on 1e8 arguments.
+// (A host WITHOUT FMA runs the unfused build and differs from this in the last bit for a fraction of a percent of arguments -- the UNMODIFIED reference is not
+// bit-reproducible from such a host to an FMA host either.)
+__device__ inline void ref_sincosf(float y, float &sinp, float &cosp)
+{
+    // __sincosf_table[0]; table [1] is the same with c0..c4 negated (a negated fma chain rounds to the negated result)
+    const double C0 = 0x1p0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10, C4 = 0x1.99343027bf8c3p-16;
+    const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+    unsigned yi; __builtin_memcpy(&yi, &y, 4);
+    const unsigned top = (yi >> 20) & 0x7ff;                   // abstop12
+    double x = (double)y, sgn = 1.0;
+    int n = 0, q = 0;                                          // n: quadrant (parity swaps the polynomials), q: quadrant incl. the sign of a large argument
+    if (top < 0x3f4) {                                         // |y| < pi/4
+        if (top < 0x398) { sinp = y; cosp = 1.0f; return; }    // |y| < 2^-12
+    } else if (top < 0x42f) {                                  // |y| < 120: reduce_fast, hpi_inv prescaled by 2^24, truncating conversion
+        const double r = x * 0x1.45F306DC9C883p+23;
+        n = ((int)r + 0x800000) >> 24;
+        x = __builtin_fma(-(double)n, 0x1.921FB54442D18p0, x);
+        q = n;
+    } else if (top < 0x7f8) {                                  // reduce_large: 4/pi to 192 bits, a 32 x 96 -> 128 bit product, exact 2.62 fixed point
+        const unsigned inv_pio4[24] = { 0xa2, 0xa2f9, 0xa2f983, 0xa2f9836e, 0xf9836e4e, 0x836e4e44, 0x6e4e4415, 0x4e441529, 0x441529fc, 0x1529fc27, 0x29fc2757, 0xfc2757d1,
+                                        0x2757d1f5, 0x57d1f534, 0xd1f534dd, 0xf534ddc0, 0x34ddc0db, 0xddc0db62, 0xc0db6295, 0xdb629599, 0x6295993c, 0x95993c43, 0x993c4390, 0x3c439041 };
+        const unsigned *arr = &inv_pio4[(yi >> 26) & 15];
+        const int shift = (yi >> 23) & 7;
+        unsigned xi = (yi & 0xffffff) | 0x800000;
+        xi <<= shift;
+        unsigned long long res0 = (unsigned)(xi * arr[0]);
+        const unsigned long long res1 = (unsigned long long)xi * arr[4], res2 = (unsigned long long)xi * arr[8];
+        res0 = (res2 >> 32) | (res0 << 32);
+        res0 += res1;
+        const unsigned long long nn = (res0 + (1ULL << 61)) >> 62;
+        res0 -= nn << 62;
+        x = (double)(long long)res0 * 0x1.921FB54442D18p-62;
+        n = (int)nn;
+        q = n + (int)(yi >> 31);
+    } else {                                                   // inf / NaN
+        sinp = cosp = y - y; return;
+    }
+    if (((q + 1) & 2) != 0) sgn = -1.0;                         // sign[q & 3] = { 1, -1, -1, 1 }
+    const double cs = (q & 2) ? -1.0 : 1.0;                     // table [1]
+    const double x2 = x * x, X = x * sgn;
+    const double x3 = x2 * X, x4 = x2 * x2;
+    const double s1 = __builtin_fma(x2, S3, S2), c2 = __builtin_fma(x2, C4 * cs, C3 * cs);
+    const double x5 = x2 * x3, x6 = x2 * x4;
+    const double c1 = __builtin_fma(x2, C1 * cs, C0 * cs);
+    const double s = __builtin_fma(x3, S1, X), c = __builtin_fma(x4, C2 * cs, c1);
+    const float sv = (float)__builtin_fma(s1, x5, s), cv = (float)__builtin_fma(c2, x6, c);
+    if (n & 1) { sinp = cv; cosp = sv; } else { sinp = sv; cosp = cv; }
+}
+
 // Double-precision cosine / sine / arc tangent of SMALL arguments by their Taylor series (Horner), for the NCO step of the next
 // block (prepare_block: the single lane that runs it sits at the end of the block-step chain; the device libm's three calls were
 // ~5 k of the sync kernel's ~11 k "finish" cycles).  |x| <= 0.25: the series are cut where the next term is below 1e-20 of the

@@ -107,11 +107,7 @@ template <typename S> __device__ inline Prepared prepare_values_of(const S &st, 
     } else {
         p.samperr = st.coarse_samperr;
         // angle_diff = arg(max_v * e^{-i prev_angle})        (acquire.c:153)
-#ifdef NRSC5HIP_ACCURATE_TRIG
-        const float sn = (float)sin((double)-st.prev_angle), cs = (float)cos((double)-st.prev_angle);
-#else
-        float sn, cs; sincosf(-st.prev_angle, &sn, &cs);
-#endif
+        float sn, cs; ref_sincosf(-st.prev_angle, sn, cs);     // cexpf(I * -prev_angle): glibc's sincosf restated (fastmath.h), bit for bit
         const float pr = st.coarse_re * cs - st.coarse_im * sn;
         const float pi = st.coarse_re * sn + st.coarse_im * cs;
 #ifdef NRSC5HIP_ACCURATE_TRIG
@@ -128,15 +124,14 @@ template <typename S> __device__ inline Prepared prepare_values_of(const S &st, 
     const float dtheta = angle / FFT_N;
     // The reference rotates by the float pair (cosf, sinf)(dtheta) once per sample (acquire.c:168,250);
     // the angle of that rounded unit vector, not dtheta itself, is its effective NCO step.
+    // (round 6) phase_increment = cexpf(angle / fft * I) is glibc's float sincosf, a 0.56-ulp function: a correctly rounded cosine (what rounds 3 - 5 used here:
+    // a double series rounded once) is a DIFFERENT float for 1.3 % of arguments, and one ulp of inc_c is 6e-8 of |phase_increment| -- which the reference multiplies
+    // up 2160 times per symbol (the amplitude ramp below): a block whose inc_c was the other float carried a ramp off by up to 1.3e-4 across every symbol, the size
+    // of difference the CFO search is known to amplify (DESIGN (c) limit 2).  ref_sincosf (fastmath.h) IS glibc's function, bit for bit.
     float inc_c, inc_s;
-    if (fabsf(dtheta) < 0.25f) {                               // |integer CFO| up to 80 bins: always, in practice
-        double c, sn; small_cos_sin((double)dtheta, c, sn);
-        inc_c = (float)c; inc_s = (float)sn;
-        p.dtheta = small_atan((double)inc_s / (double)inc_c);
-    } else {
-        inc_c = (float)cos((double)dtheta); inc_s = (float)sin((double)dtheta);
-        p.dtheta = atan2((double)inc_s, (double)inc_c);
-    }
+    ref_sincosf(dtheta, inc_s, inc_c);
+    if (fabsf(dtheta) < 0.25f) p.dtheta = small_atan((double)inc_s / (double)inc_c);   // |integer CFO| up to 80 bins: always, in practice
+    else p.dtheta = atan2((double)inc_s, (double)inc_c);
     // ... and its LENGTH, 1 + g with |g| up to 6e-8, is the oscillator's amplitude: phase *= phase_increment 2160 times between two
     // renormalisations (acquire.c:250-252) makes the amplitude run as (1 + g)^j across the symbol, up to 1.3e-4 at its last sample -- deterministic,
     // and 100 x the rounding noise of the recurrence.  The symbol kernel gives its closed-form phasor the same ramp (k_mixfft: nco_ramp).
@@ -148,15 +143,9 @@ template <typename S> __device__ inline Prepared prepare_values_of(const S &st, 
     p.theta = th;
     p.inc_c = inc_c; p.inc_s = inc_s;
     if (nco_wants_exact(st, nco_policy)) {
-        // st->phase *= cexpf(rot * I) as the reference computes it: glibc's cexpf is (cosf, sinf) of the float argument, the product the
-        // plain four-multiplication form in float (gcc -O3, no contraction; oracle/Makefile).  (float)cos((double)x) is cosf(x) except where
-        // glibc's own 0.56-ulp result is not the correctly rounded one: 1.3 % of arguments at |x| < 40, by one ulp = a constant phase
-        // offset of 6e-8 rad, below the FFT's rounding noise; the emulator build calls glibc itself.
-#ifdef HIPEMU
-        const float rc = cosf(rot), rs = sinf(rot);
-#else
-        const float rc = (float)cos((double)rot), rs = (float)sin((double)rot);
-#endif
+        // st->phase *= cexpf(rot * I) as the reference computes it: glibc's cexpf is sincosf of the float argument (ref_sincosf: the same function, restated),
+        // the product the plain four-multiplication form in float (gcc -O3, no contraction; oracle/Makefile)
+        float rc, rs; ref_sincosf(rot, rs, rc);
         const float a = st.nco_re, b = st.nco_im;
         const float ac = a * rc, bd = b * rs, ad = a * rs, bc = b * rc;
         p.ph_re = ac - bd; p.ph_im = ad + bc;

@@ -21,16 +21,17 @@ def stream_range(total_streams: int, world: int, rank: int) -> range:
     return range(lo, lo + base + (1 if rank < rem else 0))
 
 
-def init_from_env(backend: str | None = None, expect_world: int | None = None):
-    """(rank, world, local_rank); initialises the default process group when WORLD_SIZE > 1.  expect_world: the rank count
-    the caller was asked for (--gpus N) -- a mismatch with what the process group reports is an error, never a silent
-    single-rank run."""
+def init_from_env(backend: str | None = None, expect_world: int | None = None, always: bool = False):
+    """(rank, world, local_rank); initialises the default process group when WORLD_SIZE > 1 (always=True: also for a single rank --
+    a one-rank RCCL group is the only way a 1-GPU box can run this module's collectives on device tensors through RCCL itself:
+    tests/test_gpu_rccl_single_rank.py).  expect_world: the rank count the caller was asked for (--gpus N) -- a mismatch with what
+    the process group reports is an error, never a silent single-rank run."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # dmabuf IPC (this driver supports nothing else): also when an external torchrun started the ranks without it
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or always) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         # NRSC5_SHARD_BACKEND=gloo: TEST MODE of bench.py (with NRSC5_BENCH_SHARE_GPU=1: N ranks on ONE GPU, collectives on CPU tensors) -- the multi-rank

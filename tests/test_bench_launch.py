@@ -25,12 +25,13 @@ def test_bench_spawns_its_own_ranks():
     assert len(lines) == 1, r.stdout                    # rank 0 only
     assert lines[0]["n_gpus"] == 2 and lines[0]["ranks_in_process_group"] == 2 and lines[0]["rank_sum"] == 1
     assert lines[0]["ingest_scatter_ok"] == 2             # both ranks received their own shard from rank 0 (point-to-point)
+    assert lines[0]["collectives_ok"] is True            # max / vector / text / summary gathers: every collective of the real run
     assert lines[0]["launched_by"] == "bench.py"
 
 
 def test_bench_single_rank_is_one_process():
     r, lines = _run(["--gpus", "1", "--launch-check"])
-    assert r.returncode == 0 and lines == [{"launch_check": True, "n_gpus": 1, "ranks_in_process_group": 1, "rank_sum": 0, "ingest_scatter_ok": 1,
+    assert r.returncode == 0 and lines == [{"launch_check": True, "n_gpus": 1, "ranks_in_process_group": 1, "rank_sum": 0, "ingest_scatter_ok": 1, "collectives_ok": True,
                                             "scaling": "weak", "streams_per_rank": [256], "ipc_mode_legacy": "0",
                                             "backend": "gloo", "launched_by": "single process"}], r.stdout + r.stderr[-1000:]
 
@@ -48,7 +49,7 @@ def test_eight_ranks_strong_scaling_split():
     r, lines = _run(["--gpus", "8", "--launch-check", "--scaling", "strong", "--total-streams", "2048"])
     assert r.returncode == 0, r.stderr[-2000:]
     assert len(lines) == 1 and lines[0]["n_gpus"] == 8 and lines[0]["ranks_in_process_group"] == 8 and lines[0]["rank_sum"] == 28
-    assert lines[0]["scaling"] == "strong" and lines[0]["streams_per_rank"] == [256] * 8 and lines[0]["ingest_scatter_ok"] == 8
+    assert lines[0]["scaling"] == "strong" and lines[0]["streams_per_rank"] == [256] * 8 and lines[0]["ingest_scatter_ok"] == 8 and lines[0]["collectives_ok"] is True
     assert lines[0]["ipc_mode_legacy"] == "0"
 
 
@@ -63,3 +64,10 @@ def test_driver_style_torchrun_line_without_ipc_env():
     lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, r.stderr[-2000:]
     assert lines[0]["ipc_mode_legacy"] == "0" and lines[0]["launched_by"] == "external torchrun" and lines[0]["streams_per_rank"] == [256, 256]
+
+
+def test_single_rank_forced_process_group():
+    """one rank, but through a real process group (gloo here; on the GPU box the same line forms a one-rank RCCL group: tests/test_gpu_rccl_single_rank.py)"""
+    r, lines = _run(["--gpus", "1", "--launch-check", "--force-process-group"], env={"MASTER_PORT": str(29600 + os.getpid() % 300)})
+    assert r.returncode == 0 and len(lines) == 1, r.stderr[-2000:]
+    assert lines[0]["ranks_in_process_group"] == 1 and lines[0]["collectives_ok"] is True and lines[0]["ingest_scatter_ok"] == 1
