@@ -412,6 +412,10 @@ enum {
                                              closed-form phasor: 0 (default) = none, 1 = the first block after a reset (the block the CFO search runs on), 2 = every block until the
                                              stream is FINE, 3 = every block (diagnostic).  The float oscillator state is the reference's bit for bit for as long as every
                                              block since the reset ran in this mode; the first closed-form block ends that until the next reset */
+    , NRSC5HIP_TUNE_LOOP_EXACT             /* FM Costas loops / CFO search (sync.c:90-136, 292-337) by the reference's own operations -- glibc's sincosf and atan2f restated
+                                             bit for bit (fastmath.h), its float complex products, adjust_ref / reset_ref in place -- instead of the fast forms (v_sin / v_cos,
+                                             a 4-term arc tangent, ~5e-7): 0 = never, 1 (default) = in every block that starts un-synchronised (the tracking pass over garbage and the
+                                             CFO search, where a last-bit difference can be amplified into a different loop state), 2 = in every block */
 };
 /* process-wide wall-clock totals of the streaming seam with p1_async = 0 (what the drop-in uses): [0] s copying pushes into pinned
  * staging, [1] s enqueueing H2D + decimator, [2] s enqueueing block steps, [3] s waiting for the device (one sync per block),

@@ -498,6 +498,8 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         // the reference's oscillator sample by sample for blocks in exact mode (553 KB per stream; k_nco_exact -> k_mixfft)
         if ((rc = dev_alloc(e, &db.nco_tab, S * NSYM * SYM_N))) break;
         if ((rc = dev_alloc(e, &db.cfo_snap, S * LIVE_N * (PM_PART + 1)))) break;
+        if ((rc = dev_alloc(e, &db.cfo_phase, S * NSYM * LIVE_N))) break;     // 68 KB per stream: phases[][] of the exact CFO search's visit in progress
+        db.loop_exact = 1;                                     // the reference's own loop arithmetic in blocks that start un-synchronised (k_sync.hip; NRSC5HIP_TUNE_LOOP_EXACT)
         // Default: the closed-form phasor with the reference oscillator's amplitude ramp (NCO_CLOSED_FORM).  Measured (DESIGN.md (c) limit 2): on the CPU twin,
         // whose libm is the reference's, the exact first block takes the locks after a CFO search that deviate in loop-internal state from 5 to 2 in 900 (18
         // without the ramp); on the MI355X the deviating streams of two 256-stream CFO-search batches are the same under every policy (other last-bit
@@ -2278,6 +2280,7 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
     case NRSC5HIP_TUNE_SYNC_LANES:        e->sync_lanes = (value == 256 || value == 768) ? value : 0; break;
     case NRSC5HIP_TUNE_SEAM_PREPARE:      e->fuse_seam_prepare = value != 0; break;
     case NRSC5HIP_TUNE_NCO_EXACT:         e->db.nco_policy = e->lane.db.nco_policy = e->db.nco_tab ? std::min(std::max(value, 0), (int)NCO_EXACT_ALWAYS) : (int)NCO_CLOSED_FORM; break;
+    case NRSC5HIP_TUNE_LOOP_EXACT:        e->db.loop_exact = e->lane.db.loop_exact = std::min(std::max(value, 0), 2); break;
     case NRSC5HIP_TUNE_EARLY_FLUSH_KB:    e->early_flush = (size_t)std::max(value, 0) << 10; break;
     case NRSC5HIP_TUNE_DEFER_WAIT:        e->defer_wait = value != 0; break;
     case NRSC5HIP_TUNE_DIRECT_DECIMATE:   e->direct_decimate = value != 0; break;

@@ -41,6 +41,75 @@ __device__ inline LoopGains loop_gains()                      // sync.c:832-841
     return g;
 }
 
+// ---- the loops as the reference computes them, operation for operation (round 6; DevBuffers::loop_exact) ----------------------------------------
+// One step of adjust_ref (sync.c:101-113) on z with loop state (freq, phase): cexpf is glibc's sincosf of the float argument (ref_sincosf), cargf its atan2f
+// (ref_atan2f), the complex products gcc's four multiplications and two sums in float, none contracted (-ffp-contract=off here, no FMA in the reference's
+// x86-64 baseline build), the wrap of the phase a double comparison / double difference rounded once.  The fast form above it in this file reaches the same
+// values to ~5e-7 (v_sin / v_cos, a 4-term arc tangent, e^{2i phase} by the double-angle identities); this one reaches them to the last bit WHEN its inputs
+// are the reference's -- and where they are not quite (the transform's own rounding), it at least adds no difference of its own for the CFO search to amplify.
+// SERIAL: the second sincosf waits for the first (the CFO search's work-items hold a dozen loop variables across this call, and two interleaved double-precision
+// polynomial evaluations on top of them spilled four VGPRs: a private segment that EVERY launch of the sync kernel would pay for).
+template <bool SERIAL>
+__device__ __forceinline__ float2 costas_step_exact(const float2 z, float &freq, float &phase, float cfo_freq, const LoopGains g)
+{
+    float s2, c2; ref_sincosf(-(2.0f * phase), s2, c2);        // cexpf(-I * 2 * phase)
+    float ph1 = phase;
+#ifndef HIPEMU
+    if (SERIAL) asm volatile("" : "+v"(ph1) : "v"(s2), "v"(c2));
+#endif
+    float s1, c1; ref_sincosf(-ph1, s1, c1);                   // cexpf(-I * phase)
+    const float wr = z.x * z.x - z.y * z.y, wi = z.x * z.y + z.y * z.x;          // buffer * buffer
+    const float ur = wr * c2 - wi * s2, ui = wr * s2 + wi * c2;                  // ... * cexpf(-2 i phase)
+    const float error = ref_atan2f(ui, ur) * 0.5f;
+    const float2 zr = make_float2(z.x * c1 - z.y * s1, z.x * s1 + z.y * c1);     // buffer *= cexpf(-i phase)
+    freq += g.beta * error;
+    if (freq > 0.5f) freq = 0.5f;
+    if (freq < -0.5f) freq = -0.5f;
+    phase += freq + cfo_freq + (g.alpha * error);
+    if ((double)phase > M_PI) phase = (float)((double)phase - 2 * M_PI);
+    if ((double)phase < -M_PI) phase = (float)((double)phase + 2 * M_PI);
+    return zr;
+}
+
+// adjust_ref (sync.c:90-130) in place on col[n * stride], n = 0..31, the loop phase of every symbol filed in ph[n * ph_stride]; returns the sign bits of the
+// derotated real parts (after the flip).  RESET: followed by reset_ref (sync.c:132-136) -- what the CFO search does at every visit of a bin: the derotated values
+// are rotated back by cexpf(I * phases[n]), which restores them to within rounding, NOT bit for bit, and a bin the search visits again (up to 11 times) starts from
+// the values the previous visit left.
+template <bool RESET>
+__device__ inline uint32_t adjust_ref_exact(float2 *col, int stride, float *ph, int ph_stride, float &freq, float &phase, int cfo, const LoopGains g)
+{
+    const float cfo_freq = (float)(2 * M_PI * cfo * CP_N / FFT_N);
+    float x = 0.0f;
+#pragma unroll 1
+    for (int n = 0; n < NSYM; n++) {
+        ph[n * ph_stride] = phase;
+        const float2 zr = costas_step_exact<RESET>(col[n * stride], freq, phase, cfo_freq, g);
+        col[n * stride] = zr;
+        const float sgn = ((PAT_POS >> n) & 1u) ? 1.0f : (((PAT_NEG >> n) & 1u) ? -1.0f : 0.0f);
+        x += zr.x * sgn;
+    }
+    const bool flip = x < 0;
+    if (flip) phase = (float)((double)phase + M_PI);
+    uint32_t pos = 0;
+    if (flip || RESET) {
+#pragma unroll 1
+        for (int n = 0; n < NSYM; n++) {
+            float2 zr = col[n * stride];
+            float pn = ph[n * ph_stride];
+            if (flip) { pn = (float)((double)pn + M_PI); zr = make_float2(zr.x * -1.0f, zr.y * -1.0f); ph[n * ph_stride] = pn; }
+            if (zr.x > 0) pos |= 1u << n;
+            if (RESET) {
+                float sn, cs; ref_sincosf(pn, sn, cs);         // reset_ref: buffer *= cexpf(I * phases[n])
+                zr = make_float2(zr.x * cs - zr.y * sn, zr.x * sn + zr.y * cs);
+            }
+            col[n * stride] = zr;
+        }
+    } else {
+        for (int n = 0; n < NSYM; n++) if (col[n * stride].x > 0) pos |= 1u << n;
+    }
+    return pos;
+}
+
 // One reference carrier through its second-order Costas loop for the 32 symbols of a block
 // (sync.c:90-130).  z(n) is fetched through `src` with stride `stride`; optionally the derotated
 // values / loop phases are stored.  Returns the sign bits of the derotated real parts (bit n = re > 0).
@@ -352,11 +421,16 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
     SYNC_MARK(0);
 
     // ---- Costas loops of the active reference carriers (sync.c:360-364)
+    // loop_exact (DevBuffers): 0 = the fast forms everywhere, 1 = the reference's own operations (ref_sincosf / ref_atan2f, in-place derotate and reset_ref) in every
+    // block that starts un-synchronised -- the tracking pass over garbage and the CFO search, where a last-bit difference can be amplified into a different loop
+    // state (DESIGN (c) limit 2) --, 2 = in every block
+    const bool exact_blk = db.loop_exact == 2 || (db.loop_exact == 1 && sh_pre[PRE_STATE] != SYNC_FINE);
     if (tid < nref) {
         const int l = bin_to_live(ref_bin(tid));
         float f = e_freq, p = e_phase;
         if (SYM_N / 2 - samperr != 0) p = st.costas_phase[l];  // block-uniform: sync_adjust above has just rotated the phases
-        costas_block<true>(refz[tid], 1, f, p, 0, g, refz[tid], refph[tid]);     // in place: refz holds the carrier's raw bins
+        if (exact_blk) adjust_ref_exact<false>(refz[tid], 1, refph[tid], 1, f, p, 0, g);   // block-uniform: the reference's own operations (loop_exact)
+        else costas_block<true>(refz[tid], 1, f, p, 0, g, refz[tid], refph[tid]);         // in place: refz holds the carrier's raw bins
         int l2 = l;
 #ifndef HIPEMU
         asm volatile("" : "+v"(l2));                           // the address is computed again instead of surviving the loops in a (spilled) register pair
@@ -436,12 +510,24 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
                 const float2 *src = rslot >= 0 ? (const float2 *)&refz[rslot][0] : (const float2 *)(bins + l);
                 const int stride = rslot >= 0 ? 1 : LIVE_N;
                 float2 *snap = db.cfo_snap + ((size_t)s * LIVE_N + l) * (PM_PART + 1);
-                if (mine)
+                // (two loops, one per arithmetic: in one loop the exact form's double-precision constants were held in registers across the fast form's visits too,
+                //  and the fast form's prefetch addresses went to scratch memory -- a private segment every launch of this kernel would pay for)
+                if (mine && !exact_blk)
                 for (int q = 0; q <= PM_PART; q++) {
                     const int i = lower ? (PM_PART - q) : q;   // ascending cfo
                     const int cfo = lower ? (b - LB0 - PW * i) : (b - UB1 + PW * i);
                     if (cfo < CFO_LO || cfo >= CFO_HI) continue;
                     const uint32_t d = costas_block<false>(src, stride, f, p, cfo, g, nullptr, nullptr);
+                    cfo_offs[cfo - CFO_LO][2 * i + (lower ? 0 : 1)] = (int8_t)needle_search(d, (30 - i) & 3);
+                    snap[q] = make_float2(f, p);
+                }
+                if (mine && exact_blk)
+                for (int q = 0; q <= PM_PART; q++) {
+                    const int i = lower ? (PM_PART - q) : q;
+                    const int cfo = lower ? (b - LB0 - PW * i) : (b - UB1 + PW * i);
+                    if (cfo < CFO_LO || cfo >= CFO_HI) continue;
+                    // adjust_ref + reset_ref in place on the bin's own column (this work-item is its only visitor), phases in the stream's scratch slab
+                    const uint32_t d = adjust_ref_exact<true>(const_cast<float2 *>(src), stride, db.cfo_phase + (size_t)s * NSYM * LIVE_N + l, LIVE_N, f, p, cfo, g);
                     cfo_offs[cfo - CFO_LO][2 * i + (lower ? 0 : 1)] = (int8_t)needle_search(d, (30 - i) & 3);
                     snap[q] = make_float2(f, p);
                 }

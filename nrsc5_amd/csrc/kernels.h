@@ -42,6 +42,8 @@ struct DevBuffers {
     float2 *acq_sums;                // [S][SYM_N]
     float2 *bins;                    // [S][NSYM][LIVE_N]
     float2 *cfo_snap;                // [S][LIVE_N][11]  the CFO search's loop-state snapshots (k_sync: one per visit of a live bin)
+    float *cfo_phase;                // [S][NSYM][LIVE_N]  exact CFO search (loop_exact): phases[][] of the visit in progress, one column per live bin
+    int loop_exact;                  // 0: fast loop arithmetic, 1: the reference's own operations in blocks that start un-synchronised, 2: in every block (k_sync.hip)
     float2 *nco_tab;                 // [S][NSYM][SYM_N]  the reference's oscillator sample by sample for a block that runs in exact mode (k_nco_exact -> k_mixfft); null: closed form only
     int nco_policy;                  // NCO_*: which blocks of a freshly reset stream advance the oscillator by the reference's float recurrence
     int8_t *pm;                      // [S][NPM][PM_FRAME]  soft-bit interleaver matrices (one per frame in flight)

@@ -67,7 +67,7 @@ class L2Job(ctypes.Structure):
 
 
 L2_FM_P1, L2_FM_PX, L2_AM = 0, 1, 2
-TUNE_DECODE_STREAMS, TUNE_AM_DECODE_STREAMS, TUNE_VERDICT_LAG, TUNE_SYNC_PHASES, TUNE_FWD_SEGMENTS, TUNE_FWD_WARM, TUNE_AM_SEGMENTS, TUNE_DECODE_CUS, TUNE_DECODE_PRIORITY, TUNE_AM_WARM, TUNE_MIXFFT_SYMS, TUNE_DEFER_WAIT, TUNE_TRACEBACK_WALK, TUNE_SYNC_LANES, TUNE_DIRECT_DECIMATE, TUNE_EARLY_FLUSH_KB, TUNE_SEAM_PREPARE, TUNE_NCO_EXACT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17
+TUNE_DECODE_STREAMS, TUNE_AM_DECODE_STREAMS, TUNE_VERDICT_LAG, TUNE_SYNC_PHASES, TUNE_FWD_SEGMENTS, TUNE_FWD_WARM, TUNE_AM_SEGMENTS, TUNE_DECODE_CUS, TUNE_DECODE_PRIORITY, TUNE_AM_WARM, TUNE_MIXFFT_SYMS, TUNE_DEFER_WAIT, TUNE_TRACEBACK_WALK, TUNE_SYNC_LANES, TUNE_DIRECT_DECIMATE, TUNE_EARLY_FLUSH_KB, TUNE_SEAM_PREPARE, TUNE_NCO_EXACT, TUNE_LOOP_EXACT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18
 L2_STATUS = ("end", "no_audio", "fixed_data", "header_rs", "bad_locators", "too_many_pdus", "hef_overrun", "bad_stream", "bad_length", "audio_end")
 
 

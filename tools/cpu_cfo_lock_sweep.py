@@ -3,7 +3,7 @@ search (integer CFO != 0)?  Synthetic MP1 captures with |CFO| in (185, 300) Hz (
 through (a) the unmodified reference (oracle/_ref) and (b) the CPU-emulated twin of the library (tests/simt: the kernels' logic with glibc's libm and no fused
 multiply-adds -- a third float sequence beside the reference's and the GPU's); complete logs compared under the strict rule (tests/common.py: integers exact,
 floats 1e-4).  DESIGN.md (c) limit 2; result of the round-4 run: profiles/r04_cfo_lock_transients.txt.
-    python tools/cpu_cfo_lock_sweep.py [--self | --nco | --emu-lib PATH | --policy N] [processes=8] [captures=900]
+    python tools/cpu_cfo_lock_sweep.py [--self | --nco | --emu-lib PATH | --policy N] [--loop-exact N] [processes=8] [captures=900]
 --self: both sides are the unmodified reference, (b) linked with another FFT (oracle/_ref/libnrsc5_ref_sse_dp.so; `make -C oracle _ref/libnrsc5_ref_sse_dp.so`).
 --nco:  (b) is the reference with an ideal (double-precision) oscillator inside each symbol instead of its float recurrence (tools/build_ref_ideal_nco.py)."""
 import json, os, re, sys, time
@@ -19,6 +19,9 @@ EMU_OVERRIDE = None                         # --emu-lib PATH: another emulated t
 POLICY = None                               # --policy N: NRSC5HIP_TUNE_NCO_EXACT of the emulated twin (0 closed form [default], 1 first block exact, 2 until FINE, 3 always)
 if "--policy" in sys.argv:
     k = sys.argv.index("--policy"); POLICY = int(sys.argv[k + 1]); del sys.argv[k:k + 2]
+LOOP = None                                 # --loop-exact N: NRSC5HIP_TUNE_LOOP_EXACT of the emulated twin (0 fast loop arithmetic, 1 exact while un-synchronised [default], 2 always)
+if "--loop-exact" in sys.argv:
+    k = sys.argv.index("--loop-exact"); LOOP = int(sys.argv[k + 1]); del sys.argv[k:k + 2]
 if "--emu-lib" in sys.argv:
     k = sys.argv.index("--emu-lib"); EMU_OVERRIDE = sys.argv[k + 1]; del sys.argv[k:k + 2]
 
@@ -39,7 +42,7 @@ def work(args):
         log = R2.run(cap.iq, mode=0)[0]
     else:
         from nrsc5_amd import engine as eng
-        E, recs, log = ec.run_capture(EMU_OVERRIDE or build.EMU_LIB, cap, tune=() if POLICY is None else ((eng.TUNE_NCO_EXACT, POLICY),))
+        E, recs, log = ec.run_capture(EMU_OVERRIDE or build.EMU_LIB, cap, tune=(() if POLICY is None else ((eng.TUNE_NCO_EXACT, POLICY),)) + (() if LOOP is None else ((eng.TUNE_LOOP_EXACT, LOOP),)))
         E.close()
     exp, got = common.strip_states(ref_log), common.strip_states(log)
     diffs = common.compare_logs(exp, got)
