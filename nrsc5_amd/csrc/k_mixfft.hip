@@ -427,14 +427,17 @@ template <int NT> struct SymPrologue {
     }
 };
 
-template <bool RAW, int SPW, int NPAR, bool EXACT = false>
-__device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuffers &db, const uint8_t *raw, const SymParams &sp, int s, cf *lds, cf *twB, const SymPrologue<128 * NPAR> &pro)
+// FLOW (k_flow.hip): the bins leave WRITE-THROUGH (sc1 stores: straight to memory, dropped from this XCD's L2) -- the block step that consumes them runs as another
+// workgroup of the same launch, possibly on another XCD, and is released by a counter, not by a launch boundary.  wg: the workgroup's index among the stream's
+// NSYM / (SPW * NPAR) symbol workgroups (blockIdx.x of k_mixfft).
+template <bool RAW, int SPW, int NPAR, bool EXACT = false, bool FLOW = false>
+__device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuffers &db, const uint8_t *raw, const SymParams &sp, int s, cf *lds, cf *twB, const SymPrologue<128 * NPAR> &pro, const int wg)
 {
     // SPW consecutive symbols of one stream per workgroup: the stage-B twiddles, the half-band taps and the NCO step are set up
     // once, and symbol n + 1's capture loads (24 dwords per work-item) are in flight while symbol n goes through mix and FFT --
     // with one symbol per workgroup every workgroup began its life waiting for HBM with nothing else to do (17 % VALU-busy).
     MIX_MARK_BEGIN;
-    const int sym0 = (int)(blockIdx.x * NPAR + (threadIdx.x >> 7)) * SPW;
+    const int sym0 = (int)(wg * NPAR + (threadIdx.x >> 7)) * SPW;
     const long long a00 = sp.a00;                              // first sample of symbol 0 in the decimated stream
     uint32_t W[24];
     if (RAW && !DIAG_NOLOAD) raw_symbol_load(raw, a00 + (long long)sym0 * SYM_N, W, threadIdx.x & 127);      // first thing once the position is known
@@ -547,12 +550,13 @@ __device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuf
         cf *out = (cf *)(db.bins + ((size_t)s * NSYM + sym) * LIVE_N);
         const int kbase = (tid >> 4) + 8 * (tid & 15);
         static_assert(LB0 == 478 && UB0 == 1304 && UB1 == 1570 && LIVE_HALF == 267, "the six-output cut below is laid out for these edges");
-        if (kbase >= LB0 - 384) out[kbase + 384 - LB0] = x[14];                    // m' = 3  (X[11])
-        out[kbase + 512 - LB0] = x[3];                                             // m' = 4  (X[12])
-        if (kbase + 640 < LB0 + LIVE_HALF) out[kbase + 640 - LB0] = x[7];          // m' = 5  (X[13])
-        if (kbase + 1280 >= UB0) out[LIVE_HALF + kbase + 1280 - UB0] = x[8];       // m' = 10 (X[2])
-        out[LIVE_HALF + kbase + 1408 - UB0] = x[12];                               // m' = 11 (X[3])
-        if (kbase + 1536 <= UB1) out[LIVE_HALF + kbase + 1536 - UB0] = x[1];       // m' = 12 (X[4])
+        auto put = [&](int k, cf v) __attribute__((always_inline)) { if (FLOW) flow_store_through(&out[k], v); else out[k] = v; };
+        if (kbase >= LB0 - 384) put(kbase + 384 - LB0, x[14]);                     // m' = 3  (X[11])
+        put(kbase + 512 - LB0, x[3]);                                              // m' = 4  (X[12])
+        if (kbase + 640 < LB0 + LIVE_HALF) put(kbase + 640 - LB0, x[7]);           // m' = 5  (X[13])
+        if (kbase + 1280 >= UB0) put(LIVE_HALF + kbase + 1280 - UB0, x[8]);        // m' = 10 (X[2])
+        put(LIVE_HALF + kbase + 1408 - UB0, x[12]);                                // m' = 11 (X[3])
+        if (kbase + 1536 <= UB1) put(LIVE_HALF + kbase + 1536 - UB0, x[1]);        // m' = 12 (X[4])
         MIX_MARK(5, 1);                                            // the stores, waited for
     }
 }
@@ -566,22 +570,32 @@ __device__ __forceinline__ void mixfft_symbols(const DevTables &tb, const DevBuf
 #endif
 // NPAR = 2: two symbols of the stream side by side in one 256-lane workgroup (each half its own tile; the stage-B twiddle table, the
 // dispatch and the wave launch shared) -- half as many workgroups per launch at the same waves per SIMD
-template <int SPW, int NPAR>
-__global__ __launch_bounds__(128 * NPAR) MIXFFT_OCCUPANCY void k_mixfft(DevTables tb, DevBuffers db, const int *ids, int local_prepare)
+// the workgroup's LDS as one struct (round 6: shared with the dataflow kernel, k_flow.hip)
+template <int NPAR> struct MixLds {
+    alignas(16) cf lds_all[NPAR * 8 * PITCH_A];
+    cf twB[256];
+    SymParams sh_sp;
+};
+
+// FLOW: `flow_sp` holds the block's parameters (handed over by the previous block step of the same launch, or read from the stream state by the caller for the
+// launch's first step) -- the stream state itself is not read for them
+template <int SPW, int NPAR, bool FLOW = false>
+__device__ __forceinline__ void mixfft_wg(uint8_t *lds_base, const DevTables &tb, const DevBuffers &db, const int s, const int wg, int local_prepare, const SymParams *flow_sp = nullptr)
 {
-    wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
+    MixLds<NPAR> &L = *reinterpret_cast<MixLds<NPAR> *>(lds_base);
 #ifdef NRSC5HIP_MIXFFT_PHASES
     const long long mix_entry = (long long)clock64();
 #endif
-    const int s = wave_uniform(stream_of(ids, blockIdx.y));
     const StreamState &st = db.state[s];
     // first burst: everything that needs no stream state, then the state itself -- all in flight before the first wait
     SymPrologue<128 * NPAR> pro;
     pro.load(tb, threadIdx.x & 127);
     const uint8_t *raw = st.raw;                               // (read here, not behind the test of `active`: one trip to memory, not two)
     SymParams sp;
-    if (local_prepare) {                                       // block-uniform (fast streaming seam: no k_prepare launch in front of this kernel)
-        __shared__ SymParams sh_sp;
+    if (FLOW) {
+        sp = *flow_sp;
+    } else if (local_prepare) {                                // block-uniform (fast streaming seam: no k_prepare launch in front of this kernel)
+        SymParams &sh_sp = L.sh_sp;
         if (threadIdx.x == 0) {
             const Prepared p = prepare_values(st, false);
             sh_sp.active = p.active; sh_sp.a00 = (st.rd - st.base) + p.samperr; sh_sp.dtheta = p.dtheta; sh_sp.theta = p.theta; sh_sp.growth = p.growth; sh_sp.nco_mode = 0;   // (the fused seam runs FINE blocks only: closed form)
@@ -596,19 +610,32 @@ __global__ __launch_bounds__(128 * NPAR) MIXFFT_OCCUPANCY void k_mixfft(DevTable
 #ifdef NRSC5HIP_MIXFFT_PHASES
     if (db.sync_phase_cycles && s == 0 && threadIdx.x == 0) atomicAdd((unsigned long long *)&db.sync_phase_cycles[8], (unsigned long long)((long long)clock64() - mix_entry));
 #endif
-    __shared__ cf lds_all[NPAR * 8 * PITCH_A];
+    cf *lds_all = L.lds_all;
     cf *lds = lds_all + (threadIdx.x >> 7) * (8 * PITCH_A);
     static_assert(sizeof(cf) == sizeof(float2), "a complex value is two floats either way");
     static_assert(8 * PITCH_A >= 17 * 128 && 17 * 127 < SYM_N, "17 decimated samples per work-item fit in the FFT tile");
     static_assert(NSYM % (SPW * NPAR) == 0, "whole workgroups per block");
-    __shared__ cf twB[256];
-    if (sp.nco_mode) {                                         // block-uniform, rare (a freshly reset stream's first blocks): its own instantiation
-        if (raw) mixfft_symbols<true, SPW, NPAR, true>(tb, db, raw, sp, s, lds, twB, pro);
-        else mixfft_symbols<false, SPW, NPAR, true>(tb, db, raw, sp, s, lds, twB, pro);
+    cf *twB = L.twB;
+    if (FLOW) {                                                // dataflow grid: zero-copy FINE streams on the closed-form oscillator only (the caller checks)
+        mixfft_symbols<true, SPW, NPAR, false, true>(tb, db, raw, sp, s, lds, twB, pro, wg);
         return;
     }
-    if (raw) mixfft_symbols<true, SPW, NPAR>(tb, db, raw, sp, s, lds, twB, pro);
-    else mixfft_symbols<false, SPW, NPAR>(tb, db, raw, sp, s, lds, twB, pro);
+    if (sp.nco_mode) {                                         // block-uniform, rare (a freshly reset stream's first blocks): its own instantiation
+        if (raw) mixfft_symbols<true, SPW, NPAR, true>(tb, db, raw, sp, s, lds, twB, pro, wg);
+        else mixfft_symbols<false, SPW, NPAR, true>(tb, db, raw, sp, s, lds, twB, pro, wg);
+        return;
+    }
+    if (raw) mixfft_symbols<true, SPW, NPAR>(tb, db, raw, sp, s, lds, twB, pro, wg);
+    else mixfft_symbols<false, SPW, NPAR>(tb, db, raw, sp, s, lds, twB, pro, wg);
+}
+
+template <int SPW, int NPAR>
+__global__ __launch_bounds__(128 * NPAR) MIXFFT_OCCUPANCY void k_mixfft(DevTables tb, DevBuffers db, const int *ids, int local_prepare)
+{
+    wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
+    const int s = wave_uniform(stream_of(ids, blockIdx.y));
+    __shared__ __attribute__((aligned(16))) uint8_t lds[sizeof(MixLds<NPAR>)];
+    mixfft_wg<SPW, NPAR>(lds, tb, db, s, (int)blockIdx.x, local_prepare);
 }
 
 // =====================================================================================================================

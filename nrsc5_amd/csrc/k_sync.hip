@@ -297,11 +297,35 @@ __device__ __forceinline__ void store_px(int8_t *pair, float2 v, int side, int p
 #else
 #define SYNC_OCCUPANCY(NT)
 #endif
+// The workgroup's LDS as one struct (round 6): the kernel k_sync places it in a static array of its own; the dataflow kernel (k_flow.hip), whose workgroups are
+// symbol transforms OR block steps, places it in the region both roles share.
+enum { PRE_STATE, PRE_BC, PRE_PXS, PRE_STARTED_PM, PRE_P1_COUNT, PRE_FINE_EPOCH, PRE_PM_SLOT, PRE_MER_CNT, PRE_ERR_LB, PRE_ERR_UB, PRE_N };
+constexpr int SYNC_OFF_REFPH = NREF_MAX * NSYM * (int)sizeof(float2), SYNC_OFF_REFCS = SYNC_OFF_REFPH + NREF_MAX * NSYM * (int)sizeof(float);
+constexpr int SYNC_OFF_CFO = SYNC_OFF_REFCS + NREF_MAX * NSYM * (int)sizeof(float2), SYNC_REF_BYTES = SYNC_OFF_CFO + (CFO_HI - CFO_LO) * 22;
+template <int SYNC_NT> struct SyncLds {
+    alignas(16) uint8_t lds_raw[SYNC_REF_BYTES > PM_BLOCK ? SYNC_REF_BYTES : PM_BLOCK];
+    alignas(16) int8_t sh_pids_coded[3 * PIDS_LEN];
+    double red[2][SYNC_NT / 64];
+    long long sh_tstamp;
+    float smag[NREF_MAX];
+    int ref_ok[NREF_MAX], ref_bc[NREF_MAX], ref_psmi[NREF_MAX];
+    int sh_i[8];
+    float sh_f[8];
+    float sh_diff[2 * 14];
+    uint32_t sh_pids_out[4];
+    int sh_seen[16 + 80];                                     // (the CFO search: [0..3] vote masks, [8..8 + 76) the candidates' best offsets)
+    float ref_freq[NREF_MAX];
+    int sh_pre[PRE_N];
+    uint16_t sh_gather[PIDS_CODED];
+};
+
+// FLOW (k_flow.hip): the block step of stream s as one work item of the dataflow grid -- what the launch boundary in front of k_sync guarantees (the
+// symbol transforms' bins are visible) and what the one behind it guarantees (this step's state is visible to the next step's work items) are the caller's
+// business there; the body is the same.
 template <int SYNC_NT>
-__global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare, int window, int pids_inline, int do_prepare, int ext_refs)
+__device__ __forceinline__ void sync_body(uint8_t *lds_base, const DevTables &tb, const DevBuffers &db, const int s, int parity, int slot, int fuse_prepare, int window, int pids_inline, int do_prepare, int ext_refs)
 {
-    wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
-    const int s = wave_uniform(stream_of(ids, blockIdx.x));    // in a scalar register: every address derived from it stays off the VGPR budget
+    SyncLds<SYNC_NT> &L = *reinterpret_cast<SyncLds<SYNC_NT> *>(lds_base);
     StreamState &st = db.state[s];
     if (do_prepare) {                                          // block-uniform (fast streaming seam): this block's bookkeeping is committed here -- the
         if (threadIdx.x == 0) prepare_block(db, st, s, false); // symbol kernel computed the same values for itself (prepare_values)
@@ -321,7 +345,6 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
     // COARSE section): it publishes the new values in LDS (sh_i[4..6]) and the copies below are replaced there.
     // One word per work-item (work-items 0 .. PRE_N - 1), parked in LDS at the first barrier: held in registers across the kernel the ten values and the
     // gather index cost 11 spilled VGPRs and 204 spilled SGPRs of the 80-register budget (the 12-wave workgroup must fit beside the decode waves).
-    enum { PRE_STATE, PRE_BC, PRE_PXS, PRE_STARTED_PM, PRE_P1_COUNT, PRE_FINE_EPOCH, PRE_PM_SLOT, PRE_MER_CNT, PRE_ERR_LB, PRE_ERR_UB, PRE_N };
     int e_word = 0;
     {
         const int *w = &st.sync_state;
@@ -359,33 +382,24 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
     constexpr int SYNC_NW = SYNC_NT / 64;
     // phase instrumentation (nrsc5hip_debug_sync_phases): the running time stamp lives in LDS -- as a variable it was a register pair
     // alive across the whole kernel, spilled and reloaded around every barrier
-    __shared__ long long sh_tstamp;
+    long long &sh_tstamp = L.sh_tstamp;
     if (db.sync_phase_cycles && s == 0 && tid == 0) sh_tstamp = (long long)clock64();
 #define SYNC_MARK(i) do { if (db.sync_phase_cycles && s == 0 && tid == 0) { const long long now = (long long)clock64(); db.sync_phase_cycles[i] += now - sh_tstamp; sh_tstamp = now; } } while (0)
 
     // One LDS region, two lives: the reference-carrier scratch of the tracking and equalising phases, then -- once the last
     // equalised cell sits in a register (barrier after the MER sums) -- the block's soft-bit rows on their way to the matrix.
-    constexpr int OFF_REFPH = NREF_MAX * NSYM * (int)sizeof(float2), OFF_REFCS = OFF_REFPH + NREF_MAX * NSYM * (int)sizeof(float);
-    constexpr int OFF_CFO = OFF_REFCS + NREF_MAX * NSYM * (int)sizeof(float2), REF_BYTES = OFF_CFO + (CFO_HI - CFO_LO) * 22;
-    __shared__ __attribute__((aligned(16))) uint8_t lds_raw[REF_BYTES > PM_BLOCK ? REF_BYTES : PM_BLOCK];
+    constexpr int OFF_REFPH = SYNC_OFF_REFPH, OFF_REFCS = SYNC_OFF_REFCS, OFF_CFO = SYNC_OFF_CFO;
+    uint8_t *lds_raw = L.lds_raw;
     float2 (*refz)[NSYM] = (float2 (*)[NSYM])lds_raw;                            // derotated reference carriers
     float (*refph)[NSYM] = (float (*)[NSYM])(lds_raw + OFF_REFPH);               // loop phase per symbol (phases[][] of the reference)
     float2 (*refcs)[NSYM] = (float2 (*)[NSYM])(lds_raw + OFF_REFCS);             // e^{+i refph}
     int8_t (*cfo_offs)[22] = (int8_t (*)[22])(lds_raw + OFF_CFO);
     int8_t *pm_tile = (int8_t *)lds_raw;                                         // MP1: this block's soft-bit rows (second life)
     static_assert(PM_BLOCK % 16 == 0 && PM_FRAME % 16 == 0, "soft-bit rows leave in 16-byte pieces");
-    __shared__ float smag[NREF_MAX];
-    __shared__ int ref_ok[NREF_MAX], ref_bc[NREF_MAX], ref_psmi[NREF_MAX];
-    __shared__ int sh_i[8];
-    __shared__ float sh_f[8];
-    __shared__ double red[2][SYNC_NW];
-    __shared__ float sh_diff[2 * 14];
-    __shared__ __attribute__((aligned(16))) int8_t sh_pids_coded[3 * PIDS_LEN];
-    __shared__ uint32_t sh_pids_out[4];
-    __shared__ int sh_seen[16 + 80];                          // (the CFO search: [0..3] vote masks, [8..8 + 76) the candidates' best offsets)
-    __shared__ float ref_freq[NREF_MAX];
-    __shared__ int sh_pre[PRE_N];
-    __shared__ uint16_t sh_gather[PIDS_CODED];
+    auto &smag = L.smag; auto &ref_ok = L.ref_ok; auto &ref_bc = L.ref_bc; auto &ref_psmi = L.ref_psmi; auto &sh_i = L.sh_i; auto &sh_f = L.sh_f; auto &red = L.red;
+    auto &sh_diff = L.sh_diff; auto &sh_pids_coded = L.sh_pids_coded; auto &sh_pids_out = L.sh_pids_out; auto &sh_seen = L.sh_seen; auto &ref_freq = L.ref_freq;
+    auto &sh_pre = L.sh_pre; auto &sh_gather = L.sh_gather;
+    static_assert(SYNC_NW == SYNC_NT / 64, "one partial sum per wave");
     static_assert(PM_BLOCK <= 65536, "a gather index fits 16 bits");
     if (tid == 0) { sh_i[2] = 0; sh_i[3] = 0; }                // [2] set when this block completes a P1 frame (replay checkpoint below), [3] when a PIDS frame was decoded here
 
@@ -905,6 +919,15 @@ __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTab
     }
     if (tid == 0 && fuse_prepare) prepare_block(db, st, s, false);   // top of the NEXT block's acquire_process (FINE streams only)
     SYNC_MARK(7);
+}
+
+template <int SYNC_NT>
+__global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare, int window, int pids_inline, int do_prepare, int ext_refs)
+{
+    wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
+    const int s = wave_uniform(stream_of(ids, blockIdx.x));    // in a scalar register: every address derived from it stays off the VGPR budget
+    __shared__ __attribute__((aligned(16))) uint8_t lds[sizeof(SyncLds<SYNC_NT>)];
+    sync_body<SYNC_NT>(lds, tb, db, s, parity, slot, fuse_prepare, window, pids_inline, do_prepare, ext_refs);
 }
 
 void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, int window, hipStream_t st, int lanes, int pids_inline, int do_prepare, int ext_refs)
