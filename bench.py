@@ -924,7 +924,7 @@ class Mixed:
         return self.my_streams[k] % 4 == (2 if k >= self.nfm else 1)
 
 
-TUNE_KNOBS = {"decode_streams": 0, "am_decode_streams": 1, "fwd_segments": 4, "am_segments": 6, "decode_cus": 7, "decode_priority": 8, "mixfft_syms": 10, "traceback_walk": 12, "sync_lanes": 13, "nco_exact": 17}
+TUNE_KNOBS = {"decode_streams": 0, "am_decode_streams": 1, "fwd_segments": 4, "am_segments": 6, "decode_cus": 7, "decode_priority": 8, "mixfft_syms": 10, "traceback_walk": 12, "sync_lanes": 13, "nco_exact": 17, "flow_min": 18, "loop_exact": 19}
 
 
 def apply_tune(E, args):

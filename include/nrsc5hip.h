@@ -412,6 +412,9 @@ enum {
                                              closed-form phasor: 0 (default) = none, 1 = the first block after a reset (the block the CFO search runs on), 2 = every block until the
                                              stream is FINE, 3 = every block (diagnostic).  The float oscillator state is the reference's bit for bit for as long as every
                                              block since the reset ran in this mode; the first closed-form block ends that until the next reset */
+    , NRSC5HIP_TUNE_FLOW_MIN               /* dataflow bursts (k_flow): a zero-copy batch with the window pipeline runs the block steps of a burst in which every stream is
+                                             FINE (MP1 routing, no acquisition kernels needed) as ONE launch whose workgroups -- pairs of symbol transforms and per-stream block
+                                             steps -- hand over to each other, for stream sets of at least this many streams; 0 = never (two launches per step) */
     , NRSC5HIP_TUNE_LOOP_EXACT             /* FM Costas loops / CFO search (sync.c:90-136, 292-337) by the reference's own operations -- glibc's sincosf and atan2f restated
                                              bit for bit (fastmath.h), its float complex products, adjust_ref / reset_ref in place -- instead of the fast forms (v_sin / v_cos,
                                              a 4-term arc tangent, ~5e-7): 0 = never, 1 (default) = in every block that starts un-synchronised (the tracking pass over garbage and the
@@ -429,6 +432,8 @@ void nrsc5hip_debug_seam_counts(double out[6], int reset);   /* ... [4] block st
 int nrsc5hip_debug_poison_results(nrsc5hip_engine *e);
 /* segmented forward pass: segment boundaries checked / segments that had to be re-run since the engine was created */
 int nrsc5hip_debug_fwd_stats(nrsc5hip_engine *e, int stats[2]);
+/* dataflow bursts (NRSC5HIP_TUNE_FLOW_MIN): [0] bursts, [1] block steps issued as k_flow launches since the engine was created */
+int nrsc5hip_debug_flow_stats(nrsc5hip_engine *e, long long stats[2]);
 /* K=9 decode in segment waves: [0] forward boundaries checked, [1] segments re-run, [2] traceback boundaries checked, [3] segments re-walked */
 /* single-path traceback: [0] chunk boundaries checked, [1] chunks re-walked since the engine was created */
 int nrsc5hip_debug_tb_stats(nrsc5hip_engine *e, int stats[2]);
@@ -458,6 +463,7 @@ enum {
     NRSC5HIP_PROF_DECIMATE = 0, NRSC5HIP_PROF_ACQUIRE, NRSC5HIP_PROF_PREPARE, NRSC5HIP_PROF_MIXFFT,
     NRSC5HIP_PROF_SYNC, NRSC5HIP_PROF_P1_DEINT, NRSC5HIP_PROF_P1_VITERBI, NRSC5HIP_PROF_PIDS, NRSC5HIP_PROF_AM /* block steps */, NRSC5HIP_PROF_AM_DECODE /* window pipeline: the deferred decodes */,
     NRSC5HIP_PROF_P1_TRACEBACK /* P1_DEINT / P1_VITERBI (the forward trellis pass) / P1_TRACEBACK: the three stages of a P1 decode */,
+    NRSC5HIP_PROF_FLOW /* dataflow bursts: up to 16 block steps of a stream set (symbol transforms + block steps) as one launch of k_flow */,
     NRSC5HIP_PROF_CLASSES
 };
 int nrsc5hip_profile(nrsc5hip_engine *e, int enable, double *total_ms, long long *launches);

@@ -109,6 +109,11 @@ struct nrsc5hip_engine {
     int fuse_seam_prepare;             // 1 (default): fast seam, FINE stream: no k_prepare launch (NRSC5HIP_TUNE_SEAM_PREPARE = 0: separate launch)
     int tb_walk;                       // > 0: single-path traceback (k_p1_tbwalk + check): 1 = a workgroup per (frame, part), N > 1 = a persistent grid of N workgroups (default 512); 0: the block-parallel one of round 3
     int fwd_segments;                  // waves per frame of the P1 forward pass; 0 = pick from the size of the stream set (fwd_segments_for)
+    int flow_min;                      // dataflow bursts (k_flow, k_sync.hip): stream sets of at least this many streams (0 = never) run the steps of a burst in which every
+                                       // stream is FINE as ONE launch
+    unsigned *flow_dev; size_t flow_cap;   // its hand-off words (zeroed before every launch) and how many there are
+    unsigned *flow_err;                    // two words of pinned host memory the kernel writes when a poll gives up
+    long long flow_bursts, flow_steps;     // bursts / block steps issued that way since the engine was created
     hipStream_t main;                  // = lane.main
     std::vector<void *> allocs;
     // host mirrors
@@ -453,7 +458,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             // profiles/r05_trace_sync_decode_streams.txt): 30.1 -> 29.2 ms per pass.  AM: three, with four segment waves per P3 frame (round 5, on the
             // rewritten block step: 70.4 ms with two streams x eight segments, 67.5 with three x eight, 65.7 with three x four, 91.3 with one: the K=9 decodes are ~80 ms of kernel time per pass)
             e->naux = 1; e->naux_am = 3;
-            e->verdict_lag = 0; e->fwd_segments = 0; e->fwd_warm = 2; e->mixfft_syms = 1; e->sync_lanes = 0; e->tb_walk = 1; e->fuse_seam_prepare = 1;      // measured: profiles/r04_mixfft_persistent.txt
+            e->verdict_lag = 0; e->fwd_segments = 0; e->fwd_warm = 2; e->mixfft_syms = 1; e->sync_lanes = 0; e->flow_min = 0; e->tb_walk = 1; e->fuse_seam_prepare = 1;      // measured: profiles/r04_mixfft_persistent.txt
             e->am_segments = 4; e->am_warm = K9_WARM; e->am_runin = K9_TB_RUNIN;
         }
         {
@@ -499,6 +504,10 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if ((rc = dev_alloc(e, &db.nco_tab, S * NSYM * SYM_N))) break;
         if ((rc = dev_alloc(e, &db.cfo_snap, S * LIVE_N * (PM_PART + 1)))) break;
         if ((rc = dev_alloc(e, &db.cfo_phase, S * NSYM * LIVE_N))) break;     // 68 KB per stream: phases[][] of the exact CFO search's visit in progress
+        e->flow_cap = flow_words((int)S); e->flow_bursts = e->flow_steps = 0;
+        if ((rc = dev_alloc(e, &e->flow_dev, e->flow_cap))) break;
+        if (hipHostMalloc((void **)&e->flow_err, 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) { rc = NRSC5HIP_ENOMEM; break; }
+        e->flow_err[0] = e->flow_err[1] = 0;
         db.loop_exact = 1;                                     // the reference's own loop arithmetic in blocks that start un-synchronised (k_sync.hip; NRSC5HIP_TUNE_LOOP_EXACT)
         // Default: the closed-form phasor with the reference oscillator's amplitude ramp (NCO_CLOSED_FORM).  Measured (DESIGN.md (c) limit 2): on the CPU twin,
         // whose libm is the reference's, the exact first block takes the locks after a CFO search that deviate in loop-internal state from 5 to 2 in 900 (18
@@ -651,6 +660,7 @@ extern "C" void nrsc5hip_engine_destroy(nrsc5hip_engine *e)
     for (void *p : e->allocs) (void)hipFree(p);
     for (hipEvent_t ev : e->dec_events) (void)hipEventDestroy(ev);
     if (e->dec_stream) (void)hipStreamDestroy(e->dec_stream);
+    if (e->flow_err) (void)hipHostFree(e->flow_err);
     if (e->rec_host) (void)hipHostFree(e->rec_host);
     if (e->frames_host) (void)hipHostFree(e->frames_host);
     if (e->nblocks_host) (void)hipHostFree(e->nblocks_host);
@@ -783,6 +793,28 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
     return 0;
 }
 
+// K block steps of a set whose streams are all FINE as ONE launch (k_flow, k_sync.hip): what issue_step does for each of them -- the wait for the decoder that used
+// this window's buffers, the symbol and sync kernels with the next block's bookkeeping fused, the window decode behind step 15 -- with the K x 2 launches replaced
+// by one grid whose workgroups hand over to each other.  The caller has checked the conditions (run_steps).
+static int issue_flow_burst(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const int *ids_dev, int K)
+{
+    const long long window = ln.step_count / 16;
+    const int parity = (int)(window % NWIN), slot0 = (int)(ln.step_count % 16);
+    if (slot0 + K > 16) FAIL(NRSC5HIP_EINVAL, "a dataflow burst does not cross a window boundary");
+    if (slot0 == 0 && ln.decoded_pending[parity]) {
+        HIPCHK(hipStreamWaitEvent(ln.main, ln.ev_decoded[parity], 0));
+        ln.decoded_pending[parity] = false;
+    }
+    HIPCHK(hipMemsetAsync(e->flow_dev, 0, flow_words(n) * sizeof(unsigned), ln.main));
+    { ProfScope p(e, NRSC5HIP_PROF_FLOW, ln.main); launch_flow(e->tb, ln.db, n, ids_dev, K, e->flow_dev, e->flow_err, parity, slot0, (int)window, ln.main); }
+    // a poll that gave up (flow words [8], [9]): the host reads them with the burst's counters (run_steps)
+    ln.step_count += K;
+    e->flow_bursts++; e->flow_steps += K;
+    if ((ln.step_count % 16) == 0) { int rc = launch_window_decode(e, ln, n, ids_dev, parity, pick_decode_lane(e, ln, window)); if (rc) return rc; }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 // finish a partially filled decode window (async mode) so that every produced frame gets decoded, and wait for all decodes
 static int flush_p1(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const int *ids_dev)
 {
@@ -820,6 +852,11 @@ static int run_steps(nrsc5hip_engine *e, int n, const int *ids_dev, unsigned lon
                 every = ln.acq_needed ? std::min(4, to_boundary) : to_boundary;   // 2 measured: the same
             }
             int burst = 0;
+            // dataflow burst (k_flow): every stream of the set was FINE at the last look, MP1 routing only, zero-copy input, closed-form oscillator, the previous
+            // step's k_sync prepared this one -- the whole burst (it ends on the window boundary) is one launch
+            const bool flow = e->flow_min > 0 && n >= e->flow_min && check_every == 16 && e->cfg.p1_async && e->cfg.batch_zero_copy && !ln.acq_needed && !ln.px_needed
+                              && ln.prepared_by_sync && !e->dec_chunk && ln.db.nco_policy != NCO_EXACT_ALWAYS && !ln.db.sync_phase_cycles && done + every <= max_steps && every >= 2;
+            if (flow) { int rc = issue_flow_burst(e, ln, n, ids_dev, every); if (rc) return rc; burst = every; }
             for (; burst < every && done + burst < max_steps; burst++) { int rc = issue_step(e, ln, n, ids_dev); if (rc) return rc; }
             if (replay && (ln.step_count % 16) == 0) {
                 // Window boundary: take the first-header verdicts of the deferred decodes that have finished.  The decode whose
@@ -832,6 +869,8 @@ static int run_steps(nrsc5hip_engine *e, int n, const int *ids_dev, unsigned lon
             }
             HIPCHK(hipMemcpyAsync(ln.counters_host, ln.counters_dev, 4 * sizeof(int), hipMemcpyDeviceToHost, ln.main));
             HIPCHK(hipStreamSynchronize(ln.main));
+            if (flow && (e->flow_err[0] || e->flow_err[1]))
+                FAIL(NRSC5HIP_EHIP, "dataflow burst: a hand-off was never seen (symbol item of stream position %d, block step of %d): the burst's results are void", (int)e->flow_err[0] - 1, (int)e->flow_err[1] - 1);
             ln.acq_needed = ln.counters_host[1] > 0;
             ln.thin = ln.counters_host[0] * 4 < burst * n;
             ln.px_needed = ln.counters_host[2] > 0;
@@ -2280,6 +2319,7 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
     case NRSC5HIP_TUNE_SYNC_LANES:        e->sync_lanes = (value == 256 || value == 768) ? value : 0; break;
     case NRSC5HIP_TUNE_SEAM_PREPARE:      e->fuse_seam_prepare = value != 0; break;
     case NRSC5HIP_TUNE_NCO_EXACT:         e->db.nco_policy = e->lane.db.nco_policy = e->db.nco_tab ? std::min(std::max(value, 0), (int)NCO_EXACT_ALWAYS) : (int)NCO_CLOSED_FORM; break;
+    case NRSC5HIP_TUNE_FLOW_MIN:          e->flow_min = std::max(value, 0); break;
     case NRSC5HIP_TUNE_LOOP_EXACT:        e->db.loop_exact = e->lane.db.loop_exact = std::min(std::max(value, 0), 2); break;
     case NRSC5HIP_TUNE_EARLY_FLUSH_KB:    e->early_flush = (size_t)std::max(value, 0) << 10; break;
     case NRSC5HIP_TUNE_DEFER_WAIT:        e->defer_wait = value != 0; break;
@@ -2296,6 +2336,13 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
         break;
     default: FAIL(NRSC5HIP_EINVAL, "unknown knob %d", knob);
     }
+    return 0;
+}
+
+extern "C" int nrsc5hip_debug_flow_stats(nrsc5hip_engine *e, long long stats[2])
+{
+    if (!e || !stats) return NRSC5HIP_EINVAL;
+    stats[0] = e->flow_bursts; stats[1] = e->flow_steps;
     return 0;
 }
 

@@ -14,10 +14,10 @@
 #include "prepare_block.h"
 #include "l2_header.h"
 #include "fastmath.h"
+#include "flow_ops.h"
+#include "mixfft_body.h"                                       // (defines stream_of; the symbol transform for k_flow at the end of this file)
 
 namespace nrsc5 {
-
-__device__ inline int stream_of(const int *ids, int idx) { return ids ? ids[idx] : idx; }
 
 constexpr int NREF_MAX = 30;          // 15 per sideband (14 partitions + 1)
 constexpr int CFO_LO = -2 * PW, CFO_HI = 2 * PW;   // candidates -38..37 (sync.c:294)
@@ -1094,6 +1094,152 @@ void launch_px_decode(const DevTables &tb, const DevBuffers &db, int nstreams, c
 {
     hipLaunchKernelGGL(k_px_decode, dim3(16, nstreams), dim3(64), 0, st, tb, db, stream_ids, parity, lane_id);
     if (db.l2_px_ring) launch_l2_index_px_window(db, nstreams, stream_ids, parity, st);
+}
+
+
+// =====================================================================================================================================================
+// k_flow (round 6): K consecutive block steps of a set of FINE zero-copy streams as ONE launch whose workgroups are work items of two kinds -- a PAIR of
+// symbol transforms of one stream (the body of k_mixfft<1, 2>) or one stream's block step (the body of k_sync<256>) -- ordered so that every item depends only
+// on items in front of it:
+//     step e, stream t:   16 symbol pairs (e, t)  ->  block step (e, t)  ->  symbol pairs (e + 1, t)  -> ...
+// As two launches per step (k_mixfft, then k_sync) the chain costs the SUM of the two kernels' latencies, 46 + 38 us, although the first is a throughput kernel
+// and the second a latency chain that issues on ~12 % of its cycles: a launch boundary makes stream 0's block step wait for stream 255's last symbol, and the
+// next step's symbols of stream 0 for stream 255's block step.  Two queues do not interleave at workgroup granularity (profiles/r05_two_engines.txt); one grid
+// does: the block step of stream t is dispatched FLOW_LAG streams behind its symbols and runs beside the symbols of the streams that follow; the next step's
+// symbols of stream t come a whole round later, when its block step has long finished.
+//   * Work lists, one per XCD (streams idx % 8 == x: the hand-offs of a stream stay inside one L2 where the dispatcher's observed placement -- workgroup b on XCD
+//     b % 8 -- holds; nothing depends on it).  A workgroup reads the XCD it runs on and draws a ticket from that list; if the list is exhausted, from the next one:
+//     every item is drawn exactly once, and an item's dependencies have SMALLER tickets of the same list -- they were drawn by workgroups that are running or
+//     done -- so no wait can be circular, whatever the dispatch order.
+//   * Hand-offs (flow_ops.h; cdna_hip_programming.md Guideline 16): bins leave write-through and are counted per stream (flow.sym); the block step polls the
+//     counter, takes ONE agent-scope acquire and reads with plain loads.  At its end the block step releases (its state is read by the stream's next block step,
+//     possibly on another CU) and publishes the next block's symbol parameters as 8-byte {step tag, value} granules: the data is the flag.
+//   * Every poll is bounded; a poll that gives up files an error word the host turns into NRSC5HIP_EDEVICE, the item completes without its work (the counters
+//     still move: the grid drains instead of hanging).
+// What stays with the two-kernel form: steps that run the acquisition kernels (a stream that is not FINE), the extended service modes' PX kernels, FIFO input,
+// the exact oscillator, small stream sets (the per-stream chain is no shorter here; what is gained is the overlap between streams).
+constexpr int FLOW_LAG = 8;                // a stream's block step is dispatched this many streams (x 16 symbol items) behind its symbols
+constexpr int FLOW_GRANULES = 9;           // a00 (2), dtheta (2), theta (2), growth (2), active
+constexpr unsigned FLOW_SPIN_LIMIT = 1u << 21;   // polls of ~0.25 us: ~0.5 s
+
+struct FlowItem { int e, t, pair; };       // pair < 0: the block step of stream t in step e
+// ticket q of a list of nx streams -> item (see the order above)
+__device__ __forceinline__ FlowItem flow_item(int q, int nx)
+{
+    const int per = 17 * nx, e = q / per, r = q - e * per;
+    const int L = nx < FLOW_LAG ? nx : FLOW_LAG;
+    FlowItem it; it.e = e;
+    if (r < 16 * L) { it.t = r >> 4; it.pair = r & 15; return it; }
+    const int rb = r - 16 * L, nb = 17 * (nx - L);
+    if (rb < nb) { const int k = rb / 17, j = rb - 17 * k; if (j < 16) { it.t = L + k; it.pair = j; } else { it.t = k; it.pair = -1; } return it; }
+    it.t = nx - L + (rb - nb); it.pair = -1;
+    return it;
+}
+
+union FlowLds { MixLds<2> mix; SyncLds<256> sync; };
+
+// flow words (zeroed by the host before every launch): head[8] | err[8] | sym[n] | granules[n][FLOW_GRANULES] (8-byte aligned)
+__global__ __launch_bounds__(256) void k_flow(DevTables tb, DevBuffers db, const int *ids, int n, int K, unsigned *flow, unsigned *err_host, int parity, int slot0, int window)
+{
+    wave_set_priority_high();
+    __shared__ __attribute__((aligned(16))) uint8_t lds[sizeof(FlowLds)];
+    __shared__ int sh_role[4];
+    const int tid = threadIdx.x;
+    unsigned *head = flow, *err = flow + 8, *symc = flow + 16;
+    unsigned long long *gran = (unsigned long long *)(flow + 16 + ((n + 1) & ~1));
+    if (tid == 0) {
+        int x = flow_xcc_id(), q = -1, nx = 0;
+        for (int k = 0; k < 8; k++, x = (x + 1) & 7) {
+            nx = x < n ? (n - x + 7) >> 3 : 0;
+            if (!nx) continue;
+            q = (int)flow_add_u32(&head[x], 1u);
+            if (q < K * 17 * nx) break;
+            q = -1;
+        }
+        sh_role[0] = q; sh_role[1] = x; sh_role[2] = nx;
+    }
+    __syncthreads();
+    const int q = sh_role[0];
+    if (q < 0) return;                                         // more workgroups on this XCD than items anywhere: nothing left
+    const FlowItem it = flow_item(q, sh_role[2]);
+    const int idx = sh_role[1] + 8 * it.t;                     // position in the stream set
+    const int s = wave_uniform(stream_of(ids, idx));
+    if (it.pair >= 0) {
+        // ---- two symbol transforms.  Their parameters: step 0 from the stream state (the launch boundary published it), later steps from the granules
+        SymParams &sp = reinterpret_cast<FlowLds *>(lds)->mix.sh_sp;
+        if (it.e == 0) {
+            if (tid == 0) {
+                const StreamState &st = db.state[s];
+                sp.active = st.active; sp.a00 = (st.rd - st.base) + st.samperr_cur; sp.dtheta = st.dtheta; sp.theta = st.theta; sp.growth = st.growth; sp.nco_mode = 0;
+            }
+        } else if (tid < 64) {
+            const unsigned long long *g = gran + (size_t)idx * FLOW_GRANULES + (tid < FLOW_GRANULES ? tid : 0);
+            unsigned long long v = 0; bool ok = false, dead = false;
+            for (unsigned spins = 0; ; spins++) {
+                v = flow_load_u64(g);
+                ok = (unsigned)(v >> 32) == (unsigned)it.e;
+                if (__all(ok)) break;
+                if (spins > FLOW_SPIN_LIMIT) { dead = true; break; }
+                flow_sleep();
+            }
+            const unsigned lo = (unsigned)v;
+            // lanes 0..8 hold one granule each: a00 = [0] | [1] << 32, dtheta = [2,3], theta = [4,5], growth = [6,7], active = [8]
+            unsigned w[FLOW_GRANULES];                         // (every lane of the wave takes part in the reads: the CPU twin's readlane is a collective)
+#pragma unroll
+            for (int l = 0; l < FLOW_GRANULES; l++) w[l] = (unsigned)wave_readlane((int)lo, l);
+            if (tid == 0) {
+                const unsigned long long a = w[0] | (unsigned long long)w[1] << 32, d = w[2] | (unsigned long long)w[3] << 32, th = w[4] | (unsigned long long)w[5] << 32, gr = w[6] | (unsigned long long)w[7] << 32;
+                sp.a00 = (long long)a; __builtin_memcpy(&sp.dtheta, &d, 8); __builtin_memcpy(&sp.theta, &th, 8); __builtin_memcpy(&sp.growth, &gr, 8);
+                sp.active = dead ? 0 : (int)w[8]; sp.nco_mode = 0;
+                if (dead) { flow_store_u32(&err[0], 1u + (unsigned)idx); err_host[0] = 1u + (unsigned)idx; }
+            }
+        }
+        __syncthreads();
+        mixfft_wg<1, 2, true>(lds, tb, db, s, it.pair, 0, &sp);
+        flow_drain_stores();                                   // every wave: its write-through stores have left
+        __syncthreads();
+        if (tid == 0) flow_add_u32(&symc[idx], 1u);
+        return;
+    }
+    // ---- the stream's block step: wait for its 32 symbols of this step, one acquire for the workgroup, then k_sync's body
+    if (tid == 0) {
+        const unsigned want = 16u * (unsigned)(it.e + 1);
+        bool dead = false;
+        for (unsigned spins = 0; flow_load_u32(&symc[idx]) < want; spins++) {
+            if (spins > FLOW_SPIN_LIMIT) { dead = true; break; }
+            flow_sleep();
+        }
+        if (dead) { flow_store_u32(&err[1], 1u + (unsigned)idx); err_host[1] = 1u + (unsigned)idx; }
+        flow_acquire();
+    }
+    __syncthreads();
+    sync_body<256>(lds, tb, db, s, parity, (slot0 + it.e) & 15, 1, window, 0, 0, 0);
+    if (it.e + 1 >= K) return;                                 // the launch's last step: the launch boundary publishes
+    flow_drain_stores();
+    __syncthreads();
+    if (tid == 0) {
+        flow_release();                                        // this step's state, for the stream's next block step (another workgroup, maybe another XCD)
+        const StreamState &st = db.state[s];
+        const long long a00 = (st.rd - st.base) + st.samperr_cur;
+        unsigned long long d, th, gr;
+        { const double v = st.dtheta; __builtin_memcpy(&d, &v, 8); } { const double v = st.theta; __builtin_memcpy(&th, &v, 8); } { const double v = st.growth; __builtin_memcpy(&gr, &v, 8); }
+        const unsigned w[FLOW_GRANULES] = { (unsigned)a00, (unsigned)((unsigned long long)a00 >> 32), (unsigned)d, (unsigned)(d >> 32), (unsigned)th, (unsigned)(th >> 32),
+                                            (unsigned)gr, (unsigned)(gr >> 32), (unsigned)st.active };
+        unsigned long long *g = gran + (size_t)idx * FLOW_GRANULES;
+        const unsigned long long tag = (unsigned long long)(unsigned)(it.e + 1) << 32;
+#pragma unroll
+        for (int k = 0; k < FLOW_GRANULES; k++) flow_store_u64(&g[k], tag | w[k]);
+    }
+}
+
+size_t flow_words(int n) { return 16 + (size_t)((n + 1) & ~1) + 2 * (size_t)n * FLOW_GRANULES; }
+
+// K block steps of the n listed streams (all FINE, zero-copy, MP1 routing, closed-form oscillator: the caller checks); `flow` = flow_words(n) zeroed dwords;
+// err_host: two words of device-visible host memory, written only when a poll gives up ([0]: a symbol item, [1]: a block step; 1 + position of the stream)
+void launch_flow(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int K, unsigned *flow, unsigned *err_host, int parity, int slot0, int window, hipStream_t st)
+{
+    const unsigned items = (unsigned)K * 17u * (unsigned)nstreams;
+    hipLaunchKernelGGL(k_flow, dim3(items), dim3(256), 0, st, tb, db, stream_ids, nstreams, K, flow, err_host, parity, slot0, window);
 }
 
 }  // namespace nrsc5

@@ -1388,3 +1388,48 @@ def check_exact_oscillator_first_block(lib, reflib, bit_exact_min, policies=(0, 
     if 0 in policies:
         assert exact[0] < n, "the closed-form phasor cannot reproduce the recurrence's rounding drift"
     return exact, worst
+
+
+def run_zero_copy_batch(lib, caps, tune=(), l2_feedback=True, p1_slots=8):
+    """the captures as ONE zero-copy batch with the window pipeline -> (records, counts, frames, flow stats)"""
+    n = len(caps)
+    stride = max(c.iq.size for c in caps); stride += (-stride) % 16
+    host = np.zeros((n, stride), dtype=np.uint8)
+    for k, c in enumerate(caps):
+        host[k, :c.iq.size] = c.iq
+    E = eng.Engine(max_streams=n, q15_capacity=2 * 71280, record_capacity=512, p1_slots=p1_slots, p1_async=True, l2_feedback=l2_feedback, batch_zero_copy=True, lib_path=lib)
+    for knob, value in tune:
+        E.tune(knob, value)
+    dev = _to_device(E, host)
+    E.batch_append_cu8(dev, stride, [c.iq.size - c.iq.size % 4 for c in caps])
+    E.batch_process(n)
+    recs, counts, frames = E.batch_fetch_view(n)
+    out = (np.array(recs, copy=True), np.array(counts, copy=True), [[np.array(f, copy=True) for f in fr] if isinstance(fr, (list, tuple)) else np.array(fr, copy=True) for fr in frames], E.flow_stats(),
+           [eng.records_to_log(E, k, recs[k, :counts[k]], frames[k]) for k in range(n)])
+    _free_device(E, dev)
+    E.close()
+    return out
+
+
+def check_flow_bursts(lib, caps, l2_feedback=True, min_flow_steps=8):
+    """Dataflow bursts (k_flow: the block steps of a burst in which every stream is FINE as ONE launch of symbol-pair and block-step work items that hand over to each
+    other) leave every record and every frame exactly as the two-kernel form with the same bodies does (k_mixfft<1, 2> + k_sync<256>: knobs MIXFFT_SYMS 16, SYNC_LANES 256),
+    bit for bit; and as the default form (k_sync<768>: another summation grouping of the MER) does under the strict rule."""
+    base = ((eng.TUNE_MIXFFT_SYMS, 16), (eng.TUNE_SYNC_LANES, 256))
+    r0, c0, f0, s0, l0 = run_zero_copy_batch(lib, caps, tune=base + ((eng.TUNE_FLOW_MIN, 0),), l2_feedback=l2_feedback)
+    r1, c1, f1, s1, l1 = run_zero_copy_batch(lib, caps, tune=base + ((eng.TUNE_FLOW_MIN, 1),), l2_feedback=l2_feedback)     # (the steps outside the bursts on the same bodies too)
+    assert s0 == (0, 0) and s1[1] >= min_flow_steps, (s0, s1)
+    assert np.array_equal(c0, c1), (c0, c1)
+    for k in range(len(caps)):
+        a, b = r0[k, :c0[k]], r1[k, :c1[k]]
+        assert a.tobytes() == b.tobytes(), (k, [n for n in a.dtype.names if not np.array_equal(a[n], b[n])])
+        diffs = common.compare_logs(l0[k], l1[k], rtol=0.0)
+        assert not diffs, (k, diffs[:10])
+    # the shipped configuration: bursts as k_flow, the steps between them on k_mixfft<1, 1> + k_sync<768> -- against the same without bursts
+    r2, c2, f2, s2, l2 = run_zero_copy_batch(lib, caps, tune=((eng.TUNE_FLOW_MIN, 0),), l2_feedback=l2_feedback)
+    r3, c3, f3, s3, l3 = run_zero_copy_batch(lib, caps, tune=((eng.TUNE_FLOW_MIN, 1),), l2_feedback=l2_feedback)
+    assert s3[1] >= min_flow_steps and np.array_equal(c2, c3)
+    for k in range(len(caps)):
+        diffs = common.compare_logs(l2[k], l3[k])
+        assert not diffs, (k, diffs[:10])
+    return s1

@@ -283,3 +283,12 @@ def test_emu_traceback_variants(emu_lib):
 
 def test_emu_exact_oscillator_first_block_is_the_references(emu_lib, reflib):
     ec.check_exact_oscillator_first_block(emu_lib, reflib, bit_exact_min=4, n=4)
+
+
+def test_emu_dataflow_bursts_equal_the_two_kernel_form(emu_lib):
+    """k_flow on the CPU twin (its work items run one after the other in ticket order): three streams -- one through the CFO search, one with a sample-clock error, so
+    that bursts of every length and the fall-back to the two-kernel form on acquisition steps are exercised -- record for record, frame for frame."""
+    from tests import common
+    caps = [synth.fm_mp1_capture(0, seed=81, cfo_hz=33.0, offset=400, snr_db=22, n_blocks=40), synth.fm_mp1_capture(0, seed=82, cfo_hz=-2300.0, offset=3001, snr_db=18, n_blocks=36),
+            synth.fm_mp1_capture(**dict(common.IMPAIRED_FM_CASES["ppm+60"], n_blocks=40))]
+    ec.check_flow_bursts(emu_lib, caps)

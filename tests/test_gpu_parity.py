@@ -442,3 +442,18 @@ def test_gpu_exact_oscillator_first_block_is_the_references(hip_lib, reflib):
     """on the device the coarse angle goes through OCML's atan2f instead of glibc's (one ulp apart for ~16 % of arguments): bit-identical NCO
     state in at least half of the captures, never more than 1e-4 away"""
     ec.check_exact_oscillator_first_block(hip_lib, reflib, bit_exact_min=3, n=6)
+
+
+def test_gpu_dataflow_bursts_equal_the_two_kernel_form(hip_lib):
+    """k_flow on the MI355X: the block steps of a burst as ONE launch of symbol-pair and block-step work items that hand over to each other (write-through bins + a per-stream
+    counter, agent-scope release / acquire around the stream state, parameter granules) -- every record and frame bit for bit as k_mixfft<1, 2> + k_sync<256> leave them, for
+    24 streams (three per XCD list) of which two go through the CFO search and three carry a sample-clock error, with the replay on."""
+    from nrsc5_amd import synth
+    caps = []
+    for k in range(24):
+        if k % 8 == 3:
+            caps.append(synth.fm_mp1_capture(**dict(common.IMPAIRED_FM_CASES["ppm+60"], n_blocks=48, seed=300 + k)))
+        else:
+            caps.append(synth.fm_mp1_capture(0, seed=300 + k, cfo_hz=(-2300.0 if k % 12 == 5 else 20.0 * k - 150.0), offset=(137 * k) % 4320, snr_db=18 + k % 5, n_blocks=40 + (k % 3) * 8))
+    stats = ec.check_flow_bursts(hip_lib, caps, min_flow_steps=16)
+    print("flow bursts / steps:", stats)
