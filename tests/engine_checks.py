@@ -1422,7 +1422,10 @@ def check_flow_bursts(lib, caps, l2_feedback=True, min_flow_steps=8):
     assert np.array_equal(c0, c1), (c0, c1)
     for k in range(len(caps)):
         a, b = r0[k, :c0[k]], r1[k, :c1[k]]
-        assert a.tobytes() == b.tobytes(), (k, [n for n in a.dtype.names if not np.array_equal(a[n], b[n])])
+        # every field of every record bit for bit -- but the ring slot a frame was filed in: with the replay on, slots taken by frames of discarded blocks depend on
+        # where the bursts end (the rollback runs at burst ends); the frames themselves are compared through the logs below
+        bad = [n for n in a.dtype.names if n != "p1_slot" and a[n].tobytes() != b[n].tobytes()]
+        assert not bad, (k, bad)
         diffs = common.compare_logs(l0[k], l1[k], rtol=0.0)
         assert not diffs, (k, diffs[:10])
     # the shipped configuration: bursts as k_flow, the steps between them on k_mixfft<1, 1> + k_sync<768> -- against the same without bursts
