@@ -171,6 +171,11 @@ int nrsc5hip_push_cs16(nrsc5hip_engine *e, int stream, const int16_t *iq, uint32
  * writes .angle, in the angle of the first synchronised block of an AM session that follows an FM one (acquire.c:115-118).  A LOST_SYNC that the reference
  * fires inside the reset (input_set_sync_state) is the caller's own doing and no record.  Engines with batch_zero_copy treat every reset as a fresh session. */
 int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream);
+/* ABI NOTE (NRSC5HIP_ABI_VERSION >= 5): until round 4 nrsc5hip_stream_reset gave a FRESH session; since round 5 it is the reference's input_reset as described above (stale FIR
+ * windows, samperr / angle / bc kept) and the fresh session is nrsc5hip_stream_fresh.  A caller that used reset to start an independent capture on a slot must call
+ * nrsc5hip_stream_fresh now (on engines with batch_zero_copy both are the fresh form).  nrsc5hip_abi_version() lets a binding check what it was linked against. */
+#define NRSC5HIP_ABI_VERSION 6   /* 6: + nrsc5hip_abi_version, nrsc5hip_debug_flow_stats, NRSC5HIP_TUNE_FLOW_MIN / _LOOP_EXACT, NRSC5HIP_PROF_FLOW; 5: the reset semantics above */
+int nrsc5hip_abi_version(void);
 /* nrsc5_close + nrsc5_open_pipe on this slot: a fresh session (calloc'd windows), what nrsc5hip_reset_all does for every stream */
 int nrsc5hip_stream_fresh(nrsc5hip_engine *e, int stream);
 /* nrsc5_set_mode -> input_set_mode (nrsc5.h:754, input.c:158-162): NRSC5HIP_MODE_FM (default) or _AM; resets the stream.
@@ -210,7 +215,9 @@ int nrsc5hip_stream_step(nrsc5hip_engine *e, int stream);
  * already been submitted with the old state, so the change would land one block late.  (integration/input_hip.c cannot violate it: those calls
  * only come from frame.c during a delivery, and a delivery that can produce them -- a block that may end a P1 frame -- is never stepped ahead of.)
  * Should the engine find its own prediction violated (a block submitted without its P1 decode completed a frame while the next one is running)
- * it drops both steps' bookkeeping, marks the stream's host mirror invalid (the next push re-synchronises) and returns NRSC5HIP_EHIP. */
+ * it drops both steps' bookkeeping, marks the stream's host mirror invalid (the next push re-synchronises) and returns NRSC5HIP_EHIP.  The events of those two
+ * blocks are then NOT delivered through the seam (their records remain in the device ring for nrsc5hip_drain; the first block's P1 frame has no decode): the
+ * session has failed and says so -- it never continues silently. */
 int nrsc5hip_stream_step_ahead(nrsc5hip_engine *e, int stream, int *submitted);
 /* EVENT LATENCY of the drop-in built on these calls (integration/input_hip.c; INTEGRATION.md, first section): with deferred waits and steps queued ahead, the
  * records of block n reach the caller during the first call after the device has finished it -- at the latest in the call that completes block n + 1, i.e. up to
@@ -379,7 +386,7 @@ int nrsc5hip_stage_viterbi_k9_bench(nrsc5hip_engine *e, int len, int nframes, in
 /* Tuning knobs and test hooks (the library reads nothing from the environment).  Call on an idle engine. */
 enum {
     NRSC5HIP_TUNE_DECODE_STREAMS = 0,    /* FM window pipeline: HIP streams that decode windows concurrently (1..5; default 1 since round 5, 3 before) */
-    NRSC5HIP_TUNE_AM_DECODE_STREAMS,     /* same for the AM window pipeline (default 2) */
+    NRSC5HIP_TUNE_AM_DECODE_STREAMS,     /* same for the AM window pipeline (default 3) */
     NRSC5HIP_TUNE_VERDICT_LAG,           /* TEST HOOK: the replay takes first-header verdicts this many windows late (0..8): deep speculation */
     NRSC5HIP_TUNE_SYNC_PHASES,           /* 1: k_sync accumulates shader cycles per phase for stream 0 (nrsc5hip_debug_sync_phases) */
     NRSC5HIP_TUNE_FWD_SEGMENTS           /* waves per frame of the K=7 forward trellis pass (1..64; 0 = chosen from the size of the stream set).  Any value
@@ -394,12 +401,14 @@ enum {
     , NRSC5HIP_TUNE_DECODE_PRIORITY        /* 1: decode streams at the lowest queue priority (default 0: all queues equal) */
     , NRSC5HIP_TUNE_AM_WARM                /* TEST HOOK: 0 = no forward warm-up and no traceback run-in (every boundary takes the repair path); 1 = normal */
     , NRSC5HIP_TUNE_MIXFFT_SYMS            /* OFDM symbols per k_mixfft workgroup: 1 (default), 2, 4, 8 -- any value gives identical bins; 16 = two symbols side by side in a
-                                             256-lane workgroup (identical bins); 32 = the 256-lane x 8-point kernel k_mixfft8 (bins within float tolerance); anything else = 1 */
+                                             256-lane workgroup (identical bins); 32 = the 256-lane x 8-point kernel k_mixfft8 (bins within float tolerance); 100 .. 140 =
+                                             DIAGNOSTIC: the default kernel with (value - 100) KiB of unused dynamic LDS per workgroup (fewer workgroups per CU; the engine
+                                             clamps the padding to what the device's per-workgroup LDS limit leaves); anything else = 1 */
     , NRSC5HIP_TUNE_DEFER_WAIT             /* fast streaming seam: 1 (default) = a block step whose FIFO consumption the host can compute in advance stays in
                                              flight when the push returns; 0 = every step is waited for at once (round 3's behaviour) */
-    , NRSC5HIP_TUNE_TRACEBACK_WALK         /* > 0: single-path traceback of the K=7 frames (one speculative walk per chunk, verified, re-walked where wrong): 1 = one workgroup per
-                                             (frame, part) as in round 4, N > 1 = a persistent grid of N one-wave workgroups (default 512: a launch that keeps thousands of workgroups
-                                             pending stalls the block-step kernels behind it); 0: round 3's block-parallel traceback (all 64 candidates per chunk).  Identical output */
+    , NRSC5HIP_TUNE_TRACEBACK_WALK         /* > 0: single-path traceback of the K=7 frames (one speculative walk per chunk, verified, re-walked where wrong): 1 (default) = one workgroup per
+                                             (frame, part); N > 1 = a persistent grid of N one-wave workgroups (opt-in: measured slower, profiles/r04_traceback_walk.txt);
+                                             0: round 3's block-parallel traceback (all 64 candidates per chunk).  Identical output */
     , NRSC5HIP_TUNE_SYNC_LANES             /* work-items per stream of the sync kernel: 256, 768, 0 = chosen from the size of the stream set (default) */
     , NRSC5HIP_TUNE_DIRECT_DECIMATE        /* fast streaming seam, FM cu8: 1 (default) = the decimator reads the pinned staging buffer across PCIe itself (one
                                              launch per chunk); 0 = hipMemcpyAsync into a device buffer, decimator, commit kernel (round 3's chain) */

@@ -107,7 +107,7 @@ struct nrsc5hip_engine {
     int mixfft_syms;                   // symbols per k_mixfft workgroup (1, 2, 4, 8)
     int sync_lanes;                    // work-items per stream of k_sync: 0 = by the size of the stream set, 256, 768
     int fuse_seam_prepare;             // 1 (default): fast seam, FINE stream: no k_prepare launch (NRSC5HIP_TUNE_SEAM_PREPARE = 0: separate launch)
-    int tb_walk;                       // > 0: single-path traceback (k_p1_tbwalk + check): 1 = a workgroup per (frame, part), N > 1 = a persistent grid of N workgroups (default 512); 0: the block-parallel one of round 3
+    int tb_walk;                       // > 0: single-path traceback (k_p1_tbwalk + check): 1 (default) = a workgroup per (frame, part), N > 1 = a persistent grid of N workgroups (opt-in); 0: the block-parallel one of round 3
     int fwd_segments;                  // waves per frame of the P1 forward pass; 0 = pick from the size of the stream set (fwd_segments_for)
     int flow_min;                      // dataflow bursts (k_flow, k_sync.hip): stream sets of at least this many streams (0 = never) run the steps of a burst in which every
                                        // stream is FINE as ONE launch
@@ -1078,7 +1078,9 @@ static int harvest(nrsc5hip_engine *e, bool block)
         if (e->ahead.valid) {
             // cannot happen while the caller keeps the contract of nrsc5hip_stream_step_ahead (nothing that changes L1 state between it and the drain);
             // if it does, leave the engine in a state every later call understands: nothing in flight, the stream's mirror invalid (its next push
-            // re-synchronises with the device), then report
+            // re-synchronises with the device), then report.  What is LOST in this case, and documented as such (include/nrsc5hip.h, nrsc5hip_stream_step_ahead): the events
+            // of the two blocks already run on the device are not delivered through the seam -- their records stay in the device ring and are visible to
+            // nrsc5hip_drain / nrsc5hip_batch_fetch, but the frame of the first lacks its decode (no P1 bits, no BER); the caller's session is over (error return).
             e->ahead.valid = false; e->inflight_rd_pred = -1;
             (void)hipStreamSynchronize(ln.main);
             e->mirror_ok[s] = 0; forget_prediction(e, s);
@@ -2324,7 +2326,16 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
     case NRSC5HIP_TUNE_EARLY_FLUSH_KB:    e->early_flush = (size_t)std::max(value, 0) << 10; break;
     case NRSC5HIP_TUNE_DEFER_WAIT:        e->defer_wait = value != 0; break;
     case NRSC5HIP_TUNE_DIRECT_DECIMATE:   e->direct_decimate = value != 0; break;
-    case NRSC5HIP_TUNE_MIXFFT_SYMS:       e->mixfft_syms = (value == 2 || value == 4 || value == 8 || value == 16 || value == 32 || (value >= 100 && value <= 140)) ? value : 1; break;   // 16: two symbols side by side per workgroup; 32: the 256-lane kernel
+    case NRSC5HIP_TUNE_MIXFFT_SYMS: {
+        e->mixfft_syms = (value == 2 || value == 4 || value == 8 || value == 16 || value == 32 || (value >= 100 && value <= 140)) ? value : 1;
+        if (e->mixfft_syms >= 100) {                           // DIAGNOSTIC LDS padding: never beyond what a workgroup may have beside the kernel's own ~20 KB (an oversized request failed the
+            int lds_max = 0;                                   // launch, and the failure surfaced at some later hipGetLastError)
+            HIPCHK(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, e->cfg.device));
+            const int room_kib = (lds_max - 24 * 1024) / 1024;
+            if (e->mixfft_syms - 100 > room_kib) e->mixfft_syms = 100 + std::max(room_kib, 0);
+        }
+        break;
+    }
     case NRSC5HIP_TUNE_AM_SEGMENTS:       e->am_segments = std::min(std::max(value, 1), K9_GMAX); break;
     case NRSC5HIP_TUNE_AM_WARM:           e->am_warm = value > 0 ? K9_WARM : 0; e->am_runin = value > 0 ? K9_TB_RUNIN : 0; break;
     case NRSC5HIP_TUNE_SYNC_PHASES:
@@ -2338,6 +2349,8 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
     }
     return 0;
 }
+
+extern "C" int nrsc5hip_abi_version(void) { return NRSC5HIP_ABI_VERSION; }
 
 extern "C" int nrsc5hip_debug_flow_stats(nrsc5hip_engine *e, long long stats[2])
 {

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) MIXFFT8_OCCUPANCY void k_mixfft8(DevTables tb,
 // complex product it is (four products, two sums, each rounded), phase /= cabsf(phase) at the symbol's end -- 69 120 DEPENDENT steps, so one
 // lane per stream walks them (three packed instructions a step: ~0.5 ms, whatever the number of streams) and leaves every sample's phasor in db.nco_tab for
 // the symbol kernel.  Launched only on steps that run the acquisition kernels, and it leaves at once for a stream whose block runs on the closed-form
-// phasor -- with the default policy (NCO_EXACT_UNTIL_FINE) that is every block after a stream's first lock.
+// phasor -- under NCO_EXACT_UNTIL_FINE that is every block after a stream's first lock; the batch default is NCO_CLOSED_FORM (no exact block at all), the drop-in's NCO_EXACT_FIRST_BLOCK.
 // cabsf: glibc's hypotf computes sqrt((double)x * x + (double)y * y) and rounds once to float (verified equal on 5e7 random pairs); the
 // divisions are IEEE float divisions (hipcc's default).
 // One WAVE per stream with one lane at work: as lane = stream the 64 lanes of a wave stored to 64 different cache lines per instruction and the

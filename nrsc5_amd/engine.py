@@ -180,7 +180,7 @@ EXPORTED_SYMBOLS = [
     "nrsc5hip_batch_append_cu8", "nrsc5hip_batch_append_cs16", "nrsc5hip_batch_process", "nrsc5hip_drain",
     "nrsc5hip_p1_frame_packed", "nrsc5hip_p1_frame_bits", "nrsc5hip_batch_fetch", "nrsc5hip_unpack_bits",
     "nrsc5hip_stage_halfband_fm_cu8", "nrsc5hip_stage_fft2048", "nrsc5hip_stage_viterbi_k7", "nrsc5hip_debug_fetch", "nrsc5hip_debug_fetch_costas",
-    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_debug_tune", "nrsc5hip_debug_fwd_stats", "nrsc5hip_debug_flow_stats", "nrsc5hip_debug_tb_stats", "nrsc5hip_debug_k9_stats", "nrsc5hip_stage_first_header", "nrsc5hip_debug_seam_totals", "nrsc5hip_debug_seam_counts", "nrsc5hip_drain_ready", "nrsc5hip_stream_set_manual_step", "nrsc5hip_stream_step", "nrsc5hip_stream_step_ahead", "nrsc5hip_debug_poison_results", "nrsc5hip_device_count", "nrsc5hip_device_upload", "nrsc5hip_device_free", "nrsc5hip_batch_fetch_view", "nrsc5hip_batch_fetch_l2_px", "nrsc5hip_batch_fetch_l2_am",
+    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_debug_tune", "nrsc5hip_debug_fwd_stats", "nrsc5hip_debug_flow_stats", "nrsc5hip_abi_version", "nrsc5hip_debug_tb_stats", "nrsc5hip_debug_k9_stats", "nrsc5hip_stage_first_header", "nrsc5hip_debug_seam_totals", "nrsc5hip_debug_seam_counts", "nrsc5hip_drain_ready", "nrsc5hip_stream_set_manual_step", "nrsc5hip_stream_step", "nrsc5hip_stream_step_ahead", "nrsc5hip_debug_poison_results", "nrsc5hip_device_count", "nrsc5hip_device_upload", "nrsc5hip_device_free", "nrsc5hip_batch_fetch_view", "nrsc5hip_batch_fetch_l2_px", "nrsc5hip_batch_fetch_l2_am",
     "nrsc5hip_stream_set_mode", "nrsc5hip_am_frame_bits", "nrsc5hip_stage_viterbi_k9", "nrsc5hip_px_frame_bits",
     "nrsc5hip_batch_fetch_px", "nrsc5hip_debug_fetch_px", "nrsc5hip_stage_viterbi_k9_bench",
     "nrsc5hip_l2_index", "nrsc5hip_stage_l2_index", "nrsc5hip_l2_frame_get", "nrsc5hip_batch_fetch_l2",
