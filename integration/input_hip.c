@@ -132,12 +132,16 @@ static void deliver(input_t *st, int wait)
  * submitted (deferred wait, include/nrsc5hip.h).  Events of a block therefore reach the application during the first call after
  * the device has finished it -- at the latest in the call that completes the following block, in a zero-length
  * nrsc5_pipe_samples_* call (a flush), or at input_free / input_reset;
- * NRSC5HIP_SYNC_DELIVERY=1 in the environment restores delivery inside the completing call (and the waiting that goes with it). */
+ * that is the OVERLAPPED mode, opt-in since round 6 (NRSC5HIP_OVERLAP_DELIVERY=1).  The DEFAULT is the reference's own contract (src/input.c:41-50, 96-117: every
+ * callback fires inside the nrsc5_pipe_samples_* call that completes its block): the call that completes a block waits for the device and delivers that block's
+ * events before it returns.  NRSC5HIP_SYNC_DELIVERY (rounds 4 - 5: 1 = strict, 0 = overlapped) is still honoured when set. */
 static int sync_delivery(void)
 {
     /* read per call (a getenv is ~50 ns against a block's ~80 us): a host can switch between two sessions, and bench.py times both modes in one process */
     const char *e = getenv("NRSC5HIP_SYNC_DELIVERY");
-    return (e && atoi(e) > 0) ? 1 : 0;
+    if (e && *e) return atoi(e) > 0 ? 1 : 0;
+    e = getenv("NRSC5HIP_OVERLAP_DELIVERY");
+    return (e && atoi(e) > 0) ? 0 : 1;
 }
 
 static void push_pieces(input_t *st, const uint8_t *buf, uint32_t nbytes, int cu8)

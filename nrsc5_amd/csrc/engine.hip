@@ -2329,8 +2329,10 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
     case NRSC5HIP_TUNE_MIXFFT_SYMS: {
         e->mixfft_syms = (value == 2 || value == 4 || value == 8 || value == 16 || value == 32 || (value >= 100 && value <= 140)) ? value : 1;
         if (e->mixfft_syms >= 100) {                           // DIAGNOSTIC LDS padding: never beyond what a workgroup may have beside the kernel's own ~20 KB (an oversized request failed the
-            int lds_max = 0;                                   // launch, and the failure surfaced at some later hipGetLastError)
+            int lds_max = 65536;                               // launch, and the failure surfaced at some later hipGetLastError)
+#ifndef HIPEMU
             HIPCHK(hipDeviceGetAttribute(&lds_max, hipDeviceAttributeMaxSharedMemoryPerBlock, e->cfg.device));
+#endif
             const int room_kib = (lds_max - 24 * 1024) / 1024;
             if (e->mixfft_syms - 100 > room_kib) e->mixfft_syms = 100 + std::max(room_kib, 0);
         }

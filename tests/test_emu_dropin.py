@@ -75,9 +75,10 @@ def _run_opts(path, iq, flags, chunk=32768, mode=0):
 
 @pytest.mark.parametrize("strict", [0, 1])
 def test_emu_dropin_close_without_flush_delivers_the_last_block(emu_dropin, captures, strict, monkeypatch):
-    """src/main.c:1095-1121 ends a file by calling nrsc5_close -- no zero-length nrsc5_pipe_samples_* call.  With the drop-in's default
-    (overlapped) delivery the events of the block that was on the device when the loop ended must then come out of nrsc5_close
-    (input_free -> deliver); with NRSC5HIP_SYNC_DELIVERY=1 every event has been delivered inside the call that completed its block.
+    """src/main.c:1095-1121 ends a file by calling nrsc5_close -- no zero-length nrsc5_pipe_samples_* call.  With the drop-in's overlapped
+    delivery (opt-in since round 6) the events of the block that was on the device when the loop ended must then come out of nrsc5_close
+    (input_free -> deliver) in the overlapped mode (NRSC5HIP_SYNC_DELIVERY=0 / NRSC5HIP_OVERLAP_DELIVERY=1); in the default mode -- the reference's contract, also NRSC5HIP_SYNC_DELIVERY=1 --
+    every event has been delivered inside the call that completed its block.
     Either way the complete log equals the plain reference's."""
     monkeypatch.setenv("NRSC5HIP_SYNC_DELIVERY", str(strict))
     iq = np.ascontiguousarray(captures("fm_cu8_cfo137").iq)

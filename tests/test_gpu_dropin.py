@@ -137,8 +137,8 @@ def test_batch_shard_c_host_equals_python_path(tmp_path):
 @pytest.mark.parametrize("strict", [0, 1])
 def test_dropin_close_without_flush_delivers_the_last_block(captures, strict, monkeypatch):
     """src/main.c:1095-1121 ends a file with nrsc5_close, no zero-length nrsc5_pipe_samples_* call: the events of a block that is still on
-    the device when the feeding loop ends must come out of nrsc5_close (default, overlapped delivery); with NRSC5HIP_SYNC_DELIVERY=1
-    nothing may be left for it.  The complete log equals the plain reference's in both modes."""
+    the device when the feeding loop ends must come out of nrsc5_close (overlapped delivery, opt-in since round 6); in the default mode (the reference's contract;
+    also NRSC5HIP_SYNC_DELIVERY=1) nothing may be left for it.  The complete log equals the plain reference's in both modes."""
     monkeypatch.setenv("NRSC5HIP_SYNC_DELIVERY", str(strict))
     path = os.path.join(BUILD["libnrsc5_hipdropin.so"], "libnrsc5_hipdropin.so")
     if not os.path.exists(path):

@@ -1,0 +1,87 @@
+"""`-m gpu`: a slice of the randomised sweeps ON THE MI355X (rounds 4 - 5 ran them on the CPU twin only -- whose libm is the reference's), every run against
+the UNMODIFIED reference (oracle/_ref incl. its L2) under the strict rule of tests/common.py + the counted classes of bench.py, seeds rotated by the committed counter
+tests/fuzz_seed_counter.txt (tools/bump_fuzz_counter.py):
+
+  * 256 FM captures in one zero-copy batch with CFO uniform in +-3 kHz (nearly every stream locks through detect_cfo), impaired channels on every 4th -- other streams than
+    tests/test_gpu_batch256.py's fixed set;
+  * 128 AM (MA1, cs16) captures through the window pipeline with the replay, interference bursts on every 16th;
+  * 64 two-capture sessions through the PUBLIC pipe API on the drop-in (nrsc5_open_pipe, nrsc5_set_mode, samples, nrsc5_set_mode on the live session, samples, nrsc5_close:
+    FM -> FM, FM -> AM, AM -> FM, AM -> AM with stale FIR windows and kept sync fields) against the plain reference, event by event.
+
+Budget: under three GPU-minutes.  The assertion messages carry the counts: strict / counted-transient / failed."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from tests import common
+from oracle import ref
+
+pytestmark = pytest.mark.gpu
+
+COUNTER = int(open(os.path.join(common.ROOT, "tests", "fuzz_seed_counter.txt")).read().split()[0])
+
+
+def test_gpu_fuzz_fm_cfo_search_batch(hip_lib):
+    if not ref.available(sse=True):
+        pytest.skip("oracle/_ref not prebuilt")
+    import torch
+    from tests import test_gpu_batch256 as t
+    base = 100000 + 256 * COUNTER
+    out = t.run_batch_against_reference(hip_lib, torch.device("cuda", 0), list(range(base, base + 256)))
+    strict, transient, failing = out["streams_equal_under_the_strict_rule"], out["streams_with_transient_loop_state_deviation"], out["streams_failing_by_class"]
+    msg = f"FM fuzz, streams {base}..{base + 255}: {out['first_locks_with_integer_cfo']} CFO-search locks, strict {strict}, counted transient {transient}, failing {failing}; {out['transient_details'][:4]} {out['first_diffs'][:2]}"
+    print(msg)
+    assert not failing and out["streams_compared"] == 256, msg
+    assert transient <= 8, msg                                 # 3 %: round 6 measured 2 of 256 (both outside the CFO search: DESIGN (c))
+
+
+def _bench(args, timeout=600):
+    r = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_gpu_fuzz_am_batch(hip_lib):
+    if not ref.available(sse=True):
+        pytest.skip("oracle/_ref not prebuilt")
+    base = 50000 + 128 * COUNTER
+    r, line = _bench(["--workload", "am-cs16", "--streams", "128", "--stream-base", str(base), "--am-frames", "14", "--steps", "1", "--warmup", "0", "--cpu-baseline-seconds", "1", "--no-extra-legs"])
+    assert line is not None, r.stderr[-2000:]
+    eq = line["parity"]["reference_equality_rank0"]
+    msg = (f"AM fuzz, streams {base}..{base + 127}: compared {eq['streams_compared']}, strict {eq['streams_equal_under_the_strict_rule']}, counted transient "
+           f"{eq['streams_with_transient_loop_state_deviation']}, failing {eq['streams_failing_by_class']}, lost sync {eq['streams_with_lost_sync_this_pass']}; failures {line['parity_failures']}")
+    print(msg)
+    assert r.returncode == 0 and line["parity_failures"] == [] and eq["streams_compared"] == 128, msg
+    assert eq["streams_equal_under_the_strict_rule"] + eq["streams_with_transient_loop_state_deviation"] == 128 and eq["streams_with_transient_loop_state_deviation"] <= 2, msg
+
+
+def test_gpu_fuzz_two_capture_sessions(hip_lib):
+    from tests import test_gpu_dropin as gd, test_emu_dropin as td
+    sys.path.insert(0, os.path.join(common.ROOT, "tools"))
+    import cpu_session_fuzz as fz
+    dropin = os.path.join(gd.BUILD["libnrsc5_hipdropin.so"], "libnrsc5_hipdropin.so")
+    plain = os.path.join(common.ROOT, "oracle", "_ref", "libnrsc5_plain.so")
+    if not (os.path.exists(dropin) and os.path.exists(plain)):
+        pytest.skip("drop-in / plain reference not prebuilt")
+    n, seed0 = 64, 700000 + 64 * COUNTER
+    bad, events, kinds = [], 0, {}
+    for i in range(n):
+        rng = np.random.default_rng(seed0 + i)
+        (ma, a, ka), (mb, b, kb) = fz.make_epoch(rng, long=(i % 2 == 0)), fz.make_epoch(rng, long=(i % 2 == 0))
+        exp = td.run_two(plain, a, b, mode_a=ma, mode_b=mb)
+        got = td.run_two(dropin, a, b, mode_a=ma, mode_b=mb)
+        events += len(exp[0]) + len(exp[1])
+        kinds[(ma, mb)] = kinds.get((ma, mb), 0) + 1
+        for k in range(2):
+            try:
+                td._compare_events(exp[k], got[k])
+            except AssertionError as ex:
+                bad.append(f"session {seed0 + i} capture {k} ({(ka, kb)[k]}): {str(ex)[:200]}")
+                break
+    msg = f"session fuzz {seed0}..{seed0 + n - 1}: {n} sessions ({kinds}), {events} reference events, {len(bad)} sessions with a difference: {bad[:3]}"
+    print(msg)
+    assert not bad, msg
