@@ -733,7 +733,9 @@ __device__ __forceinline__ void am_nco_steps(AmBlockSmem &sm)
     if ((tid & 63) == 0 && tid < 256) {
         const int w = tid >> 6;
         const double x = sm.dtheta * (double)(w < 2 ? AM_SYM : AM_FFT);
-        const float v = (w & 1) ? (float)sin(x) : (float)cos(x);
+        float v;
+        if (fabs(x) <= 0.25) { double c, sn; small_cos_sin(x, c, sn); v = (w & 1) ? (float)sn : (float)c; }   // integer CFO 0 (every block once tuned): the series of fastmath.h, a few ulps of a double
+        else v = (w & 1) ? (float)sin(x) : (float)cos(x);
         float2 &dst = w < 2 ? sm.step270 : sm.step256;
         if (w & 1) dst.y = v; else dst.x = v;
     }
@@ -866,7 +868,7 @@ __global__ __launch_bounds__(NT) void k_am_block(DevTables tb, DevBuffers db, co
             st.angle = 0.0f; st.prev_angle = angle;
         } else {
             samperr = st_coarse_samperr;
-            float sn, cs; sincosf(-st_prev_angle, &sn, &cs);
+            float sn, cs; ref_sincosf(-st_prev_angle, sn, cs);   // cexpf(I * -prev_angle), acquire.c:153: glibc's sincosf restated (fastmath.h)
             const float pr = st_coarse_re * cs - st_coarse_im * sn;
             const float pi = st_coarse_re * sn + st_coarse_im * cs;
             const float angle_diff = ref_atan2f(pi, pr);
@@ -884,11 +886,15 @@ __global__ __launch_bounds__(NT) void k_am_block(DevTables tb, DevBuffers db, co
         sm.samperr = samperr; sm.fine = sync_state == SYNC_FINE; sm.ma3 = st_psmi == AM_MA3;
     }
     __syncthreads();
-    // cexpf(angle / fft * I), rounded to float (kept for the slope correction below): cosine and sine on two waves
-    if (tid == 0) sm.red_v[0].x = (float)cos(sm.targ);
-    if (tid == 64) sm.red_v[0].y = (float)sin(sm.targ);
-    __syncthreads();
-    if (tid == 0) sm.dtheta = atan2((double)sm.red_v[0].y, (double)sm.red_v[0].x);
+    // phase_increment = cexpf(angle / fft * I) (acquire.c:168; kept for the slope correction below): glibc's sincosf of the float argument, restated bit for bit
+    // (ref_sincosf, fastmath.h) -- round 6; until round 5 a double-precision cosine and sine on two waves, rounded once (another float for 1.3 % of arguments) and
+    // two barriers and ~8 k cycles more.  The effective step of the closed-form oscillator is the angle of that rounded pair.
+    if (tid == 0) {
+        float sn, cs; ref_sincosf((float)sm.targ, sn, cs);       // (sm.targ holds the float dth exactly)
+        sm.red_v[0] = make_float2(cs, sn);
+        const double t = (double)sn / (double)cs;
+        sm.dtheta = (cs > 0.0f && fabs(t) <= 0.26) ? small_atan(t) : atan2((double)sn, (double)cs);
+    }
     __syncthreads();
     am_nco_steps(sm);
     __syncthreads();
@@ -951,15 +957,13 @@ __global__ __launch_bounds__(NT) void k_am_block(DevTables tb, DevBuffers db, co
         sm.theta = th; sm.targ = (double)slope;
     }
     __syncthreads();
-    // phase_increment *= cexpf(-slope I): float complex product of the two rounded unit vectors; cosine and sine on two waves
-    if (tid == 0) sm.red_v[1].x = (float)cos(sm.targ);
-    if (tid == 64) sm.red_v[1].y = (float)sin(-sm.targ);
-    __syncthreads();
+    // phase_increment *= cexpf(-slope I) (acquire.c:232): glibc's sincosf of -slope (ref_sincosf), then the float complex product of the two rounded unit vectors
     if (tid == 0) {
-        const float rc = sm.red_v[1].x, rs = sm.red_v[1].y;
+        float rs, rc; ref_sincosf(-(float)sm.targ, rs, rc);     // (sm.targ holds the float slope exactly)
         const float2 inc = sm.red_v[0];
         const float2 inc2 = make_float2(inc.x * rc - inc.y * rs, inc.x * rs + inc.y * rc);
-        sm.dtheta = atan2((double)inc2.y, (double)inc2.x);
+        const double t = (double)inc2.y / (double)inc2.x;
+        sm.dtheta = (inc2.x > 0.0f && fabs(t) <= 0.26) ? small_atan(t) : atan2((double)inc2.y, (double)inc2.x);
     }
     __syncthreads();
     am_nco_steps(sm);
