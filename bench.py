@@ -185,7 +185,7 @@ TRANSIENT_INT = {"samperr", "keep", "next_samperr"}
 TRANSIENT_ABS = {"next_angle": 2e-3, "phase_re": 5e-2, "phase_im": 5e-2}
 TRANSIENT_DETAILS = []                # the first deviations counted as transient, verbatim (per process)
 MER_EXEMPT_BUDGET_PCT, MER_NOISE_BUDGET_PCT_X10 = 1, 5      # 1 % / 0.5 % of the MER values of the compared streams
-TRANSIENT_STREAM_BUDGET_PCT = 3      # round 6 (exact loop arithmetic while un-synchronised): 1 / 1 / 1 of 256 streams in three bench batches, 2 of 256 in a CFO-search batch (round 5: 6 of 256, budget 5 %)
+TRANSIENT_STREAM_BUDGET_PCT = 2      # round 6 (exact loop arithmetic while un-synchronised + the first block's oscillator by the reference's recurrence): 0 of 256 in the bench batch, 0 of 768 in three fresh CFO-search batches, 2 of 256 in tests/test_gpu_batch256.py's (round 5: 6 of 256, budget 5 %)
 # round 5: 0.2 dB (0.5 in round 4): with the oscillator's amplitude and the exact first block on the device the largest first-MER deviation of a counted lock is
 # 0.078 dB in 2400 CFO-search locks on the CPU twin and 0.069 dB on the MI355X; the tail beyond (one lock in ~500 on the device: 0.57 dB, a timing pick by 3 samples) FAILS the run
 # round 6: 0.05 dB (0.2 in round 5): with the Costas loops and the CFO search on the reference's own operations (NRSC5HIP_TUNE_LOOP_EXACT, default) the largest first-MER deviation

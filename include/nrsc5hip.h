@@ -418,7 +418,7 @@ enum {
                                              committed by the sync kernel; 0 = k_prepare as a launch of its own in front of them */
     , NRSC5HIP_TUNE_NCO_EXACT              /* which blocks of a freshly reset FM stream advance the NCO by the reference's own float recurrence (acquire.c:237-252: 69 120
                                              dependent complex multiplications per block, ~0.4 ms of one lane per stream whatever the number of streams) instead of the
-                                             closed-form phasor: 0 (default) = none, 1 = the first block after a reset (the block the CFO search runs on), 2 = every block until the
+                                             closed-form phasor: 0 = none, 1 (default since round 6) = the first block after a reset (the block the CFO search runs on), 2 = every block until the
                                              stream is FINE, 3 = every block (diagnostic).  The float oscillator state is the reference's bit for bit for as long as every
                                              block since the reset ran in this mode; the first closed-form block ends that until the next reset */
     , NRSC5HIP_TUNE_FLOW_MIN               /* dataflow bursts (k_flow): a zero-copy batch with the window pipeline runs the block steps of a burst in which every stream is

@@ -509,11 +509,12 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         if (hipHostMalloc((void **)&e->flow_err, 2 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) { rc = NRSC5HIP_ENOMEM; break; }
         e->flow_err[0] = e->flow_err[1] = 0;
         db.loop_exact = 1;                                     // the reference's own loop arithmetic in blocks that start un-synchronised (k_sync.hip; NRSC5HIP_TUNE_LOOP_EXACT)
-        // Default: the closed-form phasor with the reference oscillator's amplitude ramp (NCO_CLOSED_FORM).  Measured (DESIGN.md (c) limit 2): on the CPU twin,
-        // whose libm is the reference's, the exact first block takes the locks after a CFO search that deviate in loop-internal state from 5 to 2 in 900 (18
-        // without the ramp); on the MI355X the deviating streams of two 256-stream CFO-search batches are the same under every policy (other last-bit
-        // differences of the device's arithmetic trigger them), while k_nco_exact costs 1.3 ms of a 29 ms pass.  nrsc5hip_debug_tune(NRSC5HIP_TUNE_NCO_EXACT) turns it on.
-        db.nco_policy = NCO_CLOSED_FORM;
+        // Default (round 6): a freshly reset stream's FIRST block -- the block its CFO search runs on -- advances the oscillator by the reference's own float recurrence
+        // (k_nco_exact), every later block by the closed-form phasor with the recurrence's amplitude ramp.  Measured on the MI355X with the loop arithmetic of k_sync on the
+        // reference's own operations (loop_exact below): 0 of 722 locks through the CFO search deviate in any field (768 / 768 streams strict), against 5 failing + 8 counted
+        // streams with the closed form in that block (profiles/r06_nco_policy_decision.txt); cost 1.8 ms of a 30.4 ms pass.  (Round 5, with the fast loop arithmetic, had
+        // seen no effect of the policy on the device and defaulted to NCO_CLOSED_FORM: both halves are needed.)  nrsc5hip_debug_tune(NRSC5HIP_TUNE_NCO_EXACT) changes it.
+        db.nco_policy = NCO_EXACT_FIRST_BLOCK;
         if ((rc = dev_alloc(e, &db.pm, S * NPM * PM_FRAME))) break;
         db.nstreams_alloc = (int)S;
         if ((rc = dev_alloc(e, &db.coded, (size_t)(cfg->p1_async ? NAUX : 1) * S * P1_LEN))) break;

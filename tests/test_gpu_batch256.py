@@ -7,6 +7,8 @@ reference session per host process (bench.py's ParityPool, the checker of the be
 Hard assertions: no decoded frame (P1 / PIDS) and no event (SYNC / LOST_SYNC, their order and blocks) differs in any stream; the number of
 streams with ANY deviation -- counted transient loop state or a float beyond its bound -- stays within 2 % (round 4 measured 2 % of the
 CFO-search locks deviating before the oscillator's amplitude ramp was on the device, 0.5 % with it: profiles/r04_cfo_lock_transients.txt)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -42,6 +44,11 @@ def run_batch_against_reference(lib, dev, streams, n_frames=N_FRAMES, payloads=8
     for k, gs in enumerate(streams):
         out = stt.receive_cu8(pool[gs % payloads][1], batch_params(gs), tail=tail, out=iq[k])
         nbytes[k] = out.shape[0] - out.shape[0] % 4
+    dump = [int(x) for x in os.environ.get("NRSC5_DUMP_STREAMS", "").split(",") if x]      # diagnostic: the captures of these global stream ids as .npy under gpurun_out/
+    for k, gs in enumerate(streams):
+        if gs in dump:
+            os.makedirs("gpurun_out", exist_ok=True)
+            np.save(os.path.join("gpurun_out", f"capture_stream{gs}.npy"), iq[k, :int(nbytes[k])].cpu().numpy())
     E = eng.Engine(max_streams=S_, q15_capacity=2 * 71280, record_capacity=max(512, 2 * 16 * n_frames + 64), p1_slots=n_frames + 12, p1_async=True,
                    l2_feedback=True, batch_zero_copy=True, lib_path=lib)
     for knob, value in tune:

@@ -36,7 +36,7 @@ def test_gpu_fuzz_fm_cfo_search_batch(hip_lib):
     msg = f"FM fuzz, streams {base}..{base + 255}: {out['first_locks_with_integer_cfo']} CFO-search locks, strict {strict}, counted transient {transient}, failing {failing}; {out['transient_details'][:4]} {out['first_diffs'][:2]}"
     print(msg)
     assert not failing and out["streams_compared"] == 256, msg
-    assert transient <= 8, msg                                 # 3 %: round 6 measured 2 of 256 (both outside the CFO search: DESIGN (c))
+    assert transient <= 4, msg                                 # round 6 measured 0 of 768 streams on three such batches (profiles/r06_nco_policy_decision.txt)
 
 
 def _bench(args, timeout=600):
