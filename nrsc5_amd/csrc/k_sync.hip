@@ -47,17 +47,12 @@ __device__ inline LoopGains loop_gains()                      // sync.c:832-841
 // x86-64 baseline build), the wrap of the phase a double comparison / double difference rounded once.  The fast form above it in this file reaches the same
 // values to ~5e-7 (v_sin / v_cos, a 4-term arc tangent, e^{2i phase} by the double-angle identities); this one reaches them to the last bit WHEN its inputs
 // are the reference's -- and where they are not quite (the transform's own rounding), it at least adds no difference of its own for the CFO search to amplify.
-// SERIAL: the second sincosf waits for the first (the CFO search's work-items hold a dozen loop variables across this call, and two interleaved double-precision
-// polynomial evaluations on top of them spilled four VGPRs: a private segment that EVERY launch of the sync kernel would pay for).
-template <bool SERIAL>
+// (The two sincosf evaluations are independent and interleave; in the CFO search that only fits the register budget because the exact visits have a loop of their own --
+// k_sync below: sharing one loop with the fast form spilled four VGPRs, a private segment EVERY launch of the sync kernel would pay for.)
 __device__ __forceinline__ float2 costas_step_exact(const float2 z, float &freq, float &phase, float cfo_freq, const LoopGains g)
 {
     float s2, c2; ref_sincosf(-(2.0f * phase), s2, c2);        // cexpf(-I * 2 * phase)
-    float ph1 = phase;
-#ifndef HIPEMU
-    if (SERIAL) asm volatile("" : "+v"(ph1) : "v"(s2), "v"(c2));
-#endif
-    float s1, c1; ref_sincosf(-ph1, s1, c1);                   // cexpf(-I * phase)
+    float s1, c1; ref_sincosf(-phase, s1, c1);                 // cexpf(-I * phase)
     const float wr = z.x * z.x - z.y * z.y, wi = z.x * z.y + z.y * z.x;          // buffer * buffer
     const float ur = wr * c2 - wi * s2, ui = wr * s2 + wi * c2;                  // ... * cexpf(-2 i phase)
     const float error = ref_atan2f(ui, ur) * 0.5f;
@@ -83,7 +78,7 @@ __device__ inline uint32_t adjust_ref_exact(float2 *col, int stride, float *ph, 
 #pragma unroll 1
     for (int n = 0; n < NSYM; n++) {
         ph[n * ph_stride] = phase;
-        const float2 zr = costas_step_exact<RESET>(col[n * stride], freq, phase, cfo_freq, g);
+        const float2 zr = costas_step_exact(col[n * stride], freq, phase, cfo_freq, g);
         col[n * stride] = zr;
         const float sgn = ((PAT_POS >> n) & 1u) ? 1.0f : (((PAT_NEG >> n) & 1u) ? -1.0f : 0.0f);
         x += zr.x * sgn;

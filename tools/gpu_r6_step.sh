@@ -1,8 +1,8 @@
 #!/bin/bash
-# round 5 work loop, one box: GPU tests, the default bench line (every stream of fm / am-cs16 / mixed against the unmodified reference, both drop-in
-# delivery modes), then the FM batch on further seeds (--stream-base: another 256 streams each).   gpurun --timeout 1500 -- 'bash tools/gpu_r5_step.sh TAG [bases]'
-cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; mkdir -p gpurun_out; TAG=${1:-r05a}; BASES=${2:-"256 512"}
-if [ "${3:-}" != notests ]; then ( time timeout 600 python -m pytest tests -m gpu -x -q ) > gpurun_out/${TAG}_tests.log 2>&1; echo "tests rc=$?"; tail -4 gpurun_out/${TAG}_tests.log; fi
+# round 6 work loop, one box: GPU tests, the default bench line (every stream of fm / am-cs16 / mixed against the unmodified reference, both drop-in
+# delivery modes), then the FM batch on further seeds (--stream-base: another 256 streams each).   gpurun --timeout 1500 -- 'bash tools/gpu_r6_step.sh TAG [bases]'
+cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; mkdir -p gpurun_out; TAG=${1:-r06a}; BASES=${2:-"256 512"}
+if [ "${3:-}" != notests ]; then ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > gpurun_out/${TAG}_tests.log 2>&1; echo "tests rc=$?"; tail -4 gpurun_out/${TAG}_tests.log; fi
 ( time timeout 900 python bench.py ) > gpurun_out/${TAG}_bench.log 2>&1; echo "bench rc=$?"
 grep "^{" gpurun_out/${TAG}_bench.log | tail -1 > gpurun_out/${TAG}_bench.json; tail -3 gpurun_out/${TAG}_bench.log | cut -c1-600
 python - "$TAG" <<'PY'
