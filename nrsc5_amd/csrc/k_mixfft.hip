@@ -332,22 +332,22 @@ __global__ __launch_bounds__(64) void k_nco_exact(DevBuffers db, const int *ids,
             pr = ac - bd; pi = ad + bc;
         }
 #else
-        // SIX plain VALU instructions per step -- the four products, then the difference and the sum, each an IEEE operation rounded once as gcc compiles the reference's
-        // float complex multiplication -- ordered so that the two products of the real part's successor issue first: ~26 cycles per step.  (Rounds 5 / 6a used three PACKED
-        // instructions per step: fewer instructions, but a packed fp32 operation is two passes and the step is one dependent chain -- 43 cycles per step measured, 1.23 ms for
-        // the block: profiles/r06_trace_final.txt.  The compiler's own vectorisation of the scalar C form is worse still: it forms the sum AND the difference of both halves.)
-        float2 *out = tab + sym * SYM_N;
+        // THREE packed instructions per step -- (ac, ad), (bd, bc), then (ac - bd, ad + bc) with the sign of the low half in neg_lo -- the same
+        // six IEEE operations, each rounded once (the compiler's own vectorisation of the scalar form spends four: it forms the sum AND the
+        // difference of both halves); the chain is latency-bound at two dependent instructions per step
+        cf P = cf_make(pr, pi);
+        const cf K = cf_make(c, d);
+        cf *out = (cf *)(tab + sym * SYM_N);
 #pragma unroll 8
         for (int j = 0; j < SYM_N; j++) {
-            out[j] = make_float2(pr, pi);
-            float t1, t2, t3, t4;
-            asm("v_mul_f32 %2, %0, %6\n\t"
-                "v_mul_f32 %4, %0, %7\n\t"
-                "v_mul_f32 %3, %1, %7\n\t"
-                "v_mul_f32 %5, %1, %6\n\t"
-                "v_sub_f32 %0, %2, %3\n\t"
-                "v_add_f32 %1, %4, %5" : "+v"(pr), "+v"(pi), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4) : "v"(c), "v"(d));
+            out[j] = P;
+            cf t1, t2;                                             // (one statement: plain VALU dependencies are interlocked in hardware, and between separate
+                                                                   //  statements the compiler pads with s_nop it cannot know to be unnecessary)
+            asm("v_pk_mul_f32 %1, %0, %3 op_sel_hi:[0,1]\n\t"
+                "v_pk_mul_f32 %2, %0, %3 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+                "v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "+v"(P), "=&v"(t1), "=&v"(t2) : "v"(K));
         }
+        pr = P.x; pi = P.y;
 #endif
         const float m = (float)sqrt((double)pr * (double)pr + (double)pi * (double)pi);
         pr = pr / m; pi = pi / m;
