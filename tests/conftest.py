@@ -38,6 +38,20 @@ def pytest_cmdline_main(config):
         opt.tx = ["popen"] * n
 
 
+def pytest_sessionstart(session):
+    """GPU runs: initialise torch's HIP runtime BEFORE anything loads libnrsc5hip.so.  torch ships its own libamdhip64 (ROCm 7.0 here); the library links /opt/rocm's (7.2).
+    Whichever is loaded first serves both; with the system runtime first, torch's device enumeration fails ("No HIP GPUs are available") in any later test that uses torch on
+    the device -- seen when the GPU test files ran in another order than the alphabetical one (tests/test_gpu_batch256.py first).  bench.py initialises torch first for the same reason."""
+    expr = (getattr(session.config.option, "markexpr", "") or "").replace(" ", "")
+    if "gpu" in expr and "notgpu" not in expr:
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
+
+
 @pytest.fixture(scope="session")
 def oracle():
     """CPU restatement (oracle/liboracle.so), compiled on demand with gcc."""
