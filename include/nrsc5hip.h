@@ -219,10 +219,11 @@ int nrsc5hip_stream_step(nrsc5hip_engine *e, int stream);
  * blocks are then NOT delivered through the seam (their records remain in the device ring for nrsc5hip_drain; the first block's P1 frame has no decode): the
  * session has failed and says so -- it never continues silently. */
 int nrsc5hip_stream_step_ahead(nrsc5hip_engine *e, int stream, int *submitted);
-/* EVENT LATENCY of the drop-in built on these calls (integration/input_hip.c; INTEGRATION.md, first section): with deferred waits and steps queued ahead, the
- * records of block n reach the caller during the first call after the device has finished it -- at the latest in the call that completes block n + 1, i.e. up to
- * one block (92.9 ms of signal) later than src/input.c fires them -- or in a zero-length push (flush), nrsc5hip_drain (waits), stream reset / engine destruction
- * paths of the shim.  NRSC5HIP_SYNC_DELIVERY=1 makes the shim wait inside the completing call (the reference's contract) at ~2 / 3 of the throughput. */
+/* EVENT LATENCY of the drop-in built on these calls (integration/input_hip.c; INTEGRATION.md, first section).  DEFAULT since round 6: the shim waits inside the call that
+ * completes a block and delivers that block's events before it returns -- the reference's contract (src/input.c:41-50).  With NRSC5HIP_OVERLAP_DELIVERY=1 (deferred waits,
+ * steps queued ahead: ~1.5 x the throughput) the records of block n reach the caller during the first call after the device has finished it -- at the latest in the call
+ * that completes block n + 1, i.e. up to one block (92.9 ms of signal) later than src/input.c fires them -- or in a zero-length push (flush), nrsc5hip_drain (waits),
+ * stream reset / engine destruction paths of the shim. */
 
 /* ---- batch path (device buffers) ------------------------------------------------------------------ */
 /* Decimate + append one cu8 chunk per listed stream.  dev_iq: device pointer, chunk k at

@@ -157,12 +157,25 @@ __device__ inline void ref_sincosf(float y, float &sinp, float &cosp)
     } else if (top < 0x7f8) {                                  // reduce_large: 4/pi to 192 bits, a 32 x 96 -> 128 bit product, exact 2.62 fixed point
         const unsigned inv_pio4[24] = { 0xa2, 0xa2f9, 0xa2f983, 0xa2f9836e, 0xf9836e4e, 0x836e4e44, 0x6e4e4415, 0x4e441529, 0x441529fc, 0x1529fc27, 0x29fc2757, 0xfc2757d1,
                                         0x2757d1f5, 0x57d1f534, 0xd1f534dd, 0xf534ddc0, 0x34ddc0db, 0xddc0db62, 0xc0db6295, 0xdb629599, 0x6295993c, 0x95993c43, 0x993c4390, 0x3c439041 };
-        const unsigned *arr = &inv_pio4[(yi >> 26) & 15];
+        // arr[0], arr[4], arr[8] of the reference = the 96-bit window of 4/pi's bit string that starts 3 bytes in front of byte `idx`.  For |y| < 2^24 (idx <= 3: every
+        // phase a Costas loop can reach) the window comes out of two 64-bit constants by shifts -- read from the table (which the compiler keeps in constant memory:
+        // three dependent per-lane loads on the serial chain of every large-argument call) it was half of an exact Costas step's time in the CFO search.
+        const unsigned idx = (yi >> 26) & 15;
+        unsigned a0, a4, a8;
+        if (idx <= 3) {
+            const unsigned long long hi = 0x000000a2f9836e4eull, lo = 0x441529fc2757d1f5ull;
+            const unsigned sh = 8u * idx;
+            const unsigned long long H = sh ? (hi << sh) | (lo >> (64u - sh)) : hi, L = lo << sh;
+            a0 = (unsigned)(H >> 32); a4 = (unsigned)H; a8 = (unsigned)(L >> 32);
+        } else {
+            const unsigned *arr = &inv_pio4[idx];
+            a0 = arr[0]; a4 = arr[4]; a8 = arr[8];
+        }
         const int shift = (yi >> 23) & 7;
         unsigned xi = (yi & 0xffffff) | 0x800000;
         xi <<= shift;
-        unsigned long long res0 = (unsigned)(xi * arr[0]);
-        const unsigned long long res1 = (unsigned long long)xi * arr[4], res2 = (unsigned long long)xi * arr[8];
+        unsigned long long res0 = (unsigned)(xi * a0);
+        const unsigned long long res1 = (unsigned long long)xi * a4, res2 = (unsigned long long)xi * a8;
         res0 = (res2 >> 32) | (res0 << 32);
         res0 += res1;
         const unsigned long long nn = (res0 + (1ULL << 61)) >> 62;
