@@ -205,6 +205,18 @@ def compare_with_reference(ref_log, got_log, am: bool):
     diffs = common.compare_logs(exp, got)
     kept = [x for x in exp if x[0] not in ("hdc", "soft", "vit", "amsym", "pxsoft", "station")]
     bad = {i for i, (k, v) in enumerate(kept) if k == "ber" and v["cber"] > 0.02}
+    # AM: the BER of an L1 frame is reported once, after its P3 frame (block 7; decode.c:507-554), and covers the whole L1 frame: the eight P1 PDUs delivered in the blocks before it
+    # were demodulated from the same signal.  A PDU of an L1 frame whose own BER estimate is above 0.02 is exempt like the P3 frame beside it (round 6: stream 52981 of the GPU
+    # fuzz -- a PDU whose first L2 header fails in the reference and here alike, LOST_SYNC on the same block, 69 bits of a 40-bit-wide burst apart: one hard QAM decision on a
+    # boundary; the record sits one LOST_SYNC away from the BER and the old index rule missed it)
+    am_bad_frames = set()
+    if am:
+        nxt_ber = None
+        for i in range(len(kept) - 1, -1, -1):
+            if kept[i][0] == "ber":
+                nxt_ber = i
+            elif kept[i][0] == "frame" and nxt_ber is not None and nxt_ber in bad and nxt_ber - i <= 40:
+                am_bad_frames.add(i)
     remaining, max_bits, transient = [], 0, 0
     global TRANSIENT_DETAILS
     syncs = [i for i, (k, _) in enumerate(kept) if k == "sync"]
@@ -213,7 +225,7 @@ def compare_with_reference(ref_log, got_log, am: bool):
         if m:
             idx, kind, field = int(m.group(1)), m.group(2), m.group(3)
             # FM: "ber" then the frame; AM: the P3 frame then "ber" (after block 7)
-            if (kind == "ber" and idx in bad) or (kind == "frame" and ((idx - 1) in bad or (am and (idx + 1) in bad))):
+            if (kind == "ber" and idx in bad) or (kind == "frame" and ((idx - 1) in bad or (am and ((idx + 1) in bad or idx in am_bad_frames)))):
                 if m.group(4):
                     max_bits = max(max_bits, int(m.group(4)))
                 continue
