@@ -85,3 +85,48 @@ def test_gpu_fuzz_two_capture_sessions(hip_lib):
     msg = f"session fuzz {seed0}..{seed0 + n - 1}: {n} sessions ({kinds}), {events} reference events, {len(bad)} sessions with a difference: {bad[:3]}"
     print(msg)
     assert not bad, msg
+
+
+def test_gpu_fuzz_fm_service_modes_streaming(hip_lib):
+    """The batches above are MP1 cu8; this slice walks what they leave out: MP2 / MP3 / MP11 (P3 / P4 through interleaver IV), cs16 input, impaired channels of every kind, SNR 14 - 30 dB,
+    CFO +-3 kHz -- through the STREAMING seam with the in-order L2 feedback (what the drop-in uses), 24 captures per run, each against the unmodified reference incl. its L2
+    (tools/cpu_parity_fuzz.py's generator; leftovers classified by its rule: a differing PIDS frame whose CRC the reference accepts, a P1 / P3 / P4 frame bit, an event: failures)."""
+    if not ref.available(sse=True):
+        pytest.skip("oracle/_ref not prebuilt")
+    sys.path.insert(0, os.path.join(common.ROOT, "tools"))
+    import bench
+    import cpu_parity_fuzz as pf
+    from nrsc5_amd import engine as eng, synth
+    run, kind = bench._checker(0, True)
+    assert kind == "reference"
+    seed0 = 900000 + 24 * COUNTER
+    strict = counted = 0
+    bad, modes = [], {}
+    for i in range(24):
+        kw = pf.params(i, seed0)
+        kw["snr_db"] = max(kw["snr_db"], 14.0)
+        if i % 3 == 0:
+            kw["mode"] = ("MP2", "MP3", "MP11")[(i // 3) % 3]         # a third of the captures on the extended modes (the generator draws them 3 times in 10)
+        if kw["mode"] != "MP1":
+            kw["n_blocks"] = max(kw["n_blocks"], 56)                  # interleaver IV needs two block pairs before a P3 frame appears
+        modes[(kw["mode"], kw["fmt"])] = modes.get((kw["mode"], kw["fmt"]), 0) + 1
+        cap = synth.fm_mp1_capture(0, **kw)
+        ref_log = run(cap.iq)
+        E = eng.Engine(max_streams=1, q15_capacity=max(2 * 71280 + 32768 * 8, 400000), lib_path=hip_lib, l2_feedback=True)
+        common.run_engine_streaming(E, 0, cap.iq)
+        log = eng.records_to_log(E, 0, E.drain(0))
+        E.close()
+        fatal, nex, max_bits, ntr = bench.compare_with_reference(ref_log, log, False)
+        if fatal:
+            cls = pf.classify(ref_log, fatal)
+            if cls["other"] or cls["pids_valid"] or cls["timing"] or cls["mer"]:
+                bad.append(f"capture {seed0 + i} {kw['mode']} {kw['fmt']} cfo {kw['cfo_hz']:.0f} snr {kw['snr_db']:.0f}: {cls} {fatal[:3]}")
+            else:
+                counted += 1                                          # only numbers formed on blocks the reference itself could not demodulate (discarded PIDS frames, MER below 0 dB, loop state there)
+        elif ntr:
+            counted += 1
+        else:
+            strict += 1
+    msg = f"service-mode fuzz {seed0}..{seed0 + 23}: {modes}: strict {strict}, counted {counted}, failing {len(bad)}: {bad[:3]}"
+    print(msg)
+    assert not bad, msg
