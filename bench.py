@@ -997,7 +997,7 @@ def dropin_leg(iq: np.ndarray, fs: float):
                 hip.nrsc5hip_debug_seam_counts(cnt, 0)
                 brk.append({"blocks": int(tot[6]), "pushes": int(tot[4]), "submissions_h2d_plus_decimator": int(tot[5]),
                             "block_steps_left_in_flight_deferred_wait": int(cnt[0]), "read_positions_mispredicted": int(cnt[1]),
-                            "block_steps_without_p1_decode_launches": int(cnt[2]), "p1_decodes_launched_late": int(cnt[3]), "block_steps_queued_ahead_of_the_previous_delivery": int(cnt[4]),
+                            "block_steps_without_p1_decode_launches": int(cnt[2]), "p1_decodes_launched_late": int(cnt[3]), "block_steps_queued_ahead_of_the_previous_delivery": int(cnt[4]), "pushes_copied_into_the_host_resident_capture": int(cnt[5]),
                             "us_per_block": {"host_copy_into_pinned_staging": round(tot[0] / blocks * 1e6, 1), "host_enqueue_h2d_and_decimator": round(tot[1] / blocks * 1e6, 1),
                                              "host_enqueue_block_step": round(tot[2] / blocks * 1e6, 1), "wait_for_device": round(tot[3] / blocks * 1e6, 1),
                                              "fetch_p1_frames": round(tot[7] / blocks * 1e6, 1),

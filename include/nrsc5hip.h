@@ -174,7 +174,7 @@ int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream);
 /* ABI NOTE (NRSC5HIP_ABI_VERSION >= 5): until round 4 nrsc5hip_stream_reset gave a FRESH session; since round 5 it is the reference's input_reset as described above (stale FIR
  * windows, samperr / angle / bc kept) and the fresh session is nrsc5hip_stream_fresh.  A caller that used reset to start an independent capture on a slot must call
  * nrsc5hip_stream_fresh now (on engines with batch_zero_copy both are the fresh form).  nrsc5hip_abi_version() lets a binding check what it was linked against. */
-#define NRSC5HIP_ABI_VERSION 6   /* 6: + nrsc5hip_abi_version, nrsc5hip_debug_flow_stats, NRSC5HIP_TUNE_FLOW_MIN / _LOOP_EXACT, NRSC5HIP_PROF_FLOW; 5: the reset semantics above */
+#define NRSC5HIP_ABI_VERSION 7   /* 7: + NRSC5HIP_TUNE_HOST_CAPTURE, nrsc5hip_debug_host_capture_stats; 6: + nrsc5hip_abi_version, nrsc5hip_debug_flow_stats, NRSC5HIP_TUNE_FLOW_MIN / _LOOP_EXACT, NRSC5HIP_PROF_FLOW; 5: the reset semantics above */
 int nrsc5hip_abi_version(void);
 /* nrsc5_close + nrsc5_open_pipe on this slot: a fresh session (calloc'd windows), what nrsc5hip_reset_all does for every stream */
 int nrsc5hip_stream_fresh(nrsc5hip_engine *e, int stream);
@@ -429,6 +429,11 @@ enum {
                                              bit for bit (fastmath.h), its float complex products, adjust_ref / reset_ref in place -- instead of the fast forms (v_sin / v_cos,
                                              a 4-term arc tangent, ~5e-7): 0 = never, 1 (default) = in every block that starts un-synchronised (the tracking pass over garbage and the
                                              CFO search, where a last-bit difference can be amplified into a different loop state), 2 = in every block */
+    , NRSC5HIP_TUNE_HOST_CAPTURE           /* fast streaming seam, FM cu8 (round 6): 1 (default) = the pushes of a session stay, as they arrive, in a pinned device-mapped capture that
+                                             the stream reads in place across PCIe (the zero-copy batch's kernels: half-band fused into the symbol transform) -- a push is one host
+                                             memcpy, no decimator launch; 0 = pinned staging + decimator kernel into the device FIFO (rounds 3 - 5).  Identical records either way.
+                                             >= 512: on, with that many KiB of capture buffer instead of 16 MiB (the live tail moves to the front when it is full).  One stream per
+                                             engine reads such a capture (the first to push cu8 after its reset); cs16 / AM input and the batch entry points use the FIFO */
 };
 /* process-wide wall-clock totals of the streaming seam with p1_async = 0 (what the drop-in uses): [0] s copying pushes into pinned
  * staging, [1] s enqueueing H2D + decimator, [2] s enqueueing block steps, [3] s waiting for the device (one sync per block),
@@ -436,7 +441,7 @@ enum {
 void nrsc5hip_debug_seam_totals(double out[8], int reset);   /* totals of the CALLING THREAD's sessions */
 /* ... [0] block steps left in flight (deferred wait), [1] read positions the host predicted wrongly (expected: 0), [2] steps submitted
  * without the P1 decode launches (no frame could complete), [3] P1 decodes launched after the fact (expected: 0) */
-void nrsc5hip_debug_seam_counts(double out[6], int reset);   /* ... [4] block steps submitted ahead of the previous block's delivery, [5] reserved */
+void nrsc5hip_debug_seam_counts(double out[6], int reset);   /* ... [4] block steps submitted ahead of the previous block's delivery, [5] pushes copied into a host-resident capture (NRSC5HIP_TUNE_HOST_CAPTURE) */
 /* test / bench hygiene: overwrite every result buffer a pass writes (frame rings on the device and their pinned host mirror, record
  * rings) with a pattern no decode produces -- a check after the next pass can then only pass on bits written by that pass */
 int nrsc5hip_debug_poison_results(nrsc5hip_engine *e);
@@ -444,6 +449,9 @@ int nrsc5hip_debug_poison_results(nrsc5hip_engine *e);
 int nrsc5hip_debug_fwd_stats(nrsc5hip_engine *e, int stats[2]);
 /* dataflow bursts (NRSC5HIP_TUNE_FLOW_MIN): [0] bursts, [1] block steps issued as k_flow launches since the engine was created */
 int nrsc5hip_debug_flow_stats(nrsc5hip_engine *e, long long stats[2]);
+/* host-resident capture of the fast seam (NRSC5HIP_TUNE_HOST_CAPTURE): [0] sessions that bound the pinned capture, [1] captures turned back into the FIFO (cs16 push,
+ * batch entry point, debug fetch), [2] times the live tail moved to the front of a full buffer, [3] the stream bound now (-1: none) */
+int nrsc5hip_debug_host_capture_stats(nrsc5hip_engine *e, long long stats[4]);
 /* K=9 decode in segment waves: [0] forward boundaries checked, [1] segments re-run, [2] traceback boundaries checked, [3] segments re-walked */
 /* single-path traceback: [0] chunk boundaries checked, [1] chunks re-walked since the engine was created */
 int nrsc5hip_debug_tb_stats(nrsc5hip_engine *e, int stats[2]);

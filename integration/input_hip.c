@@ -226,6 +226,8 @@ void input_init(input_t *st, nrsc5_t *radio, output_t *output)
      * every block with the reference's own oscillator recurrence (k_nco_exact: ~1.5 ms per such block; DESIGN.md (c) limit 2).  Default: the closed form with
      * the oscillator's amplitude ramp, as in the batch API -- measured on the MI355X the exact form changes no event and costs a 20-s capture 5 % of its speed */
     else { const char *x = getenv("NRSC5HIP_NCO_EXACT"); if (x && atoi(x) > 0 && nrsc5hip_debug_tune(e, NRSC5HIP_TUNE_NCO_EXACT, atoi(x)) != 0) fail(st, "debug_tune"); }
+    /* NRSC5HIP_HOST_CAPTURE=0: the FIFO seam of rounds 3 - 5 (pinned staging + decimator kernel) instead of the pinned capture read in place (A/B; identical events) */
+    if (e && !FAILED(st)) { const char *x = getenv("NRSC5HIP_HOST_CAPTURE"); if (x && *x && nrsc5hip_debug_tune(e, NRSC5HIP_TUNE_HOST_CAPTURE, atoi(x)) != 0) fail(st, "debug_tune"); }
     st->acq.fftin = (void *)e;
     st->decode.input = st;
     frame_init(&st->frame, st);

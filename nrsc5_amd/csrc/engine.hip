@@ -1,6 +1,7 @@
 // Host side of libnrsc5hip: engine object, device-resident per-stream state, the block-step
 // scheduler and the C ABI of include/nrsc5hip.h.  Mirrors the reference's src/input.c seam
 // (input_push_cu8/cs16, input_reset, input_set_sync_state) -- see include/nrsc5hip.h for the map.
+#include <array>
 #include <atomic>
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -170,6 +171,19 @@ struct nrsc5hip_engine {
     std::vector<char> pred_ok;         // the stream's last harvested record left it FINE and nothing else touched it since
     std::vector<int> pred_samperr, pred_bc;    // ... that record's next_samperr and block count
     std::vector<char> manual_step;     // nrsc5hip_stream_set_manual_step: pushes stage and submit samples, the caller steps
+    // Host-resident capture (round 6; fast seam, FM cu8, NRSC5HIP_TUNE_HOST_CAPTURE): the pushes of ONE stream of the engine are kept as they arrive in a pinned,
+    // device-mapped buffer and the stream reads them in place -- StreamState::raw points into it, and the symbol kernel / the acquisition run the half-band on what they
+    // read (halfband_raw.h): the zero-copy batch's kernels, fed across PCIe.  A push is one host memcpy: no decimator launch, no ingest stream, nothing in front of the
+    // block step.  The stream's own byte numbering: HC_PREFIX bytes of decimator history (what its reset left in hb_hist), then every byte pushed since that reset;
+    // decimated sample a = dword a of that numbering, so the stream's counters start at HC_OFF.  The buffer is linear: when it is full the live tail moves to its
+    // front and `raw` moves with it (hc_rebase).  Anything the capture cannot express (a cs16 push, the batch entry points) first turns it back into the FIFO (hc_detach).
+    static constexpr long long HC_OFF = 8, HC_PREFIX = 4 * HC_OFF, HC_KEEP = 16384;
+    uint8_t *hc_pin, *hc_dev; size_t hc_cap;
+    int hc_stream;                     // the stream bound to the buffer, -1: none
+    long long hc_abs0, hc_wr;          // byte index (stream numbering) of hc_pin[0] / of the next byte to be written
+    bool host_capture;                 // knob (default on where the buffer exists)
+    long long hc_rebases, hc_attaches, hc_detaches;
+    std::vector<std::array<c16, 14>> hb_hist_host;   // the decimator history each stream's last reset left on the device (zeros for a fresh session)
     // staging
     uint8_t *stage_dev; size_t stage_bytes;
     size_t stage_ring_bytes;           // size of each of the NSTAGE staging buffers of the fast seam (a block of either mode fits)
@@ -495,7 +509,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
         }
         if ((rc = dev_alloc(e, &db.q15, S * (size_t)db.q15_cap))) break;
         db.acq_win = nullptr;
-        if (cfg->batch_zero_copy && (rc = dev_alloc(e, &db.acq_win, S * WIN_N))) break;
+        if ((cfg->batch_zero_copy || !cfg->p1_async) && (rc = dev_alloc(e, &db.acq_win, S * WIN_N))) break;   // (fast-seam engines: the host-resident capture reads in place too)
         if ((rc = dev_alloc(e, &db.acq_filt, S * WIN_N))) break;
         if ((rc = dev_alloc(e, &db.acq_list, S + 1))) break;
         if ((rc = dev_alloc(e, &db.acq_sums, S * SYM_N))) break;
@@ -626,6 +640,16 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             }
             if (rc) break;
         }
+        e->hc_stream = -1; e->hc_abs0 = 0; e->hc_wr = 0; e->host_capture = false; e->hc_rebases = e->hc_attaches = e->hc_detaches = 0;
+        if (!cfg->p1_async) {
+            e->hc_cap = 16u << 20;                             // 58 FM blocks between two rebases (~300 KB of host memmove each)
+            void *hp = nullptr;
+            if (hipHostMalloc((void **)&e->hc_pin, e->hc_cap, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&hp, e->hc_pin, 0) != hipSuccess) {
+                rc = NRSC5HIP_ENOMEM; snprintf(g_err, sizeof(g_err), "pinned capture allocation failed"); break;
+            }
+            e->hc_dev = (uint8_t *)hp; e->host_capture = true;
+        }
+        e->hb_hist_host.assign(S, std::array<c16, 14>{});
         e->stage_slot = 0; e->staged_stream = -1; e->staged_bytes = 0; e->staged_q15 = 0; e->staged_cu8 = false;
         if ((rc = dev_alloc(e, &e->ids_dev, S))) break;
         if ((rc = dev_alloc(e, &e->nbytes_dev, S))) break;
@@ -667,6 +691,7 @@ extern "C" void nrsc5hip_engine_destroy(nrsc5hip_engine *e)
     if (e->nblocks_host) (void)hipHostFree(e->nblocks_host);
     for (int k = 0; k < nrsc5hip_engine::NSTAGE; k++) { if (e->stage_pin[k]) (void)hipHostFree(e->stage_pin[k]); if (e->stage_ev[k]) (void)hipEventDestroy(e->stage_ev[k]); }
     for (int k = 0; k < 2; k++) if (e->report_host[k]) (void)hipHostFree(e->report_host[k]);
+    if (e->hc_pin) (void)hipHostFree(e->hc_pin);
     if (e->ingest) (void)hipStreamDestroy(e->ingest);
     if (e->ev_ingest) (void)hipEventDestroy(e->ev_ingest);
     if (e->ev_main) (void)hipEventDestroy(e->ev_main);
@@ -1251,6 +1276,102 @@ static int flush_staged(nrsc5hip_engine *e)
     return 0;
 }
 
+// ---- host-resident capture (see nrsc5hip_engine::hc_*) ------------------------------------------------------------
+static int push_common(nrsc5hip_engine *e, int s, const void *host, size_t nbytes_total, bool cu8);
+
+// complex input sample k of the bound stream's session (k >= -14: its decimator history) as the Q15 pair the reference's decimator holds (U8_Q15, defines.h:93)
+static c16 hc_sample_q15(const nrsc5hip_engine *e, long long k)
+{
+    const uint8_t *b = e->hc_pin + (nrsc5hip_engine::HC_PREFIX + 2 * k - e->hc_abs0);
+    c16 v; v.r = (int16_t)(((int)b[0] - 127) * 64); v.i = (int16_t)(((int)b[1] - 127) * 64);
+    return v;
+}
+
+// what decim[0]'s last compaction inside the first n input samples of the session leaves at the front of its window (StaleWindows, nrsc5_dev.h; the device-side
+// form is hb_roll_history, k_decimate.hip): false = no compaction in that span, `out` untouched
+static bool hc_stale_hb(const nrsc5hip_engine *e, long long n, c16 out[14])
+{
+    const long long p = stale_start(0, n, 14);
+    if (p == STALE_NONE) return false;
+    for (int k = 0; k < 14; k++) out[k] = hc_sample_q15(e, p + k);
+    return true;
+}
+
+// a freshly reset FM stream's first cu8 push: bind the buffer to it if its decimator history is expressible as input bytes (always, unless an AM session's
+// >> 4 samples were left in decim[0]'s window)
+static int hc_try_attach(nrsc5hip_engine *e, int s)
+{
+    uint8_t pre[nrsc5hip_engine::HC_PREFIX];
+    memset(pre, 0x7f, sizeof(pre));
+    for (int k = 0; k < 14; k++) {
+        const c16 h = e->hb_hist_host[s][k];
+        if ((h.r & 63) || (h.i & 63)) return 0;
+        const int r = h.r / 64 + 127, i = h.i / 64 + 127;
+        if (r < 0 || r > 255 || i < 0 || i > 255) return 0;
+        pre[nrsc5hip_engine::HC_PREFIX - 28 + 2 * k] = (uint8_t)r; pre[nrsc5hip_engine::HC_PREFIX - 28 + 2 * k + 1] = (uint8_t)i;
+    }
+    int rc = settle(e); if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(e->main));
+    memcpy(e->hc_pin, pre, sizeof(pre));
+    e->hc_abs0 = 0; e->hc_wr = nrsc5hip_engine::HC_PREFIX;
+    // wr, rd, base, raw are the first four members of StreamState: the stream reads the capture from dword HC_OFF on, and the HOST decides when a window is complete
+    // (the fast seam steps a stream only when its mirror says so), so the device-side end of data is set out of reach
+    struct { long long wr, rd, base; const uint8_t *raw; } head = { 1ll << 60, nrsc5hip_engine::HC_OFF, 0, e->hc_dev };
+    static_assert(offsetof(StreamState, wr) == 0 && offsetof(StreamState, rd) == 8 && offsetof(StreamState, base) == 16 && offsetof(StreamState, raw) == 24, "StreamState head layout");
+    HIPCHK(hipMemcpy(e->db.state + s, &head, sizeof(head), hipMemcpyHostToDevice));
+    e->wr_host[s] = e->rd_host[s] = nrsc5hip_engine::HC_OFF; e->base_host[s] = 0;
+    e->hc_stream = s; e->hc_attaches++;
+    return 0;
+}
+
+// the buffer is full: the live tail -- HC_KEEP bytes behind the read position (the decimator taps, and what a reset needs to tell the stale window) up to the write
+// position -- moves to the front, and the stream's `raw` with it.  Nothing may be reading: every step is harvested first.
+static int hc_rebase(nrsc5hip_engine *e)
+{
+    const int s = e->hc_stream;
+    int rc = settle(e); if (rc) return rc;
+    long long from = (4 * e->rd_host[s] - nrsc5hip_engine::HC_KEEP) & ~63ll;
+    if (from <= e->hc_abs0) FAIL(NRSC5HIP_EOVERFLOW, "stream %d: the pinned capture (%zu bytes) cannot hold one window", s, e->hc_cap);
+    memmove(e->hc_pin, e->hc_pin + (from - e->hc_abs0), (size_t)(e->hc_wr - from));
+    e->hc_abs0 = from;
+    const uint8_t *raw = e->hc_dev - from;                     // dword d of the stream's numbering lives at raw + 4 d
+    HIPCHK(hipStreamSynchronize(e->main));
+    HIPCHK(hipMemcpy((char *)(e->db.state + s) + offsetof(StreamState, raw), &raw, sizeof(raw), hipMemcpyHostToDevice));
+    e->hc_rebases++;
+    return 0;
+}
+
+// Turn the bound stream back into a FIFO stream: the device forgets the capture at its read position -- FIFO empty there, decimator history = the 14 input samples in
+// front of it, decim[0]'s stale-window bookkeeping as the streaming decimator would have left it -- and the bytes behind that position go through the ordinary
+// seam again (pinned staging, decimator).  For callers that leave what the capture can express: a cs16 push into the session, the batch entry points.
+static int hc_detach(nrsc5hip_engine *e)
+{
+    const int s = e->hc_stream;
+    if (s < 0) return 0;
+    int rc = settle(e); if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(e->main));
+    const long long rd = e->rd_host[s], consumed = 2 * (rd - nrsc5hip_engine::HC_OFF);   // input samples in front of the read position
+    struct { long long wr, rd, base; const uint8_t *raw; c16 hb_hist[14]; } head = { rd, rd, rd, nullptr, {} };
+    static_assert(offsetof(StreamState, hb_hist) == 32, "StreamState head layout");
+    for (int k = 0; k < 14; k++) head.hb_hist[k] = hc_sample_q15(e, consumed - 14 + k);
+    HIPCHK(hipMemcpy(e->db.state + s, &head, sizeof(head), hipMemcpyHostToDevice));
+    c16 sw[14];
+    if (hc_stale_hb(e, consumed, sw)) HIPCHK(hipMemcpy((char *)(e->db.state + s) + offsetof(StreamState, stale) + offsetof(StaleWindows, hb), sw, sizeof(sw), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy((char *)(e->db.state + s) + offsetof(StreamState, stale) + offsetof(StaleWindows, hb_pushed), &consumed, sizeof(consumed), hipMemcpyHostToDevice));
+    e->wr_host[s] = rd; e->base_host[s] = rd;
+    e->hc_stream = -1; e->hc_detaches++;
+    const long long tail0 = 4 * rd, ntail = e->hc_wr - tail0;
+    if (ntail > 0) {
+        // (the source is the pinned capture itself: nothing writes it while the stream is unbound)
+        const bool keep = e->host_capture; e->host_capture = false;
+        const char manual = e->manual_step[s]; e->manual_step[s] = 1;      // the re-push only restores the FIFO: it completes at most the window the caller has not stepped yet
+        rc = push_common(e, s, e->hc_pin + (tail0 - e->hc_abs0), (size_t)ntail, true);
+        e->manual_step[s] = manual; e->host_capture = keep;
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 static int push_common(nrsc5hip_engine *e, int s, const void *host, size_t nbytes_total, bool cu8)
 {
     int rc = check_stream(e, s); if (rc) return rc;
@@ -1262,9 +1383,30 @@ static int push_common(nrsc5hip_engine *e, int s, const void *host, size_t nbyte
     const bool fast = !e->cfg.p1_async && e->mirror_ok[s];
     if (e->ahead.valid && (rc = harvest(e, true))) return rc;  // the mirror lacks a step submitted ahead until its predecessor is harvested
     while (e->inflight_stream >= 0 && (!fast || e->inflight_stream != s)) if ((rc = harvest(e, true))) return rc;
+    if (e->hc_stream == s && (!fast || !cu8 || am) && (rc = hc_detach(e))) return rc;      // the capture holds FM cu8 input of the fast seam, nothing else
+    if (fast && cu8 && !am && e->host_capture && e->hc_stream < 0 && e->wr_host[s] == 0 && e->rd_host[s] == 0 && e->staged_stream != s && nbytes_total &&
+        (rc = hc_try_attach(e, s))) return rc;
+    const bool hc = e->hc_stream == s;
     if (fast && e->staged_stream >= 0 && (e->staged_stream != s || e->staged_cu8 != cu8) && (rc = flush_staged(e))) return rc;
     if (fast && e->manual_step[s] && e->wr_host[s] - e->rd_host[s] >= window_of(e, s) && (rc = stream_steps(e, s))) return rc;   // the caller did not step
     while (nbytes_total) {
+        if (hc) {
+            // host-resident capture: the bytes stay where this copy puts them; a block is stepped when the mirror says its window is complete
+            size_t chunk = nbytes_total;
+            const long long to_block = nrsc5hip_bytes_to_next_block(e, s, 1);      // (as below: block by block, whatever the size of the push)
+            if (to_block > 0 && (size_t)to_block < chunk) chunk = (size_t)to_block;
+            if ((size_t)(e->hc_wr - e->hc_abs0) + chunk > e->hc_cap && (rc = hc_rebase(e))) return rc;
+            if ((size_t)(e->hc_wr - e->hc_abs0) + chunk > e->hc_cap) FAIL(NRSC5HIP_EOVERFLOW, "stream %d: the pinned capture (%zu bytes) is too small", s, e->hc_cap);
+            { SeamClock clk(0); memcpy(e->hc_pin + (e->hc_wr - e->hc_abs0), src, chunk); }
+            g_seam[4] += 1; g_seam[13] += 1;
+            e->hc_wr += (long long)chunk; e->wr_host[s] += (long long)chunk / 4;
+            src += chunk; nbytes_total -= chunk;
+            if (e->wr_host[s] - e->rd_host[s] >= window_of(e, s)) {
+                if (e->manual_step[s] && nbytes_total == 0) break;     // nrsc5hip_stream_step runs the block
+                if ((rc = stream_steps(e, s))) return rc;
+            }
+            continue;
+        }
         if (fast) {
             // stage in pinned memory; submit when the block completes (the mirror knows) or the buffer is full
             const int slot = e->stage_slot;
@@ -1344,6 +1486,7 @@ static int reset_stream(nrsc5hip_engine *e, int stream, bool keep_windows)
     HIPCHK(hipStreamSynchronize(e->main));
     if (e->cfg.p1_async) { for (int k = 0; k < NAUX; k++) HIPCHK(hipStreamSynchronize(e->lane.aux[k])); HIPCHK(hipStreamSynchronize(e->dec_stream)); }
     StreamState st; init_state(st, e->mode_host[stream]);
+    const bool was_hc = e->hc_stream == stream;
     if (keep_windows && !e->cfg.batch_zero_copy) {             // (zero-copy engines: every attach is an independent recording, read in place with byte-valued history)
         HIPCHK(hipMemcpy(&st.stale, (const char *)(e->db.state + stream) + offsetof(StreamState, stale), sizeof(st.stale), hipMemcpyDeviceToHost));
         // sync_reset (sync.c:810-830) leaves sync_t.samperr, .angle and .bc alone.  The FM path overwrites all three in the block that locks, before anything reads
@@ -1352,6 +1495,8 @@ static int reset_stream(nrsc5hip_engine *e, int stream, bool keep_windows)
         HIPCHK(hipMemcpy(&st.samperr, (const char *)(e->db.state + stream) + offsetof(StreamState, samperr), sizeof(st.samperr), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(&st.angle, (const char *)(e->db.state + stream) + offsetof(StreamState, angle), sizeof(st.angle), hipMemcpyDeviceToHost));
         HIPCHK(hipMemcpy(&st.bc, (const char *)(e->db.state + stream) + offsetof(StreamState, bc), sizeof(st.bc), hipMemcpyDeviceToHost));
+        // a stream that read the pinned capture never ran the streaming decimator: what decim[0]'s window holds after every byte pushed in that session is told from the capture
+        if (was_hc) (void)hc_stale_hb(e, (e->hc_wr - nrsc5hip_engine::HC_PREFIX) / 2, st.stale.hb);
         st.stale.hb_pushed = 0; st.stale.fir_pushed[0] = 0; st.stale.fir_pushed[1] = 0;
         memcpy(st.hb_hist, st.stale.hb, sizeof(st.hb_hist));
         memcpy(st.fir_hist, st.stale.fir[st.mode == MODE_AM ? MODE_AM : MODE_FM], sizeof(st.fir_hist));
@@ -1365,6 +1510,8 @@ static int reset_stream(nrsc5hip_engine *e, int stream, bool keep_windows)
         HIPCHK(hipMemset(e->db.am_job + (size_t)stream * NWIN, 0, NWIN * sizeof(AmJob)));
         HIPCHK(hipMemset(e->db.am_pids_rec + (size_t)stream * NWIN * 8, 0xff, NWIN * 8 * sizeof(int)));
     }
+    if (was_hc) e->hc_stream = -1;
+    memcpy(e->hb_hist_host[stream].data(), st.hb_hist, sizeof(st.hb_hist));
     e->wr_host[stream] = 0; e->base_host[stream] = 0; e->drained[stream] = 0; e->raw_host[stream] = 0; e->attached[stream] = 0;
     e->rd_host[stream] = 0; e->fetched[stream] = 0; e->pending[stream].clear(); e->mirror_ok[stream] = e->cfg.p1_async ? 0 : 1;
     forget_prediction(e, stream);
@@ -1405,6 +1552,7 @@ extern "C" int nrsc5hip_force_resync(nrsc5hip_engine *e, int stream)
 // the batch entry points move a stream's FIFO without the host mirror of the fast streaming seam: records are read from the device again
 static int leave_mirror(nrsc5hip_engine *e, int n, const int *ids)
 {
+    for (int k = 0; k < n; k++) if (e->hc_stream >= 0 && (ids ? ids[k] : k) == e->hc_stream) { int rc = hc_detach(e); if (rc) return rc; }   // the batch kernels read a FIFO (or a capture of known length)
     if (e->staged_stream >= 0) { int rc = flush_staged(e); if (rc) return rc; }   // whatever a push left in the pinned buffer goes to the FIFO first
     for (int k = 0; k < n; k++) {
         const int s = ids ? ids[k] : k;
@@ -2061,6 +2209,7 @@ extern "C" int nrsc5hip_debug_fetch_q15(nrsc5hip_engine *e, int stream, long lon
     ON_ENGINE_DEVICE(e);
     int rc = check_stream(e, stream); if (rc) return rc;
     if (n < 0 || n > e->db.q15_cap || !out) FAIL(NRSC5HIP_EINVAL, "bad argument");
+    if (e->hc_stream == stream && (rc = hc_detach(e))) return rc;      // a stream that reads the pinned capture has no FIFO to show: it gets one (from its read position on)
     if (e->staged_stream >= 0 && (rc = flush_staged(e))) return rc;
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(out, e->db.q15 + (size_t)stream * e->db.q15_cap, (size_t)n * sizeof(c16), hipMemcpyDeviceToHost));
@@ -2109,6 +2258,7 @@ extern "C" int nrsc5hip_reset_all(nrsc5hip_engine *e)
     HIPCHK(hipDeviceSynchronize());
     e->dec_chunk = 0;
     e->staged_stream = -1; e->staged_bytes = 0; e->staged_q15 = 0;
+    e->hc_stream = -1; std::fill(e->hb_hist_host.begin(), e->hb_hist_host.end(), std::array<c16, 14>{});
     const size_t S = e->cfg.max_streams;
     std::vector<StreamState> init(S);
     for (size_t s = 0; s < S; s++) init_state(init[s], e->mode_host[s]);
@@ -2327,6 +2477,18 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
     case NRSC5HIP_TUNE_EARLY_FLUSH_KB:    e->early_flush = (size_t)std::max(value, 0) << 10; break;
     case NRSC5HIP_TUNE_DEFER_WAIT:        e->defer_wait = value != 0; break;
     case NRSC5HIP_TUNE_DIRECT_DECIMATE:   e->direct_decimate = value != 0; break;
+    case NRSC5HIP_TUNE_HOST_CAPTURE: {
+        if (e->hc_stream >= 0) { int rc = hc_detach(e); if (rc) return rc; }
+        if (!e->hc_pin) break;                                 // window-pipeline engines have no fast seam
+        e->host_capture = value != 0;
+        if (value >= 512) {                                    // that many KiB of pinned capture instead of the default 16 MiB (tests: small values exercise hc_rebase)
+            uint8_t *np = nullptr; void *dp = nullptr;
+            if (hipHostMalloc((void **)&np, (size_t)value << 10, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, np, 0) != hipSuccess) FAIL(NRSC5HIP_ENOMEM, "pinned capture allocation failed");
+            (void)hipHostFree(e->hc_pin);
+            e->hc_pin = np; e->hc_dev = (uint8_t *)dp; e->hc_cap = (size_t)value << 10;
+        }
+        break;
+    }
     case NRSC5HIP_TUNE_MIXFFT_SYMS: {
         e->mixfft_syms = (value == 2 || value == 4 || value == 8 || value == 16 || value == 32 || (value >= 100 && value <= 140)) ? value : 1;
         if (e->mixfft_syms >= 100) {                           // DIAGNOSTIC LDS padding: never beyond what a workgroup may have beside the kernel's own ~20 KB (an oversized request failed the
@@ -2359,6 +2521,13 @@ extern "C" int nrsc5hip_debug_flow_stats(nrsc5hip_engine *e, long long stats[2])
 {
     if (!e || !stats) return NRSC5HIP_EINVAL;
     stats[0] = e->flow_bursts; stats[1] = e->flow_steps;
+    return 0;
+}
+
+extern "C" int nrsc5hip_debug_host_capture_stats(nrsc5hip_engine *e, long long stats[4])
+{
+    if (!e || !stats) return NRSC5HIP_EINVAL;
+    stats[0] = e->hc_attaches; stats[1] = e->hc_detaches; stats[2] = e->hc_rebases; stats[3] = e->hc_stream;
     return 0;
 }
 

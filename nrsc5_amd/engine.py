@@ -67,7 +67,7 @@ class L2Job(ctypes.Structure):
 
 
 L2_FM_P1, L2_FM_PX, L2_AM = 0, 1, 2
-TUNE_DECODE_STREAMS, TUNE_AM_DECODE_STREAMS, TUNE_VERDICT_LAG, TUNE_SYNC_PHASES, TUNE_FWD_SEGMENTS, TUNE_FWD_WARM, TUNE_AM_SEGMENTS, TUNE_DECODE_CUS, TUNE_DECODE_PRIORITY, TUNE_AM_WARM, TUNE_MIXFFT_SYMS, TUNE_DEFER_WAIT, TUNE_TRACEBACK_WALK, TUNE_SYNC_LANES, TUNE_DIRECT_DECIMATE, TUNE_EARLY_FLUSH_KB, TUNE_SEAM_PREPARE, TUNE_NCO_EXACT, TUNE_FLOW_MIN, TUNE_LOOP_EXACT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19
+TUNE_DECODE_STREAMS, TUNE_AM_DECODE_STREAMS, TUNE_VERDICT_LAG, TUNE_SYNC_PHASES, TUNE_FWD_SEGMENTS, TUNE_FWD_WARM, TUNE_AM_SEGMENTS, TUNE_DECODE_CUS, TUNE_DECODE_PRIORITY, TUNE_AM_WARM, TUNE_MIXFFT_SYMS, TUNE_DEFER_WAIT, TUNE_TRACEBACK_WALK, TUNE_SYNC_LANES, TUNE_DIRECT_DECIMATE, TUNE_EARLY_FLUSH_KB, TUNE_SEAM_PREPARE, TUNE_NCO_EXACT, TUNE_FLOW_MIN, TUNE_LOOP_EXACT, TUNE_HOST_CAPTURE = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20
 L2_STATUS = ("end", "no_audio", "fixed_data", "header_rs", "bad_locators", "too_many_pdus", "hef_overrun", "bad_stream", "bad_length", "audio_end")
 
 
@@ -136,6 +136,7 @@ def load_library(path: str | None = None) -> ctypes.CDLL:
     lib.nrsc5hip_debug_tune.argtypes = [vp, ci, ci]
     lib.nrsc5hip_debug_fwd_stats.argtypes = [vp, vp]
     lib.nrsc5hip_debug_flow_stats.argtypes = [vp, vp]
+    lib.nrsc5hip_debug_host_capture_stats.argtypes = [vp, vp]
     lib.nrsc5hip_debug_k9_stats.argtypes = [vp, vp]
     lib.nrsc5hip_debug_tb_stats.argtypes = [vp, vp]
     lib.nrsc5hip_stage_first_header.argtypes = [vp, vp, ci, ci, ci, vp]
@@ -180,7 +181,7 @@ EXPORTED_SYMBOLS = [
     "nrsc5hip_batch_append_cu8", "nrsc5hip_batch_append_cs16", "nrsc5hip_batch_process", "nrsc5hip_drain",
     "nrsc5hip_p1_frame_packed", "nrsc5hip_p1_frame_bits", "nrsc5hip_batch_fetch", "nrsc5hip_unpack_bits",
     "nrsc5hip_stage_halfband_fm_cu8", "nrsc5hip_stage_fft2048", "nrsc5hip_stage_viterbi_k7", "nrsc5hip_debug_fetch", "nrsc5hip_debug_fetch_costas",
-    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_debug_tune", "nrsc5hip_debug_fwd_stats", "nrsc5hip_debug_flow_stats", "nrsc5hip_abi_version", "nrsc5hip_debug_tb_stats", "nrsc5hip_debug_k9_stats", "nrsc5hip_stage_first_header", "nrsc5hip_debug_seam_totals", "nrsc5hip_debug_seam_counts", "nrsc5hip_drain_ready", "nrsc5hip_stream_set_manual_step", "nrsc5hip_stream_step", "nrsc5hip_stream_step_ahead", "nrsc5hip_debug_poison_results", "nrsc5hip_device_count", "nrsc5hip_device_upload", "nrsc5hip_device_free", "nrsc5hip_batch_fetch_view", "nrsc5hip_batch_fetch_l2_px", "nrsc5hip_batch_fetch_l2_am",
+    "nrsc5hip_debug_fetch_q15", "nrsc5hip_debug_alloc_copy", "nrsc5hip_debug_free", "nrsc5hip_reset_all", "nrsc5hip_profile", "nrsc5hip_stage_selftest", "nrsc5hip_stage_viterbi_k7_debug", "nrsc5hip_stage_viterbi_bench", "nrsc5hip_debug_sync_phases", "nrsc5hip_debug_tune", "nrsc5hip_debug_fwd_stats", "nrsc5hip_debug_flow_stats", "nrsc5hip_debug_host_capture_stats", "nrsc5hip_abi_version", "nrsc5hip_debug_tb_stats", "nrsc5hip_debug_k9_stats", "nrsc5hip_stage_first_header", "nrsc5hip_debug_seam_totals", "nrsc5hip_debug_seam_counts", "nrsc5hip_drain_ready", "nrsc5hip_stream_set_manual_step", "nrsc5hip_stream_step", "nrsc5hip_stream_step_ahead", "nrsc5hip_debug_poison_results", "nrsc5hip_device_count", "nrsc5hip_device_upload", "nrsc5hip_device_free", "nrsc5hip_batch_fetch_view", "nrsc5hip_batch_fetch_l2_px", "nrsc5hip_batch_fetch_l2_am",
     "nrsc5hip_stream_set_mode", "nrsc5hip_am_frame_bits", "nrsc5hip_stage_viterbi_k9", "nrsc5hip_px_frame_bits",
     "nrsc5hip_batch_fetch_px", "nrsc5hip_debug_fetch_px", "nrsc5hip_stage_viterbi_k9_bench",
     "nrsc5hip_l2_index", "nrsc5hip_stage_l2_index", "nrsc5hip_l2_frame_get", "nrsc5hip_batch_fetch_l2",
@@ -352,7 +353,7 @@ class Engine:
         """deferred steps / mispredicted read positions / steps without P1 decode launches / late P1 decodes (calling thread)"""
         out = np.zeros(6, dtype=np.float64)
         self.lib.nrsc5hip_debug_seam_counts(out.ctypes.data, int(reset))
-        return dict(zip(("deferred_steps", "mispredicted_rd", "steps_without_p1_launches", "late_p1_decodes", "steps_ahead"), (int(x) for x in out)))
+        return dict(zip(("deferred_steps", "mispredicted_rd", "steps_without_p1_launches", "late_p1_decodes", "steps_ahead", "host_capture_pushes"), (int(x) for x in out)))
 
     def p1_frame_bits(self, stream: int, slot: int) -> np.ndarray:
         bits = np.zeros(P1_BITS, dtype=np.uint8)
@@ -529,6 +530,12 @@ class Engine:
         st = (ctypes.c_longlong * 2)()
         self._check(self.lib.nrsc5hip_debug_flow_stats(self._h, st))
         return int(st[0]), int(st[1])
+
+    def host_capture_stats(self):
+        """host-resident capture of the fast seam (TUNE_HOST_CAPTURE): dict(attaches, detaches, rebases, stream)"""
+        st = (ctypes.c_longlong * 4)()
+        self._check(self.lib.nrsc5hip_debug_host_capture_stats(self._h, st))
+        return dict(zip(("attaches", "detaches", "rebases", "stream"), (int(x) for x in st)))
 
     def tb_stats(self):
         """single-path traceback: (chunk boundaries checked, chunks re-walked) since the engine was created"""

@@ -1286,7 +1286,9 @@ def check_deferred_seam(lib, names=("ppm+60", "ppm-85_cs16", "ppm+100_cfo_search
             E = eng.Engine(max_streams=1, q15_capacity=200000, record_capacity=256, p1_slots=8, lib_path=lib)
             E.seam_counts(reset=True)
             if mode == "sync":                                   # round 3's seam: wait at once, H2D copy + decimator + commit, k_prepare as its own launch
-                E.tune(eng.TUNE_DEFER_WAIT, 0); E.tune(eng.TUNE_DIRECT_DECIMATE, 0); E.tune(eng.TUNE_SEAM_PREPARE, 0)
+                E.tune(eng.TUNE_DEFER_WAIT, 0); E.tune(eng.TUNE_DIRECT_DECIMATE, 0); E.tune(eng.TUNE_SEAM_PREPARE, 0); E.tune(eng.TUNE_HOST_CAPTURE, 0)
+            if mode == "fifo":                                   # rounds 4 - 5: deferred wait over pinned staging + the direct decimator
+                E.tune(eng.TUNE_HOST_CAPTURE, 0)
             if mode in ("dropin", "ahead"):
                 E.set_manual_step(0, True)
             recs, frames = [], []
@@ -1320,13 +1322,16 @@ def check_deferred_seam(lib, names=("ppm+60", "ppm-85_cs16", "ppm+100_cfo_search
                         take(E.drain(0))
             take(E.drain(0))
             counts = E.seam_counts()
+            hcs = E.host_capture_stats()
+            # round 6: a cu8 session of the default seam reads the pinned capture in place (every push one host copy); cs16 input never does
+            assert (hcs["attaches"] == 1 and counts["host_capture_pushes"] > 0) == (cu8 and mode not in ("sync", "fifo")), (mode, hcs, counts)
             E.close()
             return np.concatenate(recs), frames, counts
         ref, ref_frames, c0 = run("sync")
         assert c0["deferred_steps"] == 0 and len(ref) >= 30 and len(ref_frames) >= 1
         fine = sum(1 for r in ref[:-1] if int(r["state_after"]) == 2)
         assert sum(1 for r in ref if int(r["state_before"]) == 2 and int(r["samperr"]) != 1080) >= 5, "the capture does not move the timing pick"
-        for mode in ("deferred", "dropin", "ahead"):
+        for mode in ("deferred", "fifo", "dropin", "ahead"):
             got, frames, c = run(mode)
             assert got.tobytes() == ref.tobytes(), (name, mode)
             assert len(frames) == len(ref_frames) and all(np.array_equal(a, b) for a, b in zip(frames, ref_frames))
@@ -1436,3 +1441,62 @@ def check_flow_bursts(lib, caps, l2_feedback=True, min_flow_steps=8):
         diffs = common.compare_logs(l2[k], l3[k])
         assert not diffs, (k, diffs[:10])
     return s1
+
+
+def check_host_capture_seam(lib, names=("ppm+60", "ppm+100_cfo_search"), capture_kib=640):
+    """Round 6's seam for FM cu8: the session's bytes stay in a pinned capture that the stream reads in place (NRSC5HIP_TUNE_HOST_CAPTURE).  Against the FIFO seam
+    (pinned staging + decimator kernel) on the same pushes, records and frames bit-identical, through: (1) a capture buffer barely larger than two windows, so
+    that the live tail moves to the front of the buffer every other block (hc_rebase); (2) a session that turns to cs16 input in its middle (the capture becomes the
+    FIFO again: hc_detach re-pushes the bytes behind the read position); (3) two captures on one stream with nrsc5hip_stream_reset between them: the second
+    session's first decimator outputs see what the first left in decim[0]'s rewound window (StaleWindows), told from the capture instead of by the decimator kernel;
+    (4) the batch entry point on a stream that holds a capture."""
+    for name in names:
+        cap = synth.fm_mp1_capture(**common.IMPAIRED_FM_CASES[name])
+        assert cap.iq.dtype == np.uint8
+        raw = cap.iq[:cap.iq.size - cap.iq.size % 4]
+
+        def session(E, data, chunk, cs16_from=None):
+            recs = []
+            for off in range(0, data.size, chunk):
+                piece = data[off:off + chunk]
+                if cs16_from is not None and off >= cs16_from:
+                    # (every other complex sample as Q15: not the half-band's output, but the same for both engines, and near enough to keep the receiver working)
+                    E.push_cs16(0, np.ascontiguousarray(((piece.astype(np.int16) - 127) * 64).reshape(-1, 2)[::2]).reshape(-1))
+                else:
+                    E.push_cu8(0, piece)
+                recs.append(E.drain(0))
+            recs.append(E.drain(0))
+            return np.concatenate(recs)
+
+        def run(hc, what):
+            E = eng.Engine(max_streams=1, q15_capacity=400000, record_capacity=512, p1_slots=8, lib_path=lib)
+            E.tune(eng.TUNE_HOST_CAPTURE, capture_kib if hc else 0)
+            out = []
+            if what == "plain":
+                out.append(session(E, raw, 32768))
+            elif what == "cs16":
+                out.append(session(E, raw, 65536, cs16_from=raw.size // 2 // 65536 * 65536))
+            elif what == "reset":
+                out.append(session(E, raw[:raw.size // 3 // 4 * 4 + 8], 50000))    # ends inside a block, 4-byte granular, with bytes that were never stepped
+                E.reset(0)
+                out.append(session(E, raw, 1 << 20))
+            elif what == "batch":
+                half = raw.size // 2 // 4 * 4
+                out.append(session(E, raw[:half], 32768))
+                E.batch_process(1)                                  # leaves the seam's mirror: the capture must become a FIFO of known length first
+                out.append(E.drain(0))
+                out.append(session(E, raw[half:], 32768))
+            frames = [E.p1_frame_bits(0, int(r["p1_slot"])).copy() for r in out[-1] if int(r["flags"]) & eng.REC_P1][-1:]
+            st = E.host_capture_stats()
+            E.close()
+            return [o.tobytes() for o in out], frames, st
+        for what in ("plain", "cs16", "reset", "batch"):
+            a, fa, _ = run(False, what)
+            b, fb, st = run(True, what)
+            assert st["attaches"] == (2 if what == "reset" else 1), (what, st)
+            assert a == b, (name, what)
+            assert len(fa) == len(fb) and all(np.array_equal(x, y) for x, y in zip(fa, fb)), (name, what)
+            if what == "plain":
+                assert st["rebases"] >= 5 and st["detaches"] == 0, st
+            if what in ("cs16", "batch"):
+                assert st["detaches"] == 1, st

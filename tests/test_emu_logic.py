@@ -260,6 +260,10 @@ def test_emu_deferred_seam_equals_synchronous(emu_lib):
     ec.check_deferred_seam(emu_lib)
 
 
+def test_emu_host_capture_seam_equals_fifo_seam(emu_lib):
+    ec.check_host_capture_seam(emu_lib, names=("ppm+100_cfo_search",))
+
+
 @pytest.mark.parametrize("syms", [4, 16])
 def test_emu_symbol_kernel_variants(emu_lib, syms):
     """k_mixfft's knob forms -- 4 symbols in a row per workgroup (next-symbol prefetch), 16 = two symbols side by side in a 256-lane

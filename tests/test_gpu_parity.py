@@ -416,6 +416,12 @@ def test_gpu_deferred_seam_equals_synchronous(hip_lib):
     ec.check_deferred_seam(hip_lib)
 
 
+def test_gpu_host_capture_seam_equals_fifo_seam(hip_lib):
+    """round 6's seam for FM cu8 (the session's bytes stay in a pinned capture the stream reads in place across PCIe) against the FIFO seam on the same pushes:
+    records and frames bit-identical through buffer rebases, a cs16 push in mid-session, a reset of a used session, the batch entry point"""
+    ec.check_host_capture_seam(hip_lib)
+
+
 @pytest.mark.parametrize("syms", [4, 16])
 def test_gpu_symbol_kernel_variants(hip_lib, syms):
     """k_mixfft's knob forms (4 symbols in a row per workgroup; 16 = two symbols side by side in a 256-lane workgroup): identical records"""

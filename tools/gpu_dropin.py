@@ -13,4 +13,4 @@ iq = np.ascontiguousarray(W.stream_iq(0))
 W.E.close(); del W
 for rep in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
     out = bench.dropin_leg(iq, bench.FS)
-    print(json.dumps({k: out.get(k) for k in ("dropin", "plain", "events_equal", "events", "breakdown")}))
+    print(json.dumps({k: out.get(k) for k in ("dropin", "dropin_strict_delivery", "plain", "events_equal", "events_equal_strict_delivery", "events", "breakdown")}))
