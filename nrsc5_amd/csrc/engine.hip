@@ -107,6 +107,7 @@ struct nrsc5hip_engine {
     int fwd_warm;                      // test hook: speculative warm-up trips of a forward segment (2; 0 makes every speculation fail -> repair path)
     int mixfft_syms;                   // symbols per k_mixfft workgroup (1, 2, 4, 8)
     int sync_lanes;                    // work-items per stream of k_sync: 0 = by the size of the stream set, 256, 768
+    int fold_report;                   // 1 (default): fast seam, a step with nothing behind k_sync: k_sync posts the report (NRSC5HIP_TUNE_FOLD_REPORT = 0: k_stream_tail as a launch of its own)
     int fuse_seam_prepare;             // 1 (default): fast seam, FINE stream: no k_prepare launch (NRSC5HIP_TUNE_SEAM_PREPARE = 0: separate launch)
     int tb_walk;                       // > 0: single-path traceback (k_p1_tbwalk + check): 1 (default) = a workgroup per (frame, part), N > 1 = a persistent grid of N workgroups (opt-in); 0: the block-parallel one of round 3
     int fwd_segments;                  // waves per frame of the P1 forward pass; 0 = pick from the size of the stream set (fwd_segments_for)
@@ -178,11 +179,17 @@ struct nrsc5hip_engine {
     // decimated sample a = dword a of that numbering, so the stream's counters start at HC_OFF.  The buffer is linear: when it is full the live tail moves to its
     // front and `raw` moves with it (hc_rebase).  Anything the capture cannot express (a cs16 push, the batch entry points) first turns it back into the FIFO (hc_detach).
     static constexpr long long HC_OFF = 8, HC_PREFIX = 4 * HC_OFF, HC_KEEP = 16384;
-    uint8_t *hc_pin, *hc_dev; size_t hc_cap;
+    uint8_t *hc_pin, *hc_dev; size_t hc_cap; unsigned hc_mem_flags;
     int hc_stream;                     // the stream bound to the buffer, -1: none
     long long hc_abs0, hc_wr;          // byte index (stream numbering) of hc_pin[0] / of the next byte to be written
     bool host_capture;                 // knob (default on where the buffer exists)
     long long hc_rebases, hc_attaches, hc_detaches;
+    long long reports_folded;          // block steps whose report the sync kernel posted itself (fold_report)
+    // Early symbols (host-resident capture, NRSC5HIP_TUNE_EARLY_SYMBOLS): once the first early_syms OFDM symbols of a FINE stream's next block lie in the capture -- the host knows
+    // where they start: read position + the previous block's timing feedback -- their transforms are launched at once; the call that completes the block launches the rest.
+    int early_syms;                    // 0 = off
+    long long early_rd;                // read position of the block whose early symbols are launched (-1: none)
+    long long early_launches;
     std::vector<std::array<c16, 14>> hb_hist_host;   // the decimator history each stream's last reset left on the device (zeros for a fresh session)
     // staging
     uint8_t *stage_dev; size_t stage_bytes;
@@ -472,7 +479,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             // profiles/r05_trace_sync_decode_streams.txt): 30.1 -> 29.2 ms per pass.  AM: three, with four segment waves per P3 frame (round 5, on the
             // rewritten block step: 70.4 ms with two streams x eight segments, 67.5 with three x eight, 65.7 with three x four, 91.3 with one: the K=9 decodes are ~80 ms of kernel time per pass)
             e->naux = 1; e->naux_am = 3;
-            e->verdict_lag = 0; e->fwd_segments = 0; e->fwd_warm = 2; e->mixfft_syms = 1; e->sync_lanes = 0; e->flow_min = 0; e->tb_walk = 1; e->fuse_seam_prepare = 1;      // measured: profiles/r04_mixfft_persistent.txt
+            e->verdict_lag = 0; e->fwd_segments = 0; e->fwd_warm = 2; e->mixfft_syms = 1; e->sync_lanes = 0; e->flow_min = 0; e->tb_walk = 1; e->fuse_seam_prepare = 1; e->fold_report = 1;      // measured: profiles/r04_mixfft_persistent.txt
             e->am_segments = 4; e->am_warm = K9_WARM; e->am_runin = K9_TB_RUNIN;
         }
         {
@@ -640,7 +647,8 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             }
             if (rc) break;
         }
-        e->hc_stream = -1; e->hc_abs0 = 0; e->hc_wr = 0; e->host_capture = false; e->hc_rebases = e->hc_attaches = e->hc_detaches = 0;
+        e->hc_stream = -1; e->hc_abs0 = 0; e->hc_wr = 0; e->host_capture = false; e->hc_rebases = e->hc_attaches = e->hc_detaches = 0; e->reports_folded = 0;
+        e->early_syms = 0; e->early_rd = -1; e->early_launches = 0;
         if (!cfg->p1_async) {
             e->hc_cap = 16u << 20;                             // 58 FM blocks between two rebases (~300 KB of host memmove each)
             void *hp = nullptr;
@@ -774,7 +782,8 @@ static int launch_inorder_p1(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int 
 // decode_p1 = false (fast streaming seam only): the caller KNOWS that no listed stream can complete a P1 frame in this step
 // local_prepare (fast streaming seam, stream known to be FINE): no k_prepare launch -- the symbol kernel computes the block's
 // bookkeeping for itself and the sync kernel commits it
-static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const int *ids_dev, bool decode_p1 = true, bool decode_pids = true, bool local_prepare = false)
+struct StepReport { StreamReport *out; unsigned seq; int first_rec; bool folded; };   // fast seam: the report the step's last kernel may post itself (issue_step sets `folded` when k_sync did)
+static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const int *ids_dev, bool decode_p1 = true, bool decode_pids = true, bool local_prepare = false, StepReport *rep = nullptr)
 {
     const bool async = e->cfg.p1_async != 0;
     const long long window = ln.step_count / 16;
@@ -800,11 +809,23 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
     // exact-oscillator blocks (a freshly reset stream up to its first lock): only a stream that is not FINE can be in that mode, and
     // those only advance on steps that run the acquisition kernels
     if (ln.db.nco_tab && (ln.acq_needed || ln.db.nco_policy == NCO_EXACT_ALWAYS)) { ProfScope p(e, NRSC5HIP_PROF_PREPARE, ln.main); launch_nco_exact(ln.db, n, ids_dev, ln.main); }
-    { ProfScope p(e, NRSC5HIP_PROF_MIXFFT, ln.main); launch_mixfft(e->tb, ln.db, n, ids_dev, ln.main, e->mixfft_syms, fused_prepare ? 1 : 0); }
+    {
+        // fast seam: the block's first symbols may be transformed already (hc_early_symbols) -- valid only for the very conditions they were launched under
+        int sym0 = 0;
+        if (e->early_rd >= 0) {
+            if (fused_prepare && n == 1 && e->hc_stream >= 0 && ids_dev == e->all_ids_dev + e->hc_stream && e->early_rd == e->rd_host[e->hc_stream] && e->mixfft_syms == 1) sym0 = e->early_syms;
+            e->early_rd = -1;
+        }
+        ProfScope p(e, NRSC5HIP_PROF_MIXFFT, ln.main); launch_mixfft(e->tb, ln.db, n, ids_dev, ln.main, e->mixfft_syms, fused_prepare ? 1 : 0, sym0, NSYM - sym0);
+    }
     const int slot = async ? (int)(ln.step_count % 16) : 0;
     // batch pipeline: once every stream of the set is FINE, the next block's bookkeeping rides in k_sync's tail
     const int fuse = (async && !ln.acq_needed) ? 1 : 0;
-    { ProfScope p(e, NRSC5HIP_PROF_SYNC, ln.main); launch_sync(e->tb, ln.db, n, ids_dev, parity, slot, fuse, (int)window, ln.main, e->sync_lanes, decode_pids ? 0 : 1, fused_prepare ? 1 : 0, ln.px_needed ? 1 : 0); }
+    // nothing runs behind k_sync on this step (no PX kernels, no separate PIDS decode, no in-order P1 decode): it posts the step's report itself
+    const bool fold = rep && n == 1 && !async && !ln.px_needed && !decode_pids && !decode_p1;
+    { ProfScope p(e, NRSC5HIP_PROF_SYNC, ln.main); launch_sync(e->tb, ln.db, n, ids_dev, parity, slot, fuse, (int)window, ln.main, e->sync_lanes, decode_pids ? 0 : 1, fused_prepare ? 1 : 0, ln.px_needed ? 1 : 0,
+                                                                fold ? rep->out : nullptr, fold ? rep->seq : 0u, fold ? rep->first_rec : 0); }
+    if (rep) rep->folded = fold;
     ln.prepared_by_sync = fuse != 0;
     if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_px_deint(e->tb, ln.db, n, ids_dev, parity, slot, ln.main); }
     if (!async) {
@@ -1069,13 +1090,20 @@ static int wait_report(nrsc5hip_engine *e, unsigned seq, bool block)
     return 1;
 }
 
-static int launch_report(nrsc5hip_engine *e, int s, bool with_pids)
+// the next report's sequence number, buffer and first record
+static StepReport next_report(nrsc5hip_engine *e, int s)
 {
     e->report_seq++;
     if (e->report_seq == 0) e->report_seq = 2;                 // 0 = the freshly cleared report; 2, not 1: the step before the wrap posted into buffer 1 (seq & 1)
     // records to post: from the first one the host has not seen -- the block of a step still in flight is not this step's to report
     const int first_rec = e->fetched[s] + ((e->inflight_stream == s) ? 1 : 0);
-    launch_stream_tail(e->tb, e->lane.db, s, first_rec, e->report_dev[e->report_seq & 1], e->report_seq, with_pids ? 1 : 0, e->lane.main);
+    return StepReport{ e->report_dev[e->report_seq & 1], e->report_seq, first_rec, false };
+}
+
+static int launch_report(nrsc5hip_engine *e, int s, bool with_pids, const StepReport *prepared = nullptr)
+{
+    const StepReport r = prepared ? *prepared : next_report(e, s);
+    launch_stream_tail(e->tb, e->lane.db, s, r.first_rec, r.out, r.seq, with_pids ? 1 : 0, e->lane.main);
     e->counters_clean = true;
     HIPCHK(hipGetLastError());
     return 0;
@@ -1165,7 +1193,8 @@ static int submit_step(nrsc5hip_engine *e, int s, bool ahead = false)
     // A P1 frame completes only in a block that starts FINE with block count 15 (k_sync: started_pm && bc == 15; a block that
     // locks restarts the frame): when the stream's last record says otherwise the three decode launches are left out.
     const bool known = e->pred_ok[s] && !e->cfg.l2_feedback;
-    bool decode = true;
+    bool decode = true, have_rep = false;
+    StepReport rep{};
     if (am) {
         ProfScope p(e, NRSC5HIP_PROF_AM, ln.main);
         launch_am_step(e->tb, ln.db, 1, ids_dev, ln.main, e->cfg.l2_feedback, -1, (int)(ln.am_step_count % 8), (int)(ln.am_step_count / 8));
@@ -1175,9 +1204,11 @@ static int submit_step(nrsc5hip_engine *e, int s, bool ahead = false)
         const int bc = ahead ? (e->pred_bc[s] + 1) % 16 : e->pred_bc[s];
         decode = !(known && bc != 15);
         if (!decode) g_seam[10] += 1;
-        int rc = issue_step(e, ln, 1, ids_dev, decode, false, known && e->fuse_seam_prepare); if (rc) return rc;   // PIDS frame: inside k_sync (pids_inline)
+        rep = next_report(e, s); have_rep = true;
+        int rc = issue_step(e, ln, 1, ids_dev, decode, false, known && e->fuse_seam_prepare, e->fold_report ? &rep : nullptr); if (rc) return rc;   // PIDS frame: inside k_sync (pids_inline)
     }
-    { int rc = launch_report(e, s, false); if (rc) return rc; }    // FM: the PIDS frame was decoded inside k_sync; AM: inside its block kernel
+    if (have_rep && rep.folded) { e->counters_clean = true; e->reports_folded++; }        // k_sync posted it
+    else { int rc = launch_report(e, s, false, have_rep ? &rep : nullptr); if (rc) return rc; }    // FM: the PIDS frame was decoded inside k_sync; AM: inside its block kernel
     g_seam[2] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enq).count();
     g_seam[6] += 1;
     if (ahead) { e->ahead.valid = true; e->ahead.stream = s; e->ahead.seq = e->report_seq; e->ahead.decoded = decode; g_seam[12] += 1; return 0; }
@@ -1359,7 +1390,7 @@ static int hc_detach(nrsc5hip_engine *e)
     if (hc_stale_hb(e, consumed, sw)) HIPCHK(hipMemcpy((char *)(e->db.state + s) + offsetof(StreamState, stale) + offsetof(StaleWindows, hb), sw, sizeof(sw), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy((char *)(e->db.state + s) + offsetof(StreamState, stale) + offsetof(StaleWindows, hb_pushed), &consumed, sizeof(consumed), hipMemcpyHostToDevice));
     e->wr_host[s] = rd; e->base_host[s] = rd;
-    e->hc_stream = -1; e->hc_detaches++;
+    e->hc_stream = -1; e->hc_detaches++; e->early_rd = -1;
     const long long tail0 = 4 * rd, ntail = e->hc_wr - tail0;
     if (ntail > 0) {
         // (the source is the pinned capture itself: nothing writes it while the stream is unbound)
@@ -1369,6 +1400,28 @@ static int hc_detach(nrsc5hip_engine *e)
         e->manual_step[s] = manual; e->host_capture = keep;
         if (rc) return rc;
     }
+    return 0;
+}
+
+// see nrsc5hip_engine::early_syms.  Called after a push into the capture that did not complete the block.
+static int hc_early_symbols(nrsc5hip_engine *e, int s)
+{
+    nrsc5hip_engine::Lane &ln = e->lane;
+    if (e->early_rd == e->rd_host[s]) return 0;                // launched for this block already
+    // exactly submit_step's conditions for the fused seam (the symbol kernel computes the block's bookkeeping for itself): FINE by the last record, nothing in flight that could
+    // change the stream's state before this block starts, no acquisition pending, closed-form oscillator
+    if (e->inflight_stream >= 0 || e->ahead.valid || !e->pred_ok[s] || e->cfg.l2_feedback || !e->fuse_seam_prepare || ln.acq_needed || e->prof_on ||
+        e->mixfft_syms != 1 || ln.db.nco_policy == NCO_EXACT_ALWAYS) return 0;
+    // a block that starts FINE picks its first symbol at rd + 1080 + the previous block's timing feedback (acquire.c:112); symbol i ends SYM_N (i + 1) samples later
+    const long long a00 = e->rd_host[s] + SYM_N / 2 + e->pred_samperr[s];
+    if (e->wr_host[s] < a00 + (long long)SYM_N * e->early_syms + 16) return 0;
+    const unsigned long long sig = set_signature(1, &s);
+    if (sig != ln.set_sig) return 0;
+    const auto t_enq = std::chrono::steady_clock::now();
+    { ProfScope p(e, NRSC5HIP_PROF_MIXFFT, ln.main); launch_mixfft(e->tb, ln.db, 1, e->all_ids_dev + s, ln.main, 1, 1, 0, e->early_syms); }
+    HIPCHK(hipGetLastError());
+    g_seam[2] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enq).count();
+    e->early_rd = e->rd_host[s]; e->early_launches++;
     return 0;
 }
 
@@ -1404,7 +1457,7 @@ static int push_common(nrsc5hip_engine *e, int s, const void *host, size_t nbyte
             if (e->wr_host[s] - e->rd_host[s] >= window_of(e, s)) {
                 if (e->manual_step[s] && nbytes_total == 0) break;     // nrsc5hip_stream_step runs the block
                 if ((rc = stream_steps(e, s))) return rc;
-            }
+            } else if (e->early_syms > 0 && (rc = hc_early_symbols(e, s))) return rc;
             continue;
         }
         if (fast) {
@@ -1510,7 +1563,7 @@ static int reset_stream(nrsc5hip_engine *e, int stream, bool keep_windows)
         HIPCHK(hipMemset(e->db.am_job + (size_t)stream * NWIN, 0, NWIN * sizeof(AmJob)));
         HIPCHK(hipMemset(e->db.am_pids_rec + (size_t)stream * NWIN * 8, 0xff, NWIN * 8 * sizeof(int)));
     }
-    if (was_hc) e->hc_stream = -1;
+    if (was_hc) { e->hc_stream = -1; e->early_rd = -1; }
     memcpy(e->hb_hist_host[stream].data(), st.hb_hist, sizeof(st.hb_hist));
     e->wr_host[stream] = 0; e->base_host[stream] = 0; e->drained[stream] = 0; e->raw_host[stream] = 0; e->attached[stream] = 0;
     e->rd_host[stream] = 0; e->fetched[stream] = 0; e->pending[stream].clear(); e->mirror_ok[stream] = e->cfg.p1_async ? 0 : 1;
@@ -1543,6 +1596,7 @@ extern "C" int nrsc5hip_force_resync(nrsc5hip_engine *e, int stream)
     int rc = check_stream(e, stream); if (rc) return rc;
     hipLaunchKernelGGL(k_force_none, dim3(1), dim3(1), 0, e->main, e->db, stream);
     forget_prediction(e, stream);
+    e->early_rd = -1;                                          // (symbols transformed ahead assumed a FINE start)
     e->lane.acq_needed = true; e->lane.px_needed = true; e->lane.set_sig = 0;
     HIPCHK(hipGetLastError());
     return 0;
@@ -2456,6 +2510,25 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
         }
         break;
     }
+    case NRSC5HIP_TUNE_CHAIN_CUS: {
+        // the block-step chain's own stream confined to a few CUs: value = 100 * CUs + stride between their mask bits (1: neighbouring bits, 8: every eighth -- with the mask
+        // bits dealt round robin to the eight XCDs that is ONE XCD); 0 = no mask.  Why: a lone stream's step is two small kernels every ~90 us, and wherever the dispatcher
+        // puts them they start on cold instruction caches and a cold L2 (k_sync alone executes ~40 KB of code once) -- on the same few CUs of one XCD the code, the stream
+        // state and the bins the symbol kernel has just written are where the last step left them.
+        const int ncu = value / 100, stride = std::max(value % 100, 1);
+        hipStream_t fresh = nullptr;
+        if (ncu <= 0) HIPCHK(hipStreamCreate(&fresh));
+        else {
+            hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, e->cfg.device));
+            const int total = prop.multiProcessorCount, words = (total + 31) / 32;
+            std::vector<uint32_t> mask((size_t)words, 0u);
+            for (int i = 0, bit = 0; i < ncu && bit < total; i++, bit += stride) mask[(size_t)bit / 32] |= 1u << (bit % 32);
+            HIPCHK(hipExtStreamCreateWithCUMask(&fresh, (uint32_t)words, mask.data()));
+        }
+        (void)hipStreamDestroy(e->lane.main);
+        e->lane.main = fresh; e->main = fresh;
+        break;
+    }
     case NRSC5HIP_TUNE_DECODE_PRIORITY: {
         int least = 0, greatest = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
@@ -2471,6 +2544,8 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
     case NRSC5HIP_TUNE_TRACEBACK_WALK:    e->tb_walk = std::min(std::max(value, 0), 16384); break;
     case NRSC5HIP_TUNE_SYNC_LANES:        e->sync_lanes = (value == 256 || value == 768) ? value : 0; break;
     case NRSC5HIP_TUNE_SEAM_PREPARE:      e->fuse_seam_prepare = value != 0; break;
+    case NRSC5HIP_TUNE_FOLD_REPORT:       e->fold_report = value != 0; break;
+    case NRSC5HIP_TUNE_EARLY_SYMBOLS:     e->early_syms = std::min(std::max(value, 0), NSYM - 1); e->early_rd = -1; break;
     case NRSC5HIP_TUNE_NCO_EXACT:         e->db.nco_policy = e->lane.db.nco_policy = e->db.nco_tab ? std::min(std::max(value, 0), (int)NCO_EXACT_ALWAYS) : (int)NCO_CLOSED_FORM; break;
     case NRSC5HIP_TUNE_FLOW_MIN:          e->flow_min = std::max(value, 0); break;
     case NRSC5HIP_TUNE_LOOP_EXACT:        e->db.loop_exact = e->lane.db.loop_exact = std::min(std::max(value, 0), 2); break;
@@ -2483,10 +2558,24 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
         e->host_capture = value != 0;
         if (value >= 512) {                                    // that many KiB of pinned capture instead of the default 16 MiB (tests: small values exercise hc_rebase)
             uint8_t *np = nullptr; void *dp = nullptr;
-            if (hipHostMalloc((void **)&np, (size_t)value << 10, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer(&dp, np, 0) != hipSuccess) FAIL(NRSC5HIP_ENOMEM, "pinned capture allocation failed");
+            if (hipHostMalloc((void **)&np, (size_t)value << 10, hipHostMallocMapped | e->hc_mem_flags) != hipSuccess || hipHostGetDevicePointer(&dp, np, 0) != hipSuccess) FAIL(NRSC5HIP_ENOMEM, "pinned capture allocation failed");
             (void)hipHostFree(e->hc_pin);
             e->hc_pin = np; e->hc_dev = (uint8_t *)dp; e->hc_cap = (size_t)value << 10;
         }
+        break;
+    }
+    case NRSC5HIP_TUNE_HOST_CAPTURE_MEM: {
+        // DIAGNOSTIC: how the capture is mapped for the device -- 0 = HIP's default for pinned host memory (coherent), 1 = hipHostMallocNonCoherent (the device may cache
+        // it between kernel boundaries), 2 = hipHostMallocWriteCombined; the buffer is re-allocated at its current size
+        if (e->hc_stream >= 0) { int rc = hc_detach(e); if (rc) return rc; }
+        if (!e->hc_pin) break;
+#ifndef HIPEMU
+        e->hc_mem_flags = value == 1 ? hipHostMallocNonCoherent : value == 2 ? hipHostMallocWriteCombined : 0u;
+#endif
+        uint8_t *np = nullptr; void *dp = nullptr;
+        if (hipHostMalloc((void **)&np, e->hc_cap, hipHostMallocMapped | e->hc_mem_flags) != hipSuccess || hipHostGetDevicePointer(&dp, np, 0) != hipSuccess) FAIL(NRSC5HIP_ENOMEM, "pinned capture allocation failed");
+        (void)hipHostFree(e->hc_pin);
+        e->hc_pin = np; e->hc_dev = (uint8_t *)dp;
         break;
     }
     case NRSC5HIP_TUNE_MIXFFT_SYMS: {
@@ -2524,10 +2613,10 @@ extern "C" int nrsc5hip_debug_flow_stats(nrsc5hip_engine *e, long long stats[2])
     return 0;
 }
 
-extern "C" int nrsc5hip_debug_host_capture_stats(nrsc5hip_engine *e, long long stats[4])
+extern "C" int nrsc5hip_debug_host_capture_stats(nrsc5hip_engine *e, long long stats[6])
 {
     if (!e || !stats) return NRSC5HIP_EINVAL;
-    stats[0] = e->hc_attaches; stats[1] = e->hc_detaches; stats[2] = e->hc_rebases; stats[3] = e->hc_stream;
+    stats[0] = e->hc_attaches; stats[1] = e->hc_detaches; stats[2] = e->hc_rebases; stats[3] = e->hc_stream; stats[4] = e->reports_folded; stats[5] = e->early_launches;
     return 0;
 }
 

@@ -916,21 +916,48 @@ __device__ __forceinline__ void sync_body(uint8_t *lds_base, const DevTables &tb
     SYNC_MARK(7);
 }
 
+// Streaming seam, ONE stream, a block that needs no kernel behind the sync kernel (no P1 frame to decode, no extended sidebands): the report -- k_stream_tail's job -- by the
+// sync kernel's own workgroup, one launch and ~8 us less on a chain the host waits for.  What the other waves of the workgroup stored is read past the vector L1
+// (fence + barrier, then agent-scope loads): the record, the read position, the step counters.
+template <int NT> __device__ __forceinline__ void stream_report_wg(const DevBuffers &db, int s, int first_rec, StreamReport *out, unsigned seq)
+{
+    __threadfence();
+    __syncthreads();
+    const int t = threadIdx.x;
+    const StreamState &st = db.state[s];
+    const int nblocks = (int)flow_load_u32((const unsigned *)&st.nblocks);
+    const int n = min(max(nblocks - first_rec, 0), 4);
+    constexpr int RW = sizeof(BlockRecord) / 4;
+    for (int q = t; q < n * RW; q += NT) {
+        const int k = q / RW, w = q % RW;
+        ((uint32_t *)&out->rec[k])[w] = flow_load_u32((const unsigned *)&db.records[(size_t)s * db.rec_cap + ((first_rec + k) % db.rec_cap)] + w);
+    }
+    if (t < 4) { out->counters[t] = (int)flow_load_u32((const unsigned *)&db.counters[t]); db.counters[t] = 0; }
+    if (t == 0) { out->rd = (long long)flow_load_u64((const unsigned long long *)&st.rd); out->nblocks = nblocks; out->nrec = n; }
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) { *(volatile unsigned *)&out->seq = seq; __threadfence_system(); }
+}
+
 template <int SYNC_NT>
-__global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare, int window, int pids_inline, int do_prepare, int ext_refs)
+__global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare, int window, int pids_inline, int do_prepare, int ext_refs,
+                                                                         StreamReport *report, unsigned report_seq, int report_first)
 {
     wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
     const int s = wave_uniform(stream_of(ids, blockIdx.x));    // in a scalar register: every address derived from it stays off the VGPR budget
     __shared__ __attribute__((aligned(16))) uint8_t lds[sizeof(SyncLds<SYNC_NT>)];
     sync_body<SYNC_NT>(lds, tb, db, s, parity, slot, fuse_prepare, window, pids_inline, do_prepare, ext_refs);
+    if (report) stream_report_wg<SYNC_NT>(db, s, report_first, report, report_seq);      // (kernel argument: uniform; one-stream launches of the fast seam only)
 }
 
-void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, int window, hipStream_t st, int lanes, int pids_inline, int do_prepare, int ext_refs)
+void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, int window, hipStream_t st, int lanes, int pids_inline, int do_prepare, int ext_refs,
+                 StreamReport *report, unsigned report_seq, int report_first)
 {
     // lanes: 0 = by the size of the stream set (see SYNC_OCCUPANCY above), else 256 / 768 (nrsc5hip_debug_tune NRSC5HIP_TUNE_SYNC_LANES)
     const int nt = lanes ? lanes : 768;                        // measured at 256 streams: 32.8 ms per pass with 768, 33.8 with 256 (profiles/r04_sync_lanes.txt)
-    if (nt == 768) hipLaunchKernelGGL(k_sync<768>, dim3(nstreams), dim3(768), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window, pids_inline, do_prepare, ext_refs);
-    else hipLaunchKernelGGL(k_sync<256>, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window, pids_inline, do_prepare, ext_refs);
+    if (nstreams != 1) report = nullptr;
+    if (nt == 768) hipLaunchKernelGGL(k_sync<768>, dim3(nstreams), dim3(768), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window, pids_inline, do_prepare, ext_refs, report, report_seq, report_first);
+    else hipLaunchKernelGGL(k_sync<256>, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window, pids_inline, do_prepare, ext_refs, report, report_seq, report_first);
 }
 
 // ---- deferred PIDS decode: one wave per (slot, stream) with a staged frame -----------------------------------

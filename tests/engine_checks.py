@@ -1286,10 +1286,12 @@ def check_deferred_seam(lib, names=("ppm+60", "ppm-85_cs16", "ppm+100_cfo_search
             E = eng.Engine(max_streams=1, q15_capacity=200000, record_capacity=256, p1_slots=8, lib_path=lib)
             E.seam_counts(reset=True)
             if mode == "sync":                                   # round 3's seam: wait at once, H2D copy + decimator + commit, k_prepare as its own launch
-                E.tune(eng.TUNE_DEFER_WAIT, 0); E.tune(eng.TUNE_DIRECT_DECIMATE, 0); E.tune(eng.TUNE_SEAM_PREPARE, 0); E.tune(eng.TUNE_HOST_CAPTURE, 0)
+                E.tune(eng.TUNE_DEFER_WAIT, 0); E.tune(eng.TUNE_DIRECT_DECIMATE, 0); E.tune(eng.TUNE_SEAM_PREPARE, 0); E.tune(eng.TUNE_HOST_CAPTURE, 0); E.tune(eng.TUNE_FOLD_REPORT, 0)
             if mode == "fifo":                                   # rounds 4 - 5: deferred wait over pinned staging + the direct decimator
                 E.tune(eng.TUNE_HOST_CAPTURE, 0)
-            if mode in ("dropin", "ahead"):
+            if mode == "early":                                  # round 6: the block's first 24 symbols transformed while its last samples are still being pushed
+                E.tune(eng.TUNE_EARLY_SYMBOLS, 24)
+            if mode in ("dropin", "ahead", "early"):
                 E.set_manual_step(0, True)
             recs, frames = [], []
 
@@ -1307,15 +1309,15 @@ def check_deferred_seam(lib, names=("ppm+60", "ppm-85_cs16", "ppm+100_cfo_search
                     piece = call[done:done + room]
                     push(E, piece)
                     done += piece.size
-                    if mode in ("dropin", "ahead"):
+                    if mode in ("dropin", "ahead", "early"):
                         if piece.size >= room:
                             ahead = E.stream_step_ahead(0)
                             take(E.drain(0))
                             if not ahead:
                                 E.stream_step(0)
-                            if mode == "dropin":
+                            if mode in ("dropin", "early"):
                                 take(E.drain_ready(0))
-                        elif mode == "dropin":
+                        elif mode in ("dropin", "early"):
                             take(E.drain_ready(0))               # (mode "ahead": no polling -- on the emulator a poll always finds the step done,
                                                                  # and the path that queues a step behind one in flight would never run)
                     else:
@@ -1325,18 +1327,23 @@ def check_deferred_seam(lib, names=("ppm+60", "ppm-85_cs16", "ppm+100_cfo_search
             hcs = E.host_capture_stats()
             # round 6: a cu8 session of the default seam reads the pinned capture in place (every push one host copy); cs16 input never does
             assert (hcs["attaches"] == 1 and counts["host_capture_pushes"] > 0) == (cu8 and mode not in ("sync", "fifo")), (mode, hcs, counts)
+            # ... and the sync kernel posts the report of every step that has nothing behind it (MP1: all but the blocks that may end a P1 frame and the un-synchronised ones)
+            assert (hcs["reports_folded"] == 0) if mode == "sync" else (hcs["reports_folded"] >= counts["steps_without_p1_launches"] - 2 > 0), (mode, hcs, counts)
             E.close()
+            counts["early_symbol_launches"] = hcs["early_symbol_launches"]
             return np.concatenate(recs), frames, counts
         ref, ref_frames, c0 = run("sync")
         assert c0["deferred_steps"] == 0 and len(ref) >= 30 and len(ref_frames) >= 1
         fine = sum(1 for r in ref[:-1] if int(r["state_after"]) == 2)
         assert sum(1 for r in ref if int(r["state_before"]) == 2 and int(r["samperr"]) != 1080) >= 5, "the capture does not move the timing pick"
-        for mode in ("deferred", "fifo", "dropin", "ahead"):
+        for mode in ("deferred", "fifo", "dropin", "ahead", "early"):
             got, frames, c = run(mode)
             assert got.tobytes() == ref.tobytes(), (name, mode)
             assert len(frames) == len(ref_frames) and all(np.array_equal(a, b) for a, b in zip(frames, ref_frames))
             assert c["mispredicted_rd"] == 0 and c["late_p1_decodes"] == 0, c
             assert c["deferred_steps"] >= fine - 1 and c["steps_without_p1_launches"] >= fine - 1 - len(ref_frames), (c, fine)
+            # (on the device a poll often finds the previous step still running and the early launch -- which needs the stream's state settled -- is skipped for that block; the twin's steps end at once)
+            assert (c["early_symbol_launches"] >= (fine - 3 if "emu" in os.path.basename(lib) else 1)) if (mode == "early" and cu8) else (c["early_symbol_launches"] == 0), (mode, c, fine)
             if mode == "ahead":                                  # every block behind a FINE block without a P1 decode was queued ahead
                 assert c["steps_ahead"] >= fine - 2 - 2 * len(ref_frames), (c, fine)
 

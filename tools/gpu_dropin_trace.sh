@@ -22,7 +22,7 @@ print(len(ops), "ops,", len(syncs), "k_sync launches")
 if len(syncs) > 150:
     lo, hi = syncs[-120], syncs[-100]
     # start at a report kernel boundary
-    while lo > 0 and not ops[lo][2].startswith("k_stream_tail"): lo -= 1
+    while lo > 0 and not (ops[lo][2].startswith("k_stream_tail") or ops[lo][2].startswith("k_sync")): lo -= 1      # (round 6: most steps end with k_sync, which posts the report itself)
     t0 = ops[lo][1]
     prev_end = t0
     for s, e, n in ops[lo + 1:hi]:
