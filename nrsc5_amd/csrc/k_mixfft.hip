@@ -23,17 +23,37 @@
 #include "halfband_raw.h"
 #include "prepare_block.h"
 
+#include "flow_ops.h"
 #include "mixfft_body.h"
 
 namespace nrsc5 {
 
 template <int SPW, int NPAR>
-__global__ __launch_bounds__(128 * NPAR) MIXFFT_OCCUPANCY void k_mixfft(DevTables tb, DevBuffers db, const int *ids, int local_prepare, int wg0)
+__global__ __launch_bounds__(128 * NPAR) MIXFFT_OCCUPANCY void k_mixfft(DevTables tb, DevBuffers db, const int *ids, int local_prepare)
 {
     wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
     const int s = wave_uniform(stream_of(ids, blockIdx.y));
     __shared__ __attribute__((aligned(16))) uint8_t lds[sizeof(MixLds<NPAR>)];
-    mixfft_wg<SPW, NPAR>(lds, tb, db, s, (int)blockIdx.x + wg0, local_prepare);     // (wg0: a launch that covers part of the block's symbols -- fast seam, launch_mixfft's sym0 / nsym)
+    mixfft_wg<SPW, NPAR>(lds, tb, db, s, (int)blockIdx.x, local_prepare);
+}
+
+// The fast seam's side-by-side step (engine.hip, issue_step): the sync kernel of the same block is launched right behind this one on a second HIP stream and waits, at its very
+// start, for `done` to reach the number of symbol workgroups -- so that its dispatch and wave launch, and this kernel's retirement, leave the chain the host waits for.
+// Closed-form blocks only (the fused seam: FINE streams), whose bins leave write-through; every workgroup counts, active or not.
+__global__ __launch_bounds__(128) MIXFFT_OCCUPANCY void k_mixfft_signal(DevTables tb, DevBuffers db, const int *ids, int local_prepare, unsigned *done)
+{
+    wave_set_priority_high();
+    const int s = wave_uniform(stream_of(ids, blockIdx.y));
+    __shared__ __attribute__((aligned(16))) uint8_t lds[sizeof(MixLds<1>)];
+    mixfft_wg<1, 1, false, true>(lds, tb, db, s, (int)blockIdx.x, local_prepare);
+    flow_drain_stores();                                       // this wave's write-through stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) (void)flow_add_u32(done, 1u);
+}
+
+void launch_mixfft_signal(const DevTables &tb, const DevBuffers &db, const int *stream_id, hipStream_t st, int local_prepare, unsigned *done)
+{
+    hipLaunchKernelGGL(k_mixfft_signal, dim3(NSYM, 1), dim3(128), 0, st, tb, db, stream_id, local_prepare, done);
 }
 
 // =====================================================================================================================
@@ -366,18 +386,15 @@ void launch_nco_exact(const DevBuffers &db, int nstreams, const int *stream_ids,
 // at 256 streams -- were MEASURED SLOWER than one symbol per workgroup (profiles/r04_mixfft_persistent.txt: 74 vs 63 us per launch,
 // pass 36.0 vs 33.0 ms): the stage-A twiddle loads, which the one-symbol kernel issues at its very start beside the capture loads,
 // cannot be held across the loop (28 VGPRs) and are exposed once per symbol behind a barrier.  Default: 1.
-void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int syms_per_wg, int local_prepare, int sym0, int nsym)
+void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int syms_per_wg, int local_prepare)
 {
     if (syms_per_wg == 32) { hipLaunchKernelGGL(k_mixfft8, dim3(NSYM, nstreams), dim3(256), 0, st, tb, db, stream_ids, local_prepare); return; }   // the 256-lane form
-    if (syms_per_wg == 16) { hipLaunchKernelGGL((k_mixfft<1, 2>), dim3(NSYM / 2, nstreams), dim3(256), 0, st, tb, db, stream_ids, local_prepare, 0); return; }   // knob value 16: NPAR = 2
+    if (syms_per_wg == 16) { hipLaunchKernelGGL((k_mixfft<1, 2>), dim3(NSYM / 2, nstreams), dim3(256), 0, st, tb, db, stream_ids, local_prepare); return; }   // knob value 16: NPAR = 2
     switch (syms_per_wg) {
-    case 2: hipLaunchKernelGGL((k_mixfft<2, 1>), dim3(NSYM / 2, nstreams), dim3(128), 0, st, tb, db, stream_ids, local_prepare, 0); break;
-    case 4: hipLaunchKernelGGL((k_mixfft<4, 1>), dim3(NSYM / 4, nstreams), dim3(128), 0, st, tb, db, stream_ids, local_prepare, 0); break;
-    case 8: hipLaunchKernelGGL((k_mixfft<8, 1>), dim3(NSYM / 8, nstreams), dim3(128), 0, st, tb, db, stream_ids, local_prepare, 0); break;
-    default:
-        // the one-symbol form alone takes a symbol range [sym0, sym0 + nsym): the fast seam transforms a block's early symbols while its last samples are still on their way
-        if (syms_per_wg >= 100) { sym0 = 0; nsym = NSYM; }
-        hipLaunchKernelGGL((k_mixfft<1, 1>), dim3(nsym, nstreams), dim3(128), syms_per_wg >= 100 ? (size_t)(syms_per_wg - 100) << 10 : 0, st, tb, db, stream_ids, local_prepare, sym0); break;   // (>= 100: DIAGNOSTIC, that many KiB of unused dynamic LDS per workgroup -- fewer workgroups per CU)
+    case 2: hipLaunchKernelGGL((k_mixfft<2, 1>), dim3(NSYM / 2, nstreams), dim3(128), 0, st, tb, db, stream_ids, local_prepare); break;
+    case 4: hipLaunchKernelGGL((k_mixfft<4, 1>), dim3(NSYM / 4, nstreams), dim3(128), 0, st, tb, db, stream_ids, local_prepare); break;
+    case 8: hipLaunchKernelGGL((k_mixfft<8, 1>), dim3(NSYM / 8, nstreams), dim3(128), 0, st, tb, db, stream_ids, local_prepare); break;
+    default: hipLaunchKernelGGL((k_mixfft<1, 1>), dim3(NSYM, nstreams), dim3(128), syms_per_wg >= 100 ? (size_t)(syms_per_wg - 100) << 10 : 0, st, tb, db, stream_ids, local_prepare); break;   // (>= 100: DIAGNOSTIC, that many KiB of unused dynamic LDS per workgroup -- fewer workgroups per CU)
     }
 }
 

@@ -932,7 +932,7 @@ template <int NT> __device__ __forceinline__ void stream_report_wg(const DevBuff
         const int k = q / RW, w = q % RW;
         ((uint32_t *)&out->rec[k])[w] = flow_load_u32((const unsigned *)&db.records[(size_t)s * db.rec_cap + ((first_rec + k) % db.rec_cap)] + w);
     }
-    if (t < 4) { out->counters[t] = (int)flow_load_u32((const unsigned *)&db.counters[t]); db.counters[t] = 0; }
+    if (t < 4) { out->counters[t] = (int)flow_load_u32((const unsigned *)&db.counters[t]); flow_store_u32((unsigned *)&db.counters[t], 0u); }   // (through the caches: nothing of this kernel may still be on its way when the host, having seen the report, launches the next step)
     if (t == 0) { out->rd = (long long)flow_load_u64((const unsigned long long *)&st.rd); out->nblocks = nblocks; out->nrec = n; }
     __threadfence_system();
     __syncthreads();
@@ -941,23 +941,44 @@ template <int NT> __device__ __forceinline__ void stream_report_wg(const DevBuff
 
 template <int SYNC_NT>
 __global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare, int window, int pids_inline, int do_prepare, int ext_refs,
-                                                                         StreamReport *report, unsigned report_seq, int report_first)
+                                                                         StreamReport *report, unsigned report_seq, int report_first, unsigned *wait_counter)
 {
     wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
     const int s = wave_uniform(stream_of(ids, blockIdx.x));    // in a scalar register: every address derived from it stays off the VGPR budget
     __shared__ __attribute__((aligned(16))) uint8_t lds[sizeof(SyncLds<SYNC_NT>)];
+    if (wait_counter) {
+        // side-by-side step (k_mixfft_signal; kernel argument: uniform): this kernel was dispatched while the block's symbol transforms were still running.  Nothing of the stream is
+        // touched before the last of them has counted itself -- they read the very state this kernel rewrites.  Bounded: ~60 ms, then the step is reported as failed.
+        __shared__ int sh_lost;
+        if (threadIdx.x == 0) {
+            int spins = 0;
+            while (flow_load_u32(wait_counter) < (unsigned)NSYM && spins < 200000) { flow_sleep(); spins++; }
+            sh_lost = flow_load_u32(wait_counter) < (unsigned)NSYM;
+            flow_store_u32(wait_counter, 0u);                  // nobody else touches it until the next step's symbol kernel
+        }
+        __syncthreads();
+        flow_acquire();                                        // every wave: bins and state as memory holds them now, not as this CU / XCD cached them during an earlier step
+        if (sh_lost) {
+            if (report && threadIdx.x == 0) {
+                report->counters[0] = 0; report->counters[1] = 0; report->counters[2] = 0; report->counters[3] = STEP_HANDOFF_LOST; report->nrec = 0;
+                __threadfence_system();
+                *(volatile unsigned *)&report->seq = report_seq; __threadfence_system();
+            }
+            return;
+        }
+    }
     sync_body<SYNC_NT>(lds, tb, db, s, parity, slot, fuse_prepare, window, pids_inline, do_prepare, ext_refs);
     if (report) stream_report_wg<SYNC_NT>(db, s, report_first, report, report_seq);      // (kernel argument: uniform; one-stream launches of the fast seam only)
 }
 
 void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, int window, hipStream_t st, int lanes, int pids_inline, int do_prepare, int ext_refs,
-                 StreamReport *report, unsigned report_seq, int report_first)
+                 StreamReport *report, unsigned report_seq, int report_first, unsigned *wait_counter)
 {
     // lanes: 0 = by the size of the stream set (see SYNC_OCCUPANCY above), else 256 / 768 (nrsc5hip_debug_tune NRSC5HIP_TUNE_SYNC_LANES)
     const int nt = lanes ? lanes : 768;                        // measured at 256 streams: 32.8 ms per pass with 768, 33.8 with 256 (profiles/r04_sync_lanes.txt)
-    if (nstreams != 1) report = nullptr;
-    if (nt == 768) hipLaunchKernelGGL(k_sync<768>, dim3(nstreams), dim3(768), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window, pids_inline, do_prepare, ext_refs, report, report_seq, report_first);
-    else hipLaunchKernelGGL(k_sync<256>, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window, pids_inline, do_prepare, ext_refs, report, report_seq, report_first);
+    if (nstreams != 1) { report = nullptr; wait_counter = nullptr; }
+    if (nt == 768) hipLaunchKernelGGL(k_sync<768>, dim3(nstreams), dim3(768), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window, pids_inline, do_prepare, ext_refs, report, report_seq, report_first, wait_counter);
+    else hipLaunchKernelGGL(k_sync<256>, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window, pids_inline, do_prepare, ext_refs, report, report_seq, report_first, wait_counter);
 }
 
 // ---- deferred PIDS decode: one wave per (slot, stream) with a staged frame -----------------------------------
