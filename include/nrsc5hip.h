@@ -174,7 +174,7 @@ int nrsc5hip_stream_reset(nrsc5hip_engine *e, int stream);
 /* ABI NOTE (NRSC5HIP_ABI_VERSION >= 5): until round 4 nrsc5hip_stream_reset gave a FRESH session; since round 5 it is the reference's input_reset as described above (stale FIR
  * windows, samperr / angle / bc kept) and the fresh session is nrsc5hip_stream_fresh.  A caller that used reset to start an independent capture on a slot must call
  * nrsc5hip_stream_fresh now (on engines with batch_zero_copy both are the fresh form).  nrsc5hip_abi_version() lets a binding check what it was linked against. */
-#define NRSC5HIP_ABI_VERSION 7   /* 7: + NRSC5HIP_TUNE_HOST_CAPTURE / _FOLD_REPORT / _CONCURRENT_STEP, nrsc5hip_debug_host_capture_stats; 6: + nrsc5hip_abi_version, nrsc5hip_debug_flow_stats, NRSC5HIP_TUNE_FLOW_MIN / _LOOP_EXACT, NRSC5HIP_PROF_FLOW; 5: the reset semantics above */
+#define NRSC5HIP_ABI_VERSION 7   /* 7: + NRSC5HIP_TUNE_HOST_CAPTURE / _FOLD_REPORT, nrsc5hip_debug_host_capture_stats; 6: + nrsc5hip_abi_version, nrsc5hip_debug_flow_stats, NRSC5HIP_TUNE_FLOW_MIN / _LOOP_EXACT, NRSC5HIP_PROF_FLOW; 5: the reset semantics above */
 int nrsc5hip_abi_version(void);
 /* nrsc5_close + nrsc5_open_pipe on this slot: a fresh session (calloc'd windows), what nrsc5hip_reset_all does for every stream */
 int nrsc5hip_stream_fresh(nrsc5hip_engine *e, int stream);
@@ -436,9 +436,6 @@ enum {
                                              engine reads such a capture (the first to push cu8 after its reset); cs16 / AM input and the batch entry points use the FIFO */
     , NRSC5HIP_TUNE_FOLD_REPORT            /* fast streaming seam: 1 (default) = a block step with nothing to launch behind the sync kernel (no P1 frame to decode, no extended sidebands: 15 of 16
                                              MP1 blocks) has the sync kernel post the step's report into pinned host memory itself; 0 = the report kernel as a launch of its own.  Identical records */
-    , NRSC5HIP_TUNE_CONCURRENT_STEP        /* fast streaming seam with the host-resident capture: 1 (default) = such a step, when the stream is idle, launches its sync kernel on a second HIP stream
-                                             right behind the symbol kernel; it waits on the device (bounded) for the 32 symbol workgroups to count themselves in -- the sync kernel's dispatch and
-                                             the symbol kernel's retirement leave the chain the completing call waits for.  0 = one behind the other on one stream.  Identical records */
 };
 /* process-wide wall-clock totals of the streaming seam with p1_async = 0 (what the drop-in uses): [0] s copying pushes into pinned
  * staging, [1] s enqueueing H2D + decimator, [2] s enqueueing block steps, [3] s waiting for the device (one sync per block),
@@ -456,8 +453,8 @@ int nrsc5hip_debug_fwd_stats(nrsc5hip_engine *e, int stats[2]);
 int nrsc5hip_debug_flow_stats(nrsc5hip_engine *e, long long stats[2]);
 /* host-resident capture of the fast seam (NRSC5HIP_TUNE_HOST_CAPTURE): [0] sessions that bound the pinned capture, [1] captures turned back into the FIFO (cs16 push,
  * batch entry point, debug fetch), [2] times the live tail moved to the front of a full buffer, [3] the stream bound now (-1: none); and of NRSC5HIP_TUNE_FOLD_REPORT:
- * [4] block steps whose report the sync kernel posted itself; of NRSC5HIP_TUNE_CONCURRENT_STEP: [5] block steps whose two kernels were launched side by side */
-int nrsc5hip_debug_host_capture_stats(nrsc5hip_engine *e, long long stats[6]);
+ * [4] block steps whose report the sync kernel posted itself */
+int nrsc5hip_debug_host_capture_stats(nrsc5hip_engine *e, long long stats[5]);
 /* K=9 decode in segment waves: [0] forward boundaries checked, [1] segments re-run, [2] traceback boundaries checked, [3] segments re-walked */
 /* single-path traceback: [0] chunk boundaries checked, [1] chunks re-walked since the engine was created */
 int nrsc5hip_debug_tb_stats(nrsc5hip_engine *e, int stats[2]);

@@ -227,9 +227,8 @@ void input_init(input_t *st, nrsc5_t *radio, output_t *output)
      * the oscillator's amplitude ramp, as in the batch API -- measured on the MI355X the exact form changes no event and costs a 20-s capture 5 % of its speed */
     else { const char *x = getenv("NRSC5HIP_NCO_EXACT"); if (x && atoi(x) > 0 && nrsc5hip_debug_tune(e, NRSC5HIP_TUNE_NCO_EXACT, atoi(x)) != 0) fail(st, "debug_tune"); }
     /* NRSC5HIP_HOST_CAPTURE=0: the FIFO seam of rounds 3 - 5 (pinned staging + decimator kernel) instead of the pinned capture read in place (A/B; identical events) */
-    /* NRSC5HIP_FOLD_REPORT=0 / NRSC5HIP_CONCURRENT_STEP=0: A/B switches of the seam's launch plan (include/nrsc5hip.h, NRSC5HIP_TUNE_*); identical events */
+    /* NRSC5HIP_FOLD_REPORT=0: A/B switch of the seam's launch plan (include/nrsc5hip.h, NRSC5HIP_TUNE_*); identical events */
     if (e && !FAILED(st)) { const char *x = getenv("NRSC5HIP_FOLD_REPORT"); if (x && *x && nrsc5hip_debug_tune(e, NRSC5HIP_TUNE_FOLD_REPORT, atoi(x)) != 0) fail(st, "debug_tune"); }
-    if (e && !FAILED(st)) { const char *x = getenv("NRSC5HIP_CONCURRENT_STEP"); if (x && *x && nrsc5hip_debug_tune(e, NRSC5HIP_TUNE_CONCURRENT_STEP, atoi(x)) != 0) fail(st, "debug_tune"); }
     if (e && !FAILED(st)) { const char *x = getenv("NRSC5HIP_HOST_CAPTURE"); if (x && *x && nrsc5hip_debug_tune(e, NRSC5HIP_TUNE_HOST_CAPTURE, atoi(x)) != 0) fail(st, "debug_tune"); }
     st->acq.fftin = (void *)e;
     st->decode.input = st;

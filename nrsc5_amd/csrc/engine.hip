@@ -98,10 +98,6 @@ struct nrsc5hip_engine {
         long long am_step_count;       // same for the AM window pipeline (8 steps per window)
         bool am_decoded_pending[NWIN];
         int *counters_dev, *counters_host;
-        // Side-by-side step (fast seam, round 6): the sync kernel of a block goes to `side` right behind the symbol kernel on `main` and waits on the device for the symbol
-        // workgroups to count themselves into *handoff_dev (k_mixfft_signal, k_sync's wait_counter).  side_busy: that sync kernel has not reported yet -- whatever is
-        // launched on `main` next must be ordered behind it (order_main_behind_side).
-        hipStream_t side; hipEvent_t ev_side; bool side_ok, side_busy; unsigned *handoff_dev;
         DevBuffers db;                 // engine buffers with this lane's counters
     } lane;
     int naux;                          // decode streams in use (<= NAUX)
@@ -189,8 +185,6 @@ struct nrsc5hip_engine {
     bool host_capture;                 // knob (default on where the buffer exists)
     long long hc_rebases, hc_attaches, hc_detaches;
     long long reports_folded;          // block steps whose report the sync kernel posted itself (fold_report)
-    int concurrent_step;               // 1 (default): see Lane::side (NRSC5HIP_TUNE_CONCURRENT_STEP)
-    long long steps_concurrent;
     std::vector<std::array<c16, 14>> hb_hist_host;   // the decimator history each stream's last reset left on the device (zeros for a fresh session)
     // staging
     uint8_t *stage_dev; size_t stage_bytes;
@@ -636,12 +630,6 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             if (hipStreamCreateWithPriority(&e->ingest, hipStreamDefault, prio_greatest) != hipSuccess || hipEventCreateWithFlags(&e->ev_ingest, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&e->ev_main, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&e->ev_appended, hipEventDisableTiming) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "ingest stream creation failed"); break; }
-            // (the side stream at the ingest stream's priority: never on the chain stream's hardware queue -- on one queue the two kernels of a step would simply run one behind the
-            //  other, symbol kernel first, as before)
-            if (hipStreamCreateWithPriority(&e->lane.side, hipStreamDefault, prio_greatest) != hipSuccess || hipEventCreateWithFlags(&e->lane.ev_side, hipEventDisableTiming) != hipSuccess) { rc = NRSC5HIP_EHIP; snprintf(g_err, sizeof(g_err), "side stream creation failed"); break; }
-            if ((rc = dev_alloc(e, &e->lane.handoff_dev, 1))) break;
-            if (hipMemset(e->lane.handoff_dev, 0, sizeof(unsigned)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
-            e->lane.side_busy = false; e->lane.side_ok = true;
             e->ingest_dirty = false; e->main_stepped = false; e->main_appended = false; e->early_flush = 128u << 10;     // a block is 270 KB of cu8: 128 + 128 + a last chunk of ~14 KB
             if ((rc = dev_alloc(e, &e->decim_ticket, 1))) break;
             if (hipMemset(e->decim_ticket, 0, sizeof(unsigned)) != hipSuccess) { rc = NRSC5HIP_EHIP; break; }
@@ -654,7 +642,7 @@ extern "C" int nrsc5hip_engine_create(const nrsc5hip_config *cfg, nrsc5hip_engin
             }
             if (rc) break;
         }
-        e->hc_stream = -1; e->hc_abs0 = 0; e->hc_wr = 0; e->host_capture = false; e->hc_rebases = e->hc_attaches = e->hc_detaches = 0; e->reports_folded = 0; e->concurrent_step = 1; e->steps_concurrent = 0;
+        e->hc_stream = -1; e->hc_abs0 = 0; e->hc_wr = 0; e->host_capture = false; e->hc_rebases = e->hc_attaches = e->hc_detaches = 0; e->reports_folded = 0;
         if (!cfg->p1_async) {
             e->hc_cap = 16u << 20;                             // 58 FM blocks between two rebases (~300 KB of host memmove each)
             void *hp = nullptr;
@@ -716,8 +704,6 @@ extern "C" void nrsc5hip_engine_destroy(nrsc5hip_engine *e)
         nrsc5hip_engine::Lane &ln = e->lane;
         if (ln.counters_host) (void)hipHostFree(ln.counters_host);
         for (int k = 0; k < NWIN; k++) { if (ln.ev_window[k]) (void)hipEventDestroy(ln.ev_window[k]); if (ln.ev_decoded[k]) (void)hipEventDestroy(ln.ev_decoded[k]); }
-        if (ln.side) (void)hipStreamDestroy(ln.side);
-        if (ln.ev_side) (void)hipEventDestroy(ln.ev_side);
         if (ln.main) (void)hipStreamDestroy(ln.main);
         for (int k = 0; k < NAUX; k++) if (ln.aux[k]) (void)hipStreamDestroy(ln.aux[k]);
     }
@@ -790,17 +776,7 @@ static int launch_inorder_p1(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int 
 // decode_p1 = false (fast streaming seam only): the caller KNOWS that no listed stream can complete a P1 frame in this step
 // local_prepare (fast streaming seam, stream known to be FINE): no k_prepare launch -- the symbol kernel computes the block's
 // bookkeeping for itself and the sync kernel commits it
-// see Lane::side
-static int order_main_behind_side(nrsc5hip_engine *e)
-{
-    nrsc5hip_engine::Lane &ln = e->lane;
-    if (!ln.side_busy) return 0;
-    HIPCHK(hipEventRecord(ln.ev_side, ln.side));
-    HIPCHK(hipStreamWaitEvent(ln.main, ln.ev_side, 0));
-    ln.side_busy = false;
-    return 0;
-}
-struct StepReport { StreamReport *out; unsigned seq; int first_rec; bool folded; bool may_run_side_by_side; };   // fast seam: the report the step's last kernel may post itself (issue_step sets `folded` when k_sync did)
+struct StepReport { StreamReport *out; unsigned seq; int first_rec; bool folded; };   // fast seam: the report the step's last kernel may post itself (issue_step sets `folded` when k_sync did)
 static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, const int *ids_dev, bool decode_p1 = true, bool decode_pids = true, bool local_prepare = false, StepReport *rep = nullptr)
 {
     const bool async = e->cfg.p1_async != 0;
@@ -827,19 +803,15 @@ static int issue_step(nrsc5hip_engine *e, nrsc5hip_engine::Lane &ln, int n, cons
     // exact-oscillator blocks (a freshly reset stream up to its first lock): only a stream that is not FINE can be in that mode, and
     // those only advance on steps that run the acquisition kernels
     if (ln.db.nco_tab && (ln.acq_needed || ln.db.nco_policy == NCO_EXACT_ALWAYS)) { ProfScope p(e, NRSC5HIP_PROF_PREPARE, ln.main); launch_nco_exact(ln.db, n, ids_dev, ln.main); }
-    // nothing runs behind k_sync on this step (no PX kernels, no separate PIDS decode, no in-order P1 decode): it posts the step's report itself ...
-    const bool fold = rep && n == 1 && !async && !ln.px_needed && !decode_pids && !decode_p1;
-    // ... and, when the stream is idle (its state settled: the caller says) and the block runs on the fused seam's closed-form path, is launched side by side with the symbol kernel
-    const bool side = fold && rep->may_run_side_by_side && fused_prepare && e->concurrent_step && ln.side_ok && e->mixfft_syms == 1 && !e->prof_on && !ln.side_busy;
-    if (side) { ProfScope p(e, NRSC5HIP_PROF_MIXFFT, ln.main); launch_mixfft_signal(e->tb, ln.db, ids_dev, ln.main, 1, ln.handoff_dev); }
-    else { ProfScope p(e, NRSC5HIP_PROF_MIXFFT, ln.main); launch_mixfft(e->tb, ln.db, n, ids_dev, ln.main, e->mixfft_syms, fused_prepare ? 1 : 0); }
+    { ProfScope p(e, NRSC5HIP_PROF_MIXFFT, ln.main); launch_mixfft(e->tb, ln.db, n, ids_dev, ln.main, e->mixfft_syms, fused_prepare ? 1 : 0); }
     const int slot = async ? (int)(ln.step_count % 16) : 0;
     // batch pipeline: once every stream of the set is FINE, the next block's bookkeeping rides in k_sync's tail
     const int fuse = (async && !ln.acq_needed) ? 1 : 0;
-    { ProfScope p(e, NRSC5HIP_PROF_SYNC, ln.main); launch_sync(e->tb, ln.db, n, ids_dev, parity, slot, fuse, (int)window, side ? ln.side : ln.main, e->sync_lanes, decode_pids ? 0 : 1, fused_prepare ? 1 : 0, ln.px_needed ? 1 : 0,
-                                                                fold ? rep->out : nullptr, fold ? rep->seq : 0u, fold ? rep->first_rec : 0, side ? ln.handoff_dev : nullptr); }
+    // nothing runs behind k_sync on this step (no PX kernels, no separate PIDS decode, no in-order P1 decode): it posts the step's report itself
+    const bool fold = rep && n == 1 && !async && !ln.px_needed && !decode_pids && !decode_p1 && e->sync_lanes != 256;     // (the wide form alone has the reporting twin: k_sync_report)
+    { ProfScope p(e, NRSC5HIP_PROF_SYNC, ln.main); launch_sync(e->tb, ln.db, n, ids_dev, parity, slot, fuse, (int)window, ln.main, e->sync_lanes, decode_pids ? 0 : 1, fused_prepare ? 1 : 0, ln.px_needed ? 1 : 0,
+                                                                fold ? rep->out : nullptr, fold ? rep->seq : 0u, fold ? rep->first_rec : 0); }
     if (rep) rep->folded = fold;
-    if (side) { ln.side_busy = true; e->steps_concurrent++; }
     ln.prepared_by_sync = fuse != 0;
     if (ln.px_needed) { ProfScope p(e, NRSC5HIP_PROF_PIDS, ln.main); launch_px_deint(e->tb, ln.db, n, ids_dev, parity, slot, ln.main); }
     if (!async) {
@@ -1100,7 +1072,6 @@ static int wait_report(nrsc5hip_engine *e, unsigned seq, bool block)
         if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;   // a block step is ~50 us: past 2 ms something else holds the queue -- stop burning a core, block
     }
     HIPCHK(hipStreamSynchronize(e->lane.main));
-    if (e->lane.side_busy) HIPCHK(hipStreamSynchronize(e->lane.side));
     if (__atomic_load_n(p, __ATOMIC_ACQUIRE) != seq) FAIL(NRSC5HIP_EHIP, "stream report %u never arrived (have %u)", seq, *p);
     return 1;
 }
@@ -1112,7 +1083,7 @@ static StepReport next_report(nrsc5hip_engine *e, int s)
     if (e->report_seq == 0) e->report_seq = 2;                 // 0 = the freshly cleared report; 2, not 1: the step before the wrap posted into buffer 1 (seq & 1)
     // records to post: from the first one the host has not seen -- the block of a step still in flight is not this step's to report
     const int first_rec = e->fetched[s] + ((e->inflight_stream == s) ? 1 : 0);
-    return StepReport{ e->report_dev[e->report_seq & 1], e->report_seq, first_rec, false, false };
+    return StepReport{ e->report_dev[e->report_seq & 1], e->report_seq, first_rec, false };
 }
 
 static int launch_report(nrsc5hip_engine *e, int s, bool with_pids, const StepReport *prepared = nullptr)
@@ -1139,14 +1110,6 @@ static int harvest(nrsc5hip_engine *e, bool block)
     }
     e->inflight_stream = -1;
     const StreamReport *rp = e->report_host[e->inflight_seq & 1];
-    // (a sync kernel on the side stream has written everything back before it posts: stream_report_wg -- what is launched next needs no ordering behind it.  With a step queued
-    //  ahead nothing ran side by side: submit_step ordered `main` behind the side stream before it queued that step.)
-    if (!e->ahead.valid) ln.side_busy = false;
-    if (rp->counters[3] == STEP_HANDOFF_LOST) {
-        (void)hipStreamSynchronize(ln.main); (void)hipStreamSynchronize(ln.side); (void)hipMemset(ln.handoff_dev, 0, sizeof(unsigned));
-        e->mirror_ok[s] = 0; forget_prediction(e, s);
-        FAIL(NRSC5HIP_EHIP, "stream %d: the block step's symbol kernel never handed over to its sync kernel", s);
-    }
     bool p1_missing = false;
     for (int k = 0; k < rp->nrec; k++) if ((rp->rec[k].flags & REC_P1) && e->mode_host[s] != MODE_AM && !e->inflight_decoded) p1_missing = true;
     if (p1_missing) {
@@ -1210,7 +1173,6 @@ static int submit_step(nrsc5hip_engine *e, int s, bool ahead = false)
     if (sig != ln.set_sig) { ln.acq_needed = true; ln.px_needed = true; ln.set_sig = sig; }
     ln.prepared_by_sync = false;
     const auto t_enq = std::chrono::steady_clock::now();
-    { int rc = order_main_behind_side(e); if (rc) return rc; }  // (a step queued behind one whose sync kernel runs on the side stream)
     if (e->ingest_dirty) { HIPCHK(hipEventRecord(e->ev_ingest, e->ingest)); HIPCHK(hipStreamWaitEvent(ln.main, e->ev_ingest, 0)); e->ingest_dirty = false; }
     e->main_stepped = true;
     if (!e->counters_clean) HIPCHK(hipMemsetAsync(ln.counters_dev, 0, 4 * sizeof(int), ln.main));
@@ -1229,8 +1191,6 @@ static int submit_step(nrsc5hip_engine *e, int s, bool ahead = false)
         decode = !(known && bc != 15);
         if (!decode) g_seam[10] += 1;
         rep = next_report(e, s); have_rep = true;
-        // side by side only for a stream that reads the pinned capture (no decimator / compaction beside the step) and is idle: nothing in flight whose sync kernel still rewrites its state
-        rep.may_run_side_by_side = !ahead && e->inflight_stream < 0 && e->hc_stream == s;
         int rc = issue_step(e, ln, 1, ids_dev, decode, false, known && e->fuse_seam_prepare, e->fold_report ? &rep : nullptr); if (rc) return rc;   // PIDS frame: inside k_sync (pids_inline)
     }
     if (have_rep && rep.folded) { e->counters_clean = true; e->reports_folded++; }        // k_sync posted it
@@ -1270,7 +1230,6 @@ static int settle(nrsc5hip_engine *e)
 {
     if (!e) return 0;
     while (e->inflight_stream >= 0) { int rc = harvest(e, true); if (rc) return rc; }
-    if (e->lane.side_busy) { HIPCHK(hipStreamSynchronize(e->lane.side)); e->lane.side_busy = false; }
     if (e->ingest_dirty) { HIPCHK(hipStreamSynchronize(e->ingest)); e->ingest_dirty = false; }    // whatever follows runs on `main` (or the host) alone
     return 0;
 }
@@ -1541,7 +1500,6 @@ static int reset_stream(nrsc5hip_engine *e, int stream, bool keep_windows)
     }
     // this engine's queues only (another session of the process keeps running)
     if (e->ingest) HIPCHK(hipStreamSynchronize(e->ingest));
-    if (e->lane.side_ok) { HIPCHK(hipStreamSynchronize(e->lane.side)); e->lane.side_busy = false; }
     HIPCHK(hipStreamSynchronize(e->main));
     if (e->cfg.p1_async) { for (int k = 0; k < NAUX; k++) HIPCHK(hipStreamSynchronize(e->lane.aux[k])); HIPCHK(hipStreamSynchronize(e->dec_stream)); }
     StreamState st; init_state(st, e->mode_host[stream]);
@@ -1600,7 +1558,6 @@ extern "C" int nrsc5hip_force_resync(nrsc5hip_engine *e, int stream)
 {
     ON_ENGINE_DEVICE(e);
     int rc = check_stream(e, stream); if (rc) return rc;
-    if ((rc = order_main_behind_side(e))) return rc;
     hipLaunchKernelGGL(k_force_none, dim3(1), dim3(1), 0, e->main, e->db, stream);
     forget_prediction(e, stream);
     e->lane.acq_needed = true; e->lane.px_needed = true; e->lane.set_sig = 0;
@@ -2532,7 +2489,6 @@ extern "C" int nrsc5hip_debug_tune(nrsc5hip_engine *e, int knob, int value)
     case NRSC5HIP_TUNE_SYNC_LANES:        e->sync_lanes = (value == 256 || value == 768) ? value : 0; break;
     case NRSC5HIP_TUNE_SEAM_PREPARE:      e->fuse_seam_prepare = value != 0; break;
     case NRSC5HIP_TUNE_FOLD_REPORT:       e->fold_report = value != 0; break;
-    case NRSC5HIP_TUNE_CONCURRENT_STEP:   e->concurrent_step = value != 0; break;
     case NRSC5HIP_TUNE_NCO_EXACT:         e->db.nco_policy = e->lane.db.nco_policy = e->db.nco_tab ? std::min(std::max(value, 0), (int)NCO_EXACT_ALWAYS) : (int)NCO_CLOSED_FORM; break;
     case NRSC5HIP_TUNE_FLOW_MIN:          e->flow_min = std::max(value, 0); break;
     case NRSC5HIP_TUNE_LOOP_EXACT:        e->db.loop_exact = e->lane.db.loop_exact = std::min(std::max(value, 0), 2); break;
@@ -2586,10 +2542,10 @@ extern "C" int nrsc5hip_debug_flow_stats(nrsc5hip_engine *e, long long stats[2])
     return 0;
 }
 
-extern "C" int nrsc5hip_debug_host_capture_stats(nrsc5hip_engine *e, long long stats[6])
+extern "C" int nrsc5hip_debug_host_capture_stats(nrsc5hip_engine *e, long long stats[5])
 {
     if (!e || !stats) return NRSC5HIP_EINVAL;
-    stats[0] = e->hc_attaches; stats[1] = e->hc_detaches; stats[2] = e->hc_rebases; stats[3] = e->hc_stream; stats[4] = e->reports_folded; stats[5] = e->steps_concurrent;
+    stats[0] = e->hc_attaches; stats[1] = e->hc_detaches; stats[2] = e->hc_rebases; stats[3] = e->hc_stream; stats[4] = e->reports_folded;
     return 0;
 }
 

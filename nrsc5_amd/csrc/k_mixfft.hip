@@ -23,7 +23,6 @@
 #include "halfband_raw.h"
 #include "prepare_block.h"
 
-#include "flow_ops.h"
 #include "mixfft_body.h"
 
 namespace nrsc5 {
@@ -35,25 +34,6 @@ __global__ __launch_bounds__(128 * NPAR) MIXFFT_OCCUPANCY void k_mixfft(DevTable
     const int s = wave_uniform(stream_of(ids, blockIdx.y));
     __shared__ __attribute__((aligned(16))) uint8_t lds[sizeof(MixLds<NPAR>)];
     mixfft_wg<SPW, NPAR>(lds, tb, db, s, (int)blockIdx.x, local_prepare);
-}
-
-// The fast seam's side-by-side step (engine.hip, issue_step): the sync kernel of the same block is launched right behind this one on a second HIP stream and waits, at its very
-// start, for `done` to reach the number of symbol workgroups -- so that its dispatch and wave launch, and this kernel's retirement, leave the chain the host waits for.
-// Closed-form blocks only (the fused seam: FINE streams), whose bins leave write-through; every workgroup counts, active or not.
-__global__ __launch_bounds__(128) MIXFFT_OCCUPANCY void k_mixfft_signal(DevTables tb, DevBuffers db, const int *ids, int local_prepare, unsigned *done)
-{
-    wave_set_priority_high();
-    const int s = wave_uniform(stream_of(ids, blockIdx.y));
-    __shared__ __attribute__((aligned(16))) uint8_t lds[sizeof(MixLds<1>)];
-    mixfft_wg<1, 1, false, true>(lds, tb, db, s, (int)blockIdx.x, local_prepare);
-    flow_drain_stores();                                       // this wave's write-through stores have left
-    __syncthreads();
-    if (threadIdx.x == 0) (void)flow_add_u32(done, 1u);
-}
-
-void launch_mixfft_signal(const DevTables &tb, const DevBuffers &db, const int *stream_id, hipStream_t st, int local_prepare, unsigned *done)
-{
-    hipLaunchKernelGGL(k_mixfft_signal, dim3(NSYM, 1), dim3(128), 0, st, tb, db, stream_id, local_prepare, done);
 }
 
 // =====================================================================================================================

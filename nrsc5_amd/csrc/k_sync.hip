@@ -940,45 +940,49 @@ template <int NT> __device__ __forceinline__ void stream_report_wg(const DevBuff
 }
 
 template <int SYNC_NT>
-__global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare, int window, int pids_inline, int do_prepare, int ext_refs,
-                                                                         StreamReport *report, unsigned report_seq, int report_first, unsigned *wait_counter)
+__global__ __launch_bounds__(SYNC_NT) SYNC_OCCUPANCY(SYNC_NT) void k_sync(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare, int window, int pids_inline, int do_prepare, int ext_refs)
 {
     wave_set_priority_high();                                  // block-step chain = critical path; decode waves run at priority 0
     const int s = wave_uniform(stream_of(ids, blockIdx.x));    // in a scalar register: every address derived from it stays off the VGPR budget
     __shared__ __attribute__((aligned(16))) uint8_t lds[sizeof(SyncLds<SYNC_NT>)];
-    if (wait_counter) {
-        // side-by-side step (k_mixfft_signal; kernel argument: uniform): this kernel was dispatched while the block's symbol transforms were still running.  Nothing of the stream is
-        // touched before the last of them has counted itself -- they read the very state this kernel rewrites.  Bounded: ~60 ms, then the step is reported as failed.
-        __shared__ int sh_lost;
-        if (threadIdx.x == 0) {
-            int spins = 0;
-            while (flow_load_u32(wait_counter) < (unsigned)NSYM && spins < 200000) { flow_sleep(); spins++; }
-            sh_lost = flow_load_u32(wait_counter) < (unsigned)NSYM;
-            flow_store_u32(wait_counter, 0u);                  // nobody else touches it until the next step's symbol kernel
-        }
-        __syncthreads();
-        flow_acquire();                                        // every wave: bins and state as memory holds them now, not as this CU / XCD cached them during an earlier step
-        if (sh_lost) {
-            if (report && threadIdx.x == 0) {
-                report->counters[0] = 0; report->counters[1] = 0; report->counters[2] = 0; report->counters[3] = STEP_HANDOFF_LOST; report->nrec = 0;
-                __threadfence_system();
-                *(volatile unsigned *)&report->seq = report_seq; __threadfence_system();
-            }
-            return;
-        }
-    }
     sync_body<SYNC_NT>(lds, tb, db, s, parity, slot, fuse_prepare, window, pids_inline, do_prepare, ext_refs);
-    if (report) stream_report_wg<SYNC_NT>(db, s, report_first, report, report_seq);      // (kernel argument: uniform; one-stream launches of the fast seam only)
+}
+
+// The fast seam's form for ONE stream: the same body, then the report.  A kernel of its own, so that the batch kernel above keeps the code (and the resource footprint: 79 VGPRs, no
+// scratch -- tests/test_codegen_guards.py) it had before the report existed.
+struct SyncReportTail { StreamReport *out; unsigned seq; int first_rec; };
+// the kernel's arguments as the kernarg segment lays them out (each at its natural alignment, like the members of a struct): where `tail` sits
+struct SyncReportKernargs { DevTables tb; DevBuffers db; const int *ids; int parity, slot, fuse_prepare, window, pids_inline, do_prepare, ext_refs; SyncReportTail tail; };
+__global__ __launch_bounds__(768) SYNC_OCCUPANCY(768) void k_sync_report(DevTables tb, DevBuffers db, const int *ids, int parity, int slot, int fuse_prepare, int window, int pids_inline, int do_prepare, int ext_refs,
+                                                                       SyncReportTail tail)
+{
+    wave_set_priority_high();
+    const int s = wave_uniform(stream_of(ids, blockIdx.x));
+    __shared__ __attribute__((aligned(16))) uint8_t lds[sizeof(SyncLds<768>)];
+    sync_body<768>(lds, tb, db, s, parity, slot, fuse_prepare, window, pids_inline, do_prepare, ext_refs);
+#ifndef HIPEMU
+    // The report's three arguments are fetched from the kernarg segment HERE, behind a fence the compiler cannot look through: as ordinary parameters they are loaded at the kernel's entry
+    // with all the others and stay in scalar registers through the whole body, which has none to spare (104 SGPRs, ~250 spilled to VGPR lanes)
+    const char *ka = (const char *)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka) : : "memory");
+    const SyncReportTail t = *(const SyncReportTail *)(ka + offsetof(SyncReportKernargs, tail));
+    const DevBuffers &dbr = *(const DevBuffers *)(ka + offsetof(SyncReportKernargs, db));      // (likewise the three buffer pointers the report reads)
+    (void)tail;
+#else
+    const SyncReportTail t = tail;
+    const DevBuffers &dbr = db;
+#endif
+    stream_report_wg<768>(dbr, s, t.first_rec, t.out, t.seq);
 }
 
 void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, int window, hipStream_t st, int lanes, int pids_inline, int do_prepare, int ext_refs,
-                 StreamReport *report, unsigned report_seq, int report_first, unsigned *wait_counter)
+                 StreamReport *report, unsigned report_seq, int report_first)
 {
     // lanes: 0 = by the size of the stream set (see SYNC_OCCUPANCY above), else 256 / 768 (nrsc5hip_debug_tune NRSC5HIP_TUNE_SYNC_LANES)
     const int nt = lanes ? lanes : 768;                        // measured at 256 streams: 32.8 ms per pass with 768, 33.8 with 256 (profiles/r04_sync_lanes.txt)
-    if (nstreams != 1) { report = nullptr; wait_counter = nullptr; }
-    if (nt == 768) hipLaunchKernelGGL(k_sync<768>, dim3(nstreams), dim3(768), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window, pids_inline, do_prepare, ext_refs, report, report_seq, report_first, wait_counter);
-    else hipLaunchKernelGGL(k_sync<256>, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window, pids_inline, do_prepare, ext_refs, report, report_seq, report_first, wait_counter);
+    if (report && nstreams == 1 && nt == 768) { hipLaunchKernelGGL(k_sync_report, dim3(1), dim3(768), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window, pids_inline, do_prepare, ext_refs, SyncReportTail{ report, report_seq, report_first }); return; }
+    if (nt == 768) hipLaunchKernelGGL(k_sync<768>, dim3(nstreams), dim3(768), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window, pids_inline, do_prepare, ext_refs);
+    else hipLaunchKernelGGL(k_sync<256>, dim3(nstreams), dim3(256), 0, st, tb, db, stream_ids, parity, slot, fuse_prepare, window, pids_inline, do_prepare, ext_refs);
 }
 
 // ---- deferred PIDS decode: one wave per (slot, stream) with a staged frame -----------------------------------

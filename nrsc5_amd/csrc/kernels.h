@@ -119,13 +119,10 @@ void launch_prepare(const DevBuffers &db, int nstreams, const int *stream_ids, i
 // streams whose current block runs in exact-oscillator mode (StreamState::nco_mode): the reference's 69 120-step float recurrence, one lane per stream
 void launch_nco_exact(const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st);
 void launch_mixfft(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, hipStream_t st, int syms_per_wg = 1, int local_prepare = 0);
-// fast seam, ONE stream, side-by-side step: the one-symbol form with write-through bins; every workgroup adds 1 to *done when its bins have left (launch_sync's wait_counter)
-void launch_mixfft_signal(const DevTables &tb, const DevBuffers &db, const int *stream_id, hipStream_t st, int local_prepare, unsigned *done);
-constexpr int STEP_HANDOFF_LOST = -12345;                        // StreamReport::counters[3] of a sync kernel that gave up waiting for the symbol kernel
 size_t flow_words(int n);
 void launch_flow(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int K, unsigned *flow, unsigned *err_host, int parity, int slot0, int window, hipStream_t st);
 void launch_sync(const DevTables &tb, const DevBuffers &db, int nstreams, const int *stream_ids, int parity, int slot, int fuse_prepare, int window, hipStream_t st, int lanes = 0, int pids_inline = 0, int do_prepare = 0, int ext_refs = 1,
-                 StreamReport *report = nullptr, unsigned report_seq = 0, int report_first = 0, unsigned *wait_counter = nullptr);   // report: one-stream launch of the fast seam posts the step's report itself (k_stream_tail's job)
+                 StreamReport *report = nullptr, unsigned report_seq = 0, int report_first = 0);   // report: one-stream launch of the fast seam posts the step's report itself (k_stream_tail's job)
 // replay (k_replay.hip): apply the first-header verdicts of finished deferred P1 decodes -- rewind the stream to the failed frame
 void launch_rollback(const DevBuffers &db, int nstreams, const int *stream_ids, int cur_window, int min_age, hipStream_t st);
 void launch_rollback_am(const DevBuffers &db, int nstreams, const int *stream_ids, int cur_window, int min_age, hipStream_t st);

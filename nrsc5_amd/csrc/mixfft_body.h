@@ -565,9 +565,7 @@ template <int NPAR> struct MixLds {
 
 // FLOW: `flow_sp` holds the block's parameters (handed over by the previous block step of the same launch, or read from the stream state by the caller for the
 // launch's first step) -- the stream state itself is not read for them
-// THROUGH (k_mixfft_signal, the fast seam's side-by-side step): parameters as usual, but the bins of a closed-form block leave write-through like FLOW's -- the sync kernel that
-// consumes them is already running, released by a counter
-template <int SPW, int NPAR, bool FLOW = false, bool THROUGH = false>
+template <int SPW, int NPAR, bool FLOW = false>
 __device__ __forceinline__ void mixfft_wg(uint8_t *lds_base, const DevTables &tb, const DevBuffers &db, const int s, const int wg, int local_prepare, const SymParams *flow_sp = nullptr)
 {
     MixLds<NPAR> &L = *reinterpret_cast<MixLds<NPAR> *>(lds_base);
@@ -613,8 +611,8 @@ __device__ __forceinline__ void mixfft_wg(uint8_t *lds_base, const DevTables &tb
         else mixfft_symbols<false, SPW, NPAR, true>(tb, db, raw, sp, s, lds, twB, pro, wg);
         return;
     }
-    if (raw) mixfft_symbols<true, SPW, NPAR, false, THROUGH>(tb, db, raw, sp, s, lds, twB, pro, wg);
-    else mixfft_symbols<false, SPW, NPAR, false, THROUGH>(tb, db, raw, sp, s, lds, twB, pro, wg);
+    if (raw) mixfft_symbols<true, SPW, NPAR>(tb, db, raw, sp, s, lds, twB, pro, wg);
+    else mixfft_symbols<false, SPW, NPAR>(tb, db, raw, sp, s, lds, twB, pro, wg);
 }
 
 

@@ -67,7 +67,7 @@ class L2Job(ctypes.Structure):
 
 
 L2_FM_P1, L2_FM_PX, L2_AM = 0, 1, 2
-TUNE_DECODE_STREAMS, TUNE_AM_DECODE_STREAMS, TUNE_VERDICT_LAG, TUNE_SYNC_PHASES, TUNE_FWD_SEGMENTS, TUNE_FWD_WARM, TUNE_AM_SEGMENTS, TUNE_DECODE_CUS, TUNE_DECODE_PRIORITY, TUNE_AM_WARM, TUNE_MIXFFT_SYMS, TUNE_DEFER_WAIT, TUNE_TRACEBACK_WALK, TUNE_SYNC_LANES, TUNE_DIRECT_DECIMATE, TUNE_EARLY_FLUSH_KB, TUNE_SEAM_PREPARE, TUNE_NCO_EXACT, TUNE_FLOW_MIN, TUNE_LOOP_EXACT, TUNE_HOST_CAPTURE, TUNE_FOLD_REPORT, TUNE_CONCURRENT_STEP = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22
+TUNE_DECODE_STREAMS, TUNE_AM_DECODE_STREAMS, TUNE_VERDICT_LAG, TUNE_SYNC_PHASES, TUNE_FWD_SEGMENTS, TUNE_FWD_WARM, TUNE_AM_SEGMENTS, TUNE_DECODE_CUS, TUNE_DECODE_PRIORITY, TUNE_AM_WARM, TUNE_MIXFFT_SYMS, TUNE_DEFER_WAIT, TUNE_TRACEBACK_WALK, TUNE_SYNC_LANES, TUNE_DIRECT_DECIMATE, TUNE_EARLY_FLUSH_KB, TUNE_SEAM_PREPARE, TUNE_NCO_EXACT, TUNE_FLOW_MIN, TUNE_LOOP_EXACT, TUNE_HOST_CAPTURE, TUNE_FOLD_REPORT = 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21
 L2_STATUS = ("end", "no_audio", "fixed_data", "header_rs", "bad_locators", "too_many_pdus", "hef_overrun", "bad_stream", "bad_length", "audio_end")
 
 
@@ -533,9 +533,9 @@ class Engine:
 
     def host_capture_stats(self):
         """host-resident capture of the fast seam (TUNE_HOST_CAPTURE): dict(attaches, detaches, rebases, stream)"""
-        st = (ctypes.c_longlong * 6)()
+        st = (ctypes.c_longlong * 5)()
         self._check(self.lib.nrsc5hip_debug_host_capture_stats(self._h, st))
-        return dict(zip(("attaches", "detaches", "rebases", "stream", "reports_folded", "steps_concurrent"), (int(x) for x in st)))
+        return dict(zip(("attaches", "detaches", "rebases", "stream", "reports_folded"), (int(x) for x in st)))
 
     def tb_stats(self):
         """single-path traceback: (chunk boundaries checked, chunks re-walked) since the engine was created"""
