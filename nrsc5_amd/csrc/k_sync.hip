@@ -813,9 +813,11 @@ __device__ __forceinline__ void sync_body(uint8_t *lds_base, const DevTables &tb
                 uint32_t *out = sh_pids_out;
                 viterbi_k7_wave_compact<PIDS_LEN>(sh_pids_coded, nullptr, out);
                 WAVE_LDS_FENCE();
-                if (tid == 64) {
+                {
                     const uint32_t p[3] = { out[0] ^ tb.scr_pids[0], out[1] ^ tb.scr_pids[1], (out[2] ^ tb.scr_pids[2]) & 0xffffu };   // descramble (decode.c:470)
-                    out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; out[3] = pids_crc_ok(p) ? 1u : 0u;
+                    const bool crc_ok = pids_crc_ok_wave(p);   // the whole wave (one lane's bit loop was a fifth of this decode)
+                    WAVE_LDS_FENCE();                          // every lane has read out[] before lane 0 rewrites it
+                    if (tid == 64) { out[0] = p[0]; out[1] = p[1]; out[2] = p[2]; out[3] = crc_ok ? 1u : 0u; }
                 }
             }
         } else {
@@ -862,6 +864,7 @@ __device__ __forceinline__ void sync_body(uint8_t *lds_base, const DevTables &tb
         }
     }
     __syncthreads();
+    SYNC_MARK(14);                                             // (the inline PIDS decode on wave 1 beside tid 0's bookkeeping, waited for)
 
     // ---- end of acquire_process (acquire.c:259-262) + record.  Two lanes of different waves share the work: the NCO phase with
     // its double-precision sine / cosine (a diagnostic of the record) on one, the FIFO / counters / record on the other, each with
@@ -999,13 +1002,14 @@ __device__ __forceinline__ void pids_decode_wave(const DevTables &tb, const DevB
     WAVE_LDS_SYNC();
     viterbi_k7_wave_compact<PIDS_LEN>(coded, dec, out);        // the rotating-layout trellis in its compact form, inlined with the frame length a constant
     WAVE_LDS_SYNC();
+    // (the CRC runs over a local copy: handed the record itself it re-read the words from global memory for each of its 80 bits -- ~17 us of the 22.7 us this decode used to
+    //  take; round 6: by the whole wave, pids_crc_ok_wave)
+    const uint32_t p[3] = { out[0] ^ tb.scr_pids[0], out[1] ^ tb.scr_pids[1], (out[2] ^ tb.scr_pids[2]) & 0xffffu };   // descramble (decode.c:470)
+    const bool crc_ok = pids_crc_ok_wave(p);
     if (lane == 0) {
         BlockRecord &rec = db.records[(size_t)s * db.rec_cap + r];
-        // (the CRC runs over a local copy: handed the record itself it re-read the words from global memory for each of its 80 bits --
-        // ~17 us of the 22.7 us this decode used to take)
-        const uint32_t p[3] = { out[0] ^ tb.scr_pids[0], out[1] ^ tb.scr_pids[1], (out[2] ^ tb.scr_pids[2]) & 0xffffu };   // descramble (decode.c:470)
         rec.pids[0] = p[0]; rec.pids[1] = p[1]; rec.pids[2] = p[2];
-        if (pids_crc_ok(p)) atomicOr(&rec.flags, (uint32_t)REC_PIDS_CRC);
+        if (crc_ok) atomicOr(&rec.flags, (uint32_t)REC_PIDS_CRC);
         *recp = -1;
     }
 }

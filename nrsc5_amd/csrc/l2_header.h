@@ -209,4 +209,37 @@ __device__ inline bool pids_crc_ok(const uint32_t *w)
     return expected == (reg & 0xfffu);
 }
 
+// The same test by the 64 lanes of ONE wave (the inline PIDS decode of the streaming seam's sync kernel: on one lane the 84-trip bit loop above was ~5 000 shader cycles of a chain
+// the host waits for).  The CRC register is linear in the message bits (it starts at zero): its final value is the XOR of one 16-bit term per set bit -- pids_crc_term(i), what a
+// lone 1 at logical bit i leaves after the remaining shifts -- so lane i contributes its term, and every bit of the XOR is the parity of a ballot.
+constexpr unsigned pids_crc_term(int i)
+{
+    unsigned reg = 0;
+    for (int j = 67; j >= 0; j--) { const unsigned low = reg & 1u; reg >>= 1; reg ^= (j == i ? 1u : 0u) << 15; if (low) reg ^= 0xD010u; }
+    for (int j = 0; j < 16; j++) { const unsigned low = reg & 1u; reg >>= 1; if (low) reg ^= 0xD010u; }
+    return reg;
+}
+struct PidsCrcTerms { uint16_t t[68]; };
+constexpr PidsCrcTerms pids_crc_terms()
+{
+    PidsCrcTerms r{};
+    for (int i = 0; i < 68; i++) r.t[i] = (uint16_t)pids_crc_term(i);
+    return r;
+}
+__device__ inline bool pids_crc_ok_wave(const uint32_t *w)      // w[0..2]: wave-uniform; call with all 64 lanes
+{
+    constexpr PidsCrcTerms T = pids_crc_terms();
+    auto logical = [&](int i) -> unsigned { const int k = ((i >> 3) << 3) + 7 - (i & 7); return (w[k >> 5] >> (k & 31)) & 1u; };
+    const int lane = threadIdx.x & 63;
+    unsigned v = logical(lane) ? (unsigned)T.t[lane] : 0u;
+    if (lane < 4 && logical(64 + lane)) v ^= (unsigned)T.t[64 + lane];
+    unsigned reg = 0;
+#pragma unroll
+    for (int b = 0; b < 12; b++) reg |= (unsigned)(__popcll(__ballot((int)((v >> b) & 1u))) & 1) << b;
+    reg ^= 0x955u;
+    unsigned expected = 0;
+    for (int i = 68; i < 80; i++) expected = (expected << 1) | logical(i);
+    return expected == (reg & 0xfffu);
+}
+
 }  // namespace nrsc5
