@@ -733,7 +733,7 @@ __device__ __forceinline__ void sync_body(uint8_t *lds_base, const DevTables &tb
                 if (side) e_ub += e; else e_lb += e;
             }
         }
-        e_lb = wave_sum_f64(e_lb); e_ub = wave_sum_f64(e_ub);
+        e_lb = wave_sum_f64_rf(e_lb); e_ub = wave_sum_f64_rf(e_ub);            // (register-file moves: 24 LDS crossbar round trips less on every wave's path to the MER barrier)
         if ((tid & 63) == 0) { red[0][tid >> 6] = e_lb; red[1][tid >> 6] = e_ub; }
         __syncthreads();
         if (tid == 0) {

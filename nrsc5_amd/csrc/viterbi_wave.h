@@ -238,13 +238,12 @@ __device__ inline void viterbi_k7_wave_fast(const int8_t *coded, int len, unsign
 // shaped ds_bpermute form (`viterbi_k7_wave`: two crossbar round trips per step on the serial chain) it took 22.7 us per block; the
 // unrolled fast path with a 16-step last chunk 19 us -- ~19 KB of straight-line code executed once per launch, all of it
 // instruction-cache misses (profiles/r04_dropin_timeline.txt).  This form is ~1 KB.
-// Decisions stay in the lane: a lane's own-wins bits of 30 steps per VGPR (the fast path parks 64-lane ballots instead: a ballot
-// store per step); the traceback fetches the word of the survivor's lane with v_readlane and runs on the scalar ALU.  `dec` is
-// not used.
+// The history stays in the lane -- five VGPRs (the fast path parks 64-lane ballots instead: a ballot store per step); the traceback fetches the word of the survivor's
+// lane with v_readlane and runs on the scalar ALU.  `dec` is not used.
 template <int len>
 __device__ __forceinline__ void viterbi_k7_wave_compact(const int8_t *coded, unsigned long long *dec, uint32_t *out)
 {
-    static_assert(len + 2 * VIT_EXTRA <= 150 && (len + 2 * VIT_EXTRA) % 6 == 0, "five history words of 30 steps, whole groups of six");
+    static_assert(len + 2 * VIT_EXTRA <= 150 && (len + 2 * VIT_EXTRA) % 6 == 0, "five map words of five groups, whole groups of six");
     const int lane = threadIdx.x & 63;
     const VitFastConst k = vit_fast_consts(lane);
     constexpr int steps = len + 2 * VIT_EXTRA;
@@ -253,35 +252,41 @@ __device__ __forceinline__ void viterbi_k7_wave_compact(const int8_t *coded, uns
 #pragma unroll
     for (int c = 0; c < 3; c++) aw[c] = (60 * c + lane < steps) ? vit_load_soft(coded, len, 60 * c + lane) : 0;
     int pm = 0;
-    uint32_t hist[5] = {0, 0, 0, 0, 0};                        // word j: steps 30 j .. 30 j + 29, bit = step - 30 j
-    auto fwd = [&](auto R, int awc, int i, uint32_t &h, int bitpos) __attribute__((always_inline)) {
+    // Survivor MAPS instead of decision bits (round 6): over the six steps of a group -- one per phase of the rotating layout -- every lane carries along the lane its survivor
+    // path STARTED the group in (own wins: keep it; the partner wins: take the partner's, one more register-file move off the metric chain), so the traceback is one v_readlane
+    // per GROUP, 24 hops, where it was one per step (144 SALU <-> VALU round trips, ~5 000 shader cycles of a chain the streaming seam's host waits for).  Word j: groups
+    // 5 j .. 5 j + 4, six bits each.  Composing the steps' choices forwards or walking them backwards names the same path: identical output.
+    uint32_t maps[5] = {0, 0, 0, 0, 0};
+    auto fwd = [&](auto R, int awc, int i, int &orig) __attribute__((always_inline)) {
         constexpr int r = decltype(R)::value;
         const int m = dot4_i8(wave_readlane(awc, i), k.sgw[r], 0);
         const int X = pm + m;
         const int Y = lane_xor<(1 << r)>(pm) - m;
+        const int po = lane_xor<(1 << r)>(orig);
         const bool own = X + k.s0[r] > Y;                      // own-wins; ties as the reference's `if (sum0 > sum1)`
         pm = own ? X : Y;
-        h |= (own ? 1u : 0u) << bitpos;
+        orig = own ? orig : po;
     };
 #pragma unroll
     for (int j = 0; j < 5; j++) {
         const int awc = aw[j >> 1], i0 = 30 * (j & 1);
 #pragma unroll 1
         for (int g = 0; g < 5; g++) {
-            if (30 * j + 6 * g >= steps) break;                // wave-uniform (the last word of a 144-step frame holds 24 steps)
-            const int i = i0 + 6 * g, bp = 6 * g;
-            fwd(std::integral_constant<int, 0>{}, awc, i, hist[j], bp);         fwd(std::integral_constant<int, 1>{}, awc, i + 1, hist[j], bp + 1);
-            fwd(std::integral_constant<int, 2>{}, awc, i + 2, hist[j], bp + 2); fwd(std::integral_constant<int, 3>{}, awc, i + 3, hist[j], bp + 3);
-            fwd(std::integral_constant<int, 4>{}, awc, i + 4, hist[j], bp + 4); fwd(std::integral_constant<int, 5>{}, awc, i + 5, hist[j], bp + 5);
+            if (30 * j + 6 * g >= steps) break;                // wave-uniform (the last word of a 144-step frame holds four groups)
+            const int i = i0 + 6 * g;
+            int orig = lane;
+            fwd(std::integral_constant<int, 0>{}, awc, i, orig);     fwd(std::integral_constant<int, 1>{}, awc, i + 1, orig);
+            fwd(std::integral_constant<int, 2>{}, awc, i + 2, orig); fwd(std::integral_constant<int, 3>{}, awc, i + 3, orig);
+            fwd(std::integral_constant<int, 4>{}, awc, i + 4, orig); fwd(std::integral_constant<int, 5>{}, awc, i + 5, orig);
+            maps[j] |= (uint32_t)orig << (6 * g);
         }
     }
     // end state: first maximum in STATE order (conv_dec.c:310-318); lane L holds state rotr6^steps(L) = L
-    const int best = wave_max_i32(pm);
-    const int smin = wave_min_i32(pm == best ? lane : 64);
+    const int best = wave_max_i32_rf(pm);
+    const int smin = wave_min_i32_rf(pm == best ? lane : 64);
     unsigned l = (unsigned)wave_uniform(smin);                 // lane of the survivor, kept in an SGPR
-    // the decoded bits of a group of six steps are the survivor's lane bits at the group's last step (bit r at step r of the group:
-    // each step only rewrites its own bit afterwards); the traceback is unrolled in full, so every group lands in the output words
-    // with constant shifts -- no memory, no barrier: the decoder can run on one wave of a larger workgroup
+    // the decoded bits of a group of six steps are the survivor's lane bits at the group's last step (bit r at step r of the group: each step only rewrites its own bit
+    // afterwards); the walk is unrolled, so every group lands in the output words with constant shifts -- no memory, no barrier: the decoder can run on one wave of a larger workgroup
     uint32_t o[5] = {0, 0, 0, 0, 0};
 #pragma unroll
     for (int j = 4; j >= 0; j--) {
@@ -289,19 +294,12 @@ __device__ __forceinline__ void viterbi_k7_wave_compact(const int8_t *coded, uns
         for (int g = 4; g >= 0; g--) {
             if (30 * j + 6 * g >= steps) continue;             // compile-time
             const unsigned six = l & 63u;
-            unsigned lw = l;
-#pragma unroll
-            for (int r = 5; r >= 0; r--) {
-                const uint32_t hw = (uint32_t)wave_readlane((int)hist[j], (int)lw);      // the word of the lane the survivor sits in now
-                const unsigned own = (hw >> (6 * g + r)) & 1u;
-                lw ^= own ? 0u : (1u << r);
-            }
-            l = lw;
 #pragma unroll
             for (int r = 0; r < 6; r++) {
                 const int ob = 30 * j + 6 * g + r - VIT_EXTRA;  // the frame bit step 30 j + 6 g + r decodes
                 if (ob >= 0 && ob < len) o[ob >> 5] |= ((six >> r) & 1u) << (ob & 31);
             }
+            l = (unsigned)wave_uniform((int)(((uint32_t)wave_readlane((int)maps[j], (int)l) >> (6 * g)) & 63u));      // where that path stood before the group
         }
     }
     (void)dec;

@@ -136,6 +136,34 @@ template <int M> __device__ __forceinline__ int lane_xor(int v)
 #endif
 }
 
+// Wave reductions over lane_xor's register-file moves (the generic wave_max_i32 / wave_min_i32 / wave_sum_f64 below go through __shfl_xor = ds_bpermute: twelve LDS
+// crossbar round trips for a max + arg-min, ~100 shader cycles each on a chain one lone wave waits for).  Same butterfly, same pairing order: identical results.
+template <int M> __device__ __forceinline__ double lane_xor_f64(double v)
+{
+    const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)lane_xor<M>((int)(unsigned)b), hi = (unsigned)lane_xor<M>((int)(unsigned)(b >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ int wave_max_i32_rf(int v)
+{
+    int o;
+    o = lane_xor<32>(v); v = o > v ? o : v; o = lane_xor<16>(v); v = o > v ? o : v; o = lane_xor<8>(v); v = o > v ? o : v;
+    o = lane_xor<4>(v); v = o > v ? o : v; o = lane_xor<2>(v); v = o > v ? o : v; o = lane_xor<1>(v); v = o > v ? o : v;
+    return v;
+}
+__device__ __forceinline__ int wave_min_i32_rf(int v)
+{
+    int o;
+    o = lane_xor<32>(v); v = o < v ? o : v; o = lane_xor<16>(v); v = o < v ? o : v; o = lane_xor<8>(v); v = o < v ? o : v;
+    o = lane_xor<4>(v); v = o < v ? o : v; o = lane_xor<2>(v); v = o < v ? o : v; o = lane_xor<1>(v); v = o < v ? o : v;
+    return v;
+}
+__device__ __forceinline__ double wave_sum_f64_rf(double v)
+{
+    v += lane_xor_f64<32>(v); v += lane_xor_f64<16>(v); v += lane_xor_f64<8>(v); v += lane_xor_f64<4>(v); v += lane_xor_f64<2>(v); v += lane_xor_f64<1>(v);
+    return v;
+}
+
 // signed 4 x int8 dot product + accumulator (v_dot4_i32_i8)
 __device__ __forceinline__ int dot4_i8(int a, int b, int acc)
 {

@@ -62,7 +62,7 @@ while off < iq.size and len(recs) < nblk:
             if df > 1e-5 or dp > 1e-4:
                 ob, eb = fft[:, b], tb[:, live]
                 k = int(np.argmin(np.abs(ob)))
-                if len(recs) == 1 and int(x['cfo']) != 0 and abs(ob).mean() < 1.0:
+                if len(recs) == 1 and int(x['cfo']) != 0:
                     # block 0 of a stream whose CFO search found an integer offset: this carrier's loop ran over the un-corrected spectrum from (0, initial phase) -- the model on both sets of bins
                     adj = 1080 - int(x['samperr']); ph0 = np.float32(0.0 - (adj * (b - 1024)) * 2 * np.pi / 2048)
                     mo, me = model(ob, 0.0, ph0), model(eb, 0.0, ph0)
