@@ -55,6 +55,17 @@ def test_emu_dropin_events_match_reference(emu_dropin, captures, name, chunk):
     _compare_events(exp, got)
 
 
+def test_emu_dropin_fifo_seam_events_match_reference(emu_dropin, captures, monkeypatch):
+    """The same through the FIFO seam of rounds 3 - 5 (NRSC5HIP_HOST_CAPTURE=0: pinned staging + decimator kernel): what cs16 / AM sessions and the fall-back of a capture
+    use.  The default since round 6 keeps an FM cu8 session's bytes in a pinned capture the stream reads in place (every other test of this file)."""
+    monkeypatch.setenv("NRSC5HIP_HOST_CAPTURE", "0")
+    iq = np.ascontiguousarray(captures("fm_cu8_cfo137").iq)
+    exp = _run(os.path.join(common.ROOT, "oracle", "_ref", "libnrsc5_plain.so"), iq, 32768)
+    got = _run(emu_dropin, iq, 32768)
+    assert len(exp) >= 2
+    _compare_events(exp, got)
+
+
 def test_emu_dropin_am(emu_dropin, captures):
     name = next(iter(common.GOLDEN_AM_CASES))
     iq = np.ascontiguousarray(captures(name).iq)

@@ -66,6 +66,18 @@ def test_dropin_public_api_events_match_reference(name, captures):
                 assert common.float_close(f, float(va), float(vb)), (k, f, va, vb)
 
 
+@pytest.mark.parametrize("name", ["fm_cu8_cfo137", "fm_cu8_cfo-2400"])
+def test_dropin_public_api_fifo_seam_events_match_reference(name, captures, monkeypatch):
+    """The FIFO seam of rounds 3 - 5 (NRSC5HIP_HOST_CAPTURE=0: pinned staging, decimator kernel on the ingest stream) through the public API -- what cs16 / AM sessions and a
+    capture's fall-back use; every other FM cu8 test of this file runs the round-6 default (the session's bytes in a pinned capture the stream reads in place)."""
+    monkeypatch.setenv("NRSC5HIP_HOST_CAPTURE", "0")
+    iq = np.ascontiguousarray(captures(name).iq)
+    exp = _run("libnrsc5_plain.so", iq)
+    got = _run("libnrsc5_hipdropin.so", iq)
+    assert len(exp) >= 2
+    _compare_events(exp, got)
+
+
 def test_two_dropin_sessions_in_one_process(captures):
     """Two nrsc5_open_pipe sessions of one process (one engine each: own HIP streams, staging and state) fed alternately in
     32768-byte calls: each delivers exactly the events it delivers alone (= the plain reference's)."""
