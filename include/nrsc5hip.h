@@ -156,9 +156,11 @@ int nrsc5hip_device_free(int device, void *dev);
 /* ---- streaming seam (host buffers), one stream at a time --------------------------------------- */
 /* input_push_cu8 (input.c:96-117): nbytes % 4 == 0.  Decimates, appends, and processes every block
  * whose 33-symbol window is complete; records are then available through nrsc5hip_drain.  With p1_async = 0 the host keeps a
- * mirror of the FIFO read position: a push that completes no block is one memcpy into pinned staging + one async H2D + the
- * decimator launch (no synchronisation); a push that completes one ends with a single stream sync, the block's record already in
- * host memory. */
+ * mirror of the stream's read position.  FM cu8 (round 6, NRSC5HIP_TUNE_HOST_CAPTURE): the bytes stay, as pushed, in a pinned device-mapped capture
+ * that the stream reads in place -- a push that completes no block is ONE host memcpy and nothing else; the block step is the symbol kernel
+ * (half-band fused, loading across PCIe) + the sync kernel, which posts the block's record into pinned host memory itself.  Other input (cs16, AM,
+ * or with the knob at 0): a push that completes no block is one memcpy into pinned staging + the decimator launch (no synchronisation).  Either way a
+ * push that completes a block ends with the host spinning on the report's sequence number, the block's record already in host memory. */
 int nrsc5hip_push_cu8(nrsc5hip_engine *e, int stream, const uint8_t *iq, uint32_t nbytes);
 /* input_push_cs16 (input.c:119-124): n = number of int16 values, n % 2 == 0 */
 int nrsc5hip_push_cs16(nrsc5hip_engine *e, int stream, const int16_t *iq, uint32_t n);
@@ -198,8 +200,8 @@ long long nrsc5hip_bytes_to_next_block(nrsc5hip_engine *e, int stream, int cu8);
  * nrsc5hip_drain_ready, which hands out what has been reported so far and never waits.
  *
  * Manual stepping lets the L2 feedback of block n (frame.c -> nrsc5hip_force_resync) reach the engine before block n + 1 is
- * STEPPED while the samples of block n + 1 are already on their way into the FIFO: with it set, a push that completes a block
- * submits the samples (H2D + decimator) and returns; the caller then drains block n (nrsc5hip_drain, waits), feeds L2, and calls
+ * STEPPED while the samples of block n + 1 are already in the capture / on their way into the FIFO: with it set, a push that completes a block
+ * copies (or submits) the samples and returns; the caller then drains block n (nrsc5hip_drain, waits), feeds L2, and calls
  * nrsc5hip_stream_step.  integration/input_hip.c does exactly that.  (A push that finds an unstepped complete block steps it
  * itself: forgetting the call costs speed, never samples.) */
 int nrsc5hip_drain_ready(nrsc5hip_engine *e, int stream, nrsc5hip_record *out, int max, int *n_out);
